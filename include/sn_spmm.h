@@ -1,0 +1,186 @@
+/*
+ * sn_spmm.h — C-ABI of the MI355X-native Surface-Network sparse-operator layer.
+ *
+ * This is the drop-in boundary for the ONE hot path of jiangzhongshi/SurfaceNetworks:
+ * the sparse-operator x dense-feature product inside the Lap/Dirac ResNet block and the
+ * operator-format plumbing around it.  Every entry point below names the reference
+ * interface it replaces (paths relative to the reference checkout, file:line).
+ *
+ * Conventions (all entry points)
+ *   - Every pointer is a DEVICE pointer (HBM) unless its name ends in `_host`.
+ *   - The library never allocates, frees or synchronises: the caller owns inputs, outputs
+ *     and workspaces (reference: launchers allocate with values.new(), sparse_bmm.py:53).
+ *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and stream-ordered
+ *     (reference: launch on torch.cuda.current_stream(), sparse_bmm.py:59, batch_csr.py:56).
+ *   - No global mutable state; re-entrant; safe from several host threads on different streams
+ *     (the reference keeps module-level caches, sparse_bmm_func.py:20-21 — deliberately not kept).
+ *   - Return value: 0 = success; negative = SN_E_* invalid argument; positive = hipError_t of the
+ *     failed launch.  sn_status_string() renders either.
+ *   - Indices are int32 (the reference uses int64, utils_pt.py:62, sparse_bmm.cu:17); an operator
+ *     whose nnz or row/col count does not fit int32 is rejected with SN_E_RANGE.
+ *   - Every output element is written (no reliance on zero-initialised outputs), including rows
+ *     with no entries — the reference kernel silently mis-handles interior empty rows
+ *     (batch_csr.cu:35-41) and that defect is NOT reproduced.
+ *
+ * Row addressing of the dense operands ("group" layout)
+ *   A dense operand with N columns is addressed as
+ *        row r  ->  base + (r / group) * ld + (r % group) * N          (floats)
+ *   group = 1 : ordinary row-major matrix with leading dimension ld >= N.
+ *   group = 4 : the quaternion view of the Dirac path.  The reference views v:(B,V,C) as
+ *               (B*V*4, C/4) (utils_pt.py:201,213): the 4 rows of one vertex/face are C = 4N
+ *               contiguous floats.  With ld = 4N this is the same contiguous matrix; with ld = 2C
+ *               the operand lives inside one half of the (B,Nodes,2C) concat buffer that feeds
+ *               BatchNorm+Linear (utils_pt.py:204,216), so SpMM can read from / write into that
+ *               buffer directly and torch.cat disappears.
+ */
+#ifndef SN_SPMM_H_
+#define SN_SPMM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SN_ABI_VERSION 1
+
+/* negative status codes (positive codes are hipError_t values) */
+#define SN_OK            0
+#define SN_E_NULL       -1   /* a required pointer is NULL                                   */
+#define SN_E_SHAPE      -2   /* negative / inconsistent dimension                            */
+#define SN_E_RANGE      -3   /* dimension or nnz does not fit the int32 index type           */
+#define SN_E_LD         -4   /* leading dimension / group layout invalid for N               */
+#define SN_E_ALIGN      -5   /* reserved: pointer/ld alignment required by a kernel variant  */
+#define SN_E_WORKSPACE  -6   /* workspace too small                                          */
+#define SN_E_UNSUPPORTED -7  /* e.g. BSR4 requested for M or K not a multiple of 4           */
+
+int         sn_abi_version(void);
+const char *sn_status_string(int status);
+
+/* ------------------------------------------------------------------------------------------
+ * Y = A · X      A: M x K in CSR (int32 rowptr[M+1], colind[nnz], fp32 vals[nnz]), fp32 throughout.
+ *
+ * Replaces: SparseBMM.__call__(values, col_ind, col_ptr, size, dense)   src/utils/cuda/sparse_bmm.py:28-61
+ *           and its kernel                                               src/utils/cuda/sparse_bmm.cu:16-61
+ *           and the ATen call sites  torch.mm(L, x) / torch.mm(Di, x) / torch.mm(DiA, x)
+ *                                                                         src/utils/utils_pt.py:167,176,202,214
+ * The batched (B,R,K) operator of the reference is the block-diagonal 2-D operator with
+ * M = B*R, K = B*Kb (col_ptr there already holds global nnz offsets, sparse_bmm.cu:36-37).
+ * The same entry point computes the backward  grad_X = Aᵀ · grad_Y  when given the CSR of Aᵀ
+ * (sparse_bmm_func.py:66-70); no gradient w.r.t. the operator exists (sparse_bmm_func.py:72).
+ *
+ * X: K rows, Y: M rows, both N columns, addressed with (ld, group) as described above.
+ * Any N >= 1 is accepted; N in {16,32,64,128} with 16-byte aligned bases/ld take the
+ * vectorised wave64 kernels.  X and Y must not alias.
+ * ------------------------------------------------------------------------------------------ */
+int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *vals,
+                    int64_t M, int64_t K, int64_t nnz,
+                    const float *X, int64_t ldx, int32_t x_group,
+                    int32_t N,
+                    float *Y, int64_t ldy, int32_t y_group,
+                    void *stream);
+
+/* Same product with A stored as 4x4-block BSR (block rows Mb = M/4, block cols Kb = K/4,
+ * bvals holds 16 floats per block, row-major inside the block).  This is the packed form of the
+ * quaternionic Dirac operators: every 4x4 block of Di is -Q(0,e)/(2 Af) (src/utils/mesh.py:28-33,55-58).
+ * Results are bit-identical to sn_spmm_csr_f32 on the same operator for finite X (the explicit
+ * zeros of a block contribute fma(0,x,acc) == acc). N must be a multiple of 4. */
+int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals,
+                     int64_t Mb, int64_t Kb, int64_t nblocks,
+                     const float *X, int64_t ldx, int32_t x_group,
+                     int32_t N,
+                     float *Y, int64_t ldy, int32_t y_group,
+                     void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Sorted COO -> CSR.
+ *
+ * Replaces: BatchCSR.__call__(indices, size) -> (col_ind, col_ptr)      src/utils/cuda/batch_csr.py:28-59
+ *           and its kernel                                               src/utils/cuda/batch_csr.cu:13-47
+ *           plus the implicit COO->CSR inside ATen's sparse addmm behind utils_pt.py:167,176,202,214.
+ *
+ * idx_batch may be NULL (2-D operator, B = 1).  For a 3-D batched operator (B, R, Kb) — the output
+ * of sparse_cat (utils_pt.py:21-39) — the result is the block-diagonal CSR with
+ *      global row = b*R + r  (M = B*R rows),   global col = b*Kb + c.
+ * Indices are the int64 rows of a torch COO `_indices()` tensor; entries must be sorted by
+ * (batch,row[,col]) — i.e. coalesced, as the reference requires (batch_csr.cu comment, :13).
+ * rowptr (M+1 entries) is computed by binary search per row, so interior empty rows are correct.
+ * ------------------------------------------------------------------------------------------ */
+int sn_coo_to_csr_i32(const int64_t *idx_batch, const int64_t *idx_row, const int64_t *idx_col,
+                      int64_t nnz, int64_t B, int64_t R, int64_t Kb,
+                      int32_t *rowptr, int32_t *colind,
+                      void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CSR of Aᵀ from CSR of A (deterministic: entries of each output row ordered by column).
+ *
+ * Replaces: matrix1.transpose(2,1).coalesce() + batch_csr on every backward
+ *                                                                         src/utils/cuda/sparse_bmm_func.py:66-67
+ * Done ONCE per operator here and kept resident next to A.
+ * workspace: sn_csr_transpose_workspace_bytes(M, K, nnz) bytes of device scratch.
+ * ------------------------------------------------------------------------------------------ */
+size_t sn_csr_transpose_workspace_bytes(int64_t M, int64_t K, int64_t nnz);
+int sn_csr_transpose_f32(const int32_t *rowptr, const int32_t *colind, const float *vals,
+                         int64_t M, int64_t K, int64_t nnz,
+                         int32_t *t_rowptr, int32_t *t_colind, float *t_vals,
+                         void *workspace, size_t workspace_bytes,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CSR -> BSR4 (4x4 blocks).  Two phases because the caller owns the allocation:
+ *   1. sn_bsr4_count: b_rowptr[Mb+1] <- exclusive scan of the number of distinct 4-wide block
+ *      columns touched by each group of 4 rows; the caller reads b_rowptr[Mb] (= nblocks).
+ *   2. sn_bsr4_fill : b_colind[nblocks], b_vals[16*nblocks] (zero-filled where A has no entry).
+ * Column indices inside each CSR row must be sorted ascending (coalesced operator).
+ * workspace for count: sn_scan_workspace_bytes(Mb + 1).
+ * ------------------------------------------------------------------------------------------ */
+size_t sn_scan_workspace_bytes(int64_t n);
+int sn_bsr4_count(const int32_t *rowptr, const int32_t *colind, int64_t M, int64_t K,
+                  int32_t *b_rowptr, void *workspace, size_t workspace_bytes, void *stream);
+int sn_bsr4_fill(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
+                 const int32_t *b_rowptr, int32_t *b_colind, float *b_vals, void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Block-diagonal batch assembly from a device-resident pool of per-mesh operators.
+ *
+ * Replaces: sparse_diag_cat(tensors, size0, size1)                       src/utils/utils_pt.py:41-53
+ *           (index shift i*[size0;size1], concat, coalesce() sort on the host every step) and the
+ *           per-sample sp_sparse_to_pt_sparse conversions               src/utils/utils_pt.py:56-69,
+ *           src/as_rigid_as_possible/main.py:161-162,174-175.
+ *
+ * The pool holds every mesh's operator once (CSR with vals_per_entry = 1, or BSR4 with 16), rowptr
+ * local to the mesh (starting at 0).  desc is a (B x 4) int64 table, one row per selected mesh:
+ *      desc[b] = { offset of the mesh's rowptr in pool_rowptr,
+ *                  offset of the mesh's first entry in pool_colind (vals: x vals_per_entry),
+ *                  number of rows of the mesh (<= size0),
+ *                  offset of the mesh's first entry in the OUTPUT (exclusive prefix of entry counts) }
+ * Output: out_rowptr[B*size0 + 1], out_colind[total], out_vals[total*vals_per_entry] with
+ * row = b*size0 + r and col = b*size1 + c; rows beyond a mesh's own count are empty (the padding to
+ * the batch maximum of the reference).  `total` = number of entries of the whole batch.
+ * ------------------------------------------------------------------------------------------ */
+int sn_blockdiag_concat_i32(const int32_t *pool_rowptr, const int32_t *pool_colind, const float *pool_vals,
+                            const int64_t *desc, int64_t B, int64_t size0, int64_t size1,
+                            int64_t total, int32_t vals_per_entry,
+                            int32_t *out_rowptr, int32_t *out_colind, float *out_vals,
+                            void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused elementwise helpers of the residual blocks (each replaces separate ATen passes).
+ *
+ * sn_elu_into_f32: dst[r, 0:C] = elu(src[r, 0:C]) for `rows` rows; src stride lds, dst stride ldd.
+ *   Replaces F.elu (utils_pt.py:161,171,195,208) + the first operand copy of torch.cat
+ *   (utils_pt.py:168,177,204,216): ELU is written straight into the first half of the concat buffer.
+ * sn_elu_bwd_acc_f32: gsrc[r,c] (+)= gdst[r,c] * (out[r,c] > 0 ? 1 : out[r,c] + 1), out = elu value.
+ *   accumulate != 0 adds into gsrc (the activated tensor also feeds SpMM, so two gradients meet).
+ * ------------------------------------------------------------------------------------------ */
+int sn_elu_into_f32(const float *src, int64_t lds, float *dst, int64_t ldd,
+                    int64_t rows, int32_t C, void *stream);
+int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *out, int64_t ldo,
+                       float *gsrc, int64_t ldgs, int64_t rows, int32_t C, int32_t accumulate,
+                       void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SN_SPMM_H_ */

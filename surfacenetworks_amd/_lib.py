@@ -1,0 +1,62 @@
+"""ctypes binding of the C-ABI in include/sn_spmm.h (libsn_hip.so, built in-tree by __graft_entry__.build()).
+
+There is deliberately NO fallback: if the shared library is missing or a launch fails this module raises.
+The product never computes the hot path on the CPU or through torch.sparse.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsn_hip.so")
+
+_vp, _i64, _i32, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/sn_spmm.h declares (tests/test_boundary.py checks).
+SIGNATURES = {
+    "sn_abi_version": (C.c_int, []),
+    "sn_status_string": (C.c_char_p, [C.c_int]),
+    "sn_spmm_csr_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "sn_spmm_bsr4_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "sn_coo_to_csr_i32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "sn_csr_transpose_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "sn_csr_transpose_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sn_scan_workspace_bytes": (_sz, [_i64]),
+    "sn_bsr4_count": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "sn_bsr4_fill": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "sn_blockdiag_concat_i32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "sn_elu_into_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
+    "sn_elu_bwd_acc_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class SnError(RuntimeError):
+    """A C-ABI call returned non-zero (negative: SN_E_* argument error, positive: hipError_t)."""
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). surfacenetworks_amd has no CPU/eager fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        msg = load().sn_status_string(status).decode()
+        raise SnError(f"{what} failed with status {status}: {msg}")
+
+
+def call(name: str, *args) -> None:
+    check(getattr(load(), name)(*args), name)

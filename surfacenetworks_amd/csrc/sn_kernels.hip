@@ -1,0 +1,778 @@
+// sn_kernels.hip — CDNA4 (gfx950, wave64) kernels + C-ABI of the Surface-Network operator layer.
+//
+// Written for MI355X only: 64-lane wavefronts, 256 CUs in 8 XCDs (private 4 MiB L2 each),
+// HBM3E-bound arithmetic (≈2 flop/B), so everything here is about coalescing, bytes in flight
+// and L2 locality — there is no MFMA in this file on purpose.
+//
+// Kernel inventory
+//   spmm_csr_v4<N,XG,YG>   Y = A·X, CSR, N ∈ {16,32,64,128}: N/4 lanes own one row (float4 each),
+//                          a wave owns 256/N consecutive rows; no cross-lane reduction is needed
+//                          because a lane owns whole output columns.
+//   spmm_bsr4_v4<N,XG,YG>  same product for 4x4-block operators (Dirac): N/4 lanes own one block
+//                          row (4 output rows), each gathered X quad is used 16x from registers.
+//   spmm_csr_any           any N, one thread per output element (correctness fallback).
+//   coo_to_csr / transpose / bsr4 count+fill / blockdiag concat / scan / elu helpers.
+//
+// Reference semantics being replaced are cited per entry point in include/sn_spmm.h.
+
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "sn_spmm.h"
+
+namespace {
+
+constexpr int kWG = 256;    // 4 wavefronts per workgroup
+constexpr int kXCD = 8;     // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8
+constexpr int kMaxBlocksPerCU = 8;
+constexpr int kCUs = 256;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
+__device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+__device__ __forceinline__ void st4_stream(float *p, f4 v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+}
+__device__ __forceinline__ f4 fma4(float a, f4 x, f4 acc) {
+  acc.x = __builtin_fmaf(a, x.x, acc.x);
+  acc.y = __builtin_fmaf(a, x.y, acc.y);
+  acc.z = __builtin_fmaf(a, x.z, acc.z);
+  acc.w = __builtin_fmaf(a, x.w, acc.w);
+  return acc;
+}
+
+// Offset (floats) of dense row r under the (ld, group) addressing of sn_spmm.h.
+template <int G, int N>
+__device__ __forceinline__ int64_t row_off(int r, int64_t ld) {
+  if constexpr (G == 1) return (int64_t)r * ld;
+  else return (int64_t)(r >> 2) * ld + (int64_t)(r & 3) * N;
+}
+
+// XCD-aware chunk walk.  Workgroup b runs on XCD b % 8; giving each XCD one contiguous eighth of
+// the row chunks keeps the X rows shared by neighbouring mesh rows in ONE L2 instead of eight.
+struct ChunkWalk {
+  int first, step, cpx, base;
+  __device__ ChunkWalk(int nchunks) {
+    const int xcd = blockIdx.x % kXCD;
+    cpx = (nchunks + kXCD - 1) / kXCD;
+    base = xcd * cpx;
+    first = blockIdx.x / kXCD;
+    step = gridDim.x / kXCD;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// CSR SpMM, N/4 lanes per row.
+// ------------------------------------------------------------------------------------------------
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) void spmm_csr_v4(const int *__restrict__ rowptr,
+                                                   const int *__restrict__ colind,
+                                                   const float *__restrict__ vals, int M,
+                                                   const float *__restrict__ X, int64_t ldx,
+                                                   float *__restrict__ Y, int64_t ldy, int nchunks) {
+  constexpr int LPR = N / 4;       // lanes per row
+  constexpr int RPB = kWG / LPR;   // rows per workgroup pass
+  const int sub = threadIdx.x % LPR;
+  const int rloc = threadIdx.x / LPR;
+  const float *xb = X + sub * 4;
+  ChunkWalk w(nchunks);
+  for (int local = w.first; local < w.cpx; local += w.step) {
+    const int r = (w.base + local) * RPB + rloc;
+    if (r >= M) continue;
+    int k = rowptr[r];
+    const int e = rowptr[r + 1];
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    // 4 independent gathers in flight per lane; summation order stays k-ascending.
+    for (; k + 4 <= e; k += 4) {
+      const int c0 = colind[k], c1 = colind[k + 1], c2 = colind[k + 2], c3 = colind[k + 3];
+      const float a0 = vals[k], a1 = vals[k + 1], a2 = vals[k + 2], a3 = vals[k + 3];
+      const f4 x0 = ld4(xb + row_off<XG, N>(c0, ldx));
+      const f4 x1 = ld4(xb + row_off<XG, N>(c1, ldx));
+      const f4 x2 = ld4(xb + row_off<XG, N>(c2, ldx));
+      const f4 x3 = ld4(xb + row_off<XG, N>(c3, ldx));
+      acc = fma4(a0, x0, acc);
+      acc = fma4(a1, x1, acc);
+      acc = fma4(a2, x2, acc);
+      acc = fma4(a3, x3, acc);
+    }
+    for (; k < e; ++k) {
+      const f4 x0 = ld4(xb + row_off<XG, N>(colind[k], ldx));
+      acc = fma4(vals[k], x0, acc);
+    }
+    st4_stream(Y + row_off<YG, N>(r, ldy) + sub * 4, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BSR4 SpMM: N/4 lanes per block row; each lane keeps the 4 output rows of its column slice.
+// ------------------------------------------------------------------------------------------------
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) void spmm_bsr4_v4(const int *__restrict__ b_rowptr,
+                                                    const int *__restrict__ b_colind,
+                                                    const float *__restrict__ b_vals, int Mb,
+                                                    const float *__restrict__ X, int64_t ldx,
+                                                    float *__restrict__ Y, int64_t ldy, int nchunks) {
+  constexpr int LPR = N / 4;
+  constexpr int RPB = kWG / LPR;   // block rows per workgroup pass
+  const int sub = threadIdx.x % LPR;
+  const int rloc = threadIdx.x / LPR;
+  // quad base offset and the stride between the 4 rows of a quad
+  const int64_t xq = (XG == 4) ? ldx : 4 * ldx;
+  const int64_t xs = (XG == 4) ? (int64_t)N : ldx;
+  const int64_t yq = (YG == 4) ? ldy : 4 * ldy;
+  const int64_t ys = (YG == 4) ? (int64_t)N : ldy;
+  const float *xb = X + sub * 4;
+  ChunkWalk w(nchunks);
+  for (int local = w.first; local < w.cpx; local += w.step) {
+    const int br = (w.base + local) * RPB + rloc;
+    if (br >= Mb) continue;
+    int k = b_rowptr[br];
+    const int e = b_rowptr[br + 1];
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+#pragma unroll 3
+    for (; k < e; ++k) {
+      const int bc = b_colind[k];
+      const f4 *bv = reinterpret_cast<const f4 *>(b_vals + 16 * (int64_t)k);
+      const f4 a0 = bv[0], a1 = bv[1], a2 = bv[2], a3 = bv[3];
+      const float *xp = xb + (int64_t)bc * xq;
+      const f4 x0 = ld4(xp), x1 = ld4(xp + xs), x2 = ld4(xp + 2 * xs), x3 = ld4(xp + 3 * xs);
+      acc0 = fma4(a0.x, x0, acc0); acc0 = fma4(a0.y, x1, acc0); acc0 = fma4(a0.z, x2, acc0); acc0 = fma4(a0.w, x3, acc0);
+      acc1 = fma4(a1.x, x0, acc1); acc1 = fma4(a1.y, x1, acc1); acc1 = fma4(a1.z, x2, acc1); acc1 = fma4(a1.w, x3, acc1);
+      acc2 = fma4(a2.x, x0, acc2); acc2 = fma4(a2.y, x1, acc2); acc2 = fma4(a2.z, x2, acc2); acc2 = fma4(a2.w, x3, acc2);
+      acc3 = fma4(a3.x, x0, acc3); acc3 = fma4(a3.y, x1, acc3); acc3 = fma4(a3.z, x2, acc3); acc3 = fma4(a3.w, x3, acc3);
+    }
+    float *yp = Y + (int64_t)br * yq + sub * 4;
+    st4_stream(yp, acc0);
+    st4_stream(yp + ys, acc1);
+    st4_stream(yp + 2 * ys, acc2);
+    st4_stream(yp + 3 * ys, acc3);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Any-N fallback: one thread per output element (j fastest => coalesced along a dense row).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void spmm_csr_any(const int *__restrict__ rowptr,
+                                                    const int *__restrict__ colind,
+                                                    const float *__restrict__ vals, int64_t M, int N,
+                                                    const float *__restrict__ X, int64_t ldx, int xg,
+                                                    float *__restrict__ Y, int64_t ldy, int yg) {
+  const int64_t total = M * (int64_t)N;
+  for (int64_t t = (int64_t)blockIdx.x * kWG + threadIdx.x; t < total; t += (int64_t)gridDim.x * kWG) {
+    const int64_t r = t / N;
+    const int j = (int)(t - r * N);
+    float acc = 0.f;
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      const int64_t c = colind[k];
+      acc = __builtin_fmaf(vals[k], X[(c / xg) * ldx + (c % xg) * N + j], acc);
+    }
+    Y[(r / yg) * ldy + (r % yg) * N + j] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sorted COO -> CSR (binary search per row: interior empty rows come out right).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void coo_to_csr_k(const int64_t *__restrict__ ib,
+                                                    const int64_t *__restrict__ ir,
+                                                    const int64_t *__restrict__ ic, int64_t nnz,
+                                                    int64_t M, int64_t R, int64_t Kb,
+                                                    int *__restrict__ rowptr, int *__restrict__ colind) {
+  const int64_t n = (M + 1 > nnz) ? M + 1 : nnz;
+  for (int64_t t = (int64_t)blockIdx.x * kWG + threadIdx.x; t < n; t += (int64_t)gridDim.x * kWG) {
+    if (t <= M) {
+      // first k with key(k) >= t
+      int64_t lo = 0, hi = nnz;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        const int64_t key = (ib ? ib[mid] * R : 0) + ir[mid];
+        if (key < t) lo = mid + 1; else hi = mid;
+      }
+      rowptr[t] = (int)lo;
+    }
+    if (t < nnz) colind[t] = (int)((ib ? ib[t] * Kb : 0) + ic[t]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// int32 exclusive scan, 3 launches (block sums -> scan of sums -> rescan with offsets).
+// ------------------------------------------------------------------------------------------------
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kWG * kScanItems;
+
+__device__ __forceinline__ int wave_incl_scan(int v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan of one value per thread across the 256-thread workgroup; returns the prefix,
+// *total receives the workgroup sum.
+__device__ __forceinline__ int block_excl_scan(int v, int *total) {
+  __shared__ int wsum[kWG / 64];
+  const int incl = wave_incl_scan(v);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  __syncthreads();
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int off = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < kWG / 64; ++i) {
+    if (i < wave) off += wsum[i];
+    tot += wsum[i];
+  }
+  *total = tot;
+  return off + incl - v;
+}
+
+__global__ __launch_bounds__(kWG) void scan_block_sums(const int *__restrict__ in, int64_t n,
+                                                       int *__restrict__ sums) {
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i)
+    if (base + i < n) s += in[base + i];
+  int tot;
+  block_excl_scan(s, &tot);
+  if (threadIdx.x == 0) sums[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(kWG) void scan_sums_inplace(int *__restrict__ sums, int nblk) {
+  int carry = 0;
+  for (int b0 = 0; b0 < nblk; b0 += kWG) {
+    const int i = b0 + threadIdx.x;
+    const int v = (i < nblk) ? sums[i] : 0;
+    int tot;
+    const int ex = block_excl_scan(v, &tot);
+    if (i < nblk) sums[i] = carry + ex;
+    carry += tot;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kWG) void scan_apply(const int *__restrict__ in, int64_t n,
+                                                  const int *__restrict__ sums, int *__restrict__ out) {
+  const int64_t base = (int64_t)blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+  int v[kScanItems];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    v[i] = (base + i < n) ? in[base + i] : 0;
+    s += v[i];
+  }
+  int tot;
+  int run = block_excl_scan(s, &tot) + sums[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanItems; ++i) {
+    if (base + i < n) out[base + i] = run;
+    run += v[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR transpose.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void histogram_cols(const int *__restrict__ colind, int64_t nnz,
+                                                      int *__restrict__ counts) {
+  for (int64_t k = (int64_t)blockIdx.x * kWG + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * kWG)
+    atomicAdd(&counts[colind[k]], 1);
+}
+
+__global__ __launch_bounds__(kWG) void transpose_scatter(const int *__restrict__ rowptr,
+                                                         const int *__restrict__ colind,
+                                                         const float *__restrict__ vals, int64_t M,
+                                                         int *__restrict__ cursor,
+                                                         int *__restrict__ t_colind,
+                                                         float *__restrict__ t_vals) {
+  // one thread per source row keeps the row id for free; rows are short on meshes.
+  for (int64_t r = (int64_t)blockIdx.x * kWG + threadIdx.x; r < M; r += (int64_t)gridDim.x * kWG) {
+    for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) {
+      const int pos = atomicAdd(&cursor[colind[k]], 1);
+      t_colind[pos] = (int)r;
+      t_vals[pos] = vals[k];
+    }
+  }
+}
+
+// The scatter order inside an output row depends on atomic timing; sorting each (short) row by
+// its column index restores a unique, deterministic layout (entries are distinct: A is coalesced).
+__global__ __launch_bounds__(kWG) void sort_rows_by_col(const int *__restrict__ rowptr, int64_t M,
+                                                        int *__restrict__ colind,
+                                                        float *__restrict__ vals) {
+  for (int64_t r = (int64_t)blockIdx.x * kWG + threadIdx.x; r < M; r += (int64_t)gridDim.x * kWG) {
+    const int b = rowptr[r], e = rowptr[r + 1];
+    for (int i = b + 1; i < e; ++i) {
+      const int c = colind[i];
+      const float v = vals[i];
+      int j = i - 1;
+      while (j >= b && colind[j] > c) {
+        colind[j + 1] = colind[j];
+        vals[j + 1] = vals[j];
+        --j;
+      }
+      colind[j + 1] = c;
+      vals[j + 1] = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR -> BSR4: 4-way merge of the (sorted) block-column lists of 4 consecutive rows.
+// ------------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(kWG) void bsr4_merge(const int *__restrict__ rowptr,
+                                                  const int *__restrict__ colind,
+                                                  const float *__restrict__ vals, int64_t Mb,
+                                                  int *__restrict__ counts_or_rowptr,
+                                                  int *__restrict__ b_colind,
+                                                  float *__restrict__ b_vals) {
+  for (int64_t br = (int64_t)blockIdx.x * kWG + threadIdx.x; br < Mb; br += (int64_t)gridDim.x * kWG) {
+    int p[4], e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      p[q] = rowptr[4 * br + q];
+      e[q] = rowptr[4 * br + q + 1];
+    }
+    int n = 0;
+    int out = FILL ? counts_or_rowptr[br] : 0;
+    while (true) {
+      int cur = INT_MAX;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (p[q] < e[q]) {
+          const int bc = colind[p[q]] >> 2;
+          cur = bc < cur ? bc : cur;
+        }
+      if (cur == INT_MAX) break;
+      if constexpr (FILL) {
+        b_colind[out] = cur;
+        float blk[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) blk[i] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          while (p[q] < e[q] && (colind[p[q]] >> 2) == cur) {
+            const int c = colind[p[q]] & 3;
+            // static indexing keeps blk[] in registers
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc)
+              if (cc == c) blk[q * 4 + cc] = vals[p[q]];
+            ++p[q];
+          }
+        f4 *dst = reinterpret_cast<f4 *>(b_vals + 16 * (int64_t)out);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dst[q] = f4{blk[4 * q], blk[4 * q + 1], blk[4 * q + 2], blk[4 * q + 3]};
+        ++out;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          while (p[q] < e[q] && (colind[p[q]] >> 2) == cur) ++p[q];
+        ++n;
+      }
+    }
+    if constexpr (!FILL) counts_or_rowptr[br] = n;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Block-diagonal batch assembly from the resident operator pool.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void blockdiag_rowptr(const int *__restrict__ pool_rowptr,
+                                                        const int64_t *__restrict__ desc, int64_t B,
+                                                        int64_t size0, int64_t total,
+                                                        int *__restrict__ out_rowptr) {
+  const int64_t n = B * size0 + 1;
+  for (int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += (int64_t)gridDim.x * kWG) {
+    if (i == n - 1) {
+      out_rowptr[i] = (int)total;
+      continue;
+    }
+    const int64_t b = i / size0, r = i - b * size0;
+    const int64_t *d = desc + 4 * b;
+    const int64_t rows = d[2];
+    const int local = pool_rowptr[d[0] + (r < rows ? r : rows)];
+    out_rowptr[i] = (int)(d[3] + local);
+  }
+}
+
+template <int VPE>
+__global__ __launch_bounds__(kWG) void blockdiag_entries(const int *__restrict__ pool_colind,
+                                                         const float *__restrict__ pool_vals,
+                                                         const int64_t *__restrict__ desc, int64_t B,
+                                                         int64_t size1, int64_t total,
+                                                         int *__restrict__ out_colind,
+                                                         float *__restrict__ out_vals) {
+  for (int64_t k = (int64_t)blockIdx.x * kWG + threadIdx.x; k < total; k += (int64_t)gridDim.x * kWG) {
+    // last b with desc[b].out_off <= k
+    int64_t lo = 0, hi = B;
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (desc[4 * mid + 3] <= k) lo = mid; else hi = mid;
+    }
+    const int64_t *d = desc + 4 * lo;
+    const int64_t src = d[1] + (k - d[3]);
+    out_colind[k] = pool_colind[src] + (int)(lo * size1);
+    if constexpr (VPE == 1) {
+      out_vals[k] = pool_vals[src];
+    } else {
+      const f4 *s = reinterpret_cast<const f4 *>(pool_vals + (int64_t)VPE * src);
+      f4 *o = reinterpret_cast<f4 *>(out_vals + (int64_t)VPE * k);
+#pragma unroll
+      for (int i = 0; i < VPE / 4; ++i) o[i] = s[i];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ELU helpers (alpha = 1, as F.elu defaults in the reference).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+
+template <bool VEC>
+__global__ __launch_bounds__(kWG) void elu_into_k(const float *__restrict__ src, int64_t lds,
+                                                  float *__restrict__ dst, int64_t ldd, int64_t rows,
+                                                  int C) {
+  constexpr int W = VEC ? 4 : 1;
+  const int cw = C / W;
+  const int64_t total = rows * cw;
+  for (int64_t t = (int64_t)blockIdx.x * kWG + threadIdx.x; t < total; t += (int64_t)gridDim.x * kWG) {
+    const int64_t r = t / cw;
+    const int c = (int)(t - r * cw) * W;
+    if constexpr (VEC) {
+      f4 v = ld4(src + r * lds + c);
+      v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
+      st4(dst + r * ldd + c, v);
+    } else {
+      dst[r * ldd + c] = elu1(src[r * lds + c]);
+    }
+  }
+}
+
+template <bool VEC, bool ACC>
+__global__ __launch_bounds__(kWG) void elu_bwd_k(const float *__restrict__ gdst, int64_t ldg,
+                                                 const float *__restrict__ out, int64_t ldo,
+                                                 float *__restrict__ gsrc, int64_t ldgs, int64_t rows,
+                                                 int C) {
+  constexpr int W = VEC ? 4 : 1;
+  const int cw = C / W;
+  const int64_t total = rows * cw;
+  for (int64_t t = (int64_t)blockIdx.x * kWG + threadIdx.x; t < total; t += (int64_t)gridDim.x * kWG) {
+    const int64_t r = t / cw;
+    const int c = (int)(t - r * cw) * W;
+    if constexpr (VEC) {
+      const f4 g = ld4(gdst + r * ldg + c);
+      const f4 o = ld4(out + r * ldo + c);
+      f4 d;
+      d.x = g.x * (o.x > 0.f ? 1.f : o.x + 1.f);
+      d.y = g.y * (o.y > 0.f ? 1.f : o.y + 1.f);
+      d.z = g.z * (o.z > 0.f ? 1.f : o.z + 1.f);
+      d.w = g.w * (o.w > 0.f ? 1.f : o.w + 1.f);
+      float *p = gsrc + r * ldgs + c;
+      if constexpr (ACC) {
+        const f4 a = ld4(p);
+        d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
+      }
+      st4(p, d);
+    } else {
+      const float o = out[r * ldo + c];
+      const float d = gdst[r * ldg + c] * (o > 0.f ? 1.f : o + 1.f);
+      float *p = gsrc + r * ldgs + c;
+      *p = ACC ? *p + d : d;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side helpers
+// ------------------------------------------------------------------------------------------------
+inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SN_OK : (int)e;
+}
+
+inline unsigned grid_for(int64_t work_items, int per_block) {
+  int64_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  const int64_t cap = (int64_t)kCUs * kMaxBlocksPerCU;
+  return (unsigned)(b < cap ? b : cap);
+}
+
+// grid for the XCD-aware chunk walk: a multiple of 8 workgroups, at most 8 per CU.
+inline unsigned chunk_grid(int64_t nchunks) {
+  int64_t b = ((nchunks + kXCD - 1) / kXCD) * kXCD;
+  const int64_t cap = (int64_t)kCUs * kMaxBlocksPerCU;
+  if (b > cap) b = cap;
+  if (b < kXCD) b = kXCD;
+  return (unsigned)b;
+}
+
+inline bool fits_i32(int64_t v) { return v >= 0 && v <= (int64_t)INT_MAX; }
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+inline int check_dense(const float *P, int64_t ld, int group, int N) {
+  if (!P) return SN_E_NULL;
+  if (group != 1 && group != 4) return SN_E_LD;
+  if (group == 1 && ld < N) return SN_E_LD;
+  if (group == 4 && ld < 4 * (int64_t)N) return SN_E_LD;
+  return SN_OK;
+}
+
+int exclusive_scan_i32(const int *in, int64_t n, int *out, void *ws, size_t ws_bytes, hipStream_t s) {
+  const int64_t nblk = (n + kScanTile - 1) / kScanTile;
+  if (ws_bytes < (size_t)nblk * sizeof(int)) return SN_E_WORKSPACE;
+  if (n <= 0) return SN_OK;
+  int *sums = static_cast<int *>(ws);
+  hipLaunchKernelGGL(scan_block_sums, dim3((unsigned)nblk), dim3(kWG), 0, s, in, n, sums);
+  hipLaunchKernelGGL(scan_sums_inplace, dim3(1), dim3(kWG), 0, s, sums, (int)nblk);
+  hipLaunchKernelGGL(scan_apply, dim3((unsigned)nblk), dim3(kWG), 0, s, in, n, sums, out);
+  return launch_status();
+}
+
+#define SN_DISPATCH_N_G(KERNEL, N, xg, yg, grid, stream, ...)                                          \
+  do {                                                                                                 \
+    if (xg == 1 && yg == 1) hipLaunchKernelGGL((KERNEL<N, 1, 1>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
+    else if (xg == 4 && yg == 4) hipLaunchKernelGGL((KERNEL<N, 4, 4>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
+    else if (xg == 1 && yg == 4) hipLaunchKernelGGL((KERNEL<N, 1, 4>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((KERNEL<N, 4, 1>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__);         \
+  } while (0)
+
+}  // namespace
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" {
+
+int sn_abi_version(void) { return SN_ABI_VERSION; }
+
+const char *sn_status_string(int status) {
+  switch (status) {
+    case SN_OK: return "ok";
+    case SN_E_NULL: return "null pointer argument";
+    case SN_E_SHAPE: return "invalid shape";
+    case SN_E_RANGE: return "dimension or nnz exceeds int32 index range";
+    case SN_E_LD: return "invalid leading dimension / group layout";
+    case SN_E_ALIGN: return "misaligned pointer";
+    case SN_E_WORKSPACE: return "workspace too small";
+    case SN_E_UNSUPPORTED: return "unsupported configuration";
+    default: break;
+  }
+  if (status > 0) return hipGetErrorString((hipError_t)status);
+  return "unknown sn status";
+}
+
+int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M,
+                    int64_t K, int64_t nnz, const float *X, int64_t ldx, int32_t x_group, int32_t N,
+                    float *Y, int64_t ldy, int32_t y_group, void *stream) {
+  if (M < 0 || K < 0 || nnz < 0 || N < 1) return SN_E_SHAPE;
+  if (!fits_i32(M + 1) || !fits_i32(K) || !fits_i32(nnz)) return SN_E_RANGE;
+  if (M == 0) return SN_OK;
+  if (!rowptr || (nnz > 0 && (!colind || !vals))) return SN_E_NULL;
+  int st = check_dense(Y, ldy, y_group, N);
+  if (st) return st;
+  if (K > 0 || nnz > 0) {
+    st = check_dense(X, ldx, x_group, N);
+    if (st) return st;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (N == 16 || N == 32 || N == 64 || N == 128) && aligned16(X) && aligned16(Y) &&
+                   (ldx % 4 == 0) && (ldy % 4 == 0);
+  if (vec) {
+    const int rpb = kWG / (N / 4);
+    const int64_t nchunks = (M + rpb - 1) / rpb;
+    const unsigned grid = chunk_grid(nchunks);
+    switch (N) {
+      case 16: SN_DISPATCH_N_G(spmm_csr_v4, 16, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks); break;
+      case 32: SN_DISPATCH_N_G(spmm_csr_v4, 32, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks); break;
+      case 64: SN_DISPATCH_N_G(spmm_csr_v4, 64, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks); break;
+      default: SN_DISPATCH_N_G(spmm_csr_v4, 128, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks); break;
+    }
+  } else {
+    hipLaunchKernelGGL(spmm_csr_any, dim3(grid_for(M * (int64_t)N, kWG)), dim3(kWG), 0, s, rowptr, colind,
+                       vals, M, (int)N, X, ldx, (int)x_group, Y, ldy, (int)y_group);
+  }
+  return launch_status();
+}
+
+int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb,
+                     int64_t Kb, int64_t nblocks, const float *X, int64_t ldx, int32_t x_group,
+                     int32_t N, float *Y, int64_t ldy, int32_t y_group, void *stream) {
+  if (Mb < 0 || Kb < 0 || nblocks < 0 || N < 1) return SN_E_SHAPE;
+  if (!fits_i32(4 * Mb + 1) || !fits_i32(4 * Kb) || !fits_i32(nblocks)) return SN_E_RANGE;
+  if (Mb == 0) return SN_OK;
+  if (!b_rowptr || (nblocks > 0 && (!b_colind || !b_vals))) return SN_E_NULL;
+  int st = check_dense(Y, ldy, y_group, N);
+  if (st) return st;
+  if (Kb > 0 || nblocks > 0) {
+    st = check_dense(X, ldx, x_group, N);
+    if (st) return st;
+  }
+  if (!(N == 16 || N == 32 || N == 64 || N == 128)) return SN_E_UNSUPPORTED;
+  if (!aligned16(X) || !aligned16(Y) || !aligned16(b_vals) || ldx % 4 || ldy % 4) return SN_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int rpb = kWG / (N / 4);
+  const int64_t nchunks = (Mb + rpb - 1) / rpb;
+  const unsigned grid = chunk_grid(nchunks);
+  switch (N) {
+    case 16: SN_DISPATCH_N_G(spmm_bsr4_v4, 16, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks); break;
+    case 32: SN_DISPATCH_N_G(spmm_bsr4_v4, 32, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks); break;
+    case 64: SN_DISPATCH_N_G(spmm_bsr4_v4, 64, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks); break;
+    default: SN_DISPATCH_N_G(spmm_bsr4_v4, 128, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks); break;
+  }
+  return launch_status();
+}
+
+int sn_coo_to_csr_i32(const int64_t *idx_batch, const int64_t *idx_row, const int64_t *idx_col,
+                      int64_t nnz, int64_t B, int64_t R, int64_t Kb, int32_t *rowptr, int32_t *colind,
+                      void *stream) {
+  if (nnz < 0 || B < 1 || R < 0 || Kb < 0) return SN_E_SHAPE;
+  const int64_t M = B * R;
+  if (!fits_i32(M + 1) || !fits_i32(B * Kb) || !fits_i32(nnz)) return SN_E_RANGE;
+  if (!rowptr || (nnz > 0 && (!idx_row || !idx_col || !colind))) return SN_E_NULL;
+  const int64_t n = (M + 1 > nnz) ? M + 1 : nnz;
+  hipLaunchKernelGGL(coo_to_csr_k, dim3(grid_for(n, kWG)), dim3(kWG), 0, static_cast<hipStream_t>(stream),
+                     idx_batch, idx_row, idx_col, nnz, M, R, Kb, rowptr, colind);
+  return launch_status();
+}
+
+size_t sn_scan_workspace_bytes(int64_t n) {
+  if (n < 0) n = 0;
+  return (size_t)((n + kScanTile - 1) / kScanTile + 1) * sizeof(int);
+}
+
+size_t sn_csr_transpose_workspace_bytes(int64_t M, int64_t K, int64_t nnz) {
+  (void)M;
+  (void)nnz;
+  if (K < 0) K = 0;
+  // cursor[K] (16-byte padded) + scan scratch for K+1 counters
+  const size_t cursor = ((size_t)K * sizeof(int) + 15) & ~(size_t)15;
+  return cursor + sn_scan_workspace_bytes(K + 1);
+}
+
+int sn_csr_transpose_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M,
+                         int64_t K, int64_t nnz, int32_t *t_rowptr, int32_t *t_colind, float *t_vals,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+  if (M < 0 || K < 0 || nnz < 0) return SN_E_SHAPE;
+  if (!fits_i32(M + 1) || !fits_i32(K + 1) || !fits_i32(nnz)) return SN_E_RANGE;
+  if (!t_rowptr || !rowptr) return SN_E_NULL;
+  if (nnz > 0 && (!colind || !vals || !t_colind || !t_vals)) return SN_E_NULL;
+  if (workspace_bytes < sn_csr_transpose_workspace_bytes(M, K, nnz) || (!workspace && K > 0))
+    return SN_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(t_rowptr, 0, (size_t)(K + 1) * sizeof(int), s);
+  if (e != hipSuccess) return (int)e;
+  if (nnz == 0 || K == 0) return SN_OK;
+  int *cursor = static_cast<int *>(workspace);
+  const size_t cursor_bytes = ((size_t)K * sizeof(int) + 15) & ~(size_t)15;
+  void *scan_ws = static_cast<char *>(workspace) + cursor_bytes;
+  hipLaunchKernelGGL(histogram_cols, dim3(grid_for(nnz, kWG)), dim3(kWG), 0, s, colind, nnz, t_rowptr);
+  int st = exclusive_scan_i32(t_rowptr, K + 1, t_rowptr, scan_ws, workspace_bytes - cursor_bytes, s);
+  if (st) return st;
+  e = hipMemcpyAsync(cursor, t_rowptr, (size_t)K * sizeof(int), hipMemcpyDeviceToDevice, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(transpose_scatter, dim3(grid_for(M, kWG)), dim3(kWG), 0, s, rowptr, colind, vals, M,
+                     cursor, t_colind, t_vals);
+  hipLaunchKernelGGL(sort_rows_by_col, dim3(grid_for(K, kWG)), dim3(kWG), 0, s, t_rowptr, K, t_colind,
+                     t_vals);
+  return launch_status();
+}
+
+int sn_bsr4_count(const int32_t *rowptr, const int32_t *colind, int64_t M, int64_t K, int32_t *b_rowptr,
+                  void *workspace, size_t workspace_bytes, void *stream) {
+  if (M < 0 || K < 0) return SN_E_SHAPE;
+  if ((M & 3) || (K & 3)) return SN_E_UNSUPPORTED;
+  if (!fits_i32(M + 1) || !fits_i32(K)) return SN_E_RANGE;
+  if (!rowptr || !b_rowptr) return SN_E_NULL;
+  const int64_t Mb = M / 4;
+  if (workspace_bytes < sn_scan_workspace_bytes(Mb + 1) || !workspace) return SN_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(b_rowptr + Mb, 0, sizeof(int), s);
+  if (e != hipSuccess) return (int)e;
+  if (Mb > 0)
+    hipLaunchKernelGGL((bsr4_merge<false>), dim3(grid_for(Mb, kWG)), dim3(kWG), 0, s, rowptr, colind,
+                       (const float *)nullptr, Mb, b_rowptr, (int *)nullptr, (float *)nullptr);
+  return exclusive_scan_i32(b_rowptr, Mb + 1, b_rowptr, workspace, workspace_bytes, s);
+}
+
+int sn_bsr4_fill(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
+                 const int32_t *b_rowptr, int32_t *b_colind, float *b_vals, void *stream) {
+  if (M < 0 || K < 0) return SN_E_SHAPE;
+  if ((M & 3) || (K & 3)) return SN_E_UNSUPPORTED;
+  if (!rowptr || !b_rowptr) return SN_E_NULL;
+  const int64_t Mb = M / 4;
+  if (Mb == 0) return SN_OK;
+  if (!colind || !vals || !b_colind || !b_vals) return SN_E_NULL;
+  if (!aligned16(b_vals)) return SN_E_ALIGN;
+  hipLaunchKernelGGL((bsr4_merge<true>), dim3(grid_for(Mb, kWG)), dim3(kWG), 0,
+                     static_cast<hipStream_t>(stream), rowptr, colind, vals, Mb,
+                     const_cast<int *>(b_rowptr), b_colind, b_vals);
+  return launch_status();
+}
+
+int sn_blockdiag_concat_i32(const int32_t *pool_rowptr, const int32_t *pool_colind,
+                            const float *pool_vals, const int64_t *desc, int64_t B, int64_t size0,
+                            int64_t size1, int64_t total, int32_t vals_per_entry, int32_t *out_rowptr,
+                            int32_t *out_colind, float *out_vals, void *stream) {
+  if (B < 0 || size0 < 0 || size1 < 0 || total < 0) return SN_E_SHAPE;
+  if (vals_per_entry != 1 && vals_per_entry != 16) return SN_E_UNSUPPORTED;
+  if (!fits_i32(B * size0 + 1) || !fits_i32(B * size1) || !fits_i32(total)) return SN_E_RANGE;
+  if (!out_rowptr) return SN_E_NULL;
+  if (B > 0 && (!desc || !pool_rowptr)) return SN_E_NULL;
+  if (total > 0 && (!pool_colind || !pool_vals || !out_colind || !out_vals)) return SN_E_NULL;
+  if (vals_per_entry == 16 && total > 0 && (!aligned16(pool_vals) || !aligned16(out_vals))) return SN_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(blockdiag_rowptr, dim3(grid_for(B * size0 + 1, kWG)), dim3(kWG), 0, s, pool_rowptr,
+                     desc, B, size0, total, out_rowptr);
+  if (total > 0) {
+    if (vals_per_entry == 1)
+      hipLaunchKernelGGL((blockdiag_entries<1>), dim3(grid_for(total, kWG)), dim3(kWG), 0, s, pool_colind,
+                         pool_vals, desc, B, size1, total, out_colind, out_vals);
+    else
+      hipLaunchKernelGGL((blockdiag_entries<16>), dim3(grid_for(total, kWG)), dim3(kWG), 0, s, pool_colind,
+                         pool_vals, desc, B, size1, total, out_colind, out_vals);
+  }
+  return launch_status();
+}
+
+int sn_elu_into_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t rows, int32_t C,
+                    void *stream) {
+  if (rows < 0 || C < 1 || lds < C || ldd < C) return SN_E_SHAPE;
+  if (rows == 0) return SN_OK;
+  if (!src || !dst) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && aligned16(src) && aligned16(dst);
+  if (vec)
+    hipLaunchKernelGGL((elu_into_k<true>), dim3(grid_for(rows * (C / 4), kWG)), dim3(kWG), 0, s, src, lds,
+                       dst, ldd, rows, (int)C);
+  else
+    hipLaunchKernelGGL((elu_into_k<false>), dim3(grid_for(rows * (int64_t)C, kWG)), dim3(kWG), 0, s, src,
+                       lds, dst, ldd, rows, (int)C);
+  return launch_status();
+}
+
+int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *out, int64_t ldo, float *gsrc,
+                       int64_t ldgs, int64_t rows, int32_t C, int32_t accumulate, void *stream) {
+  if (rows < 0 || C < 1 || ldg < C || ldo < C || ldgs < C) return SN_E_SHAPE;
+  if (rows == 0) return SN_OK;
+  if (!gdst || !out || !gsrc) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (C % 4 == 0) && (ldg % 4 == 0) && (ldo % 4 == 0) && (ldgs % 4 == 0) &&
+                   aligned16(gdst) && aligned16(out) && aligned16(gsrc);
+  const unsigned grid = grid_for(vec ? rows * (C / 4) : rows * (int64_t)C, kWG);
+  if (vec) {
+    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<true, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, out, ldo, gsrc, ldgs, rows, (int)C);
+    else hipLaunchKernelGGL((elu_bwd_k<true, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, out, ldo, gsrc, ldgs, rows, (int)C);
+  } else {
+    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<false, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, out, ldo, gsrc, ldgs, rows, (int)C);
+    else hipLaunchKernelGGL((elu_bwd_k<false, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, out, ldo, gsrc, ldgs, rows, (int)C);
+  }
+  return launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+"""Autograd entry points of the hot path.  Each Function is a thin shell around launches in kernels.py.
+
+    spmm(A, x)                  y = A·x ; backward grad_x = A^T·grad_y through the cached CSR of A^T, grad_A = None
+                                (contract of SparseBMMFunc, src/utils/cuda/sparse_bmm_func.py:27-72, and of
+                                torch.mm(sparse, dense) at src/utils/utils_pt.py:167,176,202,214)
+    lap_propagate(L, x)         [elu(x), L·elu(x)] written straight into one (rows, 2C) buffer
+                                (F.elu + torch.mm + torch.cat of src/utils/utils_pt.py:161-168 and :171-177)
+    dirac_face_stage(Di, v, f)  ([elu(f), Di·elu(v)], elu(v))         (src/utils/utils_pt.py:195-204)
+    dirac_vert_stage(DiA, f_out, e_v)  [e_v, DiA·elu(f_out)]          (src/utils/utils_pt.py:208-216)
+
+Dense operands are 2-D (rows, C) fp32 tensors; `group` says how many operator rows one tensor row holds
+(1 for the Laplacian, 4 for the quaternion view (B*V*4, C/4) of the Dirac path, utils_pt.py:201,213).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import kernels
+from .operators import SparseOperator, as_operator
+
+__all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "set_dirac_format", "SpmmTimer"]
+
+_USE_BSR4 = True
+
+
+def set_dirac_format(fmt: str) -> None:
+    """'bsr4' (default: packed 4x4 blocks when the operator has them) or 'csr' (always the generic kernel)."""
+    global _USE_BSR4
+    if fmt not in ("bsr4", "csr"):
+        raise ValueError(fmt)
+    _USE_BSR4 = fmt == "bsr4"
+
+
+class SpmmTimer:
+    """Optional HIP-event timing of every SpMM launch (bench.py uses it to measure the dominant kernel live,
+    on the stream the kernel is launched on).  Off by default: zero overhead."""
+
+    active = None
+
+    def __init__(self):
+        self.records = []      # (tag, M, K, nnz, N, start_event, end_event)
+
+    def __enter__(self):
+        SpmmTimer.active = self
+        return self
+
+    def __exit__(self, *exc):
+        SpmmTimer.active = None
+
+    def results(self):
+        torch.cuda.synchronize()
+        return [(tag, M, K, nnz, N, s.elapsed_time(e)) for tag, M, K, nnz, N, s, e in self.records]
+
+
+def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, tag: str = "") -> None:
+    """y <- op·x with the best resident format of `op`."""
+    M, K = op.shape
+    timer = SpmmTimer.active
+    if timer is not None:
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+    b = op.bsr4() if (_USE_BSR4 and group == 4) else None
+    if b is not None:
+        kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
+    else:
+        kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x, y, group)
+    if timer is not None:
+        e.record()
+        timer.records.append((tag + ("/bsr4" if b is not None else "/csr"), M, K, op.nnz, y.shape[1] // group, s, e))
+
+
+def _rows2d(x: torch.Tensor) -> torch.Tensor:
+    """A 2-D fp32 view with contiguous rows (copies only if the rows themselves are strided)."""
+    if x.dim() != 2:
+        raise ValueError("expected a 2-D dense operand")
+    if x.dtype != torch.float32:
+        raise TypeError("the Surface-Network path is fp32")
+    if x.shape[1] > 1 and x.stride(1) != 1:
+        x = x.contiguous()
+    return x
+
+
+class _SpMM(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, op, group):
+        x = _rows2d(x)
+        M, K = op.shape
+        N = x.shape[1] // group
+        y = torch.empty((M // group, group * N), dtype=torch.float32, device=x.device)
+        _launch(op, x, y, group, "fwd")
+        ctx.op, ctx.group = op, group
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if not ctx.needs_input_grad[0]:
+            return None, None, None
+        op, group = ctx.op, ctx.group
+        gy = _rows2d(gy)
+        M, K = op.shape
+        gx = torch.empty((K // group, gy.shape[1]), dtype=torch.float32, device=gy.device)
+        _launch(op.t(), gy, gx, group, "bwd")
+        return gx, None, None            # no gradient w.r.t. the operator (sparse_bmm_func.py:72)
+
+
+def spmm(A, x: torch.Tensor, group: int = 1) -> torch.Tensor:
+    """A·x for a 2-D dense x of shape (K/group, group*N); returns (M/group, group*N)."""
+    op = as_operator(A)
+    if x.shape[0] * group != op.shape[1]:
+        raise ValueError(f"spmm: operator is {tuple(op.shape)} but x has {x.shape[0]}x{group} rows")
+    return _SpMM.apply(x, op, group)
+
+
+class _LapPropagate(torch.autograd.Function):
+    """cat = [e, L·e], e = elu(x).  Backward: g_e = g_cat[:, :C] + L^T·g_cat[:, C:]; g_x = g_e * elu'(e)."""
+
+    @staticmethod
+    def forward(ctx, x, op):
+        x = _rows2d(x)
+        rows, C = x.shape
+        cat = torch.empty((rows, 2 * C), dtype=torch.float32, device=x.device)
+        e, le = cat[:, :C], cat[:, C:]
+        kernels.elu_into(x, e)
+        _launch(op, e, le, 1, "fwd")
+        ctx.op = op
+        ctx.save_for_backward(cat)
+        return cat
+
+    @staticmethod
+    def backward(ctx, g_cat):
+        (cat,) = ctx.saved_tensors
+        g_cat = _rows2d(g_cat)
+        C = cat.shape[1] // 2
+        g_e = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
+        _launch(ctx.op.t(), g_cat[:, C:], g_e, 1, "bwd")
+        # g_x = (g_e + g_cat[:, :C]) * elu'(e): fold the add into two accumulate passes of the elu-backward kernel
+        g_x = torch.empty_like(g_e)
+        kernels.elu_bwd(g_e, cat[:, :C], g_x, False)
+        kernels.elu_bwd(g_cat[:, :C], cat[:, :C], g_x, True)
+        return g_x, None
+
+
+def lap_propagate(L, x2d: torch.Tensor) -> torch.Tensor:
+    op = as_operator(L)
+    if op.shape[0] != op.shape[1] or op.shape[1] != x2d.shape[0]:
+        raise ValueError(f"lap_propagate: operator {tuple(op.shape)} vs {x2d.shape[0]} rows")
+    return _LapPropagate.apply(x2d, op)
+
+
+class _DiracFaceStage(torch.autograd.Function):
+    """cat0 = [elu(f), Di·elu(v)] (face rows) and e_v = elu(v) (vertex rows, reused by the vertex stage)."""
+
+    @staticmethod
+    def forward(ctx, v, f, op):
+        v, f = _rows2d(v), _rows2d(f)
+        C = v.shape[1]
+        e_v = torch.empty_like(v, memory_format=torch.contiguous_format)
+        kernels.elu_into(v, e_v)
+        cat0 = torch.empty((f.shape[0], 2 * C), dtype=torch.float32, device=v.device)
+        kernels.elu_into(f, cat0[:, :C])
+        _launch(op, e_v, cat0[:, C:], 4, "fwd")
+        ctx.op = op
+        ctx.save_for_backward(cat0, e_v)
+        ctx.set_materialize_grads(False)
+        return cat0, e_v
+
+    @staticmethod
+    def backward(ctx, g_cat0, g_ev):
+        cat0, e_v = ctx.saved_tensors
+        C = e_v.shape[1]
+        g_v = g_f = None
+        if g_cat0 is not None:
+            g_cat0 = _rows2d(g_cat0)
+        if ctx.needs_input_grad[1] and g_cat0 is not None:
+            g_f = torch.empty((cat0.shape[0], C), dtype=torch.float32, device=cat0.device)
+            kernels.elu_bwd(g_cat0[:, :C], cat0[:, :C], g_f, False)
+        if ctx.needs_input_grad[0]:
+            g_e = torch.empty_like(e_v)
+            if g_cat0 is not None:
+                _launch(ctx.op.t(), g_cat0[:, C:], g_e, 4, "bwd")
+            else:
+                g_e.zero_()
+            g_v = torch.empty_like(e_v)
+            kernels.elu_bwd(g_e, e_v, g_v, False)
+            if g_ev is not None:
+                kernels.elu_bwd(_rows2d(g_ev), e_v, g_v, True)
+        return g_v, g_f, None
+
+
+def dirac_face_stage(Di, v2d: torch.Tensor, f2d: torch.Tensor):
+    op = as_operator(Di)
+    if op.shape[1] != 4 * v2d.shape[0] or op.shape[0] != 4 * f2d.shape[0]:
+        raise ValueError(f"dirac_face_stage: Di is {tuple(op.shape)}, v rows {v2d.shape[0]}, f rows {f2d.shape[0]}")
+    return _DiracFaceStage.apply(v2d, f2d, op)
+
+
+class _DiracVertStage(torch.autograd.Function):
+    """cat1 = [e_v, DiA·elu(f_out)] (vertex rows)."""
+
+    @staticmethod
+    def forward(ctx, f_out, e_v, op):
+        f_out, e_v = _rows2d(f_out), _rows2d(e_v)
+        C = e_v.shape[1]
+        e_f = torch.empty_like(f_out, memory_format=torch.contiguous_format)
+        kernels.elu_into(f_out, e_f)
+        cat1 = torch.empty((e_v.shape[0], 2 * C), dtype=torch.float32, device=e_v.device)
+        cat1[:, :C].copy_(e_v)
+        _launch(op, e_f, cat1[:, C:], 4, "fwd")
+        ctx.op = op
+        ctx.save_for_backward(e_f)
+        return cat1
+
+    @staticmethod
+    def backward(ctx, g_cat1):
+        (e_f,) = ctx.saved_tensors
+        g_cat1 = _rows2d(g_cat1)
+        C = e_f.shape[1]
+        g_fo = None
+        if ctx.needs_input_grad[0]:
+            g_e = torch.empty_like(e_f)
+            _launch(ctx.op.t(), g_cat1[:, C:], g_e, 4, "bwd")
+            g_fo = torch.empty_like(e_f)
+            kernels.elu_bwd(g_e, e_f, g_fo, False)
+        g_ev = g_cat1[:, :C] if ctx.needs_input_grad[1] else None
+        return g_fo, g_ev, None
+
+
+def dirac_vert_stage(DiA, f_out2d: torch.Tensor, e_v2d: torch.Tensor) -> torch.Tensor:
+    op = as_operator(DiA)
+    if op.shape[0] != 4 * e_v2d.shape[0] or op.shape[1] != 4 * f_out2d.shape[0]:
+        raise ValueError(f"dirac_vert_stage: DiA is {tuple(op.shape)}, v rows {e_v2d.shape[0]}, f rows {f_out2d.shape[0]}")
+    return _DiracVertStage.apply(f_out2d, e_v2d, op)

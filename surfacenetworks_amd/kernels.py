@@ -1,0 +1,143 @@
+"""Tensor-level launchers of the C-ABI (include/sn_spmm.h).  PyTorch is plumbing here: it owns the HBM
+allocations and the HIP stream; every byte of the hot path is moved by the kernels in csrc/sn_kernels.hip.
+
+All functions require device ("cuda" = HIP under PyTorch-ROCm) tensors and raise otherwise — there is no
+CPU path in the product.  Launches go to torch's current stream and never synchronise, except
+csr_to_bsr4 which must read one integer (the block count) back to size its outputs.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+__all__ = [
+    "spmm_csr", "spmm_bsr4", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
+    "elu_into", "elu_bwd",
+]
+
+
+def _dev(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "surfacenetworks_amd kernels run on the MI355X only: got a CPU tensor. There is no CPU/eager "
+                "fallback in this package (the reference's CPU torch.sparse path lives in oracle/ for tests).")
+
+
+def _p(t):
+    return None if t is None or t.numel() == 0 else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ld(t: torch.Tensor) -> int:
+    """Leading dimension of a 2-D view whose rows are contiguous."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise ValueError(f"expected a 2-D tensor with unit column stride, got shape {tuple(t.shape)} stride {t.stride()}")
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def _check_dense(x: torch.Tensor, rows: int, group: int, N: int, what: str) -> int:
+    if x.dtype != torch.float32:
+        raise TypeError(f"{what} must be float32")
+    if rows % group or x.shape[0] != rows // group or x.shape[1] != group * N:
+        raise ValueError(f"{what}: expected ({rows // group}, {group * N}) for {rows} operator rows in groups of {group}, got {tuple(x.shape)}")
+    return _ld(x)
+
+
+def spmm_csr(rowptr, colind, vals, M: int, K: int, x, y, group: int = 1) -> None:
+    """y <- A·x.  x: (K/group, group*N) and y: (M/group, group*N) 2-D views with contiguous rows
+    (any row stride), e.g. halves of a (rows, 2C) concat buffer.  group=4 is the quaternion view."""
+    _dev(rowptr, colind, vals, x, y)
+    N = y.shape[1] // group
+    ldx = _check_dense(x, K, group, N, "x")
+    ldy = _check_dense(y, M, group, N, "y")
+    _lib.call("sn_spmm_csr_f32", _p(rowptr), _p(colind), _p(vals), M, K, int(colind.numel()),
+              _p(x), ldx, group, N, _p(y), ldy, group, _stream())
+
+
+def spmm_bsr4(b_rowptr, b_colind, b_vals, Mb: int, Kb: int, x, y, group: int = 1) -> None:
+    _dev(b_rowptr, b_colind, b_vals, x, y)
+    N = y.shape[1] // group
+    ldx = _check_dense(x, 4 * Kb, group, N, "x")
+    ldy = _check_dense(y, 4 * Mb, group, N, "y")
+    _lib.call("sn_spmm_bsr4_f32", _p(b_rowptr), _p(b_colind), _p(b_vals), Mb, Kb, int(b_colind.numel()),
+              _p(x), ldx, group, N, _p(y), ldy, group, _stream())
+
+
+def coo_to_csr(idx_batch, idx_row, idx_col, B: int, R: int, Kb: int):
+    """Sorted int64 COO index rows -> (rowptr int32 [B*R+1], colind int32 [nnz]) of the block-diagonal operator."""
+    _dev(idx_batch, idx_row, idx_col)
+    nnz = int(idx_row.numel())
+    dev = idx_row.device
+    rowptr = torch.empty(B * R + 1, dtype=torch.int32, device=dev)
+    colind = torch.empty(nnz, dtype=torch.int32, device=dev)
+    ib = None if idx_batch is None else idx_batch.contiguous()
+    _lib.call("sn_coo_to_csr_i32", _p(ib), _p(idx_row.contiguous()), _p(idx_col.contiguous()), nnz, B, R, Kb,
+              _p(rowptr), _p(colind), _stream())
+    return rowptr, colind
+
+
+def csr_transpose(rowptr, colind, vals, M: int, K: int):
+    _dev(rowptr, colind, vals)
+    nnz = int(colind.numel())
+    dev = rowptr.device
+    t_rowptr = torch.empty(K + 1, dtype=torch.int32, device=dev)
+    t_colind = torch.empty(nnz, dtype=torch.int32, device=dev)
+    t_vals = torch.empty(nnz, dtype=torch.float32, device=dev)
+    ws_bytes = int(_lib.load().sn_csr_transpose_workspace_bytes(M, K, nnz))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.call("sn_csr_transpose_f32", _p(rowptr), _p(colind), _p(vals), M, K, nnz, _p(t_rowptr), _p(t_colind),
+              _p(t_vals), _p(ws), ws_bytes, _stream())
+    return t_rowptr, t_colind, t_vals
+
+
+def csr_to_bsr4(rowptr, colind, vals, M: int, K: int):
+    """CSR -> 4x4-block BSR.  Synchronises once (reads the block count)."""
+    _dev(rowptr, colind, vals)
+    if M % 4 or K % 4:
+        raise ValueError("BSR4 needs M and K to be multiples of 4")
+    dev = rowptr.device
+    Mb = M // 4
+    b_rowptr = torch.empty(Mb + 1, dtype=torch.int32, device=dev)
+    ws_bytes = int(_lib.load().sn_scan_workspace_bytes(Mb + 1))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.call("sn_bsr4_count", _p(rowptr), _p(colind), M, K, _p(b_rowptr), _p(ws), ws_bytes, _stream())
+    nblocks = int(b_rowptr[-1].item())
+    b_colind = torch.empty(nblocks, dtype=torch.int32, device=dev)
+    b_vals = torch.empty(max(nblocks, 1) * 16, dtype=torch.float32, device=dev)[: nblocks * 16]
+    _lib.call("sn_bsr4_fill", _p(rowptr), _p(colind), _p(vals), M, K, _p(b_rowptr), _p(b_colind), _p(b_vals), _stream())
+    return b_rowptr, b_colind, b_vals
+
+
+def blockdiag_concat(pool_rowptr, pool_colind, pool_vals, desc, size0: int, size1: int, total: int, vpe: int = 1):
+    """Batch assembly from the resident pool; `desc` is the (B,4) int64 table of include/sn_spmm.h (device)."""
+    _dev(pool_rowptr, pool_colind, pool_vals, desc)
+    B = int(desc.shape[0])
+    dev = pool_rowptr.device
+    out_rowptr = torch.empty(B * size0 + 1, dtype=torch.int32, device=dev)
+    out_colind = torch.empty(total, dtype=torch.int32, device=dev)
+    out_vals = torch.empty(total * vpe, dtype=torch.float32, device=dev)
+    _lib.call("sn_blockdiag_concat_i32", _p(pool_rowptr), _p(pool_colind), _p(pool_vals), _p(desc), B, size0, size1,
+              total, vpe, _p(out_rowptr), _p(out_colind), _p(out_vals), _stream())
+    return out_rowptr, out_colind, out_vals
+
+
+def elu_into(src, dst) -> None:
+    """dst <- elu(src); both 2-D (rows, C) views with contiguous rows (dst may be half of a concat buffer)."""
+    _dev(src, dst)
+    if src.shape != dst.shape:
+        raise ValueError("elu_into: shape mismatch")
+    _lib.call("sn_elu_into_f32", _p(src), _ld(src), _p(dst), _ld(dst), src.shape[0], src.shape[1], _stream())
+
+
+def elu_bwd(gdst, out, gsrc, accumulate: bool) -> None:
+    """gsrc (+)= gdst * elu'(.) expressed through the activation output `out`."""
+    _dev(gdst, out, gsrc)
+    if not (gdst.shape == out.shape == gsrc.shape):
+        raise ValueError("elu_bwd: shape mismatch")
+    _lib.call("sn_elu_bwd_acc_f32", _p(gdst), _ld(gdst), _p(out), _ld(out), _p(gsrc), _ld(gsrc), out.shape[0],
+              out.shape[1], 1 if accumulate else 0, _stream())

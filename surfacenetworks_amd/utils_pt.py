@@ -1,0 +1,207 @@
+"""Drop-in for the reference operator layer `utils.utils_pt` (src/utils/utils_pt.py) on MI355X.
+
+    import surfacenetworks_amd.utils_pt as utils        # instead of: import utils.utils_pt as utils
+
+Same public names, call signatures and `state_dict` keys as the reference module:
+GraphConv1x1, GraphBatchNorm, global_average, LapResNet2, DenseLapResNet2, DirResNet2, AvgResNet2,
+MlpResNet2, sparse_cat, sparse_diag_cat, sp_sparse_to_pt_sparse, to_dense_batched — plus SparseBMMFunc, the
+name utils_pt.py:199,211 uses without importing.
+
+What differs is how a block executes.  Every sparse product goes through the hand-written HIP kernels
+(functional.py -> kernels.py -> csrc/sn_kernels.hip); ELU, the product and torch.cat are fused into one
+(rows, 2C) buffer; BatchNorm runs on the (rows, C) view instead of two transposed copies.  Operators may be
+`SparseOperator`s (resident CSR, see operators.py) or the torch sparse COO tensors the reference drivers
+build (2-D block-diagonal from sparse_diag_cat or 3-D batched from sparse_cat) — those are converted on the
+device once per tensor.  There is no CPU path: CPU tensors raise.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import functional as snF
+from .operators import SparseOperator, as_operator
+
+__all__ = [
+    "sparse_cat", "sparse_diag_cat", "sp_sparse_to_pt_sparse", "to_dense_batched", "GraphConv1x1",
+    "GraphBatchNorm", "global_average", "DenseLapResNet2", "LapResNet2", "DirResNet2", "AvgResNet2",
+    "MlpResNet2", "SparseBMMFunc",
+]
+
+
+# --------------------------------------------------------------------------------------------------
+# host-side operator batching with the reference's return types (torch sparse COO, coalesced)
+# --------------------------------------------------------------------------------------------------
+def sp_sparse_to_pt_sparse(L):
+    """scipy sparse matrix -> torch sparse COO (uncoalesced, dtype kept), as utils_pt.py:56-69."""
+    coo = L.tocoo()
+    index = torch.from_numpy(np.stack([coo.row, coo.col]).astype(np.int64))
+    return torch.sparse_coo_tensor(index, torch.from_numpy(coo.data), torch.Size(coo.shape))
+
+
+def sparse_diag_cat(tensors, size0, size1):
+    """Block-diagonal (len*size0, len*size1) operator from per-mesh COO operators, as utils_pt.py:41-53.
+    (The fast path never calls this per step: see operators.OperatorPool.assemble.)"""
+    shift = torch.tensor([[size0], [size1]], dtype=torch.int64)
+    index = torch.cat([t._indices() + i * shift for i, t in enumerate(tensors)], dim=1)
+    values = torch.cat([t._values() for t in tensors], dim=0)
+    n = len(tensors)
+    return torch.sparse_coo_tensor(index, values, torch.Size((n * size0, n * size1))).coalesce()
+
+
+def sparse_cat(tensors, size0, size1):
+    """3-D batched (len, size0, size1) COO operator, as utils_pt.py:21-39."""
+    index = torch.cat([torch.cat([torch.full((1, t._nnz()), i, dtype=torch.int64), t._indices()], dim=0)
+                       for i, t in enumerate(tensors)], dim=1)
+    values = torch.cat([t._values() for t in tensors], dim=0)
+    return torch.sparse_coo_tensor(index, values, torch.Size((len(tensors), size0, size1))).coalesce()
+
+
+def to_dense_batched(x, batch_size):
+    return x.to_dense().unsqueeze(0).repeat(batch_size, 1, 1)
+
+
+def global_average(x, mask):
+    """Masked mean over the node axis, kept as (B,1,C) (utils_pt.py:120-122)."""
+    m = mask.expand_as(x)
+    return (x * m).sum(1, keepdim=True) / m.sum(1, keepdim=True)
+
+
+class SparseBMMFunc:
+    """`SparseBMMFunc()(A, X)` of src/utils/cuda/sparse_bmm_func.py:23-72 for 3-D batched operands:
+    A (B,R,K) sparse COO / SparseOperator, X (B,K,N) dense -> (B,R,N); grad only w.r.t. X."""
+
+    def __call__(self, matrix1, matrix2):
+        op = as_operator(matrix1)
+        B, _, N = matrix2.shape
+        y = snF.spmm(op, matrix2.reshape(-1, N), 1)
+        return y.view(B, -1, N)
+
+
+# --------------------------------------------------------------------------------------------------
+# modules
+# --------------------------------------------------------------------------------------------------
+class GraphConv1x1(nn.Module):
+    """Optional BatchNorm1d ("pre" | "post" | None) + Linear over the channel axis of (B, Nodes, C)
+    (utils_pt.py:76-104).  BatchNorm statistics run over all B*Nodes rows, padded rows included, exactly
+    as BatchNorm1d on the reference's transposed (B,C,Nodes) view does."""
+
+    def __init__(self, num_inputs, num_outputs, batch_norm=None):
+        super().__init__()
+        self.num_inputs, self.num_outputs, self.batch_norm = num_inputs, num_outputs, batch_norm
+        if batch_norm == "pre":
+            self.bn = nn.BatchNorm1d(num_inputs)
+        if batch_norm == "post":
+            self.bn = nn.BatchNorm1d(num_outputs)
+        self.fc = nn.Linear(num_inputs, num_outputs)
+
+    def forward2d(self, x2d):
+        """(rows, Cin) -> (rows, Cout) on the flattened node axis."""
+        if self.batch_norm == "pre":
+            x2d = self.bn(x2d)
+        x2d = self.fc(x2d)
+        if self.batch_norm == "post":
+            x2d = self.bn(x2d)
+        return x2d
+
+    def forward(self, x):
+        batch_size, num_nodes, num_inputs = x.size()
+        assert num_inputs == self.num_inputs
+        return self.forward2d(x.reshape(-1, num_inputs)).view(batch_size, num_nodes, self.num_outputs)
+
+
+class GraphBatchNorm(nn.Module):
+    """BatchNorm over B*Nodes rows that always uses batch statistics (utils_pt.py:107-118)."""
+
+    def __init__(self, num_inputs):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_inputs)
+
+    def forward(self, x):
+        self.bn.train()
+        b, n, c = x.size()
+        return self.bn(x.reshape(b * n, c)).view(b, n, c)
+
+
+class _TwoStage(nn.Module):
+    """Shared constructor: two BN("pre")+Linear(2C -> C) stages named bn_fc0 / bn_fc1 (utils_pt.py:156-157,
+    187-188,227-228) — the names are part of the checkpoint format."""
+
+    def __init__(self, num_outputs):
+        super().__init__()
+        self.num_outputs = num_outputs
+        self.bn_fc0 = GraphConv1x1(2 * num_outputs, num_outputs, batch_norm="pre")
+        self.bn_fc1 = GraphConv1x1(2 * num_outputs, num_outputs, batch_norm="pre")
+
+
+class DenseLapResNet2(_TwoStage):
+    """Laplacian block with a dense (B,V,V) operator: plain batched GEMM (utils_pt.py:124-148)."""
+
+    def forward(self, L, mask, inputs):
+        x = F.elu(inputs)
+        x = self.bn_fc0(torch.cat([x, torch.bmm(L, x)], 2))
+        x = F.elu(x)
+        x = self.bn_fc1(torch.cat([x, torch.bmm(L, x)], 2))
+        return x + inputs
+
+
+class LapResNet2(_TwoStage):
+    """x + Lin(BN([e1, L e1])), e1 = elu(Lin(BN([e0, L e0]))), e0 = elu(x)   (utils_pt.py:151-180)."""
+
+    def forward(self, L, mask, inputs):
+        if isinstance(L, torch.Tensor) and L.layout == torch.strided:
+            return DenseLapResNet2.forward(self, L, mask, inputs)
+        batch, node, feat = inputs.size()
+        op = as_operator(L)
+        h = self.bn_fc0.forward2d(snF.lap_propagate(op, inputs.reshape(batch * node, feat)))
+        h = self.bn_fc1.forward2d(snF.lap_propagate(op, h))
+        return h.view(batch, node, feat) + inputs
+
+
+class DirResNet2(_TwoStage):
+    """Dirac block (utils_pt.py:182-220): vertices -> faces through Di, faces -> vertices through DiA, on the
+    quaternion view (rows*4, C/4); returns (v + v_out, f_out)."""
+
+    def __init__(self, num_outputs, res_f=False):
+        super().__init__(num_outputs)
+        self.res_f = res_f          # accepted and unused, as in the reference (utils_pt.py:189)
+
+    def forward(self, Di, DiA, v, f):
+        batch_size, num_nodes, num_inputs = v.size()
+        _, num_faces, _ = f.size()
+        cat0, e_v = snF.dirac_face_stage(as_operator(Di), v.reshape(batch_size * num_nodes, num_inputs),
+                                         f.reshape(batch_size * num_faces, num_inputs))
+        f_out = self.bn_fc0.forward2d(cat0)
+        cat1 = snF.dirac_vert_stage(as_operator(DiA), f_out, e_v)
+        v_out = self.bn_fc1.forward2d(cat1)
+        return v + v_out.view(batch_size, num_nodes, num_inputs), f_out.view(batch_size, num_faces, num_inputs)
+
+
+class AvgResNet2(_TwoStage):
+    """Global-average block (utils_pt.py:222-243): no sparse operator, plain PyTorch."""
+
+    def forward(self, L, mask, inputs):
+        x = F.elu(inputs)
+        x = self.bn_fc0(torch.cat([x, global_average(x, mask).expand_as(x)], 2))
+        x = F.elu(x)
+        x = self.bn_fc1(torch.cat([x, global_average(x, mask).expand_as(x)], 2))
+        return x + inputs
+
+
+class MlpResNet2(nn.Module):
+    """Per-node MLP block (utils_pt.py:245-263); checkpoint keys bn0.bn.*, fc0.fc.*, bn1.bn.*, fc1.fc.*."""
+
+    def __init__(self, num_outputs):
+        super().__init__()
+        self.num_outputs = num_outputs
+        self.bn0 = GraphBatchNorm(num_outputs)
+        self.fc0 = GraphConv1x1(num_outputs, num_outputs, batch_norm=None)
+        self.bn1 = GraphBatchNorm(num_outputs)
+        self.fc1 = GraphConv1x1(num_outputs, num_outputs, batch_norm=None)
+
+    def forward(self, L, mask, inputs):
+        x = self.fc0(F.elu(self.bn0(inputs)))
+        x = self.fc1(F.elu(self.bn1(x)))
+        return x + inputs

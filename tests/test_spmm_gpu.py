@@ -1,0 +1,269 @@
+"""GPU parity of the HIP kernels (through the C-ABI) against the C oracle: bit-exact for SpMM and the
+integer/index work, 1e-6 relative for ELU (expm1f implementations differ by an ulp)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from helpers import mesh_fixture, random_csr, rel_err
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+
+from surfacenetworks_amd import functional as snF, kernels  # noqa: E402
+from surfacenetworks_amd.operators import OperatorPool, SparseOperator, as_operator  # noqa: E402
+
+DEV = "cuda"
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+def csr_dev(A):
+    return dev(A.indptr.astype(np.int32)), dev(A.indices.astype(np.int32)), dev(A.data.astype(np.float32))
+
+
+@pytest.mark.parametrize("N", [16, 32, 64, 128, 1, 3, 20, 48])
+@pytest.mark.parametrize("shape", [(257, 190), (64, 64), (1, 7), (1000, 40)])
+def test_spmm_csr_bit_exact(N, shape):
+    M, K = shape
+    A = random_csr(M, K, 0.05, seed=M + N, empty_rows=[0, M // 2, M - 1])
+    X = np.random.default_rng(N).standard_normal((K, N)).astype(np.float32)
+    want = c_oracle.spmm_csr(A.indptr, A.indices, A.data, X.ravel(), N).reshape(M, N)
+    y = torch.full((M, N), float("nan"), device=DEV)          # every element must be written
+    kernels.spmm_csr(*csr_dev(A), M, K, dev(X), y, 1)
+    got = y.cpu().numpy()
+    assert np.array_equal(got, want)
+    assert rel_err(got, A.astype(np.float64) @ X.astype(np.float64)) < 1e-6
+
+
+@pytest.mark.parametrize("N", [16, 32, 64, 128])
+@pytest.mark.parametrize("kind", ["cloth", "cloth_perm", "torus", "delaunay"])
+@pytest.mark.parametrize("which", ["Di", "DiA"])
+def test_dirac_csr_and_bsr4_group_layouts(N, kind, which):
+    """Quaternion (group=4) view, contiguous and embedded in a 2C-wide concat buffer, CSR and BSR4."""
+    _, _, ops = mesh_fixture(kind)
+    A = ops[which]
+    M, K = A.shape
+    C = 4 * N
+    rng = np.random.default_rng(1)
+    xcat = rng.standard_normal((K // 4, 2 * C)).astype(np.float32)      # X lives in the FIRST half
+    X = np.ascontiguousarray(xcat[:, :C])
+    want = c_oracle.spmm_csr(A.indptr, A.indices, A.data, X.ravel(), N).reshape(M // 4, C)
+    # oracle with the strided addressing must agree with the contiguous one
+    ycat_o = np.zeros((M // 4, 2 * C), np.float32)
+    c_oracle.spmm_csr(A.indptr, A.indices, A.data, xcat.ravel(), N, ldx=2 * C, xg=4, Y=ycat_o.reshape(-1)[C:],
+                      ldy=2 * C, yg=4, M=M)
+    assert np.array_equal(ycat_o[:, C:], want)
+    rp, ci, va = csr_dev(A)
+    xc = dev(xcat)
+    ycat = torch.full((M // 4, 2 * C), float("nan"), device=DEV)
+    # CSR, strided in and out (second half of the output buffer)
+    kernels.spmm_csr(rp, ci, va, M, K, xc[:, :C], ycat[:, C:], 4)
+    assert np.array_equal(ycat[:, C:].cpu().numpy(), want)
+    assert torch.isnan(ycat[:, :C]).all()                                 # the other half is untouched
+    # BSR4 built on the device vs the oracle's conversion, then the product
+    b = kernels.csr_to_bsr4(rp, ci, va, M, K)
+    bo = c_oracle.csr_to_bsr4(A.indptr, A.indices, A.data)
+    for g_, o_ in zip(b, bo):
+        assert np.array_equal(g_.cpu().numpy(), o_)
+    y2 = torch.full((M // 4, C), float("nan"), device=DEV)
+    kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, xc[:, :C], y2, 4)
+    assert np.array_equal(y2.cpu().numpy(), want)
+    # group = 1 view of the same contiguous data gives the same numbers
+    y3 = torch.empty((M, N), device=DEV)
+    kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, dev(X).view(K, N), y3, 1)
+    assert np.array_equal(y3.cpu().numpy().reshape(M // 4, C), want)
+    assert rel_err(want.reshape(M, N), A.astype(np.float64) @ X.reshape(K, N).astype(np.float64)) < 1e-6
+
+
+@pytest.mark.parametrize("N", [64, 128])
+@pytest.mark.parametrize("kind", ["cloth", "delaunay"])
+def test_laplacian_strided(N, kind):
+    _, _, ops = mesh_fixture(kind)
+    L = ops["L"]
+    V = L.shape[0]
+    xcat = np.random.default_rng(2).standard_normal((V, 2 * N)).astype(np.float32)
+    want = c_oracle.spmm_csr(L.indptr, L.indices, L.data, np.ascontiguousarray(xcat[:, :N]).ravel(), N).reshape(V, N)
+    cat = dev(xcat)
+    kernels.spmm_csr(*csr_dev(L), V, V, cat[:, :N], cat[:, N:], 1)
+    assert np.array_equal(cat[:, N:].cpu().numpy(), want)
+    assert np.array_equal(cat[:, :N].cpu().numpy(), xcat[:, :N])
+
+
+def test_transpose_matches_oracle_and_scipy():
+    for kind in ["cloth", "delaunay"]:
+        _, _, ops = mesh_fixture(kind)
+        for name in ["L", "Di", "DiA"]:
+            A = ops[name]
+            M, K = A.shape
+            t = kernels.csr_transpose(*csr_dev(A), M, K)
+            to = c_oracle.csr_transpose(A.indptr, A.indices, A.data, K)
+            for g_, o_ in zip(t, to):
+                assert np.array_equal(g_.cpu().numpy(), o_)
+            T = A.T.tocsr()
+            T.sort_indices()
+            assert np.array_equal(t[0].cpu().numpy(), T.indptr) and np.array_equal(t[1].cpu().numpy(), T.indices)
+    # rectangular with empty rows/cols
+    A = random_csr(300, 77, 0.03, seed=5, empty_rows=[0, 10, 299])
+    t = kernels.csr_transpose(*csr_dev(A), 300, 77)
+    to = c_oracle.csr_transpose(A.indptr, A.indices, A.data, 77)
+    for g_, o_ in zip(t, to):
+        assert np.array_equal(g_.cpu().numpy(), o_)
+
+
+def test_large_scan_path():
+    """Transpose of an operator with > 2048*256 columns exercises the multi-block scan."""
+    K = 700_000
+    rng = np.random.default_rng(3)
+    M = 5000
+    cols = np.sort(rng.choice(K, size=(M, 6)), axis=1)
+    A = sp.csr_matrix((rng.standard_normal(M * 6).astype(np.float32), cols.ravel(), np.arange(0, 6 * M + 1, 6)), shape=(M, K))
+    A.sum_duplicates()
+    A.sort_indices()
+    t = kernels.csr_transpose(*csr_dev(A), M, K)
+    to = c_oracle.csr_transpose(A.indptr, A.indices, A.data, K)
+    for g_, o_ in zip(t, to):
+        assert np.array_equal(g_.cpu().numpy(), o_)
+
+
+def test_coo_to_csr_2d_3d_and_empty_rows():
+    _, _, ops = mesh_fixture("cloth")
+    A = ops["Di"].tocoo()
+    order = np.lexsort((A.col, A.row))
+    r, c = A.row[order].astype(np.int64), A.col[order].astype(np.int64)
+    rp, ci = kernels.coo_to_csr(None, dev(r), dev(c), 1, A.shape[0], A.shape[1])
+    rpo, cio = c_oracle.coo_to_csr(None, r, c, 1, A.shape[0], A.shape[1])
+    assert np.array_equal(rp.cpu().numpy(), rpo) and np.array_equal(ci.cpu().numpy(), cio)
+    # 3-D batched with interior empty rows (the case batch_csr.cu gets wrong)
+    B, R, Kb = 3, 40, 25
+    rng = np.random.default_rng(4)
+    ent = []
+    for b in range(B):
+        for rr in range(R):
+            if rr % 7 == 3 or (b == 1 and rr < 5):
+                continue
+            for cc in np.sort(rng.choice(Kb, 3, replace=False)):
+                ent.append((b, rr, cc))
+    ent = np.array(ent, dtype=np.int64)
+    rp, ci = kernels.coo_to_csr(dev(ent[:, 0]), dev(ent[:, 1]), dev(ent[:, 2]), B, R, Kb)
+    rpo, cio = c_oracle.coo_to_csr(ent[:, 0], ent[:, 1], ent[:, 2], B, R, Kb)
+    assert np.array_equal(rp.cpu().numpy(), rpo) and np.array_equal(ci.cpu().numpy(), cio)
+    S = sp.csr_matrix((np.ones(len(ent), np.float32), (ent[:, 0] * R + ent[:, 1], ent[:, 0] * Kb + ent[:, 2])), shape=(B * R, B * Kb))
+    S.sort_indices()
+    assert np.array_equal(rpo, S.indptr) and np.array_equal(cio, S.indices)
+
+
+def test_pool_assemble_matches_blockdiag():
+    meshes = [mesh_fixture(k)[2] for k in ["cloth", "delaunay", "torus", "cloth_perm"]]
+    for name, bsr in [("L", False), ("Di", True), ("DiA", True)]:
+        mats = [m[name] for m in meshes]
+        pool = OperatorPool(mats, DEV, want_bsr4=bsr)
+        sel = [2, 0, 3, 0, 1]
+        s0 = max(m.shape[0] for m in mats) + (4 if bsr else 3)
+        s1 = max(m.shape[1] for m in mats) + (8 if bsr else 1)
+        op = pool.assemble(sel, s0, s1)
+        blocks = []
+        for i in sel:
+            P = sp.lil_matrix((s0, s1), dtype=np.float32)
+            P[: mats[i].shape[0], : mats[i].shape[1]] = mats[i]
+            blocks.append(P.tocsr())
+        want = sp.block_diag(blocks, format="csr")
+        want.sort_indices()
+        got = op.to_scipy()
+        assert got.shape == want.shape
+        assert np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+        assert np.array_equal(got.data, want.data)
+        gt, wt = op.t().to_scipy(), want.T.tocsr()
+        wt.sort_indices()
+        assert np.array_equal(gt.indptr, wt.indptr) and np.array_equal(gt.indices, wt.indices) and np.array_equal(gt.data, wt.data)
+        if bsr:
+            bo = c_oracle.csr_to_bsr4(want.indptr, want.indices, want.data)
+            for g_, o_ in zip(op.bsr4(), bo):
+                assert np.array_equal(g_.cpu().numpy(), o_)
+            bt = c_oracle.csr_to_bsr4(wt.indptr, wt.indices, wt.data)
+            for g_, o_ in zip(op.t().bsr4(), bt):
+                assert np.array_equal(g_.cpu().numpy(), o_)
+
+
+def test_elu_kernels():
+    rng = np.random.default_rng(6)
+    x = (rng.standard_normal((333, 128)) * 3).astype(np.float32)
+    x[0, :4] = [0.0, -0.0, 1e-8, -1e-8]
+    cat = torch.zeros((333, 256), device=DEV)
+    kernels.elu_into(dev(x), cat[:, :128])
+    want = c_oracle.elu(x)
+    got = cat[:, :128].cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-7)
+    assert torch.equal(cat[:, 128:], torch.zeros_like(cat[:, 128:]))
+    g = rng.standard_normal((333, 128)).astype(np.float32)
+    acc0 = rng.standard_normal((333, 128)).astype(np.float32)
+    out = torch.empty((333, 128), device=DEV)
+    kernels.elu_bwd(dev(g), dev(want), out, False)
+    assert np.allclose(out.cpu().numpy(), c_oracle.elu_bwd(g, want), rtol=1e-6, atol=1e-7)
+    acc = dev(acc0)
+    kernels.elu_bwd(dev(g), dev(want), acc, True)
+    assert np.allclose(acc.cpu().numpy(), c_oracle.elu_bwd(g, want, acc0), rtol=1e-6, atol=1e-7)
+    # odd channel count takes the scalar kernel
+    x3 = x[:, :7].copy()
+    o3 = torch.empty((333, 7), device=DEV)
+    kernels.elu_into(dev(x3), o3)
+    assert np.allclose(o3.cpu().numpy(), c_oracle.elu(x3), rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("fmt", ["csr", "bsr4"])
+def test_autograd_spmm_forward_backward(fmt):
+    snF.set_dirac_format(fmt)
+    try:
+        _, _, ops = mesh_fixture("cloth")
+        A = ops["DiA"]
+        M, K = A.shape
+        N = 32
+        rng = np.random.default_rng(7)
+        x = rng.standard_normal((K // 4, 4 * N)).astype(np.float32)
+        g = rng.standard_normal((M // 4, 4 * N)).astype(np.float32)
+        xt = dev(x).requires_grad_(True)
+        op = SparseOperator.from_scipy(A, DEV)
+        y = snF.spmm(op, xt, group=4)
+        y.backward(dev(g))
+        want_y = c_oracle.spmm_csr(A.indptr, A.indices, A.data, x.ravel(), N).reshape(M // 4, 4 * N)
+        tr = c_oracle.csr_transpose(A.indptr, A.indices, A.data, K)
+        want_g = c_oracle.spmm_csr(tr[0], tr[1], tr[2], g.ravel(), N).reshape(K // 4, 4 * N)
+        assert np.array_equal(y.detach().cpu().numpy(), want_y)
+        assert np.array_equal(xt.grad.cpu().numpy(), want_g)
+        # same through a torch sparse COO operator (the reference drivers' type), and vs torch.mm on the device
+        coo = A.tocoo()
+        Ac = torch.sparse_coo_tensor(np.stack([coo.row, coo.col]).astype(np.int64), coo.data, A.shape).coalesce().to(DEV)
+        xt2 = dev(x).requires_grad_(True)
+        y2 = snF.spmm(Ac, xt2, group=4)
+        y2.backward(dev(g))
+        assert np.array_equal(y2.detach().cpu().numpy(), want_y) and np.array_equal(xt2.grad.cpu().numpy(), want_g)
+        assert as_operator(Ac) is as_operator(Ac)            # converted once per tensor
+    finally:
+        snF.set_dirac_format("bsr4")
+
+
+def test_cpu_tensors_raise():
+    A = random_csr(8, 8, 0.3, 1)
+    op = SparseOperator.from_scipy(A, "cpu")
+    with pytest.raises(RuntimeError, match="MI355X only"):
+        snF.spmm(op, torch.zeros(8, 4))
+
+
+def test_error_codes():
+    from surfacenetworks_amd import _lib
+
+    lib = _lib.load()
+    y = torch.zeros(4, 16, device=DEV)
+    rp = torch.zeros(5, dtype=torch.int32, device=DEV)
+    assert lib.sn_spmm_csr_f32(None, None, None, 4, 4, 0, y.data_ptr(), 16, 1, 16, y.data_ptr(), 16, 1, None) == -1
+    assert lib.sn_spmm_csr_f32(rp.data_ptr(), None, None, 4, 4, 0, y.data_ptr(), 8, 1, 16, y.data_ptr(), 16, 1, None) == -4
+    assert lib.sn_spmm_csr_f32(rp.data_ptr(), None, None, -1, 4, 0, y.data_ptr(), 16, 1, 16, y.data_ptr(), 16, 1, None) == -2
+    assert lib.sn_spmm_csr_f32(rp.data_ptr(), None, None, 2**31, 4, 0, y.data_ptr(), 16, 1, 16, y.data_ptr(), 16, 1, None) == -3
+    assert lib.sn_bsr4_count(rp.data_ptr(), None, 6, 8, rp.data_ptr(), rp.data_ptr(), 64, None) == -7
+    # empty operator: all-zero output, every element written
+    y.fill_(float("nan"))
+    kernels.spmm_csr(rp, torch.zeros(0, dtype=torch.int32, device=DEV), torch.zeros(0, device=DEV), 4, 4,
+                     torch.ones(4, 16, device=DEV), y, 1)
+    assert torch.equal(y, torch.zeros_like(y))
