@@ -1,0 +1,188 @@
+"""bench.py — headline benchmark of the Surface-Network hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+Workload (BASELINE.json configs[2], the config the metric "meshes/sec fwd+bwd, Dirac temporal-predict" is quoted on):
+as_rigid_as_possible temporal prediction, Dirac model (15 blocks @128 ch, 1 018 872 params), 64 grid-cloth meshes of
+71x71 vertices (V=5041, F=9800) per GPU, fp32, synthetic data, random-init weights.  A step = batch assembly on the
+GPU + forward + masked smooth-L1 loss + backward + flat-bucket RCCL gradient all-reduce (N>1) + Adam update.
+Weak scaling: every rank owns its own 64 meshes (the path shards by mesh; no data-path collective).
+
+The JSON line also carries
+  roofline     the dominant kernel (Dirac SpMM, BSR4 form, N=32 dense columns) timed live with HIP events on the
+               launch stream during the timed steps; achieved = ALGORITHMIC CSR bytes (SURVEY.md §8d:
+               nnz*8 + (M+1)*4 + K*N*4 + M*N*4) / average launch duration; peak = 8 TB/s HBM3E.
+  cpu_baseline the reference's own CPU torch.sparse path (oracle restatement = "port") timed on this box's host cores
+               on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+GRID = (71, 71)            # V = 5041, F = 9800
+MESHES_PER_GPU = 64
+
+
+def alg_bytes(M, K, nnz, N):
+    return nnz * 8 + (M + 1) * 4 + K * N * 4 + M * N * 4
+
+
+def cpu_baseline(sample_meshes: int, seed: int):
+    """The reference path (torch.mm(sparse_coo, dense) + autograd, oracle/ref_blocks.py) on the host cores:
+    one fwd+bwd+Adam step of the same model on `sample_meshes` meshes of the same shape, incl. the reference's
+    per-step host batching (sparse_diag_cat + coalesce)."""
+    from oracle import ref_blocks as OB          # checker/baseline only — never the measured product path
+    from surfacenetworks_amd import mesh_ops
+
+    cores = os.cpu_count() or 1
+    threads = min(cores, 64)
+    torch.set_num_threads(threads)
+    rng = np.random.default_rng(seed)
+    per_mesh = []
+    for _ in range(sample_meshes):
+        V, F_ = mesh_ops.grid_cloth(*GRID, rng)
+        Di, DiA = mesh_ops.dirac(V, F_)
+        per_mesh.append((V.astype(np.float32), Di.astype(np.float32), DiA.astype(np.float32), F_.shape[0]))
+    nv, nf = per_mesh[0][0].shape[0], per_mesh[0][3]
+    model = OB.ArapDirModel().train()
+    opt = torch.optim.Adam(model.parameters(), 1e-3, weight_decay=1e-5)
+    inputs = torch.from_numpy(np.stack([np.concatenate([m[0], m[0]], 1) for m in per_mesh]))
+    targets = torch.zeros(sample_meshes, nv, 120)
+    mask = torch.ones(sample_meshes, nv, 1)
+
+    def step():
+        Di = OB.diag_cat([OB.sp_to_coo(m[1]) for m in per_mesh], 4 * nf, 4 * nv)      # per-step host batching, as the reference
+        DiA = OB.diag_cat([OB.sp_to_coo(m[2]) for m in per_mesh], 4 * nv, 4 * nf)
+        out = model(Di, DiA, mask, inputs)
+        loss = OB.arap_loss(out, targets, mask, sample_meshes)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+
+    step()                                   # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or (time.perf_counter() - t0 < 8.0 and reps < 20):
+        step()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": sample_meshes / dt, "unit": "meshes/s", "cores": threads, "kind": "port",
+            "sample": f"{reps} steps of fwd+bwd+Adam incl. per-step sparse_diag_cat on {sample_meshes} meshes {GRID[0]}x{GRID[1]} "
+                      f"(same model/shape as the GPU workload, 1/{MESHES_PER_GPU // sample_meshes} of the per-GPU batch), "
+                      f"torch {torch.__version__} CPU torch.sparse path, {threads} threads of {cores} logical CPUs"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--meshes", type=int, default=MESHES_PER_GPU, help="meshes per GPU (default: the BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--format", default="bsr4", choices=["bsr4", "csr"])
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+
+    from surfacenetworks_amd import arap, dp
+    from surfacenetworks_amd import functional as snF
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
+    rank, local_rank, world, device = dp.init_distributed()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    snF.set_dirac_format(args.format)
+    torch.manual_seed(1234)
+
+    # ---- data: this rank's shard (own meshes; weak scaling) -----------------------------------------
+    n_local = args.meshes
+    ds = arap.ClothSequences([GRID] * n_local, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 2, op_frames=2,
+                             seed=3 + 1000 * rank, device=device, model="dir")
+    model = arap.DirModel().to(device).train()
+    dp.broadcast_parameters(model, 0)
+    bucket = dp.FlatGradBucket(model.parameters())
+    opt = arap.make_optimizer(model)
+    global_batch = n_local * world
+    rng = np.random.default_rng(10 + rank)
+    seq_ids = np.arange(n_local)
+
+    def one_step():
+        batch = ds.sample_batch(n_local, rng, seq_ids=seq_ids)          # every local mesh once, random start frame
+        return arap.train_step(model, opt, batch, global_batch=global_batch, grad_sync=bucket.all_reduce)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    timer = snF.SpmmTimer()
+    t0 = time.perf_counter()
+    with timer:
+        for _ in range(args.steps):
+            loss = one_step()
+    sync()
+    dt = time.perf_counter() - t0
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt = float(dt_t.item())
+    assert torch.isfinite(loss).item(), "training diverged"
+
+    # ---- roofline of the dominant kernel, from the HIP events recorded during the timed steps ---------
+    recs = timer.results()
+    by = {}
+    for tag, M, K, nnz, N, ms in recs:
+        by.setdefault((tag, M, K, nnz, N), []).append(ms)
+    tot_ms = {k: float(np.sum(v)) for k, v in by.items()}
+    dom = max(tot_ms, key=tot_ms.get)             # the (kernel, shape) with the most accumulated time
+    tag, M, K, nnz, N = dom
+    avg_ms = float(np.mean(by[dom]))
+    ab = alg_bytes(M, K, nnz, N)
+    achieved = ab / (avg_ms * 1e-3)
+    spmm_ms_per_step = sum(tot_ms.values()) / args.steps
+
+    out = {
+        "metric": "meshes/sec fwd+bwd, Dirac temporal-predict",
+        "value": global_batch * args.steps / dt,
+        "unit": "meshes/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"as_rigid_as_possible Dirac temporal prediction: {n_local} grid-cloth meshes {GRID[0]}x{GRID[1]} "
+                               f"(V=5041,F=9800) per GPU, C=128, 15 layers, fwd+loss+bwd+allreduce+Adam",
+                   "meshes_per_gpu": n_local, "global_batch": global_batch, "parallelism": f"dp{world} (mesh sharding, flat-bucket RCCL all-reduce)",
+                   "operator_format": args.format, "grad_bucket_bytes": bucket.nbytes},
+        "roofline": {"bound": "hbm", "kernel": f"spmm_{'bsr4' if 'bsr4' in tag else 'csr'}_v4<32> ({tag}, M={M}, K={K}, nnz={nnz}, N={N})",
+                     "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                     "traffic": None, "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg_ms,
+                     "launches_timed": len(by[dom]), "spmm_ms_per_step_all_kernels": spmm_ms_per_step},
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sample_meshes=4, seed=3)
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -142,3 +142,18 @@ def elu_bwd(gdst, out, gsrc=None):
     g = _c(gsrc, np.float32).copy() if acc else np.empty_like(out)
     lib().oracle_elu_bwd(_p(gdst), i64(Cc), _p(out), i64(Cc), _p(g), i64(Cc), i64(rows), i32(Cc), i32(1 if acc else 0))
     return g
+
+
+# ---- raw-pointer variants (used by tests/cpu_kernels.py to run the product's host logic on CPU tensors) ----------
+def spmm_csr_raw(rowptr, colind, vals, M, x_ptr, ldx, xg, N, y_ptr, ldy, yg):
+    lib().oracle_spmm_csr_f32(_p(rowptr), _p(colind), _p(vals), i64(M), C.c_void_p(x_ptr), i64(ldx), i32(xg), i32(N),
+                              C.c_void_p(y_ptr), i64(ldy), i32(yg))
+
+
+def elu_raw(src_ptr, lds, dst_ptr, ldd, rows, Cc):
+    lib().oracle_elu(C.c_void_p(src_ptr), i64(lds), C.c_void_p(dst_ptr), i64(ldd), i64(rows), i32(Cc))
+
+
+def elu_bwd_raw(g_ptr, ldg, o_ptr, ldo, s_ptr, ldgs, rows, Cc, accumulate):
+    lib().oracle_elu_bwd(C.c_void_p(g_ptr), i64(ldg), C.c_void_p(o_ptr), i64(ldo), C.c_void_p(s_ptr), i64(ldgs),
+                         i64(rows), i32(Cc), i32(1 if accumulate else 0))

@@ -1,0 +1,205 @@
+"""as_rigid_as_possible temporal prediction — the build's counterpart of the reference harness
+(src/as_rigid_as_possible/models.py, main.py): 2 input frames -> 40 predicted frames, 15 residual blocks at
+128 channels (Dirac/Laplacian blocks on even layers, global-average blocks on odd ones), masked smooth-L1 loss.
+
+Model classes keep the reference's names, layer order, widths and `state_dict` keys (conv1.fc.*, rn{i}.bn_fc{0,1}.*,
+conv2.*), so reference checkpoints load.  What differs is the data path: every sequence's
+operators are converted once into device-resident CSR / CSR^T / BSR4 pools (operators.OperatorPool) and a batch is
+assembled on the GPU per step, instead of per-sample scipy->COO conversion, sparse_diag_cat + coalesce on the host
+and an H2D copy of the operators every step (main.py:98-185).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import mesh_ops
+from . import utils_pt as utils
+from .operators import OperatorPool
+
+INPUT_FRAMES = 2       # main.py:105
+OUTPUT_FRAMES = 40     # main.py:106
+
+
+def _num_faces(Di, DiA, batch_size):
+    """models.py:133-136 — works for 3-D batched and 2-D block-diagonal operators."""
+    return DiA.size(2) // 4 if len(Di.size()) == 3 else DiA.size(1) // 4 // batch_size
+
+
+class Model(nn.Module):
+    """Laplacian variant (models.py:21-52)."""
+
+    def __init__(self, layer=15, dense=False):
+        super().__init__()
+        self.conv1 = utils.GraphConv1x1(6, 128, batch_norm=None)
+        self.layer = layer
+        for i in range(layer):
+            if i % 2 == 0:
+                blk = utils.DenseLapResNet2(128) if dense else utils.LapResNet2(128)
+            else:
+                blk = utils.AvgResNet2(128)
+            self.add_module("rn{}".format(i), blk)
+        self.conv2 = utils.GraphConv1x1(128, 120, batch_norm="pre")
+
+    def forward(self, L, mask, inputs):
+        x = self.conv1(inputs)
+        for i in range(self.layer):
+            x = self._modules["rn{}".format(i)](L, mask, x)
+        x = self.conv2(F.elu(x))
+        return x + inputs[:, :, -3:].repeat(1, 1, OUTPUT_FRAMES)
+
+
+class DirModel(nn.Module):
+    """Dirac variant (models.py:108-152): the `metric`'s "Dirac temporal-predict" model, 1 018 872 parameters."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = utils.GraphConv1x1(6, 128, batch_norm=None)
+        for i in range(15):
+            self.add_module("rn{}".format(i), utils.DirResNet2(128) if i % 2 == 0 else utils.AvgResNet2(128))
+        self.do = nn.Dropout2d()          # declared and never applied, as in the reference (models.py:123)
+        self.conv2 = utils.GraphConv1x1(128, 120, batch_norm="pre")
+
+    def forward(self, Di, DiA, mask, inputs):
+        batch_size = inputs.size(0)
+        v = self.conv1(inputs)
+        f = torch.zeros(batch_size, _num_faces(Di, DiA, batch_size), 128, dtype=v.dtype, device=v.device)
+        for i in range(15):
+            blk = self._modules["rn{}".format(i)]
+            if i % 2 == 0:
+                v, f = blk(Di, DiA, v, f)
+            else:
+                v = blk(None, mask, v)
+        x = self.conv2(F.elu(v))
+        return x + inputs[:, :, -3:].repeat(1, 1, OUTPUT_FRAMES)
+
+
+def loss_fn(outputs, targets, mask, batch_size):
+    """Masked smooth-L1, summed, divided by the batch size (main.py:225-226).  Under data parallelism pass the
+    GLOBAL batch size so that the all-reduced (summed) gradients equal the single-process ones."""
+    outputs = outputs * mask.expand_as(outputs)
+    return F.smooth_l1_loss(outputs, targets, reduction="sum") / batch_size
+
+
+def make_optimizer(model):
+    """Adam(lr 1e-3, weight_decay 1e-5), main.py:207."""
+    return torch.optim.Adam(model.parameters(), 1e-3, weight_decay=1e-5)
+
+
+# --------------------------------------------------------------------------------------------------
+# data: synthetic cloth sequences, resident on the GPU
+# --------------------------------------------------------------------------------------------------
+@dataclass
+class Batch:
+    inputs: torch.Tensor      # (B, Vmax, 6)
+    targets: torch.Tensor     # (B, Vmax, 120)
+    mask: torch.Tensor        # (B, Vmax, 1)
+    L: Optional[object]
+    Di: Optional[object]
+    DiA: Optional[object]
+    num_meshes: int
+
+
+class ClothSequences:
+    """Synthetic stand-in for the reference's data_plus/*.npy sequences (as_rigid_as_possible/add_laplacian.py:39-70):
+    each sequence is one grid-cloth mesh whose vertices follow a smooth travelling deformation over `frames` frames;
+    operators are precomputed for the first `op_frames` frames (the reference does it for frames < 10).
+
+    Everything the training loop touches lives in HBM: frame coordinates as one (S, T, Vmax, 3) tensor and the
+    operators in OperatorPools (entry s*op_frames + t is sequence s at frame t)."""
+
+    def __init__(self, grids, frames=50, op_frames=2, seed=3, device="cuda", model="dir", permute=False):
+        rng = np.random.default_rng(seed)
+        self.device = torch.device(device)
+        self.frames, self.op_frames, self.kind = frames, op_frames, model
+        assert frames >= INPUT_FRAMES + OUTPUT_FRAMES + 1 and 1 <= op_frames
+        Vs, Fs, mats = [], [], {"L": [], "Di": [], "DiA": []}
+        coords = []
+        for (n, m) in grids:
+            V0, F_ = mesh_ops.grid_cloth(n, m, rng, permute=permute)
+            amp = 0.03 * (0.5 + rng.random())
+            k = 2 * np.pi * (1 + rng.integers(0, 3))
+            ph = rng.random() * 2 * np.pi
+            t = np.arange(frames)[:, None]
+            disp = amp * np.sin(k * V0[None, :, 0] + 0.25 * t + ph)            # (T, V)
+            Vt = np.repeat(V0[None], frames, 0)
+            Vt[:, :, 2] += disp
+            Vt[:, :, 1] += 0.5 * amp * np.cos(k * V0[None, :, 1] + 0.2 * t)
+            coords.append(Vt.astype(np.float32))
+            Vs.append(V0.shape[0])
+            Fs.append(F_.shape[0])
+            for tf in range(op_frames):
+                if model == "dir":
+                    Di, DiA = mesh_ops.dirac(Vt[tf].astype(np.float64), F_)
+                    mats["Di"].append(Di.astype(np.float32))
+                    mats["DiA"].append(DiA.astype(np.float32))
+                else:
+                    mats["L"].append(mesh_ops.laplacian(Vt[tf].astype(np.float64), F_).astype(np.float32))
+        self.num_vertices = np.array(Vs)
+        self.num_faces = np.array(Fs)
+        self.n = len(grids)
+        vmax = int(self.num_vertices.max())
+        xyz = np.zeros((self.n, frames, vmax, 3), np.float32)
+        for s, c in enumerate(coords):
+            xyz[s, :, : c.shape[1]] = c
+        self.xyz = torch.from_numpy(xyz).to(self.device)
+        self.vcount = torch.from_numpy(self.num_vertices).to(self.device)
+        if model == "dir":
+            self.pool_Di = OperatorPool(mats["Di"], self.device, want_bsr4=True)
+            self.pool_DiA = OperatorPool(mats["DiA"], self.device, want_bsr4=True)
+        else:
+            self.pool_L = OperatorPool(mats["L"], self.device, want_bsr4=False)
+
+    def sample_batch(self, batch_size, rng: np.random.Generator, seq_ids=None, offsets=None) -> Batch:
+        """Counterpart of sample_batch (main.py:98-185): random sequence + random start frame per sample; operator of
+        the last input frame (main.py:156); everything zero-padded to the batch maximum (main.py:126-130)."""
+        if seq_ids is None:
+            seq_ids = rng.integers(0, self.n, size=batch_size)
+        if offsets is None:
+            hi = min(self.op_frames - INPUT_FRAMES + 1, self.frames - INPUT_FRAMES - OUTPUT_FRAMES)
+            offsets = rng.integers(0, max(hi, 1), size=batch_size)
+        seq_ids = np.asarray(seq_ids)
+        offsets = np.asarray(offsets)
+        B = len(seq_ids)
+        nv = int(self.num_vertices[seq_ids].max())
+        nf = int(self.num_faces[seq_ids].max())
+        sid = torch.from_numpy(seq_ids).to(self.device)
+        off = torch.from_numpy(offsets).to(self.device)
+        tt = off[:, None] + torch.arange(INPUT_FRAMES + OUTPUT_FRAMES, device=self.device)[None]     # (B, 42)
+        fr = self.xyz[sid[:, None], tt][:, :, :nv]                                                   # (B, 42, nv, 3)
+        fr = fr.permute(0, 2, 1, 3).reshape(B, nv, (INPUT_FRAMES + OUTPUT_FRAMES) * 3)
+        inputs = fr[:, :, : 3 * INPUT_FRAMES].contiguous()
+        targets = fr[:, :, 3 * INPUT_FRAMES:].contiguous()
+        mask = (torch.arange(nv, device=self.device)[None, :] < self.vcount[sid][:, None]).float().unsqueeze(2)
+        op_ids = seq_ids * self.op_frames + (offsets + INPUT_FRAMES - 1)
+        L = Di = DiA = None
+        if self.kind == "dir":
+            Di = self.pool_Di.assemble(op_ids, 4 * nf, 4 * nv)
+            DiA = self.pool_DiA.assemble(op_ids, 4 * nv, 4 * nf)
+        else:
+            L = self.pool_L.assemble(op_ids, nv, nv)
+        return Batch(inputs, targets, mask, L, Di, DiA, B)
+
+
+def forward_loss(model, batch: Batch, global_batch: Optional[int] = None):
+    if batch.Di is not None:
+        out = model(batch.Di, batch.DiA, batch.mask, batch.inputs)
+    else:
+        out = model(batch.L, batch.mask, batch.inputs)
+    return loss_fn(out, batch.targets, batch.mask, global_batch or batch.num_meshes), out
+
+
+def train_step(model, optimizer, batch: Batch, global_batch: Optional[int] = None, grad_sync=None):
+    """One update (main.py:217-232): forward, masked smooth-L1, backward, [gradient all-reduce], Adam."""
+    loss, _ = forward_loss(model, batch, global_batch)
+    optimizer.zero_grad(set_to_none=False)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    optimizer.step()
+    return loss

@@ -1,0 +1,144 @@
+"""FAUST dense correspondence — counterpart of src/dense_correspondence/models.py and main.py:106-240,310-327.
+
+One tower (`Model`: Laplacian, `DirModel`: Dirac; conv1 3->128, 15 residual blocks at 128 channels, conv2 128->120 plus
+the input coordinates repeated 40x) is applied to both shapes; `SiameseModel` returns bmm(FA, FB^T), a (B, NA, NB)
+score matrix, trained with the argmin-target cross entropy of loss_fun_delta_cross_entropy (main.py:229-240).
+`state_dict` keys match the reference (model.conv1.*, model.rn{i}.*, model.conv2.*).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import mesh_ops
+from . import utils_pt as utils
+from .operators import OperatorPool, SparseOperator
+
+
+class Model(nn.Module):
+    def __init__(self, layer):
+        super().__init__()
+        self.conv1 = utils.GraphConv1x1(3, 128, batch_norm=None)
+        self.layer = layer
+        for i in range(layer):
+            self.add_module("rn{}".format(i), utils.LapResNet2(128) if i % 2 == 0 else utils.AvgResNet2(128))
+        self.conv2 = utils.GraphConv1x1(128, 120, batch_norm="pre")
+
+    def forward(self, L, mask, inputs):
+        x = self.conv1(inputs)
+        for i in range(self.layer):
+            x = self._modules["rn{}".format(i)](L, mask, x)
+        x = self.conv2(F.elu(x))
+        return x + inputs[:, :, -3:].repeat(1, 1, 40)
+
+
+class DirModel(nn.Module):
+    def __init__(self, layer):
+        super().__init__()
+        self.conv1 = utils.GraphConv1x1(3, 128, batch_norm=None)
+        self.layer = layer
+        for i in range(layer):
+            self.add_module("rn{}".format(i), utils.DirResNet2(128) if i % 2 == 0 else utils.AvgResNet2(128))
+        self.do = nn.Dropout2d()
+        self.conv2 = utils.GraphConv1x1(128, 120, batch_norm="pre")
+
+    def forward(self, Di, DiA, mask, inputs):
+        batch_size = inputs.size(0)
+        v = self.conv1(inputs)
+        num_faces = DiA.size(2) // 4 if len(Di.size()) == 3 else DiA.size(1) // 4 // batch_size
+        f = torch.zeros(batch_size, num_faces, 128, dtype=v.dtype, device=v.device)
+        for i in range(self.layer):
+            blk = self._modules["rn{}".format(i)]
+            if i % 2 == 0:
+                v, f = blk(Di, DiA, v, f)
+            else:
+                v = blk(None, mask, v)
+        x = self.conv2(F.elu(v))
+        return x + inputs[:, :, -3:].repeat(1, 1, 40)
+
+
+class SiameseModel(nn.Module):
+    """models.py:184-203."""
+
+    def __init__(self, model="dirac", layer=15):
+        super().__init__()
+        if "dir" in model:
+            self.model = DirModel(layer)
+        elif "lap" in model:
+            self.model = Model(layer)
+        else:
+            raise ValueError("supported towers: 'lap', 'dir'")
+
+    def forward(self, OperationA, OperationB, inputA, inputB):
+        FA = self.model(*OperationA, inputA)
+        FB = self.model(*OperationB, inputB)
+        return torch.bmm(FA, FB.transpose(1, 2))
+
+
+def loss_fun_delta_cross_entropy(outputs, targetX, targetY):
+    """main.py:229-240, including its quirk of always scoring outputs[0] (the reference runs batch 1, main.py:40)."""
+    loss = outputs.new_zeros(1)
+    for i in range(outputs.size(0)):
+        GA, lA, liA = targetX[i]
+        GB, lB, liB = targetY[i]
+        NA, NB = lA.size(0), lB.size(0)
+        _, GAB = torch.min(GA[:, liA[lB]] + GB[liB[lA], :], dim=1)
+        loss = loss + F.cross_entropy(outputs[0, :NA, :NB], GAB)
+    return loss / outputs.size(0)
+
+
+def make_optimizer(model):
+    return torch.optim.Adam(model.parameters(), 1e-3, weight_decay=1e-5)       # main.py:285
+
+
+class TorusBodies:
+    """Synthetic stand-in for the FAUST .npz frames (main.py:65-104): torus-grid meshes (65 x 106 -> 6890 vertices,
+    13 780 faces), padded to 7000 vertices (main.py:193), a random label permutation pair and a synthetic
+    'geodesic' matrix per shape."""
+
+    def __init__(self, count, n=65, m=106, pad_to=7000, seed=4, device="cuda"):
+        rng = np.random.default_rng(seed)
+        self.device = torch.device(device)
+        self.pad_to = pad_to
+        self.frames = []
+        mats = []
+        for _ in range(count):
+            V, F_ = mesh_ops.torus_grid(n, m, rng)
+            nv = V.shape[0]
+            mats.append(mesh_ops.laplacian(V, F_).astype(np.float32))
+            label = rng.permutation(nv)
+            G = torch.from_numpy(V.astype(np.float32)).to(self.device)
+            self.frames.append({
+                "V": torch.from_numpy(V.astype(np.float32)).to(self.device),
+                "label": torch.from_numpy(label).to(self.device),
+                "label_inv": torch.from_numpy(np.argsort(label)).to(self.device),
+                "G": torch.cdist(G, G),                    # synthetic stand-in for dist_mat
+            })
+        self.pool_L = OperatorPool(mats, self.device)
+        self.n = count
+
+    def sample(self, idx):
+        fr = self.frames[idx]
+        nv = fr["V"].shape[0]
+        inputs = torch.zeros(1, self.pad_to, 3, device=self.device)
+        inputs[0, :nv] = fr["V"]
+        mask = torch.zeros(1, self.pad_to, 1, device=self.device)
+        mask[0, :nv] = 1
+        L = self.pool_L.assemble([idx], self.pad_to, self.pad_to)
+        return inputs, [(fr["G"], fr["label"], fr["label_inv"])], mask, L
+
+
+def train_step(model, optimizer, ds: TorusBodies, ia: int, ib: int, grad_sync=None):
+    """main.py:310-327: two independent samples, siamese forward, delta-CE loss, Adam."""
+    inX, tX, mX, LX = ds.sample(ia)
+    inY, tY, mY, LY = ds.sample(ib)
+    out = model([LX, mX], [LY, mY], inX, inY)
+    loss = loss_fun_delta_cross_entropy(out, tX, tY)
+    optimizer.zero_grad(set_to_none=False)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    optimizer.step()
+    return loss

@@ -1,0 +1,131 @@
+"""Data parallelism for the Surface-Network training step: one process per GPU, the mesh batch sharded across ranks,
+ONE RCCL all-reduce per step over a single flat fp32 gradient bucket.
+
+The reference is single-process/single-GPU; this layer is what `north_star` adds.  Design for MI355X:
+  * The batched operator is block-diagonal, so meshes never interact inside SpMM / Linear / ELU: a mesh never spans
+    GPUs and the data path needs NO collective.  Only gradients cross xGMI.
+  * ~1.02 M parameters = 4.08 MB of fp32 gradients per step (ARAP / FAUST towers).  On the fully connected xGMI
+    topology (7 links x ~153 GB/s per GPU) that is latency-bound, so the right shape is one contiguous bucket and
+    one collective — not per-parameter hooks or many small buckets.  Parameter .grad tensors are views into the
+    bucket, so there is no flatten/unflatten copy either.
+  * BatchNorm statistics stay per replica (standard DDP semantics); `sync_batchnorm()` is an opt-in used to show
+    parity with the single-process step at the same global batch.
+  * Loss normalisation uses the GLOBAL batch (arap.loss_fn(..., global_batch)), so a SUM all-reduce of the shard
+    gradients equals the single-process gradient — no averaging pass.
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+__all__ = ["init_distributed", "shard_round_robin", "shard_balanced", "FlatGradBucket", "broadcast_parameters",
+           "sync_batchnorm", "world_info"]
+
+
+def world_info():
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_distributed(backend: Optional[str] = None):
+    """Join the job described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
+    backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests.  Returns (rank, local_rank, world, device)."""
+    rank, local_rank, world = world_info()
+    use_gpu = torch.cuda.is_available() and backend != "gloo"
+    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    if use_gpu:
+        torch.cuda.set_device(device)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {"device_id": device} if use_gpu else {}
+        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world, **kw)
+    return rank, local_rank, world, device
+
+
+def shard_round_robin(n_items: int, rank: int, world: int) -> np.ndarray:
+    """Rank r owns items {i : i mod world == r}."""
+    return np.arange(rank, n_items, world)
+
+
+def shard_balanced(weights: Sequence[float], rank: int, world: int) -> np.ndarray:
+    """Size-balanced bins for ragged batches (e.g. weight = nnz of a mesh): longest-processing-time greedy.
+    Deterministic, identical on every rank."""
+    w = np.asarray(weights, dtype=np.float64)
+    order = np.argsort(-w, kind="stable")
+    load = np.zeros(world)
+    owner = np.empty(len(w), dtype=np.int64)
+    for i in order:
+        r = int(np.argmin(load))
+        owner[i] = r
+        load[r] += w[i]
+    return np.flatnonzero(owner == rank)
+
+
+class FlatGradBucket:
+    """All gradients of a module in one contiguous fp32 buffer; `.grad` of every parameter is a view into it."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev, dt = self.params[0].device, self.params[0].dtype
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=dt, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off: off + n].view_as(p)
+            off += n
+        self._work = None
+
+    @property
+    def nbytes(self) -> int:
+        return self.flat.numel() * self.flat.element_size()
+
+    def zero_(self):
+        self.flat.zero_()
+
+    def check_views(self) -> bool:
+        """True while every .grad still aliases the bucket (optimizer.zero_grad(set_to_none=True) would break it)."""
+        base = self.flat.untyped_storage().data_ptr()
+        return all(p.grad is not None and p.grad.untyped_storage().data_ptr() == base for p in self.params)
+
+    def all_reduce(self, async_op: bool = False):
+        """SUM over ranks (gradients were computed with the loss normalised by the global batch)."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+        return self._work
+
+    def wait(self):
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    """Make every replica start from rank `src`'s parameters and buffers (one flat broadcast per dtype)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    tensors = [t for t in list(module.parameters()) + list(module.buffers())]
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dt, ts in by_dtype.items():
+        flat = torch.cat([t.detach().reshape(-1) for t in ts])
+        dist.broadcast(flat, src)
+        off = 0
+        with torch.no_grad():
+            for t in ts:
+                t.copy_(flat[off: off + t.numel()].view_as(t))
+                off += t.numel()
+
+
+def sync_batchnorm(module: torch.nn.Module) -> torch.nn.Module:
+    """Opt-in: replace BatchNorm1d by SyncBatchNorm (all-reduce of per-channel sums) so that N replicas reproduce
+    the single-process statistics at the same global batch.  GPU/RCCL only."""
+    return torch.nn.SyncBatchNorm.convert_sync_batchnorm(module)

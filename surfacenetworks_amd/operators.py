@@ -166,9 +166,6 @@ def as_operator(A) -> SparseOperator:
     if isinstance(A, torch.Tensor) and A.layout == torch.sparse_coo:
         cached = getattr(A, "_sn_operator", None)
         if cached is None:
-            if not A.is_cuda:
-                raise RuntimeError("surfacenetworks_amd operators live on the GPU: call .cuda() on the sparse operator "
-                                   "(there is no CPU path; the reference's CPU torch.sparse path is in oracle/).")
             cached = SparseOperator.from_torch_coo(A)
             A._sn_operator = cached
         return cached

@@ -25,3 +25,12 @@ def _built():
     import __graft_entry__ as g
 
     g.build()
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    """Run the product's host logic on CPU tensors with oracle-backed kernels (test-only seam)."""
+    import cpu_kernels as ck
+
+    ck.install(monkeypatch)
+    return ck

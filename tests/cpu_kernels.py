@@ -1,0 +1,77 @@
+"""TEST-ONLY: oracle-backed stand-ins for surfacenetworks_amd.kernels so that the product's HOST logic (autograd
+Functions, modules, samplers, data-parallel layer) can be exercised on CPU tensors in this GPU-less container.
+Installed with pytest's monkeypatch (see the `cpu_kernels` fixture in conftest.py); never imported by the package."""
+import numpy as np
+import torch
+
+from oracle import c_oracle
+
+
+def _np(t):
+    return t.detach().cpu().numpy()
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], 1)
+
+
+def spmm_csr(rowptr, colind, vals, M, K, x, y, group=1):
+    N = y.shape[1] // group
+    assert x.stride(1) == 1 and y.stride(1) == 1
+    c_oracle.spmm_csr_raw(_np(rowptr), _np(colind), _np(vals), M, x.data_ptr(), _ld(x), group, N, y.data_ptr(), _ld(y), group)
+
+
+def spmm_bsr4(b_rowptr, b_colind, b_vals, Mb, Kb, x, y, group=1):
+    # expand the blocks back to CSR (explicit zeros kept) and reuse the CSR oracle: same arithmetic order
+    brp, bci, bv = _np(b_rowptr), _np(b_colind), _np(b_vals).reshape(-1, 4, 4)
+    counts = np.diff(brp)
+    rowptr = np.zeros(4 * Mb + 1, np.int32)
+    rowptr[1:] = np.cumsum(np.repeat(counts * 4, 4))
+    colind = np.empty(rowptr[-1], np.int32)
+    vals = np.empty(rowptr[-1], np.float32)
+    for br in range(Mb):
+        blk = slice(brp[br], brp[br + 1])
+        for q in range(4):
+            dst = slice(rowptr[4 * br + q], rowptr[4 * br + q + 1])
+            colind[dst] = (4 * bci[blk, None] + np.arange(4)[None]).ravel()
+            vals[dst] = bv[blk, q, :].ravel()
+    spmm_csr(torch.from_numpy(rowptr), torch.from_numpy(colind), torch.from_numpy(vals), 4 * Mb, 4 * Kb, x, y, group)
+
+
+def coo_to_csr(idx_batch, idx_row, idx_col, B, R, Kb):
+    rp, ci = c_oracle.coo_to_csr(None if idx_batch is None else _np(idx_batch), _np(idx_row), _np(idx_col), B, R, Kb)
+    return torch.from_numpy(rp), torch.from_numpy(ci)
+
+
+def csr_transpose(rowptr, colind, vals, M, K):
+    return tuple(torch.from_numpy(a) for a in c_oracle.csr_transpose(_np(rowptr), _np(colind), _np(vals), K))
+
+
+def csr_to_bsr4(rowptr, colind, vals, M, K):
+    return tuple(torch.from_numpy(a) for a in c_oracle.csr_to_bsr4(_np(rowptr), _np(colind), _np(vals)))
+
+
+def blockdiag_concat(pool_rowptr, pool_colind, pool_vals, desc, size0, size1, total, vpe=1):
+    out = c_oracle.blockdiag_concat(_np(pool_rowptr), _np(pool_colind), _np(pool_vals), _np(desc), size0, size1, total, vpe)
+    return tuple(torch.from_numpy(a) for a in out)
+
+
+def elu_into(src, dst):
+    c_oracle.elu_raw(src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst), src.shape[0], src.shape[1])
+
+
+def elu_bwd(gdst, out, gsrc, accumulate):
+    c_oracle.elu_bwd_raw(gdst.data_ptr(), _ld(gdst), out.data_ptr(), _ld(out), gsrc.data_ptr(), _ld(gsrc), out.shape[0],
+                         out.shape[1], accumulate)
+
+
+def install(monkeypatch=None):
+    """Patch surfacenetworks_amd.kernels in place (monkeypatch=None: permanent, for spawned worker processes)."""
+    from surfacenetworks_amd import kernels
+
+    for name in kernels.__all__:
+        fn = globals()[name]
+        if monkeypatch is not None:
+            monkeypatch.setattr(kernels, name, fn)
+        else:
+            setattr(kernels, name, fn)

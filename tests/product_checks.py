@@ -1,0 +1,299 @@
+"""Checks of the PRODUCT modules against the reference-generated golden fixtures, parametrised by device so that the
+CPU suite (oracle-backed kernels) and the GPU suite (real HIP kernels) run the very same assertions."""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from helpers import deterministic_init, det_tensor, grad_signature, rel_err, sigs_close
+from oracle import ref_blocks as OB
+
+# Model-level criterion.  The deep fixtures are ill-conditioned in fp32 (perturbing the INPUT of the reference ARAP model
+# by 1e-7 relative moves its conv1 gradient by 2.4e-3; the Laplacian has entries up to 3e4 with rows summing to 0), so a
+# fixed tolerance against the reference's fp32 numbers would either be vacuous or flaky.  Instead the exact answer is
+# computed with the oracle in fp64 and the product must be as close to it as the reference's own fp32 run is:
+#     err(product, fp64) <= SLACK * err(reference_fp32, fp64) + FLOOR.
+# The tight fixed bar (1e-5 relative) is held at block level (check_block) and bit-exactness at kernel level.
+SLACK, FLOOR = 4.0, 2e-6
+
+
+def _sig_err(sigs, ref64):
+    """Largest deviation of any gradient signature from the fp64 one, relative to the largest gradient norm."""
+    top = max(abs(float(ref64[k][0])) for k in ref64)
+    return max(float(np.abs(np.asarray(sigs[k]) - ref64[k]).max()) for k in ref64) / top
+
+
+def _as_close_as_reference(name, prod, ref32, truth64):
+    e_prod, e_ref = rel_err(prod, truth64), rel_err(ref32, truth64)
+    assert e_prod <= SLACK * e_ref + FLOOR, (name, "product err", e_prod, "reference fp32 err", e_ref)
+
+
+BLOCKS = [("LapResNet2", 64), ("LapResNet2", 128), ("DirResNet2", 64), ("DirResNet2", 128), ("AvgResNet2", 128),
+          ("MlpResNet2", 128)]
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def csr_of(z, k):
+    return sp.csr_matrix((z[f"{k}_data"], z[f"{k}_indices"], z[f"{k}_indptr"]), shape=tuple(z[f"{k}_shape"]))
+
+
+def batch_operators(golden_dir, opkind, dev):
+    """The ragged fixture batch (cube, delaunay150, delaunay60) as operators of the requested kind on `dev`."""
+    from surfacenetworks_amd.operators import OperatorPool
+
+    rb = load(golden_dir, "ragged_batch.npz")
+    order = [str(s) for s in rb["order"]]
+    nv, nf = int(rb["nv"]), int(rb["nf"])
+    ops = {}
+    for k, (s0, s1) in {"L": (nv, nv), "Di": (4 * nf, 4 * nv), "DiA": (4 * nv, 4 * nf)}.items():
+        if opkind == "pool":
+            mats = [csr_of(load(golden_dir, f"ops_{m}.npz"), k) for m in order]
+            ops[k] = OperatorPool(mats, dev, want_bsr4=(k != "L")).assemble(np.arange(len(order)), s0, s1)
+        else:
+            key = "bd" if opkind == "coo2d" else "3d"
+            ops[k] = torch.sparse_coo_tensor(torch.from_numpy(rb[f"{k}_{key}_indices"]), torch.from_numpy(rb[f"{k}_{key}_values"]),
+                                             tuple(rb[f"{k}_{key}_shape"])).coalesce().to(dev)
+    return rb, ops
+
+
+def check_block(golden_dir, cname, C, opkind, dev, tol=1e-5):
+    import surfacenetworks_amd.utils_pt as U
+
+    rb, ops = batch_operators(golden_dir, opkind, dev)
+    g = load(golden_dir, "blocks_reference.npz")
+    B, nv, nf = rb["mask"].shape[0], int(rb["nv"]), int(rb["nf"])
+    mask = torch.from_numpy(rb["mask"]).to(dev)
+    tag = f"{cname}{C}"
+    mod = deterministic_init(getattr(U, cname)(C), seed=C + len(cname)).train().to(dev)
+    v = torch.from_numpy(det_tensor((B, nv, C), 11 + C, 1.0) * rb["mask"]).to(dev).requires_grad_(True)
+    if cname == "DirResNet2":
+        f = torch.from_numpy(det_tensor((B, nf, C), 12 + C, 1.0)).to(dev).requires_grad_(True)
+        outs, gin = mod(ops["Di"], ops["DiA"], v, f), [v, f]
+    else:
+        outs, gin = (mod(ops["L"], mask, v),), [v]
+    loss = sum((o * torch.from_numpy(det_tensor(tuple(o.shape), s)).to(dev)).sum() for o, s in zip(outs, [21, 22]))
+    loss.backward()
+    for i, o in enumerate(outs):
+        assert rel_err(o.detach().cpu().numpy(), g[f"{tag}_out{i}"]) <= tol, (tag, i, rel_err(o.detach().cpu().numpy(), g[f"{tag}_out{i}"]))
+    for i, t in enumerate(gin):
+        assert rel_err(t.grad.cpu().numpy(), g[f"{tag}_gin{i}"]) <= tol, (tag, "gin", i, rel_err(t.grad.cpu().numpy(), g[f"{tag}_gin{i}"]))
+    assert not sigs_close(grad_signature(mod), lambda k: g[f"{tag}_psig_{k}"])
+    for k, t in mod.state_dict().items():
+        if "running" in k:
+            assert rel_err(t.cpu().numpy(), g[f"{tag}_{k}"]) <= 1e-5, (k, rel_err(t.cpu().numpy(), g[f"{tag}_{k}"]))
+
+
+def _bn_train_only(m):
+    m.eval()
+    for mod in m.modules():
+        if "BatchNorm" in mod.__class__.__name__:
+            mod.train()
+    return m
+
+
+def check_model(golden_dir, tag, dev, opkind="pool", tol_out=5e-5):
+    from surfacenetworks_amd import arap, dense_correspondence, mesh_mnist
+    from surfacenetworks_amd.operators import OperatorPool
+
+    g = load(golden_dir, "models_reference.npz")
+    if tag == "faust_lap":
+        rb = load(golden_dir, "ragged_batch.npz")
+        nv = int(rb["nv"])
+        L = csr_of(load(golden_dir, "ops_delaunay150.npz"), "L")
+        L1 = OperatorPool([L], dev).assemble([0], nv, nv)
+        lA, lB = torch.from_numpy(g["faust_lA"]).to(dev), torch.from_numpy(g["faust_lB"]).to(dev)
+        tX = [(torch.from_numpy(g["faust_GA"]).to(dev), lA, torch.argsort(lA))]
+        tY = [(torch.from_numpy(g["faust_GB"]).to(dev), lB, torch.argsort(lB))]
+        cA = torch.from_numpy(rb["coords"][1:2]).to(dev)
+        cB = torch.from_numpy(rb["coords"][1:2] * 1.1 + 0.02).to(dev)
+        mask = torch.from_numpy(rb["mask"][1:2]).to(dev)
+        m = deterministic_init(dense_correspondence.SiameseModel("lap", 15), 11).train().to(dev)
+        out = m([L1, mask], [L1, mask], cA, cB)
+        loss = dense_correspondence.loss_fun_delta_cross_entropy(out, tX, tY)
+        loss.backward()
+        L64 = OB.diag_cat([OB.sp_to_coo(L.astype(np.float64))], nv, nv)
+        m64 = deterministic_init(OB.SiameseModel("lap", 15), 11).train().double()
+        c = lambda x: x.detach().cpu().double()
+        out64 = m64([L64, c(mask)], [L64, c(mask)], c(cA), c(cB))
+        loss64 = OB.delta_cross_entropy(out64, [(c(tX[0][0]), tX[0][1].cpu(), tX[0][2].cpu())], [(c(tY[0][0]), tY[0][1].cpu(), tY[0][2].cpu())])
+        loss64.backward()
+        s64 = grad_signature(m64)
+        _as_close_as_reference("faust loss", loss.item(), float(g["faust_lap_loss"]), loss64.item())
+        _as_close_as_reference("faust out", out.detach().cpu().numpy()[0, ::7, ::7], g["faust_lap_out_sample"], out64.detach().numpy()[0, ::7, ::7])
+        e_prod = _sig_err(grad_signature(m), s64)
+        e_ref = _sig_err({k: g[f"faust_lap_psig_{k}"] for k in s64}, s64)
+        assert e_prod <= SLACK * e_ref + FLOOR, ("faust grad", e_prod, e_ref)
+        return
+    rb, ops = batch_operators(golden_dir, opkind, dev)
+    mask = torch.from_numpy(rb["mask"]).to(dev)
+    B = mask.shape[0]
+    t = lambda a: torch.from_numpy(a).to(dev)
+    if tag == "arap_dir":
+        m = deterministic_init(arap.DirModel(), 7).train().to(dev)
+        out = m(ops["Di"], ops["DiA"], mask, t(g["inputs6"]))
+        loss = arap.loss_fn(out, t(g["targets"]), mask, B)
+    elif tag == "arap_lap":
+        m = deterministic_init(arap.Model(15), 8).train().to(dev)
+        out = m(ops["L"], mask, t(g["inputs6"]))
+        loss = arap.loss_fn(out, t(g["targets"]), mask, B)
+    elif tag == "mnist_lap":
+        m = _bn_train_only(deterministic_init(mesh_mnist.Model(), 9)).to(dev)
+        out = m(t(rb["coords"]), ops["L"], mask)
+        loss = torch.nn.functional.nll_loss(out, t(g["labels"]))
+    elif tag == "mnist_dir":
+        m = _bn_train_only(deterministic_init(mesh_mnist.DirModel(), 10)).to(dev)
+        out = m(t(rb["coords"]), ops["Di"], ops["DiA"], mask)
+        loss = torch.nn.functional.nll_loss(out, t(g["labels"]))
+    else:
+        raise KeyError(tag)
+    loss.backward()
+    l64, o64, s64 = _oracle_fp64(golden_dir, tag, rb, g)
+    _as_close_as_reference(tag + " loss", loss.item(), float(g[f"{tag}_loss"]), l64)
+    _as_close_as_reference(tag + " out", out.detach().cpu().numpy(), g[f"{tag}_out"], o64)
+    ref_sig = {k: g[f"{tag}_psig_{k}"] for k in s64}
+    e_prod, e_ref = _sig_err(grad_signature(m), s64), _sig_err(ref_sig, s64)
+    assert e_prod <= SLACK * e_ref + FLOOR, (tag, "grad: product err", e_prod, "reference fp32 err", e_ref)
+
+
+def _oracle_fp64(golden_dir, tag, rb, g):
+    """The exact answer: the oracle restatement of the reference model run in float64 on the CPU."""
+    ops = {}
+    for k in ("L", "Di", "DiA"):
+        ops[k] = torch.sparse_coo_tensor(torch.from_numpy(rb[f"{k}_bd_indices"]), torch.from_numpy(rb[f"{k}_bd_values"]).double(),
+                                         tuple(rb[f"{k}_bd_shape"])).coalesce()
+    mask = torch.from_numpy(rb["mask"]).double()
+    B = mask.shape[0]
+    d = lambda a: torch.from_numpy(a).double()
+    if tag == "arap_dir":
+        m = deterministic_init(OB.ArapDirModel(), 7).train().double()
+        out = m(ops["Di"], ops["DiA"], mask, d(g["inputs6"]))
+        loss = OB.arap_loss(out, d(g["targets"]), mask, B)
+    elif tag == "arap_lap":
+        m = deterministic_init(OB.ArapLapModel(15), 8).train().double()
+        out = m(ops["L"], mask, d(g["inputs6"]))
+        loss = OB.arap_loss(out, d(g["targets"]), mask, B)
+    elif tag == "mnist_lap":
+        m = _bn_train_only(deterministic_init(OB.MnistLapModel(), 9)).double()
+        out = m(d(rb["coords"]), ops["L"], mask)
+        loss = torch.nn.functional.nll_loss(out, torch.from_numpy(g["labels"]))
+    else:
+        m = _bn_train_only(deterministic_init(OB.MnistDirModel(), 10)).double()
+        out = m(d(rb["coords"]), ops["Di"], ops["DiA"], mask)
+        loss = torch.nn.functional.nll_loss(out, torch.from_numpy(g["labels"]))
+    loss.backward()
+    return loss.item(), out.detach().numpy(), grad_signature(m)
+
+
+def check_cat_functions(golden_dir):
+    """utils_pt.sparse_diag_cat / sparse_cat / sp_sparse_to_pt_sparse reproduce the reference's outputs exactly."""
+    import surfacenetworks_amd.utils_pt as U
+
+    rb = load(golden_dir, "ragged_batch.npz")
+    order = [str(s) for s in rb["order"]]
+    nv, nf = int(rb["nv"]), int(rb["nf"])
+    for k, (s0, s1) in {"L": (nv, nv), "Di": (4 * nf, 4 * nv), "DiA": (4 * nv, 4 * nf)}.items():
+        parts = [U.sp_sparse_to_pt_sparse(csr_of(load(golden_dir, f"ops_{m}.npz"), k)) for m in order]
+        assert parts[0].dtype == torch.float32 and not parts[0].is_coalesced()
+        bd, b3 = U.sparse_diag_cat(parts, s0, s1), U.sparse_cat(parts, s0, s1)
+        assert np.array_equal(bd._indices().numpy(), rb[f"{k}_bd_indices"]) and np.array_equal(bd._values().numpy(), rb[f"{k}_bd_values"])
+        assert tuple(bd.shape) == tuple(rb[f"{k}_bd_shape"])
+        assert np.array_equal(b3._indices().numpy(), rb[f"{k}_3d_indices"]) and np.array_equal(b3._values().numpy(), rb[f"{k}_3d_values"])
+        assert tuple(b3.shape) == tuple(rb[f"{k}_3d_shape"])
+    dense = U.to_dense_batched(parts[0], 2)
+    assert dense.shape[0] == 2 and torch.equal(dense[0], parts[0].to_dense())
+
+
+def check_spmm_autograd(dev):
+    """spmm() and SparseBMMFunc: forward vs dense fp64, backward = A^T g, no grad to the operator."""
+    import surfacenetworks_amd.utils_pt as U
+    from helpers import mesh_fixture
+    from surfacenetworks_amd import functional as snF
+    from surfacenetworks_amd.operators import SparseOperator
+
+    _, _, ops = mesh_fixture("cloth")
+    for name, group, N in [("L", 1, 24), ("Di", 4, 16), ("DiA", 4, 32)]:
+        A = ops[name]
+        M, K = A.shape
+        rng = np.random.default_rng(3)
+        x = rng.standard_normal((K // group, group * N)).astype(np.float32)
+        gy = rng.standard_normal((M // group, group * N)).astype(np.float32)
+        xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+        y = snF.spmm(SparseOperator.from_scipy(A, dev), xt, group)
+        y.backward(torch.from_numpy(gy).to(dev))
+        A64 = A.astype(np.float64)
+        assert rel_err(y.detach().cpu().numpy().reshape(M, N), A64 @ x.reshape(K, N).astype(np.float64)) < 1e-6
+        assert rel_err(xt.grad.cpu().numpy().reshape(K, N), A64.T @ gy.reshape(M, N).astype(np.float64)) < 1e-6
+    # 3-D batched call shape of the reference: SparseBMMFunc()(A3d, X3d)
+    A = ops["Di"].tocoo()
+    B = 2
+    idx = np.stack([np.repeat(np.arange(B), A.nnz), np.tile(A.row, B), np.tile(A.col, B)]).astype(np.int64)
+    A3 = torch.sparse_coo_tensor(torch.from_numpy(idx), torch.from_numpy(np.tile(A.data, B)), (B,) + A.shape).coalesce().to(dev)
+    X3 = torch.from_numpy(np.random.default_rng(4).standard_normal((B, A.shape[1], 16)).astype(np.float32)).to(dev).requires_grad_(True)
+    Y3 = U.SparseBMMFunc()(A3, X3)
+    assert Y3.shape == (B, A.shape[0], 16)
+    Y3.sum().backward()
+    want = np.stack([ops["Di"].astype(np.float64) @ X3.detach().cpu().numpy()[b].astype(np.float64) for b in range(B)])
+    assert rel_err(Y3.detach().cpu().numpy(), want) < 1e-6
+    colsum = np.asarray(ops["Di"].astype(np.float64).sum(axis=0)).ravel()
+    assert rel_err(X3.grad.cpu().numpy()[0][:, 0], colsum) < 1e-5
+
+
+def check_arap_sampler(dev):
+    """ClothSequences.sample_batch == the reference's sample_batch semantics: padded tensors + block-diag operators
+    equal to sparse_diag_cat of the per-sample operators."""
+    from surfacenetworks_amd import arap, mesh_ops
+
+    ds = arap.ClothSequences([(7, 6), (9, 8), (5, 5)], frames=45, op_frames=3, seed=1, device=dev, model="dir")
+    rng = np.random.default_rng(0)
+    seq_ids, offsets = np.array([1, 0, 2, 1]), np.array([0, 1, 1, 1])
+    b = ds.sample_batch(4, rng, seq_ids=seq_ids, offsets=offsets)
+    nv, nf = 72, int(ds.num_faces.max())
+    assert b.inputs.shape == (4, nv, 6) and b.targets.shape == (4, nv, 120) and b.mask.shape == (4, nv, 1)
+    xyz = ds.xyz.cpu().numpy()
+    for i, (s, o) in enumerate(zip(seq_ids, offsets)):
+        n = ds.num_vertices[s]
+        for fr in range(2):
+            assert np.array_equal(b.inputs[i, :n, 3 * fr: 3 * fr + 3].cpu().numpy(), xyz[s, o + fr, :n])
+        for fr in range(40):
+            assert np.array_equal(b.targets[i, :n, 3 * fr: 3 * fr + 3].cpu().numpy(), xyz[s, o + 2 + fr, :n])
+        assert b.mask[i, :n].sum() == n and b.mask[i, n:].sum() == 0 and b.inputs[i, n:].abs().sum() == 0
+    # operators: frame offset+1 of each sequence (main.py:156), padded block-diagonal
+    blocks = []
+    for s, o in zip(seq_ids, offsets):
+        n, m = [(7, 6), (9, 8), (5, 5)][s]
+        F_ = mesh_ops._grid_faces(n, m, False)
+        Di, _ = mesh_ops.dirac(xyz[s, o + 1, : ds.num_vertices[s]].astype(np.float64), F_)
+        P = sp.lil_matrix((4 * nf, 4 * nv), dtype=np.float32)
+        P[: Di.shape[0], : Di.shape[1]] = Di.astype(np.float32)
+        blocks.append(P.tocsr())
+    want = sp.block_diag(blocks, format="csr")
+    got = b.Di.to_scipy()
+    # operators are built from the fp64 frame coordinates (as the reference does from its .obj files), the test rebuilds
+    # them from the stored fp32 coordinates: same pattern, values equal to fp32 round-off of the coordinates
+    assert got.shape == want.shape and np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+    assert abs(got - want).max() <= 1e-4 * abs(want).max()
+    assert b.DiA.shape == (4 * 4 * nv, 4 * 4 * nf)
+    m = arap.DirModel().to(dev)
+    loss, out = arap.forward_loss(m, b)
+    assert out.shape == (4, nv, 120) and torch.isfinite(loss)
+
+
+def check_mnist_sampler(dev):
+    from surfacenetworks_amd import mesh_mnist
+
+    ds = mesh_mnist.MeshDigits(6, seed=2, device=dev, vmin=20, vmax=40, model="lap")
+    rng = np.random.default_rng(0)
+    order = np.argsort(ds.nv)
+    b1 = ds.sample_batch(2, rng, ids=order[:2])
+    b2 = ds.sample_batch(2, rng, ids=order[-2:])
+    b3 = ds.sample_batch(2, rng, ids=order[:2])
+    assert b1.inputs.shape[1] == ds.nv[order[1]] and b2.inputs.shape[1] == ds.nv.max()
+    assert b3.inputs.shape[1] == ds.nv.max()          # running maximum, as mesh_mnist/main.py:83-84,119-120
+    assert b3.L.shape == (2 * ds.nv.max(), 2 * ds.nv.max())
+    m = mesh_mnist.Model().to(dev)
+    loss, out = mesh_mnist.forward_loss(m, b3)
+    assert out.shape == (2, 10) and torch.isfinite(loss)

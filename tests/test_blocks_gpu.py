@@ -1,0 +1,117 @@
+"""GPU parity of the product blocks / models / samplers (real HIP kernels through the C-ABI) against the
+reference-generated golden fixtures and the fp64 oracle: the same assertions as tests/test_product_host.py."""
+import numpy as np
+import pytest
+import torch
+
+import product_checks as pc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.mark.parametrize("fmt", ["bsr4", "csr"])
+@pytest.mark.parametrize("cname,C", pc.BLOCKS)
+@pytest.mark.parametrize("opkind", ["pool", "coo2d", "coo3d"])
+def test_blocks_match_reference(golden_dir, cname, C, opkind, fmt):
+    from surfacenetworks_amd import functional as snF
+
+    if cname in ("AvgResNet2", "MlpResNet2") and (opkind != "pool" or fmt != "bsr4"):
+        pytest.skip("no sparse operator in this block")
+    if cname == "LapResNet2" and fmt != "bsr4":
+        pytest.skip("format switch only affects Dirac blocks")
+    snF.set_dirac_format(fmt)
+    try:
+        pc.check_block(golden_dir, cname, C, opkind, DEV)
+    finally:
+        snF.set_dirac_format("bsr4")
+
+
+@pytest.mark.parametrize("tag", ["arap_dir", "arap_lap", "mnist_lap", "mnist_dir", "faust_lap"])
+def test_models_match_reference(golden_dir, tag):
+    pc.check_model(golden_dir, tag, DEV)
+
+
+@pytest.mark.parametrize("tag", ["arap_dir", "mnist_dir"])
+def test_models_with_reference_driver_operator_types(golden_dir, tag):
+    """Same models fed with the torch sparse COO operators the reference drivers build (2-D block-diag)."""
+    pc.check_model(golden_dir, tag, DEV, opkind="coo2d")
+
+
+def test_unfused_spmm_function():
+    pc.check_spmm_autograd(DEV)
+
+
+def test_arap_sampler():
+    pc.check_arap_sampler(DEV)
+
+
+def test_mnist_sampler():
+    pc.check_mnist_sampler(DEV)
+
+
+def test_fused_block_equals_unfused_composition(golden_dir):
+    """DirResNet2 (fused stages) == the same block composed from F.elu + spmm() + torch.cat, forward and backward."""
+    import torch.nn.functional as F
+
+    import surfacenetworks_amd.utils_pt as U
+    from helpers import deterministic_init, det_tensor, rel_err
+    from surfacenetworks_amd import functional as snF
+
+    rb, ops = pc.batch_operators(golden_dir, "pool", DEV)
+    B, nv, nf, C = rb["mask"].shape[0], int(rb["nv"]), int(rb["nf"]), 128
+    blk = deterministic_init(U.DirResNet2(C), 5).train().to(DEV)
+    res = []
+    for fused in (True, False):
+        blk.zero_grad()
+        v = torch.from_numpy(det_tensor((B, nv, C), 1) * rb["mask"]).to(DEV).requires_grad_(True)
+        f = torch.from_numpy(det_tensor((B, nf, C), 2)).to(DEV).requires_grad_(True)
+        if fused:
+            vo, fo = blk(ops["Di"], ops["DiA"], v, f)
+        else:
+            x_in, f_in = F.elu(v), F.elu(f)
+            y = snF.spmm(ops["Di"], x_in.reshape(B * nv, C), 4).view(B, nf, C)
+            fo = blk.bn_fc0(torch.cat([f_in, y], 2))
+            z = snF.spmm(ops["DiA"], F.elu(fo).reshape(B * nf, C), 4).view(B, nv, C)
+            vo = v + blk.bn_fc1(torch.cat([x_in, z], 2))
+        (vo.sum() + (fo * fo).sum()).backward()
+        res.append([t.detach().cpu().numpy() for t in (vo, fo, v.grad, f.grad, blk.bn_fc0.fc.weight.grad)])
+    for a, b in zip(*res):
+        assert rel_err(a, b) < 2e-6
+
+
+def test_size_independent_properties_at_config_scale():
+    """BASELINE config-3 scale (64 cloth meshes of 71x71, C=128): linearity, adjoint identity <A x, g> == <x, A^T g>,
+    CSR == BSR4 bit-for-bit, block-diagonal independence of the meshes."""
+    from surfacenetworks_amd import functional as snF, kernels, mesh_ops
+    from surfacenetworks_amd.operators import OperatorPool
+
+    rng = np.random.default_rng(3)
+    mats = []
+    for _ in range(4):
+        V, F_ = mesh_ops.grid_cloth(71, 71, rng)
+        mats.append(mesh_ops.dirac(V, F_)[0].astype(np.float32))
+    pool = OperatorPool(mats, DEV, want_bsr4=True)
+    sel = np.arange(64) % 4
+    op = pool.assemble(sel, mats[0].shape[0], mats[0].shape[1])
+    M, K = op.shape
+    assert (M, K) == (64 * 39200, 64 * 20164)
+    N = 32
+    g = torch.Generator(device=DEV).manual_seed(0)
+    x1 = torch.randn(K // 4, 4 * N, device=DEV, generator=g)
+    x2 = torch.randn(K // 4, 4 * N, device=DEV, generator=g)
+    gy = torch.randn(M // 4, 4 * N, device=DEV, generator=g)
+    y1, y2, y12 = snF.spmm(op, x1, 4), snF.spmm(op, x2, 4), snF.spmm(op, x1 + 2 * x2, 4)
+    assert ((y12 - (y1 + 2 * y2)).abs().max() / y12.abs().max()).item() < 1e-5
+    gx = snF.spmm(op.t(), gy, 4)
+    lhs, rhs = (y1.double() * gy.double()).sum().item(), (x1.double() * gx.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0) * 100
+    yc = torch.empty_like(y1)
+    kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x1, yc, 4)
+    assert torch.equal(yc, y1)                                 # y1 came from the BSR4 kernel
+    # mesh b of the batch only sees its own slice of x: same mesh + same slice => identical rows
+    rows = M // 4 // 64
+    xs = x1.clone()
+    xs[4 * (K // 4 // 64): 5 * (K // 4 // 64)] = x1[: K // 4 // 64]
+    ys = snF.spmm(op, xs, 4)
+    assert torch.equal(ys[4 * rows: 5 * rows], y1[:rows]) and torch.equal(ys[:rows], y1[:rows])

@@ -1,0 +1,124 @@
+"""Data-parallel layer on CPU: world_size 2 over gloo (the N>1 path of bench.py / the trainers, minus RCCL).
+Kernels are the oracle-backed test stand-ins (tests/cpu_kernels.py); what is under test is the host logic of
+surfacenetworks_amd.dp: sharding, flat gradient bucket, SUM all-reduce with global-batch loss normalisation,
+parameter broadcast — and the property SURVEY.md §8e asks for: sum of shard gradients == full-batch gradient."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    import cpu_kernels
+
+    cpu_kernels.install()
+    from helpers import deterministic_init
+    from surfacenetworks_amd import arap, dp
+
+    r, lr, w, dev = dp.init_distributed("gloo")
+    assert (r, w, dev.type) == (rank, world, "cpu")
+    ds = arap.ClothSequences([(6, 5), (7, 7), (5, 6), (8, 5)], frames=44, op_frames=2, seed=5, device="cpu", model="dir")
+    G = 4                                                     # global batch: one sample of every sequence
+    seq, off = np.arange(G), np.zeros(G, dtype=np.int64)
+
+    def make_model(seed):
+        m = deterministic_init(arap.DirModel(), seed)
+        m.eval()                                              # BN frozen: shards are then exactly additive
+        return m
+
+    # rank-dependent init, then broadcast from rank 0 -> identical replicas
+    model = make_model(3 + rank)
+    dp.broadcast_parameters(model, 0)
+    ref = make_model(3)
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a, b), k
+
+    bucket = dp.FlatGradBucket(model.parameters())
+    assert bucket.nbytes == 4 * 1018872 and bucket.check_views()
+    mine = dp.shard_round_robin(G, rank, world)
+    batch = ds.sample_batch(len(mine), None, seq_ids=seq[mine], offsets=off[mine])
+    opt = arap.make_optimizer(model)
+    loss = arap.train_step(model, opt, batch, global_batch=G, grad_sync=bucket.all_reduce)
+    assert bucket.check_views()                               # zero_grad(set_to_none=False) keeps the views alive
+    g_dp = bucket.flat.clone()
+
+    # single-process full batch on the same data
+    full = ds.sample_batch(G, None, seq_ids=seq, offsets=off)
+    l_full, _ = arap.forward_loss(ref, full, G)
+    l_full.backward()
+    g_full = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    err = ((g_dp - g_full).norm() / g_full.norm()).item()
+    # losses: sum over ranks of shard losses == full loss
+    lsum = loss.detach().clone()
+    dist.all_reduce(lsum)
+    # replicas stay identical after the optimizer step
+    flat_p = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    other = flat_p.clone()
+    dist.broadcast(other, 0)
+    q.put((rank, err, abs(lsum.item() - l_full.item()) / abs(l_full.item()), torch.equal(other, flat_p), len(mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_gradients_sum_to_full_batch_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    res = sorted(q.get(timeout=10) for _ in range(2))
+    for rank, err, lerr, same, n in res:
+        assert n == 2
+        assert err < 1e-5, f"rank {rank}: all-reduced shard gradients differ from the full-batch gradient by {err:.2e}"
+        assert lerr < 1e-6 and same
+
+
+def test_sharding_helpers():
+    from surfacenetworks_amd import dp
+
+    parts = [dp.shard_round_robin(11, r, 4) for r in range(4)]
+    assert sorted(np.concatenate(parts).tolist()) == list(range(11))
+    assert parts[1].tolist() == [1, 5, 9]
+    w = np.array([20000, 1000, 1500, 19000, 7000, 7200, 300, 12000], dtype=float)
+    bins = [dp.shard_balanced(w, r, 3) for r in range(3)]
+    assert sorted(np.concatenate(bins).tolist()) == list(range(8))
+    loads = [w[b].sum() for b in bins]
+    assert max(loads) <= 4 / 3 * w.sum() / 3 + 1            # LPT bound
+    assert all(np.array_equal(dp.shard_balanced(w, r, 3), bins[r]) for r in range(3))     # deterministic
+
+
+def test_flat_bucket_single_process():
+    from surfacenetworks_amd import dp
+
+    lin = torch.nn.Linear(5, 3)
+    b = dp.FlatGradBucket(lin.parameters())
+    assert b.flat.numel() == 18 and b.all_reduce() is None
+    lin(torch.ones(2, 5)).sum().backward()
+    assert torch.equal(b.flat[:15].view(3, 5), lin.weight.grad) and b.flat[15:].tolist() == [2.0, 2.0, 2.0]
+    torch.optim.SGD(lin.parameters(), 0.1).zero_grad(set_to_none=False)
+    assert b.check_views() and float(b.flat.abs().sum()) == 0.0

@@ -1,0 +1,255 @@
+"""Pins the oracle (test infrastructure) against the committed golden fixtures, which are outputs of the REFERENCE
+itself (tests/golden/make_golden.py, run in the build container with /root/reference imported).  No GPU needed."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+from helpers import deterministic_init, grad_signature, rel_err, sigs_close
+from oracle import c_oracle, ref_blocks as OB
+from surfacenetworks_amd import mesh_ops
+
+
+def load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def csr_of(z, k):
+    return sp.csr_matrix((z[f"{k}_data"], z[f"{k}_indices"], z[f"{k}_indptr"]), shape=tuple(z[f"{k}_shape"]))
+
+
+@pytest.mark.parametrize("mesh", ["cube", "delaunay150", "delaunay60"])
+def test_operator_construction_matches_reference(golden_dir, mesh):
+    """mesh_ops (sparse-direct) == utils.mesh / utils.graph (dense builders) on the fixture meshes, fp32-identical."""
+    z = load(golden_dir, f"ops_{mesh}.npz")
+    mine = mesh_ops.mesh_operators(z["V"], z["F"])
+    for k in ("L", "Di", "DiA"):
+        A = mine[k].tocsr()
+        A.sort_indices()
+        assert tuple(z[f"{k}_shape"]) == A.shape
+        assert np.array_equal(A.indptr, z[f"{k}_indptr"]) and np.array_equal(A.indices, z[f"{k}_indices"])
+        assert np.array_equal(A.data, z[f"{k}_data"])
+    if mesh == "cube":
+        assert (mine["L"].nnz, mine["Di"].nnz, mine["DiA"].nnz) == (44, 192, 192)
+
+
+def test_operator_identities(golden_dir):
+    """rows of L sum to ~0; DiA has the pattern of Di^T; 9 nnz per Di row on a generic mesh."""
+    z = load(golden_dir, "ops_delaunay150.npz")
+    L, Di, DiA = csr_of(z, "L"), csr_of(z, "Di"), csr_of(z, "DiA")
+    assert np.abs(np.asarray(L.sum(axis=1))).max() < 1e-3 * np.abs(L.data).max()
+    assert (np.diff(Di.indptr) == 9).all()
+    P, Q = Di.T.tocsr(), DiA.tocsr()
+    P.sort_indices(); Q.sort_indices()
+    assert np.array_equal(P.indptr, Q.indptr) and np.array_equal(P.indices, Q.indices)
+
+
+def test_c_oracle_spmm_matches_reference_torch_mm(golden_dir):
+    """oracle_spmm_csr_f32 (forward) and transpose+spmm (backward) vs torch.mm(sparse, dense) + autograd of the
+    reference path, <= 1e-6 relative (tolerance of SURVEY.md §8c); and vs fp64."""
+    g = load(golden_dir, "spmm_reference.npz")
+    for mesh in ("cube", "delaunay150"):
+        z = load(golden_dir, f"ops_{mesh}.npz")
+        for k, Ns in (("L", (64, 128)), ("Di", (16, 32)), ("DiA", (16, 32))):
+            A = csr_of(z, k)
+            M, K = A.shape
+            for N in Ns:
+                t = f"{mesh}_{k}_N{N}"
+                X, Y, G, GX = g[f"{t}_X"], g[f"{t}_Y"], g[f"{t}_G"], g[f"{t}_GX"]
+                yo = c_oracle.spmm_csr(A.indptr, A.indices, A.data, X.ravel(), N).reshape(M, N)
+                tr = c_oracle.csr_transpose(A.indptr, A.indices, A.data, K)
+                go = c_oracle.spmm_csr(tr[0], tr[1], tr[2], G.ravel(), N).reshape(K, N)
+                assert rel_err(yo, Y) <= 1e-6 and rel_err(go, GX) <= 1e-6
+                y64 = c_oracle.spmm_csr_f64(A.indptr, A.indices, A.data, X.ravel(), N)
+                assert rel_err(yo, y64) <= 1e-6 and rel_err(Y, y64) <= 1e-6
+
+
+def test_literal_cuda_kernel_restatements(golden_dir):
+    """oracle_batch_csr + oracle_sparse_bmm (line-by-line batch_csr.cu / sparse_bmm.cu) reproduce the reference's
+    own torch.mm results on the 3-D batched operator of the ragged batch, where batch_csr is valid (no interior
+    empty rows in Di), and the corrected COO->CSR agrees with them there."""
+    rb = load(golden_dir, "ragged_batch.npz")
+    idx, vals, shape = rb["Di_3d_indices"], rb["Di_3d_values"], tuple(rb["Di_3d_shape"])
+    B, R, K = shape
+    col_ind, col_ptr = c_oracle.batch_csr(idx, B, R)
+    # trailing padded rows of a batch keep col_ptr 0 -> make them empty ranges the way the kernel is meant to be read
+    rp, ci = c_oracle.coo_to_csr(idx[0], idx[1], idx[2], B, R, K)
+    N = 16
+    X = np.random.default_rng(0).standard_normal((B, K, N)).astype(np.float32)
+    want = c_oracle.spmm_csr(rp, ci, vals, X.reshape(-1), N).reshape(B, R, N)
+    Abd = torch.sparse_coo_tensor(torch.from_numpy(np.stack([idx[0] * R + idx[1], idx[0] * K + idx[2]])),
+                                  torch.from_numpy(vals), (B * R, B * K))
+    ref = torch.mm(Abd, torch.from_numpy(X.reshape(B * K, N))).numpy().reshape(B, R, N)
+    assert rel_err(want, ref) <= 1e-6
+    # rows that own entries: literal batch_csr gives the same [start,end) as the corrected conversion
+    nrows_used = [int(idx[1][idx[0] == b].max()) + 1 for b in range(B)]
+    for b in range(B):
+        for r in range(nrows_used[b] - 1):
+            assert col_ptr[b, r] == rp[b * R + r] and col_ptr[b, r + 1] == rp[b * R + r + 1]
+    assert np.array_equal(col_ind, idx[2])
+    # literal sparse_bmm on a batch with full rows only (B copies of delaunay60's Di: every row has entries)
+    z = load(golden_dir, "ops_delaunay60.npz")
+    A = csr_of(z, "Di").tocoo()
+    o = np.lexsort((A.col, A.row))
+    nnz = A.nnz
+    ind3 = np.stack([np.repeat(np.arange(2), nnz), np.tile(A.row[o], 2), np.tile(A.col[o], 2)]).astype(np.int64)
+    v3 = np.tile(A.data[o], 2)
+    ci3, cp3 = c_oracle.batch_csr(ind3, 2, A.shape[0])
+    X3 = np.random.default_rng(1).standard_normal((2, A.shape[1], N)).astype(np.float32)
+    out = c_oracle.sparse_bmm(v3, ci3, cp3, X3)
+    for b in range(2):
+        assert rel_err(out[b], csr_of(z, "Di").astype(np.float64) @ X3[b].astype(np.float64)) <= 1e-6
+
+
+def test_batch_csr_defect_is_real_and_not_reproduced():
+    """An interior empty row breaks the reference's batch_csr (col_ptr stays 0); the specified conversion does not."""
+    ind = np.array([[0, 0, 0, 0], [0, 0, 2, 2], [1, 3, 0, 2]], dtype=np.int64)     # row 1 is empty
+    _, cp = c_oracle.batch_csr(ind, 1, 3)
+    assert cp[0, 1] == 0 and cp[0, 0] == 0            # row 0 -> [0,0): its two entries are lost
+    rp, _ = c_oracle.coo_to_csr(ind[0], ind[1], ind[2], 1, 3, 4)
+    assert rp.tolist() == [0, 2, 2, 4]
+
+
+def test_blockdiag_oracle_matches_reference_sparse_diag_cat(golden_dir):
+    """oracle_blockdiag_concat on per-mesh CSR == the reference's sparse_diag_cat output (indices and values)."""
+    rb = load(golden_dir, "ragged_batch.npz")
+    order = [str(s) for s in rb["order"]]
+    nv, nf = int(rb["nv"]), int(rb["nf"])
+    for k, (s0, s1) in {"L": (nv, nv), "Di": (4 * nf, 4 * nv), "DiA": (4 * nv, 4 * nf)}.items():
+        mats = [csr_of(load(golden_dir, f"ops_{m}.npz"), k) for m in order]
+        rp_off = np.cumsum([0] + [m.shape[0] + 1 for m in mats])
+        e_off = np.cumsum([0] + [m.nnz for m in mats])
+        desc = np.stack([rp_off[:-1], e_off[:-1], [m.shape[0] for m in mats], e_off[:-1]], 1).astype(np.int64)
+        out = c_oracle.blockdiag_concat(np.concatenate([m.indptr for m in mats]), np.concatenate([m.indices for m in mats]),
+                                        np.concatenate([m.data for m in mats]), desc, s0, s1, int(e_off[-1]))
+        got = sp.csr_matrix((out[2], out[1], out[0]), shape=(len(mats) * s0, len(mats) * s1)).tocoo()
+        o = np.lexsort((got.col, got.row))
+        assert np.array_equal(np.stack([got.row[o], got.col[o]]), rb[f"{k}_bd_indices"])
+        assert np.array_equal(got.data[o], rb[f"{k}_bd_values"])
+        assert tuple(rb[f"{k}_bd_shape"]) == got.shape
+        # and the restated sparse_diag_cat / sparse_cat of oracle.ref_blocks
+        parts = [OB.sp_to_coo(m) for m in mats]
+        bd, b3 = OB.diag_cat(parts, s0, s1), OB.batch_cat(parts, s0, s1)
+        assert np.array_equal(bd._indices().numpy(), rb[f"{k}_bd_indices"]) and np.array_equal(bd._values().numpy(), rb[f"{k}_bd_values"])
+        assert np.array_equal(b3._indices().numpy(), rb[f"{k}_3d_indices"]) and np.array_equal(b3._values().numpy(), rb[f"{k}_3d_values"])
+
+
+def _batch_ops(golden_dir):
+    rb = load(golden_dir, "ragged_batch.npz")
+    ops = {}
+    for k in ("L", "Di", "DiA"):
+        ops[k] = torch.sparse_coo_tensor(torch.from_numpy(rb[f"{k}_bd_indices"]), torch.from_numpy(rb[f"{k}_bd_values"]),
+                                         tuple(rb[f"{k}_bd_shape"])).coalesce()
+    return rb, ops
+
+
+BLOCKS = [("LapResNet2", 64), ("LapResNet2", 128), ("DirResNet2", 64), ("DirResNet2", 128), ("AvgResNet2", 128), ("MlpResNet2", 128)]
+
+
+@pytest.mark.parametrize("cname,C", BLOCKS)
+def test_oracle_blocks_match_reference(golden_dir, cname, C):
+    from helpers import det_tensor
+
+    rb, ops = _batch_ops(golden_dir)
+    g = load(golden_dir, "blocks_reference.npz")
+    B, nv, nf = rb["mask"].shape[0], int(rb["nv"]), int(rb["nf"])
+    mask = torch.from_numpy(rb["mask"])
+    tag = f"{cname}{C}"
+    mod = deterministic_init(getattr(OB, cname)(C), seed=C + len(cname)).train()
+    v = torch.from_numpy(det_tensor((B, nv, C), 11 + C, 1.0) * rb["mask"]).requires_grad_(True)
+    if cname == "DirResNet2":
+        f = torch.from_numpy(det_tensor((B, nf, C), 12 + C, 1.0)).requires_grad_(True)
+        outs, gin = mod(ops["Di"], ops["DiA"], v, f), [v, f]
+    else:
+        outs, gin = (mod(ops["L"], mask, v),), [v]
+    loss = sum((o * torch.from_numpy(det_tensor(tuple(o.shape), s))).sum() for o, s in zip(outs, [21, 22]))
+    loss.backward()
+    for i, o in enumerate(outs):
+        assert rel_err(o.detach().numpy(), g[f"{tag}_out{i}"]) <= 1e-6
+    for i, t in enumerate(gin):
+        assert rel_err(t.grad.numpy(), g[f"{tag}_gin{i}"]) <= 1e-6
+    assert not sigs_close(grad_signature(mod), lambda k: g[f"{tag}_psig_{k}"])
+    for k, t in mod.state_dict().items():
+        if "running" in k:
+            assert np.allclose(t.numpy(), g[f"{tag}_{k}"], rtol=1e-6, atol=1e-7)
+
+
+def _bn_train_only(m):
+    m.eval()
+    for mod in m.modules():
+        if "BatchNorm" in mod.__class__.__name__:
+            mod.train()
+    return m
+
+
+def run_model(tag, golden_dir, lib, rb, ops, g):
+    """Shared by the oracle test here and the product tests (lib = oracle.ref_blocks or the product modules)."""
+    mask = torch.from_numpy(rb["mask"]).to(ops["L"].device if hasattr(ops["L"], "device") else "cpu")
+    dev = mask.device
+    B = mask.shape[0]
+    if tag == "arap_dir":
+        m = deterministic_init(lib["arap_dir"](), 7).train().to(dev)
+        out = m(ops["Di"], ops["DiA"], mask, torch.from_numpy(g["inputs6"]).to(dev))
+        loss = OB.arap_loss(out, torch.from_numpy(g["targets"]).to(dev), mask, B)
+    elif tag == "arap_lap":
+        m = deterministic_init(lib["arap_lap"](), 8).train().to(dev)
+        out = m(ops["L"], mask, torch.from_numpy(g["inputs6"]).to(dev))
+        loss = OB.arap_loss(out, torch.from_numpy(g["targets"]).to(dev), mask, B)
+    elif tag == "mnist_lap":
+        m = _bn_train_only(deterministic_init(lib["mnist_lap"](), 9)).to(dev)
+        out = m(torch.from_numpy(rb["coords"]).to(dev), ops["L"], mask)
+        loss = torch.nn.functional.nll_loss(out, torch.from_numpy(g["labels"]).to(dev))
+    elif tag == "mnist_dir":
+        m = _bn_train_only(deterministic_init(lib["mnist_dir"](), 10)).to(dev)
+        out = m(torch.from_numpy(rb["coords"]).to(dev), ops["Di"], ops["DiA"], mask)
+        loss = torch.nn.functional.nll_loss(out, torch.from_numpy(g["labels"]).to(dev))
+    else:
+        raise KeyError(tag)
+    loss.backward()
+    return loss, out, m
+
+
+def check_model(tag, loss, out, m, g, rtol_loss=1e-5, rtol_out=2e-5, rtol_sig=2e-4):
+    assert abs(loss.item() - float(g[f"{tag}_loss"])) <= rtol_loss * abs(float(g[f"{tag}_loss"]))
+    assert rel_err(out.detach().cpu().numpy(), g[f"{tag}_out"]) <= rtol_out
+    assert not sigs_close(grad_signature(m), lambda k: g[f"{tag}_psig_{k}"], rtol_sig)
+
+
+ORACLE_LIB = {"arap_dir": OB.ArapDirModel, "arap_lap": OB.ArapLapModel, "mnist_lap": OB.MnistLapModel, "mnist_dir": OB.MnistDirModel}
+
+
+@pytest.mark.parametrize("tag", ["arap_dir", "arap_lap", "mnist_lap", "mnist_dir"])
+def test_oracle_models_match_reference(golden_dir, tag):
+    rb, ops = _batch_ops(golden_dir)
+    g = load(golden_dir, "models_reference.npz")
+    loss, out, m = run_model(tag, golden_dir, ORACLE_LIB, rb, ops, g)
+    check_model(tag, loss, out, m, g)
+
+
+def faust_inputs(golden_dir, dev="cpu"):
+    rb = load(golden_dir, "ragged_batch.npz")
+    g = load(golden_dir, "models_reference.npz")
+    z = load(golden_dir, "ops_delaunay150.npz")
+    nv = int(rb["nv"])
+    L = csr_of(z, "L")
+    lA, lB = torch.from_numpy(g["faust_lA"]).to(dev), torch.from_numpy(g["faust_lB"]).to(dev)
+    tX = [(torch.from_numpy(g["faust_GA"]).to(dev), lA, torch.argsort(lA))]
+    tY = [(torch.from_numpy(g["faust_GB"]).to(dev), lB, torch.argsort(lB))]
+    cA = torch.from_numpy(rb["coords"][1:2]).to(dev)
+    cB = torch.from_numpy(rb["coords"][1:2] * 1.1 + 0.02).to(dev)
+    mask = torch.from_numpy(rb["mask"][1:2]).to(dev)
+    return g, L, nv, tX, tY, cA, cB, mask
+
+
+def test_oracle_faust_matches_reference(golden_dir):
+    g, L, nv, tX, tY, cA, cB, mask = faust_inputs(golden_dir)
+    L1 = OB.diag_cat([OB.sp_to_coo(L)], nv, nv)
+    m = deterministic_init(OB.SiameseModel("lap", 15), 11).train()
+    out = m([L1, mask], [L1, mask], cA, cB)
+    loss = OB.delta_cross_entropy(out, tX, tY)
+    loss.backward()
+    assert abs(loss.item() - float(g["faust_lap_loss"])) <= 1e-5 * abs(float(g["faust_lap_loss"]))
+    assert rel_err(out.detach().numpy()[0, ::7, ::7], g["faust_lap_out_sample"]) <= 2e-5
+    assert not sigs_close(grad_signature(m), lambda k: g[f"faust_lap_psig_{k}"], 2e-4)

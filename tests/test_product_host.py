@@ -1,0 +1,40 @@
+"""Host logic of the product (autograd Functions, fused blocks, models, samplers, operator pool) run on CPU tensors with
+oracle-backed kernels (tests/cpu_kernels.py, test-only seam) and compared with the golden fixtures produced by the
+reference.  The same checks run against the real HIP kernels in tests/test_blocks_gpu.py."""
+import os
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import torch
+
+import product_checks as pc
+
+
+@pytest.mark.parametrize("cname,C", pc.BLOCKS)
+@pytest.mark.parametrize("opkind", ["pool", "coo2d", "coo3d"])
+def test_blocks_match_reference(golden_dir, cpu_kernels, cname, C, opkind):
+    if cname in ("AvgResNet2", "MlpResNet2") and opkind != "pool":
+        pytest.skip("no sparse operator in this block")
+    pc.check_block(golden_dir, cname, C, opkind, "cpu")
+
+
+@pytest.mark.parametrize("tag", ["arap_dir", "arap_lap", "mnist_lap", "mnist_dir", "faust_lap"])
+def test_models_match_reference(golden_dir, cpu_kernels, tag):
+    pc.check_model(golden_dir, tag, "cpu")
+
+
+def test_sparse_cat_functions_match_reference(golden_dir):
+    pc.check_cat_functions(golden_dir)
+
+
+def test_unfused_spmm_function_gradcheck(cpu_kernels):
+    pc.check_spmm_autograd("cpu")
+
+
+def test_arap_sampler_matches_padded_blockdiag(cpu_kernels):
+    pc.check_arap_sampler("cpu")
+
+
+def test_mnist_sampler_running_max(cpu_kernels):
+    pc.check_mnist_sampler("cpu")
