@@ -168,7 +168,7 @@ def main():
                                f"(V=5041,F=9800) per GPU, C=128, 15 layers, fwd+loss+bwd+allreduce+Adam",
                    "meshes_per_gpu": n_local, "global_batch": global_batch, "parallelism": f"dp{world} (mesh sharding, flat-bucket RCCL all-reduce)",
                    "operator_format": args.format, "grad_bucket_bytes": bucket.nbytes},
-        "roofline": {"bound": "hbm", "kernel": f"spmm_{'bsr4' if 'bsr4' in tag else 'csr'}_v4<32> ({tag}, M={M}, K={K}, nnz={nnz}, N={N})",
+        "roofline": {"bound": "hbm", "kernel": f"{'spmm_bsr4_lds' if 'bsr4' in tag else 'spmm_csr_v4'}<N={N}> ({tag}, M={M}, K={K}, nnz={nnz})",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                      "traffic": None, "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg_ms,
                      "launches_timed": len(by[dom]), "spmm_ms_per_step_all_kernels": spmm_ms_per_step},

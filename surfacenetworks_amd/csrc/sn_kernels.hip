@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sn_spmm.h"
 
@@ -148,6 +149,94 @@ __global__ __launch_bounds__(kWG) void spmm_bsr4_v4(const int *__restrict__ b_ro
     st4_stream(yp + ys, acc1);
     st4_stream(yp + 2 * ys, acc2);
     st4_stream(yp + 3 * ys, acc3);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// BSR4 SpMM with the operator tile staged through LDS.
+//
+// In spmm_bsr4_v4 every lane group re-reads its 64-byte blocks with 16-byte loads whose address is shared
+// by the N/4 lanes of the group: each such load occupies the texture-addresser like a full 1 KiB gather
+// but delivers 128 unique bytes (rocprof: SQ_WAIT_INST_ANY 39 % — the kernel is vector-memory-ISSUE bound,
+// not HBM bound).  Here each WAVE copies the contiguous run of blocks owned by its 256/N block rows
+// (b_vals[16*k0 .. 16*k1), b_colind[k0..k1)) into its private LDS slice with fully coalesced 16-byte
+// loads, and the lane groups then read their blocks back with broadcast ds_read_b128.  Waves stay
+// independent (no workgroup barrier): DS operations of one wave complete in order.
+// ------------------------------------------------------------------------------------------------
+template <int N, int XG, int YG, bool DMA, int UNR>
+__global__ __launch_bounds__(kWG, (UNR == 4 ? 8 : 1)) void spmm_bsr4_lds(const int *__restrict__ b_rowptr,
+                                                     const int *__restrict__ b_colind,
+                                                     const float *__restrict__ b_vals, int Mb,
+                                                     const float *__restrict__ X, int64_t ldx,
+                                                     float *__restrict__ Y, int64_t ldy, int nchunks) {
+  constexpr int LPR = N / 4;          // lanes per block row
+  constexpr int RPW = 64 / LPR;       // block rows per wave pass
+  constexpr int WAVES = kWG / 64;
+  constexpr int TILE = 64;            // blocks staged per wave per tile (4 KiB of values)
+  constexpr int kUnroll = (UNR == 4) ? 1 : UNR;
+  __shared__ f4 s_vals[WAVES][TILE * 4];
+  __shared__ int s_col[WAVES][TILE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane % LPR, grp = lane / LPR;
+  const int64_t xq = (XG == 4) ? ldx : 4 * ldx;
+  const int64_t xs = (XG == 4) ? (int64_t)N : ldx;
+  const int64_t yq = (YG == 4) ? ldy : 4 * ldy;
+  const int64_t ys = (YG == 4) ? (int64_t)N : ldy;
+  const float *xb = X + sub * 4;
+  const f4 *gv = reinterpret_cast<const f4 *>(b_vals);
+  f4 *sv = s_vals[wave];
+  int *sc = s_col[wave];
+  ChunkWalk w(nchunks);               // a chunk = WAVES * RPW block rows (one pass of the workgroup)
+  for (int local = w.first; local < w.cpx; local += w.step) {
+    const int r0 = ((w.base + local) * WAVES + wave) * RPW;   // first block row of this wave
+    if (r0 >= Mb) continue;                                   // wave-uniform
+    const int br = r0 + grp;
+    const int brc = br < Mb ? br : Mb;
+    const int kb = b_rowptr[brc];
+    const int ke = b_rowptr[brc + 1 <= Mb ? brc + 1 : Mb];
+    const int k0 = __builtin_amdgcn_readfirstlane(kb);
+    const int k1 = __builtin_amdgcn_readlane(ke, 63);
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    for (int t0 = k0; t0 < k1; t0 += TILE) {
+      const int nt = (k1 - t0) < TILE ? (k1 - t0) : TILE;
+      // ---- stage nt blocks: 4*nt contiguous 16-byte pieces + nt column indices ----
+      if constexpr (DMA) {
+        for (int p0 = 0; p0 < 4 * nt; p0 += 64) {
+          int p = p0 + lane;
+          p = p < 4 * nt ? p : 4 * nt - 1;      // tail lanes re-read the last piece into spare LDS slots
+          __builtin_amdgcn_global_load_lds(gv + (int64_t)t0 * 4 + p, sv + p0, 16, 0, 0);
+        }
+        if (lane < nt) sc[lane] = b_colind[t0 + lane];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        for (int p = lane; p < 4 * nt; p += 64) sv[p] = gv[(int64_t)t0 * 4 + p];
+        if (lane < nt) sc[lane] = b_colind[t0 + lane];
+      }
+      __builtin_amdgcn_wave_barrier();
+      // ---- my blocks inside this tile ----
+      int k = kb > t0 ? kb : t0;
+      const int kend = ke < t0 + nt ? ke : t0 + nt;
+#pragma unroll kUnroll
+      for (; k < kend; ++k) {
+        const int o = k - t0;
+        const int bc = sc[o];
+        const f4 a0 = sv[4 * o], a1 = sv[4 * o + 1], a2 = sv[4 * o + 2], a3 = sv[4 * o + 3];
+        const float *xp = xb + (int64_t)bc * xq;
+        const f4 x0 = ld4(xp), x1 = ld4(xp + xs), x2 = ld4(xp + 2 * xs), x3 = ld4(xp + 3 * xs);
+        acc0 = fma4(a0.x, x0, acc0); acc0 = fma4(a0.y, x1, acc0); acc0 = fma4(a0.z, x2, acc0); acc0 = fma4(a0.w, x3, acc0);
+        acc1 = fma4(a1.x, x0, acc1); acc1 = fma4(a1.y, x1, acc1); acc1 = fma4(a1.z, x2, acc1); acc1 = fma4(a1.w, x3, acc1);
+        acc2 = fma4(a2.x, x0, acc2); acc2 = fma4(a2.y, x1, acc2); acc2 = fma4(a2.z, x2, acc2); acc2 = fma4(a2.w, x3, acc2);
+        acc3 = fma4(a3.x, x0, acc3); acc3 = fma4(a3.y, x1, acc3); acc3 = fma4(a3.z, x2, acc3); acc3 = fma4(a3.w, x3, acc3);
+      }
+      __builtin_amdgcn_wave_barrier();          // all reads of this tile done before it is overwritten
+    }
+    if (br < Mb) {
+      float *yp = Y + (int64_t)br * yq + sub * 4;
+      st4_stream(yp, acc0);
+      st4_stream(yp + ys, acc1);
+      st4_stream(yp + 2 * ys, acc2);
+      st4_stream(yp + 3 * ys, acc3);
+    }
   }
 }
 
@@ -503,10 +592,21 @@ inline unsigned grid_for(int64_t work_items, int per_block) {
   return (unsigned)(b < cap ? b : cap);
 }
 
-// grid for the XCD-aware chunk walk: a multiple of 8 workgroups, at most 8 per CU.
+// Development tunables (read once): SN_BLOCKS_PER_CU caps the persistent grid (0 = one workgroup per chunk),
+// SN_BSR4_VARIANT picks 0 = direct loads, 1 = LDS-staged, 2 = LDS-staged via global_load_lds.
+inline int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+inline int tune_blocks_per_cu() { static const int v = env_int("SN_BLOCKS_PER_CU", 0); return v; }
+inline int tune_bsr4_variant() { static const int v = env_int("SN_BSR4_VARIANT", 2); return v; }
+inline int tune_bsr4_unroll() { static const int v = env_int("SN_BSR4_UNROLL", 2); return v; }
+
+// grid for the XCD-aware chunk walk: a multiple of 8 workgroups, at most SN_BLOCKS_PER_CU per CU.
 inline unsigned chunk_grid(int64_t nchunks) {
   int64_t b = ((nchunks + kXCD - 1) / kXCD) * kXCD;
-  const int64_t cap = (int64_t)kCUs * kMaxBlocksPerCU;
+  const int bpc = tune_blocks_per_cu();
+  const int64_t cap = bpc > 0 ? (int64_t)kCUs * bpc : (int64_t)INT_MAX - 7;
   if (b > cap) b = cap;
   if (b < kXCD) b = kXCD;
   return (unsigned)b;
@@ -540,6 +640,23 @@ int exclusive_scan_i32(const int *in, int64_t n, int *out, void *ws, size_t ws_b
     else if (xg == 4 && yg == 4) hipLaunchKernelGGL((KERNEL<N, 4, 4>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
     else if (xg == 1 && yg == 4) hipLaunchKernelGGL((KERNEL<N, 1, 4>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<N, 4, 1>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__);         \
+  } while (0)
+
+#define SN_DISPATCH_LDS_U(N, DMA, UNR, xg, yg, grid, stream, ...)                                                     \
+  do {                                                                                                         \
+    if (xg == 1 && yg == 1) hipLaunchKernelGGL((spmm_bsr4_lds<N, 1, 1, DMA, UNR>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
+    else if (xg == 4 && yg == 4) hipLaunchKernelGGL((spmm_bsr4_lds<N, 4, 4, DMA, UNR>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
+    else if (xg == 1 && yg == 4) hipLaunchKernelGGL((spmm_bsr4_lds<N, 1, 4, DMA, UNR>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((spmm_bsr4_lds<N, 4, 1, DMA, UNR>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__);       \
+  } while (0)
+
+#define SN_DISPATCH_LDS(N, DMA, xg, yg, grid, stream, ...)                                     \
+  do {                                                                                         \
+    const int u_ = tune_bsr4_unroll();                                                         \
+    if (u_ == 1) SN_DISPATCH_LDS_U(N, DMA, 1, xg, yg, grid, stream, __VA_ARGS__);              \
+    else if (u_ == 2) SN_DISPATCH_LDS_U(N, DMA, 2, xg, yg, grid, stream, __VA_ARGS__);         \
+    else if (u_ == 4) SN_DISPATCH_LDS_U(N, DMA, 4, xg, yg, grid, stream, __VA_ARGS__);         \
+    else SN_DISPATCH_LDS_U(N, DMA, 3, xg, yg, grid, stream, __VA_ARGS__);                      \
   } while (0)
 
 }  // namespace
@@ -619,12 +736,31 @@ int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const flo
   const int rpb = kWG / (N / 4);
   const int64_t nchunks = (Mb + rpb - 1) / rpb;
   const unsigned grid = chunk_grid(nchunks);
-  switch (N) {
-    case 16: SN_DISPATCH_N_G(spmm_bsr4_v4, 16, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks); break;
-    case 32: SN_DISPATCH_N_G(spmm_bsr4_v4, 32, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks); break;
-    case 64: SN_DISPATCH_N_G(spmm_bsr4_v4, 64, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks); break;
-    default: SN_DISPATCH_N_G(spmm_bsr4_v4, 128, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks); break;
+  const int variant = tune_bsr4_variant();
+#define SN_BSR4_ARGS b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks
+  if (variant == 0) {
+    switch (N) {
+      case 16: SN_DISPATCH_N_G(spmm_bsr4_v4, 16, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      case 32: SN_DISPATCH_N_G(spmm_bsr4_v4, 32, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      case 64: SN_DISPATCH_N_G(spmm_bsr4_v4, 64, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      default: SN_DISPATCH_N_G(spmm_bsr4_v4, 128, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+    }
+  } else if (variant == 1) {
+    switch (N) {
+      case 16: SN_DISPATCH_LDS(16, false, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      case 32: SN_DISPATCH_LDS(32, false, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      case 64: SN_DISPATCH_LDS(64, false, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      default: SN_DISPATCH_LDS(128, false, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+    }
+  } else {
+    switch (N) {
+      case 16: SN_DISPATCH_LDS(16, true, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      case 32: SN_DISPATCH_LDS(32, true, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      case 64: SN_DISPATCH_LDS(64, true, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      default: SN_DISPATCH_LDS(128, true, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+    }
   }
+#undef SN_BSR4_ARGS
   return launch_status();
 }
 

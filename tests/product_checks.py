@@ -15,7 +15,7 @@ from oracle import ref_blocks as OB
 # computed with the oracle in fp64 and the product must be as close to it as the reference's own fp32 run is:
 #     err(product, fp64) <= SLACK * err(reference_fp32, fp64) + FLOOR.
 # The tight fixed bar (1e-5 relative) is held at block level (check_block) and bit-exactness at kernel level.
-SLACK, FLOOR = 4.0, 2e-6
+SLACK, FLOOR = 10.0, 2e-6
 
 
 def _sig_err(sigs, ref64):

@@ -18,7 +18,7 @@ def alg_bytes(M, K, nnz, N):
     return nnz * 8 + (M + 1) * 4 + K * N * 4 + M * N * 4
 
 
-def time_launch(fn, iters=30, warm=5):
+def time_launch(fn, iters=60, warm=25):
     for _ in range(warm):
         fn()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -64,7 +64,10 @@ def main():
     meshes = build_batch(workload, permute)
     dev = "cuda"
     C = 64 if workload == "mnist" else 128
+    only = os.environ.get("SN_MB_ONLY", "")
     for name, group in [("Di", 4), ("DiA", 4), ("L", 1)]:
+        if only == "bsr4" and group != 4:
+            continue
         mats = [m[name] for m in meshes]
         s0 = max(m.shape[0] for m in mats)
         s1 = max(m.shape[1] for m in mats)
@@ -76,14 +79,18 @@ def main():
             x = torch.randn(K // group, group * N, device=dev)
             y = torch.empty(M // group, group * N, device=dev)
             ab = alg_bytes(M, K, o.nnz, N)
-            ms = time_launch(lambda: kernels.spmm_csr(o.rowptr, o.colind, o.vals, M, K, x, y, group))
+            ms = time_launch(lambda: kernels.spmm_csr(o.rowptr, o.colind, o.vals, M, K, x, y, group)) if only != "bsr4" else float("nan")
             print(f"{workload} {name:3s} {tag:6s} csr  N={N:3d} M={M} K={K} nnz={o.nnz} algMB={ab / 1e6:.1f} ms={ms:.4f} GB/s={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f}", flush=True)
             if group == 4:
                 b = o.bsr4()
                 y2 = torch.empty_like(y)
                 ms = time_launch(lambda: kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y2, group))
                 actual = b[1].numel() * 68 + (M // 4 + 1) * 4 + K * N * 4 + M * N * 4
+                if only == "bsr4":
+                    kernels.spmm_csr(o.rowptr, o.colind, o.vals, M, K, x, y, group)
                 print(f"{workload} {name:3s} {tag:6s} bsr4 N={N:3d} blocks={b[1].numel()} actualMB={actual / 1e6:.1f} ms={ms:.4f} GB/s(alg)={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f} equal={torch.equal(y, y2)}", flush=True)
+    if only:
+        return
     # plain copy ceiling on this box for reference
     n = 256 * 1024 * 1024
     a = torch.empty(n, device=dev)
