@@ -180,6 +180,34 @@ int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *out, int64_t
                        float *gsrc, int64_t ldgs, int64_t rows, int32_t C, int32_t accumulate,
                        void *stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm("pre") + Linear of GraphConv1x1 (src/utils/utils_pt.py:83-99) without materialising the
+ * normalised tensor.  With s = gamma*invstd, t = beta - mean*s the layer is  y = x·(W·diag(s))ᵀ + (b + W·t),
+ * so the forward needs only per-channel statistics of x; the backward needs G = dyᵀ·x and colsum(dy), from
+ * which every BatchNorm reduction follows algebraically (sum dz = colsum(dy)·W, sum dz*x = sum_j W∘G).
+ *
+ * sn_colstats_f32 : out[0:C] = column sums, out[C:2C] = column sums of squares of x (rows x C, row stride ld),
+ *                   accumulated in fp64, two deterministic stages.  Replaces the statistics pass of
+ *                   nn.BatchNorm1d (train mode) and the bias-gradient reduction.
+ * sn_wgrad_f32    : G (J x C, row-major, fp32) = dyᵀ·(x - center) with dy (rows x J, stride lddy), x (rows x C, stride
+ *                   ldx), center[C] optional (NULL = 0; BatchNorm passes the batch mean so that no cancellation
+ *                   between dyᵀ·x and mean·colsum(dy) is left to fp32):
+ *                   split-K over row slabs on the fp32 MFMA (v_mfma_f32_32x32x2_f32), partial tiles reduced in a
+ *                   fixed order.  J and C must be multiples of 32 (J <= 128 per call slice handled internally).
+ *                   Replaces the weight-gradient GEMM of nn.Linear for tall-skinny operands (K = rows ~ 1e5..1e6).
+ * sn_affine_cols_acc_f32 : dx[r,c] += (x[r,c] - center[c])*B[c] + Cc[c]  (the elementwise tail of BatchNorm
+ *                   backward, fused; center may be NULL).
+ * ------------------------------------------------------------------------------------------ */
+size_t sn_colstats_workspace_bytes(int64_t rows, int32_t C);
+int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *out,
+                    void *workspace, size_t workspace_bytes, void *stream);
+size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C);
+int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                 int32_t J, int32_t C, float *G, void *workspace, size_t workspace_bytes, void *stream);
+int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
+                           const float *Cc, int64_t rows, int32_t C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,3 +157,24 @@ def elu_raw(src_ptr, lds, dst_ptr, ldd, rows, Cc):
 def elu_bwd_raw(g_ptr, ldg, o_ptr, ldo, s_ptr, ldgs, rows, Cc, accumulate):
     lib().oracle_elu_bwd(C.c_void_p(g_ptr), i64(ldg), C.c_void_p(o_ptr), i64(ldo), C.c_void_p(s_ptr), i64(ldgs),
                          i64(rows), i32(Cc), i32(1 if accumulate else 0))
+
+
+def colstats_raw(x_ptr, ld, rows, Cc):
+    out = np.empty(2 * Cc, np.float64)
+    lib().oracle_colstats(C.c_void_p(x_ptr), i64(ld), i64(rows), i32(Cc), _p(out))
+    return out.reshape(2, Cc)
+
+
+def wgrad_raw(dy_ptr, lddy, x_ptr, ldx, rows, J, Cc, center=None):
+    G = np.empty((J, Cc), np.float64)
+    cen = None if center is None else _c(center, np.float32)
+    lib().oracle_wgrad(C.c_void_p(dy_ptr), i64(lddy), C.c_void_p(x_ptr), i64(ldx), _p(cen) if cen is not None else None,
+                       i64(rows), i32(J), i32(Cc), _p(G))
+    return G
+
+
+def affine_cols_acc_raw(dx_ptr, lddx, x_ptr, ldx, B, Cvec, rows, Cc, center=None):
+    B, Cvec = _c(B, np.float32), _c(Cvec, np.float32)
+    cen = None if center is None else _c(center, np.float32)
+    lib().oracle_affine_cols_acc(C.c_void_p(dx_ptr), i64(lddx), C.c_void_p(x_ptr), i64(ldx), _p(cen) if cen is not None else None,
+                                 _p(B), _p(Cvec), i64(rows), i32(Cc))

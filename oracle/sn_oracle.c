@@ -238,3 +238,33 @@ void oracle_elu_bwd(const float *gdst, int64_t ldg, const float *out, int64_t ld
       *p = accumulate ? *p + d : d;
     }
 }
+
+/* --------------------------------------------------------------------------------------------
+ * Checkers for the BatchNorm+Linear helpers (include/sn_spmm.h): the reductions nn.BatchNorm1d / nn.Linear perform
+ * inside GraphConv1x1 (src/utils/utils_pt.py:83-99), in double precision.
+ * -------------------------------------------------------------------------------------------- */
+void oracle_colstats(const float *x, int64_t ld, int64_t rows, int C, double *out /* [2*C] */) {
+  for (int c = 0; c < 2 * C; ++c) out[c] = 0.0;
+  for (int64_t r = 0; r < rows; ++r)
+    for (int c = 0; c < C; ++c) {
+      const double v = x[r * ld + c];
+      out[c] += v;
+      out[C + c] += v * v;
+    }
+}
+
+void oracle_wgrad(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows, int J,
+                  int C, double *G /* J x C */) {
+  for (int64_t i = 0; i < (int64_t)J * C; ++i) G[i] = 0.0;
+  for (int64_t r = 0; r < rows; ++r)
+    for (int j = 0; j < J; ++j) {
+      const double d = dy[r * lddy + j];
+      for (int c = 0; c < C; ++c) G[(int64_t)j * C + c] += d * (double)(x[r * ldx + c] - (center ? center[c] : 0.0f));
+    }
+}
+
+void oracle_affine_cols_acc(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
+                            const float *Cc, int64_t rows, int C) {
+  for (int64_t r = 0; r < rows; ++r)
+    for (int c = 0; c < C; ++c) dx[r * lddx + c] += fmaf(x[r * ldx + c] - (center ? center[c] : 0.0f), B[c], Cc[c]);
+}

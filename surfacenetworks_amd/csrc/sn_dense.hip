@@ -1,0 +1,321 @@
+// sn_dense.hip — kernels around the per-node BatchNorm+Linear of the residual blocks (gfx950).
+//
+//   colstats_k / colstats_final_k   per-channel sum and sum of squares, fp64 accumulation (HBM-bound, one pass)
+//   wgrad_mfma_k / wgrad_reduce_k   G = dyᵀ·x for tall-skinny operands: split-K over row slabs on the fp32 MFMA
+//                                   (v_mfma_f32_32x32x2_f32: exact fp32, 64 FLOP/clk/SIMD) — the only MFMA use in
+//                                   this library, as the dense per-node MLP is the only GEMM-shaped work on the path
+//   affine_cols_acc_k               dx += x*B[c] + C[c]  (tail of the BatchNorm backward)
+//
+// Interfaces and the reference code they replace: include/sn_spmm.h.
+
+#include <hip/hip_runtime.h>
+#include <limits.h>
+#include <stdint.h>
+
+#include "sn_spmm.h"
+
+namespace {
+
+constexpr int kWG = 256;
+constexpr int kCUs = 256;
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+inline int launch_status() {
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SN_OK : (int)e;
+}
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ------------------------------------------------------------------------------------------------
+// column statistics
+// ------------------------------------------------------------------------------------------------
+constexpr int kStatBlocks = 1024;
+
+// VEC: C % 4 == 0 and (C/4) divides 256: a thread owns 4 adjacent columns and every (256/(C/4))-th row.
+template <bool VEC>
+__global__ __launch_bounds__(kWG) void colstats_k(const float *__restrict__ x, int64_t ld, int64_t rows, int C,
+                                                  double *__restrict__ partial /* [grid][2][C] */) {
+  extern __shared__ double sm[];   // [lanes_r][2][C]
+  const int cw = VEC ? C / 4 : C;              // column groups
+  const int lanes_r = kWG / cw;                // row lanes per block (>= 1)
+  const int cg = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+  if constexpr (VEC) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    if (rl < lanes_r) {
+      const float *p = x + cg * 4;
+      int64_t r = r0 + rl;
+      for (; r + 3 * lanes_r < r1; r += 4 * lanes_r) {     // 4 independent 16-byte loads in flight
+        const f4 a = *reinterpret_cast<const f4 *>(p + r * ld);
+        const f4 b = *reinterpret_cast<const f4 *>(p + (r + lanes_r) * ld);
+        const f4 c = *reinterpret_cast<const f4 *>(p + (r + 2 * lanes_r) * ld);
+        const f4 d = *reinterpret_cast<const f4 *>(p + (r + 3 * lanes_r) * ld);
+#define SN_ACC(v)                                                                    \
+  s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;        \
+  q0 += (double)v.x * v.x; q1 += (double)v.y * v.y; q2 += (double)v.z * v.z; q3 += (double)v.w * v.w;
+        SN_ACC(a) SN_ACC(b) SN_ACC(c) SN_ACC(d)
+      }
+      for (; r < r1; r += lanes_r) {
+        const f4 a = *reinterpret_cast<const f4 *>(p + r * ld);
+        SN_ACC(a)
+#undef SN_ACC
+      }
+      double *o = sm + (int64_t)rl * 2 * C;
+      o[cg * 4] = s0; o[cg * 4 + 1] = s1; o[cg * 4 + 2] = s2; o[cg * 4 + 3] = s3;
+      o[C + cg * 4] = q0; o[C + cg * 4 + 1] = q1; o[C + cg * 4 + 2] = q2; o[C + cg * 4 + 3] = q3;
+    }
+  } else {
+    double s = 0, q = 0;
+    if (rl < lanes_r) {
+      for (int64_t r = r0 + rl; r < r1; r += lanes_r) {
+        const double v = x[r * ld + cg];
+        s += v;
+        q += v * v;
+      }
+      sm[(int64_t)rl * 2 * C + cg] = s;
+      sm[(int64_t)rl * 2 * C + C + cg] = q;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += kWG) {
+    double t = 0;
+    for (int l = 0; l < lanes_r; ++l) t += sm[(int64_t)l * 2 * C + i];      // fixed order
+    partial[(int64_t)blockIdx.x * 2 * C + i] = t;
+  }
+}
+
+__global__ __launch_bounds__(kWG) void colstats_final_k(const double *__restrict__ partial, int nblk, int C2,
+                                                        double *__restrict__ out) {
+  const int i = blockIdx.x * kWG + threadIdx.x;
+  if (i >= C2) return;
+  double t = 0;
+  for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * C2 + i];         // fixed order => deterministic
+  out[i] = t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient G = dyᵀ·x on the fp32 MFMA.
+//
+// v_mfma_f32_32x32x2_f32: D[i][n] += A[i][k]·B[k][n], k = 0,1; lane l supplies A[i = l&31][k = l>>5] and
+// B[k = l>>5][n = l&31].  With k = two consecutive ROWS of the operands, lanes 0-31 read row r, lanes 32-63 row r+1 —
+// i.e. the natural row-major layout, no transposition.  A lane loads 4 adjacent columns with one 16-byte load
+// (32 lanes x 16 B = one 512-byte row of 128 columns); register q of that load then stands for columns 4n+q, so
+// MFMA tile (qa, qb) accumulates G[4i+qa][4n+qb] — a column permutation undone when the tile is written out.
+// Workgroup = 4 waves = one slab of rows; wave w owns dy columns {4i+w} (A register w) and all x columns:
+// (C/128)*4 tiles of 16 accumulators.  Partial 128 x C tiles go to the workspace, reduced in slab order.
+// ------------------------------------------------------------------------------------------------
+template <int CT /* C / 128: 1 or 2 */>
+__global__ __launch_bounds__(kWG, 1) void wgrad_mfma_k(const float *__restrict__ dy, int64_t lddy,
+                                                       const float *__restrict__ x, int64_t ldx,
+                                                       const float *__restrict__ center, int64_t rows,
+                                                       int J /* <= 128, multiple of 4 */, int C,
+                                                       float *__restrict__ partial /* [grid][128][C] */) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = lane & 31, kk = lane >> 5;
+  const int64_t per = (((rows + gridDim.x - 1) / gridDim.x) + 1) & ~(int64_t)1;   // even slab size
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+  f16v acc[CT * 4];
+#pragma unroll
+  for (int t = 0; t < CT * 4; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+  const bool jok = 4 * n < J;                       // dy narrower than 128 columns: missing columns read as 0
+  const float *pd = dy + 4 * n;
+  const float *px = x + 4 * n;
+  f4 mu[CT];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+    mu[c] = center ? *reinterpret_cast<const f4 *>(center + 4 * n + 128 * c) : f4{0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 4;                              // row pairs in flight
+  int64_t r = r0;
+  for (; r + 2 * U <= r1; r += 2 * U) {
+    f4 a[U], b[U][CT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t row = r + 2 * u + kk;
+      a[u] = jok ? *reinterpret_cast<const f4 *>(pd + row * lddy) : f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int c = 0; c < CT; ++c) b[u][c] = *reinterpret_cast<const f4 *>(px + row * ldx + 128 * c) - mu[c];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float av = a[u][wave];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        acc[c * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][c].x, acc[c * 4 + 0], 0, 0, 0);
+        acc[c * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][c].y, acc[c * 4 + 1], 0, 0, 0);
+        acc[c * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][c].z, acc[c * 4 + 2], 0, 0, 0);
+        acc[c * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][c].w, acc[c * 4 + 3], 0, 0, 0);
+      }
+    }
+  }
+  for (; r < r1; r += 2) {                          // tail pairs (second row of the last pair may be past the end)
+    const int64_t row = r + kk;
+    const bool ok = row < r1;
+    const f4 a = (ok && jok) ? *reinterpret_cast<const f4 *>(pd + row * lddy) : f4{0.f, 0.f, 0.f, 0.f};
+    const float av = a[wave];
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const f4 b = ok ? *reinterpret_cast<const f4 *>(px + row * ldx + 128 * c) - mu[c] : f4{0.f, 0.f, 0.f, 0.f};
+      acc[c * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.x, acc[c * 4 + 0], 0, 0, 0);
+      acc[c * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.y, acc[c * 4 + 1], 0, 0, 0);
+      acc[c * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.z, acc[c * 4 + 2], 0, 0, 0);
+      acc[c * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.w, acc[c * 4 + 3], 0, 0, 0);
+    }
+  }
+  // D layout (32x32): column n = lane & 31, row i = (e & 3) + 8*(e >> 2) + 4*(lane >> 5), e = 0..15.
+  float *P = partial + (int64_t)blockIdx.x * 128 * C;
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int qb = 0; qb < 4; ++qb)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int i = (e & 3) + 8 * (e >> 2) + 4 * kk;
+        P[(int64_t)(4 * i + wave) * C + 128 * c + 4 * n + qb] = acc[c * 4 + qb][e];
+      }
+}
+
+__global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ partial, int nslab, int J, int C,
+                                                      float *__restrict__ G) {
+  const int i = blockIdx.x * kWG + threadIdx.x;
+  if (i >= J * C) return;
+  const int j = i / C, c = i - j * C;
+  double t = 0;
+  for (int s = 0; s < nslab; ++s) t += (double)partial[((int64_t)s * 128 + j) * C + c];   // fixed order
+  G[i] = (float)t;
+}
+
+// ------------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(kWG) void affine_cols_acc_k(float *__restrict__ dx, int64_t lddx,
+                                                         const float *__restrict__ x, int64_t ldx,
+                                                         const float *__restrict__ center,
+                                                         const float *__restrict__ B, const float *__restrict__ Cc,
+                                                         int64_t rows, int C) {
+  constexpr int W = VEC ? 4 : 1;
+  const int cw = C / W;
+  const int64_t total = rows * cw;
+  for (int64_t t = (int64_t)blockIdx.x * kWG + threadIdx.x; t < total; t += (int64_t)gridDim.x * kWG) {
+    const int64_t r = t / cw;
+    const int c = (int)(t - r * cw) * W;
+    if constexpr (VEC) {
+      f4 d = *reinterpret_cast<f4 *>(dx + r * lddx + c);
+      f4 xv = *reinterpret_cast<const f4 *>(x + r * ldx + c);
+      if (center) xv -= *reinterpret_cast<const f4 *>(center + c);
+      const f4 b = *reinterpret_cast<const f4 *>(B + c);
+      const f4 k = *reinterpret_cast<const f4 *>(Cc + c);
+      d.x += __builtin_fmaf(xv.x, b.x, k.x);
+      d.y += __builtin_fmaf(xv.y, b.y, k.y);
+      d.z += __builtin_fmaf(xv.z, b.z, k.z);
+      d.w += __builtin_fmaf(xv.w, b.w, k.w);
+      *reinterpret_cast<f4 *>(dx + r * lddx + c) = d;
+    } else {
+      dx[r * lddx + c] += __builtin_fmaf(x[r * ldx + c] - (center ? center[c] : 0.f), B[c], Cc[c]);
+    }
+  }
+}
+
+inline int stat_blocks(int64_t rows) {
+  int64_t b = (rows + 63) / 64;
+  if (b > kStatBlocks) b = kStatBlocks;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+inline int wgrad_slabs(int64_t rows) {
+  int64_t b = (rows + 255) / 256;          // at least 256 rows per slab
+  const int64_t cap = 2 * kCUs;            // one 4-wave workgroup per CU (launch_bounds 1 wave/SIMD), two rounds
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sn_colstats_workspace_bytes(int64_t rows, int32_t C) {
+  if (C < 1) return 0;
+  return (size_t)stat_blocks(rows) * 2 * (size_t)C * sizeof(double);
+}
+
+int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *out, void *workspace,
+                    size_t workspace_bytes, void *stream) {
+  if (rows < 0 || C < 1 || C > 4096 || ld < C) return SN_E_SHAPE;
+  if (!out) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows == 0) {
+    hipError_t e = hipMemsetAsync(out, 0, (size_t)2 * C * sizeof(double), s);
+    return e == hipSuccess ? SN_OK : (int)e;
+  }
+  if (!x || !workspace) return SN_E_NULL;
+  if (workspace_bytes < sn_colstats_workspace_bytes(rows, C)) return SN_E_WORKSPACE;
+  const int nblk = stat_blocks(rows);
+  double *partial = static_cast<double *>(workspace);
+  const bool vec = (C % 4 == 0) && (kWG % (C / 4) == 0) && (ld % 4 == 0) && aligned16(x);
+  const int cw = vec ? C / 4 : C;
+  if (!vec && cw > kWG) return SN_E_UNSUPPORTED;
+  const int lanes_r = kWG / cw;
+  const size_t shm = (size_t)lanes_r * 2 * C * sizeof(double);
+  if (vec)
+    hipLaunchKernelGGL((colstats_k<true>), dim3(nblk), dim3(kWG), shm, s, x, ld, rows, (int)C, partial);
+  else
+    hipLaunchKernelGGL((colstats_k<false>), dim3(nblk), dim3(kWG), shm, s, x, ld, rows, (int)C, partial);
+  hipLaunchKernelGGL(colstats_final_k, dim3((2 * C + kWG - 1) / kWG), dim3(kWG), 0, s, partial, nblk, 2 * (int)C, out);
+  return launch_status();
+}
+
+size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C) {
+  (void)J;
+  if (C < 1) return 0;
+  return (size_t)wgrad_slabs(rows) * 128 * (size_t)C * sizeof(float);
+}
+
+int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                 int32_t J, int32_t C, float *G, void *workspace, size_t workspace_bytes, void *stream) {
+  if (rows < 0 || J < 1 || C < 1 || lddy < J || ldx < C) return SN_E_SHAPE;
+  if (J > 128 || (J % 4) || (C != 128 && C != 256)) return SN_E_UNSUPPORTED;
+  if (!G) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows == 0) {
+    hipError_t e = hipMemsetAsync(G, 0, (size_t)J * C * sizeof(float), s);
+    return e == hipSuccess ? SN_OK : (int)e;
+  }
+  if (!dy || !x || !workspace) return SN_E_NULL;
+  if (!aligned16(dy) || !aligned16(x) || (center && !aligned16(center)) || (lddy % 4) || (ldx % 4)) return SN_E_ALIGN;
+  if (workspace_bytes < sn_wgrad_workspace_bytes(rows, J, C)) return SN_E_WORKSPACE;
+  const int nslab = wgrad_slabs(rows);
+  float *partial = static_cast<float *>(workspace);
+  if (C == 128)
+    hipLaunchKernelGGL((wgrad_mfma_k<1>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial);
+  else
+    hipLaunchKernelGGL((wgrad_mfma_k<2>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((J * C + kWG - 1) / kWG), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G);
+  return launch_status();
+}
+
+int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
+                           const float *Cc, int64_t rows, int32_t C, void *stream) {
+  if (rows < 0 || C < 1 || lddx < C || ldx < C) return SN_E_SHAPE;
+  if (rows == 0) return SN_OK;
+  if (!dx || !x || !B || !Cc) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (C % 4 == 0) && (lddx % 4 == 0) && (ldx % 4 == 0) && aligned16(dx) && aligned16(x) && aligned16(B) &&
+                   aligned16(Cc) && (!center || aligned16(center));
+  int64_t items = vec ? rows * (C / 4) : rows * (int64_t)C;
+  int64_t blocks = (items + kWG - 1) / kWG;
+  if (blocks > (int64_t)kCUs * 16) blocks = (int64_t)kCUs * 16;
+  if (vec)
+    hipLaunchKernelGGL((affine_cols_acc_k<true>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C);
+  else
+    hipLaunchKernelGGL((affine_cols_acc_k<false>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C);
+  return launch_status();
+}
+
+}  // extern "C"

@@ -18,7 +18,7 @@ import torch
 from . import kernels
 from .operators import SparseOperator, as_operator
 
-__all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "set_dirac_format", "SpmmTimer"]
+__all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "bn_linear", "set_dirac_format", "SpmmTimer"]
 
 _USE_BSR4 = True
 
@@ -230,3 +230,79 @@ def dirac_vert_stage(DiA, f_out2d: torch.Tensor, e_v2d: torch.Tensor) -> torch.T
     if op.shape[0] != 4 * e_v2d.shape[0] or op.shape[1] != 4 * f_out2d.shape[0]:
         raise ValueError(f"dirac_vert_stage: DiA is {tuple(op.shape)}, v rows {e_v2d.shape[0]}, f rows {f_out2d.shape[0]}")
     return _DiracVertStage.apply(f_out2d, e_v2d, op)
+
+
+class _BNLinear(torch.autograd.Function):
+    """BatchNorm1d("pre") + Linear of GraphConv1x1 (src/utils/utils_pt.py:83-99) on a (rows, C) operand without
+    materialising the normalised tensor.
+
+    forward : per-channel sum / sum of squares in ONE pass (fp64 accumulation), BN folded into the weights:
+              y = x·(W·diag(s))ᵀ + (b + W·t),  s = gamma*invstd,  t = beta - mean*s.
+    backward: G = dyᵀ·x (split-K fp32-MFMA kernel) and colsum(dy) give every BatchNorm reduction algebraically:
+              sum_r dz = colsum(dy)·W,  sum_r dz∘x = sum_j W∘G;  then dx = dy·(W·diag(s)) + x∘B + C in one GEMM + one
+              fused elementwise pass.  Running statistics follow nn.BatchNorm1d (momentum, unbiased running_var).
+    """
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps):
+        x = _rows2d(x)
+        rows, C = x.shape
+        if training:
+            st = kernels.colstats(x)
+            mean = st[0] / rows
+            var = (st[1] / rows - mean * mean).clamp_min_(0.0)
+            with torch.no_grad():
+                if running_mean is not None:
+                    unbiased = var * (rows / max(rows - 1, 1))
+                    running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
+                    running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
+        else:
+            mean, var = running_mean.double(), running_var.double()
+        invstd = torch.rsqrt(var + eps)
+        s64 = gamma.double() * invstd
+        t64 = beta.double() - mean * s64
+        s, t = s64.float(), t64.float()
+        Wf = W * s
+        bf = torch.addmv(b, W, t) if b is not None else torch.mv(W, t)
+        y = torch.addmm(bf, x, Wf.t())
+        ctx.save_for_backward(x, W, Wf, s, t, mean, invstd)
+        ctx.training, ctx.has_bias = training, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W, Wf, s, t, mean, invstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        rows, C = x.shape
+        J = dy.shape[1]
+        mu = mean.float().contiguous()
+        # Gc = dyᵀ·(x - mean): centring inside the kernel leaves no fp32 cancellation against mean·colsum(dy)
+        Gc = kernels.wgrad(dy, x, mu) if kernels.wgrad_supported(J, C) else dy.t().mm(x - mu)
+        sdy = kernels.colstats(dy)[0]                       # (J,) float64
+        G64, W64 = Gc.double(), W.double()
+        a = sdy @ W64                                        # sum_r dz
+        p = (W64 * G64).sum(0)                               # sum_r dz∘(x - mean)
+        dgamma64 = invstd * p
+        # z = s∘(x - mean) + beta  =>  dW = s∘Gc + colsum(dy) ⊗ beta ;  beta = t + mean∘s
+        beta64 = t.double() + mean * s.double()
+        dW = (G64 * s.double() + torch.outer(sdy, beta64)).float()
+        db = sdy.float() if ctx.has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = dy.mm(Wf)
+            if ctx.training:
+                Bc = -(s.double() * invstd * dgamma64) / rows
+                Cc = -(s.double() * a) / rows
+                kernels.affine_cols_acc(dx, x, Bc.float().contiguous(), Cc.float().contiguous(), mu)
+        return dx, dgamma64.float(), a.float(), dW, db, None, None, None, None, None
+
+
+def bn_linear(x2d: torch.Tensor, bn: torch.nn.BatchNorm1d, fc: torch.nn.Linear) -> torch.Tensor:
+    """Fused BatchNorm1d + Linear on a (rows, C) fp32 operand; updates bn's running statistics like nn.BatchNorm1d."""
+    training = bn.training or not bn.track_running_stats
+    if bn.momentum is None or not bn.affine:
+        raise NotImplementedError("bn_linear supports the default affine BatchNorm1d with a fixed momentum")
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return _BNLinear.apply(x2d, bn.weight, bn.bias, fc.weight, fc.bias, bn.running_mean, bn.running_var, training,
+                           bn.momentum, bn.eps)

@@ -13,7 +13,7 @@ from . import _lib
 
 __all__ = [
     "spmm_csr", "spmm_bsr4", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
-    "elu_into", "elu_bwd",
+    "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
 ]
 
 
@@ -141,3 +141,40 @@ def elu_bwd(gdst, out, gsrc, accumulate: bool) -> None:
         raise ValueError("elu_bwd: shape mismatch")
     _lib.call("sn_elu_bwd_acc_f32", _p(gdst), _ld(gdst), _p(out), _ld(out), _p(gsrc), _ld(gsrc), out.shape[0],
               out.shape[1], 1 if accumulate else 0, _stream())
+
+
+def colstats(x):
+    """(2, C) float64: column sums and column sums of squares of the 2-D view x (contiguous rows, any row stride)."""
+    _dev(x)
+    rows, C = x.shape
+    out = torch.empty((2, C), dtype=torch.float64, device=x.device)
+    ws_bytes = int(_lib.load().sn_colstats_workspace_bytes(rows, C))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.call("sn_colstats_f32", _p(x), _ld(x), rows, C, _p(out), _p(ws), ws_bytes, _stream())
+    return out
+
+
+def wgrad_supported(J: int, C: int) -> bool:
+    return C in (128, 256) and J <= 128 and J % 4 == 0
+
+
+def wgrad(dy, x, center=None):
+    """G = dy^T · (x - center) (J x C, fp32) for tall-skinny operands on the fp32 MFMA; see sn_wgrad_f32."""
+    _dev(dy, x, center)
+    rows, J = dy.shape
+    C = x.shape[1]
+    if x.shape[0] != rows:
+        raise ValueError("wgrad: row mismatch")
+    G = torch.empty((J, C), dtype=torch.float32, device=x.device)
+    ws_bytes = int(_lib.load().sn_wgrad_workspace_bytes(rows, J, C))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.call("sn_wgrad_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, J, C, _p(G), _p(ws), ws_bytes, _stream())
+    return G
+
+
+def affine_cols_acc(dx, x, B, Cc, center=None) -> None:
+    """dx[r,c] += (x[r,c] - center[c])*B[c] + Cc[c] in place."""
+    _dev(dx, x, B, Cc, center)
+    if dx.shape != x.shape or B.numel() != x.shape[1] or Cc.numel() != x.shape[1]:
+        raise ValueError("affine_cols_acc: shape mismatch")
+    _lib.call("sn_affine_cols_acc_f32", _p(dx), _ld(dx), _p(x), _ld(x), _p(center), _p(B), _p(Cc), x.shape[0], x.shape[1], _stream())

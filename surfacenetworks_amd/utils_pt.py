@@ -100,6 +100,8 @@ class GraphConv1x1(nn.Module):
     def forward2d(self, x2d):
         """(rows, Cin) -> (rows, Cout) on the flattened node axis."""
         if self.batch_norm == "pre":
+            if x2d.dtype == torch.float32 and self.bn.affine and self.bn.momentum is not None:
+                return snF.bn_linear(x2d, self.bn, self.fc)      # one statistics pass + folded GEMM (functional.py)
             x2d = self.bn(x2d)
         x2d = self.fc(x2d)
         if self.batch_norm == "post":

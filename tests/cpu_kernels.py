@@ -65,6 +65,25 @@ def elu_bwd(gdst, out, gsrc, accumulate):
                          out.shape[1], accumulate)
 
 
+def colstats(x):
+    return torch.from_numpy(c_oracle.colstats_raw(x.data_ptr(), _ld(x), x.shape[0], x.shape[1]))
+
+
+def wgrad_supported(J, C):
+    return C in (128, 256) and J <= 128 and J % 4 == 0
+
+
+def wgrad(dy, x, center=None):
+    G = c_oracle.wgrad_raw(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), x.shape[0], dy.shape[1], x.shape[1],
+                           None if center is None else _np(center))
+    return torch.from_numpy(G.astype(np.float32))
+
+
+def affine_cols_acc(dx, x, B, Cc, center=None):
+    c_oracle.affine_cols_acc_raw(dx.data_ptr(), _ld(dx), x.data_ptr(), _ld(x), _np(B), _np(Cc), x.shape[0], x.shape[1],
+                                 None if center is None else _np(center))
+
+
 def install(monkeypatch=None):
     """Patch surfacenetworks_amd.kernels in place (monkeypatch=None: permanent, for spawned worker processes)."""
     from surfacenetworks_amd import kernels

@@ -1,0 +1,118 @@
+"""GPU parity of the BatchNorm+Linear helper kernels (colstats fp64, fp32-MFMA weight gradient, affine epilogue) and of
+the fused bn_linear Function against nn.BatchNorm1d + nn.Linear (the layers GraphConv1x1 is made of in the reference,
+src/utils/utils_pt.py:83-99)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import rel_err
+from oracle import c_oracle
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+from surfacenetworks_amd import functional as snF, kernels  # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("rows,C", [(1, 256), (63, 256), (1000, 128), (20011, 256), (4097, 64), (300, 120), (77, 3), (5000, 6)])
+def test_colstats(rows, C):
+    rng = np.random.default_rng(rows + C)
+    x = (rng.standard_normal((rows, C)) * 3 + 100.0 * rng.standard_normal(C)).astype(np.float32)   # |mean| >> std
+    want = c_oracle.colstats_raw(x.ctypes.data, C, rows, C)
+    got = kernels.colstats(dev(x)).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+    # strided view (first half of a wider buffer)
+    if C % 4 == 0:
+        wide = np.concatenate([x, x[:, ::-1]], 1).copy()
+        got2 = kernels.colstats(dev(wide)[:, :C]).cpu().numpy()
+        assert np.allclose(got2, want, rtol=1e-12, atol=0)
+
+
+@pytest.mark.parametrize("rows", [1, 2, 7, 255, 256, 1000, 33333, 400001])
+@pytest.mark.parametrize("J,C", [(128, 256), (128, 128), (120, 128), (64, 128), (4, 256)])
+def test_wgrad_mfma(rows, J, C):
+    rng = np.random.default_rng(rows * 7 + J + C)
+    dy = rng.standard_normal((rows, J)).astype(np.float32)
+    x = rng.standard_normal((rows, C)).astype(np.float32)
+    # asymmetric operands catch transposed / permuted tiles
+    x[:, 0] += 3.0
+    dy[:, min(1, J - 1)] -= 2.0
+    want = dy.astype(np.float64).T @ x.astype(np.float64)
+    got = kernels.wgrad(dev(dy), dev(x)).cpu().numpy()
+    assert got.shape == (J, C)
+    assert rel_err(got, want) < 2e-6
+    # centred operand (BatchNorm backward passes the batch mean)
+    cen = (rng.standard_normal(C) * 5).astype(np.float32)
+    got_c = kernels.wgrad(dev(dy), dev(x), dev(cen)).cpu().numpy()
+    assert rel_err(got_c, dy.astype(np.float64).T @ (x - cen).astype(np.float64)) < 2e-6
+    # x as a strided half of a concat buffer
+    if rows > 1:
+        wide = dev(np.concatenate([x, np.zeros_like(x)], 1))
+        got2 = kernels.wgrad(dev(dy), wide[:, :C]).cpu().numpy()
+        assert np.array_equal(got2, got)
+
+
+def test_wgrad_exact_tile_mapping():
+    """dy = one-hot rows, x = distinct integers: G must reproduce x rows exactly at the right (j, c)."""
+    rows, J, C = 64, 128, 256
+    dy = np.zeros((rows, J), np.float32)
+    for r in range(rows):
+        dy[r, (5 * r + 3) % J] = 1.0
+    x = (np.arange(rows * C, dtype=np.float32).reshape(rows, C) % 4093)
+    want = dy.T @ x
+    got = kernels.wgrad(dev(dy), dev(x)).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_affine_cols_acc():
+    rng = np.random.default_rng(0)
+    for rows, C in [(1001, 256), (17, 7)]:
+        dx = rng.standard_normal((rows, C)).astype(np.float32)
+        x = rng.standard_normal((rows, C)).astype(np.float32)
+        B = rng.standard_normal(C).astype(np.float32)
+        Cc = rng.standard_normal(C).astype(np.float32)
+        for cen in (None, rng.standard_normal(C).astype(np.float32)):
+            want = dx.copy()
+            c_oracle.affine_cols_acc_raw(want.ctypes.data, C, x.ctypes.data, C, B, Cc, rows, C, cen)
+            d = dev(dx)
+            kernels.affine_cols_acc(d, dev(x), dev(B), dev(Cc), None if cen is None else dev(cen))
+            assert np.array_equal(d.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("rows,C,J,train", [(5000, 256, 128, True), (5000, 256, 128, False), (3001, 128, 120, True),
+                                             (2000, 128, 64, True), (999, 64, 64, True), (50, 6, 128, True)])
+def test_bn_linear_matches_torch_layers(rows, C, J, train):
+    """Fused function vs nn.BatchNorm1d + nn.Linear in float64 (the exact answer) and float32 (the reference's layers)."""
+    torch.manual_seed(rows + C + J)
+    bn = torch.nn.BatchNorm1d(C).to(DEV)
+    fc = torch.nn.Linear(C, J).to(DEV)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+        bn.running_mean.uniform_(-1, 1)
+        bn.running_var.uniform_(0.5, 2)
+    import copy
+
+    bn64, fc64 = copy.deepcopy(bn).double(), copy.deepcopy(fc).double()
+    bn32, fc32 = copy.deepcopy(bn), copy.deepcopy(fc)
+    for m in (bn, bn64, bn32):
+        m.train(train)
+    x0 = torch.randn(rows, C, device=DEV) * 2 + 5 * torch.randn(C, device=DEV)
+    gy = torch.randn(rows, J, device=DEV)
+    outs = {}
+    for tag, b, f, dt in (("fused", bn, fc, torch.float32), ("t32", bn32, fc32, torch.float32), ("t64", bn64, fc64, torch.float64)):
+        x = x0.to(dt).clone().requires_grad_(True)
+        y = snF.bn_linear(x, b, f) if tag == "fused" else f(b(x))
+        y.backward(gy.to(dt))
+        outs[tag] = [y.detach(), x.grad, b.weight.grad, b.bias.grad, f.weight.grad, f.bias.grad, b.running_mean.clone(),
+                     b.running_var.clone()]
+    names = ["y", "dx", "dgamma", "dbeta", "dW", "db", "running_mean", "running_var"]
+    for n, a, b32, b64 in zip(names, outs["fused"], outs["t32"], outs["t64"]):
+        e_f = rel_err(a.double().cpu().numpy(), b64.cpu().numpy())
+        e_t = rel_err(b32.double().cpu().numpy(), b64.cpu().numpy())
+        assert e_f <= max(4 * e_t, 2e-6), (n, "fused err", e_f, "torch fp32 err", e_t)
+    assert int(bn.num_batches_tracked) == int(bn32.num_batches_tracked)
