@@ -31,7 +31,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // ------------------------------------------------------------------------------------------------
 // column statistics
 // ------------------------------------------------------------------------------------------------
-constexpr int kStatBlocks = 1024;
+constexpr int kStatBlocks = 512;
 
 // VEC: C % 4 == 0 and (C/4) divides 256: a thread owns 4 adjacent columns and every (256/(C/4))-th row.
 template <bool VEC>
@@ -88,13 +88,23 @@ __global__ __launch_bounds__(kWG) void colstats_k(const float *__restrict__ x, i
   }
 }
 
+// 32 columns x 8 partial groups per block; group g sums partial blocks g, g+8, ... ; groups combined in fixed order.
 __global__ __launch_bounds__(kWG) void colstats_final_k(const double *__restrict__ partial, int nblk, int C2,
                                                         double *__restrict__ out) {
-  const int i = blockIdx.x * kWG + threadIdx.x;
-  if (i >= C2) return;
+  __shared__ double sm[8][32];
+  const int cg = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + cg;
   double t = 0;
-  for (int b = 0; b < nblk; ++b) t += partial[(int64_t)b * C2 + i];         // fixed order => deterministic
-  out[i] = t;
+  if (i < C2)
+    for (int b = pg; b < nblk; b += 8) t += partial[(int64_t)b * C2 + i];
+  sm[pg][cg] = t;
+  __syncthreads();
+  if (pg == 0 && i < C2) {
+    double r = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) r += sm[g][cg];
+    out[i] = r;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -109,7 +119,7 @@ __global__ __launch_bounds__(kWG) void colstats_final_k(const double *__restrict
 // (C/128)*4 tiles of 16 accumulators.  Partial 128 x C tiles go to the workspace, reduced in slab order.
 // ------------------------------------------------------------------------------------------------
 template <int CT /* C / 128: 1 or 2 */>
-__global__ __launch_bounds__(kWG, 1) void wgrad_mfma_k(const float *__restrict__ dy, int64_t lddy,
+__global__ __launch_bounds__(kWG, 2) void wgrad_mfma_k(const float *__restrict__ dy, int64_t lddy,
                                                        const float *__restrict__ x, int64_t ldx,
                                                        const float *__restrict__ center, int64_t rows,
                                                        int J /* <= 128, multiple of 4 */, int C,
@@ -131,27 +141,46 @@ __global__ __launch_bounds__(kWG, 1) void wgrad_mfma_k(const float *__restrict__
 #pragma unroll
   for (int c = 0; c < CT; ++c)
     mu[c] = center ? *reinterpret_cast<const f4 *>(center + 4 * n + 128 * c) : f4{0.f, 0.f, 0.f, 0.f};
-  constexpr int U = 4;                              // row pairs in flight
+  constexpr int U = 4;                              // row pairs per group; two groups of loads are in flight
   int64_t r = r0;
-  for (; r + 2 * U <= r1; r += 2 * U) {
-    f4 a[U], b[U][CT];
+  float a[2][U];                                    // this wave only needs dy column 4n + wave
+  f4 b[2][U][CT];
+  auto load_group = [&](int buf, int64_t rb) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int64_t row = r + 2 * u + kk;
-      a[u] = jok ? *reinterpret_cast<const f4 *>(pd + row * lddy) : f4{0.f, 0.f, 0.f, 0.f};
+      const int64_t row = rb + 2 * u + kk;
+      a[buf][u] = jok ? pd[row * lddy + wave] : 0.f;
 #pragma unroll
-      for (int c = 0; c < CT; ++c) b[u][c] = *reinterpret_cast<const f4 *>(px + row * ldx + 128 * c) - mu[c];
+      for (int c = 0; c < CT; ++c) b[buf][u][c] = *reinterpret_cast<const f4 *>(px + row * ldx + 128 * c);
     }
+  };
+  auto mfma_group = [&](int buf) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const float av = a[u][wave];
+      const float av = a[buf][u];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
-        acc[c * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][c].x, acc[c * 4 + 0], 0, 0, 0);
-        acc[c * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][c].y, acc[c * 4 + 1], 0, 0, 0);
-        acc[c * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][c].z, acc[c * 4 + 2], 0, 0, 0);
-        acc[c * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b[u][c].w, acc[c * 4 + 3], 0, 0, 0);
+        const f4 bv = b[buf][u][c] - mu[c];
+        acc[c * 4 + 0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.x, acc[c * 4 + 0], 0, 0, 0);
+        acc[c * 4 + 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.y, acc[c * 4 + 1], 0, 0, 0);
+        acc[c * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.z, acc[c * 4 + 2], 0, 0, 0);
+        acc[c * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv.w, acc[c * 4 + 3], 0, 0, 0);
       }
+    }
+  };
+  const int64_t ngroups = (r1 - r0) / (2 * U);
+  if (ngroups > 0) {
+    load_group(0, r);
+    for (int64_t g = 0; g + 1 < ngroups; g += 2) {      // steady state: loads of the next group fly under the MFMAs
+      load_group(1, r + 2 * U);
+      mfma_group(0);
+      if (g + 2 < ngroups) load_group(0, r + 4 * U);
+      mfma_group(1);
+      r += 4 * U;
+    }
+    if (ngroups & 1) {
+      mfma_group(0);
+      r += 2 * U;
     }
   }
   for (; r < r1; r += 2) {                          // tail pairs (second row of the last pair may be past the end)
@@ -183,12 +212,15 @@ __global__ __launch_bounds__(kWG, 1) void wgrad_mfma_k(const float *__restrict__
 
 __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ partial, int nslab, int J, int C,
                                                       float *__restrict__ G) {
-  const int i = blockIdx.x * kWG + threadIdx.x;
-  if (i >= J * C) return;
-  const int j = i / C, c = i - j * C;
+  __shared__ double sm[4][64];
+  const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;            // output element j*C + c  (partials are laid out [slab][128][C])
   double t = 0;
-  for (int s = 0; s < nslab; ++s) t += (double)partial[((int64_t)s * 128 + j) * C + c];   // fixed order
-  G[i] = (float)t;
+  if (i < J * C)
+    for (int sl = g; sl < nslab; sl += 4) t += (double)partial[(int64_t)sl * 128 * C + i];
+  sm[g][o] = t;
+  __syncthreads();
+  if (g == 0 && i < J * C) G[i] = (float)(sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -221,6 +253,92 @@ __global__ __launch_bounds__(kWG) void affine_cols_acc_k(float *__restrict__ dx,
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm folding coefficients.  One workgroup per output row j of Wf (plus its bias dot product);
+// every workgroup recomputes the C per-channel scalars in double (C <= 1024), workgroup 0 publishes them.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void bn_fold_k(const double *__restrict__ stats, int64_t rows,
+                                                 const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                 const float *__restrict__ W, const float *__restrict__ b, int C,
+                                                 double eps, double momentum, int training,
+                                                 float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                 float *__restrict__ mean_o, float *__restrict__ invstd_o,
+                                                 float *__restrict__ s_o, float *__restrict__ t_o,
+                                                 float *__restrict__ Wf, float *__restrict__ bf) {
+  __shared__ float ss[1024], st[1024];
+  __shared__ double red[kWG];
+  const int j = blockIdx.x;
+  for (int c = threadIdx.x; c < C; c += kWG) {
+    double mean, var;
+    if (training) {
+      mean = stats[c] / (double)rows;
+      var = stats[C + c] / (double)rows - mean * mean;
+      var = var > 0 ? var : 0;
+    } else {
+      mean = running_mean[c];
+      var = running_var[c];
+    }
+    const double invstd = 1.0 / sqrt(var + eps);
+    const double sc = (double)gamma[c] * invstd;
+    const double tc = (double)beta[c] - mean * sc;
+    ss[c] = (float)sc;
+    st[c] = (float)tc;
+    if (j == 0) {
+      mean_o[c] = (float)mean;
+      invstd_o[c] = (float)invstd;
+      s_o[c] = (float)sc;
+      t_o[c] = (float)tc;
+      if (training && running_mean) {
+        const double unbiased = var * ((double)rows / (double)(rows > 1 ? rows - 1 : 1));
+        running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+      }
+    }
+  }
+  __syncthreads();
+  double dot = 0;
+  for (int c = threadIdx.x; c < C; c += kWG) {
+    const float w = W[(int64_t)j * C + c];
+    Wf[(int64_t)j * C + c] = w * ss[c];
+    dot += (double)w * (double)st[c];
+  }
+  red[threadIdx.x] = dot;
+  __syncthreads();
+  for (int o = kWG / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) bf[j] = (float)((b ? (double)b[j] : 0.0) + red[0]);
+}
+
+// one thread per channel c: reductions over the J output rows (coalesced across channels)
+__global__ __launch_bounds__(kWG) void bn_bwd_coeffs_k(const float *__restrict__ Gc, const double *__restrict__ sdy,
+                                                       const float *__restrict__ W, const float *__restrict__ s,
+                                                       const float *__restrict__ invstd, const float *__restrict__ beta,
+                                                       int64_t rows, int J, int C, float *__restrict__ dW,
+                                                       float *__restrict__ db, float *__restrict__ dgamma,
+                                                       float *__restrict__ dbeta, float *__restrict__ Bc,
+                                                       float *__restrict__ Cc) {
+  const int c = blockIdx.x * kWG + threadIdx.x;
+  if (c < J && db) db[c] = (float)sdy[c];
+  if (c >= C) return;
+  double a = 0, p = 0;
+  const double sc = s[c], bc = beta[c];
+  for (int j = 0; j < J; ++j) {
+    const double w = W[(int64_t)j * C + c], g = Gc[(int64_t)j * C + c];
+    a += sdy[j] * w;
+    p += w * g;
+    dW[(int64_t)j * C + c] = (float)(g * sc + sdy[j] * bc);
+  }
+  const double is = invstd[c];
+  const double dg = is * p;
+  dgamma[c] = (float)dg;
+  dbeta[c] = (float)a;
+  Bc[c] = (float)(-(sc * is * dg) / (double)rows);
+  Cc[c] = (float)(-(sc * a) / (double)rows);
+}
+
 inline int stat_blocks(int64_t rows) {
   int64_t b = (rows + 63) / 64;
   if (b > kStatBlocks) b = kStatBlocks;
@@ -230,7 +348,7 @@ inline int stat_blocks(int64_t rows) {
 
 inline int wgrad_slabs(int64_t rows) {
   int64_t b = (rows + 255) / 256;          // at least 256 rows per slab
-  const int64_t cap = 2 * kCUs;            // one 4-wave workgroup per CU (launch_bounds 1 wave/SIMD), two rounds
+  const int64_t cap = 2 * kCUs;            // two 4-wave workgroups per CU (2 waves/SIMD), one round
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
@@ -267,7 +385,7 @@ int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double 
     hipLaunchKernelGGL((colstats_k<true>), dim3(nblk), dim3(kWG), shm, s, x, ld, rows, (int)C, partial);
   else
     hipLaunchKernelGGL((colstats_k<false>), dim3(nblk), dim3(kWG), shm, s, x, ld, rows, (int)C, partial);
-  hipLaunchKernelGGL(colstats_final_k, dim3((2 * C + kWG - 1) / kWG), dim3(kWG), 0, s, partial, nblk, 2 * (int)C, out);
+  hipLaunchKernelGGL(colstats_final_k, dim3((2 * C + 31) / 32), dim3(kWG), 0, s, partial, nblk, 2 * (int)C, out);
   return launch_status();
 }
 
@@ -296,7 +414,7 @@ int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, con
     hipLaunchKernelGGL((wgrad_mfma_k<1>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial);
   else
     hipLaunchKernelGGL((wgrad_mfma_k<2>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial);
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((J * C + kWG - 1) / kWG), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((J * C + 63) / 64), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G);
   return launch_status();
 }
 
@@ -315,6 +433,29 @@ int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx,
     hipLaunchKernelGGL((affine_cols_acc_k<true>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C);
   else
     hipLaunchKernelGGL((affine_cols_acc_k<false>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C);
+  return launch_status();
+}
+
+int sn_bn_fold_f32(const double *stats, int64_t rows, const float *gamma, const float *beta, const float *W,
+                   const float *b, int32_t J, int32_t C, double eps, double momentum, int32_t training,
+                   float *running_mean, float *running_var, float *mean, float *invstd, float *s, float *t,
+                   float *Wf, float *bf, void *stream) {
+  if (rows < 0 || J < 1 || C < 1 || C > 1024) return SN_E_SHAPE;
+  if (!gamma || !beta || !W || !mean || !invstd || !s || !t || !Wf || !bf) return SN_E_NULL;
+  if (training ? !stats : (!running_mean || !running_var)) return SN_E_NULL;
+  hipLaunchKernelGGL(bn_fold_k, dim3(J), dim3(kWG), 0, static_cast<hipStream_t>(stream), stats, rows, gamma, beta, W,
+                     b, (int)C, eps, momentum, (int)training, running_mean, running_var, mean, invstd, s, t, Wf, bf);
+  return launch_status();
+}
+
+int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W, const float *s, const float *invstd,
+                         const float *beta, int64_t rows, int32_t J, int32_t C, float *dW, float *db, float *dgamma,
+                         float *dbeta, float *Bc, float *Cc, void *stream) {
+  if (rows < 1 || J < 1 || C < 1) return SN_E_SHAPE;
+  if (!Gc || !dystats || !W || !s || !invstd || !beta || !dW || !dgamma || !dbeta || !Bc || !Cc) return SN_E_NULL;
+  const int n = C > J ? C : J;
+  hipLaunchKernelGGL(bn_bwd_coeffs_k, dim3((n + kWG - 1) / kWG), dim3(kWG), 0, static_cast<hipStream_t>(stream), Gc,
+                     dystats, W, s, invstd, beta, rows, (int)J, (int)C, dW, db, dgamma, dbeta, Bc, Cc);
   return launch_status();
 }
 

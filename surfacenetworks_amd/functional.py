@@ -246,55 +246,31 @@ class _BNLinear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps):
         x = _rows2d(x)
-        rows, C = x.shape
-        if training:
-            st = kernels.colstats(x)
-            mean = st[0] / rows
-            var = (st[1] / rows - mean * mean).clamp_min_(0.0)
-            with torch.no_grad():
-                if running_mean is not None:
-                    unbiased = var * (rows / max(rows - 1, 1))
-                    running_mean.mul_(1 - momentum).add_(mean.to(running_mean.dtype), alpha=momentum)
-                    running_var.mul_(1 - momentum).add_(unbiased.to(running_var.dtype), alpha=momentum)
-        else:
-            mean, var = running_mean.double(), running_var.double()
-        invstd = torch.rsqrt(var + eps)
-        s64 = gamma.double() * invstd
-        t64 = beta.double() - mean * s64
-        s, t = s64.float(), t64.float()
-        Wf = W * s
-        bf = torch.addmv(b, W, t) if b is not None else torch.mv(W, t)
+        rows = x.shape[0]
+        stats = kernels.colstats(x) if training else None
+        mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training,
+                                                     running_mean, running_var)
         y = torch.addmm(bf, x, Wf.t())
-        ctx.save_for_backward(x, W, Wf, s, t, mean, invstd)
+        ctx.save_for_backward(x, W, Wf, s, mean, invstd, beta)
         ctx.training, ctx.has_bias = training, b is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W, Wf, s, t, mean, invstd = ctx.saved_tensors
+        x, W, Wf, s, mean, invstd, beta = ctx.saved_tensors
         dy = dy.contiguous()
         rows, C = x.shape
         J = dy.shape[1]
-        mu = mean.float().contiguous()
         # Gc = dyᵀ·(x - mean): centring inside the kernel leaves no fp32 cancellation against mean·colsum(dy)
-        Gc = kernels.wgrad(dy, x, mu) if kernels.wgrad_supported(J, C) else dy.t().mm(x - mu)
-        sdy = kernels.colstats(dy)[0]                       # (J,) float64
-        G64, W64 = Gc.double(), W.double()
-        a = sdy @ W64                                        # sum_r dz
-        p = (W64 * G64).sum(0)                               # sum_r dz∘(x - mean)
-        dgamma64 = invstd * p
-        # z = s∘(x - mean) + beta  =>  dW = s∘Gc + colsum(dy) ⊗ beta ;  beta = t + mean∘s
-        beta64 = t.double() + mean * s.double()
-        dW = (G64 * s.double() + torch.outer(sdy, beta64)).float()
-        db = sdy.float() if ctx.has_bias else None
+        Gc = kernels.wgrad(dy, x, mean) if kernels.wgrad_supported(J, C) else dy.t().mm(x - mean)
+        dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, kernels.colstats(dy), W, s, invstd, beta, rows,
+                                                               ctx.has_bias)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = dy.mm(Wf)
             if ctx.training:
-                Bc = -(s.double() * invstd * dgamma64) / rows
-                Cc = -(s.double() * a) / rows
-                kernels.affine_cols_acc(dx, x, Bc.float().contiguous(), Cc.float().contiguous(), mu)
-        return dx, dgamma64.float(), a.float(), dW, db, None, None, None, None, None
+                kernels.affine_cols_acc(dx, x, Bc, Cc, mean)
+        return dx, dgamma, dbeta, dW, db, None, None, None, None, None
 
 
 def bn_linear(x2d: torch.Tensor, bn: torch.nn.BatchNorm1d, fc: torch.nn.Linear) -> torch.Tensor:

@@ -14,6 +14,7 @@ from . import _lib
 __all__ = [
     "spmm_csr", "spmm_bsr4", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
+    "bn_fold", "bn_bwd_coeffs",
 ]
 
 
@@ -178,3 +179,31 @@ def affine_cols_acc(dx, x, B, Cc, center=None) -> None:
     if dx.shape != x.shape or B.numel() != x.shape[1] or Cc.numel() != x.shape[1]:
         raise ValueError("affine_cols_acc: shape mismatch")
     _lib.call("sn_affine_cols_acc_f32", _p(dx), _ld(dx), _p(x), _ld(x), _p(center), _p(B), _p(Cc), x.shape[0], x.shape[1], _stream())
+
+
+def bn_fold(stats, rows: int, gamma, beta, W, b, eps: float, momentum: float, training: bool, running_mean, running_var):
+    """Fold BatchNorm into the Linear weights (see sn_bn_fold_f32). Returns (mean, invstd, s, t, Wf, bf); updates the
+    running statistics in place when training."""
+    _dev(stats, gamma, beta, W, b, running_mean, running_var)
+    J, C = W.shape
+    dev = W.device
+    vec = torch.empty((4, C), dtype=torch.float32, device=dev)
+    Wf = torch.empty((J, C), dtype=torch.float32, device=dev)
+    bf = torch.empty(J, dtype=torch.float32, device=dev)
+    _lib.call("sn_bn_fold_f32", _p(stats), rows, _p(gamma), _p(beta), _p(W.contiguous()), _p(b), J, C, float(eps),
+              float(momentum), 1 if training else 0, _p(running_mean), _p(running_var), _p(vec[0]), _p(vec[1]),
+              _p(vec[2]), _p(vec[3]), _p(Wf), _p(bf), _stream())
+    return vec[0], vec[1], vec[2], vec[3], Wf, bf
+
+
+def bn_bwd_coeffs(Gc, dystats, W, s, invstd, beta, rows: int, has_bias: bool):
+    """(dW, db, dgamma, dbeta, Bc, Cc) of the folded BatchNorm+Linear backward (see sn_bn_bwd_coeffs_f32)."""
+    _dev(Gc, dystats, W, s, invstd, beta)
+    J, C = W.shape
+    dev = W.device
+    dW = torch.empty((J, C), dtype=torch.float32, device=dev)
+    db = torch.empty(J, dtype=torch.float32, device=dev) if has_bias else None
+    vec = torch.empty((4, C), dtype=torch.float32, device=dev)
+    _lib.call("sn_bn_bwd_coeffs_f32", _p(Gc), _p(dystats), _p(W.contiguous()), _p(s), _p(invstd), _p(beta.contiguous()),
+              rows, J, C, _p(dW), _p(db), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _stream())
+    return dW, db, vec[0], vec[1], vec[2], vec[3]

@@ -84,6 +84,41 @@ def affine_cols_acc(dx, x, B, Cc, center=None):
                                  None if center is None else _np(center))
 
 
+def bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training, running_mean, running_var):
+    """numpy/double restatement of what nn.BatchNorm1d + the weight folding compute (checker for sn_bn_fold_f32)."""
+    g, be, Wd = _np(gamma).astype(np.float64), _np(beta).astype(np.float64), _np(W).astype(np.float64)
+    if training:
+        st = _np(stats)
+        mean = st[0] / rows
+        var = np.maximum(st[1] / rows - mean * mean, 0.0)
+        if running_mean is not None:
+            with torch.no_grad():
+                running_mean.mul_(1 - momentum).add_(torch.from_numpy((momentum * mean).astype(np.float32)))
+                running_var.mul_(1 - momentum).add_(torch.from_numpy((momentum * var * rows / max(rows - 1, 1)).astype(np.float32)))
+    else:
+        mean, var = _np(running_mean).astype(np.float64), _np(running_var).astype(np.float64)
+    invstd = 1.0 / np.sqrt(var + eps)
+    s = g * invstd
+    t = be - mean * s
+    s32, t32 = s.astype(np.float32), t.astype(np.float32)
+    Wf = (_np(W) * s32[None, :]).astype(np.float32)
+    bf = ((0.0 if b is None else _np(b).astype(np.float64)) + Wd @ t32.astype(np.float64)).astype(np.float32)
+    f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return f(mean), f(invstd), f(s32), f(t32), f(Wf), f(bf)
+
+
+def bn_bwd_coeffs(Gc, dystats, W, s, invstd, beta, rows, has_bias):
+    G, Wd = _np(Gc).astype(np.float64), _np(W).astype(np.float64)
+    sdy = _np(dystats)[0]
+    sd, isd, be = _np(s).astype(np.float64), _np(invstd).astype(np.float64), _np(beta).astype(np.float64)
+    a = sdy @ Wd
+    p = (Wd * G).sum(0)
+    dg = isd * p
+    dW = G * sd[None, :] + np.outer(sdy, be)
+    f = lambda v: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return f(dW), (f(sdy) if has_bias else None), f(dg), f(a), f(-(sd * isd * dg) / rows), f(-(sd * a) / rows)
+
+
 def install(monkeypatch=None):
     """Patch surfacenetworks_amd.kernels in place (monkeypatch=None: permanent, for spawned worker processes)."""
     from surfacenetworks_amd import kernels
