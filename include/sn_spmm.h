@@ -224,6 +224,26 @@ int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W,
                          const float *beta, int64_t rows, int32_t J, int32_t C, float *dW, float *db, float *dgamma,
                          float *dbeta, float *Bc, float *Cc, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Global-average block helpers (AvgResNet2, src/utils/utils_pt.py:222-243; global_average :120-122).
+ * A batch is nseg meshes of rows_per_seg (padded) rows each; mask[r] in {0,1} marks real vertices (may be NULL = all).
+ *
+ * sn_segment_colsum_f32 : out[seg, c] = sum over the rows r of mesh seg of mask[r] * x[r, c]   (fp64 accumulation,
+ *                         two deterministic stages).  Replaces (x * mask).sum(1).
+ * sn_bcast_rows_f32     : dst[r, c] = src[seg(r), c]  — writes the per-mesh mean into the second half of the concat
+ *                         buffer (expand_as + contiguous + torch.cat in the reference).
+ * sn_elu_bwd_bcast_f32  : gsrc[r,c] = (gdst[r,c] + mask[r] * bias[seg(r), c]) * elu'(out[r,c]): ELU backward with the
+ *                         gradient of the mean path folded in.
+ * ------------------------------------------------------------------------------------------ */
+size_t sn_segment_colsum_workspace_bytes(int64_t rows_per_seg, int64_t nseg, int32_t C);
+int sn_segment_colsum_f32(const float *x, int64_t ld, const float *mask, int64_t rows_per_seg, int64_t nseg, int32_t C,
+                          float *out, void *workspace, size_t workspace_bytes, void *stream);
+int sn_bcast_rows_f32(const float *src, float *dst, int64_t ldd, int64_t rows_per_seg, int64_t nseg, int32_t C,
+                      void *stream);
+int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64_t ldo, const float *bias,
+                         const float *mask, float *gsrc, int64_t ldgs, int64_t rows_per_seg, int64_t nseg, int32_t C,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -339,6 +339,87 @@ __global__ __launch_bounds__(kWG) void bn_bwd_coeffs_k(const float *__restrict__
   Cc[c] = (float)(-(sc * a) / (double)rows);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// per-mesh (segment) masked column sums, broadcast, and ELU backward with a broadcast term
+// ------------------------------------------------------------------------------------------------
+constexpr int kSegSlabs = 16;      // row slabs per mesh in stage 1
+
+// grid (kSegSlabs, nseg); C % 4 == 0 and (C/4) divides 256
+__global__ __launch_bounds__(kWG) void segsum_k(const float *__restrict__ x, int64_t ld, const float *__restrict__ mask,
+                                                int64_t rows_per_seg, int C, double *__restrict__ partial) {
+  extern __shared__ double sm[];               // [lanes_r][C]
+  const int cw = C / 4, lanes_r = kWG / cw;
+  const int cg = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int64_t seg = blockIdx.y;
+  const int64_t per = (rows_per_seg + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = seg * rows_per_seg + (int64_t)blockIdx.x * per;
+  int64_t r1 = r0 + per;
+  const int64_t rend = (seg + 1) * rows_per_seg;
+  r1 = r1 < rend ? r1 : rend;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int64_t r = r0 + rl; r < r1; r += lanes_r) {
+    const float m = mask ? mask[r] : 1.f;
+    if (m != 0.f) {
+      const f4 v = *reinterpret_cast<const f4 *>(x + r * ld + cg * 4);
+      s0 += (double)(m * v.x); s1 += (double)(m * v.y); s2 += (double)(m * v.z); s3 += (double)(m * v.w);
+    }
+  }
+  double *o = sm + (int64_t)rl * C + cg * 4;
+  o[0] = s0; o[1] = s1; o[2] = s2; o[3] = s3;
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += kWG) {
+    double t = 0;
+    for (int l = 0; l < lanes_r; ++l) t += sm[(int64_t)l * C + i];
+    partial[((int64_t)seg * gridDim.x + blockIdx.x) * C + i] = t;
+  }
+}
+
+__global__ __launch_bounds__(kWG) void segsum_final_k(const double *__restrict__ partial, int nslab, int64_t total,
+                                                      int C, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;       // seg*C + c
+  if (i >= total) return;
+  const int64_t seg = i / C;
+  const int c = (int)(i - seg * C);
+  double t = 0;
+  for (int sl = 0; sl < nslab; ++sl) t += partial[(seg * nslab + sl) * C + c];
+  out[i] = (float)t;
+}
+
+__global__ __launch_bounds__(kWG) void bcast_rows_k(const float *__restrict__ src, float *__restrict__ dst, int64_t ldd,
+                                                    int64_t rows_per_seg, int64_t rows, int C) {
+  const int cw = C / 4;
+  const int64_t total = rows * cw;
+  for (int64_t t = (int64_t)blockIdx.x * kWG + threadIdx.x; t < total; t += (int64_t)gridDim.x * kWG) {
+    const int64_t r = t / cw;
+    const int c = (int)(t - r * cw) * 4;
+    *reinterpret_cast<f4 *>(dst + r * ldd + c) = *reinterpret_cast<const f4 *>(src + (r / rows_per_seg) * C + c);
+  }
+}
+
+__global__ __launch_bounds__(kWG) void elu_bwd_bcast_k(const float *__restrict__ gdst, int64_t ldg,
+                                                       const float *__restrict__ out, int64_t ldo,
+                                                       const float *__restrict__ bias, const float *__restrict__ mask,
+                                                       float *__restrict__ gsrc, int64_t ldgs, int64_t rows_per_seg,
+                                                       int64_t rows, int C) {
+  const int cw = C / 4;
+  const int64_t total = rows * cw;
+  for (int64_t t = (int64_t)blockIdx.x * kWG + threadIdx.x; t < total; t += (int64_t)gridDim.x * kWG) {
+    const int64_t r = t / cw;
+    const int c = (int)(t - r * cw) * 4;
+    const f4 g = *reinterpret_cast<const f4 *>(gdst + r * ldg + c);
+    const f4 o = *reinterpret_cast<const f4 *>(out + r * ldo + c);
+    const f4 b = *reinterpret_cast<const f4 *>(bias + (r / rows_per_seg) * C + c);
+    const float m = mask ? mask[r] : 1.f;
+    f4 d;
+    d.x = __builtin_fmaf(m, b.x, g.x) * (o.x > 0.f ? 1.f : o.x + 1.f);
+    d.y = __builtin_fmaf(m, b.y, g.y) * (o.y > 0.f ? 1.f : o.y + 1.f);
+    d.z = __builtin_fmaf(m, b.z, g.z) * (o.z > 0.f ? 1.f : o.z + 1.f);
+    d.w = __builtin_fmaf(m, b.w, g.w) * (o.w > 0.f ? 1.f : o.w + 1.f);
+    *reinterpret_cast<f4 *>(gsrc + r * ldgs + c) = d;
+  }
+}
+
 inline int stat_blocks(int64_t rows) {
   int64_t b = (rows + 63) / 64;
   if (b > kStatBlocks) b = kStatBlocks;
@@ -456,6 +537,66 @@ int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W,
   const int n = C > J ? C : J;
   hipLaunchKernelGGL(bn_bwd_coeffs_k, dim3((n + kWG - 1) / kWG), dim3(kWG), 0, static_cast<hipStream_t>(stream), Gc,
                      dystats, W, s, invstd, beta, rows, (int)J, (int)C, dW, db, dgamma, dbeta, Bc, Cc);
+  return launch_status();
+}
+
+size_t sn_segment_colsum_workspace_bytes(int64_t rows_per_seg, int64_t nseg, int32_t C) {
+  (void)rows_per_seg;
+  if (nseg < 0 || C < 1) return 0;
+  return (size_t)nseg * kSegSlabs * (size_t)C * sizeof(double);
+}
+
+static bool seg_shape_ok(int32_t C) { return C >= 4 && (C % 4 == 0) && (kWG % (C / 4) == 0); }
+
+static unsigned ew_grid(int64_t items) {
+  int64_t b = (items + kWG - 1) / kWG;
+  if (b > (int64_t)kCUs * 16) b = (int64_t)kCUs * 16;
+  return (unsigned)(b < 1 ? 1 : b);
+}
+
+int sn_segment_colsum_f32(const float *x, int64_t ld, const float *mask, int64_t rows_per_seg, int64_t nseg, int32_t C,
+                          float *out, void *workspace, size_t workspace_bytes, void *stream) {
+  if (rows_per_seg < 0 || nseg < 0 || C < 1 || ld < C) return SN_E_SHAPE;
+  if (!seg_shape_ok(C) || (ld % 4)) return SN_E_UNSUPPORTED;
+  if (nseg == 0) return SN_OK;
+  if (!x || !out || !workspace) return SN_E_NULL;
+  if (!aligned16(x)) return SN_E_ALIGN;
+  if (workspace_bytes < sn_segment_colsum_workspace_bytes(rows_per_seg, nseg, C)) return SN_E_WORKSPACE;
+  if (nseg > 65535) return SN_E_RANGE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double *partial = static_cast<double *>(workspace);
+  const size_t shm = (size_t)(kWG / (C / 4)) * C * sizeof(double);
+  hipLaunchKernelGGL(segsum_k, dim3(kSegSlabs, (unsigned)nseg), dim3(kWG), shm, s, x, ld, mask, rows_per_seg, (int)C, partial);
+  const int64_t total = nseg * C;
+  hipLaunchKernelGGL(segsum_final_k, dim3((unsigned)((total + kWG - 1) / kWG)), dim3(kWG), 0, s, partial, kSegSlabs, total,
+                     (int)C, out);
+  return launch_status();
+}
+
+int sn_bcast_rows_f32(const float *src, float *dst, int64_t ldd, int64_t rows_per_seg, int64_t nseg, int32_t C,
+                      void *stream) {
+  if (rows_per_seg < 0 || nseg < 0 || C < 1 || ldd < C) return SN_E_SHAPE;
+  if ((C % 4) || (ldd % 4)) return SN_E_UNSUPPORTED;
+  const int64_t rows = rows_per_seg * nseg;
+  if (rows == 0) return SN_OK;
+  if (!src || !dst) return SN_E_NULL;
+  if (!aligned16(src) || !aligned16(dst)) return SN_E_ALIGN;
+  hipLaunchKernelGGL(bcast_rows_k, dim3(ew_grid(rows * (C / 4))), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, dst,
+                     ldd, rows_per_seg, rows, (int)C);
+  return launch_status();
+}
+
+int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64_t ldo, const float *bias,
+                         const float *mask, float *gsrc, int64_t ldgs, int64_t rows_per_seg, int64_t nseg, int32_t C,
+                         void *stream) {
+  if (rows_per_seg < 0 || nseg < 0 || C < 1 || ldg < C || ldo < C || ldgs < C) return SN_E_SHAPE;
+  if ((C % 4) || (ldg % 4) || (ldo % 4) || (ldgs % 4)) return SN_E_UNSUPPORTED;
+  const int64_t rows = rows_per_seg * nseg;
+  if (rows == 0) return SN_OK;
+  if (!gdst || !out || !bias || !gsrc) return SN_E_NULL;
+  if (!aligned16(gdst) || !aligned16(out) || !aligned16(bias) || !aligned16(gsrc)) return SN_E_ALIGN;
+  hipLaunchKernelGGL(elu_bwd_bcast_k, dim3(ew_grid(rows * (C / 4))), dim3(kWG), 0, static_cast<hipStream_t>(stream), gdst,
+                     ldg, out, ldo, bias, mask, gsrc, ldgs, rows_per_seg, rows, (int)C);
   return launch_status();
 }
 

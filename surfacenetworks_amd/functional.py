@@ -18,7 +18,7 @@ import torch
 from . import kernels
 from .operators import SparseOperator, as_operator
 
-__all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "bn_linear", "set_dirac_format", "SpmmTimer"]
+__all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg_propagate", "bn_linear", "set_dirac_format", "SpmmTimer"]
 
 _USE_BSR4 = True
 
@@ -282,3 +282,41 @@ def bn_linear(x2d: torch.Tensor, bn: torch.nn.BatchNorm1d, fc: torch.nn.Linear) 
         bn.num_batches_tracked.add_(1)
     return _BNLinear.apply(x2d, bn.weight, bn.bias, fc.weight, fc.bias, bn.running_mean, bn.running_var, training,
                            bn.momentum, bn.eps)
+
+
+class _AvgPropagate(torch.autograd.Function):
+    """cat = [e, mean_mesh(e)], e = elu(x): the propagate step of AvgResNet2 (src/utils/utils_pt.py:230-241) with
+    global_average (utils_pt.py:120-122) fused: ELU straight into the concat buffer, per-mesh masked column sums in one
+    pass, the mean broadcast written into the second half; backward folds the mean-path gradient into the ELU backward."""
+
+    @staticmethod
+    def forward(ctx, x, mask_rows, inv_count, nseg):
+        x = _rows2d(x)
+        rows, C = x.shape
+        per = rows // nseg
+        cat = torch.empty((rows, 2 * C), dtype=torch.float32, device=x.device)
+        e = cat[:, :C]
+        kernels.elu_into(x, e)
+        mean = kernels.segment_colsum(e, mask_rows, per, nseg) * inv_count          # (nseg, C) * (nseg, 1)
+        kernels.bcast_rows(mean, cat[:, C:], per)
+        ctx.save_for_backward(cat, mask_rows, inv_count)
+        ctx.per, ctx.nseg = per, nseg
+        return cat
+
+    @staticmethod
+    def backward(ctx, g_cat):
+        cat, mask_rows, inv_count = ctx.saved_tensors
+        g_cat = _rows2d(g_cat)
+        C = cat.shape[1] // 2
+        gm = kernels.segment_colsum(g_cat[:, C:], None, ctx.per, ctx.nseg) * inv_count   # d/d(mean) / count
+        g_x = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
+        kernels.elu_bwd_bcast(g_cat[:, :C], cat[:, :C], gm.contiguous(), mask_rows, g_x, ctx.per)
+        return g_x, None, None, None
+
+
+def avg_propagate(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    """x: (B, V, C), mask: (B, V, 1) -> (B*V, 2C) concat buffer [elu(x), per-mesh masked mean of elu(x)]."""
+    B, V, C = x.shape
+    mask_rows = mask.reshape(B * V).contiguous()
+    inv_count = 1.0 / mask.reshape(B, V).sum(1, keepdim=True)
+    return _AvgPropagate.apply(x.reshape(B * V, C), mask_rows, inv_count, B)

@@ -14,7 +14,7 @@ from . import _lib
 __all__ = [
     "spmm_csr", "spmm_bsr4", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
-    "bn_fold", "bn_bwd_coeffs",
+    "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast",
 ]
 
 
@@ -207,3 +207,33 @@ def bn_bwd_coeffs(Gc, dystats, W, s, invstd, beta, rows: int, has_bias: bool):
     _lib.call("sn_bn_bwd_coeffs_f32", _p(Gc), _p(dystats), _p(W.contiguous()), _p(s), _p(invstd), _p(beta.contiguous()),
               rows, J, C, _p(dW), _p(db), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _stream())
     return dW, db, vec[0], vec[1], vec[2], vec[3]
+
+
+def segment_colsum(x, mask, rows_per_seg: int, nseg: int):
+    """(nseg, C) fp32: per-mesh masked column sums of the 2-D view x (nseg*rows_per_seg rows); mask is (rows,) or None."""
+    _dev(x, mask)
+    C = x.shape[1]
+    if x.shape[0] != rows_per_seg * nseg:
+        raise ValueError("segment_colsum: row count mismatch")
+    out = torch.empty((nseg, C), dtype=torch.float32, device=x.device)
+    ws_bytes = int(_lib.load().sn_segment_colsum_workspace_bytes(rows_per_seg, nseg, C))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.call("sn_segment_colsum_f32", _p(x), _ld(x), _p(mask), rows_per_seg, nseg, C, _p(out), _p(ws), ws_bytes, _stream())
+    return out
+
+
+def bcast_rows(src, dst, rows_per_seg: int) -> None:
+    """dst[r, :] = src[r // rows_per_seg, :]."""
+    _dev(src, dst)
+    nseg, C = src.shape
+    if dst.shape[0] != nseg * rows_per_seg or dst.shape[1] != C:
+        raise ValueError("bcast_rows: shape mismatch")
+    _lib.call("sn_bcast_rows_f32", _p(src), _p(dst), _ld(dst), rows_per_seg, nseg, C, _stream())
+
+
+def elu_bwd_bcast(gdst, out, bias, mask, gsrc, rows_per_seg: int) -> None:
+    """gsrc = (gdst + mask[r] * bias[mesh(r)]) * elu'(out)."""
+    _dev(gdst, out, bias, mask, gsrc)
+    nseg, C = bias.shape
+    _lib.call("sn_elu_bwd_bcast_f32", _p(gdst), _ld(gdst), _p(out), _ld(out), _p(bias), _p(mask), _p(gsrc), _ld(gsrc),
+              rows_per_seg, nseg, C, _stream())

@@ -119,6 +119,23 @@ def bn_bwd_coeffs(Gc, dystats, W, s, invstd, beta, rows, has_bias):
     return f(dW), (f(sdy) if has_bias else None), f(dg), f(a), f(-(sd * isd * dg) / rows), f(-(sd * a) / rows)
 
 
+def segment_colsum(x, mask, rows_per_seg, nseg):
+    xv = x.detach().double().reshape(nseg, rows_per_seg, x.shape[1])
+    if mask is not None:
+        xv = xv * mask.detach().double().reshape(nseg, rows_per_seg, 1)
+    return xv.sum(1).float()
+
+
+def bcast_rows(src, dst, rows_per_seg):
+    dst.copy_(src.repeat_interleave(rows_per_seg, dim=0))
+
+
+def elu_bwd_bcast(gdst, out, bias, mask, gsrc, rows_per_seg):
+    b = bias.repeat_interleave(rows_per_seg, dim=0)
+    m = 1.0 if mask is None else mask.reshape(-1, 1)
+    gsrc.copy_(torch.addcmul(gdst, b, torch.ones_like(b) * m) * torch.where(out > 0, torch.ones_like(out), out + 1))
+
+
 def install(monkeypatch=None):
     """Patch surfacenetworks_amd.kernels in place (monkeypatch=None: permanent, for spawned worker processes)."""
     from surfacenetworks_amd import kernels

@@ -116,3 +116,29 @@ def test_bn_linear_matches_torch_layers(rows, C, J, train):
         e_t = rel_err(b32.double().cpu().numpy(), b64.cpu().numpy())
         assert e_f <= max(4 * e_t, 2e-6), (n, "fused err", e_f, "torch fp32 err", e_t)
     assert int(bn.num_batches_tracked) == int(bn32.num_batches_tracked)
+
+
+def test_segment_kernels():
+    import cpu_kernels as ck
+
+    rng = np.random.default_rng(5)
+    for per, nseg, C in [(301, 5, 128), (64, 3, 64), (5041, 4, 128), (7, 9, 16)]:
+        rows = per * nseg
+        x = rng.standard_normal((rows, 2 * C)).astype(np.float32)
+        mask = (rng.random(rows) < 0.8).astype(np.float32)
+        xd, md = dev(x), dev(mask)
+        for m_np, m_d in ((mask, md), (None, None)):
+            want = ck.segment_colsum(torch.from_numpy(x[:, :C].copy()), None if m_np is None else torch.from_numpy(m_np), per, nseg)
+            got = kernels.segment_colsum(xd[:, :C], m_d, per, nseg)
+            assert rel_err(got.cpu().numpy(), want.numpy()) < 1e-6
+        src = rng.standard_normal((nseg, C)).astype(np.float32)
+        dst = torch.zeros(rows, 2 * C, device=DEV)
+        kernels.bcast_rows(dev(src), dst[:, C:], per)
+        assert np.array_equal(dst[:, C:].cpu().numpy(), np.repeat(src, per, 0)) and float(dst[:, :C].abs().sum()) == 0
+        g = rng.standard_normal((rows, C)).astype(np.float32)
+        out = c_oracle.elu(rng.standard_normal((rows, C)).astype(np.float32) * 2)
+        gs = torch.empty(rows, C, device=DEV)
+        kernels.elu_bwd_bcast(dev(g), dev(out), dev(src), md, gs, per)
+        want = torch.empty(rows, C)
+        ck.elu_bwd_bcast(torch.from_numpy(g), torch.from_numpy(out), torch.from_numpy(src), torch.from_numpy(mask), want, per)
+        assert np.allclose(gs.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
