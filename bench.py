@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--meshes", type=int, default=MESHES_PER_GPU, help="meshes per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--format", default="bsr4", choices=["bsr4", "csr"])
+    ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
+                    help="default nccl (= RCCL); gloo only for functional tests of the N>1 path on a 1-GPU box")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -100,7 +102,7 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
-    rank, local_rank, world, device = dp.init_distributed()
+    rank, local_rank, world, device = dp.init_distributed(args.backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     snF.set_dirac_format(args.format)

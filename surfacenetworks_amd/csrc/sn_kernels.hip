@@ -67,40 +67,45 @@ struct ChunkWalk {
 // ------------------------------------------------------------------------------------------------
 // CSR SpMM, N/4 lanes per row.
 // ------------------------------------------------------------------------------------------------
-template <int N, int XG, int YG>
+template <int N, int XG, int YG, int KB = 8>
 __global__ __launch_bounds__(kWG) void spmm_csr_v4(const int *__restrict__ rowptr,
                                                    const int *__restrict__ colind,
                                                    const float *__restrict__ vals, int M,
                                                    const float *__restrict__ X, int64_t ldx,
-                                                   float *__restrict__ Y, int64_t ldy, int nchunks) {
+                                                   float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
   constexpr int LPR = N / 4;       // lanes per row
   constexpr int RPB = kWG / LPR;   // rows per workgroup pass
   const int sub = threadIdx.x % LPR;
   const int rloc = threadIdx.x / LPR;
   const float *xb = X + sub * 4;
-  ChunkWalk w(nchunks);
-  for (int local = w.first; local < w.cpx; local += w.step) {
-    const int r = (w.base + local) * RPB + rloc;
+  ChunkWalk w(nchunks);            // a chunk = iters consecutive passes of RPB rows
+  for (int local = w.first; local < w.cpx; local += w.step)
+  for (int it = 0; it < iters; ++it) {
+    const int r = ((w.base + local) * iters + it) * RPB + rloc;
     if (r >= M) continue;
     int k = rowptr[r];
     const int e = rowptr[r + 1];
     f4 acc = {0.f, 0.f, 0.f, 0.f};
-    // 4 independent gathers in flight per lane; summation order stays k-ascending.
-    for (; k + 4 <= e; k += 4) {
-      const int c0 = colind[k], c1 = colind[k + 1], c2 = colind[k + 2], c3 = colind[k + 3];
-      const float a0 = vals[k], a1 = vals[k + 1], a2 = vals[k + 2], a3 = vals[k + 3];
-      const f4 x0 = ld4(xb + row_off<XG, N>(c0, ldx));
-      const f4 x1 = ld4(xb + row_off<XG, N>(c1, ldx));
-      const f4 x2 = ld4(xb + row_off<XG, N>(c2, ldx));
-      const f4 x3 = ld4(xb + row_off<XG, N>(c3, ldx));
-      acc = fma4(a0, x0, acc);
-      acc = fma4(a1, x1, acc);
-      acc = fma4(a2, x2, acc);
-      acc = fma4(a3, x3, acc);
-    }
-    for (; k < e; ++k) {
-      const f4 x0 = ld4(xb + row_off<XG, N>(colind[k], ldx));
-      acc = fma4(vals[k], x0, acc);
+    // Batches of kBatch entries with ALL gathers of a batch in flight at once.  A short row (7 entries for the
+    // Laplacian, 9 for Di) is one or two batches — no serial tail loop of dependent colind -> gather round trips.
+    // Slots past the end re-read the row's last entry with a zero coefficient: fma(0, x, acc) == acc, and the
+    // re-read column already belongs to the row, so non-finite inputs propagate exactly as in the plain loop.
+    constexpr int kBatch = KB;
+    for (; k < e; k += kBatch) {
+      int c[kBatch];
+      float a[kBatch];
+      f4 x[kBatch];
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i) {
+        const bool in = k + i < e;
+        const int kk = in ? k + i : e - 1;
+        c[i] = colind[kk];
+        a[i] = in ? vals[kk] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i) x[i] = ld4(xb + row_off<XG, N>(c[i], ldx));
+#pragma unroll
+      for (int i = 0; i < kBatch; ++i) acc = fma4(a[i], x[i], acc);
     }
     st4_stream(Y + row_off<YG, N>(r, ldy) + sub * 4, acc);
   }
@@ -168,7 +173,7 @@ __global__ __launch_bounds__(kWG, (UNR == 4 ? 8 : 1)) void spmm_bsr4_lds(const i
                                                      const int *__restrict__ b_colind,
                                                      const float *__restrict__ b_vals, int Mb,
                                                      const float *__restrict__ X, int64_t ldx,
-                                                     float *__restrict__ Y, int64_t ldy, int nchunks) {
+                                                     float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
   constexpr int LPR = N / 4;          // lanes per block row
   constexpr int RPW = 64 / LPR;       // block rows per wave pass
   constexpr int WAVES = kWG / 64;
@@ -186,9 +191,10 @@ __global__ __launch_bounds__(kWG, (UNR == 4 ? 8 : 1)) void spmm_bsr4_lds(const i
   const f4 *gv = reinterpret_cast<const f4 *>(b_vals);
   f4 *sv = s_vals[wave];
   int *sc = s_col[wave];
-  ChunkWalk w(nchunks);               // a chunk = WAVES * RPW block rows (one pass of the workgroup)
-  for (int local = w.first; local < w.cpx; local += w.step) {
-    const int r0 = ((w.base + local) * WAVES + wave) * RPW;   // first block row of this wave
+  ChunkWalk w(nchunks);               // a chunk = iters passes of WAVES * RPW block rows
+  for (int local = w.first; local < w.cpx; local += w.step)
+  for (int it = 0; it < iters; ++it) {
+    const int r0 = (((w.base + local) * iters + it) * WAVES + wave) * RPW;   // first block row of this wave
     if (r0 >= Mb) continue;                                   // wave-uniform
     const int br = r0 + grp;
     const int brc = br < Mb ? br : Mb;
@@ -600,6 +606,9 @@ inline int env_int(const char *name, int dflt) {
 }
 inline int tune_blocks_per_cu() { static const int v = env_int("SN_BLOCKS_PER_CU", 0); return v; }
 inline int tune_bsr4_variant() { static const int v = env_int("SN_BSR4_VARIANT", 2); return v; }
+inline int tune_csr_iters() { static const int v = env_int("SN_CSR_ITERS", 1); return v < 1 ? 1 : v; }
+inline int tune_csr_batch() { static const int v = env_int("SN_CSR_BATCH", 8); return v; }
+inline int tune_bsr4_iters() { static const int v = env_int("SN_BSR4_ITERS", 1); return v < 1 ? 1 : v; }
 inline int tune_bsr4_unroll() { static const int v = env_int("SN_BSR4_UNROLL", 2); return v; }
 
 // grid for the XCD-aware chunk walk: a multiple of 8 workgroups, at most SN_BLOCKS_PER_CU per CU.
@@ -640,6 +649,19 @@ int exclusive_scan_i32(const int *in, int64_t n, int *out, void *ws, size_t ws_b
     else if (xg == 4 && yg == 4) hipLaunchKernelGGL((KERNEL<N, 4, 4>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
     else if (xg == 1 && yg == 4) hipLaunchKernelGGL((KERNEL<N, 1, 4>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
     else hipLaunchKernelGGL((KERNEL<N, 4, 1>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__);         \
+  } while (0)
+
+#define SN_DISPATCH_CSR_KB(N, KB, xg, yg, grid, stream, ...)                                                   \
+  do {                                                                                                         \
+    if (xg == 1 && yg == 1) hipLaunchKernelGGL((spmm_csr_v4<N, 1, 1, KB>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
+    else if (xg == 4 && yg == 4) hipLaunchKernelGGL((spmm_csr_v4<N, 4, 4, KB>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
+    else if (xg == 1 && yg == 4) hipLaunchKernelGGL((spmm_csr_v4<N, 1, 4, KB>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
+    else hipLaunchKernelGGL((spmm_csr_v4<N, 4, 1, KB>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__);         \
+  } while (0)
+#define SN_DISPATCH_CSR(N, xg, yg, grid, stream, ...)                                      \
+  do {                                                                                     \
+    if (tune_csr_batch() == 4) SN_DISPATCH_CSR_KB(N, 4, xg, yg, grid, stream, __VA_ARGS__); \
+    else SN_DISPATCH_CSR_KB(N, 8, xg, yg, grid, stream, __VA_ARGS__);                      \
   } while (0)
 
 #define SN_DISPATCH_LDS_U(N, DMA, UNR, xg, yg, grid, stream, ...)                                                     \
@@ -701,14 +723,15 @@ int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *v
   const bool vec = (N == 16 || N == 32 || N == 64 || N == 128) && aligned16(X) && aligned16(Y) &&
                    (ldx % 4 == 0) && (ldy % 4 == 0);
   if (vec) {
-    const int rpb = kWG / (N / 4);
+    const int iters = tune_csr_iters();
+    const int rpb = kWG / (N / 4) * iters;
     const int64_t nchunks = (M + rpb - 1) / rpb;
     const unsigned grid = chunk_grid(nchunks);
     switch (N) {
-      case 16: SN_DISPATCH_N_G(spmm_csr_v4, 16, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks); break;
-      case 32: SN_DISPATCH_N_G(spmm_csr_v4, 32, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks); break;
-      case 64: SN_DISPATCH_N_G(spmm_csr_v4, 64, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks); break;
-      default: SN_DISPATCH_N_G(spmm_csr_v4, 128, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks); break;
+      case 16: SN_DISPATCH_CSR(16, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters); break;
+      case 32: SN_DISPATCH_CSR(32, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters); break;
+      case 64: SN_DISPATCH_CSR(64, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters); break;
+      default: SN_DISPATCH_CSR(128, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters); break;
     }
   } else {
     hipLaunchKernelGGL(spmm_csr_any, dim3(grid_for(M * (int64_t)N, kWG)), dim3(kWG), 0, s, rowptr, colind,
@@ -733,10 +756,11 @@ int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const flo
   if (!(N == 16 || N == 32 || N == 64 || N == 128)) return SN_E_UNSUPPORTED;
   if (!aligned16(X) || !aligned16(Y) || !aligned16(b_vals) || ldx % 4 || ldy % 4) return SN_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const int rpb = kWG / (N / 4);
+  const int variant = tune_bsr4_variant();
+  const int iters = variant == 0 ? 1 : tune_bsr4_iters();
+  const int rpb = kWG / (N / 4) * iters;
   const int64_t nchunks = (Mb + rpb - 1) / rpb;
   const unsigned grid = chunk_grid(nchunks);
-  const int variant = tune_bsr4_variant();
 #define SN_BSR4_ARGS b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks
   if (variant == 0) {
     switch (N) {
@@ -747,17 +771,17 @@ int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const flo
     }
   } else if (variant == 1) {
     switch (N) {
-      case 16: SN_DISPATCH_LDS(16, false, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
-      case 32: SN_DISPATCH_LDS(32, false, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
-      case 64: SN_DISPATCH_LDS(64, false, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
-      default: SN_DISPATCH_LDS(128, false, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      case 16: SN_DISPATCH_LDS(16, false, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
+      case 32: SN_DISPATCH_LDS(32, false, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
+      case 64: SN_DISPATCH_LDS(64, false, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
+      default: SN_DISPATCH_LDS(128, false, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
     }
   } else {
     switch (N) {
-      case 16: SN_DISPATCH_LDS(16, true, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
-      case 32: SN_DISPATCH_LDS(32, true, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
-      case 64: SN_DISPATCH_LDS(64, true, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
-      default: SN_DISPATCH_LDS(128, true, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
+      case 16: SN_DISPATCH_LDS(16, true, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
+      case 32: SN_DISPATCH_LDS(32, true, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
+      case 64: SN_DISPATCH_LDS(64, true, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
+      default: SN_DISPATCH_LDS(128, true, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
     }
   }
 #undef SN_BSR4_ARGS

@@ -34,15 +34,19 @@ def init_distributed(backend: Optional[str] = None):
     """Join the job described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
     backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests.  Returns (rank, local_rank, world, device)."""
     rank, local_rank, world = world_info()
-    use_gpu = torch.cuda.is_available() and backend != "gloo"
-    device = torch.device("cuda", local_rank) if use_gpu else torch.device("cpu")
+    use_gpu = torch.cuda.is_available() and os.environ.get("SN_DP_FORCE_CPU", "0") != "1"
     if use_gpu:
+        # one process per GPU; the modulo only matters for functional tests that put several gloo ranks on one GPU
+        device = torch.device("cuda", local_rank % torch.cuda.device_count())
         torch.cuda.set_device(device)
+    else:
+        device = torch.device("cpu")
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        kw = {"device_id": device} if use_gpu else {}
-        dist.init_process_group(backend or ("nccl" if use_gpu else "gloo"), rank=rank, world_size=world, **kw)
+        backend = backend or ("nccl" if use_gpu else "gloo")
+        kw = {"device_id": device} if (use_gpu and backend == "nccl") else {}
+        dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world, device
 
 

@@ -28,7 +28,8 @@ def _worker(rank, world, port, q):
     for p in (ROOT, HERE):
         if p not in sys.path:
             sys.path.insert(0, p)
-    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      SN_DP_FORCE_CPU="1")
     torch.set_num_threads(2)
     import cpu_kernels
 
