@@ -171,14 +171,14 @@ int sn_blockdiag_concat_i32(const int32_t *pool_rowptr, const int32_t *pool_coli
  * sn_elu_into_f32: dst[r, 0:C] = elu(src[r, 0:C]) for `rows` rows; src stride lds, dst stride ldd.
  *   Replaces F.elu (utils_pt.py:161,171,195,208) + the first operand copy of torch.cat
  *   (utils_pt.py:168,177,204,216): ELU is written straight into the first half of the concat buffer.
- * sn_elu_bwd_acc_f32: gsrc[r,c] (+)= gdst[r,c] * (out[r,c] > 0 ? 1 : out[r,c] + 1), out = elu value.
- *   accumulate != 0 adds into gsrc (the activated tensor also feeds SpMM, so two gradients meet).
+ * sn_elu_bwd_acc_f32: gsrc[r,c] (+)= (gdst[r,c] + gdst2[r,c]) * (out[r,c] > 0 ? 1 : out[r,c] + 1), out = elu value.
+ *   gdst2 may be NULL.  The activated tensor feeds both the concat buffer and the SpMM, so two gradients meet here;
+ *   accumulate != 0 additionally adds into gsrc.
  * ------------------------------------------------------------------------------------------ */
 int sn_elu_into_f32(const float *src, int64_t lds, float *dst, int64_t ldd,
                     int64_t rows, int32_t C, void *stream);
-int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *out, int64_t ldo,
-                       float *gsrc, int64_t ldgs, int64_t rows, int32_t C, int32_t accumulate,
-                       void *stream);
+int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64_t ldg2, const float *out, int64_t ldo,
+                       float *gsrc, int64_t ldgs, int64_t rows, int32_t C, int32_t accumulate, void *stream);
 
 
 /* ------------------------------------------------------------------------------------------

@@ -312,7 +312,8 @@ __global__ __launch_bounds__(kWG) void bn_fold_k(const double *__restrict__ stat
   if (threadIdx.x == 0) bf[j] = (float)((b ? (double)b[j] : 0.0) + red[0]);
 }
 
-// one thread per channel c: reductions over the J output rows (coalesced across channels)
+// 32 channels x 8 row-groups per workgroup: group g handles output rows j = g, g+8, ...; the two per-channel
+// reductions over j are combined across the 8 groups in a fixed order.
 __global__ __launch_bounds__(kWG) void bn_bwd_coeffs_k(const float *__restrict__ Gc, const double *__restrict__ sdy,
                                                        const float *__restrict__ W, const float *__restrict__ s,
                                                        const float *__restrict__ invstd, const float *__restrict__ beta,
@@ -320,25 +321,39 @@ __global__ __launch_bounds__(kWG) void bn_bwd_coeffs_k(const float *__restrict__
                                                        float *__restrict__ db, float *__restrict__ dgamma,
                                                        float *__restrict__ dbeta, float *__restrict__ Bc,
                                                        float *__restrict__ Cc) {
-  const int c = blockIdx.x * kWG + threadIdx.x;
-  if (c < J && db) db[c] = (float)sdy[c];
-  if (c >= C) return;
+  __shared__ double sa[8][32], sp[8][32];
+  const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  if (blockIdx.x == 0 && db)
+    for (int j = threadIdx.x; j < J; j += kWG) db[j] = (float)sdy[j];
   double a = 0, p = 0;
-  const double sc = s[c], bc = beta[c];
-  for (int j = 0; j < J; ++j) {
-    const double w = W[(int64_t)j * C + c], g = Gc[(int64_t)j * C + c];
-    a += sdy[j] * w;
-    p += w * g;
-    dW[(int64_t)j * C + c] = (float)(g * sc + sdy[j] * bc);
+  if (c < C) {
+    const double sc = s[c], bc = beta[c];
+    for (int j = g; j < J; j += 8) {
+      const double w = W[(int64_t)j * C + c], gg = Gc[(int64_t)j * C + c];
+      a += sdy[j] * w;
+      p += w * gg;
+      dW[(int64_t)j * C + c] = (float)(gg * sc + sdy[j] * bc);
+    }
   }
-  const double is = invstd[c];
-  const double dg = is * p;
-  dgamma[c] = (float)dg;
-  dbeta[c] = (float)a;
-  Bc[c] = (float)(-(sc * is * dg) / (double)rows);
-  Cc[c] = (float)(-(sc * a) / (double)rows);
+  sa[g][cl] = a;
+  sp[g][cl] = p;
+  __syncthreads();
+  if (g == 0 && c < C) {
+    double at = 0, pt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      at += sa[i][cl];
+      pt += sp[i][cl];
+    }
+    const double sc = s[c], is = invstd[c];
+    const double dg = is * pt;
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)at;
+    Bc[c] = (float)(-(sc * is * dg) / (double)rows);
+    Cc[c] = (float)(-(sc * at) / (double)rows);
+  }
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // per-mesh (segment) masked column sums, broadcast, and ELU backward with a broadcast term
@@ -534,8 +549,7 @@ int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W,
                          float *dbeta, float *Bc, float *Cc, void *stream) {
   if (rows < 1 || J < 1 || C < 1) return SN_E_SHAPE;
   if (!Gc || !dystats || !W || !s || !invstd || !beta || !dW || !dgamma || !dbeta || !Bc || !Cc) return SN_E_NULL;
-  const int n = C > J ? C : J;
-  hipLaunchKernelGGL(bn_bwd_coeffs_k, dim3((n + kWG - 1) / kWG), dim3(kWG), 0, static_cast<hipStream_t>(stream), Gc,
+  hipLaunchKernelGGL(bn_bwd_coeffs_k, dim3((C + 31) / 32), dim3(kWG), 0, static_cast<hipStream_t>(stream), Gc,
                      dystats, W, s, invstd, beta, rows, (int)J, (int)C, dW, db, dgamma, dbeta, Bc, Cc);
   return launch_status();
 }

@@ -133,10 +133,8 @@ class _LapPropagate(torch.autograd.Function):
         C = cat.shape[1] // 2
         g_e = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
         _launch(ctx.op.t(), g_cat[:, C:], g_e, 1, "bwd")
-        # g_x = (g_e + g_cat[:, :C]) * elu'(e): fold the add into two accumulate passes of the elu-backward kernel
         g_x = torch.empty_like(g_e)
-        kernels.elu_bwd(g_e, cat[:, :C], g_x, False)
-        kernels.elu_bwd(g_cat[:, :C], cat[:, :C], g_x, True)
+        kernels.elu_bwd(g_e, cat[:, :C], g_x, False, g_cat[:, :C])       # (g_e + g_cat[:, :C]) * elu'(e) in one pass
         return g_x, None
 
 
@@ -181,9 +179,7 @@ class _DiracFaceStage(torch.autograd.Function):
             else:
                 g_e.zero_()
             g_v = torch.empty_like(e_v)
-            kernels.elu_bwd(g_e, e_v, g_v, False)
-            if g_ev is not None:
-                kernels.elu_bwd(_rows2d(g_ev), e_v, g_v, True)
+            kernels.elu_bwd(g_e, e_v, g_v, False, _rows2d(g_ev) if g_ev is not None else None)
         return g_v, g_f, None
 
 

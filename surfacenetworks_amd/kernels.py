@@ -135,13 +135,13 @@ def elu_into(src, dst) -> None:
     _lib.call("sn_elu_into_f32", _p(src), _ld(src), _p(dst), _ld(dst), src.shape[0], src.shape[1], _stream())
 
 
-def elu_bwd(gdst, out, gsrc, accumulate: bool) -> None:
-    """gsrc (+)= gdst * elu'(.) expressed through the activation output `out`."""
-    _dev(gdst, out, gsrc)
-    if not (gdst.shape == out.shape == gsrc.shape):
+def elu_bwd(gdst, out, gsrc, accumulate: bool, gdst2=None) -> None:
+    """gsrc (+)= (gdst + gdst2) * elu'(.) expressed through the activation output `out`."""
+    _dev(gdst, out, gsrc, gdst2)
+    if not (gdst.shape == out.shape == gsrc.shape) or (gdst2 is not None and gdst2.shape != out.shape):
         raise ValueError("elu_bwd: shape mismatch")
-    _lib.call("sn_elu_bwd_acc_f32", _p(gdst), _ld(gdst), _p(out), _ld(out), _p(gsrc), _ld(gsrc), out.shape[0],
-              out.shape[1], 1 if accumulate else 0, _stream())
+    _lib.call("sn_elu_bwd_acc_f32", _p(gdst), _ld(gdst), _p(gdst2), _ld(gdst2) if gdst2 is not None else 0, _p(out),
+              _ld(out), _p(gsrc), _ld(gsrc), out.shape[0], out.shape[1], 1 if accumulate else 0, _stream())
 
 
 def colstats(x):

@@ -60,9 +60,9 @@ def elu_into(src, dst):
     c_oracle.elu_raw(src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst), src.shape[0], src.shape[1])
 
 
-def elu_bwd(gdst, out, gsrc, accumulate):
+def elu_bwd(gdst, out, gsrc, accumulate, gdst2=None):
     c_oracle.elu_bwd_raw(gdst.data_ptr(), _ld(gdst), out.data_ptr(), _ld(out), gsrc.data_ptr(), _ld(gsrc), out.shape[0],
-                         out.shape[1], accumulate)
+                         out.shape[1], accumulate, None if gdst2 is None else gdst2.data_ptr(), 0 if gdst2 is None else _ld(gdst2))
 
 
 def colstats(x):

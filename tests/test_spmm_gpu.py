@@ -205,6 +205,10 @@ def test_elu_kernels():
     acc = dev(acc0)
     kernels.elu_bwd(dev(g), dev(want), acc, True)
     assert np.allclose(acc.cpu().numpy(), c_oracle.elu_bwd(g, want, acc0), rtol=1e-6, atol=1e-7)
+    # two gradient inputs in one pass
+    g2 = rng.standard_normal((333, 128)).astype(np.float32)
+    kernels.elu_bwd(dev(g), dev(want), out, False, dev(g2))
+    assert np.allclose(out.cpu().numpy(), c_oracle.elu_bwd(g + g2, want), rtol=1e-6, atol=1e-6)
     # odd channel count takes the scalar kernel
     x3 = x[:, :7].copy()
     o3 = torch.empty((333, 7), device=DEV)
