@@ -158,6 +158,16 @@ def main():
     achieved = ab / (avg_ms * 1e-3)
     spmm_ms_per_step = sum(tot_ms.values()) / args.steps
 
+    # HBM traffic of that kernel/shape from the committed PMC measurement (rocprofv3 cannot run inside this process)
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_c3.json")) as fh:
+            rec = json.load(fh).get("spmm_bsr4_lds", {}).get(f"M={M},K={K},nnz={nnz},N={N}")
+        if rec and "bsr4" in tag:
+            traffic = rec["read_bytes"] + rec["write_bytes"]
+    except OSError:
+        pass
+
     out = {
         "metric": "meshes/sec fwd+bwd, Dirac temporal-predict",
         "value": global_batch * args.steps / dt,
@@ -172,7 +182,8 @@ def main():
                    "operator_format": args.format, "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": f"{'spmm_bsr4_lds' if 'bsr4' in tag else 'spmm_csr_v4'}<N={N}> ({tag}, M={M}, K={K}, nnz={nnz})",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                     "traffic": None, "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg_ms,
+                     "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_c3.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per launch)" if traffic else None,
+                     "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg_ms,
                      "launches_timed": len(by[dom]), "spmm_ms_per_step_all_kernels": spmm_ms_per_step},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
