@@ -91,6 +91,9 @@ def main():
     ap.add_argument("--meshes", type=int, default=MESHES_PER_GPU, help="meshes per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--format", default="bsr4", choices=["bsr4", "csr"])
+    ap.add_argument("--operators", default="pool", choices=["pool", "device"],
+                    help="pool: precomputed per-frame operators resident in HBM (default, = the reference's dataset); "
+                         "device: Dirac operators rebuilt on the GPU from the frame coordinates every step")
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
                     help="default nccl (= RCCL); gloo only for functional tests of the N>1 path on a 1-GPU box")
     args = ap.parse_args()
@@ -111,7 +114,7 @@ def main():
     # ---- data: this rank's shard (own meshes; weak scaling) -----------------------------------------
     n_local = args.meshes
     ds = arap.ClothSequences([GRID] * n_local, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 2, op_frames=2,
-                             seed=3 + 1000 * rank, device=device, model="dir")
+                             seed=3 + 1000 * rank, device=device, model="dir", operators=args.operators)
     model = arap.DirModel().to(device).train()
     dp.broadcast_parameters(model, 0)
     bucket = dp.FlatGradBucket(model.parameters())
@@ -179,7 +182,7 @@ def main():
         "config": {"workload": f"as_rigid_as_possible Dirac temporal prediction: {n_local} grid-cloth meshes {GRID[0]}x{GRID[1]} "
                                f"(V=5041,F=9800) per GPU, C=128, 15 layers, fwd+loss+bwd+allreduce+Adam",
                    "meshes_per_gpu": n_local, "global_batch": global_batch, "parallelism": f"dp{world} (mesh sharding, flat-bucket RCCL all-reduce)",
-                   "operator_format": args.format, "grad_bucket_bytes": bucket.nbytes},
+                   "operator_format": args.format, "operators": args.operators, "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": f"{'spmm_bsr4_lds' if 'bsr4' in tag else 'spmm_csr_v4'}<N={N}> ({tag}, M={M}, K={K}, nnz={nnz})",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                      "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_c3.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per launch)" if traffic else None,

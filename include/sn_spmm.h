@@ -244,6 +244,31 @@ int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64
                          const float *mask, float *gsrc, int64_t ldgs, int64_t rows_per_seg, int64_t nseg, int32_t C,
                          void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-side construction of the quaternionic Dirac operators from a triangle mesh.
+ *
+ * Replaces: mesh.dirac(V, F)                      src/utils/mesh.py:35-64  (dense O(F·V) numpy builder, 8 s at V=1000)
+ *           with mesh.dist / mesh.area            src/utils/mesh.py:17-26, 67-80
+ *           and Q = quaternion_matrix             src/utils/mesh.py:28-33
+ * All geometry is evaluated in fp64 with the reference's operation order (no FMA contraction) and rounded to fp32 at
+ * the end, exactly like `D.astype('float32')` in the reference's preprocessing (add_laplacian.py:61-65).
+ *
+ * Inputs : V (nV x 3, fp32 — the dtype the reference stores in its datasets), F (nF x 3, int32).
+ * Outputs: four operators in BSR4 (4x4 blocks, explicit zeros):
+ *            Di   (4nF x 4nV): block row = face, 3 blocks, block columns ascending
+ *            DiA  (4nV x 4nF): block row = vertex, one block per incident face, block columns ascending
+ *            DiT = Diᵀ (structure of DiA), DiAT = DiAᵀ (structure of Di)   — for the backward products
+ *          di_rowptr[nF+1], di_colind[3nF], di_vals[48nF], diat_vals[48nF];
+ *          dia_rowptr[nV+1], dia_colind[3nF], dia_vals[48nF], dit_vals[48nF]   (DiT shares DiA's index arrays,
+ *          DiAT shares Di's).  Faces must reference three distinct vertices.
+ * workspace: sn_dirac_workspace_bytes(nV, nF).
+ * ------------------------------------------------------------------------------------------ */
+size_t sn_dirac_workspace_bytes(int64_t nV, int64_t nF);
+int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_t nF,
+                            int32_t *di_rowptr, int32_t *di_colind, float *di_vals, float *diat_vals,
+                            int32_t *dia_rowptr, int32_t *dia_colind, float *dia_vals, float *dit_vals,
+                            void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -113,13 +113,23 @@ class ClothSequences:
     Everything the training loop touches lives in HBM: frame coordinates as one (S, T, Vmax, 3) tensor and the
     operators in OperatorPools (entry s*op_frames + t is sequence s at frame t)."""
 
-    def __init__(self, grids, frames=50, op_frames=2, seed=3, device="cuda", model="dir", permute=False):
+    def __init__(self, grids, frames=50, op_frames=2, seed=3, device="cuda", model="dir", permute=False,
+                 operators="pool"):
+        """operators="pool": per-frame operators precomputed (host, fp64 coordinates) and pooled in HBM, as the
+        reference's dataset does.  operators="device": nothing is precomputed — the Dirac operators of the sampled
+        frames are built on the GPU every step from the stored fp32 coordinates (sn_dirac_bsr4_from_mesh); needs
+        meshes of one size (no padding) and model="dir"."""
         rng = np.random.default_rng(seed)
         self.device = torch.device(device)
         self.frames, self.op_frames, self.kind = frames, op_frames, model
+        self.operators = operators
+        if operators not in ("pool", "device"):
+            raise ValueError(operators)
+        if operators == "device" and (model != "dir" or len(set(grids)) != 1):
+            raise ValueError("on-device operator construction supports the Dirac model on equally sized meshes")
         assert frames >= INPUT_FRAMES + OUTPUT_FRAMES + 1 and 1 <= op_frames
         Vs, Fs, mats = [], [], {"L": [], "Di": [], "DiA": []}
-        coords = []
+        coords, faces_all = [], []
         for (n, m) in grids:
             V0, F_ = mesh_ops.grid_cloth(n, m, rng, permute=permute)
             amp = 0.03 * (0.5 + rng.random())
@@ -133,7 +143,8 @@ class ClothSequences:
             coords.append(Vt.astype(np.float32))
             Vs.append(V0.shape[0])
             Fs.append(F_.shape[0])
-            for tf in range(op_frames):
+            faces_all.append(F_.astype(np.int32))
+            for tf in range(op_frames if operators == "pool" else 0):
                 if model == "dir":
                     Di, DiA = mesh_ops.dirac(Vt[tf].astype(np.float64), F_)
                     mats["Di"].append(Di.astype(np.float32))
@@ -149,7 +160,9 @@ class ClothSequences:
             xyz[s, :, : c.shape[1]] = c
         self.xyz = torch.from_numpy(xyz).to(self.device)
         self.vcount = torch.from_numpy(self.num_vertices).to(self.device)
-        if model == "dir":
+        if operators == "device":
+            self.faces = torch.from_numpy(np.stack(faces_all)).to(self.device)          # (S, F, 3) int32
+        elif model == "dir":
             self.pool_Di = OperatorPool(mats["Di"], self.device, want_bsr4=True)
             self.pool_DiA = OperatorPool(mats["DiA"], self.device, want_bsr4=True)
         else:
@@ -178,7 +191,12 @@ class ClothSequences:
         mask = (torch.arange(nv, device=self.device)[None, :] < self.vcount[sid][:, None]).float().unsqueeze(2)
         op_ids = seq_ids * self.op_frames + (offsets + INPUT_FRAMES - 1)
         L = Di = DiA = None
-        if self.kind == "dir":
+        if self.operators == "device":
+            from .operators import dirac_operators_from_mesh
+
+            Vop = self.xyz[sid, off + INPUT_FRAMES - 1]                                   # (B, nv, 3): last input frame
+            Di, DiA = dirac_operators_from_mesh(Vop, self.faces[sid])
+        elif self.kind == "dir":
             Di = self.pool_Di.assemble(op_ids, 4 * nf, 4 * nv)
             DiA = self.pool_DiA.assemble(op_ids, 4 * nv, 4 * nf)
         else:

@@ -14,7 +14,7 @@ from . import _lib
 __all__ = [
     "spmm_csr", "spmm_bsr4", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
-    "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast",
+    "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh",
 ]
 
 
@@ -237,3 +237,24 @@ def elu_bwd_bcast(gdst, out, bias, mask, gsrc, rows_per_seg: int) -> None:
     nseg, C = bias.shape
     _lib.call("sn_elu_bwd_bcast_f32", _p(gdst), _ld(gdst), _p(out), _ld(out), _p(bias), _p(mask), _p(gsrc), _ld(gsrc),
               rows_per_seg, nseg, C, _stream())
+
+
+def dirac_from_mesh(V, F):
+    """Dirac operators of one triangle mesh (or of a batch laid out as one disjoint mesh) built on the device.
+    V: (nV, 3) fp32, F: (nF, 3) int32.  Returns four BSR4 triples (rowptr, colind, vals):
+    Di (4nF x 4nV), DiAT (= DiA^T, Di's structure), DiA (4nV x 4nF), DiT (= Di^T, DiA's structure)."""
+    _dev(V, F)
+    if V.dtype != torch.float32 or F.dtype != torch.int32 or V.shape[1] != 3 or F.shape[1] != 3:
+        raise TypeError("dirac_from_mesh wants V (nV,3) float32 and F (nF,3) int32")
+    V, F = V.contiguous(), F.contiguous()
+    nV, nF = V.shape[0], F.shape[0]
+    dev = V.device
+    i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)
+    f32 = lambda n: torch.empty(n, dtype=torch.float32, device=dev)
+    di_rp, di_ci, di_v, diat_v = i32(nF + 1), i32(3 * nF), f32(48 * nF), f32(48 * nF)
+    dia_rp, dia_ci, dia_v, dit_v = i32(nV + 1), i32(3 * nF), f32(48 * nF), f32(48 * nF)
+    ws_bytes = int(_lib.load().sn_dirac_workspace_bytes(nV, nF))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.call("sn_dirac_bsr4_from_mesh", _p(V), _p(F), nV, nF, _p(di_rp), _p(di_ci), _p(di_v), _p(diat_v), _p(dia_rp),
+              _p(dia_ci), _p(dia_v), _p(dit_v), _p(ws), ws_bytes, _stream())
+    return (di_rp, di_ci, di_v), (di_rp, di_ci, diat_v), (dia_rp, dia_ci, dia_v), (dia_rp, dia_ci, dit_v)

@@ -22,7 +22,7 @@ import torch
 
 from . import kernels
 
-__all__ = ["SparseOperator", "OperatorPool", "as_operator"]
+__all__ = ["SparseOperator", "OperatorPool", "as_operator", "dirac_operators_from_mesh"]
 
 # A BSR4 copy is kept when zero-fill costs at most this much extra storage over CSR entries.
 _BSR4_MAX_FILL = 1.6
@@ -42,11 +42,17 @@ class SparseOperator:
     def __init__(self, rowptr, colind, vals, shape, *, batch: int = 1, transpose: "Optional[SparseOperator]" = None,
                  bsr4=None):
         M, K = int(shape[0]), int(shape[1])
-        if rowptr.dtype != torch.int32 or colind.dtype != torch.int32 or vals.dtype != torch.float32:
-            raise TypeError("SparseOperator wants int32 rowptr/colind and float32 vals")
-        if rowptr.numel() != M + 1 or colind.numel() != vals.numel():
-            raise ValueError("inconsistent CSR arrays")
-        self.rowptr, self.colind, self.vals = rowptr, colind, vals
+        if rowptr is None:
+            if not isinstance(bsr4, tuple):
+                raise ValueError("an operator needs CSR arrays or a BSR4 triple")
+            self._csr = None                     # BSR4-only operator (device-built Dirac); CSR is expanded on demand
+        else:
+            if rowptr.dtype != torch.int32 or colind.dtype != torch.int32 or vals.dtype != torch.float32:
+                raise TypeError("SparseOperator wants int32 rowptr/colind and float32 vals")
+            if rowptr.numel() != M + 1 or colind.numel() != vals.numel():
+                raise ValueError("inconsistent CSR arrays")
+            self._csr = (rowptr, colind, vals)
+        self._nnz_cache = None
         self._shape = (M, K)
         self.batch = int(batch)                  # number of diagonal blocks (B of the reference's (B,R,K) operators)
         self._t = transpose
@@ -63,20 +69,43 @@ class SparseOperator:
     def dim(self) -> int:
         return 2
 
+    # CSR arrays; for a BSR4-only operator they are expanded once (explicit zeros of the blocks dropped)
+    def _ensure_csr(self):
+        if self._csr is None:
+            self._csr = _bsr4_to_csr(*self._bsr4, self._shape[0])
+        return self._csr
+
+    @property
+    def rowptr(self):
+        return self._ensure_csr()[0]
+
+    @property
+    def colind(self):
+        return self._ensure_csr()[1]
+
+    @property
+    def vals(self):
+        return self._ensure_csr()[2]
+
     @property
     def nnz(self) -> int:
-        return int(self.colind.numel())
+        if self._nnz_cache is None:
+            if self._csr is not None:
+                self._nnz_cache = int(self._csr[1].numel())
+            else:
+                self._nnz_cache = int(torch.count_nonzero(self._bsr4[2]).item())
+        return self._nnz_cache
 
     def _nnz(self) -> int:
         return self.nnz
 
     @property
     def device(self):
-        return self.rowptr.device
+        return (self._csr[0] if self._csr is not None else self._bsr4[0]).device
 
     @property
     def is_cuda(self) -> bool:
-        return self.rowptr.is_cuda
+        return self.device.type == "cuda"
 
     def cuda(self, *_, **__):
         return self.to("cuda")
@@ -86,9 +115,11 @@ class SparseOperator:
         if device.type == self.device.type and (device.index is None or device.index == self.device.index):
             return self
         mv = lambda t: t.to(device)
-        out = SparseOperator(mv(self.rowptr), mv(self.colind), mv(self.vals), self._shape, batch=self.batch)
-        if isinstance(self._bsr4, tuple):
-            out._bsr4 = tuple(mv(t) for t in self._bsr4)
+        b = tuple(mv(t) for t in self._bsr4) if isinstance(self._bsr4, tuple) else None
+        if self._csr is None:
+            out = SparseOperator(None, None, None, self._shape, batch=self.batch, bsr4=b)
+        else:
+            out = SparseOperator(mv(self.rowptr), mv(self.colind), mv(self.vals), self._shape, batch=self.batch, bsr4=b)
         if self._t is not None:
             out._t = self._t.to(device)
             out._t._t = out
@@ -107,6 +138,15 @@ class SparseOperator:
         return self._t
 
     T = property(t)
+
+    @classmethod
+    def from_bsr4(cls, fwd, bwd, shape, batch: int = 1) -> "SparseOperator":
+        """Operator and its transpose given directly as BSR4 triples (kernels.dirac_from_mesh)."""
+        M, K = int(shape[0]), int(shape[1])
+        op = cls(None, None, None, (M, K), batch=batch, bsr4=tuple(fwd))
+        opt = cls(None, None, None, (K, M), batch=batch, bsr4=tuple(bwd), transpose=op)
+        op._t = opt
+        return op
 
     def bsr4(self):
         """(b_rowptr, b_colind, b_vals) or None when the 4x4-block form is not applicable / not worthwhile."""
@@ -155,6 +195,50 @@ class SparseOperator:
 
         return sp.csr_matrix((self.vals.cpu().numpy(), self.colind.cpu().numpy(), self.rowptr.cpu().numpy()),
                              shape=self._shape)
+
+
+def _bsr4_to_csr(b_rowptr, b_colind, b_vals, M: int):
+    """Expand BSR4 to CSR with torch index arithmetic (not on the hot path: export / generic-kernel fallback only).
+    Explicit zeros of the blocks are dropped so that the result equals the coalesced operator."""
+    dev = b_rowptr.device
+    Mb = M // 4
+    nblk = int(b_colind.numel())
+    cnt = (b_rowptr[1:] - b_rowptr[:-1]).long()                                   # blocks per block row
+    brow = torch.repeat_interleave(torch.arange(Mb, device=dev), cnt)             # block row of each block
+    q = torch.arange(4, device=dev)
+    rows = (4 * brow[:, None, None] + q[None, :, None]).expand(nblk, 4, 4)
+    cols = (4 * b_colind.long()[:, None, None] + q[None, None, :]).expand(nblk, 4, 4)
+    v = b_vals.view(nblk, 4, 4)
+    keep = v != 0
+    rows, cols, v = rows[keep], cols[keep], v[keep]
+    order = torch.argsort(rows * (4 * (int(b_colind.max().item()) + 1 if nblk else 1)) + cols)
+    rows, cols, v = rows[order], cols[order], v[order]
+    rowptr = torch.zeros(M + 1, dtype=torch.int64, device=dev)
+    rowptr[1:] = torch.cumsum(torch.bincount(rows, minlength=M), 0)
+    return rowptr.int(), cols.int(), v.contiguous()
+
+
+def dirac_operators_from_mesh(V: torch.Tensor, F: torch.Tensor):
+    """(Di, DiA) SparseOperators (with transposes attached) built on the device from vertex positions V and faces F —
+    the on-the-fly replacement of the per-frame operators the reference precomputes with mesh.dirac
+    (src/as_rigid_as_possible/add_laplacian.py:50-65).
+
+    V: (nV,3) and F: (nF,3) for one mesh, or V: (B,nV,3) and F: (nF,3) shared / (B,nF,3) per-mesh faces for a batch
+    of equally sized meshes, which yields the block-diagonal batched operators directly."""
+    if V.dim() == 3:
+        B, nV = V.shape[0], V.shape[1]
+        Fb = F if F.dim() == 3 else F.unsqueeze(0).expand(B, -1, -1)
+        nF = Fb.shape[1]
+        off = (torch.arange(B, device=V.device, dtype=torch.int32) * nV).view(B, 1, 1)
+        Fg = (Fb.to(torch.int32) + off).reshape(B * nF, 3)
+        Vg = V.reshape(B * nV, 3)
+    else:
+        B, nV, nF = 1, V.shape[0], F.shape[0]
+        Vg, Fg = V, F.to(torch.int32)
+    di, diat, dia, dit = kernels.dirac_from_mesh(Vg.float(), Fg)
+    Di = SparseOperator.from_bsr4(di, dit, (4 * B * nF, 4 * B * nV), batch=B)
+    DiA = SparseOperator.from_bsr4(dia, diat, (4 * B * nV, 4 * B * nF), batch=B)
+    return Di, DiA
 
 
 def as_operator(A) -> SparseOperator:

@@ -136,6 +136,21 @@ def elu_bwd_bcast(gdst, out, bias, mask, gsrc, rows_per_seg):
     gsrc.copy_(torch.addcmul(gdst, b, torch.ones_like(b) * m) * torch.where(out > 0, torch.ones_like(out), out + 1))
 
 
+def dirac_from_mesh(V, F):
+    """Host restatement through mesh_ops.dirac (pinned to the reference) + the oracle's CSR->BSR4."""
+    import scipy.sparse as sp
+    from surfacenetworks_amd import mesh_ops
+
+    Vn, Fn = _np(V).astype(np.float64), _np(F).astype(np.int64)
+    D, DA = mesh_ops.dirac(Vn, Fn)
+    outs = []
+    for A in (D, DA.T.tocsr(), DA, D.T.tocsr()):
+        A = A.astype(np.float32).tocsr()
+        A.sort_indices()
+        outs.append(tuple(torch.from_numpy(a) for a in c_oracle.csr_to_bsr4(A.indptr, A.indices, A.data)))
+    return tuple(outs)
+
+
 def install(monkeypatch=None):
     """Patch surfacenetworks_amd.kernels in place (monkeypatch=None: permanent, for spawned worker processes)."""
     from surfacenetworks_amd import kernels
