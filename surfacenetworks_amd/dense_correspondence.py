@@ -89,6 +89,59 @@ def loss_fun_delta_cross_entropy(outputs, targetX, targetY):
     return loss / outputs.size(0)
 
 
+class _StreamedCorrespondenceCE(torch.autograd.Function):
+    """mean_i CE(FA[i]·FBᵀ, target[i]) without materialising the (NA, NB) score matrix (196 MB at 7000 x 7000, plus its
+    softmax and gradient in the reference: models.py:203, main.py:238-239).  Row blocks of FA are multiplied against FB,
+    reduced to a log-sum-exp and the target logit, and discarded; the backward recomputes each block."""
+
+    @staticmethod
+    def forward(ctx, FA, FB, target, block):
+        NA = FA.shape[0]
+        loss = FA.new_zeros((), dtype=torch.float64)
+        for r0 in range(0, NA, block):
+            logits = FA[r0:r0 + block] @ FB.t()
+            lse = torch.logsumexp(logits, dim=1)
+            tgt = logits.gather(1, target[r0:r0 + block, None]).squeeze(1)
+            loss += (lse - tgt).double().sum()
+        ctx.save_for_backward(FA, FB, target)
+        ctx.block = block
+        return (loss / NA).to(FA.dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        FA, FB, target = ctx.saved_tensors
+        NA = FA.shape[0]
+        gFA = torch.empty_like(FA)
+        gFB = torch.zeros_like(FB)
+        scale = g / NA
+        for r0 in range(0, NA, ctx.block):
+            a = FA[r0:r0 + ctx.block]
+            p = torch.softmax(a @ FB.t(), dim=1)
+            p.scatter_add_(1, target[r0:r0 + ctx.block, None], -torch.ones_like(p[:, :1]))
+            p *= scale
+            gFA[r0:r0 + ctx.block] = p @ FB
+            gFB += p.t() @ a
+        return gFA, gFB, None, None
+
+
+def streamed_delta_cross_entropy(FA, FB, targetX, targetY, block=1024):
+    """loss_fun_delta_cross_entropy (main.py:229-240) computed from the tower features instead of bmm(FA, FBᵀ):
+    FA, FB are the (B, N, 120) tower outputs.  Same value/gradients as SiameseModel + loss_fun_delta_cross_entropy,
+    including the reference's use of sample 0's scores for every i."""
+    B = FA.size(0)
+    loss = FA.new_zeros(())
+    for i in range(B):
+        GA, lA, liA = targetX[i]
+        GB, lB, liB = targetY[i]
+        NA, NB = lA.size(0), lB.size(0)
+        tgt = torch.empty(NA, dtype=torch.int64, device=FA.device)
+        for r0 in range(0, NA, block):                                  # argmin of GA[:, liA[lB]] + GB[liB[lA], :] by row blocks
+            rows = slice(r0, min(r0 + block, NA))
+            tgt[rows] = torch.argmin(GA[rows][:, liA[lB]] + GB[liB[lA[rows]], :], dim=1)
+        loss = loss + _StreamedCorrespondenceCE.apply(FA[0, :NA], FB[0, :NB], tgt, block)
+    return loss / B
+
+
 def make_optimizer(model):
     return torch.optim.Adam(model.parameters(), 1e-3, weight_decay=1e-5)       # main.py:285
 
