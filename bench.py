@@ -148,6 +148,16 @@ def main():
     dt = float(dt_t.item())
     assert torch.isfinite(loss).item(), "training diverged"
 
+    # ---- HIP-event bracket overhead (an empty start/end pair on the same busy stream), reported next to the raw number --
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
+    scratch = torch.empty(32 * 1024 * 1024, device=device)
+    for s_ev, e_ev in pairs:
+        scratch.add_(1.0)                      # keeps the queue non-empty so that the host stays ahead, as in the step
+        s_ev.record()
+        e_ev.record()
+    torch.cuda.synchronize()
+    ev_overhead_ms = float(np.median([a.elapsed_time(b) for a, b in pairs]))
+
     # ---- roofline of the dominant kernel, from the HIP events recorded during the timed steps ---------
     recs = timer.results()
     by = {}
@@ -187,6 +197,8 @@ def main():
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                      "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_c3.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per launch)" if traffic else None,
                      "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg_ms,
+                     "event_pair_overhead_ms": ev_overhead_ms,
+                     "frac_minus_event_overhead": ab / ((avg_ms - ev_overhead_ms) * 1e-3) / HBM_PEAK,
                      "launches_timed": len(by[dom]), "spmm_ms_per_step_all_kernels": spmm_ms_per_step},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
