@@ -9,8 +9,8 @@ GPU + forward + masked smooth-L1 loss + backward + flat-bucket RCCL gradient all
 Weak scaling: every rank owns its own 64 meshes (the path shards by mesh; no data-path collective).
 
 The JSON line also carries
-  roofline     the dominant kernel (Dirac SpMM, BSR4 form, N=32 dense columns) timed live with HIP events on the
-               launch stream during the timed steps; achieved = ALGORITHMIC CSR bytes (SURVEY.md §8d:
+  roofline     the dominant kernel (Dirac SpMM, BSR4 form, N=32 dense columns) timed live during the timed steps with
+               HIP events that carry the kernel's own start/stop (hipExtLaunchKernelGGL) on the launch stream; achieved = ALGORITHMIC CSR bytes (SURVEY.md §8d:
                nnz*8 + (M+1)*4 + K*N*4 + M*N*4) / average launch duration; peak = 8 TB/s HBM3E.
   cpu_baseline the reference's own CPU torch.sparse path (oracle restatement = "port") timed on this box's host cores
                on a bounded sample of the same workload (rank 0, N=1 only).
@@ -148,36 +148,39 @@ def main():
     dt = float(dt_t.item())
     assert torch.isfinite(loss).item(), "training diverged"
 
-    # ---- HIP-event bracket overhead (an empty start/end pair on the same busy stream), reported next to the raw number --
-    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(64)]
-    scratch = torch.empty(32 * 1024 * 1024, device=device)
-    for s_ev, e_ev in pairs:
-        scratch.add_(1.0)                      # keeps the queue non-empty so that the host stays ahead, as in the step
-        s_ev.record()
-        e_ev.record()
-    torch.cuda.synchronize()
-    ev_overhead_ms = float(np.median([a.elapsed_time(b) for a, b in pairs]))
-
     # ---- roofline of the dominant kernel, from the HIP events recorded during the timed steps ---------
     recs = timer.results()
-    by = {}
+    # group by KERNEL (as rocprofv3 --stats does): one template instantiation serves the four Dirac products
+    # (Di, DiA forward; Di^T, DiA^T backward), which differ only in which side is the face side.
+    by_kernel = {}
     for tag, M, K, nnz, N, ms in recs:
-        by.setdefault((tag, M, K, nnz, N), []).append(ms)
-    tot_ms = {k: float(np.sum(v)) for k, v in by.items()}
-    dom = max(tot_ms, key=tot_ms.get)             # the (kernel, shape) with the most accumulated time
-    tag, M, K, nnz, N = dom
-    avg_ms = float(np.mean(by[dom]))
-    ab = alg_bytes(M, K, nnz, N)
-    achieved = ab / (avg_ms * 1e-3)
-    spmm_ms_per_step = sum(tot_ms.values()) / args.steps
+        kname = ("spmm_bsr4_lds" if tag.endswith("/bsr4") else "spmm_csr_v4") + f"<N={N}>"
+        by_kernel.setdefault(kname, []).append((tag, M, K, nnz, N, ms))
+    dom_name = max(by_kernel, key=lambda k: sum(r[5] for r in by_kernel[k]))
+    dom = by_kernel[dom_name]
+    tot_ms = sum(r[5] for r in dom)
+    tot_bytes = sum(alg_bytes(r[1], r[2], r[3], r[4]) for r in dom)
+    avg_ms = tot_ms / len(dom)
+    ab = tot_bytes / len(dom)                      # average algorithmic bytes per launch of this kernel
+    achieved = tot_bytes / (tot_ms * 1e-3)
+    spmm_ms_per_step = sum(r[5] for r in recs) / args.steps
+    shapes = {}
+    for tag, M, K, nnz, N, ms in dom:
+        shapes.setdefault((tag, M, K, nnz, N), []).append(ms)
+    per_shape = [{"product": t, "M": M, "K": K, "nnz": nnz, "N": N, "launches": len(v), "avg_launch_ms": float(np.mean(v)),
+                  "algorithmic_bytes": alg_bytes(M, K, nnz, N), "frac": alg_bytes(M, K, nnz, N) / (float(np.mean(v)) * 1e-3) / HBM_PEAK}
+                 for (t, M, K, nnz, N), v in shapes.items()]
+    tag = dom[0][0]
 
-    # HBM traffic of that kernel/shape from the committed PMC measurement (rocprofv3 cannot run inside this process)
+    # HBM traffic of that kernel from the committed PMC measurement (rocprofv3 cannot run inside this process):
+    # average over the launches of the shapes that were measured
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_c3.json")) as fh:
-            rec = json.load(fh).get("spmm_bsr4_lds", {}).get(f"M={M},K={K},nnz={nnz},N={N}")
-        if rec and "bsr4" in tag:
-            traffic = rec["read_bytes"] + rec["write_bytes"]
+            table = json.load(fh).get("spmm_bsr4_lds", {})
+        per = [table.get(f"M={r[1]},K={r[2]},nnz={r[3]},N={r[4]}") for r in dom]
+        if "bsr4" in dom_name and all(per):
+            traffic = float(np.mean([p_["read_bytes"] + p_["write_bytes"] for p_ in per]))
     except OSError:
         pass
 
@@ -193,13 +196,12 @@ def main():
                                f"(V=5041,F=9800) per GPU, C=128, 15 layers, fwd+loss+bwd+allreduce+Adam",
                    "meshes_per_gpu": n_local, "global_batch": global_batch, "parallelism": f"dp{world} (mesh sharding, flat-bucket RCCL all-reduce)",
                    "operator_format": args.format, "operators": args.operators, "grad_bucket_bytes": bucket.nbytes},
-        "roofline": {"bound": "hbm", "kernel": f"{'spmm_bsr4_lds' if 'bsr4' in tag else 'spmm_csr_v4'}<N={N}> ({tag}, M={M}, K={K}, nnz={nnz})",
+        "roofline": {"bound": "hbm", "kernel": dom_name + " (all Dirac products of the step: Di, DiA forward; Di^T, DiA^T backward)",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                      "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_c3.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per launch)" if traffic else None,
                      "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg_ms,
-                     "event_pair_overhead_ms": ev_overhead_ms,
-                     "frac_minus_event_overhead": ab / ((avg_ms - ev_overhead_ms) * 1e-3) / HBM_PEAK,
-                     "launches_timed": len(by[dom]), "spmm_ms_per_step_all_kernels": spmm_ms_per_step},
+                     "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, every launch of the timed steps",
+                     "launches_timed": len(dom), "spmm_ms_per_step_all_kernels": spmm_ms_per_step, "per_product": per_shape},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sample_meshes=4, seed=3)

@@ -269,6 +269,17 @@ int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_
                             int32_t *dia_rowptr, int32_t *dia_colind, float *dia_vals, float *dit_vals,
                             void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Profiling aid (off by default; the library's only global state, mutex-guarded).  While enabled every SpMM launch
+ * (sn_spmm_csr_f32 / sn_spmm_bsr4_f32) is issued with hipExtLaunchKernelGGL so that the KERNEL's own start and stop are
+ * stamped into two events: durations carry no marker / kernel-boundary overhead and agree with rocprofv3's kernel trace.
+ * sn_timing_drain waits for the recorded launches, writes up to `capacity` durations (ms) and 5 int64 per record
+ * {kind (0 csr, 1 bsr4), M, K, nnz (csr) | nblocks (bsr4), N}, and clears the list.
+ * ------------------------------------------------------------------------------------------ */
+int     sn_timing_enable(int32_t on);
+int64_t sn_timing_count(void);
+int     sn_timing_drain(double *ms, int64_t *meta, int64_t capacity, int64_t *written);
+
 #ifdef __cplusplus
 }
 #endif

@@ -16,9 +16,13 @@
 // Reference semantics being replaced are cited per entry point in include/sn_spmm.h.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <limits.h>
 #include <stdint.h>
 #include <stdlib.h>
+
+#include <mutex>
+#include <vector>
 
 #include "sn_spmm.h"
 
@@ -645,20 +649,57 @@ int exclusive_scan_i32(const int *in, int64_t n, int *out, void *ws, size_t ws_b
   return launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------
+// Optional per-launch timing of the SpMM kernels (profiling aid, off by default): hipExtLaunchKernelGGL stamps the
+// kernel's own start/stop into two events, so the duration carries no marker or kernel-boundary overhead and agrees
+// with rocprofv3's kernel trace.  The only global state of the library; guarded by a mutex.
+// ------------------------------------------------------------------------------------------------
+struct TimedLaunch {
+  hipEvent_t start, stop;
+  int64_t meta[5];          // kind (0 csr, 1 bsr4), M, K, nnz (csr) or nblocks (bsr4), N
+};
+std::mutex g_timing_mu;
+bool g_timing_on = false;
+std::vector<TimedLaunch> g_timing;
+
+inline bool timing_slot(int kind, int64_t M, int64_t K, int64_t nnz, int N, hipEvent_t *s, hipEvent_t *e) {
+  *s = *e = nullptr;
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  if (!g_timing_on) return false;
+  TimedLaunch t;
+  if (hipEventCreate(&t.start) != hipSuccess) return false;
+  if (hipEventCreate(&t.stop) != hipSuccess) {
+    (void)hipEventDestroy(t.start);
+    return false;
+  }
+  t.meta[0] = kind; t.meta[1] = M; t.meta[2] = K; t.meta[3] = nnz; t.meta[4] = N;
+  g_timing.push_back(t);
+  *s = t.start;
+  *e = t.stop;
+  return true;
+}
+
+// launch with (t_start, t_stop) of the enclosing entry point when timing is on
+#define SN_KLAUNCH(KERNEL, grid, stream, ...)                                                                  \
+  do {                                                                                                         \
+    if (t_start) hipExtLaunchKernelGGL(KERNEL, dim3(grid), dim3(kWG), 0, stream, t_start, t_stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__);                            \
+  } while (0)
+
 #define SN_DISPATCH_N_G(KERNEL, N, xg, yg, grid, stream, ...)                                          \
   do {                                                                                                 \
-    if (xg == 1 && yg == 1) hipLaunchKernelGGL((KERNEL<N, 1, 1>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
-    else if (xg == 4 && yg == 4) hipLaunchKernelGGL((KERNEL<N, 4, 4>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
-    else if (xg == 1 && yg == 4) hipLaunchKernelGGL((KERNEL<N, 1, 4>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((KERNEL<N, 4, 1>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__);         \
+    if (xg == 1 && yg == 1) SN_KLAUNCH((KERNEL<N, 1, 1>), grid, stream, __VA_ARGS__); \
+    else if (xg == 4 && yg == 4) SN_KLAUNCH((KERNEL<N, 4, 4>), grid, stream, __VA_ARGS__); \
+    else if (xg == 1 && yg == 4) SN_KLAUNCH((KERNEL<N, 1, 4>), grid, stream, __VA_ARGS__); \
+    else SN_KLAUNCH((KERNEL<N, 4, 1>), grid, stream, __VA_ARGS__);         \
   } while (0)
 
 #define SN_DISPATCH_CSR_KB(N, KB, xg, yg, grid, stream, ...)                                                   \
   do {                                                                                                         \
-    if (xg == 1 && yg == 1) hipLaunchKernelGGL((spmm_csr_v4<N, 1, 1, KB>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
-    else if (xg == 4 && yg == 4) hipLaunchKernelGGL((spmm_csr_v4<N, 4, 4, KB>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
-    else if (xg == 1 && yg == 4) hipLaunchKernelGGL((spmm_csr_v4<N, 1, 4, KB>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((spmm_csr_v4<N, 4, 1, KB>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__);         \
+    if (xg == 1 && yg == 1) SN_KLAUNCH((spmm_csr_v4<N, 1, 1, KB>), grid, stream, __VA_ARGS__); \
+    else if (xg == 4 && yg == 4) SN_KLAUNCH((spmm_csr_v4<N, 4, 4, KB>), grid, stream, __VA_ARGS__); \
+    else if (xg == 1 && yg == 4) SN_KLAUNCH((spmm_csr_v4<N, 1, 4, KB>), grid, stream, __VA_ARGS__); \
+    else SN_KLAUNCH((spmm_csr_v4<N, 4, 1, KB>), grid, stream, __VA_ARGS__);         \
   } while (0)
 #define SN_DISPATCH_CSR(N, xg, yg, grid, stream, ...)                                      \
   do {                                                                                     \
@@ -668,10 +709,10 @@ int exclusive_scan_i32(const int *in, int64_t n, int *out, void *ws, size_t ws_b
 
 #define SN_DISPATCH_LDS_U(N, DMA, UNR, xg, yg, grid, stream, ...)                                                     \
   do {                                                                                                         \
-    if (xg == 1 && yg == 1) hipLaunchKernelGGL((spmm_bsr4_lds<N, 1, 1, DMA, UNR>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
-    else if (xg == 4 && yg == 4) hipLaunchKernelGGL((spmm_bsr4_lds<N, 4, 4, DMA, UNR>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
-    else if (xg == 1 && yg == 4) hipLaunchKernelGGL((spmm_bsr4_lds<N, 1, 4, DMA, UNR>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__); \
-    else hipLaunchKernelGGL((spmm_bsr4_lds<N, 4, 1, DMA, UNR>), dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__);       \
+    if (xg == 1 && yg == 1) SN_KLAUNCH((spmm_bsr4_lds<N, 1, 1, DMA, UNR>), grid, stream, __VA_ARGS__); \
+    else if (xg == 4 && yg == 4) SN_KLAUNCH((spmm_bsr4_lds<N, 4, 4, DMA, UNR>), grid, stream, __VA_ARGS__); \
+    else if (xg == 1 && yg == 4) SN_KLAUNCH((spmm_bsr4_lds<N, 1, 4, DMA, UNR>), grid, stream, __VA_ARGS__); \
+    else SN_KLAUNCH((spmm_bsr4_lds<N, 4, 1, DMA, UNR>), grid, stream, __VA_ARGS__);       \
   } while (0)
 
 #define SN_DISPATCH_LDS(N, DMA, xg, yg, grid, stream, ...)                                     \
@@ -722,6 +763,8 @@ int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *v
     if (st) return st;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t t_start, t_stop;
+  timing_slot(0, M, K, nnz, N, &t_start, &t_stop);
   const bool vec = (N == 16 || N == 32 || N == 64 || N == 128) && aligned16(X) && aligned16(Y) &&
                    (ldx % 4 == 0) && (ldy % 4 == 0);
   if (vec) {
@@ -736,8 +779,8 @@ int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *v
       default: SN_DISPATCH_CSR(128, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters); break;
     }
   } else {
-    hipLaunchKernelGGL(spmm_csr_any, dim3(grid_for(M * (int64_t)N, kWG)), dim3(kWG), 0, s, rowptr, colind,
-                       vals, M, (int)N, X, ldx, (int)x_group, Y, ldy, (int)y_group);
+    SN_KLAUNCH(spmm_csr_any, grid_for(M * (int64_t)N, kWG), s, rowptr, colind, vals, M, (int)N, X, ldx, (int)x_group, Y,
+               ldy, (int)y_group);
   }
   return launch_status();
 }
@@ -758,6 +801,8 @@ int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const flo
   if (!(N == 16 || N == 32 || N == 64 || N == 128)) return SN_E_UNSUPPORTED;
   if (!aligned16(X) || !aligned16(Y) || !aligned16(b_vals) || ldx % 4 || ldy % 4) return SN_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t t_start, t_stop;
+  timing_slot(1, 4 * Mb, 4 * Kb, nblocks, N, &t_start, &t_stop);
   const int variant = tune_bsr4_variant();
   const int iters = variant == 0 ? 1 : tune_bsr4_iters();
   const int rpb = kWG / (N / 4) * iters;
@@ -935,6 +980,43 @@ int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64
     else hipLaunchKernelGGL((elu_bwd_k<false, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C);
   }
   return launch_status();
+}
+
+int sn_timing_enable(int32_t on) {
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  g_timing_on = on != 0;
+  return SN_OK;
+}
+
+int64_t sn_timing_count(void) {
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  return (int64_t)g_timing.size();
+}
+
+int sn_timing_drain(double *ms, int64_t *meta, int64_t capacity, int64_t *written) {
+  if (capacity < 0 || !written || (capacity > 0 && (!ms || !meta))) return SN_E_NULL;
+  std::vector<TimedLaunch> recs;
+  {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    recs.swap(g_timing);
+  }
+  int64_t n = 0;
+  int status = SN_OK;
+  for (const TimedLaunch &t : recs) {
+    float el = 0.f;
+    hipError_t e = hipEventSynchronize(t.stop);
+    if (e == hipSuccess) e = hipEventElapsedTime(&el, t.start, t.stop);
+    if (e != hipSuccess && status == SN_OK) status = (int)e;
+    if (e == hipSuccess && n < capacity) {
+      ms[n] = el;
+      for (int i = 0; i < 5; ++i) meta[5 * n + i] = t.meta[i];
+      ++n;
+    }
+    (void)hipEventDestroy(t.start);
+    (void)hipEventDestroy(t.stop);
+  }
+  *written = n;
+  return status;
 }
 
 }  // extern "C"

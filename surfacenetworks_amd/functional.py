@@ -32,24 +32,55 @@ def set_dirac_format(fmt: str) -> None:
 
 
 class SpmmTimer:
-    """Optional HIP-event timing of every SpMM launch (bench.py uses it to measure the dominant kernel live,
-    on the stream the kernel is launched on).  Off by default: zero overhead."""
+    """Optional per-launch timing of every SpMM (bench.py measures the dominant kernel live with it).  Uses the
+    library's timing facility (sn_timing_*): hipExtLaunchKernelGGL stamps each kernel's own start/stop into HIP events
+    on the launch stream, so the durations agree with rocprofv3's kernel trace.  Off by default: zero overhead."""
 
     active = None
 
     def __init__(self):
-        self.records = []      # (tag, M, K, nnz, N, start_event, end_event)
+        self.tags = []          # one (tag, nnz) per launch, in launch order
 
     def __enter__(self):
+        from . import _lib
+
+        _lib.call("sn_timing_drain", None, None, 0, _ctypes_i64_ref())       # drop stale records
+        _lib.call("sn_timing_enable", 1)
         SpmmTimer.active = self
         return self
 
     def __exit__(self, *exc):
+        from . import _lib
+
         SpmmTimer.active = None
+        _lib.call("sn_timing_enable", 0)
 
     def results(self):
-        torch.cuda.synchronize()
-        return [(tag, M, K, nnz, N, s.elapsed_time(e)) for tag, M, K, nnz, N, s, e in self.records]
+        """[(tag, M, K, nnz, N, milliseconds)] for every launch recorded while the timer was active."""
+        import ctypes
+        import numpy as np
+
+        from . import _lib
+
+        n = int(_lib.load().sn_timing_count())
+        ms = np.zeros(max(n, 1), np.float64)
+        meta = np.zeros((max(n, 1), 5), np.int64)
+        written = ctypes.c_int64(0)
+        _lib.call("sn_timing_drain", ms.ctypes.data, meta.ctypes.data, n, ctypes.addressof(written))
+        if written.value != len(self.tags):
+            raise RuntimeError(f"timing records ({written.value}) do not match launches ({len(self.tags)})")
+        out = []
+        for i, (tag, nnz) in enumerate(self.tags):
+            kind, M, K, _, N = meta[i]
+            out.append((tag + ("/bsr4" if kind == 1 else "/csr"), int(M), int(K), int(nnz), int(N), float(ms[i])))
+        return out
+
+
+def _ctypes_i64_ref():
+    import ctypes
+
+    _ctypes_i64_ref.slot = ctypes.c_int64(0)          # kept alive on the function object
+    return ctypes.addressof(_ctypes_i64_ref.slot)
 
 
 def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, tag: str = "") -> None:
@@ -57,16 +88,12 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
     M, K = op.shape
     timer = SpmmTimer.active
     if timer is not None:
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
+        timer.tags.append((tag, op.nnz))
     b = op.bsr4() if (_USE_BSR4 and group == 4) else None
     if b is not None:
         kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
     else:
         kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x, y, group)
-    if timer is not None:
-        e.record()
-        timer.records.append((tag + ("/bsr4" if b is not None else "/csr"), M, K, op.nnz, y.shape[1] // group, s, e))
 
 
 def _rows2d(x: torch.Tensor) -> torch.Tensor:

@@ -271,3 +271,25 @@ def test_error_codes():
     kernels.spmm_csr(rp, torch.zeros(0, dtype=torch.int32, device=DEV), torch.zeros(0, device=DEV), 4, 4,
                      torch.ones(4, 16, device=DEV), y, 1)
     assert torch.equal(y, torch.zeros_like(y))
+
+
+def test_timing_facility_matches_event_bracketing():
+    """sn_timing_*: per-launch kernel durations via hipExtLaunchKernelGGL; count/order/metadata and plausibility."""
+    _, _, ops = mesh_fixture("cloth")
+    A = ops["Di"]
+    M, K = A.shape
+    op = SparseOperator.from_scipy(A, DEV)
+    x = torch.randn(K // 4, 128, device=DEV, requires_grad=True)
+    with snF.SpmmTimer() as t:
+        for _ in range(3):
+            y = snF.spmm(op, x, 4)
+        y.sum().backward()
+    recs = t.results()
+    assert [r[0] for r in recs] == ["fwd/bsr4"] * 3 + ["bwd/bsr4"]
+    assert all(r[1:3] == (M, K) for r in recs[:3]) and recs[3][1:3] == (K, M)
+    assert all(r[3] == A.nnz and r[4] == 32 for r in recs)
+    assert all(1e-4 < r[5] < 5.0 for r in recs)
+    # facility is off again: nothing recorded
+    snF.spmm(op, x, 4)
+    from surfacenetworks_amd import _lib
+    assert _lib.load().sn_timing_count() == 0
