@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sn_spmm.h"
 
@@ -21,6 +22,20 @@ constexpr int kCUs = 256;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
+  return nt ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p);
+}
+__device__ __forceinline__ void st4_s(float *p, f4 v, int nt) {
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+  else *reinterpret_cast<f4 *>(p) = v;
+}
+
+inline int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+inline int64_t tune_ew_cap() { static const int v = env_int("SN_EW_BLOCKS_CAP", 0); return v > 0 ? v : (int64_t)INT_MAX; }
+inline int tune_ew_nt() { static const int v = env_int("SN_EW_NT", 1); return v; }
 
 inline int launch_status() {
   const hipError_t e = hipGetLastError();
@@ -229,7 +244,7 @@ __global__ __launch_bounds__(kWG) void affine_cols_acc_k(float *__restrict__ dx,
                                                          const float *__restrict__ x, int64_t ldx,
                                                          const float *__restrict__ center,
                                                          const float *__restrict__ B, const float *__restrict__ Cc,
-                                                         int64_t rows, int C) {
+                                                         int64_t rows, int C, int nt) {
   constexpr int W = VEC ? 4 : 1;
   const int cw = C / W;
   const int64_t total = rows * cw;
@@ -237,8 +252,8 @@ __global__ __launch_bounds__(kWG) void affine_cols_acc_k(float *__restrict__ dx,
     const int64_t r = t / cw;
     const int c = (int)(t - r * cw) * W;
     if constexpr (VEC) {
-      f4 d = *reinterpret_cast<f4 *>(dx + r * lddx + c);
-      f4 xv = *reinterpret_cast<const f4 *>(x + r * ldx + c);
+      f4 d = ld4_s(dx + r * lddx + c, nt);
+      f4 xv = ld4_s(x + r * ldx + c, nt);
       if (center) xv -= *reinterpret_cast<const f4 *>(center + c);
       const f4 b = *reinterpret_cast<const f4 *>(B + c);
       const f4 k = *reinterpret_cast<const f4 *>(Cc + c);
@@ -246,7 +261,7 @@ __global__ __launch_bounds__(kWG) void affine_cols_acc_k(float *__restrict__ dx,
       d.y += __builtin_fmaf(xv.y, b.y, k.y);
       d.z += __builtin_fmaf(xv.z, b.z, k.z);
       d.w += __builtin_fmaf(xv.w, b.w, k.w);
-      *reinterpret_cast<f4 *>(dx + r * lddx + c) = d;
+      st4_s(dx + r * lddx + c, d, nt);
     } else {
       dx[r * lddx + c] += __builtin_fmaf(x[r * ldx + c] - (center ? center[c] : 0.f), B[c], Cc[c]);
     }
@@ -402,13 +417,13 @@ __global__ __launch_bounds__(kWG) void segsum_final_k(const double *__restrict__
 }
 
 __global__ __launch_bounds__(kWG) void bcast_rows_k(const float *__restrict__ src, float *__restrict__ dst, int64_t ldd,
-                                                    int64_t rows_per_seg, int64_t rows, int C) {
+                                                    int64_t rows_per_seg, int64_t rows, int C, int nt) {
   const int cw = C / 4;
   const int64_t total = rows * cw;
   for (int64_t t = (int64_t)blockIdx.x * kWG + threadIdx.x; t < total; t += (int64_t)gridDim.x * kWG) {
     const int64_t r = t / cw;
     const int c = (int)(t - r * cw) * 4;
-    *reinterpret_cast<f4 *>(dst + r * ldd + c) = *reinterpret_cast<const f4 *>(src + (r / rows_per_seg) * C + c);
+    st4_s(dst + r * ldd + c, *reinterpret_cast<const f4 *>(src + (r / rows_per_seg) * C + c), nt);
   }
 }
 
@@ -416,14 +431,14 @@ __global__ __launch_bounds__(kWG) void elu_bwd_bcast_k(const float *__restrict__
                                                        const float *__restrict__ out, int64_t ldo,
                                                        const float *__restrict__ bias, const float *__restrict__ mask,
                                                        float *__restrict__ gsrc, int64_t ldgs, int64_t rows_per_seg,
-                                                       int64_t rows, int C) {
+                                                       int64_t rows, int C, int nt) {
   const int cw = C / 4;
   const int64_t total = rows * cw;
   for (int64_t t = (int64_t)blockIdx.x * kWG + threadIdx.x; t < total; t += (int64_t)gridDim.x * kWG) {
     const int64_t r = t / cw;
     const int c = (int)(t - r * cw) * 4;
-    const f4 g = *reinterpret_cast<const f4 *>(gdst + r * ldg + c);
-    const f4 o = *reinterpret_cast<const f4 *>(out + r * ldo + c);
+    const f4 g = ld4_s(gdst + r * ldg + c, nt);
+    const f4 o = ld4_s(out + r * ldo + c, nt);
     const f4 b = *reinterpret_cast<const f4 *>(bias + (r / rows_per_seg) * C + c);
     const float m = mask ? mask[r] : 1.f;
     f4 d;
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(kWG) void elu_bwd_bcast_k(const float *__restrict__
     d.y = __builtin_fmaf(m, b.y, g.y) * (o.y > 0.f ? 1.f : o.y + 1.f);
     d.z = __builtin_fmaf(m, b.z, g.z) * (o.z > 0.f ? 1.f : o.z + 1.f);
     d.w = __builtin_fmaf(m, b.w, g.w) * (o.w > 0.f ? 1.f : o.w + 1.f);
-    *reinterpret_cast<f4 *>(gsrc + r * ldgs + c) = d;
+    st4_s(gsrc + r * ldgs + c, d, nt);
   }
 }
 
@@ -524,11 +539,11 @@ int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx,
                    aligned16(Cc) && (!center || aligned16(center));
   int64_t items = vec ? rows * (C / 4) : rows * (int64_t)C;
   int64_t blocks = (items + kWG - 1) / kWG;
-  if (blocks > (int64_t)kCUs * 16) blocks = (int64_t)kCUs * 16;
+  if (blocks > tune_ew_cap()) blocks = tune_ew_cap();
   if (vec)
-    hipLaunchKernelGGL((affine_cols_acc_k<true>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C);
+    hipLaunchKernelGGL((affine_cols_acc_k<true>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C, tune_ew_nt());
   else
-    hipLaunchKernelGGL((affine_cols_acc_k<false>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C);
+    hipLaunchKernelGGL((affine_cols_acc_k<false>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C, tune_ew_nt());
   return launch_status();
 }
 
@@ -564,7 +579,7 @@ static bool seg_shape_ok(int32_t C) { return C >= 4 && (C % 4 == 0) && (kWG % (C
 
 static unsigned ew_grid(int64_t items) {
   int64_t b = (items + kWG - 1) / kWG;
-  if (b > (int64_t)kCUs * 16) b = (int64_t)kCUs * 16;
+  if (b > tune_ew_cap()) b = tune_ew_cap();
   return (unsigned)(b < 1 ? 1 : b);
 }
 
@@ -596,7 +611,7 @@ int sn_bcast_rows_f32(const float *src, float *dst, int64_t ldd, int64_t rows_pe
   if (!src || !dst) return SN_E_NULL;
   if (!aligned16(src) || !aligned16(dst)) return SN_E_ALIGN;
   hipLaunchKernelGGL(bcast_rows_k, dim3(ew_grid(rows * (C / 4))), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, dst,
-                     ldd, rows_per_seg, rows, (int)C);
+                     ldd, rows_per_seg, rows, (int)C, tune_ew_nt());
   return launch_status();
 }
 
@@ -610,7 +625,7 @@ int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64
   if (!gdst || !out || !bias || !gsrc) return SN_E_NULL;
   if (!aligned16(gdst) || !aligned16(out) || !aligned16(bias) || !aligned16(gsrc)) return SN_E_ALIGN;
   hipLaunchKernelGGL(elu_bwd_bcast_k, dim3(ew_grid(rows * (C / 4))), dim3(kWG), 0, static_cast<hipStream_t>(stream), gdst,
-                     ldg, out, ldo, bias, mask, gsrc, ldgs, rows_per_seg, rows, (int)C);
+                     ldg, out, ldo, bias, mask, gsrc, ldgs, rows_per_seg, rows, (int)C, tune_ew_nt());
   return launch_status();
 }
 

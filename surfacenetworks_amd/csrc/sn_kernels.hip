@@ -40,6 +40,14 @@ __device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p)
 __device__ __forceinline__ void st4_stream(float *p, f4 v) {
   __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
 }
+// streaming (non-temporal) forms for data that is touched once per kernel: measured +15-30 % on 1:1 copy-like passes
+__device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
+  return nt ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p);
+}
+__device__ __forceinline__ void st4_s(float *p, f4 v, int nt) {
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+  else *reinterpret_cast<f4 *>(p) = v;
+}
 __device__ __forceinline__ f4 fma4(float a, f4 x, f4 acc) {
   acc.x = __builtin_fmaf(a, x.x, acc.x);
   acc.y = __builtin_fmaf(a, x.y, acc.y);
@@ -112,6 +120,173 @@ __global__ __launch_bounds__(kWG) void spmm_csr_v4(const int *__restrict__ rowpt
       for (int i = 0; i < kBatch; ++i) acc = fma4(a[i], x[i], acc);
     }
     st4_stream(Y + row_off<YG, N>(r, ldy) + sub * 4, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR SpMM with the operator entries of each wave pass staged through LDS.
+//
+// In spmm_csr_v4 the N/4 lanes of a row all load the same colind / vals words: at N = 128 a wave issues 16 two-address
+// "broadcast" loads per pass next to 8 useful 1-KiB gathers, and vector-memory ISSUE, not HBM, bounds the kernel.
+// Here a wave copies the contiguous entry run [rowptr[r0], rowptr[r0 + P)) of its P = 256/N rows into its private LDS
+// slice with two coalesced 4-byte-per-lane DMA loads per 64 entries, and lane groups read their entries back with
+// broadcast ds_reads.  Same arithmetic order as spmm_csr_v4 (k-ascending FMA chain), so results are bit-identical.
+// ------------------------------------------------------------------------------------------------
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) void spmm_csr_lds(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                    const float *__restrict__ vals, int M,
+                                                    const float *__restrict__ X, int64_t ldx,
+                                                    float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
+  constexpr int LPR = N / 4;          // lanes per row
+  constexpr int P = 64 / LPR;         // rows per wave pass
+  constexpr int WAVES = kWG / 64;
+  constexpr int TILE = 256;           // entries staged per wave per tile
+  constexpr int KB = 8;               // gathers in flight per lane
+  __shared__ int s_col[WAVES][TILE];
+  __shared__ float s_val[WAVES][TILE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane % LPR, grp = lane / LPR;
+  const float *xb = X + sub * 4;
+  int *sc = s_col[wave];
+  float *sv = s_val[wave];
+  ChunkWalk w(nchunks);               // a chunk = iters passes of WAVES * P rows
+  for (int local = w.first; local < w.cpx; local += w.step)
+  for (int it = 0; it < iters; ++it) {
+    const int r0 = (((w.base + local) * iters + it) * WAVES + wave) * P;
+    if (r0 >= M) continue;            // wave-uniform
+    const int r = r0 + grp;
+    const int rc = r < M ? r : M;
+    const int kb = rowptr[rc];
+    const int ke = rowptr[rc + 1 <= M ? rc + 1 : M];
+    const int k0 = __builtin_amdgcn_readfirstlane(kb);
+    const int k1 = __builtin_amdgcn_readlane(ke, 63);
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int t0 = k0; t0 < k1; t0 += TILE) {
+      const int nt = (k1 - t0) < TILE ? (k1 - t0) : TILE;
+      for (int p0 = 0; p0 < nt; p0 += 64) {
+        int p = p0 + lane;
+        p = p < nt ? p : nt - 1;      // tail lanes re-read the last entry into spare slots
+        __builtin_amdgcn_global_load_lds(colind + t0 + p, sc + p0, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(vals + t0 + p, sv + p0, 4, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      int k = kb > t0 ? kb : t0;
+      const int kend = ke < t0 + nt ? ke : t0 + nt;
+      for (; k < kend; k += KB) {
+        int c[KB];
+        float a[KB];
+        f4 x[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const bool in = k + i < kend;
+          const int o = (in ? k + i : kend - 1) - t0;
+          c[i] = sc[o];
+          a[i] = in ? sv[o] : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < KB; ++i) x[i] = ld4(xb + row_off<XG, N>(c[i], ldx));
+#pragma unroll
+        for (int i = 0; i < KB; ++i) acc = fma4(a[i], x[i], acc);
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (r < M) st4_stream(Y + row_off<YG, N>(r, ldy) + sub * 4, acc);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Software-pipelined variant of spmm_csr_lds: a wave walks `iters` passes and keeps the NEXT pass's operator entries
+// (LDS-DMA into the other half of a double buffer) and the pass-after-next's row pointers in flight while it gathers
+// and accumulates the current pass.  One exposed memory latency per pass instead of three dependent ones
+// (rowptr -> entries -> gathers): with 2 rows per wave pass at N = 128 that chain, not HBM, bounded the kernel.
+// ------------------------------------------------------------------------------------------------
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) void spmm_csr_pipe(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                     const float *__restrict__ vals, int M,
+                                                     const float *__restrict__ X, int64_t ldx,
+                                                     float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
+  constexpr int LPR = N / 4;
+  constexpr int P = 64 / LPR;
+  constexpr int WAVES = kWG / 64;
+  constexpr int TILE = 256;
+  constexpr int KB = 8;
+  __shared__ int s_col[WAVES][2][TILE];
+  __shared__ float s_val[WAVES][2][TILE];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane % LPR, grp = lane / LPR;
+  const float *xb = X + sub * 4;
+  ChunkWalk w(nchunks);
+  for (int local = w.first; local < w.cpx; local += w.step) {
+    const int pass0 = (w.base + local) * iters;                    // first pass index of this workgroup's chunk
+    auto first_row = [&](int it) { return ((pass0 + it) * WAVES + wave) * P; };
+    auto load_rp = [&](int it, int &kb, int &ke) {                  // this lane group's [begin, end) for pass `it`
+      const int r = first_row(it) + grp;
+      const int rc = r < M ? r : M;
+      kb = rowptr[rc];
+      ke = rowptr[rc + 1 <= M ? rc + 1 : M];
+    };
+    auto stage = [&](int buf, int k0, int k1) {                     // async copy of entries [k0, k1) (<= TILE) into LDS
+      const int nt = k1 - k0;
+      for (int p0 = 0; p0 < nt; p0 += 64) {
+        int p = p0 + lane;
+        p = p < nt ? p : nt - 1;
+        __builtin_amdgcn_global_load_lds(colind + k0 + p, &s_col[wave][buf][p0], 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(vals + k0 + p, &s_val[wave][buf][p0], 4, 0, 0);
+      }
+    };
+    int kb, ke, kbn = 0, ken = 0;
+    load_rp(0, kb, ke);
+    int k0 = __builtin_amdgcn_readfirstlane(kb), k1 = __builtin_amdgcn_readlane(ke, 63);
+    bool staged = (k1 - k0) <= TILE;
+    if (staged && first_row(0) < M) stage(0, k0, k1);
+    if (iters > 1) load_rp(1, kbn, ken);
+    for (int it = 0; it < iters; ++it) {
+      const int cur = it & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // entries of pass `it` landed, row pointers of it+1 arrived
+      __builtin_amdgcn_wave_barrier();
+      // ---- kick off pass it+1 (entries) and it+2 (row pointers) before touching pass it ----
+      int k0n = 0, k1n = 0, kb2 = 0, ke2 = 0;
+      bool stagedn = false;
+      if (it + 1 < iters) {
+        k0n = __builtin_amdgcn_readfirstlane(kbn);
+        k1n = __builtin_amdgcn_readlane(ken, 63);
+        stagedn = (k1n - k0n) <= TILE;
+        if (stagedn && first_row(it + 1) < M) stage(cur ^ 1, k0n, k1n);
+      }
+      if (it + 2 < iters) load_rp(it + 2, kb2, ke2);
+      // ---- pass it ----
+      const int r = first_row(it) + grp;
+      if (first_row(it) < M) {
+        f4 acc = {0.f, 0.f, 0.f, 0.f};
+        if (staged) {
+          const int *sc = s_col[wave][cur];
+          const float *sv = s_val[wave][cur];
+          for (int k = kb; k < ke; k += KB) {
+            int c[KB];
+            float a[KB];
+            f4 x[KB];
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+              const bool in = k + i < ke;
+              const int o = (in ? k + i : ke - 1) - k0;
+              c[i] = sc[o];
+              a[i] = in ? sv[o] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < KB; ++i) x[i] = ld4(xb + row_off<XG, N>(c[i], ldx));
+#pragma unroll
+            for (int i = 0; i < KB; ++i) acc = fma4(a[i], x[i], acc);
+          }
+        } else {                                                    // a pass with more than TILE entries: direct loads
+          for (int k = kb; k < ke; ++k) acc = fma4(vals[k], ld4(xb + row_off<XG, N>(colind[k], ldx)), acc);
+        }
+        if (r < M) st4_stream(Y + row_off<YG, N>(r, ldy) + sub * 4, acc);
+      }
+      kb = kbn; ke = ken; k0 = k0n; k1 = k1n; staged = stagedn;
+      kbn = kb2; ken = ke2;
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -536,7 +711,7 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x);
 template <bool VEC>
 __global__ __launch_bounds__(kWG) void elu_into_k(const float *__restrict__ src, int64_t lds,
                                                   float *__restrict__ dst, int64_t ldd, int64_t rows,
-                                                  int C) {
+                                                  int C, int nt) {
   constexpr int W = VEC ? 4 : 1;
   const int cw = C / W;
   const int64_t total = rows * cw;
@@ -544,9 +719,9 @@ __global__ __launch_bounds__(kWG) void elu_into_k(const float *__restrict__ src,
     const int64_t r = t / cw;
     const int c = (int)(t - r * cw) * W;
     if constexpr (VEC) {
-      f4 v = ld4(src + r * lds + c);
+      f4 v = ld4_s(src + r * lds + c, nt);
       v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
-      st4(dst + r * ldd + c, v);
+      st4_s(dst + r * ldd + c, v, nt);
     } else {
       dst[r * ldd + c] = elu1(src[r * lds + c]);
     }
@@ -558,7 +733,7 @@ __global__ __launch_bounds__(kWG) void elu_bwd_k(const float *__restrict__ gdst,
                                                  const float *__restrict__ gdst2, int64_t ldg2,
                                                  const float *__restrict__ out, int64_t ldo,
                                                  float *__restrict__ gsrc, int64_t ldgs, int64_t rows,
-                                                 int C) {
+                                                 int C, int nt) {
   constexpr int W = VEC ? 4 : 1;
   const int cw = C / W;
   const int64_t total = rows * cw;
@@ -566,9 +741,9 @@ __global__ __launch_bounds__(kWG) void elu_bwd_k(const float *__restrict__ gdst,
     const int64_t r = t / cw;
     const int c = (int)(t - r * cw) * W;
     if constexpr (VEC) {
-      f4 g = ld4(gdst + r * ldg + c);
-      if (gdst2) g += ld4(gdst2 + r * ldg2 + c);
-      const f4 o = ld4(out + r * ldo + c);
+      f4 g = ld4_s(gdst + r * ldg + c, nt);
+      if (gdst2) g += ld4_s(gdst2 + r * ldg2 + c, nt);
+      const f4 o = ld4_s(out + r * ldo + c, nt);
       f4 d;
       d.x = g.x * (o.x > 0.f ? 1.f : o.x + 1.f);
       d.y = g.y * (o.y > 0.f ? 1.f : o.y + 1.f);
@@ -576,10 +751,10 @@ __global__ __launch_bounds__(kWG) void elu_bwd_k(const float *__restrict__ gdst,
       d.w = g.w * (o.w > 0.f ? 1.f : o.w + 1.f);
       float *p = gsrc + r * ldgs + c;
       if constexpr (ACC) {
-        const f4 a = ld4(p);
+        const f4 a = ld4_s(p, nt);
         d.x += a.x; d.y += a.y; d.z += a.z; d.w += a.w;
       }
-      st4(p, d);
+      st4_s(p, d, nt);
     } else {
       const float o = out[r * ldo + c];
       const float d = (gdst[r * ldg + c] + (gdst2 ? gdst2[r * ldg2 + c] : 0.f)) * (o > 0.f ? 1.f : o + 1.f);
@@ -597,22 +772,27 @@ inline int launch_status() {
   return e == hipSuccess ? SN_OK : (int)e;
 }
 
+inline int env_int(const char *name, int dflt) {
+  const char *v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+// Elementwise passes: one 16-byte item per thread and as many workgroups as that takes (measured faster than a capped
+// grid-stride loop: 6.5 vs 4.9 TB/s on a 1 GiB copy), non-temporal loads/stores.  SN_EW_BLOCKS_CAP / SN_EW_NT for A/B.
+inline int64_t tune_ew_cap() { static const int v = env_int("SN_EW_BLOCKS_CAP", 0); return v > 0 ? v : (int64_t)INT_MAX; }
+inline int tune_ew_nt() { static const int v = env_int("SN_EW_NT", 1); return v; }
 inline unsigned grid_for(int64_t work_items, int per_block) {
   int64_t b = (work_items + per_block - 1) / per_block;
   if (b < 1) b = 1;
-  const int64_t cap = (int64_t)kCUs * kMaxBlocksPerCU;
+  const int64_t cap = tune_ew_cap();
   return (unsigned)(b < cap ? b : cap);
 }
 
 // Development tunables (read once): SN_BLOCKS_PER_CU caps the persistent grid (0 = one workgroup per chunk),
 // SN_BSR4_VARIANT picks 0 = direct loads, 1 = LDS-staged, 2 = LDS-staged via global_load_lds.
-inline int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
 inline int tune_blocks_per_cu() { static const int v = env_int("SN_BLOCKS_PER_CU", 0); return v; }
 inline int tune_bsr4_variant() { static const int v = env_int("SN_BSR4_VARIANT", 2); return v; }
 inline int tune_csr_iters() { static const int v = env_int("SN_CSR_ITERS", 1); return v < 1 ? 1 : v; }
+inline int tune_csr_variant() { static const int v = env_int("SN_CSR_VARIANT", 1); return v; }
 inline int tune_csr_batch() { static const int v = env_int("SN_CSR_BATCH", 8); return v; }
 inline int tune_bsr4_iters() { static const int v = env_int("SN_BSR4_ITERS", 1); return v < 1 ? 1 : v; }
 inline int tune_bsr4_unroll() { static const int v = env_int("SN_BSR4_UNROLL", 2); return v; }
@@ -701,9 +881,25 @@ inline bool timing_slot(int kind, int64_t M, int64_t K, int64_t nnz, int N, hipE
     else if (xg == 1 && yg == 4) SN_KLAUNCH((spmm_csr_v4<N, 1, 4, KB>), grid, stream, __VA_ARGS__); \
     else SN_KLAUNCH((spmm_csr_v4<N, 4, 1, KB>), grid, stream, __VA_ARGS__);         \
   } while (0)
+#define SN_DISPATCH_CSR_LDS(N, xg, yg, grid, stream, ...)                                                     \
+  do {                                                                                                         \
+    if (xg == 1 && yg == 1) SN_KLAUNCH((spmm_csr_lds<N, 1, 1>), grid, stream, __VA_ARGS__);                    \
+    else if (xg == 4 && yg == 4) SN_KLAUNCH((spmm_csr_lds<N, 4, 4>), grid, stream, __VA_ARGS__);               \
+    else if (xg == 1 && yg == 4) SN_KLAUNCH((spmm_csr_lds<N, 1, 4>), grid, stream, __VA_ARGS__);               \
+    else SN_KLAUNCH((spmm_csr_lds<N, 4, 1>), grid, stream, __VA_ARGS__);                                       \
+  } while (0)
+#define SN_DISPATCH_CSR_PIPE(N, xg, yg, grid, stream, ...)                                                    \
+  do {                                                                                                         \
+    if (xg == 1 && yg == 1) SN_KLAUNCH((spmm_csr_pipe<N, 1, 1>), grid, stream, __VA_ARGS__);                   \
+    else if (xg == 4 && yg == 4) SN_KLAUNCH((spmm_csr_pipe<N, 4, 4>), grid, stream, __VA_ARGS__);              \
+    else if (xg == 1 && yg == 4) SN_KLAUNCH((spmm_csr_pipe<N, 1, 4>), grid, stream, __VA_ARGS__);              \
+    else SN_KLAUNCH((spmm_csr_pipe<N, 4, 1>), grid, stream, __VA_ARGS__);                                      \
+  } while (0)
 #define SN_DISPATCH_CSR(N, xg, yg, grid, stream, ...)                                      \
   do {                                                                                     \
-    if (tune_csr_batch() == 4) SN_DISPATCH_CSR_KB(N, 4, xg, yg, grid, stream, __VA_ARGS__); \
+    if (tune_csr_variant() == 2) SN_DISPATCH_CSR_PIPE(N, xg, yg, grid, stream, __VA_ARGS__); \
+    else if (tune_csr_variant() == 1) SN_DISPATCH_CSR_LDS(N, xg, yg, grid, stream, __VA_ARGS__); \
+    else if (tune_csr_batch() == 4) SN_DISPATCH_CSR_KB(N, 4, xg, yg, grid, stream, __VA_ARGS__); \
     else SN_DISPATCH_CSR_KB(N, 8, xg, yg, grid, stream, __VA_ARGS__);                      \
   } while (0)
 
@@ -956,10 +1152,10 @@ int sn_elu_into_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int6
   const bool vec = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && aligned16(src) && aligned16(dst);
   if (vec)
     hipLaunchKernelGGL((elu_into_k<true>), dim3(grid_for(rows * (C / 4), kWG)), dim3(kWG), 0, s, src, lds,
-                       dst, ldd, rows, (int)C);
+                       dst, ldd, rows, (int)C, tune_ew_nt());
   else
     hipLaunchKernelGGL((elu_into_k<false>), dim3(grid_for(rows * (int64_t)C, kWG)), dim3(kWG), 0, s, src,
-                       lds, dst, ldd, rows, (int)C);
+                       lds, dst, ldd, rows, (int)C, tune_ew_nt());
   return launch_status();
 }
 
@@ -973,11 +1169,11 @@ int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64
                    aligned16(gdst) && aligned16(out) && aligned16(gsrc) && (!gdst2 || (aligned16(gdst2) && ldg2 % 4 == 0));
   const unsigned grid = grid_for(vec ? rows * (C / 4) : rows * (int64_t)C, kWG);
   if (vec) {
-    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<true, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C);
-    else hipLaunchKernelGGL((elu_bwd_k<true, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C);
+    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<true, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
+    else hipLaunchKernelGGL((elu_bwd_k<true, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
   } else {
-    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<false, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C);
-    else hipLaunchKernelGGL((elu_bwd_k<false, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C);
+    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<false, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
+    else hipLaunchKernelGGL((elu_bwd_k<false, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
   }
   return launch_status();
 }
