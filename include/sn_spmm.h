@@ -280,6 +280,25 @@ int     sn_timing_enable(int32_t on);
 int64_t sn_timing_count(void);
 int     sn_timing_drain(double *ms, int64_t *meta, int64_t capacity, int64_t *written);
 
+/* ------------------------------------------------------------------------------------------
+ * Device-side construction of the mass-normalised cotangent Laplacian  L = A^-1 (D - W)  in CSR.
+ *
+ * Replaces: mesh.dist / mesh.area / mesh.cotangent_weights     src/utils/mesh.py:17-26, 67-80, 102-112
+ *           graph.laplacian(W, normalized=False)               src/utils/graph.py:40-49
+ *           L = A * L                                           src/mesh_mnist/add_laplacian.py:47-48
+ * fp64 in the reference's operation order (W[i,j] += (-l_ij^2 + l_jk^2 + l_ki^2)/(8a + 1e-6) per face, A[i] += a/3/4
+ * twice per incident face in face order, d = column sums of W in ascending row order), rounded to fp32 at the end.
+ * Two phases (the caller owns the allocation): phase 0 writes rowptr[nV+1] (row i holds its distinct neighbours with a
+ * non-zero weight plus the diagonal); the caller reads rowptr[nV] = nnz, allocates colind/vals, and calls phase 1.
+ * A vertex may have at most SN_LAP_MAX_DEGREE incident faces (else SN_E_UNSUPPORTED is reported through *status_flag).
+ * workspace: sn_laplacian_workspace_bytes(nV, nF) — must be the same buffer for both phases.
+ * ------------------------------------------------------------------------------------------ */
+#define SN_LAP_MAX_DEGREE 24
+size_t sn_laplacian_workspace_bytes(int64_t nV, int64_t nF);
+int sn_laplacian_csr_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_t nF, int32_t phase,
+                               int32_t *rowptr, int32_t *colind, float *vals, int32_t *status_flag,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

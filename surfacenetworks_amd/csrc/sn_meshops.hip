@@ -143,6 +143,21 @@ __global__ __launch_bounds__(kWG) void vertex_lists_k(const int *__restrict__ vp
   }
 }
 
+__global__ __launch_bounds__(kWG) void vertex_sort_k(const int *__restrict__ vptr, int64_t nV, int *__restrict__ inc) {
+  for (int64_t v = (int64_t)blockIdx.x * kWG + threadIdx.x; v < nV; v += (int64_t)gridDim.x * kWG) {
+    const int b = vptr[v], e = vptr[v + 1];
+    for (int i = b + 1; i < e; ++i) {
+      const int key = inc[i];
+      int j = i - 1;
+      while (j >= b && inc[j] > key) {
+        inc[j + 1] = inc[j];
+        --j;
+      }
+      inc[j + 1] = key;
+    }
+  }
+}
+
 // the 4x4 block  -Q(0,e)/(2Af)  (mesh.py:28-33,55-58), row-major, as doubles
 __device__ __forceinline__ void dirac_block(const float *__restrict__ V, const int *__restrict__ F, int64_t f, int c,
                                             double Af, double *m /*16*/) {
@@ -216,6 +231,96 @@ __global__ __launch_bounds__(kWG) void dia_fill_k(const float *__restrict__ V, c
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Cotangent Laplacian, vertex-centric.  Thread i walks its incident faces (ascending face id) and builds, for every
+// neighbour j, W[i,j] (row i's value) and W[j,i] (row j's value, needed for the column sum d_i) from the same face data,
+// exactly as the reference's permutation loop does:  (-l_pq^2 + l_qr^2 + l_rp^2) / (8 a + 1e-6)  for (p,q,r) = (i,j,k).
+// ------------------------------------------------------------------------------------------------
+constexpr int kMaxDeg = SN_LAP_MAX_DEGREE;
+
+template <bool FILL>
+__global__ __launch_bounds__(kWG) void laplacian_rows_k(const float *__restrict__ V, const int *__restrict__ F, int64_t nV,
+                                                        const int *__restrict__ vptr, const int *__restrict__ inc,
+                                                        const double *__restrict__ Af, int *__restrict__ rowptr,
+                                                        int *__restrict__ colind, float *__restrict__ vals,
+                                                        int *__restrict__ status_flag) {
+  for (int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x; i < nV; i += (int64_t)gridDim.x * kWG) {
+    const int b = vptr[i], e = vptr[i + 1];
+    if (e - b > kMaxDeg) {
+      if (status_flag) atomicExch(status_flag, 1);
+      if constexpr (!FILL) rowptr[i] = 1;
+      continue;
+    }
+    int nb[2 * kMaxDeg];          // neighbour ids (with duplicates), in face order
+    double wij[2 * kMaxDeg];      // contribution to W[i, nb]
+    double wji[2 * kMaxDeg];      // contribution to W[nb, i]
+    int n = 0;
+    double A = 0;
+    for (int o = b; o < e; ++o) {
+      const int64_t f = inc[o] >> 2;
+      const int c = inc[o] & 3;
+      const int j = F[3 * f + (c + 1) % 3], k = F[3 * f + (c + 2) % 3];
+      const double lij = edge_len(V, (int)i, j), ljk = edge_len(V, j, k), lki = edge_len(V, k, (int)i);
+      const double a2 = lij * lij, b2 = ljk * ljk, c2 = lki * lki;
+      const double den = 8 * Af[f] + 1e-6;
+      // permutations (i,j,k): W[i,j];  (i,k,j): W[i,k];  (j,i,k): W[j,i];  (k,i,j): W[k,i]
+      nb[n] = j; wij[n] = ((-a2 + b2) + c2) / den; wji[n] = ((-a2 + c2) + b2) / den; ++n;
+      nb[n] = k; wij[n] = ((-c2 + b2) + a2) / den; wji[n] = ((-c2 + a2) + b2) / den; ++n;
+      const double t = Af[f] / 3 / 4;
+      A += t;
+      A += t;
+    }
+    // stable insertion sort by neighbour id (keeps face order among duplicates)
+    for (int x = 1; x < n; ++x) {
+      const int kn = nb[x];
+      const double u = wij[x], v = wji[x];
+      int y = x - 1;
+      while (y >= 0 && nb[y] > kn) {
+        nb[y + 1] = nb[y]; wij[y + 1] = wij[y]; wji[y + 1] = wji[y];
+        --y;
+      }
+      nb[y + 1] = kn; wij[y + 1] = u; wji[y + 1] = v;
+    }
+    // merge duplicates; d_i = sum over neighbours (ascending) of W[nb, i]; entries with W[i,nb] == 0 are dropped
+    const double ainv = 1 / (A + 1e-9);
+    double d = 0;
+    int cnt = 0;
+    int out = FILL ? rowptr[i] : 0;
+    bool diag_done = false;
+    for (int x = 0; x < n;) {
+      const int kn = nb[x];
+      double w = 0, wt = 0;
+      while (x < n && nb[x] == kn) { w += wij[x]; wt += wji[x]; ++x; }
+      if (wt != 0) d += wt;
+      if (w != 0) {
+        if constexpr (FILL) {
+          if (!diag_done && kn > i) { ++out; diag_done = true; }          // leave the diagonal slot, filled below
+          colind[out] = kn;
+          vals[out] = (float)(ainv * (0 - w));
+          ++out;
+        }
+        ++cnt;
+      }
+    }
+    if constexpr (FILL) {
+      // diagonal position: after the neighbours smaller than i
+      int pos = rowptr[i];
+      for (int x = 0, seen = -1; x < n; ++x) {
+        if (nb[x] == seen) continue;
+        seen = nb[x];
+        double w = 0;
+        for (int y = x; y < n && nb[y] == seen; ++y) w += wij[y];
+        if (w != 0 && seen < i) ++pos;
+      }
+      colind[pos] = (int)i;
+      vals[pos] = (float)(ainv * d);
+    } else {
+      rowptr[i] = cnt + 1;
+    }
+  }
+}
+
 inline size_t align16(size_t b) { return (b + 15) & ~(size_t)15; }
 
 }  // namespace
@@ -261,6 +366,57 @@ int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_
   if (nV > 0) hipLaunchKernelGGL(vertex_lists_k, dim3(grid_for(nV)), dim3(kWG), 0, s, vptr, nV, inc, Af, Av, dia_colind);
   hipLaunchKernelGGL(di_fill_k, dim3(grid_for(nF + 1)), dim3(kWG), 0, s, V, F, nF, Af, Av, di_rowptr, di_colind, di_vals, diat_vals);
   hipLaunchKernelGGL(dia_fill_k, dim3(grid_for(nV + 1)), dim3(kWG), 0, s, V, F, nV, vptr, inc, Af, Av, dia_rowptr, dia_vals, dit_vals);
+  return launch_status();
+}
+
+size_t sn_laplacian_workspace_bytes(int64_t nV, int64_t nF) { return sn_dirac_workspace_bytes(nV, nF); }
+
+int sn_laplacian_csr_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_t nF, int32_t phase,
+                               int32_t *rowptr, int32_t *colind, float *vals, int32_t *status_flag,
+                               void *workspace, size_t workspace_bytes, void *stream) {
+  if (nV < 0 || nF < 0 || (phase != 0 && phase != 1)) return SN_E_SHAPE;
+  if (nV + 1 > INT_MAX || 3 * nF > INT_MAX) return SN_E_RANGE;
+  if (!rowptr) return SN_E_NULL;
+  if (nF > 0 && (!V || !F)) return SN_E_NULL;
+  if (phase == 1 && nV > 0 && (!colind || !vals)) return SN_E_NULL;
+  if (workspace_bytes < sn_laplacian_workspace_bytes(nV, nF) || !workspace) return SN_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  char *w = static_cast<char *>(workspace);
+  double *Af = reinterpret_cast<double *>(w); w += align16((size_t)nF * sizeof(double));
+  w += align16((size_t)nV * sizeof(double));                                       // (Av slot of the Dirac layout, unused)
+  int *vptr = reinterpret_cast<int *>(w); w += align16((size_t)(nV + 1) * sizeof(int));
+  int *cursor = reinterpret_cast<int *>(w); w += align16((size_t)(nV + 1) * sizeof(int));
+  int *inc = reinterpret_cast<int *>(w); w += align16((size_t)3 * nF * sizeof(int));
+  int *sums = reinterpret_cast<int *>(w);
+  const int64_t n = nV + 1;
+  const int nblk = (int)((n + kScanTile - 1) / kScanTile);
+  if (phase == 0) {
+    hipError_t e = hipMemsetAsync(vptr, 0, (size_t)(nV + 1) * sizeof(int), s);
+    if (e != hipSuccess) return (int)e;
+    if (status_flag) {
+      e = hipMemsetAsync(status_flag, 0, sizeof(int), s);
+      if (e != hipSuccess) return (int)e;
+    }
+    if (nF > 0) hipLaunchKernelGGL(face_area_k, dim3(grid_for(nF)), dim3(kWG), 0, s, V, F, nF, Af, vptr);
+    hipLaunchKernelGGL(scan_sums_k, dim3(nblk), dim3(kWG), 0, s, vptr, n, sums);
+    hipLaunchKernelGGL(scan_top_k, dim3(1), dim3(kWG), 0, s, sums, nblk);
+    hipLaunchKernelGGL(scan_apply_k, dim3(nblk), dim3(kWG), 0, s, vptr, n, sums, vptr);
+    e = hipMemcpyAsync(cursor, vptr, (size_t)(nV + 1) * sizeof(int), hipMemcpyDeviceToDevice, s);
+    if (e != hipSuccess) return (int)e;
+    if (nF > 0) hipLaunchKernelGGL(incidence_scatter_k, dim3(grid_for(nF)), dim3(kWG), 0, s, F, nF, cursor, inc);
+    if (nV > 0) hipLaunchKernelGGL(vertex_sort_k, dim3(grid_for(nV)), dim3(kWG), 0, s, vptr, nV, inc);
+    e = hipMemsetAsync(rowptr + nV, 0, sizeof(int), s);
+    if (e != hipSuccess) return (int)e;
+    if (nV > 0)
+      hipLaunchKernelGGL((laplacian_rows_k<false>), dim3(grid_for(nV)), dim3(kWG), 0, s, V, F, nV, vptr, inc, Af, rowptr,
+                         (int *)nullptr, (float *)nullptr, status_flag);
+    hipLaunchKernelGGL(scan_sums_k, dim3(nblk), dim3(kWG), 0, s, rowptr, n, sums);
+    hipLaunchKernelGGL(scan_top_k, dim3(1), dim3(kWG), 0, s, sums, nblk);
+    hipLaunchKernelGGL(scan_apply_k, dim3(nblk), dim3(kWG), 0, s, rowptr, n, sums, rowptr);
+  } else if (nV > 0) {
+    hipLaunchKernelGGL((laplacian_rows_k<true>), dim3(grid_for(nV)), dim3(kWG), 0, s, V, F, nV, vptr, inc, Af, rowptr, colind,
+                       vals, (int *)nullptr);
+  }
   return launch_status();
 }
 

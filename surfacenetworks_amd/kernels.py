@@ -14,7 +14,7 @@ from . import _lib
 __all__ = [
     "spmm_csr", "spmm_bsr4", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
-    "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh",
+    "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh",
 ]
 
 
@@ -258,3 +258,26 @@ def dirac_from_mesh(V, F):
     _lib.call("sn_dirac_bsr4_from_mesh", _p(V), _p(F), nV, nF, _p(di_rp), _p(di_ci), _p(di_v), _p(diat_v), _p(dia_rp),
               _p(dia_ci), _p(dia_v), _p(dit_v), _p(ws), ws_bytes, _stream())
     return (di_rp, di_ci, di_v), (di_rp, di_ci, diat_v), (dia_rp, dia_ci, dia_v), (dia_rp, dia_ci, dit_v)
+
+
+def laplacian_from_mesh(V, F):
+    """Mass-normalised cotangent Laplacian of one mesh (or a batch laid out as one disjoint mesh) built on the device:
+    (rowptr, colind, vals) CSR.  Synchronises once (reads nnz).  V: (nV,3) fp32, F: (nF,3) int32."""
+    _dev(V, F)
+    if V.dtype != torch.float32 or F.dtype != torch.int32:
+        raise TypeError("laplacian_from_mesh wants V float32 and F int32")
+    V, F = V.contiguous(), F.contiguous()
+    nV, nF = V.shape[0], F.shape[0]
+    dev = V.device
+    rowptr = torch.empty(nV + 1, dtype=torch.int32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    ws_bytes = int(_lib.load().sn_laplacian_workspace_bytes(nV, nF))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.call("sn_laplacian_csr_from_mesh", _p(V), _p(F), nV, nF, 0, _p(rowptr), None, None, _p(flag), _p(ws), ws_bytes, _stream())
+    nnz, bad = int(rowptr[-1].item()), int(flag.item())
+    if bad:
+        raise _lib.SnError("laplacian_from_mesh: a vertex has more incident faces than SN_LAP_MAX_DEGREE")
+    colind = torch.empty(nnz, dtype=torch.int32, device=dev)
+    vals = torch.empty(nnz, dtype=torch.float32, device=dev)
+    _lib.call("sn_laplacian_csr_from_mesh", _p(V), _p(F), nV, nF, 1, _p(rowptr), _p(colind), _p(vals), None, _p(ws), ws_bytes, _stream())
+    return rowptr, colind, vals

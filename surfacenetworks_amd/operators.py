@@ -22,7 +22,7 @@ import torch
 
 from . import kernels
 
-__all__ = ["SparseOperator", "OperatorPool", "as_operator", "dirac_operators_from_mesh"]
+__all__ = ["SparseOperator", "OperatorPool", "as_operator", "dirac_operators_from_mesh", "laplacian_operator_from_mesh"]
 
 # A BSR4 copy is kept when zero-fill costs at most this much extra storage over CSR entries.
 _BSR4_MAX_FILL = 1.6
@@ -239,6 +239,23 @@ def dirac_operators_from_mesh(V: torch.Tensor, F: torch.Tensor):
     Di = SparseOperator.from_bsr4(di, dit, (4 * B * nF, 4 * B * nV), batch=B)
     DiA = SparseOperator.from_bsr4(dia, diat, (4 * B * nV, 4 * B * nF), batch=B)
     return Di, DiA
+
+
+def laplacian_operator_from_mesh(V: torch.Tensor, F: torch.Tensor) -> SparseOperator:
+    """L = A^-1 (D - W) built on the device (sn_laplacian_csr_from_mesh) — replaces the host pipeline
+    mesh.cotangent_weights + graph.laplacian (src/mesh_mnist/add_laplacian.py:43-48).  V: (nV,3) or (B,nV,3) for a batch
+    of equally sized meshes (block-diagonal result); F: (nF,3) shared or (B,nF,3)."""
+    if V.dim() == 3:
+        B, nV = V.shape[0], V.shape[1]
+        Fb = F if F.dim() == 3 else F.unsqueeze(0).expand(B, -1, -1)
+        off = (torch.arange(B, device=V.device, dtype=torch.int32) * nV).view(B, 1, 1)
+        Fg = (Fb.to(torch.int32) + off).reshape(-1, 3)
+        Vg = V.reshape(B * nV, 3)
+    else:
+        B, nV = 1, V.shape[0]
+        Vg, Fg = V, F.to(torch.int32)
+    rowptr, colind, vals = kernels.laplacian_from_mesh(Vg.float(), Fg)
+    return SparseOperator(rowptr, colind, vals, (B * nV, B * nV), batch=B)
 
 
 def as_operator(A) -> SparseOperator:

@@ -151,6 +151,14 @@ def dirac_from_mesh(V, F):
     return tuple(outs)
 
 
+def laplacian_from_mesh(V, F):
+    from surfacenetworks_amd import mesh_ops
+
+    L = mesh_ops.laplacian(_np(V).astype(np.float64), _np(F).astype(np.int64)).astype(np.float32).tocsr()
+    L.sort_indices()
+    return torch.from_numpy(L.indptr.astype(np.int32)), torch.from_numpy(L.indices.astype(np.int32)), torch.from_numpy(L.data)
+
+
 def install(monkeypatch=None):
     """Patch surfacenetworks_amd.kernels in place (monkeypatch=None: permanent, for spawned worker processes)."""
     from surfacenetworks_amd import kernels
