@@ -299,6 +299,29 @@ int sn_laplacian_csr_from_mesh(const float *V, const int32_t *F, int64_t nV, int
                                int32_t *rowptr, int32_t *colind, float *vals, int32_t *status_flag,
                                void *workspace, size_t workspace_bytes, void *stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Row-streaming fp32 GEMMs of the per-node Linear layers with the weights held in registers
+ * (v_mfma_f32_32x32x2_f32; the operands are tall-skinny: rows ~ 1e5..1e6, K and N in {128, 256}).
+ *
+ * sn_linear_fwd_f32 : y[r, j] = sum_k x[r,k] * W[j,k] + bias[j] (+ residual[r,j]);  optionally also
+ *                     y_elu[r, j] = elu(y[r, j]) written to a second destination (e.g. the concat buffer of the next
+ *                     stage).  W is (J x K) row-major — the BN-folded weight W·diag(s) of sn_bn_fold_f32.
+ *                     Replaces nn.Linear (src/utils/utils_pt.py:89,99) + the residual add (utils_pt.py:180,220) + the
+ *                     F.elu that follows (utils_pt.py:171,208).
+ * sn_linear_dgrad_f32 : dx[r, c] = sum_j dy[r,j] * W[j,c]  (+ (x[r,c] - center[c]) * B[c] + Cc[c]  when B != NULL):
+ *                     input gradient of the folded BatchNorm+Linear with the BatchNorm tail fused in the epilogue
+ *                     (replaces the dgrad GEMM + sn_affine_cols_acc_f32).  W is (J x C) row-major.
+ * Supported: K in {128, 256}, J = 128 for the forward; J = 128, C in {128, 256} for the input gradient; all leading
+ * dimensions multiples of 4 floats and 16-byte aligned bases (else SN_E_UNSUPPORTED / SN_E_ALIGN: the caller falls
+ * back to a library GEMM).
+ * ------------------------------------------------------------------------------------------ */
+int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias,
+                      const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu, int64_t lde,
+                      int64_t rows, int32_t K, int32_t J, void *stream);
+int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                        const float *center, const float *B, const float *Cc, float *dx, int64_t lddx,
+                        int64_t rows, int32_t J, int32_t C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

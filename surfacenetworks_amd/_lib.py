@@ -46,6 +46,8 @@ SIGNATURES = {
     "sn_timing_drain": (C.c_int, [_vp, _vp, _i64, _vp]),
     "sn_laplacian_workspace_bytes": (_sz, [_i64, _i64]),
     "sn_laplacian_csr_from_mesh": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sn_linear_fwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "sn_linear_dgrad_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "sn_affine_cols_acc_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
 }
 

@@ -273,7 +273,10 @@ class _BNLinear(torch.autograd.Function):
         stats = kernels.colstats(x) if training else None
         mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training,
                                                      running_mean, running_var)
-        y = torch.addmm(bf, x, Wf.t())
+        if kernels.linear_fwd_supported(x.shape[1], W.shape[0]):
+            y = kernels.linear_fwd(x, Wf, bf)                  # weights-in-registers fp32-MFMA GEMM (sn_gemm.hip)
+        else:
+            y = torch.addmm(bf, x, Wf.t())
         ctx.save_for_backward(x, W, Wf, s, mean, invstd, beta)
         ctx.training, ctx.has_bias = training, b is not None
         return y
@@ -290,9 +293,13 @@ class _BNLinear(torch.autograd.Function):
                                                                ctx.has_bias)
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = dy.mm(Wf)
-            if ctx.training:
-                kernels.affine_cols_acc(dx, x, Bc, Cc, mean)
+            if kernels.linear_dgrad_supported(J, C):
+                # dgrad GEMM with the BatchNorm tail (x - mean)*B + C fused into its epilogue
+                dx = kernels.linear_dgrad(dy, Wf, x, mean, Bc, Cc) if ctx.training else kernels.linear_dgrad(dy, Wf)
+            else:
+                dx = dy.mm(Wf)
+                if ctx.training:
+                    kernels.affine_cols_acc(dx, x, Bc, Cc, mean)
         return dx, dgamma, dbeta, dW, db, None, None, None, None, None
 
 

@@ -14,7 +14,8 @@ from . import _lib
 __all__ = [
     "spmm_csr", "spmm_bsr4", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
-    "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh",
+    "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
+    "linear_dgrad_supported",
 ]
 
 
@@ -281,3 +282,34 @@ def laplacian_from_mesh(V, F):
     vals = torch.empty(nnz, dtype=torch.float32, device=dev)
     _lib.call("sn_laplacian_csr_from_mesh", _p(V), _p(F), nV, nF, 1, _p(rowptr), _p(colind), _p(vals), None, _p(ws), ws_bytes, _stream())
     return rowptr, colind, vals
+
+
+def linear_fwd_supported(K: int, J: int) -> bool:
+    return J == 128 and K in (128, 256)
+
+
+def linear_fwd(x, W, bias, residual=None, y_elu=None):
+    """y = x·Wᵀ + bias (+ residual); optionally also writes elu(y) into the 2-D view `y_elu` (sn_linear_fwd_f32)."""
+    _dev(x, W, bias, residual, y_elu)
+    rows, K = x.shape
+    J = W.shape[0]
+    y = torch.empty((rows, J), dtype=torch.float32, device=x.device)
+    _lib.call("sn_linear_fwd_f32", _p(x), _ld(x), _p(W), _ld(W), _p(bias), _p(residual),
+              _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu), _ld(y_elu) if y_elu is not None else 0,
+              rows, K, J, _stream())
+    return y
+
+
+def linear_dgrad_supported(J: int, C: int) -> bool:
+    return J == 128 and C in (128, 256)
+
+
+def linear_dgrad(dy, W, x=None, center=None, B=None, Cc=None):
+    """dx = dy·W (+ (x - center)*B + Cc): input gradient of the folded BatchNorm+Linear (sn_linear_dgrad_f32)."""
+    _dev(dy, W, x, center, B, Cc)
+    rows, J = dy.shape
+    C = W.shape[1]
+    dx = torch.empty((rows, C), dtype=torch.float32, device=dy.device)
+    _lib.call("sn_linear_dgrad_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x) if x is not None else 0, _p(center),
+              _p(B), _p(Cc), _p(dx), C, rows, J, C, _stream())
+    return dx

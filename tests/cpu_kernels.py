@@ -159,6 +159,31 @@ def laplacian_from_mesh(V, F):
     return torch.from_numpy(L.indptr.astype(np.int32)), torch.from_numpy(L.indices.astype(np.int32)), torch.from_numpy(L.data)
 
 
+def linear_fwd_supported(K, J):
+    return J == 128 and K in (128, 256)
+
+
+def linear_fwd(x, W, bias, residual=None, y_elu=None):
+    y = (x.double() @ W.double().t() + bias.double()).float()
+    if residual is not None:
+        y = y + residual
+    if y_elu is not None:
+        y_elu.copy_(torch.nn.functional.elu(y))
+    return y
+
+
+def linear_dgrad_supported(J, C):
+    return J == 128 and C in (128, 256)
+
+
+def linear_dgrad(dy, W, x=None, center=None, B=None, Cc=None):
+    dx = (dy.double() @ W.double()).float()
+    if B is not None:
+        xc = x if center is None else x - center
+        dx = dx + torch.addcmul(Cc.expand_as(xc), xc, B.expand_as(xc))
+    return dx
+
+
 def install(monkeypatch=None):
     """Patch surfacenetworks_amd.kernels in place (monkeypatch=None: permanent, for spawned worker processes)."""
     from surfacenetworks_amd import kernels

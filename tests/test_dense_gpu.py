@@ -142,3 +142,43 @@ def test_segment_kernels():
         want = torch.empty(rows, C)
         ck.elu_bwd_bcast(torch.from_numpy(g), torch.from_numpy(out), torch.from_numpy(src), torch.from_numpy(mask), want, per)
         assert np.allclose(gs.cpu().numpy(), want.numpy(), rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 1000, 40001])
+@pytest.mark.parametrize("K", [128, 256])
+def test_linear_fwd_mfma(rows, K):
+    rng = np.random.default_rng(rows + K)
+    J = 128
+    xw = rng.standard_normal((rows, K + 64)).astype(np.float32)        # x is a strided view
+    W = (rng.standard_normal((J, K)) / np.sqrt(K)).astype(np.float32)
+    W[5, 7] = 3.0                                                        # asymmetric marker
+    b = rng.standard_normal(J).astype(np.float32)
+    res = rng.standard_normal((rows, J)).astype(np.float32)
+    x = dev(xw)[:, :K]
+    want = xw[:, :K].astype(np.float64) @ W.astype(np.float64).T + b
+    y = kernels.linear_fwd(x, dev(W), dev(b))
+    assert rel_err(y.cpu().numpy(), want) < 2e-6
+    cat = torch.zeros(rows, 2 * J, device=DEV)
+    y2 = kernels.linear_fwd(x, dev(W), dev(b), residual=dev(res), y_elu=cat[:, :J])
+    want2 = want + res
+    assert rel_err(y2.cpu().numpy(), want2) < 2e-6
+    assert np.allclose(cat[:, :J].cpu().numpy(), np.where(want2 > 0, want2, np.expm1(want2)), rtol=1e-5, atol=1e-5)
+    assert float(cat[:, J:].abs().sum()) == 0
+
+
+@pytest.mark.parametrize("rows", [1, 33, 1000, 40001])
+@pytest.mark.parametrize("C", [128, 256])
+def test_linear_dgrad_mfma(rows, C):
+    rng = np.random.default_rng(rows + C)
+    J = 128
+    dy = rng.standard_normal((rows, J)).astype(np.float32)
+    W = (rng.standard_normal((J, C)) / np.sqrt(J)).astype(np.float32)
+    W[3, 11] = -2.5
+    x = rng.standard_normal((rows, C)).astype(np.float32)
+    cen, B, Cc = [rng.standard_normal(C).astype(np.float32) for _ in range(3)]
+    want = dy.astype(np.float64) @ W.astype(np.float64)
+    got = kernels.linear_dgrad(dev(dy), dev(W))
+    assert rel_err(got.cpu().numpy(), want) < 2e-6
+    got2 = kernels.linear_dgrad(dev(dy), dev(W), dev(x), dev(cen), dev(B), dev(Cc))
+    want2 = want + (x.astype(np.float64) - cen) * B + Cc
+    assert rel_err(got2.cpu().numpy(), want2) < 2e-6
