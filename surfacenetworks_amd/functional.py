@@ -267,18 +267,22 @@ class _BNLinear(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps):
+    def forward(ctx, x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual):
         x = _rows2d(x)
         rows = x.shape[0]
         stats = kernels.colstats(x) if training else None
         mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training,
                                                      running_mean, running_var)
+        if residual is not None:
+            residual = _rows2d(residual)
         if kernels.linear_fwd_supported(x.shape[1], W.shape[0]):
-            y = kernels.linear_fwd(x, Wf, bf)                  # weights-in-registers fp32-MFMA GEMM (sn_gemm.hip)
+            y = kernels.linear_fwd(x, Wf, bf, residual)        # weights-in-registers fp32-MFMA GEMM (sn_gemm.hip)
         else:
             y = torch.addmm(bf, x, Wf.t())
+            if residual is not None:
+                y += residual
         ctx.save_for_backward(x, W, Wf, s, mean, invstd, beta)
-        ctx.training, ctx.has_bias = training, b is not None
+        ctx.training, ctx.has_bias, ctx.has_res = training, b is not None, residual is not None
         return y
 
     @staticmethod
@@ -300,18 +304,19 @@ class _BNLinear(torch.autograd.Function):
                 dx = dy.mm(Wf)
                 if ctx.training:
                     kernels.affine_cols_acc(dx, x, Bc, Cc, mean)
-        return dx, dgamma, dbeta, dW, db, None, None, None, None, None
+        return dx, dgamma, dbeta, dW, db, None, None, None, None, None, (dy if ctx.has_res else None)
 
 
-def bn_linear(x2d: torch.Tensor, bn: torch.nn.BatchNorm1d, fc: torch.nn.Linear) -> torch.Tensor:
-    """Fused BatchNorm1d + Linear on a (rows, C) fp32 operand; updates bn's running statistics like nn.BatchNorm1d."""
+def bn_linear(x2d: torch.Tensor, bn: torch.nn.BatchNorm1d, fc: torch.nn.Linear, residual=None) -> torch.Tensor:
+    """Fused BatchNorm1d + Linear on a (rows, C) fp32 operand (+ `residual`, added in the GEMM epilogue); updates bn's
+    running statistics like nn.BatchNorm1d."""
     training = bn.training or not bn.track_running_stats
     if bn.momentum is None or not bn.affine:
         raise NotImplementedError("bn_linear supports the default affine BatchNorm1d with a fixed momentum")
     if training and bn.track_running_stats and bn.num_batches_tracked is not None:
         bn.num_batches_tracked.add_(1)
     return _BNLinear.apply(x2d, bn.weight, bn.bias, fc.weight, fc.bias, bn.running_mean, bn.running_var, training,
-                           bn.momentum, bn.eps)
+                           bn.momentum, bn.eps, residual)
 
 
 class _AvgPropagate(torch.autograd.Function):

@@ -97,16 +97,17 @@ class GraphConv1x1(nn.Module):
             self.bn = nn.BatchNorm1d(num_outputs)
         self.fc = nn.Linear(num_inputs, num_outputs)
 
-    def forward2d(self, x2d):
-        """(rows, Cin) -> (rows, Cout) on the flattened node axis."""
+    def forward2d(self, x2d, residual=None):
+        """(rows, Cin) -> (rows, Cout) on the flattened node axis; `residual` (rows, Cout) is added to the result
+        (inside the GEMM epilogue on the fused path)."""
         if self.batch_norm == "pre":
             if x2d.dtype == torch.float32 and self.bn.affine and self.bn.momentum is not None:
-                return snF.bn_linear(x2d, self.bn, self.fc)      # one statistics pass + folded GEMM (functional.py)
+                return snF.bn_linear(x2d, self.bn, self.fc, residual)   # one statistics pass + folded GEMM (functional.py)
             x2d = self.bn(x2d)
         x2d = self.fc(x2d)
         if self.batch_norm == "post":
             x2d = self.bn(x2d)
-        return x2d
+        return x2d if residual is None else x2d + residual
 
     def forward(self, x):
         batch_size, num_nodes, num_inputs = x.size()
@@ -157,9 +158,10 @@ class LapResNet2(_TwoStage):
             return DenseLapResNet2.forward(self, L, mask, inputs)
         batch, node, feat = inputs.size()
         op = as_operator(L)
-        h = self.bn_fc0.forward2d(snF.lap_propagate(op, inputs.reshape(batch * node, feat)))
-        h = self.bn_fc1.forward2d(snF.lap_propagate(op, h))
-        return h.view(batch, node, feat) + inputs
+        x2d = inputs.reshape(batch * node, feat)
+        h = self.bn_fc0.forward2d(snF.lap_propagate(op, x2d))
+        h = self.bn_fc1.forward2d(snF.lap_propagate(op, h), residual=x2d)        # "+ inputs" rides in the GEMM epilogue
+        return h.view(batch, node, feat)
 
 
 class DirResNet2(_TwoStage):
@@ -173,12 +175,12 @@ class DirResNet2(_TwoStage):
     def forward(self, Di, DiA, v, f):
         batch_size, num_nodes, num_inputs = v.size()
         _, num_faces, _ = f.size()
-        cat0, e_v = snF.dirac_face_stage(as_operator(Di), v.reshape(batch_size * num_nodes, num_inputs),
-                                         f.reshape(batch_size * num_faces, num_inputs))
+        v2d = v.reshape(batch_size * num_nodes, num_inputs)
+        cat0, e_v = snF.dirac_face_stage(as_operator(Di), v2d, f.reshape(batch_size * num_faces, num_inputs))
         f_out = self.bn_fc0.forward2d(cat0)
         cat1 = snF.dirac_vert_stage(as_operator(DiA), f_out, e_v)
-        v_out = self.bn_fc1.forward2d(cat1)
-        return v + v_out.view(batch_size, num_nodes, num_inputs), f_out.view(batch_size, num_faces, num_inputs)
+        v_new = self.bn_fc1.forward2d(cat1, residual=v2d)                        # v + v_out in the GEMM epilogue
+        return v_new.view(batch_size, num_nodes, num_inputs), f_out.view(batch_size, num_faces, num_inputs)
 
 
 class AvgResNet2(_TwoStage):
@@ -193,8 +195,8 @@ class AvgResNet2(_TwoStage):
             x = self.bn_fc1(torch.cat([x, global_average(x, mask).expand_as(x)], 2))
             return x + inputs
         h = self.bn_fc0.forward2d(snF.avg_propagate(inputs, mask))
-        h = self.bn_fc1.forward2d(snF.avg_propagate(h.view(b, n, c), mask))
-        return h.view(b, n, c) + inputs
+        h = self.bn_fc1.forward2d(snF.avg_propagate(h.view(b, n, c), mask), residual=inputs.reshape(b * n, c))
+        return h.view(b, n, c)
 
 
 class MlpResNet2(nn.Module):
