@@ -196,101 +196,6 @@ __global__ __launch_bounds__(kWG) void spmm_csr_lds(const int *__restrict__ rowp
 }
 
 // ------------------------------------------------------------------------------------------------
-// Software-pipelined variant of spmm_csr_lds: a wave walks `iters` passes and keeps the NEXT pass's operator entries
-// (LDS-DMA into the other half of a double buffer) and the pass-after-next's row pointers in flight while it gathers
-// and accumulates the current pass.  One exposed memory latency per pass instead of three dependent ones
-// (rowptr -> entries -> gathers): with 2 rows per wave pass at N = 128 that chain, not HBM, bounded the kernel.
-// ------------------------------------------------------------------------------------------------
-template <int N, int XG, int YG>
-__global__ __launch_bounds__(kWG) void spmm_csr_pipe(const int *__restrict__ rowptr, const int *__restrict__ colind,
-                                                     const float *__restrict__ vals, int M,
-                                                     const float *__restrict__ X, int64_t ldx,
-                                                     float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
-  constexpr int LPR = N / 4;
-  constexpr int P = 64 / LPR;
-  constexpr int WAVES = kWG / 64;
-  constexpr int TILE = 256;
-  constexpr int KB = 8;
-  __shared__ int s_col[WAVES][2][TILE];
-  __shared__ float s_val[WAVES][2][TILE];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sub = lane % LPR, grp = lane / LPR;
-  const float *xb = X + sub * 4;
-  ChunkWalk w(nchunks);
-  for (int local = w.first; local < w.cpx; local += w.step) {
-    const int pass0 = (w.base + local) * iters;                    // first pass index of this workgroup's chunk
-    auto first_row = [&](int it) { return ((pass0 + it) * WAVES + wave) * P; };
-    auto load_rp = [&](int it, int &kb, int &ke) {                  // this lane group's [begin, end) for pass `it`
-      const int r = first_row(it) + grp;
-      const int rc = r < M ? r : M;
-      kb = rowptr[rc];
-      ke = rowptr[rc + 1 <= M ? rc + 1 : M];
-    };
-    auto stage = [&](int buf, int k0, int k1) {                     // async copy of entries [k0, k1) (<= TILE) into LDS
-      const int nt = k1 - k0;
-      for (int p0 = 0; p0 < nt; p0 += 64) {
-        int p = p0 + lane;
-        p = p < nt ? p : nt - 1;
-        __builtin_amdgcn_global_load_lds(colind + k0 + p, &s_col[wave][buf][p0], 4, 0, 0);
-        __builtin_amdgcn_global_load_lds(vals + k0 + p, &s_val[wave][buf][p0], 4, 0, 0);
-      }
-    };
-    int kb, ke, kbn = 0, ken = 0;
-    load_rp(0, kb, ke);
-    int k0 = __builtin_amdgcn_readfirstlane(kb), k1 = __builtin_amdgcn_readlane(ke, 63);
-    bool staged = (k1 - k0) <= TILE;
-    if (staged && first_row(0) < M) stage(0, k0, k1);
-    if (iters > 1) load_rp(1, kbn, ken);
-    for (int it = 0; it < iters; ++it) {
-      const int cur = it & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // entries of pass `it` landed, row pointers of it+1 arrived
-      __builtin_amdgcn_wave_barrier();
-      // ---- kick off pass it+1 (entries) and it+2 (row pointers) before touching pass it ----
-      int k0n = 0, k1n = 0, kb2 = 0, ke2 = 0;
-      bool stagedn = false;
-      if (it + 1 < iters) {
-        k0n = __builtin_amdgcn_readfirstlane(kbn);
-        k1n = __builtin_amdgcn_readlane(ken, 63);
-        stagedn = (k1n - k0n) <= TILE;
-        if (stagedn && first_row(it + 1) < M) stage(cur ^ 1, k0n, k1n);
-      }
-      if (it + 2 < iters) load_rp(it + 2, kb2, ke2);
-      // ---- pass it ----
-      const int r = first_row(it) + grp;
-      if (first_row(it) < M) {
-        f4 acc = {0.f, 0.f, 0.f, 0.f};
-        if (staged) {
-          const int *sc = s_col[wave][cur];
-          const float *sv = s_val[wave][cur];
-          for (int k = kb; k < ke; k += KB) {
-            int c[KB];
-            float a[KB];
-            f4 x[KB];
-#pragma unroll
-            for (int i = 0; i < KB; ++i) {
-              const bool in = k + i < ke;
-              const int o = (in ? k + i : ke - 1) - k0;
-              c[i] = sc[o];
-              a[i] = in ? sv[o] : 0.f;
-            }
-#pragma unroll
-            for (int i = 0; i < KB; ++i) x[i] = ld4(xb + row_off<XG, N>(c[i], ldx));
-#pragma unroll
-            for (int i = 0; i < KB; ++i) acc = fma4(a[i], x[i], acc);
-          }
-        } else {                                                    // a pass with more than TILE entries: direct loads
-          for (int k = kb; k < ke; ++k) acc = fma4(vals[k], ld4(xb + row_off<XG, N>(colind[k], ldx)), acc);
-        }
-        if (r < M) st4_stream(Y + row_off<YG, N>(r, ldy) + sub * 4, acc);
-      }
-      kb = kbn; ke = ken; k0 = k0n; k1 = k1n; staged = stagedn;
-      kbn = kb2; ken = ke2;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // BSR4 SpMM: N/4 lanes per block row; each lane keeps the 4 output rows of its column slice.
 // ------------------------------------------------------------------------------------------------
 template <int N, int XG, int YG>
@@ -888,17 +793,9 @@ inline bool timing_slot(int kind, int64_t M, int64_t K, int64_t nnz, int N, hipE
     else if (xg == 1 && yg == 4) SN_KLAUNCH((spmm_csr_lds<N, 1, 4>), grid, stream, __VA_ARGS__);               \
     else SN_KLAUNCH((spmm_csr_lds<N, 4, 1>), grid, stream, __VA_ARGS__);                                       \
   } while (0)
-#define SN_DISPATCH_CSR_PIPE(N, xg, yg, grid, stream, ...)                                                    \
-  do {                                                                                                         \
-    if (xg == 1 && yg == 1) SN_KLAUNCH((spmm_csr_pipe<N, 1, 1>), grid, stream, __VA_ARGS__);                   \
-    else if (xg == 4 && yg == 4) SN_KLAUNCH((spmm_csr_pipe<N, 4, 4>), grid, stream, __VA_ARGS__);              \
-    else if (xg == 1 && yg == 4) SN_KLAUNCH((spmm_csr_pipe<N, 1, 4>), grid, stream, __VA_ARGS__);              \
-    else SN_KLAUNCH((spmm_csr_pipe<N, 4, 1>), grid, stream, __VA_ARGS__);                                      \
-  } while (0)
 #define SN_DISPATCH_CSR(N, xg, yg, grid, stream, ...)                                      \
   do {                                                                                     \
-    if (tune_csr_variant() == 2) SN_DISPATCH_CSR_PIPE(N, xg, yg, grid, stream, __VA_ARGS__); \
-    else if (tune_csr_variant() == 1) SN_DISPATCH_CSR_LDS(N, xg, yg, grid, stream, __VA_ARGS__); \
+    if (tune_csr_variant() == 1) SN_DISPATCH_CSR_LDS(N, xg, yg, grid, stream, __VA_ARGS__); \
     else if (tune_csr_batch() == 4) SN_DISPATCH_CSR_KB(N, 4, xg, yg, grid, stream, __VA_ARGS__); \
     else SN_DISPATCH_CSR_KB(N, 8, xg, yg, grid, stream, __VA_ARGS__);                      \
   } while (0)
