@@ -171,14 +171,16 @@ int sn_blockdiag_concat_i32(const int32_t *pool_rowptr, const int32_t *pool_coli
  * sn_elu_into_f32: dst[r, 0:C] = elu(src[r, 0:C]) for `rows` rows; src stride lds, dst stride ldd.
  *   Replaces F.elu (utils_pt.py:161,171,195,208) + the first operand copy of torch.cat
  *   (utils_pt.py:168,177,204,216): ELU is written straight into the first half of the concat buffer.
- * sn_elu_bwd_acc_f32: gsrc[r,c] (+)= (gdst[r,c] + gdst2[r,c]) * (out[r,c] > 0 ? 1 : out[r,c] + 1), out = elu value.
- *   gdst2 may be NULL.  The activated tensor feeds both the concat buffer and the SpMM, so two gradients meet here;
+ * sn_elu_bwd_acc_f32: gsrc[r,c] (+)= (gdst[r,c] + gdst2[r,c]) * (out[r,c] > 0 ? 1 : out[r,c] + 1) + gadd[r,c], out = elu
+ *   value.  gdst2 and gadd may be NULL.  The activated tensor feeds both the concat buffer and the SpMM (two gradients
+ *   meet before the ELU derivative) and the un-activated tensor also feeds the residual path (gadd, after it);
  *   accumulate != 0 additionally adds into gsrc.
  * ------------------------------------------------------------------------------------------ */
 int sn_elu_into_f32(const float *src, int64_t lds, float *dst, int64_t ldd,
                     int64_t rows, int32_t C, void *stream);
-int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64_t ldg2, const float *out, int64_t ldo,
-                       float *gsrc, int64_t ldgs, int64_t rows, int32_t C, int32_t accumulate, void *stream);
+int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64_t ldg2, const float *gadd, int64_t ldga,
+                       const float *out, int64_t ldo, float *gsrc, int64_t ldgs, int64_t rows, int32_t C,
+                       int32_t accumulate, void *stream);
 
 
 /* ------------------------------------------------------------------------------------------
@@ -232,8 +234,8 @@ int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W,
  *                         two deterministic stages).  Replaces (x * mask).sum(1).
  * sn_bcast_rows_f32     : dst[r, c] = src[seg(r), c]  — writes the per-mesh mean into the second half of the concat
  *                         buffer (expand_as + contiguous + torch.cat in the reference).
- * sn_elu_bwd_bcast_f32  : gsrc[r,c] = (gdst[r,c] + mask[r] * bias[seg(r), c]) * elu'(out[r,c]): ELU backward with the
- *                         gradient of the mean path folded in.
+ * sn_elu_bwd_bcast_f32  : gsrc[r,c] = (gdst[r,c] + mask[r] * bias[seg(r), c]) * elu'(out[r,c]) + gadd[r,c]: ELU backward
+ *                         with the gradient of the mean path folded in (gadd: optional residual-path gradient).
  * ------------------------------------------------------------------------------------------ */
 size_t sn_segment_colsum_workspace_bytes(int64_t rows_per_seg, int64_t nseg, int32_t C);
 int sn_segment_colsum_f32(const float *x, int64_t ld, const float *mask, int64_t rows_per_seg, int64_t nseg, int32_t C,
@@ -241,8 +243,8 @@ int sn_segment_colsum_f32(const float *x, int64_t ld, const float *mask, int64_t
 int sn_bcast_rows_f32(const float *src, float *dst, int64_t ldd, int64_t rows_per_seg, int64_t nseg, int32_t C,
                       void *stream);
 int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64_t ldo, const float *bias,
-                         const float *mask, float *gsrc, int64_t ldgs, int64_t rows_per_seg, int64_t nseg, int32_t C,
-                         void *stream);
+                         const float *mask, const float *gadd, int64_t ldga, float *gsrc, int64_t ldgs,
+                         int64_t rows_per_seg, int64_t nseg, int32_t C, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side construction of the quaternionic Dirac operators from a triangle mesh.

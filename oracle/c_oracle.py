@@ -140,7 +140,8 @@ def elu_bwd(gdst, out, gsrc=None):
     rows, Cc = out.reshape(-1, out.shape[-1]).shape
     acc = gsrc is not None
     g = _c(gsrc, np.float32).copy() if acc else np.empty_like(out)
-    lib().oracle_elu_bwd(_p(gdst), i64(Cc), None, i64(0), _p(out), i64(Cc), _p(g), i64(Cc), i64(rows), i32(Cc), i32(1 if acc else 0))
+    lib().oracle_elu_bwd(_p(gdst), i64(Cc), None, i64(0), None, i64(0), _p(out), i64(Cc), _p(g), i64(Cc), i64(rows), i32(Cc),
+                         i32(1 if acc else 0))
     return g
 
 
@@ -154,9 +155,10 @@ def elu_raw(src_ptr, lds, dst_ptr, ldd, rows, Cc):
     lib().oracle_elu(C.c_void_p(src_ptr), i64(lds), C.c_void_p(dst_ptr), i64(ldd), i64(rows), i32(Cc))
 
 
-def elu_bwd_raw(g_ptr, ldg, o_ptr, ldo, s_ptr, ldgs, rows, Cc, accumulate, g2_ptr=None, ldg2=0):
-    lib().oracle_elu_bwd(C.c_void_p(g_ptr), i64(ldg), C.c_void_p(g2_ptr) if g2_ptr else None, i64(ldg2), C.c_void_p(o_ptr),
-                         i64(ldo), C.c_void_p(s_ptr), i64(ldgs), i64(rows), i32(Cc), i32(1 if accumulate else 0))
+def elu_bwd_raw(g_ptr, ldg, o_ptr, ldo, s_ptr, ldgs, rows, Cc, accumulate, g2_ptr=None, ldg2=0, ga_ptr=None, ldga=0):
+    lib().oracle_elu_bwd(C.c_void_p(g_ptr), i64(ldg), C.c_void_p(g2_ptr) if g2_ptr else None, i64(ldg2),
+                         C.c_void_p(ga_ptr) if ga_ptr else None, i64(ldga), C.c_void_p(o_ptr), i64(ldo), C.c_void_p(s_ptr),
+                         i64(ldgs), i64(rows), i32(Cc), i32(1 if accumulate else 0))
 
 
 def colstats_raw(x_ptr, ld, rows, Cc):

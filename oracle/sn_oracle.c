@@ -228,12 +228,13 @@ void oracle_elu(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t 
     }
 }
 
-void oracle_elu_bwd(const float *gdst, int64_t ldg, const float *gdst2, int64_t ldg2, const float *out, int64_t ldo,
-                    float *gsrc, int64_t ldgs, int64_t rows, int C, int accumulate) {
+void oracle_elu_bwd(const float *gdst, int64_t ldg, const float *gdst2, int64_t ldg2, const float *gadd, int64_t ldga,
+                    const float *out, int64_t ldo, float *gsrc, int64_t ldgs, int64_t rows, int C, int accumulate) {
   for (int64_t r = 0; r < rows; ++r)
     for (int c = 0; c < C; ++c) {
       const float o = out[r * ldo + c];
-      const float d = (gdst[r * ldg + c] + (gdst2 ? gdst2[r * ldg2 + c] : 0.0f)) * (o > 0.0f ? 1.0f : o + 1.0f);
+      const float d = (gdst[r * ldg + c] + (gdst2 ? gdst2[r * ldg2 + c] : 0.0f)) * (o > 0.0f ? 1.0f : o + 1.0f) +
+                      (gadd ? gadd[r * ldga + c] : 0.0f);
       float *p = gsrc + r * ldgs + c;
       *p = accumulate ? *p + d : d;
     }

@@ -27,7 +27,7 @@ SIGNATURES = {
     "sn_bsr4_fill": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "sn_blockdiag_concat_i32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sn_elu_into_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
-    "sn_elu_bwd_acc_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "sn_elu_bwd_acc_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
     "sn_colstats_workspace_bytes": (_sz, [_i64, _i32]),
     "sn_colstats_f32": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _sz, _vp]),
     "sn_wgrad_workspace_bytes": (_sz, [_i64, _i32, _i32]),
@@ -38,7 +38,7 @@ SIGNATURES = {
     "sn_segment_colsum_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "sn_segment_colsum_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _sz, _vp]),
     "sn_bcast_rows_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _vp]),
-    "sn_elu_bwd_bcast_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp]),
+    "sn_elu_bwd_bcast_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _vp, _i64, _i64, _i64, _i32, _vp]),
     "sn_dirac_workspace_bytes": (_sz, [_i64, _i64]),
     "sn_dirac_bsr4_from_mesh": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sn_timing_enable": (C.c_int, [_i32]),

@@ -1,0 +1,226 @@
+"""Whole residual blocks as single autograd nodes.
+
+Each of the three blocks of the reference operator layer (src/utils/utils_pt.py: LapResNet2 :151-180, DirResNet2 :182-220,
+AvgResNet2 :222-243) runs here as ONE torch.autograd.Function whose forward and backward chain the kernels by hand.  Owning
+the whole block removes what per-op autograd cannot:
+  * the GEMM epilogue of one stage writes elu(y) straight into the first half of the NEXT stage's (rows, 2C) concat buffer
+    (sn_linear_fwd_f32 `y_elu`), inside a block and — through the `_sn_cat` hand-off — across blocks, so an ELU pass and the
+    re-read of its input disappear per stage;
+  * the residual `x + block(x)` rides in the second GEMM's epilogue and its gradient is added inside the last ELU-backward
+    kernel (`gadd`), and a tensor that feeds two consumers (f_out: this block's vertex stage and the next block's face
+    stage) gets its two gradients summed in that same kernel — no separate accumulation passes.
+
+Activated hand-off: a block returns its outputs with the attribute `_sn_cat` = a fresh (rows, 2C) buffer whose first half
+already holds elu(output).  The next block takes (and removes) it instead of running its own ELU pass.  The attribute lives
+on one tensor object only — any other op on the tensor yields an object without it — so a stale buffer cannot be picked up.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import kernels
+from .functional import _launch, _rows2d, bn_prepare, bnlin_backward, bnlin_forward
+from .operators import as_operator
+
+__all__ = ["lap_block", "dirac_block", "avg_block", "take_activated", "attach_activated"]
+
+
+def attach_activated(t: torch.Tensor, cat: torch.Tensor) -> torch.Tensor:
+    t._sn_cat = cat
+    return t
+
+
+def take_activated(t: torch.Tensor, rows: int, C: int):
+    d = getattr(t, "__dict__", None)
+    cat = d.pop("_sn_cat", None) if d is not None else None
+    if cat is None or tuple(cat.shape) != (rows, 2 * C) or cat.device != t.device or cat.dtype != torch.float32:
+        return None
+    return cat
+
+
+def _new_cat(rows, C, device):
+    return torch.empty((rows, 2 * C), dtype=torch.float32, device=device)
+
+
+def _activated(x2d, pre):
+    """(rows, 2C) buffer whose first half is elu(x2d): the handed-off one, or a new one filled here."""
+    if pre is not None:
+        return pre
+    rows, C = x2d.shape
+    cat = _new_cat(rows, C, x2d.device)
+    kernels.elu_into(x2d, cat[:, :C])
+    return cat
+
+
+def _bn_args(conv):
+    """Flatten a GraphConv1x1("pre") into the tensors/flags bnlin_forward needs (and do BatchNorm's Python bookkeeping)."""
+    training, momentum, eps = bn_prepare(conv.bn)
+    return (conv.bn.weight, conv.bn.bias, conv.fc.weight, conv.fc.bias, conv.bn.running_mean, conv.bn.running_var,
+            training, momentum, eps)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _DiracBlock(torch.autograd.Function):
+    """DirResNet2 (utils_pt.py:191-220):
+         cat0 = [elu(f), Di·elu(v)]  -> f_out = Lin(BN(cat0));   cat1 = [elu(v), DiA·elu(f_out)] -> v + Lin(BN(cat1))."""
+
+    @staticmethod
+    def forward(ctx, v, f, opDi, opDiA, pre_v, pre_f, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1, rm1, rv1,
+                tr1, mo1, ep1):
+        v, f = _rows2d(v), _rows2d(f)
+        rv, C = v.shape
+        rf = f.shape[0]
+        cat1 = _activated(v, pre_v)
+        cat0 = _activated(f, pre_f)
+        _launch(opDi, cat1[:, :C], cat0[:, C:], 4, "fwd")
+        nxt_f = _new_cat(rf, C, v.device)                        # the next Dirac block's cat0; first half = elu(f_out)
+        f_out, st0 = bnlin_forward(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, nxt_f[:, :C])
+        _launch(opDiA, nxt_f[:, :C], cat1[:, C:], 4, "fwd")
+        nxt_v = _new_cat(rv, C, v.device)
+        v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C])
+        ctx.ops = (opDi, opDiA)
+        ctx.bufs = (cat0, cat1, nxt_f)
+        ctx.st = (st0, st1)
+        ctx.mark_non_differentiable(nxt_v, nxt_f)
+        ctx.set_materialize_grads(False)
+        return v_new, f_out, nxt_v, nxt_f
+
+    @staticmethod
+    def backward(ctx, g_vnew, g_fout, _gv, _gf):
+        opDi, opDiA = ctx.ops
+        cat0, cat1, nxt_f = ctx.bufs
+        st0, st1 = ctx.st
+        C = cat1.shape[1] // 2
+        dev = cat1.device
+        none9 = (None,) * 9
+        if g_vnew is None and g_fout is None:
+            return (None,) * 24
+        # ---- second stage (vertex rows) ----
+        g_fo = g_fout.contiguous() if g_fout is not None else None
+        gp1 = none9
+        dx1 = None
+        if g_vnew is not None:
+            g_vnew = g_vnew.contiguous()
+            dx1, dg1, db1, dW1, dc1 = bnlin_backward(st1, g_vnew)                 # gradient w.r.t. cat1
+            gp1 = (dg1, db1, dW1, dc1, None, None, None, None, None)
+            g_ef = torch.empty((nxt_f.shape[0], C), dtype=torch.float32, device=dev)
+            _launch(opDiA.t(), dx1[:, C:], g_ef, 4, "bwd")
+            g_sum = torch.empty_like(g_ef)
+            # (DiA^T·g) * elu'(e_f)  +  the gradient f_out receives from the next block, in one pass
+            kernels.elu_bwd(g_ef, nxt_f[:, :C], g_sum, False, None, g_fo)
+            g_fo = g_sum
+        # ---- first stage (face rows) ----
+        gp0 = none9
+        g_v = g_f = None
+        dx0 = None
+        if g_fo is not None:
+            dx0, dg0, db0, dW0, dc0 = bnlin_backward(st0, g_fo)                   # gradient w.r.t. cat0
+            gp0 = (dg0, db0, dW0, dc0, None, None, None, None, None)
+            if ctx.needs_input_grad[1]:
+                g_f = torch.empty((cat0.shape[0], C), dtype=torch.float32, device=dev)
+                kernels.elu_bwd(dx0[:, :C], cat0[:, :C], g_f, False)
+        if ctx.needs_input_grad[0]:
+            g_ev = torch.empty((cat1.shape[0], C), dtype=torch.float32, device=dev)
+            if dx0 is not None:
+                _launch(opDi.t(), dx0[:, C:], g_ev, 4, "bwd")
+            else:
+                g_ev.zero_()
+            g_v = torch.empty_like(g_ev)
+            # (Di^T·g + g_cat1[:, :C]) * elu'(e_v) + residual-path gradient, in one pass
+            kernels.elu_bwd(g_ev, cat1[:, :C], g_v, False, dx1[:, :C] if dx1 is not None else None, g_vnew)
+        return (g_v, g_f, None, None, None, None) + gp0 + gp1
+
+
+def dirac_block(mod, Di, DiA, v, f):
+    """DirResNet2.forward on (B, V, C) / (B, F, C) tensors; `mod` supplies bn_fc0 / bn_fc1."""
+    B, V, C = v.shape
+    F_ = f.shape[1]
+    rv, rf = B * V, B * F_
+    opDi, opDiA = as_operator(Di), as_operator(DiA)
+    if opDi.shape != (4 * rf, 4 * rv) or opDiA.shape != (4 * rv, 4 * rf):
+        raise ValueError(f"DirResNet2: Di {tuple(opDi.shape)} / DiA {tuple(opDiA.shape)} do not match v rows {rv}, f rows {rf}")
+    v_new, f_out, nxt_v, nxt_f = _DiracBlock.apply(v.reshape(rv, C), f.reshape(rf, C), opDi, opDiA,
+                                                  take_activated(v, rv, C), take_activated(f, rf, C),
+                                                  *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+    return attach_activated(v_new.view(B, V, C), nxt_v), attach_activated(f_out.view(B, F_, C), nxt_f)
+
+
+# ------------------------------------------------------------------------------------------------------------
+class _PropagateBlock(torch.autograd.Function):
+    """LapResNet2 (utils_pt.py:159-180) and AvgResNet2 (utils_pt.py:230-243): two stages  [e, P(e)] -> Lin(BN(.))  with the
+    same propagation P — the sparse product with L, or the per-mesh masked mean broadcast back (global_average)."""
+
+    @staticmethod
+    def forward(ctx, x, op, mask_rows, inv_count, nseg, pre, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1, rm1,
+                rv1, tr1, mo1, ep1):
+        x = _rows2d(x)
+        rows, C = x.shape
+        per = rows // nseg if nseg else 0
+
+        def propagate(cat):
+            if op is not None:
+                _launch(op, cat[:, :C], cat[:, C:], 1, "fwd")
+            else:
+                mean = kernels.segment_colsum(cat[:, :C], mask_rows, per, nseg) * inv_count
+                kernels.bcast_rows(mean, cat[:, C:], per)
+
+        cat_a = _activated(x, pre)
+        propagate(cat_a)
+        cat_b = _new_cat(rows, C, x.device)
+        _, st0 = bnlin_forward(cat_a, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, cat_b[:, :C])
+        propagate(cat_b)
+        nxt = _new_cat(rows, C, x.device)
+        out, st1 = bnlin_forward(cat_b, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x, nxt[:, :C])
+        ctx.op, ctx.seg = op, (mask_rows, inv_count, nseg, per)
+        ctx.bufs, ctx.st = (cat_a, cat_b), (st0, st1)
+        ctx.mark_non_differentiable(nxt)
+        return out, nxt
+
+    @staticmethod
+    def backward(ctx, g_out, _gn):
+        op = ctx.op
+        mask_rows, inv_count, nseg, per = ctx.seg
+        cat_a, cat_b = ctx.bufs
+        st0, st1 = ctx.st
+        C = cat_a.shape[1] // 2
+        g_out = g_out.contiguous()
+
+        def back_propagate(dcat, cat, gadd):
+            """gradient w.r.t. the stage input: ((dcat[:, :C] + P^T dcat[:, C:]) * elu'(e)) + gadd."""
+            g = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
+            if op is not None:
+                g_e = torch.empty_like(g)
+                _launch(op.t(), dcat[:, C:], g_e, 1, "bwd")
+                kernels.elu_bwd(g_e, cat[:, :C], g, False, dcat[:, :C], gadd)
+            else:
+                gm = (kernels.segment_colsum(dcat[:, C:], None, per, nseg) * inv_count).contiguous()
+                kernels.elu_bwd_bcast(dcat[:, :C], cat[:, :C], gm, mask_rows, g, per, gadd)
+            return g
+
+        dxb, dg1, db1, dW1, dc1 = bnlin_backward(st1, g_out)
+        g_h = back_propagate(dxb, cat_b, None)
+        dxa, dg0, db0, dW0, dc0 = bnlin_backward(st0, g_h)
+        g_x = back_propagate(dxa, cat_a, g_out) if ctx.needs_input_grad[0] else None     # + residual-path gradient
+        return (g_x, None, None, None, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None,
+                None, None, None, None)
+
+
+def lap_block(mod, L, inputs):
+    B, V, C = inputs.shape
+    rows = B * V
+    op = as_operator(L)
+    if op.shape != (rows, rows):
+        raise ValueError(f"LapResNet2: operator {tuple(op.shape)} vs {rows} rows")
+    out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), op, None, None, 0, take_activated(inputs, rows, C),
+                                     *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+    return attach_activated(out.view(B, V, C), nxt)
+
+
+def avg_block(mod, mask, inputs):
+    B, V, C = inputs.shape
+    rows = B * V
+    mask_rows = mask.reshape(rows).contiguous()
+    inv_count = 1.0 / mask.reshape(B, V).sum(1, keepdim=True)
+    out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), None, mask_rows, inv_count, B, take_activated(inputs, rows, C),
+                                     *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+    return attach_activated(out.view(B, V, C), nxt)

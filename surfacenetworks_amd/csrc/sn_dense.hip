@@ -430,6 +430,7 @@ __global__ __launch_bounds__(kWG) void bcast_rows_k(const float *__restrict__ sr
 __global__ __launch_bounds__(kWG) void elu_bwd_bcast_k(const float *__restrict__ gdst, int64_t ldg,
                                                        const float *__restrict__ out, int64_t ldo,
                                                        const float *__restrict__ bias, const float *__restrict__ mask,
+                                                       const float *__restrict__ gadd, int64_t ldga,
                                                        float *__restrict__ gsrc, int64_t ldgs, int64_t rows_per_seg,
                                                        int64_t rows, int C, int nt) {
   const int cw = C / 4;
@@ -446,6 +447,7 @@ __global__ __launch_bounds__(kWG) void elu_bwd_bcast_k(const float *__restrict__
     d.y = __builtin_fmaf(m, b.y, g.y) * (o.y > 0.f ? 1.f : o.y + 1.f);
     d.z = __builtin_fmaf(m, b.z, g.z) * (o.z > 0.f ? 1.f : o.z + 1.f);
     d.w = __builtin_fmaf(m, b.w, g.w) * (o.w > 0.f ? 1.f : o.w + 1.f);
+    if (gadd) d += ld4_s(gadd + r * ldga + c, nt);
     st4_s(gsrc + r * ldgs + c, d, nt);
   }
 }
@@ -616,16 +618,16 @@ int sn_bcast_rows_f32(const float *src, float *dst, int64_t ldd, int64_t rows_pe
 }
 
 int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64_t ldo, const float *bias,
-                         const float *mask, float *gsrc, int64_t ldgs, int64_t rows_per_seg, int64_t nseg, int32_t C,
-                         void *stream) {
-  if (rows_per_seg < 0 || nseg < 0 || C < 1 || ldg < C || ldo < C || ldgs < C) return SN_E_SHAPE;
-  if ((C % 4) || (ldg % 4) || (ldo % 4) || (ldgs % 4)) return SN_E_UNSUPPORTED;
+                         const float *mask, const float *gadd, int64_t ldga, float *gsrc, int64_t ldgs,
+                         int64_t rows_per_seg, int64_t nseg, int32_t C, void *stream) {
+  if (rows_per_seg < 0 || nseg < 0 || C < 1 || ldg < C || ldo < C || ldgs < C || (gadd && ldga < C)) return SN_E_SHAPE;
+  if ((C % 4) || (ldg % 4) || (ldo % 4) || (ldgs % 4) || (gadd && (ldga % 4))) return SN_E_UNSUPPORTED;
   const int64_t rows = rows_per_seg * nseg;
   if (rows == 0) return SN_OK;
   if (!gdst || !out || !bias || !gsrc) return SN_E_NULL;
-  if (!aligned16(gdst) || !aligned16(out) || !aligned16(bias) || !aligned16(gsrc)) return SN_E_ALIGN;
+  if (!aligned16(gdst) || !aligned16(out) || !aligned16(bias) || !aligned16(gsrc) || (gadd && !aligned16(gadd))) return SN_E_ALIGN;
   hipLaunchKernelGGL(elu_bwd_bcast_k, dim3(ew_grid(rows * (C / 4))), dim3(kWG), 0, static_cast<hipStream_t>(stream), gdst,
-                     ldg, out, ldo, bias, mask, gsrc, ldgs, rows_per_seg, rows, (int)C, tune_ew_nt());
+                     ldg, out, ldo, bias, mask, gadd, ldga, gsrc, ldgs, rows_per_seg, rows, (int)C, tune_ew_nt());
   return launch_status();
 }
 

@@ -636,6 +636,7 @@ __global__ __launch_bounds__(kWG) void elu_into_k(const float *__restrict__ src,
 template <bool VEC, bool ACC>
 __global__ __launch_bounds__(kWG) void elu_bwd_k(const float *__restrict__ gdst, int64_t ldg,
                                                  const float *__restrict__ gdst2, int64_t ldg2,
+                                                 const float *__restrict__ gadd, int64_t ldga,
                                                  const float *__restrict__ out, int64_t ldo,
                                                  float *__restrict__ gsrc, int64_t ldgs, int64_t rows,
                                                  int C, int nt) {
@@ -654,6 +655,7 @@ __global__ __launch_bounds__(kWG) void elu_bwd_k(const float *__restrict__ gdst,
       d.y = g.y * (o.y > 0.f ? 1.f : o.y + 1.f);
       d.z = g.z * (o.z > 0.f ? 1.f : o.z + 1.f);
       d.w = g.w * (o.w > 0.f ? 1.f : o.w + 1.f);
+      if (gadd) d += ld4_s(gadd + r * ldga + c, nt);
       float *p = gsrc + r * ldgs + c;
       if constexpr (ACC) {
         const f4 a = ld4_s(p, nt);
@@ -662,7 +664,8 @@ __global__ __launch_bounds__(kWG) void elu_bwd_k(const float *__restrict__ gdst,
       st4_s(p, d, nt);
     } else {
       const float o = out[r * ldo + c];
-      const float d = (gdst[r * ldg + c] + (gdst2 ? gdst2[r * ldg2 + c] : 0.f)) * (o > 0.f ? 1.f : o + 1.f);
+      const float d = (gdst[r * ldg + c] + (gdst2 ? gdst2[r * ldg2 + c] : 0.f)) * (o > 0.f ? 1.f : o + 1.f) +
+                      (gadd ? gadd[r * ldga + c] : 0.f);
       float *p = gsrc + r * ldgs + c;
       *p = ACC ? *p + d : d;
     }
@@ -1056,21 +1059,23 @@ int sn_elu_into_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int6
   return launch_status();
 }
 
-int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64_t ldg2, const float *out, int64_t ldo,
-                       float *gsrc, int64_t ldgs, int64_t rows, int32_t C, int32_t accumulate, void *stream) {
-  if (rows < 0 || C < 1 || ldg < C || ldo < C || ldgs < C || (gdst2 && ldg2 < C)) return SN_E_SHAPE;
+int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64_t ldg2, const float *gadd, int64_t ldga,
+                       const float *out, int64_t ldo, float *gsrc, int64_t ldgs, int64_t rows, int32_t C,
+                       int32_t accumulate, void *stream) {
+  if (rows < 0 || C < 1 || ldg < C || ldo < C || ldgs < C || (gdst2 && ldg2 < C) || (gadd && ldga < C)) return SN_E_SHAPE;
   if (rows == 0) return SN_OK;
   if (!gdst || !out || !gsrc) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool vec = (C % 4 == 0) && (ldg % 4 == 0) && (ldo % 4 == 0) && (ldgs % 4 == 0) &&
-                   aligned16(gdst) && aligned16(out) && aligned16(gsrc) && (!gdst2 || (aligned16(gdst2) && ldg2 % 4 == 0));
+                   aligned16(gdst) && aligned16(out) && aligned16(gsrc) && (!gdst2 || (aligned16(gdst2) && ldg2 % 4 == 0)) &&
+                   (!gadd || (aligned16(gadd) && ldga % 4 == 0));
   const unsigned grid = grid_for(vec ? rows * (C / 4) : rows * (int64_t)C, kWG);
   if (vec) {
-    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<true, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
-    else hipLaunchKernelGGL((elu_bwd_k<true, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
+    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<true, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
+    else hipLaunchKernelGGL((elu_bwd_k<true, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
   } else {
-    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<false, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
-    else hipLaunchKernelGGL((elu_bwd_k<false, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
+    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<false, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
+    else hipLaunchKernelGGL((elu_bwd_k<false, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
   }
   return launch_status();
 }

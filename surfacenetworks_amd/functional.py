@@ -18,7 +18,8 @@ import torch
 from . import kernels
 from .operators import SparseOperator, as_operator
 
-__all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg_propagate", "bn_linear", "set_dirac_format", "SpmmTimer"]
+__all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg_propagate", "bn_linear", "bnlin_forward",
+           "bnlin_backward", "bn_prepare", "set_dirac_format", "SpmmTimer"]
 
 _USE_BSR4 = True
 
@@ -255,68 +256,82 @@ def dirac_vert_stage(DiA, f_out2d: torch.Tensor, e_v2d: torch.Tensor) -> torch.T
     return _DiracVertStage.apply(f_out2d, e_v2d, op)
 
 
-class _BNLinear(torch.autograd.Function):
-    """BatchNorm1d("pre") + Linear of GraphConv1x1 (src/utils/utils_pt.py:83-99) on a (rows, C) operand without
-    materialising the normalised tensor.
+def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual=None, elu_out=None):
+    """Forward of the folded BatchNorm1d("pre") + Linear on a (rows, C) operand (no autograd): statistics in one pass
+    (fp64 accumulation), BN folded into the weights  y = x·(W·diag(s))ᵀ + (b + W·t),  s = gamma*invstd, t = beta - mean*s,
+    optional residual add and ELU copy in the GEMM epilogue.  Returns (y, state) with `state` for bnlin_backward."""
+    x = _rows2d(x)
+    rows = x.shape[0]
+    stats = kernels.colstats(x) if training else None
+    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training, running_mean,
+                                                 running_var)
+    if residual is not None:
+        residual = _rows2d(residual)
+    if kernels.linear_fwd_supported(x.shape[1], W.shape[0]):
+        y = kernels.linear_fwd(x, Wf, bf, residual, elu_out)       # weights-in-registers fp32-MFMA GEMM (sn_gemm.hip)
+    else:
+        y = torch.addmm(bf, x, Wf.t())
+        if residual is not None:
+            y += residual
+        if elu_out is not None:
+            kernels.elu_into(y, elu_out)
+    return y, (x, W, Wf, s, mean, invstd, beta, training, b is not None)
 
-    forward : per-channel sum / sum of squares in ONE pass (fp64 accumulation), BN folded into the weights:
-              y = x·(W·diag(s))ᵀ + (b + W·t),  s = gamma*invstd,  t = beta - mean*s.
-    backward: G = dyᵀ·x (split-K fp32-MFMA kernel) and colsum(dy) give every BatchNorm reduction algebraically:
-              sum_r dz = colsum(dy)·W,  sum_r dz∘x = sum_j W∘G;  then dx = dy·(W·diag(s)) + x∘B + C in one GEMM + one
-              fused elementwise pass.  Running statistics follow nn.BatchNorm1d (momentum, unbiased running_var).
-    """
+
+def bnlin_backward(state, dy, need_dx=True):
+    """Backward of bnlin_forward: G = dyᵀ·(x - mean) (split-K fp32-MFMA kernel) and colsum(dy) give every BatchNorm
+    reduction algebraically (sum_r dz = colsum(dy)·W, sum_r dz∘(x-mean) = sum_j W∘G); dx = dy·(W·diag(s)) + (x-mean)∘B + C
+    in ONE GEMM with the tail in its epilogue.  Returns (dx, dgamma, dbeta, dW, db)."""
+    x, W, Wf, s, mean, invstd, beta, training, has_bias = state
+    dy = dy.contiguous()
+    rows, C = x.shape
+    J = dy.shape[1]
+    # centring inside the kernel leaves no fp32 cancellation against mean·colsum(dy)
+    Gc = kernels.wgrad(dy, x, mean) if kernels.wgrad_supported(J, C) else dy.t().mm(x - mean)
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, kernels.colstats(dy), W, s, invstd, beta, rows, has_bias)
+    dx = None
+    if need_dx:
+        if kernels.linear_dgrad_supported(J, C):
+            dx = kernels.linear_dgrad(dy, Wf, x, mean, Bc, Cc) if training else kernels.linear_dgrad(dy, Wf)
+        else:
+            dx = dy.mm(Wf)
+            if training:
+                kernels.affine_cols_acc(dx, x, Bc, Cc, mean)
+    return dx, dgamma, dbeta, dW, db
+
+
+class _BNLinear(torch.autograd.Function):
+    """autograd wrapper of bnlin_forward / bnlin_backward (BatchNorm1d("pre") + Linear of GraphConv1x1,
+    src/utils/utils_pt.py:83-99, without materialising the normalised tensor)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual):
-        x = _rows2d(x)
-        rows = x.shape[0]
-        stats = kernels.colstats(x) if training else None
-        mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training,
-                                                     running_mean, running_var)
-        if residual is not None:
-            residual = _rows2d(residual)
-        if kernels.linear_fwd_supported(x.shape[1], W.shape[0]):
-            y = kernels.linear_fwd(x, Wf, bf, residual)        # weights-in-registers fp32-MFMA GEMM (sn_gemm.hip)
-        else:
-            y = torch.addmm(bf, x, Wf.t())
-            if residual is not None:
-                y += residual
-        ctx.save_for_backward(x, W, Wf, s, mean, invstd, beta)
-        ctx.training, ctx.has_bias, ctx.has_res = training, b is not None, residual is not None
+        y, ctx.state = bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual)
+        ctx.has_res = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, W, Wf, s, mean, invstd, beta = ctx.saved_tensors
-        dy = dy.contiguous()
-        rows, C = x.shape
-        J = dy.shape[1]
-        # Gc = dyᵀ·(x - mean): centring inside the kernel leaves no fp32 cancellation against mean·colsum(dy)
-        Gc = kernels.wgrad(dy, x, mean) if kernels.wgrad_supported(J, C) else dy.t().mm(x - mean)
-        dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, kernels.colstats(dy), W, s, invstd, beta, rows,
-                                                               ctx.has_bias)
-        dx = None
-        if ctx.needs_input_grad[0]:
-            if kernels.linear_dgrad_supported(J, C):
-                # dgrad GEMM with the BatchNorm tail (x - mean)*B + C fused into its epilogue
-                dx = kernels.linear_dgrad(dy, Wf, x, mean, Bc, Cc) if ctx.training else kernels.linear_dgrad(dy, Wf)
-            else:
-                dx = dy.mm(Wf)
-                if ctx.training:
-                    kernels.affine_cols_acc(dx, x, Bc, Cc, mean)
+        dx, dgamma, dbeta, dW, db = bnlin_backward(ctx.state, dy, ctx.needs_input_grad[0])
         return dx, dgamma, dbeta, dW, db, None, None, None, None, None, (dy if ctx.has_res else None)
+
+
+def bn_prepare(bn: torch.nn.BatchNorm1d):
+    """Per-call bookkeeping nn.BatchNorm1d does in Python: returns (training, momentum, eps) and bumps num_batches_tracked."""
+    training = bn.training or not bn.track_running_stats
+    if bn.momentum is None or not bn.affine:
+        raise NotImplementedError("the fused BatchNorm+Linear supports the default affine BatchNorm1d with a fixed momentum")
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return training, bn.momentum, bn.eps
 
 
 def bn_linear(x2d: torch.Tensor, bn: torch.nn.BatchNorm1d, fc: torch.nn.Linear, residual=None) -> torch.Tensor:
     """Fused BatchNorm1d + Linear on a (rows, C) fp32 operand (+ `residual`, added in the GEMM epilogue); updates bn's
     running statistics like nn.BatchNorm1d."""
-    training = bn.training or not bn.track_running_stats
-    if bn.momentum is None or not bn.affine:
-        raise NotImplementedError("bn_linear supports the default affine BatchNorm1d with a fixed momentum")
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    training, momentum, eps = bn_prepare(bn)
     return _BNLinear.apply(x2d, bn.weight, bn.bias, fc.weight, fc.bias, bn.running_mean, bn.running_var, training,
-                           bn.momentum, bn.eps, residual)
+                           momentum, eps, residual)
 
 
 class _AvgPropagate(torch.autograd.Function):

@@ -136,13 +136,17 @@ def elu_into(src, dst) -> None:
     _lib.call("sn_elu_into_f32", _p(src), _ld(src), _p(dst), _ld(dst), src.shape[0], src.shape[1], _stream())
 
 
-def elu_bwd(gdst, out, gsrc, accumulate: bool, gdst2=None) -> None:
-    """gsrc (+)= (gdst + gdst2) * elu'(.) expressed through the activation output `out`."""
-    _dev(gdst, out, gsrc, gdst2)
-    if not (gdst.shape == out.shape == gsrc.shape) or (gdst2 is not None and gdst2.shape != out.shape):
+def elu_bwd(gdst, out, gsrc, accumulate: bool, gdst2=None, gadd=None) -> None:
+    """gsrc (+)= (gdst + gdst2) * elu'(.) + gadd, the derivative expressed through the activation output `out`."""
+    _dev(gdst, out, gsrc, gdst2, gadd)
+    for t in (gdst2, gadd):
+        if t is not None and t.shape != out.shape:
+            raise ValueError("elu_bwd: shape mismatch")
+    if not (gdst.shape == out.shape == gsrc.shape):
         raise ValueError("elu_bwd: shape mismatch")
-    _lib.call("sn_elu_bwd_acc_f32", _p(gdst), _ld(gdst), _p(gdst2), _ld(gdst2) if gdst2 is not None else 0, _p(out),
-              _ld(out), _p(gsrc), _ld(gsrc), out.shape[0], out.shape[1], 1 if accumulate else 0, _stream())
+    _lib.call("sn_elu_bwd_acc_f32", _p(gdst), _ld(gdst), _p(gdst2), _ld(gdst2) if gdst2 is not None else 0, _p(gadd),
+              _ld(gadd) if gadd is not None else 0, _p(out), _ld(out), _p(gsrc), _ld(gsrc), out.shape[0], out.shape[1],
+              1 if accumulate else 0, _stream())
 
 
 def colstats(x):
@@ -232,12 +236,12 @@ def bcast_rows(src, dst, rows_per_seg: int) -> None:
     _lib.call("sn_bcast_rows_f32", _p(src), _p(dst), _ld(dst), rows_per_seg, nseg, C, _stream())
 
 
-def elu_bwd_bcast(gdst, out, bias, mask, gsrc, rows_per_seg: int) -> None:
-    """gsrc = (gdst + mask[r] * bias[mesh(r)]) * elu'(out)."""
-    _dev(gdst, out, bias, mask, gsrc)
+def elu_bwd_bcast(gdst, out, bias, mask, gsrc, rows_per_seg: int, gadd=None) -> None:
+    """gsrc = (gdst + mask[r] * bias[mesh(r)]) * elu'(out) + gadd."""
+    _dev(gdst, out, bias, mask, gsrc, gadd)
     nseg, C = bias.shape
-    _lib.call("sn_elu_bwd_bcast_f32", _p(gdst), _ld(gdst), _p(out), _ld(out), _p(bias), _p(mask), _p(gsrc), _ld(gsrc),
-              rows_per_seg, nseg, C, _stream())
+    _lib.call("sn_elu_bwd_bcast_f32", _p(gdst), _ld(gdst), _p(out), _ld(out), _p(bias), _p(mask), _p(gadd),
+              _ld(gadd) if gadd is not None else 0, _p(gsrc), _ld(gsrc), rows_per_seg, nseg, C, _stream())
 
 
 def dirac_from_mesh(V, F):

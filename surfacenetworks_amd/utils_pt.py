@@ -21,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import blocks as snB
 from . import functional as snF
 from .operators import SparseOperator, as_operator
 
@@ -128,6 +129,19 @@ class GraphBatchNorm(nn.Module):
         return self.bn(x.reshape(b * n, c)).view(b, n, c)
 
 
+def _blocks_ok(mod, x) -> bool:
+    """Whole-block path (blocks.py): fp32, default affine BatchNorm with a fixed momentum, channel count the vector kernels
+    take.  Everything else goes through the per-stage functions."""
+    c = x.shape[-1]
+    if not USE_WHOLE_BLOCKS or x.dtype != torch.float32 or c % 4 or 256 % (c // 4):
+        return False
+    return all(conv.bn.affine and conv.bn.momentum is not None and conv.bn.track_running_stats
+               for conv in (mod.bn_fc0, mod.bn_fc1))
+
+
+USE_WHOLE_BLOCKS = True     # set False to run the per-stage autograd functions (functional.py) instead — for A/B tests
+
+
 class _TwoStage(nn.Module):
     """Shared constructor: two BN("pre")+Linear(2C -> C) stages named bn_fc0 / bn_fc1 (utils_pt.py:156-157,
     187-188,227-228) — the names are part of the checkpoint format."""
@@ -158,6 +172,8 @@ class LapResNet2(_TwoStage):
             return DenseLapResNet2.forward(self, L, mask, inputs)
         batch, node, feat = inputs.size()
         op = as_operator(L)
+        if _blocks_ok(self, inputs):
+            return snB.lap_block(self, op, inputs)                              # the whole block as one autograd node
         x2d = inputs.reshape(batch * node, feat)
         h = self.bn_fc0.forward2d(snF.lap_propagate(op, x2d))
         h = self.bn_fc1.forward2d(snF.lap_propagate(op, h), residual=x2d)        # "+ inputs" rides in the GEMM epilogue
@@ -175,6 +191,8 @@ class DirResNet2(_TwoStage):
     def forward(self, Di, DiA, v, f):
         batch_size, num_nodes, num_inputs = v.size()
         _, num_faces, _ = f.size()
+        if _blocks_ok(self, v):
+            return snB.dirac_block(self, Di, DiA, v, f)                         # the whole block as one autograd node
         v2d = v.reshape(batch_size * num_nodes, num_inputs)
         cat0, e_v = snF.dirac_face_stage(as_operator(Di), v2d, f.reshape(batch_size * num_faces, num_inputs))
         f_out = self.bn_fc0.forward2d(cat0)
@@ -194,6 +212,8 @@ class AvgResNet2(_TwoStage):
             x = F.elu(x)
             x = self.bn_fc1(torch.cat([x, global_average(x, mask).expand_as(x)], 2))
             return x + inputs
+        if _blocks_ok(self, inputs):
+            return snB.avg_block(self, mask, inputs)                            # the whole block as one autograd node
         h = self.bn_fc0.forward2d(snF.avg_propagate(inputs, mask))
         h = self.bn_fc1.forward2d(snF.avg_propagate(h.view(b, n, c), mask), residual=inputs.reshape(b * n, c))
         return h.view(b, n, c)

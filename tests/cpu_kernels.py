@@ -60,9 +60,10 @@ def elu_into(src, dst):
     c_oracle.elu_raw(src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst), src.shape[0], src.shape[1])
 
 
-def elu_bwd(gdst, out, gsrc, accumulate, gdst2=None):
+def elu_bwd(gdst, out, gsrc, accumulate, gdst2=None, gadd=None):
     c_oracle.elu_bwd_raw(gdst.data_ptr(), _ld(gdst), out.data_ptr(), _ld(out), gsrc.data_ptr(), _ld(gsrc), out.shape[0],
-                         out.shape[1], accumulate, None if gdst2 is None else gdst2.data_ptr(), 0 if gdst2 is None else _ld(gdst2))
+                         out.shape[1], accumulate, None if gdst2 is None else gdst2.data_ptr(), 0 if gdst2 is None else _ld(gdst2),
+                         None if gadd is None else gadd.data_ptr(), 0 if gadd is None else _ld(gadd))
 
 
 def colstats(x):
@@ -130,10 +131,11 @@ def bcast_rows(src, dst, rows_per_seg):
     dst.copy_(src.repeat_interleave(rows_per_seg, dim=0))
 
 
-def elu_bwd_bcast(gdst, out, bias, mask, gsrc, rows_per_seg):
+def elu_bwd_bcast(gdst, out, bias, mask, gsrc, rows_per_seg, gadd=None):
     b = bias.repeat_interleave(rows_per_seg, dim=0)
     m = 1.0 if mask is None else mask.reshape(-1, 1)
-    gsrc.copy_(torch.addcmul(gdst, b, torch.ones_like(b) * m) * torch.where(out > 0, torch.ones_like(out), out + 1))
+    res = torch.addcmul(gdst, b, torch.ones_like(b) * m) * torch.where(out > 0, torch.ones_like(out), out + 1)
+    gsrc.copy_(res if gadd is None else res + gadd)
 
 
 def dirac_from_mesh(V, F):

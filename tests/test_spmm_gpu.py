@@ -209,6 +209,10 @@ def test_elu_kernels():
     g2 = rng.standard_normal((333, 128)).astype(np.float32)
     kernels.elu_bwd(dev(g), dev(want), out, False, dev(g2))
     assert np.allclose(out.cpu().numpy(), c_oracle.elu_bwd(g + g2, want), rtol=1e-6, atol=1e-6)
+    # ... plus a term added after the derivative (residual-path gradient)
+    g3 = rng.standard_normal((333, 128)).astype(np.float32)
+    kernels.elu_bwd(dev(g), dev(want), out, False, dev(g2), dev(g3))
+    assert np.allclose(out.cpu().numpy(), c_oracle.elu_bwd(g + g2, want) + g3, rtol=1e-6, atol=1e-6)
     # odd channel count takes the scalar kernel
     x3 = x[:, :7].copy()
     o3 = torch.empty((333, 7), device=DEV)
