@@ -40,7 +40,7 @@ class SpmmTimer:
     active = None
 
     def __init__(self):
-        self.tags = []          # one (tag, nnz) per launch, in launch order
+        self.tags = []          # one (tag, operator) per launch, in launch order (nnz is read after the run: no sync inside)
 
     def __enter__(self):
         from . import _lib
@@ -71,9 +71,9 @@ class SpmmTimer:
         if written.value != len(self.tags):
             raise RuntimeError(f"timing records ({written.value}) do not match launches ({len(self.tags)})")
         out = []
-        for i, (tag, nnz) in enumerate(self.tags):
+        for i, (tag, op) in enumerate(self.tags):
             kind, M, K, _, N = meta[i]
-            out.append((tag + ("/bsr4" if kind == 1 else "/csr"), int(M), int(K), int(nnz), int(N), float(ms[i])))
+            out.append((tag + ("/bsr4" if kind == 1 else "/csr"), int(M), int(K), int(op.nnz), int(N), float(ms[i])))
         return out
 
 
@@ -89,7 +89,7 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
     M, K = op.shape
     timer = SpmmTimer.active
     if timer is not None:
-        timer.tags.append((tag, op.nnz))
+        timer.tags.append((tag, op))
     b = op.bsr4() if (_USE_BSR4 and group == 4) else None
     if b is not None:
         kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)

@@ -346,16 +346,18 @@ class OperatorPool:
         rows, cols = self.rows[sel], self.cols[sel]
         if (rows > size0).any() or (cols > size1).any():
             raise ValueError("size0/size1 smaller than a selected mesh")
+        if self.want_bsr4:
+            # Dirac pools: only the packed blocks are assembled per step (the products use them exclusively); the CSR
+            # view of the batch is expanded from the blocks on demand (export / generic-kernel fallback).
+            if size0 % 4 or size1 % 4:
+                raise ValueError("BSR4 pools need size0 and size1 to be multiples of 4")
+            fb = self._concat(self._fwd_b, sel, rows // 4, size0 // 4, size1 // 4, 16)
+            bb = self._concat(self._bwd_b, sel, cols // 4, size1 // 4, size0 // 4, 16)
+            return SparseOperator.from_bsr4(fb, bb, (B * size0, B * size1), batch=B)
         f = self._concat(self._fwd, sel, rows, size0, size1, 1)
         b = self._concat(self._bwd, sel, cols, size1, size0, 1)
         op = SparseOperator(*f, (B * size0, B * size1), batch=B)
         opt = SparseOperator(*b, (B * size1, B * size0), batch=B, transpose=op)
         op._t = opt
-        if self.want_bsr4:
-            if size0 % 4 or size1 % 4:
-                raise ValueError("BSR4 pools need size0 and size1 to be multiples of 4")
-            op._bsr4 = self._concat(self._fwd_b, sel, rows // 4, size0 // 4, size1 // 4, 16)
-            opt._bsr4 = self._concat(self._bwd_b, sel, cols // 4, size1 // 4, size0 // 4, 16)
-        else:
-            op._bsr4 = opt._bsr4 = False
+        op._bsr4 = opt._bsr4 = False
         return op
