@@ -30,7 +30,9 @@ inline int launch_status() {
   return e == hipSuccess ? SN_OK : (int)e;
 }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
-__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+// ELU in the GEMM epilogue runs while the matrix pipe of this SIMD idles (one wave per SIMD), so it uses the hardware
+// exponential (v_exp_f32) instead of the ~30-instruction expm1f: |error| <= 1.2e-7 absolute, far below the 1e-5 parity bar.
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 
 enum { EPI_FWD = 0, EPI_DGRAD = 1 };
 
