@@ -196,7 +196,9 @@ int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64
  *                   ldx), center[C] optional (NULL = 0; BatchNorm passes the batch mean so that no cancellation
  *                   between dyᵀ·x and mean·colsum(dy) is left to fp32):
  *                   split-K over row slabs on the fp32 MFMA (v_mfma_f32_32x32x2_f32), partial tiles reduced in a
- *                   fixed order.  J and C must be multiples of 32 (J <= 128 per call slice handled internally).
+ *                   fixed order.  J <= 128 and a multiple of 4, C in {128, 256}.  dysum (optional, J doubles) receives the
+ *                   column sums of dy — the bias gradient and the input of sn_bn_bwd_coeffs_f32 — accumulated by the
+ *                   same pass over dy, so no separate reduction kernel is needed.
  *                   Replaces the weight-gradient GEMM of nn.Linear for tall-skinny operands (K = rows ~ 1e5..1e6).
  * sn_affine_cols_acc_f32 : dx[r,c] += (x[r,c] - center[c])*B[c] + Cc[c]  (the elementwise tail of BatchNorm
  *                   backward, fused; center may be NULL).
@@ -206,7 +208,7 @@ int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double 
                     void *workspace, size_t workspace_bytes, void *stream);
 size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C);
 int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
-                 int32_t J, int32_t C, float *G, void *workspace, size_t workspace_bytes, void *stream);
+                 int32_t J, int32_t C, float *G, double *dysum, void *workspace, size_t workspace_bytes, void *stream);
 int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
                            const float *Cc, int64_t rows, int32_t C, void *stream);
 

@@ -138,7 +138,8 @@ __global__ __launch_bounds__(kWG, 2) void wgrad_mfma_k(const float *__restrict__
                                                        const float *__restrict__ x, int64_t ldx,
                                                        const float *__restrict__ center, int64_t rows,
                                                        int J /* <= 128, multiple of 4 */, int C,
-                                                       float *__restrict__ partial /* [grid][128][C] */) {
+                                                       float *__restrict__ partial /* [grid][128][C] */,
+                                                       float *__restrict__ colpart /* [grid][128] column sums of dy | NULL */) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n = lane & 31, kk = lane >> 5;
   const int64_t per = (((rows + gridDim.x - 1) / gridDim.x) + 1) & ~(int64_t)1;   // even slab size
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(kWG, 2) void wgrad_mfma_k(const float *__restrict__
     mu[c] = center ? *reinterpret_cast<const f4 *>(center + 4 * n + 128 * c) : f4{0.f, 0.f, 0.f, 0.f};
   constexpr int U = 4;                              // row pairs per group; two groups of loads are in flight
   int64_t r = r0;
+  float dsum = 0.f;                                 // this lane's share of colsum(dy)[4n + wave] (the bias gradient)
   float a[2][U];                                    // this wave only needs dy column 4n + wave
   f4 b[2][U][CT];
   auto load_group = [&](int buf, int64_t rb) {
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(kWG, 2) void wgrad_mfma_k(const float *__restrict__
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float av = a[buf][u];
+      dsum += av;
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const f4 bv = b[buf][u][c] - mu[c];
@@ -203,6 +206,7 @@ __global__ __launch_bounds__(kWG, 2) void wgrad_mfma_k(const float *__restrict__
     const bool ok = row < r1;
     const f4 a = (ok && jok) ? *reinterpret_cast<const f4 *>(pd + row * lddy) : f4{0.f, 0.f, 0.f, 0.f};
     const float av = a[wave];
+    dsum += av;
 #pragma unroll
     for (int c = 0; c < CT; ++c) {
       const f4 b = ok ? *reinterpret_cast<const f4 *>(px + row * ldx + 128 * c) - mu[c] : f4{0.f, 0.f, 0.f, 0.f};
@@ -211,6 +215,10 @@ __global__ __launch_bounds__(kWG, 2) void wgrad_mfma_k(const float *__restrict__
       acc[c * 4 + 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.z, acc[c * 4 + 2], 0, 0, 0);
       acc[c * 4 + 3] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b.w, acc[c * 4 + 3], 0, 0, 0);
     }
+  }
+  if (colpart) {
+    dsum += __shfl_xor(dsum, 32, 64);               // even + odd rows
+    if (kk == 0) colpart[(int64_t)blockIdx.x * 128 + 4 * n + wave] = dsum;
   }
   // D layout (32x32): column n = lane & 31, row i = (e & 3) + 8*(e >> 2) + 4*(lane >> 5), e = 0..15.
   float *P = partial + (int64_t)blockIdx.x * 128 * C;
@@ -226,16 +234,24 @@ __global__ __launch_bounds__(kWG, 2) void wgrad_mfma_k(const float *__restrict__
 }
 
 __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ partial, int nslab, int J, int C,
-                                                      float *__restrict__ G) {
+                                                      float *__restrict__ G, const float *__restrict__ colpart,
+                                                      double *__restrict__ dysum) {
   __shared__ double sm[4][64];
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
-  const int i = blockIdx.x * 64 + o;            // output element j*C + c  (partials are laid out [slab][128][C])
-  double t = 0;
-  if (i < J * C)
+  const int nG = J * C;
+  const int i = blockIdx.x * 64 + o;            // output element j*C + c  (partials are laid out [slab][128][C]);
+  double t = 0;                                 // elements past J*C are the J column sums of dy ([slab][128])
+  if (i < nG)
     for (int sl = g; sl < nslab; sl += 4) t += (double)partial[(int64_t)sl * 128 * C + i];
+  else if (colpart && i < nG + J)
+    for (int sl = g; sl < nslab; sl += 4) t += (double)colpart[(int64_t)sl * 128 + (i - nG)];
   sm[g][o] = t;
   __syncthreads();
-  if (g == 0 && i < J * C) G[i] = (float)(sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o]);
+  if (g == 0) {
+    const double r = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
+    if (i < nG) G[i] = (float)r;
+    else if (colpart && i < nG + J) dysum[i - nG] = r;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -505,17 +521,18 @@ int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double 
 size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C) {
   (void)J;
   if (C < 1) return 0;
-  return (size_t)wgrad_slabs(rows) * 128 * (size_t)C * sizeof(float);
+  return (size_t)wgrad_slabs(rows) * 128 * ((size_t)C + 1) * sizeof(float);      // tile partials + column-sum partials
 }
 
 int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
-                 int32_t J, int32_t C, float *G, void *workspace, size_t workspace_bytes, void *stream) {
+                 int32_t J, int32_t C, float *G, double *dysum, void *workspace, size_t workspace_bytes, void *stream) {
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldx < C) return SN_E_SHAPE;
   if (J > 128 || (J % 4) || (C != 128 && C != 256)) return SN_E_UNSUPPORTED;
   if (!G) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (rows == 0) {
     hipError_t e = hipMemsetAsync(G, 0, (size_t)J * C * sizeof(float), s);
+    if (e == hipSuccess && dysum) e = hipMemsetAsync(dysum, 0, (size_t)J * sizeof(double), s);
     return e == hipSuccess ? SN_OK : (int)e;
   }
   if (!dy || !x || !workspace) return SN_E_NULL;
@@ -523,11 +540,13 @@ int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, con
   if (workspace_bytes < sn_wgrad_workspace_bytes(rows, J, C)) return SN_E_WORKSPACE;
   const int nslab = wgrad_slabs(rows);
   float *partial = static_cast<float *>(workspace);
+  float *colpart = dysum ? partial + (size_t)nslab * 128 * C : nullptr;
   if (C == 128)
-    hipLaunchKernelGGL((wgrad_mfma_k<1>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial);
+    hipLaunchKernelGGL((wgrad_mfma_k<1>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
   else
-    hipLaunchKernelGGL((wgrad_mfma_k<2>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial);
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((J * C + 63) / 64), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G);
+    hipLaunchKernelGGL((wgrad_mfma_k<2>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((J * C + (dysum ? J : 0) + 63) / 64), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G,
+                     colpart, dysum);
   return launch_status();
 }
 

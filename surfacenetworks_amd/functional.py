@@ -287,8 +287,11 @@ def bnlin_backward(state, dy, need_dx=True):
     rows, C = x.shape
     J = dy.shape[1]
     # centring inside the kernel leaves no fp32 cancellation against mean·colsum(dy)
-    Gc = kernels.wgrad(dy, x, mean) if kernels.wgrad_supported(J, C) else dy.t().mm(x - mean)
-    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, kernels.colstats(dy), W, s, invstd, beta, rows, has_bias)
+    if kernels.wgrad_supported(J, C):
+        Gc, sdy = kernels.wgrad(dy, x, mean, want_colsum=True)      # colsum(dy) rides on the same pass over dy
+    else:
+        Gc, sdy = dy.t().mm(x - mean), kernels.colstats(dy)
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows, has_bias)
     dx = None
     if need_dx:
         if kernels.linear_dgrad_supported(J, C):

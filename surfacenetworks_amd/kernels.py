@@ -164,18 +164,21 @@ def wgrad_supported(J: int, C: int) -> bool:
     return C in (128, 256) and J <= 128 and J % 4 == 0
 
 
-def wgrad(dy, x, center=None):
-    """G = dy^T · (x - center) (J x C, fp32) for tall-skinny operands on the fp32 MFMA; see sn_wgrad_f32."""
+def wgrad(dy, x, center=None, want_colsum: bool = False):
+    """G = dy^T · (x - center) (J x C, fp32) for tall-skinny operands on the fp32 MFMA; see sn_wgrad_f32.
+    want_colsum: also return colsum(dy) as a (J,) float64 tensor, accumulated by the same pass."""
     _dev(dy, x, center)
     rows, J = dy.shape
     C = x.shape[1]
     if x.shape[0] != rows:
         raise ValueError("wgrad: row mismatch")
     G = torch.empty((J, C), dtype=torch.float32, device=x.device)
+    dysum = torch.empty(J, dtype=torch.float64, device=x.device) if want_colsum else None
     ws_bytes = int(_lib.load().sn_wgrad_workspace_bytes(rows, J, C))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-    _lib.call("sn_wgrad_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, J, C, _p(G), _p(ws), ws_bytes, _stream())
-    return G
+    _lib.call("sn_wgrad_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, J, C, _p(G), _p(dysum), _p(ws), ws_bytes,
+              _stream())
+    return (G, dysum) if want_colsum else G
 
 
 def affine_cols_acc(dx, x, B, Cc, center=None) -> None:

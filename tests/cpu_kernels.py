@@ -74,10 +74,11 @@ def wgrad_supported(J, C):
     return C in (128, 256) and J <= 128 and J % 4 == 0
 
 
-def wgrad(dy, x, center=None):
+def wgrad(dy, x, center=None, want_colsum=False):
     G = c_oracle.wgrad_raw(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), x.shape[0], dy.shape[1], x.shape[1],
                            None if center is None else _np(center))
-    return torch.from_numpy(G.astype(np.float32))
+    G = torch.from_numpy(G.astype(np.float32))
+    return (G, dy.detach().double().sum(0)) if want_colsum else G
 
 
 def affine_cols_acc(dx, x, B, Cc, center=None):
@@ -110,7 +111,8 @@ def bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training, running_mea
 
 def bn_bwd_coeffs(Gc, dystats, W, s, invstd, beta, rows, has_bias):
     G, Wd = _np(Gc).astype(np.float64), _np(W).astype(np.float64)
-    sdy = _np(dystats)[0]
+    sdy = _np(dystats)
+    sdy = sdy[0] if sdy.ndim == 2 else sdy
     sd, isd, be = _np(s).astype(np.float64), _np(invstd).astype(np.float64), _np(beta).astype(np.float64)
     a = sdy @ Wd
     p = (Wd * G).sum(0)

@@ -45,6 +45,9 @@ def test_wgrad_mfma(rows, J, C):
     got = kernels.wgrad(dev(dy), dev(x)).cpu().numpy()
     assert got.shape == (J, C)
     assert rel_err(got, want) < 2e-6
+    got_g, got_s = kernels.wgrad(dev(dy), dev(x), None, want_colsum=True)
+    assert np.array_equal(got_g.cpu().numpy(), got)
+    assert rel_err(got_s.cpu().numpy(), dy.astype(np.float64).sum(0)) < 2e-6
     # centred operand (BatchNorm backward passes the batch mean)
     cen = (rng.standard_normal(C) * 5).astype(np.float32)
     got_c = kernels.wgrad(dev(dy), dev(x), dev(cen)).cpu().numpy()
