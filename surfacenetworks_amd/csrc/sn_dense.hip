@@ -11,7 +11,6 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
-#include <stdlib.h>
 
 #include "sn_spmm.h"
 
@@ -30,12 +29,7 @@ __device__ __forceinline__ void st4_s(float *p, f4 v, int nt) {
   else *reinterpret_cast<f4 *>(p) = v;
 }
 
-inline int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-inline int64_t tune_ew_cap() { static const int v = env_int("SN_EW_BLOCKS_CAP", 0); return v > 0 ? v : (int64_t)INT_MAX; }
-inline int tune_ew_nt() { static const int v = env_int("SN_EW_NT", 1); return v; }
+constexpr int kStreamNT = 1;     // elementwise passes stream with non-temporal loads/stores (see sn_kernels.hip)
 
 inline int launch_status() {
   const hipError_t e = hipGetLastError();
@@ -560,11 +554,10 @@ int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx,
                    aligned16(Cc) && (!center || aligned16(center));
   int64_t items = vec ? rows * (C / 4) : rows * (int64_t)C;
   int64_t blocks = (items + kWG - 1) / kWG;
-  if (blocks > tune_ew_cap()) blocks = tune_ew_cap();
   if (vec)
-    hipLaunchKernelGGL((affine_cols_acc_k<true>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C, tune_ew_nt());
+    hipLaunchKernelGGL((affine_cols_acc_k<true>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C, kStreamNT);
   else
-    hipLaunchKernelGGL((affine_cols_acc_k<false>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C, tune_ew_nt());
+    hipLaunchKernelGGL((affine_cols_acc_k<false>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C, kStreamNT);
   return launch_status();
 }
 
@@ -600,7 +593,6 @@ static bool seg_shape_ok(int32_t C) { return C >= 4 && (C % 4 == 0) && (kWG % (C
 
 static unsigned ew_grid(int64_t items) {
   int64_t b = (items + kWG - 1) / kWG;
-  if (b > tune_ew_cap()) b = tune_ew_cap();
   return (unsigned)(b < 1 ? 1 : b);
 }
 
@@ -632,7 +624,7 @@ int sn_bcast_rows_f32(const float *src, float *dst, int64_t ldd, int64_t rows_pe
   if (!src || !dst) return SN_E_NULL;
   if (!aligned16(src) || !aligned16(dst)) return SN_E_ALIGN;
   hipLaunchKernelGGL(bcast_rows_k, dim3(ew_grid(rows * (C / 4))), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, dst,
-                     ldd, rows_per_seg, rows, (int)C, tune_ew_nt());
+                     ldd, rows_per_seg, rows, (int)C, kStreamNT);
   return launch_status();
 }
 
@@ -646,7 +638,7 @@ int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64
   if (!gdst || !out || !bias || !gsrc) return SN_E_NULL;
   if (!aligned16(gdst) || !aligned16(out) || !aligned16(bias) || !aligned16(gsrc) || (gadd && !aligned16(gadd))) return SN_E_ALIGN;
   hipLaunchKernelGGL(elu_bwd_bcast_k, dim3(ew_grid(rows * (C / 4))), dim3(kWG), 0, static_cast<hipStream_t>(stream), gdst,
-                     ldg, out, ldo, bias, mask, gadd, ldga, gsrc, ldgs, rows_per_seg, rows, (int)C, tune_ew_nt());
+                     ldg, out, ldo, bias, mask, gadd, ldga, gsrc, ldgs, rows_per_seg, rows, (int)C, kStreamNT);
   return launch_status();
 }
 

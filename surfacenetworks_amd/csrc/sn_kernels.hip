@@ -30,7 +30,6 @@ namespace {
 
 constexpr int kWG = 256;    // 4 wavefronts per workgroup
 constexpr int kXCD = 8;     // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8
-constexpr int kMaxBlocksPerCU = 8;
 constexpr int kCUs = 256;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -63,38 +62,31 @@ __device__ __forceinline__ int64_t row_off(int r, int64_t ld) {
   else return (int64_t)(r >> 2) * ld + (int64_t)(r & 3) * N;
 }
 
-// XCD-aware chunk walk.  Workgroup b runs on XCD b % 8; giving each XCD one contiguous eighth of
-// the row chunks keeps the X rows shared by neighbouring mesh rows in ONE L2 instead of eight.
-struct ChunkWalk {
-  int first, step, cpx, base;
-  __device__ ChunkWalk(int nchunks) {
-    const int xcd = blockIdx.x % kXCD;
-    cpx = (nchunks + kXCD - 1) / kXCD;
-    base = xcd * cpx;
-    first = blockIdx.x / kXCD;
-    step = gridDim.x / kXCD;
-  }
-};
+// XCD-aware chunk map.  Workgroup b runs on XCD b % 8; giving each XCD one contiguous eighth of the row chunks keeps the
+// X rows shared by neighbouring mesh rows in ONE 4 MiB L2 instead of eight.  One workgroup per chunk: a capped persistent
+// grid measured 5 % slower (late workgroups lose L2 reuse with their spatial neighbours) — the grid is a multiple of 8.
+__device__ __forceinline__ int my_chunk(int nchunks) {
+  const int cpx = (nchunks + kXCD - 1) / kXCD;
+  return (blockIdx.x % kXCD) * cpx + blockIdx.x / kXCD;      // may be >= nchunks for the padding workgroups: callers test rows
+}
 
 // ------------------------------------------------------------------------------------------------
 // CSR SpMM, N/4 lanes per row.
 // ------------------------------------------------------------------------------------------------
-template <int N, int XG, int YG, int KB = 8>
+template <int N, int XG, int YG>
 __global__ __launch_bounds__(kWG) void spmm_csr_v4(const int *__restrict__ rowptr,
                                                    const int *__restrict__ colind,
                                                    const float *__restrict__ vals, int M,
                                                    const float *__restrict__ X, int64_t ldx,
-                                                   float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
+                                                   float *__restrict__ Y, int64_t ldy, int nchunks) {
   constexpr int LPR = N / 4;       // lanes per row
-  constexpr int RPB = kWG / LPR;   // rows per workgroup pass
+  constexpr int RPB = kWG / LPR;   // rows per workgroup
   const int sub = threadIdx.x % LPR;
   const int rloc = threadIdx.x / LPR;
   const float *xb = X + sub * 4;
-  ChunkWalk w(nchunks);            // a chunk = iters consecutive passes of RPB rows
-  for (int local = w.first; local < w.cpx; local += w.step)
-  for (int it = 0; it < iters; ++it) {
-    const int r = ((w.base + local) * iters + it) * RPB + rloc;
-    if (r >= M) continue;
+  {
+    const int r = my_chunk(nchunks) * RPB + rloc;
+    if (r >= M) return;
     int k = rowptr[r];
     const int e = rowptr[r + 1];
     f4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -102,7 +94,7 @@ __global__ __launch_bounds__(kWG) void spmm_csr_v4(const int *__restrict__ rowpt
     // Laplacian, 9 for Di) is one or two batches — no serial tail loop of dependent colind -> gather round trips.
     // Slots past the end re-read the row's last entry with a zero coefficient: fma(0, x, acc) == acc, and the
     // re-read column already belongs to the row, so non-finite inputs propagate exactly as in the plain loop.
-    constexpr int kBatch = KB;
+    constexpr int kBatch = 8;
     for (; k < e; k += kBatch) {
       int c[kBatch];
       float a[kBatch];
@@ -136,9 +128,9 @@ template <int N, int XG, int YG>
 __global__ __launch_bounds__(kWG) void spmm_csr_lds(const int *__restrict__ rowptr, const int *__restrict__ colind,
                                                     const float *__restrict__ vals, int M,
                                                     const float *__restrict__ X, int64_t ldx,
-                                                    float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
+                                                    float *__restrict__ Y, int64_t ldy, int nchunks) {
   constexpr int LPR = N / 4;          // lanes per row
-  constexpr int P = 64 / LPR;         // rows per wave pass
+  constexpr int P = 64 / LPR;         // rows per wave
   constexpr int WAVES = kWG / 64;
   constexpr int TILE = 256;           // entries staged per wave per tile
   constexpr int KB = 8;               // gathers in flight per lane
@@ -149,11 +141,9 @@ __global__ __launch_bounds__(kWG) void spmm_csr_lds(const int *__restrict__ rowp
   const float *xb = X + sub * 4;
   int *sc = s_col[wave];
   float *sv = s_val[wave];
-  ChunkWalk w(nchunks);               // a chunk = iters passes of WAVES * P rows
-  for (int local = w.first; local < w.cpx; local += w.step)
-  for (int it = 0; it < iters; ++it) {
-    const int r0 = (((w.base + local) * iters + it) * WAVES + wave) * P;
-    if (r0 >= M) continue;            // wave-uniform
+  {
+    const int r0 = (my_chunk(nchunks) * WAVES + wave) * P;      // a chunk = WAVES * P rows
+    if (r0 >= M) return;              // wave-uniform
     const int r = r0 + grp;
     const int rc = r < M ? r : M;
     const int kb = rowptr[rc];
@@ -214,10 +204,9 @@ __global__ __launch_bounds__(kWG) void spmm_bsr4_v4(const int *__restrict__ b_ro
   const int64_t yq = (YG == 4) ? ldy : 4 * ldy;
   const int64_t ys = (YG == 4) ? (int64_t)N : ldy;
   const float *xb = X + sub * 4;
-  ChunkWalk w(nchunks);
-  for (int local = w.first; local < w.cpx; local += w.step) {
-    const int br = (w.base + local) * RPB + rloc;
-    if (br >= Mb) continue;
+  {
+    const int br = my_chunk(nchunks) * RPB + rloc;
+    if (br >= Mb) return;
     int k = b_rowptr[br];
     const int e = b_rowptr[br + 1];
     f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
@@ -252,17 +241,16 @@ __global__ __launch_bounds__(kWG) void spmm_bsr4_v4(const int *__restrict__ b_ro
 // loads, and the lane groups then read their blocks back with broadcast ds_read_b128.  Waves stay
 // independent (no workgroup barrier): DS operations of one wave complete in order.
 // ------------------------------------------------------------------------------------------------
-template <int N, int XG, int YG, bool DMA, int UNR>
-__global__ __launch_bounds__(kWG, (UNR == 4 ? 8 : 1)) void spmm_bsr4_lds(const int *__restrict__ b_rowptr,
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) void spmm_bsr4_lds(const int *__restrict__ b_rowptr,
                                                      const int *__restrict__ b_colind,
                                                      const float *__restrict__ b_vals, int Mb,
                                                      const float *__restrict__ X, int64_t ldx,
-                                                     float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
+                                                     float *__restrict__ Y, int64_t ldy, int nchunks) {
   constexpr int LPR = N / 4;          // lanes per block row
   constexpr int RPW = 64 / LPR;       // block rows per wave pass
   constexpr int WAVES = kWG / 64;
   constexpr int TILE = 64;            // blocks staged per wave per tile (4 KiB of values)
-  constexpr int kUnroll = (UNR == 4) ? 1 : UNR;
   __shared__ f4 s_vals[WAVES][TILE * 4];
   __shared__ int s_col[WAVES][TILE];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -275,11 +263,9 @@ __global__ __launch_bounds__(kWG, (UNR == 4 ? 8 : 1)) void spmm_bsr4_lds(const i
   const f4 *gv = reinterpret_cast<const f4 *>(b_vals);
   f4 *sv = s_vals[wave];
   int *sc = s_col[wave];
-  ChunkWalk w(nchunks);               // a chunk = iters passes of WAVES * RPW block rows
-  for (int local = w.first; local < w.cpx; local += w.step)
-  for (int it = 0; it < iters; ++it) {
-    const int r0 = (((w.base + local) * iters + it) * WAVES + wave) * RPW;   // first block row of this wave
-    if (r0 >= Mb) continue;                                   // wave-uniform
+  {
+    const int r0 = (my_chunk(nchunks) * WAVES + wave) * RPW;  // first block row of this wave (a chunk = WAVES * RPW block rows)
+    if (r0 >= Mb) return;                                     // wave-uniform
     const int br = r0 + grp;
     const int brc = br < Mb ? br : Mb;
     const int kb = b_rowptr[brc];
@@ -290,23 +276,18 @@ __global__ __launch_bounds__(kWG, (UNR == 4 ? 8 : 1)) void spmm_bsr4_lds(const i
     for (int t0 = k0; t0 < k1; t0 += TILE) {
       const int nt = (k1 - t0) < TILE ? (k1 - t0) : TILE;
       // ---- stage nt blocks: 4*nt contiguous 16-byte pieces + nt column indices ----
-      if constexpr (DMA) {
-        for (int p0 = 0; p0 < 4 * nt; p0 += 64) {
-          int p = p0 + lane;
-          p = p < 4 * nt ? p : 4 * nt - 1;      // tail lanes re-read the last piece into spare LDS slots
-          __builtin_amdgcn_global_load_lds(gv + (int64_t)t0 * 4 + p, sv + p0, 16, 0, 0);
-        }
-        if (lane < nt) sc[lane] = b_colind[t0 + lane];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      } else {
-        for (int p = lane; p < 4 * nt; p += 64) sv[p] = gv[(int64_t)t0 * 4 + p];
-        if (lane < nt) sc[lane] = b_colind[t0 + lane];
+      for (int p0 = 0; p0 < 4 * nt; p0 += 64) {
+        int p = p0 + lane;
+        p = p < 4 * nt ? p : 4 * nt - 1;        // tail lanes re-read the last piece into spare LDS slots
+        __builtin_amdgcn_global_load_lds(gv + (int64_t)t0 * 4 + p, sv + p0, 16, 0, 0);
       }
+      if (lane < nt) sc[lane] = b_colind[t0 + lane];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_wave_barrier();
       // ---- my blocks inside this tile ----
       int k = kb > t0 ? kb : t0;
       const int kend = ke < t0 + nt ? ke : t0 + nt;
-#pragma unroll kUnroll
+#pragma unroll 2
       for (; k < kend; ++k) {
         const int o = k - t0;
         const int bc = sc[o];
@@ -685,32 +666,23 @@ inline int env_int(const char *name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 // Elementwise passes: one 16-byte item per thread and as many workgroups as that takes (measured faster than a capped
-// grid-stride loop: 6.5 vs 4.9 TB/s on a 1 GiB copy), non-temporal loads/stores.  SN_EW_BLOCKS_CAP / SN_EW_NT for A/B.
-inline int64_t tune_ew_cap() { static const int v = env_int("SN_EW_BLOCKS_CAP", 0); return v > 0 ? v : (int64_t)INT_MAX; }
-inline int tune_ew_nt() { static const int v = env_int("SN_EW_NT", 1); return v; }
+// grid-stride loop: 6.5 vs 4.9 TB/s on a 1 GiB copy, tools/scratch/copybench.hip), non-temporal loads/stores.
+constexpr int kStreamNT = 1;
 inline unsigned grid_for(int64_t work_items, int per_block) {
   int64_t b = (work_items + per_block - 1) / per_block;
   if (b < 1) b = 1;
-  const int64_t cap = tune_ew_cap();
-  return (unsigned)(b < cap ? b : cap);
+  return (unsigned)(b < (int64_t)INT_MAX ? b : (int64_t)INT_MAX);
 }
 
-// Development tunables (read once): SN_BLOCKS_PER_CU caps the persistent grid (0 = one workgroup per chunk),
-// SN_BSR4_VARIANT picks 0 = direct loads, 1 = LDS-staged, 2 = LDS-staged via global_load_lds.
-inline int tune_blocks_per_cu() { static const int v = env_int("SN_BLOCKS_PER_CU", 0); return v; }
+// A/B switches for measurements (read once from the environment; the defaults are the shipped kernels):
+//   SN_BSR4_VARIANT = 0 -> spmm_bsr4_v4 (operator blocks re-read from global by every lane group) instead of spmm_bsr4_lds
+//   SN_CSR_VARIANT  = 0 -> spmm_csr_v4 (entries loaded directly) instead of spmm_csr_lds
 inline int tune_bsr4_variant() { static const int v = env_int("SN_BSR4_VARIANT", 2); return v; }
-inline int tune_csr_iters() { static const int v = env_int("SN_CSR_ITERS", 1); return v < 1 ? 1 : v; }
 inline int tune_csr_variant() { static const int v = env_int("SN_CSR_VARIANT", 1); return v; }
-inline int tune_csr_batch() { static const int v = env_int("SN_CSR_BATCH", 8); return v; }
-inline int tune_bsr4_iters() { static const int v = env_int("SN_BSR4_ITERS", 1); return v < 1 ? 1 : v; }
-inline int tune_bsr4_unroll() { static const int v = env_int("SN_BSR4_UNROLL", 2); return v; }
 
-// grid for the XCD-aware chunk walk: a multiple of 8 workgroups, at most SN_BLOCKS_PER_CU per CU.
+// grid of the chunked kernels: one workgroup per chunk, rounded up to a multiple of the 8 XCDs (see my_chunk)
 inline unsigned chunk_grid(int64_t nchunks) {
   int64_t b = ((nchunks + kXCD - 1) / kXCD) * kXCD;
-  const int bpc = tune_blocks_per_cu();
-  const int64_t cap = bpc > 0 ? (int64_t)kCUs * bpc : (int64_t)INT_MAX - 7;
-  if (b > cap) b = cap;
   if (b < kXCD) b = kXCD;
   return (unsigned)b;
 }
@@ -774,50 +746,21 @@ inline bool timing_slot(int kind, int64_t M, int64_t K, int64_t nnz, int N, hipE
     else hipLaunchKernelGGL(KERNEL, dim3(grid), dim3(kWG), 0, stream, __VA_ARGS__);                            \
   } while (0)
 
-#define SN_DISPATCH_N_G(KERNEL, N, xg, yg, grid, stream, ...)                                          \
-  do {                                                                                                 \
-    if (xg == 1 && yg == 1) SN_KLAUNCH((KERNEL<N, 1, 1>), grid, stream, __VA_ARGS__); \
-    else if (xg == 4 && yg == 4) SN_KLAUNCH((KERNEL<N, 4, 4>), grid, stream, __VA_ARGS__); \
-    else if (xg == 1 && yg == 4) SN_KLAUNCH((KERNEL<N, 1, 4>), grid, stream, __VA_ARGS__); \
-    else SN_KLAUNCH((KERNEL<N, 4, 1>), grid, stream, __VA_ARGS__);         \
-  } while (0)
-
-#define SN_DISPATCH_CSR_KB(N, KB, xg, yg, grid, stream, ...)                                                   \
+#define SN_DISPATCH_G(KERNEL, N, xg, yg, grid, stream, ...)                                                    \
   do {                                                                                                         \
-    if (xg == 1 && yg == 1) SN_KLAUNCH((spmm_csr_v4<N, 1, 1, KB>), grid, stream, __VA_ARGS__); \
-    else if (xg == 4 && yg == 4) SN_KLAUNCH((spmm_csr_v4<N, 4, 4, KB>), grid, stream, __VA_ARGS__); \
-    else if (xg == 1 && yg == 4) SN_KLAUNCH((spmm_csr_v4<N, 1, 4, KB>), grid, stream, __VA_ARGS__); \
-    else SN_KLAUNCH((spmm_csr_v4<N, 4, 1, KB>), grid, stream, __VA_ARGS__);         \
+    if (xg == 1 && yg == 1) SN_KLAUNCH((KERNEL<N, 1, 1>), grid, stream, __VA_ARGS__);                          \
+    else if (xg == 4 && yg == 4) SN_KLAUNCH((KERNEL<N, 4, 4>), grid, stream, __VA_ARGS__);                     \
+    else if (xg == 1 && yg == 4) SN_KLAUNCH((KERNEL<N, 1, 4>), grid, stream, __VA_ARGS__);                     \
+    else SN_KLAUNCH((KERNEL<N, 4, 1>), grid, stream, __VA_ARGS__);                                             \
   } while (0)
-#define SN_DISPATCH_CSR_LDS(N, xg, yg, grid, stream, ...)                                                     \
-  do {                                                                                                         \
-    if (xg == 1 && yg == 1) SN_KLAUNCH((spmm_csr_lds<N, 1, 1>), grid, stream, __VA_ARGS__);                    \
-    else if (xg == 4 && yg == 4) SN_KLAUNCH((spmm_csr_lds<N, 4, 4>), grid, stream, __VA_ARGS__);               \
-    else if (xg == 1 && yg == 4) SN_KLAUNCH((spmm_csr_lds<N, 1, 4>), grid, stream, __VA_ARGS__);               \
-    else SN_KLAUNCH((spmm_csr_lds<N, 4, 1>), grid, stream, __VA_ARGS__);                                       \
-  } while (0)
-#define SN_DISPATCH_CSR(N, xg, yg, grid, stream, ...)                                      \
+#define SN_DISPATCH_N(KERNEL, N, xg, yg, grid, stream, ...)                                \
   do {                                                                                     \
-    if (tune_csr_variant() == 1) SN_DISPATCH_CSR_LDS(N, xg, yg, grid, stream, __VA_ARGS__); \
-    else if (tune_csr_batch() == 4) SN_DISPATCH_CSR_KB(N, 4, xg, yg, grid, stream, __VA_ARGS__); \
-    else SN_DISPATCH_CSR_KB(N, 8, xg, yg, grid, stream, __VA_ARGS__);                      \
-  } while (0)
-
-#define SN_DISPATCH_LDS_U(N, DMA, UNR, xg, yg, grid, stream, ...)                                                     \
-  do {                                                                                                         \
-    if (xg == 1 && yg == 1) SN_KLAUNCH((spmm_bsr4_lds<N, 1, 1, DMA, UNR>), grid, stream, __VA_ARGS__); \
-    else if (xg == 4 && yg == 4) SN_KLAUNCH((spmm_bsr4_lds<N, 4, 4, DMA, UNR>), grid, stream, __VA_ARGS__); \
-    else if (xg == 1 && yg == 4) SN_KLAUNCH((spmm_bsr4_lds<N, 1, 4, DMA, UNR>), grid, stream, __VA_ARGS__); \
-    else SN_KLAUNCH((spmm_bsr4_lds<N, 4, 1, DMA, UNR>), grid, stream, __VA_ARGS__);       \
-  } while (0)
-
-#define SN_DISPATCH_LDS(N, DMA, xg, yg, grid, stream, ...)                                     \
-  do {                                                                                         \
-    const int u_ = tune_bsr4_unroll();                                                         \
-    if (u_ == 1) SN_DISPATCH_LDS_U(N, DMA, 1, xg, yg, grid, stream, __VA_ARGS__);              \
-    else if (u_ == 2) SN_DISPATCH_LDS_U(N, DMA, 2, xg, yg, grid, stream, __VA_ARGS__);         \
-    else if (u_ == 4) SN_DISPATCH_LDS_U(N, DMA, 4, xg, yg, grid, stream, __VA_ARGS__);         \
-    else SN_DISPATCH_LDS_U(N, DMA, 3, xg, yg, grid, stream, __VA_ARGS__);                      \
+    switch (N) {                                                                           \
+      case 16: SN_DISPATCH_G(KERNEL, 16, xg, yg, grid, stream, __VA_ARGS__); break;        \
+      case 32: SN_DISPATCH_G(KERNEL, 32, xg, yg, grid, stream, __VA_ARGS__); break;        \
+      case 64: SN_DISPATCH_G(KERNEL, 64, xg, yg, grid, stream, __VA_ARGS__); break;        \
+      default: SN_DISPATCH_G(KERNEL, 128, xg, yg, grid, stream, __VA_ARGS__); break;       \
+    }                                                                                      \
   } while (0)
 
 }  // namespace
@@ -864,16 +807,13 @@ int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *v
   const bool vec = (N == 16 || N == 32 || N == 64 || N == 128) && aligned16(X) && aligned16(Y) &&
                    (ldx % 4 == 0) && (ldy % 4 == 0);
   if (vec) {
-    const int iters = tune_csr_iters();
-    const int rpb = kWG / (N / 4) * iters;
+    const int rpb = kWG / (N / 4);
     const int64_t nchunks = (M + rpb - 1) / rpb;
     const unsigned grid = chunk_grid(nchunks);
-    switch (N) {
-      case 16: SN_DISPATCH_CSR(16, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters); break;
-      case 32: SN_DISPATCH_CSR(32, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters); break;
-      case 64: SN_DISPATCH_CSR(64, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters); break;
-      default: SN_DISPATCH_CSR(128, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters); break;
-    }
+    if (tune_csr_variant() == 0)
+      SN_DISPATCH_N(spmm_csr_v4, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks);
+    else
+      SN_DISPATCH_N(spmm_csr_lds, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks);
   } else {
     SN_KLAUNCH(spmm_csr_any, grid_for(M * (int64_t)N, kWG), s, rowptr, colind, vals, M, (int)N, X, ldx, (int)x_group, Y,
                ldy, (int)y_group);
@@ -899,35 +839,13 @@ int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const flo
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipEvent_t t_start, t_stop;
   timing_slot(1, 4 * Mb, 4 * Kb, nblocks, N, &t_start, &t_stop);
-  const int variant = tune_bsr4_variant();
-  const int iters = variant == 0 ? 1 : tune_bsr4_iters();
-  const int rpb = kWG / (N / 4) * iters;
+  const int rpb = kWG / (N / 4);
   const int64_t nchunks = (Mb + rpb - 1) / rpb;
   const unsigned grid = chunk_grid(nchunks);
-#define SN_BSR4_ARGS b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks
-  if (variant == 0) {
-    switch (N) {
-      case 16: SN_DISPATCH_N_G(spmm_bsr4_v4, 16, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
-      case 32: SN_DISPATCH_N_G(spmm_bsr4_v4, 32, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
-      case 64: SN_DISPATCH_N_G(spmm_bsr4_v4, 64, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
-      default: SN_DISPATCH_N_G(spmm_bsr4_v4, 128, x_group, y_group, grid, s, SN_BSR4_ARGS); break;
-    }
-  } else if (variant == 1) {
-    switch (N) {
-      case 16: SN_DISPATCH_LDS(16, false, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
-      case 32: SN_DISPATCH_LDS(32, false, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
-      case 64: SN_DISPATCH_LDS(64, false, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
-      default: SN_DISPATCH_LDS(128, false, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
-    }
-  } else {
-    switch (N) {
-      case 16: SN_DISPATCH_LDS(16, true, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
-      case 32: SN_DISPATCH_LDS(32, true, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
-      case 64: SN_DISPATCH_LDS(64, true, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
-      default: SN_DISPATCH_LDS(128, true, x_group, y_group, grid, s, SN_BSR4_ARGS, iters); break;
-    }
-  }
-#undef SN_BSR4_ARGS
+  if (tune_bsr4_variant() == 0)
+    SN_DISPATCH_N(spmm_bsr4_v4, N, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks);
+  else
+    SN_DISPATCH_N(spmm_bsr4_lds, N, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks);
   return launch_status();
 }
 
@@ -1052,10 +970,10 @@ int sn_elu_into_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int6
   const bool vec = (C % 4 == 0) && (lds % 4 == 0) && (ldd % 4 == 0) && aligned16(src) && aligned16(dst);
   if (vec)
     hipLaunchKernelGGL((elu_into_k<true>), dim3(grid_for(rows * (C / 4), kWG)), dim3(kWG), 0, s, src, lds,
-                       dst, ldd, rows, (int)C, tune_ew_nt());
+                       dst, ldd, rows, (int)C, kStreamNT);
   else
     hipLaunchKernelGGL((elu_into_k<false>), dim3(grid_for(rows * (int64_t)C, kWG)), dim3(kWG), 0, s, src,
-                       lds, dst, ldd, rows, (int)C, tune_ew_nt());
+                       lds, dst, ldd, rows, (int)C, kStreamNT);
   return launch_status();
 }
 
@@ -1071,11 +989,11 @@ int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64
                    (!gadd || (aligned16(gadd) && ldga % 4 == 0));
   const unsigned grid = grid_for(vec ? rows * (C / 4) : rows * (int64_t)C, kWG);
   if (vec) {
-    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<true, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
-    else hipLaunchKernelGGL((elu_bwd_k<true, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
+    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<true, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, kStreamNT);
+    else hipLaunchKernelGGL((elu_bwd_k<true, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, kStreamNT);
   } else {
-    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<false, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
-    else hipLaunchKernelGGL((elu_bwd_k<false, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, tune_ew_nt());
+    if (accumulate) hipLaunchKernelGGL((elu_bwd_k<false, true>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, kStreamNT);
+    else hipLaunchKernelGGL((elu_bwd_k<false, false>), dim3(grid), dim3(kWG), 0, s, gdst, ldg, gdst2, ldg2, gadd, ldga, out, ldo, gsrc, ldgs, rows, (int)C, kStreamNT);
   }
   return launch_status();
 }
