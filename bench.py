@@ -90,6 +90,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--meshes", type=int, default=MESHES_PER_GPU, help="meshes per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay forward+loss+backward from one captured hipGraph per step instead of launching every "
+                         "kernel from Python (same kernels; pays off when the step is launch-bound: small batches, busy hosts)")
+    ap.add_argument("--roofline-steps", type=int, default=5,
+                    help="eager steps run AFTER the timed region with per-launch HIP events (graph mode only)")
     ap.add_argument("--format", default="bsr4", choices=["bsr4", "csr"])
     ap.add_argument("--operators", default="pool", choices=["pool", "device"],
                     help="pool: precomputed per-frame operators resident in HBM (default, = the reference's dataset); "
@@ -97,6 +102,7 @@ def main():
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
                     help="default nccl (= RCCL); gloo only for functional tests of the N>1 path on a 1-GPU box")
     args = ap.parse_args()
+    args.no_graph = not args.graph
 
     import torch.distributed as dist
 
@@ -123,26 +129,52 @@ def main():
     rng = np.random.default_rng(10 + rank)
     seq_ids = np.arange(n_local)
 
-    def one_step():
+    def eager_step():
         batch = ds.sample_batch(n_local, rng, seq_ids=seq_ids)          # every local mesh once, random start frame
         return arap.train_step(model, opt, batch, global_batch=global_batch, grad_sync=bucket.all_reduce)
+
+    graphed = None
+
+    def graph_step():
+        batch = ds.sample_batch(n_local, rng, seq_ids=seq_ids)
+        return graphed(batch, grad_sync=bucket.all_reduce)              # load -> one hipGraphLaunch -> all-reduce -> Adam
+
+    one_step = eager_step if args.no_graph else graph_step
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # untimed: lazy code-object loading, allocator growth and clock ramp (3 steps), then the W warm-up steps asked for
-    for _ in range(3 + args.warmup):
+    # untimed: lazy code-object loading, allocator growth and clock ramp (3 eager steps; in graph mode the capture of
+    # forward+loss+backward follows), then the W warm-up steps asked for
+    for _ in range(3):
+        eager_step()
+    if not args.no_graph:
+        graphed = arap.GraphedTrainStep(model, opt, ds.sample_batch(n_local, rng, seq_ids=seq_ids),
+                                        global_batch=global_batch, bucket=bucket)
+    for _ in range(args.warmup):
         one_step()
     sync()
     timer = snF.SpmmTimer()
     t0 = time.perf_counter()
-    with timer:
+    if args.no_graph:
+        with timer:                                  # per-launch HIP events on every SpMM of the timed steps
+            for _ in range(args.steps):
+                loss = one_step()
+    else:
         for _ in range(args.steps):
             loss = one_step()
     sync()
     dt = time.perf_counter() - t0
+    if not args.no_graph:
+        # kernels inside a replayed hipGraph cannot carry start/stop events, so the SpMM launches are timed on the same
+        # steps launched eagerly right after the timed region (same kernels, operands and preceding kernels; the
+        # rocprofv3 summary under profiles/ covers the replayed launches and agrees)
+        with timer:
+            for _ in range(max(1, args.roofline_steps)):
+                eager_step()
+        sync()
     dt_t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
@@ -164,7 +196,7 @@ def main():
     avg_ms = tot_ms / len(dom)
     ab = tot_bytes / len(dom)                      # average algorithmic bytes per launch of this kernel
     achieved = tot_bytes / (tot_ms * 1e-3)
-    spmm_ms_per_step = sum(r[5] for r in recs) / args.steps
+    spmm_ms_per_step = sum(r[5] for r in recs) / (args.steps if args.no_graph else max(1, args.roofline_steps))
     shapes = {}
     for tag, M, K, nnz, N, ms in dom:
         shapes.setdefault((tag, M, K, nnz, N), []).append(ms)
@@ -196,12 +228,15 @@ def main():
         "config": {"workload": f"as_rigid_as_possible Dirac temporal prediction: {n_local} grid-cloth meshes {GRID[0]}x{GRID[1]} "
                                f"(V=5041,F=9800) per GPU, C=128, 15 layers, fwd+loss+bwd+allreduce+Adam",
                    "meshes_per_gpu": n_local, "global_batch": global_batch, "parallelism": f"dp{world} (mesh sharding, flat-bucket RCCL all-reduce)",
-                   "operator_format": args.format, "operators": args.operators, "grad_bucket_bytes": bucket.nbytes},
+                   "operator_format": args.format, "operators": args.operators,
+                   "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager", "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": dom_name + " (all Dirac products of the step: Di, DiA forward; Di^T, DiA^T backward)",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                      "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_c3.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per launch)" if traffic else None,
                      "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg_ms,
-                     "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, every launch of the timed steps",
+                     "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, " +
+                               ("every launch of the timed steps" if args.no_graph else
+                                f"every launch of {max(1, args.roofline_steps)} eager steps run right after the timed hipGraph replays"),
                      "launches_timed": len(dom), "spmm_ms_per_step_all_kernels": spmm_ms_per_step, "per_product": per_shape},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -212,6 +212,39 @@ def forward_loss(model, batch: Batch, global_batch: Optional[int] = None):
     return loss_fn(out, batch.targets, batch.mask, global_batch or batch.num_meshes), out
 
 
+class GraphedTrainStep:
+    """train_step with forward + loss + backward replayed from one hipGraph (graphs.GraphedStep); the gradient
+    all-reduce and the optimizer stay eager.  `example` fixes the batch signature (and becomes the static batch)."""
+
+    def __init__(self, model, optimizer, example: Batch, global_batch: Optional[int] = None, bucket=None):
+        from .graphs import GraphedStep
+
+        self.optimizer = optimizer
+        params = [p for p in model.parameters() if p.requires_grad]
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        grads = [p.grad for p in params]
+        zero = bucket.zero_ if bucket is not None else (lambda: torch._foreach_zero_(grads))
+
+        def body(b):
+            loss, _ = forward_loss(model, b, global_batch)
+            loss.backward()
+            return loss
+
+        self.step = GraphedStep(body, example, zero, preserve=list(model.buffers()))
+
+    def matches(self, batch: Batch) -> bool:
+        return self.step.matches(batch)
+
+    def __call__(self, batch: Batch, grad_sync=None):
+        loss = self.step(batch)
+        if grad_sync is not None:
+            grad_sync()
+        self.optimizer.step()
+        return loss
+
+
 def train_step(model, optimizer, batch: Batch, global_batch: Optional[int] = None, grad_sync=None):
     """One update (main.py:217-232): forward, masked smooth-L1, backward, [gradient all-reduce], Adam."""
     loss, _ = forward_loss(model, batch, global_batch)

@@ -1,0 +1,120 @@
+"""hipGraph capture of one training step (forward + loss + backward) of the Surface-Network models.
+
+A step of the ARAP Dirac model is ~800 kernel launches of 5-400 us; launched one by one from Python the host needs
+30-50 us per launch, which is the same order as the GPU time, so any host slowdown (a busy node, eight ranks sharing
+the cores) turns the step launch-bound.  The reference has the same structure (one Python-dispatched torch op after
+the other, src/as_rigid_as_possible/main.py:217-232).  Here the whole forward/backward is recorded once into a
+hipGraph on static buffers and replayed with a single launch per step:
+
+    batch  = dataset.sample_batch(...)        # eager: a few launches, new tensors
+    step.load(batch)                          # device-to-device copies into the static batch
+    step.replay()                             # ONE hipGraphLaunch: zero grads, forward, loss, backward
+    bucket.all_reduce(); optimizer.step()     # eager (RCCL and the optimizer stay outside the graph)
+
+Only the kernel launches are recorded — same kernels, same order, same arithmetic — so a replay is bit-identical to
+the eager step (tests/test_graph_gpu.py).  The graph is tied to the batch *signature* (tensor shapes and operator
+entry counts); `GraphedStep.matches(batch)` tells the caller whether a batch can be replayed or needs a new capture.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional
+
+import torch
+
+from .operators import SparseOperator
+
+__all__ = ["operator_tensors", "batch_tensors", "batch_signature", "GraphedStep"]
+
+
+def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
+    """Every materialised device array of an operator and its attached transpose, in a fixed order."""
+    if op is None:
+        return []
+    out: List[torch.Tensor] = []
+    for o in (op, op._t):
+        if o is None:
+            continue
+        if o._csr is not None:
+            out.extend(o._csr)
+        if isinstance(o._bsr4, tuple):
+            out.extend(o._bsr4)
+    return out
+
+
+def batch_tensors(batch) -> List[torch.Tensor]:
+    """Device tensors of a Batch-like object (inputs, targets, mask, then L / Di / DiA arrays)."""
+    out = [batch.inputs, batch.targets, batch.mask]
+    for name in ("L", "Di", "DiA"):
+        out.extend(operator_tensors(getattr(batch, name, None)))
+    return out
+
+
+def batch_signature(batch):
+    return tuple((tuple(t.shape), t.dtype) for t in batch_tensors(batch))
+
+
+class GraphedStep:
+    """`body(batch) -> loss` (forward, loss, backward into pre-existing .grad buffers) captured in a hipGraph.
+
+    `example` supplies shapes and becomes the static batch (its tensors are the graph's inputs; `load` overwrites them).
+    `zero_grads()` is recorded at the head of the graph, so a replay leaves exactly this step's gradients in `.grad`.
+    """
+
+    def __init__(self, body: Callable, example, zero_grads: Callable[[], None], warmup: int = 2,
+                 preserve: Optional[List[torch.Tensor]] = None):
+        """`preserve`: tensors the body updates in place (BatchNorm running statistics) — restored after the eager
+        warm-up runs so that capturing leaves the model state untouched."""
+        if not example.inputs.is_cuda:
+            raise RuntimeError("GraphedStep needs a GPU batch (hipGraph capture)")
+        self.static = example
+        self._static_tensors = batch_tensors(example)
+        self.signature = batch_signature(example)
+        self._body, self._zero = body, zero_grads
+        # eager warm-up on a side stream (lazy conversions, allocator, autotuned library kernels), then capture
+        saved = [t.clone() for t in (preserve or [])]
+        # AccumulateGrad nodes created by earlier eager steps live on the default stream; the warm-up below runs on a
+        # side stream on purpose, so the (harmless) stream-mismatch warning is silenced for its duration
+        warn_ctl = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if warn_ctl is not None:
+            warn_ctl(False)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._run()
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for t, s0 in zip(preserve or [], saved):
+                t.copy_(s0)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = self._run()
+        torch.cuda.synchronize()
+        if warn_ctl is not None:
+            warn_ctl(True)
+
+    def _run(self):
+        self._zero()
+        return self._body(self.static)
+
+    def matches(self, batch) -> bool:
+        return batch_signature(batch) == self.signature
+
+    def load(self, batch) -> None:
+        """Copy a freshly sampled batch into the static buffers (device-to-device, on the current stream)."""
+        src = batch_tensors(batch)
+        if len(src) != len(self._static_tensors) or any(
+                s.shape != d.shape or s.dtype != d.dtype for s, d in zip(src, self._static_tensors)):
+            raise ValueError("batch does not match the captured signature; capture a new GraphedStep")
+        with torch.no_grad():
+            if src:
+                torch._foreach_copy_(self._static_tensors, src)
+
+    def replay(self) -> torch.Tensor:
+        self.graph.replay()
+        return self.loss
+
+    def __call__(self, batch) -> torch.Tensor:
+        self.load(batch)
+        return self.replay()

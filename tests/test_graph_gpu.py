@@ -1,0 +1,58 @@
+"""hipGraph replay of a training step == the same step launched eagerly, bit for bit (graphs.GraphedStep)."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _setup(model_kind, meshes=3, grid=(9, 8)):
+    from surfacenetworks_amd import arap
+
+    torch.manual_seed(5)
+    ds = arap.ClothSequences([grid] * meshes, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 3, op_frames=3, seed=11,
+                             device=DEV, model=model_kind)
+    model = (arap.DirModel() if model_kind == "dir" else arap.Model()).to(DEV).train()
+    return arap, ds, model
+
+
+@pytest.mark.parametrize("model_kind", ["dir", "lap"])
+def test_graph_replay_is_bit_identical_to_eager(model_kind):
+    arap, ds, model_e = _setup(model_kind)
+    model_g = copy.deepcopy(model_e)
+    opt_e, opt_g = arap.make_optimizer(model_e), arap.make_optimizer(model_g)
+    n = ds.n
+    ids = np.arange(n)
+    example = ds.sample_batch(n, np.random.default_rng(0), seq_ids=ids)
+    state0 = [b.clone() for b in model_g.buffers()]
+    graphed = arap.GraphedTrainStep(model_g, opt_g, example, global_batch=n)
+    # capturing (warm-up + record) must leave the model state untouched
+    for b0, b in zip(state0, model_g.buffers()):
+        assert torch.equal(b0, b)
+    rng_e, rng_g = np.random.default_rng(1), np.random.default_rng(1)
+    for step in range(3):
+        be = ds.sample_batch(n, rng_e, seq_ids=ids)
+        bg = ds.sample_batch(n, rng_g, seq_ids=ids)
+        assert graphed.matches(bg)
+        le = arap.train_step(model_e, opt_e, be, global_batch=n)
+        lg = graphed(bg)
+        assert torch.equal(le.detach(), lg.detach()), f"loss differs at step {step}"
+        for (name, pe), pg in zip(model_e.named_parameters(), model_g.parameters()):
+            assert torch.equal(pe.grad, pg.grad), f"grad of {name} differs at step {step}"
+            assert torch.equal(pe.detach(), pg.detach()), f"{name} differs after step {step}"
+    for be_, bg_ in zip(model_e.buffers(), model_g.buffers()):
+        assert torch.equal(be_, bg_)
+
+
+def test_signature_mismatch_is_refused():
+    arap, ds, model = _setup("dir", meshes=2)
+    opt = arap.make_optimizer(model)
+    graphed = arap.GraphedTrainStep(model, opt, ds.sample_batch(2, np.random.default_rng(0), seq_ids=np.arange(2)),
+                                    global_batch=2)
+    other = ds.sample_batch(1, np.random.default_rng(0), seq_ids=np.arange(1))
+    assert not graphed.matches(other)
+    with pytest.raises(ValueError):
+        graphed(other)
