@@ -157,16 +157,23 @@ def main():
         one_step()
     sync()
     timer = snF.SpmmTimer()
+    ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     if args.no_graph:
         with timer:                                  # per-launch HIP events on every SpMM of the timed steps
             for _ in range(args.steps):
-                loss = one_step()
+                loss = one_step().detach()           # (keeping the loss itself would keep the step's autograd graph alive)
     else:
         for _ in range(args.steps):
-            loss = one_step()
+            loss = one_step().detach()
     sync()
     dt = time.perf_counter() - t0
+    ms1 = torch.cuda.memory_stats()
+    alloc = {"hipMalloc_calls_in_timed_region": ms1.get("num_device_alloc", 0) - ms0.get("num_device_alloc", 0),
+             "hipFree_calls_in_timed_region": ms1.get("num_device_free", 0) - ms0.get("num_device_free", 0),
+             "alloc_retries": ms1.get("num_alloc_retries", 0) - ms0.get("num_alloc_retries", 0),
+             "reserved_GiB": round(ms1.get("reserved_bytes.all.peak", 0) / 2**30, 2),
+             "allocated_peak_GiB": round(ms1.get("allocated_bytes.all.peak", 0) / 2**30, 2)}
     if not args.no_graph:
         # kernels inside a replayed hipGraph cannot carry start/stop events, so the SpMM launches are timed on the same
         # steps launched eagerly right after the timed region (same kernels, operands and preceding kernels; the
@@ -228,7 +235,7 @@ def main():
         "config": {"workload": f"as_rigid_as_possible Dirac temporal prediction: {n_local} grid-cloth meshes {GRID[0]}x{GRID[1]} "
                                f"(V=5041,F=9800) per GPU, C=128, 15 layers, fwd+loss+bwd+allreduce+Adam",
                    "meshes_per_gpu": n_local, "global_batch": global_batch, "parallelism": f"dp{world} (mesh sharding, flat-bucket RCCL all-reduce)",
-                   "operator_format": args.format, "operators": args.operators,
+                   "allocator": alloc, "operator_format": args.format, "operators": args.operators,
                    "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager", "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": dom_name + " (all Dirac products of the step: Di, DiA forward; Di^T, DiA^T backward)",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,

@@ -19,7 +19,7 @@ from __future__ import annotations
 import torch
 
 from . import kernels
-from .functional import _launch, _rows2d, bn_prepare, bnlin_backward, bnlin_forward
+from .functional import _launch, _rows2d, bn_prepare, bnlin_backward, bnlin_forward, stash, unstash
 from .operators import as_operator
 
 __all__ = ["lap_block", "dirac_block", "avg_block", "take_activated", "attach_activated"]
@@ -79,8 +79,7 @@ class _DiracBlock(torch.autograd.Function):
         nxt_v = _new_cat(rv, C, v.device)
         v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C])
         ctx.ops = (opDi, opDiA)
-        ctx.bufs = (cat0, cat1, nxt_f)
-        ctx.st = (st0, st1)
+        stash(ctx, (cat0, cat1, nxt_f), st0, st1)
         ctx.mark_non_differentiable(nxt_v, nxt_f)
         ctx.set_materialize_grads(False)
         return v_new, f_out, nxt_v, nxt_f
@@ -88,8 +87,7 @@ class _DiracBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_vnew, g_fout, _gv, _gf):
         opDi, opDiA = ctx.ops
-        cat0, cat1, nxt_f = ctx.bufs
-        st0, st1 = ctx.st
+        (cat0, cat1, nxt_f), st0, st1 = unstash(ctx)
         C = cat1.shape[1] // 2
         dev = cat1.device
         none9 = (None,) * 9
@@ -172,7 +170,7 @@ class _PropagateBlock(torch.autograd.Function):
         nxt = _new_cat(rows, C, x.device)
         out, st1 = bnlin_forward(cat_b, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x, nxt[:, :C])
         ctx.op, ctx.seg = op, (mask_rows, inv_count, nseg, per)
-        ctx.bufs, ctx.st = (cat_a, cat_b), (st0, st1)
+        stash(ctx, (cat_a, cat_b), st0, st1)
         ctx.mark_non_differentiable(nxt)
         return out, nxt
 
@@ -180,8 +178,7 @@ class _PropagateBlock(torch.autograd.Function):
     def backward(ctx, g_out, _gn):
         op = ctx.op
         mask_rows, inv_count, nseg, per = ctx.seg
-        cat_a, cat_b = ctx.bufs
-        st0, st1 = ctx.st
+        (cat_a, cat_b), st0, st1 = unstash(ctx)
         C = cat_a.shape[1] // 2
         g_out = g_out.contiguous()
 

@@ -40,7 +40,10 @@ class SpmmTimer:
     active = None
 
     def __init__(self):
-        self.tags = []          # one (tag, operator) per launch, in launch order (nnz is read after the run: no sync inside)
+        # one (tag, nnz | operator) per launch, in launch order.  Operators whose entry count is already known on the
+        # host (pool-assembled batches) are recorded by that number; only the others are kept alive until results()
+        # reads their nnz (no sync inside the timed region either way)
+        self.tags = []
 
     def __enter__(self):
         from . import _lib
@@ -73,7 +76,8 @@ class SpmmTimer:
         out = []
         for i, (tag, op) in enumerate(self.tags):
             kind, M, K, _, N = meta[i]
-            out.append((tag + ("/bsr4" if kind == 1 else "/csr"), int(M), int(K), int(op.nnz), int(N), float(ms[i])))
+            nnz = op if isinstance(op, int) else op.nnz
+            out.append((tag + ("/bsr4" if kind == 1 else "/csr"), int(M), int(K), int(nnz), int(N), float(ms[i])))
         return out
 
 
@@ -89,7 +93,8 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
     M, K = op.shape
     timer = SpmmTimer.active
     if timer is not None:
-        timer.tags.append((tag, op))
+        known = op._nnz_cache if op._nnz_cache is not None else (int(op._csr[1].numel()) if op._csr is not None else None)
+        timer.tags.append((tag, op if known is None else known))
     b = op.bsr4() if (_USE_BSR4 and group == 4) else None
     if b is not None:
         kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
@@ -256,6 +261,36 @@ def dirac_vert_stage(DiA, f_out2d: torch.Tensor, e_v2d: torch.Tensor) -> torch.T
     return _DiracVertStage.apply(f_out2d, e_v2d, op)
 
 
+class _Const:
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = v
+
+
+def stash(ctx, *groups) -> None:
+    """Keep tuples of (tensors | plain values) for backward THROUGH ctx.save_for_backward, so that autograd releases the
+    buffers as soon as the node has run (a plain ctx attribute would pin hundreds of MB of HBM per block until the
+    whole graph object dies — e.g. until the caller drops the previous step's loss)."""
+    tensors, spec = [], []
+    for g in groups:
+        gs = []
+        for item in g:
+            if isinstance(item, torch.Tensor):
+                gs.append(len(tensors))
+                tensors.append(item)
+            else:
+                gs.append(_Const(item))
+        spec.append(gs)
+    ctx.save_for_backward(*tensors)
+    ctx._sn_spec = spec
+
+
+def unstash(ctx):
+    t = ctx.saved_tensors
+    return [tuple(t[i] if isinstance(i, int) else i.v for i in gs) for gs in ctx._sn_spec]
+
+
 def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual=None, elu_out=None):
     """Forward of the folded BatchNorm1d("pre") + Linear on a (rows, C) operand (no autograd): statistics in one pass
     (fp64 accumulation), BN folded into the weights  y = x·(W·diag(s))ᵀ + (b + W·t),  s = gamma*invstd, t = beta - mean*s,
@@ -309,13 +344,15 @@ class _BNLinear(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual):
-        y, ctx.state = bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual)
+        y, state = bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual)
+        stash(ctx, state)
         ctx.has_res = residual is not None
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        dx, dgamma, dbeta, dW, db = bnlin_backward(ctx.state, dy, ctx.needs_input_grad[0])
+        (state,) = unstash(ctx)
+        dx, dgamma, dbeta, dW, db = bnlin_backward(state, dy, ctx.needs_input_grad[0])
         return dx, dgamma, dbeta, dW, db, None, None, None, None, None, (dy if ctx.has_res else None)
 
 

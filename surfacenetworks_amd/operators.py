@@ -15,6 +15,7 @@ What this replaces in the reference (paths relative to the reference checkout):
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional, Sequence
 
 import numpy as np
@@ -55,8 +56,22 @@ class SparseOperator:
         self._nnz_cache = None
         self._shape = (M, K)
         self.batch = int(batch)                  # number of diagonal blocks (B of the reference's (B,R,K) operators)
-        self._t = transpose
+        # operator -> transpose is a strong reference, transpose -> operator a weak one: a strong pair would be a
+        # reference cycle, and the per-step batch operators (hundreds of MB of HBM each) would then live until Python's
+        # cyclic collector happens to run instead of being returned to the caching allocator when the step drops them
+        self._t_strong = None
+        self._t_weak = weakref.ref(transpose) if transpose is not None else None
         self._bsr4 = bsr4                        # (b_rowptr, b_colind, b_vals) | None | False (= not worthwhile)
+
+    @property
+    def _t(self) -> "Optional[SparseOperator]":
+        if self._t_strong is not None:
+            return self._t_strong
+        return self._t_weak() if self._t_weak is not None else None
+
+    @_t.setter
+    def _t(self, value):
+        self._t_strong, self._t_weak = value, None
 
     # ---- tensor-like surface -------------------------------------------------------------------
     @property
@@ -121,8 +136,9 @@ class SparseOperator:
         else:
             out = SparseOperator(mv(self.rowptr), mv(self.colind), mv(self.vals), self._shape, batch=self.batch, bsr4=b)
         if self._t is not None:
-            out._t = self._t.to(device)
-            out._t._t = out
+            t = self._t.to(device)
+            t._t_strong, t._t_weak = None, weakref.ref(out)
+            out._t = t
         return out
 
     def __repr__(self):
@@ -131,11 +147,12 @@ class SparseOperator:
     # ---- derived forms --------------------------------------------------------------------------
     def t(self) -> "SparseOperator":
         """CSR of the transpose, built on first use by sn_csr_transpose_f32 and cached both ways."""
-        if self._t is None:
+        t = self._t
+        if t is None:
             M, K = self._shape
             tr, tc, tv = kernels.csr_transpose(self.rowptr, self.colind, self.vals, M, K)
-            self._t = SparseOperator(tr, tc, tv, (K, M), batch=self.batch, transpose=self)
-        return self._t
+            t = self._t = SparseOperator(tr, tc, tv, (K, M), batch=self.batch, transpose=self)
+        return t
 
     T = property(t)
 
@@ -353,7 +370,9 @@ class OperatorPool:
                 raise ValueError("BSR4 pools need size0 and size1 to be multiples of 4")
             fb = self._concat(self._fwd_b, sel, rows // 4, size0 // 4, size1 // 4, 16)
             bb = self._concat(self._bwd_b, sel, cols // 4, size1 // 4, size0 // 4, 16)
-            return SparseOperator.from_bsr4(fb, bb, (B * size0, B * size1), batch=B)
+            op = SparseOperator.from_bsr4(fb, bb, (B * size0, B * size1), batch=B)
+            op._nnz_cache = op._t._nnz_cache = int(self._fwd["cnt"][sel].sum())      # entries of the pooled CSR: no sync
+            return op
         f = self._concat(self._fwd, sel, rows, size0, size1, 1)
         b = self._concat(self._bwd, sel, cols, size1, size0, 1)
         op = SparseOperator(*f, (B * size0, B * size1), batch=B)
