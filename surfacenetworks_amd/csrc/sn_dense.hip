@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 #include <limits.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sn_spmm.h"
 
@@ -225,6 +226,196 @@ __global__ __launch_bounds__(kWG, 2) void wgrad_mfma_k(const float *__restrict__
         const int i = (e & 3) + 8 * (e >> 2) + 4 * kk;
         P[(int64_t)(4 * i + wave) * C + 128 * c + 4 * n + qb] = acc[c * 4 + qb][e];
       }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight gradient on the bf16 matrix pipe (default): the exact three-piece bf16 split of sn_gemm.hip (six partial products
+// per term, fp32 accumulation — as accurate as the fp32 MFMA), 16 rows of the operands per step.
+//
+// v_mfma_f32_32x32x16_bf16 takes, per lane, EIGHT CONSECUTIVE k of one row/column: with k = operand rows that is a column
+// walk, so the operands go through LDS transposed.  A loader thread owns 8 rows x 4 columns of the step (8 full-line
+// 16-byte loads, prefetched one step ahead), splits its 32 values and writes, per column and piece, the 8 rows as one
+// 16-byte slot.  Slot of (column c, row group g): g·PL + (c%4)·QP + c/4 with QP = (#columns/4) + 4 — consecutive loader
+// lanes write consecutive slots, and the 16-lane groups of a fragment ds_read_b128 (lane = column within the tile) fall on
+// 16 different slot residues mod 16: both directions are conflict-free.  Columns 0..127 are dy (zero past J), the rest
+// x - center.  Waves are 2 (dy tiles) x 2 (x tiles): 2 x 2·CT accumulators each, 18 fragment reads per 48 MFMAs (CT = 2).
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f16v mfma_bf16(const u4 &a, const u4 &b, const f16v &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+}
+
+// Workgroup = 8 waves with two roles (two waves per SIMD, so the SIMD interleaves them by itself):
+//   waves 0-3  matrix waves, 2 (dy tiles) x 2 (x tiles): fragments of the current image, 2 x 2·CT accumulators each,
+//              18 fragment reads per 48 MFMAs (CT = 2);
+//   waves 4-7  loader waves: 8 rows x 4 columns per thread and step, requested THREE steps ahead (three register sets),
+//              split on the vector ALU while the matrix waves multiply, written to the other image.
+// One workgroup barrier per step.
+constexpr int kWgradThreads = 512;
+
+template <int CT /* C / 128: 1 or 2 */>
+__global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__restrict__ dy, int64_t lddy,
+                                                               const float *__restrict__ x, int64_t ldx,
+                                                               const float *__restrict__ center, int64_t rows, int J, int C,
+                                                               float *__restrict__ partial /* [grid][128][C] */,
+                                                               float *__restrict__ colpart /* [grid][128] | NULL */) {
+  constexpr int NCG = 32 + 32 * CT;          // column groups of 4: 32 of dy, 32·CT of x
+  constexpr int QP = NCG + 4;                // slots per (column % 4) plane; QP % 16 == 4 keeps fragment reads conflict-free
+  constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
+  constexpr int NB = 2 * CT;                 // x tiles per matrix wave
+  static_assert(QP % 16 == 4, "slot permutation");
+  __shared__ u4 img[2][3][2 * PL];           // [buffer][piece][slot]; one step = 16 rows = 2 row groups
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  per = (per + 15) & ~(int64_t)15;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+  const int64_t nsteps = r1 > r0 ? (r1 - r0 + 15) / 16 : 0;
+  float *P = partial + (int64_t)blockIdx.x * 128 * C;
+#define SN_STEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+  if (wave >= 4) {
+    // ======================= loader waves =======================
+    const int task = tid - 256;
+    const bool active = task < 2 * NCG;
+    const int rg = active ? task / NCG : 0, cg = active ? task % NCG : 0;
+    const bool isdy = cg < 32;
+    const bool colok = active && (isdy ? 4 * cg < J : true);
+    const float *src = isdy ? dy + (colok ? 4 * cg : 0) : x + 4 * (cg - 32);
+    const int64_t ld = isdy ? lddy : ldx;
+    const f4 mu = (!isdy && center) ? *reinterpret_cast<const f4 *>(center + 4 * (cg - 32)) : f4{0.f, 0.f, 0.f, 0.f};
+    f4 dsum = {0.f, 0.f, 0.f, 0.f};          // dy loaders: column sums of their rows (the bias gradient)
+    f4 ra[8], rb[8], rc[8];                  // rows of three consecutive steps
+    // The registers receive the raw loads only: anything computed from them here would make the compiler wait for the
+    // data in the step that requests it.  Centring and the zeroing of rows past the slab happen at conversion time.
+    auto load_step = [&](f4 (&raw)[8], int64_t s) {
+      const int64_t base = r0 + 16 * s + 8 * rg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int64_t row = base + j;
+        raw[j] = *reinterpret_cast<const f4 *>(src + (row < r1 ? row : r1 - 1) * ld);        // clamped: always in bounds
+      }
+    };
+    auto convert_step = [&](f4 (&raw)[8], int64_t s, int buf) {
+      const int64_t base = r0 + 16 * s + 8 * rg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) raw[j] = (colok && base + j < r1) ? raw[j] - mu : f4{0.f, 0.f, 0.f, 0.f};
+      if (isdy) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dsum += raw[j];
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {          // column 4cg+q: rows 8rg .. 8rg+7 of each piece as one 16-byte slot
+        unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xv = raw[j][q];
+          hb[j] = __float_as_uint(xv);
+          const float r = xv - __uint_as_float(hb[j] & 0xFFFF0000u);
+          mb[j] = __float_as_uint(r);
+          lb[j] = __float_as_uint(r - __uint_as_float(mb[j] & 0xFFFF0000u));
+        }
+        u4 H, M, L;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+          H[p] = __builtin_amdgcn_perm(hb[2 * p + 1], hb[2 * p], 0x07060302u);
+          M[p] = __builtin_amdgcn_perm(mb[2 * p + 1], mb[2 * p], 0x07060302u);
+          L[p] = __builtin_amdgcn_perm(lb[2 * p + 1], lb[2 * p], 0x07060302u);
+        }
+        const int slot = rg * PL + q * QP + cg;
+        if (active) {
+          img[buf][0][slot] = H;
+          img[buf][1][slot] = M;
+          img[buf][2][slot] = L;
+        }
+      }
+    };
+    if (nsteps > 0) {
+      load_step(ra, 0);
+      load_step(rb, 1);
+      load_step(rc, 2);
+      convert_step(ra, 0, 0);
+      load_step(ra, 3);
+      // step s: the matrix waves work on image s&1; this wave converts step s+1 into the other image and re-fills the
+      // registers it frees with step s+4
+      int64_t s = 0;
+      while (true) {
+        SN_STEP_BARRIER();
+        convert_step(rb, s + 1, (int)((s + 1) & 1));
+        load_step(rb, s + 4);
+        if (++s >= nsteps) break;
+        SN_STEP_BARRIER();
+        convert_step(rc, s + 1, (int)((s + 1) & 1));
+        load_step(rc, s + 4);
+        if (++s >= nsteps) break;
+        SN_STEP_BARRIER();
+        convert_step(ra, s + 1, (int)((s + 1) & 1));
+        load_step(ra, s + 4);
+        if (++s >= nsteps) break;
+      }
+    }
+    if (colpart) {                           // (rows past the slab were read as zero: they add nothing)
+      __syncthreads();
+      float *sm = reinterpret_cast<float *>(&img[0][0][0]);
+      if (active && isdy) *reinterpret_cast<f4 *>(sm + rg * 128 + 4 * cg) = dsum;
+      __syncthreads();
+    }
+  } else {
+    // ======================= matrix waves =======================
+    const int i = lane & 31, kh = lane >> 5;
+    const int wj = wave >> 1, wc = wave & 1;
+    const int fo = kh * PL + (i & 3) * QP + (i >> 2);        // my fragment slot, + 8·(tile index in column groups of 32)
+    f16v acc[2][NB];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+    for (int64_t s = 0; s < nsteps; ++s) {
+      const int buf = (int)(s & 1);
+      SN_STEP_BARRIER();                     // image `buf` complete; image buf^1 may be overwritten
+      u4 A[2][3], B[NB][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) A[a][p] = img[buf][p][fo + 8 * (2 * wj + a)];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) B[b][p] = img[buf][p][fo + 32 + 8 * (NB * wc + b)];
+      }
+      // six partial products (pieces of dy, x): (l,h) (h,l) (m,m) (m,h) (h,m) (h,h) — small terms first; tile-inner, so
+      // consecutive MFMAs never share an accumulator
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const int pa = (0x001102 >> (4 * t)) & 15, pb = (0x010120 >> (4 * t)) & 15;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < NB; ++b) acc[a][b] = mfma_bf16(A[a][pa], B[b][pb], acc[a][b]);
+      }
+    }
+    if (colpart) {
+      __syncthreads();
+      __syncthreads();
+      const float *sm = reinterpret_cast<const float *>(&img[0][0][0]);
+      if (tid < 128) colpart[(int64_t)blockIdx.x * 128 + tid] = sm[tid] + sm[128 + tid];
+    }
+    // D layout (32x32): column n = lane & 31 (x column within its tile), row (dy column within its tile)
+    // = (e & 3) + 8 (e >> 2) + 4 (lane >> 5), e = 0..15
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int jr = 32 * (2 * wj + a) + (e & 3) + 8 * (e >> 2) + 4 * kh;
+          P[(int64_t)jr * C + 32 * (NB * wc + b) + i] = acc[a][b][e];
+        }
+  }
+#undef SN_STEP_BARRIER
 }
 
 __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ partial, int nslab, int J, int C,
@@ -469,6 +660,15 @@ inline int stat_blocks(int64_t rows) {
   return (int)b;
 }
 
+// SN_GEMM_VARIANT: 1 (default) split-bf16 kernels, 0 the fp32-MFMA kernels (A/B baseline); shared with sn_gemm.hip
+inline int gemm_variant() {
+  static const int v = [] {
+    const char *e = getenv("SN_GEMM_VARIANT");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
 inline int wgrad_slabs(int64_t rows) {
   int64_t b = (rows + 255) / 256;          // at least 256 rows per slab
   const int64_t cap = 2 * kCUs;            // two 4-wave workgroups per CU (2 waves/SIMD), one round
@@ -532,10 +732,16 @@ int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, con
   if (!dy || !x || !workspace) return SN_E_NULL;
   if (!aligned16(dy) || !aligned16(x) || (center && !aligned16(center)) || (lddy % 4) || (ldx % 4)) return SN_E_ALIGN;
   if (workspace_bytes < sn_wgrad_workspace_bytes(rows, J, C)) return SN_E_WORKSPACE;
-  const int nslab = wgrad_slabs(rows);
+  const bool x3 = gemm_variant() != 0;
+  int nslab = wgrad_slabs(rows);
+  if (x3 && nslab > kCUs) nslab = kCUs;      // one resident workgroup per CU
   float *partial = static_cast<float *>(workspace);
   float *colpart = dysum ? partial + (size_t)nslab * 128 * C : nullptr;
-  if (C == 128)
+  if (x3 && C == 128)
+    hipLaunchKernelGGL((wgrad_x3_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
+  else if (x3)
+    hipLaunchKernelGGL((wgrad_x3_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
+  else if (C == 128)
     hipLaunchKernelGGL((wgrad_mfma_k<1>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
   else
     hipLaunchKernelGGL((wgrad_mfma_k<2>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);

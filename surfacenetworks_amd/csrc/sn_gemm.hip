@@ -15,6 +15,7 @@
 //   four 16-byte pieces per tile — the epilogue (bias / residual / ELU copy, or the BatchNorm tail) works on them.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "sn_spmm.h"
 
@@ -176,6 +177,275 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_k(const float *__restrict__ 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Split-bf16 variant (default): the same product on the bf16 matrix pipe, 16x the fp32 MFMA rate per instruction.
+//
+// Every fp32 value is split EXACTLY into three bf16 pieces by truncation, x = xh + xm + xl (8 + 8 + 8 significant bits;
+// each remainder is formed by an exact fp32 subtraction), and x·w is evaluated as the six partial products
+//     xh·wh + (xh·wm + xm·wh) + (xh·wl + xl·wh + xm·wm)
+// each of them EXACT in the fp32 accumulator's product (8x8 bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The
+// three dropped products (xm·wl, xl·wm, xl·wl) are <= 2^-23 |x·w| in total — the size of ONE fp32 rounding of the product,
+// i.e. the result is as accurate as the fp32 MFMA / an fmaf chain (tests/test_dense_gpu.py bounds both against fp64) —
+// while the matrix pipe needs 6 x 32 cycles per 16 k instead of 8 x 64: the kernel turns from MFMA-bound into HBM-bound.
+// Inf inputs give NaN (inf - inf in the remainder); denormal low pieces may flush (absolute error < 1e-38·|w|).
+//
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[i = l&31][k = 8(l>>5) .. +7] and B[k = 8(l>>5) .. +7][n = l&31] (8 bf16 =
+// 4 VGPRs each); C/D layout as the fp32 form.  i = output column, n = data row as above: the weights' three pieces stay in
+// registers (NT·K·3/4 = 192 VGPRs), a lane reads 32 contiguous bytes of its data row per k-step, splits them (44 VALU
+// operations, issued in the shadow of the 6·NT MFMAs) and the consumed registers are re-filled with the next tile's data.
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split8(const f4 &p, const f4 &q, u4 &H, u4 &M, u4 &L) {
+  const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
+  unsigned hb[8], mb[8], lb[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hb[e] = __float_as_uint(x[e]);
+    const float r = x[e] - __uint_as_float(hb[e] & 0xFFFF0000u);
+    mb[e] = __float_as_uint(r);
+    lb[e] = __float_as_uint(r - __uint_as_float(mb[e] & 0xFFFF0000u));
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {          // pack the upper halves of two words: (w1 & 0xffff0000) | (w0 >> 16)
+    H[j] = __builtin_amdgcn_perm(hb[2 * j + 1], hb[2 * j], 0x07060302u);
+    M[j] = __builtin_amdgcn_perm(mb[2 * j + 1], mb[2 * j], 0x07060302u);
+    L[j] = __builtin_amdgcn_perm(lb[2 * j + 1], lb[2 * j], 0x07060302u);
+  }
+}
+
+__device__ __forceinline__ f16v mfma_bf16(const u4 &a, const u4 &b, const f16v &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
+}
+
+// Operand path.  A lane's MFMA fragment is 32 bytes of ITS row, so fragment-shaped global loads touch 32 cache lines per
+// wave instruction and the four waves of a workgroup would repeat both the loads and the split — the texture addresser and
+// the vector ALU, not HBM or the matrix pipe, then bound the kernel (measured: the fp32-MFMA kernel above and a
+// register-fed split-bf16 kernel run at the same speed).  Instead each wave loads 8 of the tile's 32 rows with full-line
+// loads (one wave instruction = 1 KiB contiguous), splits them ONCE and writes the three bf16 images of the tile to LDS
+// (row stride 2K+16 bytes: conflict-free ds_read_b128); all four waves then read their fragments of every image.  The
+// conversion of tile t+1 (and the global loads of tile t+2 into the registers it frees) is spread over the k-steps of tile
+// t, so the vector ALU works in the shadow of the matrix pipe; one workgroup barrier per tile.
+template <int I>
+struct IC {
+  static constexpr int value = I;
+};
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {          // f(IC<I>{}) for I in [I, N): the index is a constant expression
+  if constexpr (I < N) {
+    f(IC<I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
+
+// x (4 floats) -> 4 bf16 of each piece
+__device__ __forceinline__ void split4(const f4 &x, u2 &H, u2 &M, u2 &L) {
+  const float xs[4] = {x.x, x.y, x.z, x.w};
+  unsigned hb[4], mb[4], lb[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hb[e] = __float_as_uint(xs[e]);
+    const float r = xs[e] - __uint_as_float(hb[e] & 0xFFFF0000u);
+    mb[e] = __float_as_uint(r);
+    lb[e] = __float_as_uint(r - __uint_as_float(mb[e] & 0xFFFF0000u));
+  }
+  H = u2{__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u)};
+  M = u2{__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u)};
+  L = u2{__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u)};
+}
+
+// LDS writes of this wave done, then the workgroup barrier — without the vmcnt(0) a __syncthreads() fence would add
+// (it would drain the global prefetch and wait for the previous tile's stores to be acknowledged).
+#define SN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+template <int K, int NT, bool TRANSW, int EPI, bool SIDE, bool ELU>
+__global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict__ In, int64_t ldi,
+                                                         const float *__restrict__ W, int64_t ldw,
+                                                         float *__restrict__ Out, int64_t ldo, int64_t rows, EpiArgs ep) {
+  constexpr int KS = K / 16;                 // MFMA k-steps per output tile
+  constexpr int RS = 2 * K + 16;             // bytes per row of one bf16 image
+  constexpr int PART = 32 * RS;              // bytes per image
+  constexpr int LPR = K / 4;                 // loader lanes per row (16 bytes each)
+  constexpr int RPL = 64 / LPR;              // rows per load instruction (1 | 2)
+  constexpr int NL = 8 / RPL;                // load instructions per wave per tile (8 | 4)
+  constexpr int CSTEP = KS / NL;             // one conversion chunk every CSTEP k-steps
+  static_assert(KS % NL == 0, "conversion chunks must divide the k-steps");
+  constexpr int CPR = 8 * NT;                // 16-byte chunks per row of a wave's output slab (32·NT columns)
+  constexpr int SROW = 16 * CPR + 16;        // bytes per staged output row (+16: conflict-free transposition)
+  constexpr int RPI = 64 / CPR;              // output rows per store instruction (8 | 4)
+  constexpr int NST = 32 / RPI;              // store instructions per slab (4 | 8)
+  __shared__ __attribute__((aligned(16))) unsigned char img[2][3][PART];
+  __shared__ __attribute__((aligned(16))) unsigned char stg[4][32 * SROW];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n = lane & 31, h = lane >> 5;
+  // ---- stationary weights, split once: w?[t][ks] = pieces of Wmat[col = 32(wave·NT + t) + n][k = 16ks + 8h .. +7] ----
+  u4 wh[NT][KS], wm[NT][KS], wl[NT][KS];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = 32 * (wave * NT + t) + n;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      f4 p, q;
+      if constexpr (!TRANSW) {
+        p = *reinterpret_cast<const f4 *>(W + (int64_t)col * ldw + 16 * ks + 8 * h);
+        q = *reinterpret_cast<const f4 *>(W + (int64_t)col * ldw + 16 * ks + 8 * h + 4);
+      } else {
+        const float *w0 = W + (int64_t)(16 * ks + 8 * h) * ldw + col;
+        p = f4{w0[0], w0[ldw], w0[2 * ldw], w0[3 * ldw]};
+        q = f4{w0[4 * ldw], w0[5 * ldw], w0[6 * ldw], w0[7 * ldw]};
+      }
+      split8(p, q, wh[t][ks], wm[t][ks], wl[t][ks]);
+    }
+  }
+  const int64_t ntiles = (rows + 31) / 32;
+  const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+  int64_t tile = (int64_t)blockIdx.x * per;
+  const int64_t tend = tile + per < ntiles ? tile + per : ntiles;
+  if (tile >= tend) return;
+  const float *side_p = (EPI == EPI_FWD) ? ep.v1 : ep.v0;   // SIDE: forward: the residual; dgrad: x of the BatchNorm tail
+  // ---- epilogue geometry: the slab goes through LDS so that global accesses are full lines — lane l handles the 16 bytes
+  // at chunk (l % CPR) of rows (l / CPR) + RPI·j; its columns, hence its epilogue constants, are fixed for the kernel ----
+  const int erow = lane / CPR;
+  const int ecol = 32 * NT * wave + 4 * (lane % CPR);
+  f4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, k2 = k0;
+  if constexpr (EPI == EPI_FWD) {
+    k0 = *reinterpret_cast<const f4 *>(ep.v0 + ecol);                                // bias
+  } else if constexpr (SIDE) {
+    if (ep.v1) k0 = *reinterpret_cast<const f4 *>(ep.v1 + ecol);                     // center (optional)
+    k1 = *reinterpret_cast<const f4 *>(ep.v2 + ecol);                                // B
+    k2 = *reinterpret_cast<const f4 *>(ep.v3 + ecol);                                // Cc
+  }
+  unsigned char *const sw = &stg[wave][0] + n * SROW + 16 * h;                       // where my accumulators go (+128t + 32g)
+  const unsigned char *const sr = &stg[wave][0] + erow * SROW + 16 * (lane % CPR);   // what I read back (+ RPI·j·SROW)
+
+  // ---- loader: this wave stages rows 8·wave .. +7 of a tile; chunk i = load instruction i ----
+  const int lrow = 8 * wave + lane / LPR;                    // + RPL·i
+  const int lcol = 4 * (lane % LPR);                         // first of my 4 floats
+  f4 raw[NL];
+  auto load_chunk = [&](int64_t tl, int i) {
+    int64_t r = tl * 32 + lrow + RPL * i;
+    r = r < rows ? r : rows - 1;                             // rows past the end re-read the last row (masked at the store)
+    raw[i] = *reinterpret_cast<const f4 *>(In + r * ldi + lcol);
+  };
+  auto convert_chunk = [&](int buf, int i) {
+    u2 H, M, L;
+    split4(raw[i], H, M, L);
+    unsigned char *d = &img[buf][0][0] + (lrow + RPL * i) * RS + 2 * lcol;
+    *reinterpret_cast<u2 *>(d) = H;
+    *reinterpret_cast<u2 *>(d + PART) = M;
+    *reinterpret_cast<u2 *>(d + 2 * PART) = L;
+  };
+  // prologue: tile 0 converted into image 0, tile 1 in flight in the registers
+#pragma unroll
+  for (int i = 0; i < NL; ++i) load_chunk(tile, i);
+#pragma unroll
+  for (int i = 0; i < NL; ++i) {
+    convert_chunk(0, i);
+    load_chunk(tile + 1 < tend ? tile + 1 : tile, i);
+  }
+
+  auto do_tile = [&](auto bufc, int64_t tl) {
+    constexpr int buf = decltype(bufc)::value;
+    SN_LDS_BARRIER();                  // image `buf` complete and visible; every wave is done reading image buf^1
+    const int64_t tl2 = tl + 2 < tend ? tl + 2 : tend - 1;   // tile whose rows refill the registers (clamped: always loads)
+    // side operand in the epilogue layout (full lines), requested now, consumed after the k loop
+    f4 sd[NST];
+    if constexpr (SIDE) {
+#pragma unroll
+      for (int j = 0; j < NST; ++j) {
+        int64_t r = tl * 32 + erow + RPI * j;
+        r = r < rows ? r : rows - 1;
+        sd[j] = *reinterpret_cast<const f4 *>(side_p + r * ep.ld1 + ecol);
+      }
+    }
+    // three accumulators per output tile (leading products | two sets of correction products), visited so that no two
+    // consecutive MFMAs write the same one
+    f16v acc0[NT], acc1[NT], acc2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc0[t][e] = acc1[t][e] = acc2[t][e] = 0.f;
+    const unsigned char *fp = &img[buf][0][0] + n * RS + 16 * h;
+    u4 dh = *reinterpret_cast<const u4 *>(fp), dm = *reinterpret_cast<const u4 *>(fp + PART),
+       dl = *reinterpret_cast<const u4 *>(fp + 2 * PART);
+    static_for<0, KS>([&](auto ic) {
+      constexpr int ks = decltype(ic)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      u4 nh, nm, nl;                              // fragments of the next k-step: read while this one is multiplied
+      if constexpr (ks + 1 < KS) {
+        nh = *reinterpret_cast<const u4 *>(fp + 32 * (ks + 1));
+        nm = *reinterpret_cast<const u4 *>(fp + PART + 32 * (ks + 1));
+        nl = *reinterpret_cast<const u4 *>(fp + 2 * PART + 32 * (ks + 1));
+      }
+      if constexpr (ks % CSTEP == 0) {           // conversion of the next tile, one chunk at a time, under the MFMAs
+        constexpr int i = ks / CSTEP;
+        convert_chunk(buf ^ 1, i);
+        load_chunk(tl2, i);
+      }
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        acc1[t] = mfma_bf16(wl[t][ks], dh, acc1[t]);
+        acc2[t] = mfma_bf16(wh[t][ks], dl, acc2[t]);
+        acc1[t] = mfma_bf16(wm[t][ks], dm, acc1[t]);
+        acc0[t] = mfma_bf16(wh[t][ks], dh, acc0[t]);
+        acc1[t] = mfma_bf16(wm[t][ks], dh, acc1[t]);
+        acc2[t] = mfma_bf16(wh[t][ks], dm, acc2[t]);
+      }
+      if constexpr (ks + 1 < KS) {
+        dh = nh; dm = nm; dl = nl;
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- epilogue.  Accumulator layout: lane (n, h) holds row n, columns 32t + 8g + 4h .. +3 of the wave's slab.  Through
+    // this wave's LDS staging area (same-wave LDS operations complete in order: no barrier) into the full-line layout ----
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
+            f4{acc0[t][4 * g] + (acc1[t][4 * g] + acc2[t][4 * g]), acc0[t][4 * g + 1] + (acc1[t][4 * g + 1] + acc2[t][4 * g + 1]),
+               acc0[t][4 * g + 2] + (acc1[t][4 * g + 2] + acc2[t][4 * g + 2]),
+               acc0[t][4 * g + 3] + (acc1[t][4 * g + 3] + acc2[t][4 * g + 3])};
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      f4 v = *reinterpret_cast<const f4 *>(sr + RPI * j * SROW);
+      const int64_t r = tl * 32 + erow + RPI * j;
+      if constexpr (EPI == EPI_FWD) {
+        v += k0;
+        if constexpr (SIDE) v += sd[j];
+      } else if constexpr (SIDE) {
+        const f4 xv = sd[j] - k0;
+        v.x += __builtin_fmaf(xv.x, k1.x, k2.x);
+        v.y += __builtin_fmaf(xv.y, k1.y, k2.y);
+        v.z += __builtin_fmaf(xv.z, k1.z, k2.z);
+        v.w += __builtin_fmaf(xv.w, k1.w, k2.w);
+      }
+      if (r < rows) {
+        *reinterpret_cast<f4 *>(Out + r * ldo + ecol) = v;
+        if constexpr (EPI == EPI_FWD && ELU)
+          *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
+      }
+    }
+  };
+  while (true) {
+    do_tile(IC<0>{}, tile);
+    if (++tile >= tend) break;
+    do_tile(IC<1>{}, tile);
+    if (++tile >= tend) break;
+  }
+}
+
+// SN_GEMM_VARIANT: 1 (default) split-bf16 on the bf16 matrix pipe, 0 the fp32-MFMA kernel above (A/B baseline)
+inline int gemm_variant() {
+  static const int v = [] {
+    const char *e = getenv("SN_GEMM_VARIANT");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+
 inline unsigned gemm_grid(int64_t rows) {
   const int64_t ntiles = (rows + 31) / 32;
   int64_t b = kCUs;                       // one 4-wave workgroup per CU: a single wave per SIMD owns the register file
@@ -200,7 +470,24 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
   EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
-  if (K == 256)
+  const bool x3 = gemm_variant() != 0;
+#define SN_X3_FWD(KK, RES, EL)                                                                                        \
+  hipLaunchKernelGGL((gemm_rows_x3_k<KK, 1, false, EPI_FWD, RES, EL>), dim3(grid), dim3(kWG), 0, s, x, ldx, W, ldw, y, \
+                     ldy, rows, ep)
+  if (x3) {
+    const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
+    switch (sel) {
+      case 0: SN_X3_FWD(128, false, false); break;
+      case 1: SN_X3_FWD(128, false, true); break;
+      case 2: SN_X3_FWD(128, true, false); break;
+      case 3: SN_X3_FWD(128, true, true); break;
+      case 4: SN_X3_FWD(256, false, false); break;
+      case 5: SN_X3_FWD(256, false, true); break;
+      case 6: SN_X3_FWD(256, true, false); break;
+      default: SN_X3_FWD(256, true, true); break;
+    }
+  }
+  else if (K == 256)
     hipLaunchKernelGGL((gemm_rows_k<256, 1, false, EPI_FWD>), dim3(grid), dim3(kWG), 0, s, x, ldx, W, ldw, y, ldy, rows, ep);
   else
     hipLaunchKernelGGL((gemm_rows_k<128, 1, false, EPI_FWD>), dim3(grid), dim3(kWG), 0, s, x, ldx, W, ldw, y, ldy, rows, ep);
@@ -221,8 +508,17 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
-  if (C == 256)
+  const bool x3 = gemm_variant() != 0;
+  if (C == 256 && x3 && B)
+    hipLaunchKernelGGL((gemm_rows_x3_k<128, 2, true, EPI_DGRAD, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
+  else if (C == 256 && x3)
+    hipLaunchKernelGGL((gemm_rows_x3_k<128, 2, true, EPI_DGRAD, false, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
+  else if (C == 256)
     hipLaunchKernelGGL((gemm_rows_k<128, 2, true, EPI_DGRAD>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
+  else if (x3 && B)
+    hipLaunchKernelGGL((gemm_rows_x3_k<128, 1, true, EPI_DGRAD, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
+  else if (x3)
+    hipLaunchKernelGGL((gemm_rows_x3_k<128, 1, true, EPI_DGRAD, false, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
   else
     hipLaunchKernelGGL((gemm_rows_k<128, 1, true, EPI_DGRAD>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
   return launch_status();

@@ -15,7 +15,15 @@ for rows in (627200, 322624):
     W = torch.randn(128, 256, device=dev) / 16
     b = torch.randn(128, device=dev)
     mu, B, Cc = torch.randn(256, device=dev), torch.randn(256, device=dev), torch.randn(256, device=dev)
+    res = torch.randn(rows, 128, device=dev)
+    cat = torch.empty(rows, 256, device=dev)
+    # accuracy against fp64 on a slice
+    ref = (x[:4096].double() @ W.double().t() + b.double())
+    got = kernels.linear_fwd(x[:4096], W, b).double()
+    print(f"fwd max|err|/max|ref| = {float((got - ref).abs().max() / ref.abs().max()):.3e}  "
+          f"rms = {float(((got - ref) ** 2).mean().sqrt() / (ref ** 2).mean().sqrt()):.3e}")
     for name, fn in (("fwd", lambda: kernels.linear_fwd(x, W, b)),
+                     ("fwd+res+elu", lambda: kernels.linear_fwd(x, W, b, residual=res, y_elu=cat[:, :128])),
                      ("dgrad+affine", lambda: kernels.linear_dgrad(dy, W, x, mu, B, Cc)),
                      ("wgrad", lambda: kernels.wgrad(dy, x, mu)),
                      ("torch addmm", lambda: torch.addmm(b, x, W.t())),
