@@ -229,8 +229,11 @@ __global__ __launch_bounds__(kWG, 2) void wgrad_mfma_k(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight gradient on the bf16 matrix pipe (default): the exact three-piece bf16 split of sn_gemm.hip (six partial products
-// per term, fp32 accumulation — as accurate as the fp32 MFMA), 16 rows of the operands per step.
+// weight gradient on the bf16 matrix pipe (default): the exact three-piece bf16 split of sn_gemm.hip (six exact partial
+// products per term, fp32 accumulation), 16 rows of the operands per step.  All six products of a term go into the tile's
+// single accumulator (8 tiles per wave leave no registers for separate correction accumulators), so the rounding is up to
+// ~2.5x that of one fp32 chain — measured against fp64 it stays below hipBLASLt's fp32 GEMM on the same operands
+// (tests/test_dense_gpu.py::test_split_bf16_is_as_accurate_as_an_fp32_fma_chain).
 //
 // v_mfma_f32_32x32x16_bf16 takes, per lane, EIGHT CONSECUTIVE k of one row/column: with k = operand rows that is a column
 // walk, so the operands go through LDS transposed.  A loader thread owns 8 rows x 4 columns of the step (8 full-line

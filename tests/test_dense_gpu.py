@@ -185,3 +185,71 @@ def test_linear_dgrad_mfma(rows, C):
     got2 = kernels.linear_dgrad(dev(dy), dev(W), dev(x), dev(cen), dev(B), dev(Cc))
     want2 = want + (x.astype(np.float64) - cen) * B + Cc
     assert rel_err(got2.cpu().numpy(), want2) < 2e-6
+
+
+# ---- the exact three-piece bf16 split behind the Linear GEMMs (sn_gemm.hip, wgrad_x3_k) ------------------------------
+def _three_piece(rng, shape, pieces, keep=None):
+    """fp32 values whose bf16 pieces (8 bits each, by truncation) are small non-zero integers scaled by 1, 2^-8, 2^-16:
+    `pieces` says which of (h, m, l) are present; `keep` leaves only that many non-zero entries per row."""
+    v = np.zeros(shape, np.float64)
+    for p, scale in zip(pieces, (1.0, 2.0 ** -8, 2.0 ** -16)):
+        if p:
+            v += rng.integers(1, 4, size=shape) * scale       # all pieces positive: truncation splits them as built
+    if keep is not None:
+        mask = np.zeros(shape, bool)
+        for r in range(shape[0]):
+            mask[r, rng.choice(shape[1], keep, replace=False)] = True
+        v *= mask
+    return v.astype(np.float32)
+
+
+@pytest.mark.parametrize("xp,wp", [((1, 1, 1), (1, 0, 0)), ((1, 0, 0), (1, 1, 1)), ((1, 1, 0), (1, 1, 0)),
+                                   ((0, 1, 0), (1, 0, 0)), ((0, 0, 1), (1, 0, 0)), ((1, 0, 0), (0, 0, 1))])
+def test_split_bf16_keeps_every_partial_product(xp, wp):
+    """Each of the six retained products (hh, hm, mh, hl, lh, mm) is needed for these operands to come out EXACT; the three
+    dropped ones (ml, lm, ll) are absent by construction.  At most 16 non-zero terms of at most 4·4 per output keep every
+    sum below 2^8 with a resolution of 2^-16, i.e. exactly representable in fp32."""
+    rng = np.random.default_rng(sum(xp) * 7 + sum(wp))
+    rows, K, J = 96, 256, 128
+    x = _three_piece(rng, (rows, K), xp, keep=16)
+    W = _three_piece(rng, (J, K), wp)
+    b = np.zeros(J, np.float32)
+    want = x.astype(np.float64) @ W.astype(np.float64).T
+    assert np.array_equal(want.astype(np.float32).astype(np.float64), want)          # the test's own premise
+    got = kernels.linear_fwd(dev(x), dev(W), dev(b)).cpu().numpy().astype(np.float64)
+    assert np.array_equal(got, want)
+    # dgrad: dx = dy·W with dy (rows, J), W (J, C)
+    dy = _three_piece(rng, (rows, J), xp, keep=16)
+    Wd = _three_piece(rng, (J, K), wp)
+    assert np.array_equal(kernels.linear_dgrad(dev(dy), dev(Wd)).cpu().numpy().astype(np.float64),
+                          dy.astype(np.float64) @ Wd.astype(np.float64))
+    # wgrad: G = dyᵀ·x, contraction over 16 rows
+    dyg = _three_piece(rng, (16, J), xp)
+    xg = _three_piece(rng, (16, K), wp)
+    assert np.array_equal(kernels.wgrad(dev(dyg), dev(xg)).cpu().numpy().astype(np.float64),
+                          dyg.astype(np.float64).T @ xg.astype(np.float64))
+
+
+def test_split_bf16_is_as_accurate_as_an_fp32_fma_chain():
+    """Random operands with a wide dynamic range, errors against fp64.  Forward / dgrad keep the correction products in
+    their own accumulators and must be at least as accurate as a plain fp32 dot product (numpy fp32 matmul).  The weight
+    gradient adds all six partial products of a term into one accumulator per tile (8 tiles per wave leave no registers
+    for more), which costs up to ~2.5x the rounding of a single chain — still below the library fp32 GEMM the reference
+    would call (torch matmul), which is the bound asserted here next to 3x the numpy figure."""
+    rng = np.random.default_rng(99)
+    rows, K, J = 4096, 256, 128
+    x = (rng.standard_normal((rows, K)) * np.exp(rng.standard_normal((rows, K)))).astype(np.float32)
+    W = (rng.standard_normal((J, K)) / 16).astype(np.float32)
+    ref = x.astype(np.float64) @ W.astype(np.float64).T
+    err_fp32 = np.abs((x @ W.T).astype(np.float64) - ref).max()
+    got = kernels.linear_fwd(dev(x), dev(W), dev(np.zeros(J, np.float32))).cpu().numpy().astype(np.float64)
+    assert np.abs(got - ref).max() <= 1.01 * err_fp32
+    dy = rng.standard_normal((rows, J)).astype(np.float32)
+    refd = dy.astype(np.float64) @ W.astype(np.float64)
+    err_d = np.abs((dy @ W).astype(np.float64) - refd).max()
+    assert np.abs(kernels.linear_dgrad(dev(dy), dev(W)).cpu().numpy().astype(np.float64) - refd).max() <= 1.01 * err_d
+    refg = dy.astype(np.float64).T @ x.astype(np.float64)
+    err_g = np.abs((dy.T @ x).astype(np.float64) - refg).max()
+    err_lib = np.abs((dev(dy).t() @ dev(x)).cpu().numpy().astype(np.float64) - refg).max()
+    err_k = np.abs(kernels.wgrad(dev(dy), dev(x)).cpu().numpy().astype(np.float64) - refg).max()
+    assert err_k <= 3.0 * err_g and err_k <= err_lib
