@@ -34,8 +34,11 @@ GRID = (71, 71)            # V = 5041, F = 9800
 MESHES_PER_GPU = 64
 
 
-def alg_bytes(M, K, nnz, N):
-    return nnz * 8 + (M + 1) * 4 + K * N * 4 + M * N * 4
+def alg_bytes(M, K, nnz, N, tag=""):
+    """Algorithmic bytes of one product: CSR entries + row pointers + X + Y; a fused ELU-backward epilogue
+    also reads the activation output E (+e) and the other branch's gradient G (+g), M x N floats each."""
+    extra = (1 if "+e" in tag else 0) + (1 if "+g" in tag else 0)
+    return nnz * 8 + (M + 1) * 4 + K * N * 4 + M * N * 4 * (1 + extra)
 
 
 def cpu_baseline(sample_meshes: int, seed: int):
@@ -194,12 +197,12 @@ def main():
     # (Di, DiA forward; Di^T, DiA^T backward), which differ only in which side is the face side.
     by_kernel = {}
     for tag, M, K, nnz, N, ms in recs:
-        kname = ("spmm_bsr4_lds" if tag.endswith("/bsr4") else "spmm_csr_v4") + f"<N={N}>"
+        kname = ("spmm_bsr4_lds" if "/bsr4" in tag else "spmm_csr_lds") + ("_epi" if "+e" in tag else "") + f"<N={N}>"
         by_kernel.setdefault(kname, []).append((tag, M, K, nnz, N, ms))
     dom_name = max(by_kernel, key=lambda k: sum(r[5] for r in by_kernel[k]))
     dom = by_kernel[dom_name]
     tot_ms = sum(r[5] for r in dom)
-    tot_bytes = sum(alg_bytes(r[1], r[2], r[3], r[4]) for r in dom)
+    tot_bytes = sum(alg_bytes(r[1], r[2], r[3], r[4], r[0]) for r in dom)
     avg_ms = tot_ms / len(dom)
     ab = tot_bytes / len(dom)                      # average algorithmic bytes per launch of this kernel
     achieved = tot_bytes / (tot_ms * 1e-3)
@@ -208,19 +211,24 @@ def main():
     for tag, M, K, nnz, N, ms in dom:
         shapes.setdefault((tag, M, K, nnz, N), []).append(ms)
     per_shape = [{"product": t, "M": M, "K": K, "nnz": nnz, "N": N, "launches": len(v), "avg_launch_ms": float(np.mean(v)),
-                  "algorithmic_bytes": alg_bytes(M, K, nnz, N), "frac": alg_bytes(M, K, nnz, N) / (float(np.mean(v)) * 1e-3) / HBM_PEAK}
+                  "algorithmic_bytes": alg_bytes(M, K, nnz, N, t), "frac": alg_bytes(M, K, nnz, N, t) / (float(np.mean(v)) * 1e-3) / HBM_PEAK}
                  for (t, M, K, nnz, N), v in shapes.items()]
     tag = dom[0][0]
 
     # HBM traffic of that kernel from the committed PMC measurement (rocprofv3 cannot run inside this process):
     # average over the launches of the shapes that were measured
-    traffic = None
+    traffic = coverage = None
     try:
         with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_c3.json")) as fh:
-            table = json.load(fh).get("spmm_bsr4_lds", {})
-        per = [table.get(f"M={r[1]},K={r[2]},nnz={r[3]},N={r[4]}") for r in dom]
-        if "bsr4" in dom_name and all(per):
-            traffic = float(np.mean([p_["read_bytes"] + p_["write_bytes"] for p_ in per]))
+            table = json.load(fh).get(dom_name.split("<")[0], {})
+        per = []
+        for r in dom:
+            suffix = r[0][r[0].index("+"):] if "+" in r[0] else ""
+            per.append(table.get(f"M={r[1]},K={r[2]},nnz={r[3]},N={r[4]}" + ("," + suffix if suffix else "")))
+        have = [p_ for p_ in per if p_]
+        if have:
+            traffic = float(np.mean([p_["read_bytes"] + p_["write_bytes"] for p_ in have]))
+            coverage = len(have) / len(per)
     except OSError:
         pass
 
@@ -239,7 +247,8 @@ def main():
                    "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager", "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": dom_name + " (all Dirac products of the step: Di, DiA forward; Di^T, DiA^T backward)",
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                     "traffic": traffic, "traffic_source": "profiles/r1_pmc_traffic_c3.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per launch)" if traffic else None,
+                     "traffic": traffic, "traffic_source": (f"profiles/r1_pmc_traffic_c3.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per launch; "
+                                        f"mean over the {coverage:.0%} of the timed launches whose shape and epilogue were measured)") if traffic else None,
                      "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg_ms,
                      "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, " +
                                ("every launch of the timed steps" if args.no_graph else

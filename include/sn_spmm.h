@@ -93,6 +93,27 @@ int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const flo
                      float *Y, int64_t ldy, int32_t y_group,
                      void *stream);
 
+/* The same two products with the backward of the ELU that precedes the propagation fused into the store:
+ *     Y = (A·X) ∘ elu'(E) + G,      elu'(·) taken from the activation OUTPUT E: 1 where E > 0, E + 1 elsewhere
+ * — with A = Lᵀ / Diᵀ / DiAᵀ this is the gradient that autograd assembles from the sparse product's backward
+ * (src/utils/cuda/sparse_bmm_func.py:60-71), ELUBackward (F.elu at src/utils/utils_pt.py:161,171,193,208) and the sum of
+ * the other branches' gradients (G), without the two intermediate arrays.  E and G have Y's shape and row grouping
+ * (y_group) with their own leading dimensions; G may be NULL.  N in {16,32,64,128}, 16-byte aligned operands. */
+int sn_spmm_csr_elubwd_f32(const int32_t *rowptr, const int32_t *colind, const float *vals,
+                           int64_t M, int64_t K, int64_t nnz,
+                           const float *X, int64_t ldx, int32_t x_group,
+                           int32_t N,
+                           const float *E, int64_t lde, const float *G, int64_t ldg,
+                           float *Y, int64_t ldy, int32_t y_group,
+                           void *stream);
+int sn_spmm_bsr4_elubwd_f32(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals,
+                            int64_t Mb, int64_t Kb, int64_t nblocks,
+                            const float *X, int64_t ldx, int32_t x_group,
+                            int32_t N,
+                            const float *E, int64_t lde, const float *G, int64_t ldg,
+                            float *Y, int64_t ldy, int32_t y_group,
+                            void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Sorted COO -> CSR.
  *
@@ -275,10 +296,11 @@ int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_
 
 /* ------------------------------------------------------------------------------------------
  * Profiling aid (off by default; the library's only global state, mutex-guarded).  While enabled every SpMM launch
- * (sn_spmm_csr_f32 / sn_spmm_bsr4_f32) is issued with hipExtLaunchKernelGGL so that the KERNEL's own start and stop are
+ * (sn_spmm_csr_f32 / sn_spmm_bsr4_f32 and their _elubwd forms) is issued with hipExtLaunchKernelGGL so that the KERNEL's own start and stop are
  * stamped into two events: durations carry no marker / kernel-boundary overhead and agree with rocprofv3's kernel trace.
  * sn_timing_drain waits for the recorded launches, writes up to `capacity` durations (ms) and 5 int64 per record
- * {kind (0 csr, 1 bsr4), M, K, nnz (csr) | nblocks (bsr4), N}, and clears the list.
+ * {kind (bit 0: 0 csr, 1 bsr4; bit 1: fused ELU-backward epilogue, E read; bit 2: G read too), M, K,
+ *  nnz (csr) | nblocks (bsr4), N}, and clears the list.
  * ------------------------------------------------------------------------------------------ */
 int     sn_timing_enable(int32_t on);
 int64_t sn_timing_count(void);
@@ -315,6 +337,12 @@ int sn_laplacian_csr_from_mesh(const float *V, const int32_t *F, int64_t nV, int
  * sn_linear_dgrad_f32 : dx[r, c] = sum_j dy[r,j] * W[j,c]  (+ (x[r,c] - center[c]) * B[c] + Cc[c]  when B != NULL):
  *                     input gradient of the folded BatchNorm+Linear with the BatchNorm tail fused in the epilogue
  *                     (replaces the dgrad GEMM + sn_affine_cols_acc_f32).  W is (J x C) row-major.
+ * sn_linear_dgrad_elu_f32 : the same input gradient when x is the concat buffer [elu(u) | P·elu(u)] of a residual stage
+ *                     (C = 2·C/2 columns): the first C/2 columns continue through the activation in the epilogue,
+ *                         gact[r, c] = dx[r, c] * elu'(x[r, c]) + gadd[r, c]      (c < C/2; gadd may be NULL),
+ *                     and only the last C/2 columns are written, to dx_hi (rows x C/2) — the operand of the transposed
+ *                     sparse product.  B (the BatchNorm tail) is required.  Split-bf16 kernels only
+ *                     (SN_E_UNSUPPORTED with SN_GEMM_VARIANT=0: the caller composes the unfused calls).
  * Supported: K in {128, 256}, J = 128 for the forward; J = 128, C in {128, 256} for the input gradient; all leading
  * dimensions multiples of 4 floats and 16-byte aligned bases (else SN_E_UNSUPPORTED / SN_E_ALIGN: the caller falls
  * back to a library GEMM).
@@ -325,6 +353,10 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
 int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
                         const float *center, const float *B, const float *Cc, float *dx, int64_t lddx,
                         int64_t rows, int32_t J, int32_t C, void *stream);
+int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                            const float *center, const float *B, const float *Cc, float *dx_hi, int64_t lddx,
+                            float *gact, int64_t ldga, const float *gadd, int64_t ldgadd,
+                            int64_t rows, int32_t J, int32_t C, void *stream);
 
 #ifdef __cplusplus
 }

@@ -19,6 +19,10 @@ SIGNATURES = {
     "sn_status_string": (C.c_char_p, [C.c_int]),
     "sn_spmm_csr_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
     "sn_spmm_bsr4_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "sn_spmm_csr_elubwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64,
+                                         _i32, _vp]),
+    "sn_spmm_bsr4_elubwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64,
+                                          _i32, _vp]),
     "sn_coo_to_csr_i32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "sn_csr_transpose_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "sn_csr_transpose_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -48,6 +52,8 @@ SIGNATURES = {
     "sn_laplacian_csr_from_mesh": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sn_linear_fwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
     "sn_linear_dgrad_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "sn_linear_dgrad_elu_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64,
+                                          _i32, _i32, _vp]),
     "sn_affine_cols_acc_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
 }
 

@@ -93,39 +93,36 @@ class _DiracBlock(torch.autograd.Function):
         none9 = (None,) * 9
         if g_vnew is None and g_fout is None:
             return (None,) * 24
+        # Every ELU backward of the block is fused: the dgrad GEMM's epilogue sends the first half of a stage's input
+        # gradient through the activation (h = dx[:, :C]·elu'(e) + the gradient of the other branch), and the transposed
+        # product's store does the same for the propagated half:  (opᵀ·dx[:, C:])·elu'(e) + h.
         # ---- second stage (vertex rows) ----
         g_fo = g_fout.contiguous() if g_fout is not None else None
         gp1 = none9
-        dx1 = None
+        h1 = None                                                                   # dx1[:, :C]·elu'(e_v) + g_vnew
         if g_vnew is not None:
             g_vnew = g_vnew.contiguous()
-            dx1, dg1, db1, dW1, dc1 = bnlin_backward(st1, g_vnew)                 # gradient w.r.t. cat1
+            (dx1_hi, h1), dg1, db1, dW1, dc1 = bnlin_backward(st1, g_vnew, through_elu=(g_vnew,))
             gp1 = (dg1, db1, dW1, dc1, None, None, None, None, None)
-            g_ef = torch.empty((nxt_f.shape[0], C), dtype=torch.float32, device=dev)
-            _launch(opDiA.t(), dx1[:, C:], g_ef, 4, "bwd")
-            g_sum = torch.empty_like(g_ef)
-            # (DiA^T·g) * elu'(e_f)  +  the gradient f_out receives from the next block, in one pass
-            kernels.elu_bwd(g_ef, nxt_f[:, :C], g_sum, False, None, g_fo)
+            g_sum = torch.empty((nxt_f.shape[0], C), dtype=torch.float32, device=dev)
+            # (DiA^T·dx1_hi)·elu'(e_f)  +  the gradient f_out receives from the next block
+            _launch(opDiA.t(), dx1_hi, g_sum, 4, "bwd", elubwd=(nxt_f[:, :C], g_fo))
             g_fo = g_sum
         # ---- first stage (face rows) ----
         gp0 = none9
         g_v = g_f = None
-        dx0 = None
+        dx0_hi = None
         if g_fo is not None:
-            dx0, dg0, db0, dW0, dc0 = bnlin_backward(st0, g_fo)                   # gradient w.r.t. cat0
+            (dx0_hi, g_f), dg0, db0, dW0, dc0 = bnlin_backward(st0, g_fo, through_elu=(None,))   # g_f = dx0[:, :C]·elu'(e_f)
             gp0 = (dg0, db0, dW0, dc0, None, None, None, None, None)
-            if ctx.needs_input_grad[1]:
-                g_f = torch.empty((cat0.shape[0], C), dtype=torch.float32, device=dev)
-                kernels.elu_bwd(dx0[:, :C], cat0[:, :C], g_f, False)
         if ctx.needs_input_grad[0]:
-            g_ev = torch.empty((cat1.shape[0], C), dtype=torch.float32, device=dev)
-            if dx0 is not None:
-                _launch(opDi.t(), dx0[:, C:], g_ev, 4, "bwd")
+            if dx0_hi is not None:
+                g_v = torch.empty((cat1.shape[0], C), dtype=torch.float32, device=dev)
+                _launch(opDi.t(), dx0_hi, g_v, 4, "bwd", elubwd=(cat1[:, :C], h1))   # (Di^T·dx0_hi)·elu'(e_v) + h1
             else:
-                g_ev.zero_()
-            g_v = torch.empty_like(g_ev)
-            # (Di^T·g + g_cat1[:, :C]) * elu'(e_v) + residual-path gradient, in one pass
-            kernels.elu_bwd(g_ev, cat1[:, :C], g_v, False, dx1[:, :C] if dx1 is not None else None, g_vnew)
+                g_v = h1
+        if not ctx.needs_input_grad[1]:
+            g_f = None
         return (g_v, g_f, None, None, None, None) + gp0 + gp1
 
 
@@ -182,22 +179,24 @@ class _PropagateBlock(torch.autograd.Function):
         C = cat_a.shape[1] // 2
         g_out = g_out.contiguous()
 
-        def back_propagate(dcat, cat, gadd):
-            """gradient w.r.t. the stage input: ((dcat[:, :C] + P^T dcat[:, C:]) * elu'(e)) + gadd."""
-            g = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
-            if op is not None:
-                g_e = torch.empty_like(g)
-                _launch(op.t(), dcat[:, C:], g_e, 1, "bwd")
-                kernels.elu_bwd(g_e, cat[:, :C], g, False, dcat[:, :C], gadd)
-            else:
+        def stage_backward(st, g_in, cat, gadd):
+            """gradient w.r.t. the stage input: ((dcat[:, :C] + P^T dcat[:, C:]) * elu'(e)) + gadd, and the parameter
+            gradients of the stage's BatchNorm+Linear."""
+            if op is not None:                       # sparse propagation: both ELU backward passes fused (see _DiracBlock)
+                (d_hi, h), dg, db, dW, dc = bnlin_backward(st, g_in, through_elu=(gadd,))
+                g = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
+                _launch(op.t(), d_hi, g, 1, "bwd", elubwd=(cat[:, :C], h))
+            else:                                    # global average: per-mesh column sums of dcat[:, C:], broadcast back
+                dcat, dg, db, dW, dc = bnlin_backward(st, g_in)
+                g = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
                 gm = (kernels.segment_colsum(dcat[:, C:], None, per, nseg) * inv_count).contiguous()
                 kernels.elu_bwd_bcast(dcat[:, :C], cat[:, :C], gm, mask_rows, g, per, gadd)
-            return g
+            return g, dg, db, dW, dc
 
-        dxb, dg1, db1, dW1, dc1 = bnlin_backward(st1, g_out)
-        g_h = back_propagate(dxb, cat_b, None)
-        dxa, dg0, db0, dW0, dc0 = bnlin_backward(st0, g_h)
-        g_x = back_propagate(dxa, cat_a, g_out) if ctx.needs_input_grad[0] else None     # + residual-path gradient
+        g_h, dg1, db1, dW1, dc1 = stage_backward(st1, g_out, cat_b, None)
+        g_x, dg0, db0, dW0, dc0 = stage_backward(st0, g_h, cat_a, g_out)              # + residual-path gradient
+        if not ctx.needs_input_grad[0]:
+            g_x = None
         return (g_x, None, None, None, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None,
                 None, None, None, None)
 

@@ -35,14 +35,19 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // exponential (v_exp_f32) instead of the ~30-instruction expm1f: |error| <= 1.2e-7 absolute, far below the 1e-5 parity bar.
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 
-enum { EPI_FWD = 0, EPI_DGRAD = 1 };
+enum { EPI_FWD = 0, EPI_DGRAD = 1, EPI_DGRAD_ELU = 2 };
 
 struct EpiArgs {
-  // forward: bias[Nout], residual (rows x Nout, ldr) | NULL, y_elu (rows x Nout, lde) | NULL
-  // dgrad  : x (rows x Nout, ldx2), center / B / Cc [Nout] (B == NULL: plain product)
+  // forward  : v0 bias[Nout], v1 residual (rows x Nout, ld1) | NULL, o2 y_elu (rows x Nout, ld2) | NULL
+  // dgrad    : v0 x (rows x Nout, ld1), v1 / v2 / v3 center / B / Cc [Nout] (B == NULL: plain product)
+  // dgrad+elu: as dgrad (B required); columns c < half leave as  o2[r][c] = dx·elu'(x[r][c]) + v4[r][c]  (o2: ld2, v4: ld3,
+  //            v4 may be NULL) instead of Out[r][c]; columns >= half go to Out as usual
   const float *v0, *v1, *v2, *v3;
   float *o2;
   int64_t ld1, ld2;
+  const float *v4;
+  int64_t ld3;
+  int half;
 };
 
 template <int K, int NT, bool TRANSW, int EPI>
@@ -310,6 +315,9 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
   const int erow = lane / CPR;
   const int ecol = 32 * NT * wave + 4 * (lane % CPR);
   f4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, k2 = k0;
+  constexpr bool DGE = (EPI == EPI_DGRAD_ELU);
+  static_assert(!DGE || SIDE, "the ELU variant needs the BatchNorm tail operand");
+  const bool lowhalf = DGE && ecol < ep.half;                                        // wave-uniform
   if constexpr (EPI == EPI_FWD) {
     k0 = *reinterpret_cast<const f4 *>(ep.v0 + ecol);                                // bias
   } else if constexpr (SIDE) {
@@ -360,6 +368,20 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
         sd[j] = *reinterpret_cast<const f4 *>(side_p + r * ep.ld1 + ecol);
       }
     }
+    f4 ga[NST];                        // dgrad+elu, low half: the gradient added after the activation derivative
+    if constexpr (DGE) {
+      if (lowhalf && ep.v4) {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+          int64_t r = tl * 32 + erow + RPI * j;
+          r = r < rows ? r : rows - 1;
+          ga[j] = *reinterpret_cast<const f4 *>(ep.v4 + r * ep.ld3 + ecol);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) ga[j] = f4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
     // three accumulators per output tile (leading products | two sets of correction products), visited so that no two
     // consecutive MFMAs write the same one
     f16v acc0[NT], acc1[NT], acc2[NT];
@@ -384,14 +406,26 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
         convert_chunk(buf ^ 1, i);
         load_chunk(tl2, i);
       }
+      if constexpr (NT == 1) {
+        acc1[0] = mfma_bf16(wl[0][ks], dh, acc1[0]);
+        acc2[0] = mfma_bf16(wh[0][ks], dl, acc2[0]);
+        acc1[0] = mfma_bf16(wm[0][ks], dm, acc1[0]);
+        acc0[0] = mfma_bf16(wh[0][ks], dh, acc0[0]);
+        acc1[0] = mfma_bf16(wm[0][ks], dh, acc1[0]);
+        acc2[0] = mfma_bf16(wh[0][ks], dm, acc2[0]);
+      } else {                         // several tiles: product-outer, tile-inner — two accumulators per tile are enough
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        acc1[t] = mfma_bf16(wl[t][ks], dh, acc1[t]);
-        acc2[t] = mfma_bf16(wh[t][ks], dl, acc2[t]);
-        acc1[t] = mfma_bf16(wm[t][ks], dm, acc1[t]);
-        acc0[t] = mfma_bf16(wh[t][ks], dh, acc0[t]);
-        acc1[t] = mfma_bf16(wm[t][ks], dh, acc1[t]);
-        acc2[t] = mfma_bf16(wh[t][ks], dm, acc2[t]);
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wl[t][ks], dh, acc1[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wh[t][ks], dl, acc1[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wm[t][ks], dm, acc1[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc0[t] = mfma_bf16(wh[t][ks], dh, acc0[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wm[t][ks], dh, acc1[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wh[t][ks], dm, acc1[t]);
       }
       if constexpr (ks + 1 < KS) {
         dh = nh; dm = nm; dl = nl;
@@ -415,14 +449,23 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
       if constexpr (EPI == EPI_FWD) {
         v += k0;
         if constexpr (SIDE) v += sd[j];
-      } else if constexpr (SIDE) {
+      } else if constexpr (SIDE) {            // dgrad (both forms): BatchNorm tail
         const f4 xv = sd[j] - k0;
         v.x += __builtin_fmaf(xv.x, k1.x, k2.x);
         v.y += __builtin_fmaf(xv.y, k1.y, k2.y);
         v.z += __builtin_fmaf(xv.z, k1.z, k2.z);
         v.w += __builtin_fmaf(xv.w, k1.w, k2.w);
       }
-      if (r < rows) {
+      if constexpr (DGE) {
+        if (lowhalf) {                   // through the activation: elu'(.) from the activation OUTPUT held in the side operand
+          const f4 o = sd[j];
+          v = f4{v.x * (o.x > 0.f ? 1.f : o.x + 1.f), v.y * (o.y > 0.f ? 1.f : o.y + 1.f),
+                 v.z * (o.z > 0.f ? 1.f : o.z + 1.f), v.w * (o.w > 0.f ? 1.f : o.w + 1.f)} + ga[j];
+          if (r < rows) *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = v;
+        } else if (r < rows) {
+          *reinterpret_cast<f4 *>(Out + r * ldo + ecol) = v;
+        }
+      } else if (r < rows) {
         *reinterpret_cast<f4 *>(Out + r * ldo + ecol) = v;
         if constexpr (EPI == EPI_FWD && ELU)
           *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
@@ -467,7 +510,7 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
   if (!aligned16(x) || !aligned16(W) || !aligned16(bias) || !aligned16(y) || (ldx % 4) || (ldw % 4) || (ldy % 4) ||
       (residual && (!aligned16(residual) || (ldr % 4) || ldr < J)) || (y_elu && (!aligned16(y_elu) || (lde % 4) || lde < J)))
     return SN_E_ALIGN;
-  EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde};
+  EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
   const bool x3 = gemm_variant() != 0;
@@ -505,7 +548,7 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx) || (lddy % 4) || (ldw % 4) || (lddx % 4)) return SN_E_ALIGN;
   if (B && (!aligned16(x) || !aligned16(B) || !aligned16(Cc) || (center && !aligned16(center)) || (ldx % 4) || ldx < C))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0};
+  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
   const bool x3 = gemm_variant() != 0;
@@ -521,6 +564,32 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
     hipLaunchKernelGGL((gemm_rows_x3_k<128, 1, true, EPI_DGRAD, false, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
   else
     hipLaunchKernelGGL((gemm_rows_k<128, 1, true, EPI_DGRAD>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
+  return launch_status();
+}
+
+int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                            const float *center, const float *B, const float *Cc, float *dx_hi, int64_t lddx, float *gact,
+                            int64_t ldga, const float *gadd, int64_t ldgadd, int64_t rows, int32_t J, int32_t C,
+                            void *stream) {
+  if (rows < 0 || J < 1 || C < 2 || lddy < J || ldw < C || lddx < C / 2 || ldga < C / 2 || ldx < C) return SN_E_SHAPE;
+  if (J != 128 || (C != 128 && C != 256) || gemm_variant() == 0) return SN_E_UNSUPPORTED;
+  if (rows == 0) return SN_OK;
+  if (!dy || !W || !dx_hi || !gact || !x || !B || !Cc) return SN_E_NULL;
+  if (!aligned16(dy) || !aligned16(W) || !aligned16(dx_hi) || !aligned16(gact) || !aligned16(x) || !aligned16(B) ||
+      !aligned16(Cc) || (center && !aligned16(center)) || (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C / 2)) ||
+      (lddy % 4) || (ldw % 4) || (lddx % 4) || (ldga % 4) || (ldx % 4))
+    return SN_E_ALIGN;
+  const int half = C / 2;
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half};
+  float *out = dx_hi - half;           // the kernel indexes absolute columns; only columns >= half are written through `out`
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned grid = gemm_grid(rows);
+  if (C == 256)
+    hipLaunchKernelGGL((gemm_rows_x3_k<128, 2, true, EPI_DGRAD_ELU, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, out,
+                       lddx, rows, ep);
+  else
+    hipLaunchKernelGGL((gemm_rows_x3_k<128, 1, true, EPI_DGRAD_ELU, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, out,
+                       lddx, rows, ep);
   return launch_status();
 }
 

@@ -40,6 +40,7 @@ __device__ __forceinline__ void st4_stream(float *p, f4 v) {
   __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
 }
 // streaming (non-temporal) forms for data that is touched once per kernel: measured +15-30 % on 1:1 copy-like passes
+constexpr int kStreamNT = 1;   // streamed-once operands use non-temporal loads/stores
 __device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
   return nt ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p);
 }
@@ -115,6 +116,20 @@ __global__ __launch_bounds__(kWG) void spmm_csr_v4(const int *__restrict__ rowpt
   }
 }
 
+// Optional fused epilogue of the LDS SpMM kernels (the backward of an ELU-activated propagation stage):
+//     Y = (A·X) ∘ elu'(E) + G,    elu'(·) through the activation OUTPUT E: 1 where E > 0, E + 1 elsewhere,
+// E and G laid out and addressed like Y (same row grouping, own leading dimensions); G may be NULL.  e == NULL: plain product.
+struct SpmmEpi {
+  const float *e;
+  int64_t lde;
+  const float *g;
+  int64_t ldg;
+};
+__device__ __forceinline__ f4 elu_bwd4(const f4 &a, const f4 &o) {
+  return f4{a.x * (o.x > 0.f ? 1.f : o.x + 1.f), a.y * (o.y > 0.f ? 1.f : o.y + 1.f), a.z * (o.z > 0.f ? 1.f : o.z + 1.f),
+            a.w * (o.w > 0.f ? 1.f : o.w + 1.f)};
+}
+
 // ------------------------------------------------------------------------------------------------
 // CSR SpMM with the operator entries of each wave pass staged through LDS.
 //
@@ -124,11 +139,11 @@ __global__ __launch_bounds__(kWG) void spmm_csr_v4(const int *__restrict__ rowpt
 // slice with two coalesced 4-byte-per-lane DMA loads per 64 entries, and lane groups read their entries back with
 // broadcast ds_reads.  Same arithmetic order as spmm_csr_v4 (k-ascending FMA chain), so results are bit-identical.
 // ------------------------------------------------------------------------------------------------
-template <int N, int XG, int YG>
-__global__ __launch_bounds__(kWG) void spmm_csr_lds(const int *__restrict__ rowptr, const int *__restrict__ colind,
-                                                    const float *__restrict__ vals, int M,
-                                                    const float *__restrict__ X, int64_t ldx,
-                                                    float *__restrict__ Y, int64_t ldy, int nchunks) {
+template <int N, int XG, int YG, bool EPI>
+__device__ __forceinline__ void spmm_csr_lds_body(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                  const float *__restrict__ vals, int M,
+                                                  const float *__restrict__ X, int64_t ldx,
+                                                  float *__restrict__ Y, int64_t ldy, int nchunks, SpmmEpi epi) {
   constexpr int LPR = N / 4;          // lanes per row
   constexpr int P = 64 / LPR;         // rows per wave
   constexpr int WAVES = kWG / 64;
@@ -181,8 +196,28 @@ __global__ __launch_bounds__(kWG) void spmm_csr_lds(const int *__restrict__ rowp
       }
       __builtin_amdgcn_wave_barrier();
     }
+    if constexpr (EPI) {
+      if (r < M) {
+        acc = elu_bwd4(acc, ld4_s(epi.e + row_off<YG, N>(r, epi.lde) + sub * 4, kStreamNT));
+        if (epi.g) acc += ld4_s(epi.g + row_off<YG, N>(r, epi.ldg) + sub * 4, kStreamNT);
+      }
+    }
     if (r < M) st4_stream(Y + row_off<YG, N>(r, ldy) + sub * 4, acc);
   }
+}
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) void spmm_csr_lds(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                    const float *__restrict__ vals, int M,
+                                                    const float *__restrict__ X, int64_t ldx,
+                                                    float *__restrict__ Y, int64_t ldy, int nchunks) {
+  spmm_csr_lds_body<N, XG, YG, false>(rowptr, colind, vals, M, X, ldx, Y, ldy, nchunks, SpmmEpi{nullptr, 0, nullptr, 0});
+}
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) void spmm_csr_lds_epi(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                        const float *__restrict__ vals, int M,
+                                                        const float *__restrict__ X, int64_t ldx,
+                                                        float *__restrict__ Y, int64_t ldy, int nchunks, SpmmEpi epi) {
+  spmm_csr_lds_body<N, XG, YG, true>(rowptr, colind, vals, M, X, ldx, Y, ldy, nchunks, epi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -241,12 +276,12 @@ __global__ __launch_bounds__(kWG) void spmm_bsr4_v4(const int *__restrict__ b_ro
 // loads, and the lane groups then read their blocks back with broadcast ds_read_b128.  Waves stay
 // independent (no workgroup barrier): DS operations of one wave complete in order.
 // ------------------------------------------------------------------------------------------------
-template <int N, int XG, int YG>
-__global__ __launch_bounds__(kWG) void spmm_bsr4_lds(const int *__restrict__ b_rowptr,
-                                                     const int *__restrict__ b_colind,
-                                                     const float *__restrict__ b_vals, int Mb,
-                                                     const float *__restrict__ X, int64_t ldx,
-                                                     float *__restrict__ Y, int64_t ldy, int nchunks) {
+template <int N, int XG, int YG, bool EPI>
+__device__ __forceinline__ void spmm_bsr4_lds_body(const int *__restrict__ b_rowptr,
+                                                   const int *__restrict__ b_colind,
+                                                   const float *__restrict__ b_vals, int Mb,
+                                                   const float *__restrict__ X, int64_t ldx,
+                                                   float *__restrict__ Y, int64_t ldy, int nchunks, SpmmEpi epi) {
   constexpr int LPR = N / 4;          // lanes per block row
   constexpr int RPW = 64 / LPR;       // block rows per wave pass
   constexpr int WAVES = kWG / 64;
@@ -301,6 +336,21 @@ __global__ __launch_bounds__(kWG) void spmm_bsr4_lds(const int *__restrict__ b_r
       }
       __builtin_amdgcn_wave_barrier();          // all reads of this tile done before it is overwritten
     }
+    if constexpr (EPI) {
+      if (br < Mb) {                  // operands read here, not before the loop: the plain kernel's register budget stays
+        const int64_t eq = (YG == 4) ? epi.lde : 4 * epi.lde, es = (YG == 4) ? (int64_t)N : epi.lde;
+        const float *ep = epi.e + (int64_t)br * eq + sub * 4;
+        const f4 e0 = ld4_s(ep, kStreamNT), e1 = ld4_s(ep + es, kStreamNT), e2 = ld4_s(ep + 2 * es, kStreamNT),
+                 e3 = ld4_s(ep + 3 * es, kStreamNT);
+        acc0 = elu_bwd4(acc0, e0); acc1 = elu_bwd4(acc1, e1); acc2 = elu_bwd4(acc2, e2); acc3 = elu_bwd4(acc3, e3);
+        if (epi.g) {
+          const int64_t gq = (YG == 4) ? epi.ldg : 4 * epi.ldg, gs = (YG == 4) ? (int64_t)N : epi.ldg;
+          const float *gp = epi.g + (int64_t)br * gq + sub * 4;
+          acc0 += ld4_s(gp, kStreamNT); acc1 += ld4_s(gp + gs, kStreamNT);
+          acc2 += ld4_s(gp + 2 * gs, kStreamNT); acc3 += ld4_s(gp + 3 * gs, kStreamNT);
+        }
+      }
+    }
     if (br < Mb) {
       float *yp = Y + (int64_t)br * yq + sub * 4;
       st4_stream(yp, acc0);
@@ -309,6 +359,24 @@ __global__ __launch_bounds__(kWG) void spmm_bsr4_lds(const int *__restrict__ b_r
       st4_stream(yp + 3 * ys, acc3);
     }
   }
+}
+// Four waves per SIMD (= 4 workgroups per CU), on purpose: left alone the compiler fits the kernel into 80 VGPRs and 6
+// workgroups per CU, whose larger combined working set re-reads 15-20 % of X from HBM on the vertex-row products
+// (PMC TCC_EA0_RDREQ: 519 MB against the compulsory 451 MB).
+#define SN_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_bsr4_lds(const int *__restrict__ b_rowptr, const int *__restrict__ b_colind,
+                                                     const float *__restrict__ b_vals, int Mb,
+                                                     const float *__restrict__ X, int64_t ldx,
+                                                     float *__restrict__ Y, int64_t ldy, int nchunks) {
+  spmm_bsr4_lds_body<N, XG, YG, false>(b_rowptr, b_colind, b_vals, Mb, X, ldx, Y, ldy, nchunks, SpmmEpi{nullptr, 0, nullptr, 0});
+}
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_bsr4_lds_epi(const int *__restrict__ b_rowptr, const int *__restrict__ b_colind,
+                                                         const float *__restrict__ b_vals, int Mb,
+                                                         const float *__restrict__ X, int64_t ldx,
+                                                         float *__restrict__ Y, int64_t ldy, int nchunks, SpmmEpi epi) {
+  spmm_bsr4_lds_body<N, XG, YG, true>(b_rowptr, b_colind, b_vals, Mb, X, ldx, Y, ldy, nchunks, epi);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -666,8 +734,7 @@ inline int env_int(const char *name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 // Elementwise passes: one 16-byte item per thread and as many workgroups as that takes (measured faster than a capped
-// grid-stride loop: 6.5 vs 4.9 TB/s on a 1 GiB copy, tools/scratch/copybench.hip), non-temporal loads/stores.
-constexpr int kStreamNT = 1;
+// grid-stride loop: 6.5 vs 4.9 TB/s on a 1 GiB copy, tools/scratch/copybench.hip), non-temporal loads/stores (kStreamNT).
 inline unsigned grid_for(int64_t work_items, int per_block) {
   int64_t b = (work_items + per_block - 1) / per_block;
   if (b < 1) b = 1;
@@ -788,9 +855,9 @@ const char *sn_status_string(int status) {
   return "unknown sn status";
 }
 
-int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M,
-                    int64_t K, int64_t nnz, const float *X, int64_t ldx, int32_t x_group, int32_t N,
-                    float *Y, int64_t ldy, int32_t y_group, void *stream) {
+static int spmm_csr_launch(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
+                           int64_t nnz, const float *X, int64_t ldx, int32_t x_group, int32_t N, float *Y, int64_t ldy,
+                           int32_t y_group, SpmmEpi epi, void *stream) {
   if (M < 0 || K < 0 || nnz < 0 || N < 1) return SN_E_SHAPE;
   if (!fits_i32(M + 1) || !fits_i32(K) || !fits_i32(nnz)) return SN_E_RANGE;
   if (M == 0) return SN_OK;
@@ -802,15 +869,24 @@ int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *v
     if (st) return st;
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipEvent_t t_start, t_stop;
-  timing_slot(0, M, K, nnz, N, &t_start, &t_stop);
   const bool vec = (N == 16 || N == 32 || N == 64 || N == 128) && aligned16(X) && aligned16(Y) &&
                    (ldx % 4 == 0) && (ldy % 4 == 0);
+  if (epi.e) {                         // fused epilogue: vector kernels only, operands like Y
+    if (!vec) return SN_E_UNSUPPORTED;
+    st = check_dense(epi.e, epi.lde, y_group, N);
+    if (!st && epi.g) st = check_dense(epi.g, epi.ldg, y_group, N);
+    if (st) return st;
+    if (!aligned16(epi.e) || epi.lde % 4 || (epi.g && (!aligned16(epi.g) || epi.ldg % 4))) return SN_E_ALIGN;
+  }
+  hipEvent_t t_start, t_stop;
+  timing_slot(0 | (epi.e ? 2 : 0) | (epi.g ? 4 : 0), M, K, nnz, N, &t_start, &t_stop);
   if (vec) {
     const int rpb = kWG / (N / 4);
     const int64_t nchunks = (M + rpb - 1) / rpb;
     const unsigned grid = chunk_grid(nchunks);
-    if (tune_csr_variant() == 0)
+    if (epi.e)
+      SN_DISPATCH_N(spmm_csr_lds_epi, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, epi);
+    else if (tune_csr_variant() == 0)
       SN_DISPATCH_N(spmm_csr_v4, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks);
     else
       SN_DISPATCH_N(spmm_csr_lds, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks);
@@ -821,9 +897,24 @@ int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *v
   return launch_status();
 }
 
-int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb,
-                     int64_t Kb, int64_t nblocks, const float *X, int64_t ldx, int32_t x_group,
-                     int32_t N, float *Y, int64_t ldy, int32_t y_group, void *stream) {
+int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M,
+                    int64_t K, int64_t nnz, const float *X, int64_t ldx, int32_t x_group, int32_t N,
+                    float *Y, int64_t ldy, int32_t y_group, void *stream) {
+  return spmm_csr_launch(rowptr, colind, vals, M, K, nnz, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{nullptr, 0, nullptr, 0},
+                         stream);
+}
+
+int sn_spmm_csr_elubwd_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
+                           int64_t nnz, const float *X, int64_t ldx, int32_t x_group, int32_t N, const float *E,
+                           int64_t lde, const float *G, int64_t ldg, float *Y, int64_t ldy, int32_t y_group,
+                           void *stream) {
+  if (!E) return SN_E_NULL;
+  return spmm_csr_launch(rowptr, colind, vals, M, K, nnz, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{E, lde, G, ldg}, stream);
+}
+
+static int spmm_bsr4_launch(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb, int64_t Kb,
+                            int64_t nblocks, const float *X, int64_t ldx, int32_t x_group, int32_t N, float *Y,
+                            int64_t ldy, int32_t y_group, SpmmEpi epi, void *stream) {
   if (Mb < 0 || Kb < 0 || nblocks < 0 || N < 1) return SN_E_SHAPE;
   if (!fits_i32(4 * Mb + 1) || !fits_i32(4 * Kb) || !fits_i32(nblocks)) return SN_E_RANGE;
   if (Mb == 0) return SN_OK;
@@ -836,17 +927,41 @@ int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const flo
   }
   if (!(N == 16 || N == 32 || N == 64 || N == 128)) return SN_E_UNSUPPORTED;
   if (!aligned16(X) || !aligned16(Y) || !aligned16(b_vals) || ldx % 4 || ldy % 4) return SN_E_ALIGN;
+  if (epi.e) {
+    st = check_dense(epi.e, epi.lde, y_group, N);
+    if (!st && epi.g) st = check_dense(epi.g, epi.ldg, y_group, N);
+    if (st) return st;
+    if (!aligned16(epi.e) || epi.lde % 4 || (epi.g && (!aligned16(epi.g) || epi.ldg % 4))) return SN_E_ALIGN;
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipEvent_t t_start, t_stop;
-  timing_slot(1, 4 * Mb, 4 * Kb, nblocks, N, &t_start, &t_stop);
+  timing_slot(1 | (epi.e ? 2 : 0) | (epi.g ? 4 : 0), 4 * Mb, 4 * Kb, nblocks, N, &t_start, &t_stop);
   const int rpb = kWG / (N / 4);
   const int64_t nchunks = (Mb + rpb - 1) / rpb;
   const unsigned grid = chunk_grid(nchunks);
-  if (tune_bsr4_variant() == 0)
+  if (epi.e)
+    SN_DISPATCH_N(spmm_bsr4_lds_epi, N, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks, epi);
+  else if (tune_bsr4_variant() == 0)
     SN_DISPATCH_N(spmm_bsr4_v4, N, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks);
   else
     SN_DISPATCH_N(spmm_bsr4_lds, N, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks);
   return launch_status();
+}
+
+int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb,
+                     int64_t Kb, int64_t nblocks, const float *X, int64_t ldx, int32_t x_group,
+                     int32_t N, float *Y, int64_t ldy, int32_t y_group, void *stream) {
+  return spmm_bsr4_launch(b_rowptr, b_colind, b_vals, Mb, Kb, nblocks, X, ldx, x_group, N, Y, ldy, y_group,
+                          SpmmEpi{nullptr, 0, nullptr, 0}, stream);
+}
+
+int sn_spmm_bsr4_elubwd_f32(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb, int64_t Kb,
+                            int64_t nblocks, const float *X, int64_t ldx, int32_t x_group, int32_t N, const float *E,
+                            int64_t lde, const float *G, int64_t ldg, float *Y, int64_t ldy, int32_t y_group,
+                            void *stream) {
+  if (!E) return SN_E_NULL;
+  return spmm_bsr4_launch(b_rowptr, b_colind, b_vals, Mb, Kb, nblocks, X, ldx, x_group, N, Y, ldy, y_group,
+                          SpmmEpi{E, lde, G, ldg}, stream);
 }
 
 int sn_coo_to_csr_i32(const int64_t *idx_batch, const int64_t *idx_row, const int64_t *idx_col,

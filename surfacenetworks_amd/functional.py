@@ -60,7 +60,8 @@ class SpmmTimer:
         _lib.call("sn_timing_enable", 0)
 
     def results(self):
-        """[(tag, M, K, nnz, N, milliseconds)] for every launch recorded while the timer was active."""
+        """[(tag, M, K, nnz, N, milliseconds)] for every launch recorded while the timer was active; the tag ends in
+        /csr or /bsr4, then +e (fused ELU-backward epilogue: E read) and +g (G read too)."""
         import ctypes
         import numpy as np
 
@@ -77,7 +78,8 @@ class SpmmTimer:
         for i, (tag, op) in enumerate(self.tags):
             kind, M, K, _, N = meta[i]
             nnz = op if isinstance(op, int) else op.nnz
-            out.append((tag + ("/bsr4" if kind == 1 else "/csr"), int(M), int(K), int(nnz), int(N), float(ms[i])))
+            fmt = ("/bsr4" if kind & 1 else "/csr") + ("+e" if kind & 2 else "") + ("+g" if kind & 4 else "")
+            out.append((tag + fmt, int(M), int(K), int(nnz), int(N), float(ms[i])))
         return out
 
 
@@ -88,8 +90,9 @@ def _ctypes_i64_ref():
     return ctypes.addressof(_ctypes_i64_ref.slot)
 
 
-def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, tag: str = "") -> None:
-    """y <- op·x with the best resident format of `op`."""
+def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, tag: str = "", elubwd=None) -> None:
+    """y <- op·x with the best resident format of `op`.  elubwd = (e, g): y <- (op·x) * elu'(e) + g fused into the store
+    (the backward of an ELU-activated propagation stage; g may be None)."""
     M, K = op.shape
     timer = SpmmTimer.active
     if timer is not None:
@@ -97,9 +100,14 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
         timer.tags.append((tag, op if known is None else known))
     b = op.bsr4() if (_USE_BSR4 and group == 4) else None
     if b is not None:
-        kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
-    else:
+        if elubwd is None:
+            kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
+        else:
+            kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, x, elubwd[0], elubwd[1], y, group)
+    elif elubwd is None:
         kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x, y, group)
+    else:
+        kernels.spmm_csr_elubwd(op.rowptr, op.colind, op.vals, M, K, x, elubwd[0], elubwd[1], y, group)
 
 
 def _rows2d(x: torch.Tensor) -> torch.Tensor:
@@ -313,10 +321,14 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     return y, (x, W, Wf, s, mean, invstd, beta, training, b is not None)
 
 
-def bnlin_backward(state, dy, need_dx=True):
-    """Backward of bnlin_forward: G = dyᵀ·(x - mean) (split-K fp32-MFMA kernel) and colsum(dy) give every BatchNorm
+def bnlin_backward(state, dy, need_dx=True, through_elu=None):
+    """Backward of bnlin_forward: G = dyᵀ·(x - mean) (split-K MFMA kernel) and colsum(dy) give every BatchNorm
     reduction algebraically (sum_r dz = colsum(dy)·W, sum_r dz∘(x-mean) = sum_j W∘G); dx = dy·(W·diag(s)) + (x-mean)∘B + C
-    in ONE GEMM with the tail in its epilogue.  Returns (dx, dgamma, dbeta, dW, db)."""
+    in ONE GEMM with the tail in its epilogue.  Returns (dx, dgamma, dbeta, dW, db).
+
+    through_elu=(gadd,): x is a stage's concat buffer [e | P·e]; instead of dx the first element returned is the pair
+    (dx[:, C/2:],  dx[:, :C/2] * elu'(e) + gadd) — the operand of the transposed propagation and the gradient that has
+    already passed the activation (gadd may be None), produced by the GEMM epilogue when the fused kernel applies."""
     x, W, Wf, s, mean, invstd, beta, training, has_bias = state
     dy = dy.contiguous()
     rows, C = x.shape
@@ -328,13 +340,20 @@ def bnlin_backward(state, dy, need_dx=True):
         Gc, sdy = dy.t().mm(x - mean), kernels.colstats(dy)
     dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows, has_bias)
     dx = None
-    if need_dx:
+    if through_elu is not None and training and kernels.linear_dgrad_elu_supported(J, C):
+        dx = kernels.linear_dgrad_elu(dy, Wf, x, mean, Bc, Cc, through_elu[0])
+    elif need_dx or through_elu is not None:
         if kernels.linear_dgrad_supported(J, C):
             dx = kernels.linear_dgrad(dy, Wf, x, mean, Bc, Cc) if training else kernels.linear_dgrad(dy, Wf)
         else:
             dx = dy.mm(Wf)
             if training:
                 kernels.affine_cols_acc(dx, x, Bc, Cc, mean)
+        if through_elu is not None:                                  # unfused composition of the same result
+            h = C // 2
+            gact = torch.empty((rows, h), dtype=torch.float32, device=dx.device)
+            kernels.elu_bwd(dx[:, :h], x[:, :h], gact, False, None, through_elu[0])
+            dx = (dx[:, h:], gact)
     return dx, dgamma, dbeta, dW, db
 
 

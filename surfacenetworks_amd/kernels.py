@@ -12,10 +12,10 @@ import torch
 from . import _lib
 
 __all__ = [
-    "spmm_csr", "spmm_bsr4", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
+    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
-    "linear_dgrad_supported",
+    "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
 ]
 
 
@@ -68,6 +68,29 @@ def spmm_bsr4(b_rowptr, b_colind, b_vals, Mb: int, Kb: int, x, y, group: int = 1
     ldy = _check_dense(y, 4 * Mb, group, N, "y")
     _lib.call("sn_spmm_bsr4_f32", _p(b_rowptr), _p(b_colind), _p(b_vals), Mb, Kb, int(b_colind.numel()),
               _p(x), ldx, group, N, _p(y), ldy, group, _stream())
+
+
+def spmm_csr_elubwd(rowptr, colind, vals, M: int, K: int, x, e, g, y, group: int = 1) -> None:
+    """y <- (A·x) * elu'(e) + g with elu' taken from the activation output e (sn_spmm_csr_elubwd_f32); g may be None."""
+    _dev(rowptr, colind, vals, x, e, g, y)
+    N = y.shape[1] // group
+    ldx = _check_dense(x, K, group, N, "x")
+    ldy = _check_dense(y, M, group, N, "y")
+    lde = _check_dense(e, M, group, N, "e")
+    ldg = _check_dense(g, M, group, N, "g") if g is not None else 0
+    _lib.call("sn_spmm_csr_elubwd_f32", _p(rowptr), _p(colind), _p(vals), M, K, int(colind.numel()),
+              _p(x), ldx, group, N, _p(e), lde, _p(g), ldg, _p(y), ldy, group, _stream())
+
+
+def spmm_bsr4_elubwd(b_rowptr, b_colind, b_vals, Mb: int, Kb: int, x, e, g, y, group: int = 1) -> None:
+    _dev(b_rowptr, b_colind, b_vals, x, e, g, y)
+    N = y.shape[1] // group
+    ldx = _check_dense(x, 4 * Kb, group, N, "x")
+    ldy = _check_dense(y, 4 * Mb, group, N, "y")
+    lde = _check_dense(e, 4 * Mb, group, N, "e")
+    ldg = _check_dense(g, 4 * Mb, group, N, "g") if g is not None else 0
+    _lib.call("sn_spmm_bsr4_elubwd_f32", _p(b_rowptr), _p(b_colind), _p(b_vals), Mb, Kb, int(b_colind.numel()),
+              _p(x), ldx, group, N, _p(e), lde, _p(g), ldg, _p(y), ldy, group, _stream())
 
 
 def coo_to_csr(idx_batch, idx_row, idx_col, B: int, R: int, Kb: int):
@@ -309,6 +332,27 @@ def linear_fwd(x, W, bias, residual=None, y_elu=None):
 
 def linear_dgrad_supported(J: int, C: int) -> bool:
     return J == 128 and C in (128, 256)
+
+
+def linear_dgrad_elu_supported(J: int, C: int) -> bool:
+    """The fused form exists only in the split-bf16 kernels (SN_GEMM_VARIANT != 0)."""
+    import os
+
+    return J == 128 and C in (128, 256) and os.environ.get("SN_GEMM_VARIANT", "1") != "0"
+
+
+def linear_dgrad_elu(dy, W, x, center, B, Cc, gadd=None):
+    """Input gradient of the folded BatchNorm+Linear whose operand x is a stage's concat buffer [e | P·e]
+    (sn_linear_dgrad_elu_f32): returns (dx_hi, gact) with dx_hi = dx[:, C/2:] and gact = dx[:, :C/2] * elu'(e) + gadd."""
+    _dev(dy, W, x, center, B, Cc, gadd)
+    rows, J = dy.shape
+    C = W.shape[1]
+    h = C // 2
+    dx_hi = torch.empty((rows, h), dtype=torch.float32, device=dy.device)
+    gact = torch.empty((rows, h), dtype=torch.float32, device=dy.device)
+    _lib.call("sn_linear_dgrad_elu_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x), _p(center), _p(B), _p(Cc),
+              _p(dx_hi), h, _p(gact), h, _p(gadd), _ld(gadd) if gadd is not None else 0, rows, J, C, _stream())
+    return dx_hi, gact
 
 
 def linear_dgrad(dy, W, x=None, center=None, B=None, Cc=None):

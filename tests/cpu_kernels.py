@@ -38,6 +38,22 @@ def spmm_bsr4(b_rowptr, b_colind, b_vals, Mb, Kb, x, y, group=1):
     spmm_csr(torch.from_numpy(rowptr), torch.from_numpy(colind), torch.from_numpy(vals), 4 * Mb, 4 * Kb, x, y, group)
 
 
+def _elubwd_epilogue(y, e, g):
+    """y <- y * elu'(e) + g in place, through the C oracle's elu_bwd (same element-wise arithmetic as the fused store)."""
+    tmp = y.clone()
+    elu_bwd(tmp, e, y, False, None, g)
+
+
+def spmm_csr_elubwd(rowptr, colind, vals, M, K, x, e, g, y, group=1):
+    spmm_csr(rowptr, colind, vals, M, K, x, y, group)
+    _elubwd_epilogue(y, e, g)
+
+
+def spmm_bsr4_elubwd(b_rowptr, b_colind, b_vals, Mb, Kb, x, e, g, y, group=1):
+    spmm_bsr4(b_rowptr, b_colind, b_vals, Mb, Kb, x, y, group)
+    _elubwd_epilogue(y, e, g)
+
+
 def coo_to_csr(idx_batch, idx_row, idx_col, B, R, Kb):
     rp, ci = c_oracle.coo_to_csr(None if idx_batch is None else _np(idx_batch), _np(idx_row), _np(idx_col), B, R, Kb)
     return torch.from_numpy(rp), torch.from_numpy(ci)
@@ -186,6 +202,18 @@ def linear_dgrad(dy, W, x=None, center=None, B=None, Cc=None):
         xc = x if center is None else x - center
         dx = dx + torch.addcmul(Cc.expand_as(xc), xc, B.expand_as(xc))
     return dx
+
+
+def linear_dgrad_elu_supported(J, C):
+    return J == 128 and C in (128, 256)
+
+
+def linear_dgrad_elu(dy, W, x, center, B, Cc, gadd=None):
+    dx = linear_dgrad(dy, W, x, center, B, Cc)
+    h = W.shape[1] // 2
+    gact = torch.empty((dy.shape[0], h), dtype=torch.float32)
+    elu_bwd(dx[:, :h], x[:, :h], gact, False, None, gadd)
+    return dx[:, h:].contiguous(), gact
 
 
 def install(monkeypatch=None):

@@ -253,3 +253,23 @@ def test_split_bf16_is_as_accurate_as_an_fp32_fma_chain():
     err_lib = np.abs((dev(dy).t() @ dev(x)).cpu().numpy().astype(np.float64) - refg).max()
     err_k = np.abs(kernels.wgrad(dev(dy), dev(x)).cpu().numpy().astype(np.float64) - refg).max()
     assert err_k <= 3.0 * err_g and err_k <= err_lib
+
+
+@pytest.mark.parametrize("with_gadd", [True, False])
+@pytest.mark.parametrize("rows", [1, 33, 1000, 40001])
+@pytest.mark.parametrize("C", [128, 256])
+def test_linear_dgrad_through_elu(rows, C, with_gadd):
+    """sn_linear_dgrad_elu_f32 == sn_linear_dgrad_f32 followed by the ELU backward on the first half of the columns."""
+    rng = np.random.default_rng(rows + C)
+    J, h = 128, C // 2
+    dy = rng.standard_normal((rows, J)).astype(np.float32)
+    W = (rng.standard_normal((J, C)) / np.sqrt(J)).astype(np.float32)
+    x = rng.standard_normal((rows, C)).astype(np.float32)          # first half plays the activation output e
+    cen, B, Cc = [rng.standard_normal(C).astype(np.float32) for _ in range(3)]
+    gadd = rng.standard_normal((rows, h)).astype(np.float32) if with_gadd else None
+    full = kernels.linear_dgrad(dev(dy), dev(W), dev(x), dev(cen), dev(B), dev(Cc)).cpu().numpy()
+    f = np.where(x[:, :h] > 0, np.float32(1), x[:, :h] + np.float32(1)).astype(np.float32)
+    want_act = full[:, :h] * f + (gadd if with_gadd else 0)
+    dx_hi, gact = kernels.linear_dgrad_elu(dev(dy), dev(W), dev(x), dev(cen), dev(B), dev(Cc), dev(gadd) if with_gadd else None)
+    assert np.array_equal(dx_hi.cpu().numpy(), full[:, h:])        # the untouched half: same kernel arithmetic
+    assert np.allclose(gact.cpu().numpy(), want_act, rtol=1e-6, atol=1e-6)

@@ -297,3 +297,54 @@ def test_timing_facility_matches_event_bracketing():
     snF.spmm(op, x, 4)
     from surfacenetworks_amd import _lib
     assert _lib.load().sn_timing_count() == 0
+
+
+def _elubwd_want(prod, e, g):
+    """(A·x) * elu'(e) + g with the derivative expressed through the activation output, fp32 like the kernel."""
+    f = np.where(e > 0, np.float32(1), e + np.float32(1)).astype(np.float32)
+    out = prod * f
+    return out if g is None else out + g
+
+
+@pytest.mark.parametrize("with_g", [True, False])
+@pytest.mark.parametrize("N", [32, 128])
+@pytest.mark.parametrize("which", ["Di", "DiA"])
+def test_fused_elu_backward_epilogue_dirac(which, N, with_g):
+    """sn_spmm_*_elubwd_f32 == the plain product followed by the ELU backward, group-4 layout with E a strided half of a
+    concat buffer (the way blocks.py calls it); both formats."""
+    _, _, ops = mesh_fixture("cloth")
+    A = ops[which].T.tocsr()                                 # the backward multiplies by the transpose
+    A.sort_indices()
+    M, K = A.shape
+    C = 4 * N
+    rng = np.random.default_rng(7)
+    X = rng.standard_normal((K // 4, C)).astype(np.float32)
+    ecat = rng.standard_normal((M // 4, 2 * C)).astype(np.float32)
+    G = rng.standard_normal((M // 4, C)).astype(np.float32) if with_g else None
+    prod = c_oracle.spmm_csr(A.indptr, A.indices, A.data, X.ravel(), N).reshape(M // 4, C)
+    want = _elubwd_want(prod, ecat[:, :C], G)
+    rp, ci, va = csr_dev(A)
+    e_d, g_d = dev(ecat), (dev(G) if with_g else None)
+    y = torch.full((M // 4, C), float("nan"), device=DEV)
+    kernels.spmm_csr_elubwd(rp, ci, va, M, K, dev(X), e_d[:, :C], g_d, y, 4)
+    assert np.allclose(y.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    b = kernels.csr_to_bsr4(rp, ci, va, M, K)
+    y2 = torch.full((M // 4, C), float("nan"), device=DEV)
+    kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, dev(X), e_d[:, :C], g_d, y2, 4)
+    assert np.allclose(y2.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+    assert np.array_equal(y.cpu().numpy(), y2.cpu().numpy())          # the two formats agree bit for bit
+
+
+def test_fused_elu_backward_epilogue_laplacian():
+    _, _, ops = mesh_fixture("delaunay")
+    L = ops["L"].T.tocsr()
+    L.sort_indices()
+    V, N = L.shape[0], 128
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((V, N)).astype(np.float32)
+    ecat = rng.standard_normal((V, 2 * N)).astype(np.float32)
+    G = rng.standard_normal((V, N)).astype(np.float32)
+    want = _elubwd_want(c_oracle.spmm_csr(L.indptr, L.indices, L.data, X.ravel(), N).reshape(V, N), ecat[:, :N], G)
+    y = torch.empty((V, N), device=DEV)
+    kernels.spmm_csr_elubwd(*csr_dev(L), V, V, dev(X), dev(ecat)[:, :N], dev(G), y, 1)
+    assert np.allclose(y.cpu().numpy(), want, rtol=1e-6, atol=1e-6)

@@ -1,5 +1,5 @@
 """Launch sequence for PMC calibration (run under rocprofv3 --pmc ...): a streaming copy of known size, then the Dirac
-SpMM products of the config-3 batch, 10 launches each.  Prints the byte counts every launch should move."""
+SpMM products of the config-3 batch, 10 plain launches and 10 with the fused ELU-backward epilogue each.  Prints the byte counts every launch should move."""
 import os
 import sys
 
@@ -33,6 +33,10 @@ for name in ("Di", "DiA"):
         bb = o.bsr4()
         for _ in range(10):
             kernels.spmm_bsr4(bb[0], bb[1], bb[2], M // 4, K // 4, x, y, 4)
+        e = torch.randn(M // 4, 128, device=dev)
+        g = torch.randn(M // 4, 128, device=dev)
+        for _ in range(10):                          # fused ELU-backward epilogue: + E and G reads (M*32*4 bytes each)
+            kernels.spmm_bsr4_elubwd(bb[0], bb[1], bb[2], M // 4, K // 4, x, e, g, y, 4)
         rd = bb[1].numel() * 68 + (M // 4 + 1) * 4 + K * 32 * 4
         print(f"{name} {tag}: expected reads {rd} B (operator {bb[1].numel() * 68 + (M // 4 + 1) * 4} + X {K * 128}), writes {M * 128} B; "
               f"algorithmic CSR bytes {o.nnz * 8 + (M + 1) * 4 + K * 128 + M * 128}")
