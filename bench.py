@@ -245,7 +245,8 @@ def main():
                    "meshes_per_gpu": n_local, "global_batch": global_batch, "parallelism": f"dp{world} (mesh sharding, flat-bucket RCCL all-reduce)",
                    "allocator": alloc, "operator_format": args.format, "operators": args.operators,
                    "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager", "grad_bucket_bytes": bucket.nbytes},
-        "roofline": {"bound": "hbm", "kernel": dom_name + " (all Dirac products of the step: Di, DiA forward; Di^T, DiA^T backward)",
+        "roofline": {"bound": "hbm", "kernel": dom_name + (" (the backward products Di^T, DiA^T, ELU backward fused into the store)" if "_epi" in dom_name
+                                                          else " (the Dirac products launched without epilogue)"),
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
                      "traffic": traffic, "traffic_source": (f"profiles/r1_pmc_traffic_c3.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per launch; "
                                         f"mean over the {coverage:.0%} of the timed launches whose shape and epilogue were measured)") if traffic else None,
@@ -253,7 +254,11 @@ def main():
                      "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, " +
                                ("every launch of the timed steps" if args.no_graph else
                                 f"every launch of {max(1, args.roofline_steps)} eager steps run right after the timed hipGraph replays"),
-                     "launches_timed": len(dom), "spmm_ms_per_step_all_kernels": spmm_ms_per_step, "per_product": per_shape},
+                     "launches_timed": len(dom), "spmm_ms_per_step_all_kernels": spmm_ms_per_step, "per_product": per_shape,
+                     "other_spmm_kernels": [
+                         {"kernel": k, "launches": len(v), "avg_launch_ms": sum(r[5] for r in v) / len(v),
+                          "frac": sum(alg_bytes(r[1], r[2], r[3], r[4], r[0]) for r in v) / (sum(r[5] for r in v) * 1e-3) / HBM_PEAK}
+                         for k, v in by_kernel.items() if k != dom_name]},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(sample_meshes=4, seed=3)
