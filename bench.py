@@ -134,7 +134,7 @@ def main():
 
     def eager_step():
         batch = ds.sample_batch(n_local, rng, seq_ids=seq_ids)          # every local mesh once, random start frame
-        return arap.train_step(model, opt, batch, global_batch=global_batch, grad_sync=bucket.all_reduce)
+        return arap.train_step(model, opt, batch, global_batch=global_batch, grad_sync=bucket.all_reduce, zero_grads=bucket.zero_)
 
     graphed = None
 

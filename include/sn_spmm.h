@@ -259,6 +259,19 @@ int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W,
  *                         buffer (expand_as + contiguous + torch.cat in the reference).
  * sn_elu_bwd_bcast_f32  : gsrc[r,c] = (gdst[r,c] + mask[r] * bias[seg(r), c]) * elu'(out[r,c]) + gadd[r,c]: ELU backward
  *                         with the gradient of the mean path folded in (gadd: optional residual-path gradient).
+ *
+ * Half-width form of a global-average stage.  The second half of its concat buffer [e | mean(e) broadcast] is a per-mesh
+ * constant, so the stage needs only e: the BatchNorm statistics of the second half, its share of the Linear product (a
+ * per-mesh bias), of the weight gradient and of the input gradient are nseg x C algebra on the per-mesh mean m:
+ * sn_avg_fwd_prep_f32   : m = segsum * inv_count;  stats (2 x 2C fp64, the layout sn_bn_fold_f32 reads) = [stats1 |
+ *                         rows_per_seg * sum_mesh m, rows_per_seg * sum_mesh m^2]  (stats1 = sn_colstats_f32 of e).
+ * sn_seg_affine_f32     : out[g, j] = bias[j] + sum_c A[g, c] * W[j, c]  — the per-mesh bias  m·Wf[:, C:]^T + bf  consumed
+ *                         by sn_linear_fwd_segbias_f32.
+ * sn_avg_bwd_gc_f32     : Gc (J x 2C) = [ G1 | sum_mesh seg_dy[mesh]^T (m[mesh] - mu2) ]  (G1 = sn_wgrad_f32 of the first
+ *                         half, seg_dy = sn_segment_colsum_f32 of dy): the operand of sn_bn_bwd_coeffs_f32.
+ * sn_avg_bwd_segvec_f32 : v[mesh, c] = inv_count[mesh] * ( seg_dy[mesh]·Wf2[:, c] + rows_per_seg * ((m[mesh,c] - mu2[c]) *
+ *                         B2[c] + C2[c]) ): gradient of the mean path, added per row (times the row mask) inside
+ *                         sn_linear_dgrad_eluseg_f32.
  * ------------------------------------------------------------------------------------------ */
 size_t sn_segment_colsum_workspace_bytes(int64_t rows_per_seg, int64_t nseg, int32_t C);
 int sn_segment_colsum_f32(const float *x, int64_t ld, const float *mask, int64_t rows_per_seg, int64_t nseg, int32_t C,
@@ -268,6 +281,15 @@ int sn_bcast_rows_f32(const float *src, float *dst, int64_t ldd, int64_t rows_pe
 int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64_t ldo, const float *bias,
                          const float *mask, const float *gadd, int64_t ldga, float *gsrc, int64_t ldgs,
                          int64_t rows_per_seg, int64_t nseg, int32_t C, void *stream);
+int sn_avg_fwd_prep_f32(const float *segsum, const float *inv_count, int64_t nseg, int32_t C, int64_t rows_per_seg,
+                        const double *stats1, float *m, double *stats, void *stream);
+int sn_seg_affine_f32(const float *A, int64_t nseg, int32_t K, const float *W, int64_t ldw, const float *bias, int32_t J,
+                      float *out, void *stream);
+int sn_avg_bwd_gc_f32(const float *G1, const float *seg_dy, const float *m, const float *mu2, int64_t nseg, int32_t J,
+                      int32_t C, float *Gc, void *stream);
+int sn_avg_bwd_segvec_f32(const float *seg_dy, const float *Wf2, int64_t ldw, const float *m, const float *mu2,
+                          const float *B2, const float *C2, const float *inv_count, int64_t rows_per_seg, int64_t nseg,
+                          int32_t J, int32_t C, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side construction of the quaternionic Dirac operators from a triangle mesh.
@@ -343,6 +365,12 @@ int sn_laplacian_csr_from_mesh(const float *V, const int32_t *F, int64_t nV, int
  *                     and only the last C/2 columns are written, to dx_hi (rows x C/2) — the operand of the transposed
  *                     sparse product.  B (the BatchNorm tail) is required.  Split-bf16 kernels only
  *                     (SN_E_UNSUPPORTED with SN_GEMM_VARIANT=0: the caller composes the unfused calls).
+ * sn_linear_fwd_segbias_f32 : the forward with a PER-MESH bias, y[r, :] = x[r]·W^T + segbias[r / rows_per_seg, :]
+ *                     (+ residual) — the half-width global-average stage; y may be NULL when only y_elu is wanted (also
+ *                     accepted by sn_linear_fwd_f32).  rows_per_seg >= 32.  Split-bf16 kernels only.
+ * sn_linear_dgrad_eluseg_f32 : input gradient through the activation for ALL C columns with a per-mesh vector added before
+ *                     the derivative:  gact[r, c] = (dy[r]·W[:, c] + (x[r,c] - center[c]) B[c] + Cc[c] + rowmask[r] *
+ *                     segvec[r / rows_per_seg, c]) * elu'(x[r, c]) + gadd[r, c]   (rowmask, gadd may be NULL).
  * Supported: K in {128, 256}, J = 128 for the forward; J = 128, C in {128, 256} for the input gradient; all leading
  * dimensions multiples of 4 floats and 16-byte aligned bases (else SN_E_UNSUPPORTED / SN_E_ALIGN: the caller falls
  * back to a library GEMM).
@@ -357,6 +385,13 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
                             const float *center, const float *B, const float *Cc, float *dx_hi, int64_t lddx,
                             float *gact, int64_t ldga, const float *gadd, int64_t ldgadd,
                             int64_t rows, int32_t J, int32_t C, void *stream);
+int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
+                              int64_t rows_per_seg, const float *residual, int64_t ldr, float *y, int64_t ldy,
+                              float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J, void *stream);
+int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                               const float *center, const float *B, const float *Cc, const float *segvec,
+                               int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,
+                               int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,13 @@ SIGNATURES = {
     "sn_linear_dgrad_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),
     "sn_linear_dgrad_elu_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64,
                                           _i32, _i32, _vp]),
+    "sn_linear_fwd_segbias_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
+    "sn_linear_dgrad_eluseg_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64,
+                                             _i64, _i32, _i32, _vp]),
+    "sn_avg_fwd_prep_f32": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "sn_seg_affine_f32": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
+    "sn_avg_bwd_gc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "sn_avg_bwd_segvec_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "sn_affine_cols_acc_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
 }
 

@@ -245,10 +245,14 @@ class GraphedTrainStep:
         return loss
 
 
-def train_step(model, optimizer, batch: Batch, global_batch: Optional[int] = None, grad_sync=None):
-    """One update (main.py:217-232): forward, masked smooth-L1, backward, [gradient all-reduce], Adam."""
+def train_step(model, optimizer, batch: Batch, global_batch: Optional[int] = None, grad_sync=None, zero_grads=None):
+    """One update (main.py:217-232): forward, masked smooth-L1, backward, [gradient all-reduce], Adam.
+    zero_grads: e.g. FlatGradBucket.zero_ — one memset of the flat buffer instead of one launch per parameter."""
     loss, _ = forward_loss(model, batch, global_batch)
-    optimizer.zero_grad(set_to_none=False)
+    if zero_grads is not None:
+        zero_grads()
+    else:
+        optimizer.zero_grad(set_to_none=False)
     loss.backward()
     if grad_sync is not None:
         grad_sync()

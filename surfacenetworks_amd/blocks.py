@@ -19,7 +19,8 @@ from __future__ import annotations
 import torch
 
 from . import kernels
-from .functional import _launch, _rows2d, bn_prepare, bnlin_backward, bnlin_forward, stash, unstash
+from .functional import (_launch, _rows2d, avg_stage_backward, avg_stage_forward, bn_prepare, bnlin_backward, bnlin_forward,
+                         stash, unstash)
 from .operators import as_operator
 
 __all__ = ["lap_block", "dirac_block", "avg_block", "take_activated", "attach_activated"]
@@ -201,6 +202,42 @@ class _PropagateBlock(torch.autograd.Function):
                 None, None, None, None)
 
 
+class _AvgBlock(torch.autograd.Function):
+    """AvgResNet2 (utils_pt.py:230-243) at half width (functional.avg_stage_forward): the broadcast mean is never written,
+    both Linear layers run over C instead of 2C columns, and the whole backward of a stage — BatchNorm tail, mean-path
+    gradient, ELU derivative, residual-path gradient — leaves the dgrad GEMM's epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, mask_rows, inv_count, nseg, pre, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1, rm1, rv1,
+                tr1, mo1, ep1):
+        x = _rows2d(x)
+        rows, C = x.shape
+        per = rows // nseg
+        e_a = _activated(x, pre)[:, :C]
+        e_b = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+        _, st0 = avg_stage_forward(e_a, mask_rows, inv_count, nseg, per, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, e_b,
+                                   want_y=False)                      # only elu(h) is needed downstream
+        nxt = _new_cat(rows, C, x.device)
+        out, st1 = avg_stage_forward(e_b, mask_rows, inv_count, nseg, per, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x,
+                                     nxt[:, :C])
+        stash(ctx, st0, st1, (mask_rows, inv_count))
+        ctx.seg = (nseg, per)
+        ctx.mark_non_differentiable(nxt)
+        return out, nxt
+
+    @staticmethod
+    def backward(ctx, g_out, _gn):
+        st0, st1, (mask_rows, inv_count) = unstash(ctx)
+        nseg, per = ctx.seg
+        g_out = g_out.contiguous()
+        g_h, dg1, db1, dW1, dc1 = avg_stage_backward(st1, mask_rows, inv_count, nseg, per, g_out, None)
+        g_x, dg0, db0, dW0, dc0 = avg_stage_backward(st0, mask_rows, inv_count, nseg, per, g_h, g_out)   # + residual path
+        if not ctx.needs_input_grad[0]:
+            g_x = None
+        return (g_x, None, None, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None,
+                None, None, None, None)
+
+
 def lap_block(mod, L, inputs):
     B, V, C = inputs.shape
     rows = B * V
@@ -217,6 +254,11 @@ def avg_block(mod, mask, inputs):
     rows = B * V
     mask_rows = mask.reshape(rows).contiguous()
     inv_count = 1.0 / mask.reshape(B, V).sum(1, keepdim=True)
-    out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), None, mask_rows, inv_count, B, take_activated(inputs, rows, C),
-                                     *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+    a0, a1 = _bn_args(mod.bn_fc0), _bn_args(mod.bn_fc1)
+    if a0[6] and a1[6] and kernels.avg_stage_supported(C, mod.bn_fc0.fc.weight.shape[0], V) and \
+            mod.bn_fc0.fc.weight.shape[1] == 2 * C and mod.bn_fc1.fc.weight.shape[0] == C:
+        out, nxt = _AvgBlock.apply(inputs.reshape(rows, C), mask_rows, inv_count, B, take_activated(inputs, rows, C), *a0, *a1)
+    else:
+        out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), None, mask_rows, inv_count, B, take_activated(inputs, rows, C),
+                                         *a0, *a1)
     return attach_activated(out.view(B, V, C), nxt)

@@ -620,6 +620,68 @@ __global__ __launch_bounds__(kWG) void segsum_final_k(const double *__restrict__
   out[i] = (float)t;
 }
 
+// ---- half-width global-average stage: the second half of its concat buffer is a per-mesh constant (the masked mean m
+// of the first half, broadcast over the mesh's rows), so everything that concerns that half is nseg x C algebra ----
+// m = Ssum * inv_count;  stats (2 x 2C, fp64) = [ stats1 | per * sum_mesh m , per * sum_mesh m^2 ]
+__global__ __launch_bounds__(kWG) void avg_fwd_prep_k(const float *__restrict__ ssum, const float *__restrict__ inv_count,
+                                                      int nseg, int C, double per, const double *__restrict__ stats1,
+                                                      float *__restrict__ m, double *__restrict__ stats) {
+  const int c = blockIdx.x * kWG + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int g = 0; g < nseg; ++g) {
+    const float mv = ssum[(int64_t)g * C + c] * inv_count[g];
+    m[(int64_t)g * C + c] = mv;
+    s1 += (double)mv;
+    s2 += (double)mv * (double)mv;
+  }
+  stats[c] = stats1[c];
+  stats[C + c] = per * s1;
+  stats[2 * C + c] = stats1[C + c];
+  stats[3 * C + c] = per * s2;
+}
+// out[g][j] = bias[j] + sum_c A[g][c] * W[j][c]      (W: J rows, leading dimension ldw, already offset to the half used)
+__global__ __launch_bounds__(kWG) void seg_affine_k(const float *__restrict__ A, int nseg, int K, const float *__restrict__ W,
+                                                    int64_t ldw, const float *__restrict__ bias, int J,
+                                                    float *__restrict__ out) {
+  const int t = blockIdx.x * kWG + threadIdx.x;
+  if (t >= nseg * J) return;
+  const int g = t / J, j = t - g * J;
+  double acc = bias ? (double)bias[j] : 0.0;
+  for (int c = 0; c < K; ++c) acc += (double)A[(int64_t)g * K + c] * (double)W[(int64_t)j * ldw + c];
+  out[t] = (float)acc;
+}
+// Gc (J x 2C): [ G1 | sum_mesh Sg[mesh][j] * (m[mesh][c] - mu2[c]) ]
+__global__ __launch_bounds__(kWG) void avg_bwd_gc_k(const float *__restrict__ G1, const float *__restrict__ Sg,
+                                                    const float *__restrict__ m, const float *__restrict__ mu2, int nseg,
+                                                    int J, int C, float *__restrict__ Gc) {
+  const int t = blockIdx.x * kWG + threadIdx.x;
+  if (t >= J * 2 * C) return;
+  const int j = t / (2 * C), c2 = t - j * 2 * C;
+  if (c2 < C) {
+    Gc[t] = G1[(int64_t)j * C + c2];
+    return;
+  }
+  const int c = c2 - C;
+  double acc = 0;
+  for (int g = 0; g < nseg; ++g) acc += (double)Sg[(int64_t)g * J + j] * ((double)m[(int64_t)g * C + c] - (double)mu2[c]);
+  Gc[t] = (float)acc;
+}
+// segvec[mesh][c] = inv_count[mesh] * ( sum_j Sg[mesh][j] * Wf2[j][c] + per * ((m[mesh][c] - mu2[c]) * B2[c] + C2[c]) )
+__global__ __launch_bounds__(kWG) void avg_bwd_segvec_k(const float *__restrict__ Sg, const float *__restrict__ Wf2,
+                                                        int64_t ldw, const float *__restrict__ m,
+                                                        const float *__restrict__ mu2, const float *__restrict__ B2,
+                                                        const float *__restrict__ C2, const float *__restrict__ inv_count,
+                                                        double per, int nseg, int J, int C, float *__restrict__ out) {
+  const int t = blockIdx.x * kWG + threadIdx.x;
+  if (t >= nseg * C) return;
+  const int g = t / C, c = t - g * C;
+  double acc = 0;
+  for (int j = 0; j < J; ++j) acc += (double)Sg[(int64_t)g * J + j] * (double)Wf2[(int64_t)j * ldw + c];
+  acc += per * (((double)m[t] - (double)mu2[c]) * (double)B2[c] + (double)C2[c]);
+  out[t] = (float)(acc * (double)inv_count[g]);
+}
+
 __global__ __launch_bounds__(kWG) void bcast_rows_k(const float *__restrict__ src, float *__restrict__ dst, int64_t ldd,
                                                     int64_t rows_per_seg, int64_t rows, int C, int nt) {
   const int cw = C / 4;
@@ -750,6 +812,44 @@ int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, con
     hipLaunchKernelGGL((wgrad_mfma_k<2>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
   hipLaunchKernelGGL(wgrad_reduce_k, dim3((J * C + (dysum ? J : 0) + 63) / 64), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G,
                      colpart, dysum);
+  return launch_status();
+}
+
+int sn_avg_fwd_prep_f32(const float *segsum, const float *inv_count, int64_t nseg, int32_t C, int64_t rows_per_seg,
+                        const double *stats1, float *m, double *stats, void *stream) {
+  if (nseg < 1 || C < 1 || rows_per_seg < 1) return SN_E_SHAPE;
+  if (!segsum || !inv_count || !stats1 || !m || !stats) return SN_E_NULL;
+  hipLaunchKernelGGL(avg_fwd_prep_k, dim3((C + kWG - 1) / kWG), dim3(kWG), 0, static_cast<hipStream_t>(stream), segsum,
+                     inv_count, (int)nseg, (int)C, (double)rows_per_seg, stats1, m, stats);
+  return launch_status();
+}
+
+int sn_seg_affine_f32(const float *A, int64_t nseg, int32_t K, const float *W, int64_t ldw, const float *bias, int32_t J,
+                      float *out, void *stream) {
+  if (nseg < 1 || K < 1 || J < 1 || ldw < K) return SN_E_SHAPE;
+  if (!A || !W || !out) return SN_E_NULL;
+  hipLaunchKernelGGL(seg_affine_k, dim3((unsigned)((nseg * J + kWG - 1) / kWG)), dim3(kWG), 0,
+                     static_cast<hipStream_t>(stream), A, (int)nseg, (int)K, W, ldw, bias, (int)J, out);
+  return launch_status();
+}
+
+int sn_avg_bwd_gc_f32(const float *G1, const float *seg_dy, const float *m, const float *mu2, int64_t nseg, int32_t J,
+                      int32_t C, float *Gc, void *stream) {
+  if (nseg < 1 || J < 1 || C < 1) return SN_E_SHAPE;
+  if (!G1 || !seg_dy || !m || !mu2 || !Gc) return SN_E_NULL;
+  hipLaunchKernelGGL(avg_bwd_gc_k, dim3((unsigned)((J * 2 * C + kWG - 1) / kWG)), dim3(kWG), 0,
+                     static_cast<hipStream_t>(stream), G1, seg_dy, m, mu2, (int)nseg, (int)J, (int)C, Gc);
+  return launch_status();
+}
+
+int sn_avg_bwd_segvec_f32(const float *seg_dy, const float *Wf2, int64_t ldw, const float *m, const float *mu2,
+                          const float *B2, const float *C2, const float *inv_count, int64_t rows_per_seg, int64_t nseg,
+                          int32_t J, int32_t C, float *out, void *stream) {
+  if (nseg < 1 || J < 1 || C < 1 || ldw < C || rows_per_seg < 1) return SN_E_SHAPE;
+  if (!seg_dy || !Wf2 || !m || !mu2 || !B2 || !C2 || !inv_count || !out) return SN_E_NULL;
+  hipLaunchKernelGGL(avg_bwd_segvec_k, dim3((unsigned)((nseg * C + kWG - 1) / kWG)), dim3(kWG), 0,
+                     static_cast<hipStream_t>(stream), seg_dy, Wf2, ldw, m, mu2, B2, C2, inv_count, (double)rows_per_seg,
+                     (int)nseg, (int)J, (int)C, out);
   return launch_status();
 }
 

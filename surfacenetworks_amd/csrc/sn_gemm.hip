@@ -48,6 +48,11 @@ struct EpiArgs {
   const float *v4;
   int64_t ld3;
   int half;
+  // per-mesh row vectors (period = rows per mesh > 0): forward: segv[mesh(r)][c] REPLACES the bias; dgrad+elu: rowmask[r] *
+  // segv[mesh(r)][c] is added before the activation derivative (rowmask may be NULL = 1)
+  const float *segv;
+  int64_t period, ldseg;
+  const float *rowmask;
 };
 
 template <int K, int NT, bool TRANSW, int EPI>
@@ -368,6 +373,28 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
         sd[j] = *reinterpret_cast<const f4 *>(side_p + r * ep.ld1 + ecol);
       }
     }
+    f4 sg[NST];                        // per-mesh vector of my rows (forward: the bias; dgrad+elu: added before elu')
+    const bool useseg = ep.period > 0 && (EPI == EPI_FWD || (DGE && lowhalf));                 // wave-uniform
+    if (useseg) {
+      // a 32-row tile meets at most two meshes (period >= 32): the mesh of its first row, and the next one past `bnd`
+      const int64_t m0 = (tl * 32) / ep.period, bnd = (m0 + 1) * ep.period;
+#pragma unroll
+      for (int j = 0; j < NST; ++j) {
+        int64_t r = tl * 32 + erow + RPI * j;
+        r = r < rows ? r : rows - 1;
+        const int64_t mesh = r < bnd ? m0 : m0 + 1;
+        sg[j] = *reinterpret_cast<const f4 *>(ep.segv + mesh * ep.ldseg + ecol);
+        if constexpr (DGE) {
+          if (ep.rowmask) {
+            const float mk = ep.rowmask[r];
+            sg[j] = f4{sg[j].x * mk, sg[j].y * mk, sg[j].z * mk, sg[j].w * mk};
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NST; ++j) sg[j] = f4{0.f, 0.f, 0.f, 0.f};
+    }
     f4 ga[NST];                        // dgrad+elu, low half: the gradient added after the activation derivative
     if constexpr (DGE) {
       if (lowhalf && ep.v4) {
@@ -447,7 +474,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
       f4 v = *reinterpret_cast<const f4 *>(sr + RPI * j * SROW);
       const int64_t r = tl * 32 + erow + RPI * j;
       if constexpr (EPI == EPI_FWD) {
-        v += k0;
+        v += useseg ? sg[j] : k0;
         if constexpr (SIDE) v += sd[j];
       } else if constexpr (SIDE) {            // dgrad (both forms): BatchNorm tail
         const f4 xv = sd[j] - k0;
@@ -459,6 +486,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
       if constexpr (DGE) {
         if (lowhalf) {                   // through the activation: elu'(.) from the activation OUTPUT held in the side operand
           const f4 o = sd[j];
+          v += sg[j];
           v = f4{v.x * (o.x > 0.f ? 1.f : o.x + 1.f), v.y * (o.y > 0.f ? 1.f : o.y + 1.f),
                  v.z * (o.z > 0.f ? 1.f : o.z + 1.f), v.w * (o.w > 0.f ? 1.f : o.w + 1.f)} + ga[j];
           if (r < rows) *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = v;
@@ -466,7 +494,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
           *reinterpret_cast<f4 *>(Out + r * ldo + ecol) = v;
         }
       } else if (r < rows) {
-        *reinterpret_cast<f4 *>(Out + r * ldo + ecol) = v;
+        if (EPI != EPI_FWD || Out) *reinterpret_cast<f4 *>(Out + r * ldo + ecol) = v;
         if constexpr (EPI == EPI_FWD && ELU)
           *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
       }
@@ -503,14 +531,14 @@ extern "C" {
 int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias,
                       const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu, int64_t lde,
                       int64_t rows, int32_t K, int32_t J, void *stream) {
-  if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || ldy < J) return SN_E_SHAPE;
+  if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J)) return SN_E_SHAPE;
   if (J != 128 || (K != 128 && K != 256)) return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
-  if (!x || !W || !bias || !y) return SN_E_NULL;
-  if (!aligned16(x) || !aligned16(W) || !aligned16(bias) || !aligned16(y) || (ldx % 4) || (ldw % 4) || (ldy % 4) ||
+  if (!x || !W || !bias || (!y && !(y_elu && gemm_variant() != 0))) return SN_E_NULL;     // y may be NULL when only elu(y) is wanted
+  if (!aligned16(x) || !aligned16(W) || !aligned16(bias) || (y && (!aligned16(y) || (ldy % 4))) || (ldx % 4) || (ldw % 4) ||
       (residual && (!aligned16(residual) || (ldr % 4) || ldr < J)) || (y_elu && (!aligned16(y_elu) || (lde % 4) || lde < J)))
     return SN_E_ALIGN;
-  EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0};
+  EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
   const bool x3 = gemm_variant() != 0;
@@ -548,7 +576,7 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx) || (lddy % 4) || (ldw % 4) || (lddx % 4)) return SN_E_ALIGN;
   if (B && (!aligned16(x) || !aligned16(B) || !aligned16(Cc) || (center && !aligned16(center)) || (ldx % 4) || ldx < C))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0};
+  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
   const bool x3 = gemm_variant() != 0;
@@ -580,7 +608,7 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
       (lddy % 4) || (ldw % 4) || (lddx % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   const int half = C / 2;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr};
   float *out = dx_hi - half;           // the kernel indexes absolute columns; only columns >= half are written through `out`
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
@@ -590,6 +618,58 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
   else
     hipLaunchKernelGGL((gemm_rows_x3_k<128, 1, true, EPI_DGRAD_ELU, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, out,
                        lddx, rows, ep);
+  return launch_status();
+}
+
+int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
+                              int64_t rows_per_seg, const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu,
+                              int64_t lde, int64_t rows, int32_t K, int32_t J, void *stream) {
+  if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J) || rows_per_seg < 1) return SN_E_SHAPE;
+  if (J != 128 || (K != 128 && K != 256) || rows_per_seg < 32 || gemm_variant() == 0) return SN_E_UNSUPPORTED;
+  if (rows == 0) return SN_OK;
+  if (!x || !W || !segbias || (!y && !y_elu)) return SN_E_NULL;
+  if (!aligned16(x) || !aligned16(W) || !aligned16(segbias) || (y && (!aligned16(y) || (ldy % 4))) || (ldx % 4) || (ldw % 4) ||
+      (residual && (!aligned16(residual) || (ldr % 4) || ldr < J)) || (y_elu && (!aligned16(y_elu) || (lde % 4) || lde < J)))
+    return SN_E_ALIGN;
+  EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, rows_per_seg, J, nullptr};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned grid = gemm_grid(rows);
+  const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
+  switch (sel) {
+    case 0: SN_X3_FWD(128, false, false); break;
+    case 1: SN_X3_FWD(128, false, true); break;
+    case 2: SN_X3_FWD(128, true, false); break;
+    case 3: SN_X3_FWD(128, true, true); break;
+    case 4: SN_X3_FWD(256, false, false); break;
+    case 5: SN_X3_FWD(256, false, true); break;
+    case 6: SN_X3_FWD(256, true, false); break;
+    default: SN_X3_FWD(256, true, true); break;
+  }
+  return launch_status();
+}
+
+int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                               const float *center, const float *B, const float *Cc, const float *segvec,
+                               int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,
+                               int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream) {
+  if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || ldga < C || ldx < C || rows_per_seg < 1) return SN_E_SHAPE;
+  if (J != 128 || (C != 128 && C != 256) || rows_per_seg < 32 || gemm_variant() == 0) return SN_E_UNSUPPORTED;
+  if (rows == 0) return SN_OK;
+  if (!dy || !W || !gact || !x || !B || !Cc || !segvec) return SN_E_NULL;
+  if (!aligned16(dy) || !aligned16(W) || !aligned16(gact) || !aligned16(x) || !aligned16(B) || !aligned16(Cc) ||
+      !aligned16(segvec) || (center && !aligned16(center)) || (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C)) ||
+      (lddy % 4) || (ldw % 4) || (ldga % 4) || (ldx % 4))
+    return SN_E_ALIGN;
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, rows_per_seg, C, rowmask};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const unsigned grid = gemm_grid(rows);
+  float *none = nullptr;               // every column leaves through gact: nothing is written through Out
+  if (C == 256)
+    hipLaunchKernelGGL((gemm_rows_x3_k<128, 2, true, EPI_DGRAD_ELU, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, none,
+                       (int64_t)0, rows, ep);
+  else
+    hipLaunchKernelGGL((gemm_rows_x3_k<128, 1, true, EPI_DGRAD_ELU, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, none,
+                       (int64_t)0, rows, ep);
   return launch_status();
 }
 

@@ -357,6 +357,40 @@ def bnlin_backward(state, dy, need_dx=True, through_elu=None):
     return dx, dgamma, dbeta, dW, db
 
 
+def avg_stage_forward(e, mask_rows, inv_count, nseg, per, gamma, beta, W, b, running_mean, running_var, training, momentum,
+                      eps, residual=None, elu_out=None, want_y=True):
+    """One stage of AvgResNet2 (utils_pt.py:230-243), Lin(BN([e | global_average(e) broadcast])), at HALF width: the second
+    half of the concat buffer is a per-mesh constant m, so it is never materialised — its BatchNorm statistics follow from
+    m (nseg x C numbers), its share of the Linear product is a per-mesh bias m·Wf[:, C:]^T + bf, and the GEMM runs over the
+    C real columns only.  Training-mode BatchNorm only (the caller checks kernels.avg_stage_supported)."""
+    e = _rows2d(e)
+    rows, C = e.shape
+    ssum = kernels.segment_colsum(e, mask_rows, per, nseg)
+    m, stats = kernels.avg_fwd_prep(ssum, inv_count, per, kernels.colstats(e))
+    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, True, running_mean, running_var)
+    segb = kernels.seg_affine(m, Wf[:, C:], bf)
+    if residual is not None:
+        residual = _rows2d(residual)
+    y = kernels.linear_fwd_segbias(e, Wf[:, :C], segb, per, residual, elu_out, want_y)
+    return y, (e, m, W, Wf, s, mean, invstd, beta, b is not None)
+
+
+def avg_stage_backward(state, mask_rows, inv_count, nseg, per, dy, gadd):
+    """Backward of avg_stage_forward THROUGH the ELU that produced e: returns (dL/d(pre-activation of e) + gadd, dgamma,
+    dbeta, dW, db).  Second-half terms: G[:, C:] = sum_mesh S^T (m - mu2) with S the per-mesh column sums of dy; the gradient
+    of the mean path, inv_count * (S·Wf2 + per ((m - mu2) B2 + C2)), is added per row inside the dgrad GEMM's epilogue."""
+    e, m, W, Wf, s, mean, invstd, beta, has_bias = state
+    dy = dy.contiguous()
+    rows, C = e.shape
+    G1, sdy = kernels.wgrad(dy, e, mean[:C], want_colsum=True)
+    Sg = kernels.segment_colsum(dy, None, per, nseg)
+    Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows, has_bias)
+    segvec = kernels.avg_bwd_segvec(Sg, Wf[:, C:], m, mean[C:], Bc[C:], Cc[C:], inv_count, per)
+    g = kernels.linear_dgrad_eluseg(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, per, mask_rows, gadd)
+    return g, dgamma, dbeta, dW, db
+
+
 class _BNLinear(torch.autograd.Function):
     """autograd wrapper of bnlin_forward / bnlin_backward (BatchNorm1d("pre") + Linear of GraphConv1x1,
     src/utils/utils_pt.py:83-99, without materialising the normalised tensor)."""

@@ -16,6 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
+    "avg_stage_supported", "avg_fwd_prep", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg",
 ]
 
 
@@ -364,3 +365,72 @@ def linear_dgrad(dy, W, x=None, center=None, B=None, Cc=None):
     _lib.call("sn_linear_dgrad_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x) if x is not None else 0, _p(center),
               _p(B), _p(Cc), _p(dx), C, rows, J, C, _stream())
     return dx
+
+
+# ---- half-width global-average stage (see include/sn_spmm.h) ----------------------------------------------------------
+def avg_stage_supported(C: int, J: int, rows_per_seg: int) -> bool:
+    import os
+
+    return C == 128 and J == 128 and rows_per_seg >= 32 and os.environ.get("SN_GEMM_VARIANT", "1") != "0"
+
+
+def avg_fwd_prep(segsum, inv_count, rows_per_seg: int, stats1):
+    """(m (nseg, C) fp32, stats (2, 2C) fp64): per-mesh mean and the BatchNorm statistics of [e | mean broadcast]."""
+    _dev(segsum, inv_count, stats1)
+    nseg, C = segsum.shape
+    m = torch.empty((nseg, C), dtype=torch.float32, device=segsum.device)
+    stats = torch.empty((2, 2 * C), dtype=torch.float64, device=segsum.device)
+    _lib.call("sn_avg_fwd_prep_f32", _p(segsum), _p(inv_count.contiguous()), nseg, C, rows_per_seg, _p(stats1), _p(m), _p(stats),
+              _stream())
+    return m, stats
+
+
+def seg_affine(A, W, bias):
+    """out[g, j] = bias[j] + sum_c A[g, c] * W[j, c]; W may be a column slice (row stride kept)."""
+    _dev(A, W, bias)
+    nseg, K = A.shape
+    J = W.shape[0]
+    out = torch.empty((nseg, J), dtype=torch.float32, device=A.device)
+    _lib.call("sn_seg_affine_f32", _p(A), nseg, K, _p(W), _ld(W), _p(bias), J, _p(out), _stream())
+    return out
+
+
+def avg_bwd_gc(G1, seg_dy, m, mu2):
+    _dev(G1, seg_dy, m, mu2)
+    J, C = G1.shape
+    Gc = torch.empty((J, 2 * C), dtype=torch.float32, device=G1.device)
+    _lib.call("sn_avg_bwd_gc_f32", _p(G1), _p(seg_dy), _p(m), _p(mu2), m.shape[0], J, C, _p(Gc), _stream())
+    return Gc
+
+
+def avg_bwd_segvec(seg_dy, Wf2, m, mu2, B2, C2, inv_count, rows_per_seg: int):
+    _dev(seg_dy, Wf2, m, mu2, B2, C2, inv_count)
+    nseg, C = m.shape
+    J = seg_dy.shape[1]
+    out = torch.empty((nseg, C), dtype=torch.float32, device=m.device)
+    _lib.call("sn_avg_bwd_segvec_f32", _p(seg_dy), _p(Wf2), _ld(Wf2), _p(m), _p(mu2), _p(B2), _p(C2), _p(inv_count.contiguous()),
+              rows_per_seg, nseg, J, C, _p(out), _stream())
+    return out
+
+
+def linear_fwd_segbias(x, W, segbias, rows_per_seg: int, residual=None, y_elu=None, want_y: bool = True):
+    """y = x·W^T + segbias[row // rows_per_seg] (+ residual), optionally elu(y) into y_elu; want_y=False: only y_elu is written."""
+    _dev(x, W, segbias, residual, y_elu)
+    rows, K = x.shape
+    J = W.shape[0]
+    y = torch.empty((rows, J), dtype=torch.float32, device=x.device) if want_y else None
+    _lib.call("sn_linear_fwd_segbias_f32", _p(x), _ld(x), _p(W), _ld(W), _p(segbias), rows_per_seg, _p(residual),
+              _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu), _ld(y_elu) if y_elu is not None else 0,
+              rows, K, J, _stream())
+    return y
+
+
+def linear_dgrad_eluseg(dy, W, x, center, B, Cc, segvec, rows_per_seg: int, rowmask=None, gadd=None):
+    """(dy·W + (x - center) B + Cc + rowmask * segvec[row // rows_per_seg]) * elu'(x) + gadd for all C columns."""
+    _dev(dy, W, x, center, B, Cc, segvec, rowmask, gadd)
+    rows, J = dy.shape
+    C = x.shape[1]
+    gact = torch.empty((rows, C), dtype=torch.float32, device=dy.device)
+    _lib.call("sn_linear_dgrad_eluseg_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x), _p(center), _p(B), _p(Cc), _p(segvec),
+              rows_per_seg, _p(rowmask), _p(gact), C, _p(gadd), _ld(gadd) if gadd is not None else 0, rows, J, C, _stream())
+    return gact

@@ -216,6 +216,51 @@ def linear_dgrad_elu(dy, W, x, center, B, Cc, gadd=None):
     return dx[:, h:].contiguous(), gact
 
 
+def avg_stage_supported(C, J, rows_per_seg):
+    return C == 128 and J == 128 and rows_per_seg >= 32
+
+
+def avg_fwd_prep(segsum, inv_count, rows_per_seg, stats1):
+    m = (segsum * inv_count.reshape(-1, 1)).float()
+    md = m.double()
+    stats = torch.cat([stats1, torch.stack([rows_per_seg * md.sum(0), rows_per_seg * (md * md).sum(0)])], 1)
+    return m, stats.contiguous()
+
+
+def seg_affine(A, W, bias):
+    out = A.double() @ W.double().t()
+    return (out + bias.double() if bias is not None else out).float()
+
+
+def avg_bwd_gc(G1, seg_dy, m, mu2):
+    return torch.cat([G1, (seg_dy.double().t() @ (m.double() - mu2.double())).float()], 1).contiguous()
+
+
+def avg_bwd_segvec(seg_dy, Wf2, m, mu2, B2, C2, inv_count, rows_per_seg):
+    v = seg_dy.double() @ Wf2.double() + rows_per_seg * ((m.double() - mu2.double()) * B2.double() + C2.double())
+    return (v * inv_count.double().reshape(-1, 1)).float()
+
+
+def linear_fwd_segbias(x, W, segbias, rows_per_seg, residual=None, y_elu=None, want_y=True):
+    seg = torch.arange(x.shape[0]) // rows_per_seg
+    y = (x.double() @ W.double().t()).float() + segbias[seg]
+    if residual is not None:
+        y = y + residual
+    if y_elu is not None:
+        elu_into(y, y_elu)
+    return y if want_y else None
+
+
+def linear_dgrad_eluseg(dy, W, x, center, B, Cc, segvec, rows_per_seg, rowmask=None, gadd=None):
+    dx = linear_dgrad(dy, W, x, center, B, Cc)
+    seg = torch.arange(x.shape[0]) // rows_per_seg
+    add = segvec[seg] if rowmask is None else segvec[seg] * rowmask.reshape(-1, 1)
+    pre = (dx + add).contiguous()
+    gact = torch.empty_like(pre)
+    elu_bwd(pre, x, gact, False, None, gadd)
+    return gact
+
+
 def install(monkeypatch=None):
     """Patch surfacenetworks_amd.kernels in place (monkeypatch=None: permanent, for spawned worker processes)."""
     from surfacenetworks_amd import kernels

@@ -153,5 +153,8 @@ def test_whole_block_node_equals_per_stage_functions(golden_dir, cname):
                         b1.bn_fc1.bn.running_var.cpu().numpy()])
         finally:
             U.USE_WHOLE_BLOCKS = True
+    # AvgResNet2's whole-block node is the half-width form: the mean-path terms are evaluated analytically (per-mesh algebra in
+    # fp64) instead of through a broadcast second half, so the two paths differ by fp32 rounding of different summations
+    tol = 2e-5 if cname == "AvgResNet2" else 5e-6
     for a, b in zip(*res):
-        assert rel_err(a, b) < 5e-6
+        assert rel_err(a, b) < tol

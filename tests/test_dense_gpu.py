@@ -273,3 +273,68 @@ def test_linear_dgrad_through_elu(rows, C, with_gadd):
     dx_hi, gact = kernels.linear_dgrad_elu(dev(dy), dev(W), dev(x), dev(cen), dev(B), dev(Cc), dev(gadd) if with_gadd else None)
     assert np.array_equal(dx_hi.cpu().numpy(), full[:, h:])        # the untouched half: same kernel arithmetic
     assert np.allclose(gact.cpu().numpy(), want_act, rtol=1e-6, atol=1e-6)
+
+
+# ---- half-width global-average stage kernels ---------------------------------------------------------------------------
+@pytest.mark.parametrize("nseg,per", [(3, 150), (5, 32), (2, 5041)])
+def test_avg_stage_small_kernels(nseg, per):
+    rng = np.random.default_rng(nseg * 1000 + per)
+    C, J = 128, 128
+    ssum = rng.standard_normal((nseg, C)).astype(np.float32) * per
+    inv = (1.0 / rng.integers(per // 2 + 1, per + 1, size=nseg)).astype(np.float32)
+    stats1 = rng.standard_normal((2, C))
+    m, stats = kernels.avg_fwd_prep(dev(ssum), dev(inv), per, dev(stats1))
+    m_want = ssum * inv[:, None]
+    assert np.array_equal(m.cpu().numpy(), m_want)
+    md = m_want.astype(np.float64)
+    want = np.concatenate([stats1, np.stack([per * md.sum(0), per * (md * md).sum(0)])], 1)
+    assert np.allclose(stats.cpu().numpy(), want, rtol=1e-13, atol=0)
+    Wf = rng.standard_normal((J, 2 * C)).astype(np.float32)
+    bf = rng.standard_normal(J).astype(np.float32)
+    segb = kernels.seg_affine(m, dev(Wf)[:, C:], dev(bf)).cpu().numpy()
+    assert rel_err(segb, md @ Wf[:, C:].astype(np.float64).T + bf) < 1e-6
+    Sg = rng.standard_normal((nseg, J)).astype(np.float32)
+    G1 = rng.standard_normal((J, C)).astype(np.float32)
+    mu2, B2, C2 = [rng.standard_normal(C).astype(np.float32) for _ in range(3)]
+    Gc = kernels.avg_bwd_gc(dev(G1), dev(Sg), m, dev(mu2)).cpu().numpy()
+    assert np.array_equal(Gc[:, :C], G1)
+    assert rel_err(Gc[:, C:], Sg.astype(np.float64).T @ (md - mu2)) < 1e-6
+    sv = kernels.avg_bwd_segvec(dev(Sg), dev(Wf)[:, C:], m, dev(mu2), dev(B2), dev(C2), dev(inv), per).cpu().numpy()
+    want_sv = (Sg.astype(np.float64) @ Wf[:, C:].astype(np.float64) + per * ((md - mu2) * B2 + C2)) * inv[:, None]
+    assert rel_err(sv, want_sv) < 1e-6
+
+
+@pytest.mark.parametrize("nseg,per", [(3, 150), (7, 33), (2, 5041)])
+def test_linear_fwd_with_per_mesh_bias_and_dgrad_through_elu(nseg, per):
+    rng = np.random.default_rng(per)
+    rows, C, J = nseg * per, 128, 128
+    xw = rng.standard_normal((rows, 2 * C)).astype(np.float32)         # e = first half of a wider buffer
+    W = (rng.standard_normal((J, 2 * C)) / 16).astype(np.float32)      # only the first C columns are multiplied
+    segb = rng.standard_normal((nseg, J)).astype(np.float32)
+    res = rng.standard_normal((rows, J)).astype(np.float32)
+    seg = np.arange(rows) // per
+    want = xw[:, :C].astype(np.float64) @ W[:, :C].astype(np.float64).T + segb[seg] + res
+    cat = torch.zeros(rows, 2 * J, device=DEV)
+    y = kernels.linear_fwd_segbias(dev(xw)[:, :C], dev(W)[:, :C], dev(segb), per, dev(res), cat[:, :J])
+    assert rel_err(y.cpu().numpy(), want) < 2e-6
+    assert np.allclose(cat[:, :J].cpu().numpy(), np.where(want > 0, want, np.expm1(want)), rtol=1e-5, atol=1e-5)
+    # ELU copy only (no y)
+    cat2 = torch.zeros(rows, 2 * J, device=DEV)
+    assert kernels.linear_fwd_segbias(dev(xw)[:, :C], dev(W)[:, :C], dev(segb), per, dev(res), cat2[:, :J], want_y=False) is None
+    assert torch.equal(cat2, cat)
+    # input gradient through the activation, all C columns, per-mesh vector (masked per row) added before elu'
+    dy = rng.standard_normal((rows, J)).astype(np.float32)
+    Wd = (rng.standard_normal((J, 2 * C)) / np.sqrt(J)).astype(np.float32)
+    cen, B, Cc = [rng.standard_normal(C).astype(np.float32) for _ in range(3)]
+    segv = rng.standard_normal((nseg, C)).astype(np.float32)
+    mask = (rng.random(rows) > 0.2).astype(np.float32)
+    gadd = rng.standard_normal((rows, C)).astype(np.float32)
+    e = xw[:, :C]
+    pre = dy.astype(np.float64) @ Wd[:, :C].astype(np.float64) + (e.astype(np.float64) - cen) * B + Cc + mask[:, None] * segv[seg]
+    want_g = pre * np.where(e > 0, 1.0, e.astype(np.float64) + 1.0) + gadd
+    got = kernels.linear_dgrad_eluseg(dev(dy), dev(Wd)[:, :C], dev(xw)[:, :C], dev(cen), dev(B), dev(Cc), dev(segv), per,
+                                      dev(mask), dev(gadd)).cpu().numpy()
+    assert rel_err(got, want_g) < 2e-6
+    got2 = kernels.linear_dgrad_eluseg(dev(dy), dev(Wd)[:, :C], dev(xw)[:, :C], dev(cen), dev(B), dev(Cc), dev(segv), per).cpu().numpy()
+    pre2 = pre - mask[:, None] * segv[seg] + segv[seg]
+    assert rel_err(got2, pre2 * np.where(e > 0, 1.0, e.astype(np.float64) + 1.0)) < 2e-6
