@@ -230,6 +230,14 @@ int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double 
 size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C);
 int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                  int32_t J, int32_t C, float *G, double *dysum, void *workspace, size_t workspace_bytes, void *stream);
+/* sn_wgrad_seg_f32: the same weight gradient for a batch of rows / rows_per_seg meshes, with the row slabs aligned to mesh
+ * boundaries so that the pass also yields the PER-MESH column sums of dy, seg_dysum (nseg x J, fp32) — what the half-width
+ * global-average stage needs (it replaces a sn_segment_colsum_f32 pass over dy).  dysum and seg_dysum are required; rows
+ * must be a multiple of rows_per_seg.  Split-bf16 kernels only (SN_E_UNSUPPORTED with SN_GEMM_VARIANT=0). */
+size_t sn_wgrad_seg_workspace_bytes(int64_t rows, int64_t rows_per_seg, int32_t J, int32_t C);
+int sn_wgrad_seg_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                     int64_t rows_per_seg, int32_t J, int32_t C, float *G, double *dysum, float *seg_dysum, void *workspace,
+                     size_t workspace_bytes, void *stream);
 int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
                            const float *Cc, int64_t rows, int32_t C, void *stream);
 

@@ -263,7 +263,8 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
                                                                const float *__restrict__ x, int64_t ldx,
                                                                const float *__restrict__ center, int64_t rows, int J, int C,
                                                                float *__restrict__ partial /* [grid][128][C] */,
-                                                               float *__restrict__ colpart /* [grid][128] | NULL */) {
+                                                               float *__restrict__ colpart /* [grid][128] | NULL */,
+                                                               int64_t seg_rows /* 0: even split of all rows */, int spm) {
   constexpr int NCG = 32 + 32 * CT;          // column groups of 4: 32 of dy, 32·CT of x
   constexpr int QP = NCG + 4;                // slots per (column % 4) plane; QP % 16 == 4 keeps fragment reads conflict-free
   constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
@@ -272,10 +273,22 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
   __shared__ u4 img[2][3][2 * PL];           // [buffer][piece][slot]; one step = 16 rows = 2 row groups
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  int64_t per = (rows + gridDim.x - 1) / gridDim.x;
-  per = (per + 15) & ~(int64_t)15;
-  const int64_t r0 = (int64_t)blockIdx.x * per;
-  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+  // row slab of this workgroup: an even split of all rows, or — seg_rows > 0 — `spm` slabs per mesh that never cross a mesh
+  // boundary, so that the per-slab column sums of dy also add up to PER-MESH sums (the global-average stage needs them)
+  int64_t r0, r1;
+  if (seg_rows > 0) {
+    const int64_t mesh = blockIdx.x / spm, part = blockIdx.x % spm;
+    int64_t per = (seg_rows + spm - 1) / spm;
+    per = (per + 15) & ~(int64_t)15;
+    const int64_t mend = (mesh + 1) * seg_rows < rows ? (mesh + 1) * seg_rows : rows;
+    r0 = mesh * seg_rows + part * per;
+    r1 = r0 + per < mend ? r0 + per : mend;
+  } else {
+    int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    per = (per + 15) & ~(int64_t)15;
+    r0 = (int64_t)blockIdx.x * per;
+    r1 = r0 + per < rows ? r0 + per : rows;
+  }
   const int64_t nsteps = r1 > r0 ? (r1 - r0 + 15) / 16 : 0;
   float *P = partial + (int64_t)blockIdx.x * 128 * C;
 #define SN_STEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -423,12 +436,20 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
 
 __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ partial, int nslab, int J, int C,
                                                       float *__restrict__ G, const float *__restrict__ colpart,
-                                                      double *__restrict__ dysum) {
+                                                      double *__restrict__ dysum,
+                                                      float *__restrict__ segsum /* [nslab/spm][J] | NULL */, int spm) {
   __shared__ double sm[4][64];
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int nG = J * C;
   const int i = blockIdx.x * 64 + o;            // output element j*C + c  (partials are laid out [slab][128][C]);
   double t = 0;                                 // elements past J*C are the J column sums of dy ([slab][128])
+  if (i >= nG + J && segsum && g == 0 && i < nG + J + (nslab / spm) * J) {
+    // past G and colsum(dy): the per-mesh column sums of dy — spm consecutive slabs each
+    const int k = i - nG - J, mesh = k / J, j = k - mesh * J;
+    double t2 = 0;
+    for (int p_ = 0; p_ < spm; ++p_) t2 += (double)colpart[(int64_t)(mesh * spm + p_) * 128 + j];
+    segsum[k] = (float)t2;
+  }
   if (i < nG)
     for (int sl = g; sl < nslab; sl += 4) t += (double)partial[(int64_t)sl * 128 * C + i];
   else if (colpart && i < nG + J)
@@ -629,6 +650,7 @@ __global__ __launch_bounds__(kWG) void avg_fwd_prep_k(const float *__restrict__ 
   const int c = blockIdx.x * kWG + threadIdx.x;
   if (c >= C) return;
   double s1 = 0, s2 = 0;
+#pragma unroll 8                        // (independent loads: keep several in flight — these kernels are latency-, not work-bound)
   for (int g = 0; g < nseg; ++g) {
     const float mv = ssum[(int64_t)g * C + c] * inv_count[g];
     m[(int64_t)g * C + c] = mv;
@@ -648,6 +670,7 @@ __global__ __launch_bounds__(kWG) void seg_affine_k(const float *__restrict__ A,
   if (t >= nseg * J) return;
   const int g = t / J, j = t - g * J;
   double acc = bias ? (double)bias[j] : 0.0;
+#pragma unroll 16
   for (int c = 0; c < K; ++c) acc += (double)A[(int64_t)g * K + c] * (double)W[(int64_t)j * ldw + c];
   out[t] = (float)acc;
 }
@@ -664,6 +687,7 @@ __global__ __launch_bounds__(kWG) void avg_bwd_gc_k(const float *__restrict__ G1
   }
   const int c = c2 - C;
   double acc = 0;
+#pragma unroll 16
   for (int g = 0; g < nseg; ++g) acc += (double)Sg[(int64_t)g * J + j] * ((double)m[(int64_t)g * C + c] - (double)mu2[c]);
   Gc[t] = (float)acc;
 }
@@ -677,6 +701,7 @@ __global__ __launch_bounds__(kWG) void avg_bwd_segvec_k(const float *__restrict_
   if (t >= nseg * C) return;
   const int g = t / C, c = t - g * C;
   double acc = 0;
+#pragma unroll 16
   for (int j = 0; j < J; ++j) acc += (double)Sg[(int64_t)g * J + j] * (double)Wf2[(int64_t)j * ldw + c];
   acc += per * (((double)m[t] - (double)mu2[c]) * (double)B2[c] + (double)C2[c]);
   out[t] = (float)(acc * (double)inv_count[g]);
@@ -783,12 +808,16 @@ size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C) {
   return (size_t)wgrad_slabs(rows) * 128 * ((size_t)C + 1) * sizeof(float);      // tile partials + column-sum partials
 }
 
-int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
-                 int32_t J, int32_t C, float *G, double *dysum, void *workspace, size_t workspace_bytes, void *stream) {
+static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                        int32_t J, int32_t C, float *G, double *dysum, int64_t rows_per_seg, float *seg_dysum,
+                        void *workspace, size_t workspace_bytes, void *stream) {
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldx < C) return SN_E_SHAPE;
   if (J > 128 || (J % 4) || (C != 128 && C != 256)) return SN_E_UNSUPPORTED;
   if (!G) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool x3 = gemm_variant() != 0;
+  const bool segmented = rows_per_seg > 0;
+  if (segmented && (!x3 || !dysum || !seg_dysum || rows % rows_per_seg)) return x3 ? SN_E_SHAPE : SN_E_UNSUPPORTED;
   if (rows == 0) {
     hipError_t e = hipMemsetAsync(G, 0, (size_t)J * C * sizeof(float), s);
     if (e == hipSuccess && dysum) e = hipMemsetAsync(dysum, 0, (size_t)J * sizeof(double), s);
@@ -796,23 +825,53 @@ int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, con
   }
   if (!dy || !x || !workspace) return SN_E_NULL;
   if (!aligned16(dy) || !aligned16(x) || (center && !aligned16(center)) || (lddy % 4) || (ldx % 4)) return SN_E_ALIGN;
-  if (workspace_bytes < sn_wgrad_workspace_bytes(rows, J, C)) return SN_E_WORKSPACE;
-  const bool x3 = gemm_variant() != 0;
-  int nslab = wgrad_slabs(rows);
+  int nslab = wgrad_slabs(rows), spm = 1;
   if (x3 && nslab > kCUs) nslab = kCUs;      // one resident workgroup per CU
+  if (segmented) {
+    const int64_t nseg = rows / rows_per_seg;
+    spm = (int)(kCUs / nseg);
+    if (spm < 1) spm = 1;
+    if ((int64_t)spm * 16 > rows_per_seg) spm = (int)((rows_per_seg + 15) / 16);
+    if (nseg * spm > INT_MAX) return SN_E_RANGE;
+    nslab = (int)(nseg * spm);
+  }
+  if (workspace_bytes < (size_t)nslab * 128 * ((size_t)C + 1) * sizeof(float)) return SN_E_WORKSPACE;
   float *partial = static_cast<float *>(workspace);
   float *colpart = dysum ? partial + (size_t)nslab * 128 * C : nullptr;
+  const int64_t sr = segmented ? rows_per_seg : 0;
   if (x3 && C == 128)
-    hipLaunchKernelGGL((wgrad_x3_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
+    hipLaunchKernelGGL((wgrad_x3_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
   else if (x3)
-    hipLaunchKernelGGL((wgrad_x3_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
+    hipLaunchKernelGGL((wgrad_x3_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
   else if (C == 128)
     hipLaunchKernelGGL((wgrad_mfma_k<1>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
   else
     hipLaunchKernelGGL((wgrad_mfma_k<2>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
-  hipLaunchKernelGGL(wgrad_reduce_k, dim3((J * C + (dysum ? J : 0) + 63) / 64), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G,
-                     colpart, dysum);
+  const int64_t extra = (dysum ? J : 0) + (segmented ? (int64_t)(nslab / spm) * J : 0);
+  hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)((J * C + extra + 63) / 64)), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G,
+                     colpart, dysum, segmented ? seg_dysum : nullptr, spm);
   return launch_status();
+}
+
+int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                 int32_t J, int32_t C, float *G, double *dysum, void *workspace, size_t workspace_bytes, void *stream) {
+  return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, 0, nullptr, workspace, workspace_bytes, stream);
+}
+
+size_t sn_wgrad_seg_workspace_bytes(int64_t rows, int64_t rows_per_seg, int32_t J, int32_t C) {
+  (void)J;
+  if (C < 1 || rows_per_seg < 1 || rows < 0) return 0;
+  const int64_t nseg = rows / rows_per_seg;
+  int64_t spm = kCUs / (nseg > 0 ? nseg : 1);
+  if (spm < 1) spm = 1;
+  return (size_t)(nseg * spm) * 128 * ((size_t)C + 1) * sizeof(float);
+}
+
+int sn_wgrad_seg_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                     int64_t rows_per_seg, int32_t J, int32_t C, float *G, double *dysum, float *seg_dysum, void *workspace,
+                     size_t workspace_bytes, void *stream) {
+  if (rows_per_seg < 1) return SN_E_SHAPE;
+  return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, rows_per_seg, seg_dysum, workspace, workspace_bytes, stream);
 }
 
 int sn_avg_fwd_prep_f32(const float *segsum, const float *inv_count, int64_t nseg, int32_t C, int64_t rows_per_seg,

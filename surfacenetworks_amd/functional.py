@@ -382,8 +382,7 @@ def avg_stage_backward(state, mask_rows, inv_count, nseg, per, dy, gadd):
     e, m, W, Wf, s, mean, invstd, beta, has_bias = state
     dy = dy.contiguous()
     rows, C = e.shape
-    G1, sdy = kernels.wgrad(dy, e, mean[:C], want_colsum=True)
-    Sg = kernels.segment_colsum(dy, None, per, nseg)
+    G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per)          # per-mesh column sums of dy from the same pass
     Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
     dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows, has_bias)
     segvec = kernels.avg_bwd_segvec(Sg, Wf[:, C:], m, mean[C:], Bc[C:], Cc[C:], inv_count, per)

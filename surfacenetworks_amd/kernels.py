@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg",
+    "avg_stage_supported", "avg_fwd_prep", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg",
 ]
 
 
@@ -411,6 +411,23 @@ def avg_bwd_segvec(seg_dy, Wf2, m, mu2, B2, C2, inv_count, rows_per_seg: int):
     _lib.call("sn_avg_bwd_segvec_f32", _p(seg_dy), _p(Wf2), _ld(Wf2), _p(m), _p(mu2), _p(B2), _p(C2), _p(inv_count.contiguous()),
               rows_per_seg, nseg, J, C, _p(out), _stream())
     return out
+
+
+def wgrad_seg(dy, x, center, rows_per_seg: int):
+    """(G, colsum(dy) fp64, per-mesh colsum(dy) (nseg, J) fp32) in one pass (sn_wgrad_seg_f32)."""
+    _dev(dy, x, center)
+    rows, J = dy.shape
+    C = x.shape[1]
+    nseg = rows // rows_per_seg
+    dev = dy.device
+    G = torch.empty((J, C), dtype=torch.float32, device=dev)
+    dysum = torch.empty(J, dtype=torch.float64, device=dev)
+    seg = torch.empty((nseg, J), dtype=torch.float32, device=dev)
+    ws_bytes = int(_lib.load().sn_wgrad_seg_workspace_bytes(rows, rows_per_seg, J, C))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.call("sn_wgrad_seg_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, rows_per_seg, J, C, _p(G), _p(dysum), _p(seg),
+              _p(ws), ws_bytes, _stream())
+    return G, dysum, seg
 
 
 def linear_fwd_segbias(x, W, segbias, rows_per_seg: int, residual=None, y_elu=None, want_y: bool = True):

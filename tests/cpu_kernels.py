@@ -241,6 +241,12 @@ def avg_bwd_segvec(seg_dy, Wf2, m, mu2, B2, C2, inv_count, rows_per_seg):
     return (v * inv_count.double().reshape(-1, 1)).float()
 
 
+def wgrad_seg(dy, x, center, rows_per_seg):
+    G, sdy = wgrad(dy, x, center, want_colsum=True)
+    nseg = dy.shape[0] // rows_per_seg
+    return G, sdy, dy.double().reshape(nseg, rows_per_seg, -1).sum(1).float()
+
+
 def linear_fwd_segbias(x, W, segbias, rows_per_seg, residual=None, y_elu=None, want_y=True):
     seg = torch.arange(x.shape[0]) // rows_per_seg
     y = (x.double() @ W.double().t()).float() + segbias[seg]

@@ -338,3 +338,17 @@ def test_linear_fwd_with_per_mesh_bias_and_dgrad_through_elu(nseg, per):
     got2 = kernels.linear_dgrad_eluseg(dev(dy), dev(Wd)[:, :C], dev(xw)[:, :C], dev(cen), dev(B), dev(Cc), dev(segv), per).cpu().numpy()
     pre2 = pre - mask[:, None] * segv[seg] + segv[seg]
     assert rel_err(got2, pre2 * np.where(e > 0, 1.0, e.astype(np.float64) + 1.0)) < 2e-6
+
+
+@pytest.mark.parametrize("nseg,per", [(3, 150), (7, 33), (2, 5041), (300, 40)])
+def test_wgrad_with_per_mesh_column_sums(nseg, per):
+    """sn_wgrad_seg_f32: mesh-aligned row slabs — same G and colsum(dy) as the flat split, plus per-mesh sums of dy."""
+    rng = np.random.default_rng(nseg + per)
+    rows, J, C = nseg * per, 128, 128
+    dy = rng.standard_normal((rows, J)).astype(np.float32)
+    x = rng.standard_normal((rows, C)).astype(np.float32)
+    cen = rng.standard_normal(C).astype(np.float32)
+    G, sdy, seg = kernels.wgrad_seg(dev(dy), dev(x), dev(cen), per)
+    assert rel_err(G.cpu().numpy(), dy.astype(np.float64).T @ (x - cen).astype(np.float64)) < 2e-6
+    assert rel_err(sdy.cpu().numpy(), dy.astype(np.float64).sum(0)) < 2e-6
+    assert rel_err(seg.cpu().numpy(), dy.astype(np.float64).reshape(nseg, per, J).sum(1)) < 2e-6
