@@ -273,6 +273,9 @@ int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W,
  * per-mesh bias), of the weight gradient and of the input gradient are nseg x C algebra on the per-mesh mean m:
  * sn_avg_fwd_prep_f32   : m = segsum * inv_count;  stats (2 x 2C fp64, the layout sn_bn_fold_f32 reads) = [stats1 |
  *                         rows_per_seg * sum_mesh m, rows_per_seg * sum_mesh m^2]  (stats1 = sn_colstats_f32 of e).
+ * sn_avg_stats_f32      : the two above in ONE pass over e (per-mesh masked sums, and sums / sums of squares of all rows,
+ *                         fp64): m and stats as sn_avg_fwd_prep_f32 would produce them from sn_segment_colsum_f32 +
+ *                         sn_colstats_f32.
  * sn_seg_affine_f32     : out[g, j] = bias[j] + sum_c A[g, c] * W[j, c]  — the per-mesh bias  m·Wf[:, C:]^T + bf  consumed
  *                         by sn_linear_fwd_segbias_f32.
  * sn_avg_bwd_gc_f32     : Gc (J x 2C) = [ G1 | sum_mesh seg_dy[mesh]^T (m[mesh] - mu2) ]  (G1 = sn_wgrad_f32 of the first
@@ -291,6 +294,9 @@ int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64
                          int64_t rows_per_seg, int64_t nseg, int32_t C, void *stream);
 int sn_avg_fwd_prep_f32(const float *segsum, const float *inv_count, int64_t nseg, int32_t C, int64_t rows_per_seg,
                         const double *stats1, float *m, double *stats, void *stream);
+size_t sn_avg_stats_workspace_bytes(int64_t rows_per_seg, int64_t nseg, int32_t C);
+int sn_avg_stats_f32(const float *e, int64_t ld, const float *mask, const float *inv_count, int64_t rows_per_seg, int64_t nseg,
+                     int32_t C, float *m, double *stats, void *workspace, size_t workspace_bytes, void *stream);
 int sn_seg_affine_f32(const float *A, int64_t nseg, int32_t K, const float *W, int64_t ldw, const float *bias, int32_t J,
                       float *out, void *stream);
 int sn_avg_bwd_gc_f32(const float *G1, const float *seg_dy, const float *m, const float *mu2, int64_t nseg, int32_t J,

@@ -60,6 +60,8 @@ SIGNATURES = {
     "sn_linear_dgrad_eluseg_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp, _i64,
                                              _i64, _i32, _i32, _vp]),
     "sn_avg_fwd_prep_f32": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
+    "sn_avg_stats_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "sn_avg_stats_f32": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
     "sn_seg_affine_f32": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     "sn_avg_bwd_gc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "sn_avg_bwd_segvec_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),

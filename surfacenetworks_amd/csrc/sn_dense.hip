@@ -707,6 +707,88 @@ __global__ __launch_bounds__(kWG) void avg_bwd_segvec_k(const float *__restrict_
   out[t] = (float)(acc * (double)inv_count[g]);
 }
 
+// One pass over e for everything the half-width global-average stage needs from it: per-mesh MASKED column sums (-> the
+// mean m), and the unmasked column sums / sums of squares of all rows (-> BatchNorm statistics of the first half).
+// Stage 1: grid (kSegSlabs, nseg), partial[mesh][slab][3][C] fp64 (masked sum | sum | sum of squares).
+__global__ __launch_bounds__(kWG) void segstats_k(const float *__restrict__ x, int64_t ld, const float *__restrict__ mask,
+                                                  int64_t rows_per_seg, int C, double *__restrict__ partial) {
+  extern __shared__ double sm[];               // [lanes_r][3C]
+  const int cw = C / 4, lanes_r = kWG / cw;
+  const int cg = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int64_t seg = blockIdx.y;
+  const int64_t per = (rows_per_seg + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = seg * rows_per_seg + (int64_t)blockIdx.x * per;
+  int64_t r1 = r0 + per;
+  const int64_t rend = (seg + 1) * rows_per_seg;
+  r1 = r1 < rend ? r1 : rend;
+  double s[4] = {0, 0, 0, 0}, u[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+#pragma unroll 4
+  for (int64_t r = r0 + rl; r < r1; r += lanes_r) {
+    const float mk = mask ? mask[r] : 1.f;
+    const f4 v = ld4_s(x + r * ld + cg * 4, 0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double d = (double)v[k];
+      s[k] += (double)(mk * v[k]);
+      u[k] += d;
+      q[k] += d * d;
+    }
+  }
+  double *o = sm + (int64_t)rl * 3 * C + cg * 4;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    o[k] = s[k];
+    o[C + k] = u[k];
+    o[2 * C + k] = q[k];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * C; i += kWG) {
+    double t = 0;
+    for (int l = 0; l < lanes_r; ++l) t += sm[(int64_t)l * 3 * C + i];
+    partial[((int64_t)seg * gridDim.x + blockIdx.x) * 3 * C + i] = t;
+  }
+}
+// Stage 2 (grid C/32 blocks of 32 columns x 8 mesh groups): m = masked sum * inv_count, and
+// stats (2 x 2C fp64) = [ sum | per * sum_mesh m ;  sum of squares | per * sum_mesh m^2 ]  (the layout sn_bn_fold_f32 reads)
+__global__ __launch_bounds__(kWG) void segstats_final_k(const double *__restrict__ partial, int nslab, int nseg, int C,
+                                                        const float *__restrict__ inv_count, double per,
+                                                        float *__restrict__ m, double *__restrict__ stats) {
+  __shared__ double sm[4][8][32];
+  const int cl = threadIdx.x & 31, gg = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double U = 0, Q = 0, S1 = 0, S2 = 0;
+  if (c < C)
+    for (int g = gg; g < nseg; g += 8) {
+      double ms = 0;
+      const double *p = partial + (int64_t)g * nslab * 3 * C + c;
+#pragma unroll 8
+      for (int sl = 0; sl < nslab; ++sl) {
+        ms += p[(int64_t)sl * 3 * C];
+        U += p[(int64_t)sl * 3 * C + C];
+        Q += p[(int64_t)sl * 3 * C + 2 * C];
+      }
+      const float mv = (float)ms * inv_count[g];
+      m[(int64_t)g * C + c] = mv;
+      S1 += (double)mv;
+      S2 += (double)mv * (double)mv;
+    }
+  sm[0][gg][cl] = U; sm[1][gg][cl] = Q; sm[2][gg][cl] = S1; sm[3][gg][cl] = S2;
+  __syncthreads();
+  if (gg == 0 && c < C) {
+    double t[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      t[k] = 0;
+#pragma unroll
+      for (int l = 0; l < 8; ++l) t[k] += sm[k][l][cl];
+    }
+    stats[c] = t[0];
+    stats[C + c] = per * t[2];
+    stats[2 * C + c] = t[1];
+    stats[3 * C + c] = per * t[3];
+  }
+}
+
 __global__ __launch_bounds__(kWG) void bcast_rows_k(const float *__restrict__ src, float *__restrict__ dst, int64_t ldd,
                                                     int64_t rows_per_seg, int64_t rows, int C, int nt) {
   const int cw = C / 4;
@@ -980,6 +1062,29 @@ int sn_segment_colsum_f32(const float *x, int64_t ld, const float *mask, int64_t
   const int64_t total = nseg * C;
   hipLaunchKernelGGL(segsum_final_k, dim3((unsigned)((total + kWG - 1) / kWG)), dim3(kWG), 0, s, partial, kSegSlabs, total,
                      (int)C, out);
+  return launch_status();
+}
+
+size_t sn_avg_stats_workspace_bytes(int64_t rows_per_seg, int64_t nseg, int32_t C) {
+  (void)rows_per_seg;
+  if (nseg < 0 || C < 1) return 0;
+  return (size_t)nseg * kSegSlabs * 3 * (size_t)C * sizeof(double);
+}
+
+int sn_avg_stats_f32(const float *e, int64_t ld, const float *mask, const float *inv_count, int64_t rows_per_seg, int64_t nseg,
+                     int32_t C, float *m, double *stats, void *workspace, size_t workspace_bytes, void *stream) {
+  if (rows_per_seg < 1 || nseg < 1 || C < 1 || ld < C) return SN_E_SHAPE;
+  if (!seg_shape_ok(C) || (ld % 4)) return SN_E_UNSUPPORTED;
+  if (!e || !inv_count || !m || !stats || !workspace) return SN_E_NULL;
+  if (!aligned16(e)) return SN_E_ALIGN;
+  if (workspace_bytes < sn_avg_stats_workspace_bytes(rows_per_seg, nseg, C)) return SN_E_WORKSPACE;
+  if (nseg > 65535) return SN_E_RANGE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double *partial = static_cast<double *>(workspace);
+  const size_t shm = (size_t)(kWG / (C / 4)) * 3 * C * sizeof(double);
+  hipLaunchKernelGGL(segstats_k, dim3(kSegSlabs, (unsigned)nseg), dim3(kWG), shm, s, e, ld, mask, rows_per_seg, (int)C, partial);
+  hipLaunchKernelGGL(segstats_final_k, dim3((unsigned)((C + 31) / 32)), dim3(kWG), 0, s, partial, kSegSlabs, (int)nseg, (int)C,
+                     inv_count, (double)rows_per_seg, m, stats);
   return launch_status();
 }
 

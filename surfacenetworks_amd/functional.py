@@ -365,8 +365,7 @@ def avg_stage_forward(e, mask_rows, inv_count, nseg, per, gamma, beta, W, b, run
     C real columns only.  Training-mode BatchNorm only (the caller checks kernels.avg_stage_supported)."""
     e = _rows2d(e)
     rows, C = e.shape
-    ssum = kernels.segment_colsum(e, mask_rows, per, nseg)
-    m, stats = kernels.avg_fwd_prep(ssum, inv_count, per, kernels.colstats(e))
+    m, stats = kernels.avg_stats(e, mask_rows, inv_count, per, nseg)       # per-mesh mean + BatchNorm statistics, one pass over e
     mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, True, running_mean, running_var)
     segb = kernels.seg_affine(m, Wf[:, C:], bf)
     if residual is not None:

@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg",
 ]
 
 
@@ -382,6 +382,19 @@ def avg_fwd_prep(segsum, inv_count, rows_per_seg: int, stats1):
     stats = torch.empty((2, 2 * C), dtype=torch.float64, device=segsum.device)
     _lib.call("sn_avg_fwd_prep_f32", _p(segsum), _p(inv_count.contiguous()), nseg, C, rows_per_seg, _p(stats1), _p(m), _p(stats),
               _stream())
+    return m, stats
+
+
+def avg_stats(e, mask, inv_count, rows_per_seg: int, nseg: int):
+    """(m, stats) of avg_fwd_prep from ONE pass over e (sn_avg_stats_f32)."""
+    _dev(e, mask, inv_count)
+    C = e.shape[1]
+    m = torch.empty((nseg, C), dtype=torch.float32, device=e.device)
+    stats = torch.empty((2, 2 * C), dtype=torch.float64, device=e.device)
+    ws_bytes = int(_lib.load().sn_avg_stats_workspace_bytes(rows_per_seg, nseg, C))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=e.device)
+    _lib.call("sn_avg_stats_f32", _p(e), _ld(e), _p(mask), _p(inv_count.contiguous()), rows_per_seg, nseg, C, _p(m), _p(stats),
+              _p(ws), ws_bytes, _stream())
     return m, stats
 
 

@@ -227,6 +227,10 @@ def avg_fwd_prep(segsum, inv_count, rows_per_seg, stats1):
     return m, stats.contiguous()
 
 
+def avg_stats(e, mask, inv_count, rows_per_seg, nseg):
+    return avg_fwd_prep(segment_colsum(e, mask, rows_per_seg, nseg), inv_count, rows_per_seg, colstats(e))
+
+
 def seg_affine(A, W, bias):
     out = A.double() @ W.double().t()
     return (out + bias.double() if bias is not None else out).float()

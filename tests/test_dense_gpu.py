@@ -352,3 +352,19 @@ def test_wgrad_with_per_mesh_column_sums(nseg, per):
     assert rel_err(G.cpu().numpy(), dy.astype(np.float64).T @ (x - cen).astype(np.float64)) < 2e-6
     assert rel_err(sdy.cpu().numpy(), dy.astype(np.float64).sum(0)) < 2e-6
     assert rel_err(seg.cpu().numpy(), dy.astype(np.float64).reshape(nseg, per, J).sum(1)) < 2e-6
+
+
+@pytest.mark.parametrize("nseg,per", [(3, 150), (5, 33), (2, 5041)])
+def test_avg_stats_single_pass(nseg, per):
+    """sn_avg_stats_f32 == sn_segment_colsum_f32 + sn_colstats_f32 + sn_avg_fwd_prep_f32 (fp64 accumulation everywhere)."""
+    rng = np.random.default_rng(nseg * 31 + per)
+    rows, C = nseg * per, 128
+    wide = (rng.standard_normal((rows, 2 * C)) + 3.0).astype(np.float32)
+    e = dev(wide)[:, :C]
+    mask = (rng.random(rows) > 0.3).astype(np.float32)
+    inv = (1.0 / np.maximum(mask.reshape(nseg, per).sum(1), 1)).astype(np.float32)
+    m, stats = kernels.avg_stats(e, dev(mask), dev(inv), per, nseg)
+    ssum = kernels.segment_colsum(e, dev(mask), per, nseg)
+    m2, stats2 = kernels.avg_fwd_prep(ssum, dev(inv), per, kernels.colstats(e))
+    assert np.array_equal(m.cpu().numpy(), m2.cpu().numpy())
+    assert np.allclose(stats.cpu().numpy(), stats2.cpu().numpy(), rtol=1e-12, atol=0)
