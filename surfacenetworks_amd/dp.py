@@ -129,7 +129,10 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
                 off += t.numel()
 
 
-def sync_batchnorm(module: torch.nn.Module) -> torch.nn.Module:
-    """Opt-in: replace BatchNorm1d by SyncBatchNorm (all-reduce of per-channel sums) so that N replicas reproduce
-    the single-process statistics at the same global batch.  GPU/RCCL only."""
-    return torch.nn.SyncBatchNorm.convert_sync_batchnorm(module)
+def sync_batchnorm(enabled: bool = True, group=None) -> None:
+    """Opt-in: BatchNorm statistics of the GLOBAL batch in every fused BatchNorm+Linear (functional.set_bn_sync): the
+    per-channel sums and the row count are all-reduced in the forward, the two backward reductions in the backward, so N
+    replicas reproduce the single-process result at the same global batch (tests/test_dp_gloo.py)."""
+    from . import functional as snF
+
+    snF.set_bn_sync(enabled, group)

@@ -269,6 +269,60 @@ def dirac_vert_stage(DiA, f_out2d: torch.Tensor, e_v2d: torch.Tensor) -> torch.T
     return _DiracVertStage.apply(f_out2d, e_v2d, op)
 
 
+# ---- optional synchronised BatchNorm statistics over data-parallel replicas --------------------------------
+_BN_SYNC = None          # None: per-replica statistics (DDP semantics, default) | True / a process group: global statistics
+
+
+def set_bn_sync(enabled: bool = True, group=None) -> None:
+    """Make every fused BatchNorm+Linear use statistics of the GLOBAL batch: the per-channel sums (fp64) and the row count
+    are all-reduced in the forward, G = dy^T(x - mean) and colsum(dy) in the backward, so that N replicas reproduce the
+    single-process result at the same global batch (parameter gradients are returned divided by N: the gradient all-reduce
+    (SUM) then restores them).  Costs one small collective per layer and direction and a host read of the global row
+    count (shards may have different padded sizes)."""
+    global _BN_SYNC
+    _BN_SYNC = (group if group is not None else True) if enabled else None
+
+
+def _sync_world():
+    import torch.distributed as dist
+
+    if _BN_SYNC is None or not (dist.is_available() and dist.is_initialized()):
+        return None, 1
+    grp = None if _BN_SYNC is True else _BN_SYNC
+    n = dist.get_world_size(grp)
+    return (grp, n) if n > 1 else (None, 1)
+
+
+def _sync_stats(stats, rows: int):
+    grp, n = _sync_world()
+    if n == 1:
+        return stats, rows
+    import torch.distributed as dist
+
+    buf = torch.cat([stats.reshape(-1), stats.new_tensor([float(rows)])])
+    dist.all_reduce(buf, group=grp)
+    k = stats.numel()
+    return buf[:k].view_as(stats).contiguous(), int(round(float(buf[k].item())))
+
+
+def _sync_grad_stats(Gc, sdy):
+    """All-reduced (Gc, colsum(dy)) and the factor the parameter gradients derived from them must be multiplied by."""
+    grp, n = _sync_world()
+    if n == 1:
+        return Gc, sdy, 1.0
+    import torch.distributed as dist
+
+    Gc = Gc.contiguous()
+    dist.all_reduce(Gc, group=grp)
+    sdy = sdy.contiguous()
+    dist.all_reduce(sdy, group=grp)
+    return Gc, sdy, 1.0 / n
+
+
+def _scale_param_grads(scale, *grads):
+    return grads if scale == 1.0 else tuple(None if g is None else g * scale for g in grads)
+
+
 class _Const:
     __slots__ = ("v",)
 
@@ -306,7 +360,10 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     x = _rows2d(x)
     rows = x.shape[0]
     stats = kernels.colstats(x) if training else None
-    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training, running_mean,
+    rows_g = rows
+    if training:
+        stats, rows_g = _sync_stats(stats, rows)
+    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
                                                  running_var)
     if residual is not None:
         residual = _rows2d(residual)
@@ -318,7 +375,7 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
             y += residual
         if elu_out is not None:
             kernels.elu_into(y, elu_out)
-    return y, (x, W, Wf, s, mean, invstd, beta, training, b is not None)
+    return y, (x, W, Wf, s, mean, invstd, beta, training, b is not None, rows_g)
 
 
 def bnlin_backward(state, dy, need_dx=True, through_elu=None):
@@ -329,7 +386,7 @@ def bnlin_backward(state, dy, need_dx=True, through_elu=None):
     through_elu=(gadd,): x is a stage's concat buffer [e | P·e]; instead of dx the first element returned is the pair
     (dx[:, C/2:],  dx[:, :C/2] * elu'(e) + gadd) — the operand of the transposed propagation and the gradient that has
     already passed the activation (gadd may be None), produced by the GEMM epilogue when the fused kernel applies."""
-    x, W, Wf, s, mean, invstd, beta, training, has_bias = state
+    x, W, Wf, s, mean, invstd, beta, training, has_bias, rows_g = state
     dy = dy.contiguous()
     rows, C = x.shape
     J = dy.shape[1]
@@ -338,7 +395,11 @@ def bnlin_backward(state, dy, need_dx=True, through_elu=None):
         Gc, sdy = kernels.wgrad(dy, x, mean, want_colsum=True)      # colsum(dy) rides on the same pass over dy
     else:
         Gc, sdy = dy.t().mm(x - mean), kernels.colstats(dy)
-    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows, has_bias)
+    scale = 1.0
+    if training:
+        Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
+    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
     dx = None
     if through_elu is not None and training and kernels.linear_dgrad_elu_supported(J, C):
         dx = kernels.linear_dgrad_elu(dy, Wf, x, mean, Bc, Cc, through_elu[0])
@@ -366,24 +427,27 @@ def avg_stage_forward(e, mask_rows, inv_count, nseg, per, gamma, beta, W, b, run
     e = _rows2d(e)
     rows, C = e.shape
     m, stats = kernels.avg_stats(e, mask_rows, inv_count, per, nseg)       # per-mesh mean + BatchNorm statistics, one pass over e
-    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, True, running_mean, running_var)
+    stats, rows_g = _sync_stats(stats, rows)
+    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, True, running_mean, running_var)
     segb = kernels.seg_affine(m, Wf[:, C:], bf)
     if residual is not None:
         residual = _rows2d(residual)
     y = kernels.linear_fwd_segbias(e, Wf[:, :C], segb, per, residual, elu_out, want_y)
-    return y, (e, m, W, Wf, s, mean, invstd, beta, b is not None)
+    return y, (e, m, W, Wf, s, mean, invstd, beta, b is not None, rows_g)
 
 
 def avg_stage_backward(state, mask_rows, inv_count, nseg, per, dy, gadd):
     """Backward of avg_stage_forward THROUGH the ELU that produced e: returns (dL/d(pre-activation of e) + gadd, dgamma,
     dbeta, dW, db).  Second-half terms: G[:, C:] = sum_mesh S^T (m - mu2) with S the per-mesh column sums of dy; the gradient
     of the mean path, inv_count * (S·Wf2 + per ((m - mu2) B2 + C2)), is added per row inside the dgrad GEMM's epilogue."""
-    e, m, W, Wf, s, mean, invstd, beta, has_bias = state
+    e, m, W, Wf, s, mean, invstd, beta, has_bias, rows_g = state
     dy = dy.contiguous()
     rows, C = e.shape
     G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per)          # per-mesh column sums of dy from the same pass
     Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
-    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows, has_bias)
+    Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
+    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
     segvec = kernels.avg_bwd_segvec(Sg, Wf[:, C:], m, mean[C:], Bc[C:], Cc[C:], inv_count, per)
     g = kernels.linear_dgrad_eluseg(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, per, mask_rows, gadd)
     return g, dgamma, dbeta, dW, db

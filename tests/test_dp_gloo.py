@@ -99,6 +99,65 @@ def test_shard_gradients_sum_to_full_batch_world2():
         assert lerr < 1e-6 and same
 
 
+def _worker_syncbn(rank, world, port, q):
+    """Train-mode BatchNorm with synchronised statistics: two replicas of half the batch == one process on the full batch."""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      SN_DP_FORCE_CPU="1")
+    torch.set_num_threads(2)
+    import cpu_kernels
+
+    cpu_kernels.install()
+    from helpers import deterministic_init
+    from surfacenetworks_amd import arap, dp
+
+    dp.init_distributed("gloo")
+    # equal-size meshes with >= 32 vertices so that the half-width global-average stages run too
+    ds = arap.ClothSequences([(6, 6)] * 4, frames=44, op_frames=2, seed=9, device="cpu", model="dir")
+    G = 4
+    seq, off = np.arange(G), np.zeros(G, dtype=np.int64)
+    model = deterministic_init(arap.DirModel(), 3).train()
+    ref = deterministic_init(arap.DirModel(), 3).train()
+    bucket = dp.FlatGradBucket(model.parameters())
+    mine = dp.shard_round_robin(G, rank, world)
+    batch = ds.sample_batch(len(mine), None, seq_ids=seq[mine], offsets=off[mine])
+    dp.sync_batchnorm(True)
+    loss, _ = arap.forward_loss(model, batch, G)
+    loss.backward()
+    bucket.all_reduce()
+    g_dp = bucket.flat.clone()
+    dp.sync_batchnorm(False)
+    full = ds.sample_batch(G, None, seq_ids=seq, offsets=off)
+    l_full, _ = arap.forward_loss(ref, full, G)
+    l_full.backward()
+    g_full = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    err = ((g_dp - g_full).norm() / g_full.norm()).item()
+    lsum = loss.detach().clone()
+    dist.all_reduce(lsum)
+    rv = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+             for (ka, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()) if "running" in ka)
+    q.put((rank, err, abs(lsum.item() - l_full.item()) / abs(l_full.item()), rv))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_synchronised_batchnorm_world2_equals_full_batch():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_syncbn, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    for rank, err, lerr, rv in sorted(q.get(timeout=10) for _ in range(2)):
+        assert err < 1e-5, f"rank {rank}: sync-BN shard gradients differ from the full-batch gradient by {err:.2e}"
+        assert lerr < 1e-6 and rv < 1e-5
+
+
 def test_sharding_helpers():
     from surfacenetworks_amd import dp
 
