@@ -134,7 +134,8 @@ def main():
 
     def eager_step():
         batch = ds.sample_batch(n_local, rng, seq_ids=seq_ids)          # every local mesh once, random start frame
-        return arap.train_step(model, opt, batch, global_batch=global_batch, grad_sync=bucket.all_reduce, zero_grads=bucket.zero_)
+        # gradients are stored, not accumulated (.grad = None before the backward); bucket.sync() packs + all-reduces them
+        return arap.train_step(model, opt, batch, global_batch=global_batch, grad_sync=bucket.sync, zero_grads=bucket.detach_grads)
 
     graphed = None
 
@@ -154,6 +155,8 @@ def main():
     for _ in range(3):
         eager_step()
     if not args.no_graph:
+        for p_, v_ in zip(bucket.params, bucket._views()):          # the captured step accumulates into the static bucket slices
+            p_.grad = v_
         graphed = arap.GraphedTrainStep(model, opt, ds.sample_batch(n_local, rng, seq_ids=seq_ids),
                                         global_batch=global_batch, bucket=bucket)
     for _ in range(args.warmup):

@@ -105,6 +105,41 @@ class FlatGradBucket:
         self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         return self._work
 
+    def detach_grads(self):
+        """Leave `.grad = None` on every parameter: the next backward then STORES each gradient instead of adding it into
+        its bucket slice (one small kernel launch per parameter saved), and no zeroing pass is needed.  `sync()` brings
+        the gradients back into the bucket when there is anything to reduce."""
+        for p in self.params:
+            p.grad = None
+
+    def sync(self):
+        """After a backward that followed `detach_grads()`: with one rank nothing is copied (the optimizer reads the
+        fresh gradients); with several ranks the gradients are packed into the flat buffer by one multi-tensor copy,
+        all-reduced (SUM) and the parameters' `.grad` re-pointed at the bucket slices."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+            return None
+        grads = [p.grad for p in self.params]
+        have = [(v, g) for v, g in zip(self._views(), grads) if g is not None]
+        missing = [v for v, g in zip(self._views(), grads) if g is None]
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        if missing:
+            torch._foreach_zero_(missing)
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        for p, v in zip(self.params, self._views()):
+            p.grad = v
+        return None
+
+    def _views(self):
+        if getattr(self, "_view_list", None) is None:
+            out, off = [], 0
+            for p in self.params:
+                n = p.numel()
+                out.append(self.flat[off: off + n].view_as(p))
+                off += n
+            self._view_list = out
+        return self._view_list
+
     def wait(self):
         if self._work is not None:
             self._work.wait()

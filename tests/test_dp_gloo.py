@@ -60,9 +60,20 @@ def _worker(rank, world, port, q):
     mine = dp.shard_round_robin(G, rank, world)
     batch = ds.sample_batch(len(mine), None, seq_ids=seq[mine], offsets=off[mine])
     opt = arap.make_optimizer(model)
+    # variant 1: gradients stored (not accumulated) by the backward, packed into the bucket and all-reduced by sync()
+    bucket.detach_grads()
+    l1, _ = arap.forward_loss(model, batch, G)
+    l1.backward()
+    assert all(p.grad is not None and p.grad.untyped_storage().data_ptr() != bucket.flat.untyped_storage().data_ptr()
+               for p in model.parameters())
+    bucket.sync()
+    assert bucket.check_views()
+    g_sync = bucket.flat.clone()
+    # variant 2: zero the bucket, accumulate into its slices, all-reduce in place
     loss = arap.train_step(model, opt, batch, global_batch=G, grad_sync=bucket.all_reduce)
     assert bucket.check_views()                               # zero_grad(set_to_none=False) keeps the views alive
     g_dp = bucket.flat.clone()
+    assert torch.allclose(g_sync, g_dp, rtol=1e-6, atol=1e-9)
 
     # single-process full batch on the same data
     full = ds.sample_batch(G, None, seq_ids=seq, offsets=off)
