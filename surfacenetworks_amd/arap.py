@@ -213,36 +213,20 @@ def forward_loss(model, batch: Batch, global_batch: Optional[int] = None):
 
 
 class GraphedTrainStep:
-    """train_step with forward + loss + backward replayed from one hipGraph (graphs.GraphedStep); the gradient
+    """train_step with forward + loss + backward replayed from one hipGraph (graphs.GraphedTrainStep); the gradient
     all-reduce and the optimizer stay eager.  `example` fixes the batch signature (and becomes the static batch)."""
 
     def __init__(self, model, optimizer, example: Batch, global_batch: Optional[int] = None, bucket=None):
-        from .graphs import GraphedStep
+        from .graphs import GraphedTrainStep as _G
 
-        self.optimizer = optimizer
-        params = [p for p in model.parameters() if p.requires_grad]
-        for p in params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        grads = [p.grad for p in params]
-        zero = bucket.zero_ if bucket is not None else (lambda: torch._foreach_zero_(grads))
-
-        def body(b):
-            loss, _ = forward_loss(model, b, global_batch)
-            loss.backward()
-            return loss
-
-        self.step = GraphedStep(body, example, zero, preserve=list(model.buffers()))
+        self._g = _G(model, optimizer, example, lambda m, b: forward_loss(m, b, global_batch)[0], bucket)
+        self.step, self.optimizer = self._g.step, optimizer
 
     def matches(self, batch: Batch) -> bool:
-        return self.step.matches(batch)
+        return self._g.matches(batch)
 
     def __call__(self, batch: Batch, grad_sync=None):
-        loss = self.step(batch)
-        if grad_sync is not None:
-            grad_sync()
-        self.optimizer.step()
-        return loss
+        return self._g(batch, grad_sync)
 
 
 def train_step(model, optimizer, batch: Batch, global_batch: Optional[int] = None, grad_sync=None, zero_grads=None):

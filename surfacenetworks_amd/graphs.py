@@ -23,7 +23,7 @@ import torch
 
 from .operators import SparseOperator
 
-__all__ = ["operator_tensors", "batch_tensors", "batch_signature", "GraphedStep"]
+__all__ = ["operator_tensors", "batch_tensors", "batch_signature", "GraphedStep", "GraphedTrainStep"]
 
 
 def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
@@ -43,7 +43,7 @@ def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
 
 def batch_tensors(batch) -> List[torch.Tensor]:
     """Device tensors of a Batch-like object (inputs, targets, mask, then L / Di / DiA arrays)."""
-    out = [batch.inputs, batch.targets, batch.mask]
+    out = [t for t in (batch.inputs, batch.targets, batch.mask) if t is not None]
     for name in ("L", "Di", "DiA"):
         out.extend(operator_tensors(getattr(batch, name, None)))
     return out
@@ -118,3 +118,35 @@ class GraphedStep:
     def __call__(self, batch) -> torch.Tensor:
         self.load(batch)
         return self.replay()
+
+
+
+class GraphedTrainStep:
+    """A training step whose forward + loss + backward is one hipGraph replay; the gradient all-reduce and the optimizer
+    stay eager.  `loss_of(model, batch) -> loss`; `example` fixes the batch signature and becomes the static batch."""
+
+    def __init__(self, model, optimizer, example, loss_of: Callable, bucket=None):
+        self.optimizer = optimizer
+        params = [p for p in model.parameters() if p.requires_grad]
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        grads = [p.grad for p in params]
+        zero = bucket.zero_ if bucket is not None else (lambda: torch._foreach_zero_(grads))
+
+        def body(b):
+            loss = loss_of(model, b)
+            loss.backward()
+            return loss
+
+        self.step = GraphedStep(body, example, zero, preserve=list(model.buffers()))
+
+    def matches(self, batch) -> bool:
+        return self.step.matches(batch)
+
+    def __call__(self, batch, grad_sync=None):
+        loss = self.step(batch)
+        if grad_sync is not None:
+            grad_sync()
+        self.optimizer.step()
+        return loss

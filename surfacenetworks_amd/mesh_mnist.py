@@ -140,6 +140,15 @@ def forward_loss(model, batch: Batch):
     return F.nll_loss(out, batch.targets), out                                  # main.py:159
 
 
+def graphed_train_step(model, optimizer, example: Batch, bucket=None):
+    """Training step with forward + loss + backward replayed from one hipGraph (graphs.GraphedTrainStep) — these models
+    are launch-bound when run eagerly (≈500 launches of a few microseconds per step).  Needs batches of one signature
+    (e.g. MeshDigits(fixed_vertices=...)); check `.matches(batch)`."""
+    from .graphs import GraphedTrainStep
+
+    return GraphedTrainStep(model, optimizer, example, lambda m, b: forward_loss(m, b)[0], bucket)
+
+
 def train_step(model, optimizer, batch: Batch, grad_sync=None):
     loss, _ = forward_loss(model, batch)
     optimizer.zero_grad(set_to_none=False)

@@ -38,6 +38,17 @@ def main():
         opt = mm.make_optimizer(model)
         ids = np.arange(B)
         dt = timed(lambda: mm.train_step(model, opt, ds.sample_batch(B, rng, ids=ids)), steps)
+        ex = ds.sample_batch(B, rng, ids=ids)
+        try:
+            g = mm.graphed_train_step(model, opt, ex)
+            nb = ds.sample_batch(B, rng, ids=ids)
+            if g.matches(nb):
+                dtg = timed(lambda: g(ds.sample_batch(B, rng, ids=ids)), steps)
+                print(f"{what}: hipGraph replay of fwd+loss+bwd: {dtg * 1e3:.2f} ms/step, {B / dtg:.0f} meshes/s")
+            else:
+                print(f"{what}: batches have varying signatures (ragged meshes): no graph replay")
+        except Exception as exc:  # noqa: BLE001
+            print(f"{what}: graph capture failed: {exc}")
         print(f"{what}: batch {B}, {dt * 1e3:.2f} ms/step, {B / dt:.0f} meshes/s")
     elif what == "faust_lap":
         ds = dc.TorusBodies(4, device=dev)
