@@ -82,6 +82,16 @@ def load() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; "
                 "g.build()'` (hipcc --offload-arch=gfx950). surfacenetworks_amd has no CPU/eager fallback.")
+        # The HIP runtime must be initialised BEFORE the library (whose load registers its code objects) is mapped: loaded
+        # first, every later launch fails with hipErrorNoDevice (observed with ROCm 7.2 / torch 2.10: `build()` followed
+        # by `smoke()` in one process).  On a box without a GPU there is nothing to initialise and only the symbols are used.
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                torch.cuda.init()
+        except ImportError:
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

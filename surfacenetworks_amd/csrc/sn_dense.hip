@@ -860,6 +860,7 @@ size_t sn_colstats_workspace_bytes(int64_t rows, int32_t C) {
 
 int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *out, void *workspace,
                     size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || C < 1 || C > 4096 || ld < C) return SN_E_SHAPE;
   if (!out) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
@@ -893,6 +894,7 @@ size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C) {
 static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                         int32_t J, int32_t C, float *G, double *dysum, int64_t rows_per_seg, float *seg_dysum,
                         void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldx < C) return SN_E_SHAPE;
   if (J > 128 || (J % 4) || (C != 128 && C != 256)) return SN_E_UNSUPPORTED;
   if (!G) return SN_E_NULL;
@@ -937,6 +939,7 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
 
 int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                  int32_t J, int32_t C, float *G, double *dysum, void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, 0, nullptr, workspace, workspace_bytes, stream);
 }
 
@@ -952,12 +955,14 @@ size_t sn_wgrad_seg_workspace_bytes(int64_t rows, int64_t rows_per_seg, int32_t 
 int sn_wgrad_seg_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                      int64_t rows_per_seg, int32_t J, int32_t C, float *G, double *dysum, float *seg_dysum, void *workspace,
                      size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows_per_seg < 1) return SN_E_SHAPE;
   return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, rows_per_seg, seg_dysum, workspace, workspace_bytes, stream);
 }
 
 int sn_avg_fwd_prep_f32(const float *segsum, const float *inv_count, int64_t nseg, int32_t C, int64_t rows_per_seg,
                         const double *stats1, float *m, double *stats, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (nseg < 1 || C < 1 || rows_per_seg < 1) return SN_E_SHAPE;
   if (!segsum || !inv_count || !stats1 || !m || !stats) return SN_E_NULL;
   hipLaunchKernelGGL(avg_fwd_prep_k, dim3((C + kWG - 1) / kWG), dim3(kWG), 0, static_cast<hipStream_t>(stream), segsum,
@@ -967,6 +972,7 @@ int sn_avg_fwd_prep_f32(const float *segsum, const float *inv_count, int64_t nse
 
 int sn_seg_affine_f32(const float *A, int64_t nseg, int32_t K, const float *W, int64_t ldw, const float *bias, int32_t J,
                       float *out, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (nseg < 1 || K < 1 || J < 1 || ldw < K) return SN_E_SHAPE;
   if (!A || !W || !out) return SN_E_NULL;
   hipLaunchKernelGGL(seg_affine_k, dim3((unsigned)((nseg * J + kWG - 1) / kWG)), dim3(kWG), 0,
@@ -976,6 +982,7 @@ int sn_seg_affine_f32(const float *A, int64_t nseg, int32_t K, const float *W, i
 
 int sn_avg_bwd_gc_f32(const float *G1, const float *seg_dy, const float *m, const float *mu2, int64_t nseg, int32_t J,
                       int32_t C, float *Gc, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (nseg < 1 || J < 1 || C < 1) return SN_E_SHAPE;
   if (!G1 || !seg_dy || !m || !mu2 || !Gc) return SN_E_NULL;
   hipLaunchKernelGGL(avg_bwd_gc_k, dim3((unsigned)((J * 2 * C + kWG - 1) / kWG)), dim3(kWG), 0,
@@ -986,6 +993,7 @@ int sn_avg_bwd_gc_f32(const float *G1, const float *seg_dy, const float *m, cons
 int sn_avg_bwd_segvec_f32(const float *seg_dy, const float *Wf2, int64_t ldw, const float *m, const float *mu2,
                           const float *B2, const float *C2, const float *inv_count, int64_t rows_per_seg, int64_t nseg,
                           int32_t J, int32_t C, float *out, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (nseg < 1 || J < 1 || C < 1 || ldw < C || rows_per_seg < 1) return SN_E_SHAPE;
   if (!seg_dy || !Wf2 || !m || !mu2 || !B2 || !C2 || !inv_count || !out) return SN_E_NULL;
   hipLaunchKernelGGL(avg_bwd_segvec_k, dim3((unsigned)((nseg * C + kWG - 1) / kWG)), dim3(kWG), 0,
@@ -996,6 +1004,7 @@ int sn_avg_bwd_segvec_f32(const float *seg_dy, const float *Wf2, int64_t ldw, co
 
 int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
                            const float *Cc, int64_t rows, int32_t C, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || C < 1 || lddx < C || ldx < C) return SN_E_SHAPE;
   if (rows == 0) return SN_OK;
   if (!dx || !x || !B || !Cc) return SN_E_NULL;
@@ -1015,6 +1024,7 @@ int sn_bn_fold_f32(const double *stats, int64_t rows, const float *gamma, const 
                    const float *b, int32_t J, int32_t C, double eps, double momentum, int32_t training,
                    float *running_mean, float *running_var, float *mean, float *invstd, float *s, float *t,
                    float *Wf, float *bf, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || C > 1024) return SN_E_SHAPE;
   if (!gamma || !beta || !W || !mean || !invstd || !s || !t || !Wf || !bf) return SN_E_NULL;
   if (training ? !stats : (!running_mean || !running_var)) return SN_E_NULL;
@@ -1026,6 +1036,7 @@ int sn_bn_fold_f32(const double *stats, int64_t rows, const float *gamma, const 
 int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W, const float *s, const float *invstd,
                          const float *beta, int64_t rows, int32_t J, int32_t C, float *dW, float *db, float *dgamma,
                          float *dbeta, float *Bc, float *Cc, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 1 || J < 1 || C < 1) return SN_E_SHAPE;
   if (!Gc || !dystats || !W || !s || !invstd || !beta || !dW || !dgamma || !dbeta || !Bc || !Cc) return SN_E_NULL;
   hipLaunchKernelGGL(bn_bwd_coeffs_k, dim3((C + 31) / 32), dim3(kWG), 0, static_cast<hipStream_t>(stream), Gc,
@@ -1048,6 +1059,7 @@ static unsigned ew_grid(int64_t items) {
 
 int sn_segment_colsum_f32(const float *x, int64_t ld, const float *mask, int64_t rows_per_seg, int64_t nseg, int32_t C,
                           float *out, void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows_per_seg < 0 || nseg < 0 || C < 1 || ld < C) return SN_E_SHAPE;
   if (!seg_shape_ok(C) || (ld % 4)) return SN_E_UNSUPPORTED;
   if (nseg == 0) return SN_OK;
@@ -1073,6 +1085,7 @@ size_t sn_avg_stats_workspace_bytes(int64_t rows_per_seg, int64_t nseg, int32_t 
 
 int sn_avg_stats_f32(const float *e, int64_t ld, const float *mask, const float *inv_count, int64_t rows_per_seg, int64_t nseg,
                      int32_t C, float *m, double *stats, void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows_per_seg < 1 || nseg < 1 || C < 1 || ld < C) return SN_E_SHAPE;
   if (!seg_shape_ok(C) || (ld % 4)) return SN_E_UNSUPPORTED;
   if (!e || !inv_count || !m || !stats || !workspace) return SN_E_NULL;
@@ -1090,6 +1103,7 @@ int sn_avg_stats_f32(const float *e, int64_t ld, const float *mask, const float 
 
 int sn_bcast_rows_f32(const float *src, float *dst, int64_t ldd, int64_t rows_per_seg, int64_t nseg, int32_t C,
                       void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows_per_seg < 0 || nseg < 0 || C < 1 || ldd < C) return SN_E_SHAPE;
   if ((C % 4) || (ldd % 4)) return SN_E_UNSUPPORTED;
   const int64_t rows = rows_per_seg * nseg;
@@ -1104,6 +1118,7 @@ int sn_bcast_rows_f32(const float *src, float *dst, int64_t ldd, int64_t rows_pe
 int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64_t ldo, const float *bias,
                          const float *mask, const float *gadd, int64_t ldga, float *gsrc, int64_t ldgs,
                          int64_t rows_per_seg, int64_t nseg, int32_t C, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows_per_seg < 0 || nseg < 0 || C < 1 || ldg < C || ldo < C || ldgs < C || (gadd && ldga < C)) return SN_E_SHAPE;
   if ((C % 4) || (ldg % 4) || (ldo % 4) || (ldgs % 4) || (gadd && (ldga % 4))) return SN_E_UNSUPPORTED;
   const int64_t rows = rows_per_seg * nseg;

@@ -531,6 +531,7 @@ extern "C" {
 int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias,
                       const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu, int64_t lde,
                       int64_t rows, int32_t K, int32_t J, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J)) return SN_E_SHAPE;
   if (J != 128 || (K != 128 && K != 256)) return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
@@ -568,6 +569,7 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
 int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
                         const float *center, const float *B, const float *Cc, float *dx, int64_t lddx, int64_t rows,
                         int32_t J, int32_t C, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || lddx < C) return SN_E_SHAPE;
   if (J != 128 || (C != 128 && C != 256)) return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
@@ -599,6 +601,7 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
                             const float *center, const float *B, const float *Cc, float *dx_hi, int64_t lddx, float *gact,
                             int64_t ldga, const float *gadd, int64_t ldgadd, int64_t rows, int32_t J, int32_t C,
                             void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 2 || lddy < J || ldw < C || lddx < C / 2 || ldga < C / 2 || ldx < C) return SN_E_SHAPE;
   if (J != 128 || (C != 128 && C != 256) || gemm_variant() == 0) return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
@@ -624,6 +627,7 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
 int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
                               int64_t rows_per_seg, const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu,
                               int64_t lde, int64_t rows, int32_t K, int32_t J, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J) || rows_per_seg < 1) return SN_E_SHAPE;
   if (J != 128 || (K != 128 && K != 256) || rows_per_seg < 32 || gemm_variant() == 0) return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
@@ -652,6 +656,7 @@ int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, in
                                const float *center, const float *B, const float *Cc, const float *segvec,
                                int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,
                                int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || ldga < C || ldx < C || rows_per_seg < 1) return SN_E_SHAPE;
   if (J != 128 || (C != 128 && C != 256) || rows_per_seg < 32 || gemm_variant() == 0) return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;

@@ -858,6 +858,7 @@ const char *sn_status_string(int status) {
 static int spmm_csr_launch(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
                            int64_t nnz, const float *X, int64_t ldx, int32_t x_group, int32_t N, float *Y, int64_t ldy,
                            int32_t y_group, SpmmEpi epi, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (M < 0 || K < 0 || nnz < 0 || N < 1) return SN_E_SHAPE;
   if (!fits_i32(M + 1) || !fits_i32(K) || !fits_i32(nnz)) return SN_E_RANGE;
   if (M == 0) return SN_OK;
@@ -900,6 +901,7 @@ static int spmm_csr_launch(const int32_t *rowptr, const int32_t *colind, const f
 int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M,
                     int64_t K, int64_t nnz, const float *X, int64_t ldx, int32_t x_group, int32_t N,
                     float *Y, int64_t ldy, int32_t y_group, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   return spmm_csr_launch(rowptr, colind, vals, M, K, nnz, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{nullptr, 0, nullptr, 0},
                          stream);
 }
@@ -908,6 +910,7 @@ int sn_spmm_csr_elubwd_f32(const int32_t *rowptr, const int32_t *colind, const f
                            int64_t nnz, const float *X, int64_t ldx, int32_t x_group, int32_t N, const float *E,
                            int64_t lde, const float *G, int64_t ldg, float *Y, int64_t ldy, int32_t y_group,
                            void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (!E) return SN_E_NULL;
   return spmm_csr_launch(rowptr, colind, vals, M, K, nnz, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{E, lde, G, ldg}, stream);
 }
@@ -915,6 +918,7 @@ int sn_spmm_csr_elubwd_f32(const int32_t *rowptr, const int32_t *colind, const f
 static int spmm_bsr4_launch(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb, int64_t Kb,
                             int64_t nblocks, const float *X, int64_t ldx, int32_t x_group, int32_t N, float *Y,
                             int64_t ldy, int32_t y_group, SpmmEpi epi, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (Mb < 0 || Kb < 0 || nblocks < 0 || N < 1) return SN_E_SHAPE;
   if (!fits_i32(4 * Mb + 1) || !fits_i32(4 * Kb) || !fits_i32(nblocks)) return SN_E_RANGE;
   if (Mb == 0) return SN_OK;
@@ -951,6 +955,7 @@ static int spmm_bsr4_launch(const int32_t *b_rowptr, const int32_t *b_colind, co
 int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb,
                      int64_t Kb, int64_t nblocks, const float *X, int64_t ldx, int32_t x_group,
                      int32_t N, float *Y, int64_t ldy, int32_t y_group, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   return spmm_bsr4_launch(b_rowptr, b_colind, b_vals, Mb, Kb, nblocks, X, ldx, x_group, N, Y, ldy, y_group,
                           SpmmEpi{nullptr, 0, nullptr, 0}, stream);
 }
@@ -959,6 +964,7 @@ int sn_spmm_bsr4_elubwd_f32(const int32_t *b_rowptr, const int32_t *b_colind, co
                             int64_t nblocks, const float *X, int64_t ldx, int32_t x_group, int32_t N, const float *E,
                             int64_t lde, const float *G, int64_t ldg, float *Y, int64_t ldy, int32_t y_group,
                             void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (!E) return SN_E_NULL;
   return spmm_bsr4_launch(b_rowptr, b_colind, b_vals, Mb, Kb, nblocks, X, ldx, x_group, N, Y, ldy, y_group,
                           SpmmEpi{E, lde, G, ldg}, stream);
@@ -967,6 +973,7 @@ int sn_spmm_bsr4_elubwd_f32(const int32_t *b_rowptr, const int32_t *b_colind, co
 int sn_coo_to_csr_i32(const int64_t *idx_batch, const int64_t *idx_row, const int64_t *idx_col,
                       int64_t nnz, int64_t B, int64_t R, int64_t Kb, int32_t *rowptr, int32_t *colind,
                       void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (nnz < 0 || B < 1 || R < 0 || Kb < 0) return SN_E_SHAPE;
   const int64_t M = B * R;
   if (!fits_i32(M + 1) || !fits_i32(B * Kb) || !fits_i32(nnz)) return SN_E_RANGE;
@@ -994,6 +1001,7 @@ size_t sn_csr_transpose_workspace_bytes(int64_t M, int64_t K, int64_t nnz) {
 int sn_csr_transpose_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M,
                          int64_t K, int64_t nnz, int32_t *t_rowptr, int32_t *t_colind, float *t_vals,
                          void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (M < 0 || K < 0 || nnz < 0) return SN_E_SHAPE;
   if (!fits_i32(M + 1) || !fits_i32(K + 1) || !fits_i32(nnz)) return SN_E_RANGE;
   if (!t_rowptr || !rowptr) return SN_E_NULL;
@@ -1021,6 +1029,7 @@ int sn_csr_transpose_f32(const int32_t *rowptr, const int32_t *colind, const flo
 
 int sn_bsr4_count(const int32_t *rowptr, const int32_t *colind, int64_t M, int64_t K, int32_t *b_rowptr,
                   void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (M < 0 || K < 0) return SN_E_SHAPE;
   if ((M & 3) || (K & 3)) return SN_E_UNSUPPORTED;
   if (!fits_i32(M + 1) || !fits_i32(K)) return SN_E_RANGE;
@@ -1038,6 +1047,7 @@ int sn_bsr4_count(const int32_t *rowptr, const int32_t *colind, int64_t M, int64
 
 int sn_bsr4_fill(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
                  const int32_t *b_rowptr, int32_t *b_colind, float *b_vals, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (M < 0 || K < 0) return SN_E_SHAPE;
   if ((M & 3) || (K & 3)) return SN_E_UNSUPPORTED;
   if (!rowptr || !b_rowptr) return SN_E_NULL;
@@ -1055,6 +1065,7 @@ int sn_blockdiag_concat_i32(const int32_t *pool_rowptr, const int32_t *pool_coli
                             const float *pool_vals, const int64_t *desc, int64_t B, int64_t size0,
                             int64_t size1, int64_t total, int32_t vals_per_entry, int32_t *out_rowptr,
                             int32_t *out_colind, float *out_vals, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (B < 0 || size0 < 0 || size1 < 0 || total < 0) return SN_E_SHAPE;
   if (vals_per_entry != 1 && vals_per_entry != 16) return SN_E_UNSUPPORTED;
   if (!fits_i32(B * size0 + 1) || !fits_i32(B * size1) || !fits_i32(total)) return SN_E_RANGE;
@@ -1078,6 +1089,7 @@ int sn_blockdiag_concat_i32(const int32_t *pool_rowptr, const int32_t *pool_coli
 
 int sn_elu_into_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int64_t rows, int32_t C,
                     void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || C < 1 || lds < C || ldd < C) return SN_E_SHAPE;
   if (rows == 0) return SN_OK;
   if (!src || !dst) return SN_E_NULL;
@@ -1095,6 +1107,7 @@ int sn_elu_into_f32(const float *src, int64_t lds, float *dst, int64_t ldd, int6
 int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64_t ldg2, const float *gadd, int64_t ldga,
                        const float *out, int64_t ldo, float *gsrc, int64_t ldgs, int64_t rows, int32_t C,
                        int32_t accumulate, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || C < 1 || ldg < C || ldo < C || ldgs < C || (gdst2 && ldg2 < C) || (gadd && ldga < C)) return SN_E_SHAPE;
   if (rows == 0) return SN_OK;
   if (!gdst || !out || !gsrc) return SN_E_NULL;

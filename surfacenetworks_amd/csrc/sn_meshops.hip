@@ -339,6 +339,7 @@ int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_
                             int32_t *di_colind, float *di_vals, float *diat_vals, int32_t *dia_rowptr,
                             int32_t *dia_colind, float *dia_vals, float *dit_vals, void *workspace,
                             size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (nV < 0 || nF < 0) return SN_E_SHAPE;
   if (4 * nV + 1 > INT_MAX || 12 * nF > INT_MAX) return SN_E_RANGE;
   if (!di_rowptr || !dia_rowptr) return SN_E_NULL;
@@ -374,6 +375,7 @@ size_t sn_laplacian_workspace_bytes(int64_t nV, int64_t nF) { return sn_dirac_wo
 int sn_laplacian_csr_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_t nF, int32_t phase,
                                int32_t *rowptr, int32_t *colind, float *vals, int32_t *status_flag,
                                void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (nV < 0 || nF < 0 || (phase != 0 && phase != 1)) return SN_E_SHAPE;
   if (nV + 1 > INT_MAX || 3 * nF > INT_MAX) return SN_E_RANGE;
   if (!rowptr) return SN_E_NULL;
