@@ -253,7 +253,7 @@ __device__ __forceinline__ f16v mfma_bf16(const u4 &a, const u4 &b, const f16v &
 // Workgroup = 8 waves with two roles (two waves per SIMD, so the SIMD interleaves them by itself):
 //   waves 0-3  matrix waves, 2 (dy tiles) x 2 (x tiles): fragments of the current image, 2 x 2·CT accumulators each,
 //              18 fragment reads per 48 MFMAs (CT = 2);
-//   waves 4-7  loader waves: 8 rows x 4 columns per thread and step, requested THREE steps ahead (three register sets),
+//   waves 4-7  loader waves: 8 rows x 4 columns per thread and step, requested FOUR steps ahead (four register sets),
 //              split on the vector ALU while the matrix waves multiply, written to the other image.
 // One workgroup barrier per step.
 constexpr int kWgradThreads = 512;
@@ -295,30 +295,53 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
 
   if (wave >= 4) {
     // ======================= loader waves =======================
+    // Tasks: 64 dy tasks (2 row groups x 32 column groups) = wave 4, then 64·CT x tasks = waves 5.. — a wave is all-dy or
+    // all-x, so the role-dependent work (column sums | centring) is wave-uniform control flow.
     const int task = tid - 256;
-    const bool active = task < 2 * NCG;
-    const int rg = active ? task / NCG : 0, cg = active ? task % NCG : 0;
-    const bool isdy = cg < 32;
-    const bool colok = active && (isdy ? 4 * cg < J : true);
-    const float *src = isdy ? dy + (colok ? 4 * cg : 0) : x + 4 * (cg - 32);
+    const bool active = task < 64 + 64 * CT;
+    const bool isdy = __builtin_amdgcn_readfirstlane(task) < 64;                       // wave-uniform
+    const int tl_ = isdy ? task : task - 64;
+    const int ncgt = isdy ? 32 : 32 * CT;                                               // column groups of my operand
+    const int rg = active ? tl_ / ncgt : 0, cgl = active ? tl_ % ncgt : 0;
+    const int cg = isdy ? cgl : 32 + cgl;                                               // column group in the image
+    const bool colok = active && (isdy ? 4 * cgl < J : true);
+    // address = wave-uniform row base (scalar arithmetic) + a 32-bit lane offset: no per-load vector address math
+    const float *opnd = isdy ? dy : x;
     const int64_t ld = isdy ? lddy : ldx;
-    const f4 mu = (!isdy && center) ? *reinterpret_cast<const f4 *>(center + 4 * (cg - 32)) : f4{0.f, 0.f, 0.f, 0.f};
+    const int lane_off = (int)(8 * rg * ld) + (colok ? 4 * cgl : 0);
+    const f4 mu = (!isdy && center) ? *reinterpret_cast<const f4 *>(center + 4 * cgl) : f4{0.f, 0.f, 0.f, 0.f};
+    const bool all_cols = __all(colok) != 0;                                            // wave-uniform: no column masking needed
     f4 dsum = {0.f, 0.f, 0.f, 0.f};          // dy loaders: column sums of their rows (the bias gradient)
-    f4 ra[8], rb[8], rc[8];                  // rows of three consecutive steps
+    f4 ra[8], rb[8], rc[8], rd[8];           // rows of four consecutive steps
     // The registers receive the raw loads only: anything computed from them here would make the compiler wait for the
     // data in the step that requests it.  Centring and the zeroing of rows past the slab happen at conversion time.
     auto load_step = [&](f4 (&raw)[8], int64_t s) {
-      const int64_t base = r0 + 16 * s + 8 * rg;
+      const int64_t base = r0 + 16 * s;
+      if (base + 16 <= r1) {                 // whole step inside the slab (wave-uniform): plain strided rows
+        const float *sb = opnd + base * ld;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int64_t row = base + j;
-        raw[j] = *reinterpret_cast<const f4 *>(src + (row < r1 ? row : r1 - 1) * ld);        // clamped: always in bounds
+        for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const f4 *>(sb + j * ld + lane_off);
+      } else {                               // last (or a prefetched, empty) step: rows past the slab re-read its last row
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int64_t row = base + 8 * rg + j;
+          raw[j] = *reinterpret_cast<const f4 *>(opnd + (row < r1 ? row : r1 - 1) * ld + (colok ? 4 * cgl : 0));
+        }
       }
     };
     auto convert_step = [&](f4 (&raw)[8], int64_t s, int buf) {
-      const int64_t base = r0 + 16 * s + 8 * rg;
+      const int64_t base = r0 + 16 * s;
+      if (base + 16 > r1 || !all_cols) {     // partial step / narrow dy: mask
 #pragma unroll
-      for (int j = 0; j < 8; ++j) raw[j] = (colok && base + j < r1) ? raw[j] - mu : f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < 8; ++j) raw[j] = (colok && base + 8 * rg + j < r1) ? raw[j] : f4{0.f, 0.f, 0.f, 0.f};
+        if (!isdy) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) raw[j] = (base + 8 * rg + j < r1) ? raw[j] - mu : raw[j];
+        }
+      } else if (!isdy) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] -= mu;
+      }
       if (isdy) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) dsum += raw[j];
@@ -353,23 +376,28 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
       load_step(ra, 0);
       load_step(rb, 1);
       load_step(rc, 2);
+      load_step(rd, 3);
       convert_step(ra, 0, 0);
-      load_step(ra, 3);
+      load_step(ra, 4);
       // step s: the matrix waves work on image s&1; this wave converts step s+1 into the other image and re-fills the
-      // registers it frees with step s+4
+      // registers it frees with step s+5 (four register sets: up to four steps of rows in flight per thread)
       int64_t s = 0;
       while (true) {
         SN_STEP_BARRIER();
         convert_step(rb, s + 1, (int)((s + 1) & 1));
-        load_step(rb, s + 4);
+        load_step(rb, s + 5);
         if (++s >= nsteps) break;
         SN_STEP_BARRIER();
         convert_step(rc, s + 1, (int)((s + 1) & 1));
-        load_step(rc, s + 4);
+        load_step(rc, s + 5);
+        if (++s >= nsteps) break;
+        SN_STEP_BARRIER();
+        convert_step(rd, s + 1, (int)((s + 1) & 1));
+        load_step(rd, s + 5);
         if (++s >= nsteps) break;
         SN_STEP_BARRIER();
         convert_step(ra, s + 1, (int)((s + 1) & 1));
-        load_step(ra, s + 4);
+        load_step(ra, s + 5);
         if (++s >= nsteps) break;
       }
     }
