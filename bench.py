@@ -246,6 +246,9 @@ def main():
         "config": {"workload": f"as_rigid_as_possible Dirac temporal prediction: {n_local} grid-cloth meshes {GRID[0]}x{GRID[1]} "
                                f"(V=5041,F=9800) per GPU, C=128, 15 layers, fwd+loss+bwd+allreduce+Adam",
                    "meshes_per_gpu": n_local, "global_batch": global_batch, "parallelism": f"dp{world} (mesh sharding, flat-bucket RCCL all-reduce)",
+                   "linear_layers": ("fp32 operands and fp32 accumulation; products formed on the bf16 matrix pipe from an exact "
+                                     "3-piece bf16 split of every operand (6 partial products, error <= 2^-23 per term: fp32-accurate, "
+                                     "tests/test_dense_gpu.py); SN_GEMM_VARIANT=0 selects the fp32-MFMA kernels"),
                    "allocator": alloc, "operator_format": args.format, "operators": args.operators,
                    "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager", "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": dom_name + (" (the backward products Di^T, DiA^T, ELU backward fused into the store)" if "_epi" in dom_name
