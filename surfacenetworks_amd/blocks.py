@@ -252,8 +252,15 @@ def lap_block(mod, L, inputs):
 def avg_block(mod, mask, inputs):
     B, V, C = inputs.shape
     rows = B * V
-    mask_rows = mask.reshape(rows).contiguous()
-    inv_count = 1.0 / mask.reshape(B, V).sum(1, keepdim=True)
+    cached = getattr(mask, "_sn_avg", None)                  # the 7 global-average blocks of a model share one mask
+    key = (B, V, mask._version)                              # (in-place edits of the mask invalidate the cache)
+    if cached is None or cached[0] != key:
+        cached = (key, mask.reshape(rows).contiguous(), 1.0 / mask.reshape(B, V).sum(1, keepdim=True))
+        try:
+            mask._sn_avg = cached
+        except AttributeError:
+            pass
+    _, mask_rows, inv_count = cached
     a0, a1 = _bn_args(mod.bn_fc0), _bn_args(mod.bn_fc1)
     if a0[6] and a1[6] and kernels.avg_stage_supported(C, mod.bn_fc0.fc.weight.shape[0], V) and \
             mod.bn_fc0.fc.weight.shape[1] == 2 * C and mod.bn_fc1.fc.weight.shape[0] == C:
