@@ -183,6 +183,47 @@ class TorusBodies:
         return inputs, [(fr["G"], fr["label"], fr["label_inv"])], mask, L
 
 
+class PairBatch:
+    """One training pair (two independent samples, main.py:310-316) as a flat set of device tensors — what the hipGraph
+    replay needs as static inputs (graphs.GraphedTrainStep)."""
+
+    def __init__(self, ds: TorusBodies, ia: int, ib: int):
+        self.inX, self.tX, self.mX, self.LX = ds.sample(ia)
+        self.inY, self.tY, self.mY, self.LY = ds.sample(ib)
+
+    def owned(self) -> "PairBatch":
+        """A copy whose target tensors are private: `sample()` hands out the dataset's own (G, label, label_inv), and the
+        static batch of a captured step is overwritten in place by every `load()`."""
+        import copy
+
+        b = copy.copy(self)
+        b.tX = [tuple(t.clone() for t in trip) for trip in self.tX]
+        b.tY = [tuple(t.clone() for t in trip) for trip in self.tY]
+        return b
+
+    def graph_tensors(self):
+        from .graphs import operator_tensors
+
+        out = [self.inX, self.inY, self.mX, self.mY]
+        for t in (self.tX, self.tY):
+            for trip in t:
+                out.extend(trip)
+        return out + operator_tensors(self.LX) + operator_tensors(self.LY)
+
+
+def forward_loss(model, b: PairBatch):
+    out = model([b.LX, b.mX], [b.LY, b.mY], b.inX, b.inY)
+    return loss_fun_delta_cross_entropy(out, b.tX, b.tY)
+
+
+def graphed_train_step(model, optimizer, example: PairBatch, bucket=None):
+    """Training step with forward + loss + backward replayed from one hipGraph: a pair of 7000-row shapes is ~1000 launches
+    of a few microseconds, i.e. launch-bound when issued from Python."""
+    from .graphs import GraphedTrainStep
+
+    return GraphedTrainStep(model, optimizer, example.owned(), forward_loss, bucket)
+
+
 def train_step(model, optimizer, ds: TorusBodies, ia: int, ib: int, grad_sync=None):
     """main.py:310-327: two independent samples, siamese forward, delta-CE loss, Adam."""
     inX, tX, mX, LX = ds.sample(ia)

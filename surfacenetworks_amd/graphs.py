@@ -42,7 +42,10 @@ def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
 
 
 def batch_tensors(batch) -> List[torch.Tensor]:
-    """Device tensors of a Batch-like object (inputs, targets, mask, then L / Di / DiA arrays)."""
+    """Device tensors of a Batch-like object (inputs, targets, mask, then L / Di / DiA arrays); a batch type with another
+    layout supplies them itself through a `graph_tensors()` method."""
+    if hasattr(batch, "graph_tensors"):
+        return list(batch.graph_tensors())
     out = [t for t in (batch.inputs, batch.targets, batch.mask) if t is not None]
     for name in ("L", "Di", "DiA"):
         out.extend(operator_tensors(getattr(batch, name, None)))
@@ -64,7 +67,7 @@ class GraphedStep:
                  preserve: Optional[List[torch.Tensor]] = None):
         """`preserve`: tensors the body updates in place (BatchNorm running statistics) — restored after the eager
         warm-up runs so that capturing leaves the model state untouched."""
-        if not example.inputs.is_cuda:
+        if not batch_tensors(example)[0].is_cuda:
             raise RuntimeError("GraphedStep needs a GPU batch (hipGraph capture)")
         self.static = example
         self._static_tensors = batch_tensors(example)

@@ -56,3 +56,24 @@ def test_signature_mismatch_is_refused():
     assert not graphed.matches(other)
     with pytest.raises(ValueError):
         graphed(other)
+
+
+def test_graph_replay_of_the_siamese_pair_step():
+    """dense_correspondence: a batch type with its own tensor layout (PairBatch.graph_tensors).  The score matrix and the
+    cross entropy go through torch / hipBLASLt, whose kernel choice may differ under capture, so: equal to rounding."""
+    from surfacenetworks_amd import dense_correspondence as dc
+
+    torch.manual_seed(3)
+    ds = dc.TorusBodies(3, n=8, m=9, pad_to=80, seed=4, device=DEV)
+    model_e = dc.SiameseModel("lap", 15).to(DEV).train()
+    model_g = copy.deepcopy(model_e)
+    opt_e, opt_g = dc.make_optimizer(model_e), dc.make_optimizer(model_g)
+    graphed = dc.graphed_train_step(model_g, opt_g, dc.PairBatch(ds, 0, 1))
+    for ia, ib in [(1, 2), (2, 0)]:
+        le = dc.train_step(model_e, opt_e, ds, ia, ib)
+        pb = dc.PairBatch(ds, ia, ib)
+        assert graphed.matches(pb)
+        lg = graphed(pb)
+        assert torch.allclose(le.detach(), lg.detach(), rtol=1e-5, atol=1e-6), (le.item(), lg.item())
+        for pe, pg in zip(model_e.parameters(), model_g.parameters()):
+            assert torch.allclose(pe.detach(), pg.detach(), rtol=1e-3, atol=2e-5)

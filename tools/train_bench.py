@@ -61,6 +61,16 @@ def main():
             dc.train_step(model, opt, ds, k[0] % 4, (k[0] + 1) % 4)
         dt = timed(step, steps)
         print(f"{what}: 1 pair of 6890-vertex bodies (padded 7000), {dt * 1e3:.2f} ms/step, {2 / dt:.1f} meshes/s")
+        try:
+            g = dc.graphed_train_step(model, opt, dc.PairBatch(ds, 0, 1))
+
+            def gstep():
+                k[0] += 1
+                g(dc.PairBatch(ds, k[0] % 4, (k[0] + 1) % 4))
+            dtg = timed(gstep, steps)
+            print(f"{what}: hipGraph replay of fwd+loss+bwd: {dtg * 1e3:.2f} ms/step, {2 / dtg:.1f} meshes/s")
+        except Exception as exc:  # noqa: BLE001
+            print(f"{what}: graph capture failed: {exc!r}")
     elif what == "arap_lap":
         ds = arap.ClothSequences([(71, 71)] * 64, frames=44, op_frames=2, seed=3, device=dev, model="lap")
         model = arap.Model(15).to(dev).train()
