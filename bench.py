@@ -98,7 +98,8 @@ def main():
                          "kernel from Python (same kernels; pays off when the step is launch-bound: small batches, busy hosts)")
     ap.add_argument("--roofline-steps", type=int, default=5,
                     help="eager steps run AFTER the timed region with per-launch HIP events (graph mode only)")
-    ap.add_argument("--format", default="bsr4", choices=["bsr4", "csr"])
+    ap.add_argument("--format", default="q3", choices=["q3", "bsr4", "csr"],
+                    help="Dirac operator form: quaternion-packed blocks (default), 4x4 blocks, generic CSR")
     ap.add_argument("--operators", default="pool", choices=["pool", "device"],
                     help="pool: precomputed per-frame operators resident in HBM (default, = the reference's dataset); "
                          "device: Dirac operators rebuilt on the GPU from the frame coordinates every step")
@@ -200,7 +201,8 @@ def main():
     # (Di, DiA forward; Di^T, DiA^T backward), which differ only in which side is the face side.
     by_kernel = {}
     for tag, M, K, nnz, N, ms in recs:
-        kname = ("spmm_bsr4_lds" if "/bsr4" in tag else "spmm_csr_lds") + ("_epi" if "+e" in tag else "") + f"<N={N}>"
+        kname = ("spmm_q3_lds" if "/q3" in tag else "spmm_bsr4_lds" if "/bsr4" in tag else "spmm_csr_lds") + \
+                ("_epi" if "+e" in tag else "") + f"<N={N}>"
         by_kernel.setdefault(kname, []).append((tag, M, K, nnz, N, ms))
     dom_name = max(by_kernel, key=lambda k: sum(r[5] for r in by_kernel[k]))
     dom = by_kernel[dom_name]

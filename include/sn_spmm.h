@@ -93,6 +93,25 @@ int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const flo
                      float *Y, int64_t ldy, int32_t y_group,
                      void *stream);
 
+/* Quaternion-packed Dirac operators ("Q3").  Every 4x4 block of Di, DiA and their transposes is the matrix of a
+ * multiplication by a pure quaternion (src/utils/mesh.py:28-33: Q(0,e); :55-58: -Q/(2 Af) and its transpose times Af/Av),
+ *     M(p) = [[0, p1, p2, p3], [-p1, 0, p3, -p2], [-p2, -p3, 0, p1], [-p3, p2, -p1, 0]],
+ * i.e. three floats.  q_blk holds one 16-byte record (p1, p2, p3, block column as int32 bits) per block, b_rowptr is the
+ * BSR4 block-row pointer.  The operator stream is 16 instead of 68 bytes per block; results are bit-identical to
+ * sn_spmm_bsr4_f32 / sn_spmm_csr_f32 for finite X (same k-ascending FMA order; zeros contribute fma(0,x,acc) = acc).
+ * sn_bsr4_to_q3_f32 packs a BSR4 operator and sets *not_quaternion (device int32) to 1 if any block is not exactly M(p):
+ * the caller then keeps the BSR4 form.  sn_blockdiag_concat_i32 assembles pooled Q3 operators with vals_per_entry = 4
+ * (the column offset is applied inside the record; colind arguments are unused). */
+int sn_spmm_q3_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks,
+                   const float *X, int64_t ldx, int32_t x_group, int32_t N,
+                   float *Y, int64_t ldy, int32_t y_group, void *stream);
+int sn_spmm_q3_elubwd_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks,
+                          const float *X, int64_t ldx, int32_t x_group, int32_t N,
+                          const float *E, int64_t lde, const float *G, int64_t ldg,
+                          float *Y, int64_t ldy, int32_t y_group, void *stream);
+int sn_bsr4_to_q3_f32(const int32_t *b_colind, const float *b_vals, int64_t nblocks, float *q_blk,
+                      int32_t *not_quaternion, void *stream);
+
 /* The same two products with the backward of the ELU that precedes the propagation fused into the store:
  *     Y = (A·X) ∘ elu'(E) + G,      elu'(·) taken from the activation OUTPUT E: 1 where E > 0, E + 1 elsewhere
  * — with A = Lᵀ / Diᵀ / DiAᵀ this is the gradient that autograd assembles from the sparse product's backward
@@ -335,7 +354,8 @@ int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_
  * (sn_spmm_csr_f32 / sn_spmm_bsr4_f32 and their _elubwd forms) is issued with hipExtLaunchKernelGGL so that the KERNEL's own start and stop are
  * stamped into two events: durations carry no marker / kernel-boundary overhead and agree with rocprofv3's kernel trace.
  * sn_timing_drain waits for the recorded launches, writes up to `capacity` durations (ms) and 5 int64 per record
- * {kind (bit 0: 0 csr, 1 bsr4; bit 1: fused ELU-backward epilogue, E read; bit 2: G read too), M, K,
+ * {kind (bit 0: 0 csr, 1 blocked; bit 3: the blocked form is Q3; bit 1: fused ELU-backward epilogue, E read; bit 2: G read
+ *  too), M, K,
  *  nnz (csr) | nblocks (bsr4), N}, and clears the list.
  * ------------------------------------------------------------------------------------------ */
 int     sn_timing_enable(int32_t on);

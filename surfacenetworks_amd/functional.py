@@ -21,15 +21,22 @@ from .operators import SparseOperator, as_operator
 __all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg_propagate", "bn_linear", "bnlin_forward",
            "bnlin_backward", "bn_prepare", "set_dirac_format", "SpmmTimer"]
 
-_USE_BSR4 = True
+_DIRAC_FORMAT = "q3"
 
 
 def set_dirac_format(fmt: str) -> None:
-    """'bsr4' (default: packed 4x4 blocks when the operator has them) or 'csr' (always the generic kernel)."""
-    global _USE_BSR4
-    if fmt not in ("bsr4", "csr"):
+    """Kernel / storage form of the group-4 (quaternionic Dirac) products:
+    'q3'   (default) quaternion-packed blocks, 16 bytes each, when the operator's blocks are pure-quaternion matrices;
+                     operators that are not fall back to 'bsr4';
+    'bsr4' packed 4x4 blocks (68 bytes each) when the operator has them;
+    'csr'  always the generic CSR kernel."""
+    global _DIRAC_FORMAT
+    if fmt not in ("q3", "bsr4", "csr"):
         raise ValueError(fmt)
-    _USE_BSR4 = fmt == "bsr4"
+    _DIRAC_FORMAT = fmt
+    from . import operators
+
+    operators._POOL_FORMAT = "q3" if fmt == "q3" else "bsr4"
 
 
 class SpmmTimer:
@@ -61,7 +68,7 @@ class SpmmTimer:
 
     def results(self):
         """[(tag, M, K, nnz, N, milliseconds)] for every launch recorded while the timer was active; the tag ends in
-        /csr or /bsr4, then +e (fused ELU-backward epilogue: E read) and +g (G read too)."""
+        /csr, /bsr4 or /q3, then +e (fused ELU-backward epilogue: E read) and +g (G read too)."""
         import ctypes
         import numpy as np
 
@@ -78,7 +85,7 @@ class SpmmTimer:
         for i, (tag, op) in enumerate(self.tags):
             kind, M, K, _, N = meta[i]
             nnz = op if isinstance(op, int) else op.nnz
-            fmt = ("/bsr4" if kind & 1 else "/csr") + ("+e" if kind & 2 else "") + ("+g" if kind & 4 else "")
+            fmt = ("/q3" if kind & 8 else "/bsr4" if kind & 1 else "/csr") + ("+e" if kind & 2 else "") + ("+g" if kind & 4 else "")
             out.append((tag + fmt, int(M), int(K), int(nnz), int(N), float(ms[i])))
         return out
 
@@ -98,16 +105,22 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
     if timer is not None:
         known = op._nnz_cache if op._nnz_cache is not None else (int(op._csr[1].numel()) if op._csr is not None else None)
         timer.tags.append((tag, op if known is None else known))
-    b = op.bsr4() if (_USE_BSR4 and group == 4) else None
+    e, g = elubwd if elubwd is not None else (None, None)
+    if group == 4 and _DIRAC_FORMAT == "q3":
+        q = op.q3()
+        if q is not None:
+            kernels.spmm_q3(q[0], q[1], M // 4, K // 4, x, y, group, e, g)
+            return
+    b = op.bsr4() if (_DIRAC_FORMAT != "csr" and group == 4) else None
     if b is not None:
         if elubwd is None:
             kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
         else:
-            kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, x, elubwd[0], elubwd[1], y, group)
+            kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, x, e, g, y, group)
     elif elubwd is None:
         kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x, y, group)
     else:
-        kernels.spmm_csr_elubwd(op.rowptr, op.colind, op.vals, M, K, x, elubwd[0], elubwd[1], y, group)
+        kernels.spmm_csr_elubwd(op.rowptr, op.colind, op.vals, M, K, x, e, g, y, group)
 
 
 def _rows2d(x: torch.Tensor) -> torch.Tensor:

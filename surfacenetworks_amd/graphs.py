@@ -38,6 +38,8 @@ def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
             out.extend(o._csr)
         if isinstance(o._bsr4, tuple):
             out.extend(o._bsr4)
+        if isinstance(o._q3, tuple):
+            out.extend(o._q3)
     return out
 
 

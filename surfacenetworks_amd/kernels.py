@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 __all__ = [
-    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
+    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
@@ -94,6 +94,33 @@ def spmm_bsr4_elubwd(b_rowptr, b_colind, b_vals, Mb: int, Kb: int, x, e, g, y, g
               _p(x), ldx, group, N, _p(e), lde, _p(g), ldg, _p(y), ldy, group, _stream())
 
 
+def spmm_q3(b_rowptr, q_blk, Mb: int, Kb: int, x, y, group: int = 1, e=None, g=None) -> None:
+    """y <- A·x for a quaternion-packed Dirac operator (sn_spmm_q3_f32); with e: (A·x) * elu'(e) + g (sn_spmm_q3_elubwd_f32)."""
+    _dev(b_rowptr, q_blk, x, y, e, g)
+    N = y.shape[1] // group
+    ldx = _check_dense(x, 4 * Kb, group, N, "x")
+    ldy = _check_dense(y, 4 * Mb, group, N, "y")
+    nblk = int(q_blk.shape[0])
+    if e is None:
+        _lib.call("sn_spmm_q3_f32", _p(b_rowptr), _p(q_blk), Mb, Kb, nblk, _p(x), ldx, group, N, _p(y), ldy, group, _stream())
+    else:
+        lde = _check_dense(e, 4 * Mb, group, N, "e")
+        ldg = _check_dense(g, 4 * Mb, group, N, "g") if g is not None else 0
+        _lib.call("sn_spmm_q3_elubwd_f32", _p(b_rowptr), _p(q_blk), Mb, Kb, nblk, _p(x), ldx, group, N, _p(e), lde, _p(g), ldg,
+                  _p(y), ldy, group, _stream())
+
+
+def bsr4_to_q3(b_colind, b_vals):
+    """(q_blk (nblocks, 4) fp32 with the block column in the 4th word's bits, flag (1,) int32 device tensor: 1 if some block
+    is not a pure-quaternion matrix) — sn_bsr4_to_q3_f32.  The flag is left on the device: the caller decides when to read it."""
+    _dev(b_colind, b_vals)
+    nblk = int(b_colind.numel())
+    q = torch.empty((nblk, 4), dtype=torch.float32, device=b_colind.device)
+    flag = torch.empty(1, dtype=torch.int32, device=b_colind.device)
+    _lib.call("sn_bsr4_to_q3_f32", _p(b_colind), _p(b_vals), nblk, _p(q), _p(flag), _stream())
+    return q, flag
+
+
 def coo_to_csr(idx_batch, idx_row, idx_col, B: int, R: int, Kb: int):
     """Sorted int64 COO index rows -> (rowptr int32 [B*R+1], colind int32 [nnz]) of the block-diagonal operator."""
     _dev(idx_batch, idx_row, idx_col)
@@ -145,7 +172,7 @@ def blockdiag_concat(pool_rowptr, pool_colind, pool_vals, desc, size0: int, size
     B = int(desc.shape[0])
     dev = pool_rowptr.device
     out_rowptr = torch.empty(B * size0 + 1, dtype=torch.int32, device=dev)
-    out_colind = torch.empty(total, dtype=torch.int32, device=dev)
+    out_colind = torch.empty(total, dtype=torch.int32, device=dev) if vpe != 4 else None      # Q3 records carry the column
     out_vals = torch.empty(total * vpe, dtype=torch.float32, device=dev)
     _lib.call("sn_blockdiag_concat_i32", _p(pool_rowptr), _p(pool_colind), _p(pool_vals), _p(desc), B, size0, size1,
               total, vpe, _p(out_rowptr), _p(out_colind), _p(out_vals), _stream())

@@ -27,6 +27,9 @@ __all__ = ["SparseOperator", "OperatorPool", "as_operator", "dirac_operators_fro
 
 # A BSR4 copy is kept when zero-fill costs at most this much extra storage over CSR entries.
 _BSR4_MAX_FILL = 1.6
+# Form in which pools of Dirac operators assemble a batch: "q3" (quaternion-packed, default) or "bsr4"
+# (functional.set_dirac_format switches both this and the kernel choice).
+_POOL_FORMAT = "q3"
 
 
 class SparseOperator:
@@ -41,12 +44,12 @@ class SparseOperator:
     requires_grad = False
 
     def __init__(self, rowptr, colind, vals, shape, *, batch: int = 1, transpose: "Optional[SparseOperator]" = None,
-                 bsr4=None):
+                 bsr4=None, q3=None):
         M, K = int(shape[0]), int(shape[1])
         if rowptr is None:
-            if not isinstance(bsr4, tuple):
-                raise ValueError("an operator needs CSR arrays or a BSR4 triple")
-            self._csr = None                     # BSR4-only operator (device-built Dirac); CSR is expanded on demand
+            if not isinstance(bsr4, tuple) and not isinstance(q3, tuple):
+                raise ValueError("an operator needs CSR arrays, a BSR4 triple or a Q3 pair")
+            self._csr = None                     # block-form-only operator (Dirac); CSR is expanded on demand
         else:
             if rowptr.dtype != torch.int32 or colind.dtype != torch.int32 or vals.dtype != torch.float32:
                 raise TypeError("SparseOperator wants int32 rowptr/colind and float32 vals")
@@ -62,6 +65,7 @@ class SparseOperator:
         self._t_strong = None
         self._t_weak = weakref.ref(transpose) if transpose is not None else None
         self._bsr4 = bsr4                        # (b_rowptr, b_colind, b_vals) | None | False (= not worthwhile)
+        self._q3 = q3                            # (b_rowptr, q_blk) quaternion-packed form | None (unknown) | False (not a Dirac-type operator)
 
     @property
     def _t(self) -> "Optional[SparseOperator]":
@@ -87,7 +91,7 @@ class SparseOperator:
     # CSR arrays; for a BSR4-only operator they are expanded once (explicit zeros of the blocks dropped)
     def _ensure_csr(self):
         if self._csr is None:
-            self._csr = _bsr4_to_csr(*self._bsr4, self._shape[0])
+            self._csr = _bsr4_to_csr(*self.bsr4(), self._shape[0])
         return self._csr
 
     @property
@@ -107,8 +111,10 @@ class SparseOperator:
         if self._nnz_cache is None:
             if self._csr is not None:
                 self._nnz_cache = int(self._csr[1].numel())
-            else:
+            elif isinstance(self._bsr4, tuple):
                 self._nnz_cache = int(torch.count_nonzero(self._bsr4[2]).item())
+            else:                                # Q3-only operator: every non-zero parameter appears four times in its block
+                self._nnz_cache = 4 * int(torch.count_nonzero(self._q3[1][:, :3]).item())
         return self._nnz_cache
 
     def _nnz(self) -> int:
@@ -116,7 +122,9 @@ class SparseOperator:
 
     @property
     def device(self):
-        return (self._csr[0] if self._csr is not None else self._bsr4[0]).device
+        if self._csr is not None:
+            return self._csr[0].device
+        return (self._bsr4[0] if isinstance(self._bsr4, tuple) else self._q3[0]).device
 
     @property
     def is_cuda(self) -> bool:
@@ -131,10 +139,11 @@ class SparseOperator:
             return self
         mv = lambda t: t.to(device)
         b = tuple(mv(t) for t in self._bsr4) if isinstance(self._bsr4, tuple) else None
+        q = tuple(mv(t) for t in self._q3) if isinstance(self._q3, tuple) else None
         if self._csr is None:
-            out = SparseOperator(None, None, None, self._shape, batch=self.batch, bsr4=b)
+            out = SparseOperator(None, None, None, self._shape, batch=self.batch, bsr4=b, q3=q)
         else:
-            out = SparseOperator(mv(self.rowptr), mv(self.colind), mv(self.vals), self._shape, batch=self.batch, bsr4=b)
+            out = SparseOperator(mv(self.rowptr), mv(self.colind), mv(self.vals), self._shape, batch=self.batch, bsr4=b, q3=q)
         if self._t is not None:
             t = self._t.to(device)
             t._t_strong, t._t_weak = None, weakref.ref(out)
@@ -165,8 +174,33 @@ class SparseOperator:
         op._t = opt
         return op
 
+    def q3(self):
+        """(b_rowptr, q_blk) — the quaternion-packed form (three floats + the block column per 4x4 block) — or None when the
+        operator's blocks are not pure-quaternion matrices.  Built from the BSR4 form on first use; the check reads one
+        flag back from the device (operators assembled by an OperatorPool arrive with the form already attached)."""
+        if self._q3 is None:
+            b = self.bsr4()
+            if b is None:
+                self._q3 = False
+            else:
+                q, flag = kernels.bsr4_to_q3(b[1], b[2])
+                self._q3 = (b[0], q.view(-1, 4)) if int(flag.item()) == 0 else False
+        return self._q3 or None
+
+    @classmethod
+    def from_q3(cls, fwd, bwd, shape, batch: int = 1) -> "SparseOperator":
+        """Operator and its transpose given as quaternion-packed pairs (b_rowptr, q_blk) — what an OperatorPool of Dirac
+        operators assembles per step."""
+        M, K = int(shape[0]), int(shape[1])
+        op = cls(None, None, None, (M, K), batch=batch, q3=tuple(fwd))
+        opt = cls(None, None, None, (K, M), batch=batch, q3=tuple(bwd), transpose=op)
+        op._t = opt
+        return op
+
     def bsr4(self):
         """(b_rowptr, b_colind, b_vals) or None when the 4x4-block form is not applicable / not worthwhile."""
+        if self._bsr4 is None and self._csr is None and isinstance(self._q3, tuple):
+            self._bsr4 = _q3_to_bsr4(*self._q3)          # export / fallback only
         if self._bsr4 is None:
             M, K = self._shape
             if M % 4 or K % 4 or self.nnz == 0:
@@ -214,6 +248,16 @@ class SparseOperator:
                              shape=self._shape)
 
 
+def _q3_to_bsr4(b_rowptr, q_blk):
+    """Expand quaternion-packed records to BSR4 (torch arithmetic; export / generic-kernel fallback only)."""
+    p1, p2, p3 = q_blk[:, 0], q_blk[:, 1], q_blk[:, 2]
+    col = q_blk[:, 3].contiguous().view(torch.int32)
+    z = torch.zeros_like(p1)
+    rows = [torch.stack([z, p1, p2, p3], 1), torch.stack([-p1, z, p3, -p2], 1), torch.stack([-p2, -p3, z, p1], 1),
+            torch.stack([-p3, p2, -p1, z], 1)]
+    return b_rowptr, col.clone(), torch.stack(rows, 1).reshape(-1).contiguous()
+
+
 def _bsr4_to_csr(b_rowptr, b_colind, b_vals, M: int):
     """Expand BSR4 to CSR with torch index arithmetic (not on the hot path: export / generic-kernel fallback only).
     Explicit zeros of the blocks are dropped so that the result equals the coalesced operator."""
@@ -255,6 +299,8 @@ def dirac_operators_from_mesh(V: torch.Tensor, F: torch.Tensor):
     di, diat, dia, dit = kernels.dirac_from_mesh(Vg.float(), Fg)
     Di = SparseOperator.from_bsr4(di, dit, (4 * B * nF, 4 * B * nV), batch=B)
     DiA = SparseOperator.from_bsr4(dia, diat, (4 * B * nV, 4 * B * nF), batch=B)
+    for o in (Di, Di._t, DiA, DiA._t):           # quaternion blocks by construction: pack without reading the check flag
+        o._q3 = (o._bsr4[0], kernels.bsr4_to_q3(o._bsr4[1], o._bsr4[2])[0].view(-1, 4))
     return Di, DiA
 
 
@@ -310,9 +356,16 @@ class OperatorPool:
         self._fwd = self._upload(fwd)
         self._bwd = self._upload([m.T.tocsr() for m in fwd])   # one-time host transpose at load, like the dataset prep
         self._fwd_b = self._bwd_b = None
+        self._fwd_q = self._bwd_q = None
         if self.want_bsr4:
             self._fwd_b = self._pool_bsr4(self._fwd, self.rows, self.cols)
             self._bwd_b = self._pool_bsr4(self._bwd, self.cols, self.rows)
+            # quaternion-packed pools when every block of every mesh is a pure-quaternion matrix (Dirac operators are)
+            fq, ff = kernels.bsr4_to_q3(self._fwd_b["colind"], self._fwd_b["vals"])
+            bq, bf = kernels.bsr4_to_q3(self._bwd_b["colind"], self._bwd_b["vals"])
+            if int(ff.item()) == 0 and int(bf.item()) == 0:
+                self._fwd_q = dict(self._fwd_b, vals=fq.reshape(-1), colind=None)
+                self._bwd_q = dict(self._bwd_b, vals=bq.reshape(-1), colind=None)
 
     # pooled CSR: dict(rowptr, colind, vals device tensors; rp_off, e_off, cnt host int64 arrays)
     def _upload(self, mats):
@@ -368,9 +421,14 @@ class OperatorPool:
             # view of the batch is expanded from the blocks on demand (export / generic-kernel fallback).
             if size0 % 4 or size1 % 4:
                 raise ValueError("BSR4 pools need size0 and size1 to be multiples of 4")
-            fb = self._concat(self._fwd_b, sel, rows // 4, size0 // 4, size1 // 4, 16)
-            bb = self._concat(self._bwd_b, sel, cols // 4, size1 // 4, size0 // 4, 16)
-            op = SparseOperator.from_bsr4(fb, bb, (B * size0, B * size1), batch=B)
+            if self._fwd_q is not None and _POOL_FORMAT == "q3":
+                fr, _, fq = self._concat(self._fwd_q, sel, rows // 4, size0 // 4, size1 // 4, 4)
+                br_, _, bq = self._concat(self._bwd_q, sel, cols // 4, size1 // 4, size0 // 4, 4)
+                op = SparseOperator.from_q3((fr, fq.view(-1, 4)), (br_, bq.view(-1, 4)), (B * size0, B * size1), batch=B)
+            else:
+                fb = self._concat(self._fwd_b, sel, rows // 4, size0 // 4, size1 // 4, 16)
+                bb = self._concat(self._bwd_b, sel, cols // 4, size1 // 4, size0 // 4, 16)
+                op = SparseOperator.from_bsr4(fb, bb, (B * size0, B * size1), batch=B)
             op._nnz_cache = op._t._nnz_cache = int(self._fwd["cnt"][sel].sum())      # entries of the pooled CSR: no sync
             return op
         f = self._concat(self._fwd, sel, rows, size0, size1, 1)

@@ -54,6 +54,34 @@ def spmm_bsr4_elubwd(b_rowptr, b_colind, b_vals, Mb, Kb, x, e, g, y, group=1):
     _elubwd_epilogue(y, e, g)
 
 
+def _q3_to_bsr4(q_blk):
+    q = _np(q_blk)
+    p1, p2, p3 = q[:, 0], q[:, 1], q[:, 2]
+    col = q[:, 3].copy().view(np.int32)
+    z = np.zeros_like(p1)
+    blocks = np.stack([np.stack([z, p1, p2, p3], 1), np.stack([-p1, z, p3, -p2], 1), np.stack([-p2, -p3, z, p1], 1),
+                       np.stack([-p3, p2, -p1, z], 1)], 1).astype(np.float32)
+    return torch.from_numpy(col), torch.from_numpy(blocks.reshape(-1))
+
+
+def spmm_q3(b_rowptr, q_blk, Mb, Kb, x, y, group=1, e=None, g=None):
+    bci, bv = _q3_to_bsr4(q_blk)
+    spmm_bsr4(b_rowptr, bci, bv, Mb, Kb, x, y, group)
+    if e is not None:
+        _elubwd_epilogue(y, e, g)
+
+
+def bsr4_to_q3(b_colind, b_vals):
+    b = _np(b_vals).reshape(-1, 4, 4)
+    p = b[:, 0, 1:4]
+    q = np.zeros((b.shape[0], 4), np.float32)
+    q[:, :3] = p
+    q[:, 3] = _np(b_colind).astype(np.int32).view(np.float32)
+    back = _q3_to_bsr4(torch.from_numpy(q))[1].numpy().reshape(-1, 4, 4)
+    flag = 0 if np.array_equal(back, b) else 1
+    return torch.from_numpy(q), torch.tensor([flag], dtype=torch.int32)
+
+
 def coo_to_csr(idx_batch, idx_row, idx_col, B, R, Kb):
     rp, ci = c_oracle.coo_to_csr(None if idx_batch is None else _np(idx_batch), _np(idx_row), _np(idx_col), B, R, Kb)
     return torch.from_numpy(rp), torch.from_numpy(ci)
@@ -68,6 +96,21 @@ def csr_to_bsr4(rowptr, colind, vals, M, K):
 
 
 def blockdiag_concat(pool_rowptr, pool_colind, pool_vals, desc, size0, size1, total, vpe=1):
+    if vpe == 4:                                   # Q3 records: the block column lives in the 4th word
+        rp, d = _np(pool_rowptr), _np(desc)
+        recs = _np(pool_vals).reshape(-1, 4)
+        out_rp = np.zeros(d.shape[0] * size0 + 1, np.int32)
+        out = np.zeros((total, 4), np.float32)
+        for b, (rp_off, e_off, nrows, out_off) in enumerate(d):
+            local = rp[rp_off: rp_off + nrows + 1]
+            cnt = int(local[-1])
+            row_ptr = np.concatenate([local[:-1], np.full(size0 - nrows, cnt, np.int32)]) + out_off
+            out_rp[b * size0: (b + 1) * size0] = row_ptr
+            r = recs[e_off: e_off + cnt].copy()
+            r[:, 3] = (r[:, 3].copy().view(np.int32) + b * size1).view(np.float32)
+            out[out_off: out_off + cnt] = r
+        out_rp[-1] = total
+        return torch.from_numpy(out_rp), None, torch.from_numpy(out.reshape(-1))
     out = c_oracle.blockdiag_concat(_np(pool_rowptr), _np(pool_colind), _np(pool_vals), _np(desc), size0, size1, total, vpe)
     return tuple(torch.from_numpy(a) for a in out)
 

@@ -10,21 +10,21 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("fmt", ["bsr4", "csr"])
+@pytest.mark.parametrize("fmt", ["q3", "bsr4", "csr"])
 @pytest.mark.parametrize("cname,C", pc.BLOCKS)
 @pytest.mark.parametrize("opkind", ["pool", "coo2d", "coo3d"])
 def test_blocks_match_reference(golden_dir, cname, C, opkind, fmt):
     from surfacenetworks_amd import functional as snF
 
-    if cname in ("AvgResNet2", "MlpResNet2") and (opkind != "pool" or fmt != "bsr4"):
+    if cname in ("AvgResNet2", "MlpResNet2") and (opkind != "pool" or fmt != "q3"):
         pytest.skip("no sparse operator in this block")
-    if cname == "LapResNet2" and fmt != "bsr4":
+    if cname == "LapResNet2" and fmt != "q3":
         pytest.skip("format switch only affects Dirac blocks")
     snF.set_dirac_format(fmt)
     try:
         pc.check_block(golden_dir, cname, C, opkind, DEV)
     finally:
-        snF.set_dirac_format("bsr4")
+        snF.set_dirac_format("q3")
 
 
 @pytest.mark.parametrize("tag", ["arap_dir", "arap_lap", "mnist_lap", "mnist_dir", "faust_lap"])

@@ -220,7 +220,7 @@ def test_elu_kernels():
     assert np.allclose(o3.cpu().numpy(), c_oracle.elu(x3), rtol=1e-6, atol=1e-7)
 
 
-@pytest.mark.parametrize("fmt", ["csr", "bsr4"])
+@pytest.mark.parametrize("fmt", ["csr", "bsr4", "q3"])
 def test_autograd_spmm_forward_backward(fmt):
     snF.set_dirac_format(fmt)
     try:
@@ -249,7 +249,7 @@ def test_autograd_spmm_forward_backward(fmt):
         assert np.array_equal(y2.detach().cpu().numpy(), want_y) and np.array_equal(xt2.grad.cpu().numpy(), want_g)
         assert as_operator(Ac) is as_operator(Ac)            # converted once per tensor
     finally:
-        snF.set_dirac_format("bsr4")
+        snF.set_dirac_format("q3")
 
 
 def test_cpu_tensors_raise():
@@ -289,7 +289,7 @@ def test_timing_facility_matches_event_bracketing():
             y = snF.spmm(op, x, 4)
         y.sum().backward()
     recs = t.results()
-    assert [r[0] for r in recs] == ["fwd/bsr4"] * 3 + ["bwd/bsr4"]
+    assert [r[0] for r in recs] == ["fwd/q3"] * 3 + ["bwd/q3"]        # quaternion-packed form is the default for Dirac operators
     assert all(r[1:3] == (M, K) for r in recs[:3]) and recs[3][1:3] == (K, M)
     assert all(r[3] == A.nnz and r[4] == 32 for r in recs)
     assert all(1e-4 < r[5] < 5.0 for r in recs)
@@ -348,3 +348,64 @@ def test_fused_elu_backward_epilogue_laplacian():
     y = torch.empty((V, N), device=DEV)
     kernels.spmm_csr_elubwd(*csr_dev(L), V, V, dev(X), dev(ecat)[:, :N], dev(G), y, 1)
     assert np.allclose(y.cpu().numpy(), want, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("N", [16, 32, 64, 128])
+@pytest.mark.parametrize("kind", ["cloth", "cloth_perm", "torus", "delaunay"])
+@pytest.mark.parametrize("which", ["Di", "DiA", "DiT", "DiAT"])
+def test_quaternion_packed_dirac_product_is_bit_exact(N, kind, which):
+    """sn_spmm_q3_f32: every Dirac-type operator (and its transpose) packs to three floats per block, and the product equals
+    the CSR oracle bit for bit, contiguous and strided, plain and with the fused ELU-backward epilogue."""
+    _, _, ops = mesh_fixture(kind)
+    A = ops[which[:-1]].T.tocsr() if which.endswith("T") else ops[which]
+    A.sort_indices()
+    M, K = A.shape
+    C = 4 * N
+    rng = np.random.default_rng(3)
+    xcat = rng.standard_normal((K // 4, 2 * C)).astype(np.float32)
+    want = c_oracle.spmm_csr(A.indptr, A.indices, A.data, np.ascontiguousarray(xcat[:, :C]).ravel(), N).reshape(M // 4, C)
+    rp, ci, va = csr_dev(A)
+    b = kernels.csr_to_bsr4(rp, ci, va, M, K)
+    q, flag = kernels.bsr4_to_q3(b[1], b[2])
+    assert int(flag.item()) == 0
+    assert q.shape == (b[1].numel(), 4) and np.array_equal(q[:, 3].contiguous().view(torch.int32).cpu().numpy(), b[1].cpu().numpy())
+    ycat = torch.full((M // 4, 2 * C), float("nan"), device=DEV)
+    kernels.spmm_q3(b[0], q, M // 4, K // 4, dev(xcat)[:, :C], ycat[:, C:], 4)
+    assert np.array_equal(ycat[:, C:].cpu().numpy(), want)
+    assert torch.isnan(ycat[:, :C]).all()
+    e = rng.standard_normal((M // 4, C)).astype(np.float32)
+    g = rng.standard_normal((M // 4, C)).astype(np.float32)
+    y2 = torch.empty((M // 4, C), device=DEV)
+    kernels.spmm_q3(b[0], q, M // 4, K // 4, dev(xcat)[:, :C], y2, 4, dev(e), dev(g))
+    y3 = torch.empty((M // 4, C), device=DEV)
+    kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, dev(xcat)[:, :C], dev(e), dev(g), y3, 4)
+    assert np.array_equal(y2.cpu().numpy(), y3.cpu().numpy())
+
+
+def test_non_quaternion_blocks_are_detected_and_fall_back():
+    rng = np.random.default_rng(5)
+    A = random_csr(64, 48, 0.2, 5)                        # generic operator: 4x4 blocks without any structure
+    op = SparseOperator.from_scipy(A, DEV)
+    assert op.q3() is None
+    x = torch.from_numpy(rng.standard_normal((12, 64)).astype(np.float32)).to(DEV)      # group-4 view: K/4 rows
+    y = snF.spmm(op, x, group=4)
+    want = c_oracle.spmm_csr(A.indptr, A.indices, A.data, x.cpu().numpy().ravel(), 16).reshape(16, 64)
+    assert np.array_equal(y.cpu().numpy(), want)
+
+
+def test_pool_assembles_quaternion_packed_batches():
+    _, _, o1 = mesh_fixture("cloth")
+    _, _, o2 = mesh_fixture("delaunay")
+    mats = [o1["Di"], o2["Di"], o1["Di"]]
+    pool = OperatorPool(mats, DEV, want_bsr4=True)
+    s0 = max(m.shape[0] for m in mats)
+    s1 = max(m.shape[1] for m in mats)
+    op = pool.assemble([2, 1, 0], s0, s1)
+    assert op._q3 is not None and op._bsr4 is None and op._csr is None            # only the packed form was assembled
+    want = sp.block_diag([sp.csr_matrix((m.data, m.indices, m.indptr), shape=m.shape).tocsr() if m.shape == (s0, s1) else
+                          sp.bmat([[m, None], [None, sp.csr_matrix((s0 - m.shape[0], s1 - m.shape[1]))]]) for m in
+                          (mats[2], mats[1], mats[0])]).tocsr()
+    got = op.to_scipy()
+    assert (abs(got - want)).max() == 0
+    gt = op.t().to_scipy()
+    assert (abs(gt - want.T)).max() == 0
