@@ -37,6 +37,12 @@ for name in ("Di", "DiA"):
         g = torch.randn(M // 4, 128, device=dev)
         for _ in range(10):                          # fused ELU-backward epilogue: + E and G reads (M*32*4 bytes each)
             kernels.spmm_bsr4_elubwd(bb[0], bb[1], bb[2], M // 4, K // 4, x, e, g, y, 4)
+        qq = o.q3()                                  # quaternion-packed form: 16-byte records
+        for _ in range(10):
+            kernels.spmm_q3(qq[0], qq[1], M // 4, K // 4, x, y, 4)
+        for _ in range(10):
+            kernels.spmm_q3(qq[0], qq[1], M // 4, K // 4, x, y, 4, e, g)
+        print(f"{name} {tag} q3: expected reads {qq[1].shape[0] * 16 + (M // 4 + 1) * 4 + K * 128} B (+ {2 * M * 128} B with E and G), writes {M * 128} B")
         rd = bb[1].numel() * 68 + (M // 4 + 1) * 4 + K * 32 * 4
         print(f"{name} {tag}: expected reads {rd} B (operator {bb[1].numel() * 68 + (M // 4 + 1) * 4} + X {K * 128}), writes {M * 128} B; "
               f"algorithmic CSR bytes {o.nnz * 8 + (M + 1) * 4 + K * 128 + M * 128}")

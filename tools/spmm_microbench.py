@@ -89,6 +89,12 @@ def main():
                 if only == "bsr4":
                     kernels.spmm_csr(o.rowptr, o.colind, o.vals, M, K, x, y, group)
                 print(f"{workload} {name:3s} {tag:6s} bsr4 N={N:3d} blocks={b[1].numel()} actualMB={actual / 1e6:.1f} ms={ms:.4f} GB/s(alg)={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f} equal={torch.equal(y, y2)}", flush=True)
+                q = o.q3()                                   # quaternion-packed form (the default of the product)
+                if q is not None:
+                    y3 = torch.empty_like(y)
+                    ms = time_launch(lambda: kernels.spmm_q3(q[0], q[1], M // 4, K // 4, x, y3, group))
+                    actual = q[1].shape[0] * 16 + (M // 4 + 1) * 4 + K * N * 4 + M * N * 4
+                    print(f"{workload} {name:3s} {tag:6s} q3   N={N:3d} blocks={q[1].shape[0]} actualMB={actual / 1e6:.1f} ms={ms:.4f} GB/s(alg)={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f} GB/s(actual)={actual / ms / 1e6:.0f} equal={torch.equal(y2, y3)}", flush=True)
     if only:
         return
     # plain copy ceiling on this box for reference
