@@ -72,7 +72,7 @@ class DirModel(nn.Module):
         for i in range(15):
             blk = self._modules["rn{}".format(i)]
             if i % 2 == 0:
-                v, f = blk(Di, DiA, v, f)
+                v, f = blk(Di, DiA, v, f, f_out_needed=False)     # f only ever feeds the next Dirac block (models.py:139-147)
             else:
                 v = blk(None, mask, v)
         x = self.conv2(F.elu(v))

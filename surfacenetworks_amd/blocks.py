@@ -66,16 +66,21 @@ class _DiracBlock(torch.autograd.Function):
          cat0 = [elu(f), Di·elu(v)]  -> f_out = Lin(BN(cat0));   cat1 = [elu(v), DiA·elu(f_out)] -> v + Lin(BN(cat1))."""
 
     @staticmethod
-    def forward(ctx, v, f, opDi, opDiA, pre_v, pre_f, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1, rm1, rv1,
-                tr1, mo1, ep1):
-        v, f = _rows2d(v), _rows2d(f)
+    def forward(ctx, v, f, opDi, opDiA, pre_v, pre_f, need_f, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1, rm1,
+                rv1, tr1, mo1, ep1):
+        v = _rows2d(v)
         rv, C = v.shape
         rf = f.shape[0]
         cat1 = _activated(v, pre_v)
-        cat0 = _activated(f, pre_f)
+        cat0 = pre_f if pre_f is not None else _activated(_rows2d(f), None)    # (f's values are not touched when handed off)
         _launch(opDi, cat1[:, :C], cat0[:, C:], 4, "fwd")
         nxt_f = _new_cat(rf, C, v.device)                        # the next Dirac block's cat0; first half = elu(f_out)
-        f_out, st0 = bnlin_forward(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, nxt_f[:, :C])
+        f_out, st0 = bnlin_forward(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, nxt_f[:, :C], want_y=need_f)
+        if f_out is None:
+            # The caller only chains f into the next Dirac block, which consumes the ACTIVATED hand-off: the pre-activation
+            # face features are not written (321 MB per block at the ARAP batch).  What is returned in their place is a
+            # zero-stride NaN view, so that any other use of it is loud instead of silently wrong.
+            f_out = torch.full((1, 1), float("nan"), dtype=torch.float32, device=v.device).expand(rf, C)
         _launch(opDiA, nxt_f[:, :C], cat1[:, C:], 4, "fwd")
         nxt_v = _new_cat(rv, C, v.device)
         v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C])
@@ -93,7 +98,7 @@ class _DiracBlock(torch.autograd.Function):
         dev = cat1.device
         none9 = (None,) * 9
         if g_vnew is None and g_fout is None:
-            return (None,) * 24
+            return (None,) * 25
         # Every ELU backward of the block is fused: the dgrad GEMM's epilogue sends the first half of a stage's input
         # gradient through the activation (h = dx[:, :C]·elu'(e) + the gradient of the other branch), and the transposed
         # product's store does the same for the propagated half:  (opᵀ·dx[:, C:])·elu'(e) + h.
@@ -124,11 +129,12 @@ class _DiracBlock(torch.autograd.Function):
                 g_v = h1
         if not ctx.needs_input_grad[1]:
             g_f = None
-        return (g_v, g_f, None, None, None, None) + gp0 + gp1
+        return (g_v, g_f, None, None, None, None, None) + gp0 + gp1
 
 
-def dirac_block(mod, Di, DiA, v, f):
-    """DirResNet2.forward on (B, V, C) / (B, F, C) tensors; `mod` supplies bn_fc0 / bn_fc1."""
+def dirac_block(mod, Di, DiA, v, f, need_f=True):
+    """DirResNet2.forward on (B, V, C) / (B, F, C) tensors; `mod` supplies bn_fc0 / bn_fc1.  need_f=False: the returned
+    face features are only a carrier of the activated hand-off for the next Dirac block (see _DiracBlock.forward)."""
     B, V, C = v.shape
     F_ = f.shape[1]
     rv, rf = B * V, B * F_
@@ -136,7 +142,7 @@ def dirac_block(mod, Di, DiA, v, f):
     if opDi.shape != (4 * rf, 4 * rv) or opDiA.shape != (4 * rv, 4 * rf):
         raise ValueError(f"DirResNet2: Di {tuple(opDi.shape)} / DiA {tuple(opDiA.shape)} do not match v rows {rv}, f rows {rf}")
     v_new, f_out, nxt_v, nxt_f = _DiracBlock.apply(v.reshape(rv, C), f.reshape(rf, C), opDi, opDiA,
-                                                  take_activated(v, rv, C), take_activated(f, rf, C),
+                                                  take_activated(v, rv, C), take_activated(f, rf, C), bool(need_f),
                                                   *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
     return attach_activated(v_new.view(B, V, C), nxt_v), attach_activated(f_out.view(B, F_, C), nxt_f)
 

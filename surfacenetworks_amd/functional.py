@@ -366,7 +366,8 @@ def unstash(ctx):
     return [tuple(t[i] if isinstance(i, int) else i.v for i in gs) for gs in ctx._sn_spec]
 
 
-def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual=None, elu_out=None):
+def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual=None, elu_out=None,
+                  want_y=True):
     """Forward of the folded BatchNorm1d("pre") + Linear on a (rows, C) operand (no autograd): statistics in one pass
     (fp64 accumulation), BN folded into the weights  y = x·(W·diag(s))ᵀ + (b + W·t),  s = gamma*invstd, t = beta - mean*s,
     optional residual add and ELU copy in the GEMM epilogue.  Returns (y, state) with `state` for bnlin_backward."""
@@ -381,7 +382,7 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     if residual is not None:
         residual = _rows2d(residual)
     if kernels.linear_fwd_supported(x.shape[1], W.shape[0]):
-        y = kernels.linear_fwd(x, Wf, bf, residual, elu_out)       # weights-in-registers fp32-MFMA GEMM (sn_gemm.hip)
+        y = kernels.linear_fwd(x, Wf, bf, residual, elu_out, want_y)   # row-streaming GEMM, weights in registers (sn_gemm.hip)
     else:
         y = torch.addmm(bf, x, Wf.t())
         if residual is not None:

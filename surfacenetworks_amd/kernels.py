@@ -346,12 +346,13 @@ def linear_fwd_supported(K: int, J: int) -> bool:
     return J == 128 and K in (128, 256)
 
 
-def linear_fwd(x, W, bias, residual=None, y_elu=None):
-    """y = x·Wᵀ + bias (+ residual); optionally also writes elu(y) into the 2-D view `y_elu` (sn_linear_fwd_f32)."""
+def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y: bool = True):
+    """y = x·Wᵀ + bias (+ residual); optionally also writes elu(y) into the 2-D view `y_elu` (sn_linear_fwd_f32).
+    want_y=False (with y_elu): only the activated copy is written and None is returned."""
     _dev(x, W, bias, residual, y_elu)
     rows, K = x.shape
     J = W.shape[0]
-    y = torch.empty((rows, J), dtype=torch.float32, device=x.device)
+    y = torch.empty((rows, J), dtype=torch.float32, device=x.device) if (want_y or y_elu is None) else None
     _lib.call("sn_linear_fwd_f32", _p(x), _ld(x), _p(W), _ld(W), _p(bias), _p(residual),
               _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu), _ld(y_elu) if y_elu is not None else 0,
               rows, K, J, _stream())

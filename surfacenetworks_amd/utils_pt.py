@@ -188,11 +188,14 @@ class DirResNet2(_TwoStage):
         super().__init__(num_outputs)
         self.res_f = res_f          # accepted and unused, as in the reference (utils_pt.py:189)
 
-    def forward(self, Di, DiA, v, f):
+    def forward(self, Di, DiA, v, f, f_out_needed=True):
+        """f_out_needed=False (not in the reference's signature): the caller promises to use the returned face features ONLY
+        as the `f` argument of the next DirResNet2 — the block then skips writing them (the next block reads the activated
+        copy handed over internally) and returns a NaN placeholder of the right shape in their place."""
         batch_size, num_nodes, num_inputs = v.size()
         _, num_faces, _ = f.size()
         if _blocks_ok(self, v):
-            return snB.dirac_block(self, Di, DiA, v, f)                         # the whole block as one autograd node
+            return snB.dirac_block(self, Di, DiA, v, f, f_out_needed)           # the whole block as one autograd node
         v2d = v.reshape(batch_size * num_nodes, num_inputs)
         cat0, e_v = snF.dirac_face_stage(as_operator(Di), v2d, f.reshape(batch_size * num_faces, num_inputs))
         f_out = self.bn_fc0.forward2d(cat0)

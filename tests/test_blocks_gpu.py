@@ -158,3 +158,28 @@ def test_whole_block_node_equals_per_stage_functions(golden_dir, cname):
     tol = 2e-5 if cname == "AvgResNet2" else 5e-6
     for a, b in zip(*res):
         assert rel_err(a, b) < tol
+
+
+def test_unwritten_face_features_are_a_loud_placeholder(golden_dir):
+    """DirResNet2(..., f_out_needed=False): the chained result is unchanged, the pre-activation face features are not
+    materialised, and what is returned in their place is NaN (any use other than as the next block's `f` is visible)."""
+    import surfacenetworks_amd.utils_pt as U
+    from helpers import deterministic_init, det_tensor
+
+    rb, ops = pc.batch_operators(golden_dir, "pool", DEV)
+    B, nv, nf, C = rb["mask"].shape[0], int(rb["nv"]), int(rb["nf"]), 128
+    b1 = deterministic_init(U.DirResNet2(C), 3).train().to(DEV)
+    b2 = deterministic_init(U.DirResNet2(C), 4).train().to(DEV)
+    res = []
+    for needed in (True, False):
+        v = torch.from_numpy(det_tensor((B, nv, C), 1)).to(DEV).requires_grad_(True)
+        f = torch.from_numpy(det_tensor((B, nf, C), 2)).to(DEV).requires_grad_(True)
+        v1, f1 = b1(ops["Di"], ops["DiA"], v, f, f_out_needed=needed)
+        if not needed:
+            assert f1.shape == (B, nf, C) and torch.isnan(f1).all() and f1.stride() == (0, 0, 0)
+        v2, f2 = b2(ops["Di"], ops["DiA"], v1, f1)
+        (v2.square().sum() + f2.sum()).backward()
+        res.append([v2.detach(), f2.detach(), v.grad.clone(), f.grad.clone(), b1.bn_fc0.fc.weight.grad.clone()])
+        b1.zero_grad(), b2.zero_grad()
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
