@@ -169,7 +169,8 @@ class _PropagateBlock(torch.autograd.Function):
         cat_a = _activated(x, pre)
         propagate(cat_a)
         cat_b = _new_cat(rows, C, x.device)
-        _, st0 = bnlin_forward(cat_a, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, cat_b[:, :C])
+        _, st0 = bnlin_forward(cat_a, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, cat_b[:, :C],
+                               want_y=False)                     # only elu(h) is consumed
         propagate(cat_b)
         nxt = _new_cat(rows, C, x.device)
         out, st1 = bnlin_forward(cat_b, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x, nxt[:, :C])
