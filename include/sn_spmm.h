@@ -257,6 +257,14 @@ size_t sn_wgrad_seg_workspace_bytes(int64_t rows, int64_t rows_per_seg, int32_t 
 int sn_wgrad_seg_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                      int64_t rows_per_seg, int32_t J, int32_t C, float *G, double *dysum, float *seg_dysum, void *workspace,
                      size_t workspace_bytes, void *stream);
+/* sn_wgrad_thin_f32: weight and bias gradient of a Linear with 1..8 input channels — the models' first layer,
+ * GraphConv1x1(6 | 3 -> C, batch_norm=None) (src/as_rigid_as_possible/models.py:113, src/utils/utils_pt.py:99) — on
+ * rows ~ 1e5..1e6:  G (J x C, row-major, fp32) = dy^T x,  db (J, optional) = colsum(dy).  One pass over dy; fp32
+ * accumulation over <= 64 rows per thread, fp64 above; two deterministic stages.  J % 4 == 0 and J/4 must divide 256
+ * (SN_E_UNSUPPORTED otherwise).  Replaces the weight-gradient GEMM + the bias reduction of nn.Linear's backward. */
+size_t sn_wgrad_thin_workspace_bytes(int64_t rows, int32_t J, int32_t C);
+int sn_wgrad_thin_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, int64_t rows, int32_t J, int32_t C,
+                      float *G, float *db, void *workspace, size_t workspace_bytes, void *stream);
 int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
                            const float *Cc, int64_t rows, int32_t C, void *stream);
 

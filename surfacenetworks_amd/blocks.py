@@ -177,6 +177,7 @@ class _PropagateBlock(torch.autograd.Function):
         ctx.op, ctx.seg = op, (mask_rows, inv_count, nseg, per)
         stash(ctx, (cat_a, cat_b), st0, st1)
         ctx.mark_non_differentiable(nxt)
+        ctx.set_materialize_grads(False)          # else the engine fills a (rows, 2C) zero gradient for `nxt` every backward
         return out, nxt
 
     @staticmethod
@@ -185,6 +186,8 @@ class _PropagateBlock(torch.autograd.Function):
         mask_rows, inv_count, nseg, per = ctx.seg
         (cat_a, cat_b), st0, st1 = unstash(ctx)
         C = cat_a.shape[1] // 2
+        if g_out is None:
+            return (None,) * 24
         g_out = g_out.contiguous()
 
         def stage_backward(st, g_in, cat, gadd):
@@ -230,12 +233,15 @@ class _AvgBlock(torch.autograd.Function):
         stash(ctx, st0, st1, (mask_rows, inv_count))
         ctx.seg = (nseg, per)
         ctx.mark_non_differentiable(nxt)
+        ctx.set_materialize_grads(False)          # else the engine fills a (rows, 2C) zero gradient for `nxt` every backward
         return out, nxt
 
     @staticmethod
     def backward(ctx, g_out, _gn):
         st0, st1, (mask_rows, inv_count) = unstash(ctx)
         nseg, per = ctx.seg
+        if g_out is None:
+            return (None,) * 23
         g_out = g_out.contiguous()
         g_h, dg1, db1, dW1, dc1 = avg_stage_backward(st1, mask_rows, inv_count, nseg, per, g_out, None)
         g_x, dg0, db0, dW0, dc0 = avg_stage_backward(st0, mask_rows, inv_count, nseg, per, g_h, g_out)   # + residual path

@@ -105,8 +105,18 @@ __global__ __launch_bounds__(kWG) void colstats_final_k(const double *__restrict
   const int cg = threadIdx.x & 31, pg = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + cg;
   double t = 0;
-  if (i < C2)
-    for (int b = pg; b < nblk; b += 8) t += partial[(int64_t)b * C2 + i];
+  if (i < C2) {
+    // eight loads in flight, added in the original order (a dependent load-add chain costs ~0.3 us per term)
+    int b = pg;
+    for (; b + 56 < nblk; b += 64) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + 8 * u) * C2 + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; b < nblk; b += 8) t += partial[(int64_t)b * C2 + i];
+  }
   sm[pg][cg] = t;
   __syncthreads();
   if (pg == 0 && i < C2) {
@@ -478,16 +488,129 @@ __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ 
     for (int p_ = 0; p_ < spm; ++p_) t2 += (double)colpart[(int64_t)(mesh * spm + p_) * 128 + j];
     segsum[k] = (float)t2;
   }
-  if (i < nG)
-    for (int sl = g; sl < nslab; sl += 4) t += (double)partial[(int64_t)sl * 128 * C + i];
-  else if (colpart && i < nG + J)
-    for (int sl = g; sl < nslab; sl += 4) t += (double)colpart[(int64_t)sl * 128 + (i - nG)];
+  if (i < nG || (colpart && i < nG + J)) {
+    // eight loads in flight, added in slab order
+    const float *src = i < nG ? partial + i : colpart + (i - nG);
+    const int64_t stride = i < nG ? (int64_t)128 * C : 128;
+    int sl = g;
+    for (; sl + 28 < nslab; sl += 32) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(sl + 4 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += (double)v[u];
+    }
+    for (; sl < nslab; sl += 4) t += (double)src[(int64_t)sl * stride];
+  }
   sm[g][o] = t;
   __syncthreads();
   if (g == 0) {
     const double r = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
     if (i < nG) G[i] = (float)r;
     else if (colpart && i < nG + J) dysum[i - nG] = r;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a Linear with a handful of input channels (the models' first layer, 3 or 6 coordinates -> C
+// features):  G (J x C) = dy^T x,  db = colsum(dy).  One pass over dy at HBM rate — a GEMM library sees a 128 x 6 output
+// with K = 3e5 and has no good tile for it.  A thread owns 4 adjacent dy columns and every (1024/J)-th row; the x row
+// is a broadcast load.  fp32 per-thread accumulation over <= ~64 rows, fp64 from there on; two deterministic stages.
+// ------------------------------------------------------------------------------------------------
+constexpr int kThinBlocks = 1024;
+constexpr int kThinMaxC = 8;
+
+template <int C>
+__global__ __launch_bounds__(kWG) void wgrad_thin_k(const float *__restrict__ dy, int64_t lddy,
+                                                    const float *__restrict__ x, int64_t ldx, int64_t rows, int J,
+                                                    double *__restrict__ partial /* [grid][C+1][J] */) {
+  extern __shared__ float smf[];                 // [lanes_r][C+1][J]  (the threads' fp32 sums; added up in fp64)
+  const int cw = J / 4, lanes_r = kWG / cw;
+  const int cg = threadIdx.x % cw, rl = threadIdx.x / cw;
+  const int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+  const int64_t r0 = (int64_t)blockIdx.x * per;
+  const int64_t r1 = r0 + per < rows ? r0 + per : rows;
+  float acc[C + 1][4];
+#pragma unroll
+  for (int c = 0; c <= C; ++c) acc[c][0] = acc[c][1] = acc[c][2] = acc[c][3] = 0.f;
+  if (rl < lanes_r) {
+    const float *pd = dy + cg * 4;
+    int64_t r = r0 + rl;
+    for (; r + 3 * lanes_r < r1; r += 4 * lanes_r) {         // 4 rows in flight
+      f4 d[4];
+      float xv[4][C];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        d[u] = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(pd + (r + (int64_t)u * lanes_r) * lddy));
+#pragma unroll
+        for (int c = 0; c < C; ++c) xv[u][c] = x[(r + (int64_t)u * lanes_r) * ldx + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          acc[c][0] = __builtin_fmaf(d[u].x, xv[u][c], acc[c][0]);
+          acc[c][1] = __builtin_fmaf(d[u].y, xv[u][c], acc[c][1]);
+          acc[c][2] = __builtin_fmaf(d[u].z, xv[u][c], acc[c][2]);
+          acc[c][3] = __builtin_fmaf(d[u].w, xv[u][c], acc[c][3]);
+        }
+        acc[C][0] += d[u].x; acc[C][1] += d[u].y; acc[C][2] += d[u].z; acc[C][3] += d[u].w;
+      }
+    }
+    for (; r < r1; r += lanes_r) {
+      const f4 d = *reinterpret_cast<const f4 *>(pd + r * lddy);
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        const float xv = x[r * ldx + c];
+        acc[c][0] = __builtin_fmaf(d.x, xv, acc[c][0]);
+        acc[c][1] = __builtin_fmaf(d.y, xv, acc[c][1]);
+        acc[c][2] = __builtin_fmaf(d.z, xv, acc[c][2]);
+        acc[c][3] = __builtin_fmaf(d.w, xv, acc[c][3]);
+      }
+      acc[C][0] += d.x; acc[C][1] += d.y; acc[C][2] += d.z; acc[C][3] += d.w;
+    }
+    float *o = smf + (int64_t)rl * (C + 1) * J + cg * 4;
+#pragma unroll
+    for (int c = 0; c <= C; ++c) {
+      o[c * J] = acc[c][0]; o[c * J + 1] = acc[c][1]; o[c * J + 2] = acc[c][2]; o[c * J + 3] = acc[c][3];
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (C + 1) * J; i += kWG) {
+    double t = 0;
+    for (int l = 0; l < lanes_r; ++l) t += (double)smf[(int64_t)l * (C + 1) * J + i];      // fixed order
+    partial[(int64_t)blockIdx.x * (C + 1) * J + i] = t;
+  }
+}
+
+// element i = c*J + j of the (C+1) x J partial layout -> G[j][c] (c < C) or db[j] (c == C)
+__global__ __launch_bounds__(kWG) void wgrad_thin_final_k(const double *__restrict__ partial, int nblk, int J, int C,
+                                                          float *__restrict__ G, float *__restrict__ db) {
+  __shared__ double sm[8][32];
+  const int cl = threadIdx.x & 31, pg = threadIdx.x >> 5;
+  const int n = (C + 1) * J;
+  const int i = blockIdx.x * 32 + cl;
+  double t = 0;
+  if (i < n) {
+    int b = pg;
+    for (; b + 56 < nblk; b += 64) {             // eight loads in flight, added in block order
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + 8 * u) * n + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t += v[u];
+    }
+    for (; b < nblk; b += 8) t += partial[(int64_t)b * n + i];
+  }
+  sm[pg][cl] = t;
+  __syncthreads();
+  if (pg == 0 && i < n) {
+    double r = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) r += sm[g][cl];
+    const int c = i / J, j = i - c * J;
+    if (c < C) G[(int64_t)j * C + c] = (float)r;
+    else if (db) db[j] = (float)r;
   }
 }
 
@@ -986,6 +1109,51 @@ int sn_wgrad_seg_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx,
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows_per_seg < 1) return SN_E_SHAPE;
   return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, rows_per_seg, seg_dysum, workspace, workspace_bytes, stream);
+}
+
+static int thin_blocks(int64_t rows, int J) {
+  const int lanes_r = kWG / (J / 4);
+  int64_t nb = (rows + (int64_t)lanes_r * 8 - 1) / ((int64_t)lanes_r * 8);     // >= 8 rows per row lane
+  if (nb > kThinBlocks) nb = kThinBlocks;
+  return nb < 1 ? 1 : (int)nb;
+}
+
+size_t sn_wgrad_thin_workspace_bytes(int64_t rows, int32_t J, int32_t C) {
+  if (rows < 1 || J < 4 || (J % 4) || C < 1 || C > kThinMaxC || (kWG % (J / 4))) return 0;
+  return (size_t)thin_blocks(rows, J) * ((size_t)C + 1) * J * sizeof(double);
+}
+
+int sn_wgrad_thin_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, int64_t rows, int32_t J, int32_t C,
+                      float *G, float *db, void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (rows < 0 || J < 1 || C < 1 || lddy < J || ldx < C) return SN_E_SHAPE;
+  if (C > kThinMaxC || (J % 4) || J / 4 > kWG || (kWG % (J / 4))) return SN_E_UNSUPPORTED;
+  if (!G) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows == 0) {
+    hipError_t e = hipMemsetAsync(G, 0, (size_t)J * C * sizeof(float), s);
+    if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)J * sizeof(float), s);
+    return e == hipSuccess ? SN_OK : (int)e;
+  }
+  if (!dy || !x || !workspace) return SN_E_NULL;
+  if (!aligned16(dy) || (lddy % 4)) return SN_E_ALIGN;
+  const int nblk = thin_blocks(rows, J);
+  if (workspace_bytes < (size_t)nblk * ((size_t)C + 1) * J * sizeof(double)) return SN_E_WORKSPACE;
+  double *partial = static_cast<double *>(workspace);
+  const int lanes_r = kWG / (J / 4);
+  const size_t shm = (size_t)lanes_r * (C + 1) * J * sizeof(float);
+#define SN_THIN(CC)                                                                                                       \
+  case CC:                                                                                                                \
+    hipLaunchKernelGGL((wgrad_thin_k<CC>), dim3(nblk), dim3(kWG), shm, s, dy, lddy, x, ldx, rows, (int)J, partial);      \
+    break;
+  switch (C) {
+    SN_THIN(1) SN_THIN(2) SN_THIN(3) SN_THIN(4) SN_THIN(5) SN_THIN(6) SN_THIN(7) SN_THIN(8)
+    default: return SN_E_UNSUPPORTED;
+  }
+#undef SN_THIN
+  hipLaunchKernelGGL(wgrad_thin_final_k, dim3((unsigned)(((C + 1) * J + 31) / 32)), dim3(kWG), 0, s, partial, nblk, (int)J,
+                     (int)C, G, db);
+  return launch_status();
 }
 
 int sn_avg_fwd_prep_f32(const float *segsum, const float *inv_count, int64_t nseg, int32_t C, int64_t rows_per_seg,

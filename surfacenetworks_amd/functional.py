@@ -19,7 +19,7 @@ from . import kernels
 from .operators import SparseOperator, as_operator
 
 __all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg_propagate", "bn_linear", "bnlin_forward",
-           "bnlin_backward", "bn_prepare", "set_dirac_format", "SpmmTimer"]
+           "bnlin_backward", "bn_prepare", "set_dirac_format", "SpmmTimer", "thin_linear", "thin_linear_supported"]
 
 _DIRAC_FORMAT = "q3"
 
@@ -501,6 +501,36 @@ def bn_linear(x2d: torch.Tensor, bn: torch.nn.BatchNorm1d, fc: torch.nn.Linear, 
     training, momentum, eps = bn_prepare(bn)
     return _BNLinear.apply(x2d, bn.weight, bn.bias, fc.weight, fc.bias, bn.running_mean, bn.running_var, training,
                            momentum, eps, residual)
+
+
+class _ThinLinear(torch.autograd.Function):
+    """nn.Linear with a handful of input channels on (rows, Cin <= 8) — the models' first layer,
+    GraphConv1x1(6 | 3, C, batch_norm=None) (src/utils/utils_pt.py:99).  Forward is the library GEMM (it is a plain write
+    of rows x C); the backward's weight and bias gradients are ONE pass over dy (sn_wgrad_thin_f32) instead of a
+    128 x 6, K = rows GEMM the library has no tile for (490 us -> ~40 us at the ARAP batch) plus a column reduction."""
+
+    @staticmethod
+    def forward(ctx, x, W, b):
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = b is not None
+        return torch.addmm(b, x, W.t()) if b is not None else x.mm(W.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = dy.mm(W) if ctx.needs_input_grad[0] else None
+        dW, db = kernels.wgrad_thin(dy, x, ctx.has_bias)
+        return dx, dW, db
+
+
+def thin_linear_supported(x2d: torch.Tensor, fc: torch.nn.Linear) -> bool:
+    return x2d.dtype == torch.float32 and fc.weight.dtype == torch.float32 and \
+        kernels.wgrad_thin_supported(fc.out_features, fc.in_features)
+
+
+def thin_linear(x2d: torch.Tensor, fc: torch.nn.Linear) -> torch.Tensor:
+    return _ThinLinear.apply(x2d.contiguous(), fc.weight, fc.bias)
 
 
 class _AvgPropagate(torch.autograd.Function):

@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported",
 ]
 
 
@@ -469,6 +469,24 @@ def wgrad_seg(dy, x, center, rows_per_seg: int):
     _lib.call("sn_wgrad_seg_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, rows_per_seg, J, C, _p(G), _p(dysum), _p(seg),
               _p(ws), ws_bytes, _stream())
     return G, dysum, seg
+
+
+def wgrad_thin_supported(J: int, C: int) -> bool:
+    return 1 <= C <= 8 and J % 4 == 0 and 256 % (J // 4) == 0
+
+
+def wgrad_thin(dy, x, want_bias: bool = True):
+    """(dW (J, C), db (J) | None) of a Linear with 1..8 input channels: dy^T x and colsum(dy) in one pass (sn_wgrad_thin_f32)."""
+    _dev(dy, x)
+    rows, J = dy.shape
+    C = x.shape[1]
+    dev = dy.device
+    G = torch.empty((J, C), dtype=torch.float32, device=dev)
+    db = torch.empty(J, dtype=torch.float32, device=dev) if want_bias else None
+    ws_bytes = int(_lib.load().sn_wgrad_thin_workspace_bytes(rows, J, C))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.call("sn_wgrad_thin_f32", _p(dy), _ld(dy), _p(x), _ld(x), rows, J, C, _p(G), _p(db), _p(ws), ws_bytes, _stream())
+    return G, db
 
 
 def linear_fwd_segbias(x, W, segbias, rows_per_seg: int, residual=None, y_elu=None, want_y: bool = True):

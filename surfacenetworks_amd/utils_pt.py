@@ -105,7 +105,10 @@ class GraphConv1x1(nn.Module):
             if x2d.dtype == torch.float32 and self.bn.affine and self.bn.momentum is not None:
                 return snF.bn_linear(x2d, self.bn, self.fc, residual)   # one statistics pass + folded GEMM (functional.py)
             x2d = self.bn(x2d)
-        x2d = self.fc(x2d)
+        if self.batch_norm is None and torch.is_grad_enabled() and snF.thin_linear_supported(x2d, self.fc):
+            x2d = snF.thin_linear(x2d, self.fc)       # first layer (3 / 6 coordinates in): one-pass weight gradient
+        else:
+            x2d = self.fc(x2d)
         if self.batch_norm == "post":
             x2d = self.bn(x2d)
         return x2d if residual is None else x2d + residual

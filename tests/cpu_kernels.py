@@ -294,6 +294,15 @@ def wgrad_seg(dy, x, center, rows_per_seg):
     return G, sdy, dy.double().reshape(nseg, rows_per_seg, -1).sum(1).float()
 
 
+def wgrad_thin_supported(J, C):
+    return 1 <= C <= 8 and J % 4 == 0 and 256 % (J // 4) == 0
+
+
+def wgrad_thin(dy, x, want_bias=True):
+    G = (dy.double().t() @ x.double()).float()
+    return G, (dy.double().sum(0).float() if want_bias else None)
+
+
 def linear_fwd_segbias(x, W, segbias, rows_per_seg, residual=None, y_elu=None, want_y=True):
     seg = torch.arange(x.shape[0]) // rows_per_seg
     y = (x.double() @ W.double().t()).float() + segbias[seg]

@@ -374,3 +374,57 @@ def test_avg_stats_single_pass(nseg, per):
     m2, stats2 = kernels.avg_fwd_prep(ssum, dev(inv), per, kernels.colstats(e))
     assert np.array_equal(m.cpu().numpy(), m2.cpu().numpy())
     assert np.allclose(stats.cpu().numpy(), stats2.cpu().numpy(), rtol=1e-12, atol=0)
+
+
+# ---- first-layer Linear (a handful of input channels): one-pass weight / bias gradient -----------------------------------
+@pytest.mark.parametrize("rows", [1, 7, 63, 64, 1000, 33333, 322624])
+@pytest.mark.parametrize("J,C", [(128, 6), (128, 3), (64, 3), (16, 8), (256, 1)])
+def test_wgrad_thin(rows, J, C):
+    rng = np.random.default_rng(rows * 3 + J + C)
+    dy = rng.standard_normal((rows, J)).astype(np.float32)
+    xw = (rng.standard_normal((rows, C + 3)) + 2.0).astype(np.float32)          # x = a strided view, row stride C + 3
+    want = dy.astype(np.float64).T @ xw[:, :C].astype(np.float64)
+    G, db = kernels.wgrad_thin(dev(dy), dev(xw)[:, :C])
+    scale = np.sqrt(rows) * 3.0
+    # fp32 products and <= 64-row fp32 partial sums, fp64 above: error ~ eps * sqrt(64) per partial
+    assert np.abs(G.cpu().numpy() - want).max() <= 2e-6 * scale + 1e-6
+    assert np.abs(db.cpu().numpy() - dy.astype(np.float64).sum(0)).max() <= 2e-6 * scale + 1e-6
+    G2, none = kernels.wgrad_thin(dev(dy), dev(xw)[:, :C], want_bias=False)
+    assert none is None and torch.equal(G2, G)                                    # deterministic
+
+
+def test_wgrad_thin_rejects_what_it_does_not_cover():
+    assert not kernels.wgrad_thin_supported(120, 6) and not kernels.wgrad_thin_supported(128, 9)
+    with pytest.raises(RuntimeError):
+        kernels.wgrad_thin(torch.zeros(10, 120, device=DEV), torch.zeros(10, 6, device=DEV))
+    with pytest.raises(RuntimeError):
+        kernels.wgrad_thin(torch.zeros(10, 128, device=DEV), torch.zeros(10, 9, device=DEV))
+    G, db = kernels.wgrad_thin(torch.zeros(0, 128, device=DEV), torch.zeros(0, 6, device=DEV))     # empty batch: zeros
+    assert G.shape == (128, 6) and not G.any() and not db.any()
+
+
+@pytest.mark.parametrize("cin,cout,bias", [(6, 128, True), (3, 64, True), (3, 128, False)])
+def test_first_layer_matches_nn_linear(cin, cout, bias):
+    """GraphConv1x1(cin, cout, batch_norm=None) (utils_pt.py:99) through _ThinLinear == nn.Linear, forward and backward."""
+    from surfacenetworks_amd import utils_pt as snU
+
+    torch.manual_seed(cin + cout)
+    conv = snU.GraphConv1x1(cin, cout, batch_norm=None).to(DEV)
+    if not bias:
+        conv.fc.bias = None
+    ref = torch.nn.Linear(cin, cout, bias=bias).to(DEV).double()
+    ref.weight.data.copy_(conv.fc.weight.data)
+    if bias:
+        ref.bias.data.copy_(conv.fc.bias.data)
+    x = torch.randn(5, 700, cin, device=DEV, requires_grad=True)
+    xr = x.detach().double().requires_grad_(True)
+    g = torch.randn(5, 700, cout, device=DEV)
+    y = conv(x)
+    y.backward(g)
+    yr = ref(xr)
+    yr.backward(g.double())
+    assert rel_err(y.detach().cpu().numpy(), yr.detach().cpu().numpy()) < 1e-5
+    assert rel_err(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) < 1e-5
+    assert rel_err(conv.fc.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy()) < 1e-5
+    if bias:
+        assert rel_err(conv.fc.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < 1e-5
