@@ -265,6 +265,18 @@ int sn_wgrad_seg_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx,
 size_t sn_wgrad_thin_workspace_bytes(int64_t rows, int32_t J, int32_t C);
 int sn_wgrad_thin_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, int64_t rows, int32_t J, int32_t C,
                       float *G, float *db, void *workspace, size_t workspace_bytes, void *stream);
+/* Masked smooth-L1 training loss of the ARAP harness (src/as_rigid_as_possible/main.py:225-226:
+ * `outputs * mask`, F.smooth_l1_loss(size_average=False) / batch_size), forward and backward as one pass each:
+ *   loss  = scale * sum_{r,c} l(out[r,c]*rowmask[r] - target[r,c]),  l(d) = d*d/2 if |d| < 1 else |d| - 1/2   (fp64 sums)
+ *   gout  = gloss[0]*scale * rowmask[r] * clamp(out[r,c]*rowmask[r] - target[r,c], -1, 1)
+ * rowmask (rows floats) may be NULL (= all ones); gloss is a DEVICE scalar (the gradient of the loss value). */
+size_t sn_masked_smooth_l1_workspace_bytes(int64_t rows, int32_t C);
+int sn_masked_smooth_l1_fwd_f32(const float *out, int64_t ldo, const float *target, int64_t ldt, const float *rowmask,
+                                int64_t rows, int32_t C, double scale, float *loss, void *workspace, size_t workspace_bytes,
+                                void *stream);
+int sn_masked_smooth_l1_bwd_f32(const float *out, int64_t ldo, const float *target, int64_t ldt, const float *rowmask,
+                                int64_t rows, int32_t C, double scale, const float *gloss, float *gout, int64_t ldg,
+                                void *stream);
 int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
                            const float *Cc, int64_t rows, int32_t C, void *stream);
 

@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import mesh_ops
+from . import kernels, mesh_ops
 from . import utils_pt as utils
 from .operators import OperatorPool
 
@@ -29,6 +29,14 @@ OUTPUT_FRAMES = 40     # main.py:106
 def _num_faces(Di, DiA, batch_size):
     """models.py:133-136 — works for 3-D batched and 2-D block-diagonal operators."""
     return DiA.size(2) // 4 if len(Di.size()) == 3 else DiA.size(1) // 4 // batch_size
+
+
+
+def _add_last_frame(x, inputs, frames):
+    """x + inputs[:, :, -3:].repeat(1, 1, frames) (models.py:105,152) as one broadcast add — same values, the repeated
+    tensor is never written."""
+    B, V, _ = x.shape
+    return (x.reshape(B, V, frames, 3) + inputs[:, :, None, -3:]).reshape(B, V, 3 * frames)
 
 
 class Model(nn.Module):
@@ -51,7 +59,7 @@ class Model(nn.Module):
         for i in range(self.layer):
             x = self._modules["rn{}".format(i)](L, mask, x)
         x = self.conv2(F.elu(x))
-        return x + inputs[:, :, -3:].repeat(1, 1, OUTPUT_FRAMES)
+        return _add_last_frame(x, inputs, OUTPUT_FRAMES)
 
 
 class DirModel(nn.Module):
@@ -76,12 +84,34 @@ class DirModel(nn.Module):
             else:
                 v = blk(None, mask, v)
         x = self.conv2(F.elu(v))
-        return x + inputs[:, :, -3:].repeat(1, 1, OUTPUT_FRAMES)
+        return _add_last_frame(x, inputs, OUTPUT_FRAMES)
+
+
+class _MaskedSmoothL1(torch.autograd.Function):
+    """sum smooth_l1(outputs * mask, targets) / batch_size as one pass forward (fp64 sums) and one pass backward
+    (kernels.masked_smooth_l1_*) instead of five elementwise passes over the (B, V, 120) tensors."""
+
+    @staticmethod
+    def forward(ctx, out2d, tgt2d, rowmask, scale):
+        ctx.save_for_backward(out2d, tgt2d, rowmask)
+        ctx.scale = scale
+        return kernels.masked_smooth_l1_fwd(out2d, tgt2d, rowmask, scale)
+
+    @staticmethod
+    def backward(ctx, gloss):
+        out2d, tgt2d, rowmask = ctx.saved_tensors
+        return kernels.masked_smooth_l1_bwd(out2d, tgt2d, rowmask, ctx.scale, gloss.contiguous()), None, None, None
 
 
 def loss_fn(outputs, targets, mask, batch_size):
     """Masked smooth-L1, summed, divided by the batch size (main.py:225-226).  Under data parallelism pass the
     GLOBAL batch size so that the all-reduced (summed) gradients equal the single-process ones."""
+    if outputs.dim() == 3 and outputs.dtype == torch.float32 and targets.dtype == torch.float32 and \
+            not targets.requires_grad and mask.numel() == outputs.shape[0] * outputs.shape[1]:
+        C = outputs.shape[2]
+        out = _MaskedSmoothL1.apply(outputs.reshape(-1, C), targets.reshape(-1, C).contiguous(),
+                                    mask.reshape(-1).to(torch.float32).contiguous(), 1.0 / batch_size)
+        return out
     outputs = outputs * mask.expand_as(outputs)
     return F.smooth_l1_loss(outputs, targets, reduction="sum") / batch_size
 
@@ -168,6 +198,15 @@ class ClothSequences:
         else:
             self.pool_L = OperatorPool(mats["L"], self.device, want_bsr4=False)
 
+    def _vertex_major(self):
+        """(n, vmax, frames*3) copy of self.xyz (n, frames, vmax, 3), rebuilt when self.xyz is replaced."""
+        cached = getattr(self, "_xyz_vm", None)
+        if cached is None or cached[0] is not self.xyz:
+            n, fr, vmax, _ = self.xyz.shape
+            cached = (self.xyz, self.xyz.permute(0, 2, 1, 3).reshape(n, vmax, fr * 3).contiguous())
+            self._xyz_vm = cached
+        return cached[1]
+
     def sample_batch(self, batch_size, rng: np.random.Generator, seq_ids=None, offsets=None) -> Batch:
         """Counterpart of sample_batch (main.py:98-185): random sequence + random start frame per sample; operator of
         the last input frame (main.py:156); everything zero-padded to the batch maximum (main.py:126-130)."""
@@ -183,11 +222,14 @@ class ClothSequences:
         nf = int(self.num_faces[seq_ids].max())
         sid = torch.from_numpy(seq_ids).to(self.device)
         off = torch.from_numpy(offsets).to(self.device)
-        tt = off[:, None] + torch.arange(INPUT_FRAMES + OUTPUT_FRAMES, device=self.device)[None]     # (B, 42)
-        fr = self.xyz[sid[:, None], tt][:, :, :nv]                                                   # (B, 42, nv, 3)
-        fr = fr.permute(0, 2, 1, 3).reshape(B, nv, (INPUT_FRAMES + OUTPUT_FRAMES) * 3)
-        inputs = fr[:, :, : 3 * INPUT_FRAMES].contiguous()
-        targets = fr[:, :, 3 * INPUT_FRAMES:].contiguous()
+        # a sample's 42 frames of a vertex are one contiguous run of the vertex-major copy: inputs and targets are gathered
+        # straight into their final (B, nv, frames*3) layout (no permute / slice copies of the 160 MB window)
+        vm = self._vertex_major()                                                                    # (n, vmax, frames*3)
+        vr = torch.arange(nv, device=self.device)[None, :, None]
+        col = 3 * off[:, None, None] + torch.arange(3 * (INPUT_FRAMES + OUTPUT_FRAMES), device=self.device)[None, None, :]
+        s3 = sid[:, None, None]
+        inputs = vm[s3, vr, col[:, :, : 3 * INPUT_FRAMES]]
+        targets = vm[s3, vr, col[:, :, 3 * INPUT_FRAMES:]]
         mask = (torch.arange(nv, device=self.device)[None, :] < self.vcount[sid][:, None]).float().unsqueeze(2)
         op_ids = seq_ids * self.op_frames + (offsets + INPUT_FRAMES - 1)
         L = Di = DiA = None

@@ -615,6 +615,91 @@ __global__ __launch_bounds__(kWG) void wgrad_thin_final_k(const double *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// Masked smooth-L1 training loss of the ARAP harness (src/as_rigid_as_possible/main.py:225-226):
+//   loss = scale * sum_{r,c} l(out[r,c]*mask[r] - target[r,c]),   l(d) = d^2/2 (|d| < 1) | |d| - 1/2
+// forward: one read of out and target, fp64 partial sums, two deterministic stages;
+// backward: gout = (gloss*scale) * mask[r] * clamp(out*mask - target, -1, 1), one pass.
+// (torch runs mask-multiply, loss, reduction, loss-backward, mask-multiply as five elementwise passes.)
+// ------------------------------------------------------------------------------------------------
+constexpr int kLossBlocks = 1024;
+
+__device__ __forceinline__ double sl1(float d) {
+  const float a = fabsf(d);
+  return a < 1.f ? 0.5 * (double)d * (double)d : (double)a - 0.5;
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(kWG) void masked_sl1_fwd_k(const float *__restrict__ o, int64_t ldo,
+                                                        const float *__restrict__ t, int64_t ldt,
+                                                        const float *__restrict__ mask, int64_t rows, int C,
+                                                        double *__restrict__ partial) {
+  __shared__ double red[kWG];
+  constexpr int W = VEC ? 4 : 1;
+  const int cw = C / W;
+  const int64_t total = rows * cw;
+  double acc = 0;
+  for (int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x; i < total; i += (int64_t)gridDim.x * kWG) {
+    const int64_t r = i / cw;
+    const int c = (int)(i - r * cw) * W;
+    const float m = mask ? mask[r] : 1.f;
+    if constexpr (VEC) {
+      const f4 ov = ld4_s(o + r * ldo + c, 1), tv = ld4_s(t + r * ldt + c, 1);
+      acc += sl1(ov.x * m - tv.x) + sl1(ov.y * m - tv.y) + sl1(ov.z * m - tv.z) + sl1(ov.w * m - tv.w);
+    } else {
+      acc += sl1(o[r * ldo + c] * m - t[r * ldt + c]);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kWG / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
+__global__ __launch_bounds__(kWG) void masked_sl1_final_k(const double *__restrict__ partial, int nblk, double scale,
+                                                          float *__restrict__ loss) {
+  __shared__ double red[kWG];
+  double acc = 0;
+  for (int i = threadIdx.x; i < nblk; i += kWG) acc += partial[i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = kWG / 2; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) loss[0] = (float)(red[0] * scale);
+}
+
+__device__ __forceinline__ float sl1_grad(float d) { return d < -1.f ? -1.f : (d > 1.f ? 1.f : d); }
+
+template <bool VEC>
+__global__ __launch_bounds__(kWG) void masked_sl1_bwd_k(const float *__restrict__ o, int64_t ldo,
+                                                        const float *__restrict__ t, int64_t ldt,
+                                                        const float *__restrict__ mask, int64_t rows, int C, float scale,
+                                                        const float *__restrict__ gloss, float *__restrict__ g,
+                                                        int64_t ldg) {
+  constexpr int W = VEC ? 4 : 1;
+  const int cw = C / W;
+  const int64_t total = rows * cw;
+  const float gs = gloss[0] * scale;
+  for (int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x; i < total; i += (int64_t)gridDim.x * kWG) {
+    const int64_t r = i / cw;
+    const int c = (int)(i - r * cw) * W;
+    const float m = mask ? mask[r] : 1.f;
+    const float gm = gs * m;
+    if constexpr (VEC) {
+      const f4 ov = ld4_s(o + r * ldo + c, 1), tv = ld4_s(t + r * ldt + c, 1);
+      st4_s(g + r * ldg + c, f4{gm * sl1_grad(ov.x * m - tv.x), gm * sl1_grad(ov.y * m - tv.y),
+                                gm * sl1_grad(ov.z * m - tv.z), gm * sl1_grad(ov.w * m - tv.w)}, 0);
+    } else {
+      g[r * ldg + c] = gm * sl1_grad(o[r * ldo + c] * m - t[r * ldt + c]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kWG) void affine_cols_acc_k(float *__restrict__ dx, int64_t lddx,
                                                          const float *__restrict__ x, int64_t ldx,
@@ -1323,6 +1408,63 @@ int sn_elu_bwd_bcast_f32(const float *gdst, int64_t ldg, const float *out, int64
   if (!aligned16(gdst) || !aligned16(out) || !aligned16(bias) || !aligned16(gsrc) || (gadd && !aligned16(gadd))) return SN_E_ALIGN;
   hipLaunchKernelGGL(elu_bwd_bcast_k, dim3(ew_grid(rows * (C / 4))), dim3(kWG), 0, static_cast<hipStream_t>(stream), gdst,
                      ldg, out, ldo, bias, mask, gadd, ldga, gsrc, ldgs, rows_per_seg, rows, (int)C, kStreamNT);
+  return launch_status();
+}
+
+static int loss_blocks(int64_t items) {
+  int64_t b = (items + kWG - 1) / kWG;
+  if (b > kLossBlocks) b = kLossBlocks;
+  return b < 1 ? 1 : (int)b;
+}
+
+size_t sn_masked_smooth_l1_workspace_bytes(int64_t rows, int32_t C) {
+  (void)rows; (void)C;
+  return (size_t)kLossBlocks * sizeof(double);
+}
+
+int sn_masked_smooth_l1_fwd_f32(const float *out, int64_t ldo, const float *target, int64_t ldt, const float *rowmask,
+                                int64_t rows, int32_t C, double scale, float *loss, void *workspace, size_t workspace_bytes,
+                                void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (rows < 0 || C < 1 || ldo < C || ldt < C) return SN_E_SHAPE;
+  if (!loss) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (rows == 0) {
+    const hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+    return e == hipSuccess ? SN_OK : (int)e;
+  }
+  if (!out || !target || !workspace) return SN_E_NULL;
+  if (workspace_bytes < (size_t)kLossBlocks * sizeof(double)) return SN_E_WORKSPACE;
+  const bool vec = (C % 4 == 0) && (ldo % 4 == 0) && (ldt % 4 == 0) && aligned16(out) && aligned16(target);
+  const int nblk = loss_blocks(rows * (vec ? C / 4 : C));
+  double *partial = static_cast<double *>(workspace);
+  if (vec)
+    hipLaunchKernelGGL((masked_sl1_fwd_k<true>), dim3(nblk), dim3(kWG), 0, s, out, ldo, target, ldt, rowmask, rows, (int)C, partial);
+  else
+    hipLaunchKernelGGL((masked_sl1_fwd_k<false>), dim3(nblk), dim3(kWG), 0, s, out, ldo, target, ldt, rowmask, rows, (int)C, partial);
+  hipLaunchKernelGGL(masked_sl1_final_k, dim3(1), dim3(kWG), 0, s, partial, nblk, scale, loss);
+  return launch_status();
+}
+
+int sn_masked_smooth_l1_bwd_f32(const float *out, int64_t ldo, const float *target, int64_t ldt, const float *rowmask,
+                                int64_t rows, int32_t C, double scale, const float *gloss, float *gout, int64_t ldg,
+                                void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (rows < 0 || C < 1 || ldo < C || ldt < C || ldg < C) return SN_E_SHAPE;
+  if (rows == 0) return SN_OK;
+  if (!out || !target || !gloss || !gout) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (C % 4 == 0) && (ldo % 4 == 0) && (ldt % 4 == 0) && (ldg % 4 == 0) && aligned16(out) &&
+                   aligned16(target) && aligned16(gout);
+  const int64_t items = rows * (vec ? C / 4 : C);
+  int64_t blocks = (items + kWG - 1) / kWG;
+  if (blocks > 16 * 1024) blocks = 16 * 1024;
+  if (vec)
+    hipLaunchKernelGGL((masked_sl1_bwd_k<true>), dim3((unsigned)blocks), dim3(kWG), 0, s, out, ldo, target, ldt, rowmask, rows, (int)C,
+                       (float)scale, gloss, gout, ldg);
+  else
+    hipLaunchKernelGGL((masked_sl1_bwd_k<false>), dim3((unsigned)blocks), dim3(kWG), 0, s, out, ldo, target, ldt, rowmask, rows, (int)C,
+                       (float)scale, gloss, gout, ldg);
   return launch_status();
 }
 

@@ -17,6 +17,14 @@ from . import utils_pt as utils
 from .operators import OperatorPool, SparseOperator
 
 
+
+def _add_last_frame(x, inputs, frames):
+    """x + inputs[:, :, -3:].repeat(1, 1, frames) (models.py:105,152) as one broadcast add — same values, the repeated
+    tensor is never written."""
+    B, V, _ = x.shape
+    return (x.reshape(B, V, frames, 3) + inputs[:, :, None, -3:]).reshape(B, V, 3 * frames)
+
+
 class Model(nn.Module):
     def __init__(self, layer):
         super().__init__()
@@ -31,7 +39,7 @@ class Model(nn.Module):
         for i in range(self.layer):
             x = self._modules["rn{}".format(i)](L, mask, x)
         x = self.conv2(F.elu(x))
-        return x + inputs[:, :, -3:].repeat(1, 1, 40)
+        return _add_last_frame(x, inputs, 40)
 
 
 class DirModel(nn.Module):
@@ -56,7 +64,7 @@ class DirModel(nn.Module):
             else:
                 v = blk(None, mask, v)
         x = self.conv2(F.elu(v))
-        return x + inputs[:, :, -3:].repeat(1, 1, 40)
+        return _add_last_frame(x, inputs, 40)
 
 
 class SiameseModel(nn.Module):

@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd",
 ]
 
 
@@ -487,6 +487,28 @@ def wgrad_thin(dy, x, want_bias: bool = True):
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
     _lib.call("sn_wgrad_thin_f32", _p(dy), _ld(dy), _p(x), _ld(x), rows, J, C, _p(G), _p(db), _p(ws), ws_bytes, _stream())
     return G, db
+
+
+def masked_smooth_l1_fwd(out2d, target2d, rowmask, scale: float):
+    """scale * sum smooth_l1(out*rowmask - target) as a 0-dim fp32 tensor (sn_masked_smooth_l1_fwd_f32)."""
+    _dev(out2d, target2d, rowmask)
+    rows, C = out2d.shape
+    loss = torch.empty((), dtype=torch.float32, device=out2d.device)
+    ws_bytes = int(_lib.load().sn_masked_smooth_l1_workspace_bytes(rows, C))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=out2d.device)
+    _lib.call("sn_masked_smooth_l1_fwd_f32", _p(out2d), _ld(out2d), _p(target2d), _ld(target2d), _p(rowmask), rows, C,
+              float(scale), _p(loss), _p(ws), ws_bytes, _stream())
+    return loss
+
+
+def masked_smooth_l1_bwd(out2d, target2d, rowmask, scale: float, gloss):
+    """Gradient of masked_smooth_l1_fwd w.r.t. out2d, times the device scalar gloss (sn_masked_smooth_l1_bwd_f32)."""
+    _dev(out2d, target2d, rowmask, gloss)
+    rows, C = out2d.shape
+    g = torch.empty((rows, C), dtype=torch.float32, device=out2d.device)
+    _lib.call("sn_masked_smooth_l1_bwd_f32", _p(out2d), _ld(out2d), _p(target2d), _ld(target2d), _p(rowmask), rows, C,
+              float(scale), _p(gloss), _p(g), C, _stream())
+    return g
 
 
 def linear_fwd_segbias(x, W, segbias, rows_per_seg: int, residual=None, y_elu=None, want_y: bool = True):

@@ -303,6 +303,18 @@ def wgrad_thin(dy, x, want_bias=True):
     return G, (dy.double().sum(0).float() if want_bias else None)
 
 
+def masked_smooth_l1_fwd(out2d, target2d, rowmask, scale):
+    d = out2d.double() * (1.0 if rowmask is None else rowmask.double().reshape(-1, 1)) - target2d.double()
+    a = d.abs()
+    return (torch.where(a < 1, 0.5 * d * d, a - 0.5).sum() * scale).float()
+
+
+def masked_smooth_l1_bwd(out2d, target2d, rowmask, scale, gloss):
+    m = torch.ones(out2d.shape[0], 1) if rowmask is None else rowmask.reshape(-1, 1)
+    d = out2d * m - target2d
+    return (gloss * scale) * m * d.clamp(-1, 1)
+
+
 def linear_fwd_segbias(x, W, segbias, rows_per_seg, residual=None, y_elu=None, want_y=True):
     seg = torch.arange(x.shape[0]) // rows_per_seg
     y = (x.double() @ W.double().t()).float() + segbias[seg]

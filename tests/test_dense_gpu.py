@@ -428,3 +428,35 @@ def test_first_layer_matches_nn_linear(cin, cout, bias):
     assert rel_err(conv.fc.weight.grad.cpu().numpy(), ref.weight.grad.cpu().numpy()) < 1e-5
     if bias:
         assert rel_err(conv.fc.bias.grad.cpu().numpy(), ref.bias.grad.cpu().numpy()) < 1e-5
+
+
+# ---- masked smooth-L1 loss of the ARAP harness (main.py:225-226) ---------------------------------------------------------
+@pytest.mark.parametrize("B,V,C,masked", [(3, 50, 120, True), (2, 33, 7, True), (1, 1, 4, False), (4, 5041, 120, True)])
+def test_masked_smooth_l1_matches_the_torch_composition(B, V, C, masked):
+    import torch.nn.functional as F
+
+    from surfacenetworks_amd import arap
+
+    torch.manual_seed(B * V + C)
+    out = (torch.randn(B, V, C, device=DEV) * 1.5).requires_grad_(True)       # |d| on both sides of 1
+    tgt = torch.randn(B, V, C, device=DEV)
+    mask = (torch.rand(B, V, 1, device=DEV) > 0.3).float() if masked else torch.ones(B, V, 1, device=DEV)
+    loss = arap.loss_fn(out, tgt, mask, B)
+    (loss * 3.0).backward()                                                     # a non-unit upstream gradient
+    o64 = out.detach().double().requires_grad_(True)
+    ref = F.smooth_l1_loss(o64 * mask.double(), tgt.double(), reduction="sum") / B
+    (ref * 3.0).backward()
+    assert abs(loss.item() - ref.item()) <= 1e-6 * abs(ref.item())
+    assert rel_err(out.grad.cpu().numpy(), o64.grad.cpu().numpy()) < 1e-6
+    # and bit-for-bit the gradient torch's own fp32 chain produces when the scale is a power of two
+    if B in (1, 2, 4):
+        o32 = out.detach().clone().requires_grad_(True)
+        (F.smooth_l1_loss(o32 * mask.expand_as(o32), tgt, reduction="sum") / B).backward()
+        out.grad = None
+        arap.loss_fn(out, tgt, mask, B).backward()
+        assert torch.equal(out.grad, o32.grad)
+
+
+def test_masked_smooth_l1_empty_batch():
+    loss = kernels.masked_smooth_l1_fwd(torch.zeros(0, 120, device=DEV), torch.zeros(0, 120, device=DEV), None, 1.0)
+    assert loss.item() == 0.0
