@@ -199,11 +199,17 @@ class ClothSequences:
             self.pool_L = OperatorPool(mats["L"], self.device, want_bsr4=False)
 
     def _vertex_major(self):
-        """(n, vmax, frames*3) copy of self.xyz (n, frames, vmax, 3), rebuilt when self.xyz is replaced."""
+        """Window views (n, vmax, start frame, 3*INPUT_FRAMES) and (n, vmax, start frame, 3*OUTPUT_FRAMES) of a vertex-major
+        (n, vmax, frames*3) copy of self.xyz (n, frames, vmax, 3); rebuilt when self.xyz is replaced."""
         cached = getattr(self, "_xyz_vm", None)
         if cached is None or cached[0] is not self.xyz:
             n, fr, vmax, _ = self.xyz.shape
-            cached = (self.xyz, self.xyz.permute(0, 2, 1, 3).reshape(n, vmax, fr * 3).contiguous())
+            vm = self.xyz.permute(0, 2, 1, 3).reshape(n, vmax, fr * 3).contiguous()
+            nwin = fr - (INPUT_FRAMES + OUTPUT_FRAMES) + 1
+            st = (vmax * fr * 3, fr * 3, 3, 1)
+            win_in = vm.as_strided((n, vmax, nwin, 3 * INPUT_FRAMES), st)
+            win_tg = vm.as_strided((n, vmax, nwin, 3 * OUTPUT_FRAMES), st, 3 * INPUT_FRAMES)
+            cached = (self.xyz, (win_in, win_tg))
             self._xyz_vm = cached
         return cached[1]
 
@@ -224,12 +230,9 @@ class ClothSequences:
         off = torch.from_numpy(offsets).to(self.device)
         # a sample's 42 frames of a vertex are one contiguous run of the vertex-major copy: inputs and targets are gathered
         # straight into their final (B, nv, frames*3) layout (no permute / slice copies of the 160 MB window)
-        vm = self._vertex_major()                                                                    # (n, vmax, frames*3)
-        vr = torch.arange(nv, device=self.device)[None, :, None]
-        col = 3 * off[:, None, None] + torch.arange(3 * (INPUT_FRAMES + OUTPUT_FRAMES), device=self.device)[None, None, :]
-        s3 = sid[:, None, None]
-        inputs = vm[s3, vr, col[:, :, : 3 * INPUT_FRAMES]]
-        targets = vm[s3, vr, col[:, :, 3 * INPUT_FRAMES:]]
+        win_in, win_tg = self._vertex_major()                      # (n, vmax, start frame, 6 | 120) overlapping windows
+        inputs = win_in[sid, :nv, off]                             # index tensors stay (B,): one gather each
+        targets = win_tg[sid, :nv, off]
         mask = (torch.arange(nv, device=self.device)[None, :] < self.vcount[sid][:, None]).float().unsqueeze(2)
         op_ids = seq_ids * self.op_frames + (offsets + INPUT_FRAMES - 1)
         L = Di = DiA = None
