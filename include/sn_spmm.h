@@ -284,14 +284,15 @@ int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx,
  * sn_bn_fold_f32 : from the column statistics (stats = [sums | sums of squares], fp64, `rows` rows) or, when
  *   training == 0, from running_mean / running_var, compute mean[C], invstd[C], s = gamma*invstd, t = beta - mean*s,
  *   Wf = W·diag(s) (J x C), bf = b + W·t; in training mode also update running_mean / running_var in place with
- *   `momentum` and the unbiased variance, as nn.BatchNorm1d does.  b may be NULL.
+ *   `momentum` and the unbiased variance, as nn.BatchNorm1d does, and add 1 to *num_batches_tracked (may be NULL).
+ *   b may be NULL.
  * sn_bn_bwd_coeffs_f32 : from Gc = dyᵀ·(x - mean) (J x C), the column sums of dy (fp64, first J entries of `dystats`),
  *   W, s, invstd, mean, beta: dW = s∘Gc + colsum(dy) ⊗ beta, db = colsum(dy), dgamma = invstd ∘ sum_j W∘Gc,
  *   dbeta = colsum(dy)·W, and the coefficients of the elementwise tail Bc = -s∘invstd∘dgamma/rows, Cc = -s∘dbeta/rows. */
 int sn_bn_fold_f32(const double *stats, int64_t rows, const float *gamma, const float *beta, const float *W,
                    const float *b, int32_t J, int32_t C, double eps, double momentum, int32_t training,
                    float *running_mean, float *running_var, float *mean, float *invstd, float *s, float *t,
-                   float *Wf, float *bf, void *stream);
+                   float *Wf, float *bf, int64_t *num_batches_tracked, void *stream);
 int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W, const float *s, const float *invstd,
                          const float *beta, int64_t rows, int32_t J, int32_t C, float *dW, float *db, float *dgamma,
                          float *dbeta, float *Bc, float *Cc, void *stream);

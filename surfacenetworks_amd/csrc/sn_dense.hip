@@ -741,10 +741,12 @@ __global__ __launch_bounds__(kWG) void bn_fold_k(const double *__restrict__ stat
                                                  float *__restrict__ running_mean, float *__restrict__ running_var,
                                                  float *__restrict__ mean_o, float *__restrict__ invstd_o,
                                                  float *__restrict__ s_o, float *__restrict__ t_o,
-                                                 float *__restrict__ Wf, float *__restrict__ bf) {
+                                                 float *__restrict__ Wf, float *__restrict__ bf,
+                                                 int64_t *__restrict__ num_batches_tracked) {
   __shared__ float ss[1024], st[1024];
   __shared__ double red[kWG];
   const int j = blockIdx.x;
+  if (j == 0 && threadIdx.x == 0 && training && num_batches_tracked) num_batches_tracked[0] += 1;   // nn.BatchNorm1d's counter
   for (int c = threadIdx.x; c < C; c += kWG) {
     double mean, var;
     if (training) {
@@ -805,6 +807,7 @@ __global__ __launch_bounds__(kWG) void bn_bwd_coeffs_k(const float *__restrict__
   double a = 0, p = 0;
   if (c < C) {
     const double sc = s[c], bc = beta[c];
+#pragma unroll 4
     for (int j = g; j < J; j += 8) {
       const double w = W[(int64_t)j * C + c], gg = Gc[(int64_t)j * C + c];
       a += sdy[j] * w;
@@ -997,11 +1000,27 @@ __global__ __launch_bounds__(kWG) void segstats_final_k(const double *__restrict
     for (int g = gg; g < nseg; g += 8) {
       double ms = 0;
       const double *p = partial + (int64_t)g * nslab * 3 * C + c;
+      if (nslab == kSegSlabs) {                  // the launch below always uses kSegSlabs: all 48 loads of a mesh in flight
+        double v[kSegSlabs][3];
+#pragma unroll
+        for (int sl = 0; sl < kSegSlabs; ++sl) {
+          v[sl][0] = p[(int64_t)sl * 3 * C];
+          v[sl][1] = p[(int64_t)sl * 3 * C + C];
+          v[sl][2] = p[(int64_t)sl * 3 * C + 2 * C];
+        }
+#pragma unroll
+        for (int sl = 0; sl < kSegSlabs; ++sl) {
+          ms += v[sl][0];
+          U += v[sl][1];
+          Q += v[sl][2];
+        }
+      } else {
 #pragma unroll 8
-      for (int sl = 0; sl < nslab; ++sl) {
-        ms += p[(int64_t)sl * 3 * C];
-        U += p[(int64_t)sl * 3 * C + C];
-        Q += p[(int64_t)sl * 3 * C + 2 * C];
+        for (int sl = 0; sl < nslab; ++sl) {
+          ms += p[(int64_t)sl * 3 * C];
+          U += p[(int64_t)sl * 3 * C + C];
+          Q += p[(int64_t)sl * 3 * C + 2 * C];
+        }
       }
       const float mv = (float)ms * inv_count[g];
       m[(int64_t)g * C + c] = mv;
@@ -1304,13 +1323,14 @@ int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx,
 int sn_bn_fold_f32(const double *stats, int64_t rows, const float *gamma, const float *beta, const float *W,
                    const float *b, int32_t J, int32_t C, double eps, double momentum, int32_t training,
                    float *running_mean, float *running_var, float *mean, float *invstd, float *s, float *t,
-                   float *Wf, float *bf, void *stream) {
+                   float *Wf, float *bf, int64_t *num_batches_tracked, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || C > 1024) return SN_E_SHAPE;
   if (!gamma || !beta || !W || !mean || !invstd || !s || !t || !Wf || !bf) return SN_E_NULL;
   if (training ? !stats : (!running_mean || !running_var)) return SN_E_NULL;
   hipLaunchKernelGGL(bn_fold_k, dim3(J), dim3(kWG), 0, static_cast<hipStream_t>(stream), stats, rows, gamma, beta, W,
-                     b, (int)C, eps, momentum, (int)training, running_mean, running_var, mean, invstd, s, t, Wf, bf);
+                     b, (int)C, eps, momentum, (int)training, running_mean, running_var, mean, invstd, s, t, Wf, bf,
+                     num_batches_tracked);
   return launch_status();
 }
 

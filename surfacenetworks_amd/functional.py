@@ -366,6 +366,12 @@ def unstash(ctx):
     return [tuple(t[i] if isinstance(i, int) else i.v for i in gs) for gs in ctx._sn_spec]
 
 
+def _take_counter(running_mean):
+    """The num_batches_tracked tensor bn_prepare left on the running-mean buffer for THIS call (one-shot), or None."""
+    d = getattr(running_mean, "__dict__", None)
+    return d.pop("_sn_nbt", None) if d is not None else None
+
+
 def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual=None, elu_out=None,
                   want_y=True):
     """Forward of the folded BatchNorm1d("pre") + Linear on a (rows, C) operand (no autograd): statistics in one pass
@@ -378,7 +384,7 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     if training:
         stats, rows_g = _sync_stats(stats, rows)
     mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
-                                                 running_var)
+                                                 running_var, _take_counter(running_mean))
     if residual is not None:
         residual = _rows2d(residual)
     if kernels.linear_fwd_supported(x.shape[1], W.shape[0]):
@@ -442,7 +448,8 @@ def avg_stage_forward(e, mask_rows, inv_count, nseg, per, gamma, beta, W, b, run
     rows, C = e.shape
     m, stats = kernels.avg_stats(e, mask_rows, inv_count, per, nseg)       # per-mesh mean + BatchNorm statistics, one pass over e
     stats, rows_g = _sync_stats(stats, rows)
-    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, True, running_mean, running_var)
+    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, True, running_mean, running_var,
+                                                 _take_counter(running_mean))
     segb = kernels.seg_affine(m, Wf[:, C:], bf)
     if residual is not None:
         residual = _rows2d(residual)
@@ -486,12 +493,14 @@ class _BNLinear(torch.autograd.Function):
 
 
 def bn_prepare(bn: torch.nn.BatchNorm1d):
-    """Per-call bookkeeping nn.BatchNorm1d does in Python: returns (training, momentum, eps) and bumps num_batches_tracked."""
+    """Per-call bookkeeping nn.BatchNorm1d does in Python: returns (training, momentum, eps).  The num_batches_tracked
+    counter is bumped by the fold kernel of this call (sn_bn_fold_f32) instead of a launch of its own: it rides on the
+    running-mean buffer as a one-shot attribute that bnlin_forward / avg_stage_forward pick up."""
     training = bn.training or not bn.track_running_stats
     if bn.momentum is None or not bn.affine:
         raise NotImplementedError("the fused BatchNorm+Linear supports the default affine BatchNorm1d with a fixed momentum")
-    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None and bn.running_mean is not None:
+        bn.running_mean._sn_nbt = bn.num_batches_tracked
     return training, bn.momentum, bn.eps
 
 

@@ -240,10 +240,13 @@ def affine_cols_acc(dx, x, B, Cc, center=None) -> None:
     _lib.call("sn_affine_cols_acc_f32", _p(dx), _ld(dx), _p(x), _ld(x), _p(center), _p(B), _p(Cc), x.shape[0], x.shape[1], _stream())
 
 
-def bn_fold(stats, rows: int, gamma, beta, W, b, eps: float, momentum: float, training: bool, running_mean, running_var):
+def bn_fold(stats, rows: int, gamma, beta, W, b, eps: float, momentum: float, training: bool, running_mean, running_var,
+            num_batches_tracked=None):
     """Fold BatchNorm into the Linear weights (see sn_bn_fold_f32). Returns (mean, invstd, s, t, Wf, bf); updates the
-    running statistics in place when training."""
-    _dev(stats, gamma, beta, W, b, running_mean, running_var)
+    running statistics (and the int64 batch counter, when given) in place when training."""
+    _dev(stats, gamma, beta, W, b, running_mean, running_var, num_batches_tracked)
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        raise TypeError("num_batches_tracked must be int64")
     J, C = W.shape
     dev = W.device
     vec = torch.empty((4, C), dtype=torch.float32, device=dev)
@@ -251,7 +254,7 @@ def bn_fold(stats, rows: int, gamma, beta, W, b, eps: float, momentum: float, tr
     bf = torch.empty(J, dtype=torch.float32, device=dev)
     _lib.call("sn_bn_fold_f32", _p(stats), rows, _p(gamma), _p(beta), _p(W.contiguous()), _p(b), J, C, float(eps),
               float(momentum), 1 if training else 0, _p(running_mean), _p(running_var), _p(vec[0]), _p(vec[1]),
-              _p(vec[2]), _p(vec[3]), _p(Wf), _p(bf), _stream())
+              _p(vec[2]), _p(vec[3]), _p(Wf), _p(bf), _p(num_batches_tracked), _stream())
     return vec[0], vec[1], vec[2], vec[3], Wf, bf
 
 

@@ -145,8 +145,11 @@ def affine_cols_acc(dx, x, B, Cc, center=None):
                                  None if center is None else _np(center))
 
 
-def bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training, running_mean, running_var):
+def bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training, running_mean, running_var, num_batches_tracked=None):
     """numpy/double restatement of what nn.BatchNorm1d + the weight folding compute (checker for sn_bn_fold_f32)."""
+    if training and num_batches_tracked is not None:
+        with torch.no_grad():
+            num_batches_tracked.add_(1)
     g, be, Wd = _np(gamma).astype(np.float64), _np(beta).astype(np.float64), _np(W).astype(np.float64)
     if training:
         st = _np(stats)
