@@ -246,6 +246,17 @@ int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64
 size_t sn_colstats_workspace_bytes(int64_t rows, int32_t C);
 int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *out,
                     void *workspace, size_t workspace_bytes, void *stream);
+/* sn_colstats_into_f32 : the same statistics written as ONE HALF of a wider vector: sums at out[out_off + c], sums of
+ *                   squares at out[out_ld + out_off + c] (out_ld = full width).
+ * sn_colstats_merge_f64 : the other half, from the per-workgroup partials ([nblk][2][C] fp64, nblk =
+ *                   sn_linear_fwd_stats_blocks(rows)) that sn_linear_fwd_f32 / sn_linear_fwd_segbias_f32 leave when asked for
+ *                   the column statistics of their ELU output (elu_stats_part): the statistics pass of the next stage then
+ *                   reads only the propagated half of its concat buffer. */
+int sn_colstats_into_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *out, int64_t out_ld, int64_t out_off,
+                         void *workspace, size_t workspace_bytes, void *stream);
+int sn_colstats_merge_f64(const double *part, int32_t nblk, int32_t C, double *out, int64_t out_ld, int64_t out_off,
+                          void *stream);
+int32_t sn_linear_fwd_stats_blocks(int64_t rows);
 size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C);
 int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                  int32_t J, int32_t C, float *G, double *dysum, void *workspace, size_t workspace_bytes, void *stream);
@@ -432,7 +443,8 @@ int sn_laplacian_csr_from_mesh(const float *V, const int32_t *F, int64_t nV, int
  * ------------------------------------------------------------------------------------------ */
 int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias,
                       const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu, int64_t lde,
-                      int64_t rows, int32_t K, int32_t J, void *stream);
+                      int64_t rows, int32_t K, int32_t J, double *elu_stats_part /* NULL | [stats_blocks][2][128] */,
+                      void *stream);
 int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
                         const float *center, const float *B, const float *Cc, float *dx, int64_t lddx,
                         int64_t rows, int32_t J, int32_t C, void *stream);
@@ -442,7 +454,8 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
                             int64_t rows, int32_t J, int32_t C, void *stream);
 int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
                               int64_t rows_per_seg, const float *residual, int64_t ldr, float *y, int64_t ldy,
-                              float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J, void *stream);
+                              float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J, double *elu_stats_part,
+                              void *stream);
 int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
                                const float *center, const float *B, const float *Cc, const float *segvec,
                                int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,

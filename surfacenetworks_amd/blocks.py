@@ -43,6 +43,20 @@ def _new_cat(rows, C, device):
     return torch.empty((rows, 2 * C), dtype=torch.float32, device=device)
 
 
+def _new_part(rows, C, device):
+    """Workspace in which the GEMM that writes elu(y) into a concat buffer's first half also leaves that half's column
+    statistics (kernels.linear_fwd `elu_stats`), or None where the fused GEMM does not offer it."""
+    if C != 128 or not kernels.elu_stats_supported():
+        return None
+    return kernels.new_elu_stats_part(rows, device)
+
+
+def _attach_part(cat, part):
+    """The statistics travel with the buffer object: bnlin_forward(cat, ...) then reads only the propagated half."""
+    if part is not None:
+        cat._sn_part = part
+
+
 def _activated(x2d, pre):
     """(rows, 2C) buffer whose first half is elu(x2d): the handed-off one, or a new one filled here."""
     if pre is not None:
@@ -75,7 +89,9 @@ class _DiracBlock(torch.autograd.Function):
         cat0 = pre_f if pre_f is not None else _activated(_rows2d(f), None)    # (f's values are not touched when handed off)
         _launch(opDi, cat1[:, :C], cat0[:, C:], 4, "fwd")
         nxt_f = _new_cat(rf, C, v.device)                        # the next Dirac block's cat0; first half = elu(f_out)
-        f_out, st0 = bnlin_forward(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, nxt_f[:, :C], want_y=need_f)
+        pf = _new_part(rf, C, v.device)
+        f_out, st0 = bnlin_forward(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, nxt_f[:, :C], want_y=need_f, elu_stats=pf)
+        _attach_part(nxt_f, pf)
         if f_out is None:
             # The caller only chains f into the next Dirac block, which consumes the ACTIVATED hand-off: the pre-activation
             # face features are not written (321 MB per block at the ARAP batch).  What is returned in their place is a
@@ -83,7 +99,9 @@ class _DiracBlock(torch.autograd.Function):
             f_out = torch.full((1, 1), float("nan"), dtype=torch.float32, device=v.device).expand(rf, C)
         _launch(opDiA, nxt_f[:, :C], cat1[:, C:], 4, "fwd")
         nxt_v = _new_cat(rv, C, v.device)
-        v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C])
+        pv = _new_part(rv, C, v.device)
+        v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C], elu_stats=pv)
+        _attach_part(nxt_v, pv)
         ctx.ops = (opDi, opDiA)
         stash(ctx, (cat0, cat1, nxt_f), st0, st1)
         ctx.mark_non_differentiable(nxt_v, nxt_f)
@@ -169,11 +187,15 @@ class _PropagateBlock(torch.autograd.Function):
         cat_a = _activated(x, pre)
         propagate(cat_a)
         cat_b = _new_cat(rows, C, x.device)
+        pb = _new_part(rows, C, x.device)
         _, st0 = bnlin_forward(cat_a, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, cat_b[:, :C],
-                               want_y=False)                     # only elu(h) is consumed
+                               want_y=False, elu_stats=pb)       # only elu(h) is consumed
+        _attach_part(cat_b, pb)
         propagate(cat_b)
         nxt = _new_cat(rows, C, x.device)
-        out, st1 = bnlin_forward(cat_b, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x, nxt[:, :C])
+        pn = _new_part(rows, C, x.device)
+        out, st1 = bnlin_forward(cat_b, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x, nxt[:, :C], elu_stats=pn)
+        _attach_part(nxt, pn)
         ctx.op, ctx.seg = op, (mask_rows, inv_count, nseg, per)
         stash(ctx, (cat_a, cat_b), st0, st1)
         ctx.mark_non_differentiable(nxt)
@@ -228,8 +250,10 @@ class _AvgBlock(torch.autograd.Function):
         _, st0 = avg_stage_forward(e_a, mask_rows, inv_count, nseg, per, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, e_b,
                                    want_y=False)                      # only elu(h) is needed downstream
         nxt = _new_cat(rows, C, x.device)
+        pn = _new_part(rows, C, x.device)
         out, st1 = avg_stage_forward(e_b, mask_rows, inv_count, nseg, per, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x,
-                                     nxt[:, :C])
+                                     nxt[:, :C], elu_stats=pn)
+        _attach_part(nxt, pn)
         stash(ctx, st0, st1, (mask_rows, inv_count))
         ctx.seg = (nseg, per)
         ctx.mark_non_differentiable(nxt)

@@ -99,8 +99,10 @@ __global__ __launch_bounds__(kWG) void colstats_k(const float *__restrict__ x, i
 }
 
 // 32 columns x 8 partial groups per block; group g sums partial blocks g, g+8, ... ; groups combined in fixed order.
+// Element i of a partial row is (kind = i / Ch, column = i % Ch), Ch = C2/2; it lands at out[kind * out_ld + out_off + column]
+// (out_ld = Ch, out_off = 0: the plain [sums | squares] vector; otherwise one half of a wider statistics vector).
 __global__ __launch_bounds__(kWG) void colstats_final_k(const double *__restrict__ partial, int nblk, int C2,
-                                                        double *__restrict__ out) {
+                                                        double *__restrict__ out, int64_t out_ld, int64_t out_off) {
   __shared__ double sm[8][32];
   const int cg = threadIdx.x & 31, pg = threadIdx.x >> 5;
   const int i = blockIdx.x * 32 + cg;
@@ -123,7 +125,8 @@ __global__ __launch_bounds__(kWG) void colstats_final_k(const double *__restrict
     double r = 0;
 #pragma unroll
     for (int g = 0; g < 8; ++g) r += sm[g][cg];
-    out[i] = r;
+    const int Ch = C2 >> 1, kind = i >= Ch;
+    out[(int64_t)kind * out_ld + out_off + (i - kind * Ch)] = r;
   }
 }
 
@@ -1113,14 +1116,14 @@ size_t sn_colstats_workspace_bytes(int64_t rows, int32_t C) {
   return (size_t)stat_blocks(rows) * 2 * (size_t)C * sizeof(double);
 }
 
-int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *out, void *workspace,
-                    size_t workspace_bytes, void *stream) {
-  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
-  if (rows < 0 || C < 1 || C > 4096 || ld < C) return SN_E_SHAPE;
+static int colstats_launch(const float *x, int64_t ld, int64_t rows, int32_t C, double *out, int64_t out_ld, int64_t out_off,
+                           void *workspace, size_t workspace_bytes, void *stream) {
+  if (rows < 0 || C < 1 || C > 4096 || ld < C || out_off < 0 || out_ld < out_off + C) return SN_E_SHAPE;
   if (!out) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (rows == 0) {
-    hipError_t e = hipMemsetAsync(out, 0, (size_t)2 * C * sizeof(double), s);
+    hipError_t e = hipMemsetAsync(out + out_off, 0, (size_t)C * sizeof(double), s);
+    if (e == hipSuccess) e = hipMemsetAsync(out + out_ld + out_off, 0, (size_t)C * sizeof(double), s);
     return e == hipSuccess ? SN_OK : (int)e;
   }
   if (!x || !workspace) return SN_E_NULL;
@@ -1136,7 +1139,29 @@ int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double 
     hipLaunchKernelGGL((colstats_k<true>), dim3(nblk), dim3(kWG), shm, s, x, ld, rows, (int)C, partial);
   else
     hipLaunchKernelGGL((colstats_k<false>), dim3(nblk), dim3(kWG), shm, s, x, ld, rows, (int)C, partial);
-  hipLaunchKernelGGL(colstats_final_k, dim3((2 * C + 31) / 32), dim3(kWG), 0, s, partial, nblk, 2 * (int)C, out);
+  hipLaunchKernelGGL(colstats_final_k, dim3((2 * C + 31) / 32), dim3(kWG), 0, s, partial, nblk, 2 * (int)C, out, out_ld, out_off);
+  return launch_status();
+}
+
+int sn_colstats_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *out, void *workspace,
+                    size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  return colstats_launch(x, ld, rows, C, out, C, 0, workspace, workspace_bytes, stream);
+}
+
+int sn_colstats_into_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *out, int64_t out_ld, int64_t out_off,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  return colstats_launch(x, ld, rows, C, out, out_ld, out_off, workspace, workspace_bytes, stream);
+}
+
+int sn_colstats_merge_f64(const double *part, int32_t nblk, int32_t C, double *out, int64_t out_ld, int64_t out_off,
+                          void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (nblk < 0 || C < 1 || out_off < 0 || out_ld < out_off + C) return SN_E_SHAPE;
+  if (!out || (nblk > 0 && !part)) return SN_E_NULL;
+  hipLaunchKernelGGL(colstats_final_k, dim3((2 * C + 31) / 32), dim3(kWG), 0, static_cast<hipStream_t>(stream), part, (int)nblk,
+                     2 * (int)C, out, out_ld, out_off);
   return launch_status();
 }
 

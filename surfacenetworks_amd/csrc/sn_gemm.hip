@@ -53,6 +53,10 @@ struct EpiArgs {
   const float *segv;
   int64_t period, ldseg;
   const float *rowmask;
+  // forward with an ELU copy: per-workgroup column sums / sums of squares of the ACTIVATED output, [gridDim.x][2][128] fp64
+  // (NULL: not wanted) — the BatchNorm statistics of the first half of the next stage's concat buffer, so that the
+  // statistics pass of that stage reads only the propagated half
+  double *stats;
 };
 
 template <int K, int NT, bool TRANSW, int EPI>
@@ -313,7 +317,15 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
   const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
   int64_t tile = (int64_t)blockIdx.x * per;
   const int64_t tend = tile + per < ntiles ? tile + per : ntiles;
-  if (tile >= tend) return;
+  constexpr bool STATS = (EPI == EPI_FWD) && ELU && NT == 1;
+  if (tile >= tend) {
+    if constexpr (STATS)
+      if (ep.stats) ep.stats[(int64_t)blockIdx.x * 256 + threadIdx.x] = 0.0;        // a workgroup without tiles adds nothing
+    return;
+  }
+  double ssum[STATS ? 4 : 1], ssq[STATS ? 4 : 1];
+#pragma unroll
+  for (int i = 0; i < (STATS ? 4 : 1); ++i) ssum[i] = ssq[i] = 0.0;
   const float *side_p = (EPI == EPI_FWD) ? ep.v1 : ep.v0;   // SIDE: forward: the residual; dgrad: x of the BatchNorm tail
   // ---- epilogue geometry: the slab goes through LDS so that global accesses are full lines — lane l handles the 16 bytes
   // at chunk (l % CPR) of rows (l / CPR) + RPI·j; its columns, hence its epilogue constants, are fixed for the kernel ----
@@ -495,8 +507,16 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
         }
       } else if (r < rows) {
         if (EPI != EPI_FWD || Out) *reinterpret_cast<f4 *>(Out + r * ldo + ecol) = v;
-        if constexpr (EPI == EPI_FWD && ELU)
-          *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
+        if constexpr (EPI == EPI_FWD && ELU) {
+          const f4 ev = f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
+          *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = ev;
+          if constexpr (STATS) {
+            const double e0 = ev.x, e1 = ev.y, e2 = ev.z, e3 = ev.w;
+            ssum[0] += e0; ssum[1] += e1; ssum[2] += e2; ssum[3] += e3;
+            ssq[0] = __builtin_fma(e0, e0, ssq[0]); ssq[1] = __builtin_fma(e1, e1, ssq[1]);
+            ssq[2] = __builtin_fma(e2, e2, ssq[2]); ssq[3] = __builtin_fma(e3, e3, ssq[3]);
+          }
+        }
       }
     }
   };
@@ -505,6 +525,24 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
     if (++tile >= tend) break;
     do_tile(IC<1>{}, tile);
     if (++tile >= tend) break;
+  }
+  if constexpr (STATS) {
+    if (ep.stats) {
+      // lane (erow, chunk) holds the sums of its 4 columns over its rows of every tile: combine the 8 row lanes of a
+      // chunk through this wave's staging area (same-wave LDS operations complete in order), in a fixed order
+      static_assert(CPR == 8 && 32 * SROW >= 64 * 64, "statistics staging assumes the NT == 1 epilogue geometry");
+      double *sl = reinterpret_cast<double *>(&stg[wave][0]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        sl[lane * 8 + i] = ssum[i];
+        sl[lane * 8 + 4 + i] = ssq[i];
+      }
+      const int chunk = lane >> 3, val = lane & 7;
+      double tot = 0.0;
+#pragma unroll
+      for (int er = 0; er < 8; ++er) tot += sl[(er * 8 + chunk) * 8 + val];
+      ep.stats[(int64_t)blockIdx.x * 256 + (val >> 2) * 128 + 32 * wave + 4 * chunk + (val & 3)] = tot;
+    }
   }
 }
 
@@ -528,9 +566,11 @@ inline unsigned gemm_grid(int64_t rows) {
 
 extern "C" {
 
+int32_t sn_linear_fwd_stats_blocks(int64_t rows) { return rows > 0 ? (int32_t)gemm_grid(rows) : 0; }
+
 int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias,
                       const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu, int64_t lde,
-                      int64_t rows, int32_t K, int32_t J, void *stream) {
+                      int64_t rows, int32_t K, int32_t J, double *elu_stats_part, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J)) return SN_E_SHAPE;
   if (J != 128 || (K != 128 && K != 256)) return SN_E_UNSUPPORTED;
@@ -539,7 +579,8 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
   if (!aligned16(x) || !aligned16(W) || !aligned16(bias) || (y && (!aligned16(y) || (ldy % 4))) || (ldx % 4) || (ldw % 4) ||
       (residual && (!aligned16(residual) || (ldr % 4) || ldr < J)) || (y_elu && (!aligned16(y_elu) || (lde % 4) || lde < J)))
     return SN_E_ALIGN;
-  EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr};
+  if (elu_stats_part && (!y_elu || gemm_variant() == 0)) return SN_E_UNSUPPORTED;
+  EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr, elu_stats_part};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
   const bool x3 = gemm_variant() != 0;
@@ -626,7 +667,7 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
 
 int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
                               int64_t rows_per_seg, const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu,
-                              int64_t lde, int64_t rows, int32_t K, int32_t J, void *stream) {
+                              int64_t lde, int64_t rows, int32_t K, int32_t J, double *elu_stats_part, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J) || rows_per_seg < 1) return SN_E_SHAPE;
   if (J != 128 || (K != 128 && K != 256) || rows_per_seg < 32 || gemm_variant() == 0) return SN_E_UNSUPPORTED;
@@ -635,7 +676,8 @@ int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64
   if (!aligned16(x) || !aligned16(W) || !aligned16(segbias) || (y && (!aligned16(y) || (ldy % 4))) || (ldx % 4) || (ldw % 4) ||
       (residual && (!aligned16(residual) || (ldr % 4) || ldr < J)) || (y_elu && (!aligned16(y_elu) || (lde % 4) || lde < J)))
     return SN_E_ALIGN;
-  EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, rows_per_seg, J, nullptr};
+  if (elu_stats_part && !y_elu) return SN_E_UNSUPPORTED;
+  EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, rows_per_seg, J, nullptr, elu_stats_part};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
   const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);

@@ -373,13 +373,21 @@ def _take_counter(running_mean):
 
 
 def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual=None, elu_out=None,
-                  want_y=True):
+                  want_y=True, elu_stats=None):
     """Forward of the folded BatchNorm1d("pre") + Linear on a (rows, C) operand (no autograd): statistics in one pass
     (fp64 accumulation), BN folded into the weights  y = x·(W·diag(s))ᵀ + (b + W·t),  s = gamma*invstd, t = beta - mean*s,
     optional residual add and ELU copy in the GEMM epilogue.  Returns (y, state) with `state` for bnlin_backward."""
+    # x may carry `_sn_part`: the column statistics of its first half, left by the GEMM that wrote it (blocks.py) — the
+    # statistics pass then reads only the propagated half
+    part = getattr(x, "_sn_part", None)
     x = _rows2d(x)
     rows = x.shape[0]
-    stats = kernels.colstats(x) if training else None
+    if not training:
+        stats = None
+    elif part is not None and x.shape[1] == 256:
+        stats = kernels.colstats_halves(x, part)
+    else:
+        stats = kernels.colstats(x)
     rows_g = rows
     if training:
         stats, rows_g = _sync_stats(stats, rows)
@@ -388,8 +396,10 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     if residual is not None:
         residual = _rows2d(residual)
     if kernels.linear_fwd_supported(x.shape[1], W.shape[0]):
-        y = kernels.linear_fwd(x, Wf, bf, residual, elu_out, want_y)   # row-streaming GEMM, weights in registers (sn_gemm.hip)
+        y = kernels.linear_fwd(x, Wf, bf, residual, elu_out, want_y, elu_stats)   # row-streaming GEMM, weights in registers
     else:
+        if elu_stats is not None:
+            raise ValueError("bnlin_forward: elu_stats needs a shape the fused GEMM covers")
         y = torch.addmm(bf, x, Wf.t())
         if residual is not None:
             y += residual
@@ -439,7 +449,7 @@ def bnlin_backward(state, dy, need_dx=True, through_elu=None):
 
 
 def avg_stage_forward(e, mask_rows, inv_count, nseg, per, gamma, beta, W, b, running_mean, running_var, training, momentum,
-                      eps, residual=None, elu_out=None, want_y=True):
+                      eps, residual=None, elu_out=None, want_y=True, elu_stats=None):
     """One stage of AvgResNet2 (utils_pt.py:230-243), Lin(BN([e | global_average(e) broadcast])), at HALF width: the second
     half of the concat buffer is a per-mesh constant m, so it is never materialised — its BatchNorm statistics follow from
     m (nseg x C numbers), its share of the Linear product is a per-mesh bias m·Wf[:, C:]^T + bf, and the GEMM runs over the
@@ -453,7 +463,7 @@ def avg_stage_forward(e, mask_rows, inv_count, nseg, per, gamma, beta, W, b, run
     segb = kernels.seg_affine(m, Wf[:, C:], bf)
     if residual is not None:
         residual = _rows2d(residual)
-    y = kernels.linear_fwd_segbias(e, Wf[:, :C], segb, per, residual, elu_out, want_y)
+    y = kernels.linear_fwd_segbias(e, Wf[:, :C], segb, per, residual, elu_out, want_y, elu_stats)
     return y, (e, m, W, Wf, s, mean, invstd, beta, b is not None, rows_g)
 
 

@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "elu_stats_supported", "new_elu_stats_part", "colstats_halves",
 ]
 
 
@@ -349,17 +349,52 @@ def linear_fwd_supported(K: int, J: int) -> bool:
     return J == 128 and K in (128, 256)
 
 
-def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y: bool = True):
+def elu_stats_supported() -> bool:
+    """Column statistics of the ELU output from the GEMM epilogue exist only in the split-bf16 kernels."""
+    import os
+
+    return os.environ.get("SN_GEMM_VARIANT", "1") != "0"
+
+
+def new_elu_stats_part(rows: int, device):
+    """Workspace for the per-workgroup column sums / sums of squares of a forward GEMM's ELU output (128 columns)."""
+    nblk = int(_lib.load().sn_linear_fwd_stats_blocks(rows))
+    return torch.empty((max(nblk, 1), 2, 128), dtype=torch.float64, device=device)
+
+
+def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y: bool = True, elu_stats=None):
     """y = x·Wᵀ + bias (+ residual); optionally also writes elu(y) into the 2-D view `y_elu` (sn_linear_fwd_f32).
-    want_y=False (with y_elu): only the activated copy is written and None is returned."""
-    _dev(x, W, bias, residual, y_elu)
+    want_y=False (with y_elu): only the activated copy is written and None is returned.
+    elu_stats (from new_elu_stats_part): receives the column statistics of elu(y), see colstats_halves."""
+    _dev(x, W, bias, residual, y_elu, elu_stats)
     rows, K = x.shape
     J = W.shape[0]
     y = torch.empty((rows, J), dtype=torch.float32, device=x.device) if (want_y or y_elu is None) else None
     _lib.call("sn_linear_fwd_f32", _p(x), _ld(x), _p(W), _ld(W), _p(bias), _p(residual),
               _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu), _ld(y_elu) if y_elu is not None else 0,
-              rows, K, J, _stream())
+              rows, K, J, _p(elu_stats), _stream())
     return y
+
+
+def colstats_halves(x, part):
+    """(2, 2C) float64 statistics of a stage's concat buffer x = [e | P·e] (rows, 2C), C = 128: the first half from the
+    partials `part` the GEMM that wrote e left behind (sn_colstats_merge_f64), the second half from one pass over
+    x[:, C:] only (sn_colstats_into_f32)."""
+    _dev(x, part)
+    rows, C2 = x.shape
+    C = C2 // 2
+    if C != 128 or part.dim() != 3 or part.shape[1:] != (2, 128) or part.dtype != torch.float64:
+        raise ValueError("colstats_halves: expected a (rows, 256) buffer and (nblk, 2, 128) float64 partials")
+    nblk = int(_lib.load().sn_linear_fwd_stats_blocks(rows))
+    if part.shape[0] < nblk:
+        raise ValueError("colstats_halves: partial buffer smaller than the producing launch's grid")
+    out = torch.empty((2, C2), dtype=torch.float64, device=x.device)
+    _lib.call("sn_colstats_merge_f64", _p(part), nblk, C, _p(out), C2, 0, _stream())
+    hi = x[:, C:]
+    ws_bytes = int(_lib.load().sn_colstats_workspace_bytes(rows, C))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.call("sn_colstats_into_f32", _p(hi), _ld(hi), rows, C, _p(out), C2, C, _p(ws), ws_bytes, _stream())
+    return out
 
 
 def linear_dgrad_supported(J: int, C: int) -> bool:
@@ -514,7 +549,7 @@ def masked_smooth_l1_bwd(out2d, target2d, rowmask, scale: float, gloss):
     return g
 
 
-def linear_fwd_segbias(x, W, segbias, rows_per_seg: int, residual=None, y_elu=None, want_y: bool = True):
+def linear_fwd_segbias(x, W, segbias, rows_per_seg: int, residual=None, y_elu=None, want_y: bool = True, elu_stats=None):
     """y = x·W^T + segbias[row // rows_per_seg] (+ residual), optionally elu(y) into y_elu; want_y=False: only y_elu is written."""
     _dev(x, W, segbias, residual, y_elu)
     rows, K = x.shape
@@ -522,7 +557,7 @@ def linear_fwd_segbias(x, W, segbias, rows_per_seg: int, residual=None, y_elu=No
     y = torch.empty((rows, J), dtype=torch.float32, device=x.device) if want_y else None
     _lib.call("sn_linear_fwd_segbias_f32", _p(x), _ld(x), _p(W), _ld(W), _p(segbias), rows_per_seg, _p(residual),
               _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu), _ld(y_elu) if y_elu is not None else 0,
-              rows, K, J, _stream())
+              rows, K, J, _p(elu_stats), _stream())
     return y
 
 

@@ -229,12 +229,36 @@ def linear_fwd_supported(K, J):
     return J == 128 and K in (128, 256)
 
 
-def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y=True):
+def _fill_part(part, y_elu):
+    if part is not None:
+        part.zero_()
+        part[0, 0] = y_elu.double().sum(0)
+        part[0, 1] = (y_elu.double() ** 2).sum(0)
+
+
+def elu_stats_supported():
+    return True
+
+
+def new_elu_stats_part(rows, device):
+    return torch.zeros((1, 2, 128), dtype=torch.float64)
+
+
+def colstats_halves(x, part):
+    C = x.shape[1] // 2
+    out = torch.empty((2, 2 * C), dtype=torch.float64)
+    out[:, :C] = part.sum(0)
+    out[:, C:] = colstats(x[:, C:])
+    return out
+
+
+def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y=True, elu_stats=None):
     y = (x.double() @ W.double().t() + bias.double()).float()
     if residual is not None:
         y = y + residual
     if y_elu is not None:
         y_elu.copy_(torch.nn.functional.elu(y))
+        _fill_part(elu_stats, y_elu)
     return y if (want_y or y_elu is None) else None
 
 
@@ -318,13 +342,14 @@ def masked_smooth_l1_bwd(out2d, target2d, rowmask, scale, gloss):
     return (gloss * scale) * m * d.clamp(-1, 1)
 
 
-def linear_fwd_segbias(x, W, segbias, rows_per_seg, residual=None, y_elu=None, want_y=True):
+def linear_fwd_segbias(x, W, segbias, rows_per_seg, residual=None, y_elu=None, want_y=True, elu_stats=None):
     seg = torch.arange(x.shape[0]) // rows_per_seg
     y = (x.double() @ W.double().t()).float() + segbias[seg]
     if residual is not None:
         y = y + residual
     if y_elu is not None:
         elu_into(y, y_elu)
+        _fill_part(elu_stats, y_elu)
     return y if want_y else None
 
 

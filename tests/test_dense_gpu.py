@@ -460,3 +460,37 @@ def test_masked_smooth_l1_matches_the_torch_composition(B, V, C, masked):
 def test_masked_smooth_l1_empty_batch():
     loss = kernels.masked_smooth_l1_fwd(torch.zeros(0, 120, device=DEV), torch.zeros(0, 120, device=DEV), None, 1.0)
     assert loss.item() == 0.0
+
+
+# ---- column statistics of the ELU output from the forward GEMM's epilogue ------------------------------------------------
+@pytest.mark.parametrize("rows", [1, 31, 33, 1000, 8191, 40001, 627200])
+@pytest.mark.parametrize("K,res,segbias", [(256, False, False), (256, True, False), (128, True, True), (128, False, False)])
+def test_forward_gemm_leaves_the_statistics_of_its_elu_output(rows, K, res, segbias):
+    if not kernels.elu_stats_supported():
+        pytest.skip("split-bf16 kernels only")
+    if segbias and rows < 64:
+        pytest.skip("per-mesh bias needs meshes of at least 32 rows")
+    torch.manual_seed(rows + K)
+    x = torch.randn(rows, K, device=DEV)
+    W = torch.randn(128, K, device=DEV) / np.sqrt(K)
+    b = torch.randn(128, device=DEV)
+    r = torch.randn(rows, 128, device=DEV) if res else None
+    cat = torch.empty(rows, 256, device=DEV)
+    part = kernels.new_elu_stats_part(rows, DEV)
+    part.fill_(float("nan"))                                     # every entry the merge reads must have been written
+    if segbias:
+        per = rows // 2 if rows % 2 == 0 else rows
+        segb = torch.randn(rows // per, 128, device=DEV)
+        kernels.linear_fwd_segbias(x, W, segb, per, r, cat[:, :128], False, part)
+    else:
+        kernels.linear_fwd(x, W, b, r, cat[:, :128], False, part)
+    cat[:, 128:] = torch.randn(rows, 128, device=DEV) * 2 + 1
+    got = kernels.colstats_halves(cat, part).cpu().numpy()
+    want = kernels.colstats(cat).cpu().numpy()                   # one fp64 pass over the whole buffer
+    assert np.isfinite(got).all()
+    assert np.allclose(got, want, rtol=1e-12, atol=1e-9)
+    # without the request nothing changes and the plain call still works
+    cat2 = torch.empty_like(cat)
+    kernels.linear_fwd(x, W, b, r, cat2[:, :128], False) if not segbias else \
+        kernels.linear_fwd_segbias(x, W, segb, per, r, cat2[:, :128], False)
+    assert torch.equal(cat2[:, :128], cat[:, :128])
