@@ -369,11 +369,13 @@ def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y: bool = True, elu_s
     _dev(x, W, bias, residual, y_elu, elu_stats)
     rows, K = x.shape
     J = W.shape[0]
-    y = torch.empty((rows, J), dtype=torch.float32, device=x.device) if (want_y or y_elu is None) else None
+    # (the fp32-MFMA A/B kernels, SN_GEMM_VARIANT=0, always write y)
+    keep = want_y or y_elu is None
+    y = torch.empty((rows, J), dtype=torch.float32, device=x.device) if (keep or not elu_stats_supported()) else None
     _lib.call("sn_linear_fwd_f32", _p(x), _ld(x), _p(W), _ld(W), _p(bias), _p(residual),
               _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu), _ld(y_elu) if y_elu is not None else 0,
               rows, K, J, _p(elu_stats), _stream())
-    return y
+    return y if keep else None
 
 
 def colstats_halves(x, part):
