@@ -25,10 +25,21 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
   return nt ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p);
 }
+#ifndef SN_X_EW_ST_PLAIN
+#define SN_X_EW_ST_PLAIN 0
+#endif
+#ifndef SN_X_STATS_NT
+#define SN_X_STATS_NT 0
+#endif
+#ifndef SN_X_WGRAD_NT
+#define SN_X_WGRAD_NT 0
+#endif
 __device__ __forceinline__ void st4_s(float *p, f4 v, int nt) {
-  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+  if (nt && !SN_X_EW_ST_PLAIN) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
   else *reinterpret_cast<f4 *>(p) = v;
 }
+// statistics passes (colstats_k, segstats_k): read-once operands
+__device__ __forceinline__ f4 ld4_stat(const float *p) { return ld4_s(p, SN_X_STATS_NT); }
 
 constexpr int kStreamNT = 1;     // elementwise passes stream with non-temporal loads/stores (see sn_kernels.hip)
 
@@ -60,17 +71,17 @@ __global__ __launch_bounds__(kWG) void colstats_k(const float *__restrict__ x, i
       const float *p = x + cg * 4;
       int64_t r = r0 + rl;
       for (; r + 3 * lanes_r < r1; r += 4 * lanes_r) {     // 4 independent 16-byte loads in flight
-        const f4 a = *reinterpret_cast<const f4 *>(p + r * ld);
-        const f4 b = *reinterpret_cast<const f4 *>(p + (r + lanes_r) * ld);
-        const f4 c = *reinterpret_cast<const f4 *>(p + (r + 2 * lanes_r) * ld);
-        const f4 d = *reinterpret_cast<const f4 *>(p + (r + 3 * lanes_r) * ld);
+        const f4 a = ld4_stat(p + r * ld);
+        const f4 b = ld4_stat(p + (r + lanes_r) * ld);
+        const f4 c = ld4_stat(p + (r + 2 * lanes_r) * ld);
+        const f4 d = ld4_stat(p + (r + 3 * lanes_r) * ld);
 #define SN_ACC(v)                                                                    \
   s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;        \
   q0 += (double)v.x * v.x; q1 += (double)v.y * v.y; q2 += (double)v.z * v.z; q3 += (double)v.w * v.w;
         SN_ACC(a) SN_ACC(b) SN_ACC(c) SN_ACC(d)
       }
       for (; r < r1; r += lanes_r) {
-        const f4 a = *reinterpret_cast<const f4 *>(p + r * ld);
+        const f4 a = ld4_stat(p + r * ld);
         SN_ACC(a)
 #undef SN_ACC
       }
@@ -333,7 +344,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
       if (base + 16 <= r1) {                 // whole step inside the slab (wave-uniform): plain strided rows
         const float *sb = opnd + base * ld;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const f4 *>(sb + j * ld + lane_off);
+        for (int j = 0; j < 8; ++j) raw[j] = ld4_s(sb + j * ld + lane_off, SN_X_WGRAD_NT);
       } else {                               // last (or a prefetched, empty) step: rows past the slab re-read its last row
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -695,7 +706,7 @@ __global__ __launch_bounds__(kWG) void masked_sl1_bwd_k(const float *__restrict_
     if constexpr (VEC) {
       const f4 ov = ld4_s(o + r * ldo + c, 1), tv = ld4_s(t + r * ldt + c, 1);
       st4_s(g + r * ldg + c, f4{gm * sl1_grad(ov.x * m - tv.x), gm * sl1_grad(ov.y * m - tv.y),
-                                gm * sl1_grad(ov.z * m - tv.z), gm * sl1_grad(ov.w * m - tv.w)}, 0);
+                                gm * sl1_grad(ov.z * m - tv.z), gm * sl1_grad(ov.w * m - tv.w)}, 1);
     } else {
       g[r * ldg + c] = gm * sl1_grad(o[r * ldo + c] * m - t[r * ldt + c]);
     }
@@ -967,7 +978,7 @@ __global__ __launch_bounds__(kWG) void segstats_k(const float *__restrict__ x, i
 #pragma unroll 4
   for (int64_t r = r0 + rl; r < r1; r += lanes_r) {
     const float mk = mask ? mask[r] : 1.f;
-    const f4 v = ld4_s(x + r * ld + cg * 4, 0);
+    const f4 v = ld4_stat(x + r * ld + cg * 4);
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const double d = (double)v[k];

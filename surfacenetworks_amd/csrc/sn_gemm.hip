@@ -272,6 +272,31 @@ __device__ __forceinline__ void split4(const f4 &x, u2 &H, u2 &M, u2 &L) {
 
 // LDS writes of this wave done, then the workgroup barrier — without the vmcnt(0) a __syncthreads() fence would add
 // (it would drain the global prefetch and wait for the previous tile's stores to be acknowledged).
+// Cache hints of the global accesses (1 = non-temporal), compile-time switches kept for A/B runs
+// (tools/scratch/build_hint_variants.sh / run_hint_variants.sh, same box, config 3):
+//   outputs  NON-TEMPORAL: the 0.3-0.6 GB a launch writes would otherwise sit dirty in L2 / Infinity Cache and be
+//            written back under the NEXT kernel's reads — with non-temporal stores the transposed SpMM that consumes
+//            dx runs at 83 % instead of 79 % of the HBM roofline and the step is 0.4 ms shorter;
+//   operands plain loads: non-temporal loads of In / the side operand measured neutral to slightly worse (-0.1..-0.3 ms).
+#ifndef SN_X_GEMM_IN_NT
+#define SN_X_GEMM_IN_NT 0
+#endif
+#ifndef SN_X_GEMM_SIDE_NT
+#define SN_X_GEMM_SIDE_NT 0
+#endif
+#ifndef SN_X_GEMM_ST_NT
+#define SN_X_GEMM_ST_NT 1
+#endif
+__device__ __forceinline__ f4 ldg4(const float *p, int nt) {
+  return nt ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p);
+}
+__device__ __forceinline__ void stg4(float *p, f4 v) {
+#if SN_X_GEMM_ST_NT
+  __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+#else
+  *reinterpret_cast<f4 *>(p) = v;
+#endif
+}
 #define SN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
 template <int K, int NT, bool TRANSW, int EPI, bool SIDE, bool ELU>
@@ -352,7 +377,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
   auto load_chunk = [&](int64_t tl, int i) {
     int64_t r = tl * 32 + lrow + RPL * i;
     r = r < rows ? r : rows - 1;                             // rows past the end re-read the last row (masked at the store)
-    raw[i] = *reinterpret_cast<const f4 *>(In + r * ldi + lcol);
+    raw[i] = ldg4(In + r * ldi + lcol, SN_X_GEMM_IN_NT);
   };
   auto convert_chunk = [&](int buf, int i) {
     u2 H, M, L;
@@ -382,7 +407,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
       for (int j = 0; j < NST; ++j) {
         int64_t r = tl * 32 + erow + RPI * j;
         r = r < rows ? r : rows - 1;
-        sd[j] = *reinterpret_cast<const f4 *>(side_p + r * ep.ld1 + ecol);
+        sd[j] = ldg4(side_p + r * ep.ld1 + ecol, SN_X_GEMM_SIDE_NT);
       }
     }
     f4 sg[NST];                        // per-mesh vector of my rows (forward: the bias; dgrad+elu: added before elu')
@@ -414,7 +439,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
         for (int j = 0; j < NST; ++j) {
           int64_t r = tl * 32 + erow + RPI * j;
           r = r < rows ? r : rows - 1;
-          ga[j] = *reinterpret_cast<const f4 *>(ep.v4 + r * ep.ld3 + ecol);
+          ga[j] = ldg4(ep.v4 + r * ep.ld3 + ecol, SN_X_GEMM_SIDE_NT);
         }
       } else {
 #pragma unroll
@@ -501,15 +526,15 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
           v += sg[j];
           v = f4{v.x * (o.x > 0.f ? 1.f : o.x + 1.f), v.y * (o.y > 0.f ? 1.f : o.y + 1.f),
                  v.z * (o.z > 0.f ? 1.f : o.z + 1.f), v.w * (o.w > 0.f ? 1.f : o.w + 1.f)} + ga[j];
-          if (r < rows) *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = v;
+          if (r < rows) stg4(ep.o2 + r * ep.ld2 + ecol, v);
         } else if (r < rows) {
-          *reinterpret_cast<f4 *>(Out + r * ldo + ecol) = v;
+          stg4(Out + r * ldo + ecol, v);
         }
       } else if (r < rows) {
-        if (EPI != EPI_FWD || Out) *reinterpret_cast<f4 *>(Out + r * ldo + ecol) = v;
+        if (EPI != EPI_FWD || Out) stg4(Out + r * ldo + ecol, v);
         if constexpr (EPI == EPI_FWD && ELU) {
           const f4 ev = f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
-          *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = ev;
+          stg4(ep.o2 + r * ep.ld2 + ecol, ev);
           if constexpr (STATS) {
             const double e0 = ev.x, e1 = ev.y, e2 = ev.z, e3 = ev.w;
             ssum[0] += e0; ssum[1] += e1; ssum[2] += e2; ssum[3] += e3;

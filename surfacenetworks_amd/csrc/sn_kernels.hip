@@ -36,8 +36,18 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
+#ifndef SN_X_SPMM_ST_PLAIN
+#define SN_X_SPMM_ST_PLAIN 0
+#endif
+#ifndef SN_X_EW_ST_PLAIN
+#define SN_X_EW_ST_PLAIN 0
+#endif
 __device__ __forceinline__ void st4_stream(float *p, f4 v) {
+#if SN_X_SPMM_ST_PLAIN
+  *reinterpret_cast<f4 *>(p) = v;
+#else
   __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+#endif
 }
 // streaming (non-temporal) forms for data that is touched once per kernel: measured +15-30 % on 1:1 copy-like passes
 constexpr int kStreamNT = 1;   // streamed-once operands use non-temporal loads/stores
@@ -45,7 +55,7 @@ __device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
   return nt ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p);
 }
 __device__ __forceinline__ void st4_s(float *p, f4 v, int nt) {
-  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+  if (nt && !SN_X_EW_ST_PLAIN) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
   else *reinterpret_cast<f4 *>(p) = v;
 }
 __device__ __forceinline__ f4 fma4(float a, f4 x, f4 acc) {
