@@ -287,6 +287,9 @@ __device__ __forceinline__ void split4(const f4 &x, u2 &H, u2 &M, u2 &L) {
 #ifndef SN_X_GEMM_ST_NT
 #define SN_X_GEMM_ST_NT 1
 #endif
+#ifndef SN_X_GEMM_ELU_ST_PLAIN
+#define SN_X_GEMM_ELU_ST_PLAIN 0
+#endif
 __device__ __forceinline__ f4 ldg4(const float *p, int nt) {
   return nt ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p);
 }
@@ -534,7 +537,11 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
         if (EPI != EPI_FWD || Out) stg4(Out + r * ldo + ecol, v);
         if constexpr (EPI == EPI_FWD && ELU) {
           const f4 ev = f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
+#if SN_X_GEMM_ELU_ST_PLAIN
+          *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = ev;
+#else
           stg4(ep.o2 + r * ep.ld2 + ecol, ev);
+#endif
           if constexpr (STATS) {
             const double e0 = ev.x, e1 = ev.y, e2 = ev.z, e3 = ev.w;
             ssum[0] += e0; ssum[1] += e1; ssum[2] += e2; ssum[3] += e3;
