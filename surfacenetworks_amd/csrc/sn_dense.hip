@@ -34,6 +34,9 @@ __device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
 #ifndef SN_X_WGRAD_NT
 #define SN_X_WGRAD_NT 0
 #endif
+#ifndef SN_X_WGRAD_PAIRS
+#define SN_X_WGRAD_PAIRS 1     // wgrad_x3_k: one workgroup barrier per PAIR of 16-row steps (four LDS images); 0: per step
+#endif
 __device__ __forceinline__ void st4_s(float *p, f4 v, int nt) {
   if (nt && !SN_X_EW_ST_PLAIN) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
   else *reinterpret_cast<f4 *>(p) = v;
@@ -279,7 +282,8 @@ __device__ __forceinline__ f16v mfma_bf16(const u4 &a, const u4 &b, const f16v &
 //              18 fragment reads per 48 MFMAs (CT = 2);
 //   waves 4-7  loader waves: 8 rows x 4 columns per thread and step, requested FOUR steps ahead (four register sets),
 //              split on the vector ALU while the matrix waves multiply, written to the other image.
-// One workgroup barrier per step.
+// One workgroup barrier per PAIR of steps (four LDS images, 150 KB at CT = 2: two being read, two being written) — the
+// two roles then meet half as often: -1..2 % of the training step against a barrier per step (SN_X_WGRAD_PAIRS=0).
 constexpr int kWgradThreads = 512;
 
 template <int CT /* C / 128: 1 or 2 */>
@@ -294,7 +298,12 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
   constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
   constexpr int NB = 2 * CT;                 // x tiles per matrix wave
   static_assert(QP % 16 == 4, "slot permutation");
-  __shared__ u4 img[2][3][2 * PL];           // [buffer][piece][slot]; one step = 16 rows = 2 row groups
+#if SN_X_WGRAD_PAIRS
+  constexpr int NBUF = 4;                    // one barrier per PAIR of steps: two images being read, two being written
+#else
+  constexpr int NBUF = 2;
+#endif
+  __shared__ u4 img[NBUF][3][2 * PL];        // [buffer][piece][slot]; one step = 16 rows = 2 row groups
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   // row slab of this workgroup: an even split of all rows, or — seg_rows > 0 — `spm` slabs per mesh that never cross a mesh
@@ -396,6 +405,33 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
         }
       }
     };
+#if SN_X_WGRAD_PAIRS
+    if (nsteps > 0) {
+      // pair k = steps 2k, 2k+1 read by the matrix waves from images (2k)&3, (2k+1)&3 while this wave converts steps
+      // 2k+2, 2k+3 into the other two; step t lives in register set t & 3 and is re-filled with step t+4 once converted
+      load_step(ra, 0);
+      load_step(rb, 1);
+      load_step(rc, 2);
+      load_step(rd, 3);
+      convert_step(ra, 0, 0);
+      load_step(ra, 4);
+      convert_step(rb, 1, 1);
+      load_step(rb, 5);
+      for (int64_t s = 0; s < nsteps; s += 4) {
+        SN_STEP_BARRIER();
+        convert_step(rc, s + 2, 2);
+        load_step(rc, s + 6);
+        convert_step(rd, s + 3, 3);
+        load_step(rd, s + 7);
+        if (s + 2 >= nsteps) break;
+        SN_STEP_BARRIER();
+        convert_step(ra, s + 4, 0);
+        load_step(ra, s + 8);
+        convert_step(rb, s + 5, 1);
+        load_step(rb, s + 9);
+      }
+    }
+#else
     if (nsteps > 0) {
       load_step(ra, 0);
       load_step(rb, 1);
@@ -425,6 +461,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
         if (++s >= nsteps) break;
       }
     }
+#endif
     if (colpart) {                           // (rows past the slab were read as zero: they add nothing)
       __syncthreads();
       float *sm = reinterpret_cast<float *>(&img[0][0][0]);
@@ -444,8 +481,13 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
     for (int64_t s = 0; s < nsteps; ++s) {
+#if SN_X_WGRAD_PAIRS
+      const int buf = (int)(s & 3);
+      if (!(s & 1)) SN_STEP_BARRIER();       // images of this pair complete; the previous pair's may be overwritten
+#else
       const int buf = (int)(s & 1);
       SN_STEP_BARRIER();                     // image `buf` complete; image buf^1 may be overwritten
+#endif
       u4 A[2][3], B[NB][3];
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
