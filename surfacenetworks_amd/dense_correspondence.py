@@ -14,6 +14,7 @@ import torch.nn.functional as F
 
 from . import mesh_ops
 from . import utils_pt as utils
+from .arap import make_adam
 from .operators import OperatorPool, SparseOperator
 
 
@@ -151,7 +152,7 @@ def streamed_delta_cross_entropy(FA, FB, targetX, targetY, block=1024):
 
 
 def make_optimizer(model):
-    return torch.optim.Adam(model.parameters(), 1e-3, weight_decay=1e-5)       # main.py:285
+    return make_adam(model)       # main.py:285
 
 
 class TorusBodies:

@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from . import mesh_ops
 from . import utils_pt as utils
+from .arap import make_adam
 from .operators import OperatorPool
 
 
@@ -65,7 +66,7 @@ class DirModel(_Head):
 
 
 def make_optimizer(model):
-    return torch.optim.Adam(model.parameters(), 1e-3, weight_decay=1e-5)       # main.py:139
+    return make_adam(model)       # main.py:139
 
 
 @dataclass
