@@ -288,6 +288,11 @@ int sn_masked_smooth_l1_fwd_f32(const float *out, int64_t ldo, const float *targ
 int sn_masked_smooth_l1_bwd_f32(const float *out, int64_t ldo, const float *target, int64_t ldt, const float *rowmask,
                                 int64_t rows, int32_t C, double scale, const float *gloss, float *gout, int64_t ldg,
                                 void *stream);
+/* sn_gather_segments_f32: batch assembly of dense per-sample windows (the ARAP sampler's inputs / targets,
+ * src/as_rigid_as_possible/main.py:126-152): out[(i*rows_per_item + r)*len + c] = src[base[i] + r*row_stride + c],
+ * i < nitems, r < rows_per_item, c < len; base is a DEVICE array of element offsets into the resident dataset. */
+int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems, int64_t rows_per_item, int64_t row_stride,
+                           int32_t len, float *out, void *stream);
 int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
                            const float *Cc, int64_t rows, int32_t C, void *stream);
 

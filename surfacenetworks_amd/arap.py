@@ -208,17 +208,12 @@ class ClothSequences:
             self.pool_L = OperatorPool(mats["L"], self.device, want_bsr4=False)
 
     def _vertex_major(self):
-        """Window views (n, vmax, start frame, 3*INPUT_FRAMES) and (n, vmax, start frame, 3*OUTPUT_FRAMES) of a vertex-major
-        (n, vmax, frames*3) copy of self.xyz (n, frames, vmax, 3); rebuilt when self.xyz is replaced."""
+        """Vertex-major (n, vmax, frames*3) copy of self.xyz (n, frames, vmax, 3): the 42 frames a sample needs of one
+        vertex are then ONE contiguous run, gathered by sn_gather_segments_f32; rebuilt when self.xyz is replaced."""
         cached = getattr(self, "_xyz_vm", None)
         if cached is None or cached[0] is not self.xyz:
             n, fr, vmax, _ = self.xyz.shape
-            vm = self.xyz.permute(0, 2, 1, 3).reshape(n, vmax, fr * 3).contiguous()
-            nwin = fr - (INPUT_FRAMES + OUTPUT_FRAMES) + 1
-            st = (vmax * fr * 3, fr * 3, 3, 1)
-            win_in = vm.as_strided((n, vmax, nwin, 3 * INPUT_FRAMES), st)
-            win_tg = vm.as_strided((n, vmax, nwin, 3 * OUTPUT_FRAMES), st, 3 * INPUT_FRAMES)
-            cached = (self.xyz, (win_in, win_tg))
+            cached = (self.xyz, self.xyz.permute(0, 2, 1, 3).reshape(n, vmax, fr * 3).contiguous())
             self._xyz_vm = cached
         return cached[1]
 
@@ -239,9 +234,11 @@ class ClothSequences:
         off = torch.from_numpy(offsets).to(self.device)
         # a sample's 42 frames of a vertex are one contiguous run of the vertex-major copy: inputs and targets are gathered
         # straight into their final (B, nv, frames*3) layout (no permute / slice copies of the 160 MB window)
-        win_in, win_tg = self._vertex_major()                      # (n, vmax, start frame, 6 | 120) overlapping windows
-        inputs = win_in[sid, :nv, off]                             # index tensors stay (B,): one gather each
-        targets = win_tg[sid, :nv, off]
+        vm = self._vertex_major()                                  # (n, vmax, frames*3)
+        vmax, f3 = vm.shape[1], vm.shape[2]
+        base = (sid * vmax) * f3 + 3 * off                         # element offset of (sample, vertex 0, start frame)
+        inputs = kernels.gather_segments(vm, base, nv, f3, 3 * INPUT_FRAMES)
+        targets = kernels.gather_segments(vm, base + 3 * INPUT_FRAMES, nv, f3, 3 * OUTPUT_FRAMES)
         mask = (torch.arange(nv, device=self.device)[None, :] < self.vcount[sid][:, None]).float().unsqueeze(2)
         op_ids = seq_ids * self.op_frames + (offsets + INPUT_FRAMES - 1)
         L = Di = DiA = None

@@ -756,6 +756,23 @@ __global__ __launch_bounds__(kWG) void masked_sl1_bwd_k(const float *__restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sampler gather (src/as_rigid_as_possible/main.py:126-152 builds these tensors on the host, frame by frame): item i of
+// a batch is rows_per_item segments of `len` consecutive floats, segment r at src[base[i] + r*row_stride .. + len).
+// One thread per output float: consecutive threads read consecutive floats of a segment (coalesced, no alignment needed).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void gather_segments_k(const float *__restrict__ src, const int64_t *__restrict__ base,
+                                                         int64_t rows_per_item, int64_t row_stride, int len,
+                                                         int64_t total, float *__restrict__ out) {
+  const int64_t per_item = rows_per_item * len;
+  for (int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x; i < total; i += (int64_t)gridDim.x * kWG) {
+    const int64_t item = i / per_item, w = i - item * per_item;
+    const int64_t r = w / len;
+    const int c = (int)(w - r * len);
+    __builtin_nontemporal_store(src[base[item] + r * row_stride + c], out + i);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kWG) void affine_cols_acc_k(float *__restrict__ dx, int64_t lddx,
                                                          const float *__restrict__ x, int64_t ldx,
@@ -1563,6 +1580,20 @@ int sn_masked_smooth_l1_bwd_f32(const float *out, int64_t ldo, const float *targ
   else
     hipLaunchKernelGGL((masked_sl1_bwd_k<false>), dim3((unsigned)blocks), dim3(kWG), 0, s, out, ldo, target, ldt, rowmask, rows, (int)C,
                        (float)scale, gloss, gout, ldg);
+  return launch_status();
+}
+
+int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems, int64_t rows_per_item, int64_t row_stride,
+                           int32_t len, float *out, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (nitems < 0 || rows_per_item < 0 || len < 1 || row_stride < 0) return SN_E_SHAPE;
+  const int64_t total = nitems * rows_per_item * len;
+  if (total == 0) return SN_OK;
+  if (!src || !base || !out) return SN_E_NULL;
+  int64_t blocks = (total + kWG - 1) / kWG;
+  if (blocks > 64 * 1024) blocks = 64 * 1024;
+  hipLaunchKernelGGL(gather_segments_k, dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, base,
+                     rows_per_item, row_stride, (int)len, total, out);
   return launch_status();
 }
 

@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "elu_stats_supported", "new_elu_stats_part", "colstats_halves",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves",
 ]
 
 
@@ -527,6 +527,18 @@ def wgrad_thin(dy, x, want_bias: bool = True):
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
     _lib.call("sn_wgrad_thin_f32", _p(dy), _ld(dy), _p(x), _ld(x), rows, J, C, _p(G), _p(db), _p(ws), ws_bytes, _stream())
     return G, db
+
+
+def gather_segments(src, base, rows_per_item: int, row_stride: int, length: int):
+    """(nitems, rows_per_item, length) fp32: row r of item i = src.flatten()[base[i] + r*row_stride : ... + length]
+    (sn_gather_segments_f32); base: int64 device tensor of element offsets into the contiguous src."""
+    _dev(src, base)
+    if not src.is_contiguous() or src.dtype != torch.float32 or base.dtype != torch.int64:
+        raise TypeError("gather_segments: contiguous float32 source and int64 offsets expected")
+    n = base.numel()
+    out = torch.empty((n, rows_per_item, length), dtype=torch.float32, device=src.device)
+    _lib.call("sn_gather_segments_f32", _p(src), _p(base.contiguous()), n, rows_per_item, row_stride, length, _p(out), _stream())
+    return out
 
 
 def masked_smooth_l1_fwd(out2d, target2d, rowmask, scale: float):

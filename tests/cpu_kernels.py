@@ -330,6 +330,12 @@ def wgrad_thin(dy, x, want_bias=True):
     return G, (dy.double().sum(0).float() if want_bias else None)
 
 
+def gather_segments(src, base, rows_per_item, row_stride, length):
+    flat = src.reshape(-1)
+    idx = base.reshape(-1, 1, 1) + torch.arange(rows_per_item).reshape(1, -1, 1) * row_stride + torch.arange(length).reshape(1, 1, -1)
+    return flat[idx]
+
+
 def masked_smooth_l1_fwd(out2d, target2d, rowmask, scale):
     d = out2d.double() * (1.0 if rowmask is None else rowmask.double().reshape(-1, 1)) - target2d.double()
     a = d.abs()

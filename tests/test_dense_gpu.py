@@ -494,3 +494,21 @@ def test_forward_gemm_leaves_the_statistics_of_its_elu_output(rows, K, res, segb
     kernels.linear_fwd(x, W, b, r, cat2[:, :128], False) if not segbias else \
         kernels.linear_fwd_segbias(x, W, segb, per, r, cat2[:, :128], False)
     assert torch.equal(cat2[:, :128], cat[:, :128])
+
+
+# ---- sampler gather ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,vmax,f3,nv,length,shift", [(3, 7, 135, 6, 6, 0), (5, 40, 135, 33, 120, 6), (2, 5041, 132, 5041, 120, 6),
+                                                        (1, 1, 9, 1, 3, 0)])
+def test_gather_segments(n, vmax, f3, nv, length, shift):
+    torch.manual_seed(n + vmax)
+    src = torch.randn(n, vmax, f3, device=DEV)
+    B = 4
+    sid = torch.randint(0, n, (B,), device=DEV)
+    off = torch.randint(0, (f3 - shift - length) // 3 + 1, (B,), device=DEV)
+    base = (sid * vmax) * f3 + 3 * off + shift
+    got = kernels.gather_segments(src, base, nv, f3, length)
+    assert got.shape == (B, nv, length)
+    for b in range(B):
+        c0 = 3 * int(off[b]) + shift
+        assert torch.equal(got[b], src[int(sid[b]), :nv, c0:c0 + length])
+    assert kernels.gather_segments(src, base[:0], nv, f3, length).shape == (0, nv, length)
