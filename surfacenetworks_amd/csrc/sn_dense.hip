@@ -55,7 +55,10 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // ------------------------------------------------------------------------------------------------
 // column statistics
 // ------------------------------------------------------------------------------------------------
-constexpr int kStatBlocks = 512;
+#ifndef SN_X_STAT_BLOCKS
+#define SN_X_STAT_BLOCKS 512
+#endif
+constexpr int kStatBlocks = SN_X_STAT_BLOCKS;
 
 // VEC: C % 4 == 0 and (C/4) divides 256: a thread owns 4 adjacent columns and every (256/(C/4))-th row.
 template <bool VEC>
@@ -677,7 +680,10 @@ __global__ __launch_bounds__(kWG) void wgrad_thin_final_k(const double *__restri
 // backward: gout = (gloss*scale) * mask[r] * clamp(out*mask - target, -1, 1), one pass.
 // (torch runs mask-multiply, loss, reduction, loss-backward, mask-multiply as five elementwise passes.)
 // ------------------------------------------------------------------------------------------------
-constexpr int kLossBlocks = 1024;
+#ifndef SN_X_LOSS_BLOCKS
+#define SN_X_LOSS_BLOCKS 1024
+#endif
+constexpr int kLossBlocks = SN_X_LOSS_BLOCKS;
 
 __device__ __forceinline__ double sl1(float d) {
   const float a = fabsf(d);
