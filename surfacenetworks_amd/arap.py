@@ -76,11 +76,12 @@ class DirModel(nn.Module):
     def forward(self, Di, DiA, mask, inputs):
         batch_size = inputs.size(0)
         v = self.conv1(inputs)
-        f = torch.zeros(batch_size, _num_faces(Di, DiA, batch_size), 128, dtype=v.dtype, device=v.device)
+        f = None                                                   # f = zeros(batch, faces, 128) (models.py:138), not materialised
+        nf = _num_faces(Di, DiA, batch_size)
         for i in range(15):
             blk = self._modules["rn{}".format(i)]
             if i % 2 == 0:
-                v, f = blk(Di, DiA, v, f, f_out_needed=False)     # f only ever feeds the next Dirac block (models.py:139-147)
+                v, f = blk(Di, DiA, v, f, f_out_needed=False, num_faces=nf)   # f only feeds the next Dirac block (models.py:139-147)
             else:
                 v = blk(None, mask, v)
         x = self.conv2(F.elu(v))

@@ -19,11 +19,12 @@ from __future__ import annotations
 import torch
 
 from . import kernels
-from .functional import (_launch, _rows2d, avg_stage_backward, avg_stage_forward, bn_prepare, bnlin_backward, bnlin_forward,
-                         stash, unstash)
+from .functional import (_launch, _rows2d, avg_stage_backward, avg_stage_forward, bn_prepare, bnlin_backward,
+                         bnlin_backward_zero_first, bnlin_forward, bnlin_forward_zero_first, stash, unstash,
+                         zero_first_supported)
 from .operators import as_operator
 
-__all__ = ["lap_block", "dirac_block", "avg_block", "take_activated", "attach_activated"]
+__all__ = ["lap_block", "dirac_block", "avg_block", "take_activated", "attach_activated", "zero_faces_ok"]
 
 
 def attach_activated(t: torch.Tensor, cat: torch.Tensor) -> torch.Tensor:
@@ -84,13 +85,21 @@ class _DiracBlock(torch.autograd.Function):
                 rv1, tr1, mo1, ep1):
         v = _rows2d(v)
         rv, C = v.shape
-        rf = f.shape[0]
+        rf = opDi.shape[0] // 4
         cat1 = _activated(v, pre_v)
-        cat0 = pre_f if pre_f is not None else _activated(_rows2d(f), None)    # (f's values are not touched when handed off)
-        _launch(opDi, cat1[:, :C], cat0[:, C:], 4, "fwd")
         nxt_f = _new_cat(rf, C, v.device)                        # the next Dirac block's cat0; first half = elu(f_out)
         pf = _new_part(rf, C, v.device)
-        f_out, st0 = bnlin_forward(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, nxt_f[:, :C], want_y=need_f, elu_stats=pf)
+        ctx.f_zero = f is None
+        if f is None:
+            # all-zero face features (the first Dirac block of a model): cat0 = [0 | Di·elu(v)] runs at half width
+            cat0 = torch.empty((rf, C), dtype=torch.float32, device=v.device)      # only the propagated half exists
+            _launch(opDi, cat1[:, :C], cat0, 4, "fwd")
+            f_out, st0 = bnlin_forward_zero_first(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, nxt_f[:, :C], need_f, pf)
+        else:
+            cat0 = pre_f if pre_f is not None else _activated(_rows2d(f), None)    # (f's values are not touched when handed off)
+            _launch(opDi, cat1[:, :C], cat0[:, C:], 4, "fwd")
+            f_out, st0 = bnlin_forward(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, nxt_f[:, :C], want_y=need_f,
+                                       elu_stats=pf)
         _attach_part(nxt_f, pf)
         if f_out is None:
             # The caller only chains f into the next Dirac block, which consumes the ACTIVATED hand-off: the pre-activation
@@ -136,7 +145,10 @@ class _DiracBlock(torch.autograd.Function):
         gp0 = none9
         g_v = g_f = None
         dx0_hi = None
-        if g_fo is not None:
+        if g_fo is not None and ctx.f_zero:
+            dx0_hi, dg0, db0, dW0, dc0 = bnlin_backward_zero_first(st0, g_fo)          # no gradient for the zero half
+            gp0 = (dg0, db0, dW0, dc0, None, None, None, None, None)
+        elif g_fo is not None:
             (dx0_hi, g_f), dg0, db0, dW0, dc0 = bnlin_backward(st0, g_fo, through_elu=(None,))   # g_f = dx0[:, :C]·elu'(e_f)
             gp0 = (dg0, db0, dW0, dc0, None, None, None, None, None)
         if ctx.needs_input_grad[0]:
@@ -145,24 +157,31 @@ class _DiracBlock(torch.autograd.Function):
                 _launch(opDi.t(), dx0_hi, g_v, 4, "bwd", elubwd=(cat1[:, :C], h1))   # (Di^T·dx0_hi)·elu'(e_v) + h1
             else:
                 g_v = h1
-        if not ctx.needs_input_grad[1]:
+        if ctx.f_zero or not ctx.needs_input_grad[1]:
             g_f = None
         return (g_v, g_f, None, None, None, None, None) + gp0 + gp1
 
 
-def dirac_block(mod, Di, DiA, v, f, need_f=True):
+def dirac_block(mod, Di, DiA, v, f, need_f=True, num_faces=None):
     """DirResNet2.forward on (B, V, C) / (B, F, C) tensors; `mod` supplies bn_fc0 / bn_fc1.  need_f=False: the returned
-    face features are only a carrier of the activated hand-off for the next Dirac block (see _DiracBlock.forward)."""
+    face features are only a carrier of the activated hand-off for the next Dirac block (see _DiracBlock.forward).
+    f=None (with num_faces): all-zero face features, never materialised (zero_faces_ok says when)."""
     B, V, C = v.shape
-    F_ = f.shape[1]
+    F_ = f.shape[1] if f is not None else int(num_faces)
     rv, rf = B * V, B * F_
     opDi, opDiA = as_operator(Di), as_operator(DiA)
     if opDi.shape != (4 * rf, 4 * rv) or opDiA.shape != (4 * rv, 4 * rf):
         raise ValueError(f"DirResNet2: Di {tuple(opDi.shape)} / DiA {tuple(opDiA.shape)} do not match v rows {rv}, f rows {rf}")
-    v_new, f_out, nxt_v, nxt_f = _DiracBlock.apply(v.reshape(rv, C), f.reshape(rf, C), opDi, opDiA,
-                                                  take_activated(v, rv, C), take_activated(f, rf, C), bool(need_f),
+    v_new, f_out, nxt_v, nxt_f = _DiracBlock.apply(v.reshape(rv, C), f.reshape(rf, C) if f is not None else None, opDi, opDiA,
+                                                  take_activated(v, rv, C),
+                                                  take_activated(f, rf, C) if f is not None else None, bool(need_f),
                                                   *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
     return attach_activated(v_new.view(B, V, C), nxt_v), attach_activated(f_out.view(B, F_, C), nxt_f)
+
+
+def zero_faces_ok(mod, C: int) -> bool:
+    """Can dirac_block take f=None (all-zero face features at half width) for this module?"""
+    return zero_first_supported(C, mod.bn_fc0.fc.weight.shape[0]) and mod.bn_fc0.fc.weight.shape[1] == 2 * C
 
 
 # ------------------------------------------------------------------------------------------------------------

@@ -57,11 +57,11 @@ class DirModel(nn.Module):
         batch_size = inputs.size(0)
         v = self.conv1(inputs)
         num_faces = DiA.size(2) // 4 if len(Di.size()) == 3 else DiA.size(1) // 4 // batch_size
-        f = torch.zeros(batch_size, num_faces, 128, dtype=v.dtype, device=v.device)
+        f = None                                # zeros(batch, faces, 128) (models.py:168), not materialised
         for i in range(self.layer):
             blk = self._modules["rn{}".format(i)]
             if i % 2 == 0:
-                v, f = blk(Di, DiA, v, f)
+                v, f = blk(Di, DiA, v, f, num_faces=num_faces)
             else:
                 v = blk(None, mask, v)
         x = self.conv2(F.elu(v))

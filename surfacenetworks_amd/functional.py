@@ -448,6 +448,54 @@ def bnlin_backward(state, dy, need_dx=True, through_elu=None):
     return dx, dgamma, dbeta, dW, db
 
 
+def zero_first_supported(C: int, J: int) -> bool:
+    """Shapes for which the stage [0 | p] -> Lin(BN(.)) runs at half width (bnlin_forward_zero_first)."""
+    return C == 128 and J == 128 and kernels.linear_fwd_supported(C, J) and kernels.wgrad_supported(J, C) and \
+        kernels.linear_dgrad_supported(J, C)
+
+
+def bnlin_forward_zero_first(p, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, elu_out=None,
+                             want_y=True, elu_stats=None):
+    """bnlin_forward of the concat buffer [0 | p] WITHOUT the zero half (the first Dirac block of a model: its face
+    features are all zero, src/as_rigid_as_possible/models.py:138).  The statistics of the zero columns are (0, 0); folded
+    into the Linear they only contribute the constant W[:, :C]·beta[:C] to the bias, so the product runs over the C real
+    columns: same y, same running statistics, half the GEMM, no zero buffer, no ELU / statistics pass over it."""
+    p = _rows2d(p)
+    rows, C = p.shape
+    stats = None
+    rows_g = rows
+    if training:
+        stats = torch.zeros((2, 2 * C), dtype=torch.float64, device=p.device)
+        kernels.colstats_into(p, stats, C)
+        stats, rows_g = _sync_stats(stats, rows)
+    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
+                                                 running_var, _take_counter(running_mean))
+    y = kernels.linear_fwd(p, Wf[:, C:], bf, None, elu_out, want_y, elu_stats)
+    return y, (p, W, Wf, s, mean, invstd, beta, training, b is not None, rows_g)
+
+
+def bnlin_backward_zero_first(state, dy):
+    """Backward of bnlin_forward_zero_first: (dp, dgamma, dbeta, dW, db) — the gradient w.r.t. the zero half is not formed
+    (nothing upstream of it)."""
+    p, W, Wf, s, mean, invstd, beta, training, has_bias, rows_g = state
+    dy = dy.contiguous()
+    rows, C = p.shape
+    J = dy.shape[1]
+    G2, sdy = kernels.wgrad(dy, p, mean[C:], want_colsum=True)
+    # zero half: x - mean = -mean there, i.e. G[:, :C] = -colsum(dy) (x) mean[:C] — zero with batch statistics (mean = 0),
+    # the running mean in eval mode
+    G1 = torch.zeros_like(G2) if training else -(sdy.to(torch.float32)[:, None] * mean[None, :C])
+    Gc = torch.cat([G1, G2], 1)
+    scale = 1.0
+    if training:
+        Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
+    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    Wf2 = Wf[:, C:]
+    dp = kernels.linear_dgrad(dy, Wf2, p, mean[C:], Bc[C:], Cc[C:]) if training else kernels.linear_dgrad(dy, Wf2)
+    return dp, dgamma, dbeta, dW, db
+
+
 def avg_stage_forward(e, mask_rows, inv_count, nseg, per, gamma, beta, W, b, running_mean, running_var, training, momentum,
                       eps, residual=None, elu_out=None, want_y=True, elu_stats=None):
     """One stage of AvgResNet2 (utils_pt.py:230-243), Lin(BN([e | global_average(e) broadcast])), at HALF width: the second

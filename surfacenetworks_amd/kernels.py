@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into",
 ]
 
 
@@ -376,6 +376,19 @@ def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y: bool = True, elu_s
               _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu), _ld(y_elu) if y_elu is not None else 0,
               rows, K, J, _p(elu_stats), _stream())
     return y if keep else None
+
+
+def colstats_into(x, out, offset: int):
+    """Column sums / sums of squares of the 2-D view x written into columns offset .. offset+C of the (2, width) float64
+    statistics tensor `out` (sn_colstats_into_f32)."""
+    _dev(x, out)
+    rows, C = x.shape
+    if out.dim() != 2 or out.shape[0] != 2 or out.dtype != torch.float64 or not out.is_contiguous() or offset + C > out.shape[1]:
+        raise ValueError("colstats_into: out must be a contiguous (2, width) float64 tensor with width >= offset + C")
+    ws_bytes = int(_lib.load().sn_colstats_workspace_bytes(rows, C))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.call("sn_colstats_into_f32", _p(x), _ld(x), rows, C, _p(out), out.shape[1], offset, _p(ws), ws_bytes, _stream())
+    return out
 
 
 def colstats_halves(x, part):

@@ -59,9 +59,9 @@ class DirModel(_Head):
         batch_size = inputs.size(0)
         v = self.conv1(inputs)
         num_faces = DiA.size(2) // 4 if len(Di.size()) == 3 else DiA.size(1) // 4 // batch_size
-        f = torch.zeros(batch_size, num_faces, 64, dtype=v.dtype, device=v.device)
+        f = None                                # zeros(batch, faces, 64) (models.py:144), materialised only where needed
         for i in range(5):
-            v, f = self._modules["rn{}".format(i)](Di, DiA, v, f)
+            v, f = self._modules["rn{}".format(i)](Di, DiA, v, f, num_faces=num_faces)
         return self._classify(v, mask)
 
 

@@ -191,11 +191,20 @@ class DirResNet2(_TwoStage):
         super().__init__(num_outputs)
         self.res_f = res_f          # accepted and unused, as in the reference (utils_pt.py:189)
 
-    def forward(self, Di, DiA, v, f, f_out_needed=True):
+    def forward(self, Di, DiA, v, f, f_out_needed=True, num_faces=None):
         """f_out_needed=False (not in the reference's signature): the caller promises to use the returned face features ONLY
         as the `f` argument of the next DirResNet2 — the block then skips writing them (the next block reads the activated
-        copy handed over internally) and returns a NaN placeholder of the right shape in their place."""
+        copy handed over internally) and returns a NaN placeholder of the right shape in their place.
+        f=None with num_faces=F (not in the reference's signature either): the face features are all zero — what every
+        model of the reference feeds its first Dirac block (as_rigid_as_possible/models.py:138) — and are not materialised:
+        the face stage runs over the propagated half only (same values)."""
         batch_size, num_nodes, num_inputs = v.size()
+        if f is None:
+            if num_faces is None:
+                raise ValueError("DirResNet2: f=None needs num_faces")
+            if _blocks_ok(self, v) and snB.zero_faces_ok(self, num_inputs):
+                return snB.dirac_block(self, Di, DiA, v, None, f_out_needed, num_faces)
+            f = torch.zeros(batch_size, int(num_faces), num_inputs, dtype=v.dtype, device=v.device)
         _, num_faces, _ = f.size()
         if _blocks_ok(self, v):
             return snB.dirac_block(self, Di, DiA, v, f, f_out_needed)           # the whole block as one autograd node

@@ -244,6 +244,12 @@ def new_elu_stats_part(rows, device):
     return torch.zeros((1, 2, 128), dtype=torch.float64)
 
 
+def colstats_into(x, out, offset):
+    C = x.shape[1]
+    out[:, offset:offset + C] = colstats(x)
+    return out
+
+
 def colstats_halves(x, part):
     C = x.shape[1] // 2
     out = torch.empty((2, 2 * C), dtype=torch.float64)

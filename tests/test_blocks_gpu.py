@@ -183,3 +183,40 @@ def test_unwritten_face_features_are_a_loud_placeholder(golden_dir):
         b1.zero_grad(), b2.zero_grad()
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_zero_face_features_are_never_materialised(golden_dir, train):
+    """DirResNet2(Di, DiA, v, None, num_faces=F) == DirResNet2(Di, DiA, v, zeros(B, F, C)) — the first Dirac block of
+    every model of the reference (as_rigid_as_possible/models.py:138) — in outputs, gradients, running statistics and batch
+    counter, with the face stage at half width (no zero tensor, no statistics / GEMM columns for it)."""
+    import copy
+
+    import surfacenetworks_amd.utils_pt as U
+    from helpers import deterministic_init, det_tensor, rel_err
+
+    rb, ops = pc.batch_operators(golden_dir, "pool", DEV)
+    B, nv, nf, C = rb["mask"].shape[0], int(rb["nv"]), int(rb["nf"]), 128
+    base = deterministic_init(U.DirResNet2(C), 3).to(DEV)
+    with torch.no_grad():                                        # non-trivial BatchNorm parameters for the zero columns
+        base.bn_fc0.bn.weight.copy_(torch.linspace(0.5, 1.5, 2 * C))
+        base.bn_fc0.bn.bias.copy_(torch.linspace(-0.3, 0.4, 2 * C))
+        base.bn_fc0.bn.running_mean.copy_(torch.linspace(-0.1, 0.1, 2 * C))
+        base.bn_fc0.bn.running_var.copy_(torch.linspace(0.5, 2.0, 2 * C))
+    res = []
+    for zero_path in (False, True):
+        blk = copy.deepcopy(base).train(train)
+        v = torch.from_numpy(det_tensor((B, nv, C), 1)).to(DEV).requires_grad_(True)
+        if zero_path:
+            v1, f1 = blk(ops["Di"], ops["DiA"], v, None, num_faces=nf)
+        else:
+            v1, f1 = blk(ops["Di"], ops["DiA"], v, torch.zeros(B, nf, C, device=DEV))
+        (v1.square().sum() + (f1 * 0.37).sum()).backward()
+        res.append([v1.detach(), f1.detach(), v.grad.clone()] + [p.grad.clone() for p in blk.parameters()] +
+                   [b.clone().float() for b in blk.buffers()])
+    for a, b in zip(*res):
+        assert a.shape == b.shape
+        assert rel_err(b.cpu().numpy(), a.cpu().numpy()) < 2e-5, (a.shape,)
+    # what the half-width form may not touch: the batch counter still counts one batch per BatchNorm
+    if train:
+        assert all(int(b) == 1 for b in res[1][-1:])
