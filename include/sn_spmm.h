@@ -293,6 +293,11 @@ int sn_masked_smooth_l1_bwd_f32(const float *out, int64_t ldo, const float *targ
  * i < nitems, r < rows_per_item, c < len; base is a DEVICE array of element offsets into the resident dataset. */
 int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems, int64_t rows_per_item, int64_t row_stride,
                            int32_t len, float *out, void *stream);
+/* sn_linear_thin_fwd_f32: forward of that first layer, y = x·W^T + bias (x: rows x C, C <= 8; W: J x C), and optionally
+ * elu(y) into y_elu (the first half of the next block's concat buffer; replaces the F.elu of utils_pt.py:161,195).  y or
+ * y_elu may be NULL (not both).  Ascending-k fp32 FMA chain on top of the bias. */
+int sn_linear_thin_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias, int64_t rows,
+                           int32_t C, int32_t J, float *y, int64_t ldy, float *y_elu, int64_t lde, void *stream);
 int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
                            const float *Cc, int64_t rows, int32_t C, void *stream);
 

@@ -779,6 +779,47 @@ __global__ __launch_bounds__(kWG) void gather_segments_k(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
+// Forward of the same first layer: y = x·W^T + b with 1..8 input channels, and optionally elu(y) straight into the next
+// block's concat buffer.  Pure output streaming (a thread owns 4 adjacent output columns, its 4 x C weights stay in
+// registers, the x row is a broadcast load).
+// ------------------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(kWG) void linear_thin_fwd_k(const float *__restrict__ x, int64_t ldx,
+                                                         const float *__restrict__ W, int64_t ldw,
+                                                         const float *__restrict__ b, int64_t rows, int J,
+                                                         float *__restrict__ y, int64_t ldy, float *__restrict__ ye,
+                                                         int64_t lde) {
+  const int cw = J / 4, lanes_r = kWG / cw;
+  const int cg = threadIdx.x % cw, rl = threadIdx.x / cw;
+  if (rl >= lanes_r) return;
+  float w[4][C];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int c = 0; c < C; ++c) w[q][c] = W[(int64_t)(4 * cg + q) * ldw + c];
+  const f4 bias = b ? *reinterpret_cast<const f4 *>(b + 4 * cg) : f4{0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = (int64_t)blockIdx.x * lanes_r + rl; r < rows; r += (int64_t)gridDim.x * lanes_r) {
+    float xv[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) xv[c] = x[r * ldx + c];
+    f4 acc = bias;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {                    // ascending-k FMA chain on top of the bias
+      acc.x = __builtin_fmaf(xv[c], w[0][c], acc.x);
+      acc.y = __builtin_fmaf(xv[c], w[1][c], acc.y);
+      acc.z = __builtin_fmaf(xv[c], w[2][c], acc.z);
+      acc.w = __builtin_fmaf(xv[c], w[3][c], acc.w);
+    }
+    if (y) __builtin_nontemporal_store(acc, reinterpret_cast<f4 *>(y + r * ldy + 4 * cg));
+    if (ye) {
+      const f4 e = {acc.x > 0.f ? acc.x : __expf(acc.x) - 1.0f, acc.y > 0.f ? acc.y : __expf(acc.y) - 1.0f,
+                    acc.z > 0.f ? acc.z : __expf(acc.z) - 1.0f, acc.w > 0.f ? acc.w : __expf(acc.w) - 1.0f};
+      __builtin_nontemporal_store(e, reinterpret_cast<f4 *>(ye + r * lde + 4 * cg));
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <bool VEC>
 __global__ __launch_bounds__(kWG) void affine_cols_acc_k(float *__restrict__ dx, int64_t lddx,
                                                          const float *__restrict__ x, int64_t ldx,
@@ -1600,6 +1641,32 @@ int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems
   if (blocks > 64 * 1024) blocks = 64 * 1024;
   hipLaunchKernelGGL(gather_segments_k, dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, base,
                      rows_per_item, row_stride, (int)len, total, out);
+  return launch_status();
+}
+
+int sn_linear_thin_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias, int64_t rows,
+                           int32_t C, int32_t J, float *y, int64_t ldy, float *y_elu, int64_t lde, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (rows < 0 || J < 1 || C < 1 || ldx < C || ldw < C || (y && ldy < J) || (y_elu && lde < J)) return SN_E_SHAPE;
+  if (C > kThinMaxC || (J % 4) || J / 4 > kWG || (kWG % (J / 4))) return SN_E_UNSUPPORTED;
+  if (rows == 0) return SN_OK;
+  if (!x || !W || (!y && !y_elu)) return SN_E_NULL;
+  if ((y && (!aligned16(y) || (ldy % 4))) || (y_elu && (!aligned16(y_elu) || (lde % 4))) || (bias && !aligned16(bias)))
+    return SN_E_ALIGN;
+  const int lanes_r = kWG / (J / 4);
+  int64_t blocks = (rows + lanes_r - 1) / lanes_r;
+  if (blocks > 16 * kCUs) blocks = 16 * kCUs;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+#define SN_THINF(CC)                                                                                                      \
+  case CC:                                                                                                                \
+    hipLaunchKernelGGL((linear_thin_fwd_k<CC>), dim3((unsigned)blocks), dim3(kWG), 0, s, x, ldx, W, ldw, bias, rows, (int)J, y, ldy, \
+                       y_elu, lde);                                                                                       \
+    break;
+  switch (C) {
+    SN_THINF(1) SN_THINF(2) SN_THINF(3) SN_THINF(4) SN_THINF(5) SN_THINF(6) SN_THINF(7) SN_THINF(8)
+    default: return SN_E_UNSUPPORTED;
+  }
+#undef SN_THINF
   return launch_status();
 }
 

@@ -572,23 +572,34 @@ def bn_linear(x2d: torch.Tensor, bn: torch.nn.BatchNorm1d, fc: torch.nn.Linear, 
 
 class _ThinLinear(torch.autograd.Function):
     """nn.Linear with a handful of input channels on (rows, Cin <= 8) — the models' first layer,
-    GraphConv1x1(6 | 3, C, batch_norm=None) (src/utils/utils_pt.py:99).  Forward is the library GEMM (it is a plain write
-    of rows x C); the backward's weight and bias gradients are ONE pass over dy (sn_wgrad_thin_f32) instead of a
-    128 x 6, K = rows GEMM the library has no tile for (490 us -> ~40 us at the ARAP batch) plus a column reduction."""
+    GraphConv1x1(6 | 3, C, batch_norm=None) (src/utils/utils_pt.py:99).  Forward: one output-streaming kernel that can also
+    leave elu(y) in the next block's concat buffer (sn_linear_thin_fwd_f32); the backward's weight and bias gradients are
+    ONE pass over dy (sn_wgrad_thin_f32) instead of a 128 x 6, K = rows GEMM the library has no tile for (490 us -> ~40 us
+    at the ARAP batch) plus a column reduction."""
 
     @staticmethod
-    def forward(ctx, x, W, b):
+    def forward(ctx, x, W, b, want_elu):
         ctx.save_for_backward(x, W)
         ctx.has_bias = b is not None
-        return torch.addmm(b, x, W.t()) if b is not None else x.mm(W.t())
+        cat = None
+        if want_elu:                             # elu(y) straight into the next block's concat buffer (blocks.py hand-off)
+            cat = torch.empty((x.shape[0], 2 * W.shape[0]), dtype=torch.float32, device=x.device)
+        y = kernels.linear_thin_fwd(x, W, b, cat[:, :W.shape[0]] if cat is not None else None)
+        if cat is None:
+            return y, None
+        ctx.mark_non_differentiable(cat)
+        ctx.set_materialize_grads(False)
+        return y, cat
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _gcat=None):
         x, W = ctx.saved_tensors
+        if dy is None:
+            return None, None, None, None
         dy = dy.contiguous()
         dx = dy.mm(W) if ctx.needs_input_grad[0] else None
         dW, db = kernels.wgrad_thin(dy, x, ctx.has_bias)
-        return dx, dW, db
+        return dx, dW, db, None
 
 
 def thin_linear_supported(x2d: torch.Tensor, fc: torch.nn.Linear) -> bool:
@@ -596,8 +607,9 @@ def thin_linear_supported(x2d: torch.Tensor, fc: torch.nn.Linear) -> bool:
         kernels.wgrad_thin_supported(fc.out_features, fc.in_features)
 
 
-def thin_linear(x2d: torch.Tensor, fc: torch.nn.Linear) -> torch.Tensor:
-    return _ThinLinear.apply(x2d.contiguous(), fc.weight, fc.bias)
+def thin_linear(x2d: torch.Tensor, fc: torch.nn.Linear, want_elu: bool = False):
+    """(y, cat): cat is None or a (rows, 2J) buffer whose first half holds elu(y) (the blocks' activated hand-off)."""
+    return _ThinLinear.apply(x2d.contiguous(), fc.weight, fc.bias, bool(want_elu))
 
 
 class _AvgPropagate(torch.autograd.Function):

@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into",
 ]
 
 
@@ -526,6 +526,17 @@ def wgrad_seg(dy, x, center, rows_per_seg: int):
 
 def wgrad_thin_supported(J: int, C: int) -> bool:
     return 1 <= C <= 8 and J % 4 == 0 and 256 % (J // 4) == 0
+
+
+def linear_thin_fwd(x, W, bias, y_elu=None):
+    """y = x·W^T + bias for 1..8 input channels; optionally elu(y) into the 2-D view y_elu (sn_linear_thin_fwd_f32)."""
+    _dev(x, W, bias, y_elu)
+    rows, C = x.shape
+    J = W.shape[0]
+    y = torch.empty((rows, J), dtype=torch.float32, device=x.device)
+    _lib.call("sn_linear_thin_fwd_f32", _p(x), _ld(x), _p(W), _ld(W), _p(bias), rows, C, J, _p(y), J, _p(y_elu),
+              _ld(y_elu) if y_elu is not None else 0, _stream())
+    return y
 
 
 def wgrad_thin(dy, x, want_bias: bool = True):

@@ -105,8 +105,13 @@ class GraphConv1x1(nn.Module):
             if x2d.dtype == torch.float32 and self.bn.affine and self.bn.momentum is not None:
                 return snF.bn_linear(x2d, self.bn, self.fc, residual)   # one statistics pass + folded GEMM (functional.py)
             x2d = self.bn(x2d)
-        if self.batch_norm is None and torch.is_grad_enabled() and snF.thin_linear_supported(x2d, self.fc):
-            x2d = snF.thin_linear(x2d, self.fc)       # first layer (3 / 6 coordinates in): one-pass weight gradient
+        if self.batch_norm is None and snF.thin_linear_supported(x2d, self.fc):
+            # first layer (3 / 6 coordinates in): output-streaming forward, one-pass weight gradient; elu(y) for the block
+            # that follows leaves the same kernel (the activated hand-off of blocks.py)
+            want_elu = residual is None and self.num_outputs % 4 == 0 and 256 % (self.num_outputs // 4) == 0
+            x2d, cat = snF.thin_linear(x2d, self.fc, want_elu)
+            if cat is not None:
+                x2d._sn_cat = cat
         else:
             x2d = self.fc(x2d)
         if self.batch_norm == "post":
@@ -116,7 +121,10 @@ class GraphConv1x1(nn.Module):
     def forward(self, x):
         batch_size, num_nodes, num_inputs = x.size()
         assert num_inputs == self.num_inputs
-        return self.forward2d(x.reshape(-1, num_inputs)).view(batch_size, num_nodes, self.num_outputs)
+        y2d = self.forward2d(x.reshape(-1, num_inputs))
+        cat = snB.take_activated(y2d, y2d.shape[0], self.num_outputs)
+        y = y2d.view(batch_size, num_nodes, self.num_outputs)
+        return y if cat is None else snB.attach_activated(y, cat)
 
 
 class GraphBatchNorm(nn.Module):

@@ -331,6 +331,13 @@ def wgrad_thin_supported(J, C):
     return 1 <= C <= 8 and J % 4 == 0 and 256 % (J // 4) == 0
 
 
+def linear_thin_fwd(x, W, bias, y_elu=None):
+    y = torch.addmm(bias, x, W.t()) if bias is not None else x.mm(W.t())       # fp32, like the kernel's FMA chain
+    if y_elu is not None:
+        elu_into(y, y_elu)
+    return y
+
+
 def wgrad_thin(dy, x, want_bias=True):
     G = (dy.double().t() @ x.double()).float()
     return G, (dy.double().sum(0).float() if want_bias else None)

@@ -24,9 +24,15 @@ def _sig_err(sigs, ref64):
     return max(float(np.abs(np.asarray(sigs[k]) - ref64[k]).max()) for k in ref64) / top
 
 
-def _as_close_as_reference(name, prod, ref32, truth64):
+# The FAUST loss is the worst-conditioned quantity of the suite: one fp32 ulp of input noise moves the reference's own fp32
+# loss by 1e-4 .. 1.4e-3 relative (tests/golden/faust_loss_sensitivity.py; the stored unperturbed run is a lucky 5.4e-5).
+# Its bound therefore also admits that measured spread (x1.5).
+FAUST_LOSS_SPREAD = 2e-3
+
+
+def _as_close_as_reference(name, prod, ref32, truth64, spread=0.0):
     e_prod, e_ref = rel_err(prod, truth64), rel_err(ref32, truth64)
-    assert e_prod <= SLACK * e_ref + FLOOR, (name, "product err", e_prod, "reference fp32 err", e_ref)
+    assert e_prod <= max(SLACK * e_ref, spread) + FLOOR, (name, "product err", e_prod, "reference fp32 err", e_ref)
 
 
 BLOCKS = [("LapResNet2", 64), ("LapResNet2", 128), ("DirResNet2", 64), ("DirResNet2", 128), ("AvgResNet2", 128),
@@ -122,7 +128,7 @@ def check_model(golden_dir, tag, dev, opkind="pool", tol_out=5e-5):
         loss64 = OB.delta_cross_entropy(out64, [(c(tX[0][0]), tX[0][1].cpu(), tX[0][2].cpu())], [(c(tY[0][0]), tY[0][1].cpu(), tY[0][2].cpu())])
         loss64.backward()
         s64 = grad_signature(m64)
-        _as_close_as_reference("faust loss", loss.item(), float(g["faust_lap_loss"]), loss64.item())
+        _as_close_as_reference("faust loss", loss.item(), float(g["faust_lap_loss"]), loss64.item(), FAUST_LOSS_SPREAD)
         _as_close_as_reference("faust out", out.detach().cpu().numpy()[0, ::7, ::7], g["faust_lap_out_sample"], out64.detach().numpy()[0, ::7, ::7])
         e_prod = _sig_err(grad_signature(m), s64)
         e_ref = _sig_err({k: g[f"faust_lap_psig_{k}"] for k in s64}, s64)

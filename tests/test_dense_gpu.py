@@ -512,3 +512,21 @@ def test_gather_segments(n, vmax, f3, nv, length, shift):
         c0 = 3 * int(off[b]) + shift
         assert torch.equal(got[b], src[int(sid[b]), :nv, c0:c0 + length])
     assert kernels.gather_segments(src, base[:0], nv, f3, length).shape == (0, nv, length)
+
+
+@pytest.mark.parametrize("rows", [1, 9, 1000, 40001])
+@pytest.mark.parametrize("J,C,bias", [(128, 6, True), (128, 3, True), (64, 3, False), (16, 8, True)])
+def test_linear_thin_fwd(rows, J, C, bias):
+    torch.manual_seed(rows + J + C)
+    xw = torch.randn(rows, C + 2, device=DEV)
+    x = xw[:, :C]                                                   # strided rows
+    W = torch.randn(J, C, device=DEV)
+    b = torch.randn(J, device=DEV) if bias else None
+    cat = torch.full((rows, 2 * J), float("nan"), device=DEV)
+    y = kernels.linear_thin_fwd(x, W, b, cat[:, :J])
+    want = x.double() @ W.double().t() + (b.double() if bias else 0.0)
+    assert rel_err(y.cpu().numpy(), want.cpu().numpy()) < 1e-6
+    assert torch.equal(cat[:, :J], torch.where(y > 0, y, torch.expm1(y))) or \
+        rel_err(cat[:, :J].cpu().numpy(), torch.nn.functional.elu(want).cpu().numpy()) < 1e-6
+    assert torch.isnan(cat[:, J:]).all()                            # the other half is not touched
+    assert torch.equal(kernels.linear_thin_fwd(x, W, b), y)
