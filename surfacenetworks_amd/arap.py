@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from . import kernels, mesh_ops
 from . import utils_pt as utils
-from .operators import OperatorPool
+from .operators import OperatorPool, h2d_async
 
 INPUT_FRAMES = 2       # main.py:105
 OUTPUT_FRAMES = 40     # main.py:106
@@ -231,8 +231,8 @@ class ClothSequences:
         B = len(seq_ids)
         nv = int(self.num_vertices[seq_ids].max())
         nf = int(self.num_faces[seq_ids].max())
-        sid = torch.from_numpy(seq_ids).to(self.device)
-        off = torch.from_numpy(offsets).to(self.device)
+        sid = h2d_async(seq_ids, self.device)
+        off = h2d_async(offsets, self.device)
         # a sample's 42 frames of a vertex are one contiguous run of the vertex-major copy: inputs and targets are gathered
         # straight into their final (B, nv, frames*3) layout (no permute / slice copies of the 160 MB window)
         vm = self._vertex_major()                                  # (n, vmax, frames*3)

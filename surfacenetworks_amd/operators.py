@@ -15,6 +15,7 @@ What this replaces in the reference (paths relative to the reference checkout):
 """
 from __future__ import annotations
 
+import os
 import weakref
 from typing import Optional, Sequence
 
@@ -336,6 +337,19 @@ def as_operator(A) -> SparseOperator:
     raise TypeError(f"cannot interpret {type(A)} as a sparse operator")
 
 
+def h2d_async(arr, device) -> torch.Tensor:
+    """Small host array -> device tensor WITHOUT stalling the host on the stream: staged through pinned memory (torch's
+    caching host allocator keeps the staging block alive until the copy has run), so the per-step index / descriptor
+    uploads of the samplers do not wait for the previous step's kernels — a pageable-source copy does."""
+    t = torch.from_numpy(np.ascontiguousarray(arr))
+    dev = torch.device(device)
+    if dev.type != "cuda" or os.environ.get("SN_PINNED_H2D", "1") == "0":
+        return t.to(dev, non_blocking=True)
+    stage = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    stage.copy_(t)
+    return stage.to(dev, non_blocking=True)
+
+
 class OperatorPool:
     """All per-mesh operators of one kind (e.g. every Di of a dataset) resident in HBM, A and A^T.
 
@@ -406,7 +420,7 @@ class OperatorPool:
         out_off = np.zeros(len(sel) + 1, dtype=np.int64)
         np.cumsum(cnt, out=out_off[1:])
         desc = np.stack([pool["rp_off"][sel], pool["e_off"][sel], nrows, out_off[:-1]], axis=1)
-        desc_d = torch.from_numpy(np.ascontiguousarray(desc)).to(self.device, non_blocking=True)
+        desc_d = h2d_async(desc, self.device)
         return kernels.blockdiag_concat(pool["rowptr"], pool["colind"], pool["vals"], desc_d, size0, size1,
                                         int(out_off[-1]), vpe)
 
