@@ -300,6 +300,12 @@ int sn_linear_thin_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t 
                            int32_t C, int32_t J, float *y, int64_t ldy, float *y_elu, int64_t lde, void *stream);
 int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
                            const float *Cc, int64_t rows, int32_t C, void *stream);
+/* sn_affine_cols_elu_bwd_f32: the same tail for a layer whose operand x is itself the output of an ELU (the models' last
+ * layer, `conv2(F.elu(v))`, src/as_rigid_as_possible/models.py:149-150), continued through that activation in the same
+ * pass:  dx[r,c] = (dx[r,c] + (x[r,c]-center[c])*B[c] + Cc[c]) * (x[r,c] > 0 ? 1 : x[r,c] + 1).  B = Cc = NULL: no
+ * BatchNorm tail (eval mode).  Replaces the tail pass + ELUBackward. */
+int sn_affine_cols_elu_bwd_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
+                               const float *Cc, int64_t rows, int32_t C, void *stream);
 
 /* Small coefficient kernels of the folded BatchNorm+Linear (they replace ~40 tiny elementwise launches per layer):
  * sn_bn_fold_f32 : from the column statistics (stats = [sums | sums of squares], fp64, `rows` rows) or, when

@@ -20,11 +20,11 @@ import torch
 
 from . import kernels
 from .functional import (_launch, _rows2d, avg_stage_backward, avg_stage_forward, bn_prepare, bnlin_backward,
-                         bnlin_backward_zero_first, bnlin_forward, bnlin_forward_zero_first, stash, unstash,
+                         bnlin_backward_elu_input, bnlin_backward_zero_first, bnlin_forward, bnlin_forward_zero_first, stash, unstash,
                          zero_first_supported)
 from .operators import as_operator
 
-__all__ = ["lap_block", "dirac_block", "avg_block", "take_activated", "attach_activated", "zero_faces_ok"]
+__all__ = ["lap_block", "dirac_block", "avg_block", "take_activated", "attach_activated", "zero_faces_ok", "elu_conv", "elu_conv_ok"]
 
 
 def attach_activated(t: torch.Tensor, cat: torch.Tensor) -> torch.Tensor:
@@ -292,6 +292,45 @@ class _AvgBlock(torch.autograd.Function):
             g_x = None
         return (g_x, None, None, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None,
                 None, None, None, None)
+
+
+class _EluConv(torch.autograd.Function):
+    """GraphConv1x1("pre")(F.elu(v)) — the models' last layer (src/as_rigid_as_possible/models.py:148-150) — as one node:
+    elu(v) is the activated hand-off of the preceding block when there is one (no ELU pass), and the backward runs the
+    BatchNorm tail and the activation derivative as one pass."""
+
+    @staticmethod
+    def forward(ctx, v, pre, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0):
+        v = _rows2d(v)
+        C = v.shape[1]
+        cat = _activated(v, pre)
+        part = getattr(cat, "_sn_part", None)        # statistics of elu(v) left by the GEMM that wrote it
+        pre_stats = kernels.colstats_from_part(part, v.shape[0]) if (part is not None and tr0 and C == 128) else None
+        y, st = bnlin_forward(cat[:, :C], g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, pre_stats=pre_stats)
+        stash(ctx, st)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (st,) = unstash(ctx)
+        g_v, dg, db, dW, dc = bnlin_backward_elu_input(st, dy)
+        if not ctx.needs_input_grad[0]:
+            g_v = None
+        return g_v, None, dg, db, dW, dc, None, None, None, None, None
+
+
+def elu_conv(conv, v):
+    """conv(F.elu(v)) for a GraphConv1x1 with batch_norm="pre" on a (B, N, C) tensor, as one autograd node."""
+    B, N, C = v.shape
+    rows = B * N
+    y = _EluConv.apply(v.reshape(rows, C), take_activated(v, rows, C), *_bn_args(conv))
+    return y.view(B, N, conv.num_outputs)
+
+
+def elu_conv_ok(conv, v) -> bool:
+    c = v.shape[-1]
+    return getattr(conv, "batch_norm", None) == "pre" and v.dtype == torch.float32 and c % 4 == 0 and 256 % (c // 4) == 0 and \
+        conv.bn.affine and conv.bn.momentum is not None and conv.bn.track_running_stats
 
 
 def lap_block(mod, L, inputs):

@@ -820,7 +820,9 @@ __global__ __launch_bounds__(kWG) void linear_thin_fwd_k(const float *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-template <bool VEC>
+// ELU: x is the OUTPUT of an ELU (the operand of the BatchNorm) and the result continues through that activation:
+//      dx = (dx + (x - center)·B + Cc) · elu'(.) with elu' = 1 (x > 0) | x + 1;  B == NULL: no BatchNorm tail (eval mode).
+template <bool VEC, bool ELU>
 __global__ __launch_bounds__(kWG) void affine_cols_acc_k(float *__restrict__ dx, int64_t lddx,
                                                          const float *__restrict__ x, int64_t ldx,
                                                          const float *__restrict__ center,
@@ -834,17 +836,27 @@ __global__ __launch_bounds__(kWG) void affine_cols_acc_k(float *__restrict__ dx,
     const int c = (int)(t - r * cw) * W;
     if constexpr (VEC) {
       f4 d = ld4_s(dx + r * lddx + c, nt);
-      f4 xv = ld4_s(x + r * ldx + c, nt);
-      if (center) xv -= *reinterpret_cast<const f4 *>(center + c);
-      const f4 b = *reinterpret_cast<const f4 *>(B + c);
-      const f4 k = *reinterpret_cast<const f4 *>(Cc + c);
-      d.x += __builtin_fmaf(xv.x, b.x, k.x);
-      d.y += __builtin_fmaf(xv.y, b.y, k.y);
-      d.z += __builtin_fmaf(xv.z, b.z, k.z);
-      d.w += __builtin_fmaf(xv.w, b.w, k.w);
+      const f4 xr = ld4_s(x + r * ldx + c, nt);
+      if (B) {
+        f4 xv = xr;
+        if (center) xv -= *reinterpret_cast<const f4 *>(center + c);
+        const f4 b = *reinterpret_cast<const f4 *>(B + c);
+        const f4 k = *reinterpret_cast<const f4 *>(Cc + c);
+        d.x += __builtin_fmaf(xv.x, b.x, k.x);
+        d.y += __builtin_fmaf(xv.y, b.y, k.y);
+        d.z += __builtin_fmaf(xv.z, b.z, k.z);
+        d.w += __builtin_fmaf(xv.w, b.w, k.w);
+      }
+      if constexpr (ELU)
+        d = f4{d.x * (xr.x > 0.f ? 1.f : xr.x + 1.f), d.y * (xr.y > 0.f ? 1.f : xr.y + 1.f),
+               d.z * (xr.z > 0.f ? 1.f : xr.z + 1.f), d.w * (xr.w > 0.f ? 1.f : xr.w + 1.f)};
       st4_s(dx + r * lddx + c, d, nt);
     } else {
-      dx[r * lddx + c] += __builtin_fmaf(x[r * ldx + c] - (center ? center[c] : 0.f), B[c], Cc[c]);
+      const float xr = x[r * ldx + c];
+      float d = dx[r * lddx + c];
+      if (B) d += __builtin_fmaf(xr - (center ? center[c] : 0.f), B[c], Cc[c]);
+      if constexpr (ELU) d *= xr > 0.f ? 1.f : xr + 1.f;
+      dx[r * lddx + c] = d;
     }
   }
 }
@@ -1444,22 +1456,35 @@ int sn_avg_bwd_segvec_f32(const float *seg_dy, const float *Wf2, int64_t ldw, co
   return launch_status();
 }
 
+static int affine_cols_launch(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
+                              const float *Cc, int64_t rows, int32_t C, bool elu, void *stream) {
+  if (rows < 0 || C < 1 || lddx < C || ldx < C) return SN_E_SHAPE;
+  if (rows == 0) return SN_OK;
+  if (!dx || !x || (!elu && !B) || (B && !Cc)) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const bool vec = (C % 4 == 0) && (lddx % 4 == 0) && (ldx % 4 == 0) && aligned16(dx) && aligned16(x) &&
+                   (!B || (aligned16(B) && aligned16(Cc))) && (!center || aligned16(center));
+  int64_t items = vec ? rows * (C / 4) : rows * (int64_t)C;
+  int64_t blocks = (items + kWG - 1) / kWG;
+#define SN_AFF(V, E) hipLaunchKernelGGL((affine_cols_acc_k<V, E>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C, kStreamNT)
+  if (vec && elu) SN_AFF(true, true);
+  else if (vec) SN_AFF(true, false);
+  else if (elu) SN_AFF(false, true);
+  else SN_AFF(false, false);
+#undef SN_AFF
+  return launch_status();
+}
+
 int sn_affine_cols_acc_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
                            const float *Cc, int64_t rows, int32_t C, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
-  if (rows < 0 || C < 1 || lddx < C || ldx < C) return SN_E_SHAPE;
-  if (rows == 0) return SN_OK;
-  if (!dx || !x || !B || !Cc) return SN_E_NULL;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const bool vec = (C % 4 == 0) && (lddx % 4 == 0) && (ldx % 4 == 0) && aligned16(dx) && aligned16(x) && aligned16(B) &&
-                   aligned16(Cc) && (!center || aligned16(center));
-  int64_t items = vec ? rows * (C / 4) : rows * (int64_t)C;
-  int64_t blocks = (items + kWG - 1) / kWG;
-  if (vec)
-    hipLaunchKernelGGL((affine_cols_acc_k<true>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C, kStreamNT);
-  else
-    hipLaunchKernelGGL((affine_cols_acc_k<false>), dim3((unsigned)blocks), dim3(kWG), 0, s, dx, lddx, x, ldx, center, B, Cc, rows, (int)C, kStreamNT);
-  return launch_status();
+  return affine_cols_launch(dx, lddx, x, ldx, center, B, Cc, rows, C, false, stream);
+}
+
+int sn_affine_cols_elu_bwd_f32(float *dx, int64_t lddx, const float *x, int64_t ldx, const float *center, const float *B,
+                               const float *Cc, int64_t rows, int32_t C, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  return affine_cols_launch(dx, lddx, x, ldx, center, B, Cc, rows, C, true, stream);
 }
 
 int sn_bn_fold_f32(const double *stats, int64_t rows, const float *gamma, const float *beta, const float *W,

@@ -39,7 +39,7 @@ class Model(nn.Module):
         x = self.conv1(inputs)
         for i in range(self.layer):
             x = self._modules["rn{}".format(i)](L, mask, x)
-        x = self.conv2(F.elu(x))
+        x = utils.elu_conv1x1(self.conv2, x)
         return _add_last_frame(x, inputs, 40)
 
 
@@ -64,7 +64,7 @@ class DirModel(nn.Module):
                 v, f = blk(Di, DiA, v, f, num_faces=num_faces)
             else:
                 v = blk(None, mask, v)
-        x = self.conv2(F.elu(v))
+        x = utils.elu_conv1x1(self.conv2, v)
         return _add_last_frame(x, inputs, 40)
 
 

@@ -373,7 +373,7 @@ def _take_counter(running_mean):
 
 
 def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual=None, elu_out=None,
-                  want_y=True, elu_stats=None):
+                  want_y=True, elu_stats=None, pre_stats=None):
     """Forward of the folded BatchNorm1d("pre") + Linear on a (rows, C) operand (no autograd): statistics in one pass
     (fp64 accumulation), BN folded into the weights  y = x·(W·diag(s))ᵀ + (b + W·t),  s = gamma*invstd, t = beta - mean*s,
     optional residual add and ELU copy in the GEMM epilogue.  Returns (y, state) with `state` for bnlin_backward."""
@@ -384,6 +384,8 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     rows = x.shape[0]
     if not training:
         stats = None
+    elif pre_stats is not None:                 # (2, C) float64 statistics of x supplied by its producer
+        stats = pre_stats
     elif part is not None and x.shape[1] == 256:
         stats = kernels.colstats_halves(x, part)
     else:
@@ -494,6 +496,30 @@ def bnlin_backward_zero_first(state, dy):
     Wf2 = Wf[:, C:]
     dp = kernels.linear_dgrad(dy, Wf2, p, mean[C:], Bc[C:], Cc[C:]) if training else kernels.linear_dgrad(dy, Wf2)
     return dp, dgamma, dbeta, dW, db
+
+
+def bnlin_backward_elu_input(state, dy):
+    """Backward of bnlin_forward whose operand x is the OUTPUT of an ELU (`conv(F.elu(v))`), continued through that
+    activation: returns (dL/dv, dgamma, dbeta, dW, db).  The BatchNorm tail and the activation derivative are one in-place
+    pass over the input gradient (sn_affine_cols_elu_bwd_f32) instead of a tail pass plus torch's ELUBackward."""
+    x, W, Wf, s, mean, invstd, beta, training, has_bias, rows_g = state
+    dy = dy.contiguous()
+    J, C = dy.shape[1], x.shape[1]
+    if kernels.wgrad_supported(J, C):
+        Gc, sdy = kernels.wgrad(dy, x, mean, want_colsum=True)
+    else:
+        Gc, sdy = dy.t().mm(x - mean), kernels.colstats(dy)
+    scale = 1.0
+    if training:
+        Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
+    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    dx = kernels.linear_dgrad(dy, Wf) if kernels.linear_dgrad_supported(J, C) else dy.mm(Wf)
+    if training:
+        kernels.affine_cols_elu_bwd(dx, x, Bc, Cc, mean)
+    else:
+        kernels.affine_cols_elu_bwd(dx, x)
+    return dx, dgamma, dbeta, dW, db
 
 
 def avg_stage_forward(e, mask_rows, inv_count, nseg, per, gamma, beta, W, b, running_mean, running_var, training, momentum,

@@ -13,10 +13,10 @@ from . import _lib
 
 __all__ = [
     "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
-    "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc",
+    "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part",
 ]
 
 
@@ -240,6 +240,16 @@ def affine_cols_acc(dx, x, B, Cc, center=None) -> None:
     _lib.call("sn_affine_cols_acc_f32", _p(dx), _ld(dx), _p(x), _ld(x), _p(center), _p(B), _p(Cc), x.shape[0], x.shape[1], _stream())
 
 
+def affine_cols_elu_bwd(dx, x, B=None, Cc=None, center=None) -> None:
+    """dx[r,c] = (dx[r,c] + (x[r,c] - center[c])*B[c] + Cc[c]) * elu'(.) in place, x = the ELU OUTPUT that fed the layer
+    (sn_affine_cols_elu_bwd_f32); B = Cc = None: only the activation derivative."""
+    _dev(dx, x, B, Cc, center)
+    if dx.shape != x.shape or (B is not None and (B.numel() != x.shape[1] or Cc is None or Cc.numel() != x.shape[1])):
+        raise ValueError("affine_cols_elu_bwd: shape mismatch")
+    _lib.call("sn_affine_cols_elu_bwd_f32", _p(dx), _ld(dx), _p(x), _ld(x), _p(center), _p(B), _p(Cc), x.shape[0], x.shape[1],
+              _stream())
+
+
 def bn_fold(stats, rows: int, gamma, beta, W, b, eps: float, momentum: float, training: bool, running_mean, running_var,
             num_batches_tracked=None):
     """Fold BatchNorm into the Linear weights (see sn_bn_fold_f32). Returns (mean, invstd, s, t, Wf, bf); updates the
@@ -376,6 +386,19 @@ def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y: bool = True, elu_s
               _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu), _ld(y_elu) if y_elu is not None else 0,
               rows, K, J, _p(elu_stats), _stream())
     return y if keep else None
+
+
+def colstats_from_part(part, rows: int):
+    """(2, 128) float64 statistics of a forward GEMM's ELU output from the partials it left (sn_colstats_merge_f64)."""
+    _dev(part)
+    if part.dim() != 3 or part.shape[1:] != (2, 128) or part.dtype != torch.float64:
+        raise ValueError("colstats_from_part: expected (nblk, 2, 128) float64 partials")
+    nblk = int(_lib.load().sn_linear_fwd_stats_blocks(rows))
+    if part.shape[0] < nblk:
+        raise ValueError("colstats_from_part: partial buffer smaller than the producing launch's grid")
+    out = torch.empty((2, 128), dtype=torch.float64, device=part.device)
+    _lib.call("sn_colstats_merge_f64", _p(part), nblk, 128, _p(out), 128, 0, _stream())
+    return out
 
 
 def colstats_into(x, out, offset: int):

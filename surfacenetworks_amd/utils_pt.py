@@ -127,6 +127,14 @@ class GraphConv1x1(nn.Module):
         return y if cat is None else snB.attach_activated(y, cat)
 
 
+def elu_conv1x1(conv: GraphConv1x1, x: torch.Tensor) -> torch.Tensor:
+    """conv(F.elu(x)) — how every model of the reference enters its last GraphConv1x1 (as_rigid_as_possible/models.py:148-150,
+    dense_correspondence/models.py:177-179) — as one fused node where the shapes allow, else literally that."""
+    if USE_WHOLE_BLOCKS and snB.elu_conv_ok(conv, x):
+        return snB.elu_conv(conv, x)
+    return conv(F.elu(x))
+
+
 class GraphBatchNorm(nn.Module):
     """BatchNorm over B*Nodes rows that always uses batch statistics (utils_pt.py:107-118)."""
 

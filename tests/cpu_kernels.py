@@ -145,6 +145,14 @@ def affine_cols_acc(dx, x, B, Cc, center=None):
                                  None if center is None else _np(center))
 
 
+def affine_cols_elu_bwd(dx, x, B=None, Cc=None, center=None):
+    d = dx.double()
+    if B is not None:
+        d = d + (x.double() - (0.0 if center is None else center.double())) * B.double() + Cc.double()
+    d = d * torch.where(x > 0, torch.ones_like(x), x + 1).double()
+    dx.copy_(d.float())
+
+
 def bn_fold(stats, rows, gamma, beta, W, b, eps, momentum, training, running_mean, running_var, num_batches_tracked=None):
     """numpy/double restatement of what nn.BatchNorm1d + the weight folding compute (checker for sn_bn_fold_f32)."""
     if training and num_batches_tracked is not None:
@@ -242,6 +250,10 @@ def elu_stats_supported():
 
 def new_elu_stats_part(rows, device):
     return torch.zeros((1, 2, 128), dtype=torch.float64)
+
+
+def colstats_from_part(part, rows):
+    return part.sum(0)
 
 
 def colstats_into(x, out, offset):

@@ -530,3 +530,47 @@ def test_linear_thin_fwd(rows, J, C, bias):
         rel_err(cat[:, :J].cpu().numpy(), torch.nn.functional.elu(want).cpu().numpy()) < 1e-6
     assert torch.isnan(cat[:, J:]).all()                            # the other half is not touched
     assert torch.equal(kernels.linear_thin_fwd(x, W, b), y)
+
+
+# ---- last layer: conv(F.elu(v)) as one node -------------------------------------------------------------------------------
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("C,J", [(128, 120), (128, 128), (64, 10)])
+def test_elu_conv_matches_torch_layers(C, J, train):
+    """utils.elu_conv1x1(conv, x) == conv(F.elu(x)) with nn.BatchNorm1d + nn.Linear in fp64 (models.py:148-150): output, input
+    gradient, parameter gradients, running statistics — also when elu(x) arrives as the activated hand-off of a block."""
+    import torch.nn.functional as F
+
+    from surfacenetworks_amd import blocks as snB, utils_pt as U
+
+    torch.manual_seed(C + J)
+    B, N = 3, 333
+    conv = U.GraphConv1x1(C, J, batch_norm="pre").to(DEV).train(train)
+    with torch.no_grad():
+        conv.bn.weight.uniform_(0.5, 1.5), conv.bn.bias.uniform_(-0.3, 0.3)
+        conv.bn.running_mean.uniform_(-0.2, 0.2), conv.bn.running_var.uniform_(0.5, 2.0)
+    bn64 = torch.nn.BatchNorm1d(C).to(DEV).double().train(train)
+    fc64 = torch.nn.Linear(C, J).to(DEV).double()
+    bn64.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in conv.bn.state_dict().items()})
+    fc64.load_state_dict({k: v.double() for k, v in conv.fc.state_dict().items()})
+    g = torch.randn(B, N, J, device=DEV)
+    x0 = torch.randn(B, N, C, device=DEV) * 1.5
+    x64 = x0.double().requires_grad_(True)
+    y64 = fc64(bn64(F.elu(x64).reshape(B * N, C))).view(B, N, J)
+    y64.backward(g.double())
+    for handoff in (False, True):
+        conv.zero_grad()
+        x = x0.clone().requires_grad_(True)
+        xin = x
+        if handoff:
+            if C != 128:
+                continue
+            cat = torch.empty(B * N, 2 * C, device=DEV)
+            cat[:, :C] = F.elu(x0).reshape(B * N, C)
+            xin = snB.attach_activated(x.view(B, N, C), cat)
+        y = U.elu_conv1x1(conv, xin)
+        y.backward(g)
+        assert rel_err(y.detach().cpu().numpy(), y64.detach().cpu().numpy()) < 1e-5
+        assert rel_err(x.grad.cpu().numpy(), x64.grad.cpu().numpy()) < 1e-5
+        assert rel_err(conv.fc.weight.grad.cpu().numpy(), fc64.weight.grad.cpu().numpy()) < 1e-5
+        assert rel_err(conv.bn.weight.grad.cpu().numpy(), bn64.weight.grad.cpu().numpy()) < 1e-5
+        assert rel_err(conv.bn.bias.grad.cpu().numpy(), bn64.bias.grad.cpu().numpy()) < 1e-5
