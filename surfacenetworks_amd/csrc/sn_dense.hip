@@ -766,15 +766,24 @@ __global__ __launch_bounds__(kWG) void masked_sl1_bwd_k(const float *__restrict_
 // a batch is rows_per_item segments of `len` consecutive floats, segment r at src[base[i] + r*row_stride .. + len).
 // One thread per output float: consecutive threads read consecutive floats of a segment (coalesced, no alignment needed).
 // ------------------------------------------------------------------------------------------------
+// W = 4 (len % 4 == 0, out 16-byte aligned): a thread gathers four consecutive floats (the source run has no alignment)
+// and stores them as one 16-byte word.
+template <int W>
 __global__ __launch_bounds__(kWG) void gather_segments_k(const float *__restrict__ src, const int64_t *__restrict__ base,
                                                          int64_t rows_per_item, int64_t row_stride, int len,
                                                          int64_t total, float *__restrict__ out) {
-  const int64_t per_item = rows_per_item * len;
+  const int lw = len / W;
+  const int64_t per_item = rows_per_item * lw;
   for (int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x; i < total; i += (int64_t)gridDim.x * kWG) {
     const int64_t item = i / per_item, w = i - item * per_item;
-    const int64_t r = w / len;
-    const int c = (int)(w - r * len);
-    __builtin_nontemporal_store(src[base[item] + r * row_stride + c], out + i);
+    const int64_t r = w / lw;
+    const int c = (int)(w - r * lw) * W;
+    const float *p = src + base[item] + r * row_stride + c;
+    if constexpr (W == 4) {
+      __builtin_nontemporal_store(f4{p[0], p[1], p[2], p[3]}, reinterpret_cast<f4 *>(out) + i);
+    } else {
+      __builtin_nontemporal_store(p[0], out + i);
+    }
   }
 }
 
@@ -1659,13 +1668,18 @@ int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems
                            int32_t len, float *out, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (nitems < 0 || rows_per_item < 0 || len < 1 || row_stride < 0) return SN_E_SHAPE;
-  const int64_t total = nitems * rows_per_item * len;
-  if (total == 0) return SN_OK;
+  if (nitems * rows_per_item * len == 0) return SN_OK;
   if (!src || !base || !out) return SN_E_NULL;
+  const bool vec = (len % 4 == 0) && aligned16(out);
+  const int64_t total = nitems * rows_per_item * (vec ? len / 4 : len);
   int64_t blocks = (total + kWG - 1) / kWG;
   if (blocks > 64 * 1024) blocks = 64 * 1024;
-  hipLaunchKernelGGL(gather_segments_k, dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, base,
-                     rows_per_item, row_stride, (int)len, total, out);
+  if (vec)
+    hipLaunchKernelGGL((gather_segments_k<4>), dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, base,
+                       rows_per_item, row_stride, (int)len, total, out);
+  else
+    hipLaunchKernelGGL((gather_segments_k<1>), dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, base,
+                       rows_per_item, row_stride, (int)len, total, out);
   return launch_status();
 }
 
