@@ -1128,17 +1128,22 @@ __global__ __launch_bounds__(kWG) void segstats_k(const float *__restrict__ x, i
     partial[((int64_t)seg * gridDim.x + blockIdx.x) * 3 * C + i] = t;
   }
 }
-// Stage 2 (grid C/32 blocks of 32 columns x 8 mesh groups): m = masked sum * inv_count, and
+// Stage 2: m = masked sum * inv_count, and
 // stats (2 x 2C fp64) = [ sum | per * sum_mesh m ;  sum of squares | per * sum_mesh m^2 ]  (the layout sn_bn_fold_f32 reads)
-__global__ __launch_bounds__(kWG) void segstats_final_k(const double *__restrict__ partial, int nslab, int nseg, int C,
-                                                        const float *__restrict__ inv_count, double per,
-                                                        float *__restrict__ m, double *__restrict__ stats) {
-  __shared__ double sm[4][8][32];
-  const int cl = threadIdx.x & 31, gg = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + cl;
+// 256 threads = 8 columns x 32 mesh lanes, C/8 workgroups: the 3 MB of partials are pulled by 16 CUs instead of 4 and a
+// thread handles 2 instead of 8 meshes in sequence (48 loads in flight each) — this tiny kernel is bound by both.
+constexpr int kSegFinalLanes = 32, kSegFinalCols = 8;
+__global__ __launch_bounds__(kSegFinalCols * kSegFinalLanes) void segstats_final_k(const double *__restrict__ partial, int nslab,
+                                                                                   int nseg, int C,
+                                                                                   const float *__restrict__ inv_count,
+                                                                                   double per, float *__restrict__ m,
+                                                                                   double *__restrict__ stats) {
+  __shared__ double sm[4][kSegFinalLanes][kSegFinalCols];
+  const int cl = threadIdx.x % kSegFinalCols, gg = threadIdx.x / kSegFinalCols;
+  const int c = blockIdx.x * kSegFinalCols + cl;
   double U = 0, Q = 0, S1 = 0, S2 = 0;
   if (c < C)
-    for (int g = gg; g < nseg; g += 8) {
+    for (int g = gg; g < nseg; g += kSegFinalLanes) {
       double ms = 0;
       const double *p = partial + (int64_t)g * nslab * 3 * C + c;
       if (nslab == kSegSlabs) {                  // the launch below always uses kSegSlabs: all 48 loads of a mesh in flight
@@ -1176,7 +1181,7 @@ __global__ __launch_bounds__(kWG) void segstats_final_k(const double *__restrict
     for (int k = 0; k < 4; ++k) {
       t[k] = 0;
 #pragma unroll
-      for (int l = 0; l < 8; ++l) t[k] += sm[k][l][cl];
+      for (int l = 0; l < kSegFinalLanes; ++l) t[k] += sm[k][l][cl];
     }
     stats[c] = t[0];
     stats[C + c] = per * t[2];
@@ -1573,7 +1578,7 @@ int sn_avg_stats_f32(const float *e, int64_t ld, const float *mask, const float 
   double *partial = static_cast<double *>(workspace);
   const size_t shm = (size_t)(kWG / (C / 4)) * 3 * C * sizeof(double);
   hipLaunchKernelGGL(segstats_k, dim3(kSegSlabs, (unsigned)nseg), dim3(kWG), shm, s, e, ld, mask, rows_per_seg, (int)C, partial);
-  hipLaunchKernelGGL(segstats_final_k, dim3((unsigned)((C + 31) / 32)), dim3(kWG), 0, s, partial, kSegSlabs, (int)nseg, (int)C,
+  hipLaunchKernelGGL(segstats_final_k, dim3((unsigned)((C + kSegFinalCols - 1) / kSegFinalCols)), dim3(kSegFinalCols * kSegFinalLanes), 0, s, partial, kSegSlabs, (int)nseg, (int)C,
                      inv_count, (double)rows_per_seg, m, stats);
   return launch_status();
 }
