@@ -105,6 +105,17 @@ int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const flo
 int sn_spmm_q3_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks,
                    const float *X, int64_t ldx, int32_t x_group, int32_t N,
                    float *Y, int64_t ldy, int32_t y_group, void *stream);
+/* sn_spmm_q3_stats_f32: sn_spmm_q3_f32 for N = 32, y_group = 4 (the (rows/4, 128) view of a 128-channel tensor) that ALSO
+ * leaves the BatchNorm statistics of its output: stats_part[sn_spmm_q3_stats_blocks()][2][128] fp64 partial column sums /
+ * sums of squares (per channel c = 32*component + column), to be combined by sn_colstats_merge_f64 — the statistics pass over
+ * the propagated half of a stage's concat buffer (utils_pt.py:204-205,216-217: torch.cat + BatchNorm1d) disappears.
+ * Each workgroup's fp32 partial of its 32 output rows goes through `workspace` (sn_spmm_q3_stats_workspace_bytes(Mb)) and is
+ * added up in fp64 in a fixed order (deterministic).  Y is bit-identical to sn_spmm_q3_f32. */
+size_t sn_spmm_q3_stats_workspace_bytes(int64_t Mb);
+int32_t sn_spmm_q3_stats_blocks(void);
+int sn_spmm_q3_stats_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks, const float *X,
+                         int64_t ldx, int32_t x_group, int32_t N, float *Y, int64_t ldy, int32_t y_group, double *stats_part,
+                         void *workspace, size_t workspace_bytes, void *stream);
 int sn_spmm_q3_elubwd_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks,
                           const float *X, int64_t ldx, int32_t x_group, int32_t N,
                           const float *E, int64_t lde, const float *G, int64_t ldg,
@@ -402,7 +413,7 @@ int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_
  * (sn_spmm_csr_f32 / sn_spmm_bsr4_f32 and their _elubwd forms) is issued with hipExtLaunchKernelGGL so that the KERNEL's own start and stop are
  * stamped into two events: durations carry no marker / kernel-boundary overhead and agree with rocprofv3's kernel trace.
  * sn_timing_drain waits for the recorded launches, writes up to `capacity` durations (ms) and 5 int64 per record
- * {kind (bit 0: 0 csr, 1 blocked; bit 3: the blocked form is Q3; bit 1: fused ELU-backward epilogue, E read; bit 2: G read
+ * {kind (bit 0: 0 csr, 1 blocked; bit 3: the blocked form is Q3; bit 4: the launch also left column statistics (sn_spmm_q3_stats_f32); bit 1: fused ELU-backward epilogue, E read; bit 2: G read
  *  too), M, K,
  *  nnz (csr) | nblocks (bsr4), N}, and clears the list.
  * ------------------------------------------------------------------------------------------ */

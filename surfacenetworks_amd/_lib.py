@@ -24,6 +24,9 @@ SIGNATURES = {
     "sn_spmm_bsr4_elubwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64,
                                           _i32, _vp]),
     "sn_spmm_q3_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "sn_spmm_q3_stats_workspace_bytes": (_sz, [_i64]),
+    "sn_spmm_q3_stats_blocks": (_i32, []),
+    "sn_spmm_q3_stats_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "sn_spmm_q3_elubwd_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp]),
     "sn_bsr4_to_q3_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "sn_coo_to_csr_i32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),

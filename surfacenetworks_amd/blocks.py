@@ -58,6 +58,12 @@ def _attach_part(cat, part):
         cat._sn_part = part
 
 
+def _attach_hi(cat, part):
+    """Statistics of the PROPAGATED half, left by the SpMM that wrote it (functional._launch(..., stats=True))."""
+    if part is not None:
+        cat._sn_part_hi = part
+
+
 def _activated(x2d, pre):
     """(rows, 2C) buffer whose first half is elu(x2d): the handed-off one, or a new one filled here."""
     if pre is not None:
@@ -93,11 +99,11 @@ class _DiracBlock(torch.autograd.Function):
         if f is None:
             # all-zero face features (the first Dirac block of a model): cat0 = [0 | Di·elu(v)] runs at half width
             cat0 = torch.empty((rf, C), dtype=torch.float32, device=v.device)      # only the propagated half exists
-            _launch(opDi, cat1[:, :C], cat0, 4, "fwd")
+            _attach_hi(cat0, _launch(opDi, cat1[:, :C], cat0, 4, "fwd", stats=tr0))
             f_out, st0 = bnlin_forward_zero_first(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, nxt_f[:, :C], need_f, pf)
         else:
             cat0 = pre_f if pre_f is not None else _activated(_rows2d(f), None)    # (f's values are not touched when handed off)
-            _launch(opDi, cat1[:, :C], cat0[:, C:], 4, "fwd")
+            _attach_hi(cat0, _launch(opDi, cat1[:, :C], cat0[:, C:], 4, "fwd", stats=tr0))
             f_out, st0 = bnlin_forward(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, nxt_f[:, :C], want_y=need_f,
                                        elu_stats=pf)
         _attach_part(nxt_f, pf)
@@ -106,7 +112,7 @@ class _DiracBlock(torch.autograd.Function):
             # face features are not written (321 MB per block at the ARAP batch).  What is returned in their place is a
             # zero-stride NaN view, so that any other use of it is loud instead of silently wrong.
             f_out = torch.full((1, 1), float("nan"), dtype=torch.float32, device=v.device).expand(rf, C)
-        _launch(opDiA, nxt_f[:, :C], cat1[:, C:], 4, "fwd")
+        _attach_hi(cat1, _launch(opDiA, nxt_f[:, :C], cat1[:, C:], 4, "fwd", stats=tr1))
         nxt_v = _new_cat(rv, C, v.device)
         pv = _new_part(rv, C, v.device)
         v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C], elu_stats=pv)

@@ -399,10 +399,14 @@ __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_bsr4_lds_epi(const int
 // of the BSR4 form contribute fma(0, x, acc) = acc), so results stay bit-identical for finite X.
 // Work decomposition, LDS staging (one 1 KiB DMA instruction per 64 blocks) and epilogue as spmm_bsr4_lds.
 // ------------------------------------------------------------------------------------------------
-template <int N, int XG, int YG, bool EPI>
+// STATS (N = 32, YG = 4, i.e. the (rows/4, 128) view of a 128-channel tensor): the workgroup also leaves the column sums and
+// sums of squares of its 32 output rows — per channel c = 32·(component) + column — in stats_part[blockIdx.x][2][128] (fp32
+// over the 32 rows; added up in fp64 by sn_spmm_stats_reduce): the BatchNorm statistics of the propagated half of a stage's
+// concat buffer, so that no statistics pass has to read it back.
+template <int N, int XG, int YG, bool EPI, bool STATS = false>
 __device__ __forceinline__ void spmm_q3_lds_body(const int *__restrict__ b_rowptr, const f4 *__restrict__ q_blk, int Mb,
                                                  const float *__restrict__ X, int64_t ldx, float *__restrict__ Y,
-                                                 int64_t ldy, int nchunks, SpmmEpi epi) {
+                                                 int64_t ldy, int nchunks, SpmmEpi epi, float *__restrict__ stats_part = nullptr) {
   constexpr int LPR = N / 4;          // lanes per block row
   constexpr int RPW = 64 / LPR;       // block rows per wave pass
   constexpr int WAVES = kWG / 64;
@@ -417,13 +421,15 @@ __device__ __forceinline__ void spmm_q3_lds_body(const int *__restrict__ b_rowpt
   const float *xb = X + sub * 4;
   f4 *sv = s_blk[wave];
   const int r0 = (my_chunk(nchunks) * WAVES + wave) * RPW;    // first block row of this wave
-  if (r0 >= Mb) return;                                       // wave-uniform
+  if constexpr (!STATS) {
+    if (r0 >= Mb) return;                                     // wave-uniform
+  }
   const int br = r0 + grp;
   const int brc = br < Mb ? br : Mb;
   const int kb = b_rowptr[brc];
   const int ke = b_rowptr[brc + 1 <= Mb ? brc + 1 : Mb];
   const int k0 = __builtin_amdgcn_readfirstlane(kb);
-  const int k1 = __builtin_amdgcn_readlane(ke, 63);
+  const int k1 = (STATS && r0 >= Mb) ? k0 : __builtin_amdgcn_readlane(ke, 63);   // (a wave past the end has no blocks)
   f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   for (int t0 = k0; t0 < k1; t0 += TILE) {
     const int nt = (k1 - t0) < TILE ? (k1 - t0) : TILE;
@@ -470,6 +476,58 @@ __device__ __forceinline__ void spmm_q3_lds_body(const int *__restrict__ b_rowpt
     st4_stream(yp + 2 * ys, acc2);
     st4_stream(yp + 3 * ys, acc3);
   }
+  if constexpr (STATS) {
+    static_assert(N == 32 && YG == 4 && !EPI, "statistics: 128-channel rows in the group-4 layout");
+    // wave-private transposition: lane (grp, sub) writes its 16 channel values of block row grp (row stride 160 floats: the
+    // two block rows of a 16-lane group land on disjoint banks), lane l then sums channels 2l, 2l+1 over the 8 block rows
+    constexpr int ST = 160;
+    __shared__ float s_st[WAVES][RPW * ST];
+    __shared__ float s_wv[WAVES][256];
+    float *st = s_st[wave];
+    const bool live = br < Mb;
+    const f4 z = {0.f, 0.f, 0.f, 0.f};
+    f4 *row = reinterpret_cast<f4 *>(st + grp * ST + sub * 4);
+    row[0] = live ? acc0 : z;
+    row[8] = live ? acc1 : z;
+    row[16] = live ? acc2 : z;
+    row[24] = live ? acc3 : z;
+    __builtin_amdgcn_wave_barrier();            // (same-wave LDS operations complete in order)
+    float sa = 0.f, sb = 0.f, qa = 0.f, qb = 0.f;
+#pragma unroll
+    for (int g = 0; g < RPW; ++g) {
+      const float2 v = *reinterpret_cast<const float2 *>(st + g * ST + 2 * lane);
+      sa += v.x; sb += v.y;
+      qa = __builtin_fmaf(v.x, v.x, qa); qb = __builtin_fmaf(v.y, v.y, qb);
+    }
+    s_wv[wave][2 * lane] = sa; s_wv[wave][2 * lane + 1] = sb;
+    s_wv[wave][128 + 2 * lane] = qa; s_wv[wave][128 + 2 * lane + 1] = qb;
+    __syncthreads();
+    const int t = threadIdx.x;                  // 256 threads = [sums | squares] x 128 channels; waves added in order
+    stats_part[(int64_t)blockIdx.x * 256 + t] = (s_wv[0][t] + s_wv[1][t]) + (s_wv[2][t] + s_wv[3][t]);
+  }
+}
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_q3_lds_stats(const int *__restrict__ b_rowptr,
+                                                                       const f4 *__restrict__ q_blk, int Mb,
+                                                                       const float *__restrict__ X, int64_t ldx,
+                                                                       float *__restrict__ Y, int64_t ldy, int nchunks,
+                                                                       float *__restrict__ stats_part) {
+  spmm_q3_lds_body<N, XG, YG, false, true>(b_rowptr, q_blk, Mb, X, ldx, Y, ldy, nchunks, SpmmEpi{nullptr, 0, nullptr, 0},
+                                           stats_part);
+}
+// stage 1 of the reduction of those partials: workgroup b adds rows b, b + gridDim.x, ... (fixed order) in fp64
+__global__ __launch_bounds__(kWG) void spmm_stats_reduce_k(const float *__restrict__ part, int64_t n,
+                                                           double *__restrict__ out /* [gridDim.x][256] */) {
+  double t = 0.0;
+  int64_t r = blockIdx.x;
+  for (; r + 3 * (int64_t)gridDim.x < n; r += 4 * (int64_t)gridDim.x) {       // four loads in flight, added in row order
+    const float a = part[r * 256 + threadIdx.x], b = part[(r + gridDim.x) * 256 + threadIdx.x],
+                c = part[(r + 2 * (int64_t)gridDim.x) * 256 + threadIdx.x],
+                d = part[(r + 3 * (int64_t)gridDim.x) * 256 + threadIdx.x];
+    t += (double)a; t += (double)b; t += (double)c; t += (double)d;
+  }
+  for (; r < n; r += gridDim.x) t += (double)part[r * 256 + threadIdx.x];
+  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = t;
 }
 template <int N, int XG, int YG>
 __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_q3_lds(const int *__restrict__ b_rowptr, const f4 *__restrict__ q_blk,
@@ -1099,9 +1157,11 @@ int sn_spmm_bsr4_elubwd_f32(const int32_t *b_rowptr, const int32_t *b_colind, co
                           SpmmEpi{E, lde, G, ldg}, stream);
 }
 
+constexpr int kSpmmStatsBlocks = 128;        // partial rows after stage 1 of the statistics reduction
+
 static int spmm_q3_launch(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks, const float *X,
                           int64_t ldx, int32_t x_group, int32_t N, float *Y, int64_t ldy, int32_t y_group, SpmmEpi epi,
-                          void *stream) {
+                          void *stream, float *stats_part = nullptr, double *stats_out = nullptr) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (Mb < 0 || Kb < 0 || nblocks < 0 || N < 1) return SN_E_SHAPE;
   if (!fits_i32(4 * Mb + 1) || !fits_i32(4 * Kb) || !fits_i32(nblocks)) return SN_E_RANGE;
@@ -1123,11 +1183,19 @@ static int spmm_q3_launch(const int32_t *b_rowptr, const float *q_blk, int64_t M
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipEvent_t t_start, t_stop;
-  timing_slot(1 | 8 | (epi.e ? 2 : 0) | (epi.g ? 4 : 0), 4 * Mb, 4 * Kb, nblocks, N, &t_start, &t_stop);
+  timing_slot(1 | 8 | (epi.e ? 2 : 0) | (epi.g ? 4 : 0) | (stats_part ? 16 : 0), 4 * Mb, 4 * Kb, nblocks, N, &t_start, &t_stop);
   const int rpb = kWG / (N / 4);
   const int64_t nchunks = (Mb + rpb - 1) / rpb;
   const unsigned grid = chunk_grid(nchunks);
   const f4 *q = reinterpret_cast<const f4 *>(q_blk);
+  if (stats_part) {
+    if (epi.e || N != 32 || y_group != 4) return SN_E_UNSUPPORTED;
+    if (!stats_out) return SN_E_NULL;
+    if (x_group == 4) SN_KLAUNCH((spmm_q3_lds_stats<32, 4, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+    else SN_KLAUNCH((spmm_q3_lds_stats<32, 1, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+    hipLaunchKernelGGL(spmm_stats_reduce_k, dim3(kSpmmStatsBlocks), dim3(kWG), 0, s, stats_part, (int64_t)grid, stats_out);
+    return launch_status();
+  }
   if (epi.e)
     SN_DISPATCH_N(spmm_q3_lds_epi, N, x_group, y_group, grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, epi);
   else
@@ -1140,6 +1208,23 @@ int sn_spmm_q3_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int6
   return spmm_q3_launch(b_rowptr, q_blk, Mb, Kb, nblocks, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{nullptr, 0, nullptr, 0},
                         stream);
 }
+
+size_t sn_spmm_q3_stats_workspace_bytes(int64_t Mb) {
+  if (Mb < 1) return 0;
+  const int64_t nchunks = (Mb + 31) / 32;                 // N = 32: 32 block rows per workgroup
+  return (size_t)chunk_grid(nchunks) * 256 * sizeof(float);
+}
+
+int sn_spmm_q3_stats_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks, const float *X,
+                         int64_t ldx, int32_t x_group, int32_t N, float *Y, int64_t ldy, int32_t y_group, double *stats_part,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+  if (!stats_part || !workspace) return SN_E_NULL;
+  if (workspace_bytes < sn_spmm_q3_stats_workspace_bytes(Mb)) return SN_E_WORKSPACE;
+  return spmm_q3_launch(b_rowptr, q_blk, Mb, Kb, nblocks, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{nullptr, 0, nullptr, 0},
+                        stream, static_cast<float *>(workspace), stats_part);
+}
+
+int32_t sn_spmm_q3_stats_blocks(void) { return kSpmmStatsBlocks; }
 
 int sn_spmm_q3_elubwd_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks,
                           const float *X, int64_t ldx, int32_t x_group, int32_t N, const float *E, int64_t lde,

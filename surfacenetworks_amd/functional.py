@@ -68,7 +68,7 @@ class SpmmTimer:
 
     def results(self):
         """[(tag, M, K, nnz, N, milliseconds)] for every launch recorded while the timer was active; the tag ends in
-        /csr, /bsr4 or /q3, then +e (fused ELU-backward epilogue: E read) and +g (G read too)."""
+        /csr, /bsr4 or /q3, then +e (fused ELU-backward epilogue: E read), +g (G read too), +s (column statistics left)."""
         import ctypes
         import numpy as np
 
@@ -85,7 +85,8 @@ class SpmmTimer:
         for i, (tag, op) in enumerate(self.tags):
             kind, M, K, _, N = meta[i]
             nnz = op if isinstance(op, int) else op.nnz
-            fmt = ("/q3" if kind & 8 else "/bsr4" if kind & 1 else "/csr") + ("+e" if kind & 2 else "") + ("+g" if kind & 4 else "")
+            fmt = ("/q3" if kind & 8 else "/bsr4" if kind & 1 else "/csr") + ("+e" if kind & 2 else "") + \
+                ("+g" if kind & 4 else "") + ("+s" if kind & 16 else "")
             out.append((tag + fmt, int(M), int(K), int(nnz), int(N), float(ms[i])))
         return out
 
@@ -97,9 +98,11 @@ def _ctypes_i64_ref():
     return ctypes.addressof(_ctypes_i64_ref.slot)
 
 
-def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, tag: str = "", elubwd=None) -> None:
+def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, tag: str = "", elubwd=None, stats: bool = False):
     """y <- op·x with the best resident format of `op`.  elubwd = (e, g): y <- (op·x) * elu'(e) + g fused into the store
-    (the backward of an ELU-activated propagation stage; g may be None)."""
+    (the backward of an ELU-activated propagation stage; g may be None).  stats=True: where the kernel offers it (packed
+    Dirac operators, 128 channels) the launch also leaves the column statistics of y and their partials are returned
+    (kernels.spmm_q3_stats), else None."""
     M, K = op.shape
     timer = SpmmTimer.active
     if timer is not None:
@@ -109,8 +112,10 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
     if group == 4 and _DIRAC_FORMAT == "q3":
         q = op.q3()
         if q is not None:
+            if stats and e is None and kernels.spmm_q3_stats_supported(y.shape[1] // group, group):
+                return kernels.spmm_q3_stats(q[0], q[1], M // 4, K // 4, x, y, group)
             kernels.spmm_q3(q[0], q[1], M // 4, K // 4, x, y, group, e, g)
-            return
+            return None
     b = op.bsr4() if (_DIRAC_FORMAT != "csr" and group == 4) else None
     if b is not None:
         if elubwd is None:
@@ -121,6 +126,7 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
         kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x, y, group)
     else:
         kernels.spmm_csr_elubwd(op.rowptr, op.colind, op.vals, M, K, x, e, g, y, group)
+    return None
 
 
 def _rows2d(x: torch.Tensor) -> torch.Tensor:
@@ -379,15 +385,15 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     optional residual add and ELU copy in the GEMM epilogue.  Returns (y, state) with `state` for bnlin_backward."""
     # x may carry `_sn_part`: the column statistics of its first half, left by the GEMM that wrote it (blocks.py) — the
     # statistics pass then reads only the propagated half
-    part = getattr(x, "_sn_part", None)
+    part, part_hi = getattr(x, "_sn_part", None), getattr(x, "_sn_part_hi", None)   # (hi: left by the SpMM that wrote P·e)
     x = _rows2d(x)
     rows = x.shape[0]
     if not training:
         stats = None
     elif pre_stats is not None:                 # (2, C) float64 statistics of x supplied by its producer
         stats = pre_stats
-    elif part is not None and x.shape[1] == 256:
-        stats = kernels.colstats_halves(x, part)
+    elif (part is not None or part_hi is not None) and x.shape[1] == 256:
+        stats = kernels.colstats_halves(x, part, part_hi)
     else:
         stats = kernels.colstats(x)
     rows_g = rows
@@ -462,13 +468,17 @@ def bnlin_forward_zero_first(p, gamma, beta, W, b, running_mean, running_var, tr
     features are all zero, src/as_rigid_as_possible/models.py:138).  The statistics of the zero columns are (0, 0); folded
     into the Linear they only contribute the constant W[:, :C]·beta[:C] to the bias, so the product runs over the C real
     columns: same y, same running statistics, half the GEMM, no zero buffer, no ELU / statistics pass over it."""
+    part_hi = getattr(p, "_sn_part_hi", None)       # statistics of p left by the SpMM that wrote it
     p = _rows2d(p)
     rows, C = p.shape
     stats = None
     rows_g = rows
     if training:
         stats = torch.zeros((2, 2 * C), dtype=torch.float64, device=p.device)
-        kernels.colstats_into(p, stats, C)
+        if part_hi is not None and C == 128:
+            kernels.colstats_merge_into(part_hi, stats, C)
+        else:
+            kernels.colstats_into(p, stats, C)
         stats, rows_g = _sync_stats(stats, rows)
     mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
                                                  running_var, _take_counter(running_mean))

@@ -12,11 +12,11 @@ import torch
 from . import _lib
 
 __all__ = [
-    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
+    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
 ]
 
 
@@ -108,6 +108,28 @@ def spmm_q3(b_rowptr, q_blk, Mb: int, Kb: int, x, y, group: int = 1, e=None, g=N
         ldg = _check_dense(g, 4 * Mb, group, N, "g") if g is not None else 0
         _lib.call("sn_spmm_q3_elubwd_f32", _p(b_rowptr), _p(q_blk), Mb, Kb, nblk, _p(x), ldx, group, N, _p(e), lde, _p(g), ldg,
                   _p(y), ldy, group, _stream())
+
+
+def spmm_q3_stats_supported(N: int, group: int) -> bool:
+    return N == 32 and group == 4
+
+
+def spmm_q3_stats(b_rowptr, q_blk, Mb: int, Kb: int, x, y, group: int = 4):
+    """y <- A·x as spmm_q3, and the partial column statistics of y viewed as (Mb, 128): returns the (blocks, 2, 128) float64
+    partials that colstats_halves / colstats_from_part-style merges combine (sn_spmm_q3_stats_f32)."""
+    _dev(b_rowptr, q_blk, x, y)
+    N = y.shape[1] // group
+    if not spmm_q3_stats_supported(N, group):
+        raise ValueError("spmm_q3_stats: 128-channel operands in the group-4 layout only")
+    ldx = _check_dense(x, 4 * Kb, group, N, "x")
+    ldy = _check_dense(y, 4 * Mb, group, N, "y")
+    lib = _lib.load()
+    part = torch.empty((int(lib.sn_spmm_q3_stats_blocks()), 2, 128), dtype=torch.float64, device=y.device)
+    ws_bytes = int(lib.sn_spmm_q3_stats_workspace_bytes(Mb))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=y.device)
+    _lib.call("sn_spmm_q3_stats_f32", _p(b_rowptr), _p(q_blk), Mb, Kb, int(q_blk.shape[0]), _p(x), ldx, group, N, _p(y), ldy,
+              group, _p(part), _p(ws), ws_bytes, _stream())
+    return part
 
 
 def bsr4_to_q3(b_colind, b_vals):
@@ -401,6 +423,17 @@ def colstats_from_part(part, rows: int):
     return out
 
 
+def colstats_merge_into(part, out, offset: int) -> None:
+    """Combine (nblk, 2, C) float64 partials into columns offset .. offset+C of the (2, width) statistics tensor `out`
+    (sn_colstats_merge_f64)."""
+    _dev(part, out)
+    C = part.shape[2]
+    if part.dim() != 3 or part.shape[1] != 2 or part.dtype != torch.float64 or out.dtype != torch.float64 or \
+            not out.is_contiguous() or offset + C > out.shape[1]:
+        raise ValueError("colstats_merge_into: (nblk, 2, C) float64 partials into a contiguous (2, width >= offset + C) tensor")
+    _lib.call("sn_colstats_merge_f64", _p(part), int(part.shape[0]), C, _p(out), out.shape[1], offset, _stream())
+
+
 def colstats_into(x, out, offset: int):
     """Column sums / sums of squares of the 2-D view x written into columns offset .. offset+C of the (2, width) float64
     statistics tensor `out` (sn_colstats_into_f32)."""
@@ -414,24 +447,30 @@ def colstats_into(x, out, offset: int):
     return out
 
 
-def colstats_halves(x, part):
+def colstats_halves(x, part, part_hi=None):
     """(2, 2C) float64 statistics of a stage's concat buffer x = [e | P·e] (rows, 2C), C = 128: the first half from the
-    partials `part` the GEMM that wrote e left behind (sn_colstats_merge_f64), the second half from one pass over
-    x[:, C:] only (sn_colstats_into_f32)."""
-    _dev(x, part)
+    partials `part` the GEMM that wrote e left behind (sn_colstats_merge_f64); the second half from the partials `part_hi`
+    of the SpMM that wrote P·e (spmm_q3_stats) or, without them, from one pass over x[:, C:] only (sn_colstats_into_f32).
+    part=None: the first half by a pass over x[:, :C]."""
+    _dev(x, part, part_hi)
     rows, C2 = x.shape
     C = C2 // 2
-    if C != 128 or part.dim() != 3 or part.shape[1:] != (2, 128) or part.dtype != torch.float64:
-        raise ValueError("colstats_halves: expected a (rows, 256) buffer and (nblk, 2, 128) float64 partials")
-    nblk = int(_lib.load().sn_linear_fwd_stats_blocks(rows))
-    if part.shape[0] < nblk:
-        raise ValueError("colstats_halves: partial buffer smaller than the producing launch's grid")
+    for p_ in (part, part_hi):
+        if p_ is not None and (C != 128 or p_.dim() != 3 or p_.shape[1:] != (2, 128) or p_.dtype != torch.float64):
+            raise ValueError("colstats_halves: expected a (rows, 256) buffer and (nblk, 2, 128) float64 partials")
+    lib = _lib.load()
     out = torch.empty((2, C2), dtype=torch.float64, device=x.device)
-    _lib.call("sn_colstats_merge_f64", _p(part), nblk, C, _p(out), C2, 0, _stream())
-    hi = x[:, C:]
-    ws_bytes = int(_lib.load().sn_colstats_workspace_bytes(rows, C))
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-    _lib.call("sn_colstats_into_f32", _p(hi), _ld(hi), rows, C, _p(out), C2, C, _p(ws), ws_bytes, _stream())
+    for half, p_, nblk in ((0, part, int(lib.sn_linear_fwd_stats_blocks(rows))), (1, part_hi, None)):
+        if p_ is not None:
+            nb = nblk if nblk is not None else int(p_.shape[0])
+            if p_.shape[0] < nb:
+                raise ValueError("colstats_halves: partial buffer smaller than the producing launch's grid")
+            _lib.call("sn_colstats_merge_f64", _p(p_), nb, C, _p(out), C2, half * C, _stream())
+        else:
+            xs = x[:, half * C:(half + 1) * C]
+            ws_bytes = int(lib.sn_colstats_workspace_bytes(rows, C))
+            ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+            _lib.call("sn_colstats_into_f32", _p(xs), _ld(xs), rows, C, _p(out), C2, half * C, _p(ws), ws_bytes, _stream())
     return out
 
 

@@ -256,18 +256,34 @@ def colstats_from_part(part, rows):
     return part.sum(0)
 
 
+def colstats_merge_into(part, out, offset):
+    out[:, offset:offset + part.shape[2]] = part.sum(0)
+
+
 def colstats_into(x, out, offset):
     C = x.shape[1]
     out[:, offset:offset + C] = colstats(x)
     return out
 
 
-def colstats_halves(x, part):
+def colstats_halves(x, part, part_hi=None):
     C = x.shape[1] // 2
     out = torch.empty((2, 2 * C), dtype=torch.float64)
-    out[:, :C] = part.sum(0)
-    out[:, C:] = colstats(x[:, C:])
+    out[:, :C] = part.sum(0) if part is not None else colstats(x[:, :C])
+    out[:, C:] = part_hi.sum(0) if part_hi is not None else colstats(x[:, C:])
     return out
+
+
+def spmm_q3_stats_supported(N, group):
+    return N == 32 and group == 4
+
+
+def spmm_q3_stats(b_rowptr, q_blk, Mb, Kb, x, y, group=4):
+    spmm_q3(b_rowptr, q_blk, Mb, Kb, x, y, group)
+    part = torch.zeros((1, 2, 128), dtype=torch.float64)
+    part[0, 0] = y.double().sum(0)
+    part[0, 1] = (y.double() ** 2).sum(0)
+    return part
 
 
 def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y=True, elu_stats=None):

@@ -409,3 +409,36 @@ def test_pool_assembles_quaternion_packed_batches():
     assert (abs(got - want)).max() == 0
     gt = op.t().to_scipy()
     assert (abs(gt - want.T)).max() == 0
+
+
+@pytest.mark.parametrize("kind", ["cloth", "cloth_perm", "torus", "delaunay"])
+@pytest.mark.parametrize("which", ["Di", "DiA"])
+def test_spmm_leaves_the_column_statistics_of_its_output(kind, which):
+    """sn_spmm_q3_stats_f32: Y bit-identical to sn_spmm_q3_f32 (hence to the CSR oracle), and the partials it leaves add up
+    to the column sums / sums of squares of Y — contiguous and into one half of a concat buffer, ragged tails included."""
+    _, _, ops = mesh_fixture(kind)
+    A = ops[which]
+    A.sort_indices()
+    M, K = A.shape
+    N, C = 32, 128
+    rng = np.random.default_rng(7)
+    xcat = (rng.standard_normal((K // 4, 2 * C)) * 2 + 0.5).astype(np.float32)
+    want = c_oracle.spmm_csr(A.indptr, A.indices, A.data, np.ascontiguousarray(xcat[:, :C]).ravel(), N).reshape(M // 4, C)
+    rp, ci, va = csr_dev(A)
+    b = kernels.csr_to_bsr4(rp, ci, va, M, K)
+    q, _ = kernels.bsr4_to_q3(b[1], b[2])
+    for strided in (False, True):
+        ybuf = torch.full((M // 4, 2 * C), float("nan"), device=DEV)
+        y = ybuf[:, C:] if strided else torch.empty((M // 4, C), device=DEV)
+        part = kernels.spmm_q3_stats(b[0], q, M // 4, K // 4, dev(xcat)[:, :C], y, 4)
+        assert np.array_equal(y.cpu().numpy(), want)
+        got = part.sum(0).cpu().numpy()
+        w64 = want.astype(np.float64)
+        ref = np.stack([w64.sum(0), (w64 * w64).sum(0)])
+        scale = np.stack([np.abs(w64).sum(0), (w64 * w64).sum(0)]) + 1e-30
+        assert (np.abs(got - ref) / scale).max() < 1e-6            # fp32 over 32 rows, fp64 above
+        if strided:
+            assert torch.isnan(ybuf[:, :C]).all()
+            st = torch.full((2, 2 * C), float("nan"), dtype=torch.float64, device=DEV)
+            kernels.colstats_merge_into(part, st, C)
+            assert np.allclose(st[:, C:].cpu().numpy(), got, rtol=1e-14) and torch.isnan(st[:, :C]).all()
