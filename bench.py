@@ -202,7 +202,7 @@ def main():
     by_kernel = {}
     for tag, M, K, nnz, N, ms in recs:
         kname = ("spmm_q3_lds" if "/q3" in tag else "spmm_bsr4_lds" if "/bsr4" in tag else "spmm_csr_lds") + \
-                ("_epi" if "+e" in tag else "") + f"<N={N}>"
+                ("_epi" if "+e" in tag else "_stats" if "+s" in tag else "") + f"<N={N}>"
         by_kernel.setdefault(kname, []).append((tag, M, K, nnz, N, ms))
     dom_name = max(by_kernel, key=lambda k: sum(r[5] for r in by_kernel[k]))
     dom = by_kernel[dom_name]
