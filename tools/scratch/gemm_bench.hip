@@ -26,8 +26,9 @@ int main(int argc, char **argv) {
     float ms; hipEventElapsedTime(&ms, s, t);
     printf("%-14s %8.1f us\n", name, ms / reps * 1e3);
   };
-  time("fwd", [&] { sn_linear_fwd_f32(x, 256, W, 256, b, nullptr, 0, y, 128, nullptr, 0, rows, 256, 128, nullptr); });
-  time("fwd+res+elu", [&] { sn_linear_fwd_f32(x, 256, W, 256, b, res, 128, y, 128, e, 256, rows, 256, 128, nullptr); });
+  time("fwd", [&] { sn_linear_fwd_f32(x, 256, W, 256, b, nullptr, 0, y, 128, nullptr, 0, rows, 256, 128, nullptr, nullptr); });
+  time("fwd elu-only", [&] { sn_linear_fwd_f32(x, 256, W, 256, b, nullptr, 0, nullptr, 128, e, 256, rows, 256, 128, nullptr, nullptr); });
+  time("fwd+res+elu", [&] { sn_linear_fwd_f32(x, 256, W, 256, b, res, 128, y, 128, e, 256, rows, 256, 128, nullptr, nullptr); });
   time("dgrad+affine", [&] { sn_linear_dgrad_f32(dy, 128, W, 256, x, 256, mu, B, C, dx, 256, rows, 128, 256, nullptr); });
   return 0;
 }
