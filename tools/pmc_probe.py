@@ -42,6 +42,9 @@ for name in ("Di", "DiA"):
             kernels.spmm_q3(qq[0], qq[1], M // 4, K // 4, x, y, 4)
         for _ in range(10):
             kernels.spmm_q3(qq[0], qq[1], M // 4, K // 4, x, y, 4, e, g)
+        if tag == "fwd":                             # forward launches of the blocks: + the statistics partials (1 KiB / 32 rows)
+            for _ in range(10):
+                kernels.spmm_q3_stats(qq[0], qq[1], M // 4, K // 4, x, y, 4)
         print(f"{name} {tag} q3: expected reads {qq[1].shape[0] * 16 + (M // 4 + 1) * 4 + K * 128} B (+ {2 * M * 128} B with E and G), writes {M * 128} B")
         rd = bb[1].numel() * 68 + (M // 4 + 1) * 4 + K * 32 * 4
         print(f"{name} {tag}: expected reads {rd} B (operator {bb[1].numel() * 68 + (M // 4 + 1) * 4} + X {K * 128}), writes {M * 128} B; "
