@@ -1,6 +1,10 @@
 """bench.py — headline benchmark of the Surface-Network hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: one rank per GPU.  Either the caller starts the ranks (python -m torch.distributed.run --nproc-per-node N bench.py
+--gpus N ...: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or — when WORLD_SIZE is not set — bench.py
+starts them itself through the same launcher on 127.0.0.1; rank 0 prints the one JSON line either way.
 
 Workload (BASELINE.json configs[2], the config the metric "meshes/sec fwd+bwd, Dirac temporal-predict" is quoted on):
 as_rigid_as_possible temporal prediction, Dirac model (15 blocks @128 ch, 1 018 872 params), 64 grid-cloth meshes of
@@ -13,13 +17,19 @@ The JSON line also carries
                HIP events that carry the kernel's own start/stop (hipExtLaunchKernelGGL) on the launch stream; achieved = ALGORITHMIC CSR bytes (SURVEY.md §8d:
                nnz*8 + (M+1)*4 + K*N*4 + M*N*4) / average launch duration; peak = 8 TB/s HBM3E.
   cpu_baseline the reference's own CPU torch.sparse path (oracle restatement = "port") timed on this box's host cores
-               on a bounded sample of the same workload (rank 0, N=1 only).
+               (all of them, plus a 1-thread figure) on a bounded sample of the same workload (rank 0, N=1 only).
+  secondary    BASELINE.json configs[4] (the config north_star's ">= 60 % of the HBM roofline on the Dirac SpMM at 128
+               channels" is quoted on): 128 meshes per GPU with 1 000 .. 20 000 vertices, Di / Di^T / DiA / DiA^T at N = 32,
+               as a PACKED (unpadded, ragged) batch and — for comparison — padded to the batch maximum as the reference
+               batches; algorithmic bytes always from the real sum of V_i, F_i.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -41,15 +51,11 @@ def alg_bytes(M, K, nnz, N, tag=""):
     return nnz * 8 + (M + 1) * 4 + K * N * 4 + M * N * 4 * (1 + extra)
 
 
-def cpu_baseline(sample_meshes: int, seed: int):
-    """The reference path (torch.mm(sparse_coo, dense) + autograd, oracle/ref_blocks.py) on the host cores:
-    one fwd+bwd+Adam step of the same model on `sample_meshes` meshes of the same shape, incl. the reference's
-    per-step host batching (sparse_diag_cat + coalesce)."""
+def _cpu_leg(sample_meshes: int, seed: int, threads: int, budget_s: float, max_reps: int):
+    """One fwd+bwd+Adam step loop of the reference path on `sample_meshes` meshes with `threads` threads: meshes/s."""
     from oracle import ref_blocks as OB          # checker/baseline only — never the measured product path
     from surfacenetworks_amd import mesh_ops
 
-    cores = os.cpu_count() or 1
-    threads = min(cores, 64)
     torch.set_num_threads(threads)
     rng = np.random.default_rng(seed)
     per_mesh = []
@@ -76,14 +82,119 @@ def cpu_baseline(sample_meshes: int, seed: int):
     step()                                   # warm-up (allocator, thread pool)
     t0 = time.perf_counter()
     reps = 0
-    while reps < 2 or (time.perf_counter() - t0 < 8.0 and reps < 20):
+    while reps < 1 or (time.perf_counter() - t0 < budget_s and reps < max_reps):
         step()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
-    return {"value": sample_meshes / dt, "unit": "meshes/s", "cores": threads, "kind": "port",
-            "sample": f"{reps} steps of fwd+bwd+Adam incl. per-step sparse_diag_cat on {sample_meshes} meshes {GRID[0]}x{GRID[1]} "
-                      f"(same model/shape as the GPU workload, 1/{MESHES_PER_GPU // sample_meshes} of the per-GPU batch), "
-                      f"torch {torch.__version__} CPU torch.sparse path, {threads} threads of {cores} logical CPUs"}
+    return sample_meshes / dt, reps
+
+
+def cpu_baseline(seed: int):
+    """The reference path (torch.mm(sparse_coo, dense) + autograd, oracle/ref_blocks.py) on the host cores, as SURVEY.md
+    §8d asks: torch.set_num_threads(os.cpu_count()) on a bounded sample of the same workload (same model, same mesh shape,
+    incl. the reference's per-step host batching sparse_diag_cat + coalesce), plus the 1-thread figure."""
+    cores = os.cpu_count() or 1
+    v_all, reps_all = _cpu_leg(4, seed, cores, 9.0, 20)
+    v_one, reps_one = _cpu_leg(1, seed, 1, 6.0, 4)
+    torch.set_num_threads(cores)
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "unknown")
+    except OSError:
+        cpu = "unknown"
+    return {"value": v_all, "unit": "meshes/s", "cores": cores, "kind": "port",
+            "sample": f"{reps_all} steps of fwd+bwd+Adam incl. per-step sparse_diag_cat on 4 meshes {GRID[0]}x{GRID[1]} "
+                      f"(same model/shape as the GPU workload, 1/{MESHES_PER_GPU // 4} of the per-GPU batch), "
+                      f"torch {torch.__version__} CPU torch.sparse path, torch.set_num_threads({cores}) = all logical CPUs of {cpu}",
+            "one_thread": {"value": v_one, "unit": "meshes/s", "cores": 1,
+                           "sample": f"{reps_one} step(s) of the same loop on 1 mesh {GRID[0]}x{GRID[1]}, torch.set_num_threads(1)"}}
+
+
+# ---- secondary: BASELINE configs[4], the Dirac SpMM roofline batch ------------------------------------------------------
+C5_MESHES_PER_GPU = 128
+C5_VMIN, C5_VMAX = 1000, 20000
+
+
+def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10):
+    """Config 5: 128 grid-cloth meshes per GPU, V_i uniform in [1000, 20000] (seed 5 + rank), Dirac
+    operators, N = 32 (C = 128).  The four products Di, Di^T, DiA, DiA^T are launched back to back (>= 50 timed launches
+    after >= 10 warm-ups, the kernel's own start/stop in HIP events on the launch stream) on
+      packed  the ragged batch without padding (OperatorPool.assemble(sel): prefix-sum offsets, operands (sum V_i, C));
+      padded  every mesh padded to the batch maximum as the reference's sparse_diag_cat does (utils_pt.py:41-53).
+    Algorithmic bytes = nnz*8 + (M+1)*4 + K*N*4 + M*N*4 with M, K from the REAL sum of 4*F_i / 4*V_i in both cases, so the
+    padded variant gets no credit for the zeros it writes."""
+    from surfacenetworks_amd import functional as snF
+    from surfacenetworks_amd import mesh_ops
+    from surfacenetworks_amd.operators import OperatorPool
+
+    rng = np.random.default_rng(5 + rank)
+    vs = rng.integers(C5_VMIN, C5_VMAX + 1, size=C5_MESHES_PER_GPU)
+    Dis, DiAs, sumV, sumF = [], [], 0, 0
+    for v in vs:
+        n = int(np.sqrt(v))
+        V, F_ = mesh_ops.grid_cloth(n, int(v) // n, rng)
+        Di, DiA = mesh_ops.dirac(V, F_)
+        Dis.append(Di.astype(np.float32))
+        DiAs.append(DiA.astype(np.float32))
+        sumV += V.shape[0]
+        sumF += F_.shape[0]
+    pools = {"Di": OperatorPool(Dis, device, want_bsr4=True), "DiA": OperatorPool(DiAs, device, want_bsr4=True)}
+    sel = np.arange(C5_MESHES_PER_GPU)
+    N = 32
+    out = {"workload": f"BASELINE configs[4]: {C5_MESHES_PER_GPU} grid-cloth meshes per GPU, V in [{C5_VMIN}, {C5_VMAX}] "
+                       f"(sum V = {sumV}, sum F = {sumF}), Dirac operators, C = 128 (N = {N}), quaternion-packed records",
+           "timing": f"{iters} back-to-back launches after {warm} warm-ups; hipExtLaunchKernelGGL start/stop events per launch",
+           "peak_GBps": HBM_PEAK / 1e9, "products": []}
+    g = torch.Generator(device=device).manual_seed(7)
+    for layout in ("packed", "padded"):
+        for name in ("Di", "DiA"):
+            pool = pools[name]
+            if layout == "packed":
+                op = pool.assemble(sel)
+            else:
+                op = pool.assemble(sel, int(pool.rows.max()), int(pool.cols.max()))
+            for prod, o in ((name, op), (name + "^T", op.t())):
+                M, K = o.shape
+                real_M = int((pool.rows if prod == name else pool.cols).sum())
+                real_K = int((pool.cols if prod == name else pool.rows).sum())
+                x = torch.randn(K // 4, 4 * N, device=device, generator=g)
+                y = torch.empty(M // 4, 4 * N, device=device)
+                for _ in range(warm):
+                    snF._launch(o, x, y, 4, "c5")
+                timer = snF.SpmmTimer()
+                with timer:
+                    for _ in range(iters):
+                        snF._launch(o, x, y, 4, "c5")
+                ms = np.array([r[5] for r in timer.results()])
+                ab = alg_bytes(real_M, real_K, o.nnz, N)
+                out["products"].append({
+                    "layout": layout, "product": prod, "M": M, "K": K, "real_M": real_M, "real_K": real_K, "nnz": o.nnz,
+                    "algorithmic_bytes": ab, "ms_median": float(np.median(ms)), "ms_min": float(ms.min()),
+                    "ms_mean": float(ms.mean()), "GBps": ab / (float(np.median(ms)) * 1e-3) / 1e9,
+                    "frac": ab / (float(np.median(ms)) * 1e-3) / HBM_PEAK})
+                del x, y
+            del op
+    packed = [p_ for p_ in out["products"] if p_["layout"] == "packed"]
+    out["frac_min_packed"] = min(p_["frac"] for p_ in packed)
+    out["GBps_mean_packed"] = float(np.mean([p_["GBps"] for p_ in packed]))
+    return out
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks here, through the same
+    launcher the contract names (python -m torch.distributed.run, rendezvous on 127.0.0.1).  With fewer visible GPUs than
+    ranks (a 1-GPU box) the ranks share devices and the collective backend falls back to gloo — a functional run of the
+    N > 1 path, flagged as such in the JSON line."""
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // max(args.gpus, 1))))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -104,9 +215,13 @@ def main():
                     help="pool: precomputed per-frame operators resident in HBM (default, = the reference's dataset); "
                          "device: Dirac operators rebuilt on the GPU from the frame coordinates every step")
     ap.add_argument("--backend", default=None, choices=[None, "nccl", "gloo"],
-                    help="default nccl (= RCCL); gloo only for functional tests of the N>1 path on a 1-GPU box")
+                    help="default nccl (= RCCL); gloo only for functional tests of the N>1 path on a 1-GPU box "
+                         "(chosen automatically when there are fewer visible GPUs than ranks)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config-5 SpMM roofline block")
     args = ap.parse_args()
     args.no_graph = not args.graph
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, sys.argv[1:]))
 
     import torch.distributed as dist
 
@@ -115,7 +230,9 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path in the product)")
-    rank, local_rank, world, device = dp.init_distributed(args.backend)
+    oversubscribed = int(os.environ.get("WORLD_SIZE", "1")) > torch.cuda.device_count()
+    backend = args.backend or ("gloo" if oversubscribed else None)      # RCCL cannot put two ranks on one device
+    rank, local_rank, world, device = dp.init_distributed(backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     snF.set_dirac_format(args.format)
@@ -248,6 +365,9 @@ def main():
         "config": {"workload": f"as_rigid_as_possible Dirac temporal prediction: {n_local} grid-cloth meshes {GRID[0]}x{GRID[1]} "
                                f"(V=5041,F=9800) per GPU, C=128, 15 layers, fwd+loss+bwd+allreduce+Adam",
                    "meshes_per_gpu": n_local, "global_batch": global_batch, "parallelism": f"dp{world} (mesh sharding, flat-bucket RCCL all-reduce)",
+                   "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                   "collective_backend": (dist.get_backend() if dist.is_initialized() else "none (single rank)"),
+                   "devices_visible": torch.cuda.device_count(), "ranks_share_devices": bool(oversubscribed),
                    "linear_layers": ("fp32 operands and fp32 accumulation; products formed on the bf16 matrix pipe from an exact "
                                      "3-piece bf16 split of every operand (6 partial products, error <= 2^-23 per term: fp32-accurate, "
                                      "tests/test_dense_gpu.py); SN_GEMM_VARIANT=0 selects the fp32-MFMA kernels"),
@@ -268,8 +388,18 @@ def main():
                           "frac": sum(alg_bytes(r[1], r[2], r[3], r[4], r[0]) for r in v) / (sum(r[5] for r in v) * 1e-3) / HBM_PEAK}
                          for k, v in by_kernel.items() if k != dom_name]},
     }
+    if not args.no_secondary:
+        # config 5: every rank runs its own replica of the microbench (no collective on this path: aggregate = sum)
+        del ds, model, opt, bucket, graphed
+        torch.cuda.empty_cache()
+        sec = c5_secondary(device, rank)
+        agg = torch.tensor([sum(p_["GBps"] for p_ in sec["products"] if p_["layout"] == "packed") / 4.0], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(agg)
+        sec["aggregate_GBps_all_ranks_packed_mean"] = float(agg.item())
+        out["secondary"] = sec
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(sample_meshes=4, seed=3)
+        out["cpu_baseline"] = cpu_baseline(seed=3)
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:

@@ -216,6 +216,23 @@ int sn_blockdiag_concat_i32(const int32_t *pool_rowptr, const int32_t *pool_coli
                             int32_t *out_rowptr, int32_t *out_colind, float *out_vals,
                             void *stream);
 
+/* Ragged (packed) form of the same assembly — what the reference cannot express: sparse_diag_cat pads every block to
+ * (size0, size1) = the batch maximum (src/utils/utils_pt.py:48-52; src/as_rigid_as_possible/main.py:172-185 computes the
+ * maxima), so half of a 1k..20k-vertex batch is padding.  Here mesh b owns the output rows [desc[b][4], desc[b+1][4])
+ * (the last mesh up to total_rows), the first desc[b][2] of which carry its entries, and its column indices are shifted by
+ * desc[b][5].  With both offsets = exclusive prefix sums of the meshes' own row / column counts the batch has no padding
+ * at all: the dense operands are the concatenation of the meshes' rows.  (desc[b][4] = b*size0, desc[b][5] = b*size1
+ * reproduces sn_blockdiag_concat_i32.)
+ *      desc[b] = { rowptr offset in the pool, entry offset in the pool, rows with entries,
+ *                  entry offset in the output, first output row, column shift }          (B x 6) int64
+ * desc[b][4] must be ascending with desc[0][4] = 0.  Output: out_rowptr[total_rows + 1], out_colind[total],
+ * out_vals[total * vals_per_entry]; total_cols only enters the int32 range check. */
+int sn_blockdiag_concat_ragged_i32(const int32_t *pool_rowptr, const int32_t *pool_colind, const float *pool_vals,
+                                   const int64_t *desc, int64_t B, int64_t total_rows, int64_t total_cols,
+                                   int64_t total, int32_t vals_per_entry,
+                                   int32_t *out_rowptr, int32_t *out_colind, float *out_vals,
+                                   void *stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused elementwise helpers of the residual blocks (each replaces separate ATen passes).
  *

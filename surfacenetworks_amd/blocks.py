@@ -12,7 +12,9 @@ the whole block removes what per-op autograd cannot:
 
 Activated hand-off: a block returns its outputs with the attribute `_sn_cat` = a fresh (rows, 2C) buffer whose first half
 already holds elu(output).  The next block takes (and removes) it instead of running its own ELU pass.  The attribute lives
-on one tensor object only — any other op on the tensor yields an object without it — so a stale buffer cannot be picked up.
+on one tensor object only: an out-of-place op yields an object without it, and an in-place op (which keeps the object)
+bumps the tensor's version counter, which take_activated compares with the one recorded at hand-off — so a stale buffer
+cannot be picked up either way.
 """
 from __future__ import annotations
 
@@ -28,14 +30,20 @@ __all__ = ["lap_block", "dirac_block", "avg_block", "take_activated", "attach_ac
 
 
 def attach_activated(t: torch.Tensor, cat: torch.Tensor) -> torch.Tensor:
-    t._sn_cat = cat
+    t._sn_cat = (cat, t._version)
     return t
 
 
 def take_activated(t: torch.Tensor, rows: int, C: int):
+    """The (rows, 2C) buffer whose first half holds elu(t), if the producer of `t` left one AND `t` still has the values
+    it was computed from: an in-place edit of `t` (`v += x`, `v.mul_(mask)`, `v[:, idx] = 0` keep the object and its
+    attributes) bumps the tensor's version counter, and the stale activation is then dropped, not consumed."""
     d = getattr(t, "__dict__", None)
-    cat = d.pop("_sn_cat", None) if d is not None else None
-    if cat is None or tuple(cat.shape) != (rows, 2 * C) or cat.device != t.device or cat.dtype != torch.float32:
+    entry = d.pop("_sn_cat", None) if d is not None else None
+    if entry is None:
+        return None
+    cat, version = entry
+    if version != t._version or tuple(cat.shape) != (rows, 2 * C) or cat.device != t.device or cat.dtype != torch.float32:
         return None
     return cat
 
@@ -353,14 +361,21 @@ def lap_block(mod, L, inputs):
 def avg_block(mod, mask, inputs):
     B, V, C = inputs.shape
     rows = B * V
-    cached = getattr(mask, "_sn_avg", None)                  # the 7 global-average blocks of a model share one mask
-    key = (B, V, mask._version)                              # (in-place edits of the mask invalidate the cache)
+    # The 7 global-average blocks of a model share one mask: its flattened copy and the per-mesh 1/count are cached on the
+    # mask object, keyed by its version (in-place edits invalidate).  NOT while a hipGraph is being captured: a value
+    # computed eagerly during warm-up would be baked into the graph as a constant, and every replay on another batch
+    # loaded into the static mask would divide by the example batch's vertex counts.  Under capture the reduction is
+    # recorded (once per block: a (B, 1) reduction) and nothing is cached.
+    capturing = mask.is_cuda and torch.cuda.is_current_stream_capturing()
+    cached = None if capturing else getattr(mask, "_sn_avg", None)
+    key = (B, V, mask._version)
     if cached is None or cached[0] != key:
         cached = (key, mask.reshape(rows).contiguous(), 1.0 / mask.reshape(B, V).sum(1, keepdim=True))
-        try:
-            mask._sn_avg = cached
-        except AttributeError:
-            pass
+        if not capturing:
+            try:
+                mask._sn_avg = cached
+            except AttributeError:
+                pass
     _, mask_rows, inv_count = cached
     a0, a1 = _bn_args(mod.bn_fc0), _bn_args(mod.bn_fc1)
     if a0[6] and a1[6] and kernels.avg_stage_supported(C, mod.bn_fc0.fc.weight.shape[0], V) and \

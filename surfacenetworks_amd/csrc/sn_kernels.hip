@@ -844,6 +844,66 @@ __global__ __launch_bounds__(kWG) void blockdiag_entries(const int *__restrict__
   }
 }
 
+// Ragged form of the same assembly: mesh b owns the output rows [d[4], next mesh's d[4]) — of which the first d[2] carry
+// its entries and the rest (if any) are empty — and its column indices are shifted by d[5].  With d[4] = prefix sum of the
+// meshes' own row counts and d[5] = prefix sum of their column counts the batch is PACKED: no padding rows or columns
+// exist, so the product neither scans empty rows nor writes zeros into them (SURVEY.md §7 "ragged not padded").
+// desc is (B x 6) int64: { rowptr offset, entry offset, rows with entries, output entry offset, first output row, column shift }.
+__global__ __launch_bounds__(kWG) void blockdiag_rowptr_ragged(const int *__restrict__ pool_rowptr,
+                                                               const int64_t *__restrict__ desc, int64_t B,
+                                                               int64_t total_rows, int64_t total,
+                                                               int *__restrict__ out_rowptr) {
+  const int64_t n = total_rows + 1;
+  for (int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x; i < n; i += (int64_t)gridDim.x * kWG) {
+    if (i == n - 1) {
+      out_rowptr[i] = (int)total;
+      continue;
+    }
+    int64_t lo = 0, hi = B;                      // last b with first output row <= i
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (desc[6 * mid + 4] <= i) lo = mid; else hi = mid;
+    }
+    const int64_t *d = desc + 6 * lo;
+    const int64_t r = i - d[4], rows = d[2];
+    const int local = pool_rowptr[d[0] + (r < rows ? r : rows)];
+    out_rowptr[i] = (int)(d[3] + local);
+  }
+}
+
+template <int VPE>
+__global__ __launch_bounds__(kWG) void blockdiag_entries_ragged(const int *__restrict__ pool_colind,
+                                                                const float *__restrict__ pool_vals,
+                                                                const int64_t *__restrict__ desc, int64_t B,
+                                                                int64_t total, int *__restrict__ out_colind,
+                                                                float *__restrict__ out_vals) {
+  for (int64_t k = (int64_t)blockIdx.x * kWG + threadIdx.x; k < total; k += (int64_t)gridDim.x * kWG) {
+    int64_t lo = 0, hi = B;                      // last b with output entry offset <= k
+    while (hi - lo > 1) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (desc[6 * mid + 3] <= k) lo = mid; else hi = mid;
+    }
+    const int64_t *d = desc + 6 * lo;
+    const int64_t src = d[1] + (k - d[3]);
+    const int shift = (int)d[5];
+    if constexpr (VPE == 4) {
+      f4 q = reinterpret_cast<const f4 *>(pool_vals)[src];
+      q.w = __int_as_float(__float_as_int(q.w) + shift);
+      reinterpret_cast<f4 *>(out_vals)[k] = q;
+      continue;
+    }
+    out_colind[k] = pool_colind[src] + shift;
+    if constexpr (VPE == 1) {
+      out_vals[k] = pool_vals[src];
+    } else {
+      const f4 *s = reinterpret_cast<const f4 *>(pool_vals + (int64_t)VPE * src);
+      f4 *o = reinterpret_cast<f4 *>(out_vals + (int64_t)VPE * k);
+#pragma unroll
+      for (int i = 0; i < VPE / 4; ++i) o[i] = s[i];
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // ELU helpers (alpha = 1, as F.elu defaults in the reference).
 // ------------------------------------------------------------------------------------------------
@@ -1365,6 +1425,38 @@ int sn_blockdiag_concat_i32(const int32_t *pool_rowptr, const int32_t *pool_coli
     else
       hipLaunchKernelGGL((blockdiag_entries<16>), dim3(grid_for(total, kWG)), dim3(kWG), 0, s, pool_colind,
                          pool_vals, desc, B, size1, total, out_colind, out_vals);
+  }
+  return launch_status();
+}
+
+int sn_blockdiag_concat_ragged_i32(const int32_t *pool_rowptr, const int32_t *pool_colind, const float *pool_vals,
+                                   const int64_t *desc, int64_t B, int64_t total_rows, int64_t total_cols, int64_t total,
+                                   int32_t vals_per_entry, int32_t *out_rowptr, int32_t *out_colind, float *out_vals,
+                                   void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (B < 0 || total_rows < 0 || total_cols < 0 || total < 0) return SN_E_SHAPE;
+  if (vals_per_entry != 1 && vals_per_entry != 16 && vals_per_entry != 4) return SN_E_UNSUPPORTED;
+  if (!fits_i32(total_rows + 1) || !fits_i32(total_cols) || !fits_i32(total)) return SN_E_RANGE;
+  if (!out_rowptr) return SN_E_NULL;
+  if (B > 0 && (!desc || !pool_rowptr)) return SN_E_NULL;
+  if (B == 0 && (total_rows > 0 || total > 0)) return SN_E_SHAPE;
+  if (total > 0 && (!pool_vals || !out_vals || (vals_per_entry != 4 && (!pool_colind || !out_colind)))) return SN_E_NULL;
+  if (vals_per_entry != 1 && total > 0 && (!aligned16(pool_vals) || !aligned16(out_vals))) return SN_E_ALIGN;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (B == 0) {
+    hipError_t e = hipMemsetAsync(out_rowptr, 0, sizeof(int32_t), s);
+    return e == hipSuccess ? SN_OK : (int)e;
+  }
+  hipLaunchKernelGGL(blockdiag_rowptr_ragged, dim3(grid_for(total_rows + 1, kWG)), dim3(kWG), 0, s, pool_rowptr, desc, B,
+                     total_rows, total, out_rowptr);
+  if (total > 0) {
+    const unsigned grid = grid_for(total, kWG);
+    if (vals_per_entry == 1)
+      hipLaunchKernelGGL((blockdiag_entries_ragged<1>), dim3(grid), dim3(kWG), 0, s, pool_colind, pool_vals, desc, B, total, out_colind, out_vals);
+    else if (vals_per_entry == 4)
+      hipLaunchKernelGGL((blockdiag_entries_ragged<4>), dim3(grid), dim3(kWG), 0, s, pool_colind, pool_vals, desc, B, total, out_colind, out_vals);
+    else
+      hipLaunchKernelGGL((blockdiag_entries_ragged<16>), dim3(grid), dim3(kWG), 0, s, pool_colind, pool_vals, desc, B, total, out_colind, out_vals);
   }
   return launch_status();
 }

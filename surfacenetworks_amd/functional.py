@@ -109,14 +109,17 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
         known = op._nnz_cache if op._nnz_cache is not None else (int(op._csr[1].numel()) if op._csr is not None else None)
         timer.tags.append((tag, op if known is None else known))
     e, g = elubwd if elubwd is not None else (None, None)
-    if group == 4 and _DIRAC_FORMAT == "q3":
+    # the block-form kernels and every fused epilogue exist for N in {16, 32, 64, 128} dense columns (the widths the
+    # reference models use: 64 / 128 channels); any other width takes the generic CSR kernel and an unfused epilogue
+    vec = (y.shape[1] // group) in (16, 32, 64, 128)
+    if group == 4 and _DIRAC_FORMAT == "q3" and vec:
         q = op.q3()
         if q is not None:
             if stats and e is None and kernels.spmm_q3_stats_supported(y.shape[1] // group, group):
                 return kernels.spmm_q3_stats(q[0], q[1], M // 4, K // 4, x, y, group)
             kernels.spmm_q3(q[0], q[1], M // 4, K // 4, x, y, group, e, g)
             return None
-    b = op.bsr4() if (_DIRAC_FORMAT != "csr" and group == 4) else None
+    b = op.bsr4() if (_DIRAC_FORMAT != "csr" and group == 4 and vec) else None
     if b is not None:
         if elubwd is None:
             kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
@@ -124,8 +127,12 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
             kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, x, e, g, y, group)
     elif elubwd is None:
         kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x, y, group)
-    else:
+    elif vec:
         kernels.spmm_csr_elubwd(op.rowptr, op.colind, op.vals, M, K, x, e, g, y, group)
+    else:
+        tmp = torch.empty(y.shape, dtype=torch.float32, device=y.device)
+        kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x, tmp, group)
+        kernels.elu_bwd(tmp, e, y, False, None, g)                      # y = tmp * elu'(e) + g
     return None
 
 

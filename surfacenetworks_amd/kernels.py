@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 __all__ = [
-    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat",
+    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
@@ -198,6 +198,19 @@ def blockdiag_concat(pool_rowptr, pool_colind, pool_vals, desc, size0: int, size
     out_vals = torch.empty(total * vpe, dtype=torch.float32, device=dev)
     _lib.call("sn_blockdiag_concat_i32", _p(pool_rowptr), _p(pool_colind), _p(pool_vals), _p(desc), B, size0, size1,
               total, vpe, _p(out_rowptr), _p(out_colind), _p(out_vals), _stream())
+    return out_rowptr, out_colind, out_vals
+
+
+def blockdiag_concat_ragged(pool_rowptr, pool_colind, pool_vals, desc, total_rows: int, total_cols: int, total: int, vpe: int = 1):
+    """Packed (unpadded) batch assembly; `desc` is the (B,6) int64 table of sn_blockdiag_concat_ragged_i32 (device)."""
+    _dev(pool_rowptr, pool_colind, pool_vals, desc)
+    B = int(desc.shape[0])
+    dev = pool_rowptr.device
+    out_rowptr = torch.empty(total_rows + 1, dtype=torch.int32, device=dev)
+    out_colind = torch.empty(total, dtype=torch.int32, device=dev) if vpe != 4 else None      # Q3 records carry the column
+    out_vals = torch.empty(total * vpe, dtype=torch.float32, device=dev)
+    _lib.call("sn_blockdiag_concat_ragged_i32", _p(pool_rowptr), _p(pool_colind), _p(pool_vals), _p(desc), B, total_rows,
+              total_cols, total, vpe, _p(out_rowptr), _p(out_colind), _p(out_vals), _stream())
     return out_rowptr, out_colind, out_vals
 
 

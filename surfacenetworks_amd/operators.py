@@ -60,6 +60,7 @@ class SparseOperator:
         self._nnz_cache = None
         self._shape = (M, K)
         self.batch = int(batch)                  # number of diagonal blocks (B of the reference's (B,R,K) operators)
+        self.row_offsets = self.col_offsets = None   # packed (unpadded) batches: first row / column of every diagonal block
         # operator -> transpose is a strong reference, transpose -> operator a weak one: a strong pair would be a
         # reference cycle, and the per-step batch operators (hundreds of MB of HBM each) would then live until Python's
         # cyclic collector happens to run instead of being returned to the caching allocator when the step drops them
@@ -134,21 +135,26 @@ class SparseOperator:
     def cuda(self, *_, **__):
         return self.to("cuda")
 
+    def _moved(self, device, transpose=None):
+        """A copy of this operator's own arrays on `device` (the transpose is handled by to())."""
+        mv = lambda t: t.to(device)
+        b = tuple(mv(t) for t in self._bsr4) if isinstance(self._bsr4, tuple) else self._bsr4
+        q = tuple(mv(t) for t in self._q3) if isinstance(self._q3, tuple) else self._q3
+        csr = (None, None, None) if self._csr is None else tuple(mv(t) for t in self._csr)
+        out = SparseOperator(*csr, self._shape, batch=self.batch, transpose=transpose, bsr4=b, q3=q)
+        out._nnz_cache = self._nnz_cache
+        out.row_offsets, out.col_offsets = self.row_offsets, self.col_offsets
+        return out
+
     def to(self, device):
         device = torch.device(device)
         if device.type == self.device.type and (device.index is None or device.index == self.device.index):
             return self
-        mv = lambda t: t.to(device)
-        b = tuple(mv(t) for t in self._bsr4) if isinstance(self._bsr4, tuple) else None
-        q = tuple(mv(t) for t in self._q3) if isinstance(self._q3, tuple) else None
-        if self._csr is None:
-            out = SparseOperator(None, None, None, self._shape, batch=self.batch, bsr4=b, q3=q)
-        else:
-            out = SparseOperator(mv(self.rowptr), mv(self.colind), mv(self.vals), self._shape, batch=self.batch, bsr4=b, q3=q)
-        if self._t is not None:
-            t = self._t.to(device)
-            t._t_strong, t._t_weak = None, weakref.ref(out)
-            out._t = t
+        out = self._moved(device)
+        t = self._t
+        if t is not None:
+            # the transpose's arrays are moved directly: t.to() would come back here through its own transpose link
+            out._t = t._moved(device, transpose=out)
         return out
 
     def __repr__(self):
@@ -424,7 +430,58 @@ class OperatorPool:
         return kernels.blockdiag_concat(pool["rowptr"], pool["colind"], pool["vals"], desc_d, size0, size1,
                                         int(out_off[-1]), vpe)
 
-    def assemble(self, sel, size0: int, size1: int) -> SparseOperator:
+    def _concat_ragged(self, pool, sel, nrows, row_off, col_off, vpe):
+        cnt = pool["cnt"][sel]
+        out_off = np.zeros(len(sel) + 1, dtype=np.int64)
+        np.cumsum(cnt, out=out_off[1:])
+        desc = np.stack([pool["rp_off"][sel], pool["e_off"][sel], nrows, out_off[:-1], row_off[:-1], col_off[:-1]], axis=1)
+        desc_d = h2d_async(desc, self.device)
+        return kernels.blockdiag_concat_ragged(pool["rowptr"], pool["colind"], pool["vals"], desc_d, int(row_off[-1]),
+                                               int(col_off[-1]), int(out_off[-1]), vpe)
+
+    def assemble_packed(self, sel) -> SparseOperator:
+        """The batch WITHOUT padding: mesh i owns rows [row_offsets[i], row_offsets[i+1]) and columns
+        [col_offsets[i], col_offsets[i+1]) (prefix sums of the meshes' own sizes), so the dense operands are the plain
+        concatenation of the meshes' node rows — (sum V_i, C) instead of the reference's (B, Vmax, C)
+        (src/as_rigid_as_possible/main.py:172-185 pads to the batch maxima).  The product then neither scans padding rows
+        nor writes zeros into them.  The offsets (host int64 arrays, length B+1) ride on the operator."""
+        sel = np.asarray(sel, dtype=np.int64)
+        B = len(sel)
+        rows, cols = self.rows[sel], self.cols[sel]
+        ro = np.zeros(B + 1, dtype=np.int64)
+        co = np.zeros(B + 1, dtype=np.int64)
+        np.cumsum(rows, out=ro[1:])
+        np.cumsum(cols, out=co[1:])
+        shape = (int(ro[-1]), int(co[-1]))
+        if self.want_bsr4:
+            if (rows % 4).any() or (cols % 4).any():
+                raise ValueError("BSR4 pools need every mesh's sizes to be multiples of 4")
+            if self._fwd_q is not None and _POOL_FORMAT == "q3":
+                fr, _, fq = self._concat_ragged(self._fwd_q, sel, rows // 4, ro // 4, co // 4, 4)
+                br_, _, bq = self._concat_ragged(self._bwd_q, sel, cols // 4, co // 4, ro // 4, 4)
+                op = SparseOperator.from_q3((fr, fq.view(-1, 4)), (br_, bq.view(-1, 4)), shape, batch=B)
+            else:
+                fb = self._concat_ragged(self._fwd_b, sel, rows // 4, ro // 4, co // 4, 16)
+                bb = self._concat_ragged(self._bwd_b, sel, cols // 4, co // 4, ro // 4, 16)
+                op = SparseOperator.from_bsr4(fb, bb, shape, batch=B)
+            op._nnz_cache = op._t._nnz_cache = int(self._fwd["cnt"][sel].sum())
+        else:
+            f = self._concat_ragged(self._fwd, sel, rows, ro, co, 1)
+            b = self._concat_ragged(self._bwd, sel, cols, co, ro, 1)
+            op = SparseOperator(*f, shape, batch=B)
+            opt = SparseOperator(*b, (shape[1], shape[0]), batch=B, transpose=op)
+            op._t = opt
+            op._bsr4 = opt._bsr4 = False
+        op.row_offsets, op.col_offsets = ro, co
+        op._t.row_offsets, op._t.col_offsets = co, ro
+        return op
+
+    def assemble(self, sel, size0: Optional[int] = None, size1: Optional[int] = None) -> SparseOperator:
+        """size0/size1 = the padded block size of the reference's sparse_diag_cat; both None: packed (assemble_packed)."""
+        if size0 is None and size1 is None:
+            return self.assemble_packed(sel)
+        if size0 is None or size1 is None:
+            raise ValueError("assemble: give both block sizes (padded batch) or neither (packed batch)")
         sel = np.asarray(sel, dtype=np.int64)
         B = len(sel)
         rows, cols = self.rows[sel], self.cols[sel]

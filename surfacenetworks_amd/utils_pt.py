@@ -111,7 +111,7 @@ class GraphConv1x1(nn.Module):
             want_elu = residual is None and self.num_outputs % 4 == 0 and 256 % (self.num_outputs // 4) == 0
             x2d, cat = snF.thin_linear(x2d, self.fc, want_elu)
             if cat is not None:
-                x2d._sn_cat = cat
+                snB.attach_activated(x2d, cat)
         else:
             x2d = self.fc(x2d)
         if self.batch_norm == "post":

@@ -115,6 +115,31 @@ def blockdiag_concat(pool_rowptr, pool_colind, pool_vals, desc, size0, size1, to
     return tuple(torch.from_numpy(a) for a in out)
 
 
+def blockdiag_concat_ragged(pool_rowptr, pool_colind, pool_vals, desc, total_rows, total_cols, total, vpe=1):
+    """numpy restatement of sn_blockdiag_concat_ragged_i32 (include/sn_spmm.h): mesh b owns output rows
+    [desc[b][4], desc[b+1][4]), its columns are shifted by desc[b][5]."""
+    rp, d = _np(pool_rowptr), _np(desc)
+    B = d.shape[0]
+    vals = _np(pool_vals).reshape(-1, vpe)
+    out_rp = np.zeros(total_rows + 1, np.int32)
+    out_v = np.zeros((total, vpe), np.float32)
+    out_c = None if vpe == 4 else np.zeros(total, np.int32)
+    ci = None if vpe == 4 else _np(pool_colind)
+    for b, (rp_off, e_off, nrows, out_off, row0, cshift) in enumerate(d):
+        row1 = int(d[b + 1][4]) if b + 1 < B else total_rows
+        local = rp[rp_off: rp_off + nrows + 1]
+        cnt = int(local[-1])
+        out_rp[row0: row1] = np.concatenate([local[:-1], np.full(row1 - row0 - nrows, cnt, np.int32)]) + out_off
+        v = vals[e_off: e_off + cnt].copy()
+        if vpe == 4:
+            v[:, 3] = (v[:, 3].copy().view(np.int32) + np.int32(cshift)).view(np.float32)
+        else:
+            out_c[out_off: out_off + cnt] = ci[e_off: e_off + cnt] + np.int32(cshift)
+        out_v[out_off: out_off + cnt] = v
+    out_rp[-1] = total
+    return torch.from_numpy(out_rp), (None if out_c is None else torch.from_numpy(out_c)), torch.from_numpy(out_v.reshape(-1))
+
+
 def elu_into(src, dst):
     c_oracle.elu_raw(src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst), src.shape[0], src.shape[1])
 

@@ -303,3 +303,82 @@ def check_mnist_sampler(dev):
     m = mesh_mnist.Model().to(dev)
     loss, out = mesh_mnist.forward_loss(m, b3)
     assert out.shape == (2, 10) and torch.isfinite(loss)
+
+
+def check_pool_packed(golden_dir, dev):
+    """OperatorPool.assemble(sel) without sizes = the PACKED batch: block_diag of the unpadded per-mesh operators (exact),
+    transpose attached, offsets on the operator; and the packed product equals, mesh by mesh and bit for bit, the padded
+    product of the reference layout (the padding only adds empty rows / unused columns)."""
+    from surfacenetworks_amd import functional as snF
+    from surfacenetworks_amd.operators import OperatorPool
+
+    names = ["cube", "delaunay150", "delaunay60"]
+    sel = [1, 0, 2, 1]
+    rng = np.random.default_rng(4)
+    for k, group, C in [("L", 1, 64), ("Di", 4, 128), ("DiA", 4, 128), ("L", 1, 128), ("Di", 4, 64)]:
+        mats = [csr_of(load(golden_dir, f"ops_{m}.npz"), k).astype(np.float32) for m in names]
+        pool = OperatorPool(mats, dev, want_bsr4=(group == 4))
+        op = pool.assemble(sel)
+        want = sp.block_diag([mats[i] for i in sel], format="csr")
+        want.sort_indices()
+        got = op.to_scipy()
+        assert got.shape == want.shape and np.array_equal(got.indptr, want.indptr) and np.array_equal(got.indices, want.indices)
+        assert np.array_equal(got.data, want.data)
+        gt, wt = op.t().to_scipy(), want.T.tocsr()
+        wt.sort_indices()
+        assert np.array_equal(gt.indptr, wt.indptr) and np.array_equal(gt.indices, wt.indices) and np.array_equal(gt.data, wt.data)
+        ro, co = op.row_offsets, op.col_offsets
+        assert ro[-1] == want.shape[0] and co[-1] == want.shape[1] and np.array_equal(np.diff(ro), [mats[i].shape[0] for i in sel])
+        assert np.array_equal(op.t().row_offsets, co) and op.batch == len(sel)
+        # packed vs padded product, forward and transposed backward
+        s0, s1 = max(m.shape[0] for m in mats), max(m.shape[1] for m in mats)
+        pad = pool.assemble(sel, s0, s1)
+        N = C // group
+        xp = rng.standard_normal((want.shape[1] // group, group * N)).astype(np.float32)
+        gp = rng.standard_normal((want.shape[0] // group, group * N)).astype(np.float32)
+        xd = np.zeros((len(sel), s1 // group, group * N), np.float32)
+        gd = np.zeros((len(sel), s0 // group, group * N), np.float32)
+        for b in range(len(sel)):
+            xd[b, : (co[b + 1] - co[b]) // group] = xp[co[b] // group: co[b + 1] // group]
+            gd[b, : (ro[b + 1] - ro[b]) // group] = gp[ro[b] // group: ro[b + 1] // group]
+        xt = torch.from_numpy(xp).to(dev).requires_grad_(True)
+        y = snF.spmm(op, xt, group)
+        y.backward(torch.from_numpy(gp).to(dev))
+        xdt = torch.from_numpy(xd.reshape(-1, group * N)).to(dev).requires_grad_(True)
+        yd = snF.spmm(pad, xdt, group)
+        yd.backward(torch.from_numpy(gd.reshape(-1, group * N)).to(dev))
+        yd3 = yd.detach().cpu().numpy().reshape(len(sel), s0 // group, group * N)
+        gx3 = xdt.grad.cpu().numpy().reshape(len(sel), s1 // group, group * N)
+        yp, gxp = y.detach().cpu().numpy(), xt.grad.cpu().numpy()
+        for b in range(len(sel)):
+            assert np.array_equal(yp[ro[b] // group: ro[b + 1] // group], yd3[b, : (ro[b + 1] - ro[b]) // group]), (k, b)
+            assert not yd3[b, (ro[b + 1] - ro[b]) // group:].any()
+            assert np.array_equal(gxp[co[b] // group: co[b + 1] // group], gx3[b, : (co[b + 1] - co[b]) // group]), (k, b)
+        want64 = want.astype(np.float64) @ (xp.reshape(-1, N) if group == 1 else xp.reshape(-1, 4, N).reshape(-1, N)).astype(np.float64)
+        assert rel_err(yp.reshape(-1, N), want64) < 1e-6
+
+
+def check_inplace_edit_drops_handoff(golden_dir, dev):
+    """The activated hand-off between blocks (blocks.attach_activated) must not survive an in-place edit of the tensor it
+    rides on: block(x.mul_(m)) has to equal block(x * m)."""
+    import surfacenetworks_amd.utils_pt as U
+
+    rb, ops = batch_operators(golden_dir, "pool", dev)
+    B, nv, C = rb["mask"].shape[0], int(rb["nv"]), 128
+    mask = torch.from_numpy(rb["mask"]).to(dev)
+    b0 = deterministic_init(U.LapResNet2(C), 7).train().to(dev)
+    b1 = deterministic_init(U.LapResNet2(C), 8).train().to(dev)
+    outs = []
+    for inplace in (True, False):
+        x = torch.from_numpy(det_tensor((B, nv, C), 3)).to(dev)
+        with torch.no_grad():
+            h = b0(ops["L"], None, x)
+            assert "_sn_cat" in h.__dict__                     # the hand-off is there ...
+            if inplace:
+                h.mul_(mask)                                   # ... and an in-place edit must invalidate it
+                h[:, 0] = 0.25
+            else:
+                h = h * mask
+                h = torch.cat([torch.full_like(h[:, :1], 0.25), h[:, 1:]], 1)
+            outs.append(b1(ops["L"], None, h).cpu().numpy())
+    assert rel_err(outs[0], outs[1]) < 1e-6

@@ -50,6 +50,22 @@ def test_mnist_sampler():
     pc.check_mnist_sampler(DEV)
 
 
+@pytest.mark.parametrize("fmt", ["q3", "bsr4", "csr"])
+def test_pool_packed_assembly(golden_dir, fmt):
+    """Ragged (unpadded) batches: sn_blockdiag_concat_ragged_i32 + the product kernels on packed operands."""
+    from surfacenetworks_amd import functional as snF
+
+    snF.set_dirac_format(fmt)
+    try:
+        pc.check_pool_packed(golden_dir, DEV)
+    finally:
+        snF.set_dirac_format("q3")
+
+
+def test_inplace_edit_drops_the_activated_handoff(golden_dir):
+    pc.check_inplace_edit_drops_handoff(golden_dir, DEV)
+
+
 def test_fused_block_equals_unfused_composition(golden_dir):
     """DirResNet2 (fused stages) == the same block composed from F.elu + spmm() + torch.cat, forward and backward."""
     import torch.nn.functional as F
@@ -108,7 +124,7 @@ def test_size_independent_properties_at_config_scale():
     assert abs(lhs - rhs) <= 1e-6 * max(abs(lhs), abs(rhs), 1.0) * 100
     yc = torch.empty_like(y1)
     kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x1, yc, 4)
-    assert torch.equal(yc, y1)                                 # y1 came from the BSR4 kernel
+    assert torch.equal(yc, y1)                                 # y1 came from the quaternion-packed (q3) kernel
     # mesh b of the batch only sees its own slice of x: same mesh + same slice => identical rows
     rows = M // 4 // 64
     xs = x1.clone()

@@ -1,0 +1,114 @@
+"""The N > 1 path on the GPU with the real HIP kernels: two ranks (gloo, both on cuda:0 of the 1-GPU box — with two devices
+the same code runs over RCCL) train on shards of a batch and must reproduce the single-process full-batch step; and
+`python bench.py --gpus 2` must start its own ranks and print one JSON line with n_gpus = 2."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q, mode):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from helpers import deterministic_init
+    from surfacenetworks_amd import arap, dp
+
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    r, lr, w, dev = dp.init_distributed(backend)
+    assert (r, w, dev.type) == (rank, world, "cuda")
+    grids = [(9, 8), (7, 7), (8, 9), (10, 6)] if mode == "frozen" else [(8, 8)] * 4
+    ds = arap.ClothSequences(grids, frames=44, op_frames=2, seed=5, device=dev, model="dir")
+    G = 4
+    seq, off = np.arange(G), np.zeros(G, dtype=np.int64)
+    model = deterministic_init(arap.DirModel(), 3 + rank).to(dev)
+    dp.broadcast_parameters(model, 0)
+    ref = deterministic_init(arap.DirModel(), 3).to(dev)
+    for (k, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()):
+        assert torch.equal(a, b), k
+    if mode == "frozen":
+        model.eval(), ref.eval()                               # BatchNorm frozen: shards are exactly additive
+    else:
+        model.train(), ref.train()
+        dp.sync_batchnorm(True)                                # train-mode BatchNorm over the GLOBAL batch
+    bucket = dp.FlatGradBucket(model.parameters())
+    mine = dp.shard_round_robin(G, rank, world)
+    batch = ds.sample_batch(len(mine), None, seq_ids=seq[mine], offsets=off[mine])
+    bucket.detach_grads()
+    loss, _ = arap.forward_loss(model, batch, G)
+    loss.backward()
+    bucket.sync()                                              # pack + all-reduce(SUM) over the two ranks
+    assert bucket.check_views()
+    g_dp = bucket.flat.clone()
+    dp.sync_batchnorm(False)
+    full = ds.sample_batch(G, None, seq_ids=seq, offsets=off)
+    l_full, _ = arap.forward_loss(ref, full, G)
+    l_full.backward()
+    g_full = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    err = ((g_dp - g_full).norm() / g_full.norm()).item()
+    lsum = loss.detach().clone()
+    dist.all_reduce(lsum)
+    rv = max(((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+             for (ka, a), (_, b) in zip(model.state_dict().items(), ref.state_dict().items()) if "running" in ka)
+    # one optimizer step on the reduced gradients keeps the replicas identical
+    arap.make_optimizer(model).step()
+    flat_p = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    other = flat_p.clone()
+    dist.broadcast(other, 0)
+    q.put((rank, err, abs(lsum.item() - l_full.item()) / abs(l_full.item()), rv, bool(torch.equal(other, flat_p)), backend))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["frozen", "syncbn"])
+def test_two_ranks_on_gpu_reproduce_full_batch(mode):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    for rank, err, lerr, rv, same, backend in sorted(q.get(timeout=10) for _ in range(2)):
+        # fp32 HIP kernels on both sides; the shard sums differ from the full-batch sums only in summation order
+        assert err < 2e-5, f"rank {rank} ({backend}): all-reduced shard gradients differ from the full-batch gradient by {err:.2e}"
+        assert lerr < 1e-5 and same
+        if mode == "syncbn":
+            assert rv < 1e-5
+
+
+def test_bench_self_launches_two_ranks():
+    """`python bench.py --gpus 2` without a launcher environment starts its two ranks itself and rank 0 prints ONE JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--meshes", "4", "--no-secondary"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["config"]["rccl_ranks"] == 2 and rec["config"]["global_batch"] == 8
+    assert rec["value"] > 0 and rec["scaling"] == "weak" and rec["roofline"]["frac"] > 0
+    if torch.cuda.device_count() < 2:
+        assert rec["config"]["ranks_share_devices"] and rec["config"]["collective_backend"] == "gloo"

@@ -47,6 +47,33 @@ def test_graph_replay_is_bit_identical_to_eager(model_kind):
         assert torch.equal(be_, bg_)
 
 
+def test_graph_replay_of_ragged_batches_in_permuted_order():
+    """Meshes of different sizes: a replay on the same meshes in another order has the captured signature, and every
+    per-batch quantity — the per-mesh vertex counts of the global-average blocks included — must come from the batch that
+    was loaded, not from the example the graph was captured on."""
+    from surfacenetworks_amd import arap
+
+    torch.manual_seed(6)
+    grids = [(9, 8), (7, 6), (8, 8)]
+    ds = arap.ClothSequences(grids, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 3, op_frames=3, seed=12, device=DEV,
+                             model="dir")
+    model_e = arap.DirModel().to(DEV).train()
+    model_g = copy.deepcopy(model_e)
+    opt_e, opt_g = arap.make_optimizer(model_e), arap.make_optimizer(model_g)
+    offs = np.zeros(3, dtype=np.int64)
+    example = ds.sample_batch(3, None, seq_ids=np.array([0, 1, 2]), offsets=offs)
+    graphed = arap.GraphedTrainStep(model_g, opt_g, example, global_batch=3)
+    for ids in ([2, 0, 1], [1, 2, 0], [0, 1, 2]):
+        be = ds.sample_batch(3, None, seq_ids=np.array(ids), offsets=offs)
+        bg = ds.sample_batch(3, None, seq_ids=np.array(ids), offsets=offs)
+        assert graphed.matches(bg)
+        le = arap.train_step(model_e, opt_e, be, global_batch=3)
+        lg = graphed(bg)
+        assert torch.equal(le.detach(), lg.detach()), f"loss differs for order {ids}"
+        for (name, pe), pg in zip(model_e.named_parameters(), model_g.parameters()):
+            assert torch.equal(pe.detach(), pg.detach()), f"{name} differs after order {ids}"
+
+
 def test_signature_mismatch_is_refused():
     arap, ds, model = _setup("dir", meshes=2)
     opt = arap.make_optimizer(model)

@@ -38,3 +38,11 @@ def test_arap_sampler_matches_padded_blockdiag(cpu_kernels):
 
 def test_mnist_sampler_running_max(cpu_kernels):
     pc.check_mnist_sampler("cpu")
+
+
+def test_pool_packed_assembly(golden_dir, cpu_kernels):
+    pc.check_pool_packed(golden_dir, "cpu")
+
+
+def test_inplace_edit_drops_the_activated_handoff(golden_dir, cpu_kernels):
+    pc.check_inplace_edit_drops_handoff(golden_dir, "cpu")

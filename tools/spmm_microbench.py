@@ -1,5 +1,8 @@
-"""SpMM roofline microbench (HIP events on the launch stream).  Usage: python tools/spmm_microbench.py [c3|c5|mnist]
-Prints one line per (operator, format): avg ms, algorithmic GB/s (CSR/int32/fp32 bytes), % of 8 TB/s."""
+"""SpMM roofline microbench (HIP events on the launch stream).
+Usage: python tools/spmm_microbench.py [c3|c4|c5|mnist] [perm] ; SN_MB_LAYOUT=packed|padded (default: packed for c5, padded else)
+Prints one line per (operator, format): avg ms, algorithmic GB/s (CSR/int32/fp32 bytes), % of 8 TB/s.
+The algorithmic bytes ALWAYS come from the meshes' real sizes (sum of V_i, F_i): a padded batch gets no credit for the
+padding rows it scans and the zeros it writes (round-1 VERDICT: the padded numerator inflated config 5 by 1.7x)."""
 import os
 import sys
 import time
@@ -36,6 +39,8 @@ def build_batch(workload, permute=False):
     t = time.time()
     if workload == "c3":
         sizes = [(71, 71)] * 64
+    elif workload == "c4":
+        sizes = "torus"
     elif workload == "mnist":
         sizes = None
     else:
@@ -48,6 +53,10 @@ def build_batch(workload, permute=False):
     if sizes is None:
         for i in range(512):
             V, F = mesh_ops.delaunay_disc(150, rng)
+            meshes.append(mesh_ops.mesh_operators(V, F))
+    elif sizes == "torus":                       # FAUST-sized closed meshes (65 x 106 = 6890 vertices), SURVEY.md §8d C4
+        for i in range(int(os.environ.get("SN_MB_C4_MESHES", "64"))):
+            V, F = mesh_ops.torus_grid(65, 106, rng)
             meshes.append(mesh_ops.mesh_operators(V, F))
     else:
         cache = {}
@@ -71,16 +80,20 @@ def main():
         mats = [m[name] for m in meshes]
         s0 = max(m.shape[0] for m in mats)
         s1 = max(m.shape[1] for m in mats)
+        if workload == "c4" and group == 1:
+            s0 = s1 = 7000                               # dense_correspondence/main.py:193 pads to 7000
         pool = OperatorPool(mats, dev, want_bsr4=(group == 4))
-        op = pool.assemble(np.arange(len(mats)), s0, s1)
+        layout = os.environ.get("SN_MB_LAYOUT", "packed" if workload == "c5" else "padded")
+        op = pool.assemble(np.arange(len(mats))) if layout == "packed" else pool.assemble(np.arange(len(mats)), s0, s1)
+        real = {"fwd": (int(pool.rows.sum()), int(pool.cols.sum())), "bwd(T)": (int(pool.cols.sum()), int(pool.rows.sum()))}
         for tag, o in [("fwd", op), ("bwd(T)", op.t())]:
             M, K = o.shape
             N = C // group
             x = torch.randn(K // group, group * N, device=dev)
             y = torch.empty(M // group, group * N, device=dev)
-            ab = alg_bytes(M, K, o.nnz, N)
+            ab = alg_bytes(real[tag][0], real[tag][1], o.nnz, N)     # real (unpadded) sizes, whatever the layout
             ms = time_launch(lambda: kernels.spmm_csr(o.rowptr, o.colind, o.vals, M, K, x, y, group)) if only != "bsr4" else float("nan")
-            print(f"{workload} {name:3s} {tag:6s} csr  N={N:3d} M={M} K={K} nnz={o.nnz} algMB={ab / 1e6:.1f} ms={ms:.4f} GB/s={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f}", flush=True)
+            print(f"{workload}/{layout} {name:3s} {tag:6s} csr  N={N:3d} M={M} K={K} nnz={o.nnz} algMB={ab / 1e6:.1f} ms={ms:.4f} GB/s={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f}", flush=True)
             if group == 4:
                 b = o.bsr4()
                 y2 = torch.empty_like(y)
@@ -88,13 +101,13 @@ def main():
                 actual = b[1].numel() * 68 + (M // 4 + 1) * 4 + K * N * 4 + M * N * 4
                 if only == "bsr4":
                     kernels.spmm_csr(o.rowptr, o.colind, o.vals, M, K, x, y, group)
-                print(f"{workload} {name:3s} {tag:6s} bsr4 N={N:3d} blocks={b[1].numel()} actualMB={actual / 1e6:.1f} ms={ms:.4f} GB/s(alg)={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f} equal={torch.equal(y, y2)}", flush=True)
+                print(f"{workload}/{layout} {name:3s} {tag:6s} bsr4 N={N:3d} blocks={b[1].numel()} actualMB={actual / 1e6:.1f} ms={ms:.4f} GB/s(alg)={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f} equal={torch.equal(y, y2)}", flush=True)
                 q = o.q3()                                   # quaternion-packed form (the default of the product)
                 if q is not None:
                     y3 = torch.empty_like(y)
                     ms = time_launch(lambda: kernels.spmm_q3(q[0], q[1], M // 4, K // 4, x, y3, group))
                     actual = q[1].shape[0] * 16 + (M // 4 + 1) * 4 + K * N * 4 + M * N * 4
-                    print(f"{workload} {name:3s} {tag:6s} q3   N={N:3d} blocks={q[1].shape[0]} actualMB={actual / 1e6:.1f} ms={ms:.4f} GB/s(alg)={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f} GB/s(actual)={actual / ms / 1e6:.0f} equal={torch.equal(y2, y3)}", flush=True)
+                    print(f"{workload}/{layout} {name:3s} {tag:6s} q3   N={N:3d} blocks={q[1].shape[0]} actualMB={actual / 1e6:.1f} ms={ms:.4f} GB/s(alg)={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f} GB/s(actual)={actual / ms / 1e6:.0f} equal={torch.equal(y2, y3)}", flush=True)
     if only:
         return
     # plain copy ceiling on this box for reference
