@@ -81,6 +81,16 @@ int sn_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const float *v
                     float *Y, int64_t ldy, int32_t y_group,
                     void *stream);
 
+/* sn_spmm_csr_stats_f32: sn_spmm_csr_f32 for N = 128, y_group = 1 (the Laplacian product on 128-channel rows,
+ * torch.mm(L, x) at src/utils/utils_pt.py:167,176) that ALSO leaves the BatchNorm statistics of its output:
+ * stats_part[sn_spmm_q3_stats_blocks()][2][128] fp64 partial column sums / sums of squares, to be combined by
+ * sn_colstats_merge_f64 — the statistics pass over the propagated half of [x | L x] (utils_pt.py:168-169,177-178:
+ * torch.cat + BatchNorm1d) disappears.  workspace: sn_spmm_csr_stats_workspace_bytes(M). Y is bit-identical to sn_spmm_csr_f32. */
+size_t sn_spmm_csr_stats_workspace_bytes(int64_t M);
+int sn_spmm_csr_stats_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
+                          const float *X, int64_t ldx, int32_t x_group, int32_t N, float *Y, int64_t ldy, int32_t y_group,
+                          double *stats_part, void *workspace, size_t workspace_bytes, void *stream);
+
 /* Same product with A stored as 4x4-block BSR (block rows Mb = M/4, block cols Kb = K/4,
  * bvals holds 16 floats per block, row-major inside the block).  This is the packed form of the
  * quaternionic Dirac operators: every 4x4 block of Di is -Q(0,e)/(2 Af) (src/utils/mesh.py:28-33,55-58).

@@ -18,6 +18,8 @@ SIGNATURES = {
     "sn_abi_version": (C.c_int, []),
     "sn_status_string": (C.c_char_p, [C.c_int]),
     "sn_spmm_csr_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "sn_spmm_csr_stats_workspace_bytes": (_sz, [_i64]),
+    "sn_spmm_csr_stats_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _vp, _sz, _vp]),
     "sn_spmm_bsr4_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
     "sn_spmm_csr_elubwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64,
                                          _i32, _vp]),

@@ -210,21 +210,22 @@ class _PropagateBlock(torch.autograd.Function):
         rows, C = x.shape
         per = rows // nseg if nseg else 0
 
-        def propagate(cat):
+        def propagate(cat, training):
             if op is not None:
-                _launch(op, cat[:, :C], cat[:, C:], 1, "fwd")
+                # (the Laplacian product leaves the BatchNorm statistics of the half it writes, like the Dirac products)
+                _attach_hi(cat, _launch(op, cat[:, :C], cat[:, C:], 1, "fwd", stats=training))
             else:
                 mean = kernels.segment_colsum(cat[:, :C], mask_rows, per, nseg) * inv_count
                 kernels.bcast_rows(mean, cat[:, C:], per)
 
         cat_a = _activated(x, pre)
-        propagate(cat_a)
+        propagate(cat_a, tr0)
         cat_b = _new_cat(rows, C, x.device)
         pb = _new_part(rows, C, x.device)
         _, st0 = bnlin_forward(cat_a, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, cat_b[:, :C],
                                want_y=False, elu_stats=pb)       # only elu(h) is consumed
         _attach_part(cat_b, pb)
-        propagate(cat_b)
+        propagate(cat_b, tr1)
         nxt = _new_cat(rows, C, x.device)
         pn = _new_part(rows, C, x.device)
         out, st1 = bnlin_forward(cat_b, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x, nxt[:, :C], elu_stats=pn)

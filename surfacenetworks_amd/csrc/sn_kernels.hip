@@ -231,6 +231,178 @@ __global__ __launch_bounds__(kWG) void spmm_csr_lds_epi(const int *__restrict__ 
 }
 
 // ------------------------------------------------------------------------------------------------
+// CSR SpMM, several row passes per wave ("rows" kernel) — the Laplacian kernel (N = 128: the products at utils_pt.py:167,176).
+//
+// spmm_csr_lds gives a wave ONE pass of P = 256/N rows: at N = 128 that is 2 rows, ~14 entries, 1 KiB of unique X and 1 KiB
+// of Y per wave, reached through three dependent memory round trips (row pointers -> entry run -> gathers).  Per byte moved
+// that is ~3x the fixed cost of the Dirac block kernels, and the kernel sat at 47-62 % of the roofline where those reach
+// 80 %+.  Here a wave owns R = P*iters consecutive rows: ONE coalesced load fetches its R+1 row pointers, the whole entry
+// run of those rows (R*7 entries for a Laplacian) goes to the wave's LDS slice with a few DMA instructions, and the wave
+// then walks its passes with nothing but LDS reads, gathers and stores — the two leading round trips are paid once per R
+// rows.  Same k-ascending FMA chain per row as every other CSR kernel (bit-identical results).  A wave whose entry run
+// exceeds the LDS slice (rows far longer than a mesh operator's) stages each pass's entries in tiles instead.
+// STATS (N = 128, YG = 1): the workgroup also leaves the column sums / sums of squares of its output rows in
+// stats_part[blockIdx.x][2][128] (fp32 over <= 256 rows, combined in fp64 by spmm_stats_reduce_k) — the BatchNorm statistics
+// of the propagated half [e | L·e] of a Laplacian stage, so that no statistics pass reads it back.
+// ------------------------------------------------------------------------------------------------
+template <int N, int XG, int YG, bool EPI, bool STATS>
+__device__ __forceinline__ void spmm_csr_rows_body(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                   const float *__restrict__ vals, int M, const float *__restrict__ X,
+                                                   int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters,
+                                                   SpmmEpi epi, float *__restrict__ stats_part) {
+  constexpr int LPR = N / 4;          // lanes per row
+  constexpr int P = 64 / LPR;         // rows per pass
+  constexpr int WAVES = kWG / 64;
+  constexpr int CAP = 512;            // entries of a wave's rows held in LDS (4 KiB per wave)
+  constexpr int KB = 8;               // gathers in flight per lane
+  __shared__ int s_col[WAVES][CAP];
+  __shared__ float s_val[WAVES][CAP];
+  __shared__ int s_rp[WAVES][68];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane % LPR, grp = lane / LPR;
+  const float *xb = X + sub * 4;
+  int *sc = s_col[wave];
+  float *sv = s_val[wave];
+  int *rp = s_rp[wave];
+  const int R = P * iters;                                        // rows of this wave (<= 64)
+  const int r0 = (my_chunk(nchunks) * WAVES + wave) * R;
+  if constexpr (!STATS) {
+    if (r0 >= M) return;                                          // wave-uniform
+  }
+  {
+    int rl = r0 + lane;
+    rl = rl < M ? rl : M;
+    rp[lane] = rowptr[rl];
+    int re = r0 + R;
+    re = re < M ? re : M;
+    if (lane == 0) rp[64] = rowptr[r0 < M ? re : M];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int k0 = rp[0];
+  const int k1 = R < 64 ? rp[R] : rp[64];
+  const bool fast = (k1 - k0) <= CAP;                             // wave-uniform
+  if (fast) {
+    for (int p0 = 0; p0 < k1 - k0; p0 += 64) {
+      int p = p0 + lane;
+      p = p < k1 - k0 ? p : k1 - k0 - 1;                          // tail lanes re-read the last entry into spare slots
+      __builtin_amdgcn_global_load_lds(colind + k0 + p, sc + p0, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(vals + k0 + p, sv + p0, 4, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  f4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = ssum;
+  for (int i = 0; i < iters; ++i) {
+    const int lr = i * P + grp;
+    const int r = r0 + lr;
+    const int kb = rp[lr];
+    const int ke = (lr + 1 < 64) ? rp[lr + 1] : rp[64];
+    f4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (fast) {
+      for (int k = kb; k < ke; k += KB) {
+        int c[KB];
+        float a[KB];
+        f4 x[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+          const bool in = k + j < ke;
+          const int o = (in ? k + j : ke - 1) - k0;
+          c[j] = sc[o];
+          a[j] = in ? sv[o] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) x[j] = ld4(xb + row_off<XG, N>(c[j], ldx));
+#pragma unroll
+        for (int j = 0; j < KB; ++j) acc = fma4(a[j], x[j], acc);
+      }
+    } else {
+      // entries of this pass's P rows, in tiles of CAP through the same LDS slice
+      const int pk0 = __builtin_amdgcn_readfirstlane(kb);
+      const int pk1 = __builtin_amdgcn_readlane(ke, 63);
+      for (int t0 = pk0; t0 < pk1; t0 += CAP) {
+        const int nt = (pk1 - t0) < CAP ? (pk1 - t0) : CAP;
+        for (int p0 = 0; p0 < nt; p0 += 64) {
+          int p = p0 + lane;
+          p = p < nt ? p : nt - 1;
+          __builtin_amdgcn_global_load_lds(colind + t0 + p, sc + p0, 4, 0, 0);
+          __builtin_amdgcn_global_load_lds(vals + t0 + p, sv + p0, 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        int k = kb > t0 ? kb : t0;
+        const int kend = ke < t0 + nt ? ke : t0 + nt;
+        for (; k < kend; k += KB) {
+          int c[KB];
+          float a[KB];
+          f4 x[KB];
+#pragma unroll
+          for (int j = 0; j < KB; ++j) {
+            const bool in = k + j < kend;
+            const int o = (in ? k + j : kend - 1) - t0;
+            c[j] = sc[o];
+            a[j] = in ? sv[o] : 0.f;
+          }
+#pragma unroll
+          for (int j = 0; j < KB; ++j) x[j] = ld4(xb + row_off<XG, N>(c[j], ldx));
+#pragma unroll
+          for (int j = 0; j < KB; ++j) acc = fma4(a[j], x[j], acc);
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (r < M) {
+      if constexpr (EPI) {
+        acc = elu_bwd4(acc, ld4_s(epi.e + row_off<YG, N>(r, epi.lde) + sub * 4, kStreamNT));
+        if (epi.g) acc += ld4_s(epi.g + row_off<YG, N>(r, epi.ldg) + sub * 4, kStreamNT);
+      }
+      st4_stream(Y + row_off<YG, N>(r, ldy) + sub * 4, acc);
+      if constexpr (STATS) {
+        ssum += acc;
+        ssq.x = __builtin_fmaf(acc.x, acc.x, ssq.x); ssq.y = __builtin_fmaf(acc.y, acc.y, ssq.y);
+        ssq.z = __builtin_fmaf(acc.z, acc.z, ssq.z); ssq.w = __builtin_fmaf(acc.w, acc.w, ssq.w);
+      }
+    }
+  }
+  if constexpr (STATS) {
+    static_assert(N == 128 && YG == 1 && !EPI, "statistics: 128-column rows in the plain row-major layout");
+    // lane (grp, sub) holds the sums of columns 4*sub .. 4*sub+3 over its rows: [wave][grp][sum | squares][128] -> one
+    // (2 x 128) partial per workgroup, added in a fixed order
+    __shared__ float s_st[WAVES * P][256];
+    float *st = s_st[wave * P + grp];
+    *reinterpret_cast<f4 *>(st + sub * 4) = ssum;
+    *reinterpret_cast<f4 *>(st + 128 + sub * 4) = ssq;
+    __syncthreads();
+    const int t = threadIdx.x;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES * P; ++w) tot += s_st[w][t];
+    stats_part[(int64_t)blockIdx.x * 256 + t] = tot;
+  }
+}
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) void spmm_csr_rows(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                     const float *__restrict__ vals, int M, const float *__restrict__ X,
+                                                     int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
+  spmm_csr_rows_body<N, XG, YG, false, false>(rowptr, colind, vals, M, X, ldx, Y, ldy, nchunks, iters,
+                                              SpmmEpi{nullptr, 0, nullptr, 0}, nullptr);
+}
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) void spmm_csr_rows_epi(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                         const float *__restrict__ vals, int M, const float *__restrict__ X,
+                                                         int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters,
+                                                         SpmmEpi epi) {
+  spmm_csr_rows_body<N, XG, YG, true, false>(rowptr, colind, vals, M, X, ldx, Y, ldy, nchunks, iters, epi, nullptr);
+}
+template <int XG>
+__global__ __launch_bounds__(kWG) void spmm_csr_rows_stats(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                           const float *__restrict__ vals, int M, const float *__restrict__ X,
+                                                           int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters,
+                                                           float *__restrict__ stats_part) {
+  spmm_csr_rows_body<128, XG, 1, false, true>(rowptr, colind, vals, M, X, ldx, Y, ldy, nchunks, iters,
+                                              SpmmEpi{nullptr, 0, nullptr, 0}, stats_part);
+}
+
+// ------------------------------------------------------------------------------------------------
 // BSR4 SpMM: N/4 lanes per block row; each lane keeps the 4 output rows of its column slice.
 // ------------------------------------------------------------------------------------------------
 template <int N, int XG, int YG>
@@ -990,9 +1162,10 @@ inline unsigned grid_for(int64_t work_items, int per_block) {
 
 // A/B switches for measurements (read once from the environment; the defaults are the shipped kernels):
 //   SN_BSR4_VARIANT = 0 -> spmm_bsr4_v4 (operator blocks re-read from global by every lane group) instead of spmm_bsr4_lds
-//   SN_CSR_VARIANT  = 0 -> spmm_csr_v4 (entries loaded directly) instead of spmm_csr_lds
+//   SN_CSR_VARIANT  = 0 -> spmm_csr_v4 (entries loaded directly), 1 -> spmm_csr_lds (one row pass per wave) instead of
+//                          spmm_csr_rows (several passes per wave, the default); SN_CSR_ITERS forces its passes per wave
 inline int tune_bsr4_variant() { static const int v = env_int("SN_BSR4_VARIANT", 2); return v; }
-inline int tune_csr_variant() { static const int v = env_int("SN_CSR_VARIANT", 1); return v; }
+inline int tune_csr_variant() { static const int v = env_int("SN_CSR_VARIANT", 2); return v; }
 
 // grid of the chunked kernels: one workgroup per chunk, rounded up to a multiple of the 8 XCDs (see my_chunk)
 inline unsigned chunk_grid(int64_t nchunks) {
@@ -1102,9 +1275,26 @@ const char *sn_status_string(int status) {
   return "unknown sn status";
 }
 
+constexpr int kSpmmStatsBlocks = 128;        // partial rows after stage 1 of the statistics reduction
+
+// rows kernel: passes per wave.  As many as keep >= 8 workgroups per CU in the grid (small batches stay wide), at most 64 rows.
+static int csr_rows_iters(int64_t M, int N) {
+  const int P = 64 / (N / 4);
+  static const int forced = env_int("SN_CSR_ITERS", 0);
+  int it = forced > 0 ? forced : 16;
+  if (it * P > 64) it = 64 / P;
+  if (forced <= 0)
+    while (it > 1 && (M + (int64_t)4 * P * it - 1) / ((int64_t)4 * P * it) < 8 * kCUs) it >>= 1;
+  return it < 1 ? 1 : it;
+}
+static int64_t csr_rows_chunks(int64_t M, int N, int iters) {
+  const int64_t rows_per_wg = (int64_t)(kWG / 64) * (64 / (N / 4)) * iters;
+  return (M + rows_per_wg - 1) / rows_per_wg;
+}
+
 static int spmm_csr_launch(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
                            int64_t nnz, const float *X, int64_t ldx, int32_t x_group, int32_t N, float *Y, int64_t ldy,
-                           int32_t y_group, SpmmEpi epi, void *stream) {
+                           int32_t y_group, SpmmEpi epi, void *stream, float *stats_part = nullptr, double *stats_out = nullptr) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (M < 0 || K < 0 || nnz < 0 || N < 1) return SN_E_SHAPE;
   if (!fits_i32(M + 1) || !fits_i32(K) || !fits_i32(nnz)) return SN_E_RANGE;
@@ -1127,8 +1317,27 @@ static int spmm_csr_launch(const int32_t *rowptr, const int32_t *colind, const f
     if (!aligned16(epi.e) || epi.lde % 4 || (epi.g && (!aligned16(epi.g) || epi.ldg % 4))) return SN_E_ALIGN;
   }
   hipEvent_t t_start, t_stop;
-  timing_slot(0 | (epi.e ? 2 : 0) | (epi.g ? 4 : 0), M, K, nnz, N, &t_start, &t_stop);
-  if (vec) {
+  timing_slot(0 | (epi.e ? 2 : 0) | (epi.g ? 4 : 0) | (stats_part ? 16 : 0), M, K, nnz, N, &t_start, &t_stop);
+  if (stats_part) {
+    if (!vec || N != 128 || y_group != 1 || epi.e) return SN_E_UNSUPPORTED;
+    if (!stats_out) return SN_E_NULL;
+    const int iters = csr_rows_iters(M, N);
+    const int64_t nchunks = csr_rows_chunks(M, N, iters);
+    const unsigned grid = chunk_grid(nchunks);
+    if (x_group == 1) SN_KLAUNCH((spmm_csr_rows_stats<1>), grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters, stats_part);
+    else SN_KLAUNCH((spmm_csr_rows_stats<4>), grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters, stats_part);
+    hipLaunchKernelGGL(spmm_stats_reduce_k, dim3(kSpmmStatsBlocks), dim3(kWG), 0, s, stats_part, (int64_t)grid, stats_out);
+    return launch_status();
+  }
+  if (vec && tune_csr_variant() >= 2) {
+    const int iters = csr_rows_iters(M, N);
+    const int64_t nchunks = csr_rows_chunks(M, N, iters);
+    const unsigned grid = chunk_grid(nchunks);
+    if (epi.e)
+      SN_DISPATCH_N(spmm_csr_rows_epi, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters, epi);
+    else
+      SN_DISPATCH_N(spmm_csr_rows, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters);
+  } else if (vec) {
     const int rpb = kWG / (N / 4);
     const int64_t nchunks = (M + rpb - 1) / rpb;
     const unsigned grid = chunk_grid(nchunks);
@@ -1160,6 +1369,22 @@ int sn_spmm_csr_elubwd_f32(const int32_t *rowptr, const int32_t *colind, const f
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (!E) return SN_E_NULL;
   return spmm_csr_launch(rowptr, colind, vals, M, K, nnz, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{E, lde, G, ldg}, stream);
+}
+
+size_t sn_spmm_csr_stats_workspace_bytes(int64_t M) {
+  if (M < 1) return 0;
+  return (size_t)chunk_grid(csr_rows_chunks(M, 128, csr_rows_iters(M, 128))) * 256 * sizeof(float);
+}
+
+int sn_spmm_csr_stats_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
+                          const float *X, int64_t ldx, int32_t x_group, int32_t N, float *Y, int64_t ldy, int32_t y_group,
+                          double *stats_part, void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (!stats_part || !workspace) return SN_E_NULL;
+  if (M < 1) return SN_E_SHAPE;
+  if (workspace_bytes < sn_spmm_csr_stats_workspace_bytes(M)) return SN_E_WORKSPACE;
+  return spmm_csr_launch(rowptr, colind, vals, M, K, nnz, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{nullptr, 0, nullptr, 0},
+                         stream, static_cast<float *>(workspace), stats_part);
 }
 
 static int spmm_bsr4_launch(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb, int64_t Kb,
@@ -1216,8 +1441,6 @@ int sn_spmm_bsr4_elubwd_f32(const int32_t *b_rowptr, const int32_t *b_colind, co
   return spmm_bsr4_launch(b_rowptr, b_colind, b_vals, Mb, Kb, nblocks, X, ldx, x_group, N, Y, ldy, y_group,
                           SpmmEpi{E, lde, G, ldg}, stream);
 }
-
-constexpr int kSpmmStatsBlocks = 128;        // partial rows after stage 1 of the statistics reduction
 
 static int spmm_q3_launch(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks, const float *X,
                           int64_t ldx, int32_t x_group, int32_t N, float *Y, int64_t ldy, int32_t y_group, SpmmEpi epi,

@@ -101,8 +101,8 @@ def _ctypes_i64_ref():
 def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, tag: str = "", elubwd=None, stats: bool = False):
     """y <- op·x with the best resident format of `op`.  elubwd = (e, g): y <- (op·x) * elu'(e) + g fused into the store
     (the backward of an ELU-activated propagation stage; g may be None).  stats=True: where the kernel offers it (packed
-    Dirac operators, 128 channels) the launch also leaves the column statistics of y and their partials are returned
-    (kernels.spmm_q3_stats), else None."""
+    Dirac operators and Laplacian-type CSR operators, 128 channels) the launch also leaves the column statistics of y and
+    their partials are returned (kernels.spmm_q3_stats / spmm_csr_stats), else None."""
     M, K = op.shape
     timer = SpmmTimer.active
     if timer is not None:
@@ -126,6 +126,8 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
         else:
             kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, x, e, g, y, group)
     elif elubwd is None:
+        if stats and kernels.spmm_csr_stats_supported(y.shape[1] // group, group):
+            return kernels.spmm_csr_stats(op.rowptr, op.colind, op.vals, M, K, x, y)
         kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x, y, group)
     elif vec:
         kernels.spmm_csr_elubwd(op.rowptr, op.colind, op.vals, M, K, x, e, g, y, group)

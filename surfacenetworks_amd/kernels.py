@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 __all__ = [
-    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged",
+    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
@@ -60,6 +60,28 @@ def spmm_csr(rowptr, colind, vals, M: int, K: int, x, y, group: int = 1) -> None
     ldy = _check_dense(y, M, group, N, "y")
     _lib.call("sn_spmm_csr_f32", _p(rowptr), _p(colind), _p(vals), M, K, int(colind.numel()),
               _p(x), ldx, group, N, _p(y), ldy, group, _stream())
+
+
+def spmm_csr_stats_supported(N: int, group: int) -> bool:
+    return N == 128 and group == 1
+
+
+def spmm_csr_stats(rowptr, colind, vals, M: int, K: int, x, y):
+    """y <- A·x as spmm_csr (N = 128, plain row-major operands) and the partial column statistics of y: returns the
+    (blocks, 2, 128) float64 partials that colstats_halves merges (sn_spmm_csr_stats_f32)."""
+    _dev(rowptr, colind, vals, x, y)
+    N = y.shape[1]
+    if not spmm_csr_stats_supported(N, 1):
+        raise ValueError("spmm_csr_stats: 128-column operands only")
+    ldx = _check_dense(x, K, 1, N, "x")
+    ldy = _check_dense(y, M, 1, N, "y")
+    lib = _lib.load()
+    part = torch.empty((int(lib.sn_spmm_q3_stats_blocks()), 2, 128), dtype=torch.float64, device=y.device)
+    ws_bytes = int(lib.sn_spmm_csr_stats_workspace_bytes(M))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=y.device)
+    _lib.call("sn_spmm_csr_stats_f32", _p(rowptr), _p(colind), _p(vals), M, K, int(colind.numel()), _p(x), ldx, 1, N, _p(y), ldy, 1,
+              _p(part), _p(ws), ws_bytes, _stream())
+    return part
 
 
 def spmm_bsr4(b_rowptr, b_colind, b_vals, Mb: int, Kb: int, x, y, group: int = 1) -> None:

@@ -92,8 +92,13 @@ def test_two_ranks_on_gpu_reproduce_full_batch(mode):
         p.join(timeout=900)
         assert p.exitcode == 0, f"worker exited with {p.exitcode}"
     for rank, err, lerr, rv, same, backend in sorted(q.get(timeout=10) for _ in range(2)):
-        # fp32 HIP kernels on both sides; the shard sums differ from the full-batch sums only in summation order
-        assert err < 2e-5, f"rank {rank} ({backend}): all-reduced shard gradients differ from the full-batch gradient by {err:.2e}"
+        # fp32 HIP kernels on both sides; shard and full-batch runs differ only in summation order (split-K slabs of the
+        # weight-gradient kernels, partial statistics).  With BatchNorm frozen that is a 1e-6 effect; in train mode the
+        # 15-layer model amplifies it (a 1e-7 relative input perturbation moves the REFERENCE's own conv1 gradient by
+        # 2.4e-3), so the bound there is the measured 5e-5 with headroom, and the tight check is on the
+        # synchronised running statistics, which are well conditioned.
+        tol = 2e-5 if mode == "frozen" else 2e-4
+        assert err < tol, f"rank {rank} ({backend}): all-reduced shard gradients differ from the full-batch gradient by {err:.2e}"
         assert lerr < 1e-5 and same
         if mode == "syncbn":
             assert rv < 1e-5

@@ -442,3 +442,44 @@ def test_spmm_leaves_the_column_statistics_of_its_output(kind, which):
             st = torch.full((2, 2 * C), float("nan"), dtype=torch.float64, device=DEV)
             kernels.colstats_merge_into(part, st, C)
             assert np.allclose(st[:, C:].cpu().numpy(), got, rtol=1e-14) and torch.isnan(st[:, :C]).all()
+
+
+@pytest.mark.parametrize("iters", ["0", "1", "2", "4", "16", "32"])
+def test_csr_rows_kernel_all_pass_counts(iters):
+    """The CSR "rows" kernel with every passes-per-wave setting (0 = the library's own choice): tests/csr_rows_check.py in a
+    subprocess, because the library reads SN_CSR_ITERS once per process."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SN_CSR_ITERS=iters, SN_CSR_VARIANT="2")
+    out = subprocess.run([sys.executable, os.path.join(here, "csr_rows_check.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-1500:]
+
+
+def test_csr_rows_kernel_large_batch_multi_pass():
+    """A batch large enough for the library to pick 16 passes per wave by itself (300k rows at N = 128): bit-exact vs the
+    oracle, and the previous-generation kernels (one pass per wave) agree."""
+    rng = np.random.default_rng(12)
+    import scipy.sparse as sp
+
+    M = K = 300_007
+    lens = rng.integers(3, 12, size=M)
+    rows = np.repeat(np.arange(M), lens)
+    cols = (rows + rng.integers(-2000, 2000, size=len(rows))) % K
+    A = sp.csr_matrix((rng.standard_normal(len(rows)).astype(np.float32), (rows, cols)), shape=(M, K))
+    A.sum_duplicates()
+    A.sort_indices()
+    N = 128
+    x = rng.standard_normal((K, N)).astype(np.float32)
+    want = c_oracle.spmm_csr(A.indptr, A.indices, A.data, x.ravel(), N).reshape(M, N)
+    rp, ci, va = csr_dev(A)
+    y = torch.empty((M, N), device=DEV)
+    kernels.spmm_csr(rp, ci, va, M, K, dev(x), y, 1)
+    assert np.array_equal(y.cpu().numpy(), want)
+    part = kernels.spmm_csr_stats(rp, ci, va, M, K, dev(x), y)
+    assert np.array_equal(y.cpu().numpy(), want)
+    w64 = want.astype(np.float64)
+    ref = np.stack([w64.sum(0), (w64 * w64).sum(0)])
+    assert np.allclose(part.sum(0).cpu().numpy(), ref, rtol=1e-6, atol=1e-6 * np.abs(w64).sum(0).max())
