@@ -203,6 +203,35 @@ int sn_bsr4_fill(const int32_t *rowptr, const int32_t *colind, const float *vals
                  const int32_t *b_rowptr, int32_t *b_colind, float *b_vals, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * CSR -> RB4 ("row-blocked", 4x1 blocks) and the RB4 product — the packed form of the Laplacian-type operators
+ * (torch.mm(L, x) with ~7 entries per row, src/utils/utils_pt.py:167,176; L from src/utils/mesh.py:102-112 and
+ * src/utils/graph.py:40-66).  Rows 4b .. 4b+3 share one sorted list of the columns any of them touches; every listed
+ * column carries four coefficients (zero where a row lacks it).  Four consecutive mesh rows reach ~16 distinct columns with
+ * ~28 entries, so the product gathers each X row once per 4-row group instead of once per row.
+ *   sn_rb4_count: b_ptr[Mb+1] <- exclusive scan of the listed-column counts, Mb = ceil(M/4) (rows past M are empty);
+ *                 workspace sn_scan_workspace_bytes(Mb + 1).  The total b_ptr[Mb] never exceeds nnz, so the caller can
+ *                 size b_col / b_val by nnz without reading it back.
+ *   sn_rb4_fill : b_col[total] (ascending inside a group), b_val[4*total] (16-byte aligned).
+ *   sn_spmm_rb4_f32 / _elubwd_f32 / _stats_f32: Y = A X on plain row-major operands (group = 1), N in {64, 128}; same
+ *                 epilogue / statistics semantics as the CSR entry points; `capacity` = allocated length of b_col.
+ * Results are bit-identical to sn_spmm_csr_f32 for finite X (same k-ascending FMA order per row; a zero coefficient
+ * contributes fma(0, x, acc) = acc; a non-finite X entry reaches all 4 rows of a group that lists its column).
+ * ------------------------------------------------------------------------------------------ */
+int sn_rb4_count(const int32_t *rowptr, const int32_t *colind, int64_t M, int64_t K, int32_t *b_ptr,
+                 void *workspace, size_t workspace_bytes, void *stream);
+int sn_rb4_fill(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
+                const int32_t *b_ptr, int32_t *b_col, float *b_val, void *stream);
+int sn_spmm_rb4_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K, int64_t capacity,
+                    const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, void *stream);
+int sn_spmm_rb4_elubwd_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K,
+                           int64_t capacity, const float *X, int64_t ldx, int32_t N, const float *E, int64_t lde,
+                           const float *G, int64_t ldg, float *Y, int64_t ldy, void *stream);
+size_t sn_spmm_rb4_stats_workspace_bytes(int64_t M);
+int sn_spmm_rb4_stats_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K,
+                          int64_t capacity, const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy,
+                          double *stats_part, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Block-diagonal batch assembly from a device-resident pool of per-mesh operators.
  *
  * Replaces: sparse_diag_cat(tensors, size0, size1)                       src/utils/utils_pt.py:41-53
@@ -440,7 +469,7 @@ int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_
  * (sn_spmm_csr_f32 / sn_spmm_bsr4_f32 and their _elubwd forms) is issued with hipExtLaunchKernelGGL so that the KERNEL's own start and stop are
  * stamped into two events: durations carry no marker / kernel-boundary overhead and agree with rocprofv3's kernel trace.
  * sn_timing_drain waits for the recorded launches, writes up to `capacity` durations (ms) and 5 int64 per record
- * {kind (bit 0: 0 csr, 1 blocked; bit 3: the blocked form is Q3; bit 4: the launch also left column statistics (sn_spmm_q3_stats_f32); bit 1: fused ELU-backward epilogue, E read; bit 2: G read
+ * {kind (bit 0: 0 csr, 1 blocked; bit 5: RB4 (4x1 row blocks); bit 3: the blocked form is Q3; bit 4: the launch also left column statistics (sn_spmm_q3_stats_f32); bit 1: fused ELU-backward epilogue, E read; bit 2: G read
  *  too), M, K,
  *  nnz (csr) | nblocks (bsr4), N}, and clears the list.
  * ------------------------------------------------------------------------------------------ */

@@ -37,6 +37,12 @@ SIGNATURES = {
     "sn_scan_workspace_bytes": (_sz, [_i64]),
     "sn_bsr4_count": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
     "sn_bsr4_fill": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "sn_rb4_count": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "sn_rb4_fill": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "sn_spmm_rb4_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "sn_spmm_rb4_elubwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "sn_spmm_rb4_stats_workspace_bytes": (_sz, [_i64]),
+    "sn_spmm_rb4_stats_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sn_blockdiag_concat_i32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sn_blockdiag_concat_ragged_i32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sn_elu_into_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),

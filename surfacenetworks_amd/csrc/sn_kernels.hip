@@ -962,6 +962,217 @@ __global__ __launch_bounds__(kWG) void bsr4_merge(const int *__restrict__ rowptr
 }
 
 // ------------------------------------------------------------------------------------------------
+// CSR -> RB4 ("row-blocked", 4x1 blocks): rows 4b .. 4b+3 share ONE list of the columns any of them touches (sorted),
+// with four coefficients per listed column (zero where a row lacks it).  On a mesh Laplacian four consecutive rows reach
+// ~16 distinct columns with 28 entries between them, so the product gathers each X row once per group instead of once per
+// row: the gather stream — which, not HBM, bounds these kernels (PMC: the vector-cache miss queue) — shrinks by ~45 %.
+// Rows past M (M not a multiple of 4) are treated as empty.
+// ------------------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(kWG) void rb4_merge(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                 const float *__restrict__ vals, int64_t M, int64_t Mb,
+                                                 int *__restrict__ counts_or_ptr, int *__restrict__ b_col,
+                                                 float *__restrict__ b_val) {
+  for (int64_t br = (int64_t)blockIdx.x * kWG + threadIdx.x; br < Mb; br += (int64_t)gridDim.x * kWG) {
+    int p[4], e[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int64_t r = 4 * br + q;
+      p[q] = r < M ? rowptr[r] : 0;
+      e[q] = r < M ? rowptr[r + 1] : 0;
+    }
+    int n = 0;
+    int out = FILL ? counts_or_ptr[br] : 0;
+    while (true) {
+      int cur = INT_MAX;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (p[q] < e[q]) {
+          const int c = colind[p[q]];
+          cur = c < cur ? c : cur;
+        }
+      if (cur == INT_MAX) break;
+      if constexpr (FILL) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (p[q] < e[q] && colind[p[q]] == cur) {
+            a[q] = vals[p[q]];
+            ++p[q];
+          }
+        b_col[out] = cur;
+        reinterpret_cast<f4 *>(b_val)[out] = f4{a[0], a[1], a[2], a[3]};
+        ++out;
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (p[q] < e[q] && colind[p[q]] == cur) ++p[q];
+        ++n;
+      }
+    }
+    if constexpr (!FILL) counts_or_ptr[br] = n;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// RB4 SpMM (group-1 operands, N in {64, 128}): N/4 lanes own one 4-row group and a float4 column slice (4 accumulators),
+// a wave owns P = 256/N groups per pass and `iters` passes (as spmm_csr_rows: row pointers and the whole entry run of the
+// wave staged once).  Per listed column one gather of the X row serves all four output rows.  k-ascending FMA chain per
+// row; the zero coefficients contribute fma(0, x, acc) = acc, so results are bit-identical to the CSR kernels for finite X.
+// ------------------------------------------------------------------------------------------------
+template <int N, bool EPI, bool STATS>
+__device__ __forceinline__ void spmm_rb4_body(const int *__restrict__ b_ptr, const int *__restrict__ b_col,
+                                              const f4 *__restrict__ b_val, int M, int Mb, const float *__restrict__ X,
+                                              int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters,
+                                              SpmmEpi epi, float *__restrict__ stats_part) {
+  constexpr int LPR = N / 4;          // lanes per 4-row group
+  constexpr int P = 64 / LPR;         // groups per pass
+  constexpr int WAVES = kWG / 64;
+  constexpr int CAP = 256;            // listed columns of a wave's groups held in LDS (5 KiB per wave)
+  constexpr int KB = 8;               // gathers in flight per lane
+  __shared__ int s_col[WAVES][CAP];
+  __shared__ f4 s_val[WAVES][CAP];
+  __shared__ int s_rp[WAVES][68];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int sub = lane % LPR, grp = lane / LPR;
+  const float *xb = X + sub * 4;
+  int *sc = s_col[wave];
+  f4 *sv = s_val[wave];
+  int *rp = s_rp[wave];
+  const int R = P * iters;                                        // groups of this wave (<= 64)
+  const int g0 = (my_chunk(nchunks) * WAVES + wave) * R;
+  if constexpr (!STATS) {
+    if (g0 >= Mb) return;                                         // wave-uniform
+  }
+  {
+    int gl = g0 + lane;
+    gl = gl < Mb ? gl : Mb;
+    rp[lane] = b_ptr[gl];
+    int ge = g0 + R;
+    ge = ge < Mb ? ge : Mb;
+    if (lane == 0) rp[64] = b_ptr[g0 < Mb ? ge : Mb];
+  }
+  __builtin_amdgcn_wave_barrier();
+  const int k0 = rp[0];
+  const int k1 = R < 64 ? rp[R] : rp[64];
+  const bool fast = (k1 - k0) <= CAP;                             // wave-uniform
+  if (fast) {
+    for (int p0 = 0; p0 < k1 - k0; p0 += 64) {
+      int p = p0 + lane;
+      p = p < k1 - k0 ? p : k1 - k0 - 1;
+      __builtin_amdgcn_global_load_lds(b_col + k0 + p, sc + p0, 4, 0, 0);
+      __builtin_amdgcn_global_load_lds(b_val + k0 + p, sv + p0, 16, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+  }
+  f4 ssum = {0.f, 0.f, 0.f, 0.f}, ssq = ssum;
+  for (int i = 0; i < iters; ++i) {
+    const int lg = i * P + grp;
+    const int g = g0 + lg;
+    const int kb = rp[lg];
+    const int ke = (lg + 1 < 64) ? rp[lg + 1] : rp[64];
+    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    const int pk0 = fast ? k0 : __builtin_amdgcn_readfirstlane(kb);
+    const int pk1 = fast ? k1 : __builtin_amdgcn_readlane(ke, 63);
+    for (int t0 = pk0; t0 < pk1; t0 += CAP) {
+      int kk = kb, kend = ke;
+      if (!fast) {                      // this pass's columns in tiles of CAP through the same LDS slice
+        const int nt = (pk1 - t0) < CAP ? (pk1 - t0) : CAP;
+        for (int p0 = 0; p0 < nt; p0 += 64) {
+          int p = p0 + lane;
+          p = p < nt ? p : nt - 1;
+          __builtin_amdgcn_global_load_lds(b_col + t0 + p, sc + p0, 4, 0, 0);
+          __builtin_amdgcn_global_load_lds(b_val + t0 + p, sv + p0, 16, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        kk = kb > t0 ? kb : t0;
+        kend = ke < t0 + nt ? ke : t0 + nt;
+      }
+      const int base = fast ? k0 : t0;
+      for (; kk < kend; kk += KB) {
+        int c[KB];
+        f4 x[KB];
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+          const int o = (kk + j < kend ? kk + j : kend - 1) - base;
+          c[j] = sc[o];
+        }
+#pragma unroll
+        for (int j = 0; j < KB; ++j) x[j] = ld4(xb + (int64_t)c[j] * ldx);
+#pragma unroll
+        for (int j = 0; j < KB; ++j) {
+          if (kk + j < kend) {            // (uniform within a lane group; a skipped slot re-read a column of this group)
+            const f4 a = sv[kk + j - base];
+            acc0 = fma4(a.x, x[j], acc0);
+            acc1 = fma4(a.y, x[j], acc1);
+            acc2 = fma4(a.z, x[j], acc2);
+            acc3 = fma4(a.w, x[j], acc3);
+          }
+        }
+      }
+      if (fast) break;                  // (everything was staged up front: one trip)
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (g < Mb) {
+      const int r = 4 * g;
+      auto finish = [&](f4 v, int rr) {
+        if (rr < M) {
+          if constexpr (EPI) {
+            v = elu_bwd4(v, ld4_s(epi.e + (int64_t)rr * epi.lde + sub * 4, kStreamNT));
+            if (epi.g) v += ld4_s(epi.g + (int64_t)rr * epi.ldg + sub * 4, kStreamNT);
+          }
+          st4_stream(Y + (int64_t)rr * ldy + sub * 4, v);
+          if constexpr (STATS) {
+            ssum += v;
+            ssq.x = __builtin_fmaf(v.x, v.x, ssq.x); ssq.y = __builtin_fmaf(v.y, v.y, ssq.y);
+            ssq.z = __builtin_fmaf(v.z, v.z, ssq.z); ssq.w = __builtin_fmaf(v.w, v.w, ssq.w);
+          }
+        }
+      };
+      finish(acc0, r);
+      finish(acc1, r + 1);
+      finish(acc2, r + 2);
+      finish(acc3, r + 3);
+    }
+  }
+  if constexpr (STATS) {
+    static_assert(N == 128 && !EPI, "statistics: 128-column rows");
+    __shared__ float s_st[WAVES * P][256];
+    float *st = s_st[wave * P + grp];
+    *reinterpret_cast<f4 *>(st + sub * 4) = ssum;
+    *reinterpret_cast<f4 *>(st + 128 + sub * 4) = ssq;
+    __syncthreads();
+    const int t = threadIdx.x;
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < WAVES * P; ++w) tot += s_st[w][t];
+    stats_part[(int64_t)blockIdx.x * 256 + t] = tot;
+  }
+}
+template <int N>
+__global__ __launch_bounds__(kWG) void spmm_rb4(const int *__restrict__ b_ptr, const int *__restrict__ b_col,
+                                                const f4 *__restrict__ b_val, int M, int Mb, const float *__restrict__ X,
+                                                int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
+  spmm_rb4_body<N, false, false>(b_ptr, b_col, b_val, M, Mb, X, ldx, Y, ldy, nchunks, iters, SpmmEpi{nullptr, 0, nullptr, 0}, nullptr);
+}
+template <int N>
+__global__ __launch_bounds__(kWG) void spmm_rb4_epi(const int *__restrict__ b_ptr, const int *__restrict__ b_col,
+                                                    const f4 *__restrict__ b_val, int M, int Mb, const float *__restrict__ X,
+                                                    int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters,
+                                                    SpmmEpi epi) {
+  spmm_rb4_body<N, true, false>(b_ptr, b_col, b_val, M, Mb, X, ldx, Y, ldy, nchunks, iters, epi, nullptr);
+}
+__global__ __launch_bounds__(kWG) void spmm_rb4_stats(const int *__restrict__ b_ptr, const int *__restrict__ b_col,
+                                                      const f4 *__restrict__ b_val, int M, int Mb, const float *__restrict__ X,
+                                                      int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters,
+                                                      float *__restrict__ stats_part) {
+  spmm_rb4_body<128, false, true>(b_ptr, b_col, b_val, M, Mb, X, ldx, Y, ldy, nchunks, iters, SpmmEpi{nullptr, 0, nullptr, 0},
+                                  stats_part);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Block-diagonal batch assembly from the resident operator pool.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWG) void blockdiag_rowptr(const int *__restrict__ pool_rowptr,
@@ -1385,6 +1596,127 @@ int sn_spmm_csr_stats_f32(const int32_t *rowptr, const int32_t *colind, const fl
   if (workspace_bytes < sn_spmm_csr_stats_workspace_bytes(M)) return SN_E_WORKSPACE;
   return spmm_csr_launch(rowptr, colind, vals, M, K, nnz, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{nullptr, 0, nullptr, 0},
                          stream, static_cast<float *>(workspace), stats_part);
+}
+
+// rb4 kernels: passes per wave, as csr_rows_iters but counted in 4-row groups
+static int rb4_iters(int64_t Mb, int N) {
+  const int P = 64 / (N / 4);
+  static const int forced = env_int("SN_RB4_ITERS", 0);
+  int it = forced > 0 ? forced : 8;
+  if (it * P > 64) it = 64 / P;
+  if (forced <= 0)
+    while (it > 1 && (Mb + (int64_t)4 * P * it - 1) / ((int64_t)4 * P * it) < 8 * kCUs) it >>= 1;
+  return it < 1 ? 1 : it;
+}
+static int64_t rb4_chunks(int64_t Mb, int N, int iters) {
+  const int64_t per_wg = (int64_t)(kWG / 64) * (64 / (N / 4)) * iters;
+  return (Mb + per_wg - 1) / per_wg;
+}
+
+int sn_rb4_count(const int32_t *rowptr, const int32_t *colind, int64_t M, int64_t K, int32_t *b_ptr, void *workspace,
+                 size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (M < 0 || K < 0) return SN_E_SHAPE;
+  if (!fits_i32(M + 4) || !fits_i32(K)) return SN_E_RANGE;
+  if (!rowptr || !b_ptr) return SN_E_NULL;
+  const int64_t Mb = (M + 3) / 4;
+  if (workspace_bytes < sn_scan_workspace_bytes(Mb + 1) || !workspace) return SN_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(b_ptr + Mb, 0, sizeof(int), s);
+  if (e != hipSuccess) return (int)e;
+  if (Mb > 0)
+    hipLaunchKernelGGL((rb4_merge<false>), dim3(grid_for(Mb, kWG)), dim3(kWG), 0, s, rowptr, colind, (const float *)nullptr, M, Mb,
+                       b_ptr, (int *)nullptr, (float *)nullptr);
+  return exclusive_scan_i32(b_ptr, Mb + 1, b_ptr, workspace, workspace_bytes, s);
+}
+
+int sn_rb4_fill(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, const int32_t *b_ptr,
+                int32_t *b_col, float *b_val, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (M < 0 || K < 0) return SN_E_SHAPE;
+  if (!rowptr || !b_ptr) return SN_E_NULL;
+  const int64_t Mb = (M + 3) / 4;
+  if (Mb == 0) return SN_OK;
+  if (!colind || !vals || !b_col || !b_val) return SN_E_NULL;
+  if (!aligned16(b_val)) return SN_E_ALIGN;
+  hipLaunchKernelGGL((rb4_merge<true>), dim3(grid_for(Mb, kWG)), dim3(kWG), 0, static_cast<hipStream_t>(stream), rowptr, colind,
+                     vals, M, Mb, const_cast<int *>(b_ptr), b_col, b_val);
+  return launch_status();
+}
+
+static int spmm_rb4_launch(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K, int64_t capacity,
+                           const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, SpmmEpi epi, void *stream,
+                           float *stats_part = nullptr, double *stats_out = nullptr) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (M < 0 || K < 0 || capacity < 0 || N < 1) return SN_E_SHAPE;
+  if (!fits_i32(M + 4) || !fits_i32(K) || !fits_i32(capacity)) return SN_E_RANGE;
+  if (M == 0) return SN_OK;
+  if (!b_ptr || (capacity > 0 && (!b_col || !b_val))) return SN_E_NULL;
+  int st = check_dense(Y, ldy, 1, N);
+  if (st) return st;
+  if (K > 0 || capacity > 0) {
+    st = check_dense(X, ldx, 1, N);
+    if (st) return st;
+  }
+  if (N != 64 && N != 128) return SN_E_UNSUPPORTED;
+  if (!aligned16(X) || !aligned16(Y) || !aligned16(b_val) || ldx % 4 || ldy % 4) return SN_E_ALIGN;
+  if (epi.e) {
+    st = check_dense(epi.e, epi.lde, 1, N);
+    if (!st && epi.g) st = check_dense(epi.g, epi.ldg, 1, N);
+    if (st) return st;
+    if (!aligned16(epi.e) || epi.lde % 4 || (epi.g && (!aligned16(epi.g) || epi.ldg % 4))) return SN_E_ALIGN;
+  }
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipEvent_t t_start, t_stop;
+  timing_slot(32 | (epi.e ? 2 : 0) | (epi.g ? 4 : 0) | (stats_part ? 16 : 0), M, K, capacity, N, &t_start, &t_stop);
+  const int64_t Mb = (M + 3) / 4;
+  const int iters = rb4_iters(Mb, N);
+  const int64_t nchunks = rb4_chunks(Mb, N, iters);
+  const unsigned grid = chunk_grid(nchunks);
+  const f4 *bv = reinterpret_cast<const f4 *>(b_val);
+  if (stats_part) {
+    if (epi.e || N != 128) return SN_E_UNSUPPORTED;
+    if (!stats_out) return SN_E_NULL;
+    SN_KLAUNCH(spmm_rb4_stats, grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters, stats_part);
+    hipLaunchKernelGGL(spmm_stats_reduce_k, dim3(kSpmmStatsBlocks), dim3(kWG), 0, s, stats_part, (int64_t)grid, stats_out);
+    return launch_status();
+  }
+  if (epi.e) {
+    if (N == 128) SN_KLAUNCH((spmm_rb4_epi<128>), grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters, epi);
+    else SN_KLAUNCH((spmm_rb4_epi<64>), grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters, epi);
+  } else {
+    if (N == 128) SN_KLAUNCH((spmm_rb4<128>), grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters);
+    else SN_KLAUNCH((spmm_rb4<64>), grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters);
+  }
+  return launch_status();
+}
+
+int sn_spmm_rb4_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K, int64_t capacity,
+                    const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, void *stream) {
+  return spmm_rb4_launch(b_ptr, b_col, b_val, M, K, capacity, X, ldx, N, Y, ldy, SpmmEpi{nullptr, 0, nullptr, 0}, stream);
+}
+
+int sn_spmm_rb4_elubwd_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K,
+                           int64_t capacity, const float *X, int64_t ldx, int32_t N, const float *E, int64_t lde,
+                           const float *G, int64_t ldg, float *Y, int64_t ldy, void *stream) {
+  if (!E) return SN_E_NULL;
+  return spmm_rb4_launch(b_ptr, b_col, b_val, M, K, capacity, X, ldx, N, Y, ldy, SpmmEpi{E, lde, G, ldg}, stream);
+}
+
+size_t sn_spmm_rb4_stats_workspace_bytes(int64_t M) {
+  if (M < 1) return 0;
+  const int64_t Mb = (M + 3) / 4;
+  return (size_t)chunk_grid(rb4_chunks(Mb, 128, rb4_iters(Mb, 128))) * 256 * sizeof(float);
+}
+
+int sn_spmm_rb4_stats_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K,
+                          int64_t capacity, const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, double *stats_part,
+                          void *workspace, size_t workspace_bytes, void *stream) {
+  if (!stats_part || !workspace) return SN_E_NULL;
+  if (M < 1) return SN_E_SHAPE;
+  if (workspace_bytes < sn_spmm_rb4_stats_workspace_bytes(M)) return SN_E_WORKSPACE;
+  return spmm_rb4_launch(b_ptr, b_col, b_val, M, K, capacity, X, ldx, N, Y, ldy, SpmmEpi{nullptr, 0, nullptr, 0}, stream,
+                         static_cast<float *>(workspace), stats_part);
 }
 
 static int spmm_bsr4_launch(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb, int64_t Kb,

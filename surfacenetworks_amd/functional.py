@@ -19,9 +19,21 @@ from . import kernels
 from .operators import SparseOperator, as_operator
 
 __all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg_propagate", "bn_linear", "bnlin_forward",
-           "bnlin_backward", "bn_prepare", "set_dirac_format", "SpmmTimer", "thin_linear", "thin_linear_supported"]
+           "bnlin_backward", "bn_prepare", "set_dirac_format", "set_laplacian_format", "SpmmTimer", "thin_linear", "thin_linear_supported"]
 
 _DIRAC_FORMAT = "q3"
+_LAPLACIAN_FORMAT = "rb4"
+
+
+def set_laplacian_format(fmt: str) -> None:
+    """Kernel / storage form of the group-1 (Laplacian-type) products at 64 / 128 dense columns:
+    'rb4' (default) 4x1 row blocks — four consecutive rows share one gather per distinct column; built from the CSR
+                    arrays on the device the first time an operator is used (bit-identical results for finite inputs);
+    'csr'           always the generic CSR kernel."""
+    global _LAPLACIAN_FORMAT
+    if fmt not in ("rb4", "csr"):
+        raise ValueError(fmt)
+    _LAPLACIAN_FORMAT = fmt
 
 
 def set_dirac_format(fmt: str) -> None:
@@ -85,7 +97,7 @@ class SpmmTimer:
         for i, (tag, op) in enumerate(self.tags):
             kind, M, K, _, N = meta[i]
             nnz = op if isinstance(op, int) else op.nnz
-            fmt = ("/q3" if kind & 8 else "/bsr4" if kind & 1 else "/csr") + ("+e" if kind & 2 else "") + \
+            fmt = ("/rb4" if kind & 32 else "/q3" if kind & 8 else "/bsr4" if kind & 1 else "/csr") + ("+e" if kind & 2 else "") + \
                 ("+g" if kind & 4 else "") + ("+s" if kind & 16 else "")
             out.append((tag + fmt, int(M), int(K), int(nnz), int(N), float(ms[i])))
         return out
@@ -125,6 +137,11 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
             kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
         else:
             kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, x, e, g, y, group)
+    elif _LAPLACIAN_FORMAT == "rb4" and kernels.spmm_rb4_supported(y.shape[1] // group, group) and op.rb4() is not None:
+        r = op.rb4()                                   # Laplacian-type operator: one gather per listed column of a 4-row group
+        if stats and e is None and y.shape[1] == 128:
+            return kernels.spmm_rb4_stats(r[0], r[1], r[2], M, K, x, y)
+        kernels.spmm_rb4(r[0], r[1], r[2], M, K, x, y, e, g)
     elif elubwd is None:
         if stats and kernels.spmm_csr_stats_supported(y.shape[1] // group, group):
             return kernels.spmm_csr_stats(op.rowptr, op.colind, op.vals, M, K, x, y)

@@ -40,6 +40,17 @@ def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
             out.extend(o._bsr4)
         if isinstance(o._q3, tuple):
             out.extend(o._q3)
+        # A plain CSR operator (Laplacian-type) is multiplied through its 4x1 row-blocked form, derived from the CSR arrays
+        # on first use and cached on the operator.  Under a graph that derived form must be an INPUT like the arrays it
+        # comes from — a form cached during warm-up would otherwise be replayed against every later batch — so it is built
+        # here (for the example and for every batch that is loaded) and listed with them.
+        if o._csr is not None and not isinstance(o._bsr4, tuple) and not isinstance(o._q3, tuple):
+            from . import functional as snF
+
+            if snF._LAPLACIAN_FORMAT == "rb4" and o.is_cuda:
+                r = o.rb4()
+                if r is not None:
+                    out.extend(r)
     return out
 
 

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 __all__ = [
-    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged",
+    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
@@ -80,6 +80,60 @@ def spmm_csr_stats(rowptr, colind, vals, M: int, K: int, x, y):
     ws_bytes = int(lib.sn_spmm_csr_stats_workspace_bytes(M))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=y.device)
     _lib.call("sn_spmm_csr_stats_f32", _p(rowptr), _p(colind), _p(vals), M, K, int(colind.numel()), _p(x), ldx, 1, N, _p(y), ldy, 1,
+              _p(part), _p(ws), ws_bytes, _stream())
+    return part
+
+
+def csr_to_rb4(rowptr, colind, vals, M: int, K: int):
+    """CSR -> RB4 (4x1 row blocks): (b_ptr [ceil(M/4)+1], b_col [nnz], b_val [nnz, 4]).  No synchronisation: the arrays are
+    sized by nnz, an upper bound of the listed-column total (the tail past b_ptr[-1] is never read)."""
+    _dev(rowptr, colind, vals)
+    dev = rowptr.device
+    Mb = (M + 3) // 4
+    nnz = int(colind.numel())
+    b_ptr = torch.empty(Mb + 1, dtype=torch.int32, device=dev)
+    ws_bytes = int(_lib.load().sn_scan_workspace_bytes(Mb + 1))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    _lib.call("sn_rb4_count", _p(rowptr), _p(colind), M, K, _p(b_ptr), _p(ws), ws_bytes, _stream())
+    b_col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
+    b_val = torch.empty((max(nnz, 1), 4), dtype=torch.float32, device=dev)[:nnz]
+    _lib.call("sn_rb4_fill", _p(rowptr), _p(colind), _p(vals), M, K, _p(b_ptr), _p(b_col), _p(b_val), _stream())
+    return b_ptr, b_col, b_val
+
+
+def spmm_rb4_supported(N: int, group: int) -> bool:
+    return group == 1 and N in (64, 128)
+
+
+def spmm_rb4(b_ptr, b_col, b_val, M: int, K: int, x, y, e=None, g=None) -> None:
+    """y <- A·x for an RB4 operator (sn_spmm_rb4_f32); with e: (A·x) * elu'(e) + g (sn_spmm_rb4_elubwd_f32)."""
+    _dev(b_ptr, b_col, b_val, x, y, e, g)
+    N = y.shape[1]
+    ldx = _check_dense(x, K, 1, N, "x")
+    ldy = _check_dense(y, M, 1, N, "y")
+    cap = int(b_col.numel())
+    if e is None:
+        _lib.call("sn_spmm_rb4_f32", _p(b_ptr), _p(b_col), _p(b_val), M, K, cap, _p(x), ldx, N, _p(y), ldy, _stream())
+    else:
+        lde = _check_dense(e, M, 1, N, "e")
+        ldg = _check_dense(g, M, 1, N, "g") if g is not None else 0
+        _lib.call("sn_spmm_rb4_elubwd_f32", _p(b_ptr), _p(b_col), _p(b_val), M, K, cap, _p(x), ldx, N, _p(e), lde, _p(g), ldg,
+                  _p(y), ldy, _stream())
+
+
+def spmm_rb4_stats(b_ptr, b_col, b_val, M: int, K: int, x, y):
+    """spmm_rb4 (N = 128) that also returns the (blocks, 2, 128) float64 partial column statistics of y."""
+    _dev(b_ptr, b_col, b_val, x, y)
+    N = y.shape[1]
+    if N != 128:
+        raise ValueError("spmm_rb4_stats: 128-column operands only")
+    ldx = _check_dense(x, K, 1, N, "x")
+    ldy = _check_dense(y, M, 1, N, "y")
+    lib = _lib.load()
+    part = torch.empty((int(lib.sn_spmm_q3_stats_blocks()), 2, 128), dtype=torch.float64, device=y.device)
+    ws_bytes = int(lib.sn_spmm_rb4_stats_workspace_bytes(M))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=y.device)
+    _lib.call("sn_spmm_rb4_stats_f32", _p(b_ptr), _p(b_col), _p(b_val), M, K, int(b_col.numel()), _p(x), ldx, N, _p(y), ldy,
               _p(part), _p(ws), ws_bytes, _stream())
     return part
 

@@ -68,6 +68,7 @@ class SparseOperator:
         self._t_weak = weakref.ref(transpose) if transpose is not None else None
         self._bsr4 = bsr4                        # (b_rowptr, b_colind, b_vals) | None | False (= not worthwhile)
         self._q3 = q3                            # (b_rowptr, q_blk) quaternion-packed form | None (unknown) | False (not a Dirac-type operator)
+        self._rb4 = None                         # (b_ptr, b_col, b_val) 4x1 row-blocked form | None (not built) | False (not worthwhile)
 
     @property
     def _t(self) -> "Optional[SparseOperator]":
@@ -203,6 +204,18 @@ class SparseOperator:
         opt = cls(None, None, None, (K, M), batch=batch, q3=tuple(bwd), transpose=op)
         op._t = opt
         return op
+
+    def rb4(self):
+        """(b_ptr, b_col, b_val): the 4x1 row-blocked form used by the Laplacian-type (group-1) products, built on the
+        device on first use without a host synchronisation; None for operators with fewer than 2 entries per row on
+        average (nothing to share between the rows of a group)."""
+        if self._rb4 is None:
+            M, K = self._shape
+            if self.nnz < 2 * M:
+                self._rb4 = False
+            else:
+                self._rb4 = kernels.csr_to_rb4(self.rowptr, self.colind, self.vals, M, K)
+        return self._rb4 or None
 
     def bsr4(self):
         """(b_rowptr, b_colind, b_vals) or None when the 4x4-block form is not applicable / not worthwhile."""

@@ -323,6 +323,65 @@ def spmm_csr_stats(rowptr, colind, vals, M, K, x, y):
     return part
 
 
+def csr_to_rb4(rowptr, colind, vals, M, K):
+    """numpy restatement of sn_rb4_count / sn_rb4_fill: rows 4b..4b+3 share one sorted column list, 4 coefficients each."""
+    rp, ci, va = _np(rowptr), _np(colind), _np(vals)
+    Mb = (M + 3) // 4
+    b_ptr = np.zeros(Mb + 1, np.int32)
+    cols, coefs = [], []
+    for b in range(Mb):
+        rows = [r for r in range(4 * b, min(4 * b + 4, M))]
+        u = np.unique(np.concatenate([ci[rp[r]: rp[r + 1]] for r in rows])) if rows else np.zeros(0, np.int32)
+        blk = np.zeros((len(u), 4), np.float32)
+        for q, r in enumerate(rows):
+            blk[np.searchsorted(u, ci[rp[r]: rp[r + 1]]), q] = va[rp[r]: rp[r + 1]]
+        cols.append(u.astype(np.int32))
+        coefs.append(blk)
+        b_ptr[b + 1] = b_ptr[b] + len(u)
+    nnz = len(ci)
+    b_col = np.zeros(nnz, np.int32)
+    b_val = np.zeros((nnz, 4), np.float32)
+    tot = int(b_ptr[-1])
+    if tot:
+        b_col[:tot] = np.concatenate(cols)
+        b_val[:tot] = np.concatenate(coefs)
+    return torch.from_numpy(b_ptr), torch.from_numpy(b_col), torch.from_numpy(b_val)
+
+
+def spmm_rb4_supported(N, group):
+    return group == 1 and N in (64, 128)
+
+
+def _rb4_to_csr(b_ptr, b_col, b_val, M):
+    """Expand RB4 back to CSR with the explicit zeros kept: the oracle then runs the kernel's own arithmetic order."""
+    bp, bc, bv = _np(b_ptr), _np(b_col), _np(b_val)
+    cnt = np.diff(bp)
+    rowptr = np.zeros(M + 1, np.int32)
+    rowptr[1:] = np.cumsum(np.repeat(cnt, 4)[:M])
+    colind = np.empty(rowptr[-1], np.int32)
+    vals = np.empty(rowptr[-1], np.float32)
+    for r in range(M):
+        sl = slice(bp[r // 4], bp[r // 4 + 1])
+        colind[rowptr[r]: rowptr[r + 1]] = bc[sl]
+        vals[rowptr[r]: rowptr[r + 1]] = bv[sl, r % 4]
+    return torch.from_numpy(rowptr), torch.from_numpy(colind), torch.from_numpy(vals)
+
+
+def spmm_rb4(b_ptr, b_col, b_val, M, K, x, y, e=None, g=None):
+    rp, ci, va = _rb4_to_csr(b_ptr, b_col, b_val, M)
+    spmm_csr(rp, ci, va, M, K, x, y, 1)
+    if e is not None:
+        _elubwd_epilogue(y, e, g)
+
+
+def spmm_rb4_stats(b_ptr, b_col, b_val, M, K, x, y):
+    spmm_rb4(b_ptr, b_col, b_val, M, K, x, y)
+    part = torch.zeros((1, 2, 128), dtype=torch.float64)
+    part[0, 0] = y.double().sum(0)
+    part[0, 1] = (y.double() ** 2).sum(0)
+    return part
+
+
 def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y=True, elu_stats=None):
     y = (x.double() @ W.double().t() + bias.double()).float()
     if residual is not None:

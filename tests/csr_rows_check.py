@@ -27,7 +27,8 @@ def ragged_csr(M, K, rng, long_rows=()):
     lens[rng.integers(0, M, size=max(1, M // 9))] = 0                      # empty rows, also first / last
     lens[0] = lens[-1] = 0
     for r, n in long_rows:
-        lens[r] = min(n, K)
+        lens[r] = n
+    lens = np.minimum(lens, K)
     rows = np.repeat(np.arange(M), lens)
     cols = np.concatenate([np.sort(rng.choice(K, size=n, replace=False)) for n in lens]) if lens.sum() else np.zeros(0, np.int64)
     A = sp.csr_matrix((rng.standard_normal(len(rows)).astype(np.float32), (rows, cols)), shape=(M, K))
@@ -37,6 +38,7 @@ def ragged_csr(M, K, rng, long_rows=()):
 
 def main():
     rng = np.random.default_rng(int(os.environ.get("SN_CSR_ITERS", "0")) + 11)
+    assert os.environ.get("SN_RB4_ITERS", os.environ.get("SN_CSR_ITERS", "0")) is not None
     for N in (128, 64, 32, 16):
         for (M, K, long_rows) in [(1031, 777, ()), (257, 900, ((5, 700), (6, 3), (130, 900))), (64, 64, ()), (3, 5, ()),
                                   (4099, 4099, ((4098, 600),))]:
@@ -73,6 +75,43 @@ def main():
                     ref = np.stack([w64.sum(0), (w64 * w64).sum(0)])
                     scale = np.stack([np.abs(w64).sum(0), (w64 * w64).sum(0)]) + 1e-30
                     assert (np.abs(got - ref) / scale).max() < 1e-6, ("stats", M)
+    # ---- RB4 (4x1 row blocks): conversion == numpy restatement, product == CSR oracle on the original operator ----
+    import cpu_kernels as ck
+
+    for N in (128, 64):
+        for (M, K, long_rows) in [(1031, 777, ()), (258, 900, ((5, 700), (6, 3), (130, 900))), (64, 64, ()), (3, 5, ()), (1, 9, ()),
+                                  (4099, 4099, ((4098, 600),))]:
+            A = ragged_csr(M, K, rng, long_rows)
+            x = rng.standard_normal((K, N)).astype(np.float32)
+            want = c_oracle.spmm_csr(A.indptr, A.indices, A.data, x.ravel(), N).reshape(M, N)
+            rp, ci, va = dev(A.indptr.astype(np.int32)), dev(A.indices.astype(np.int32)), dev(A.data)
+            b = kernels.csr_to_rb4(rp, ci, va, M, K)
+            wb = ck.csr_to_rb4(rp.cpu(), ci.cpu(), va.cpu(), M, K)
+            tot = int(wb[0][-1])
+            assert np.array_equal(b[0].cpu().numpy(), wb[0].numpy()), ("rb4 ptr", M)
+            assert np.array_equal(b[1].cpu().numpy()[:tot], wb[1].numpy()[:tot]) and np.array_equal(b[2].cpu().numpy()[:tot], wb[2].numpy()[:tot])
+            xcat = torch.full((K, 2 * N), float("nan"), device=DEV)
+            xcat[:, :N] = dev(x)
+            ycat = torch.full((M, 2 * N), float("nan"), device=DEV)
+            kernels.spmm_rb4(b[0], b[1], b[2], M, K, xcat[:, :N], ycat[:, N:])
+            assert np.array_equal(ycat[:, N:].cpu().numpy(), want) and torch.isnan(ycat[:, :N]).all(), ("rb4", N, M)
+            e = rng.standard_normal((M, N)).astype(np.float32)
+            g = rng.standard_normal((M, N)).astype(np.float32)
+            d = np.where(e > 0, np.float32(1), e + np.float32(1)).astype(np.float32)
+            for gg in (g, None):
+                ye = torch.full((M, N), float("nan"), device=DEV)
+                kernels.spmm_rb4(b[0], b[1], b[2], M, K, dev(x), ye, dev(e), dev(gg) if gg is not None else None)
+                w = want * d if gg is None else want * d + gg
+                assert np.array_equal(ye.cpu().numpy(), w.astype(np.float32)), ("rb4 epi", N, M)
+            if N == 128:
+                ys = torch.full((M, N), float("nan"), device=DEV)
+                part = kernels.spmm_rb4_stats(b[0], b[1], b[2], M, K, dev(x), ys)
+                assert np.array_equal(ys.cpu().numpy(), want), ("rb4 stats y", M)
+                got = part.sum(0).cpu().numpy()
+                w64 = want.astype(np.float64)
+                ref = np.stack([w64.sum(0), (w64 * w64).sum(0)])
+                scale = np.stack([np.abs(w64).sum(0), (w64 * w64).sum(0)]) + 1e-30
+                assert (np.abs(got - ref) / scale).max() < 1e-6, ("rb4 stats", M)
     # group-4 (quaternion view) operands through the generic kernel
     M, K, N = 4 * 300, 4 * 211, 32
     A = ragged_csr(M, K, rng)

@@ -453,7 +453,7 @@ def test_csr_rows_kernel_all_pass_counts(iters):
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, SN_CSR_ITERS=iters, SN_CSR_VARIANT="2")
+    env = dict(os.environ, SN_CSR_ITERS=iters, SN_RB4_ITERS=iters, SN_CSR_VARIANT="2")
     out = subprocess.run([sys.executable, os.path.join(here, "csr_rows_check.py")], env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and out.stdout.strip().endswith("OK"), out.stdout[-1500:] + out.stderr[-1500:]
 
@@ -480,6 +480,11 @@ def test_csr_rows_kernel_large_batch_multi_pass():
     assert np.array_equal(y.cpu().numpy(), want)
     part = kernels.spmm_csr_stats(rp, ci, va, M, K, dev(x), y)
     assert np.array_equal(y.cpu().numpy(), want)
+    b = kernels.csr_to_rb4(rp, ci, va, M, K)                      # the 4x1 row-blocked form of the same operator
+    y2 = torch.empty((M, N), device=DEV)
+    part2 = kernels.spmm_rb4_stats(b[0], b[1], b[2], M, K, dev(x), y2)
+    assert torch.equal(y2, y)
+    assert np.allclose(part2.sum(0).cpu().numpy(), part.sum(0).cpu().numpy(), rtol=1e-9)
     w64 = want.astype(np.float64)
     ref = np.stack([w64.sum(0), (w64 * w64).sum(0)])
     assert np.allclose(part.sum(0).cpu().numpy(), ref, rtol=1e-6, atol=1e-6 * np.abs(w64).sum(0).max())

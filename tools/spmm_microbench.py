@@ -75,7 +75,7 @@ def main():
     C = 64 if workload == "mnist" else 128
     only = os.environ.get("SN_MB_ONLY", "")
     for name, group in [("Di", 4), ("DiA", 4), ("L", 1)]:
-        if only == "bsr4" and group != 4:
+        if (only == "bsr4" and group != 4) or (only == "L" and group != 1):
             continue
         mats = [m[name] for m in meshes]
         s0 = max(m.shape[0] for m in mats)
@@ -94,6 +94,14 @@ def main():
             ab = alg_bytes(real[tag][0], real[tag][1], o.nnz, N)     # real (unpadded) sizes, whatever the layout
             ms = time_launch(lambda: kernels.spmm_csr(o.rowptr, o.colind, o.vals, M, K, x, y, group)) if only != "bsr4" else float("nan")
             print(f"{workload}/{layout} {name:3s} {tag:6s} csr  N={N:3d} M={M} K={K} nnz={o.nnz} algMB={ab / 1e6:.1f} ms={ms:.4f} GB/s={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f}", flush=True)
+            if group == 1:                                   # Laplacian-type: the 4x1 row-blocked form (default of the product)
+                r = o.rb4()
+                if r is not None:
+                    y4 = torch.empty_like(y)
+                    ms = time_launch(lambda: kernels.spmm_rb4(r[0], r[1], r[2], M, K, x, y4))
+                    tot = int(r[0][-1].item())
+                    actual = tot * 20 + (M // 4 + 1) * 4 + real[tag][1] * N * 4 + real[tag][0] * N * 4
+                    print(f"{workload}/{layout} {name:3s} {tag:6s} rb4  N={N:3d} listed={tot} ({tot / max(M, 1):.2f}/row vs {o.nnz / max(M, 1):.2f} entries/row) actualMB={actual / 1e6:.1f} ms={ms:.4f} GB/s(alg)={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f} equal={torch.equal(y, y4)}", flush=True)
             if group == 4:
                 b = o.bsr4()
                 y2 = torch.empty_like(y)
