@@ -233,14 +233,14 @@ __global__ __launch_bounds__(kWG) void spmm_csr_lds_epi(const int *__restrict__ 
 // ------------------------------------------------------------------------------------------------
 // CSR SpMM, several row passes per wave ("rows" kernel) — the Laplacian kernel (N = 128: the products at utils_pt.py:167,176).
 //
-// spmm_csr_lds gives a wave ONE pass of P = 256/N rows: at N = 128 that is 2 rows, ~14 entries, 1 KiB of unique X and 1 KiB
-// of Y per wave, reached through three dependent memory round trips (row pointers -> entry run -> gathers).  Per byte moved
-// that is ~3x the fixed cost of the Dirac block kernels, and the kernel sat at 47-62 % of the roofline where those reach
-// 80 %+.  Here a wave owns R = P*iters consecutive rows: ONE coalesced load fetches its R+1 row pointers, the whole entry
-// run of those rows (R*7 entries for a Laplacian) goes to the wave's LDS slice with a few DMA instructions, and the wave
-// then walks its passes with nothing but LDS reads, gathers and stores — the two leading round trips are paid once per R
-// rows.  Same k-ascending FMA chain per row as every other CSR kernel (bit-identical results).  A wave whose entry run
-// exceeds the LDS slice (rows far longer than a mesh operator's) stages each pass's entries in tiles instead.
+// spmm_csr_lds gives a wave ONE pass of P = 256/N rows.  Here a wave owns R = P*iters consecutive rows: ONE coalesced load
+// fetches its R+1 row pointers, the whole entry run of those rows goes to the wave's LDS slice with a few DMA instructions,
+// and the wave then walks its passes with LDS reads, gathers and stores only.  Measured on the Laplacian batches (N = 128):
+// +3 % at 2 passes, slower from 8 passes on (the row ranges the resident waves walk concurrently outgrow the XCD's L2) — the
+// leading round trips are NOT what bounds this product; the gather stream through the 32 KiB vector cache is (PMC,
+// DESIGN.md §4), which is what the RB4 form below attacks.  This kernel remains the generic CSR path and carries the
+// statistics epilogue.  Same k-ascending FMA chain per row as every other CSR kernel (bit-identical results).  A wave whose
+// entry run exceeds the LDS slice (rows far longer than a mesh operator's) stages each pass's entries in tiles instead.
 // STATS (N = 128, YG = 1): the workgroup also leaves the column sums / sums of squares of its output rows in
 // stats_part[blockIdx.x][2][128] (fp32 over <= 256 rows, combined in fp64 by spmm_stats_reduce_k) — the BatchNorm statistics
 // of the propagated half [e | L·e] of a Laplacian stage, so that no statistics pass reads it back.
@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(kWG) void rb4_merge(const int *__restrict__ rowptr,
 // wave staged once).  Per listed column one gather of the X row serves all four output rows.  k-ascending FMA chain per
 // row; the zero coefficients contribute fma(0, x, acc) = acc, so results are bit-identical to the CSR kernels for finite X.
 // ------------------------------------------------------------------------------------------------
-template <int N, bool EPI, bool STATS>
+template <int N, bool EPI, bool STATS, int KB = 8>
 __device__ __forceinline__ void spmm_rb4_body(const int *__restrict__ b_ptr, const int *__restrict__ b_col,
                                               const f4 *__restrict__ b_val, int M, int Mb, const float *__restrict__ X,
                                               int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters,
@@ -1029,7 +1029,7 @@ __device__ __forceinline__ void spmm_rb4_body(const int *__restrict__ b_ptr, con
   constexpr int P = 64 / LPR;         // groups per pass
   constexpr int WAVES = kWG / 64;
   constexpr int CAP = 256;            // listed columns of a wave's groups held in LDS (5 KiB per wave)
-  constexpr int KB = 8;               // gathers in flight per lane
+                                      // KB: gathers in flight per lane
   __shared__ int s_col[WAVES][CAP];
   __shared__ f4 s_val[WAVES][CAP];
   __shared__ int s_rp[WAVES][68];
@@ -1151,25 +1151,25 @@ __device__ __forceinline__ void spmm_rb4_body(const int *__restrict__ b_ptr, con
     stats_part[(int64_t)blockIdx.x * 256 + t] = tot;
   }
 }
-template <int N>
+template <int N, int KB>
 __global__ __launch_bounds__(kWG) void spmm_rb4(const int *__restrict__ b_ptr, const int *__restrict__ b_col,
                                                 const f4 *__restrict__ b_val, int M, int Mb, const float *__restrict__ X,
                                                 int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters) {
-  spmm_rb4_body<N, false, false>(b_ptr, b_col, b_val, M, Mb, X, ldx, Y, ldy, nchunks, iters, SpmmEpi{nullptr, 0, nullptr, 0}, nullptr);
+  spmm_rb4_body<N, false, false, KB>(b_ptr, b_col, b_val, M, Mb, X, ldx, Y, ldy, nchunks, iters, SpmmEpi{nullptr, 0, nullptr, 0}, nullptr);
 }
 template <int N>
 __global__ __launch_bounds__(kWG) void spmm_rb4_epi(const int *__restrict__ b_ptr, const int *__restrict__ b_col,
                                                     const f4 *__restrict__ b_val, int M, int Mb, const float *__restrict__ X,
                                                     int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters,
                                                     SpmmEpi epi) {
-  spmm_rb4_body<N, true, false>(b_ptr, b_col, b_val, M, Mb, X, ldx, Y, ldy, nchunks, iters, epi, nullptr);
+  spmm_rb4_body<N, true, false, 4>(b_ptr, b_col, b_val, M, Mb, X, ldx, Y, ldy, nchunks, iters, epi, nullptr);
 }
 __global__ __launch_bounds__(kWG) void spmm_rb4_stats(const int *__restrict__ b_ptr, const int *__restrict__ b_col,
                                                       const f4 *__restrict__ b_val, int M, int Mb, const float *__restrict__ X,
                                                       int64_t ldx, float *__restrict__ Y, int64_t ldy, int nchunks, int iters,
                                                       float *__restrict__ stats_part) {
-  spmm_rb4_body<128, false, true>(b_ptr, b_col, b_val, M, Mb, X, ldx, Y, ldy, nchunks, iters, SpmmEpi{nullptr, 0, nullptr, 0},
-                                  stats_part);
+  spmm_rb4_body<128, false, true, 4>(b_ptr, b_col, b_val, M, Mb, X, ldx, Y, ldy, nchunks, iters, SpmmEpi{nullptr, 0, nullptr, 0},
+                                     stats_part);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1492,7 +1492,7 @@ constexpr int kSpmmStatsBlocks = 128;        // partial rows after stage 1 of th
 static int csr_rows_iters(int64_t M, int N) {
   const int P = 64 / (N / 4);
   static const int forced = env_int("SN_CSR_ITERS", 0);
-  int it = forced > 0 ? forced : 16;
+  int it = forced > 0 ? forced : 2;        // (measured best on the config-4 / config-5 Laplacian batches: 2..4 passes)
   if (it * P > 64) it = 64 / P;
   if (forced <= 0)
     while (it > 1 && (M + (int64_t)4 * P * it - 1) / ((int64_t)4 * P * it) < 8 * kCUs) it >>= 1;
@@ -1601,8 +1601,10 @@ int sn_spmm_csr_stats_f32(const int32_t *rowptr, const int32_t *colind, const fl
 // rb4 kernels: passes per wave, as csr_rows_iters but counted in 4-row groups
 static int rb4_iters(int64_t Mb, int N) {
   const int P = 64 / (N / 4);
+  // One pass per wave by default: with more, the row ranges the resident waves of an XCD walk concurrently no longer fit
+  // its 4 MiB L2 together with their neighbours' X rows (measured: 0.59 -> 0.47 of the roofline from 1 to 8 passes).
   static const int forced = env_int("SN_RB4_ITERS", 0);
-  int it = forced > 0 ? forced : 8;
+  int it = forced > 0 ? forced : 1;
   if (it * P > 64) it = 64 / P;
   if (forced <= 0)
     while (it > 1 && (Mb + (int64_t)4 * P * it - 1) / ((int64_t)4 * P * it) < 8 * kCUs) it >>= 1;
@@ -1685,8 +1687,11 @@ static int spmm_rb4_launch(const int32_t *b_ptr, const int32_t *b_col, const flo
     if (N == 128) SN_KLAUNCH((spmm_rb4_epi<128>), grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters, epi);
     else SN_KLAUNCH((spmm_rb4_epi<64>), grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters, epi);
   } else {
-    if (N == 128) SN_KLAUNCH((spmm_rb4<128>), grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters);
-    else SN_KLAUNCH((spmm_rb4<64>), grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters);
+    // 4 gathers in flight per lane: measured best (config-4 / config-5 batches, MI355X) against 2 / 8 / 12 / 16 — the
+    // vector cache (32 KiB per CU) holds 64 X rows of 128 channels, and every additional gather in flight evicts lines that
+    // neighbouring row groups are about to re-use
+    if (N == 128) SN_KLAUNCH((spmm_rb4<128, 4>), grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters);
+    else SN_KLAUNCH((spmm_rb4<64, 4>), grid, s, b_ptr, b_col, bv, (int)M, (int)Mb, X, ldx, Y, ldy, (int)nchunks, iters);
   }
   return launch_status();
 }

@@ -97,7 +97,8 @@ def csr_to_rb4(rowptr, colind, vals, M: int, K: int):
     _lib.call("sn_rb4_count", _p(rowptr), _p(colind), M, K, _p(b_ptr), _p(ws), ws_bytes, _stream())
     b_col = torch.empty(max(nnz, 1), dtype=torch.int32, device=dev)[:nnz]
     b_val = torch.empty((max(nnz, 1), 4), dtype=torch.float32, device=dev)[:nnz]
-    _lib.call("sn_rb4_fill", _p(rowptr), _p(colind), _p(vals), M, K, _p(b_ptr), _p(b_col), _p(b_val), _stream())
+    if nnz:
+        _lib.call("sn_rb4_fill", _p(rowptr), _p(colind), _p(vals), M, K, _p(b_ptr), _p(b_col), _p(b_val), _stream())
     return b_ptr, b_col, b_val
 
 
