@@ -12,8 +12,13 @@
  *     and workspaces (reference: launchers allocate with values.new(), sparse_bmm.py:53).
  *   - `stream` is a hipStream_t passed as void*; launches are asynchronous and stream-ordered
  *     (reference: launch on torch.cuda.current_stream(), sparse_bmm.py:59, batch_csr.py:56).
- *   - No global mutable state; re-entrant; safe from several host threads on different streams
- *     (the reference keeps module-level caches, sparse_bmm_func.py:20-21 — deliberately not kept).
+ *   - No per-operator or per-shape caches (the reference keeps module-level kernel / handle caches, sparse_bmm_func.py:20-21,
+ *     sparse_bmm.py:26,63 — deliberately not kept); re-entrant; safe from several host threads on different streams.
+ *     The ONLY process-global state of the library: (a) the A/B switches SN_BSR4_VARIANT, SN_CSR_VARIANT, SN_CSR_ITERS,
+ *     SN_RB4_ITERS, SN_GEMM_VARIANT, read ONCE from the environment (they select between kernels that compute the same
+ *     result, for measurements); (b) the opt-in per-launch timing facility sn_timing_* below (a mutex-guarded list, off by
+ *     default).  Neither affects results.  The Python layer adds three process-wide selectors with the same property:
+ *     functional.set_dirac_format / set_laplacian_format (kernel form) and set_bn_sync (opt-in global BatchNorm statistics).
  *   - Return value: 0 = success; negative = SN_E_* invalid argument; positive = hipError_t of the
  *     failed launch.  sn_status_string() renders either.
  *   - Indices are int32 (the reference uses int64, utils_pt.py:62, sparse_bmm.cu:17); an operator
@@ -271,6 +276,18 @@ int sn_blockdiag_concat_ragged_i32(const int32_t *pool_rowptr, const int32_t *po
                                    int64_t total, int32_t vals_per_entry,
                                    int32_t *out_rowptr, int32_t *out_colind, float *out_vals,
                                    void *stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Debug validation of a CSR operator on the device.  The reference kernels index without any bounds check
+ * (src/utils/cuda/sparse_bmm.cu:16-61, batch_csr.cu:13-47) and so do the product kernels here (an out-of-range column is
+ * an out-of-bounds gather); this entry point is the opt-in check.  *flags (device int32) receives a bit set:
+ *   1 rowptr[0] != 0 | 2 rowptr not non-decreasing | 4 rowptr[M] != nnz | 8 column index outside [0, K) |
+ *   16 column indices of a row not strictly ascending (operator not coalesced) | 32 non-finite value (vals may be NULL).
+ * 0 = the operator is well formed.  The Python layer runs it on every operator it builds when SN_DEBUG_VALIDATE=1 and
+ * raises (status SN_E_RANGE semantics) — see surfacenetworks_amd/operators.py.
+ * ------------------------------------------------------------------------------------------ */
+int sn_validate_csr_i32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
+                        int32_t *flags, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused elementwise helpers of the residual blocks (each replaces separate ATen passes).

@@ -45,6 +45,7 @@ SIGNATURES = {
     "sn_spmm_rb4_stats_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sn_blockdiag_concat_i32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sn_blockdiag_concat_ragged_i32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "sn_validate_csr_i32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _vp]),
     "sn_elu_into_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp]),
     "sn_elu_bwd_acc_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp]),
     "sn_colstats_workspace_bytes": (_sz, [_i64, _i32]),

@@ -1288,6 +1288,36 @@ __global__ __launch_bounds__(kWG) void blockdiag_entries_ragged(const int *__res
 }
 
 // ------------------------------------------------------------------------------------------------
+// Debug validation of a CSR operator (the reference kernels have no bounds checks at all: sparse_bmm.cu:16-61).
+// flags: bit 0 rowptr[0] != 0, bit 1 rowptr decreasing, bit 2 rowptr[M] != nnz, bit 3 column index out of [0, K),
+//        bit 4 column indices of a row not strictly ascending (operator not coalesced), bit 5 non-finite value.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kWG) void validate_csr_k(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                      const float *__restrict__ vals, int64_t M, int64_t K, int64_t nnz,
+                                                      int *__restrict__ flags) {
+  int bad = 0;
+  for (int64_t r = (int64_t)blockIdx.x * kWG + threadIdx.x; r < M; r += (int64_t)gridDim.x * kWG) {
+    const int b = rowptr[r], e = rowptr[r + 1];
+    if (r == 0 && b != 0) bad |= 1;
+    if (e < b) bad |= 2;
+    if (r == M - 1 && e != (int)nnz) bad |= 4;
+    if (b < 0 || e > nnz || e < b) continue;             // do not follow a broken pointer
+    int prev = -1;
+    for (int k = b; k < e; ++k) {
+      const int c = colind[k];
+      if (c < 0 || c >= K) bad |= 8;
+      if (c <= prev) bad |= 16;
+      prev = c;
+      if (vals) {
+        const float v = vals[k];
+        if (!(v == v) || v - v != 0.f) bad |= 32;
+      }
+    }
+  }
+  if (bad) atomicOr(flags, bad);
+}
+
+// ------------------------------------------------------------------------------------------------
 // ELU helpers (alpha = 1, as F.elu defaults in the reference).
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
@@ -2018,6 +2048,21 @@ int sn_blockdiag_concat_ragged_i32(const int32_t *pool_rowptr, const int32_t *po
     else
       hipLaunchKernelGGL((blockdiag_entries_ragged<16>), dim3(grid), dim3(kWG), 0, s, pool_colind, pool_vals, desc, B, total, out_colind, out_vals);
   }
+  return launch_status();
+}
+
+int sn_validate_csr_i32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
+                        int32_t *flags, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (M < 0 || K < 0 || nnz < 0) return SN_E_SHAPE;
+  if (!fits_i32(M + 1) || !fits_i32(K) || !fits_i32(nnz)) return SN_E_RANGE;
+  if (!flags) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(flags, 0, sizeof(int32_t), s);
+  if (e != hipSuccess) return (int)e;
+  if (M == 0) return SN_OK;
+  if (!rowptr || (nnz > 0 && !colind)) return SN_E_NULL;
+  hipLaunchKernelGGL(validate_csr_k, dim3(grid_for(M, kWG)), dim3(kWG), 0, s, rowptr, colind, vals, M, K, nnz, flags);
   return launch_status();
 }
 

@@ -13,6 +13,8 @@ Dense operands are 2-D (rows, C) fp32 tensors; `group` says how many operator ro
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import kernels
@@ -22,7 +24,7 @@ __all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg
            "bnlin_backward", "bn_prepare", "set_dirac_format", "set_laplacian_format", "SpmmTimer", "thin_linear", "thin_linear_supported"]
 
 _DIRAC_FORMAT = "q3"
-_LAPLACIAN_FORMAT = "rb4"
+_LAPLACIAN_FORMAT = os.environ.get("SN_LAP_FORMAT", "rb4")      # (environment override for A/B measurements)
 
 
 def set_laplacian_format(fmt: str) -> None:

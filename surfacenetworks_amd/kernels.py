@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 __all__ = [
-    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged",
+    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged", "validate_csr",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
@@ -289,6 +289,14 @@ def blockdiag_concat_ragged(pool_rowptr, pool_colind, pool_vals, desc, total_row
     _lib.call("sn_blockdiag_concat_ragged_i32", _p(pool_rowptr), _p(pool_colind), _p(pool_vals), _p(desc), B, total_rows,
               total_cols, total, vpe, _p(out_rowptr), _p(out_colind), _p(out_vals), _stream())
     return out_rowptr, out_colind, out_vals
+
+
+def validate_csr(rowptr, colind, vals, M: int, K: int) -> int:
+    """Bit set of defects of a CSR operator (0 = well formed), see sn_validate_csr_i32.  Synchronises (reads the flags)."""
+    _dev(rowptr, colind, vals)
+    flags = torch.empty(1, dtype=torch.int32, device=rowptr.device)
+    _lib.call("sn_validate_csr_i32", _p(rowptr), _p(colind), _p(vals), M, K, int(colind.numel()), _p(flags), _stream())
+    return int(flags.item())
 
 
 def elu_into(src, dst) -> None:

@@ -31,6 +31,8 @@ _BSR4_MAX_FILL = 1.6
 # Form in which pools of Dirac operators assemble a batch: "q3" (quaternion-packed, default) or "bsr4"
 # (functional.set_dirac_format switches both this and the kernel choice).
 _POOL_FORMAT = "q3"
+# SN_DEBUG_VALIDATE=1: every operator built from CSR arrays is checked on the device (SparseOperator.validate)
+_DEBUG_VALIDATE = os.environ.get("SN_DEBUG_VALIDATE", "0") == "1"
 
 
 class SparseOperator:
@@ -57,6 +59,8 @@ class SparseOperator:
             if rowptr.numel() != M + 1 or colind.numel() != vals.numel():
                 raise ValueError("inconsistent CSR arrays")
             self._csr = (rowptr, colind, vals)
+            if _DEBUG_VALIDATE and rowptr.is_cuda:
+                self.validate()
         self._nnz_cache = None
         self._shape = (M, K)
         self.batch = int(batch)                  # number of diagonal blocks (B of the reference's (B,R,K) operators)
@@ -160,6 +164,18 @@ class SparseOperator:
 
     def __repr__(self):
         return f"SparseOperator(shape={self._shape}, nnz={self.nnz}, batch={self.batch}, device={self.device})"
+
+    def validate(self) -> None:
+        """Debug check of the CSR arrays on the device (sn_validate_csr_i32): row pointers monotone from 0 to nnz, column
+        indices inside [0, K) and strictly ascending per row, finite values.  Raises ValueError naming the defects.  Run on
+        every operator built from CSR arrays when SN_DEBUG_VALIDATE=1 (the product kernels themselves do not bounds-check,
+        like the reference's)."""
+        rp, ci, va = self._ensure_csr()
+        flags = kernels.validate_csr(rp, ci, va, self._shape[0], self._shape[1])
+        if flags:
+            names = {1: "rowptr[0] != 0", 2: "rowptr decreasing", 4: "rowptr[M] != nnz", 8: "column index out of range",
+                     16: "row not sorted / duplicate columns", 32: "non-finite value"}
+            raise ValueError("invalid CSR operator: " + ", ".join(v for k, v in names.items() if flags & k))
 
     # ---- derived forms --------------------------------------------------------------------------
     def t(self) -> "SparseOperator":

@@ -140,6 +140,25 @@ def blockdiag_concat_ragged(pool_rowptr, pool_colind, pool_vals, desc, total_row
     return torch.from_numpy(out_rp), (None if out_c is None else torch.from_numpy(out_c)), torch.from_numpy(out_v.reshape(-1))
 
 
+def validate_csr(rowptr, colind, vals, M, K):
+    rp, ci, va = _np(rowptr), _np(colind), _np(vals)
+    bad = 0
+    if M and rp[0] != 0:
+        bad |= 1
+    if (np.diff(rp) < 0).any():
+        bad |= 2
+    if M and rp[-1] != len(ci):
+        bad |= 4
+    if len(ci) and ((ci < 0) | (ci >= K)).any():
+        bad |= 8
+    for r in range(M):
+        if (np.diff(ci[rp[r]: rp[r + 1]]) <= 0).any():
+            bad |= 16
+    if not np.isfinite(va).all():
+        bad |= 32
+    return bad
+
+
 def elu_into(src, dst):
     c_oracle.elu_raw(src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst), src.shape[0], src.shape[1])
 

@@ -98,3 +98,19 @@ def test_state_dict_schema_matches_reference():
     assert sd["rn14.bn_fc1.bn.running_var"].shape == (256,) and sd["conv2.fc.weight"].shape == (120, 128)
     assert sum(p.numel() for p in arap.DirModel().parameters()) == 1018872
     assert sum(p.numel() for p in mesh_mnist.Model().parameters()) == 90314
+
+
+def test_debug_validation_mode_rejects_malformed_operators(cpu_kernels, monkeypatch):
+    """SN_DEBUG_VALIDATE=1: SparseOperator checks the CSR arrays it is built from (host logic; the device kernel itself is
+    tested in tests/test_fullsize_gpu.py)."""
+    import torch
+
+    from surfacenetworks_amd import operators
+
+    rp = torch.tensor([0, 2, 3], dtype=torch.int32)
+    ci = torch.tensor([0, 7, 1], dtype=torch.int32)
+    va = torch.ones(3)
+    op = operators.SparseOperator(rp, ci, va, (2, 4))
+    with pytest.raises(ValueError, match="column index out of range"):
+        op.validate()
+    operators.SparseOperator(rp, torch.tensor([0, 3, 1], dtype=torch.int32), va, (2, 4)).validate()
