@@ -24,7 +24,7 @@ from . import arap as _arap
 from . import mesh_ops
 from .operators import OperatorPool
 
-__all__ = ["load_arap_sequence", "arap_from_files", "load_mesh_mnist", "mnist_from_samples", "load_faust_frame",
+__all__ = ["load_arap_sequence", "arap_from_files", "load_mesh_mnist", "mnist_from_samples", "load_faust_frame", "faust_from_files",
            "write_arap_sequence", "write_mesh_mnist", "write_faust_frame"]
 
 
@@ -138,6 +138,13 @@ def load_faust_frame(path: str, device="cuda") -> Dict:
             "G": torch.from_numpy(z["dist_mat"].astype("f")).to(device),
         }
     return fr
+
+
+def faust_from_files(paths: Sequence[str], device="cuda", model="lap", pad_to=None):
+    """Resident FAUST dataset (dense_correspondence.FaustFrames) from reference .npz frames."""
+    from . import dense_correspondence as dc
+
+    return dc.FaustFrames([load_faust_frame(p, device) for p in paths], model=model, pad_to=pad_to, device=device)
 
 
 def write_faust_frame(path: str, V: np.ndarray, F: np.ndarray, label: np.ndarray, dist_mat: np.ndarray) -> None:

@@ -233,12 +233,62 @@ def graphed_train_step(model, optimizer, example: PairBatch, bucket=None):
     return GraphedTrainStep(model, optimizer, example.owned(), forward_loss, bucket)
 
 
-def train_step(model, optimizer, ds: TorusBodies, ia: int, ib: int, grad_sync=None):
-    """main.py:310-327: two independent samples, siamese forward, delta-CE loss, Adam."""
+def _operation(ops, mask):
+    """[L, mask] or [Di, DiA, mask]: the `Operation` lists SiameseModel.forward unpacks (main.py:317-320)."""
+    return [*ops, mask] if isinstance(ops, (tuple, list)) else [ops, mask]
+
+
+class FaustFrames:
+    """FAUST frames read from the reference's .npz files (datasets.load_faust_frame; src/dense_correspondence/main.py:66-102)
+    as a resident dataset with the TorusBodies interface: coordinates, label permutations and geodesic matrices as device
+    tensors, the operators of the requested tower in OperatorPools; `sample(idx)` pads to `pad_to` vertices (main.py:193)."""
+
+    def __init__(self, frames, model="lap", pad_to=None, device="cuda"):
+        self.device = torch.device(device)
+        self.kind = "dir" if "dir" in model else "lap"
+        self.frames = frames
+        self.n = len(frames)
+        nv = max(int(fr["V"].shape[0]) for fr in frames)
+        nf = max(int(fr["F"].shape[0]) for fr in frames)
+        self.pad_to = int(pad_to) if pad_to is not None else nv
+        self.pad_faces = nf
+        if self.kind == "dir":
+            self.pool_Di = OperatorPool([fr["Di"] for fr in frames], self.device, want_bsr4=True)
+            self.pool_DiA = OperatorPool([fr["DiA"] for fr in frames], self.device, want_bsr4=True)
+        else:
+            self.pool_L = OperatorPool([fr["L"] for fr in frames], self.device)
+
+    def sample(self, idx):
+        fr = self.frames[idx]
+        nv = fr["V"].shape[0]
+        inputs = torch.zeros(1, self.pad_to, 3, device=self.device)
+        inputs[0, :nv] = fr["V"]
+        mask = torch.zeros(1, self.pad_to, 1, device=self.device)
+        mask[0, :nv] = 1
+        if self.kind == "dir":
+            ops = (self.pool_Di.assemble([idx], 4 * self.pad_faces, 4 * self.pad_to),
+                   self.pool_DiA.assemble([idx], 4 * self.pad_to, 4 * self.pad_faces))
+        else:
+            ops = self.pool_L.assemble([idx], self.pad_to, self.pad_to)
+        return inputs, [(fr["G"], fr["label"], fr["label_inv"])], mask, ops
+
+
+def forward_pair_loss(model, ds, ia: int, ib: int, streamed: bool = False, block: int = 1024):
+    """Siamese forward + delta cross entropy of one pair (main.py:310-324).  streamed=True: the towers' features go straight
+    into streamed_delta_cross_entropy — the (N, N) score matrix, its softmax and its gradient are never materialised."""
     inX, tX, mX, LX = ds.sample(ia)
     inY, tY, mY, LY = ds.sample(ib)
-    out = model([LX, mX], [LY, mY], inX, inY)
-    loss = loss_fun_delta_cross_entropy(out, tX, tY)
+    if streamed:
+        FA = model.model(*_operation(LX, mX), inX)
+        FB = model.model(*_operation(LY, mY), inY)
+        return streamed_delta_cross_entropy(FA, FB, tX, tY, block)
+    out = model(_operation(LX, mX), _operation(LY, mY), inX, inY)
+    return loss_fun_delta_cross_entropy(out, tX, tY)
+
+
+def train_step(model, optimizer, ds, ia: int, ib: int, grad_sync=None, streamed: bool = False):
+    """main.py:310-327: two independent samples, siamese forward, delta-CE loss, Adam."""
+    loss = forward_pair_loss(model, ds, ia, ib, streamed)
     optimizer.zero_grad(set_to_none=False)
     loss.backward()
     if grad_sync is not None:

@@ -9,13 +9,17 @@ import torch
 from helpers import deterministic_init, det_tensor, grad_signature, rel_err, sigs_close
 from oracle import ref_blocks as OB
 
-# Model-level criterion.  The deep fixtures are ill-conditioned in fp32 (perturbing the INPUT of the reference ARAP model
-# by 1e-7 relative moves its conv1 gradient by 2.4e-3; the Laplacian has entries up to 3e4 with rows summing to 0), so a
-# fixed tolerance against the reference's fp32 numbers would either be vacuous or flaky.  Instead the exact answer is
-# computed with the oracle in fp64 and the product must be as close to it as the reference's own fp32 run is:
-#     err(product, fp64) <= SLACK * err(reference_fp32, fp64) + FLOOR.
-# The tight fixed bar (1e-5 relative) is held at block level (check_block) and bit-exactness at kernel level.
-SLACK, FLOOR = 10.0, 2e-6
+# Model-level criterion.  The deep fixtures are ill-conditioned in fp32 (the reference's OWN fp32 gradients of the FAUST fixture
+# are off by 3x their norm against float64, its Mesh-MNIST gradients by 6 %: tests/golden/make_golden.py prints them), so a
+# fixed tolerance against the reference's fp32 numbers would be either vacuous or flaky.  Two complementary checks instead:
+#   * per layer (check_model_layers): every block of the product model, fed the REFERENCE's stored input of that block,
+#     reproduces the reference's stored output to 1e-5 relative — conditioning cannot compound, a defect in one block shows;
+#   * end to end (check_model): against the float64 oracle the product must be as close as the reference itself is,
+#         err(product, fp64) <= SLACK * err(reference_fp32, fp64) + spread + FLOOR,    SLACK = 3,
+#     where `spread` is MEASURED ON THE REFERENCE and stored in the fixture ({tag}_spread_*): the largest deviation from
+#     float64 of eight fp32 runs of the imported reference whose inputs carry one-ulp relative noise — what any other valid
+#     fp32 evaluation order may show.  No hand-picked constants.
+SLACK, FLOOR = 3.0, 1e-6
 
 
 def _sig_err(sigs, ref64):
@@ -24,15 +28,10 @@ def _sig_err(sigs, ref64):
     return max(float(np.abs(np.asarray(sigs[k]) - ref64[k]).max()) for k in ref64) / top
 
 
-# The FAUST loss is the worst-conditioned quantity of the suite: one fp32 ulp of input noise moves the reference's own fp32
-# loss by 1e-4 .. 1.4e-3 relative (tests/golden/faust_loss_sensitivity.py; the stored unperturbed run is a lucky 5.4e-5).
-# Its bound therefore also admits that measured spread (x1.5).
-FAUST_LOSS_SPREAD = 2e-3
-
-
 def _as_close_as_reference(name, prod, ref32, truth64, spread=0.0):
     e_prod, e_ref = rel_err(prod, truth64), rel_err(ref32, truth64)
-    assert e_prod <= max(SLACK * e_ref, spread) + FLOOR, (name, "product err", e_prod, "reference fp32 err", e_ref)
+    assert e_prod <= SLACK * e_ref + spread + FLOOR, (name, "product err", e_prod, "reference fp32 err", e_ref, "spread", spread)
+    return e_prod, e_ref
 
 
 BLOCKS = [("LapResNet2", 64), ("LapResNet2", 128), ("DirResNet2", 64), ("DirResNet2", 128), ("AvgResNet2", 128),
@@ -128,11 +127,18 @@ def check_model(golden_dir, tag, dev, opkind="pool", tol_out=5e-5):
         loss64 = OB.delta_cross_entropy(out64, [(c(tX[0][0]), tX[0][1].cpu(), tX[0][2].cpu())], [(c(tY[0][0]), tY[0][1].cpu(), tY[0][2].cpu())])
         loss64.backward()
         s64 = grad_signature(m64)
-        _as_close_as_reference("faust loss", loss.item(), float(g["faust_lap_loss"]), loss64.item(), FAUST_LOSS_SPREAD)
-        _as_close_as_reference("faust out", out.detach().cpu().numpy()[0, ::7, ::7], g["faust_lap_out_sample"], out64.detach().numpy()[0, ::7, ::7])
+        sp = lambda k: float(g[f"faust_lap_spread_{k}"])
+        # the same loss streamed over row blocks from the towers' features (no (N, N) score matrix): same value
+        with torch.no_grad():
+            FA, FB = m.model(L1, mask, cA), m.model(L1, mask, cB)
+            l_str = dense_correspondence.streamed_delta_cross_entropy(FA, FB, tX, tY, block=64)
+        assert abs(l_str.item() - loss.item()) <= 2e-5 * abs(loss.item()), ("streamed faust loss", l_str.item(), loss.item())
+        _as_close_as_reference("faust loss", loss.item(), float(g["faust_lap_loss"]), loss64.item(), sp("loss"))
+        _as_close_as_reference("faust out", out.detach().cpu().numpy()[0, ::7, ::7], g["faust_lap_out_sample"],
+                               out64.detach().numpy()[0, ::7, ::7], sp("out"))
         e_prod = _sig_err(grad_signature(m), s64)
         e_ref = _sig_err({k: g[f"faust_lap_psig_{k}"] for k in s64}, s64)
-        assert e_prod <= SLACK * e_ref + FLOOR, ("faust grad", e_prod, e_ref)
+        assert e_prod <= SLACK * e_ref + sp("grad") + FLOOR, ("faust grad", e_prod, e_ref)
         return
     rb, ops = batch_operators(golden_dir, opkind, dev)
     mask = torch.from_numpy(rb["mask"]).to(dev)
@@ -158,11 +164,15 @@ def check_model(golden_dir, tag, dev, opkind="pool", tol_out=5e-5):
         raise KeyError(tag)
     loss.backward()
     l64, o64, s64 = _oracle_fp64(golden_dir, tag, rb, g)
-    _as_close_as_reference(tag + " loss", loss.item(), float(g[f"{tag}_loss"]), l64)
-    _as_close_as_reference(tag + " out", out.detach().cpu().numpy(), g[f"{tag}_out"], o64)
+    sp = lambda k: float(g[f"{tag}_spread_{k}"])
+    el = _as_close_as_reference(tag + " loss", loss.item(), float(g[f"{tag}_loss"]), l64, sp("loss"))
+    eo = _as_close_as_reference(tag + " out", out.detach().cpu().numpy(), g[f"{tag}_out"], o64, sp("out"))
     ref_sig = {k: g[f"{tag}_psig_{k}"] for k in s64}
     e_prod, e_ref = _sig_err(grad_signature(m), s64), _sig_err(ref_sig, s64)
-    assert e_prod <= SLACK * e_ref + FLOOR, (tag, "grad: product err", e_prod, "reference fp32 err", e_ref)
+    if os.environ.get("SN_TEST_VERBOSE"):
+        print(f"[{tag}] err vs fp64 (product / reference fp32 / spread): loss {el[0]:.2e}/{el[1]:.2e}/{sp('loss'):.2e} "
+              f"out {eo[0]:.2e}/{eo[1]:.2e}/{sp('out'):.2e} grad {e_prod:.2e}/{e_ref:.2e}/{sp('grad'):.2e}")
+    assert e_prod <= SLACK * e_ref + sp("grad") + FLOOR, (tag, "grad: product err", e_prod, "reference fp32 err", e_ref)
 
 
 def _oracle_fp64(golden_dir, tag, rb, g):
@@ -382,3 +392,143 @@ def check_inplace_edit_drops_handoff(golden_dir, dev):
                 h = torch.cat([torch.full_like(h[:, :1], 0.25), h[:, 1:]], 1)
             outs.append(b1(ops["L"], None, h).cpu().numpy())
     assert rel_err(outs[0], outs[1]) < 1e-6
+
+
+def check_model_layers(golden_dir, tag, dev, tol=1e-5):
+    """Every layer of the product model, fed the REFERENCE's stored input of that layer (layers_reference.npz: the outputs
+    of conv1 and of every rn{i} of the imported reference model on the batch cube + delaunay60), reproduces the reference's
+    stored output to `tol` = 1e-5 relative — outputs and, for Dirac blocks, the face stream.  Where the reference's own fp32
+    block output is further than tol/4 from the float64 block (stored as {tag}_rn{i}_eref: the Mesh-MNIST-scaled Laplacian
+    has entries of 1e4 with rows summing to zero), the bound is 4 x that error — product within 3 x the reference's own."""
+    from surfacenetworks_amd import arap, mesh_mnist
+    from surfacenetworks_amd.operators import OperatorPool
+
+    z = load(golden_dir, "layers_reference.npz")
+    order = [str(s_) for s_ in z["order"]]
+    nv, nf = int(z["nv"]), int(z["nf"])
+    mask = torch.from_numpy(z["mask"]).to(dev)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    ops = {}
+    for k, (s0, s1) in {"L": (nv, nv), "Di": (4 * nf, 4 * nv), "DiA": (4 * nv, 4 * nf)}.items():
+        mats = [csr_of(load(golden_dir, f"ops_{m}.npz"), k) for m in order]
+        ops[k] = OperatorPool(mats, dev, want_bsr4=(k != "L")).assemble(np.arange(len(order)), s0, s1)
+    if tag == "arap_dir":
+        m, nlayer, x0 = deterministic_init(arap.DirModel(), 7).train().to(dev), 15, t(z["inputs6"])
+    elif tag == "arap_lap":
+        m, nlayer, x0 = deterministic_init(arap.Model(15), 8).train().to(dev), 15, t(z["inputs6"])
+    else:
+        m, nlayer, x0 = _bn_train_only(deterministic_init(mesh_mnist.Model(), 9)).to(dev), 5, t(z["coords"])
+    worst = 0.0
+    with torch.no_grad():
+        e = rel_err(m.conv1(x0).cpu().numpy(), z[f"{tag}_conv1_v"])
+        assert e <= tol, (tag, "conv1", e)
+        for i in range(nlayer):
+            prev = "conv1" if i == 0 else f"rn{i - 1}"
+            blk = m._modules[f"rn{i}"]
+            v_in = t(z[f"{tag}_{prev}_v"])
+            want_v = z[f"{tag}_rn{i}_v"]
+            if tag == "arap_dir" and i % 2 == 0:
+                # the face stream entering block i is the f returned by the previous Dirac block (zeros for the first)
+                fkey = f"{tag}_rn{i - 2}_f"
+                f_in = t(z[fkey]) if i >= 2 else torch.zeros(v_in.shape[0], nf, v_in.shape[2], device=dev)
+                v_out, f_out = blk(ops["Di"], ops["DiA"], v_in, f_in)
+                ef = rel_err(f_out.cpu().numpy(), z[f"{tag}_rn{i}_f"])
+                assert ef <= max(tol, 4.0 * float(z[f"{tag}_rn{i}_eref"])), (tag, f"rn{i} face stream", ef)
+                worst = max(worst, ef)
+            elif tag == "arap_dir":
+                v_out = blk(None, mask, v_in)
+            else:
+                v_out = blk(ops["L"], mask, v_in)
+            e = rel_err(v_out.cpu().numpy(), want_v)
+            assert e <= max(tol, 4.0 * float(z[f"{tag}_rn{i}_eref"])), (tag, f"rn{i}", e, "reference's own fp32 error", float(z[f"{tag}_rn{i}_eref"]))
+            worst = max(worst, e)
+    if os.environ.get("SN_TEST_VERBOSE"):
+        print(f"[{tag}] per-layer: worst relative deviation from the reference's layer outputs {worst:.2e}")
+
+
+def check_dataset_files(golden_dir, dev):
+    """files in the reference's on-disk layouts (tests/golden/data_*: written by the reference's own
+    add_laplacian.process functions, see make_dataset_fixtures.py) -> device-resident pools -> training steps."""
+    from surfacenetworks_amd import arap, datasets, dense_correspondence as dc, mesh_mnist
+
+    # ---- ARAP sequences: data_plus/<seq>.npy ----
+    paths = [os.path.join(golden_dir, f"data_arap_seq{i}.npy") for i in (0, 1)]
+    for kind in ("dir", "lap"):
+        ds = datasets.arap_from_files(paths, device=dev, model=kind)
+        assert (ds.n, ds.frames, ds.op_frames) == (2, 50, 10) and ds.num_vertices.tolist() == [36, 25]
+        seq_ids, offs = np.array([1, 0, 1, 0]), np.array([3, 0, 7, 8])
+        b = ds.sample_batch(4, None, seq_ids=seq_ids, offsets=offs)
+        nv, nf = 36, int(ds.num_faces.max())
+        raw = [datasets.load_arap_sequence(p) for p in paths]
+        for i, (s_, o) in enumerate(zip(seq_ids, offs)):                 # operator of the last input frame (main.py:156)
+            want = raw[s_][o + 1]["Di" if kind == "dir" else "L"]
+            got = (b.Di if kind == "dir" else b.L).to_scipy()
+            r0, c0 = (4 * nf * i, 4 * nv * i) if kind == "dir" else (nv * i, nv * i)
+            assert abs(got[r0: r0 + want.shape[0], c0: c0 + want.shape[1]] - want).max() == 0
+            n = raw[s_][0]["V"].shape[0]
+            assert np.array_equal(b.inputs[i, :n, :3].cpu().numpy(), raw[s_][o]["V"]) and np.array_equal(b.targets[i, :n, -3:].cpu().numpy(), raw[s_][o + 41]["V"])
+        torch.manual_seed(0)
+        model = deterministic_init(arap.DirModel() if kind == "dir" else arap.Model(15), 21).train().to(dev)
+        # the same batch through the oracle restatement of the reference model on the CPU torch.sparse path
+        o_model = deterministic_init(OB.ArapDirModel() if kind == "dir" else OB.ArapLapModel(15), 21).train()
+        cpu = lambda t_: t_.detach().cpu()
+        if kind == "dir":
+            Dib = OB.diag_cat([OB.sp_to_coo(raw[s_][o + 1]["Di"]) for s_, o in zip(seq_ids, offs)], 4 * nf, 4 * nv)
+            DiAb = OB.diag_cat([OB.sp_to_coo(raw[s_][o + 1]["DiA"]) for s_, o in zip(seq_ids, offs)], 4 * nv, 4 * nf)
+            o_out = o_model(Dib, DiAb, cpu(b.mask), cpu(b.inputs))
+        else:
+            Lb = OB.diag_cat([OB.sp_to_coo(raw[s_][o + 1]["L"]) for s_, o in zip(seq_ids, offs)], nv, nv)
+            o_out = o_model(Lb, cpu(b.mask), cpu(b.inputs))
+        o_loss = OB.arap_loss(o_out, cpu(b.targets), cpu(b.mask), 4)
+        loss, out = arap.forward_loss(model, b)
+        assert abs(loss.item() - o_loss.item()) <= 2e-4 * abs(o_loss.item()), (kind, loss.item(), o_loss.item())
+        opt = arap.make_optimizer(model)
+        before = torch.cat([p_.detach().reshape(-1) for p_ in model.parameters()]).clone()
+        l1 = arap.train_step(model, opt, b)
+        after = torch.cat([p_.detach().reshape(-1) for p_ in model.parameters()])
+        assert torch.isfinite(l1) and not torch.equal(before, after)
+    # ---- Mesh-MNIST: {train,test}_plus.np ----
+    samples = datasets.load_mesh_mnist(os.path.join(golden_dir, "data_mnist_plus.np"))
+    for kind, cls in (("lap", mesh_mnist.Model), ("dir", mesh_mnist.DirModel)):
+        ds = datasets.mnist_from_samples(samples, device=dev, model=kind)
+        b = ds.sample_batch(4, None, ids=np.array([2, 0, 3, 1]))
+        assert b.targets.tolist() == [int(samples[i]["label"]) for i in (2, 0, 3, 1)]
+        want = samples[2]["L" if kind == "lap" else "Di"]
+        got = (b.L if kind == "lap" else b.Di).to_scipy()
+        assert abs(got[: want.shape[0], : want.shape[1]] - want).max() == 0
+        model = cls().to(dev)
+        opt = mesh_mnist.make_optimizer(model)
+        l1 = mesh_mnist.train_step(model, opt, b)
+        assert torch.isfinite(l1)
+    # ---- FAUST: *.npz frames ----
+    p = os.path.join(golden_dir, "data_faust_frame.npz")
+    for kind in ("lap", "dir"):
+        ds = datasets.faust_from_files([p, p], device=dev, model=kind, pad_to=64)
+        torch.manual_seed(1)
+        model = deterministic_init(dc.SiameseModel(kind, 15), 13).train().to(dev)
+        l_mat = dc.forward_pair_loss(model, ds, 0, 1)
+        l_str = dc.forward_pair_loss(model, ds, 0, 1, streamed=True, block=16)
+        assert torch.isfinite(l_mat) and abs(l_mat.item() - l_str.item()) <= 2e-5 * abs(l_mat.item())
+        opt = dc.make_optimizer(model)
+        assert torch.isfinite(dc.train_step(model, opt, ds, 0, 1, streamed=True))
+
+
+def check_streamed_faust_loss(dev, N=1500, dtype=torch.float32, tol=2e-5):
+    """streamed_delta_cross_entropy == loss_fun_delta_cross_entropy(bmm(FA, FB^T)) — value and both gradients — on `dev`
+    (main.py:229-240, models.py:203)."""
+    from surfacenetworks_amd import dense_correspondence as dc
+
+    g = torch.Generator().manual_seed(0)
+    FA = (0.3 * torch.randn(1, N, 120, generator=g, dtype=dtype)).to(dev).requires_grad_(True)
+    FB = (0.3 * torch.randn(1, N, 120, generator=g, dtype=dtype)).to(dev).requires_grad_(True)
+    GA, GB = torch.rand(N, N, generator=g, dtype=dtype).to(dev), torch.rand(N, N, generator=g, dtype=dtype).to(dev)
+    lA, lB = torch.randperm(N, generator=g).to(dev), torch.randperm(N, generator=g).to(dev)
+    tX, tY = [(GA, lA, torch.argsort(lA))], [(GB, lB, torch.argsort(lB))]
+    ref = dc.loss_fun_delta_cross_entropy(torch.bmm(FA, FB.transpose(1, 2)), tX, tY)
+    ref.backward()
+    gA, gB = FA.grad.clone(), FB.grad.clone()
+    FA.grad = FB.grad = None
+    got = dc.streamed_delta_cross_entropy(FA, FB, tX, tY, block=256)
+    got.backward()
+    assert abs(got.item() - ref.item()) <= tol * abs(ref.item())
+    assert rel_err(FA.grad.cpu().numpy(), gA.cpu().numpy()) <= 10 * tol and rel_err(FB.grad.cpu().numpy(), gB.cpu().numpy()) <= 10 * tol

@@ -32,6 +32,12 @@ def test_models_match_reference(golden_dir, tag):
     pc.check_model(golden_dir, tag, DEV)
 
 
+@pytest.mark.parametrize("tag", ["arap_dir", "arap_lap", "mnist_lap"])
+def test_model_layers_match_reference_layer_by_layer(golden_dir, tag):
+    """Each layer given the reference's own input of that layer: <= 1e-5 relative (no compounding over 15 layers)."""
+    pc.check_model_layers(golden_dir, tag, DEV)
+
+
 @pytest.mark.parametrize("tag", ["arap_dir", "mnist_dir"])
 def test_models_with_reference_driver_operator_types(golden_dir, tag):
     """Same models fed with the torch sparse COO operators the reference drivers build (2-D block-diag)."""
@@ -60,6 +66,17 @@ def test_pool_packed_assembly(golden_dir, fmt):
         pc.check_pool_packed(golden_dir, DEV)
     finally:
         snF.set_dirac_format("q3")
+
+
+def test_reference_format_files_feed_training(golden_dir):
+    """SURVEY.md §8f-3 on the device: the reference's pickled .npy / .np / .npz layouts -> device pools -> train steps."""
+    pc.check_dataset_files(golden_dir, DEV)
+
+
+def test_streamed_faust_loss_on_device():
+    """the FAUST correspondence loss streamed over row blocks on the GPU, fp32, against the materialised
+    (N, N) score matrix; the golden faust_lap loss goes through it in test_models_match_reference[faust_lap]."""
+    pc.check_streamed_faust_loss(DEV, N=3000)
 
 
 def test_inplace_edit_drops_the_activated_handoff(golden_dir):

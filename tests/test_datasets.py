@@ -62,6 +62,13 @@ def test_faust_frame_roundtrip(tmp_path):
     assert abs(fr["L"] - mesh_ops.laplacian(V, F).astype("f")).max() == 0
 
 
+def test_reference_format_files_feed_training(golden_dir, cpu_kernels):
+    """Fixture files written by the reference's own add_laplacian.process (tests/golden/make_dataset_fixtures.py)."""
+    import product_checks as pc
+
+    pc.check_dataset_files(golden_dir, "cpu")
+
+
 def test_streamed_faust_loss_equals_materialised():
     """Streamed CE over row blocks == loss_fun_delta_cross_entropy on bmm(FA, FB^T): value and both gradients."""
     from surfacenetworks_amd import dense_correspondence as dc
