@@ -348,7 +348,7 @@ def main():
     # (Di, DiA forward; Di^T, DiA^T backward), which differ only in which side is the face side.
     by_kernel = {}
     for tag, M, K, nnz, N, ms in recs:
-        kname = ("spmm_q3_lds" if "/q3" in tag else "spmm_bsr4_lds" if "/bsr4" in tag else "spmm_csr_lds") + \
+        kname = ("spmm_rb4" if "/rb4" in tag else "spmm_q3_lds" if "/q3" in tag else "spmm_bsr4_lds" if "/bsr4" in tag else "spmm_csr_rows") + \
                 ("_epi" if "+e" in tag else "_stats" if "+s" in tag else "") + f"<N={N}>"
         by_kernel.setdefault(kname, []).append((tag, M, K, nnz, N, ms))
     dom_name = max(by_kernel, key=lambda k: sum(r[5] for r in by_kernel[k]))
@@ -367,22 +367,23 @@ def main():
                  for (t, M, K, nnz, N), v in shapes.items()]
     tag = dom[0][0]
 
-    # HBM traffic of that kernel from the committed PMC measurement (rocprofv3 cannot run inside this process):
-    # average over the launches of the shapes that were measured
-    traffic = coverage = None
+    # HBM traffic of that kernel: rocprofv3 cannot run inside this process, so the figure is the committed PMC measurement
+    # of THIS command (profiles/r2_pmc_traffic_c3.json: rocprofv3 --pmc over bench.py itself, i.e. in-step launches with
+    # the step's own predecessors and cache state; raw per-dispatch counters next to it), averaged over the kernel's launches
+    traffic = traffic_src = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r1_pmc_traffic_c3.json")) as fh:
-            table = json.load(fh).get(dom_name.split("<")[0], {})
-        per = []
-        for r in dom:
-            suffix = r[0][r[0].index("+"):] if "+" in r[0] else ""
-            per.append(table.get(f"M={r[1]},K={r[2]},nnz={r[3]},N={r[4]}" + ("," + suffix if suffix else "")))
-        have = [p_ for p_ in per if p_]
-        if have:
-            traffic = float(np.mean([p_["read_bytes"] + p_["write_bytes"] for p_ in have]))
-            coverage = len(have) / len(per)
-    except OSError:
+        with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_c3.json")) as fh:
+            table = json.load(fh)
+        base = dom_name.split("<")[0]
+        hits = [v for k, v in table.items() if not k.startswith("_") and k.split("<")[0] == base and f"<{dom[0][4]}," in k]
+        if hits:
+            n_l = sum(h["launches"] for h in hits)
+            traffic = sum((h["read_bytes_mean"] + h["write_bytes_mean"]) * h["launches"] for h in hits) / n_l
+            traffic_src = (f"profiles/r2_pmc_traffic_c3.json: rocprofv3 --pmc TCC_EA0_RDREQ_sum / TCC_EA0_WRREQ_sum over this bench "
+                           f"command (in-step), bytes = RDREQ*128 + WRREQ*64, mean over {n_l} launches of {base}")
+    except (OSError, ValueError, KeyError):
         pass
+    product_bytes = sum(alg_bytes(r[1], r[2], r[3], r[4], "") for r in dom)       # SURVEY §8(d) bytes of the products alone
 
     out = {
         "metric": "meshes/sec fwd+bwd, Dirac temporal-predict",
@@ -406,8 +407,14 @@ def main():
         "roofline": {"bound": "hbm", "kernel": dom_name + (" (the backward products Di^T, DiA^T, ELU backward fused into the store)" if "_epi" in dom_name
                                                           else " (the Dirac products launched without epilogue)"),
                      "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                     "traffic": traffic, "traffic_source": (f"profiles/r1_pmc_traffic_c3.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ, bytes per launch; "
-                                        f"mean over the {coverage:.0%} of the timed launches whose shape and epilogue were measured)") if traffic else None,
+                     "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_definition": "SURVEY.md §8(d) CSR/int32/fp32 bytes of the product (nnz*8 + (M+1)*4 + K*N*4 + M*N*4) "
+                                                     "plus, for the fused ELU-backward launches, the epilogue operands E and G (M*N*4 each) "
+                                                     "that the fused kernel must read; the three figures below separate the conventions",
+                     "frac_by_convention": {
+                         "product_plus_epilogue_operands": achieved / HBM_PEAK,
+                         "product_bytes_only": product_bytes / (tot_ms * 1e-3) / HBM_PEAK,
+                         "measured_hbm_traffic": (traffic / (avg_ms * 1e-3) / HBM_PEAK) if traffic else None},
                      "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg_ms,
                      "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, " +
                                ("every launch of the timed steps" if args.no_graph else
