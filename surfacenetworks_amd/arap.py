@@ -62,6 +62,43 @@ class Model(nn.Module):
         return _add_last_frame(x, inputs, OUTPUT_FRAMES)
 
 
+class AvgModel(nn.Module):
+    """Global-average blocks only (models.py:54-78)."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = utils.GraphConv1x1(6, 128, batch_norm=None)
+        for i in range(15):
+            self.add_module("rn{}".format(i), utils.AvgResNet2(128))
+        self.conv2 = utils.GraphConv1x1(128, 120, batch_norm="pre")
+
+    def forward(self, L, mask, inputs):
+        x = self.conv1(inputs)
+        for i in range(15):
+            x = self._modules["rn{}".format(i)](L, mask, x)
+        x = utils.elu_conv1x1(self.conv2, x)
+        return _add_last_frame(x, inputs, OUTPUT_FRAMES)
+
+
+class MlpModel(nn.Module):
+    """Per-node MLP blocks only (models.py:81-105): conv1, 15 x MlpResNet2, GraphBatchNorm, ELU, conv2 without BatchNorm."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = utils.GraphConv1x1(6, 128, batch_norm=None)
+        for i in range(15):
+            self.add_module("rn{}".format(i), utils.MlpResNet2(128))
+        self.bn = utils.GraphBatchNorm(128)
+        self.conv2 = utils.GraphConv1x1(128, 120, batch_norm=None)
+
+    def forward(self, L, mask, inputs):
+        x = self.conv1(inputs)
+        for i in range(15):
+            x = self._modules["rn{}".format(i)](L, mask, x)
+        x = self.conv2(F.elu(self.bn(x)))
+        return _add_last_frame(x, inputs, OUTPUT_FRAMES)
+
+
 class DirModel(nn.Module):
     """Dirac variant (models.py:108-152): the `metric`'s "Dirac temporal-predict" model, 1 018 872 parameters."""
 

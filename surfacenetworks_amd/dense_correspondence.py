@@ -68,17 +68,83 @@ class DirModel(nn.Module):
         return _add_last_frame(x, inputs, 40)
 
 
+class AmplifyModel(nn.Module):
+    """models.py:51-82: the Laplacian tower fed a SEQUENCE of operators — block pair i uses L_sequence[i // 2], the last
+    one from there on (main.py:72-83 builds the sequence from normalised powers of L)."""
+
+    def __init__(self, layer):
+        super().__init__()
+        self.conv1 = utils.GraphConv1x1(3, 128, batch_norm=None)
+        self.layer = layer
+        for i in range(layer):
+            self.add_module("rn{}".format(i), utils.LapResNet2(128) if i % 2 == 0 else utils.AvgResNet2(128))
+        self.conv2 = utils.GraphConv1x1(128, 120, batch_norm="pre")
+
+    def forward(self, L_sequence, mask, inputs):
+        x = self.conv1(inputs)
+        for i in range(self.layer):
+            L = L_sequence[-1] if i // 2 >= len(L_sequence) else L_sequence[i // 2]
+            x = self._modules["rn{}".format(i)](L, mask, x)
+        x = utils.elu_conv1x1(self.conv2, x)
+        return _add_last_frame(x, inputs, 40)
+
+
+class AvgModel(nn.Module):
+    """models.py:84-109: global-average blocks only."""
+
+    def __init__(self, layer):
+        super().__init__()
+        self.conv1 = utils.GraphConv1x1(3, 128, batch_norm=None)
+        self.layer = layer
+        for i in range(layer):
+            self.add_module("rn{}".format(i), utils.AvgResNet2(128))
+        self.conv2 = utils.GraphConv1x1(128, 120, batch_norm="pre")
+
+    def forward(self, L, mask, inputs):
+        x = self.conv1(inputs)
+        for i in range(self.layer):
+            x = self._modules["rn{}".format(i)](L, mask, x)
+        x = utils.elu_conv1x1(self.conv2, x)
+        return _add_last_frame(x, inputs, 40)
+
+
+class MlpModel(nn.Module):
+    """models.py:111-138: per-node MLP blocks, GraphBatchNorm before the last layer, conv2 without BatchNorm."""
+
+    def __init__(self, layer):
+        super().__init__()
+        self.conv1 = utils.GraphConv1x1(3, 128, batch_norm=None)
+        self.layer = layer
+        for i in range(layer):
+            self.add_module("rn{}".format(i), utils.MlpResNet2(128))
+        self.bn = utils.GraphBatchNorm(128)
+        self.conv2 = utils.GraphConv1x1(128, 120, batch_norm=None)
+
+    def forward(self, L, mask, inputs):
+        x = self.conv1(inputs)
+        for i in range(self.layer):
+            x = self._modules["rn{}".format(i)](L, mask, x)
+        x = self.conv2(F.elu(self.bn(x)))
+        return _add_last_frame(x, inputs, 40)
+
+
 class SiameseModel(nn.Module):
     """models.py:184-203."""
 
     def __init__(self, model="dirac", layer=15):
         super().__init__()
-        if "dir" in model:
+        if "dir" in model:                       # same dispatch order as models.py:188-199
             self.model = DirModel(layer)
+        elif "amp" in model:
+            self.model = AmplifyModel(layer)
         elif "lap" in model:
             self.model = Model(layer)
+        elif "avg" in model:
+            self.model = AvgModel(layer)
+        elif "mlp" in model:
+            self.model = MlpModel(layer)
         else:
-            raise ValueError("supported towers: 'lap', 'dir'")
+            raise ValueError("towers: 'dir', 'amp', 'lap', 'avg', 'mlp'")
 
     def forward(self, OperationA, OperationB, inputA, inputB):
         FA = self.model(*OperationA, inputA)

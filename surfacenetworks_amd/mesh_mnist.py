@@ -65,6 +65,36 @@ class DirModel(_Head):
         return self._classify(v, mask)
 
 
+class _BlockStack(_Head):
+    """Shared body of the block-type variants (models.py:55-119): conv1, five blocks of one type, the classifier head."""
+
+    block = None
+
+    def __init__(self):
+        super().__init__()
+        self.conv1 = utils.GraphConv1x1(3, 64, batch_norm=None)
+        for i in range(5):
+            self.add_module("rn{}".format(i), self.block(64))
+        self.bn_conv2 = utils.GraphConv1x1(64, 64, batch_norm="pre")
+        self.fc1 = nn.Linear(64, 10)
+
+    def forward(self, inputs, L, mask):
+        x = self.conv1(inputs)
+        for i in range(5):
+            x = self._modules["rn{}".format(i)](L, mask, x)
+        return self._classify(x, mask)
+
+
+class AvgModel(_BlockStack):
+    """Global-average blocks only (src/mesh_mnist/models.py:55-87)."""
+    block = utils.AvgResNet2
+
+
+class MlpModel(_BlockStack):
+    """Per-node MLP blocks only (src/mesh_mnist/models.py:89-119)."""
+    block = utils.MlpResNet2
+
+
 def make_optimizer(model):
     return make_adam(model)       # main.py:139
 

@@ -532,3 +532,93 @@ def check_streamed_faust_loss(dev, N=1500, dtype=torch.float32, tol=2e-5):
     got.backward()
     assert abs(got.item() - ref.item()) <= tol * abs(ref.item())
     assert rel_err(FA.grad.cpu().numpy(), gA.cpu().numpy()) <= 10 * tol and rel_err(FB.grad.cpu().numpy(), gB.cpu().numpy()) <= 10 * tol
+
+
+def check_model_variants(golden_dir, dev, tol=1e-5):
+    """The remaining model variants of the three drivers (AvgModel / MlpModel / AmplifyModel and every SiameseModel tower)
+    against tests/golden/variants_reference.npz (one forward pass of the imported reference on the two-mesh batch):
+      * state_dict keys in the reference's order and parameter counts;
+      * the ORACLE composition of the same blocks reproduces the reference's output (pins layer order, heads, wiring);
+      * the PRODUCT model agrees with that oracle layer by layer, each layer fed the oracle's input of that layer.  (End to
+        end these stacks are chaotic on the tiny fixture — 15 global-average blocks amplify a 5e-7 difference to 0.4 — so the
+        comparison re-synchronises at every layer, as check_model_layers does with stored activations.)"""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    from surfacenetworks_amd import arap, dense_correspondence as dc, mesh_mnist
+    from surfacenetworks_amd.operators import OperatorPool
+
+    z = load(golden_dir, "variants_reference.npz")
+    lay = load(golden_dir, "layers_reference.npz")
+    order = [str(s_) for s_ in lay["order"]]
+    nv = int(lay["nv"])
+    mask_c = torch.from_numpy(lay["mask"])
+    mask = mask_c.to(dev)
+    in6_c, c2_c = torch.from_numpy(lay["inputs6"]), torch.from_numpy(lay["coords"])
+    mats = [csr_of(load(golden_dir, f"ops_{m}.npz"), "L") for m in order]
+    L = OperatorPool(mats, dev).assemble(np.arange(len(order)), nv, nv)
+    L_half = OperatorPool([m_ * np.float32(0.5) for m_ in mats], dev).assemble(np.arange(len(order)), nv, nv)
+    Lo = OB.diag_cat([OB.sp_to_coo(m_) for m_ in mats], nv, nv)
+    Lo_half = OB.diag_cat([OB.sp_to_coo(m_ * np.float32(0.5)) for m_ in mats], nv, nv)
+
+    class OStack(nn.Module):
+        """Oracle restatement of a variant: the same attribute names as the reference class (=> same state_dict order)."""
+
+        def __init__(self, cin, width, blocks, head):
+            super().__init__()
+            self.conv1 = OB.GraphConv1x1(cin, width, batch_norm=None)
+            for i, b in enumerate(blocks):
+                self.add_module(f"rn{i}", getattr(OB, b)(width))
+            if head == "mnist":
+                self.bn_conv2 = OB.GraphConv1x1(width, width, batch_norm="pre")
+                self.fc1 = nn.Linear(width, 10)
+            elif head == "mlp":
+                self.bn = OB.GraphBatchNorm(width)
+                self.conv2 = OB.GraphConv1x1(width, 120, batch_norm=None)
+            else:
+                self.conv2 = OB.GraphConv1x1(width, 120, batch_norm="pre")
+
+    lap_avg = ["LapResNet2" if i % 2 == 0 else "AvgResNet2" for i in range(15)]
+    cases = (("arap_avg", arap.AvgModel, 31, (6, 128, ["AvgResNet2"] * 15, "bn"), "in6", None),
+             ("arap_mlp", arap.MlpModel, 32, (6, 128, ["MlpResNet2"] * 15, "mlp"), "in6", None),
+             ("mnist_avg", mesh_mnist.AvgModel, 33, (3, 64, ["AvgResNet2"] * 5, "mnist"), "c2", None),
+             ("mnist_mlp", mesh_mnist.MlpModel, 34, (3, 64, ["MlpResNet2"] * 5, "mnist"), "c2", None),
+             ("faust_amp", lambda: dc.AmplifyModel(15), 35, (3, 128, lap_avg, "bn"), "c2", "seq"),
+             ("faust_avg", lambda: dc.AvgModel(15), 36, (3, 128, ["AvgResNet2"] * 15, "bn"), "c2", None),
+             ("faust_mlp", lambda: dc.MlpModel(15), 37, (3, 128, ["MlpResNet2"] * 15, "mlp"), "c2", None))
+    for tag, mk, seed, ospec, inp, opmode in cases:
+        m = deterministic_init(mk(), seed)
+        assert list(m.state_dict().keys()) == [str(k) for k in z[f"{tag}_keys"]], tag
+        assert sum(p_.numel() for p_ in m.parameters()) == int(z[f"{tag}_numel"]), tag
+        mo = deterministic_init(OStack(*ospec), seed)
+        assert list(mo.state_dict().keys()) == list(m.state_dict().keys())
+        mnist = tag.startswith("mnist")
+        m = (_bn_train_only(m) if mnist else m.train()).to(dev)
+        mo = _bn_train_only(mo) if mnist else mo.train()
+        x_c = in6_c if inp == "in6" else c2_c
+        nblk = len(ospec[2])
+        with torch.no_grad():
+            xo = mo.conv1(x_c)
+            xp = m.conv1(x_c.to(dev))
+            assert rel_err(xp.cpu().numpy(), xo.numpy()) <= tol, (tag, "conv1")
+            for i in range(nblk):
+                op_p = ([L, L_half][min(i // 2, 1)] if opmode == "seq" else None)
+                op_o = ([Lo, Lo_half][min(i // 2, 1)] if opmode == "seq" else None)
+                xp = m._modules[f"rn{i}"](op_p, mask, xo.to(dev))            # product layer on the ORACLE's input
+                xo = mo._modules[f"rn{i}"](op_o, mask_c, xo)
+                e = rel_err(xp.cpu().numpy(), xo.numpy())
+                assert e <= 2 * tol, (tag, f"rn{i}", e)
+            # heads (models.py of each driver): product on the oracle's last activation, and the oracle's own output
+            if mnist:
+                out_o = F.log_softmax(mo.fc1(OB.masked_mean(F.elu(mo.bn_conv2(F.elu(xo))), mask_c).squeeze(1)), dim=1)
+                out_p = m._classify(xo.to(dev), mask)
+            elif ospec[3] == "mlp":
+                out_o = mo.conv2(F.elu(mo.bn(xo))) + x_c[:, :, -3:].repeat(1, 1, 40)
+                out_p = m.conv2(F.elu(m.bn(xo.to(dev)))) + x_c.to(dev)[:, :, -3:].repeat(1, 1, 40)
+            else:
+                out_o = mo.conv2(F.elu(xo)) + x_c[:, :, -3:].repeat(1, 1, 40)
+                out_p = m.conv2(F.elu(xo.to(dev))) + x_c.to(dev)[:, :, -3:].repeat(1, 1, 40)
+        assert rel_err(out_o.numpy(), z[f"{tag}_out"]) <= tol, (tag, "oracle composition vs reference", rel_err(out_o.numpy(), z[f"{tag}_out"]))
+        assert rel_err(out_p.cpu().numpy(), out_o.numpy()) <= 2 * tol, (tag, "head")
+    for key in ("dir", "amp", "lap", "avg", "mlp"):
+        assert list(dc.SiameseModel(key, 15).state_dict().keys()) == [str(k) for k in z[f"siamese_{key}_keys"]], key

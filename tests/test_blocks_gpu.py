@@ -79,6 +79,10 @@ def test_streamed_faust_loss_on_device():
     pc.check_streamed_faust_loss(DEV, N=3000)
 
 
+def test_model_variants_match_reference(golden_dir):
+    pc.check_model_variants(golden_dir, DEV)
+
+
 def test_inplace_edit_drops_the_activated_handoff(golden_dir):
     pc.check_inplace_edit_drops_handoff(golden_dir, DEV)
 

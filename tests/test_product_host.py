@@ -51,3 +51,7 @@ def test_inplace_edit_drops_the_activated_handoff(golden_dir, cpu_kernels):
 @pytest.mark.parametrize("tag", ["arap_dir", "arap_lap", "mnist_lap"])
 def test_model_layers_match_reference_layer_by_layer(golden_dir, cpu_kernels, tag):
     pc.check_model_layers(golden_dir, tag, "cpu")
+
+
+def test_model_variants_match_reference(golden_dir, cpu_kernels):
+    pc.check_model_variants(golden_dir, "cpu")
