@@ -12,8 +12,8 @@ _SO = os.path.join(_HERE, "libsn_oracle.so")
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "sn_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, "sn_oracle.c"), os.path.join(_HERE, "sn_host_twin.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(s_) for s_ in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "--no-print-directory"])
     return _SO
 

@@ -488,3 +488,22 @@ def test_csr_rows_kernel_large_batch_multi_pass():
     ref = np.stack([w64.sum(0), (w64 * w64).sum(0)])
     for p_ in (part, part2):
         assert np.allclose(p_.sum(0).cpu().numpy(), ref, rtol=1e-6, atol=1e-6 * np.abs(w64).sum(0).max())
+
+
+def test_device_library_matches_host_twins():
+    """The C-ABI call table of tests/abi_cases.py on the device: the same status as the host-pointer twins for every invalid
+    call, and bit-identical outputs for every valid one (ELU: expm1f implementations may differ by an ulp)."""
+    import abi_cases as ac
+
+    host, devb = ac.Backend("host"), ac.Backend("device")
+    for (what, got_h, want), (_, got_d, _) in zip(ac.invalid_calls(host), ac.invalid_calls(devb)):
+        assert got_h == want and got_d == want, (what, got_h, got_d, want)
+    oh, od = ac.run_valid(host), ac.run_valid(devb)
+    assert set(oh) == set(od)
+    for k in oh:
+        a, b = oh[k], od[k]
+        for x_, y_ in zip(a if isinstance(a, list) else [a], b if isinstance(b, list) else [b]):
+            if k == "elu":
+                assert np.allclose(x_[:, :8], y_[:, :8], rtol=1e-6, atol=1e-7) and np.isnan(y_[:, 8:]).all()
+            else:
+                assert np.array_equal(x_, y_), k
