@@ -546,6 +546,7 @@ __device__ __forceinline__ void spmm_bsr4_lds_body(const int *__restrict__ b_row
 // workgroups per CU, whose larger combined working set re-reads 15-20 % of X from HBM on the vertex-row products
 // (PMC TCC_EA0_RDREQ: 519 MB against the compulsory 451 MB).
 #define SN_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
+#define SN_SIX_WAVES __attribute__((amdgpu_waves_per_eu(6, 6)))
 template <int N, int XG, int YG>
 __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_bsr4_lds(const int *__restrict__ b_rowptr, const int *__restrict__ b_colind,
                                                      const float *__restrict__ b_vals, int Mb,
@@ -575,7 +576,7 @@ __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_bsr4_lds_epi(const int
 // sums of squares of its 32 output rows — per channel c = 32·(component) + column — in stats_part[blockIdx.x][2][128] (fp32
 // over the 32 rows; added up in fp64 by sn_spmm_stats_reduce): the BatchNorm statistics of the propagated half of a stage's
 // concat buffer, so that no statistics pass has to read it back.
-template <int N, int XG, int YG, bool EPI, bool STATS = false>
+template <int N, int XG, int YG, bool EPI, bool STATS = false, int UNROLL = 3>
 __device__ __forceinline__ void spmm_q3_lds_body(const int *__restrict__ b_rowptr, const f4 *__restrict__ q_blk, int Mb,
                                                  const float *__restrict__ X, int64_t ldx, float *__restrict__ Y,
                                                  int64_t ldy, int nchunks, SpmmEpi epi, float *__restrict__ stats_part = nullptr) {
@@ -613,7 +614,7 @@ __device__ __forceinline__ void spmm_q3_lds_body(const int *__restrict__ b_rowpt
     __builtin_amdgcn_wave_barrier();
     int k = kb > t0 ? kb : t0;
     const int kend = ke < t0 + nt ? ke : t0 + nt;
-#pragma unroll 2
+#pragma unroll UNROLL
     for (; k < kend; ++k) {
       const f4 q = sv[k - t0];
       const int bc = __float_as_int(q.w);
@@ -678,14 +679,29 @@ __device__ __forceinline__ void spmm_q3_lds_body(const int *__restrict__ b_rowpt
     stats_part[(int64_t)blockIdx.x * 256 + t] = (s_wv[0][t] + s_wv[1][t]) + (s_wv[2][t] + s_wv[3][t]);
   }
 }
+// Two launch shapes of every Q3 kernel (measured on the config-5 and config-3 batches, profiles/r2_q3_variants.txt):
+//   deep  4 waves per SIMD, 3 blocks (12 gathers) in flight per lane — the VERTEX-output products (DiA, Di^T: ~6 blocks per
+//         block row, output half the size of the input): at 6 waves the larger combined working set re-reads X from HBM;
+//   wide  6 waves per SIMD, 2 blocks in flight — the FACE-output products (Di, DiA^T: 3 blocks per block row, output twice
+//         the input, i.e. write-heavy): more waves hide the store stream; 0.84 -> 0.91 and 0.80 -> 0.92 of the roofline.
+// The launcher picks by the operator's blocks per block row (<= 4: wide).
 template <int N, int XG, int YG>
 __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_q3_lds_stats(const int *__restrict__ b_rowptr,
                                                                        const f4 *__restrict__ q_blk, int Mb,
                                                                        const float *__restrict__ X, int64_t ldx,
                                                                        float *__restrict__ Y, int64_t ldy, int nchunks,
                                                                        float *__restrict__ stats_part) {
-  spmm_q3_lds_body<N, XG, YG, false, true>(b_rowptr, q_blk, Mb, X, ldx, Y, ldy, nchunks, SpmmEpi{nullptr, 0, nullptr, 0},
-                                           stats_part);
+  spmm_q3_lds_body<N, XG, YG, false, true, 3>(b_rowptr, q_blk, Mb, X, ldx, Y, ldy, nchunks, SpmmEpi{nullptr, 0, nullptr, 0},
+                                              stats_part);
+}
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) SN_SIX_WAVES void spmm_q3_lds_stats_wide(const int *__restrict__ b_rowptr,
+                                                                           const f4 *__restrict__ q_blk, int Mb,
+                                                                           const float *__restrict__ X, int64_t ldx,
+                                                                           float *__restrict__ Y, int64_t ldy, int nchunks,
+                                                                           float *__restrict__ stats_part) {
+  spmm_q3_lds_body<N, XG, YG, false, true, 2>(b_rowptr, q_blk, Mb, X, ldx, Y, ldy, nchunks, SpmmEpi{nullptr, 0, nullptr, 0},
+                                              stats_part);
 }
 // stage 1 of the reduction of those partials: workgroup b adds rows b, b + gridDim.x, ... (fixed order) in fp64
 __global__ __launch_bounds__(kWG) void spmm_stats_reduce_k(const float *__restrict__ part, int64_t n,
@@ -705,7 +721,13 @@ template <int N, int XG, int YG>
 __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_q3_lds(const int *__restrict__ b_rowptr, const f4 *__restrict__ q_blk,
                                                                  int Mb, const float *__restrict__ X, int64_t ldx,
                                                                  float *__restrict__ Y, int64_t ldy, int nchunks) {
-  spmm_q3_lds_body<N, XG, YG, false>(b_rowptr, q_blk, Mb, X, ldx, Y, ldy, nchunks, SpmmEpi{nullptr, 0, nullptr, 0});
+  spmm_q3_lds_body<N, XG, YG, false, false, 3>(b_rowptr, q_blk, Mb, X, ldx, Y, ldy, nchunks, SpmmEpi{nullptr, 0, nullptr, 0});
+}
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) SN_SIX_WAVES void spmm_q3_lds_wide(const int *__restrict__ b_rowptr, const f4 *__restrict__ q_blk,
+                                                                     int Mb, const float *__restrict__ X, int64_t ldx,
+                                                                     float *__restrict__ Y, int64_t ldy, int nchunks) {
+  spmm_q3_lds_body<N, XG, YG, false, false, 2>(b_rowptr, q_blk, Mb, X, ldx, Y, ldy, nchunks, SpmmEpi{nullptr, 0, nullptr, 0});
 }
 template <int N, int XG, int YG>
 __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_q3_lds_epi(const int *__restrict__ b_rowptr,
@@ -713,7 +735,15 @@ __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_q3_lds_epi(const int *
                                                                      const float *__restrict__ X, int64_t ldx,
                                                                      float *__restrict__ Y, int64_t ldy, int nchunks,
                                                                      SpmmEpi epi) {
-  spmm_q3_lds_body<N, XG, YG, true>(b_rowptr, q_blk, Mb, X, ldx, Y, ldy, nchunks, epi);
+  spmm_q3_lds_body<N, XG, YG, true, false, 3>(b_rowptr, q_blk, Mb, X, ldx, Y, ldy, nchunks, epi);
+}
+template <int N, int XG, int YG>
+__global__ __launch_bounds__(kWG) SN_SIX_WAVES void spmm_q3_lds_epi_wide(const int *__restrict__ b_rowptr,
+                                                                         const f4 *__restrict__ q_blk, int Mb,
+                                                                         const float *__restrict__ X, int64_t ldx,
+                                                                         float *__restrict__ Y, int64_t ldy, int nchunks,
+                                                                         SpmmEpi epi) {
+  spmm_q3_lds_body<N, XG, YG, true, false, 2>(b_rowptr, q_blk, Mb, X, ldx, Y, ldy, nchunks, epi);
 }
 
 // BSR4 -> Q3: pack blocks that are exactly M(p); *flag is raised (atomically OR-ed) if any block is not.
@@ -1838,18 +1868,29 @@ static int spmm_q3_launch(const int32_t *b_rowptr, const float *q_blk, int64_t M
   const int64_t nchunks = (Mb + rpb - 1) / rpb;
   const unsigned grid = chunk_grid(nchunks);
   const f4 *q = reinterpret_cast<const f4 *>(q_blk);
+  // face-output products (3 blocks per block row) take the wide shape, vertex-output products (~6) the deep one
+  static const int force = env_int("SN_Q3_SHAPE", 0);                // A/B: 1 = always deep, 2 = always wide
+  const bool wide = force == 2 || (force == 0 && nblocks <= 4 * Mb);
   if (stats_part) {
     if (epi.e || N != 32 || y_group != 4) return SN_E_UNSUPPORTED;
     if (!stats_out) return SN_E_NULL;
-    if (x_group == 4) SN_KLAUNCH((spmm_q3_lds_stats<32, 4, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
-    else SN_KLAUNCH((spmm_q3_lds_stats<32, 1, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+    if (wide) {
+      if (x_group == 4) SN_KLAUNCH((spmm_q3_lds_stats_wide<32, 4, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+      else SN_KLAUNCH((spmm_q3_lds_stats_wide<32, 1, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+    } else {
+      if (x_group == 4) SN_KLAUNCH((spmm_q3_lds_stats<32, 4, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+      else SN_KLAUNCH((spmm_q3_lds_stats<32, 1, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+    }
     hipLaunchKernelGGL(spmm_stats_reduce_k, dim3(kSpmmStatsBlocks), dim3(kWG), 0, s, stats_part, (int64_t)grid, stats_out);
     return launch_status();
   }
-  if (epi.e)
-    SN_DISPATCH_N(spmm_q3_lds_epi, N, x_group, y_group, grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, epi);
-  else
-    SN_DISPATCH_N(spmm_q3_lds, N, x_group, y_group, grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks);
+  if (epi.e) {
+    if (wide) SN_DISPATCH_N(spmm_q3_lds_epi_wide, N, x_group, y_group, grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, epi);
+    else SN_DISPATCH_N(spmm_q3_lds_epi, N, x_group, y_group, grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, epi);
+  } else {
+    if (wide) SN_DISPATCH_N(spmm_q3_lds_wide, N, x_group, y_group, grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks);
+    else SN_DISPATCH_N(spmm_q3_lds, N, x_group, y_group, grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks);
+  }
   return launch_status();
 }
 

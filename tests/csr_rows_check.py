@@ -38,7 +38,6 @@ def ragged_csr(M, K, rng, long_rows=()):
 
 def main():
     rng = np.random.default_rng(int(os.environ.get("SN_CSR_ITERS", "0")) + 11)
-    assert os.environ.get("SN_RB4_ITERS", os.environ.get("SN_CSR_ITERS", "0")) is not None
     for N in (128, 64, 32, 16):
         for (M, K, long_rows) in [(1031, 777, ()), (257, 900, ((5, 700), (6, 3), (130, 900))), (64, 64, ()), (3, 5, ()),
                                   (4099, 4099, ((4098, 600),))]:
