@@ -435,6 +435,18 @@ int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W,
  *                         B2[c] + C2[c]) ): gradient of the mean path, added per row (times the row mask) inside
  *                         sn_linear_dgrad_eluseg_f32.
  * ------------------------------------------------------------------------------------------ */
+/* Ragged forms for PACKED batches (meshes of different sizes, no padding): the rows of mesh g are cut into tiles of at most
+ * 256 rows; tiles is an (ntiles x 3) int64 device table {mesh, first row, rows}, tiles of one mesh consecutive,
+ * seg_tile_ptr[nseg + 1] the first tile of every mesh.
+ * sn_segment_colsum_ragged_f32 : out[g, c] = scale[g] * sum over the rows r of mesh g of x[r, c]  (fp64, two deterministic
+ *                                stages; scale may be NULL).  With scale = 1 / vertex count: global_average on a packed batch.
+ * sn_bcast_rows_ragged_f32     : dst[r, :] = src[mesh(r), :]. */
+size_t sn_segment_colsum_ragged_workspace_bytes(int64_t ntiles, int32_t C);
+int sn_segment_colsum_ragged_f32(const float *x, int64_t ld, const int64_t *tiles, int64_t ntiles, const int64_t *seg_tile_ptr,
+                                 int64_t nseg, int32_t C, const float *scale, float *out, void *workspace,
+                                 size_t workspace_bytes, void *stream);
+int sn_bcast_rows_ragged_f32(const float *src, const int64_t *tiles, int64_t ntiles, float *dst, int64_t ldd, int32_t C,
+                             void *stream);
 size_t sn_segment_colsum_workspace_bytes(int64_t rows_per_seg, int64_t nseg, int32_t C);
 int sn_segment_colsum_f32(const float *x, int64_t ld, const float *mask, int64_t rows_per_seg, int64_t nseg, int32_t C,
                           float *out, void *workspace, size_t workspace_bytes, void *stream);

@@ -64,6 +64,9 @@ SIGNATURES = {
     "sn_bn_fold_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, C.c_double, _i32, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sn_bn_bwd_coeffs_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "sn_segment_colsum_ragged_workspace_bytes": (_sz, [_i64, _i32]),
+    "sn_segment_colsum_ragged_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "sn_bcast_rows_ragged_f32": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _i32, _vp]),
     "sn_segment_colsum_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "sn_segment_colsum_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _vp, _vp, _sz, _vp]),
     "sn_bcast_rows_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _vp]),

@@ -20,7 +20,7 @@ import torch.nn.functional as F
 
 from . import kernels, mesh_ops
 from . import utils_pt as utils
-from .operators import OperatorPool, h2d_async
+from .operators import OperatorPool, PackedSegments, h2d_async
 
 INPUT_FRAMES = 2       # main.py:105
 OUTPUT_FRAMES = 40     # main.py:106
@@ -144,6 +144,8 @@ class _MaskedSmoothL1(torch.autograd.Function):
 def loss_fn(outputs, targets, mask, batch_size):
     """Masked smooth-L1, summed, divided by the batch size (main.py:225-226).  Under data parallelism pass the
     GLOBAL batch size so that the all-reduced (summed) gradients equal the single-process ones."""
+    if isinstance(mask, PackedSegments):               # packed batch: every row is a real vertex
+        mask = torch.ones(outputs.shape[0] * outputs.shape[1], dtype=torch.float32, device=outputs.device)
     if outputs.dim() == 3 and outputs.dtype == torch.float32 and targets.dtype == torch.float32 and \
             not targets.requires_grad and mask.numel() == outputs.shape[0] * outputs.shape[1]:
         C = outputs.shape[2]
@@ -255,9 +257,11 @@ class ClothSequences:
             self._xyz_vm = cached
         return cached[1]
 
-    def sample_batch(self, batch_size, rng: np.random.Generator, seq_ids=None, offsets=None) -> Batch:
+    def sample_batch(self, batch_size, rng: np.random.Generator, seq_ids=None, offsets=None, packed: bool = False) -> Batch:
         """Counterpart of sample_batch (main.py:98-185): random sequence + random start frame per sample; operator of
-        the last input frame (main.py:156); everything zero-padded to the batch maximum (main.py:126-130)."""
+        the last input frame (main.py:156); everything zero-padded to the batch maximum (main.py:126-130).
+        packed=True (no counterpart in the reference): the batch WITHOUT padding — inputs (1, sum V_i, 6), targets
+        (1, sum V_i, 120), `mask` = PackedSegments, packed block-diagonal operators; `num_meshes` stays the sample count."""
         if seq_ids is None:
             seq_ids = rng.integers(0, self.n, size=batch_size)
         if offsets is None:
@@ -280,6 +284,17 @@ class ClothSequences:
         mask = (torch.arange(nv, device=self.device)[None, :] < self.vcount[sid][:, None]).float().unsqueeze(2)
         op_ids = seq_ids * self.op_frames + (offsets + INPUT_FRAMES - 1)
         L = Di = DiA = None
+        if packed:
+            if self.operators == "device":
+                raise ValueError("packed batches need pooled operators")
+            keep = mask.reshape(B, nv) > 0                                             # real rows, mesh-major order
+            inputs, targets = inputs[keep].unsqueeze(0), targets[keep].unsqueeze(0)
+            seg = PackedSegments(self.num_vertices[seq_ids], self.device)
+            if self.kind == "dir":
+                Di, DiA = self.pool_Di.assemble(op_ids), self.pool_DiA.assemble(op_ids)
+            else:
+                L = self.pool_L.assemble(op_ids)
+            return Batch(inputs, targets, seg, L, Di, DiA, B)
         if self.operators == "device":
             from .operators import dirac_operators_from_mesh
 

@@ -547,6 +547,7 @@ __device__ __forceinline__ void spmm_bsr4_lds_body(const int *__restrict__ b_row
 // (PMC TCC_EA0_RDREQ: 519 MB against the compulsory 451 MB).
 #define SN_FOUR_WAVES __attribute__((amdgpu_waves_per_eu(4, 4)))
 #define SN_SIX_WAVES __attribute__((amdgpu_waves_per_eu(6, 6)))
+#define SN_FIVE_WAVES __attribute__((amdgpu_waves_per_eu(5, 5)))      // (the statistics variant's LDS transposition fits 5 workgroups per CU)
 template <int N, int XG, int YG>
 __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_bsr4_lds(const int *__restrict__ b_rowptr, const int *__restrict__ b_colind,
                                                      const float *__restrict__ b_vals, int Mb,
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_q3_lds_stats(const int
                                               stats_part);
 }
 template <int N, int XG, int YG>
-__global__ __launch_bounds__(kWG) SN_SIX_WAVES void spmm_q3_lds_stats_wide(const int *__restrict__ b_rowptr,
+__global__ __launch_bounds__(kWG) SN_FIVE_WAVES void spmm_q3_lds_stats_wide(const int *__restrict__ b_rowptr,
                                                                            const f4 *__restrict__ q_blk, int Mb,
                                                                            const float *__restrict__ X, int64_t ldx,
                                                                            float *__restrict__ Y, int64_t ldy, int nchunks,
@@ -1345,6 +1346,68 @@ __global__ __launch_bounds__(kWG) void validate_csr_k(const int *__restrict__ ro
     }
   }
   if (bad) atomicOr(flags, bad);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Ragged per-mesh column means for PACKED batches (global_average, utils_pt.py:120-122, on meshes of different sizes without
+// padding).  The rows of mesh g are cut into tiles of <= kRagTile rows; `tiles` is an (ntiles x 3) int64 table
+// {mesh, first row, rows} with the tiles of a mesh consecutive, seg_tile_ptr[g] the first tile of mesh g.  Stage 1: one
+// workgroup per tile, fp64 column sums of its rows; stage 2: one thread per (mesh, column) adds the mesh's tiles in order
+// and applies the optional per-mesh scale (1 / vertex count).  Deterministic (no atomics).
+// ------------------------------------------------------------------------------------------------
+constexpr int kRagTile = 256;
+
+__global__ __launch_bounds__(kWG) void seg_colsum_ragged_tiles_k(const float *__restrict__ x, int64_t ld,
+                                                                 const int64_t *__restrict__ tiles, int C,
+                                                                 double *__restrict__ partial /* [ntiles][C] */) {
+  const int64_t *t = tiles + 3 * (int64_t)blockIdx.x;
+  const int64_t r0 = t[1];
+  const int n = (int)t[2];
+  __shared__ double s_acc[kWG];
+  // thread (lane = column within a 256/CL-row interleave): CL = columns handled per sweep
+  for (int c0 = 0; c0 < C; c0 += kWG) {
+    const int CL = (C - c0) < kWG ? (C - c0) : kWG;           // columns in this sweep
+    const int RL = kWG / CL > 0 ? kWG / CL : 1;              // row lanes sharing a column
+    const int col = threadIdx.x % CL, rl = threadIdx.x / CL;
+    double acc = 0.0;
+    if (rl < RL)
+      for (int r = rl; r < n; r += RL) acc += (double)x[(r0 + r) * ld + c0 + col];
+    s_acc[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < CL) {
+      double tot = 0.0;
+      for (int k = 0; k < RL; ++k) tot += s_acc[k * CL + threadIdx.x];    // fixed order
+      partial[(int64_t)blockIdx.x * C + c0 + threadIdx.x] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kWG) void seg_colsum_ragged_final_k(const double *__restrict__ partial,
+                                                                 const int64_t *__restrict__ seg_tile_ptr, int64_t nseg, int C,
+                                                                 const float *__restrict__ scale, float *__restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x;
+  if (i >= nseg * C) return;
+  const int64_t g = i / C;
+  const int c = (int)(i - g * C);
+  double tot = 0.0;
+  for (int64_t k = seg_tile_ptr[g]; k < seg_tile_ptr[g + 1]; ++k) tot += partial[k * C + c];
+  if (scale) tot *= (double)scale[g];
+  out[i] = (float)tot;
+}
+
+// dst[r, :] = src[mesh(r), :] for the rows of every tile (the per-mesh mean broadcast into a concat buffer's second half)
+__global__ __launch_bounds__(kWG) void bcast_rows_ragged_k(const float *__restrict__ src, const int64_t *__restrict__ tiles,
+                                                           float *__restrict__ dst, int64_t ldd, int C) {
+  const int64_t *t = tiles + 3 * (int64_t)blockIdx.x;
+  const float *row = src + t[0] * C;
+  const int64_t r0 = t[1];
+  const int n = (int)t[2];
+  const int c4 = C / 4;
+  for (int i = threadIdx.x; i < n * c4; i += kWG) {
+    const int r = i / c4, c = (i - r * c4) * 4;
+    st4_s(dst + (r0 + r) * ldd + c, ld4(row + c), kStreamNT);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2104,6 +2167,42 @@ int sn_validate_csr_i32(const int32_t *rowptr, const int32_t *colind, const floa
   if (M == 0) return SN_OK;
   if (!rowptr || (nnz > 0 && !colind)) return SN_E_NULL;
   hipLaunchKernelGGL(validate_csr_k, dim3(grid_for(M, kWG)), dim3(kWG), 0, s, rowptr, colind, vals, M, K, nnz, flags);
+  return launch_status();
+}
+
+size_t sn_segment_colsum_ragged_workspace_bytes(int64_t ntiles, int32_t C) {
+  if (ntiles < 0 || C < 1) return 0;
+  return (size_t)ntiles * (size_t)C * sizeof(double);
+}
+
+int sn_segment_colsum_ragged_f32(const float *x, int64_t ld, const int64_t *tiles, int64_t ntiles, const int64_t *seg_tile_ptr,
+                                 int64_t nseg, int32_t C, const float *scale, float *out, void *workspace,
+                                 size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (ntiles < 0 || nseg < 0 || C < 1 || ld < C) return SN_E_SHAPE;
+  if (!fits_i32(ntiles) || !fits_i32(nseg * (int64_t)C)) return SN_E_RANGE;
+  if (nseg == 0) return SN_OK;
+  if (!out || !seg_tile_ptr || (ntiles > 0 && (!x || !tiles))) return SN_E_NULL;
+  if (workspace_bytes < sn_segment_colsum_ragged_workspace_bytes(ntiles, C) || (ntiles > 0 && !workspace)) return SN_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  double *partial = static_cast<double *>(workspace);
+  if (ntiles > 0)
+    hipLaunchKernelGGL(seg_colsum_ragged_tiles_k, dim3((unsigned)ntiles), dim3(kWG), 0, s, x, ld, tiles, (int)C, partial);
+  hipLaunchKernelGGL(seg_colsum_ragged_final_k, dim3(grid_for(nseg * (int64_t)C, kWG)), dim3(kWG), 0, s, partial, seg_tile_ptr, nseg,
+                     (int)C, scale, out);
+  return launch_status();
+}
+
+int sn_bcast_rows_ragged_f32(const float *src, const int64_t *tiles, int64_t ntiles, float *dst, int64_t ldd, int32_t C,
+                             void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (ntiles < 0 || C < 4 || (C & 3) || ldd < C || (ldd & 3)) return SN_E_SHAPE;
+  if (!fits_i32(ntiles)) return SN_E_RANGE;
+  if (ntiles == 0) return SN_OK;
+  if (!src || !tiles || !dst) return SN_E_NULL;
+  if (!aligned16(src) || !aligned16(dst)) return SN_E_ALIGN;
+  hipLaunchKernelGGL(bcast_rows_ragged_k, dim3((unsigned)ntiles), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, tiles, dst,
+                     ldd, (int)C);
   return launch_status();
 }
 

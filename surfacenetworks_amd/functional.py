@@ -20,7 +20,7 @@ import torch
 from . import kernels
 from .operators import SparseOperator, as_operator
 
-__all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg_propagate", "bn_linear", "bnlin_forward",
+__all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg_propagate", "avg_propagate_ragged", "bn_linear", "bnlin_forward",
            "bnlin_backward", "bn_prepare", "set_dirac_format", "set_laplacian_format", "SpmmTimer", "thin_linear", "thin_linear_supported"]
 
 _DIRAC_FORMAT = "q3"
@@ -704,6 +704,40 @@ class _AvgPropagate(torch.autograd.Function):
         g_x = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
         kernels.elu_bwd_bcast(g_cat[:, :C], cat[:, :C], gm.contiguous(), mask_rows, g_x, ctx.per)
         return g_x, None, None, None
+
+
+class _AvgPropagateRagged(torch.autograd.Function):
+    """_AvgPropagate on a PACKED batch: cat = [e, mean_mesh(e)] with meshes of different sizes and no padding rows
+    (operators.PackedSegments; sn_segment_colsum_ragged_f32 / sn_bcast_rows_ragged_f32)."""
+
+    @staticmethod
+    def forward(ctx, x, seg):
+        x = _rows2d(x)
+        rows, C = x.shape
+        cat = torch.empty((rows, 2 * C), dtype=torch.float32, device=x.device)
+        kernels.elu_into(x, cat[:, :C])
+        kernels.bcast_rows_ragged(seg.mean(cat[:, :C]), seg.tiles, cat[:, C:])
+        ctx.seg = seg
+        ctx.save_for_backward(cat)
+        return cat
+
+    @staticmethod
+    def backward(ctx, g_cat):
+        (cat,) = ctx.saved_tensors
+        seg = ctx.seg
+        g_cat = _rows2d(g_cat)
+        C = cat.shape[1] // 2
+        gm = seg.mean(g_cat[:, C:])                               # (sum over the mesh's rows of d/d(mean)) / count
+        gb = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
+        kernels.bcast_rows_ragged(gm, seg.tiles, gb)
+        g_x = torch.empty_like(gb)
+        kernels.elu_bwd(g_cat[:, :C], cat[:, :C], g_x, False, gb)      # (g_e + broadcast mean-path gradient) * elu'(e)
+        return g_x, None
+
+
+def avg_propagate_ragged(x2d: torch.Tensor, seg) -> torch.Tensor:
+    """x2d: (sum V_i, C) packed rows, seg: operators.PackedSegments -> (sum V_i, 2C) [elu(x), per-mesh mean of elu(x)]."""
+    return _AvgPropagateRagged.apply(x2d, seg)
 
 
 def avg_propagate(x: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:

@@ -14,7 +14,7 @@ from . import _lib
 __all__ = [
     "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged", "validate_csr",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
-    "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
+    "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
     "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
 ]
@@ -412,6 +412,28 @@ def segment_colsum(x, mask, rows_per_seg: int, nseg: int):
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
     _lib.call("sn_segment_colsum_f32", _p(x), _ld(x), _p(mask), rows_per_seg, nseg, C, _p(out), _p(ws), ws_bytes, _stream())
     return out
+
+
+def segment_colsum_ragged(x, tiles, seg_tile_ptr, nseg: int, scale=None):
+    """(nseg, C) fp32: per-mesh column sums of the 2-D view x of a PACKED batch, times the optional per-mesh `scale`
+    (sn_segment_colsum_ragged_f32); tiles / seg_tile_ptr: the int64 device tables of operators.PackedSegments."""
+    _dev(x, tiles, seg_tile_ptr, scale)
+    C = x.shape[1]
+    nt = int(tiles.shape[0])
+    out = torch.empty((nseg, C), dtype=torch.float32, device=x.device)
+    ws_bytes = int(_lib.load().sn_segment_colsum_ragged_workspace_bytes(nt, C))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    _lib.call("sn_segment_colsum_ragged_f32", _p(x), _ld(x), _p(tiles), nt, _p(seg_tile_ptr), nseg, C, _p(scale), _p(out), _p(ws),
+              ws_bytes, _stream())
+    return out
+
+
+def bcast_rows_ragged(src, tiles, dst) -> None:
+    """dst[r, :] = src[mesh(r), :] for a PACKED batch (sn_bcast_rows_ragged_f32)."""
+    _dev(src, tiles, dst)
+    if dst.shape[1] != src.shape[1]:
+        raise ValueError("bcast_rows_ragged: shape mismatch")
+    _lib.call("sn_bcast_rows_ragged_f32", _p(src.contiguous()), _p(tiles), int(tiles.shape[0]), _p(dst), _ld(dst), src.shape[1], _stream())
 
 
 def bcast_rows(src, dst, rows_per_seg: int) -> None:

@@ -24,7 +24,8 @@ import torch
 
 from . import kernels
 
-__all__ = ["SparseOperator", "OperatorPool", "as_operator", "dirac_operators_from_mesh", "laplacian_operator_from_mesh"]
+__all__ = ["SparseOperator", "OperatorPool", "PackedSegments", "as_operator", "dirac_operators_from_mesh",
+           "laplacian_operator_from_mesh"]
 
 # A BSR4 copy is kept when zero-fill costs at most this much extra storage over CSR entries.
 _BSR4_MAX_FILL = 1.6
@@ -355,6 +356,50 @@ def laplacian_operator_from_mesh(V: torch.Tensor, F: torch.Tensor) -> SparseOper
         Vg, Fg = V, F.to(torch.int32)
     rowptr, colind, vals = kernels.laplacian_from_mesh(Vg.float(), Fg)
     return SparseOperator(rowptr, colind, vals, (B * nV, B * nV), batch=B)
+
+
+class PackedSegments:
+    """Per-mesh row ranges of a PACKED batch (the concatenation of the meshes' node rows, no padding) — what takes the place
+    of the reference's (B, Vmax, 1) `mask` tensor when a model runs on a packed batch: pass it as the `mask` argument of
+    AvgResNet2 / global_average / the task models.  Holds the host lengths and, on the device, the tile table of
+    sn_segment_colsum_ragged_f32 (tiles of <= 256 rows, a mesh's tiles consecutive) and 1 / vertex count per mesh."""
+
+    TILE = 256
+
+    def __init__(self, lengths, device="cuda"):
+        self.lengths = np.asarray(lengths, dtype=np.int64)
+        if self.lengths.ndim != 1 or (self.lengths < 1).any():
+            raise ValueError("PackedSegments: one positive row count per mesh")
+        self.nseg = int(len(self.lengths))
+        self.offsets = np.zeros(self.nseg + 1, dtype=np.int64)
+        np.cumsum(self.lengths, out=self.offsets[1:])
+        self.rows = int(self.offsets[-1])
+        per = (self.lengths + self.TILE - 1) // self.TILE
+        seg_tile_ptr = np.zeros(self.nseg + 1, dtype=np.int64)
+        np.cumsum(per, out=seg_tile_ptr[1:])
+        seg = np.repeat(np.arange(self.nseg), per)
+        k = np.arange(int(seg_tile_ptr[-1])) - seg_tile_ptr[seg]                   # tile index inside its mesh
+        first = self.offsets[seg] + k * self.TILE
+        cnt = np.minimum(self.TILE, self.offsets[seg + 1] - first)
+        self.device = torch.device(device)
+        self.tiles = h2d_async(np.stack([seg, first, cnt], axis=1), self.device)
+        self.seg_tile_ptr = h2d_async(seg_tile_ptr, self.device)
+        self.inv_count = h2d_async((1.0 / self.lengths).astype(np.float32), self.device)
+
+    @classmethod
+    def of_operator(cls, op: "SparseOperator", group: int = 1, side: str = "cols") -> "PackedSegments":
+        """Row ranges of the dense operand of a packed operator: its column blocks (`side="cols"`, the input side) or its
+        row blocks, divided by `group` (4 for the quaternion view of the Dirac operators)."""
+        off = op.col_offsets if side == "cols" else op.row_offsets
+        if off is None:
+            raise ValueError("not a packed operator (OperatorPool.assemble(sel) without sizes)")
+        return cls(np.diff(off) // group, op.device)
+
+    def mean(self, x2d: torch.Tensor) -> torch.Tensor:
+        """(nseg, C): per-mesh column means of the (rows, C) operand."""
+        if x2d.shape[0] != self.rows:
+            raise ValueError(f"PackedSegments: {self.rows} rows expected, got {x2d.shape[0]}")
+        return kernels.segment_colsum_ragged(x2d, self.tiles, self.seg_tile_ptr, self.nseg, self.inv_count)
 
 
 def as_operator(A) -> SparseOperator:

@@ -23,12 +23,12 @@ import torch.nn.functional as F
 
 from . import blocks as snB
 from . import functional as snF
-from .operators import SparseOperator, as_operator
+from .operators import PackedSegments, SparseOperator, as_operator
 
 __all__ = [
     "sparse_cat", "sparse_diag_cat", "sp_sparse_to_pt_sparse", "to_dense_batched", "GraphConv1x1",
     "GraphBatchNorm", "global_average", "DenseLapResNet2", "LapResNet2", "DirResNet2", "AvgResNet2",
-    "MlpResNet2", "SparseBMMFunc",
+    "MlpResNet2", "SparseBMMFunc", "PackedSegments",
 ]
 
 
@@ -65,7 +65,10 @@ def to_dense_batched(x, batch_size):
 
 
 def global_average(x, mask):
-    """Masked mean over the node axis, kept as (B,1,C) (utils_pt.py:120-122)."""
+    """Masked mean over the node axis, kept as (B,1,C) (utils_pt.py:120-122).  mask = PackedSegments (a packed batch
+    (1, sum V_i, C)): the per-mesh means, (meshes, 1, C)."""
+    if isinstance(mask, PackedSegments):
+        return mask.mean(x.reshape(-1, x.shape[-1])).unsqueeze(1)
     m = mask.expand_as(x)
     return (x * m).sum(1, keepdim=True) / m.sum(1, keepdim=True)
 
@@ -237,6 +240,13 @@ class AvgResNet2(_TwoStage):
 
     def forward(self, L, mask, inputs):
         b, n, c = inputs.size()
+        if isinstance(mask, PackedSegments):
+            # packed batch (1, sum V_i, C): per-mesh means over ragged row ranges, no padding rows anywhere; BatchNorm then
+            # sees the real rows only (the reference's padded batch includes the padding rows, utils_pt.py:97-99)
+            x2d = inputs.reshape(b * n, c)
+            h = self.bn_fc0.forward2d(snF.avg_propagate_ragged(x2d, mask))
+            h = self.bn_fc1.forward2d(snF.avg_propagate_ragged(h, mask), residual=x2d)
+            return h.view(b, n, c)
         if c % 4 or 256 % (c // 4) or inputs.dtype != torch.float32:        # shapes the fused kernels do not cover
             x = F.elu(inputs)
             x = self.bn_fc0(torch.cat([x, global_average(x, mask).expand_as(x)], 2))

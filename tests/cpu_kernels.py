@@ -159,6 +159,22 @@ def validate_csr(rowptr, colind, vals, M, K):
     return bad
 
 
+def segment_colsum_ragged(x, tiles, seg_tile_ptr, nseg, scale=None):
+    t = _np(tiles)
+    out = np.zeros((nseg, x.shape[1]), np.float64)
+    xx = x.detach().double().numpy()
+    for g, r0, n in t:
+        out[g] += xx[r0: r0 + n].sum(0)
+    if scale is not None:
+        out *= _np(scale).astype(np.float64)[:, None]
+    return torch.from_numpy(out.astype(np.float32))
+
+
+def bcast_rows_ragged(src, tiles, dst):
+    for g, r0, n in _np(tiles):
+        dst[r0: r0 + n] = src[g]
+
+
 def elu_into(src, dst):
     c_oracle.elu_raw(src.data_ptr(), _ld(src), dst.data_ptr(), _ld(dst), src.shape[0], src.shape[1])
 

@@ -630,3 +630,67 @@ def check_model_variants(golden_dir, dev, tol=1e-5):
             assert rel_err(full.cpu().numpy(), z[f"{tag}_out"]) <= 5 * tol, (tag, "end to end", rel_err(full.cpu().numpy(), z[f"{tag}_out"]))
     for key in ("dir", "amp", "lap", "avg", "mlp"):
         assert list(dc.SiameseModel(key, 15).state_dict().keys()) == [str(k) for k in z[f"siamese_{key}_keys"]], key
+
+
+def check_packed_model(dev):
+    """Whole models on PACKED batches (SURVEY.md §7 "ragged not padded"; no counterpart in the reference, which pads every
+    mesh to the batch maximum): inputs (1, sum V_i, C), PackedSegments in place of the mask, packed block-diagonal operators.
+      * eval-mode BatchNorm: the packed model equals the padded model on the real rows (padding rows cannot influence real
+        rows when no batch statistics are taken), loss included — Dirac and Laplacian ARAP models on a ragged batch;
+      * train mode on equally sized meshes (no padding exists): packed == padded in outputs, loss and gradients;
+      * the ragged global-average stage's backward against torch autograd on the same composition;
+      * one training step on a ragged packed batch runs and changes the parameters."""
+    import torch.nn.functional as F
+
+    from surfacenetworks_amd import arap, functional as snF
+    from surfacenetworks_amd.operators import PackedSegments
+
+    grids = [(6, 6), (9, 8), (7, 5), (17, 16)]                   # 36, 72, 35, 272 vertices (one mesh spans two 256-row tiles)
+    ids, offs = np.array([1, 0, 3, 2, 1]), np.array([0, 1, 1, 0, 1])
+    for kind in ("dir", "lap"):
+        ds = arap.ClothSequences(grids, frames=45, op_frames=3, seed=1, device=dev, model=kind)
+        bp = ds.sample_batch(5, None, seq_ids=ids, offsets=offs, packed=True)
+        bd = ds.sample_batch(5, None, seq_ids=ids, offsets=offs)
+        assert bp.inputs.shape == (1, int(ds.num_vertices[ids].sum()), 6) and isinstance(bp.mask, PackedSegments)
+        assert (bp.Di if kind == "dir" else bp.L).shape[1] == (4 if kind == "dir" else 1) * bp.inputs.shape[1]
+        # (eval-mode Laplacian blocks are not normalised — cotangent entries of 1e3..1e4 — so that model keeps 3 layers to stay finite)
+        m = deterministic_init(arap.DirModel() if kind == "dir" else arap.Model(3), 3).eval().to(dev)
+        with torch.no_grad():
+            lp, op_ = arap.forward_loss(m, bp)
+            ld_, od = arap.forward_loss(m, bd)
+        keep = (bd.mask.reshape(5, -1) > 0).cpu().numpy()
+        assert np.isfinite(od.cpu().numpy()).all() and rel_err(op_[0].cpu().numpy(), od.cpu().numpy()[keep]) < 1e-5, kind
+        assert abs(lp.item() - ld_.item()) <= 1e-5 * abs(ld_.item())
+    # train mode, equal sizes
+    ds = arap.ClothSequences([(8, 8)] * 3, frames=45, op_frames=3, seed=2, device=dev, model="dir")
+    ids3, offs3 = np.arange(3), np.zeros(3, dtype=np.int64)
+    res = []
+    for packed in (True, False):
+        m = deterministic_init(arap.DirModel(), 4).train().to(dev)
+        b = ds.sample_batch(3, None, seq_ids=ids3, offsets=offs3, packed=packed)
+        loss, out = arap.forward_loss(m, b)
+        loss.backward()
+        res.append((loss.item(), out.detach().reshape(-1, 120).cpu().numpy(), grad_signature(m)))
+    assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0]) and rel_err(res[0][1], res[1][1]) < 2e-5
+    assert not sigs_close(res[0][2], lambda k: res[1][2][k], 2e-4)
+    # ragged global-average stage: forward and backward against torch autograd
+    seg = PackedSegments([5, 300, 17, 64], dev)
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(seg.rows, 128, generator=g).to(dev).requires_grad_(True)
+    w = torch.randn(seg.rows, 256, generator=g).to(dev)
+    cat = snF.avg_propagate_ragged(x, seg)
+    (cat * w).sum().backward()
+    xr = x.detach().clone().requires_grad_(True)
+    e = F.elu(xr)
+    means = torch.cat([e[seg.offsets[i]: seg.offsets[i + 1]].mean(0, keepdim=True).expand(int(seg.lengths[i]), -1) for i in range(seg.nseg)])
+    ref = torch.cat([e, means], 1)
+    (ref * w).sum().backward()
+    assert rel_err(cat.detach().cpu().numpy(), ref.detach().cpu().numpy()) < 2e-6
+    assert rel_err(x.grad.cpu().numpy(), xr.grad.cpu().numpy()) < 1e-5
+    # a training step on the ragged packed batch
+    ds = arap.ClothSequences(grids, frames=45, op_frames=3, seed=1, device=dev, model="dir")
+    m = deterministic_init(arap.DirModel(), 5).train().to(dev)
+    opt = arap.make_optimizer(m)
+    before = torch.cat([p_.detach().reshape(-1) for p_ in m.parameters()]).clone()
+    l1 = arap.train_step(m, opt, ds.sample_batch(5, None, seq_ids=ids, offsets=offs, packed=True))
+    assert torch.isfinite(l1) and not torch.equal(before, torch.cat([p_.detach().reshape(-1) for p_ in m.parameters()]))

@@ -306,3 +306,33 @@ def test_operator_moves_between_devices_with_its_transpose():
     back = host.to(DEV)
     assert back.is_cuda and abs(back.t().to_scipy() - ops["Di"].T).max() == 0
     assert op.to(DEV) is op
+
+
+def test_models_on_packed_batches():
+    """Ragged batches without padding through whole models (PackedSegments, ragged global-average kernels)."""
+    pc.check_packed_model(DEV)
+
+
+@pytest.mark.parametrize("C", [128, 64, 120, 3])
+def test_ragged_segment_kernels(C):
+    """sn_segment_colsum_ragged_f32 / sn_bcast_rows_ragged_f32 against numpy: meshes shorter and longer than a 256-row tile,
+    strided operands, with and without the per-mesh scale."""
+    from surfacenetworks_amd import kernels
+    from surfacenetworks_amd.operators import PackedSegments
+
+    seg = PackedSegments([1, 256, 257, 1000, 7, 513], DEV)
+    rng = np.random.default_rng(C)
+    buf = rng.standard_normal((seg.rows, 2 * C + 4)).astype(np.float32)
+    xb = torch.from_numpy(buf).to(DEV)
+    x = xb[:, :C]
+    want = np.stack([buf[seg.offsets[i]: seg.offsets[i + 1], :C].astype(np.float64).sum(0) for i in range(seg.nseg)])
+    got = kernels.segment_colsum_ragged(x, seg.tiles, seg.seg_tile_ptr, seg.nseg).cpu().numpy()
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6 * np.abs(buf).sum(0).max())
+    got_m = seg.mean(x).cpu().numpy()
+    assert np.allclose(got_m, want / seg.lengths[:, None], rtol=1e-6, atol=1e-7)
+    if C % 4 == 0:
+        dst = torch.full((seg.rows, 2 * C), float("nan"), device=DEV)
+        src = torch.from_numpy(rng.standard_normal((seg.nseg, C)).astype(np.float32)).to(DEV)
+        kernels.bcast_rows_ragged(src, seg.tiles, dst[:, C:])
+        ids = np.repeat(np.arange(seg.nseg), seg.lengths)
+        assert np.array_equal(dst[:, C:].cpu().numpy(), src.cpu().numpy()[ids]) and torch.isnan(dst[:, :C]).all()

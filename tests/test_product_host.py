@@ -55,3 +55,7 @@ def test_model_layers_match_reference_layer_by_layer(golden_dir, cpu_kernels, ta
 
 def test_model_variants_match_reference(golden_dir, cpu_kernels):
     pc.check_model_variants(golden_dir, "cpu")
+
+
+def test_models_on_packed_batches(cpu_kernels):
+    pc.check_packed_model("cpu")

@@ -1,5 +1,5 @@
 """Step-time measurements of the other BASELINE configs (parity-test cases, not bench lines):
-   python tools/train_bench.py mnist_dir|mnist_lap|faust_lap|arap_lap [steps]
+   python tools/train_bench.py mnist_dir|mnist_lap|faust_lap|arap_lap|arap_ragged [steps]
 mnist_dir = config 2 (Mesh-MNIST Dirac, batch 512); mnist_lap = config 1 shape on the GPU; faust_lap = config 4 per-GPU
 work (one pair of 6890-vertex bodies padded to 7000); arap_lap = the Laplacian variant of config 3."""
 import os
@@ -78,6 +78,21 @@ def main():
         ids = np.arange(64)
         dt = timed(lambda: arap.train_step(model, opt, ds.sample_batch(64, rng, seq_ids=ids)), steps)
         print(f"{what}: batch 64 x 71x71, {dt * 1e3:.2f} ms/step, {64 / dt:.0f} meshes/s")
+    elif what == "arap_ragged":
+        # a ragged batch (config-5-like sizes: 64 cloth meshes with 1 000 .. 10 000 vertices): padded as the reference batches
+        # (every mesh to the batch maximum) against PACKED (no padding rows, PackedSegments; BatchNorm over real rows only)
+        vs = np.random.default_rng(5).integers(1000, 10001, size=64)
+        grids = [(int(np.sqrt(v)), int(v) // int(np.sqrt(v))) for v in vs]
+        ds = arap.ClothSequences(grids, frames=44, op_frames=2, seed=3, device=dev, model="dir")
+        ids = np.arange(64)
+        for packed in (False, True):
+            torch.manual_seed(0)
+            model = arap.DirModel().to(dev).train()
+            opt = arap.make_optimizer(model)
+            dt = timed(lambda: arap.train_step(model, opt, ds.sample_batch(64, rng, seq_ids=ids, packed=packed)), steps)
+            rows = int(ds.num_vertices.sum()) if packed else 64 * int(ds.num_vertices.max())
+            print(f"{what}: 64 ragged meshes (sum V = {int(ds.num_vertices.sum())}, max V = {int(ds.num_vertices.max())}), "
+                  f"{'packed' if packed else 'padded'}: {rows} vertex rows, {dt * 1e3:.2f} ms/step, {64 / dt:.0f} meshes/s")
     else:
         raise SystemExit(__doc__)
 
