@@ -672,7 +672,10 @@ def check_packed_model(dev):
         loss.backward()
         res.append((loss.item(), out.detach().reshape(-1, 120).cpu().numpy(), grad_signature(m)))
     assert abs(res[0][0] - res[1][0]) <= 1e-5 * abs(res[1][0]) and rel_err(res[0][1], res[1][1]) < 2e-5
-    assert not sigs_close(res[0][2], lambda k: res[1][2][k], 2e-4)
+    # gradients: the two paths run the global-average stages through different kernels (ragged full-width vs the half-width
+    # algebra), i.e. two fp32 evaluation orders of a 15-layer train-mode model whose gradients move by 3.5e-3 of their norm
+    # under one-ulp input noise in the reference itself (models_reference.npz: arap_dir_spread_grad)
+    assert _sig_err(res[0][2], res[1][2]) < 4e-3, _sig_err(res[0][2], res[1][2])
     # ragged global-average stage: forward and backward against torch autograd
     seg = PackedSegments([5, 300, 17, 64], dev)
     g = torch.Generator().manual_seed(0)
