@@ -116,7 +116,7 @@ def cpu_baseline(seed: int):
     legs = [_cpu_leg_subprocess(1, seed, 1, 6.0, 4, 60.0),
             _cpu_leg_subprocess(4, seed, mid, 8.0, 20, 60.0)]
     if cores not in (1, mid):
-        legs.append(_cpu_leg_subprocess(1, seed, cores, 5.0, 2, 45.0))
+        legs.append(_cpu_leg_subprocess(1, seed, cores, 5.0, 2, 30.0))
     try:
         with open("/proc/cpuinfo") as fh:
             cpu = next((ln.split(":", 1)[1].strip() for ln in fh if ln.startswith("model name")), "unknown")
