@@ -1933,7 +1933,9 @@ static int spmm_q3_launch(const int32_t *b_rowptr, const float *q_blk, int64_t M
   const f4 *q = reinterpret_cast<const f4 *>(q_blk);
   // face-output products (3 blocks per block row) take the wide shape, vertex-output products (~6) the deep one
   static const int force = env_int("SN_Q3_SHAPE", 0);                // A/B: 1 = always deep, 2 = always wide
-  const bool wide = force == 2 || (force == 0 && nblocks <= 4 * Mb);
+  // (a grid of fewer than two rounds of the deep shape's 4 workgroups per CU — the Mesh-MNIST batches — also runs wide: at
+  // 1 200 workgroups the deep shape leaves a 17 % tail, measured 0.67 -> 0.77 on the config-2 vertex-output products)
+  const bool wide = force == 2 || (force == 0 && (nblocks <= 4 * Mb || grid < 8u * kCUs));
   if (stats_part) {
     if (epi.e || N != 32 || y_group != 4) return SN_E_UNSUPPORTED;
     if (!stats_out) return SN_E_NULL;
