@@ -375,7 +375,8 @@ def main():
         with open(os.path.join(ROOT, "profiles", "r2_pmc_traffic_c3.json")) as fh:
             table = json.load(fh)
         base = dom_name.split("<")[0]
-        hits = [v for k, v in table.items() if not k.startswith("_") and k.split("<")[0] == base and f"<{dom[0][4]}," in k]
+        # (the library launches every Q3 kernel in two shapes, <name> and <name>_wide; the timing tags do not distinguish them)
+        hits = [v for k, v in table.items() if not k.startswith("_") and k.split("<")[0] in (base, base + "_wide") and f"<{dom[0][4]}," in k]
         if hits:
             n_l = sum(h["launches"] for h in hits)
             traffic = sum((h["read_bytes_mean"] + h["write_bytes_mean"]) * h["launches"] for h in hits) / n_l
