@@ -507,3 +507,64 @@ def test_device_library_matches_host_twins():
                 assert np.allclose(x_[:, :8], y_[:, :8], rtol=1e-6, atol=1e-7) and np.isnan(y_[:, 8:]).all()
             else:
                 assert np.array_equal(x_, y_), k
+
+
+def test_non_finite_inputs_per_storage_form():
+    """Documented caveat: BSR4 and RB4 store explicit zeros, so a non-finite X entry reaches every row of a
+    4-row group whose block (BSR4) or column list (RB4) references it (0 * inf = NaN), where CSR only reaches the rows with a
+    non-zero coefficient; the quaternion-packed form multiplies by no structural zero and behaves like CSR.  Everything
+    outside those groups is bit-identical to CSR, and stays finite."""
+    _, F, ops = mesh_fixture("cloth")
+    rng = np.random.default_rng(3)
+    # ---- Dirac: Di (4F x 4V), N = 32; poison component 0 of vertex j, column 3 ----
+    Di = ops["Di"].tocsr()
+    Di.sort_indices()
+    M, K = Di.shape
+    N, j = 32, 17
+    x = rng.standard_normal((K // 4, 4 * N)).astype(np.float32)
+    x[j, 0 * N + 3] = np.inf
+    rp, ci, va = csr_dev(Di)
+    y_csr = torch.empty((M // 4, 4 * N), device=DEV)
+    kernels.spmm_csr(rp, ci, va, M, K, dev(x), y_csr, 4)
+    y_csr = y_csr.cpu().numpy().reshape(M // 4, 4, N)
+    touched_rows = np.zeros((M // 4, 4), bool)                     # CSR: rows with a non-zero coefficient on column 4j+0
+    col = Di[:, 4 * j].toarray().ravel() != 0
+    touched_rows[:] = col.reshape(M // 4, 4)
+    assert np.array_equal(~np.isfinite(y_csr[:, :, 3]), touched_rows) and np.isfinite(np.delete(y_csr, 3, axis=2)).all()
+    faces = np.flatnonzero((F == j).any(1))                        # block rows (faces) whose block list contains vertex j
+    b = kernels.csr_to_bsr4(rp, ci, va, M, K)
+    q, flag = kernels.bsr4_to_q3(b[1], b[2])
+    assert int(flag.item()) == 0
+    for name, run in (("bsr4", lambda y: kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, dev(x), y, 4)),
+                      ("q3", lambda y: kernels.spmm_q3(b[0], q, M // 4, K // 4, dev(x), y, 4))):
+        y = torch.empty((M // 4, 4 * N), device=DEV)
+        run(y)
+        y = y.cpu().numpy().reshape(M // 4, 4, N)
+        bad = ~np.isfinite(y[:, :, 3])
+        if name == "bsr4":           # explicit zeros of the 4x4 block: the whole 4-row group of every incident face
+            assert bad[faces].all() and not np.delete(bad, faces, axis=0).any(), name
+        else:                        # Q3 multiplies by no structural zero (M(p) has none off its diagonal, and the diagonal
+            assert np.array_equal(bad, touched_rows), name     # is skipped): exactly CSR's rows (no p component is 0 here)
+        other = np.delete(np.arange(M // 4), faces)
+        assert np.array_equal(y[other], y_csr[other]) and np.array_equal(np.delete(y, 3, axis=2), np.delete(y_csr, 3, axis=2)), name
+    # ---- Laplacian: RB4 (4x1 row blocks), N = 128; poison row j, column 5 ----
+    L = ops["L"].tocsr()
+    L.sort_indices()
+    V = L.shape[0]
+    xl = rng.standard_normal((V, 128)).astype(np.float32)
+    xl[j, 5] = -np.inf
+    rp, ci, va = csr_dev(L)
+    y_csr = torch.empty((V, 128), device=DEV)
+    kernels.spmm_csr(rp, ci, va, V, V, dev(xl), y_csr, 1)
+    y_csr = y_csr.cpu().numpy()
+    assert np.array_equal(~np.isfinite(y_csr[:, 5]), L[:, j].toarray().ravel() != 0)
+    r = kernels.csr_to_rb4(rp, ci, va, V, V)
+    y = torch.empty((V, 128), device=DEV)
+    kernels.spmm_rb4(r[0], r[1], r[2], V, V, dev(xl), y)
+    y = y.cpu().numpy()
+    groups = np.unique(np.flatnonzero(L[:, j].toarray().ravel() != 0) // 4)
+    rows = np.concatenate([np.arange(4 * g_, min(4 * g_ + 4, V)) for g_ in groups])
+    bad = ~np.isfinite(y[:, 5])
+    assert bad[rows].all() and not np.delete(bad, rows).any()
+    other = np.delete(np.arange(V), rows)
+    assert np.array_equal(y[other], y_csr[other]) and np.array_equal(np.delete(y, 5, axis=1), np.delete(y_csr, 5, axis=1))
