@@ -13,9 +13,11 @@ GPU + forward + masked smooth-L1 loss + backward + flat-bucket RCCL gradient all
 Weak scaling: every rank owns its own 64 meshes (the path shards by mesh; no data-path collective).
 
 The JSON line also carries
-  roofline     the dominant kernel (Dirac SpMM, BSR4 form, N=32 dense columns) timed live during the timed steps with
-               HIP events that carry the kernel's own start/stop (hipExtLaunchKernelGGL) on the launch stream; achieved = ALGORITHMIC CSR bytes (SURVEY.md §8d:
-               nnz*8 + (M+1)*4 + K*N*4 + M*N*4) / average launch duration; peak = 8 TB/s HBM3E.
+  roofline     the dominant SpMM kernel of the timed steps (the quaternion-packed Dirac product with the fused ELU-backward
+               epilogue, N=32 dense columns), every launch timed live with HIP events that carry the kernel's own start/stop
+               (hipExtLaunchKernelGGL) on the launch stream; achieved = ALGORITHMIC bytes (nnz*8 + (M+1)*4 +
+               K*N*4 + M*N*4, plus the epilogue operands of the fused launches) / average launch duration; peak = 8 TB/s
+               HBM3E; frac_by_convention reports the alternative readings; traffic = in-step PMC of the same command.
   cpu_baseline the reference's own CPU torch.sparse path (oracle restatement = "port") timed on this box's host cores
                (all of them, plus a 1-thread figure) on a bounded sample of the same workload (rank 0, N=1 only).
   secondary    BASELINE.json configs[4] (the config north_star's ">= 60 % of the HBM roofline on the Dirac SpMM at 128
