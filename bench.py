@@ -402,9 +402,10 @@ def main():
                    "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                    "collective_backend": (dist.get_backend() if dist.is_initialized() else "none (single rank)"),
                    "devices_visible": torch.cuda.device_count(), "ranks_share_devices": bool(oversubscribed),
-                   "linear_layers": ("fp32 operands and fp32 accumulation; products formed on the bf16 matrix pipe from an exact "
-                                     "3-piece bf16 split of every operand (6 partial products, error <= 2^-23 per term: fp32-accurate, "
-                                     "tests/test_dense_gpu.py); SN_GEMM_VARIANT=0 selects the fp32-MFMA kernels"),
+                   "linear_layers": ("fp32 operands and fp32 accumulation; products formed on the 16-bit matrix pipe from an exact split of "
+                                     "every operand into two fp16 pieces after a power-of-two row / column scaling (3 partial products, "
+                                     "error <= 2^-23 per term: fp32-accurate, tests/test_dense_gpu.py); SN_GEMM_VARIANT=1 selects the "
+                                     "three-piece bf16 form, 0 the fp32-MFMA kernels; the weight gradient uses three bf16 pieces"),
                    "allocator": alloc, "operator_format": args.format, "operators": args.operators,
                    "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager", "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": dom_name + (" (the backward products Di^T, DiA^T, ELU backward fused into the store)" if "_epi" in dom_name

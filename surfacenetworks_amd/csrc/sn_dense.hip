@@ -1233,11 +1233,13 @@ inline int stat_blocks(int64_t rows) {
   return (int)b;
 }
 
-// SN_GEMM_VARIANT: 1 (default) split-bf16 kernels, 0 the fp32-MFMA kernels (A/B baseline); shared with sn_gemm.hip
+// SN_GEMM_VARIANT (shared with sn_gemm.hip): 0 = the fp32-MFMA kernels (A/B baseline); anything else = the split kernels —
+// the weight gradient always takes three bf16 pieces (its contraction runs over the ROWS, so the per-row power-of-two
+// scaling that makes the two-piece fp16 form of sn_gemm.hip safe does not factor out of it)
 inline int gemm_variant() {
   static const int v = [] {
     const char *e = getenv("SN_GEMM_VARIANT");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 2;
   }();
   return v;
 }

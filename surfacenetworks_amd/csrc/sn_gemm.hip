@@ -209,6 +209,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_k(const float *__restrict__ 
 // operations, issued in the shadow of the 6·NT MFMAs) and the consumed registers are re-filled with the next tile's data.
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split8(const f4 &p, const f4 &q, u4 &H, u4 &M, u4 &L) {
   const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
@@ -232,6 +233,82 @@ __device__ __forceinline__ f16v mfma_bf16(const u4 &a, const u4 &b, const f16v &
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two-piece fp16 form of the same exact split (PC = 2; SN_GEMM_VARIANT=2): half the matrix-pipe work of the bf16 form.
+//
+// fp16 carries 11 significant bits, so TWO round-to-nearest pieces hold an fp32 value to 2^-23: x = h + l, h = rn16(x),
+// l = rn16(x - h) (the remainder is an exact fp32 subtraction), and x·w needs three partial products
+//     xh·wh + (xh·wl + xl·wh)                  (the dropped xl·wl is <= 2^-24 |x·w|)
+// each exact in the fp32 accumulator (11 x 11 bits), against six for the three bf16 pieces.  What fp16 lacks is RANGE
+// (5 exponent bits: activations behind a cotangent Laplacian reach 1e5, gradients sit at 1e-6), so both operands are
+// scaled by exact powers of two that factor out of the contraction over k: every data ROW by 2^(14 - E_row) from its own
+// absolute maximum (found by the loader wave with four DPP steps, a few VALU operations per 1 KiB load), every weight
+// COLUMN by 2^(14 - E_col), and the low pieces by a further 2^11 so that they sit in the normal range whenever the high
+// piece does (their two products go to separate accumulators, folded in with 2^-11 at the end).  The inverse scales are
+// applied to the fp32 result in the epilogue.  Elements more than 2^28 below their row's maximum lose low-order bits — an
+// error below 2^-37 of the row's scale.  Non-finite inputs give NaN, as in the bf16 form.
+// v_mfma_f32_32x32x16_f16 has the operand layout and rate of the bf16 instruction.
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f16v mfma_f16(const u4 &a, const u4 &b, const f16v &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+}
+constexpr float kLowUp = 2048.f, kLowDown = 1.f / 2048.f;      // 2^11: the low pieces' own scale
+
+// scale_up = 2^(14 - E), scale_down = 2^(E - 14) for a row / column whose absolute maximum is m = f·2^E, f in [0.5, 1)
+__device__ __forceinline__ void pow2_scales(float m, float &up, float &down) {
+  int e = (int)((__float_as_uint(m) >> 23) & 0xffu) - 126;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);              // zero / denormal / non-finite rows: any finite scale will do
+  up = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+  down = __uint_as_float((unsigned)(127 - 14 + e) << 23);
+}
+__device__ __forceinline__ unsigned pack_h2(float a, float b) {          // two fp16 (round to nearest) in one word, a low
+  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
+  return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
+}
+__device__ __forceinline__ float h_round(float a) { return (float)(_Float16)a; }
+__device__ __forceinline__ void split4_h2(const f4 &x, float up, u2 &H, u2 &L) {
+  const float xs[4] = {x.x * up, x.y * up, x.z * up, x.w * up};
+  float lo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) lo[e] = (xs[e] - h_round(xs[e])) * kLowUp;
+  H = u2{pack_h2(xs[0], xs[1]), pack_h2(xs[2], xs[3])};
+  L = u2{pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3])};
+}
+__device__ __forceinline__ void split8_h2(const f4 &p, const f4 &q, float up, u4 &H, u4 &L) {
+  u2 h0, l0, h1, l1;
+  split4_h2(p, up, h0, l0);
+  split4_h2(q, up, h1, l1);
+  H = u4{h0.x, h0.y, h1.x, h1.y};
+  L = u4{l0.x, l0.y, l1.x, l1.y};
+}
+__device__ __forceinline__ float absmax4(const f4 &v) {
+  return fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+}
+// maximum of v (>= 0) over the 16 lanes of a DPP row, in every lane: xor 1, xor 2 (quad permutes), half-row and row mirrors
+template <int CTRL>
+__device__ __forceinline__ float dpp_max(float v) {
+  const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
+  return fmaxf(v, __builtin_bit_cast(float, o));
+}
+__device__ __forceinline__ float row16_max(float v) {
+  v = dpp_max<0xB1>(v);        // quad_perm [1,0,3,2]
+  v = dpp_max<0x4E>(v);        // quad_perm [2,3,0,1]
+  v = dpp_max<0x141>(v);       // row_half_mirror
+  v = dpp_max<0x140>(v);       // row_mirror
+  return v;
+}
+// maximum over the LPR (32 | 64) lanes that hold one data row, in every lane of that row
+template <int LPR>
+__device__ __forceinline__ float rowgroup_max(float v, int lane) {
+  v = row16_max(v);
+  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  if constexpr (LPR == 64) return fmaxf(fmaxf(a, b), fmaxf(c, d));
+  else return lane < 32 ? fmaxf(a, b) : fmaxf(c, d);
+}
+
 // Operand path.  A lane's MFMA fragment is 32 bytes of ITS row, so fragment-shaped global loads touch 32 cache lines per
 // wave instruction and the four waves of a workgroup would repeat both the loads and the split — the texture addresser and
 // the vector ALU, not HBM or the matrix pipe, then bound the kernel (measured: the fp32-MFMA kernel above and a
@@ -251,8 +328,6 @@ __device__ __forceinline__ void static_for(F &&f) {          // f(IC<I>{}) for I
     static_for<I + 1, N>(f);
   }
 }
-
-typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
 // x (4 floats) -> 4 bf16 of each piece
 __device__ __forceinline__ void split4(const f4 &x, u2 &H, u2 &M, u2 &L) {
@@ -302,8 +377,8 @@ __device__ __forceinline__ void stg4(float *p, f4 v) {
 }
 #define SN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 
-template <int K, int NT, bool TRANSW, int EPI, bool SIDE, bool ELU>
-__global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict__ In, int64_t ldi,
+template <int PC, int K, int NT, bool TRANSW, int EPI, bool SIDE, bool ELU>
+__global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restrict__ In, int64_t ldi,
                                                          const float *__restrict__ W, int64_t ldw,
                                                          float *__restrict__ Out, int64_t ldo, int64_t rows, EpiArgs ep) {
   constexpr int KS = K / 16;                 // MFMA k-steps per output tile
@@ -318,29 +393,52 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
   constexpr int SROW = 16 * CPR + 16;        // bytes per staged output row (+16: conflict-free transposition)
   constexpr int RPI = 64 / CPR;              // output rows per store instruction (8 | 4)
   constexpr int NST = 32 / RPI;              // store instructions per slab (4 | 8)
-  __shared__ __attribute__((aligned(16))) unsigned char img[2][3][PART];
+  static_assert(PC == 3 || PC == 2, "three bf16 pieces or two fp16 pieces");
+  constexpr bool H2 = PC == 2;
+  __shared__ __attribute__((aligned(16))) unsigned char img[2][PC][PART];
   __shared__ __attribute__((aligned(16))) unsigned char stg[4][32 * SROW];
+  __shared__ float s_rs[2][32];                         // H2: inverse row scales of the tile held by each image
+  __shared__ __attribute__((aligned(16))) float s_cs[128 * NT];      // H2: inverse column scales of the weights
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = lane & 31, h = lane >> 5;
   // ---- stationary weights, split once: w?[t][ks] = pieces of Wmat[col = 32(wave·NT + t) + n][k = 16ks + 8h .. +7] ----
-  u4 wh[NT][KS], wm[NT][KS], wl[NT][KS];
+  u4 wh[NT][KS], wm[H2 ? 1 : NT][H2 ? 1 : KS], wl[NT][KS];
+  auto load_w = [&](int col, int ks, f4 &p, f4 &q) {
+    if constexpr (!TRANSW) {
+      p = *reinterpret_cast<const f4 *>(W + (int64_t)col * ldw + 16 * ks + 8 * h);
+      q = *reinterpret_cast<const f4 *>(W + (int64_t)col * ldw + 16 * ks + 8 * h + 4);
+    } else {
+      const float *w0 = W + (int64_t)(16 * ks + 8 * h) * ldw + col;
+      p = f4{w0[0], w0[ldw], w0[2 * ldw], w0[3 * ldw]};
+      q = f4{w0[4 * ldw], w0[5 * ldw], w0[6 * ldw], w0[7 * ldw]};
+    }
+  };
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = 32 * (wave * NT + t) + n;
+    float cup = 1.f;
+    if constexpr (H2) {                      // column scale from the column's absolute maximum (my half of k, then my partner's)
+      float cm = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        f4 p, q;
+        load_w(col, ks, p, q);
+        cm = fmaxf(cm, fmaxf(absmax4(p), absmax4(q)));
+      }
+      cm = fmaxf(cm, __shfl_xor(cm, 32));
+      float cdown;
+      pow2_scales(cm, cup, cdown);
+      if (h == 0) s_cs[col] = cdown;
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       f4 p, q;
-      if constexpr (!TRANSW) {
-        p = *reinterpret_cast<const f4 *>(W + (int64_t)col * ldw + 16 * ks + 8 * h);
-        q = *reinterpret_cast<const f4 *>(W + (int64_t)col * ldw + 16 * ks + 8 * h + 4);
-      } else {
-        const float *w0 = W + (int64_t)(16 * ks + 8 * h) * ldw + col;
-        p = f4{w0[0], w0[ldw], w0[2 * ldw], w0[3 * ldw]};
-        q = f4{w0[4 * ldw], w0[5 * ldw], w0[6 * ldw], w0[7 * ldw]};
-      }
-      split8(p, q, wh[t][ks], wm[t][ks], wl[t][ks]);
+      load_w(col, ks, p, q);
+      if constexpr (H2) split8_h2(p, q, cup, wh[t][ks], wl[t][ks]);
+      else split8(p, q, wh[t][ks], wm[t][ks], wl[t][ks]);
     }
   }
+  if constexpr (H2) __syncthreads();        // s_cs complete (read once below, by other lanes)
   const int64_t ntiles = (rows + 31) / 32;
   const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
   int64_t tile = (int64_t)blockIdx.x * per;
@@ -370,6 +468,8 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
     k1 = *reinterpret_cast<const f4 *>(ep.v2 + ecol);                                // B
     k2 = *reinterpret_cast<const f4 *>(ep.v3 + ecol);                                // Cc
   }
+  f4 kcs = {1.f, 1.f, 1.f, 1.f};                                                       // H2: inverse scales of my 4 columns
+  if constexpr (H2) kcs = *reinterpret_cast<const f4 *>(s_cs + ecol);
   unsigned char *const sw = &stg[wave][0] + n * SROW + 16 * h;                       // where my accumulators go (+128t + 32g)
   const unsigned char *const sr = &stg[wave][0] + erow * SROW + 16 * (lane % CPR);   // what I read back (+ RPI·j·SROW)
 
@@ -383,12 +483,22 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
     raw[i] = ldg4(In + r * ldi + lcol, SN_X_GEMM_IN_NT);
   };
   auto convert_chunk = [&](int buf, int i) {
-    u2 H, M, L;
-    split4(raw[i], H, M, L);
     unsigned char *d = &img[buf][0][0] + (lrow + RPL * i) * RS + 2 * lcol;
-    *reinterpret_cast<u2 *>(d) = H;
-    *reinterpret_cast<u2 *>(d + PART) = M;
-    *reinterpret_cast<u2 *>(d + 2 * PART) = L;
+    if constexpr (H2) {
+      float up, down;
+      pow2_scales(rowgroup_max<LPR>(absmax4(raw[i]), lane), up, down);
+      u2 H, L;
+      split4_h2(raw[i], up, H, L);
+      *reinterpret_cast<u2 *>(d) = H;
+      *reinterpret_cast<u2 *>(d + PART) = L;
+      if (lane % LPR == 0) s_rs[buf][lrow + RPL * i] = down;
+    } else {
+      u2 H, M, L;
+      split4(raw[i], H, M, L);
+      *reinterpret_cast<u2 *>(d) = H;
+      *reinterpret_cast<u2 *>(d + PART) = M;
+      *reinterpret_cast<u2 *>(d + 2 * PART) = L;
+    }
   };
   // prologue: tile 0 converted into image 0, tile 1 in flight in the registers
 #pragma unroll
@@ -457,23 +567,32 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc0[t][e] = acc1[t][e] = acc2[t][e] = 0.f;
     const unsigned char *fp = &img[buf][0][0] + n * RS + 16 * h;
+    constexpr int LOWP = (PC - 1) * PART;       // offset of the lowest piece's image
+    const float rs = H2 ? s_rs[buf][n] : 1.f;   // inverse scale of MY data row (accumulator layout: lane (n, h) holds row n)
     u4 dh = *reinterpret_cast<const u4 *>(fp), dm = *reinterpret_cast<const u4 *>(fp + PART),
-       dl = *reinterpret_cast<const u4 *>(fp + 2 * PART);
+       dl = *reinterpret_cast<const u4 *>(fp + LOWP);
     static_for<0, KS>([&](auto ic) {
       constexpr int ks = decltype(ic)::value;
       __builtin_amdgcn_sched_barrier(0);
       u4 nh, nm, nl;                              // fragments of the next k-step: read while this one is multiplied
       if constexpr (ks + 1 < KS) {
         nh = *reinterpret_cast<const u4 *>(fp + 32 * (ks + 1));
-        nm = *reinterpret_cast<const u4 *>(fp + PART + 32 * (ks + 1));
-        nl = *reinterpret_cast<const u4 *>(fp + 2 * PART + 32 * (ks + 1));
+        if constexpr (!H2) nm = *reinterpret_cast<const u4 *>(fp + PART + 32 * (ks + 1));
+        nl = *reinterpret_cast<const u4 *>(fp + LOWP + 32 * (ks + 1));
       }
       if constexpr (ks % CSTEP == 0) {           // conversion of the next tile, one chunk at a time, under the MFMAs
         constexpr int i = ks / CSTEP;
         convert_chunk(buf ^ 1, i);
         load_chunk(tl2, i);
       }
-      if constexpr (NT == 1) {
+      if constexpr (H2) {                        // three exact products: leading | the two cross terms (their own accumulators)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma_f16(wl[t][ks], dh, acc1[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc0[t] = mfma_f16(wh[t][ks], dh, acc0[t]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc2[t] = mfma_f16(wh[t][ks], dl, acc2[t]);
+      } else if constexpr (NT == 1) {
         acc1[0] = mfma_bf16(wl[0][ks], dh, acc1[0]);
         acc2[0] = mfma_bf16(wh[0][ks], dl, acc2[0]);
         acc1[0] = mfma_bf16(wm[0][ks], dm, acc1[0]);
@@ -495,7 +614,8 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
         for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wh[t][ks], dm, acc1[t]);
       }
       if constexpr (ks + 1 < KS) {
-        dh = nh; dm = nm; dl = nl;
+        dh = nh; dl = nl;
+        if constexpr (!H2) dm = nm;
       }
     });
     __builtin_amdgcn_sched_barrier(0);
@@ -505,6 +625,13 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
+        if constexpr (H2)            // leading products + 2^-11 x cross products, then the row's inverse scale (all exact factors)
+          *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
+              f4{__builtin_fmaf(acc1[t][4 * g] + acc2[t][4 * g], kLowDown, acc0[t][4 * g]) * rs,
+                 __builtin_fmaf(acc1[t][4 * g + 1] + acc2[t][4 * g + 1], kLowDown, acc0[t][4 * g + 1]) * rs,
+                 __builtin_fmaf(acc1[t][4 * g + 2] + acc2[t][4 * g + 2], kLowDown, acc0[t][4 * g + 2]) * rs,
+                 __builtin_fmaf(acc1[t][4 * g + 3] + acc2[t][4 * g + 3], kLowDown, acc0[t][4 * g + 3]) * rs};
+        else
         *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
             f4{acc0[t][4 * g] + (acc1[t][4 * g] + acc2[t][4 * g]), acc0[t][4 * g + 1] + (acc1[t][4 * g + 1] + acc2[t][4 * g + 1]),
                acc0[t][4 * g + 2] + (acc1[t][4 * g + 2] + acc2[t][4 * g + 2]),
@@ -512,6 +639,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
       f4 v = *reinterpret_cast<const f4 *>(sr + RPI * j * SROW);
+      if constexpr (H2) v *= kcs;
       const int64_t r = tl * 32 + erow + RPI * j;
       if constexpr (EPI == EPI_FWD) {
         v += useseg ? sg[j] : k0;
@@ -578,19 +706,30 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_x3_k(const float *__restrict
   }
 }
 
-// SN_GEMM_VARIANT: 1 (default) split-bf16 on the bf16 matrix pipe, 0 the fp32-MFMA kernel above (A/B baseline)
+// SN_GEMM_VARIANT: 2 (default) two scaled fp16 pieces, 1 three bf16 pieces (both exact splits on the 16-bit matrix pipe; the
+// fp16 form issues half the MFMAs: -2.5 % on the ARAP step), 0 the fp32-MFMA kernel above (A/B baselines)
 inline int gemm_variant() {
   static const int v = [] {
     const char *e = getenv("SN_GEMM_VARIANT");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 2;
   }();
   return v;
 }
 
+#define SN_UNPAREN(...) __VA_ARGS__
+// launch gemm_rows_split_k<PC, TARGS...> with PC chosen by SN_GEMM_VARIANT (2: fp16 pieces, else bf16 pieces)
+#define SN_SPLIT_LAUNCH(TARGS, ...)                                                                                    \
+  do {                                                                                                                 \
+    if (gemm_variant() == 2)                                                                                           \
+      hipLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__);          \
+    else                                                                                                               \
+      hipLaunchKernelGGL((gemm_rows_split_k<3, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__);          \
+  } while (0)
+
 inline unsigned gemm_grid(int64_t rows) {
   const int64_t ntiles = (rows + 31) / 32;
   int64_t b = kCUs;                       // one 4-wave workgroup per CU: a single wave per SIMD owns the register file
-  if (b > ntiles) b = ntiles;
+  if (b > ntiles) b = ntiles;             // (two per CU, which the fp16 form's K = 128 kernels could hold, measured 2.5 % slower)
   return (unsigned)(b < 1 ? 1 : b);
 }
 
@@ -616,9 +755,7 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
   const bool x3 = gemm_variant() != 0;
-#define SN_X3_FWD(KK, RES, EL)                                                                                        \
-  hipLaunchKernelGGL((gemm_rows_x3_k<KK, 1, false, EPI_FWD, RES, EL>), dim3(grid), dim3(kWG), 0, s, x, ldx, W, ldw, y, \
-                     ldy, rows, ep)
+#define SN_X3_FWD(KK, RES, EL) SN_SPLIT_LAUNCH((KK, 1, false, EPI_FWD, RES, EL), x, ldx, W, ldw, y, ldy, rows, ep)
   if (x3) {
     const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
     switch (sel) {
@@ -656,15 +793,15 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   const unsigned grid = gemm_grid(rows);
   const bool x3 = gemm_variant() != 0;
   if (C == 256 && x3 && B)
-    hipLaunchKernelGGL((gemm_rows_x3_k<128, 2, true, EPI_DGRAD, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
+    SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD, true, false), dy, lddy, W, ldw, dx, lddx, rows, ep);
   else if (C == 256 && x3)
-    hipLaunchKernelGGL((gemm_rows_x3_k<128, 2, true, EPI_DGRAD, false, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
+    SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD, false, false), dy, lddy, W, ldw, dx, lddx, rows, ep);
   else if (C == 256)
     hipLaunchKernelGGL((gemm_rows_k<128, 2, true, EPI_DGRAD>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
   else if (x3 && B)
-    hipLaunchKernelGGL((gemm_rows_x3_k<128, 1, true, EPI_DGRAD, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
+    SN_SPLIT_LAUNCH((128, 1, true, EPI_DGRAD, true, false), dy, lddy, W, ldw, dx, lddx, rows, ep);
   else if (x3)
-    hipLaunchKernelGGL((gemm_rows_x3_k<128, 1, true, EPI_DGRAD, false, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
+    SN_SPLIT_LAUNCH((128, 1, true, EPI_DGRAD, false, false), dy, lddy, W, ldw, dx, lddx, rows, ep);
   else
     hipLaunchKernelGGL((gemm_rows_k<128, 1, true, EPI_DGRAD>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
   return launch_status();
@@ -689,10 +826,10 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows);
   if (C == 256)
-    hipLaunchKernelGGL((gemm_rows_x3_k<128, 2, true, EPI_DGRAD_ELU, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, out,
+    SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, out,
                        lddx, rows, ep);
   else
-    hipLaunchKernelGGL((gemm_rows_x3_k<128, 1, true, EPI_DGRAD_ELU, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, out,
+    SN_SPLIT_LAUNCH((128, 1, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, out,
                        lddx, rows, ep);
   return launch_status();
 }
@@ -744,10 +881,10 @@ int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, in
   const unsigned grid = gemm_grid(rows);
   float *none = nullptr;               // every column leaves through gact: nothing is written through Out
   if (C == 256)
-    hipLaunchKernelGGL((gemm_rows_x3_k<128, 2, true, EPI_DGRAD_ELU, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, none,
+    SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, none,
                        (int64_t)0, rows, ep);
   else
-    hipLaunchKernelGGL((gemm_rows_x3_k<128, 1, true, EPI_DGRAD_ELU, true, false>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, none,
+    SN_SPLIT_LAUNCH((128, 1, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, none,
                        (int64_t)0, rows, ep);
   return launch_status();
 }

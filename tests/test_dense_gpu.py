@@ -574,3 +574,53 @@ def test_elu_conv_matches_torch_layers(C, J, train):
         assert rel_err(conv.fc.weight.grad.cpu().numpy(), fc64.weight.grad.cpu().numpy()) < 1e-5
         assert rel_err(conv.bn.weight.grad.cpu().numpy(), bn64.weight.grad.cpu().numpy()) < 1e-5
         assert rel_err(conv.bn.bias.grad.cpu().numpy(), bn64.bias.grad.cpu().numpy()) < 1e-5
+
+
+def test_split_fp16_row_and_column_scaling_covers_the_fp32_range():
+    """The default Linear kernels split every operand into two fp16 pieces after scaling each data row / weight column by an
+    exact power of two (sn_gemm.hip).  fp16 has 5 exponent bits, so the scaling is what keeps the result fp32-accurate for
+    rows of any magnitude: rows at 1e-30, 1e-6 (gradients), 1, 1e5 (activations behind a cotangent Laplacian), 1e30, an
+    all-zero row, rows whose elements span 2^40, and weight columns from 1e-20 to 1e20 — each output within a few fp32
+    roundings of the fp64 result, relative to sum |x||w| of its own row and column."""
+    rng = np.random.default_rng(2024)
+    rows, K, J = 640, 256, 128
+    x = rng.standard_normal((rows, K)).astype(np.float64)
+    mags = np.array([1e-30, 1e-12, 1e-6, 1e-3, 1.0, 1e3, 1e5, 1e12, 1e30, 0.0])
+    x *= mags[np.arange(rows) % len(mags)][:, None]
+    x[7] *= np.exp2(rng.integers(-20, 20, K))                     # one row spanning 2^40
+    x = x.astype(np.float32)
+    W = rng.standard_normal((J, K)) * np.array([1e-20, 1e-5, 1.0, 1e4, 1e20])[np.arange(J) % 5][:, None]
+    W[3] = 0.0
+    W = W.astype(np.float32)
+    b = np.zeros(J, np.float32)
+    with np.errstate(over="ignore", invalid="ignore"):
+        ref = x.astype(np.float64) @ W.astype(np.float64).T
+        scale = np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64).T
+    got = kernels.linear_fwd(dev(x), dev(W), dev(b)).cpu().numpy().astype(np.float64)
+    ok = (scale < 1e38) & (scale > 1e-30)                        # outputs that neither overflow nor underflow fp32 itself
+    assert ok.mean() > 0.7 and np.isfinite(got[ok]).all()
+    err = np.abs(got - ref)[ok] / np.maximum(scale[ok], 1e-300)
+    assert err.max() <= 4 * 2.0 ** -24 * np.sqrt(K), err.max()     # a few roundings of the K-term fp32 accumulation
+    assert not got[:, 3].any() and not got[9::10].any()            # zero weight column / zero rows stay exactly zero
+    # the input gradient takes the same path with the roles of rows / columns kept: tiny gradients, huge weights
+    dy = (rng.standard_normal((rows, J)) * np.array([1e-25, 1e-9, 1e-4, 1.0, 1e8])[np.arange(rows) % 5][:, None]).astype(np.float32)
+    Wd = (rng.standard_normal((J, K)) * np.array([1e-6, 1.0, 1e6])[np.arange(K) % 3][None, :]).astype(np.float32)
+    refd = dy.astype(np.float64) @ Wd.astype(np.float64)
+    scaled = np.abs(dy).astype(np.float64) @ np.abs(Wd).astype(np.float64)
+    gotd = kernels.linear_dgrad(dev(dy), dev(Wd)).cpu().numpy().astype(np.float64)
+    assert (np.abs(gotd - refd) / np.maximum(scaled, 1e-300)).max() <= 4 * 2.0 ** -24 * np.sqrt(J)
+
+
+def test_three_piece_bf16_kernels_stay_covered():
+    """SN_GEMM_VARIANT=1 (three bf16 pieces, the previous default and A/B baseline of the fp16 form): the accuracy and
+    epilogue tests of this file in a subprocess, because the library reads the switch once per process."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, SN_GEMM_VARIANT="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_dense_gpu.py"), "-q", "-x", "-m", "gpu", "-k",
+                          "linear_fwd_mfma or linear_dgrad or split_bf16 or per_mesh_bias or statistics_of_its_elu or bn_linear"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(here))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
