@@ -34,6 +34,21 @@ __device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
 #ifndef SN_X_WGRAD_NT
 #define SN_X_WGRAD_NT 0
 #endif
+#ifndef SN_X_WGU_NOCONV
+#define SN_X_WGU_NOCONV 0
+#endif
+#ifndef SN_X_WGU_NOMFMA
+#define SN_X_WGU_NOMFMA 0
+#endif
+#ifndef SN_X_WGU_NOLOAD
+#define SN_X_WGU_NOLOAD 0
+#endif
+#ifndef SN_X_WGU_X4LOAD
+#define SN_X_WGU_X4LOAD 0
+#endif
+#ifndef SN_X_WGU_PERM
+#define SN_X_WGU_PERM 0
+#endif
 #ifndef SN_X_WGRAD_PAIRS
 #define SN_X_WGRAD_PAIRS 1     // wgrad_x3_k: one workgroup barrier per PAIR of 16-row steps (four LDS images); 0: per step
 #endif
@@ -529,6 +544,247 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
         }
   }
 #undef SN_STEP_BARRIER
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad_u_k — the same split-bf16 weight gradient with UNIFORM waves (default, SN_WGRAD_VARIANT=2).
+//
+// PMC of wgrad_x3_k (profiles/r2_pmc_wgrad.txt): matrix pipe 38 % busy, vector ALU 29 %, the three loader waves 94 % busy —
+// the wave-specialised kernel is paced by the instruction stream of ONE loader wave (≈350 instructions per 16-row step: 32
+// values per lane) while the matrix waves wait at the barrier, and the fourth loader wave (at C = 128: two of them) has no
+// task.  Here all 8 waves do both jobs: per 32-row block a wave converts its share of the operands — units of 8 rows x 1
+// column, one 16-byte LDS slot per piece: 3 units per lane at C = 256, 2 at C = 128, every lane of every wave busy — and
+// multiplies 2 x CT output tiles (2 dy tiles x CT x tiles).
+//   * conversion slot 0 of wave w = the dy half-block (row group w/2, 64 columns (w%2)·64 ..), slots 1.. = x half-blocks
+//     w + 8(k-1) of the 4 row groups x 2·CT half-blocks: roles are compile-time, a slot has one row group; global loads are
+//     dword-per-lane over 64 consecutive columns (256 contiguous bytes per row and instruction) through a raw buffer
+//     resource whose extent ends with the slab (rows past it read 0: no masks, no clamps); block b+2 is requested into the
+//     registers block b+1 was converted from, while block b is multiplied;
+//   * one workgroup barrier per 32-row block, two LDS images of 4 row groups (154 KB at C = 256); slot layout as above;
+//   * the two co-resident waves of a SIMD run the same stream, and a wave is in-order: what overlaps the matrix pipe with
+//     the vector ALU is the MIX inside the stream — one MFMA, then about five conversion instructions, again and again
+//     (sched_group_barrier pipeline below).  Measured on one box, C = 256 / 128: conversion in three lumps between groups
+//     of four MFMAs 179 / 81 µs; conversion and MFMAs in separate halves of the block 222 / 100 µs (ping-ponged between the
+//     two waves of a SIMD: 209 / 95 µs); wgrad_x3_k 199 / 113 µs.
+// ------------------------------------------------------------------------------------------------
+template <int I>
+struct WIC {
+  static constexpr int value = I;
+};
+template <int I, int N, class F>
+__device__ __forceinline__ void wstatic_for(F &&f) {
+  if constexpr (I < N) {
+    f(WIC<I>{});
+    wstatic_for<I + 1, N>(f);
+  }
+}
+
+template <int CT /* C / 128: 1 or 2 */>
+__global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__restrict__ dy, int64_t lddy,
+                                                              const float *__restrict__ x, int64_t ldx,
+                                                              const float *__restrict__ center, int64_t rows, int J, int C,
+                                                              float *__restrict__ partial /* [grid][128][C] */,
+                                                              float *__restrict__ colpart /* [grid][128] | NULL */,
+                                                              int64_t seg_rows /* 0: even split of all rows */, int spm) {
+  constexpr int NCG = 32 + 32 * CT;          // column groups of 4: 32 of dy, 32·CT of x
+  constexpr int QP = NCG + 4;                // slots per (column % 4) plane; QP % 16 == 4 keeps fragment reads conflict-free
+  constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
+  constexpr int NK = 1 + CT;                 // conversion slots per wave and block: one of dy, CT of x
+  constexpr int NM = 24 * CT;                // MFMAs per wave and block
+  static_assert(QP % 16 == 4, "slot permutation");
+  __shared__ u4 img[2][3][4 * PL];           // [buffer][piece][slot]; one block = 32 rows = 4 row groups
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  int64_t r0, r1;                            // row slab of this workgroup (as wgrad_x3_k)
+  if (seg_rows > 0) {
+    const int64_t mesh = blockIdx.x / spm, part = blockIdx.x % spm;
+    int64_t per = (seg_rows + spm - 1) / spm;
+    per = (per + 15) & ~(int64_t)15;
+    const int64_t mend = (mesh + 1) * seg_rows < rows ? (mesh + 1) * seg_rows : rows;
+    r0 = mesh * seg_rows + part * per;
+    r1 = r0 + per < mend ? r0 + per : mend;
+  } else {
+    int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    per = (per + 15) & ~(int64_t)15;
+    r0 = (int64_t)blockIdx.x * per;
+    r1 = r0 + per < rows ? r0 + per : rows;
+  }
+  const int nblocks = r1 > r0 ? (int)((r1 - r0 + 31) / 32) : 0;
+  const int span = r1 > r0 ? (int)(r1 - r0) : 0;       // rows of the slab (far below 2^31)
+  float *P = partial + (int64_t)blockIdx.x * 128 * C;
+
+  // ---- matrix role: dy tiles 2·ga, 2·ga + 1  x  x tiles CT·gb .. CT·gb + CT - 1 ----
+  const int i = lane & 31, kh = lane >> 5;
+  const int ga = wave >> 2, gb = wave & 3;
+  const int fo = kh * PL + (i & 3) * QP + (i >> 2);          // my fragment slot: + 2·PL·step + 8·(tile in column groups of 32)
+  f16v acc[2][CT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < CT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  // ---- conversion role ----
+  // my column inside a 64-column half-block: the 8 consecutive lanes of a ds_write_b128 group take columns 4j + q with
+  // 4 consecutive j and 2 consecutive q — their slots (c%4)·QP + c/4, QP = 4 mod 8, are then 8 distinct residues mod 8
+  // (conflict-free writes; lane = column gave two-way conflicts on 30 % of the LDS cycles); the wave still covers 64
+  // consecutive columns per global load instruction
+  const int lcol = SN_X_WGU_PERM ? 4 * (4 * (lane >> 4) + (lane & 3)) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1) : lane;
+  int s_rg[NK];                  // row group of the block (scalar)
+  const float *s_cur[NK];        // operand + first column of the half-block + first row of the slot in the block to load next
+  int l_voff[NK];                // my byte offset in a row of the half-block; past any extent if my dy column does not exist
+  int l_slot[NK];
+  float l_mu[NK];                // my column's centre (x slots)
+  float l_sum = 0.f;             // running sum of my dy column (slot 0)
+  const int dy_rstep = 4 * (int)lddy, x_rstep = 4 * (int)ldx;          // bytes per row
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int xhb = wave + 8 * (k - 1);
+    const int rg = k == 0 ? wave >> 1 : xhb / (2 * CT);
+    const int c = k == 0 ? 64 * (wave & 1) + lcol : 128 + 64 * (xhb % (2 * CT)) + lcol;      // column in the image
+    s_rg[k] = rg;
+    s_cur[k] = k == 0 ? dy + 64 * (wave & 1) + (r0 + 8 * rg) * lddy : x + 64 * (xhb % (2 * CT)) + (r0 + 8 * rg) * ldx;
+    l_voff[k] = (k == 0 && c >= J) ? 0x7fffff00 : 4 * lcol;
+    l_mu[k] = (k > 0 && center) ? center[c - 128] : 0.f;
+    l_slot[k] = rg * PL + (c & 3) * QP + (c >> 2);
+  }
+  float raw[1][NK][8];           // rows in flight: one register set (a second one, two blocks ahead, measured no faster)
+  u4 cH[NK], cM[NK], cL[NK];     // pieces of the slot being converted (filled pair by pair, written as three 16-byte slots)
+  // The work of a slot, in chunks small enough to sit between two MFMAs:
+  //   conv_pair   rows 2p, 2p+1: centre (x) | column sum (dy), then x = h + m + l by packed fp32 subtractions — each piece the
+  //               upper 16 bits of an exact remainder (≈10 vector instructions);
+  //   conv_write  the three pieces of the 8 rows as one LDS slot each;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+  auto conv_pair = [&](auto sc, auto kc, auto pc) {
+    constexpr int set = decltype(sc)::value, k = decltype(kc)::value, p = decltype(pc)::value;
+    f2 xv = {raw[set][k][2 * p], raw[set][k][2 * p + 1]};
+#if SN_X_WGU_NOCONV          // ablation builds only (tools/scratch/wgrad_ab.sh)
+    cH[k][p] = cM[k][p] = cL[k][p] = __float_as_uint(xv.x + xv.y);
+    return;
+#endif
+    if constexpr (k == 0) l_sum += xv.x + xv.y;
+    else xv -= f2{l_mu[k], l_mu[k]};
+    const u2v xb = __builtin_bit_cast(u2v, xv);
+    const f2 r = xv - __builtin_bit_cast(f2, xb & 0xFFFF0000u);
+    const u2v rb = __builtin_bit_cast(u2v, r);
+    const f2 l = r - __builtin_bit_cast(f2, rb & 0xFFFF0000u);
+    const u2v lb = __builtin_bit_cast(u2v, l);
+    cH[k][p] = __builtin_amdgcn_perm(xb.y, xb.x, 0x07060302u);
+    cM[k][p] = __builtin_amdgcn_perm(rb.y, rb.x, 0x07060302u);
+    cL[k][p] = __builtin_amdgcn_perm(lb.y, lb.x, 0x07060302u);
+  };
+  auto conv_write = [&](auto kc, int buf) {
+    constexpr int k = decltype(kc)::value;
+    img[buf][0][l_slot[k]] = cH[k];
+    img[buf][1][l_slot[k]] = cM[k];
+    img[buf][2][l_slot[k]] = cL[k];
+  };
+  // open_slot: the descriptor of slot k's rows in block b (b counts up by one per slot and call: s_cur runs along).  Its
+  // extent ends with the slab: rows past it — whole blocks past it: the prefetch runs two blocks ahead — read as 0 without
+  // traffic.  Such a row is 0 in BOTH operands' raw data; the centred x is then -mu, but the dy row is exactly 0 in every
+  // piece, so it adds nothing to the products or to the column sums: no masks.
+  __amdgpu_buffer_rsrc_t s_rs[NK];
+  auto open_slot = [&](auto kc, int b) {
+    constexpr int k = decltype(kc)::value;
+    const int rstep = k == 0 ? dy_rstep : x_rstep;
+    int left = span - 32 * b - 8 * s_rg[k];                           // rows of the slab from the slot's first row on
+    left = left < 0 ? 0 : (left > 8 ? 8 : left);
+    const int extent = __builtin_amdgcn_readfirstlane(left * rstep);      // (keeps the clamp's med3 out of the descriptor)
+    s_rs[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s_cur[k]), 0, extent, 0x00020000);
+    s_cur[k] += 8 * rstep;                                            // 32 rows on
+  };
+  auto load_row = [&](auto sc, auto kc, auto jc) {
+    constexpr int set = decltype(sc)::value, k = decltype(kc)::value, j = decltype(jc)::value;
+    const int rstep = k == 0 ? dy_rstep : x_rstep;
+#if SN_X_WGU_NOLOAD
+    if (s_rg[k] >= 0) return;
+#endif
+    raw[set][k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rs[k], l_voff[k] + j * rstep, 0, 0));
+  };
+  // The other work of a block, dealt out behind its MFMAs (m = 0 .. NM-1) — the two co-resident waves of a SIMD run this
+  // same stream and a wave is in-order, so what overlaps the matrix pipe, the vector ALU and the memory pipe is the mix
+  // INSIDE the stream:
+  //   conversion of block b+1 into the other image: one pair of rows every PSTEP MFMAs;
+  //   requests of block b+2 into the registers just converted: ONE load at a time — eight in a row fill the memory
+  //     pipe's queue and stall the wave, hence the MFMAs behind them, for hundreds of cycles (the kernel is HBM-bound:
+  //     a CU's share of the bandwidth is one 256-byte load per ≈26 cycles);
+  //   the three LDS slots of a unit after its fourth pair.
+  constexpr int PSTEP = NM / (4 * NK);      // 4 | 3
+  auto behind_mfma = [&](auto sc, auto ic, auto mc, int b) {
+    constexpr int set = decltype(sc)::value, image = decltype(ic)::value, m = decltype(mc)::value;
+    if constexpr (m % PSTEP == 0 && m / PSTEP < 4 * NK) {
+      constexpr int q = m / PSTEP, k = q / 4, p = q % 4;
+      if constexpr (p == 0) open_slot(WIC<k>{}, b);
+      conv_pair(sc, WIC<k>{}, WIC<p>{});
+    }
+    constexpr int L = CT == 2 ? (m % 2 == 1 ? (m - 1) / 2 : -1) : (m % 3 != 0 ? (m / 3) * 2 + (m % 3 - 1) : -1);
+    if constexpr (L >= 0 && L < 8 * NK) load_row(sc, WIC<L / 8>{}, WIC<L % 8>{});
+    constexpr int wk = CT == 2 ? (m % 16 == 14 ? m / 16 : -1) : (m % 12 == 11 ? m / 12 : -1);
+    if constexpr (wk >= 0 && wk < NK) conv_write(WIC<wk>{}, image);
+  };
+#define SN_BLOCK_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  auto multiply_block = [&](auto sc, int b) {
+    constexpr int buf = decltype(sc)::value;           // block b = image buf = b & 1
+    SN_BLOCK_BARRIER();                   // image buf complete; image buf^1 (read during block b-1) may be overwritten
+    // fragments of both 16-row steps are requested up front (before any write of this block in program order)
+    u4 A[2][2][3], B[2][CT][3];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) A[st][a][p] = img[buf][p][fo + 2 * st * PL + 8 * (2 * ga + a)];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) B[st][c][p] = img[buf][p][fo + 2 * st * PL + 32 + 8 * (CT * gb + c)];
+      }
+    // six partial products (pieces of dy, x): (l,h) (h,l) (m,m) (m,h) (h,m) (h,h) — small terms first; tile-inner, so
+    // consecutive MFMAs never share an accumulator; the order of the stream is pinned by sched_barrier
+    wstatic_for<0, NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value, g = m / (2 * CT), st = g / 6, t = g % 6;
+      constexpr int a = (m % (2 * CT)) / CT, c = m % CT;
+      constexpr int pa = (0x001102 >> (4 * t)) & 15, pb = (0x010120 >> (4 * t)) & 15;
+#if !SN_X_WGU_NOMFMA
+      acc[a][c] = mfma_bf16(A[st][a][pa], B[st][c][pb], acc[a][c]);
+#else
+      acc[a][c][m % 16] += __uint_as_float(A[st][a][pa].x ^ B[st][c][pb].x);
+#endif
+      behind_mfma(WIC<0>{}, WIC<buf ^ 1>{}, mc, b + 2);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  if (nblocks > 0) {
+    // block 0 requested, converted into image 0, block 1 requested into its registers
+    wstatic_for<0, NK>([&](auto kc) {
+      open_slot(kc, 0);
+      wstatic_for<0, 8>([&](auto jc) { load_row(WIC<0>{}, kc, jc); });
+    });
+    wstatic_for<0, NM>([&](auto mc) { behind_mfma(WIC<0>{}, WIC<0>{}, mc, 1); });
+    for (int b = 0; b < nblocks; b += 2) {
+      multiply_block(WIC<0>{}, b);
+      if (b + 1 < nblocks) multiply_block(WIC<1>{}, b + 1);
+    }
+  }
+  if (colpart) {                             // bias gradient: column sums of dy — one (row group, column) entry per wave
+    __syncthreads();
+    float *sm = reinterpret_cast<float *>(&img[0][0][0]);
+    sm[s_rg[0] * 128 + 64 * (wave & 1) + lcol] = l_sum;
+    __syncthreads();
+    if (tid < 128) colpart[(int64_t)blockIdx.x * 128 + tid] = (sm[tid] + sm[128 + tid]) + (sm[256 + tid] + sm[384 + tid]);
+  }
+  // D layout (32x32): column n = lane & 31 (x column within its tile), row (dy column within its tile)
+  // = (e & 3) + 8 (e >> 2) + 4 (lane >> 5), e = 0..15
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int jr = 32 * (2 * ga + a) + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        P[(int64_t)jr * C + 32 * (CT * gb + c) + i] = acc[a][c][e];
+      }
+#undef SN_BLOCK_BARRIER
 }
 
 __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ partial, int nslab, int J, int C,
@@ -1244,6 +1500,15 @@ inline int gemm_variant() {
   return v;
 }
 
+// SN_WGRAD_VARIANT: 2 (default) uniform waves (wgrad_u_k), 1 the wave-specialised kernel (wgrad_x3_k); both split-bf16
+inline int wgrad_variant() {
+  static const int v = [] {
+    const char *e = getenv("SN_WGRAD_VARIANT");
+    return e ? atoi(e) : 2;
+  }();
+  return v;
+}
+
 inline int wgrad_slabs(int64_t rows) {
   int64_t b = (rows + 255) / 256;          // at least 256 rows per slab
   const int64_t cap = 2 * kCUs;            // two 4-wave workgroups per CU (2 waves/SIMD), one round
@@ -1348,7 +1613,12 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
   float *partial = static_cast<float *>(workspace);
   float *colpart = dysum ? partial + (size_t)nslab * 128 * C : nullptr;
   const int64_t sr = segmented ? rows_per_seg : 0;
-  if (x3 && C == 128)
+  const bool uni = x3 && wgrad_variant() == 2 && lddy < ((int64_t)1 << 24) && ldx < ((int64_t)1 << 24);
+  if (uni && C == 128)
+    hipLaunchKernelGGL((wgrad_u_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
+  else if (uni)
+    hipLaunchKernelGGL((wgrad_u_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
+  else if (x3 && C == 128)
     hipLaunchKernelGGL((wgrad_x3_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
   else if (x3)
     hipLaunchKernelGGL((wgrad_x3_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);

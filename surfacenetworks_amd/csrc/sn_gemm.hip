@@ -31,6 +31,11 @@ inline int launch_status() {
   return e == hipSuccess ? SN_OK : (int)e;
 }
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+// the split kernels keep a lane's byte offset inside a 32-row tile in 32 bits: leading dimensions below 2^24 elements
+inline bool ld32(int64_t a, int64_t b = 0, int64_t c = 0, int64_t d = 0, int64_t e = 0) {
+  const int64_t lim = (int64_t)1 << 24;
+  return a < lim && b < lim && c < lim && d < lim && e < lim;
+}
 // ELU in the GEMM epilogue runs while the matrix pipe of this SIMD idles (one wave per SIMD), so it uses the hardware
 // exponential (v_exp_f32) instead of the ~30-instruction expm1f: |error| <= 1.2e-7 absolute, far below the 1e-5 parity bar.
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
@@ -261,18 +266,17 @@ __device__ __forceinline__ void pow2_scales(float m, float &up, float &down) {
   up = __uint_as_float((unsigned)(127 + 14 - e) << 23);
   down = __uint_as_float((unsigned)(127 - 14 + e) << 23);
 }
-__device__ __forceinline__ unsigned pack_h2(float a, float b) {          // two fp16 (round to nearest) in one word, a low
-  const _Float16 ha = (_Float16)a, hb = (_Float16)b;
-  return (unsigned)__builtin_bit_cast(unsigned short, ha) | ((unsigned)__builtin_bit_cast(unsigned short, hb) << 16);
-}
-__device__ __forceinline__ float h_round(float a) { return (float)(_Float16)a; }
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+// x·up -> fp16 pieces (round to nearest): H = rn16(x·up), L = rn16((x·up - H)·2^11); x·up and the remainder are exact in fp32
 __device__ __forceinline__ void split4_h2(const f4 &x, float up, u2 &H, u2 &L) {
-  const float xs[4] = {x.x * up, x.y * up, x.z * up, x.w * up};
-  float lo[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) lo[e] = (xs[e] - h_round(xs[e])) * kLowUp;
-  H = u2{pack_h2(xs[0], xs[1]), pack_h2(xs[2], xs[3])};
-  L = u2{pack_h2(lo[0], lo[1]), pack_h2(lo[2], lo[3])};
+  const f4 xs = x * up;
+  const h2v h01 = __builtin_convertvector(f2v{xs.x, xs.y}, h2v), h23 = __builtin_convertvector(f2v{xs.z, xs.w}, h2v);
+  const f2v l01 = f2v{xs.x - (float)h01.x, xs.y - (float)h01.y} * kLowUp;
+  const f2v l23 = f2v{xs.z - (float)h23.x, xs.w - (float)h23.y} * kLowUp;
+  H = u2{__builtin_bit_cast(unsigned, h01), __builtin_bit_cast(unsigned, h23)};
+  L = u2{__builtin_bit_cast(unsigned, __builtin_convertvector(l01, h2v)),
+         __builtin_bit_cast(unsigned, __builtin_convertvector(l23, h2v))};
 }
 __device__ __forceinline__ void split8_h2(const f4 &p, const f4 &q, float up, u4 &H, u4 &L) {
   u2 h0, l0, h1, l1;
@@ -284,29 +288,19 @@ __device__ __forceinline__ void split8_h2(const f4 &p, const f4 &q, float up, u4
 __device__ __forceinline__ float absmax4(const f4 &v) {
   return fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
 }
-// maximum of v (>= 0) over the 16 lanes of a DPP row, in every lane: xor 1, xor 2 (quad permutes), half-row and row mirrors
+// maximum of the bit patterns v (non-negative floats order like unsigned integers) over the 16 lanes of a DPP row, in every
+// lane: xor 1, xor 2 (quad permutes), half-row and row mirrors — four v_max_u32_dpp
 template <int CTRL>
-__device__ __forceinline__ float dpp_max(float v) {
-  const int o = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false);
-  return fmaxf(v, __builtin_bit_cast(float, o));
+__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
+  const unsigned o = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+  return v > o ? v : o;
 }
-__device__ __forceinline__ float row16_max(float v) {
-  v = dpp_max<0xB1>(v);        // quad_perm [1,0,3,2]
-  v = dpp_max<0x4E>(v);        // quad_perm [2,3,0,1]
-  v = dpp_max<0x141>(v);       // row_half_mirror
-  v = dpp_max<0x140>(v);       // row_mirror
+__device__ __forceinline__ unsigned row16_umax(unsigned v) {
+  v = dpp_umax<0xB1>(v);        // quad_perm [1,0,3,2]
+  v = dpp_umax<0x4E>(v);        // quad_perm [2,3,0,1]
+  v = dpp_umax<0x141>(v);       // row_half_mirror
+  v = dpp_umax<0x140>(v);       // row_mirror
   return v;
-}
-// maximum over the LPR (32 | 64) lanes that hold one data row, in every lane of that row
-template <int LPR>
-__device__ __forceinline__ float rowgroup_max(float v, int lane) {
-  v = row16_max(v);
-  const float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
-  const float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
-  const float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
-  const float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
-  if constexpr (LPR == 64) return fmaxf(fmaxf(a, b), fmaxf(c, d));
-  else return lane < 32 ? fmaxf(a, b) : fmaxf(c, d);
 }
 
 // Operand path.  A lane's MFMA fragment is 32 bytes of ITS row, so fragment-shaped global loads touch 32 cache lines per
@@ -347,48 +341,62 @@ __device__ __forceinline__ void split4(const f4 &x, u2 &H, u2 &M, u2 &L) {
 
 // LDS writes of this wave done, then the workgroup barrier — without the vmcnt(0) a __syncthreads() fence would add
 // (it would drain the global prefetch and wait for the previous tile's stores to be acknowledged).
-// Cache hints of the global accesses (1 = non-temporal), compile-time switches kept for A/B runs
-// (tools/scratch/build_hint_variants.sh / run_hint_variants.sh, same box, config 3):
-//   outputs  NON-TEMPORAL: the 0.3-0.6 GB a launch writes would otherwise sit dirty in L2 / Infinity Cache and be
-//            written back under the NEXT kernel's reads — with non-temporal stores the transposed SpMM that consumes
-//            dx runs at 83 % instead of 79 % of the HBM roofline and the step is 0.4 ms shorter;
-//   operands plain loads: non-temporal loads of In / the side operand measured neutral to slightly worse (-0.1..-0.3 ms).
-#ifndef SN_X_GEMM_IN_NT
-#define SN_X_GEMM_IN_NT 0
-#endif
-#ifndef SN_X_GEMM_SIDE_NT
-#define SN_X_GEMM_SIDE_NT 0
-#endif
-#ifndef SN_X_GEMM_ST_NT
-#define SN_X_GEMM_ST_NT 1
-#endif
-#ifndef SN_X_GEMM_ELU_ST_PLAIN
-#define SN_X_GEMM_ELU_ST_PLAIN 0
-#endif
-__device__ __forceinline__ f4 ldg4(const float *p, int nt) {
-  return nt ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p);
-}
-__device__ __forceinline__ void stg4(float *p, f4 v) {
-#if SN_X_GEMM_ST_NT
-  __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
-#else
-  *reinterpret_cast<f4 *>(p) = v;
-#endif
-}
 #define SN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+
+// ---- global accesses of the streaming kernel: raw buffer resources ----
+// With ONE wave per SIMD (the weights own the register file) every instruction of the wave — scalar, s_nop, address
+// arithmetic — costs an issue slot (about four cycles), and the matrix pipe runs in the shadow of that stream: the kernel is
+// bound by its instruction count.  Plain 64-bit pointers spent a quarter of it on per-access row clamps and address
+// products (r2 listing: 914 instructions per tile and wave, 229 of them scalar, 3.0 us per tile against 1.9 us of HBM time).
+// Every streamed matrix is therefore addressed through a raw buffer resource whose base is the first row of the CURRENT
+// tile and whose extent ends with the matrix: a lane's byte offset inside a tile is a kernel constant (32 bits), rows past
+// the end read as 0 and are not written (no clamps, no predicates), and moving to the next tile is six scalar operations.
+// Cache hints (A/B runs on config 3, r1): outputs NON-TEMPORAL — the 0.3-0.6 GB a launch writes would otherwise sit dirty
+// in L2 / Infinity Cache and be written back under the NEXT kernel's reads (the transposed SpMM that consumes dx: 83 %
+// instead of 79 % of the HBM roofline, 0.4 ms per step); operands plain loads (non-temporal measured neutral to worse).
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+struct RowWindow {
+  const char *p;       // first row of the current tile
+  int step;            // bytes per 32-row tile (leading dimensions stay below 2^24 elements)
+  int n_full, n_last;  // bytes from the first row of a tile to the end of its last addressed row: full tile | the matrix's last
+  // a row-major fp32 matrix of `rows` rows, leading dimension ld >= its width; `span` = columns addressed from `base` (a row
+  // past the end then starts at or beyond the extent for every addressed column); the window starts at row row0
+  __device__ __forceinline__ void init(const float *base, int64_t ld, int64_t row0, int last_rows, int span) {
+    step = 128 * (int)ld;
+    p = reinterpret_cast<const char *>(base + row0 * ld);
+    n_full = 4 * (31 * (int)ld + span);
+    n_last = 4 * ((last_rows - 1) * (int)ld + span);
+  }
+  __device__ __forceinline__ void init_empty() {             // a window nothing is read from or written to
+    step = 0;
+    p = nullptr;
+    n_full = n_last = 0;
+  }
+  __device__ __forceinline__ void next() { p += step; }
+  // to_last = tiles between the window's tile and the matrix's last tile (0: it is the last, < 0: past the matrix)
+  __device__ __forceinline__ rsrc_t rsrc(int to_last) const {
+    const int n = to_last > 0 ? n_full : (to_last == 0 ? n_last : 0);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(p), 0, n, 0x00020000);      // raw buffer: stride 0, bytes
+  }
+};
+__device__ __forceinline__ f4 bld4(rsrc_t r, int voff) {
+  return __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ void bst4(rsrc_t r, int voff, const f4 &v) {          // non-temporal
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, 0, 2);
+}
 
 template <int PC, int K, int NT, bool TRANSW, int EPI, bool SIDE, bool ELU>
 __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restrict__ In, int64_t ldi,
                                                          const float *__restrict__ W, int64_t ldw,
                                                          float *__restrict__ Out, int64_t ldo, int64_t rows, EpiArgs ep) {
   constexpr int KS = K / 16;                 // MFMA k-steps per output tile
-  constexpr int RS = 2 * K + 16;             // bytes per row of one bf16 image
+  constexpr int RS = 2 * K + 16;             // bytes per row of one 16-bit image
   constexpr int PART = 32 * RS;              // bytes per image
-  constexpr int LPR = K / 4;                 // loader lanes per row (16 bytes each)
-  constexpr int RPL = 64 / LPR;              // rows per load instruction (1 | 2)
-  constexpr int NL = 8 / RPL;                // load instructions per wave per tile (8 | 4)
-  constexpr int CSTEP = KS / NL;             // one conversion chunk every CSTEP k-steps
-  static_assert(KS % NL == 0, "conversion chunks must divide the k-steps");
+  constexpr int SEG = K / 64;                // 256-byte segments per data row (2 | 4)
+  constexpr int NL = 2 * SEG;                // load instructions per wave per tile: chunk p (4 of the wave's 8 rows) x segment
+  constexpr int CSTEP = KS / 2;              // one conversion chunk every CSTEP k-steps
+  constexpr int NOUT = 128 * NT;             // output columns
   constexpr int CPR = 8 * NT;                // 16-byte chunks per row of a wave's output slab (32·NT columns)
   constexpr int SROW = 16 * CPR + 16;        // bytes per staged output row (+16: conflict-free transposition)
   constexpr int RPI = 64 / CPR;              // output rows per store instruction (8 | 4)
@@ -452,7 +460,6 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
   double ssum[STATS ? 4 : 1], ssq[STATS ? 4 : 1];
 #pragma unroll
   for (int i = 0; i < (STATS ? 4 : 1); ++i) ssum[i] = ssq[i] = 0.0;
-  const float *side_p = (EPI == EPI_FWD) ? ep.v1 : ep.v0;   // SIDE: forward: the residual; dgrad: x of the BatchNorm tail
   // ---- epilogue geometry: the slab goes through LDS so that global accesses are full lines — lane l handles the 16 bytes
   // at chunk (l % CPR) of rows (l / CPR) + RPI·j; its columns, hence its epilogue constants, are fixed for the kernel ----
   const int erow = lane / CPR;
@@ -460,7 +467,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
   f4 k0 = {0.f, 0.f, 0.f, 0.f}, k1 = k0, k2 = k0;
   constexpr bool DGE = (EPI == EPI_DGRAD_ELU);
   static_assert(!DGE || SIDE, "the ELU variant needs the BatchNorm tail operand");
-  const bool lowhalf = DGE && ecol < ep.half;                                        // wave-uniform
+  const bool lowhalf = DGE && 32 * NT * wave < ep.half;          // a wave's 32·NT columns lie on one side (scalar condition)
   if constexpr (EPI == EPI_FWD) {
     k0 = *reinterpret_cast<const f4 *>(ep.v0 + ecol);                                // bias
   } else if constexpr (SIDE) {
@@ -472,100 +479,139 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
   if constexpr (H2) kcs = *reinterpret_cast<const f4 *>(s_cs + ecol);
   unsigned char *const sw = &stg[wave][0] + n * SROW + 16 * h;                       // where my accumulators go (+128t + 32g)
   const unsigned char *const sr = &stg[wave][0] + erow * SROW + 16 * (lane % CPR);   // what I read back (+ RPI·j·SROW)
+  // my byte offset inside a tile of each epilogue matrix (row erow, + RPI rows per store instruction), and the windows
+  const float *side_p = (EPI == EPI_FWD) ? ep.v1 : ep.v0;   // SIDE: forward: the residual; dgrad: x of the BatchNorm tail
+  const bool has_out = (EPI != EPI_FWD && !DGE) || Out != nullptr;
+  const bool has_ga = DGE && lowhalf && ep.v4 != nullptr;
+  const int vo_side = 4 * (erow * (int)ep.ld1 + ecol), js_side = 4 * RPI * (int)ep.ld1;
+  const int vo_out = 4 * (erow * (int)ldo + ecol), js_out = 4 * RPI * (int)ldo;
+  const int vo_o2 = 4 * (erow * (int)ep.ld2 + ecol), js_o2 = 4 * RPI * (int)ep.ld2;
+  const int vo_ga = 4 * (erow * (int)ep.ld3 + ecol), js_ga = 4 * RPI * (int)ep.ld3;
+  RowWindow w_in, w_side, w_out, w_o2, w_ga;
+  const int64_t row0 = tile * 32;
+  // valid rows of a tile: 32 except in the matrix's last tile
+  const int last_nrt = (int)(rows - (ntiles - 1) * 32);
+  int to_last = (int)(ntiles - 1 - tile);                    // tiles from the current one to the matrix's last
+  w_in.init(In, ldi, row0, last_nrt, K);
+  if constexpr (SIDE) w_side.init(side_p, ep.ld1, row0, last_nrt, NOUT);
+  if (has_out) w_out.init(Out, ldo, row0, last_nrt, NOUT);
+  else w_out.init_empty();                                   // stores through it are dropped
+  if constexpr (DGE || (EPI == EPI_FWD && ELU)) w_o2.init(ep.o2, ep.ld2, row0, last_nrt, DGE ? ep.half : NOUT);
+  if constexpr (DGE) {
+    if (has_ga) w_ga.init(ep.v4, ep.ld3, row0, last_nrt, ep.half);
+    else w_ga.init_empty();
+  }
+  // per-mesh vectors: the mesh of the tile's first row and the row where the next mesh starts, kept up as tiles advance
+  const bool useseg = ep.period > 0 && (EPI == EPI_FWD || (DGE && lowhalf));                 // wave-uniform
+  int64_t seg_m = 0;
+  int seg_left = 0;                                          // rows from the tile's first row to the next mesh (period < 2^31)
+  if (useseg) {
+    seg_m = row0 / ep.period;
+    seg_left = (int)((seg_m + 1) * ep.period - row0);
+  }
 
-  // ---- loader: this wave stages rows 8·wave .. +7 of a tile; chunk i = load instruction i ----
-  const int lrow = 8 * wave + lane / LPR;                    // + RPL·i
-  const int lcol = 4 * (lane % LPR);                         // first of my 4 floats
+  // ---- loader: this wave stages rows 8·wave .. +7 of a tile, four rows per load instruction (16 lanes x 16 bytes = one
+  // 256-byte segment of a row): chunk p = rows 4p .. 4p+3, all SEG segments — a row's absolute maximum is then one
+  // 16-lane (single DPP row) reduction for four rows at once ----
+  const int lr = lane >> 4, lc = lane & 15;
+  const int lrow = 8 * wave + lr;                              // + 4p
+  const int lvo = 4 * (lrow * (int)ldi + 4 * lc);              // + 16·ldi·p + 256·s
+  const int lps = 16 * (int)ldi;
   f4 raw[NL];
-  auto load_chunk = [&](int64_t tl, int i) {
-    int64_t r = tl * 32 + lrow + RPL * i;
-    r = r < rows ? r : rows - 1;                             // rows past the end re-read the last row (masked at the store)
-    raw[i] = ldg4(In + r * ldi + lcol, SN_X_GEMM_IN_NT);
+  auto load_chunk = [&](rsrc_t r, int p) {
+#pragma unroll
+    for (int s = 0; s < SEG; ++s) raw[p * SEG + s] = bld4(r, lvo + p * lps + 256 * s);
   };
-  auto convert_chunk = [&](int buf, int i) {
-    unsigned char *d = &img[buf][0][0] + (lrow + RPL * i) * RS + 2 * lcol;
+  auto convert_chunk = [&](int buf, int p) {
+    unsigned char *d = &img[buf][0][0] + (lrow + 4 * p) * RS + 8 * lc;          // segment s at + 128·s
     if constexpr (H2) {
+      float m = absmax4(raw[p * SEG]);
+#pragma unroll
+      for (int s = 1; s < SEG; ++s) m = fmaxf(m, absmax4(raw[p * SEG + s]));
       float up, down;
-      pow2_scales(rowgroup_max<LPR>(absmax4(raw[i]), lane), up, down);
-      u2 H, L;
-      split4_h2(raw[i], up, H, L);
-      *reinterpret_cast<u2 *>(d) = H;
-      *reinterpret_cast<u2 *>(d + PART) = L;
-      if (lane % LPR == 0) s_rs[buf][lrow + RPL * i] = down;
+      pow2_scales(__uint_as_float(row16_umax(__float_as_uint(m))), up, down);
+#pragma unroll
+      for (int s = 0; s < SEG; ++s) {
+        u2 H, L;
+        split4_h2(raw[p * SEG + s], up, H, L);
+        *reinterpret_cast<u2 *>(d + 128 * s) = H;
+        *reinterpret_cast<u2 *>(d + 128 * s + PART) = L;
+      }
+      if (lc == 0) s_rs[buf][lrow + 4 * p] = down;
     } else {
-      u2 H, M, L;
-      split4(raw[i], H, M, L);
-      *reinterpret_cast<u2 *>(d) = H;
-      *reinterpret_cast<u2 *>(d + PART) = M;
-      *reinterpret_cast<u2 *>(d + 2 * PART) = L;
+#pragma unroll
+      for (int s = 0; s < SEG; ++s) {
+        u2 H, M, L;
+        split4(raw[p * SEG + s], H, M, L);
+        *reinterpret_cast<u2 *>(d + 128 * s) = H;
+        *reinterpret_cast<u2 *>(d + 128 * s + PART) = M;
+        *reinterpret_cast<u2 *>(d + 128 * s + 2 * PART) = L;
+      }
     }
   };
-  // prologue: tile 0 converted into image 0, tile 1 in flight in the registers
-#pragma unroll
-  for (int i = 0; i < NL; ++i) load_chunk(tile, i);
-#pragma unroll
-  for (int i = 0; i < NL; ++i) {
-    convert_chunk(0, i);
-    load_chunk(tile + 1 < tend ? tile + 1 : tile, i);
+  // prologue: tile 0 converted into image 0, tile 1 in flight in the registers; the input window then runs two tiles ahead
+  {
+    const rsrc_t r0 = w_in.rsrc(to_last);
+    load_chunk(r0, 0);
+    load_chunk(r0, 1);
+    w_in.next();
+    const rsrc_t r1 = w_in.rsrc(to_last - 1);
+    convert_chunk(0, 0);
+    load_chunk(r1, 0);
+    convert_chunk(0, 1);
+    load_chunk(r1, 1);
+    w_in.next();
   }
 
   auto do_tile = [&](auto bufc, int64_t tl) {
     constexpr int buf = decltype(bufc)::value;
     SN_LDS_BARRIER();                  // image `buf` complete and visible; every wave is done reading image buf^1
-    const int64_t tl2 = tl + 2 < tend ? tl + 2 : tend - 1;   // tile whose rows refill the registers (clamped: always loads)
+    const rsrc_t r_in = w_in.rsrc(to_last - 2);          // tile tl + 2 (past the matrix: reads 0, no traffic)
+    const int nrt = to_last == 0 ? last_nrt : 32;        // valid rows of this tile
     // side operand in the epilogue layout (full lines), requested now, consumed after the k loop
     f4 sd[NST];
     if constexpr (SIDE) {
+      const rsrc_t r_side = w_side.rsrc(to_last);
 #pragma unroll
-      for (int j = 0; j < NST; ++j) {
-        int64_t r = tl * 32 + erow + RPI * j;
-        r = r < rows ? r : rows - 1;
-        sd[j] = ldg4(side_p + r * ep.ld1 + ecol, SN_X_GEMM_SIDE_NT);
-      }
+      for (int j = 0; j < NST; ++j) sd[j] = bld4(r_side, vo_side + j * js_side);
     }
     f4 sg[NST];                        // per-mesh vector of my rows (forward: the bias; dgrad+elu: added before elu')
-    const bool useseg = ep.period > 0 && (EPI == EPI_FWD || (DGE && lowhalf));                 // wave-uniform
     if (useseg) {
-      // a 32-row tile meets at most two meshes (period >= 32): the mesh of its first row, and the next one past `bnd`
-      const int64_t m0 = (tl * 32) / ep.period, bnd = (m0 + 1) * ep.period;
+      // a 32-row tile meets at most two meshes (period >= 32): the mesh of its first row, and the next one from row `nb` on
+      if (seg_left <= 0) {
+        ++seg_m;
+        seg_left += (int)ep.period;
+      }
+      const int nb = seg_left < nrt ? seg_left : nrt;                 // rows >= nb (if any) belong to the next mesh
+      const float *s0 = ep.segv + seg_m * ep.ldseg + ecol;
+      const f4 a0 = *reinterpret_cast<const f4 *>(s0);
+      f4 a1 = a0;
+      if (nb < nrt) a1 = *reinterpret_cast<const f4 *>(s0 + ep.ldseg);
 #pragma unroll
       for (int j = 0; j < NST; ++j) {
-        int64_t r = tl * 32 + erow + RPI * j;
-        r = r < rows ? r : rows - 1;
-        const int64_t mesh = r < bnd ? m0 : m0 + 1;
-        sg[j] = *reinterpret_cast<const f4 *>(ep.segv + mesh * ep.ldseg + ecol);
+        const int rt = erow + RPI * j;
+        sg[j] = rt < nb ? a0 : a1;
         if constexpr (DGE) {
           if (ep.rowmask) {
-            const float mk = ep.rowmask[r];
+            const int rc = rt < nrt ? rt : nrt - 1;
+            const float mk = ep.rowmask[tl * 32 + rc];
             sg[j] = f4{sg[j].x * mk, sg[j].y * mk, sg[j].z * mk, sg[j].w * mk};
           }
         }
       }
-    } else {
-#pragma unroll
-      for (int j = 0; j < NST; ++j) sg[j] = f4{0.f, 0.f, 0.f, 0.f};
     }
     f4 ga[NST];                        // dgrad+elu, low half: the gradient added after the activation derivative
     if constexpr (DGE) {
-      if (lowhalf && ep.v4) {
+      if (has_ga) {
+        const rsrc_t r_ga = w_ga.rsrc(to_last);
 #pragma unroll
-        for (int j = 0; j < NST; ++j) {
-          int64_t r = tl * 32 + erow + RPI * j;
-          r = r < rows ? r : rows - 1;
-          ga[j] = ldg4(ep.v4 + r * ep.ld3 + ecol, SN_X_GEMM_SIDE_NT);
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < NST; ++j) ga[j] = f4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NST; ++j) ga[j] = bld4(r_ga, vo_ga + j * js_ga);
       }
     }
-    // three accumulators per output tile (leading products | two sets of correction products), visited so that no two
-    // consecutive MFMAs write the same one
-    f16v acc0[NT], acc1[NT], acc2[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc0[t][e] = acc1[t][e] = acc2[t][e] = 0.f;
+    // accumulators per output tile: leading products | correction products (three for the bf16 form); the first k-step
+    // starts them from a zero operand
+    f16v acc0[NT], acc1[NT], acc2[H2 ? 1 : NT];
+    const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const unsigned char *fp = &img[buf][0][0] + n * RS + 16 * h;
     constexpr int LOWP = (PC - 1) * PART;       // offset of the lowest piece's image
     const float rs = H2 ? s_rs[buf][n] : 1.f;   // inverse scale of MY data row (accumulator layout: lane (n, h) holds row n)
@@ -581,33 +627,33 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
         nl = *reinterpret_cast<const u4 *>(fp + LOWP + 32 * (ks + 1));
       }
       if constexpr (ks % CSTEP == 0) {           // conversion of the next tile, one chunk at a time, under the MFMAs
-        constexpr int i = ks / CSTEP;
-        convert_chunk(buf ^ 1, i);
-        load_chunk(tl2, i);
+        constexpr int p = ks / CSTEP;
+        convert_chunk(buf ^ 1, p);
+        load_chunk(r_in, p);
       }
-      if constexpr (H2) {                        // three exact products: leading | the two cross terms (their own accumulators)
+      if constexpr (H2) {                        // three exact products: leading | the two cross terms (one accumulator)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc1[t] = mfma_f16(wl[t][ks], dh, acc1[t]);
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma_f16(wl[t][ks], dh, ks == 0 ? zero : acc1[t]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc0[t] = mfma_f16(wh[t][ks], dh, acc0[t]);
+        for (int t = 0; t < NT; ++t) acc0[t] = mfma_f16(wh[t][ks], dh, ks == 0 ? zero : acc0[t]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc2[t] = mfma_f16(wh[t][ks], dl, acc2[t]);
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma_f16(wh[t][ks], dl, acc1[t]);
       } else if constexpr (NT == 1) {
-        acc1[0] = mfma_bf16(wl[0][ks], dh, acc1[0]);
-        acc2[0] = mfma_bf16(wh[0][ks], dl, acc2[0]);
+        acc1[0] = mfma_bf16(wl[0][ks], dh, ks == 0 ? zero : acc1[0]);
+        acc2[0] = mfma_bf16(wh[0][ks], dl, ks == 0 ? zero : acc2[0]);
         acc1[0] = mfma_bf16(wm[0][ks], dm, acc1[0]);
-        acc0[0] = mfma_bf16(wh[0][ks], dh, acc0[0]);
+        acc0[0] = mfma_bf16(wh[0][ks], dh, ks == 0 ? zero : acc0[0]);
         acc1[0] = mfma_bf16(wm[0][ks], dh, acc1[0]);
         acc2[0] = mfma_bf16(wh[0][ks], dm, acc2[0]);
       } else {                         // several tiles: product-outer, tile-inner — two accumulators per tile are enough
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wl[t][ks], dh, acc1[t]);
+        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wl[t][ks], dh, ks == 0 ? zero : acc1[t]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wh[t][ks], dl, acc1[t]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wm[t][ks], dm, acc1[t]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc0[t] = mfma_bf16(wh[t][ks], dh, acc0[t]);
+        for (int t = 0; t < NT; ++t) acc0[t] = mfma_bf16(wh[t][ks], dh, ks == 0 ? zero : acc0[t]);
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wm[t][ks], dh, acc1[t]);
 #pragma unroll
@@ -627,22 +673,29 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
       for (int g = 0; g < 4; ++g)
         if constexpr (H2)            // leading products + 2^-11 x cross products, then the row's inverse scale (all exact factors)
           *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
-              f4{__builtin_fmaf(acc1[t][4 * g] + acc2[t][4 * g], kLowDown, acc0[t][4 * g]) * rs,
-                 __builtin_fmaf(acc1[t][4 * g + 1] + acc2[t][4 * g + 1], kLowDown, acc0[t][4 * g + 1]) * rs,
-                 __builtin_fmaf(acc1[t][4 * g + 2] + acc2[t][4 * g + 2], kLowDown, acc0[t][4 * g + 2]) * rs,
-                 __builtin_fmaf(acc1[t][4 * g + 3] + acc2[t][4 * g + 3], kLowDown, acc0[t][4 * g + 3]) * rs};
+              f4{__builtin_fmaf(acc1[t][4 * g], kLowDown, acc0[t][4 * g]) * rs,
+                 __builtin_fmaf(acc1[t][4 * g + 1], kLowDown, acc0[t][4 * g + 1]) * rs,
+                 __builtin_fmaf(acc1[t][4 * g + 2], kLowDown, acc0[t][4 * g + 2]) * rs,
+                 __builtin_fmaf(acc1[t][4 * g + 3], kLowDown, acc0[t][4 * g + 3]) * rs};
+        else if constexpr (NT == 1)
+          *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
+              f4{acc0[t][4 * g] + (acc1[t][4 * g] + acc2[t][4 * g]), acc0[t][4 * g + 1] + (acc1[t][4 * g + 1] + acc2[t][4 * g + 1]),
+                 acc0[t][4 * g + 2] + (acc1[t][4 * g + 2] + acc2[t][4 * g + 2]),
+                 acc0[t][4 * g + 3] + (acc1[t][4 * g + 3] + acc2[t][4 * g + 3])};
         else
-        *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
-            f4{acc0[t][4 * g] + (acc1[t][4 * g] + acc2[t][4 * g]), acc0[t][4 * g + 1] + (acc1[t][4 * g + 1] + acc2[t][4 * g + 1]),
-               acc0[t][4 * g + 2] + (acc1[t][4 * g + 2] + acc2[t][4 * g + 2]),
-               acc0[t][4 * g + 3] + (acc1[t][4 * g + 3] + acc2[t][4 * g + 3])};
+          *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
+              f4{acc0[t][4 * g] + acc1[t][4 * g], acc0[t][4 * g + 1] + acc1[t][4 * g + 1], acc0[t][4 * g + 2] + acc1[t][4 * g + 2],
+                 acc0[t][4 * g + 3] + acc1[t][4 * g + 3]};
+    const rsrc_t r_out = w_out.rsrc(to_last);
+    rsrc_t r_o2 = r_out;                          // (placeholder unless the kernel has the second output)
+    if constexpr (DGE || (EPI == EPI_FWD && ELU)) r_o2 = w_o2.rsrc(to_last);
 #pragma unroll
     for (int j = 0; j < NST; ++j) {
       f4 v = *reinterpret_cast<const f4 *>(sr + RPI * j * SROW);
       if constexpr (H2) v *= kcs;
-      const int64_t r = tl * 32 + erow + RPI * j;
       if constexpr (EPI == EPI_FWD) {
-        v += useseg ? sg[j] : k0;
+        if (useseg) v += sg[j];                 // (scalar conditions: branches, not selects)
+        else v += k0;
         if constexpr (SIDE) v += sd[j];
       } else if constexpr (SIDE) {            // dgrad (both forms): BatchNorm tail
         const f4 xv = sd[j] - k0;
@@ -654,31 +707,37 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
       if constexpr (DGE) {
         if (lowhalf) {                   // through the activation: elu'(.) from the activation OUTPUT held in the side operand
           const f4 o = sd[j];
-          v += sg[j];
+          if (useseg) v += sg[j];
           v = f4{v.x * (o.x > 0.f ? 1.f : o.x + 1.f), v.y * (o.y > 0.f ? 1.f : o.y + 1.f),
-                 v.z * (o.z > 0.f ? 1.f : o.z + 1.f), v.w * (o.w > 0.f ? 1.f : o.w + 1.f)} + ga[j];
-          if (r < rows) stg4(ep.o2 + r * ep.ld2 + ecol, v);
-        } else if (r < rows) {
-          stg4(Out + r * ldo + ecol, v);
+                 v.z * (o.z > 0.f ? 1.f : o.z + 1.f), v.w * (o.w > 0.f ? 1.f : o.w + 1.f)};
+          if (has_ga) v += ga[j];
+          bst4(r_o2, vo_o2 + j * js_o2, v);
+        } else {
+          bst4(r_out, vo_out + j * js_out, v);
         }
-      } else if (r < rows) {
-        if (EPI != EPI_FWD || Out) stg4(Out + r * ldo + ecol, v);
+      } else {
+        bst4(r_out, vo_out + j * js_out, v);
         if constexpr (EPI == EPI_FWD && ELU) {
           const f4 ev = f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
-#if SN_X_GEMM_ELU_ST_PLAIN
-          *reinterpret_cast<f4 *>(ep.o2 + r * ep.ld2 + ecol) = ev;
-#else
-          stg4(ep.o2 + r * ep.ld2 + ecol, ev);
-#endif
+          bst4(r_o2, vo_o2 + j * js_o2, ev);
           if constexpr (STATS) {
-            const double e0 = ev.x, e1 = ev.y, e2 = ev.z, e3 = ev.w;
-            ssum[0] += e0; ssum[1] += e1; ssum[2] += e2; ssum[3] += e3;
-            ssq[0] = __builtin_fma(e0, e0, ssq[0]); ssq[1] = __builtin_fma(e1, e1, ssq[1]);
-            ssq[2] = __builtin_fma(e2, e2, ssq[2]); ssq[3] = __builtin_fma(e3, e3, ssq[3]);
+            if (erow + RPI * j < nrt) {              // rows past the end hold elu(bias): not part of the statistics
+              const double e0 = ev.x, e1 = ev.y, e2 = ev.z, e3 = ev.w;
+              ssum[0] += e0; ssum[1] += e1; ssum[2] += e2; ssum[3] += e3;
+              ssq[0] = __builtin_fma(e0, e0, ssq[0]); ssq[1] = __builtin_fma(e1, e1, ssq[1]);
+              ssq[2] = __builtin_fma(e2, e2, ssq[2]); ssq[3] = __builtin_fma(e3, e3, ssq[3]);
+            }
           }
         }
       }
     }
+    w_in.next();
+    --to_last;
+    seg_left -= 32;
+    if constexpr (SIDE) w_side.next();
+    w_out.next();
+    if constexpr (DGE || (EPI == EPI_FWD && ELU)) w_o2.next();
+    if constexpr (DGE) w_ga.next();
   };
   while (true) {
     do_tile(IC<0>{}, tile);
@@ -744,7 +803,7 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
                       int64_t rows, int32_t K, int32_t J, double *elu_stats_part, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J)) return SN_E_SHAPE;
-  if (J != 128 || (K != 128 && K != 256)) return SN_E_UNSUPPORTED;
+  if (J != 128 || (K != 128 && K != 256) || !ld32(ldx, ldy, ldr, lde)) return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
   if (!x || !W || !bias || (!y && !(y_elu && gemm_variant() != 0))) return SN_E_NULL;     // y may be NULL when only elu(y) is wanted
   if (!aligned16(x) || !aligned16(W) || !aligned16(bias) || (y && (!aligned16(y) || (ldy % 4))) || (ldx % 4) || (ldw % 4) ||
@@ -781,7 +840,7 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
                         int32_t J, int32_t C, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || lddx < C) return SN_E_SHAPE;
-  if (J != 128 || (C != 128 && C != 256)) return SN_E_UNSUPPORTED;
+  if (J != 128 || (C != 128 && C != 256) || !ld32(lddy, ldx, lddx)) return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
   if (!dy || !W || !dx) return SN_E_NULL;
   if (B && (!x || !Cc)) return SN_E_NULL;
@@ -813,7 +872,8 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
                             void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 2 || lddy < J || ldw < C || lddx < C / 2 || ldga < C / 2 || ldx < C) return SN_E_SHAPE;
-  if (J != 128 || (C != 128 && C != 256) || gemm_variant() == 0) return SN_E_UNSUPPORTED;
+  if (J != 128 || (C != 128 && C != 256) || gemm_variant() == 0 || !ld32(lddy, ldx, lddx, ldga, ldgadd))
+    return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
   if (!dy || !W || !dx_hi || !gact || !x || !B || !Cc) return SN_E_NULL;
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx_hi) || !aligned16(gact) || !aligned16(x) || !aligned16(B) ||
@@ -839,7 +899,9 @@ int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64
                               int64_t lde, int64_t rows, int32_t K, int32_t J, double *elu_stats_part, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J) || rows_per_seg < 1) return SN_E_SHAPE;
-  if (J != 128 || (K != 128 && K != 256) || rows_per_seg < 32 || gemm_variant() == 0) return SN_E_UNSUPPORTED;
+  if (J != 128 || (K != 128 && K != 256) || rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL || gemm_variant() == 0 ||
+      !ld32(ldx, ldy, ldr, lde))
+    return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
   if (!x || !W || !segbias || (!y && !y_elu)) return SN_E_NULL;
   if (!aligned16(x) || !aligned16(W) || !aligned16(segbias) || (y && (!aligned16(y) || (ldy % 4))) || (ldx % 4) || (ldw % 4) ||
@@ -869,7 +931,9 @@ int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, in
                                int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || ldga < C || ldx < C || rows_per_seg < 1) return SN_E_SHAPE;
-  if (J != 128 || (C != 128 && C != 256) || rows_per_seg < 32 || gemm_variant() == 0) return SN_E_UNSUPPORTED;
+  if (J != 128 || (C != 128 && C != 256) || rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL || gemm_variant() == 0 ||
+      !ld32(lddy, ldx, ldga, ldgadd))
+    return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
   if (!dy || !W || !gact || !x || !B || !Cc || !segvec) return SN_E_NULL;
   if (!aligned16(dy) || !aligned16(W) || !aligned16(gact) || !aligned16(x) || !aligned16(B) || !aligned16(Cc) ||
