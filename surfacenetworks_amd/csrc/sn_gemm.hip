@@ -575,27 +575,30 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
 #pragma unroll
       for (int j = 0; j < NST; ++j) sd[j] = bld4(r_side, vo_side + j * js_side);
     }
-    f4 sg[NST];                        // per-mesh vector of my rows (forward: the bias; dgrad+elu: added before elu')
+    // per-mesh vector of my rows (forward: the bias; dgrad+elu: added before elu'): REQUESTED here, combined in the epilogue —
+    // anything computed from these loads before the k loop would wait for them, i.e. drain the row prefetch, once per tile.
+    // A 32-row tile meets at most two meshes (period >= 32): the mesh of its first row, and the next one from row `nb` on.
+    f4 sg0 = {0.f, 0.f, 0.f, 0.f}, sg1 = sg0;
+    float smk[NST];
+    int nb = 32;
+    const bool usemask = DGE && useseg && ep.rowmask != nullptr;
     if (useseg) {
-      // a 32-row tile meets at most two meshes (period >= 32): the mesh of its first row, and the next one from row `nb` on
       if (seg_left <= 0) {
         ++seg_m;
         seg_left += (int)ep.period;
       }
-      const int nb = seg_left < nrt ? seg_left : nrt;                 // rows >= nb (if any) belong to the next mesh
+      nb = seg_left < nrt ? seg_left : nrt;                            // rows >= nb (if any) belong to the next mesh
       const float *s0 = ep.segv + seg_m * ep.ldseg + ecol;
-      const f4 a0 = *reinterpret_cast<const f4 *>(s0);
-      f4 a1 = a0;
-      if (nb < nrt) a1 = *reinterpret_cast<const f4 *>(s0 + ep.ldseg);
+      const float *s1 = nb < nrt ? s0 + ep.ldseg : s0;                  // (no next mesh in this tile: the same vector again)
+      sg0 = *reinterpret_cast<const f4 *>(s0);
+      sg1 = *reinterpret_cast<const f4 *>(s1);
+      if constexpr (DGE) {
+        if (usemask) {
+          const float *mrow = ep.rowmask + tl * 32;
 #pragma unroll
-      for (int j = 0; j < NST; ++j) {
-        const int rt = erow + RPI * j;
-        sg[j] = rt < nb ? a0 : a1;
-        if constexpr (DGE) {
-          if (ep.rowmask) {
-            const int rc = rt < nrt ? rt : nrt - 1;
-            const float mk = ep.rowmask[tl * 32 + rc];
-            sg[j] = f4{sg[j].x * mk, sg[j].y * mk, sg[j].z * mk, sg[j].w * mk};
+          for (int j = 0; j < NST; ++j) {
+            const int rt = erow + RPI * j;
+            smk[j] = mrow[rt < nrt ? rt : nrt - 1];
           }
         }
       }
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
       f4 v = *reinterpret_cast<const f4 *>(sr + RPI * j * SROW);
       if constexpr (H2) v *= kcs;
       if constexpr (EPI == EPI_FWD) {
-        if (useseg) v += sg[j];                 // (scalar conditions: branches, not selects)
+        if (useseg) v += (erow + RPI * j < nb ? sg0 : sg1);          // (scalar condition: a branch, not a select)
         else v += k0;
         if constexpr (SIDE) v += sd[j];
       } else if constexpr (SIDE) {            // dgrad (both forms): BatchNorm tail
@@ -707,7 +710,11 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
       if constexpr (DGE) {
         if (lowhalf) {                   // through the activation: elu'(.) from the activation OUTPUT held in the side operand
           const f4 o = sd[j];
-          if (useseg) v += sg[j];
+          if (useseg) {
+            f4 sv = erow + RPI * j < nb ? sg0 : sg1;
+            if (usemask) sv *= smk[j];
+            v += sv;
+          }
           v = f4{v.x * (o.x > 0.f ? 1.f : o.x + 1.f), v.y * (o.y > 0.f ? 1.f : o.y + 1.f),
                  v.z * (o.z > 0.f ? 1.f : o.z + 1.f), v.w * (o.w > 0.f ? 1.f : o.w + 1.f)};
           if (has_ga) v += ga[j];
