@@ -605,7 +605,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
     }
     f4 ga[NST];                        // dgrad+elu, low half: the gradient added after the activation derivative
     if constexpr (DGE) {
-      if (has_ga) {
+      if (lowhalf) {                   // (without the operand: an empty window — the loads return zeros, no traffic)
         const rsrc_t r_ga = w_ga.rsrc(to_last);
 #pragma unroll
         for (int j = 0; j < NST; ++j) ga[j] = bld4(r_ga, vo_ga + j * js_ga);
@@ -692,8 +692,8 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
     const rsrc_t r_out = w_out.rsrc(to_last);
     rsrc_t r_o2 = r_out;                          // (placeholder unless the kernel has the second output)
     if constexpr (DGE || (EPI == EPI_FWD && ELU)) r_o2 = w_o2.rsrc(to_last);
-#pragma unroll
-    for (int j = 0; j < NST; ++j) {
+    // output rows RPI·j + erow, my 4 columns: the product (inverse column scales applied) + the epilogue's linear part
+    auto out_row = [&](int j) {
       f4 v = *reinterpret_cast<const f4 *>(sr + RPI * j * SROW);
       if constexpr (H2) v *= kcs;
       if constexpr (EPI == EPI_FWD) {
@@ -707,22 +707,33 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
         v.z += __builtin_fmaf(xv.z, k1.z, k2.z);
         v.w += __builtin_fmaf(xv.w, k1.w, k2.w);
       }
-      if constexpr (DGE) {
-        if (lowhalf) {                   // through the activation: elu'(.) from the activation OUTPUT held in the side operand
+      return v;
+    };
+    if constexpr (DGE) {
+      if (lowhalf) {                     // through the activation: elu'(.) from the activation OUTPUT held in the side operand
+#pragma unroll
+        for (int j = 0; j < NST; ++j) {
+          f4 v = out_row(j);
           const f4 o = sd[j];
           if (useseg) {
             f4 sv = erow + RPI * j < nb ? sg0 : sg1;
             if (usemask) sv *= smk[j];
             v += sv;
           }
-          v = f4{v.x * (o.x > 0.f ? 1.f : o.x + 1.f), v.y * (o.y > 0.f ? 1.f : o.y + 1.f),
-                 v.z * (o.z > 0.f ? 1.f : o.z + 1.f), v.w * (o.w > 0.f ? 1.f : o.w + 1.f)};
-          if (has_ga) v += ga[j];
+          // elu'(x) from elu(x) = o:  1 for o > 0, o + 1 otherwise  =  min(o, 0) + 1;  v·elu' as one fma
+          v = f4{__builtin_fmaf(v.x, fminf(o.x, 0.f), v.x), __builtin_fmaf(v.y, fminf(o.y, 0.f), v.y),
+                 __builtin_fmaf(v.z, fminf(o.z, 0.f), v.z), __builtin_fmaf(v.w, fminf(o.w, 0.f), v.w)};
+          v += ga[j];                    // (no such operand: the empty window read zeros)
           bst4(r_o2, vo_o2 + j * js_o2, v);
-        } else {
-          bst4(r_out, vo_out + j * js_out, v);
         }
       } else {
+#pragma unroll
+        for (int j = 0; j < NST; ++j) bst4(r_out, vo_out + j * js_out, out_row(j));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < NST; ++j) {
+        const f4 v = out_row(j);
         bst4(r_out, vo_out + j * js_out, v);
         if constexpr (EPI == EPI_FWD && ELU) {
           const f4 ev = f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};

@@ -1,10 +1,9 @@
 #!/bin/bash
-# On the GPU box: the weight-gradient probe with each library variant of tools/scratch/hints/ on the SAME box.
+# On the GPU box: the weight-gradient probe with each kernel variant (and each library variant of tools/scratch/hints/) on the SAME box.
 cd "$(dirname "$0")/../.."
 cp surfacenetworks_amd/libsn_hip.so /tmp/libsn_default.so
 for rep in 1 2; do
-python tools/scratch/wgrad_probe.py default
-SN_WGRAD_VARIANT=1 python tools/scratch/wgrad_probe.py x3
+for wv in 3 2 1; do SN_WGRAD_VARIANT=$wv python tools/scratch/wgrad_probe.py variant$wv; done
 for v in "$@"; do
   cp tools/scratch/hints/$v.so surfacenetworks_amd/libsn_hip.so
   python tools/scratch/wgrad_probe.py $v
