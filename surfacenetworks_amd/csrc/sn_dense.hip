@@ -43,9 +43,6 @@ __device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
 #ifndef SN_X_WGU_NOLOAD
 #define SN_X_WGU_NOLOAD 0
 #endif
-#ifndef SN_X_WGU_X4LOAD
-#define SN_X_WGU_X4LOAD 0
-#endif
 #ifndef SN_X_WGU_PERM
 #define SN_X_WGU_PERM 0
 #endif
@@ -561,11 +558,18 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
 //     resource whose extent ends with the slab (rows past it read 0: no masks, no clamps); block b+2 is requested into the
 //     registers block b+1 was converted from, while block b is multiplied;
 //   * one workgroup barrier per 32-row block, two LDS images of 4 row groups (154 KB at C = 256); slot layout as above;
-//   * the two co-resident waves of a SIMD run the same stream, and a wave is in-order: what overlaps the matrix pipe with
-//     the vector ALU is the MIX inside the stream — one MFMA, then about five conversion instructions, again and again
-//     (sched_group_barrier pipeline below).  Measured on one box, C = 256 / 128: conversion in three lumps between groups
-//     of four MFMAs 179 / 81 µs; conversion and MFMAs in separate halves of the block 222 / 100 µs (ping-ponged between the
-//     two waves of a SIMD: 209 / 95 µs); wgrad_x3_k 199 / 113 µs.
+//   * the two co-resident waves of a SIMD run the same stream, and a wave is in-order: what overlaps the matrix pipe, the
+//     vector ALU and the memory pipe is the MIX inside the stream — a pair of rows converted every few MFMAs, one load at a
+//     time behind it (program order pinned by sched_barrier).
+// Measured (same box each, µs per launch at C = 256 / 128, in the training step): wgrad_x3_k 190 / 108, this kernel 179 / 81.
+// Structures tried on the way: conversion in three lumps between groups of four MFMAs 179 / 81; conversion and MFMAs in
+// separate halves of the block 222 / 100, ping-ponged between the two waves of a SIMD 209 / 95; a second register set
+// (requests two blocks ahead): no change; two fp16 pieces with online per-column power-of-two scales (three products instead
+// of six, exact, more accurate against fp64 than this kernel — commit 60f60e6): 186 / 95, i.e. halving the matrix work buys
+// nothing.  Ablations at 322 624 rows, C = 256 (tools/scratch/wgrad_ab.sh, builds with SN_X_WGU_*): memory path alone (no
+// conversion, no MFMA) 101-107 µs, everything but the global loads 93 µs, loads + MFMAs 134-158 µs, all of it 157-175 µs:
+// the matrix work and the HBM stream do not hide each other on this chip (the same "components add" the forward GEMMs
+// showed, §6 of DESIGN.md) — what is left to gain is fewer instructions, not a better overlap.
 // ------------------------------------------------------------------------------------------------
 template <int I>
 struct WIC {
@@ -626,10 +630,10 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
   // ---- conversion role ----
-  // my column inside a 64-column half-block: the 8 consecutive lanes of a ds_write_b128 group take columns 4j + q with
-  // 4 consecutive j and 2 consecutive q — their slots (c%4)·QP + c/4, QP = 4 mod 8, are then 8 distinct residues mod 8
-  // (conflict-free writes; lane = column gave two-way conflicts on 30 % of the LDS cycles); the wave still covers 64
-  // consecutive columns per global load instruction
+  // my column inside a 64-column half-block = my lane: consecutive lanes read consecutive dwords (a permutation that made
+  // the ds_write_b128 groups conflict-free — lane = column is two-way conflicted on 30 % of the LDS cycles, still under the
+  // store's own VGPR-transfer time — left each lane quad 16 bytes apart and cost the loads 20 %: 127 against 101 µs for the
+  // memory path alone at 322 624 rows, SN_X_WGU_PERM=1)
   const int lcol = SN_X_WGU_PERM ? 4 * (4 * (lane >> 4) + (lane & 3)) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1) : lane;
   int s_rg[NK];                  // row group of the block (scalar)
   const float *s_cur[NK];        // operand + first column of the half-block + first row of the slot in the block to load next
@@ -784,306 +788,6 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
         const int jr = 32 * (2 * ga + a) + (e & 3) + 8 * (e >> 2) + 4 * kh;
         P[(int64_t)jr * C + 32 * (CT * gb + c) + i] = acc[a][c][e];
       }
-#undef SN_BLOCK_BARRIER
-}
-
-// ------------------------------------------------------------------------------------------------
-// wgrad_h_k — the weight gradient on TWO fp16 pieces per operand (default, SN_WGRAD_VARIANT=3): three exact partial products
-// per term instead of six (half the matrix-pipe work of wgrad_u_k, two LDS images instead of three), same uniform-wave
-// structure.
-//
-// fp16 lacks range, and here the contraction runs over the ROWS, so the only scaling that factors out of it is per COLUMN
-// (of dy, and of x - mu):  G[j][c] = 2^(Ea[j] + Eb[c] - 28) · Σ_r (dy[r][j]·2^(14-Ea[j])) (x[r][c]·2^(14-Eb[c])).  A column's
-// absolute maximum is not known before the pass, so the scale is ONLINE, per workgroup:
-//   * every lane converts the same column in every block (a unit = 8 rows x 1 column), and keeps that column's exponent
-//     E = exponent of the running absolute maximum in a register;
-//   * the rows of block b+2 are in registers one block before they are converted (two register sets): their maxima are
-//     pushed with ds_max_u32 into the table of that block's parity during block b, the block barrier publishes them, and
-//     during block b+1 the four lanes that convert the column's four row groups read the same entry, hence take the same
-//     new exponent — no extra synchronisation;
-//   * an exponent only grows.  When one does, the products already accumulated carry the old scale: the converting lane
-//     raises the block's flag, and every wave, before it multiplies that block, rescales its accumulators by the exact
-//     powers of two 2^-(dEa + dEb) (v_ldexp) — a rare slow path (the first blocks of a slab, then almost never).
-// With the maximum at 2^14 a value keeps 22 significant bits down to 2^-14 of its column's maximum and loses them gradually
-// below (absolute error <= 2^-36 of the scaled maximum): measured against fp64 the result is as accurate as wgrad_u_k.
-// Low pieces carry a further 2^11 (normal range), their two products go to their own accumulator, folded in with 2^-11.
-// ------------------------------------------------------------------------------------------------
-typedef _Float16 h8v_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f16v mfma_h16(const u4 &a, const u4 &b, const f16v &c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v_t, a), __builtin_bit_cast(h8v_t, b), c, 0, 0, 0);
-}
-// exponent E of m = f·2^E, f in [0.5, 1), from the bits of m >= 0, clamped to [-100, 100] (zero / denormal / non-finite
-// maxima: any finite scale will do)
-__device__ __forceinline__ int expo_of(unsigned bits) {
-  const int e = (int)((bits >> 23) & 0xffu) - 126;
-  return e < -100 ? -100 : (e > 100 ? 100 : e);
-}
-
-template <int CT /* C / 128: 1 or 2 */>
-__global__ __launch_bounds__(kWgradThreads, 1) void wgrad_h_k(const float *__restrict__ dy, int64_t lddy,
-                                                              const float *__restrict__ x, int64_t ldx,
-                                                              const float *__restrict__ center, int64_t rows, int J, int C,
-                                                              float *__restrict__ partial /* [grid][128][C] */,
-                                                              float *__restrict__ colpart /* [grid][128] | NULL */,
-                                                              int64_t seg_rows /* 0: even split of all rows */, int spm) {
-  constexpr int NCG = 32 + 32 * CT;          // column groups of 4: 32 of dy, 32·CT of x
-  constexpr int QP = NCG + 4;                // slots per (column % 4) plane; QP % 16 == 4 keeps fragment reads conflict-free
-  constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
-  constexpr int NK = 1 + CT;                 // conversion slots per wave and block: one of dy, CT of x
-  constexpr int NM = 12 * CT;                // MFMAs per wave and block: 3 products x 2·CT tiles x 2 steps
-  constexpr int NCOL = 128 + 128 * CT;       // image columns: dy, then x
-  static_assert(QP % 16 == 4, "slot permutation");
-  __shared__ u4 img[2][2][4 * PL];           // [buffer][piece][slot]; one block = 32 rows = 4 row groups
-  __shared__ unsigned s_T[2][NCOL];          // maxima (float bits) pushed for the blocks of each parity; only grow
-  __shared__ int s_S[2][NCOL];               // exponent each image's columns were scaled with
-  __shared__ int s_A[8][64 + 32 * CT];       // per wave: exponents its accumulators carry (its 64 dy and 32·CT x columns)
-  __shared__ int s_F[3];                     // "a column of block n changed its exponent": flag n % 3
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  int64_t r0, r1;                            // row slab of this workgroup (as wgrad_x3_k)
-  if (seg_rows > 0) {
-    const int64_t mesh = blockIdx.x / spm, part = blockIdx.x % spm;
-    int64_t per = (seg_rows + spm - 1) / spm;
-    per = (per + 15) & ~(int64_t)15;
-    const int64_t mend = (mesh + 1) * seg_rows < rows ? (mesh + 1) * seg_rows : rows;
-    r0 = mesh * seg_rows + part * per;
-    r1 = r0 + per < mend ? r0 + per : mend;
-  } else {
-    int64_t per = (rows + gridDim.x - 1) / gridDim.x;
-    per = (per + 15) & ~(int64_t)15;
-    r0 = (int64_t)blockIdx.x * per;
-    r1 = r0 + per < rows ? r0 + per : rows;
-  }
-  const int nblocks = r1 > r0 ? (int)((r1 - r0 + 31) / 32) : 0;
-  const int span = r1 > r0 ? (int)(r1 - r0) : 0;       // rows of the slab (far below 2^31)
-  float *P = partial + (int64_t)blockIdx.x * 128 * C;
-  for (int t = tid; t < 2 * NCOL; t += kWgradThreads) {
-    (&s_T[0][0])[t] = 0u;
-    (&s_S[0][0])[t] = -100;
-  }
-  for (int t = tid; t < 8 * (64 + 32 * CT); t += kWgradThreads) (&s_A[0][0])[t] = -100;
-  if (tid < 3) s_F[tid] = 0;
-
-  // ---- matrix role: dy tiles 2·ga, 2·ga + 1  x  x tiles CT·gb .. CT·gb + CT - 1 ----
-  const int i = lane & 31, kh = lane >> 5;
-  const int ga = wave >> 2, gb = wave & 3;
-  const int fo = kh * PL + (i & 3) * QP + (i >> 2);          // my fragment slot: + 2·PL·step + 8·(tile in column groups of 32)
-  f16v acc0[2][CT], acc1[2][CT];                             // leading products | the two cross products (x 2^11)
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < CT; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc0[a][b][e] = acc1[a][b][e] = 0.f;
-
-  // ---- conversion role: slot 0 = the dy half-block (row group wave/2, columns 64(wave%2) ..), slots 1.. = x half-blocks
-  // wave + 8(k-1) of the 4 row groups x 2·CT half-blocks; lane = column ----
-  int s_rg[NK];                  // row group of the block (scalar)
-  const float *s_cur[NK];        // operand + first column of the half-block + first row of the slot in the block to load next
-  int s_col0[NK], s_slot0[NK];   // first image column of the half-block | its LDS slot base (scalars; + my lane's part)
-  const int l_lslot = (lane & 3) * QP + (lane >> 2);      // my slot within a half-block (its first column is a multiple of 64)
-  int l_voff0;                   // my byte offset in a dy row; past any extent if my dy column does not exist
-  float l_mu[NK];                // my column's centre (x slots)
-  int l_E[NK];                   // my column's exponent in use
-  float l_sum = 0.f;             // running sum of my dy column (slot 0)
-  const int dy_rstep = 4 * (int)lddy, x_rstep = 4 * (int)ldx;          // bytes per row
-#pragma unroll
-  for (int k = 0; k < NK; ++k) {
-    const int xhb = wave + 8 * (k - 1);
-    const int rg = k == 0 ? wave >> 1 : xhb / (2 * CT);
-    const int c = k == 0 ? 64 * (wave & 1) + lane : 128 + 64 * (xhb % (2 * CT)) + lane;      // column in the image
-    s_rg[k] = rg;
-    s_cur[k] = k == 0 ? dy + 64 * (wave & 1) + (r0 + 8 * rg) * lddy : x + 64 * (xhb % (2 * CT)) + (r0 + 8 * rg) * ldx;
-    if (k == 0) l_voff0 = c >= J ? 0x7fffff00 : 4 * lane;
-    l_mu[k] = (k > 0 && center) ? center[c - 128] : 0.f;
-    s_col0[k] = c - lane;
-    s_slot0[k] = rg * PL + ((c - lane) >> 2);
-    l_E[k] = -100;
-  }
-  float raw[2][NK][8];           // rows of two blocks in flight: block n lives in set n & 1 (x values are centred by `push`)
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-  typedef _Float16 h2v_t __attribute__((ext_vector_type(2)));
-  // descriptor of slot k's rows in block b (b counts up by one per slot and call: s_cur runs along); its extent ends with
-  // the slab: rows past it read as 0 without traffic — 0 in dy is 0 in every piece, so such a row adds nothing
-  __amdgpu_buffer_rsrc_t s_rs[NK];
-  auto open_slot = [&](auto kc, int b) {
-    constexpr int k = decltype(kc)::value;
-    const int rstep = k == 0 ? dy_rstep : x_rstep;
-    int left = span - 32 * b - 8 * s_rg[k];
-    left = left < 0 ? 0 : (left > 8 ? 8 : left);
-    const int extent = __builtin_amdgcn_readfirstlane(left * rstep);
-    s_rs[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s_cur[k]), 0, extent, 0x00020000);
-    s_cur[k] += 8 * rstep;
-  };
-  auto load_row = [&](auto sc, auto kc, auto jc) {
-    constexpr int set = decltype(sc)::value, k = decltype(kc)::value, j = decltype(jc)::value;
-    int rstep = k == 0 ? dy_rstep : x_rstep;
-    asm volatile("" : "+s"(rstep));          // (opaque: or the 16 row offsets are hoisted into registers the loop does not have)
-    raw[set][k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rs[k], (k == 0 ? l_voff0 : 4 * lane) + j * rstep, 0, 0));
-  };
-  // push: my 8 rows of slot k (register set `set`, block of parity `par`) are centred in place and their absolute maximum
-  // goes into the parity's table
-  auto push = [&](auto sc, auto kc, int par) {
-    constexpr int set = decltype(sc)::value, k = decltype(kc)::value;
-    if constexpr (k == 0) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) l_sum += raw[set][k][j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) raw[set][k][j] -= l_mu[k];
-    }
-    float m = fmaxf(fmaxf(__builtin_fabsf(raw[set][k][0]), __builtin_fabsf(raw[set][k][1])),
-                    fmaxf(__builtin_fabsf(raw[set][k][2]), __builtin_fabsf(raw[set][k][3])));
-    m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(raw[set][k][4]), __builtin_fabsf(raw[set][k][5])),
-                       fmaxf(__builtin_fabsf(raw[set][k][6]), __builtin_fabsf(raw[set][k][7]))));
-    atomicMax(&s_T[par][s_col0[k] + lane], __float_as_uint(m));
-  };
-  // scale of slot k's column for the block of parity `par` (its maxima were pushed before the last barrier), recorded for
-  // the matrix role; a grown exponent raises the block's flag
-  float c_up;                    // scale of the slot being converted
-  u4 cH, cL;                     // its pieces, filled pair by pair
-  auto set_scale = [&](auto kc, int par, int flag) {
-    constexpr int k = decltype(kc)::value;
-    const int e = expo_of(s_T[par][s_col0[k] + lane]);
-    if (e > l_E[k]) {
-      l_E[k] = e;
-      s_F[flag] = 1;
-    }
-    s_S[par][s_col0[k] + lane] = l_E[k];
-    c_up = __uint_as_float((unsigned)(127 + 14 - l_E[k]) << 23);
-  };
-  // rows 2p, 2p+1: x·up = h + l·2^-11 exactly (h = rn16, l = rn16 of the remainder x 2^11), one packed pair per piece
-  auto conv_pair = [&](auto sc, auto kc, auto pc) {
-    constexpr int set = decltype(sc)::value, k = decltype(kc)::value, p = decltype(pc)::value;
-    const f2 xs = f2{raw[set][k][2 * p], raw[set][k][2 * p + 1]} * c_up;
-    const h2v_t h = __builtin_convertvector(xs, h2v_t);
-    const f2 r = (xs - __builtin_convertvector(h, f2)) * 2048.f;
-    cH[p] = __builtin_bit_cast(unsigned, h);
-    cL[p] = __builtin_bit_cast(unsigned, __builtin_convertvector(r, h2v_t));
-  };
-  auto conv_write = [&](auto kc, int image) {
-    constexpr int k = decltype(kc)::value;
-    img[image][0][s_slot0[k] + l_lslot] = cH;
-    img[image][1][s_slot0[k] + l_lslot] = cL;
-  };
-  // The other work of a block, dealt out behind its NM MFMAs in program order (sched_barrier pins it): per slot
-  //   scale + pair 0, load, load, pair 1, load, load, pair 2, load, load, pair 3, load, load, write   (13 items)
-  // of block b+1 (converted from register set `o` into image `o`, block b+3 then requested into the same registers — one
-  // load at a time: several in a row fill the memory pipe's queue and stall the in-order wave), then the pushes of block b+2
-  // (set `o^1`, which arrived during the last block).
-  constexpr int NITEM = 14 * NK;
-  auto item = [&](auto oc, auto tc, int b) {
-    constexpr int o = decltype(oc)::value, t = decltype(tc)::value;
-    if constexpr (t < 13 * NK) {
-      constexpr int k = t / 13, u = t % 13;
-      if constexpr (u == 0) {
-        open_slot(WIC<k>{}, b + 3);
-        set_scale(WIC<k>{}, o, (b + 1) % 3);
-      }
-      if constexpr (u % 3 == 0 && u < 12) conv_pair(oc, WIC<k>{}, WIC<u / 3>{});
-      else if constexpr (u < 12) load_row(oc, WIC<k>{}, WIC<2 * (u / 3) + (u % 3 - 1)>{});
-      else conv_write(WIC<k>{}, o);
-    } else if constexpr (t < NITEM) {
-      push(WIC<o ^ 1>{}, WIC<t - 13 * NK>{}, o ^ 1);
-    }
-  };
-#define SN_BLOCK_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-  u4 fA[2][2], fB[CT][2];        // fragments of the step being multiplied: [tile][piece]
-  auto multiply_block = [&](auto sc, int b) {
-    constexpr int buf = decltype(sc)::value;           // block b = image buf = b & 1
-    SN_BLOCK_BARRIER();                   // image buf, its exponents and flag complete; image buf^1 may be overwritten
-    if (s_F[b % 3] != 0) {
-      // a column of this block took a larger exponent than the products accumulated so far carry: bring my accumulators to
-      // the block's exponents by exact powers of two
-      int *A = &s_A[wave][0];
-      int dx[CT];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) {
-        const int now = s_S[buf][128 + 32 * (CT * gb + c) + i];
-        dx[c] = A[64 + 32 * c + i] - now;              // <= 0
-        A[64 + 32 * c + i] = now;
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int jr = (e & 3) + 8 * (e >> 2) + 4 * kh;
-          const int now = s_S[buf][32 * (2 * ga + a) + jr];
-          const int d = A[32 * a + jr] - now;            // every lane of the wave that holds this column reads, then writes
-          A[32 * a + jr] = now;
-#pragma unroll
-          for (int c = 0; c < CT; ++c) {
-            acc0[a][c][e] = ldexpf(acc0[a][c][e], d + dx[c]);
-            acc1[a][c][e] = ldexpf(acc1[a][c][e], d + dx[c]);
-          }
-        }
-    }
-    if (tid == 0) s_F[(b + 2) % 3] = 0;     // block b-1's flag: read before this block's barrier, raised again after the next
-    wstatic_for<0, NM>([&](auto mc) {
-      constexpr int m = decltype(mc)::value, st = m / (6 * CT), g = (m % (6 * CT)) / (2 * CT);
-      constexpr int a = (m % (2 * CT)) / CT, c = m % CT;
-      // fragments of a 16-row step: read when its first MFMA comes up
-      if constexpr (m % (6 * CT) == 0) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-#pragma unroll
-          for (int aa = 0; aa < 2; ++aa) fA[aa][p] = img[buf][p][fo + 2 * st * PL + 8 * (2 * ga + aa)];
-#pragma unroll
-          for (int cc = 0; cc < CT; ++cc) fB[cc][p] = img[buf][p][fo + 2 * st * PL + 32 + 8 * (CT * gb + cc)];
-        }
-      }
-      // three exact products (pieces of dy, x): (l,h) (h,l) into the correction accumulator, (h,h); tile-inner
-      if constexpr (g == 0) acc1[a][c] = mfma_h16(fA[a][1], fB[c][0], acc1[a][c]);
-      else if constexpr (g == 1) acc1[a][c] = mfma_h16(fA[a][0], fB[c][1], acc1[a][c]);
-      else acc0[a][c] = mfma_h16(fA[a][0], fB[c][0], acc0[a][c]);
-      wstatic_for<m * NITEM / NM, (m + 1) * NITEM / NM>([&](auto tc) { item(WIC<buf ^ 1>{}, tc, b); });
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  };
-  if (nblocks > 0) {
-    // blocks 0 and 1 requested; block 0's maxima published, block 0 converted into image 0, block 2 requested into its
-    // registers; block 1's maxima pushed (published by the first block barrier)
-    wstatic_for<0, NK>([&](auto kc) {
-      open_slot(kc, 0);
-      wstatic_for<0, 8>([&](auto jc) { load_row(WIC<0>{}, kc, jc); });
-    });
-    wstatic_for<0, NK>([&](auto kc) {
-      open_slot(kc, 1);
-      wstatic_for<0, 8>([&](auto jc) { load_row(WIC<1>{}, kc, jc); });
-    });
-    __syncthreads();                         // tables initialised
-    wstatic_for<0, NK>([&](auto kc) { push(WIC<0>{}, kc, 0); });
-    __syncthreads();
-    wstatic_for<0, 13 * NK>([&](auto tc) { item(WIC<0>{}, tc, -1); });
-    wstatic_for<0, NK>([&](auto kc) { push(WIC<1>{}, kc, 1); });
-    for (int b = 0; b < nblocks; b += 2) {
-      multiply_block(WIC<0>{}, b);
-      if (b + 1 < nblocks) multiply_block(WIC<1>{}, b + 1);
-    }
-  }
-  __syncthreads();
-  if (colpart) {                             // bias gradient: column sums of dy — one (row group, column) entry per wave
-    float *sm = reinterpret_cast<float *>(&img[0][0][0]);
-    sm[s_rg[0] * 128 + 64 * (wave & 1) + lane] = l_sum;
-    __syncthreads();
-    if (tid < 128) colpart[(int64_t)blockIdx.x * 128 + tid] = (sm[tid] + sm[128 + tid]) + (sm[256 + tid] + sm[384 + tid]);
-  }
-  // D layout (32x32): column n = lane & 31 (x column within its tile), row (dy column within its tile)
-  // = (e & 3) + 8 (e >> 2) + 4 (lane >> 5), e = 0..15.  G = (acc0 + acc1·2^-11) · 2^(Ea + Eb - 28)
-  const int *A = &s_A[wave][0];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int c = 0; c < CT; ++c) {
-      const int eb = A[64 + 32 * c + i] - 28;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int jr = (e & 3) + 8 * (e >> 2) + 4 * kh;
-        const float v = __builtin_fmaf(acc1[a][c][e], 1.f / 2048.f, acc0[a][c][e]);
-        P[(int64_t)(32 * (2 * ga + a) + jr) * C + 32 * (CT * gb + c) + i] = ldexpf(v, A[32 * a + jr] + eb);
-      }
-    }
 #undef SN_BLOCK_BARRIER
 }
 
@@ -1800,8 +1504,7 @@ inline int gemm_variant() {
   return v;
 }
 
-// SN_WGRAD_VARIANT: 3 two fp16 pieces with online column scales (wgrad_h_k), 2 (default) uniform waves, three bf16 pieces
-// (wgrad_u_k), 1 the wave-specialised bf16 kernel (wgrad_x3_k)
+// SN_WGRAD_VARIANT: 2 (default) uniform waves (wgrad_u_k), 1 the wave-specialised kernel (wgrad_x3_k); both split-bf16
 inline int wgrad_variant() {
   static const int v = [] {
     const char *e = getenv("SN_WGRAD_VARIANT");
@@ -1914,13 +1617,8 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
   float *partial = static_cast<float *>(workspace);
   float *colpart = dysum ? partial + (size_t)nslab * 128 * C : nullptr;
   const int64_t sr = segmented ? rows_per_seg : 0;
-  const bool ld24 = lddy < ((int64_t)1 << 24) && ldx < ((int64_t)1 << 24);
-  const bool uni = x3 && wgrad_variant() == 2 && ld24, h16 = x3 && wgrad_variant() == 3 && ld24;
-  if (h16 && C == 128)
-    hipLaunchKernelGGL((wgrad_h_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
-  else if (h16)
-    hipLaunchKernelGGL((wgrad_h_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
-  else if (uni && C == 128)
+  const bool uni = x3 && wgrad_variant() == 2 && lddy < ((int64_t)1 << 24) && ldx < ((int64_t)1 << 24);
+  if (uni && C == 128)
     hipLaunchKernelGGL((wgrad_u_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
   else if (uni)
     hipLaunchKernelGGL((wgrad_u_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);

@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/../.."
 cp surfacenetworks_amd/libsn_hip.so /tmp/libsn_default.so
 for rep in 1 2; do
-for wv in 3 2 1; do SN_WGRAD_VARIANT=$wv python tools/scratch/wgrad_probe.py variant$wv; done
+for wv in 2 1; do SN_WGRAD_VARIANT=$wv python tools/scratch/wgrad_probe.py variant$wv; done
 for v in "$@"; do
   cp tools/scratch/hints/$v.so surfacenetworks_amd/libsn_hip.so
   python tools/scratch/wgrad_probe.py $v
