@@ -624,3 +624,70 @@ def test_three_piece_bf16_kernels_stay_covered():
                           "linear_fwd_mfma or linear_dgrad or split_bf16 or per_mesh_bias or statistics_of_its_elu or bn_linear"],
                          env=env, capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(here))
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
+
+
+# ---- the Linear kernels address their operands through raw buffer windows (sn_gemm.hip RowWindow, wgrad_u_k): every
+# operand below is a strided view inside an arena of NaNs, every output a view inside an arena of canaries ---------------
+def _arena(rows, width, pad_rows=3, pad_cols=8, seed=0, fill=float("nan")):
+    """(arena, view): `view` = rows x width of random values inside a poisoned arena (rows before / after, columns on both
+    sides; the view's leading dimension is width + 2·pad_cols, 16-byte aligned)."""
+    a = torch.full((rows + 2 * pad_rows, width + 2 * pad_cols), fill, device=DEV)
+    v = a[pad_rows:pad_rows + rows, pad_cols:pad_cols + width]
+    v.copy_(torch.from_numpy(np.random.default_rng(seed).standard_normal((rows, width)).astype(np.float32)))
+    return a, v
+
+
+def _outside_untouched(arena, view_rows, width, canary, pad_rows=3, pad_cols=8):
+    m = torch.ones_like(arena, dtype=torch.bool)
+    m[pad_rows:pad_rows + view_rows, pad_cols:pad_cols + width] = False
+    return bool((arena[m] == canary).all())
+
+
+@pytest.mark.parametrize("rows", [1, 31, 32, 33, 95, 1017, 8200])
+@pytest.mark.parametrize("K", [128, 256])
+def test_linear_kernels_stay_inside_their_views(rows, K):
+    from surfacenetworks_amd import _lib
+    from surfacenetworks_amd.kernels import _p, _ld, _stream
+    J = 128
+    rng = np.random.default_rng(rows * 3 + K)
+    W = dev((rng.standard_normal((J, K)) / np.sqrt(K)).astype(np.float32))
+    b = dev(rng.standard_normal(J).astype(np.float32))
+    _, x = _arena(rows, K, seed=1)
+    _, res = _arena(rows, J, seed=2)
+    ya, y = _arena(rows, J, seed=3, fill=7.0)
+    ea, e = _arena(rows, J, seed=4, fill=7.0)
+    y.fill_(7.0), e.fill_(7.0)
+    _lib.call("sn_linear_fwd_f32", _p(x), _ld(x), _p(W), _ld(W), _p(b), _p(res), _ld(res), _p(y), _ld(y), _p(e), _ld(e),
+              rows, K, J, None, _stream())
+    want = x.double() @ W.double().t() + b.double() + res.double()
+    assert torch.isfinite(y).all() and float((y.double() - want).abs().max()) < 1e-4
+    assert float((e.double() - torch.where(want > 0, want, torch.expm1(want))).abs().max()) < 1e-4
+    assert _outside_untouched(ya, rows, J, 7.0) and _outside_untouched(ea, rows, J, 7.0)
+    # input gradient with the BatchNorm tail, first half through the activation (both outputs strided)
+    C = K
+    Wd = dev((rng.standard_normal((J, C)) / np.sqrt(J)).astype(np.float32))
+    cen, B, Cc = [dev(rng.standard_normal(C).astype(np.float32)) for _ in range(3)]
+    _, dy = _arena(rows, J, seed=5)
+    _, xs = _arena(rows, C, seed=6)
+    _, gadd = _arena(rows, C // 2, seed=7)
+    ha, dx_hi = _arena(rows, C // 2, seed=8, fill=7.0)
+    ga, gact = _arena(rows, C // 2, seed=9, fill=7.0)
+    dx_hi.fill_(7.0), gact.fill_(7.0)
+    _lib.call("sn_linear_dgrad_elu_f32", _p(dy), _ld(dy), _p(Wd), _ld(Wd), _p(xs), _ld(xs), _p(cen), _p(B), _p(Cc),
+              _p(dx_hi), _ld(dx_hi), _p(gact), _ld(gact), _p(gadd), _ld(gadd), rows, J, C, _stream())
+    full = dy.double() @ Wd.double() + (xs.double() - cen.double()) * B.double() + Cc.double()
+    o = xs[:, :C // 2].double()
+    want_g = full[:, :C // 2] * torch.where(o > 0, torch.ones_like(o), o + 1) + gadd.double()
+    assert float((dx_hi.double() - full[:, C // 2:]).abs().max()) < 1e-4 and float((gact.double() - want_g).abs().max()) < 1e-4
+    assert _outside_untouched(ha, rows, C // 2, 7.0) and _outside_untouched(ga, rows, C // 2, 7.0)
+    # plain input gradient into a strided view
+    da, dxv = _arena(rows, C, seed=10, fill=7.0)
+    dxv.fill_(7.0)
+    _lib.call("sn_linear_dgrad_f32", _p(dy), _ld(dy), _p(Wd), _ld(Wd), _p(xs), _ld(xs), _p(cen), _p(B), _p(Cc), _p(dxv),
+              _ld(dxv), rows, J, C, _stream())
+    assert float((dxv.double() - full).abs().max()) < 1e-4 and _outside_untouched(da, rows, C, 7.0)
+    # weight gradient: rows past the views are NaN — one of them read would poison every entry
+    G, s = kernels.wgrad(dy, xs, cen, want_colsum=True)
+    wantG = dy.double().t() @ (xs.double() - cen.double())
+    assert torch.isfinite(G).all() and float((G.double() - wantG).abs().max()) < 1e-3 * max(1.0, float(wantG.abs().max()))
+    assert float((s - dy.double().sum(0)).abs().max()) < 1e-3
