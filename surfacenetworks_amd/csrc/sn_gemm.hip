@@ -62,6 +62,7 @@ struct EpiArgs {
   // (NULL: not wanted) — the BatchNorm statistics of the first half of the next stage's concat buffer, so that the
   // statistics pass of that stage reads only the propagated half
   double *stats;
+  int stats_blocks;      // blocks the consumer of `stats` reads (sn_linear_fwd_stats_blocks): those past the grid are zeroed
 };
 
 template <int K, int NT, bool TRANSW, int EPI>
@@ -387,7 +388,7 @@ __device__ __forceinline__ void bst4(rsrc_t r, int voff, const f4 &v) {         
 }
 
 template <int PC, int K, int NT, bool TRANSW, int EPI, bool SIDE, bool ELU>
-__global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restrict__ In, int64_t ldi,
+__global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void gemm_rows_split_k(const float *__restrict__ In, int64_t ldi,
                                                          const float *__restrict__ W, int64_t ldw,
                                                          float *__restrict__ Out, int64_t ldo, int64_t rows, EpiArgs ep) {
   constexpr int KS = K / 16;                 // MFMA k-steps per output tile
@@ -454,7 +455,8 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
   constexpr bool STATS = (EPI == EPI_FWD) && ELU && NT == 1;
   if (tile >= tend) {
     if constexpr (STATS)
-      if (ep.stats) ep.stats[(int64_t)blockIdx.x * 256 + threadIdx.x] = 0.0;        // a workgroup without tiles adds nothing
+      if (ep.stats)                                                                  // a workgroup without tiles adds nothing
+        for (int64_t b = blockIdx.x; b < ep.stats_blocks; b += gridDim.x) ep.stats[b * 256 + threadIdx.x] = 0.0;
     return;
   }
   double ssum[STATS ? 4 : 1], ssq[STATS ? 4 : 1];
@@ -779,6 +781,7 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_split_k(const float *__restr
 #pragma unroll
       for (int er = 0; er < 8; ++er) tot += sl[(er * 8 + chunk) * 8 + val];
       ep.stats[(int64_t)blockIdx.x * 256 + (val >> 2) * 128 + 32 * wave + 4 * chunk + (val & 3)] = tot;
+      for (int64_t b = blockIdx.x + gridDim.x; b < ep.stats_blocks; b += gridDim.x) ep.stats[b * 256 + threadIdx.x] = 0.0;
     }
   }
 }
@@ -803,10 +806,21 @@ inline int gemm_variant() {
       hipLaunchKernelGGL((gemm_rows_split_k<3, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__);          \
   } while (0)
 
-inline unsigned gemm_grid(int64_t rows) {
+// Workgroups per CU.  One 4-wave workgroup per CU is a single wave per SIMD that owns the register file; the K = 128, one-tile
+// kernels of the fp16 form need <= 256 registers and run TWO per CU (2 waves per SIMD): -14 % on the plain forward, -10 % on
+// the input gradient through the activation, neutral with a residual (same box, r2); the others lose 3-7 % when their grid is
+// doubled (the second round of workgroups re-loads and re-splits the weights).  SN_GEMM_WGS=1 forces one per CU everywhere.
+inline int gemm_wgs(int K, int NT) {
+  static const int cap = [] {
+    const char *e = getenv("SN_GEMM_WGS");
+    return e ? atoi(e) : 2;
+  }();
+  return (gemm_variant() == 2 && K == 128 && NT == 1 && cap >= 2) ? 2 : 1;
+}
+inline unsigned gemm_grid(int64_t rows, int wgs) {
   const int64_t ntiles = (rows + 31) / 32;
-  int64_t b = kCUs;                       // one 4-wave workgroup per CU: a single wave per SIMD owns the register file
-  if (b > ntiles) b = ntiles;             // (two per CU, which the fp16 form's K = 128 kernels could hold, measured 2.5 % slower)
+  int64_t b = (int64_t)kCUs * wgs;
+  if (b > ntiles) b = ntiles;
   return (unsigned)(b < 1 ? 1 : b);
 }
 
@@ -814,7 +828,8 @@ inline unsigned gemm_grid(int64_t rows) {
 
 extern "C" {
 
-int32_t sn_linear_fwd_stats_blocks(int64_t rows) { return rows > 0 ? (int32_t)gemm_grid(rows) : 0; }
+// (the largest grid any forward kernel uses: a kernel with a smaller one zeroes the blocks past its own)
+int32_t sn_linear_fwd_stats_blocks(int64_t rows) { return rows > 0 ? (int32_t)gemm_grid(rows, 2) : 0; }
 
 int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias,
                       const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu, int64_t lde,
@@ -828,9 +843,10 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
       (residual && (!aligned16(residual) || (ldr % 4) || ldr < J)) || (y_elu && (!aligned16(y_elu) || (lde % 4) || lde < J)))
     return SN_E_ALIGN;
   if (elu_stats_part && (!y_elu || gemm_variant() == 0)) return SN_E_UNSUPPORTED;
-  EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr, elu_stats_part};
+  EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr, elu_stats_part,
+             sn_linear_fwd_stats_blocks(rows)};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const unsigned grid = gemm_grid(rows);
+  const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const bool x3 = gemm_variant() != 0;
 #define SN_X3_FWD(KK, RES, EL) SN_SPLIT_LAUNCH((KK, 1, false, EPI_FWD, RES, EL), x, ldx, W, ldw, y, ldy, rows, ep)
   if (x3) {
@@ -865,9 +881,9 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx) || (lddy % 4) || (ldw % 4) || (lddx % 4)) return SN_E_ALIGN;
   if (B && (!aligned16(x) || !aligned16(B) || !aligned16(Cc) || (center && !aligned16(center)) || (ldx % 4) || ldx < C))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr};
+  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const unsigned grid = gemm_grid(rows);
+  const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   const bool x3 = gemm_variant() != 0;
   if (C == 256 && x3 && B)
     SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD, true, false), dy, lddy, W, ldw, dx, lddx, rows, ep);
@@ -899,10 +915,10 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
       (lddy % 4) || (ldw % 4) || (lddx % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   const int half = C / 2;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0};
   float *out = dx_hi - half;           // the kernel indexes absolute columns; only columns >= half are written through `out`
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const unsigned grid = gemm_grid(rows);
+  const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   if (C == 256)
     SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, out,
                        lddx, rows, ep);
@@ -926,9 +942,10 @@ int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64
       (residual && (!aligned16(residual) || (ldr % 4) || ldr < J)) || (y_elu && (!aligned16(y_elu) || (lde % 4) || lde < J)))
     return SN_E_ALIGN;
   if (elu_stats_part && !y_elu) return SN_E_UNSUPPORTED;
-  EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, rows_per_seg, J, nullptr, elu_stats_part};
+  EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, rows_per_seg, J, nullptr, elu_stats_part,
+             sn_linear_fwd_stats_blocks(rows)};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const unsigned grid = gemm_grid(rows);
+  const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
   switch (sel) {
     case 0: SN_X3_FWD(128, false, false); break;
@@ -958,9 +975,9 @@ int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, in
       !aligned16(segvec) || (center && !aligned16(center)) || (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C)) ||
       (lddy % 4) || (ldw % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, rows_per_seg, C, rowmask};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, rows_per_seg, C, rowmask, nullptr, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
-  const unsigned grid = gemm_grid(rows);
+  const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   float *none = nullptr;               // every column leaves through gact: nothing is written through Out
   if (C == 256)
     SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, none,
