@@ -15,8 +15,8 @@
  *   - No per-operator or per-shape caches (the reference keeps module-level kernel / handle caches, sparse_bmm_func.py:20-21,
  *     sparse_bmm.py:26,63 — deliberately not kept); re-entrant; safe from several host threads on different streams.
  *     The ONLY process-global state of the library: (a) the A/B switches SN_BSR4_VARIANT, SN_CSR_VARIANT, SN_CSR_ITERS,
- *     SN_RB4_ITERS, SN_GEMM_VARIANT, read ONCE from the environment (they select between kernels that compute the same
- *     result, for measurements); (b) the opt-in per-launch timing facility sn_timing_* below (a mutex-guarded list, off by
+ *     SN_RB4_ITERS, SN_GEMM_VARIANT, SN_GEMM_WGS, SN_WGRAD_VARIANT, read ONCE from the environment (they select between
+ *     kernels / launch shapes that compute the same result, for measurements); (b) the opt-in per-launch timing facility sn_timing_* below (a mutex-guarded list, off by
  *     default).  Neither affects results.  The Python layer adds three process-wide selectors with the same property:
  *     functional.set_dirac_format / set_laplacian_format (kernel form) and set_bn_sync (opt-in global BatchNorm statistics).
  *   - Return value: 0 = success; negative = SN_E_* invalid argument; positive = hipError_t of the
@@ -550,8 +550,13 @@ int sn_laplacian_csr_from_mesh(const float *V, const int32_t *F, int64_t nV, int
  *                     the derivative:  gact[r, c] = (dy[r]·W[:, c] + (x[r,c] - center[c]) B[c] + Cc[c] + rowmask[r] *
  *                     segvec[r / rows_per_seg, c]) * elu'(x[r, c]) + gadd[r, c]   (rowmask, gadd may be NULL).
  * Supported: K in {128, 256}, J = 128 for the forward; J = 128, C in {128, 256} for the input gradient; all leading
- * dimensions multiples of 4 floats and 16-byte aligned bases (else SN_E_UNSUPPORTED / SN_E_ALIGN: the caller falls
- * back to a library GEMM).
+ * dimensions multiples of 4 floats, below 2^24 floats (a lane's byte offset inside a 32-row tile is kept in 32 bits),
+ * and 16-byte aligned bases (else SN_E_UNSUPPORTED / SN_E_ALIGN: the caller falls back to a library GEMM).
+ * The kernels address every streamed matrix through a raw buffer window that ends with its last row: nothing before the
+ * first or past the last row of a view, and no column outside it, is read or written (strided views inside larger
+ * buffers are safe; tests/test_dense_gpu.py::test_linear_kernels_stay_inside_their_views).
+ * elu_stats_part holds sn_linear_fwd_stats_blocks(rows) blocks — the largest grid any forward kernel uses; a kernel with a
+ * smaller grid writes zeros into the blocks past its own, so the merge may always read all of them.
  * ------------------------------------------------------------------------------------------ */
 int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias,
                       const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu, int64_t lde,
