@@ -549,7 +549,11 @@ int sn_laplacian_csr_from_mesh(const float *V, const int32_t *F, int64_t nV, int
  * sn_linear_dgrad_eluseg_f32 : input gradient through the activation for ALL C columns with a per-mesh vector added before
  *                     the derivative:  gact[r, c] = (dy[r]·W[:, c] + (x[r,c] - center[c]) B[c] + Cc[c] + rowmask[r] *
  *                     segvec[r / rows_per_seg, c]) * elu'(x[r, c]) + gadd[r, c]   (rowmask, gadd may be NULL).
- * Supported: K in {128, 256}, J = 128 for the forward; J = 128, C in {128, 256} for the input gradient; all leading
+ * sn_linear_dgrad_eluseg_f32 also takes segvec = NULL (then rowmask must be NULL and rows_per_seg is ignored): every column
+ * through the activation without a per-mesh vector — the backward of conv(F.elu(v)), the models' last layer.
+ * Supported: K in {128, 256} for the forward; C in {128, 256} for the input gradient; J = 128 or, with the split kernels
+ * (SN_GEMM_VARIANT != 0), any multiple of 4 up to 128 — the last layer has 120 outputs (models.py:148-150): weights,
+ * bias, residual and dy columns past J are never read and nothing is stored past column J of y / y_elu; all leading
  * dimensions multiples of 4 floats, below 2^24 floats (a lane's byte offset inside a 32-row tile is kept in 32 bits),
  * and 16-byte aligned bases (else SN_E_UNSUPPORTED / SN_E_ALIGN: the caller falls back to a library GEMM).
  * The kernels address every streamed matrix through a raw buffer window that ends with its last row: nothing before the

@@ -63,6 +63,10 @@ struct EpiArgs {
   // statistics pass of that stage reads only the propagated half
   double *stats;
   int stats_blocks;      // blocks the consumer of `stats` reads (sn_linear_fwd_stats_blocks): those past the grid are zeroed
+  // narrow layers (J < 128, a multiple of 4 — the models' last layer has 120 outputs): forward: output columns that exist
+  // (the weights, bias, residual of the others read as 0, nothing is stored to them); input gradient: columns of dy = rows of
+  // W that exist (the others read as 0).  128: full width.
+  int jv;
 };
 
 template <int K, int NT, bool TRANSW, int EPI>
@@ -412,14 +416,21 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
   const int n = lane & 31, h = lane >> 5;
   // ---- stationary weights, split once: w?[t][ks] = pieces of Wmat[col = 32(wave·NT + t) + n][k = 16ks + 8h .. +7] ----
   u4 wh[NT][KS], wm[H2 ? 1 : NT][H2 ? 1 : KS], wl[NT][KS];
+  constexpr int kOob = 0x7fffff00;          // a byte offset past every buffer extent: loads return 0, stores are dropped
+  const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_w = [&](int col, int ks, f4 &p, f4 &q) {
-    if constexpr (!TRANSW) {
-      p = *reinterpret_cast<const f4 *>(W + (int64_t)col * ldw + 16 * ks + 8 * h);
-      q = *reinterpret_cast<const f4 *>(W + (int64_t)col * ldw + 16 * ks + 8 * h + 4);
-    } else {
-      const float *w0 = W + (int64_t)(16 * ks + 8 * h) * ldw + col;
-      p = f4{w0[0], w0[ldw], w0[2 * ldw], w0[3 * ldw]};
-      q = f4{w0[4 * ldw], w0[5 * ldw], w0[6 * ldw], w0[7 * ldw]};
+    if constexpr (!TRANSW) {                  // forward: W is (J x K), row = output column
+      p = q = zero4;
+      if (col < ep.jv) {
+        p = *reinterpret_cast<const f4 *>(W + (int64_t)col * ldw + 16 * ks + 8 * h);
+        q = *reinterpret_cast<const f4 *>(W + (int64_t)col * ldw + 16 * ks + 8 * h + 4);
+      }
+    } else {                                  // input gradient: W is (J x C), row = k (jv is a multiple of 4)
+      const int k0w = 16 * ks + 8 * h;
+      const float *w0 = W + (int64_t)k0w * ldw + col;
+      p = q = zero4;
+      if (k0w < ep.jv) p = f4{w0[0], w0[ldw], w0[2 * ldw], w0[3 * ldw]};
+      if (k0w + 4 < ep.jv) q = f4{w0[4 * ldw], w0[5 * ldw], w0[6 * ldw], w0[7 * ldw]};
     }
   };
 #pragma unroll
@@ -470,8 +481,9 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
   constexpr bool DGE = (EPI == EPI_DGRAD_ELU);
   static_assert(!DGE || SIDE, "the ELU variant needs the BatchNorm tail operand");
   const bool lowhalf = DGE && 32 * NT * wave < ep.half;          // a wave's 32·NT columns lie on one side (scalar condition)
+  const bool colv = EPI != EPI_FWD || ecol < ep.jv;          // my 4 output columns exist
   if constexpr (EPI == EPI_FWD) {
-    k0 = *reinterpret_cast<const f4 *>(ep.v0 + ecol);                                // bias
+    if (colv) k0 = *reinterpret_cast<const f4 *>(ep.v0 + ecol);                      // bias
   } else if constexpr (SIDE) {
     if (ep.v1) k0 = *reinterpret_cast<const f4 *>(ep.v1 + ecol);                     // center (optional)
     k1 = *reinterpret_cast<const f4 *>(ep.v2 + ecol);                                // B
@@ -485,20 +497,22 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
   const float *side_p = (EPI == EPI_FWD) ? ep.v1 : ep.v0;   // SIDE: forward: the residual; dgrad: x of the BatchNorm tail
   const bool has_out = (EPI != EPI_FWD && !DGE) || Out != nullptr;
   const bool has_ga = DGE && lowhalf && ep.v4 != nullptr;
-  const int vo_side = 4 * (erow * (int)ep.ld1 + ecol), js_side = 4 * RPI * (int)ep.ld1;
-  const int vo_out = 4 * (erow * (int)ldo + ecol), js_out = 4 * RPI * (int)ldo;
-  const int vo_o2 = 4 * (erow * (int)ep.ld2 + ecol), js_o2 = 4 * RPI * (int)ep.ld2;
+  const int vo_side = colv ? 4 * (erow * (int)ep.ld1 + ecol) : kOob, js_side = 4 * RPI * (int)ep.ld1;
+  const int vo_out = colv ? 4 * (erow * (int)ldo + ecol) : kOob, js_out = 4 * RPI * (int)ldo;
+  const int vo_o2 = colv ? 4 * (erow * (int)ep.ld2 + ecol) : kOob, js_o2 = 4 * RPI * (int)ep.ld2;
   const int vo_ga = 4 * (erow * (int)ep.ld3 + ecol), js_ga = 4 * RPI * (int)ep.ld3;
   RowWindow w_in, w_side, w_out, w_o2, w_ga;
   const int64_t row0 = tile * 32;
   // valid rows of a tile: 32 except in the matrix's last tile
   const int last_nrt = (int)(rows - (ntiles - 1) * 32);
   int to_last = (int)(ntiles - 1 - tile);                    // tiles from the current one to the matrix's last
-  w_in.init(In, ldi, row0, last_nrt, K);
-  if constexpr (SIDE) w_side.init(side_p, ep.ld1, row0, last_nrt, NOUT);
-  if (has_out) w_out.init(Out, ldo, row0, last_nrt, NOUT);
+  const int ispan = EPI == EPI_FWD ? K : ep.jv;              // columns the operands really have (a window's span must not
+  const int ospan = EPI == EPI_FWD ? ep.jv : NOUT;           // exceed its leading dimension, or the row past the end is in range)
+  w_in.init(In, ldi, row0, last_nrt, ispan);
+  if constexpr (SIDE) w_side.init(side_p, ep.ld1, row0, last_nrt, ospan);
+  if (has_out) w_out.init(Out, ldo, row0, last_nrt, ospan);
   else w_out.init_empty();                                   // stores through it are dropped
-  if constexpr (DGE || (EPI == EPI_FWD && ELU)) w_o2.init(ep.o2, ep.ld2, row0, last_nrt, DGE ? ep.half : NOUT);
+  if constexpr (DGE || (EPI == EPI_FWD && ELU)) w_o2.init(ep.o2, ep.ld2, row0, last_nrt, DGE ? ep.half : ospan);
   if constexpr (DGE) {
     if (has_ga) w_ga.init(ep.v4, ep.ld3, row0, last_nrt, ep.half);
     else w_ga.init_empty();
@@ -517,12 +531,15 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
   // 16-lane (single DPP row) reduction for four rows at once ----
   const int lr = lane >> 4, lc = lane & 15;
   const int lrow = 8 * wave + lr;                              // + 4p
-  const int lvo = 4 * (lrow * (int)ldi + 4 * lc);              // + 16·ldi·p + 256·s
+  int lvo[SEG];                                                // per segment: + 16·ldi·p; columns past jv (dy of a narrow layer): out
+#pragma unroll
+  for (int s = 0; s < SEG; ++s)
+    lvo[s] = (EPI == EPI_FWD || 64 * s + 4 * lc < ep.jv) ? 4 * (lrow * (int)ldi + 4 * lc) + 256 * s : kOob;
   const int lps = 16 * (int)ldi;
   f4 raw[NL];
   auto load_chunk = [&](rsrc_t r, int p) {
 #pragma unroll
-    for (int s = 0; s < SEG; ++s) raw[p * SEG + s] = bld4(r, lvo + p * lps + 256 * s);
+    for (int s = 0; s < SEG; ++s) raw[p * SEG + s] = bld4(r, lvo[s] + p * lps);
   };
   auto convert_chunk = [&](int buf, int p) {
     unsigned char *d = &img[buf][0][0] + (lrow + 4 * p) * RS + 8 * lc;          // segment s at + 128·s
@@ -590,7 +607,7 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
         seg_left += (int)ep.period;
       }
       nb = seg_left < nrt ? seg_left : nrt;                            // rows >= nb (if any) belong to the next mesh
-      const float *s0 = ep.segv + seg_m * ep.ldseg + ecol;
+      const float *s0 = ep.segv + seg_m * ep.ldseg + (colv ? ecol : 0);
       const float *s1 = nb < nrt ? s0 + ep.ldseg : s0;                  // (no next mesh in this tile: the same vector again)
       sg0 = *reinterpret_cast<const f4 *>(s0);
       sg1 = *reinterpret_cast<const f4 *>(s1);
@@ -836,7 +853,8 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
                       int64_t rows, int32_t K, int32_t J, double *elu_stats_part, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J)) return SN_E_SHAPE;
-  if (J != 128 || (K != 128 && K != 256) || !ld32(ldx, ldy, ldr, lde)) return SN_E_UNSUPPORTED;
+  if (J > 128 || (J % 4) || (J != 128 && gemm_variant() == 0) || (K != 128 && K != 256) || !ld32(ldx, ldy, ldr, lde))
+    return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
   if (!x || !W || !bias || (!y && !(y_elu && gemm_variant() != 0))) return SN_E_NULL;     // y may be NULL when only elu(y) is wanted
   if (!aligned16(x) || !aligned16(W) || !aligned16(bias) || (y && (!aligned16(y) || (ldy % 4))) || (ldx % 4) || (ldw % 4) ||
@@ -844,7 +862,7 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
     return SN_E_ALIGN;
   if (elu_stats_part && (!y_elu || gemm_variant() == 0)) return SN_E_UNSUPPORTED;
   EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr, elu_stats_part,
-             sn_linear_fwd_stats_blocks(rows)};
+             sn_linear_fwd_stats_blocks(rows), (int)J};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const bool x3 = gemm_variant() != 0;
@@ -874,14 +892,15 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
                         int32_t J, int32_t C, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || lddx < C) return SN_E_SHAPE;
-  if (J != 128 || (C != 128 && C != 256) || !ld32(lddy, ldx, lddx)) return SN_E_UNSUPPORTED;
+  if (J > 128 || (J % 4) || (J != 128 && gemm_variant() == 0) || (C != 128 && C != 256) || !ld32(lddy, ldx, lddx))
+    return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
   if (!dy || !W || !dx) return SN_E_NULL;
   if (B && (!x || !Cc)) return SN_E_NULL;
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx) || (lddy % 4) || (ldw % 4) || (lddx % 4)) return SN_E_ALIGN;
   if (B && (!aligned16(x) || !aligned16(B) || !aligned16(Cc) || (center && !aligned16(center)) || (ldx % 4) || ldx < C))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0};
+  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   const bool x3 = gemm_variant() != 0;
@@ -906,7 +925,7 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
                             void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 2 || lddy < J || ldw < C || lddx < C / 2 || ldga < C / 2 || ldx < C) return SN_E_SHAPE;
-  if (J != 128 || (C != 128 && C != 256) || gemm_variant() == 0 || !ld32(lddy, ldx, lddx, ldga, ldgadd))
+  if (J > 128 || (J % 4) || (C != 128 && C != 256) || gemm_variant() == 0 || !ld32(lddy, ldx, lddx, ldga, ldgadd))
     return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
   if (!dy || !W || !dx_hi || !gact || !x || !B || !Cc) return SN_E_NULL;
@@ -915,7 +934,7 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
       (lddy % 4) || (ldw % 4) || (lddx % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   const int half = C / 2;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J};
   float *out = dx_hi - half;           // the kernel indexes absolute columns; only columns >= half are written through `out`
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
@@ -933,7 +952,7 @@ int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64
                               int64_t lde, int64_t rows, int32_t K, int32_t J, double *elu_stats_part, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J) || rows_per_seg < 1) return SN_E_SHAPE;
-  if (J != 128 || (K != 128 && K != 256) || rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL || gemm_variant() == 0 ||
+  if (J > 128 || (J % 4) || (K != 128 && K != 256) || rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL || gemm_variant() == 0 ||
       !ld32(ldx, ldy, ldr, lde))
     return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
@@ -943,7 +962,7 @@ int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64
     return SN_E_ALIGN;
   if (elu_stats_part && !y_elu) return SN_E_UNSUPPORTED;
   EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, rows_per_seg, J, nullptr, elu_stats_part,
-             sn_linear_fwd_stats_blocks(rows)};
+             sn_linear_fwd_stats_blocks(rows), (int)J};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
@@ -965,17 +984,18 @@ int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, in
                                int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,
                                int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
-  if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || ldga < C || ldx < C || rows_per_seg < 1) return SN_E_SHAPE;
-  if (J != 128 || (C != 128 && C != 256) || rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL || gemm_variant() == 0 ||
-      !ld32(lddy, ldx, ldga, ldgadd))
+  if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || ldga < C || ldx < C || (segvec && rows_per_seg < 1)) return SN_E_SHAPE;
+  if (J > 128 || (J % 4) || (C != 128 && C != 256) || gemm_variant() == 0 || !ld32(lddy, ldx, ldga, ldgadd) ||
+      (segvec && (rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL)))
     return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
-  if (!dy || !W || !gact || !x || !B || !Cc || !segvec) return SN_E_NULL;
+  if (!dy || !W || !gact || !x || !B || !Cc || (rowmask && !segvec)) return SN_E_NULL;      // segvec may be NULL: no per-mesh vector
   if (!aligned16(dy) || !aligned16(W) || !aligned16(gact) || !aligned16(x) || !aligned16(B) || !aligned16(Cc) ||
-      !aligned16(segvec) || (center && !aligned16(center)) || (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C)) ||
-      (lddy % 4) || (ldw % 4) || (ldga % 4) || (ldx % 4))
+      (segvec && !aligned16(segvec)) || (center && !aligned16(center)) ||
+      (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C)) || (lddy % 4) || (ldw % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, rows_per_seg, C, rowmask, nullptr, 0};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, segvec ? rows_per_seg : 0, C, rowmask, nullptr, 0,
+             (int)J};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   float *none = nullptr;               // every column leaves through gact: nothing is written through Out

@@ -552,6 +552,10 @@ def bnlin_backward_elu_input(state, dy):
         Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
     dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
     dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    if training and kernels.linear_dgrad_elu_supported(128, C) and kernels.linear_dgrad_supported(J, C):
+        # product, BatchNorm tail and activation derivative in one kernel (epilogue of the input-gradient GEMM)
+        dx = kernels.linear_dgrad_eluseg(dy, Wf, x, mean, Bc, Cc, None, 0)
+        return dx, dgamma, dbeta, dW, db
     dx = kernels.linear_dgrad(dy, Wf) if kernels.linear_dgrad_supported(J, C) else dy.mm(Wf)
     if training:
         kernels.affine_cols_elu_bwd(dx, x, Bc, Cc, mean)

@@ -497,8 +497,15 @@ def laplacian_from_mesh(V, F):
     return rowptr, colind, vals
 
 
+def _split_gemm() -> bool:
+    import os
+
+    return os.environ.get("SN_GEMM_VARIANT", "2") != "0"
+
+
 def linear_fwd_supported(K: int, J: int) -> bool:
-    return J == 128 and K in (128, 256)
+    """J = 128, or — split kernels only — any multiple of 4 up to 128 (the models' last layer has 120 outputs)."""
+    return K in (128, 256) and (J == 128 or (_split_gemm() and 0 < J < 128 and J % 4 == 0))
 
 
 def elu_stats_supported() -> bool:
@@ -595,7 +602,7 @@ def colstats_halves(x, part, part_hi=None):
 
 
 def linear_dgrad_supported(J: int, C: int) -> bool:
-    return J == 128 and C in (128, 256)
+    return C in (128, 256) and (J == 128 or (_split_gemm() and 0 < J < 128 and J % 4 == 0))
 
 
 def linear_dgrad_elu_supported(J: int, C: int) -> bool:
@@ -782,7 +789,8 @@ def linear_fwd_segbias(x, W, segbias, rows_per_seg: int, residual=None, y_elu=No
 
 
 def linear_dgrad_eluseg(dy, W, x, center, B, Cc, segvec, rows_per_seg: int, rowmask=None, gadd=None):
-    """(dy·W + (x - center) B + Cc + rowmask * segvec[row // rows_per_seg]) * elu'(x) + gadd for all C columns."""
+    """(dy·W + (x - center) B + Cc + rowmask * segvec[row // rows_per_seg]) * elu'(x) + gadd for all C columns
+    (segvec=None: no per-mesh vector)."""
     _dev(dy, W, x, center, B, Cc, segvec, rowmask, gadd)
     rows, J = dy.shape
     C = x.shape[1]

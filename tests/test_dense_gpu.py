@@ -644,12 +644,13 @@ def _outside_untouched(arena, view_rows, width, canary, pad_rows=3, pad_cols=8):
 
 
 @pytest.mark.parametrize("rows", [1, 31, 32, 33, 95, 1017, 8200])
-@pytest.mark.parametrize("K", [128, 256])
-def test_linear_kernels_stay_inside_their_views(rows, K):
+@pytest.mark.parametrize("K,J", [(128, 128), (256, 128), (128, 120), (256, 4), (128, 64)])
+def test_linear_kernels_stay_inside_their_views(rows, K, J):
+    """J < 128: the narrow layers (the models' last layer has 120 outputs) — weights, bias, residual and dy of the columns
+    that do not exist are never read, nothing is stored to them."""
     from surfacenetworks_amd import _lib
     from surfacenetworks_amd.kernels import _p, _ld, _stream
-    J = 128
-    rng = np.random.default_rng(rows * 3 + K)
+    rng = np.random.default_rng(rows * 3 + K + J)
     W = dev((rng.standard_normal((J, K)) / np.sqrt(K)).astype(np.float32))
     b = dev(rng.standard_normal(J).astype(np.float32))
     _, x = _arena(rows, K, seed=1)
@@ -686,6 +687,15 @@ def test_linear_kernels_stay_inside_their_views(rows, K):
     _lib.call("sn_linear_dgrad_f32", _p(dy), _ld(dy), _p(Wd), _ld(Wd), _p(xs), _ld(xs), _p(cen), _p(B), _p(Cc), _p(dxv),
               _ld(dxv), rows, J, C, _stream())
     assert float((dxv.double() - full).abs().max()) < 1e-4 and _outside_untouched(da, rows, C, 7.0)
+    # every column through the activation, no per-mesh vector (the backward of conv(F.elu(v)))
+    _, gadd2 = _arena(rows, C, seed=11)
+    aa, gall = _arena(rows, C, seed=12, fill=7.0)
+    gall.fill_(7.0)
+    _lib.call("sn_linear_dgrad_eluseg_f32", _p(dy), _ld(dy), _p(Wd), _ld(Wd), _p(xs), _ld(xs), _p(cen), _p(B), _p(Cc), None, 0,
+              None, _p(gall), _ld(gall), _p(gadd2), _ld(gadd2), rows, J, C, _stream())
+    oa = xs.double()
+    want_all = full * torch.where(oa > 0, torch.ones_like(oa), oa + 1) + gadd2.double()
+    assert float((gall.double() - want_all).abs().max()) < 1e-4 and _outside_untouched(aa, rows, C, 7.0)
     # weight gradient: rows past the views are NaN — one of them read would poison every entry
     G, s = kernels.wgrad(dy, xs, cen, want_colsum=True)
     wantG = dy.double().t() @ (xs.double() - cen.double())
