@@ -609,7 +609,7 @@ def linear_dgrad_elu_supported(J: int, C: int) -> bool:
     """The fused form exists only in the split-bf16 kernels (SN_GEMM_VARIANT != 0)."""
     import os
 
-    return J == 128 and C in (128, 256) and os.environ.get("SN_GEMM_VARIANT", "1") != "0"
+    return 0 < J <= 128 and J % 4 == 0 and C in (128, 256) and os.environ.get("SN_GEMM_VARIANT", "1") != "0"
 
 
 def linear_dgrad_elu(dy, W, x, center, B, Cc, gadd=None):
