@@ -291,7 +291,7 @@ def main():
 
     def graph_step():
         batch = ds.sample_batch(n_local, rng, seq_ids=seq_ids)
-        return graphed(batch, grad_sync=bucket.all_reduce)              # load -> one hipGraphLaunch -> all-reduce -> Adam
+        return graphed(batch, grad_sync=bucket.sync)                    # load -> one hipGraphLaunch -> pack + all-reduce -> Adam
 
     one_step = eager_step if args.no_graph else graph_step
 
@@ -305,8 +305,6 @@ def main():
     for _ in range(3):
         eager_step()
     if not args.no_graph:
-        for p_, v_ in zip(bucket.params, bucket._views()):          # the captured step accumulates into the static bucket slices
-            p_.grad = v_
         graphed = arap.GraphedTrainStep(model, opt, ds.sample_batch(n_local, rng, seq_ids=seq_ids),
                                         global_batch=global_batch, bucket=bucket)
     for _ in range(args.warmup):

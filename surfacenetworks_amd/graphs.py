@@ -139,29 +139,38 @@ class GraphedStep:
 
 class GraphedTrainStep:
     """A training step whose forward + loss + backward is one hipGraph replay; the gradient all-reduce and the optimizer
-    stay eager.  `loss_of(model, batch) -> loss`; `example` fixes the batch signature and becomes the static batch."""
+    stay eager.  `loss_of(model, batch) -> loss`; `example` fixes the batch signature and becomes the static batch.
+
+    Gradients are STORED, not accumulated: every parameter's `.grad` is None while the step is captured, so autograd
+    assigns the freshly computed gradient tensors (static buffers of the graph's memory pool) instead of adding them into
+    pre-existing ones — no zeroing pass and no add per parameter in the replay (124 small launches for the ARAP models).
+    A replay rewrites those buffers in place; `.grad` is re-pointed at them after every replay because a gradient
+    reduction (`FlatGradBucket.sync`) may have re-pointed it at the bucket slices."""
 
     def __init__(self, model, optimizer, example, loss_of: Callable, bucket=None):
         self.optimizer = optimizer
-        params = [p for p in model.parameters() if p.requires_grad]
-        for p in params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        grads = [p.grad for p in params]
-        zero = bucket.zero_ if bucket is not None else (lambda: torch._foreach_zero_(grads))
+        self.params = [p for p in model.parameters() if p.requires_grad]
+
+        def drop():
+            for p in self.params:
+                p.grad = None
 
         def body(b):
             loss = loss_of(model, b)
             loss.backward()
             return loss
 
-        self.step = GraphedStep(body, example, zero, preserve=list(model.buffers()))
+        # (the `zero_grads` slot of GraphedStep runs before the body, at warm-up and at capture time: host code, not recorded)
+        self.step = GraphedStep(body, example, drop, preserve=list(model.buffers()))
+        self.grads = [p.grad for p in self.params]      # static; None for a parameter the loss does not reach
 
     def matches(self, batch) -> bool:
         return self.step.matches(batch)
 
     def __call__(self, batch, grad_sync=None):
         loss = self.step(batch)
+        for p, g in zip(self.params, self.grads):
+            p.grad = g
         if grad_sync is not None:
             grad_sync()
         self.optimizer.step()
