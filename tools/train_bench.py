@@ -10,7 +10,7 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from surfacenetworks_amd import arap, dense_correspondence as dc, mesh_mnist as mm  # noqa: E402
+from surfacenetworks_amd import dp, arap, dense_correspondence as dc, mesh_mnist as mm  # noqa: E402
 
 
 def timed(step, steps, warm=3):
@@ -76,7 +76,9 @@ def main():
         model = arap.Model(15).to(dev).train()
         opt = arap.make_optimizer(model)
         ids = np.arange(64)
-        dt = timed(lambda: arap.train_step(model, opt, ds.sample_batch(64, rng, seq_ids=ids)), steps)
+        bucket = dp.FlatGradBucket(model.parameters())          # stored gradients, as bench.py's step
+        dt = timed(lambda: arap.train_step(model, opt, ds.sample_batch(64, rng, seq_ids=ids), grad_sync=bucket.sync,
+                                           zero_grads=bucket.detach_grads), steps)
         print(f"{what}: batch 64 x 71x71, {dt * 1e3:.2f} ms/step, {64 / dt:.0f} meshes/s")
     elif what == "arap_ragged":
         # a ragged batch (config-5-like sizes: 64 cloth meshes with 1 000 .. 10 000 vertices): padded as the reference batches
@@ -89,7 +91,9 @@ def main():
             torch.manual_seed(0)
             model = arap.DirModel().to(dev).train()
             opt = arap.make_optimizer(model)
-            dt = timed(lambda: arap.train_step(model, opt, ds.sample_batch(64, rng, seq_ids=ids, packed=packed)), steps)
+            bucket = dp.FlatGradBucket(model.parameters())
+            dt = timed(lambda: arap.train_step(model, opt, ds.sample_batch(64, rng, seq_ids=ids, packed=packed),
+                                               grad_sync=bucket.sync, zero_grads=bucket.detach_grads), steps)
             rows = int(ds.num_vertices.sum()) if packed else 64 * int(ds.num_vertices.max())
             print(f"{what}: 64 ragged meshes (sum V = {int(ds.num_vertices.sum())}, max V = {int(ds.num_vertices.max())}), "
                   f"{'packed' if packed else 'padded'}: {rows} vertex rows, {dt * 1e3:.2f} ms/step, {64 / dt:.0f} meshes/s")
