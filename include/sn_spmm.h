@@ -352,6 +352,14 @@ size_t sn_wgrad_seg_workspace_bytes(int64_t rows, int64_t rows_per_seg, int32_t 
 int sn_wgrad_seg_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                      int64_t rows_per_seg, int32_t J, int32_t C, float *G, double *dysum, float *seg_dysum, void *workspace,
                      size_t workspace_bytes, void *stream);
+/* sn_wgrad_slabs_f32: the same for RAGGED meshes (packed batches, no padding rows — the reference pads every mesh to the
+ * batch maximum, src/as_rigid_as_possible/main.py:172-185): the caller supplies the row slabs, slab b = rows
+ * [slab_off[b], slab_off[b+1]) (device int64[nslab + 1], consecutive, none crossing a mesh boundary) and the slabs of every
+ * mesh, [seg_slab_ptr[m], seg_slab_ptr[m+1]) (device int64[nseg + 1]); seg_dysum is (nseg x J).  Workspace:
+ * nslab * 128 * (C + 1) floats.  Uniform-wave kernel only (SN_E_UNSUPPORTED with SN_GEMM_VARIANT=0 / SN_WGRAD_VARIANT=1). */
+int sn_wgrad_slabs_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                       const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg, int32_t J, int32_t C,
+                       float *G, double *dysum, float *seg_dysum, void *workspace, size_t workspace_bytes, void *stream);
 /* sn_wgrad_thin_f32: weight and bias gradient of a Linear with 1..8 input channels — the models' first layer,
  * GraphConv1x1(6 | 3 -> C, batch_norm=None) (src/as_rigid_as_possible/models.py:113, src/utils/utils_pt.py:99) — on
  * rows ~ 1e5..1e6:  G (J x C, row-major, fp32) = dy^T x,  db (J, optional) = colsum(dy).  One pass over dy; fp32
@@ -467,6 +475,10 @@ int sn_avg_bwd_gc_f32(const float *G1, const float *seg_dy, const float *m, cons
 int sn_avg_bwd_segvec_f32(const float *seg_dy, const float *Wf2, int64_t ldw, const float *m, const float *mu2,
                           const float *B2, const float *C2, const float *inv_count, int64_t rows_per_seg, int64_t nseg,
                           int32_t J, int32_t C, float *out, void *stream);
+/* ... for ragged meshes: mesh g has segoff[g+1] - segoff[g] rows (device int64[nseg + 1]) in place of rows_per_seg */
+int sn_avg_bwd_segvec_ragged_f32(const float *seg_dy, const float *Wf2, int64_t ldw, const float *m, const float *mu2,
+                                 const float *B2, const float *C2, const float *inv_count, const int64_t *segoff, int64_t nseg,
+                                 int32_t J, int32_t C, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------
  * Device-side construction of the quaternionic Dirac operators from a triangle mesh.
@@ -581,6 +593,17 @@ int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, in
                                const float *center, const float *B, const float *Cc, const float *segvec,
                                int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,
                                int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream);
+/* The two per-mesh-vector kernels for RAGGED meshes (packed batches): mesh g owns rows [segoff[g], segoff[g+1]) (device
+ * int64[nseg + 1], segoff[0] = 0, segoff[nseg] = rows, every mesh at least 32 rows — the caller's responsibility: a device
+ * array is not validated here); no row mask (a packed batch has no padding rows). */
+int sn_linear_fwd_segbias_ragged_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
+                                     const int64_t *segoff, int32_t nseg, const float *residual, int64_t ldr, float *y,
+                                     int64_t ldy, float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J,
+                                     double *elu_stats_part, void *stream);
+int sn_linear_dgrad_eluseg_ragged_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                                      const float *center, const float *B, const float *Cc, const float *segvec,
+                                      const int64_t *segoff, int32_t nseg, float *gact, int64_t ldga, const float *gadd,
+                                      int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,7 @@ SIGNATURES = {
     "sn_wgrad_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "sn_wgrad_seg_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "sn_wgrad_seg_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sn_wgrad_slabs_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sn_wgrad_thin_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sn_wgrad_thin_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "sn_masked_smooth_l1_workspace_bytes": (_sz, [_i64, _i32]),
@@ -95,6 +96,11 @@ SIGNATURES = {
     "sn_seg_affine_f32": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _vp, _i32, _vp, _vp]),
     "sn_avg_bwd_gc_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "sn_avg_bwd_segvec_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "sn_avg_bwd_segvec_ragged_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "sn_linear_fwd_segbias_ragged_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32,
+                                                   _i32, _vp, _vp]),
+    "sn_linear_dgrad_eluseg_ragged_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64, _vp,
+                                                    _i64, _i64, _i32, _i32, _vp]),
     "sn_affine_cols_acc_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "sn_affine_cols_elu_bwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
 }

@@ -21,12 +21,13 @@ from __future__ import annotations
 import torch
 
 from . import kernels
-from .functional import (_launch, _rows2d, avg_stage_backward, avg_stage_forward, bn_prepare, bnlin_backward,
+from .functional import (_launch, _rows2d, avg_stage_backward, avg_stage_backward_ragged, avg_stage_forward,
+                         avg_stage_forward_ragged, bn_prepare, bnlin_backward,
                          bnlin_backward_elu_input, bnlin_backward_zero_first, bnlin_forward, bnlin_forward_zero_first, stash, unstash,
                          zero_first_supported)
 from .operators import as_operator
 
-__all__ = ["lap_block", "dirac_block", "avg_block", "take_activated", "attach_activated", "zero_faces_ok", "elu_conv", "elu_conv_ok"]
+__all__ = ["lap_block", "dirac_block", "avg_block", "avg_block_ragged", "avg_block_ragged_ok", "take_activated", "attach_activated", "zero_faces_ok", "elu_conv", "elu_conv_ok"]
 
 
 def attach_activated(t: torch.Tensor, cat: torch.Tensor) -> torch.Tensor:
@@ -307,6 +308,61 @@ class _AvgBlock(torch.autograd.Function):
             g_x = None
         return (g_x, None, None, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None,
                 None, None, None, None)
+
+
+class _AvgBlockRagged(torch.autograd.Function):
+    """_AvgBlock on a PACKED batch: `seg` (operators.PackedSegments) gives the meshes' row ranges; no mask, every row is real
+    (BatchNorm over real rows only — the reference's padded batch includes the padding rows, utils_pt.py:97-99)."""
+
+    @staticmethod
+    def forward(ctx, x, seg, pre, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1):
+        x = _rows2d(x)
+        rows, C = x.shape
+        cat = _activated(x, pre)
+        e_a = cat[:, :C]
+        e_b = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+        pb = _new_part(rows, C, x.device)
+        _, st0 = avg_stage_forward_ragged(e_a, seg, g0, b0, W0, c0, rm0, rv0, mo0, ep0, None, e_b, want_y=False, elu_stats=pb,
+                                          part=getattr(cat, "_sn_part", None))
+        nxt = _new_cat(rows, C, x.device)
+        pn = _new_part(rows, C, x.device)
+        out, st1 = avg_stage_forward_ragged(e_b, seg, g1, b1, W1, c1, rm1, rv1, mo1, ep1, x, nxt[:, :C], elu_stats=pn, part=pb)
+        _attach_part(nxt, pn)
+        stash(ctx, st0, st1)
+        ctx.seg = seg
+        ctx.mark_non_differentiable(nxt)
+        ctx.set_materialize_grads(False)
+        return out, nxt
+
+    @staticmethod
+    def backward(ctx, g_out, _gn):
+        st0, st1 = unstash(ctx)
+        if g_out is None:
+            return (None,) * 21
+        g_out = g_out.contiguous()
+        g_h, dg1, db1, dW1, dc1 = avg_stage_backward_ragged(st1, ctx.seg, g_out, None)
+        g_x, dg0, db0, dW0, dc0 = avg_stage_backward_ragged(st0, ctx.seg, g_h, g_out)      # + residual path
+        if not ctx.needs_input_grad[0]:
+            g_x = None
+        return (g_x, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None, None, None, None,
+                None)
+
+
+def avg_block_ragged_ok(mod, seg, inputs) -> bool:
+    C = inputs.shape[-1]
+    a0, a1 = _bn_args(mod.bn_fc0), _bn_args(mod.bn_fc1)
+    return bool(a0[6] and a1[6]) and inputs.dtype == torch.float32 and mod.bn_fc0.fc.weight.shape == (C, 2 * C) and \
+        mod.bn_fc1.fc.weight.shape == (C, 2 * C) and kernels.avg_stage_ragged_supported(C, C, seg) and \
+        seg.rows == inputs.shape[0] * inputs.shape[1]
+
+
+def avg_block_ragged(mod, seg, inputs):
+    """AvgResNet2 on a packed (1, sum V_i, C) batch as one autograd node at half width."""
+    B, V, C = inputs.shape
+    rows = B * V
+    out, nxt = _AvgBlockRagged.apply(inputs.reshape(rows, C), seg, take_activated(inputs, rows, C), *_bn_args(mod.bn_fc0),
+                                     *_bn_args(mod.bn_fc1))
+    return attach_activated(out.view(B, V, C), nxt)
 
 
 class _EluConv(torch.autograd.Function):

@@ -589,7 +589,8 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
                                                               const float *__restrict__ center, int64_t rows, int J, int C,
                                                               float *__restrict__ partial /* [grid][128][C] */,
                                                               float *__restrict__ colpart /* [grid][128] | NULL */,
-                                                              int64_t seg_rows /* 0: even split of all rows */, int spm) {
+                                                              int64_t seg_rows /* 0: even split of all rows */, int spm,
+                                                              const int64_t *__restrict__ slab_off /* [grid + 1] | NULL */) {
   constexpr int NCG = 32 + 32 * CT;          // column groups of 4: 32 of dy, 32·CT of x
   constexpr int QP = NCG + 4;                // slots per (column % 4) plane; QP % 16 == 4 keeps fragment reads conflict-free
   constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
@@ -599,8 +600,11 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
   __shared__ u4 img[2][3][4 * PL];           // [buffer][piece][slot]; one block = 32 rows = 4 row groups
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  int64_t r0, r1;                            // row slab of this workgroup (as wgrad_x3_k)
-  if (seg_rows > 0) {
+  int64_t r0, r1;                            // row slab of this workgroup: from the caller's table (ragged meshes), or as wgrad_x3_k
+  if (slab_off) {
+    r0 = slab_off[blockIdx.x];
+    r1 = slab_off[blockIdx.x + 1];
+  } else if (seg_rows > 0) {
     const int64_t mesh = blockIdx.x / spm, part = blockIdx.x % spm;
     int64_t per = (seg_rows + spm - 1) / spm;
     per = (per + 15) & ~(int64_t)15;
@@ -794,17 +798,21 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
 __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ partial, int nslab, int J, int C,
                                                       float *__restrict__ G, const float *__restrict__ colpart,
                                                       double *__restrict__ dysum,
-                                                      float *__restrict__ segsum /* [nslab/spm][J] | NULL */, int spm) {
+                                                      float *__restrict__ segsum /* [nslab/spm][J] | NULL */, int spm,
+                                                      const int64_t *__restrict__ seg_slab_ptr /* [nseg + 1] | NULL */,
+                                                      int nseg) {
   __shared__ double sm[4][64];
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int nG = J * C;
   const int i = blockIdx.x * 64 + o;            // output element j*C + c  (partials are laid out [slab][128][C]);
   double t = 0;                                 // elements past J*C are the J column sums of dy ([slab][128])
-  if (i >= nG + J && segsum && g == 0 && i < nG + J + (nslab / spm) * J) {
-    // past G and colsum(dy): the per-mesh column sums of dy — spm consecutive slabs each
+  if (i >= nG + J && segsum && g == 0 && i < nG + J + (seg_slab_ptr ? nseg : nslab / spm) * J) {
+    // past G and colsum(dy): the per-mesh column sums of dy — the mesh's consecutive slabs (spm each, or from the table)
     const int k = i - nG - J, mesh = k / J, j = k - mesh * J;
+    const int64_t p0 = seg_slab_ptr ? seg_slab_ptr[mesh] : (int64_t)mesh * spm;
+    const int64_t p1 = seg_slab_ptr ? seg_slab_ptr[mesh + 1] : p0 + spm;
     double t2 = 0;
-    for (int p_ = 0; p_ < spm; ++p_) t2 += (double)colpart[(int64_t)(mesh * spm + p_) * 128 + j];
+    for (int64_t p_ = p0; p_ < p1; ++p_) t2 += (double)colpart[p_ * 128 + j];
     segsum[k] = (float)t2;
   }
   if (i < nG || (colpart && i < nG + J)) {
@@ -1336,10 +1344,12 @@ __global__ __launch_bounds__(kWG) void avg_bwd_segvec_k(const float *__restrict_
                                                         int64_t ldw, const float *__restrict__ m,
                                                         const float *__restrict__ mu2, const float *__restrict__ B2,
                                                         const float *__restrict__ C2, const float *__restrict__ inv_count,
-                                                        double per, int nseg, int J, int C, float *__restrict__ out) {
+                                                        double per, int nseg, int J, int C, float *__restrict__ out,
+                                                        const int64_t *__restrict__ segoff /* ragged: rows of mesh g | NULL */) {
   const int t = blockIdx.x * kWG + threadIdx.x;
   if (t >= nseg * C) return;
   const int g = t / C, c = t - g * C;
+  if (segoff) per = (double)(segoff[g + 1] - segoff[g]);
   double acc = 0;
 #pragma unroll 16
   for (int j = 0; j < J; ++j) acc += (double)Sg[(int64_t)g * J + j] * (double)Wf2[(int64_t)j * ldw + c];
@@ -1587,15 +1597,18 @@ size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C) {
 
 static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                         int32_t J, int32_t C, float *G, double *dysum, int64_t rows_per_seg, float *seg_dysum,
-                        void *workspace, size_t workspace_bytes, void *stream) {
+                        void *workspace, size_t workspace_bytes, void *stream, const int64_t *slab_off = nullptr,
+                        int32_t nslab_tab = 0, const int64_t *seg_slab_ptr = nullptr, int32_t nseg_tab = 0) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldx < C) return SN_E_SHAPE;
   if (J > 128 || (J % 4) || (C != 128 && C != 256)) return SN_E_UNSUPPORTED;
   if (!G) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool x3 = gemm_variant() != 0;
-  const bool segmented = rows_per_seg > 0;
+  const bool ragged = slab_off != nullptr;                  // slabs and their meshes from the caller's tables
+  const bool segmented = rows_per_seg > 0 && !ragged;
   if (segmented && (!x3 || !dysum || !seg_dysum || rows % rows_per_seg)) return x3 ? SN_E_SHAPE : SN_E_UNSUPPORTED;
+  if (ragged && (nslab_tab < 1 || nseg_tab < 1 || !seg_slab_ptr || !dysum || !seg_dysum)) return SN_E_SHAPE;
   if (rows == 0) {
     hipError_t e = hipMemsetAsync(G, 0, (size_t)J * C * sizeof(float), s);
     if (e == hipSuccess && dysum) e = hipMemsetAsync(dysum, 0, (size_t)J * sizeof(double), s);
@@ -1613,15 +1626,17 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
     if (nseg * spm > INT_MAX) return SN_E_RANGE;
     nslab = (int)(nseg * spm);
   }
+  if (ragged) nslab = nslab_tab;
   if (workspace_bytes < (size_t)nslab * 128 * ((size_t)C + 1) * sizeof(float)) return SN_E_WORKSPACE;
   float *partial = static_cast<float *>(workspace);
   float *colpart = dysum ? partial + (size_t)nslab * 128 * C : nullptr;
   const int64_t sr = segmented ? rows_per_seg : 0;
   const bool uni = x3 && wgrad_variant() == 2 && lddy < ((int64_t)1 << 24) && ldx < ((int64_t)1 << 24);
+  if (ragged && !uni) return SN_E_UNSUPPORTED;              // slab tables: the uniform-wave kernel only
   if (uni && C == 128)
-    hipLaunchKernelGGL((wgrad_u_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
+    hipLaunchKernelGGL((wgrad_u_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
   else if (uni)
-    hipLaunchKernelGGL((wgrad_u_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
+    hipLaunchKernelGGL((wgrad_u_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
   else if (x3 && C == 128)
     hipLaunchKernelGGL((wgrad_x3_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
   else if (x3)
@@ -1630,9 +1645,10 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
     hipLaunchKernelGGL((wgrad_mfma_k<1>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
   else
     hipLaunchKernelGGL((wgrad_mfma_k<2>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
-  const int64_t extra = (dysum ? J : 0) + (segmented ? (int64_t)(nslab / spm) * J : 0);
+  const int64_t extra = (dysum ? J : 0) + (segmented ? (int64_t)(nslab / spm) * J : 0) + (ragged ? (int64_t)nseg_tab * J : 0);
   hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)((J * C + extra + 63) / 64)), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G,
-                     colpart, dysum, segmented ? seg_dysum : nullptr, spm);
+                     colpart, dysum, (segmented || ragged) ? seg_dysum : nullptr, spm, ragged ? seg_slab_ptr : nullptr,
+                     (int)nseg_tab);
   return launch_status();
 }
 
@@ -1657,6 +1673,18 @@ int sn_wgrad_seg_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx,
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows_per_seg < 1) return SN_E_SHAPE;
   return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, rows_per_seg, seg_dysum, workspace, workspace_bytes, stream);
+}
+
+// Weight gradient over caller-defined row slabs (ragged meshes): slab b = rows [slab_off[b], slab_off[b+1]) — consecutive,
+// none crossing a mesh boundary — and mesh m owns slabs [seg_slab_ptr[m], seg_slab_ptr[m+1]); seg_dysum receives the per-mesh
+// column sums of dy ([nseg][J]).  Workspace: nslab·128·(C+1) floats.  Uniform-wave kernel only (SN_E_UNSUPPORTED otherwise).
+int sn_wgrad_slabs_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                       const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg, int32_t J, int32_t C,
+                       float *G, double *dysum, float *seg_dysum, void *workspace, size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (!slab_off || !seg_slab_ptr) return SN_E_NULL;
+  return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, 0, seg_dysum, workspace, workspace_bytes, stream, slab_off,
+                      nslab, seg_slab_ptr, nseg);
 }
 
 static int thin_blocks(int64_t rows, int J) {
@@ -1742,7 +1770,20 @@ int sn_avg_bwd_segvec_f32(const float *seg_dy, const float *Wf2, int64_t ldw, co
   if (!seg_dy || !Wf2 || !m || !mu2 || !B2 || !C2 || !inv_count || !out) return SN_E_NULL;
   hipLaunchKernelGGL(avg_bwd_segvec_k, dim3((unsigned)((nseg * C + kWG - 1) / kWG)), dim3(kWG), 0,
                      static_cast<hipStream_t>(stream), seg_dy, Wf2, ldw, m, mu2, B2, C2, inv_count, (double)rows_per_seg,
-                     (int)nseg, (int)J, (int)C, out);
+                     (int)nseg, (int)J, (int)C, out, (const int64_t *)nullptr);
+  return launch_status();
+}
+
+// the same per-mesh vector for RAGGED meshes: mesh g has segoff[g+1] - segoff[g] rows
+int sn_avg_bwd_segvec_ragged_f32(const float *seg_dy, const float *Wf2, int64_t ldw, const float *m, const float *mu2,
+                                 const float *B2, const float *C2, const float *inv_count, const int64_t *segoff, int64_t nseg,
+                                 int32_t J, int32_t C, float *out, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (nseg < 1 || J < 1 || C < 1 || ldw < C) return SN_E_SHAPE;
+  if (!seg_dy || !Wf2 || !m || !mu2 || !B2 || !C2 || !inv_count || !out || !segoff) return SN_E_NULL;
+  hipLaunchKernelGGL(avg_bwd_segvec_k, dim3((unsigned)((nseg * C + kWG - 1) / kWG)), dim3(kWG), 0,
+                     static_cast<hipStream_t>(stream), seg_dy, Wf2, ldw, m, mu2, B2, C2, inv_count, 0.0, (int)nseg, (int)J, (int)C,
+                     out, segoff);
   return launch_status();
 }
 

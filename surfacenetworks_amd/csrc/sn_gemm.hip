@@ -67,6 +67,10 @@ struct EpiArgs {
   // (the weights, bias, residual of the others read as 0, nothing is stored to them); input gradient: columns of dy = rows of
   // W that exist (the others read as 0).  128: full width.
   int jv;
+  // ragged meshes: segoff[0 .. nseg] = first row of every mesh (and the row count), each mesh at least 32 rows; takes the
+  // place of `period` (then 0) for the per-mesh vectors.  NULL: equal meshes of `period` rows.
+  const int64_t *segoff;
+  int nseg;
 };
 
 template <int K, int NT, bool TRANSW, int EPI>
@@ -518,12 +522,23 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
     else w_ga.init_empty();
   }
   // per-mesh vectors: the mesh of the tile's first row and the row where the next mesh starts, kept up as tiles advance
-  const bool useseg = ep.period > 0 && (EPI == EPI_FWD || (DGE && lowhalf));                 // wave-uniform
+  const bool useseg = (ep.period > 0 || ep.segoff != nullptr) && (EPI == EPI_FWD || (DGE && lowhalf));      // wave-uniform
   int64_t seg_m = 0;
-  int seg_left = 0;                                          // rows from the tile's first row to the next mesh (period < 2^31)
+  int seg_left = 0;                                          // rows from the tile's first row to the next mesh (< 2^31)
   if (useseg) {
-    seg_m = row0 / ep.period;
-    seg_left = (int)((seg_m + 1) * ep.period - row0);
+    if (ep.segoff) {                                         // the mesh that holds row0: last m with segoff[m] <= row0
+      int lo = 0, hi = ep.nseg - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (ep.segoff[mid] <= row0) lo = mid;
+        else hi = mid - 1;
+      }
+      seg_m = lo;
+      seg_left = (int)(ep.segoff[lo + 1] - row0);
+    } else {
+      seg_m = row0 / ep.period;
+      seg_left = (int)((seg_m + 1) * ep.period - row0);
+    }
   }
 
   // ---- loader: this wave stages rows 8·wave .. +7 of a tile, four rows per load instruction (16 lanes x 16 bytes = one
@@ -604,7 +619,7 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
     if (useseg) {
       if (seg_left <= 0) {
         ++seg_m;
-        seg_left += (int)ep.period;
+        seg_left += ep.segoff ? (int)(ep.segoff[seg_m + 1] - ep.segoff[seg_m]) : (int)ep.period;
       }
       nb = seg_left < nrt ? seg_left : nrt;                            // rows >= nb (if any) belong to the next mesh
       const float *s0 = ep.segv + seg_m * ep.ldseg + (colv ? ecol : 0);
@@ -862,7 +877,7 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
     return SN_E_ALIGN;
   if (elu_stats_part && (!y_elu || gemm_variant() == 0)) return SN_E_UNSUPPORTED;
   EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr, elu_stats_part,
-             sn_linear_fwd_stats_blocks(rows), (int)J};
+             sn_linear_fwd_stats_blocks(rows), (int)J, nullptr, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const bool x3 = gemm_variant() != 0;
@@ -900,7 +915,7 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx) || (lddy % 4) || (ldw % 4) || (lddx % 4)) return SN_E_ALIGN;
   if (B && (!aligned16(x) || !aligned16(B) || !aligned16(Cc) || (center && !aligned16(center)) || (ldx % 4) || ldx < C))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J};
+  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   const bool x3 = gemm_variant() != 0;
@@ -934,7 +949,7 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
       (lddy % 4) || (ldw % 4) || (lddx % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   const int half = C / 2;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0};
   float *out = dx_hi - half;           // the kernel indexes absolute columns; only columns >= half are written through `out`
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
@@ -947,13 +962,17 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
   return launch_status();
 }
 
-int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
-                              int64_t rows_per_seg, const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu,
-                              int64_t lde, int64_t rows, int32_t K, int32_t J, double *elu_stats_part, void *stream) {
+// segoff != NULL: ragged meshes (rows_per_seg ignored); the caller guarantees segoff[0] = 0 < ... < segoff[nseg] = rows with
+// at least 32 rows per mesh (device array: not checked here)
+static int fwd_segbias_launch(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
+                              int64_t rows_per_seg, const int64_t *segoff, int32_t nseg, const float *residual, int64_t ldr,
+                              float *y, int64_t ldy, float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J,
+                              double *elu_stats_part, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
-  if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J) || rows_per_seg < 1) return SN_E_SHAPE;
-  if (J > 128 || (J % 4) || (K != 128 && K != 256) || rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL || gemm_variant() == 0 ||
-      !ld32(ldx, ldy, ldr, lde))
+  if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J) || (!segoff && rows_per_seg < 1) || (segoff && nseg < 1))
+    return SN_E_SHAPE;
+  if (J > 128 || (J % 4) || (K != 128 && K != 256) || gemm_variant() == 0 || !ld32(ldx, ldy, ldr, lde) ||
+      (!segoff && (rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL)))
     return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
   if (!x || !W || !segbias || (!y && !y_elu)) return SN_E_NULL;
@@ -961,8 +980,8 @@ int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64
       (residual && (!aligned16(residual) || (ldr % 4) || ldr < J)) || (y_elu && (!aligned16(y_elu) || (lde % 4) || lde < J)))
     return SN_E_ALIGN;
   if (elu_stats_part && !y_elu) return SN_E_UNSUPPORTED;
-  EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, rows_per_seg, J, nullptr, elu_stats_part,
-             sn_linear_fwd_stats_blocks(rows), (int)J};
+  EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, segoff ? 0 : rows_per_seg, J, nullptr,
+             elu_stats_part, sn_linear_fwd_stats_blocks(rows), (int)J, segoff, nseg};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
@@ -979,14 +998,33 @@ int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64
   return launch_status();
 }
 
-int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
+                              int64_t rows_per_seg, const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu,
+                              int64_t lde, int64_t rows, int32_t K, int32_t J, double *elu_stats_part, void *stream) {
+  return fwd_segbias_launch(x, ldx, W, ldw, segbias, rows_per_seg, nullptr, 0, residual, ldr, y, ldy, y_elu, lde, rows, K, J,
+                            elu_stats_part, stream);
+}
+
+int sn_linear_fwd_segbias_ragged_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
+                                     const int64_t *segoff, int32_t nseg, const float *residual, int64_t ldr, float *y,
+                                     int64_t ldy, float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J,
+                                     double *elu_stats_part, void *stream) {
+  if (!segoff) return SN_E_NULL;
+  return fwd_segbias_launch(x, ldx, W, ldw, segbias, 0, segoff, nseg, residual, ldr, y, ldy, y_elu, lde, rows, K, J,
+                            elu_stats_part, stream);
+}
+
+static int dgrad_eluseg_launch(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
                                const float *center, const float *B, const float *Cc, const float *segvec,
-                               int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,
-                               int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream) {
+                               int64_t rows_per_seg, const int64_t *segoff, int32_t nseg, const float *rowmask, float *gact,
+                               int64_t ldga, const float *gadd, int64_t ldgadd, int64_t rows, int32_t J, int32_t C,
+                               void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
-  if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || ldga < C || ldx < C || (segvec && rows_per_seg < 1)) return SN_E_SHAPE;
+  if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || ldga < C || ldx < C || (segvec && !segoff && rows_per_seg < 1) ||
+      (segoff && (nseg < 1 || !segvec)))
+    return SN_E_SHAPE;
   if (J > 128 || (J % 4) || (C != 128 && C != 256) || gemm_variant() == 0 || !ld32(lddy, ldx, ldga, ldgadd) ||
-      (segvec && (rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL)))
+      (segvec && !segoff && (rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL)))
     return SN_E_UNSUPPORTED;
   if (rows == 0) return SN_OK;
   if (!dy || !W || !gact || !x || !B || !Cc || (rowmask && !segvec)) return SN_E_NULL;      // segvec may be NULL: no per-mesh vector
@@ -994,8 +1032,8 @@ int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, in
       (segvec && !aligned16(segvec)) || (center && !aligned16(center)) ||
       (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C)) || (lddy % 4) || (ldw % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, segvec ? rows_per_seg : 0, C, rowmask, nullptr, 0,
-             (int)J};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, (segvec && !segoff) ? rows_per_seg : 0, C, rowmask,
+             nullptr, 0, (int)J, segoff, nseg};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   float *none = nullptr;               // every column leaves through gact: nothing is written through Out
@@ -1006,6 +1044,23 @@ int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, in
     SN_SPLIT_LAUNCH((128, 1, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, none,
                        (int64_t)0, rows, ep);
   return launch_status();
+}
+
+int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                               const float *center, const float *B, const float *Cc, const float *segvec,
+                               int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,
+                               int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream) {
+  return dgrad_eluseg_launch(dy, lddy, W, ldw, x, ldx, center, B, Cc, segvec, rows_per_seg, nullptr, 0, rowmask, gact, ldga, gadd,
+                             ldgadd, rows, J, C, stream);
+}
+
+int sn_linear_dgrad_eluseg_ragged_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                                      const float *center, const float *B, const float *Cc, const float *segvec,
+                                      const int64_t *segoff, int32_t nseg, float *gact, int64_t ldga, const float *gadd,
+                                      int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream) {
+  if (!segoff) return SN_E_NULL;
+  return dgrad_eluseg_launch(dy, lddy, W, ldw, x, ldx, center, B, Cc, segvec, 0, segoff, nseg, nullptr, gact, ldga, gadd, ldgadd,
+                             rows, J, C, stream);
 }
 
 }  // extern "C"

@@ -21,7 +21,7 @@ from . import kernels
 from .operators import SparseOperator, as_operator
 
 __all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg_propagate", "avg_propagate_ragged", "bn_linear", "bnlin_forward",
-           "bnlin_backward", "bn_prepare", "set_dirac_format", "set_laplacian_format", "SpmmTimer", "thin_linear", "thin_linear_supported"]
+           "bnlin_backward", "bn_prepare", "avg_stage_forward_ragged", "avg_stage_backward_ragged", "set_dirac_format", "set_laplacian_format", "SpmmTimer", "thin_linear", "thin_linear_supported"]
 
 _DIRAC_FORMAT = "q3"
 _LAPLACIAN_FORMAT = os.environ.get("SN_LAP_FORMAT", "rb4")      # (environment override for A/B measurements)
@@ -597,6 +597,45 @@ def avg_stage_backward(state, mask_rows, inv_count, nseg, per, dy, gadd):
     dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
     segvec = kernels.avg_bwd_segvec(Sg, Wf[:, C:], m, mean[C:], Bc[C:], Cc[C:], inv_count, per)
     g = kernels.linear_dgrad_eluseg(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, per, mask_rows, gadd)
+    return g, dgamma, dbeta, dW, db
+
+
+def avg_stage_forward_ragged(e, seg, gamma, beta, W, b, running_mean, running_var, momentum, eps, residual=None, elu_out=None,
+                             want_y=True, elu_stats=None, part=None):
+    """avg_stage_forward on a PACKED batch (`seg`: operators.PackedSegments — ragged meshes, no padding rows, every row
+    real): per-mesh means by sn_segment_colsum_ragged_f32; BatchNorm statistics of the first half from the partials `part`
+    the GEMM that wrote e left (else one more pass over e), of the broadcast half from the means (mesh i contributes
+    len_i·m_i and len_i·m_i²); the per-mesh bias enters the GEMM by mesh offsets (sn_linear_fwd_segbias_ragged_f32)."""
+    e = _rows2d(e)
+    rows, C = e.shape
+    m = seg.mean(e)
+    s1 = kernels.colstats_from_part(part, rows) if part is not None else kernels.colstats(e)
+    md = m.to(torch.float64)
+    s2 = torch.stack([(md * seg.len_f64[:, None]).sum(0), (md * md * seg.len_f64[:, None]).sum(0)])
+    stats = torch.cat([s1, s2], 1)
+    stats, rows_g = _sync_stats(stats, rows)
+    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, True, running_mean, running_var,
+                                                 _take_counter(running_mean))
+    segb = kernels.seg_affine(m, Wf[:, C:], bf)
+    if residual is not None:
+        residual = _rows2d(residual)
+    y = kernels.linear_fwd_segbias_ragged(e, Wf[:, :C], segb, seg, residual, elu_out, want_y, elu_stats)
+    return y, (e, m, W, Wf, s, mean, invstd, beta, b is not None, rows_g)
+
+
+def avg_stage_backward_ragged(state, seg, dy, gadd):
+    """Backward of avg_stage_forward_ragged through the ELU that produced e (as avg_stage_backward; the mean-path gradient of
+    mesh i is inv_count_i (S_i·Wf2 + len_i ((m_i - mu2) B2 + C2)))."""
+    e, m, W, Wf, s, mean, invstd, beta, has_bias, rows_g = state
+    dy = dy.contiguous()
+    rows, C = e.shape
+    G1, sdy, Sg = kernels.wgrad_slabs(dy, e, mean[:C], seg)
+    Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
+    Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
+    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    segvec = kernels.avg_bwd_segvec_ragged(Sg, Wf[:, C:], m, mean[C:], Bc[C:], Cc[C:], seg)
+    g = kernels.linear_dgrad_eluseg_ragged(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, seg, gadd)
     return g, dgamma, dbeta, dW, db
 
 

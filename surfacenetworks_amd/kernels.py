@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
 ]
 
 
@@ -711,6 +711,64 @@ def wgrad_seg(dy, x, center, rows_per_seg: int):
     _lib.call("sn_wgrad_seg_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, rows_per_seg, J, C, _p(G), _p(dysum), _p(seg),
               _p(ws), ws_bytes, _stream())
     return G, dysum, seg
+
+
+def wgrad_slabs(dy, x, center, seg):
+    """wgrad_seg for RAGGED meshes (`seg`: operators.PackedSegments): (G, colsum(dy) fp64, per-mesh colsum(dy) (nseg, J))
+    from one pass, the row slabs taken from seg's table (sn_wgrad_slabs_f32)."""
+    _dev(dy, x, center)
+    rows, J = dy.shape
+    C = x.shape[1]
+    dev = dy.device
+    G = torch.empty((J, C), dtype=torch.float32, device=dev)
+    dysum = torch.empty(J, dtype=torch.float64, device=dev)
+    segsum = torch.empty((seg.nseg, J), dtype=torch.float32, device=dev)
+    ws_bytes = seg.nslab * 128 * (C + 1) * 4
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.call("sn_wgrad_slabs_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, _p(seg.slab_off), seg.nslab,
+              _p(seg.seg_slab_ptr), seg.nseg, J, C, _p(G), _p(dysum), _p(segsum), _p(ws), ws_bytes, _stream())
+    return G, dysum, segsum
+
+
+def avg_bwd_segvec_ragged(seg_dy, Wf2, m, mu2, B2, C2, seg):
+    _dev(seg_dy, Wf2, m, mu2, B2, C2)
+    nseg, C = m.shape
+    J = seg_dy.shape[1]
+    out = torch.empty((nseg, C), dtype=torch.float32, device=m.device)
+    _lib.call("sn_avg_bwd_segvec_ragged_f32", _p(seg_dy), _p(Wf2), _ld(Wf2), _p(m), _p(mu2), _p(B2), _p(C2), _p(seg.inv_count),
+              _p(seg.off_dev), nseg, J, C, _p(out), _stream())
+    return out
+
+
+def linear_fwd_segbias_ragged(x, W, segbias, seg, residual=None, y_elu=None, want_y: bool = True, elu_stats=None):
+    """linear_fwd_segbias with the bias row of each RAGGED mesh (`seg`: operators.PackedSegments)."""
+    _dev(x, W, segbias, residual, y_elu)
+    rows, K = x.shape
+    J = W.shape[0]
+    y = torch.empty((rows, J), dtype=torch.float32, device=x.device) if want_y else None
+    _lib.call("sn_linear_fwd_segbias_ragged_f32", _p(x), _ld(x), _p(W), _ld(W), _p(segbias), _p(seg.off_dev), seg.nseg,
+              _p(residual), _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu),
+              _ld(y_elu) if y_elu is not None else 0, rows, K, J, _p(elu_stats), _stream())
+    return y
+
+
+def linear_dgrad_eluseg_ragged(dy, W, x, center, B, Cc, segvec, seg, gadd=None):
+    """linear_dgrad_eluseg with the vector of each RAGGED mesh, no row mask (a packed batch has no padding rows)."""
+    _dev(dy, W, x, center, B, Cc, segvec, gadd)
+    rows, J = dy.shape
+    C = x.shape[1]
+    gact = torch.empty((rows, C), dtype=torch.float32, device=dy.device)
+    _lib.call("sn_linear_dgrad_eluseg_ragged_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x), _p(center), _p(B), _p(Cc),
+              _p(segvec), _p(seg.off_dev), seg.nseg, _p(gact), C, _p(gadd), _ld(gadd) if gadd is not None else 0, rows, J, C,
+              _stream())
+    return gact
+
+
+def avg_stage_ragged_supported(C: int, J: int, seg) -> bool:
+    import os
+
+    return C == 128 and J == 128 and seg.min_len >= 32 and os.environ.get("SN_GEMM_VARIANT", "2") != "0" and \
+        os.environ.get("SN_WGRAD_VARIANT", "2") == "2"
 
 
 def wgrad_thin_supported(J: int, C: int) -> bool:

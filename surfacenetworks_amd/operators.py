@@ -385,6 +385,22 @@ class PackedSegments:
         self.tiles = h2d_async(np.stack([seg, first, cnt], axis=1), self.device)
         self.seg_tile_ptr = h2d_async(seg_tile_ptr, self.device)
         self.inv_count = h2d_async((1.0 / self.lengths).astype(np.float32), self.device)
+        self.off_dev = h2d_async(self.offsets, self.device)                        # (nseg + 1,) int64: first row of every mesh
+        # row slabs of the weight-gradient pass (sn_wgrad_slabs_f32): about 256 in all, none crossing a mesh boundary
+        target = max(256, -(-self.rows // 256))
+        nsl = np.maximum(1, -(-self.lengths // target))
+        slab_ptr = np.zeros(self.nseg + 1, dtype=np.int64)
+        np.cumsum(nsl, out=slab_ptr[1:])
+        sseg = np.repeat(np.arange(self.nseg), nsl)
+        sk = np.arange(int(slab_ptr[-1])) - slab_ptr[sseg]
+        per = -(-self.lengths // nsl)
+        per = (per + 15) // 16 * 16
+        s0 = np.minimum(self.offsets[sseg] + sk * per[sseg], self.offsets[sseg + 1])
+        self.nslab = int(slab_ptr[-1])
+        self.slab_off = h2d_async(np.concatenate([s0, self.offsets[-1:]]), self.device)
+        self.seg_slab_ptr = h2d_async(slab_ptr, self.device)
+        self.len_f64 = h2d_async(self.lengths.astype(np.float64), self.device)
+        self.min_len = int(self.lengths.min())
 
     @classmethod
     def of_operator(cls, op: "SparseOperator", group: int = 1, side: str = "cols") -> "PackedSegments":

@@ -243,6 +243,8 @@ class AvgResNet2(_TwoStage):
         if isinstance(mask, PackedSegments):
             # packed batch (1, sum V_i, C): per-mesh means over ragged row ranges, no padding rows anywhere; BatchNorm then
             # sees the real rows only (the reference's padded batch includes the padding rows, utils_pt.py:97-99)
+            if self.training and snB.avg_block_ragged_ok(self, mask, inputs):
+                return snB.avg_block_ragged(self, mask, inputs)                 # half width, one autograd node
             x2d = inputs.reshape(b * n, c)
             h = self.bn_fc0.forward2d(snF.avg_propagate_ragged(x2d, mask))
             h = self.bn_fc1.forward2d(snF.avg_propagate_ragged(h, mask), residual=x2d)

@@ -541,6 +541,45 @@ def linear_dgrad_eluseg(dy, W, x, center, B, Cc, segvec, rows_per_seg, rowmask=N
     return gact
 
 
+def _seg_of_rows(seg):
+    return torch.from_numpy(np.repeat(np.arange(seg.nseg), seg.lengths))
+
+
+def avg_stage_ragged_supported(C, J, seg):
+    return C == 128 and J == 128 and seg.min_len >= 32
+
+
+def wgrad_slabs(dy, x, center, seg):
+    G, sdy = wgrad(dy, x, center, want_colsum=True)
+    out = torch.zeros((seg.nseg, dy.shape[1]), dtype=torch.float64)
+    out.index_add_(0, _seg_of_rows(seg), dy.double())
+    return G, sdy, out.float()
+
+
+def avg_bwd_segvec_ragged(seg_dy, Wf2, m, mu2, B2, C2, seg):
+    lens = torch.from_numpy(seg.lengths.astype(np.float64)).reshape(-1, 1)
+    v = seg_dy.double() @ Wf2.double() + lens * ((m.double() - mu2.double()) * B2.double() + C2.double())
+    return (v * seg.inv_count.double().reshape(-1, 1)).float()
+
+
+def linear_fwd_segbias_ragged(x, W, segbias, seg, residual=None, y_elu=None, want_y=True, elu_stats=None):
+    y = (x.double() @ W.double().t()).float() + segbias[_seg_of_rows(seg)]
+    if residual is not None:
+        y = y + residual
+    if y_elu is not None:
+        elu_into(y, y_elu)
+        _fill_part(elu_stats, y_elu)
+    return y if want_y else None
+
+
+def linear_dgrad_eluseg_ragged(dy, W, x, center, B, Cc, segvec, seg, gadd=None):
+    dx = linear_dgrad(dy, W, x, center, B, Cc)
+    pre = (dx + segvec[_seg_of_rows(seg)]).contiguous()
+    gact = torch.empty_like(pre)
+    elu_bwd(pre, x, gact, False, None, gadd)
+    return gact
+
+
 def install(monkeypatch=None):
     """Patch surfacenetworks_amd.kernels in place (monkeypatch=None: permanent, for spawned worker processes)."""
     from surfacenetworks_amd import kernels

@@ -336,3 +336,44 @@ def test_ragged_segment_kernels(C):
         kernels.bcast_rows_ragged(src, seg.tiles, dst[:, C:])
         ids = np.repeat(np.arange(seg.nseg), seg.lengths)
         assert np.array_equal(dst[:, C:].cpu().numpy(), src.cpu().numpy()[ids]) and torch.isnan(dst[:, :C]).all()
+
+
+@pytest.mark.parametrize("lengths", [[40, 300, 33, 64, 1000], [5041] * 3, [32, 32, 4097]])
+def test_ragged_average_block_at_half_width_matches_the_full_width_composition(lengths, monkeypatch):
+    """AvgResNet2 on a PACKED batch (PackedSegments, ragged meshes): the half-width autograd node (per-mesh bias / vector
+    by mesh offsets in the GEMM epilogues, weight gradient over caller-defined slabs) against the full-width composition
+    ([elu(x) | per-mesh mean] materialised, 2C-wide GEMMs) — outputs, input gradient, parameter gradients, running stats."""
+    import copy
+
+    from surfacenetworks_amd import blocks as snB, utils_pt as utils
+    from surfacenetworks_amd.operators import PackedSegments
+
+    torch.manual_seed(3)
+    seg = PackedSegments(lengths, DEV)
+    blk_a = utils.AvgResNet2(128).to(DEV).train()
+    with torch.no_grad():
+        for p in blk_a.parameters():
+            p.copy_(torch.randn_like(p) * (0.1 if p.dim() > 1 else 0.5) + (1.0 if p.dim() == 1 else 0.0))
+    blk_b = copy.deepcopy(blk_a)
+    x = torch.randn(1, seg.rows, 128, device=DEV)
+    w = torch.randn(1, seg.rows, 128, device=DEV)
+    res = []
+    for blk, half in ((blk_a, True), (blk_b, False)):
+        if not half:
+            monkeypatch.setattr(snB, "avg_block_ragged_ok", lambda *a: False)
+        else:
+            assert snB.avg_block_ragged_ok(blk, seg, x)
+        xi = x.clone().requires_grad_(True)
+        y = blk(None, seg, xi)
+        (y * w).sum().backward()
+        res.append((y.detach(), xi.grad, [p.grad.clone() for p in blk.parameters()],
+                    [b.clone() for b in blk.buffers() if b.dtype.is_floating_point]))
+    (ya, ga, pa, ba), (yb, gb, pb, bb) = res
+
+    def rel(a, b):
+        return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    assert rel(ya, yb) < 2e-5 and rel(ga, gb) < 2e-4, (rel(ya, yb), rel(ga, gb))
+    for a, b in zip(pa, pb):
+        assert rel(a, b) < 5e-4, rel(a, b)
+    for a, b in zip(ba, bb):
+        assert rel(a, b) < 1e-5
