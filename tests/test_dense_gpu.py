@@ -701,3 +701,59 @@ def test_linear_kernels_stay_inside_their_views(rows, K, J):
     wantG = dy.double().t() @ (xs.double() - cen.double())
     assert torch.isfinite(G).all() and float((G.double() - wantG).abs().max()) < 1e-3 * max(1.0, float(wantG.abs().max()))
     assert float((s - dy.double().sum(0)).abs().max()) < 1e-3
+
+
+@pytest.mark.parametrize("lengths", [[32, 700, 45, 33, 2000], [5041, 5041], [40] * 37])
+def test_ragged_mesh_entry_points(lengths):
+    """The per-mesh-vector GEMM epilogues and the slab weight gradient on RAGGED meshes (packed batches) against fp64, and
+    the statuses of their argument checks."""
+    from surfacenetworks_amd import _lib
+    from surfacenetworks_amd._lib import SnError
+    from surfacenetworks_amd.kernels import _p, _ld, _stream
+    from surfacenetworks_amd.operators import PackedSegments
+
+    seg = PackedSegments(lengths, DEV)
+    rows, C, J = seg.rows, 128, 128
+    rng = np.random.default_rng(len(lengths) + rows)
+    mesh = torch.from_numpy(np.repeat(np.arange(seg.nseg), seg.lengths)).to(DEV)
+    x, res, dy, gadd = [dev(rng.standard_normal((rows, C)).astype(np.float32)) for _ in range(4)]
+    W = dev((rng.standard_normal((J, C)) / 11).astype(np.float32))
+    segb = dev(rng.standard_normal((seg.nseg, J)).astype(np.float32))
+    # forward with a per-mesh bias (+ residual, + elu copy with statistics)
+    cat = torch.zeros(rows, 2 * J, device=DEV)
+    part = kernels.new_elu_stats_part(rows, DEV)
+    y = kernels.linear_fwd_segbias_ragged(x, W, segb, seg, res, cat[:, :J], True, part)
+    want = x.double() @ W.double().t() + segb.double()[mesh] + res.double()
+    assert float((y.double() - want).abs().max()) < 2e-4
+    we = torch.where(want > 0, want, torch.expm1(want))
+    assert float((cat[:, :J].double() - we).abs().max()) < 2e-4 and float(cat[:, J:].abs().sum()) == 0
+    st = kernels.colstats_from_part(part, rows)
+    assert torch.allclose(st[0], we.sum(0), rtol=1e-5, atol=1e-3) and torch.allclose(st[1], (we * we).sum(0), rtol=1e-5, atol=1e-3)
+    # input gradient through the activation with a per-mesh vector
+    cen, B, Cc = [dev(rng.standard_normal(C).astype(np.float32)) for _ in range(3)]
+    segv = dev(rng.standard_normal((seg.nseg, C)).astype(np.float32))
+    g = kernels.linear_dgrad_eluseg_ragged(dy, W, x, cen, B, Cc, segv, seg, gadd)
+    pre = dy.double() @ W.double() + (x.double() - cen.double()) * B.double() + Cc.double() + segv.double()[mesh]
+    wantg = pre * torch.where(x.double() > 0, torch.ones_like(pre), x.double() + 1) + gadd.double()
+    assert float((g.double() - wantg).abs().max()) < 5e-4
+    # weight gradient over the segments' slabs: G, colsum(dy), per-mesh colsum(dy)
+    G, sdy, sg = kernels.wgrad_slabs(dy, x, cen, seg)
+    G0, sdy0 = kernels.wgrad(dy, x, cen, want_colsum=True)
+    refG = dy.double().t() @ (x.double() - cen.double())
+    assert float((G.double() - refG).abs().max()) <= 2.0 * float((G0.double() - refG).abs().max()) + 1e-4
+    assert torch.allclose(sdy, dy.double().sum(0), rtol=1e-9, atol=1e-3)
+    wsg = torch.zeros(seg.nseg, J, dtype=torch.float64, device=DEV).index_add_(0, mesh, dy.double())
+    assert float((sg.double() - wsg).abs().max()) < 1e-3
+    # argument checks
+    lib = _lib.load()
+    assert lib.sn_linear_fwd_segbias_ragged_f32(_p(x), _ld(x), _p(W), _ld(W), _p(segb), None, seg.nseg, None, 0, _p(y), J, None, 0,
+                                                rows, C, J, None, _stream()) == -1          # SN_E_NULL: no offsets
+    assert lib.sn_linear_fwd_segbias_ragged_f32(_p(x), _ld(x), _p(W), _ld(W), _p(segb), _p(seg.off_dev), 0, None, 0, _p(y), J, None,
+                                                0, rows, C, J, None, _stream()) == -2        # SN_E_SHAPE: no meshes
+    assert lib.sn_linear_dgrad_eluseg_ragged_f32(_p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x), _p(cen), _p(B), _p(Cc), None,
+                                                 _p(seg.off_dev), seg.nseg, _p(g), C, None, 0, rows, J, C, _stream()) == -2
+    ws = torch.empty(16, dtype=torch.uint8, device=DEV)
+    assert lib.sn_wgrad_slabs_f32(_p(dy), _ld(dy), _p(x), _ld(x), _p(cen), rows, _p(seg.slab_off), seg.nslab, _p(seg.seg_slab_ptr),
+                                  seg.nseg, J, C, _p(G), _p(sdy), _p(sg), _p(ws), 16, _stream()) == -6   # SN_E_WORKSPACE
+    assert lib.sn_wgrad_slabs_f32(_p(dy), _ld(dy), _p(x), _ld(x), _p(cen), rows, None, seg.nslab, _p(seg.seg_slab_ptr),
+                                  seg.nseg, J, C, _p(G), _p(sdy), _p(sg), _p(ws), 16, _stream()) == -1   # SN_E_NULL
