@@ -289,7 +289,7 @@ class ClothSequences:
                 raise ValueError("packed batches need pooled operators")
             keep = mask.reshape(B, nv) > 0                                             # real rows, mesh-major order
             inputs, targets = inputs[keep].unsqueeze(0), targets[keep].unsqueeze(0)
-            seg = PackedSegments(self.num_vertices[seq_ids], self.device)
+            seg = PackedSegments.cached(self.num_vertices[seq_ids], self.device)
             if self.kind == "dir":
                 Di, DiA = self.pool_Di.assemble(op_ids), self.pool_DiA.assemble(op_ids)
             else:

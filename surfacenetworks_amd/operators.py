@@ -402,6 +402,20 @@ class PackedSegments:
         self.len_f64 = h2d_async(self.lengths.astype(np.float64), self.device)
         self.min_len = int(self.lengths.min())
 
+    _recent = {}
+
+    @classmethod
+    def cached(cls, lengths, device="cuda") -> "PackedSegments":
+        """The segments of `lengths`, re-used when the same sizes come back (a sampler that draws the same meshes every step
+        would otherwise upload the eight small tables again per step); holds the last 16 distinct size lists."""
+        key = (tuple(int(v) for v in lengths), str(torch.device(device)))
+        hit = cls._recent.get(key)
+        if hit is None:
+            if len(cls._recent) >= 16:
+                cls._recent.pop(next(iter(cls._recent)))
+            hit = cls._recent[key] = cls(lengths, device)
+        return hit
+
     @classmethod
     def of_operator(cls, op: "SparseOperator", group: int = 1, side: str = "cols") -> "PackedSegments":
         """Row ranges of the dense operand of a packed operator: its column blocks (`side="cols"`, the input side) or its
