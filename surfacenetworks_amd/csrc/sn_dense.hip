@@ -43,6 +43,9 @@ __device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
 #ifndef SN_X_WGU_NOLOAD
 #define SN_X_WGU_NOLOAD 0
 #endif
+#ifndef SN_X_WGU_NT
+#define SN_X_WGU_NT 0
+#endif
 #ifndef SN_X_WGU_PERM
 #define SN_X_WGU_PERM 0
 #endif
@@ -564,7 +567,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
 // Measured (same box each, µs per launch at C = 256 / 128, in the training step): wgrad_x3_k 190 / 108, this kernel 179 / 81.
 // Structures tried on the way: conversion in three lumps between groups of four MFMAs 179 / 81; conversion and MFMAs in
 // separate halves of the block 222 / 100, ping-ponged between the two waves of a SIMD 209 / 95; a second register set
-// (requests two blocks ahead): no change; two fp16 pieces with online per-column power-of-two scales (three products instead
+// (requests two blocks ahead): no change; non-temporal loads (SN_X_WGU_NT=1): within the run-to-run spread; two fp16 pieces with online per-column power-of-two scales (three products instead
 // of six, exact, more accurate against fp64 than this kernel — commit 60f60e6): 186 / 95, i.e. halving the matrix work buys
 // nothing.  Ablations at 322 624 rows, C = 256 (tools/scratch/wgrad_ab.sh, builds with SN_X_WGU_*): memory path alone (no
 // conversion, no MFMA) 101-107 µs, everything but the global loads 93 µs, loads + MFMAs 134-158 µs, all of it 157-175 µs:
@@ -709,7 +712,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
 #if SN_X_WGU_NOLOAD
     if (s_rg[k] >= 0) return;
 #endif
-    raw[set][k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rs[k], l_voff[k] + j * rstep, 0, 0));
+    raw[set][k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rs[k], l_voff[k] + j * rstep, 0, SN_X_WGU_NT ? 2 : 0));
   };
   // The other work of a block, dealt out behind its MFMAs (m = 0 .. NM-1) — the two co-resident waves of a SIMD run this
   // same stream and a wave is in-order, so what overlaps the matrix pipe, the vector ALU and the memory pipe is the mix
