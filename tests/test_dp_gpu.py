@@ -80,6 +80,58 @@ def _worker(rank, world, port, q, mode):
     dist.destroy_process_group()
 
 
+def _graph_worker(rank, world, port, q):
+    """Two ranks, each replaying its captured step (stored gradients) and reducing through FlatGradBucket.sync, against the
+    same two ranks' eager steps: identical parameters after two updates, identical across ranks."""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import copy
+
+    from helpers import deterministic_init
+    from surfacenetworks_amd import arap, dp
+
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    _, _, _, dev = dp.init_distributed(backend)
+    ds = arap.ClothSequences([(8, 8)] * 4, frames=48, op_frames=4, seed=5, device=dev, model="dir")
+    G = 4
+    mine = dp.shard_round_robin(G, rank, world)
+    model_e = deterministic_init(arap.DirModel(), 3).to(dev).train()
+    model_g = copy.deepcopy(model_e)
+    opt_e, opt_g = arap.make_optimizer(model_e), arap.make_optimizer(model_g)
+    bucket_e, bucket_g = dp.FlatGradBucket(model_e.parameters()), dp.FlatGradBucket(model_g.parameters())
+    example = ds.sample_batch(len(mine), None, seq_ids=mine, offsets=np.zeros(len(mine), dtype=np.int64))
+    graphed = arap.GraphedTrainStep(model_g, opt_g, example, global_batch=G, bucket=bucket_g)
+    for step in range(2):
+        off = np.full(len(mine), step + 1, dtype=np.int64)
+        be = ds.sample_batch(len(mine), None, seq_ids=mine, offsets=off)
+        bg = ds.sample_batch(len(mine), None, seq_ids=mine, offsets=off)
+        arap.train_step(model_e, opt_e, be, global_batch=G, grad_sync=bucket_e.sync, zero_grads=bucket_e.detach_grads)
+        graphed(bg, grad_sync=bucket_g.sync)
+    pe = torch.cat([p.detach().reshape(-1) for p in model_e.parameters()])
+    pg = torch.cat([p.detach().reshape(-1) for p in model_g.parameters()])
+    other = pg.clone()
+    dist.broadcast(other, 0)
+    q.put((rank, bool(torch.equal(pe, pg)), bool(torch.equal(other, pg)), float((pe - pg).abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_replaying_their_graphs_match_the_eager_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    for rank, same_as_eager, same_across_ranks, diff in sorted(q.get(timeout=10) for _ in range(2)):
+        assert same_as_eager and same_across_ranks, (rank, diff)
+
+
 @pytest.mark.parametrize("mode", ["frozen", "syncbn"])
 def test_two_ranks_on_gpu_reproduce_full_batch(mode):
     ctx = mp.get_context("spawn")
