@@ -385,6 +385,14 @@ int sn_masked_smooth_l1_bwd_f32(const float *out, int64_t ldo, const float *targ
  * i < nitems, r < rows_per_item, c < len; base is a DEVICE array of element offsets into the resident dataset. */
 int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems, int64_t rows_per_item, int64_t row_stride,
                            int32_t len, float *out, void *stream);
+/* sn_pair_argmin_f32: target of the dense-correspondence loss (src/dense_correspondence/main.py:236-237,
+ * `_, GAB = torch.min(GA[:, liA[lB]] + GB[liB[lA], :], dim=1)`):  out[r] = argmin_j ( GA[r*ldA + pa[j]] + GB[pb[r]*ldB + j] ),
+ * r < NA, j < NB, with pa = liA[lB] (NB entries) and pb = liB[lA] (NA entries) as DEVICE int64 arrays; the two gathered
+ * NA x NB matrices are never materialised.  fp32 sum as in the reference; ties go to the lowest j, a NaN wins (torch.min).
+ * GA has colsA valid columns per row (rows up to 64 KB are staged in LDS, wider ones gathered from global memory); the
+ * caller guarantees 0 <= pa[j] < colsA and that pb[r] indexes a row of GB. */
+int sn_pair_argmin_f32(const float *GA, int64_t ldA, int64_t colsA, const int64_t *pa, const float *GB, int64_t ldB,
+                       const int64_t *pb, int64_t NA, int64_t NB, int64_t *out, void *stream);
 /* sn_linear_thin_fwd_f32: forward of that first layer, y = x·W^T + bias (x: rows x C, C <= 8; W: J x C), and optionally
  * elu(y) into y_elu (the first half of the next block's concat buffer; replaces the F.elu of utils_pt.py:161,195).  y or
  * y_elu may be NULL (not both).  Ascending-k fp32 FMA chain on top of the bias. */

@@ -808,29 +808,31 @@ __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ 
   const int o = threadIdx.x & 63, g = threadIdx.x >> 6;
   const int nG = J * C;
   const int i = blockIdx.x * 64 + o;            // output element j*C + c  (partials are laid out [slab][128][C]);
-  double t = 0;                                 // elements past J*C are the J column sums of dy ([slab][128])
-  if (i >= nG + J && segsum && g == 0 && i < nG + J + (seg_slab_ptr ? nseg : nslab / spm) * J) {
-    // past G and colsum(dy): the per-mesh column sums of dy — the mesh's consecutive slabs (spm each, or from the table)
+  double t = 0;                                 // elements past J*C are the J column sums of dy ([slab][128]), and past
+  const float *src = nullptr;                   // those the per-mesh column sums of dy — the mesh's consecutive slabs
+  int64_t stride = 128;                         // (spm each, or from the table)
+  int cnt = 0;
+  if (i < nG) {
+    src = partial + i, stride = (int64_t)128 * C, cnt = nslab;
+  } else if (colpart && i < nG + J) {
+    src = colpart + (i - nG), cnt = nslab;
+  } else if (segsum && i >= nG + J && i < nG + J + (seg_slab_ptr ? nseg : nslab / spm) * J) {
     const int k = i - nG - J, mesh = k / J, j = k - mesh * J;
     const int64_t p0 = seg_slab_ptr ? seg_slab_ptr[mesh] : (int64_t)mesh * spm;
     const int64_t p1 = seg_slab_ptr ? seg_slab_ptr[mesh + 1] : p0 + spm;
-    double t2 = 0;
-    for (int64_t p_ = p0; p_ < p1; ++p_) t2 += (double)colpart[p_ * 128 + j];
-    segsum[k] = (float)t2;
+    src = colpart + p0 * 128 + j, cnt = (int)(p1 - p0);
   }
-  if (i < nG || (colpart && i < nG + J)) {
-    // eight loads in flight, added in slab order
-    const float *src = i < nG ? partial + i : colpart + (i - nG);
-    const int64_t stride = i < nG ? (int64_t)128 * C : 128;
+  if (src) {
+    // the four waves take every fourth slab, eight loads in flight each
     int sl = g;
-    for (; sl + 28 < nslab; sl += 32) {
+    for (; sl + 28 < cnt; sl += 32) {
       float v[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) v[u] = src[(int64_t)(sl + 4 * u) * stride];
 #pragma unroll
       for (int u = 0; u < 8; ++u) t += (double)v[u];
     }
-    for (; sl < nslab; sl += 4) t += (double)src[(int64_t)sl * stride];
+    for (; sl < cnt; sl += 4) t += (double)src[(int64_t)sl * stride];
   }
   sm[g][o] = t;
   __syncthreads();
@@ -838,6 +840,7 @@ __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ 
     const double r = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
     if (i < nG) G[i] = (float)r;
     else if (colpart && i < nG + J) dysum[i - nG] = r;
+    else if (src) segsum[i - nG - J] = (float)r;
   }
 }
 
@@ -1526,6 +1529,115 @@ inline int wgrad_variant() {
   return v;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Target of the dense-correspondence loss:  t[r] = argmin_j ( GA[r][pa[j]] + GB[pb[r]][j] )  — the torch.min over the
+// sum of two gathered (NA x NB) geodesic matrices of src/dense_correspondence/main.py:236-237, without materialising
+// them (3 x 190 MB at 6890 vertices).  A workgroup takes kArgRows rows of the result: pa[j] is read once for the four,
+// row pb[r] of GB streams, row r of GA (27 KB) is gathered through L1/L2.  Ties go to the lowest j and a NaN wins, as
+// in torch.min.
+// ------------------------------------------------------------------------------------------------
+constexpr int kArgRows = 4;
+__device__ inline bool arg_better(float av, int aj, float bv, int bj) {
+  const bool an = av != av, bn = bv != bv;
+  if (an != bn) return an;
+  if (!an && av != bv) return av < bv;
+  return aj < bj;
+}
+__global__ __launch_bounds__(kWG) void pair_argmin_k(const float *__restrict__ GA, int64_t ldA, const int64_t *__restrict__ pa,
+                                                     const float *__restrict__ GB, int64_t ldB, const int64_t *__restrict__ pb,
+                                                     int NA, int NB, int64_t *__restrict__ out) {
+  __shared__ float sv[kArgRows][kWG / 64];
+  __shared__ int sj[kArgRows][kWG / 64];
+  const int r0 = blockIdx.x * kArgRows;
+  const float *ga[kArgRows], *gb[kArgRows];
+#pragma unroll
+  for (int q = 0; q < kArgRows; ++q) {
+    const int r = r0 + q < NA ? r0 + q : NA - 1;
+    ga[q] = GA + (int64_t)r * ldA;
+    gb[q] = GB + pb[r] * ldB;
+  }
+  float bv[kArgRows];
+  int bj[kArgRows];
+#pragma unroll
+  for (int q = 0; q < kArgRows; ++q) bv[q] = __builtin_inff(), bj[q] = INT_MAX;
+#pragma unroll 2
+  for (int j = threadIdx.x; j < NB; j += kWG) {
+    const int64_t pj = pa[j];
+#pragma unroll
+    for (int q = 0; q < kArgRows; ++q) {
+      const float v = ga[q][pj] + gb[q][j];
+      if (arg_better(v, j, bv[q], bj[q])) bv[q] = v, bj[q] = j;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < kArgRows; ++q) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+      const float ov = __shfl_xor(bv[q], d);
+      const int oj = __shfl_xor(bj[q], d);
+      if (arg_better(ov, oj, bv[q], bj[q])) bv[q] = ov, bj[q] = oj;
+    }
+    if ((threadIdx.x & 63) == 0) sv[q][threadIdx.x >> 6] = bv[q], sj[q][threadIdx.x >> 6] = bj[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < kArgRows && r0 + (int)threadIdx.x < NA) {
+    const int q = threadIdx.x;
+    float v = sv[q][0];
+    int j = sj[q][0];
+    for (int w = 1; w < kWG / 64; ++w)
+      if (arg_better(sv[q][w], sj[q][w], v, j)) v = sv[q][w], j = sj[q][w];
+    out[r0 + q] = j;
+  }
+}
+
+// The same with row r of GA staged in LDS (one coalesced pass) and gathered from there: a gather straight from global
+// memory moves a whole cache line per 4-byte element once the rows of a CU's workgroups have pushed each other out of L1
+// (measured: 550 us for 6890 x 6890, against ~75 us of HBM time for the two matrices).  One row per workgroup, 27 KB of LDS
+// at 6890 columns: five workgroups per CU overlap each other's staging and gathering.
+constexpr size_t kArgLdsMax = 64 * 1024 - 16;      // the default dynamic-LDS limit of a launch
+__global__ __launch_bounds__(kWG) void pair_argmin_lds_k(const float *__restrict__ GA, int64_t ldA, int colsA,
+                                                         const int64_t *__restrict__ pa, const float *__restrict__ GB, int64_t ldB,
+                                                         const int64_t *__restrict__ pb, int NB, int64_t *__restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float rowA[];
+  __shared__ float sv[kWG / 64];
+  __shared__ int sj[kWG / 64];
+  const int r = blockIdx.x;
+  const float *ga = GA + (int64_t)r * ldA;
+  const float *gb = GB + pb[r] * ldB;
+  // quads aligned in global memory; the LDS image is shifted by the row's misalignment so that both sides are 16-byte aligned
+  const int sh = (int)((reinterpret_cast<uintptr_t>(ga) >> 2) & 3);
+  for (int c = 4 * (int)threadIdx.x - sh; c < colsA; c += 4 * kWG) {
+    if (c >= 0 && c + 3 < colsA) {
+      *reinterpret_cast<f4 *>(rowA + sh + c) = *reinterpret_cast<const f4 *>(ga + c);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c + e >= 0 && c + e < colsA) rowA[sh + c + e] = ga[c + e];
+    }
+  }
+  __syncthreads();
+  float bv = __builtin_inff();
+  int bj = INT_MAX;
+#pragma unroll 4
+  for (int j = threadIdx.x; j < NB; j += kWG) {
+    const float v = rowA[sh + pa[j]] + gb[j];
+    if (arg_better(v, j, bv, bj)) bv = v, bj = j;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const float ov = __shfl_xor(bv, d);
+    const int oj = __shfl_xor(bj, d);
+    if (arg_better(ov, oj, bv, bj)) bv = ov, bj = oj;
+  }
+  if ((threadIdx.x & 63) == 0) sv[threadIdx.x >> 6] = bv, sj[threadIdx.x >> 6] = bj;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < kWG / 64; ++w)
+      if (arg_better(sv[w], sj[w], bv, bj)) bv = sv[w], bj = sj[w];
+    out[r] = bj;
+  }
+}
+
 inline int wgrad_slabs(int64_t rows) {
   int64_t b = (rows + 255) / 256;          // at least 256 rows per slab
   const int64_t cap = 2 * kCUs;            // two 4-wave workgroups per CU (2 waves/SIMD), one round
@@ -2005,6 +2117,25 @@ int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems
   else
     hipLaunchKernelGGL((gather_segments_k<1>), dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, base,
                        rows_per_item, row_stride, (int)len, total, out);
+  return launch_status();
+}
+
+int sn_pair_argmin_f32(const float *GA, int64_t ldA, int64_t colsA, const int64_t *pa, const float *GB, int64_t ldB,
+                       const int64_t *pb, int64_t NA, int64_t NB, int64_t *out, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (NA < 0 || NB < 1 || colsA < 1 || ldA < colsA || ldB < NB) return SN_E_SHAPE;
+  if (NA > INT_MAX - kArgRows || NB > INT_MAX || colsA > INT_MAX) return SN_E_RANGE;
+  if (NA == 0) return SN_OK;
+  if (!GA || !pa || !GB || !pb || !out) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t lds = (size_t)colsA * sizeof(float);
+  if (lds <= kArgLdsMax) {
+    hipLaunchKernelGGL(pair_argmin_lds_k, dim3((unsigned)NA), dim3(kWG), lds + 16, s, GA, ldA, (int)colsA, pa, GB, ldB, pb, (int)NB,
+                       out);
+  } else {
+    hipLaunchKernelGGL(pair_argmin_k, dim3((unsigned)((NA + kArgRows - 1) / kArgRows)), dim3(kWG), 0, s, GA, ldA, pa, GB, ldB, pb,
+                       (int)NA, (int)NB, out);
+  }
   return launch_status();
 }
 

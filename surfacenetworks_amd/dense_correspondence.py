@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import mesh_ops
+from . import kernels, mesh_ops
 from . import utils_pt as utils
 from .arap import make_adam
 from .operators import OperatorPool, SparseOperator
@@ -152,6 +152,12 @@ class SiameseModel(nn.Module):
         return torch.bmm(FA, FB.transpose(1, 2))
 
 
+def correspondence_target(GA, lA, liA, GB, lB, liB):
+    """main.py:236-237: `_, GAB = torch.min(GA[:, liA[lB]] + GB[liB[lA], :], dim=1)` in one kernel that reads each matrix
+    once and keeps neither gathered copy nor their sum (sn_pair_argmin_f32)."""
+    return kernels.pair_argmin(GA, liA[lB], GB, liB[lA])
+
+
 def loss_fun_delta_cross_entropy(outputs, targetX, targetY):
     """main.py:229-240, including its quirk of always scoring outputs[0] (the reference runs batch 1, main.py:40)."""
     loss = outputs.new_zeros(1)
@@ -159,7 +165,7 @@ def loss_fun_delta_cross_entropy(outputs, targetX, targetY):
         GA, lA, liA = targetX[i]
         GB, lB, liB = targetY[i]
         NA, NB = lA.size(0), lB.size(0)
-        _, GAB = torch.min(GA[:, liA[lB]] + GB[liB[lA], :], dim=1)
+        GAB = correspondence_target(GA, lA, liA, GB, lB, liB)
         loss = loss + F.cross_entropy(outputs[0, :NA, :NB], GAB)
     return loss / outputs.size(0)
 
@@ -209,10 +215,7 @@ def streamed_delta_cross_entropy(FA, FB, targetX, targetY, block=1024):
         GA, lA, liA = targetX[i]
         GB, lB, liB = targetY[i]
         NA, NB = lA.size(0), lB.size(0)
-        tgt = torch.empty(NA, dtype=torch.int64, device=FA.device)
-        for r0 in range(0, NA, block):                                  # argmin of GA[:, liA[lB]] + GB[liB[lA], :] by row blocks
-            rows = slice(r0, min(r0 + block, NA))
-            tgt[rows] = torch.argmin(GA[rows][:, liA[lB]] + GB[liB[lA[rows]], :], dim=1)
+        tgt = correspondence_target(GA, lA, liA, GB, lB, liB)
         loss = loss + _StreamedCorrespondenceCE.apply(FA[0, :NA], FB[0, :NB], tgt, block)
     return loss / B
 

@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
 ]
 
 
@@ -809,6 +809,24 @@ def gather_segments(src, base, rows_per_item: int, row_stride: int, length: int)
     n = base.numel()
     out = torch.empty((n, rows_per_item, length), dtype=torch.float32, device=src.device)
     _lib.call("sn_gather_segments_f32", _p(src), _p(base.contiguous()), n, rows_per_item, row_stride, length, _p(out), _stream())
+    return out
+
+
+def pair_argmin(GA, pa, GB, pb):
+    """argmin_j (GA[r, pa[j]] + GB[pb[r], j]) for every r (sn_pair_argmin_f32): the target of the dense-correspondence
+    loss, main.py:236-237, without the two gathered (NA, NB) matrices.  GA, GB: row-major fp32 matrices; pa (NB,), pb (NA,)
+    int64.  Returns (NA,) int64."""
+    _dev(GA, pa, GB, pb)
+    if GA.dtype != torch.float32 or GB.dtype != torch.float32 or pa.dtype != torch.int64 or pb.dtype != torch.int64:
+        raise TypeError("pair_argmin: float32 matrices and int64 index vectors expected")
+    if GA.dim() != 2 or GB.dim() != 2 or GA.stride(1) != 1 or GB.stride(1) != 1:
+        raise ValueError("pair_argmin: row-major 2-D matrices expected")
+    NA, NB = pb.numel(), pa.numel()
+    if NA > GA.shape[0] or NB > GB.shape[1]:
+        raise ValueError("pair_argmin: more rows / columns asked for than the matrices hold")
+    out = torch.empty(NA, dtype=torch.int64, device=GA.device)
+    _lib.call("sn_pair_argmin_f32", _p(GA), GA.stride(0), GA.shape[1], _p(pa.contiguous()), _p(GB), GB.stride(0), _p(pb.contiguous()), NA, NB,
+              _p(out), _stream())
     return out
 
 

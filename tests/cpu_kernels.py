@@ -508,6 +508,10 @@ def gather_segments(src, base, rows_per_item, row_stride, length):
     return flat[idx]
 
 
+def pair_argmin(GA, pa, GB, pb):
+    return torch.argmin(GA[:pb.numel()][:, pa] + GB[pb][:, :pa.numel()], dim=1)
+
+
 def masked_smooth_l1_fwd(out2d, target2d, rowmask, scale):
     d = out2d.double() * (1.0 if rowmask is None else rowmask.double().reshape(-1, 1)) - target2d.double()
     a = d.abs()

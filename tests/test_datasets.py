@@ -69,7 +69,7 @@ def test_reference_format_files_feed_training(golden_dir, cpu_kernels):
     pc.check_dataset_files(golden_dir, "cpu")
 
 
-def test_streamed_faust_loss_equals_materialised():
+def test_streamed_faust_loss_equals_materialised(cpu_kernels):
     """Streamed CE over row blocks == loss_fun_delta_cross_entropy on bmm(FA, FB^T): value and both gradients."""
     from surfacenetworks_amd import dense_correspondence as dc
 

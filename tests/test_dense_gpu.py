@@ -757,3 +757,42 @@ def test_ragged_mesh_entry_points(lengths):
                                   seg.nseg, J, C, _p(G), _p(sdy), _p(sg), _p(ws), 16, _stream()) == -6   # SN_E_WORKSPACE
     assert lib.sn_wgrad_slabs_f32(_p(dy), _ld(dy), _p(x), _ld(x), _p(cen), rows, None, seg.nslab, _p(seg.seg_slab_ptr),
                                   seg.nseg, J, C, _p(G), _p(sdy), _p(sg), _p(ws), 16, _stream()) == -1   # SN_E_NULL
+
+
+# ---- target of the dense-correspondence loss (dense_correspondence/main.py:236-237) ---------------------------------------
+@pytest.mark.parametrize("NA,NB,kind", [(1, 1, "real"), (5, 9, "real"), (333, 257, "real"), (1030, 700, "ties"), (64, 513, "nan"),
+                                        (6890, 6890, "real"), (40, 17000, "real")])
+def test_pair_argmin_is_the_reference_min_over_the_two_gathered_matrices(NA, NB, kind):
+    """Bit-exact index parity with numpy's argmin of the fp32 sum the reference forms, on views with a leading dimension
+    larger than the row, tie-heavy integer matrices (lowest index wins) and rows holding a NaN (which wins, as in torch.min)."""
+    rng = np.random.default_rng(NA * 7 + NB)
+    ldA, ldB = NA + NB + 3, NB + 5                      # GA has at least max(pa)+1 columns, GB exactly >= NB
+    if kind == "ties":
+        GA = rng.integers(0, 3, (NA, ldA)).astype(np.float32)
+        GB = rng.integers(0, 3, (NA + 2, ldB)).astype(np.float32)
+    else:
+        GA = rng.random((NA, ldA), dtype=np.float32)
+        GB = rng.random((NA + 2, ldB), dtype=np.float32)
+    if kind == "nan":
+        GB[rng.integers(0, NA + 2, 20), rng.integers(0, NB, 20)] = np.nan
+    pa = rng.integers(0, ldA, NB)
+    pb = rng.permutation(NA + 2)[:NA]
+    total = GA[:, pa] + GB[pb][:, :NB]                   # fp32 + fp32, as the reference adds them
+    want = np.argmin(total, axis=1)                      # numpy: first minimum; NaN wins
+    got = kernels.pair_argmin(dev(GA), dev(pa), dev(GB)[:, :NB], dev(pb))
+    assert got.dtype == torch.int64 and np.array_equal(got.cpu().numpy(), want)
+    if kind != "nan":                                    # and torch.min itself on the device, where it has no NaN to order
+        tm = torch.min(dev(GA)[:, dev(pa)] + dev(GB)[dev(pb)][:, :NB], dim=1)[0].cpu().numpy()
+        assert np.array_equal(total[np.arange(NA), want], tm)
+
+
+def test_pair_argmin_rejects_what_it_cannot_index():
+    G = torch.zeros(4, 4, device=DEV)
+    i = torch.arange(4, device=DEV)
+    with pytest.raises(TypeError):
+        kernels.pair_argmin(G.double(), i, G, i)
+    with pytest.raises(ValueError):
+        kernels.pair_argmin(torch.zeros(4, 8, device=DEV)[:, ::2], i, G, i)
+    with pytest.raises(ValueError):
+        kernels.pair_argmin(G, torch.arange(5, device=DEV), G, i)
+    assert kernels.pair_argmin(G, i, G, i[:0]).numel() == 0
