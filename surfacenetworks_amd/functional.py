@@ -444,6 +444,22 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     return y, (x, W, Wf, s, mean, invstd, beta, training, b is not None, rows_g)
 
 
+def _centered_wgrad(dy, x, mean):
+    """G = dyᵀ·(x - mean) and colsum(dy) (fp64 statistics layout of kernels.wgrad).  Widths the split-K kernel takes go to it
+    directly.  A 64-wide x (the classifier head of the Mesh-MNIST models, mesh_mnist/models.py: bn_conv2) is read as rows/2
+    rows of 128 — two consecutive rows side by side, dy likewise — so the same kernel applies: the product of the paired
+    matrices holds G of the even rows in its upper-left block and G of the odd rows in its lower-right one (the cross blocks
+    are discarded).  A library GEMM has no tile for a 64 x 64 output with K = 8e4 (217 us at 77 k rows against ~25 us)."""
+    rows, C = x.shape
+    J = dy.shape[1]
+    if kernels.wgrad_supported(J, C):
+        return kernels.wgrad(dy, x, mean, want_colsum=True)       # colsum(dy) rides on the same pass over dy
+    if C == 64 and rows % 2 == 0 and rows > 0 and x.is_contiguous() and dy.is_contiguous() and kernels.wgrad_supported(2 * J, 2 * C):
+        G2, s2 = kernels.wgrad(dy.view(rows // 2, 2 * J), x.view(rows // 2, 2 * C), torch.cat([mean, mean]), want_colsum=True)
+        return G2[:J, :C] + G2[J:, C:], s2[:J] + s2[J:]
+    return dy.t().mm(x - mean), kernels.colstats(dy)
+
+
 def bnlin_backward(state, dy, need_dx=True, through_elu=None):
     """Backward of bnlin_forward: G = dyᵀ·(x - mean) (split-K MFMA kernel) and colsum(dy) give every BatchNorm
     reduction algebraically (sum_r dz = colsum(dy)·W, sum_r dz∘(x-mean) = sum_j W∘G); dx = dy·(W·diag(s)) + (x-mean)∘B + C
@@ -457,10 +473,7 @@ def bnlin_backward(state, dy, need_dx=True, through_elu=None):
     rows, C = x.shape
     J = dy.shape[1]
     # centring inside the kernel leaves no fp32 cancellation against mean·colsum(dy)
-    if kernels.wgrad_supported(J, C):
-        Gc, sdy = kernels.wgrad(dy, x, mean, want_colsum=True)      # colsum(dy) rides on the same pass over dy
-    else:
-        Gc, sdy = dy.t().mm(x - mean), kernels.colstats(dy)
+    Gc, sdy = _centered_wgrad(dy, x, mean)
     scale = 1.0
     if training:
         Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
@@ -543,10 +556,7 @@ def bnlin_backward_elu_input(state, dy):
     x, W, Wf, s, mean, invstd, beta, training, has_bias, rows_g = state
     dy = dy.contiguous()
     J, C = dy.shape[1], x.shape[1]
-    if kernels.wgrad_supported(J, C):
-        Gc, sdy = kernels.wgrad(dy, x, mean, want_colsum=True)
-    else:
-        Gc, sdy = dy.t().mm(x - mean), kernels.colstats(dy)
+    Gc, sdy = _centered_wgrad(dy, x, mean)
     scale = 1.0
     if training:
         Gc, sdy, scale = _sync_grad_stats(Gc, sdy)

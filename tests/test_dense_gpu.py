@@ -796,3 +796,19 @@ def test_pair_argmin_rejects_what_it_cannot_index():
     with pytest.raises(ValueError):
         kernels.pair_argmin(G, torch.arange(5, device=DEV), G, i)
     assert kernels.pair_argmin(G, i, G, i[:0]).numel() == 0
+
+
+@pytest.mark.parametrize("rows,J", [(2, 64), (1000, 64), (77312, 64), (5000, 32), (999, 64)])
+def test_weight_gradient_of_a_64_wide_layer_through_the_paired_rows(rows, J):
+    """functional._centered_wgrad at C = 64 (classifier head of the Mesh-MNIST models): two consecutive rows side by side
+    feed the 128-wide split-K kernel; odd row counts take the library path.  Both against fp64."""
+    rng = np.random.default_rng(rows + J)
+    x = (rng.standard_normal((rows, 64)) + 3.0).astype(np.float32)
+    dy = rng.standard_normal((rows, J)).astype(np.float32)
+    mean = x.mean(0).astype(np.float32)
+    G, sdy = snF._centered_wgrad(dev(dy), dev(x), dev(mean))
+    want = dy.astype(np.float64).T @ (x.astype(np.float64) - mean.astype(np.float64))
+    assert G.shape == (J, 64) and rel_err(G.cpu().numpy(), want) < 2e-6
+    s = sdy.cpu().numpy().reshape(-1, J)[0]
+    # fp32 partial sums inside a slab, fp64 across slabs
+    assert np.allclose(s, dy.astype(np.float64).sum(0), rtol=0, atol=1e-6 * np.abs(dy).sum(0).max())
