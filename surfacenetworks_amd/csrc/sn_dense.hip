@@ -1639,8 +1639,15 @@ __global__ __launch_bounds__(kWG) void pair_argmin_lds_k(const float *__restrict
 }
 
 inline int wgrad_slabs(int64_t rows) {
-  int64_t b = (rows + 255) / 256;          // at least 256 rows per slab
-  const int64_t cap = 2 * kCUs;            // two 4-wave workgroups per CU (2 waves/SIMD), one round
+  // Small products: at least two 32-row blocks per slab until every CU has one (a 7000-row mesh on 27 slabs of 256 rows kept
+  // 27 CUs busy for 24 us; on 110 slabs the same product takes 13).  Beyond one slab per CU a slab has at least 256 rows
+  // (each slab costs a 128 x C tile of partials written and read again), up to two 4-wave workgroups per CU in one round.
+  int64_t b = (rows + 63) / 64;
+  if (b > kCUs) {
+    b = (rows + 255) / 256;
+    if (b < kCUs) b = kCUs;
+  }
+  const int64_t cap = 2 * kCUs;
   if (b > cap) b = cap;
   if (b < 1) b = 1;
   return (int)b;
