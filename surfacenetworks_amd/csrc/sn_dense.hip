@@ -1409,6 +1409,8 @@ __global__ __launch_bounds__(kWG) void segstats_k(const float *__restrict__ x, i
 // 256 threads = 8 columns x 32 mesh lanes, C/8 workgroups: the 3 MB of partials are pulled by 16 CUs instead of 4 and a
 // thread handles 2 instead of 8 meshes in sequence (48 loads in flight each) — this tiny kernel is bound by both.
 constexpr int kSegFinalLanes = 32, kSegFinalCols = 8;
+constexpr int kSegFewMeshes = 4, kSegSlabsFew = 128;      // few meshes: more slabs each, so that stage 1 still fills the chip
+inline int seg_slabs(int64_t nseg) { return nseg <= kSegFewMeshes ? kSegSlabsFew : kSegSlabs; }
 __global__ __launch_bounds__(kSegFinalCols * kSegFinalLanes) void segstats_final_k(const double *__restrict__ partial, int nslab,
                                                                                    int nseg, int C,
                                                                                    const float *__restrict__ inv_count,
@@ -1418,7 +1420,35 @@ __global__ __launch_bounds__(kSegFinalCols * kSegFinalLanes) void segstats_final
   const int cl = threadIdx.x % kSegFinalCols, gg = threadIdx.x / kSegFinalCols;
   const int c = blockIdx.x * kSegFinalCols + cl;
   double U = 0, Q = 0, S1 = 0, S2 = 0;
-  if (c < C)
+  if (nseg <= kSegFewMeshes) {
+    // a handful of meshes (a FAUST pair is two launches of one): the 32 lanes of a column split a mesh's slabs instead of
+    // the meshes; the mesh's totals are combined by lane 0, which then carries U, Q, S1, S2 alone
+    for (int g = 0; g < nseg; ++g) {
+      double ms = 0, u = 0, q = 0;
+      if (c < C) {
+        const double *p = partial + (int64_t)g * nslab * 3 * C + c;
+        for (int sl = gg; sl < nslab; sl += kSegFinalLanes) {
+          ms += p[(int64_t)sl * 3 * C];
+          u += p[(int64_t)sl * 3 * C + C];
+          q += p[(int64_t)sl * 3 * C + 2 * C];
+        }
+      }
+      sm[0][gg][cl] = ms; sm[1][gg][cl] = u; sm[2][gg][cl] = q;
+      __syncthreads();
+      if (gg == 0 && c < C) {
+        double t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+        for (int l = 0; l < kSegFinalLanes; ++l) t0 += sm[0][l][cl], t1 += sm[1][l][cl], t2 += sm[2][l][cl];
+        const float mv = (float)t0 * inv_count[g];
+        m[(int64_t)g * C + c] = mv;
+        U += t1;
+        Q += t2;
+        S1 += (double)mv;
+        S2 += (double)mv * (double)mv;
+      }
+      __syncthreads();
+    }
+  } else if (c < C)
     for (int g = gg; g < nseg; g += kSegFinalLanes) {
       double ms = 0;
       const double *p = partial + (int64_t)g * nslab * 3 * C + c;
@@ -2001,7 +2031,7 @@ int sn_segment_colsum_f32(const float *x, int64_t ld, const float *mask, int64_t
 size_t sn_avg_stats_workspace_bytes(int64_t rows_per_seg, int64_t nseg, int32_t C) {
   (void)rows_per_seg;
   if (nseg < 0 || C < 1) return 0;
-  return (size_t)nseg * kSegSlabs * 3 * (size_t)C * sizeof(double);
+  return (size_t)nseg * seg_slabs(nseg) * 3 * (size_t)C * sizeof(double);
 }
 
 int sn_avg_stats_f32(const float *e, int64_t ld, const float *mask, const float *inv_count, int64_t rows_per_seg, int64_t nseg,
@@ -2016,8 +2046,9 @@ int sn_avg_stats_f32(const float *e, int64_t ld, const float *mask, const float 
   hipStream_t s = static_cast<hipStream_t>(stream);
   double *partial = static_cast<double *>(workspace);
   const size_t shm = (size_t)(kWG / (C / 4)) * 3 * C * sizeof(double);
-  hipLaunchKernelGGL(segstats_k, dim3(kSegSlabs, (unsigned)nseg), dim3(kWG), shm, s, e, ld, mask, rows_per_seg, (int)C, partial);
-  hipLaunchKernelGGL(segstats_final_k, dim3((unsigned)((C + kSegFinalCols - 1) / kSegFinalCols)), dim3(kSegFinalCols * kSegFinalLanes), 0, s, partial, kSegSlabs, (int)nseg, (int)C,
+  const int nslab = seg_slabs(nseg);
+  hipLaunchKernelGGL(segstats_k, dim3(nslab, (unsigned)nseg), dim3(kWG), shm, s, e, ld, mask, rows_per_seg, (int)C, partial);
+  hipLaunchKernelGGL(segstats_final_k, dim3((unsigned)((C + kSegFinalCols - 1) / kSegFinalCols)), dim3(kSegFinalCols * kSegFinalLanes), 0, s, partial, nslab, (int)nseg, (int)C,
                      inv_count, (double)rows_per_seg, m, stats);
   return launch_status();
 }

@@ -534,6 +534,39 @@ def check_streamed_faust_loss(dev, N=1500, dtype=torch.float32, tol=2e-5):
     assert rel_err(FA.grad.cpu().numpy(), gA.cpu().numpy()) <= 10 * tol and rel_err(FB.grad.cpu().numpy(), gB.cpu().numpy()) <= 10 * tol
 
 
+def check_siamese_gradients_meet_once(dev):
+    """SiameseModel reads its tower's parameters through two aliases whose gradients are added by one multi-tensor launch
+    (dense_correspondence._TwoReaders).  Same parameter gradients as the plain double application of the tower
+    (models.py:201-203) followed by autograd's own accumulation — stored (`.grad is None`) and accumulated into existing
+    gradients — and the running statistics advance twice either way."""
+    import copy
+
+    from surfacenetworks_amd import dense_correspondence as dc
+
+    torch.manual_seed(3)
+    ds = dc.TorusBodies(2, n=7, m=9, pad_to=64, seed=5, device=dev)
+    model = dc.SiameseModel("lap", 3).to(dev).train()
+    plain = copy.deepcopy(model)
+    (inX, tX, mX, LX), (inY, tY, mY, LY) = ds.sample(0), ds.sample(1)
+    for rounds in (1, 2):                       # second round: gradients already exist and are accumulated into
+        out = model(dc._operation(LX, mX), dc._operation(LY, mY), inX, inY)
+        dc.loss_fun_delta_cross_entropy(out, tX, tY).backward()
+        FA = plain.model(*dc._operation(LX, mX), inX)
+        FB = plain.model(*dc._operation(LY, mY), inY)
+        dc.loss_fun_delta_cross_entropy(torch.bmm(FA, FB.transpose(1, 2)), tX, tY).backward()
+        for (n, a), (_, b) in zip(model.named_parameters(), plain.named_parameters()):
+            assert a.grad is not None, n
+            if rounds == 1:                     # a + b in both cases
+                assert torch.equal(a.grad, b.grad), n
+            else:                               # g + (a + b) against (g + a) + b
+                assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6 * float(b.grad.abs().max())), n
+    for (n, a), (_, b) in zip(model.named_buffers(), plain.named_buffers()):
+        assert torch.equal(a, b), n              # running statistics and counters: advanced by every application
+    with torch.no_grad():                       # no gradients wanted: the plain double application
+        o1 = model(dc._operation(LX, mX), dc._operation(LY, mY), inX, inY)
+    assert not o1.requires_grad
+
+
 def check_model_variants(golden_dir, dev, tol=1e-5):
     """The remaining model variants of the three drivers (AvgModel / MlpModel / AmplifyModel and every SiameseModel tower)
     against tests/golden/variants_reference.npz (one forward pass of the imported reference on the two-mesh batch):

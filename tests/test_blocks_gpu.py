@@ -377,3 +377,7 @@ def test_ragged_average_block_at_half_width_matches_the_full_width_composition(l
         assert rel(a, b) < 5e-4, rel(a, b)
     for a, b in zip(ba, bb):
         assert rel(a, b) < 1e-5
+
+
+def test_siamese_gradients_meet_once():
+    pc.check_siamese_gradients_meet_once(DEV)

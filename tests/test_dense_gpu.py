@@ -360,7 +360,7 @@ def test_wgrad_with_per_mesh_column_sums(nseg, per):
     assert rel_err(seg.cpu().numpy(), dy.astype(np.float64).reshape(nseg, per, J).sum(1)) < 2e-6
 
 
-@pytest.mark.parametrize("nseg,per", [(3, 150), (5, 33), (2, 5041)])
+@pytest.mark.parametrize("nseg,per", [(3, 150), (5, 33), (2, 5041), (1, 7000), (4, 17), (1, 1), (64, 300)])
 def test_avg_stats_single_pass(nseg, per):
     """sn_avg_stats_f32 == sn_segment_colsum_f32 + sn_colstats_f32 + sn_avg_fwd_prep_f32 (fp64 accumulation everywhere)."""
     rng = np.random.default_rng(nseg * 31 + per)

@@ -59,3 +59,7 @@ def test_model_variants_match_reference(golden_dir, cpu_kernels):
 
 def test_models_on_packed_batches(cpu_kernels):
     pc.check_packed_model("cpu")
+
+
+def test_siamese_gradients_meet_once(cpu_kernels):
+    pc.check_siamese_gradients_meet_once("cpu")
