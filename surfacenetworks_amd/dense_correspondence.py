@@ -301,35 +301,37 @@ class TorusBodies:
 
 class PairBatch:
     """One training pair (two independent samples, main.py:310-316) as a flat set of device tensors — what the hipGraph
-    replay needs as static inputs (graphs.GraphedTrainStep)."""
+    replay needs as static inputs (graphs.GraphedTrainStep).  The loss target (main.py:236-237) is computed here, from the
+    dataset's resident geodesic matrices: the replay then takes a 6890-entry index vector as input instead of two
+    190 MB matrices copied into static buffers every step."""
 
     def __init__(self, ds: TorusBodies, ia: int, ib: int):
         self.inX, self.tX, self.mX, self.LX = ds.sample(ia)
         self.inY, self.tY, self.mY, self.LY = ds.sample(ib)
+        (GA, lA, liA), (GB, lB, liB) = self.tX[0], self.tY[0]
+        self.NA, self.NB = int(lA.size(0)), int(lB.size(0))
+        self.target = correspondence_target(GA, lA, liA, GB, lB, liB)
 
     def owned(self) -> "PairBatch":
-        """A copy whose target tensors are private: `sample()` hands out the dataset's own (G, label, label_inv), and the
-        static batch of a captured step is overwritten in place by every `load()`."""
+        """A copy for the static batch of a captured step (overwritten in place by every `load()`): nothing in it is the
+        dataset's own tensor."""
         import copy
 
         b = copy.copy(self)
-        b.tX = [tuple(t.clone() for t in trip) for trip in self.tX]
-        b.tY = [tuple(t.clone() for t in trip) for trip in self.tY]
+        b.target = self.target.clone()
+        b.tX = b.tY = None
         return b
 
     def graph_tensors(self):
         from .graphs import operator_tensors
 
-        out = [self.inX, self.inY, self.mX, self.mY]
-        for t in (self.tX, self.tY):
-            for trip in t:
-                out.extend(trip)
-        return out + operator_tensors(self.LX) + operator_tensors(self.LY)
+        return [self.inX, self.inY, self.mX, self.mY, self.target] + operator_tensors(self.LX) + operator_tensors(self.LY)
 
 
 def forward_loss(model, b: PairBatch):
+    """loss_fun_delta_cross_entropy for the one pair of a PairBatch (main.py:229-240 at batch size 1), target precomputed."""
     out = model([b.LX, b.mX], [b.LY, b.mY], b.inX, b.inY)
-    return loss_fun_delta_cross_entropy(out, b.tX, b.tY)
+    return F.cross_entropy(out[0, :b.NA, :b.NB], b.target).reshape(1)
 
 
 def graphed_train_step(model, optimizer, example: PairBatch, bucket=None):

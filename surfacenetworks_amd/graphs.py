@@ -124,8 +124,16 @@ class GraphedStep:
                 s.shape != d.shape or s.dtype != d.dtype for s, d in zip(src, self._static_tensors)):
             raise ValueError("batch does not match the captured signature; capture a new GraphedStep")
         with torch.no_grad():
-            if src:
-                torch._foreach_copy_(self._static_tensors, src)
+            # one multi-tensor launch per dtype: a mixed list (fp32 values, int32 indices, int64 tables) would take the
+            # op's slow path, one device-to-device copy per tensor (37 copies of ~10 us for a FAUST pair)
+            groups = {}
+            for s_, d_ in zip(src, self._static_tensors):
+                if d_.numel():
+                    g = groups.setdefault(d_.dtype, ([], []))
+                    g[0].append(d_)
+                    g[1].append(s_)
+            for dst, srcs in groups.values():
+                torch._foreach_copy_(dst, srcs)
 
     def replay(self) -> torch.Tensor:
         self.graph.replay()
