@@ -393,6 +393,16 @@ int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems
  * caller guarantees 0 <= pa[j] < colsA and that pb[r] indexes a row of GB. */
 int sn_pair_argmin_f32(const float *GA, int64_t ldA, int64_t colsA, const int64_t *pa, const float *GB, int64_t ldB,
                        const int64_t *pb, int64_t NA, int64_t NB, int64_t *out, void *stream);
+/* sn_pair_ce_fwd_f32 / sn_pair_ce_bwd_f32: the cross entropy of the dense-correspondence loss on the score matrix
+ * (src/dense_correspondence/main.py:238-239, `F.cross_entropy(outputs[0, :NA, :NB], GAB)`; replaces log_softmax, nll_loss,
+ * their backward passes and the zero padding of the slice's gradient).  Forward: lse[r] = log sum_j<NB exp(S[r][j]) and
+ * rowloss[r] = lse[r] - S[r][target[r]] for r < NA (the loss is their mean; the caller sums NA floats).  Backward:
+ * dS[r][j] = (*gloss / NA) * (softmax(S[r][:NB])[j] - [j == target[r]]) for r < NA, j < NB and 0 for the rest of the
+ * rows x cols matrix (the padding of the batch); gloss is a DEVICE scalar.  fp32 throughout, max-subtracted like torch's. */
+int sn_pair_ce_fwd_f32(const float *S, int64_t ld, const int64_t *target, int64_t NA, int64_t NB, float *lse, float *rowloss,
+                       void *stream);
+int sn_pair_ce_bwd_f32(const float *S, int64_t ld, const int64_t *target, const float *lse, const float *gloss, int64_t NA,
+                       int64_t NB, int64_t rows, int64_t cols, float *dS, int64_t ldd, void *stream);
 /* sn_linear_thin_fwd_f32: forward of that first layer, y = x·W^T + bias (x: rows x C, C <= 8; W: J x C), and optionally
  * elu(y) into y_elu (the first half of the next block's concat buffer; replaces the F.elu of utils_pt.py:161,195).  y or
  * y_elu may be NULL (not both).  Ascending-k fp32 FMA chain on top of the bias. */

@@ -61,6 +61,8 @@ SIGNATURES = {
     "sn_masked_smooth_l1_fwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, C.c_double, _vp, _vp, _sz, _vp]),
     "sn_masked_smooth_l1_bwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, C.c_double, _vp, _vp, _i64, _vp]),
     "sn_pair_argmin_f32": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _vp, _i64, _i64, _vp, _vp]),
+    "sn_pair_ce_fwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "sn_pair_ce_bwd_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _vp]),
     "sn_gather_segments_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "sn_linear_thin_fwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "sn_bn_fold_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, C.c_double, _i32, _vp, _vp, _vp,

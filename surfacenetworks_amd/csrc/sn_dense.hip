@@ -1668,6 +1668,108 @@ __global__ __launch_bounds__(kWG) void pair_argmin_lds_k(const float *__restrict
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Cross entropy of the dense-correspondence loss (src/dense_correspondence/main.py:238-239:
+// F.cross_entropy(outputs[0, :NA, :NB], GAB), mean over the NA rows) on the (N x N) score matrix.  torch runs
+// log_softmax (read + write 196 MB at N = 7000), nll_loss, their two backward passes and the zero-padding of the slice's
+// gradient; here the forward reads the scores once (row maximum and sum from registers) and keeps one log-sum-exp per row,
+// the backward reads them once more and writes the gradient of the WHOLE padded matrix in the same pass.
+// One workgroup per row; a row of up to kCeRegs x 1024 columns lives in registers between the two reductions.
+// ------------------------------------------------------------------------------------------------
+constexpr int kCeRegs = 8;                   // float4 per thread held between the max and the sum pass (8192 columns)
+__device__ inline float wg_reduce_max(float v, float *sm) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v = fmaxf(v, __shfl_xor(v, d));
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+  __syncthreads();
+  return v;
+}
+__device__ inline float wg_reduce_sum(float v, float *sm) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  v = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+  __syncthreads();
+  return v;
+}
+template <bool VEC>
+__global__ __launch_bounds__(kWG) void pair_ce_fwd_k(const float *__restrict__ S, int64_t ld, const int64_t *__restrict__ target,
+                                                     int NB, float *__restrict__ lse, float *__restrict__ rowloss) {
+  __shared__ float sm[kWG / 64];
+  const float *row = S + (int64_t)blockIdx.x * ld;
+  float mx = -__builtin_inff(), sum = 0.f;
+  if (VEC && NB <= kCeRegs * 4 * kWG) {
+    f4 v[kCeRegs];
+#pragma unroll
+    for (int u = 0; u < kCeRegs; ++u) {
+      const int c = 4 * (threadIdx.x + u * kWG);
+      if (c + 3 < NB) {
+        v[u] = *reinterpret_cast<const f4 *>(row + c);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[u][e] = c + e < NB ? row[c + e] : -__builtin_inff();
+      }
+      mx = fmaxf(fmaxf(mx, fmaxf(v[u][0], v[u][1])), fmaxf(v[u][2], v[u][3]));
+    }
+    mx = wg_reduce_max(mx, sm);
+#pragma unroll
+    for (int u = 0; u < kCeRegs; ++u)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum += expf(v[u][e] - mx);        // exp(-inf) = 0 for the columns past NB
+  } else {
+    for (int c = threadIdx.x; c < NB; c += kWG) mx = fmaxf(mx, row[c]);
+    mx = wg_reduce_max(mx, sm);
+    for (int c = threadIdx.x; c < NB; c += kWG) sum += expf(row[c] - mx);
+  }
+  sum = wg_reduce_sum(sum, sm);
+  if (threadIdx.x == 0) {
+    const float l = mx + logf(sum);
+    lse[blockIdx.x] = l;
+    rowloss[blockIdx.x] = l - row[target[blockIdx.x]];
+  }
+}
+// dS[r][j] = gs * (exp(S[r][j] - lse[r]) - [j == target[r]]) inside NA x NB, 0 in the padding; gs = *gloss / NA
+template <bool VEC>
+__global__ __launch_bounds__(kWG) void pair_ce_bwd_k(const float *__restrict__ S, int64_t ld, const int64_t *__restrict__ target,
+                                                     const float *__restrict__ lse, const float *__restrict__ gloss, int NA,
+                                                     int NB, int cols, float *__restrict__ dS, int64_t ldd) {
+  const int r = blockIdx.x;
+  float *out = dS + (int64_t)r * ldd;
+  if (r >= NA) {
+    if (VEC) {
+      for (int c = 4 * threadIdx.x; c < cols; c += 4 * kWG) {
+        if (c + 3 < cols) *reinterpret_cast<f4 *>(out + c) = f4{0.f, 0.f, 0.f, 0.f};
+        else for (int e = 0; c + e < cols; ++e) out[c + e] = 0.f;
+      }
+    } else {
+      for (int c = threadIdx.x; c < cols; c += kWG) out[c] = 0.f;
+    }
+    return;
+  }
+  const float *row = S + (int64_t)r * ld;
+  const float l = lse[r], gs = gloss[0] / (float)NA;
+  const int t = (int)target[r];
+  if (VEC) {
+    for (int c = 4 * threadIdx.x; c < cols; c += 4 * kWG) {
+      if (c + 3 < NB) {
+        const f4 v = *reinterpret_cast<const f4 *>(row + c);
+        f4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = gs * (expf(v[e] - l) - (c + e == t ? 1.f : 0.f));
+        *reinterpret_cast<f4 *>(out + c) = o;
+      } else {
+        for (int e = 0; e < 4 && c + e < cols; ++e)
+          out[c + e] = c + e < NB ? gs * (expf(row[c + e] - l) - (c + e == t ? 1.f : 0.f)) : 0.f;
+      }
+    }
+  } else {
+    for (int c = threadIdx.x; c < cols; c += kWG) out[c] = c < NB ? gs * (expf(row[c] - l) - (c == t ? 1.f : 0.f)) : 0.f;
+  }
+}
+
 inline int wgrad_slabs(int64_t rows) {
   // Small products: at least two 32-row blocks per slab until every CU has one (a 7000-row mesh on 27 slabs of 256 rows kept
   // 27 CUs busy for 24 us; on 110 slabs the same product takes 13).  Beyond one slab per CU a slab has at least 256 rows
@@ -2155,6 +2257,38 @@ int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems
   else
     hipLaunchKernelGGL((gather_segments_k<1>), dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, base,
                        rows_per_item, row_stride, (int)len, total, out);
+  return launch_status();
+}
+
+int sn_pair_ce_fwd_f32(const float *S, int64_t ld, const int64_t *target, int64_t NA, int64_t NB, float *lse, float *rowloss,
+                       void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (NA < 0 || NB < 1 || ld < NB) return SN_E_SHAPE;
+  if (NA > INT_MAX || NB > INT_MAX) return SN_E_RANGE;
+  if (NA == 0) return SN_OK;
+  if (!S || !target || !lse || !rowloss) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (aligned16(S) && (ld % 4) == 0)
+    hipLaunchKernelGGL((pair_ce_fwd_k<true>), dim3((unsigned)NA), dim3(kWG), 0, s, S, ld, target, (int)NB, lse, rowloss);
+  else
+    hipLaunchKernelGGL((pair_ce_fwd_k<false>), dim3((unsigned)NA), dim3(kWG), 0, s, S, ld, target, (int)NB, lse, rowloss);
+  return launch_status();
+}
+
+int sn_pair_ce_bwd_f32(const float *S, int64_t ld, const int64_t *target, const float *lse, const float *gloss, int64_t NA,
+                       int64_t NB, int64_t rows, int64_t cols, float *dS, int64_t ldd, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (NA < 0 || NB < 1 || rows < NA || cols < NB || ld < NB || ldd < cols) return SN_E_SHAPE;
+  if (rows > INT_MAX || cols > INT_MAX) return SN_E_RANGE;
+  if (rows == 0) return SN_OK;
+  if (!S || !target || !lse || !gloss || !dS) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (aligned16(S) && aligned16(dS) && (ld % 4) == 0 && (ldd % 4) == 0)
+    hipLaunchKernelGGL((pair_ce_bwd_k<true>), dim3((unsigned)rows), dim3(kWG), 0, s, S, ld, target, lse, gloss, (int)NA, (int)NB,
+                       (int)cols, dS, ldd);
+  else
+    hipLaunchKernelGGL((pair_ce_bwd_k<false>), dim3((unsigned)rows), dim3(kWG), 0, s, S, ld, target, lse, gloss, (int)NA, (int)NB,
+                       (int)cols, dS, ldd);
   return launch_status();
 }
 

@@ -196,6 +196,30 @@ def correspondence_target(GA, lA, liA, GB, lB, liB):
     return kernels.pair_argmin(GA, liA[lB], GB, liB[lA])
 
 
+class _PairCrossEntropy(torch.autograd.Function):
+    """F.cross_entropy(S[:NA, :NB], target) (main.py:238-239) in two passes over the score matrix instead of torch's five
+    (log_softmax, nll_loss, their backward passes, the zero padding of the slice's gradient): sn_pair_ce_fwd/bwd_f32."""
+
+    @staticmethod
+    def forward(ctx, S, target, NA, NB):
+        lse, rowloss = kernels.pair_ce_fwd(S, target, NA, NB)
+        ctx.save_for_backward(S, target, lse)
+        ctx.dims = (NA, NB)
+        return rowloss.sum() / NA
+
+    @staticmethod
+    def backward(ctx, g):
+        S, target, lse = ctx.saved_tensors
+        return kernels.pair_ce_bwd(S, target, lse, g.reshape(1).contiguous(), *ctx.dims), None, None, None
+
+
+def pair_cross_entropy(S, target, NA: int, NB: int):
+    """Cross entropy of the NA x NB corner of the (padded) score matrix S against `target`, mean over rows."""
+    if S.dtype != torch.float32 or S.stride(-1) != 1:
+        return F.cross_entropy(S[:NA, :NB], target)
+    return _PairCrossEntropy.apply(S, target, NA, NB)
+
+
 def loss_fun_delta_cross_entropy(outputs, targetX, targetY):
     """main.py:229-240, including its quirk of always scoring outputs[0] (the reference runs batch 1, main.py:40)."""
     loss = outputs.new_zeros(1)
@@ -204,7 +228,7 @@ def loss_fun_delta_cross_entropy(outputs, targetX, targetY):
         GB, lB, liB = targetY[i]
         NA, NB = lA.size(0), lB.size(0)
         GAB = correspondence_target(GA, lA, liA, GB, lB, liB)
-        loss = loss + F.cross_entropy(outputs[0, :NA, :NB], GAB)
+        loss = loss + pair_cross_entropy(outputs[0], GAB, NA, NB)
     return loss / outputs.size(0)
 
 
@@ -331,7 +355,7 @@ class PairBatch:
 def forward_loss(model, b: PairBatch):
     """loss_fun_delta_cross_entropy for the one pair of a PairBatch (main.py:229-240 at batch size 1), target precomputed."""
     out = model([b.LX, b.mX], [b.LY, b.mY], b.inX, b.inY)
-    return F.cross_entropy(out[0, :b.NA, :b.NB], b.target).reshape(1)
+    return pair_cross_entropy(out[0], b.target, b.NA, b.NB).reshape(1)
 
 
 def graphed_train_step(model, optimizer, example: PairBatch, bucket=None):

@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "pair_ce_fwd", "pair_ce_bwd", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
 ]
 
 
@@ -828,6 +828,28 @@ def pair_argmin(GA, pa, GB, pb):
     _lib.call("sn_pair_argmin_f32", _p(GA), GA.stride(0), GA.shape[1], _p(pa.contiguous()), _p(GB), GB.stride(0), _p(pb.contiguous()), NA, NB,
               _p(out), _stream())
     return out
+
+
+def pair_ce_fwd(S, target, NA: int, NB: int):
+    """(lse, rowloss), NA floats each, of the cross entropy over S[:NA, :NB] (sn_pair_ce_fwd_f32; main.py:238-239)."""
+    _dev(S, target)
+    if S.dtype != torch.float32 or target.dtype != torch.int64 or S.dim() != 2 or S.stride(1) != 1:
+        raise TypeError("pair_ce_fwd: row-major float32 scores and int64 targets expected")
+    if NA > S.shape[0] or NB > S.shape[1] or target.numel() != NA:
+        raise ValueError("pair_ce_fwd: NA x NB does not fit the score matrix / target vector")
+    lse = torch.empty(NA, dtype=torch.float32, device=S.device)
+    rowloss = torch.empty(NA, dtype=torch.float32, device=S.device)
+    _lib.call("sn_pair_ce_fwd_f32", _p(S), S.stride(0), _p(target.contiguous()), NA, NB, _p(lse), _p(rowloss), _stream())
+    return lse, rowloss
+
+
+def pair_ce_bwd(S, target, lse, gloss, NA: int, NB: int):
+    """Gradient of mean_r rowloss[r] times the device scalar gloss, for the WHOLE score matrix (zeros outside NA x NB)."""
+    _dev(S, target, lse, gloss)
+    dS = torch.empty((S.shape[0], S.shape[1]), dtype=torch.float32, device=S.device)
+    _lib.call("sn_pair_ce_bwd_f32", _p(S), S.stride(0), _p(target.contiguous()), _p(lse), _p(gloss), NA, NB, S.shape[0], S.shape[1],
+              _p(dS), dS.stride(0), _stream())
+    return dS
 
 
 def masked_smooth_l1_fwd(out2d, target2d, rowmask, scale: float):

@@ -512,6 +512,20 @@ def pair_argmin(GA, pa, GB, pb):
     return torch.argmin(GA[:pb.numel()][:, pa] + GB[pb][:, :pa.numel()], dim=1)
 
 
+def pair_ce_fwd(S, target, NA, NB):
+    x = S[:NA, :NB]
+    lse = torch.logsumexp(x, dim=1)
+    return lse, lse - x.gather(1, target[:, None]).squeeze(1)
+
+
+def pair_ce_bwd(S, target, lse, gloss, NA, NB):
+    dS = torch.zeros_like(S)
+    p = torch.exp(S[:NA, :NB] - lse[:, None])
+    p.scatter_add_(1, target[:, None], -torch.ones_like(p[:, :1]))
+    dS[:NA, :NB] = p * (gloss.reshape(()) / NA)
+    return dS
+
+
 def masked_smooth_l1_fwd(out2d, target2d, rowmask, scale):
     d = out2d.double() * (1.0 if rowmask is None else rowmask.double().reshape(-1, 1)) - target2d.double()
     a = d.abs()

@@ -812,3 +812,28 @@ def test_weight_gradient_of_a_64_wide_layer_through_the_paired_rows(rows, J):
     s = sdy.cpu().numpy().reshape(-1, J)[0]
     # fp32 partial sums inside a slab, fp64 across slabs
     assert np.allclose(s, dy.astype(np.float64).sum(0), rtol=0, atol=1e-6 * np.abs(dy).sum(0).max())
+
+
+@pytest.mark.parametrize("N,NA,NB", [(7, 7, 7), (80, 63, 70), (1024, 1000, 1021), (7000, 6890, 6890), (9001, 40, 9001)])
+def test_pair_cross_entropy_matches_torch(N, NA, NB):
+    """sn_pair_ce_fwd/bwd_f32 against F.cross_entropy on the NA x NB corner of a padded score matrix: value, the gradient
+    inside the corner and exact zeros in the padding; rows longer than the register-resident form and unaligned views too."""
+    import torch.nn.functional as F
+
+    from surfacenetworks_amd import dense_correspondence as dc
+
+    g = torch.Generator().manual_seed(N)
+    rows = min(N, NA + 3)
+    for off in (0, 1):                                   # off = 1: a view that is not 16-byte aligned
+        base = (3.0 * torch.randn(rows, N + 4, generator=g)).to(DEV)
+        S = base[:, off:off + N].detach().requires_grad_(True)
+        tgt = torch.randint(0, NB, (NA,), generator=g).to(DEV)
+        want = F.cross_entropy(S[:NA, :NB], tgt)
+        (gw,) = torch.autograd.grad(want * 1.7, S)
+        S2 = S.detach().clone().requires_grad_(True) if off == 0 else base[:, off:off + N].detach().requires_grad_(True)
+        got = dc.pair_cross_entropy(S2, tgt, NA, NB)
+        (gg,) = torch.autograd.grad(got * 1.7, S2)
+        assert abs(got.item() - want.item()) <= 2e-6 * abs(want.item())
+        assert rel_err(gg.cpu().numpy(), gw.cpu().numpy()) < 5e-6
+        assert gg[NA:].abs().max().item() == 0 if rows > NA else True
+        assert gg[:, NB:].abs().max().item() == 0 if N > NB else True
