@@ -418,10 +418,19 @@ def forward_pair_loss(model, ds, ia: int, ib: int, streamed: bool = False, block
     return loss_fun_delta_cross_entropy(out, tX, tY)
 
 
-def train_step(model, optimizer, ds, ia: int, ib: int, grad_sync=None, streamed: bool = False):
-    """main.py:310-327: two independent samples, siamese forward, delta-CE loss, Adam."""
+def train_step(model, optimizer, ds, ia: int, ib: int, grad_sync=None, streamed: bool = False, global_pairs: int = 1,
+               zero_grads=None):
+    """main.py:310-327: two independent samples, siamese forward, delta-CE loss, Adam.
+    Data parallel (BASELINE config 4: one pair per GPU and step): every rank passes its own pair and `global_pairs` = the
+    number of ranks, so the loss is the mean over the job's pairs and the SUM all-reduce of `grad_sync`
+    (dp.FlatGradBucket.sync / all_reduce) needs no averaging pass.  zero_grads: e.g. FlatGradBucket.detach_grads."""
     loss = forward_pair_loss(model, ds, ia, ib, streamed)
-    optimizer.zero_grad(set_to_none=False)
+    if global_pairs != 1:
+        loss = loss / global_pairs
+    if zero_grads is not None:
+        zero_grads()
+    else:
+        optimizer.zero_grad(set_to_none=False)
     loss.backward()
     if grad_sync is not None:
         grad_sync()

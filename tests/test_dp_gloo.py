@@ -193,3 +193,59 @@ def test_flat_bucket_single_process():
     assert torch.equal(b.flat[:15].view(3, 5), lin.weight.grad) and b.flat[15:].tolist() == [2.0, 2.0, 2.0]
     torch.optim.SGD(lin.parameters(), 0.1).zero_grad(set_to_none=False)
     assert b.check_views() and float(b.flat.abs().sum()) == 0.0
+
+
+def _worker_pairs(rank, world, port, q):
+    """BASELINE config 4: dense correspondence, one pair per rank and step, gradients all-reduced."""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      SN_DP_FORCE_CPU="1")
+    torch.set_num_threads(2)
+    import cpu_kernels
+
+    cpu_kernels.install()
+    from helpers import deterministic_init
+    from surfacenetworks_amd import dense_correspondence as dc, dp
+
+    dp.init_distributed("gloo")
+    ds = dc.TorusBodies(3, n=7, m=9, pad_to=64, seed=5, device="cpu")          # every rank holds the (tiny) dataset
+    model = deterministic_init(dc.SiameseModel("lap", 3), 11 + rank).eval()      # BN frozen: pairs are exactly additive
+    dp.broadcast_parameters(model, 0)
+    ref = deterministic_init(dc.SiameseModel("lap", 3), 11).eval()
+    bucket = dp.FlatGradBucket(model.parameters())
+    opt = dc.make_optimizer(model)
+    pairs = [(0, 1), (1, 2)]
+    ia, ib = pairs[rank]
+    loss = dc.train_step(model, opt, ds, ia, ib, grad_sync=bucket.sync, global_pairs=world, zero_grads=bucket.detach_grads)
+    g_dp = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    total = sum(dc.forward_pair_loss(ref, ds, a, b) for a, b in pairs) / len(pairs)
+    total.backward()
+    g_full = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    err = ((g_dp - g_full).norm() / g_full.norm()).item()
+    lsum = loss.detach().clone()
+    dist.all_reduce(lsum)
+    flat_p = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    other = flat_p.clone()
+    dist.broadcast(other, 0)
+    q.put((rank, err, abs(lsum.item() - total.item()) / abs(total.item()), torch.equal(other, flat_p)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_correspondence_pairs_sharded_over_two_ranks():
+    """Sum over ranks of the per-pair gradients (loss / number of pairs) == gradient of the mean loss over both pairs; the
+    replicas stay identical after the optimizer step."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_pairs, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    for rank, err, lerr, same in sorted(q.get(timeout=10) for _ in range(2)):
+        assert err < 1e-5, f"rank {rank}: all-reduced pair gradients differ from the two-pair gradient by {err:.2e}"
+        assert lerr < 1e-6 and same
