@@ -1771,16 +1771,13 @@ __global__ __launch_bounds__(kWG) void pair_ce_bwd_k(const float *__restrict__ S
 }
 
 inline int wgrad_slabs(int64_t rows) {
-  // Small products: at least two 32-row blocks per slab until every CU has one (a 7000-row mesh on 27 slabs of 256 rows kept
-  // 27 CUs busy for 24 us; on 110 slabs the same product takes 13).  Beyond one slab per CU a slab has at least 256 rows
-  // (each slab costs a 128 x C tile of partials written and read again), up to two 4-wave workgroups per CU in one round.
+  // One 8-wave workgroup is resident per CU (its two LDS images take 104 / 154 KB), so slab counts are whole ROUNDS of the
+  // chip: 302 slabs were a full round plus a round that kept 46 CUs busy (Mesh-MNIST batch, 77 k rows: 29 us against 19).
+  // Small products: at least two 32-row blocks per slab until every CU has one (a 7000-row mesh on 27 slabs of 256 rows
+  // kept 27 CUs busy for 24 us; on 110 slabs the same product takes 13).  A second round only when its slabs still have
+  // 256 rows (each slab costs a 128 x C tile of partials, written and read again).
   int64_t b = (rows + 63) / 64;
-  if (b > kCUs) {
-    b = (rows + 255) / 256;
-    if (b < kCUs) b = kCUs;
-  }
-  const int64_t cap = 2 * kCUs;
-  if (b > cap) b = cap;
+  if (b > kCUs) b = rows >= (int64_t)2 * 256 * kCUs ? 2 * kCUs : kCUs;
   if (b < 1) b = 1;
   return (int)b;
 }
