@@ -167,22 +167,49 @@ class SiameseModel(nn.Module):
         else:
             raise ValueError("towers: 'dir', 'amp', 'lap', 'avg', 'mlp'")
 
+    def _tower_slots(self):
+        """[(owner module's parameter dict, key, index into the unique-parameter list)], the list itself; rebuilt when a
+        slot no longer holds the parameter it was built from."""
+        cached = self.__dict__.get("_sn_slots")
+        if cached is not None:
+            slots, plist = cached
+            if all(d.get(k) is plist[i] and plist[i].requires_grad for d, k, i in slots):
+                return cached
+        slots, plist, index = [], [], {}
+        for mod in self.model.modules():
+            for k, q in mod._parameters.items():
+                if q is not None and q.requires_grad:
+                    if id(q) not in index:
+                        index[id(q)] = len(plist)
+                        plist.append(q)
+                    slots.append((mod._parameters, k, index[id(q)]))
+        self.__dict__["_sn_slots"] = (slots, plist)
+        return slots, plist
+
     def towers(self, OperationA, OperationB, inputA, inputB):
         """The two applications of the shared tower (models.py:201-202).  When gradients are wanted, each application reads
         the parameters through its own set of aliases (`_TwoReaders`): the two gradients of a parameter then meet in ONE
         multi-tensor addition at the end of the backward instead of in one accumulation launch per parameter (the tower
-        has ~90 parameters; at a FAUST pair every launch is a few per cent of the step).  Same values: a + b either way."""
-        names, params = [], []
-        for n, q in self.model.named_parameters():
-            if q.requires_grad:
-                names.append(n)
-                params.append(q)
-        if not (torch.is_grad_enabled() and params):
+        has ~90 parameters; at a FAUST pair every launch is a few per cent of the step).  Same values: a + b either way.
+        The aliases are put into the modules' parameter slots for the duration of each application (a few dozen dict
+        assignments; torch.func.functional_call does the same with ~3 ms of bookkeeping per step)."""
+        if not torch.is_grad_enabled():
             return self.model(*OperationA, inputA), self.model(*OperationB, inputB)
-        alias = _TwoReaders.apply(*params)
-        k = len(params)
-        FA = torch.func.functional_call(self.model, dict(zip(names, alias[:k])), (*OperationA, inputA))
-        FB = torch.func.functional_call(self.model, dict(zip(names, alias[k:])), (*OperationB, inputB))
+        slots, plist = self._tower_slots()
+        if not plist:
+            return self.model(*OperationA, inputA), self.model(*OperationB, inputB)
+        alias = _TwoReaders.apply(*plist)
+        k = len(plist)
+        try:
+            for d, key, i in slots:
+                d[key] = alias[i]
+            FA = self.model(*OperationA, inputA)
+            for d, key, i in slots:
+                d[key] = alias[k + i]
+            FB = self.model(*OperationB, inputB)
+        finally:
+            for d, key, i in slots:
+                d[key] = plist[i]
         return FA, FB
 
     def forward(self, OperationA, OperationB, inputA, inputB):
