@@ -389,7 +389,7 @@ int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems
  * `_, GAB = torch.min(GA[:, liA[lB]] + GB[liB[lA], :], dim=1)`):  out[r] = argmin_j ( GA[r*ldA + pa[j]] + GB[pb[r]*ldB + j] ),
  * r < NA, j < NB, with pa = liA[lB] (NB entries) and pb = liB[lA] (NA entries) as DEVICE int64 arrays; the two gathered
  * NA x NB matrices are never materialised.  fp32 sum as in the reference; ties go to the lowest j, a NaN wins (torch.min).
- * GA has colsA valid columns per row (rows up to 64 KB are staged in LDS, wider ones gathered from global memory); the
+ * GA has colsA valid columns per row (rows up to 60 KB are staged in LDS, wider ones gathered from global memory); the
  * caller guarantees 0 <= pa[j] < colsA and that pb[r] indexes a row of GB. */
 int sn_pair_argmin_f32(const float *GA, int64_t ldA, int64_t colsA, const int64_t *pa, const float *GB, int64_t ldB,
                        const int64_t *pb, int64_t NA, int64_t NB, int64_t *out, void *stream);
@@ -398,7 +398,8 @@ int sn_pair_argmin_f32(const float *GA, int64_t ldA, int64_t colsA, const int64_
  * their backward passes and the zero padding of the slice's gradient).  Forward: lse[r] = log sum_j<NB exp(S[r][j]) and
  * rowloss[r] = lse[r] - S[r][target[r]] for r < NA (the loss is their mean; the caller sums NA floats).  Backward:
  * dS[r][j] = (*gloss / NA) * (softmax(S[r][:NB])[j] - [j == target[r]]) for r < NA, j < NB and 0 for the rest of the
- * rows x cols matrix (the padding of the batch); gloss is a DEVICE scalar.  fp32 throughout, max-subtracted like torch's. */
+ * rows x cols matrix (the padding of the batch); gloss is a DEVICE scalar.  fp32 throughout, max-subtracted like torch's.
+ * 0 <= target[r] < NB is the caller's guarantee (not checked on the device). */
 int sn_pair_ce_fwd_f32(const float *S, int64_t ld, const int64_t *target, int64_t NA, int64_t NB, float *lse, float *rowloss,
                        void *stream);
 int sn_pair_ce_bwd_f32(const float *S, int64_t ld, const int64_t *target, const float *lse, const float *gloss, int64_t NA,

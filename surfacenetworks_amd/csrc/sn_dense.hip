@@ -1624,7 +1624,7 @@ __global__ __launch_bounds__(kWG) void pair_argmin_k(const float *__restrict__ G
 // memory moves a whole cache line per 4-byte element once the rows of a CU's workgroups have pushed each other out of L1
 // (measured: 550 us for 6890 x 6890, against ~75 us of HBM time for the two matrices).  One row per workgroup, 27 KB of LDS
 // at 6890 columns: five workgroups per CU overlap each other's staging and gathering.
-constexpr size_t kArgLdsMax = 64 * 1024 - 16;      // the default dynamic-LDS limit of a launch
+constexpr size_t kArgLdsMax = 60 * 1024;           // row image; with the shift slack and the static arrays under the 64 KB a launch gets by default
 __global__ __launch_bounds__(kWG) void pair_argmin_lds_k(const float *__restrict__ GA, int64_t ldA, int colsA,
                                                          const int64_t *__restrict__ pa, const float *__restrict__ GB, int64_t ldB,
                                                          const int64_t *__restrict__ pb, int NB, int64_t *__restrict__ out) {

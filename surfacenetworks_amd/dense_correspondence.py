@@ -7,6 +7,8 @@ score matrix, trained with the argmin-target cross entropy of loss_fun_delta_cro
 """
 from __future__ import annotations
 
+import weakref
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -149,6 +151,9 @@ class _TwoReaders(torch.autograd.Function):
         return tuple(out)
 
 
+_TOWER_SLOTS = weakref.WeakKeyDictionary()
+
+
 class SiameseModel(nn.Module):
     """models.py:184-203."""
 
@@ -170,7 +175,7 @@ class SiameseModel(nn.Module):
     def _tower_slots(self):
         """[(owner module's parameter dict, key, index into the unique-parameter list)], the list itself; rebuilt when a
         slot no longer holds the parameter it was built from."""
-        cached = self.__dict__.get("_sn_slots")
+        cached = _TOWER_SLOTS.get(self)
         if cached is not None:
             slots, plist = cached
             if all(d.get(k) is plist[i] and plist[i].requires_grad for d, k, i in slots):
@@ -183,7 +188,7 @@ class SiameseModel(nn.Module):
                         index[id(q)] = len(plist)
                         plist.append(q)
                     slots.append((mod._parameters, k, index[id(q)]))
-        self.__dict__["_sn_slots"] = (slots, plist)
+        _TOWER_SLOTS[self] = (slots, plist)      # kept outside the module: nothing of it is pickled or deep-copied with it
         return slots, plist
 
     def towers(self, OperationA, OperationB, inputA, inputB):

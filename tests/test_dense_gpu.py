@@ -761,10 +761,11 @@ def test_ragged_mesh_entry_points(lengths):
 
 # ---- target of the dense-correspondence loss (dense_correspondence/main.py:236-237) ---------------------------------------
 @pytest.mark.parametrize("NA,NB,kind", [(1, 1, "real"), (5, 9, "real"), (333, 257, "real"), (1030, 700, "ties"), (64, 513, "nan"),
-                                        (6890, 6890, "real"), (40, 17000, "real")])
+                                        (6890, 6890, "real"), (40, 17000, "real"), (8, 15349, "real"), (8, 15350, "real")])
 def test_pair_argmin_is_the_reference_min_over_the_two_gathered_matrices(NA, NB, kind):
     """Bit-exact index parity with numpy's argmin of the fp32 sum the reference forms, on views with a leading dimension
-    larger than the row, tie-heavy integer matrices (lowest index wins) and rows holding a NaN (which wins, as in torch.min)."""
+    larger than the row, tie-heavy integer matrices (lowest index wins), rows holding a NaN (which wins, as in torch.min), and
+    row widths on both sides of the LDS-staged form's limit (15 360 columns)."""
     rng = np.random.default_rng(NA * 7 + NB)
     ldA, ldB = NA + NB + 3, NB + 5                      # GA has at least max(pa)+1 columns, GB exactly >= NB
     if kind == "ties":
