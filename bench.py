@@ -23,7 +23,8 @@ The JSON line also carries
   secondary    BASELINE.json configs[4] (the config north_star's ">= 60 % of the HBM roofline on the Dirac SpMM at 128
                channels" is quoted on): 128 meshes per GPU with 1 000 .. 20 000 vertices, Di / Di^T / DiA / DiA^T at N = 32,
                as a PACKED (unpadded, ragged) batch and — for comparison — padded to the batch maximum as the reference
-               batches; algorithmic bytes always from the real sum of V_i, F_i.
+               batches; algorithmic bytes always from the real sum of V_i, F_i.  `laplacian`: the same meshes' cotangent
+               Laplacians at 128 channels, packed (L, L^T).
 """
 from __future__ import annotations
 
@@ -155,13 +156,14 @@ def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10):
 
     rng = np.random.default_rng(5 + rank)
     vs = rng.integers(C5_VMIN, C5_VMAX + 1, size=C5_MESHES_PER_GPU)
-    Dis, DiAs, sumV, sumF = [], [], 0, 0
+    Dis, DiAs, Ls, sumV, sumF = [], [], [], 0, 0
     for v in vs:
         n = int(np.sqrt(v))
         V, F_ = mesh_ops.grid_cloth(n, int(v) // n, rng)
         Di, DiA = mesh_ops.dirac(V, F_)
         Dis.append(Di.astype(np.float32))
         DiAs.append(DiA.astype(np.float32))
+        Ls.append(mesh_ops.laplacian(V, F_).astype(np.float32))
         sumV += V.shape[0]
         sumF += F_.shape[0]
     pools = {"Di": OperatorPool(Dis, device, want_bsr4=True), "DiA": OperatorPool(DiAs, device, want_bsr4=True)}
@@ -200,6 +202,29 @@ def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10):
                     "frac": ab / (float(np.median(ms)) * 1e-3) / HBM_PEAK})
                 del x, y
             del op
+    # the same meshes' cotangent Laplacians at 128 channels, packed (the operator of the Laplacian models; default 4x1
+    # row-blocked form) — reported next to the Dirac products, not part of frac_min_packed (north_star's bar names the Dirac)
+    pool = OperatorPool(Ls, device)
+    op = pool.assemble(sel)
+    out["laplacian"] = []
+    for prod, o in (("L", op), ("L^T", op.t())):
+        M, K = o.shape
+        x = torch.randn(K, 128, device=device, generator=g)
+        y = torch.empty(M, 128, device=device)
+        for _ in range(warm):
+            snF._launch(o, x, y, 1, "c5")
+        timer = snF.SpmmTimer()
+        with timer:
+            for _ in range(iters):
+                snF._launch(o, x, y, 1, "c5")
+        ms = np.array([r[5] for r in timer.results()])
+        ab = alg_bytes(M, K, o.nnz, 128)
+        out["laplacian"].append({"layout": "packed", "product": prod, "M": M, "K": K, "nnz": o.nnz, "algorithmic_bytes": ab,
+                                 "ms_median": float(np.median(ms)), "ms_min": float(ms.min()),
+                                 "GBps": ab / (float(np.median(ms)) * 1e-3) / 1e9,
+                                 "frac": ab / (float(np.median(ms)) * 1e-3) / HBM_PEAK})
+        del x, y
+    del op, pool
     packed = [p_ for p_ in out["products"] if p_["layout"] == "packed"]
     out["frac_min_packed"] = min(p_["frac"] for p_ in packed)
     out["GBps_mean_packed"] = float(np.mean([p_["GBps"] for p_ in packed]))
