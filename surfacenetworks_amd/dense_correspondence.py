@@ -225,6 +225,8 @@ class SiameseModel(nn.Module):
 def correspondence_target(GA, lA, liA, GB, lB, liB):
     """main.py:236-237: `_, GAB = torch.min(GA[:, liA[lB]] + GB[liB[lA], :], dim=1)` in one kernel that reads each matrix
     once and keeps neither gathered copy nor their sum (sn_pair_argmin_f32)."""
+    if GA.dtype != torch.float32 or GB.dtype != torch.float32 or GA.stride(-1) != 1 or GB.stride(-1) != 1:
+        return torch.min(GA[:, liA[lB]] + GB[liB[lA], :], dim=1)[1]      # (the kernel takes row-major fp32 matrices)
     return kernels.pair_argmin(GA, liA[lB], GB, liB[lA])
 
 
