@@ -170,6 +170,17 @@ def make_optimizer(model):
     return make_adam(model)
 
 
+def halve_lr(optimizer, epoch: int, after: int = 50, every: int = 10) -> bool:
+    """The drivers' epoch-level schedule: the learning rate of every parameter group is halved at the end of each epoch with
+    `epoch > after and epoch % every == 0` — after = 50 for ARAP (main.py:237-239), 20 for Mesh-MNIST
+    (mesh_mnist/main.py:174-176).  Returns whether it did."""
+    if not (epoch > after and epoch % every == 0):
+        return False
+    for group in optimizer.param_groups:
+        group["lr"] *= 0.5
+    return True
+
+
 # --------------------------------------------------------------------------------------------------
 # data: synthetic cloth sequences, resident on the GPU
 # --------------------------------------------------------------------------------------------------

@@ -99,6 +99,13 @@ def make_optimizer(model):
     return make_adam(model)       # main.py:139
 
 
+def halve_lr(optimizer, epoch: int) -> bool:
+    """main.py:174-176: halve the learning rate at the end of every tenth epoch past the twentieth."""
+    from .arap import halve_lr as _halve
+
+    return _halve(optimizer, epoch, after=20, every=10)
+
+
 @dataclass
 class Batch:
     inputs: torch.Tensor      # (B, Vmax, 3)

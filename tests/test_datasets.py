@@ -88,3 +88,16 @@ def test_streamed_faust_loss_equals_materialised(cpu_kernels):
     got.backward()
     assert abs(got.item() - ref.item()) < 1e-12
     assert torch.allclose(FA.grad, gA, atol=1e-12) and torch.allclose(FB.grad, gB, atol=1e-12)
+
+
+def test_epoch_schedules_of_the_drivers():
+    """as_rigid_as_possible/main.py:237-239 and mesh_mnist/main.py:174-176: lr *= 0.5 when epoch > 50 (20) and epoch % 10 == 0."""
+    from surfacenetworks_amd import arap, mesh_mnist
+
+    w = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.Adam([w], 1e-3, weight_decay=1e-5)
+    fired = [e for e in range(1, 101) if arap.halve_lr(opt, e)]
+    assert fired == [60, 70, 80, 90, 100] and abs(opt.param_groups[0]["lr"] - 1e-3 / 32) < 1e-12
+    opt = torch.optim.Adam([w], 1e-3, weight_decay=1e-5)
+    fired = [e for e in range(1, 51) if mesh_mnist.halve_lr(opt, e)]
+    assert fired == [30, 40, 50] and abs(opt.param_groups[0]["lr"] - 1e-3 / 8) < 1e-12
