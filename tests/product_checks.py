@@ -315,6 +315,63 @@ def check_mnist_sampler(dev):
     assert out.shape == (2, 10) and torch.isfinite(loss)
 
 
+def check_mnist_evaluation_mode(dev):
+    """mesh_mnist/main.py:178-182: the driver evaluates with `model.eval()` and then puts every BatchNorm module back into
+    train mode ("BatchNorm for some reasons is not stable in eval") — dropout off, batch statistics on, running statistics
+    still advancing — and calls `loss.backward()` there too.  The product in that mixed mode against the oracle models
+    (pinned to the reference's) in the same mode.  The fixture is ill-conditioned in fp32 (Laplacian entries up to 1e4), so
+    the yardstick is the oracle's own fp32 run: the product must be as close to the fp64 result as that is."""
+    import torch.nn.functional as F
+
+    from oracle import ref_blocks as rb
+    from surfacenetworks_amd import mesh_mnist
+
+    def mixed(m_):
+        m_.eval()
+        for mod in m_.modules():
+            if mod.__class__.__name__.find("BatchNorm") > -1:
+                mod.train()
+        return m_
+
+    def flat(vals):
+        return torch.cat([v.detach().cpu().double().reshape(-1) for v in vals])
+
+    def dist(x, ref_):
+        return float((x - ref_).norm()) / max(float(ref_.norm()), 1e-30)
+
+    for kind, prod_cls, ref_cls in (("lap", mesh_mnist.Model, rb.MnistLapModel), ("dir", mesh_mnist.DirModel, rb.MnistDirModel)):
+        ds = mesh_mnist.MeshDigits(4, seed=6, device=dev, vmin=40, vmax=56, model=kind)
+        b = ds.sample_batch(4, np.random.default_rng(1), ids=np.arange(4))
+        r64 = deterministic_init(ref_cls(), 21).double()
+        r32 = deterministic_init(ref_cls(), 21)
+        prod = prod_cls()
+        prod.load_state_dict(r32.state_dict())
+        prod = prod.to(dev)
+        ops_p = (b.L,) if kind == "lap" else (b.Di, b.DiA)
+        dense = [torch.from_numpy(o.to_scipy().toarray()) for o in ops_p]
+        tg = b.targets.cpu()
+        out64 = mixed(r64)(b.inputs.cpu().double(), *(d.double().to_sparse() for d in dense), b.mask.cpu().double())
+        out32 = mixed(r32)(b.inputs.cpu(), *(d.float().to_sparse() for d in dense), b.mask.cpu())
+        outp = mixed(prod)(b.inputs, *ops_p, b.mask)
+        F.nll_loss(out64, tg).backward()
+        F.nll_loss(out32, tg).backward()
+        F.nll_loss(outp, b.targets).backward()
+        assert not prod.training and prod.rn0.bn_fc0.bn.training
+        e_ref, e_prod = dist(flat([out32]), flat([out64])), dist(flat([outp]), flat([out64]))
+        assert e_prod <= 2 * e_ref + 1e-5, (kind, "outputs", e_prod, e_ref)
+        g64 = flat(q.grad for q in r64.parameters())
+        e_ref, e_prod = dist(flat(q.grad for q in r32.parameters()), g64), dist(flat(q.grad for q in prod.parameters()), g64)
+        assert e_prod <= 2 * e_ref + 1e-5, (kind, "parameter gradients", e_prod, e_ref)
+        names = [k for k in r64.state_dict() if "running" in k]
+        s64 = flat(r64.state_dict()[k] for k in names)
+        e_ref = dist(flat(r32.state_dict()[k] for k in names), s64)
+        e_prod = dist(flat(prod.state_dict()[k] for k in names), s64)
+        assert e_prod <= 2 * e_ref + 1e-5, (kind, "running statistics", e_prod, e_ref)
+        for k, v in prod.state_dict().items():
+            if k.endswith("num_batches_tracked"):
+                assert int(v) == 1, k
+
+
 def check_pool_packed(golden_dir, dev):
     """OperatorPool.assemble(sel) without sizes = the PACKED batch: block_diag of the unpadded per-mesh operators (exact),
     transpose attached, offsets on the operator; and the packed product equals, mesh by mesh and bit for bit, the padded

@@ -381,3 +381,7 @@ def test_ragged_average_block_at_half_width_matches_the_full_width_composition(l
 
 def test_siamese_gradients_meet_once():
     pc.check_siamese_gradients_meet_once(DEV)
+
+
+def test_mnist_driver_evaluation_mode():
+    pc.check_mnist_evaluation_mode(DEV)

@@ -63,3 +63,7 @@ def test_models_on_packed_batches(cpu_kernels):
 
 def test_siamese_gradients_meet_once(cpu_kernels):
     pc.check_siamese_gradients_meet_once("cpu")
+
+
+def test_mnist_driver_evaluation_mode(cpu_kernels):
+    pc.check_mnist_evaluation_mode("cpu")
