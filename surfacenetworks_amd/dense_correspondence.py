@@ -345,16 +345,23 @@ class TorusBodies:
             })
         self.pool_L = OperatorPool(mats, self.device)
         self.n = count
+        self._samples = {}
 
     def sample(self, idx):
-        fr = self.frames[idx]
-        nv = fr["V"].shape[0]
-        inputs = torch.zeros(1, self.pad_to, 3, device=self.device)
-        inputs[0, :nv] = fr["V"]
-        mask = torch.zeros(1, self.pad_to, 1, device=self.device)
-        mask[0, :nv] = 1
-        L = self.pool_L.assemble([idx], self.pad_to, self.pad_to)
-        return inputs, [(fr["G"], fr["label"], fr["label_inv"])], mask, L
+        """(inputs, target triple, mask, operator) of frame idx, padded to `pad_to`.  A frame never changes, so its padded
+        tensors and its assembled operator (with the forms the products derive from it) are built once and handed out again:
+        they are the dataset's own — read, do not write (PairBatch.owned() copies what a captured step overwrites)."""
+        hit = self._samples.get(idx)
+        if hit is None:
+            fr = self.frames[idx]
+            nv = fr["V"].shape[0]
+            inputs = torch.zeros(1, self.pad_to, 3, device=self.device)
+            inputs[0, :nv] = fr["V"]
+            mask = torch.zeros(1, self.pad_to, 1, device=self.device)
+            mask[0, :nv] = 1
+            L = self.pool_L.assemble([idx], self.pad_to, self.pad_to)
+            hit = self._samples[idx] = (inputs, [(fr["G"], fr["label"], fr["label_inv"])], mask, L)
+        return hit
 
 
 class PairBatch:
@@ -376,19 +383,25 @@ class PairBatch:
         import copy
 
         b = copy.copy(self)
-        b.target = self.target.clone()
+        b.inX, b.inY, b.mX, b.mY, b.target = (t.clone() for t in (self.inX, self.inY, self.mX, self.mY, self.target))
+        own = lambda ops: tuple(o.clone() for o in ops) if isinstance(ops, (tuple, list)) else ops.clone()
+        b.LX, b.LY = own(self.LX), own(self.LY)
         b.tX = b.tY = None
         return b
 
     def graph_tensors(self):
         from .graphs import operator_tensors
 
-        return [self.inX, self.inY, self.mX, self.mY, self.target] + operator_tensors(self.LX) + operator_tensors(self.LY)
+        out = [self.inX, self.inY, self.mX, self.mY, self.target]
+        for ops in (self.LX, self.LY):
+            for o in (ops if isinstance(ops, (tuple, list)) else (ops,)):
+                out += operator_tensors(o)
+        return out
 
 
 def forward_loss(model, b: PairBatch):
     """loss_fun_delta_cross_entropy for the one pair of a PairBatch (main.py:229-240 at batch size 1), target precomputed."""
-    out = model([b.LX, b.mX], [b.LY, b.mY], b.inX, b.inY)
+    out = model(_operation(b.LX, b.mX), _operation(b.LY, b.mY), b.inX, b.inY)
     return pair_cross_entropy(out[0], b.target, b.NA, b.NB).reshape(1)
 
 
@@ -424,20 +437,25 @@ class FaustFrames:
             self.pool_DiA = OperatorPool([fr["DiA"] for fr in frames], self.device, want_bsr4=True)
         else:
             self.pool_L = OperatorPool([fr["L"] for fr in frames], self.device)
+        self._samples = {}
 
     def sample(self, idx):
-        fr = self.frames[idx]
-        nv = fr["V"].shape[0]
-        inputs = torch.zeros(1, self.pad_to, 3, device=self.device)
-        inputs[0, :nv] = fr["V"]
-        mask = torch.zeros(1, self.pad_to, 1, device=self.device)
-        mask[0, :nv] = 1
-        if self.kind == "dir":
-            ops = (self.pool_Di.assemble([idx], 4 * self.pad_faces, 4 * self.pad_to),
-                   self.pool_DiA.assemble([idx], 4 * self.pad_to, 4 * self.pad_faces))
-        else:
-            ops = self.pool_L.assemble([idx], self.pad_to, self.pad_to)
-        return inputs, [(fr["G"], fr["label"], fr["label_inv"])], mask, ops
+        """As TorusBodies.sample: built once per frame, the dataset's own tensors from then on."""
+        hit = self._samples.get(idx)
+        if hit is None:
+            fr = self.frames[idx]
+            nv = fr["V"].shape[0]
+            inputs = torch.zeros(1, self.pad_to, 3, device=self.device)
+            inputs[0, :nv] = fr["V"]
+            mask = torch.zeros(1, self.pad_to, 1, device=self.device)
+            mask[0, :nv] = 1
+            if self.kind == "dir":
+                ops = (self.pool_Di.assemble([idx], 4 * self.pad_faces, 4 * self.pad_to),
+                       self.pool_DiA.assemble([idx], 4 * self.pad_to, 4 * self.pad_faces))
+            else:
+                ops = self.pool_L.assemble([idx], self.pad_to, self.pad_to)
+            hit = self._samples[idx] = (inputs, [(fr["G"], fr["label"], fr["label_inv"])], mask, ops)
+        return hit
 
 
 def forward_pair_loss(model, ds, ia: int, ib: int, streamed: bool = False, block: int = 1024):

@@ -152,6 +152,25 @@ class SparseOperator:
         out.row_offsets, out.col_offsets = self.row_offsets, self.col_offsets
         return out
 
+    def _cloned(self, transpose=None):
+        cp = lambda t: t.clone()
+        b = tuple(cp(t) for t in self._bsr4) if isinstance(self._bsr4, tuple) else self._bsr4
+        q = tuple(cp(t) for t in self._q3) if isinstance(self._q3, tuple) else self._q3
+        csr = (None, None, None) if self._csr is None else tuple(cp(t) for t in self._csr)
+        out = SparseOperator(*csr, self._shape, batch=self.batch, transpose=transpose, bsr4=b, q3=q)
+        out._rb4 = tuple(cp(t) for t in self._rb4) if isinstance(self._rb4, tuple) else self._rb4
+        out._nnz_cache = self._nnz_cache
+        out.row_offsets, out.col_offsets = self.row_offsets, self.col_offsets
+        return out
+
+    def clone(self):
+        """A deep copy (every materialised form, the attached transpose included): the static batch of a captured step is
+        overwritten in place by every load, so it must not share arrays with a dataset's cached operators."""
+        out = self._cloned()
+        if self._t is not None:
+            out._t = self._t._cloned(transpose=out)
+        return out
+
     def to(self, device):
         device = torch.device(device)
         if device.type == self.device.type and (device.index is None or device.index == self.device.index):
