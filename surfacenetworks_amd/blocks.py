@@ -25,6 +25,7 @@ from .functional import (_launch, _rows2d, avg_stage_backward, avg_stage_backwar
                          avg_stage_forward_ragged, bn_prepare, bnlin_backward,
                          bnlin_backward_elu_input, bnlin_backward_zero_first, bnlin_forward, bnlin_forward_zero_first, stash, unstash,
                          zero_first_supported)
+from .graphs import active_capture
 from .operators import as_operator
 
 __all__ = ["lap_block", "dirac_block", "avg_block", "avg_block_ragged", "avg_block_ragged_ok", "take_activated", "attach_activated", "zero_faces_ok", "elu_conv", "elu_conv_ok"]
@@ -423,14 +424,19 @@ def avg_block(mod, mask, inputs):
     # computed eagerly during warm-up would be baked into the graph as a constant, and every replay on another batch
     # loaded into the static mask would divide by the example batch's vertex counts.  Under capture the reduction is
     # recorded (once per block: a (B, 1) reduction) and nothing is cached.
+    # Inside a GraphedStep capture the blocks of THAT capture share the recorded value (it is recomputed by every replay
+    # before its first use; the key carries the capture's serial number, so it is never taken for an eager value or for
+    # another capture's).
     capturing = mask.is_cuda and torch.cuda.is_current_stream_capturing()
-    cached = None if capturing else getattr(mask, "_sn_avg", None)
-    key = (B, V, mask._version)
+    gen = active_capture() if capturing else None
+    slot = "_sn_avg" if not capturing else ("_sn_avg_cap" if gen is not None else None)
+    cached = getattr(mask, slot, None) if slot else None
+    key = (B, V, mask._version, gen)
     if cached is None or cached[0] != key:
         cached = (key, mask.reshape(rows).contiguous(), 1.0 / mask.reshape(B, V).sum(1, keepdim=True))
-        if not capturing:
+        if slot:
             try:
-                mask._sn_avg = cached
+                setattr(mask, slot, cached)
             except AttributeError:
                 pass
     _, mask_rows, inv_count = cached

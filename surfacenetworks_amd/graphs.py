@@ -69,6 +69,17 @@ def batch_signature(batch):
     return tuple((tuple(t.shape), t.dtype) for t in batch_tensors(batch))
 
 
+_capture_serial = 0
+_active_capture = None
+
+
+def active_capture():
+    """Serial number of the GraphedStep capture in progress on this thread of control, else None.  Values derived from a
+    batch tensor while THAT capture records (e.g. the per-mesh 1/count of a mask) are part of its graph — recomputed by every
+    replay — and may be shared by the blocks of the same capture; they must never outlive it (blocks.avg_block)."""
+    return _active_capture
+
+
 class GraphedStep:
     """`body(batch) -> loss` (forward, loss, backward into pre-existing .grad buffers) captured in a hipGraph.
 
@@ -104,8 +115,14 @@ class GraphedStep:
                 t.copy_(s0)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = self._run()
+        global _capture_serial, _active_capture
+        _capture_serial += 1
+        _active_capture = _capture_serial
+        try:
+            with torch.cuda.graph(self.graph):
+                self.loss = self._run()
+        finally:
+            _active_capture = None
         torch.cuda.synchronize()
         if warn_ctl is not None:
             warn_ctl(True)
