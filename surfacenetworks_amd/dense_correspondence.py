@@ -235,23 +235,34 @@ class _PairCrossEntropy(torch.autograd.Function):
     (log_softmax, nll_loss, their backward passes, the zero padding of the slice's gradient): sn_pair_ce_fwd/bwd_f32."""
 
     @staticmethod
-    def forward(ctx, S, target, NA, NB):
+    def forward(ctx, scores, target, NA, NB):
+        S = scores[0] if scores.dim() == 3 else scores       # (B, N, N): sample 0 is the one scored (main.py:238)
         lse, rowloss = kernels.pair_ce_fwd(S, target, NA, NB)
         ctx.save_for_backward(S, target, lse)
         ctx.dims = (NA, NB)
+        ctx.batch = scores.shape[0] if scores.dim() == 3 else None
         return rowloss.sum() / NA
 
     @staticmethod
     def backward(ctx, g):
         S, target, lse = ctx.saved_tensors
-        return kernels.pair_ce_bwd(S, target, lse, g.reshape(1).contiguous(), *ctx.dims), None, None, None
+        dS = kernels.pair_ce_bwd(S, target, lse, g.reshape(1).contiguous(), *ctx.dims)
+        if ctx.batch is None:
+            return dS, None, None, None
+        if ctx.batch == 1:                   # the gradient of `outputs[0]` as a view: no zero fill + copy of the (1, N, N) matrix
+            return dS.unsqueeze(0), None, None, None
+        full = dS.new_zeros((ctx.batch,) + tuple(dS.shape))
+        full[0] = dS
+        return full, None, None, None
 
 
-def pair_cross_entropy(S, target, NA: int, NB: int):
-    """Cross entropy of the NA x NB corner of the (padded) score matrix S against `target`, mean over rows."""
-    if S.dtype != torch.float32 or S.stride(-1) != 1:
+def pair_cross_entropy(scores, target, NA: int, NB: int):
+    """Cross entropy of the NA x NB corner of the (padded) score matrix against `target`, mean over rows.  `scores`: the
+    (N, N) matrix, or the (B, N, N) output of SiameseModel, of which sample 0 is scored."""
+    if scores.dtype != torch.float32 or scores.stride(-1) != 1:
+        S = scores[0] if scores.dim() == 3 else scores
         return F.cross_entropy(S[:NA, :NB], target)
-    return _PairCrossEntropy.apply(S, target, NA, NB)
+    return _PairCrossEntropy.apply(scores, target, NA, NB)
 
 
 def loss_fun_delta_cross_entropy(outputs, targetX, targetY):
@@ -262,7 +273,7 @@ def loss_fun_delta_cross_entropy(outputs, targetX, targetY):
         GB, lB, liB = targetY[i]
         NA, NB = lA.size(0), lB.size(0)
         GAB = correspondence_target(GA, lA, liA, GB, lB, liB)
-        loss = loss + pair_cross_entropy(outputs[0], GAB, NA, NB)
+        loss = loss + pair_cross_entropy(outputs, GAB, NA, NB)
     return loss / outputs.size(0)
 
 
@@ -402,7 +413,7 @@ class PairBatch:
 def forward_loss(model, b: PairBatch):
     """loss_fun_delta_cross_entropy for the one pair of a PairBatch (main.py:229-240 at batch size 1), target precomputed."""
     out = model(_operation(b.LX, b.mX), _operation(b.LY, b.mY), b.inX, b.inY)
-    return pair_cross_entropy(out[0], b.target, b.NA, b.NB).reshape(1)
+    return pair_cross_entropy(out, b.target, b.NA, b.NB).reshape(1)
 
 
 def graphed_train_step(model, optimizer, example: PairBatch, bucket=None):

@@ -838,3 +838,22 @@ def test_pair_cross_entropy_matches_torch(N, NA, NB):
         assert rel_err(gg.cpu().numpy(), gw.cpu().numpy()) < 5e-6
         assert gg[NA:].abs().max().item() == 0 if rows > NA else True
         assert gg[:, NB:].abs().max().item() == 0 if N > NB else True
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_pair_cross_entropy_takes_the_siamese_output(B):
+    """The (B, N, N) output of SiameseModel goes in whole: sample 0 is scored (main.py:238), the gradient comes back in the
+    output's shape — as a view of the kernel's result for B = 1, zero for the other samples otherwise."""
+    import torch.nn.functional as F
+
+    from surfacenetworks_amd import dense_correspondence as dc
+
+    g = torch.Generator().manual_seed(5 + B)
+    N, NA, NB = 96, 90, 93
+    out = torch.randn(B, N, N, generator=g).to(DEV).requires_grad_(True)
+    tgt = torch.randint(0, NB, (NA,), generator=g).to(DEV)
+    (gw,) = torch.autograd.grad(F.cross_entropy(out[0, :NA, :NB], tgt), out)
+    (gg,) = torch.autograd.grad(dc.pair_cross_entropy(out, tgt, NA, NB), out)
+    assert gg.shape == out.shape and rel_err(gg.cpu().numpy(), gw.cpu().numpy()) < 5e-6
+    if B > 1:
+        assert gg[1:].abs().max().item() == 0

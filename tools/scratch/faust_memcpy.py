@@ -1,6 +1,6 @@
 """which torch ops issue device-to-device copies in one FAUST pair step"""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from surfacenetworks_amd import dense_correspondence as dc
 from torch.profiler import profile, ProfilerActivity
 dev = "cuda"

@@ -1,6 +1,6 @@
 """cProfile of the eager FAUST pair step (host side): where do the ~16 us per launch go"""
 import cProfile, pstats, sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from surfacenetworks_amd import dense_correspondence as dc
 dev = "cuda"
 ds = dc.TorusBodies(4, device=dev)
