@@ -568,3 +568,58 @@ def test_non_finite_inputs_per_storage_form():
     assert bad[rows].all() and not np.delete(bad, rows).any()
     other = np.delete(np.arange(V), rows)
     assert np.array_equal(y[other], y_csr[other]) and np.array_equal(np.delete(y, 5, axis=1), np.delete(y_csr, 5, axis=1))
+
+
+def test_entry_points_from_two_host_threads_on_two_streams():
+    """include/sn_spmm.h: "re-entrant; safe from several host threads on different streams".  Two Python threads (ctypes
+    releases the GIL across the foreign call), each on its own stream with its own buffers, launch the Dirac / Laplacian
+    products, a statistics product (workspace + two kernels per call) and a fused Linear a few hundred times; every result
+    equals the one computed alone on the default stream, bit for bit."""
+    import threading
+
+    V, F, ops = mesh_fixture("delaunay", 3)
+    pools = {"Di": OperatorPool([ops["Di"].astype(np.float32)] * 24, DEV, want_bsr4=True),
+             "L": OperatorPool([ops["L"].astype(np.float32)] * 24, DEV)}
+    sel = np.arange(24)
+    Di, L = pools["Di"].assemble(sel), pools["L"].assemble(sel)
+    Di.q3(), L.rb4()                                       # derived forms built before the threads start
+    g = torch.Generator(device=DEV).manual_seed(11)
+    xv = torch.randn(Di.shape[1] // 4, 128, device=DEV, generator=g)
+    xl = torch.randn(L.shape[1], 128, device=DEV, generator=g)
+    W = torch.randn(128, 128, device=DEV, generator=g) * 0.1
+    b = torch.randn(128, device=DEV, generator=g)
+
+    def work(out):
+        yd = torch.empty(Di.shape[0] // 4, 128, device=DEV)
+        snF._launch(Di, xv, yd, 4)
+        yl = torch.empty(L.shape[0], 128, device=DEV)
+        part = snF._launch(L, xl, yl, 1, stats=True)
+        y = kernels.linear_fwd(xl, W, b)
+        out.append((yd, yl, None if part is None else part.clone(), y))
+
+    ref = []
+    work(ref)
+    torch.cuda.synchronize()
+    results, errors = {0: [], 1: []}, []
+
+    def runner(k):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(150):
+                    work(results[k])
+                s.synchronize()
+        except Exception as exc:  # noqa: BLE001
+            errors.append(exc)
+
+    threads = [threading.Thread(target=runner, args=(k,)) for k in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in (0, 1):
+        assert len(results[k]) == 150
+        for got in results[k][::7] + results[k][-3:]:
+            for a, r in zip(got, ref[0]):
+                assert (a is None and r is None) or torch.equal(a, r)
