@@ -31,8 +31,14 @@ from .operators import as_operator
 __all__ = ["lap_block", "dirac_block", "avg_block", "avg_block_ragged", "avg_block_ragged_ok", "take_activated", "attach_activated", "zero_faces_ok", "elu_conv", "elu_conv_ok"]
 
 
+def _version_of(t: torch.Tensor):
+    """The tensor's version counter; None for tensors made under torch.inference_mode() — they carry none (reading it
+    raises) and cannot be edited in place outside inference mode either, so there is nothing to compare."""
+    return None if t.is_inference() else t._version
+
+
 def attach_activated(t: torch.Tensor, cat: torch.Tensor) -> torch.Tensor:
-    t._sn_cat = (cat, t._version)
+    t._sn_cat = (cat, _version_of(t))
     return t
 
 
@@ -45,7 +51,7 @@ def take_activated(t: torch.Tensor, rows: int, C: int):
     if entry is None:
         return None
     cat, version = entry
-    if version != t._version or tuple(cat.shape) != (rows, 2 * C) or cat.device != t.device or cat.dtype != torch.float32:
+    if version != _version_of(t) or tuple(cat.shape) != (rows, 2 * C) or cat.device != t.device or cat.dtype != torch.float32:
         return None
     return cat
 
@@ -431,7 +437,7 @@ def avg_block(mod, mask, inputs):
     gen = active_capture() if capturing else None
     slot = "_sn_avg" if not capturing else ("_sn_avg_cap" if gen is not None else None)
     cached = getattr(mask, slot, None) if slot else None
-    key = (B, V, mask._version, gen)
+    key = (B, V, _version_of(mask), gen)
     if cached is None or cached[0] != key:
         cached = (key, mask.reshape(rows).contiguous(), 1.0 / mask.reshape(B, V).sum(1, keepdim=True))
         if slot:

@@ -395,10 +395,15 @@ class PairBatch:
 
         b = copy.copy(self)
         b.inX, b.inY, b.mX, b.mY, b.target = (t.clone() for t in (self.inX, self.inY, self.mX, self.mY, self.target))
-        own = lambda ops: tuple(o.clone() for o in ops) if isinstance(ops, (tuple, list)) else ops.clone()
+        own = lambda ops: type(ops)(o.clone() for o in ops) if isinstance(ops, (tuple, list)) else ops.clone()
         b.LX, b.LY = own(self.LX), own(self.LY)
         b.tX = b.tY = None
         return b
+
+    def graph_constants(self):
+        """Host values baked into the captured kernels' arguments (the corner of the score matrix the cross entropy reads):
+        part of the batch signature, so a pair with other vertex counts cannot be replayed through this capture."""
+        return (self.NA, self.NB)
 
     def graph_tensors(self):
         from .graphs import operator_tensors
@@ -424,9 +429,32 @@ def graphed_train_step(model, optimizer, example: PairBatch, bucket=None):
     return GraphedTrainStep(model, optimizer, example.owned(), forward_loss, bucket)
 
 
+class LSequence(list):
+    """The operator list of the 'amp' tower (main.py:72-83, 187-188): ONE positional argument of AmplifyModel.forward."""
+
+
 def _operation(ops, mask):
-    """[L, mask] or [Di, DiA, mask]: the `Operation` lists SiameseModel.forward unpacks (main.py:317-320)."""
+    """[L, mask], [L_sequence, mask] or [Di, DiA, mask]: the `Operation` lists SiameseModel.forward unpacks (main.py:317-320)."""
+    if isinstance(ops, LSequence):
+        return [ops, mask]
     return [*ops, mask] if isinstance(ops, (tuple, list)) else [ops, mask]
+
+
+def amplify_sequence(L):
+    """main.py:72-83: the stored Laplacian scaled by D^-1/2 on both sides (D = entries per row - 1), then twice
+    `L <- (D^-1/2 L D^-1/2)^2`; three float32 CSR matrices."""
+    import scipy.sparse as sp
+
+    L = L.astype("f").tocsr()
+    idp = L.indptr
+    Dsq = sp.diags(1 / np.sqrt(idp[1:] - idp[:-1] - 1)).astype("f")
+    L = Dsq.dot(L).dot(Dsq).astype("f")
+    out = [L.tocsr()]
+    for _ in range(2):
+        L = Dsq.dot(L).dot(Dsq).astype("f")
+        L = L.dot(L).tocsr()
+        out.append(L)
+    return out
 
 
 class FaustFrames:
@@ -436,7 +464,7 @@ class FaustFrames:
 
     def __init__(self, frames, model="lap", pad_to=None, device="cuda"):
         self.device = torch.device(device)
-        self.kind = "dir" if "dir" in model else "lap"
+        self.kind = "dir" if "dir" in model else ("amp" if "amp" in model else "lap")      # dispatch order of main.py:72-95
         self.frames = frames
         self.n = len(frames)
         nv = max(int(fr["V"].shape[0]) for fr in frames)
@@ -446,6 +474,9 @@ class FaustFrames:
         if self.kind == "dir":
             self.pool_Di = OperatorPool([fr["Di"] for fr in frames], self.device, want_bsr4=True)
             self.pool_DiA = OperatorPool([fr["DiA"] for fr in frames], self.device, want_bsr4=True)
+        elif self.kind == "amp":
+            seqs = [amplify_sequence(fr["L"]) for fr in frames]
+            self.pool_Lseq = [OperatorPool([s[j] for s in seqs], self.device) for j in range(3)]
         else:
             self.pool_L = OperatorPool([fr["L"] for fr in frames], self.device)
         self._samples = {}
@@ -463,6 +494,8 @@ class FaustFrames:
             if self.kind == "dir":
                 ops = (self.pool_Di.assemble([idx], 4 * self.pad_faces, 4 * self.pad_to),
                        self.pool_DiA.assemble([idx], 4 * self.pad_to, 4 * self.pad_faces))
+            elif self.kind == "amp":
+                ops = LSequence(pl.assemble([idx], self.pad_to, self.pad_to) for pl in self.pool_Lseq)
             else:
                 ops = self.pool_L.assemble([idx], self.pad_to, self.pad_to)
             hit = self._samples[idx] = (inputs, [(fr["G"], fr["label"], fr["label_inv"])], mask, ops)

@@ -31,6 +31,11 @@ def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
     if op is None:
         return []
     out: List[torch.Tensor] = []
+    # A CSR operator that arrives without its transpose (laplacian_operator_from_mesh, as_operator) would build it lazily in
+    # the warm-up backward — after the static list was taken — and every replay would then multiply by the EXAMPLE's
+    # transpose.  Built here, it is listed (and reloaded) with the operator's own arrays, as the pools' operators are.
+    if op._t is None and op._csr is not None and op.is_cuda:
+        op.t()
     for o in (op, op._t):
         if o is None:
             continue
@@ -66,7 +71,14 @@ def batch_tensors(batch) -> List[torch.Tensor]:
 
 
 def batch_signature(batch):
-    return tuple((tuple(t.shape), t.dtype) for t in batch_tensors(batch))
+    """Shapes and dtypes of the batch tensors, followed by the batch's `graph_constants()` — host values a capture bakes into
+    kernel arguments (e.g. PairBatch.NA / NB)."""
+    consts = tuple(batch.graph_constants()) if hasattr(batch, "graph_constants") else ()
+    return tuple((tuple(t.shape), t.dtype) for t in batch_tensors(batch)) + (("const",) + consts,)
+
+
+def batch_signature_constants(batch):
+    return ("const",) + (tuple(batch.graph_constants()) if hasattr(batch, "graph_constants") else ())
 
 
 _capture_serial = 0
@@ -140,6 +152,9 @@ class GraphedStep:
         if len(src) != len(self._static_tensors) or any(
                 s.shape != d.shape or s.dtype != d.dtype for s, d in zip(src, self._static_tensors)):
             raise ValueError("batch does not match the captured signature; capture a new GraphedStep")
+        if self.signature[-1] != batch_signature_constants(batch):
+            raise ValueError(f"batch constants {batch_signature_constants(batch)[1:]} differ from the captured ones "
+                             f"{self.signature[-1][1:]}; capture a new GraphedStep")
         with torch.no_grad():
             # one multi-tensor launch per dtype: a mixed list (fp32 values, int32 indices, int64 tables) would take the
             # op's slow path, one device-to-device copy per tensor (37 copies of ~10 us for a FAUST pair)
@@ -188,14 +203,24 @@ class GraphedTrainStep:
         # (the `zero_grads` slot of GraphedStep runs before the body, at warm-up and at capture time: host code, not recorded)
         self.step = GraphedStep(body, example, drop, preserve=list(model.buffers()))
         self.grads = [p.grad for p in self.params]      # static; None for a parameter the loss does not reach
+        # A replay leaves its gradients in the graph's own buffers, NOT in a FlatGradBucket's slices: the only reduction that
+        # sees them is one that packs `.grad` first (`bucket.sync`).  With `bucket` given the step runs that itself.
+        self.bucket = bucket
 
     def matches(self, batch) -> bool:
         return self.step.matches(batch)
 
     def __call__(self, batch, grad_sync=None):
+        if grad_sync is not None and getattr(grad_sync, "__func__", None) is getattr(type(self.bucket), "all_reduce", False):
+            # (the pre-round-2 pattern `graphed(batch, grad_sync=bucket.all_reduce)` would reduce a buffer the replay never
+            # wrote and every rank would then step on its local gradients only)
+            raise ValueError("GraphedTrainStep stores its gradients outside the bucket: pass grad_sync=bucket.sync "
+                             "(or nothing: a step built with bucket= reduces by itself)")
         loss = self.step(batch)
         for p, g in zip(self.params, self.grads):
             p.grad = g
+        if grad_sync is None and self.bucket is not None:
+            grad_sync = self.bucket.sync
         if grad_sync is not None:
             grad_sync()
         self.optimizer.step()

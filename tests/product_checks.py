@@ -100,23 +100,32 @@ def _bn_train_only(m):
     return m
 
 
-def check_model(golden_dir, tag, dev, opkind="pool", tol_out=5e-5):
+def check_model(golden_dir, tag, dev, opkind="pool", tol_out=5e-5, classes=None):
+    """`classes`: tag -> constructor of the model under test (default: the product's own model classes; the import-swap test
+    passes the REFERENCE's classes built on top of the product's utils_pt)."""
     from surfacenetworks_amd import arap, dense_correspondence, mesh_mnist
     from surfacenetworks_amd.operators import OperatorPool
 
+    make = {"arap_dir": arap.DirModel, "arap_lap": lambda: arap.Model(15), "mnist_lap": mesh_mnist.Model,
+            "mnist_dir": mesh_mnist.DirModel, "faust_lap": lambda: dense_correspondence.SiameseModel("lap", 15)}
+    make.update(classes or {})
     g = load(golden_dir, "models_reference.npz")
     if tag == "faust_lap":
         rb = load(golden_dir, "ragged_batch.npz")
         nv = int(rb["nv"])
         L = csr_of(load(golden_dir, "ops_delaunay150.npz"), "L")
-        L1 = OperatorPool([L], dev).assemble([0], nv, nv)
+        if opkind == "pool":
+            L1 = OperatorPool([L], dev).assemble([0], nv, nv)
+        else:                                        # what an unmodified driver hands over: sparse_diag_cat's COO tensor
+            import surfacenetworks_amd.utils_pt as U
+            L1 = U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(L)], nv, nv).coalesce().to(dev)
         lA, lB = torch.from_numpy(g["faust_lA"]).to(dev), torch.from_numpy(g["faust_lB"]).to(dev)
         tX = [(torch.from_numpy(g["faust_GA"]).to(dev), lA, torch.argsort(lA))]
         tY = [(torch.from_numpy(g["faust_GB"]).to(dev), lB, torch.argsort(lB))]
         cA = torch.from_numpy(rb["coords"][1:2]).to(dev)
         cB = torch.from_numpy(rb["coords"][1:2] * 1.1 + 0.02).to(dev)
         mask = torch.from_numpy(rb["mask"][1:2]).to(dev)
-        m = deterministic_init(dense_correspondence.SiameseModel("lap", 15), 11).train().to(dev)
+        m = deterministic_init(make["faust_lap"](), 11).train().to(dev)
         out = m([L1, mask], [L1, mask], cA, cB)
         loss = dense_correspondence.loss_fun_delta_cross_entropy(out, tX, tY)
         loss.backward()
@@ -145,19 +154,19 @@ def check_model(golden_dir, tag, dev, opkind="pool", tol_out=5e-5):
     B = mask.shape[0]
     t = lambda a: torch.from_numpy(a).to(dev)
     if tag == "arap_dir":
-        m = deterministic_init(arap.DirModel(), 7).train().to(dev)
+        m = deterministic_init(make["arap_dir"](), 7).train().to(dev)
         out = m(ops["Di"], ops["DiA"], mask, t(g["inputs6"]))
         loss = arap.loss_fn(out, t(g["targets"]), mask, B)
     elif tag == "arap_lap":
-        m = deterministic_init(arap.Model(15), 8).train().to(dev)
+        m = deterministic_init(make["arap_lap"](), 8).train().to(dev)
         out = m(ops["L"], mask, t(g["inputs6"]))
         loss = arap.loss_fn(out, t(g["targets"]), mask, B)
     elif tag == "mnist_lap":
-        m = _bn_train_only(deterministic_init(mesh_mnist.Model(), 9)).to(dev)
+        m = _bn_train_only(deterministic_init(make["mnist_lap"](), 9)).to(dev)
         out = m(t(rb["coords"]), ops["L"], mask)
         loss = torch.nn.functional.nll_loss(out, t(g["labels"]))
     elif tag == "mnist_dir":
-        m = _bn_train_only(deterministic_init(mesh_mnist.DirModel(), 10)).to(dev)
+        m = _bn_train_only(deterministic_init(make["mnist_dir"](), 10)).to(dev)
         out = m(t(rb["coords"]), ops["Di"], ops["DiA"], mask)
         loss = torch.nn.functional.nll_loss(out, t(g["labels"]))
     else:
@@ -787,3 +796,60 @@ def check_packed_model(dev):
     before = torch.cat([p_.detach().reshape(-1) for p_ in m.parameters()]).clone()
     l1 = arap.train_step(m, opt, ds.sample_batch(5, None, seq_ids=ids, offsets=offs, packed=True))
     assert torch.isfinite(l1) and not torch.equal(before, torch.cat([p_.detach().reshape(-1) for p_ in m.parameters()]))
+
+
+def check_inference_mode(golden_dir, dev):
+    """A forward under torch.inference_mode(): inference tensors carry no version counter (reading it raises), so the
+    activated hand-off between blocks and the per-mask cache must not ask for one.  Same values as under no_grad."""
+    from surfacenetworks_amd import arap
+
+    rb, ops = batch_operators(golden_dir, "pool", dev)
+    g = load(golden_dir, "models_reference.npz")
+    mask = torch.from_numpy(rb["mask"]).to(dev)
+    x = torch.from_numpy(g["inputs6"]).to(dev)
+    for make, args in ((arap.DirModel, ("Di", "DiA")), (lambda: arap.Model(15), ("L",))):
+        # (train-mode BatchNorm: with the fixture's untrained running statistics the 15 cotangent-Laplacian layers overflow)
+        m = deterministic_init(make(), 7).train().to(dev)
+        with torch.no_grad():
+            want = m(*(ops[k] for k in args), mask, x)
+        with torch.inference_mode():
+            got = m(*(ops[k] for k in args), mask.clone(), x.clone())
+        assert torch.isfinite(want).all() and torch.equal(got, want)
+
+
+def check_faust_amp_tower(golden_dir, dev):
+    """The 'amp' tower fed from FAUST files: the operator sequence of main.py:72-83 (D^-1/2 scaling, two squarings) as ONE
+    list argument of AmplifyModel.forward (main.py:187-188), forward + backward."""
+    import scipy.sparse as sps
+
+    from surfacenetworks_amd import datasets, dense_correspondence as dc
+
+    p = os.path.join(golden_dir, "data_faust_frame.npz")
+    fr = datasets.load_faust_frame(p, device=dev)
+    seq = dc.amplify_sequence(fr["L"])
+    # independent restatement of main.py:72-83 in float64 on dense matrices
+    L = fr["L"].astype(np.float64).toarray()
+    cnt = np.diff(fr["L"].tocsr().indptr) - 1
+    Dm = np.diag(1.0 / np.sqrt(cnt.astype(np.float32)).astype(np.float64))
+    cur = Dm @ L @ Dm
+    want = [cur]
+    for _ in range(2):
+        cur = Dm @ cur @ Dm
+        cur = cur @ cur
+        want.append(cur)
+    assert len(seq) == 3
+    for got, w in zip(seq, want):
+        assert sps.issparse(got) and got.dtype == np.float32
+        assert rel_err(got.toarray(), w) <= 5e-6
+    ds = datasets.faust_from_files([p, p], device=dev, model="amp", pad_to=64)
+    inX, tX, mX, LX = ds.sample(0)
+    assert isinstance(LX, dc.LSequence) and len(LX) == 3 and tuple(LX[0].shape) == (64, 64)
+    assert len(dc._operation(LX, mX)) == 2                      # [L_sequence, mask]: one positional argument, not splatted
+    model = deterministic_init(dc.SiameseModel("amp", 15), 13).train().to(dev)
+    loss = dc.forward_pair_loss(model, ds, 0, 1)
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(q.grad).all() for q in model.parameters() if q.grad is not None)
+    pb = dc.PairBatch(ds, 0, 1)
+    assert pb.graph_constants() == (pb.NA, pb.NB) and len(pb.graph_tensors()) > 5
+    own = pb.owned()
+    assert isinstance(own.LX, dc.LSequence) and own.LX[0].rowptr.data_ptr() != pb.LX[0].rowptr.data_ptr()

@@ -67,3 +67,30 @@ def test_siamese_gradients_meet_once(cpu_kernels):
 
 def test_mnist_driver_evaluation_mode(cpu_kernels):
     pc.check_mnist_evaluation_mode("cpu")
+
+
+def test_forward_under_inference_mode(golden_dir, cpu_kernels):
+    pc.check_inference_mode(golden_dir, "cpu")
+
+
+def test_faust_amp_tower_from_files(golden_dir, cpu_kernels):
+    pc.check_faust_amp_tower(golden_dir, "cpu")
+
+
+def test_graph_signature_carries_batch_constants():
+    """PairBatch.NA / NB are baked into the captured kernels' arguments: they are part of the signature GraphedStep compares."""
+    from surfacenetworks_amd import graphs
+
+    class B:
+        def __init__(self, n, consts):
+            self.t, self.c = [torch.zeros(n)], consts
+
+        def graph_tensors(self):
+            return self.t
+
+        def graph_constants(self):
+            return self.c
+
+    assert graphs.batch_signature(B(3, (5, 6))) == graphs.batch_signature(B(3, (5, 6)))
+    assert graphs.batch_signature(B(3, (5, 6))) != graphs.batch_signature(B(3, (5, 7)))
+    assert graphs.batch_signature_constants(B(3, (5, 7))) == ("const", 5, 7)
