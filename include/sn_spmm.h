@@ -237,6 +237,30 @@ int sn_spmm_rb4_stats_f32(const int32_t *b_ptr, const int32_t *b_col, const floa
                           double *stats_part, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Sliding-window ("ring") product for BANDED SQUARE CSR operators — the Laplacian products torch.mm(L, x) at 64 / 128
+ * channels (src/utils/utils_pt.py:167,176) on batches that fill the chip; same arguments, epilogue and statistics semantics
+ * as sn_spmm_csr_f32 / _elubwd_f32 / _stats_f32 with group = 1, straight from the CSR arrays (no derived form).
+ * A persistent workgroup walks a strip of rows and keeps the X rows within +-sn_spmm_csr_ring_half_window() of the current
+ * rows in an LDS ring: every X line and every entry is requested once per 64-column slice, by LDS-DMA.  Columns outside
+ * the window are gathered from global memory (correct for ANY operator, fast for banded ones): callers decide with
+ * sn_csr_band_i32, which leaves max |column - row|, the longest row and the number of rows with an entry outside the window
+ * in band_longest_outside[0..2] (device memory).
+ * Requirements: M == K, N in {64, 128}, columns ascending inside each row; SN_E_UNSUPPORTED otherwise.
+ * Results are bit-identical to sn_spmm_csr_f32 (same k-ascending FMA order per row).
+ * ------------------------------------------------------------------------------------------ */
+int sn_spmm_csr_ring_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
+                         const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, void *stream);
+int sn_spmm_csr_ring_elubwd_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
+                                int64_t nnz, const float *X, int64_t ldx, int32_t N, const float *E, int64_t lde, const float *G,
+                                int64_t ldg, float *Y, int64_t ldy, void *stream);
+size_t sn_spmm_csr_ring_stats_workspace_bytes(int64_t M);
+int sn_spmm_csr_ring_stats_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
+                               const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, double *stats_part, void *workspace,
+                               size_t workspace_bytes, void *stream);
+int32_t sn_spmm_csr_ring_half_window(void);
+int sn_csr_band_i32(const int32_t *rowptr, const int32_t *colind, int64_t M, int64_t K, int32_t *band_longest_outside, void *stream);
+
+/* ------------------------------------------------------------------------------------------
  * Block-diagonal batch assembly from a device-resident pool of per-mesh operators.
  *
  * Replaces: sparse_diag_cat(tensors, size0, size1)                       src/utils/utils_pt.py:41-53

@@ -9,11 +9,15 @@
 // Interfaces and the reference code they replace: include/sn_spmm.h.
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <limits.h>
 #include <stdint.h>
 #include <stdlib.h>
 
 #include "sn_spmm.h"
+
+// per-launch timing shared with sn_kernels.hip (the facility behind sn_timing_*)
+bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e);
 
 namespace {
 
@@ -1884,7 +1888,13 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
   const int64_t sr = segmented ? rows_per_seg : 0;
   const bool uni = x3 && wgrad_variant() == 2 && lddy < ((int64_t)1 << 24) && ldx < ((int64_t)1 << 24);
   if (ragged && !uni) return SN_E_UNSUPPORTED;              // slab tables: the uniform-wave kernel only
-  if (uni && C == 128)
+  hipEvent_t t_start = nullptr, t_stop = nullptr;
+  if (uni) sn_internal_timing_slot(0x400 | (segmented ? 1 : 0) | (ragged ? 2 : 0), rows, C, rows * 4 * ((int64_t)J + C), J, &t_start, &t_stop);
+  if (uni && C == 128 && t_start)
+    hipExtLaunchKernelGGL((wgrad_u_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
+  else if (uni && t_start)
+    hipExtLaunchKernelGGL((wgrad_u_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
+  else if (uni && C == 128)
     hipLaunchKernelGGL((wgrad_u_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
   else if (uni)
     hipLaunchKernelGGL((wgrad_u_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);

@@ -14,10 +14,14 @@
 //   D layout: lane (n, h = l>>5) holds, for its data row n, the 16 outputs at columns 8g + 4h + q (g, q = 0..3):
 //   four 16-byte pieces per tile — the epilogue (bias / residual / ELU copy, or the BatchNorm tail) works on them.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 
 #include "sn_spmm.h"
+
+// per-launch timing shared with sn_kernels.hip (the facility behind sn_timing_*)
+bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e);
 
 namespace {
 
@@ -829,13 +833,18 @@ inline int gemm_variant() {
 }
 
 #define SN_UNPAREN(...) __VA_ARGS__
-// launch gemm_rows_split_k<PC, TARGS...> with PC chosen by SN_GEMM_VARIANT (2: fp16 pieces, else bf16 pieces)
+// launch gemm_rows_split_k<PC, TARGS...> with PC chosen by SN_GEMM_VARIANT (2: fp16 pieces, else bf16 pieces); with the
+// timing facility on (sn_timing_enable: t_start / t_stop of the enclosing entry point) the kernel's own start / stop go
+// into two events
 #define SN_SPLIT_LAUNCH(TARGS, ...)                                                                                    \
   do {                                                                                                                 \
-    if (gemm_variant() == 2)                                                                                           \
-      hipLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__);          \
-    else                                                                                                               \
-      hipLaunchKernelGGL((gemm_rows_split_k<3, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__);          \
+    if (gemm_variant() == 2) {                                                                                         \
+      if (t_start) hipExtLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, t_start, t_stop, 0, __VA_ARGS__); \
+      else hipLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__);     \
+    } else {                                                                                                           \
+      if (t_start) hipExtLaunchKernelGGL((gemm_rows_split_k<3, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, t_start, t_stop, 0, __VA_ARGS__); \
+      else hipLaunchKernelGGL((gemm_rows_split_k<3, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__);     \
+    }                                                                                                                  \
   } while (0)
 
 // Workgroups per CU.  One 4-wave workgroup per CU is a single wave per SIMD that owns the register file; the K = 128, one-tile
@@ -881,6 +890,10 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const bool x3 = gemm_variant() != 0;
+  hipEvent_t t_start = nullptr, t_stop = nullptr;
+  if (x3)
+    sn_internal_timing_slot(0x100 | (residual ? 2 : 0) | (y_elu ? 1 : 0) | (y ? 4 : 0), rows, K,
+                            rows * 4 * ((int64_t)K + (y ? J : 0) + (residual ? J : 0) + (y_elu ? J : 0)), J, &t_start, &t_stop);
 #define SN_X3_FWD(KK, RES, EL) SN_SPLIT_LAUNCH((KK, 1, false, EPI_FWD, RES, EL), x, ldx, W, ldw, y, ldy, rows, ep)
   if (x3) {
     const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
@@ -919,6 +932,8 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   const bool x3 = gemm_variant() != 0;
+  hipEvent_t t_start = nullptr, t_stop = nullptr;
+  if (x3) sn_internal_timing_slot(0x200 | (B ? 1 : 0), rows, C, rows * 4 * ((int64_t)J + C + (B ? C : 0)), J, &t_start, &t_stop);
   if (C == 256 && x3 && B)
     SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD, true, false), dy, lddy, W, ldw, dx, lddx, rows, ep);
   else if (C == 256 && x3)
@@ -953,6 +968,8 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
   float *out = dx_hi - half;           // the kernel indexes absolute columns; only columns >= half are written through `out`
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
+  hipEvent_t t_start = nullptr, t_stop = nullptr;
+  sn_internal_timing_slot(0x200 | 2 | (gadd ? 4 : 0), rows, C, rows * 4 * ((int64_t)J + C + C + (gadd ? half : 0)), J, &t_start, &t_stop);
   if (C == 256)
     SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, out,
                        lddx, rows, ep);
@@ -984,6 +1001,9 @@ static int fwd_segbias_launch(const float *x, int64_t ldx, const float *W, int64
              elu_stats_part, sn_linear_fwd_stats_blocks(rows), (int)J, segoff, nseg};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
+  hipEvent_t t_start = nullptr, t_stop = nullptr;
+  sn_internal_timing_slot(0x100 | 8 | (residual ? 2 : 0) | (y_elu ? 1 : 0) | (y ? 4 : 0), rows, K,
+                          rows * 4 * ((int64_t)K + (y ? J : 0) + (residual ? J : 0) + (y_elu ? J : 0)), J, &t_start, &t_stop);
   const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
   switch (sel) {
     case 0: SN_X3_FWD(128, false, false); break;
@@ -1036,6 +1056,8 @@ static int dgrad_eluseg_launch(const float *dy, int64_t lddy, const float *W, in
              nullptr, 0, (int)J, segoff, nseg};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
+  hipEvent_t t_start = nullptr, t_stop = nullptr;
+  sn_internal_timing_slot(0x200 | 8 | (gadd ? 4 : 0), rows, C, rows * 4 * ((int64_t)J + C + C + (gadd ? C : 0)), J, &t_start, &t_stop);
   float *none = nullptr;               // every column leaves through gact: nothing is written through Out
   if (C == 256)
     SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, none,

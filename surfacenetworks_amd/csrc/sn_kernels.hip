@@ -1204,6 +1204,365 @@ __global__ __launch_bounds__(kWG) void spmm_rb4_stats(const int *__restrict__ b_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Sliding-window ("ring") CSR SpMM for banded square operators — the Laplacian products at 64 / 128 dense columns
+// (the products at src/utils/utils_pt.py:167,176) on batches large enough to fill the chip.
+//
+// What bounds the gather kernels above (csr_rows, rb4) is the number of L2 requests: a mesh Laplacian in row-major vertex
+// order touches three index bands, a band is re-used ~m rows later, and 128-channel rows do not survive that long in the
+// 32 KiB vector cache — every gather goes to L2 (3.4 requests per compulsory line with RB4, rocprofv3 PMC).
+// Here a PERSISTENT workgroup walks a strip of consecutive rows in steps of R and keeps the X rows [r - H, r + R + H) of a
+// 64-column slice in an LDS ring addressed by (row mod W): every X line and every CSR entry is requested ONCE per slice,
+// by fully coalesced LDS-DMA (global_load_lds: 1 KiB per wave instruction), and all irregular access happens in LDS.
+//   * NLW loader waves only issue DMA (the X piece, the entries and the row pointers of step t + D) and wait with a
+//     partial s_waitcnt vmcnt — they never store, so their counter counts DMA only and D steps stay in flight;
+//   * R/8 compute waves (one 8-row round per step: 8 lanes x 2 float4 per row) read LDS, multiply and store; they never
+//     wait for their stores; one s_barrier per step (no implicit vmcnt(0));
+//   * a column outside the window (|c - r| > H: wrap-around rows of closed meshes, unordered meshes) is gathered from
+//     global memory inside the same batch ("mixed" rounds); rows of more than 32 entries take an entry-by-entry path.
+// Same k-ascending FMA chain per row as every other CSR kernel: bit-identical results (slots past a row's end multiply the
+// row's own first column by 0, as in spmm_csr_v4).  Measured (MI355X, 128 channels): 0.65-0.67 of the HBM roofline on the
+// config-5 Laplacian batch (RB4: 0.55-0.58), 0.83 on the config-3-sized batch (0.72-0.79), 0.81 on config 4's (0.57).
+// ------------------------------------------------------------------------------------------------
+constexpr int kRingCS = 64;          // dense columns per slice (one 256-byte piece of an X row)
+constexpr int kRingW = 512;          // ring rows (128 KiB)
+constexpr int kRingR = 64;           // rows per step
+constexpr int kRingH = 160;          // half window: columns within +-H of the row come from the ring
+constexpr int kRingD = 2;            // steps of DMA in flight
+constexpr int kRingNLW = 4;          // loader waves
+constexpr int kRingNCW = kRingR / 8; // compute waves
+constexpr int kRingThreads = (kRingNCW + kRingNLW) * 64;
+constexpr int kRingECap = kRingR * 8;                     // entry slots per step buffer
+constexpr int kRingRPS = kRingR + 64;                     // row-pointer slots per step buffer
+constexpr size_t kRingLds = (size_t)kRingW * kRingCS * 4 + (size_t)(kRingD + 1) * kRingECap * 8 + (size_t)(kRingD + 1) * kRingRPS * 4;
+static_assert(kRingW >= (kRingD + 1) * kRingR + 2 * kRingH && (kRingW & (kRingW - 1)) == 0, "ring too small");
+static_assert(kRingLds <= 160 * 1024, "LDS");
+
+template <int N_>
+__device__ __forceinline__ void wait_vmcnt_imm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+
+// (A x) * elu'(e) + g with the product rounded BEFORE the addition, as the unfused composition and the other fused kernels do
+// (with the operands in registers the compiler would otherwise contract the two into one fma)
+__device__ __forceinline__ f4 ring_epilogue(f4 a, const f4 &e, const f4 &g, bool has_g) {
+#pragma clang fp contract(off)
+  f4 p = elu_bwd4(a, e);
+  if (has_g) p = p + g;
+  return p;
+}
+
+template <bool EPI, bool STATS>
+__global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restrict__ rowptr, const int *__restrict__ colind,
+                                                            const float *__restrict__ vals, int M, int K, int nnz,
+                                                            const float *__restrict__ X, int64_t ldx, float *__restrict__ Y,
+                                                            int64_t ldy, int nstrips, int cps, int nsl, SpmmEpi epi,
+                                                            float *__restrict__ stats_part) {
+  constexpr int CS = kRingCS, W = kRingW, R = kRingR, H = kRingH, D = kRingD, NLW = kRingNLW, NCW = kRingNCW;
+  constexpr int ECAP = kRingECap, NB = D + 1, RPS = kRingRPS;
+  constexpr int LPX = CS / 4, RPI = 64 / LPX;   // lanes per X row in a DMA instruction, rows per instruction
+  constexpr int NV = CS / 32;                   // float4 pieces per lane
+  // DMA instructions of ONE step per loader wave: a constant, so that the partial wait is an immediate
+  constexpr int NX = (R / RPI + NLW - 1) / NLW;
+  constexpr int NE = 2 * ((ECAP / 64 + NLW - 1) / NLW);
+  constexpr int NR = ((R + 1 + 63) / 64 + NLW - 1) / NLW;
+  constexpr int NSTEP = NX + NE + NR;
+  static_assert((D - 1) * NSTEP <= 63 && R % RPI == 0 && H % RPI == 0 && ECAP % 64 == 0, "shape");
+  extern __shared__ __attribute__((aligned(16))) unsigned char ring_smem[];
+  float *xs = reinterpret_cast<float *>(ring_smem);                   // W x CS floats
+  int *sc = reinterpret_cast<int *>(xs + W * CS);                     // [NB][ECAP]
+  float *sv = reinterpret_cast<float *>(sc + NB * ECAP);              // [NB][ECAP]
+  int *rp = reinterpret_cast<int *>(sv + NB * ECAP);                  // [NB][RPS]
+
+  // workgroup b runs on XCD b % 8: an XCD owns a contiguous eighth of the strips, the slices of a strip sit next to each
+  // other in dispatch order (they read the same entries: the second reader hits L2)
+  const int b = blockIdx.x, xcd = b & 7, li = b >> 3;
+  const int spx = nstrips >> 3;
+  const int strip = xcd * spx + li / nsl, sl = li % nsl;
+  const int nsteps = (M + R - 1) / R;
+  const int t0 = strip * cps;
+  const int t1 = (t0 + cps) < nsteps ? (t0 + cps) : nsteps;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int c0 = sl * CS;
+  const bool idle = li / nsl >= spx || t0 >= t1;                      // (a strip past the end: nothing to do)
+  if (idle) {
+    if constexpr (STATS) {
+      if (li / nsl < spx && threadIdx.x < 2 * CS)
+        stats_part[(int64_t)strip * 256 + (threadIdx.x / CS) * 128 + c0 + (threadIdx.x % CS)] = 0.f;
+    }
+    return;
+  }
+
+  if (wave >= NCW) {
+    // ------------------------------------------------------------------ loader waves
+    const int lw = wave - NCW;
+    const float *xg = X + c0 + (lane % LPX) * 4;
+    auto issue_rows = [&](int row0, int i) {                          // RPI rows from row0 + RPI*i -> ring
+      int row = row0 + RPI * i + lane / LPX;
+      row = row < 0 ? 0 : (row < K ? row : K - 1);
+      __builtin_amdgcn_global_load_lds(xg + (int64_t)row * ldx, xs + ((row0 + RPI * i) & (W - 1)) * CS, 16, 0, 0);
+    };
+    auto issue_step = [&](int t) {                                    // X piece, entries, row pointers of step t: NSTEP instr.
+      const int buf = t % NB;
+      const int x0 = t * R + H;
+#pragma unroll
+      for (int q = 0; q < NX; ++q) {
+        int i = lw + q * NLW;
+        i = i < R / RPI ? i : R / RPI - 1;
+        issue_rows(x0, i);
+      }
+      const int64_t ra = (int64_t)t * R, rb = ra + R;
+      const int k0 = rowptr[ra < M ? ra : M], k1 = rowptr[rb < M ? rb : M];
+      int ne = k1 - k0;
+      ne = ne < ECAP ? ne : ECAP;                                     // (entries past the buffer are read from global memory)
+#pragma unroll
+      for (int q = 0; q < NE / 2; ++q) {
+        int p0 = (lw + q * NLW) * 64;
+        p0 = p0 < ECAP ? p0 : ECAP - 64;
+        int p = p0 + lane;
+        p = p < ne ? p : (ne > 0 ? ne - 1 : 0);
+        int k = k0 + p;
+        k = k < nnz ? k : nnz - 1;
+        __builtin_amdgcn_global_load_lds(colind + k, sc + buf * ECAP + p0, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(vals + k, sv + buf * ECAP + p0, 4, 0, 0);
+      }
+      const int r0 = t * R;
+      int nr = M - r0;
+      nr = nr < R ? (nr > 0 ? nr : 0) : R;
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        int p0 = (lw + q * NLW) * 64;
+        p0 = p0 < RPS ? p0 : RPS - 64;
+        int p = p0 + lane;
+        p = p < nr + 1 ? p : nr;
+        int r = r0 + p;
+        r = r < M ? r : M;
+        __builtin_amdgcn_global_load_lds(rowptr + r, rp + buf * RPS + p0, 4, 0, 0);
+      }
+    };
+    // prologue: the first window [t0 R - H, t0 R + H) and the steps t0 .. t0 + D - 1 (steps past the end are loaded too:
+    // clamped addresses, dead ring slots — the instruction counts stay uniform)
+    for (int i = lw; i < 2 * H / RPI; i += NLW) issue_rows(t0 * R - H, i);
+#pragma unroll
+    for (int d = 0; d < D; ++d) issue_step(t0 + d);
+    wait_vmcnt_imm<(D - 1) * NSTEP>();
+    __builtin_amdgcn_s_barrier();
+    for (int t = t0; t < t1; ++t) {
+      issue_step(t + D);
+      wait_vmcnt_imm<(D - 1) * NSTEP>();                              // step t + 1 has landed
+      __builtin_amdgcn_s_barrier();
+    }
+    wait_vmcnt_imm<0>();                                              // nothing may land in LDS after the workgroup has gone
+    return;
+  }
+
+  // -------------------------------------------------------------------- compute waves
+  const int g = lane >> 3, sub = lane & 7;
+  const float *xl = xs + sub * 4;
+  const float *xgl = X + c0 + sub * 4;
+  f4 ssum[NV], ssq[NV];
+#pragma unroll
+  for (int v = 0; v < NV; ++v) ssum[v] = ssq[v] = f4{0.f, 0.f, 0.f, 0.f};
+  f4 evn[NV], gvn[NV];                                                // epilogue operands of the NEXT step (requested a step ahead)
+  if constexpr (EPI) {
+    const int rf = t0 * R + wave * 8 + g;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      evn[v] = gvn[v] = f4{0.f, 0.f, 0.f, 0.f};
+      if (rf < M) {
+        evn[v] = ld4_s(epi.e + (int64_t)rf * epi.lde + c0 + v * 32 + sub * 4, kStreamNT);
+        if (epi.g) gvn[v] = ld4_s(epi.g + (int64_t)rf * epi.ldg + c0 + v * 32 + sub * 4, kStreamNT);
+      }
+    }
+  }
+  __builtin_amdgcn_s_barrier();
+  for (int t = t0; t < t1; ++t) {
+    asm volatile("" ::: "memory");
+    const int buf = t % NB;
+    const int *scb = sc + buf * ECAP;
+    const float *svb = sv + buf * ECAP;
+    const int *rpb = rp + buf * RPS;
+    const int r0 = t * R;
+    const int nr = (M - r0) < R ? (M - r0) : R;
+    const int wlo = r0 - H;
+    const int lr = wave * 8 + g;
+    const bool live = lr < nr;
+    const int r = r0 + lr;
+    const int k0 = rpb[0];                                            // entry held by slot 0 of the buffer
+    int kb = 0, ke = 0;
+    if (live) {
+      kb = rpb[lr] - k0;
+      ke = rpb[lr + 1] - k0;
+    }
+    f4 ev[NV], gv[NV];
+    if constexpr (EPI) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        ev[v] = evn[v];
+        gv[v] = gvn[v];
+      }
+      const int rn = r + R;                                           // this lane group's row of the next step
+      if (rn < M && t + 1 < t1) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          evn[v] = ld4_s(epi.e + (int64_t)rn * epi.lde + c0 + v * 32 + sub * 4, kStreamNT);
+          if (epi.g) gvn[v] = ld4_s(epi.g + (int64_t)rn * epi.ldg + c0 + v * 32 + sub * 4, kStreamNT);
+        }
+      }
+    }
+    const int len = ke - kb;
+    const bool fits = ke <= ECAP && len <= 32;
+    int cf = r0 < K ? r0 : K - 1, cl = cf;                            // (an empty row: any loaded column, multiplied by 0)
+    if (len > 0 && fits) {
+      cf = scb[kb];
+      cl = scb[ke - 1];                                               // columns ascend within a row: first and last bound the rest
+    }
+    const bool inwin = (unsigned)(cf - wlo) < (unsigned)(R + 2 * H) && (unsigned)(cl - wlo) < (unsigned)(R + 2 * H);
+    f4 acc[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[v] = f4{0.f, 0.f, 0.f, 0.f};
+    if (__builtin_amdgcn_ballot_w64(!fits) == 0) {
+      // batches of 8 slots per row, read from kb onwards whatever the row's length: a slot past the row's end holds the next
+      // rows' entries (or spare buffer words) and becomes (first column, 0) — fma(0, x, acc) == acc
+      int kmax = 8;
+      if (__builtin_amdgcn_ballot_w64(len > 8)) kmax = 16;
+      if (__builtin_amdgcn_ballot_w64(len > 16)) kmax = 32;
+      const bool allin = __builtin_amdgcn_ballot_w64(!inwin) == 0;    // wave-uniform
+      for (int k = 0; k < kmax; k += 8) {
+        int c[8];
+        float a[8];
+        f4 x[8][NV];
+        const int *cp = scb + kb + k;
+        const float *ap = svb + kb + k;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          c[j] = cp[j];
+          a[j] = ap[j];
+        }
+        if (allin) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int cj = k + j < len ? c[j] : cf;
+            a[j] = k + j < len ? a[j] : 0.f;
+            const float *xp = xl + (cj & (W - 1)) * CS;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) x[j][v] = *reinterpret_cast<const f4 *>(xp + v * 32);
+          }
+        } else {
+          // mixed round: every slot is read from the ring AND, where its column lies outside the window, from global memory
+          // (lanes inside are masked off), all loads in flight together
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int cj = k + j < len ? c[j] : cf;
+            a[j] = k + j < len ? a[j] : 0.f;
+            const bool in = (unsigned)(cj - wlo) < (unsigned)(R + 2 * H);
+            const float *xp = xl + (cj & (W - 1)) * CS;
+            const float *gp = xgl + (int64_t)cj * ldx;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+              x[j][v] = *reinterpret_cast<const f4 *>(xp + v * 32);
+              if (!in) x[j][v] = ld4(gp + v * 32);
+            }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+#pragma unroll
+          for (int v = 0; v < NV; ++v) acc[v] = fma4(a[j], x[j][v], acc[v]);
+        }
+      }
+      if (len <= 0) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = f4{0.f, 0.f, 0.f, 0.f};  // (an empty row is 0 whatever the placeholder column held)
+      }
+    } else {
+      for (int k = kb; k < ke; ++k) {                                 // rows of more than 32 entries / past the buffer: one by one
+        int cc;
+        float aa;
+        if (k < ECAP) {
+          cc = scb[k];
+          aa = svb[k];
+        } else {
+          cc = colind[k0 + k];
+          aa = vals[k0 + k];
+        }
+        const bool in = (unsigned)(cc - wlo) < (unsigned)(R + 2 * H);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          f4 x;
+          if (in) x = *reinterpret_cast<const f4 *>(xl + (cc & (W - 1)) * CS + v * 32);
+          else x = ld4(xgl + (int64_t)cc * ldx + v * 32);
+          acc[v] = fma4(aa, x, acc[v]);
+        }
+      }
+    }
+    if (live) {
+#pragma unroll
+      for (int v = 0; v < NV; ++v) {
+        f4 o = acc[v];
+        if constexpr (EPI) o = ring_epilogue(o, ev[v], gv[v], epi.g != nullptr);
+        st4_stream(Y + (int64_t)r * ldy + c0 + v * 32 + sub * 4, o);
+        if constexpr (STATS) {
+          ssum[v] += o;
+          ssq[v].x = __builtin_fmaf(o.x, o.x, ssq[v].x); ssq[v].y = __builtin_fmaf(o.y, o.y, ssq[v].y);
+          ssq[v].z = __builtin_fmaf(o.z, o.z, ssq[v].z); ssq[v].w = __builtin_fmaf(o.w, o.w, ssq[v].w);
+        }
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // every LDS read of this step has returned
+    __builtin_amdgcn_s_barrier();
+  }
+  if constexpr (STATS) {
+    // column sums / sums of squares of this workgroup's output rows -> stats_part[strip][sum | squares][128] (fp32 over the
+    // strip per lane, then a fixed-order sum; fp64 above).  The loader waves have left: a finished wave no longer counts at
+    // s_barrier.
+    float *st = xs + (wave * 8 + g) * (2 * CS);                       // [NCW*8][sum | squares][CS] in the (now free) ring
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      *reinterpret_cast<f4 *>(st + v * 32 + sub * 4) = ssum[v];
+      *reinterpret_cast<f4 *>(st + CS + v * 32 + sub * 4) = ssq[v];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int tt = threadIdx.x;
+    if (tt < 2 * CS) {
+      float tot = 0.f;
+      for (int w = 0; w < NCW * 8; ++w) tot += xs[w * (2 * CS) + tt];
+      stats_part[(int64_t)strip * 256 + (tt / CS) * 128 + c0 + (tt % CS)] = tot;
+    }
+  }
+}
+
+// max |column - row| over the entries, the longest row, and the number of rows with an entry outside the ring kernel's window
+// (|column - row| > kRingH) of a CSR operator: what decides between the ring kernel and the gather kernels
+// (out[0..2]; all start at 0)
+__global__ __launch_bounds__(kWG) void csr_band_k(const int *__restrict__ rowptr, const int *__restrict__ colind, int64_t M,
+                                                  int *__restrict__ out) {
+  int band = 0, longest = 0, outside = 0;
+  for (int64_t r = (int64_t)blockIdx.x * kWG + threadIdx.x; r < M; r += (int64_t)gridDim.x * kWG) {
+    const int kb = rowptr[r], ke = rowptr[r + 1];
+    if (ke > kb) {                                                    // columns ascend: the first and the last entry bound the row
+      const int lo = (int)r - colind[kb], hi = colind[ke - 1] - (int)r;
+      const int far = lo > hi ? lo : hi;
+      band = far > band ? far : band;
+      outside += far > kRingH ? 1 : 0;
+      longest = ke - kb > longest ? ke - kb : longest;
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    const int b2 = __shfl_xor(band, o), l2 = __shfl_xor(longest, o);
+    band = b2 > band ? b2 : band;
+    longest = l2 > longest ? l2 : longest;
+    outside += __shfl_xor(outside, o);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(out, band);
+    atomicMax(out + 1, longest);
+    if (outside) atomicAdd(out + 2, outside);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Block-diagonal batch assembly from the resident operator pool.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kWG) void blockdiag_rowptr(const int *__restrict__ pool_rowptr,
@@ -1586,6 +1945,13 @@ inline bool timing_slot(int kind, int64_t M, int64_t K, int64_t nnz, int N, hipE
 
 }  // namespace
 
+// The same timing slot for the Linear-layer launchers of the other translation units (sn_gemm.hip, sn_dense.hip): kind
+// 0x100 forward / 0x200 input gradient / 0x400 weight gradient (+ a variant number in the low byte), then rows, the contraction
+// or input width, the ALGORITHMIC bytes of the launch (operands read + results written, weights excluded) and the output width.
+bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e) {
+  return timing_slot(kind, rows, width, bytes, outw, s, e);
+}
+
 // ================================================================================================
 // C-ABI
 // ================================================================================================
@@ -1845,6 +2211,127 @@ int sn_spmm_rb4_stats_f32(const int32_t *b_ptr, const int32_t *b_col, const floa
   if (workspace_bytes < sn_spmm_rb4_stats_workspace_bytes(M)) return SN_E_WORKSPACE;
   return spmm_rb4_launch(b_ptr, b_col, b_val, M, K, capacity, X, ldx, N, Y, ldy, SpmmEpi{nullptr, 0, nullptr, 0}, stream,
                          static_cast<float *>(workspace), stats_part);
+}
+
+// ---- ring kernel (banded square CSR operators, N in {64, 128}) ------------------------------------------------------
+// strips: a multiple of 8 (one contiguous eighth per XCD) chosen so that strips x slices = one workgroup per CU
+static int ring_strips(int64_t M, int N) {
+  const int nsl = N / kRingCS;
+  int nstrips = kCUs / nsl;
+  const int64_t nsteps = (M + kRingR - 1) / kRingR;
+  while (nstrips > kXCD && nsteps < (int64_t)nstrips * 4) nstrips >>= 1;      // (a strip shorter than 4 steps is mostly prologue)
+  return nstrips;
+}
+
+static int spmm_ring_launch(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
+                            const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, SpmmEpi epi, void *stream,
+                            float *stats_ws = nullptr, double *stats_out = nullptr) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (M < 0 || K < 0 || nnz < 0 || N < 1) return SN_E_SHAPE;
+  if (!fits_i32(M + kRingR + 1) || !fits_i32(K) || !fits_i32(nnz)) return SN_E_RANGE;
+  if (M != K) return SN_E_UNSUPPORTED;                    // the window follows the diagonal
+  if (N != 64 && N != 128) return SN_E_UNSUPPORTED;
+  if (M == 0) return SN_OK;
+  if (!rowptr || (nnz > 0 && (!colind || !vals))) return SN_E_NULL;
+  int st = check_dense(Y, ldy, 1, N);
+  if (!st) st = check_dense(X, ldx, 1, N);
+  if (st) return st;
+  if (!aligned16(X) || !aligned16(Y) || ldx % 4 || ldy % 4) return SN_E_ALIGN;
+  if (epi.e) {
+    st = check_dense(epi.e, epi.lde, 1, N);
+    if (!st && epi.g) st = check_dense(epi.g, epi.ldg, 1, N);
+    if (st) return st;
+    if (!aligned16(epi.e) || epi.lde % 4 || (epi.g && (!aligned16(epi.g) || epi.ldg % 4))) return SN_E_ALIGN;
+  }
+  if (stats_ws && (N != 128 || epi.e)) return SN_E_UNSUPPORTED;
+  if (stats_ws && !stats_out) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (nnz == 0) {                                         // an all-zero operator: Y = 0 (+ the epilogue's G), through the generic kernel
+    return spmm_csr_launch(rowptr, colind, vals, M, K, nnz, X, ldx, 1, N, Y, ldy, 1, epi, stream, stats_ws, stats_out);
+  }
+  // kernels that ask for more than 64 KiB of dynamic LDS have to be told once (per kernel, idempotent)
+  static const hipError_t attr_status = [] {
+    hipError_t e = hipFuncSetAttribute((const void *)spmm_ring_k<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)spmm_ring_k<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute((const void *)spmm_ring_k<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kRingLds);
+    return e;
+  }();
+  if (attr_status != hipSuccess) return (int)attr_status;
+  hipEvent_t t_start, t_stop;
+  timing_slot(64 | (epi.e ? 2 : 0) | (epi.g ? 4 : 0) | (stats_ws ? 16 : 0), M, K, nnz, N, &t_start, &t_stop);
+  const int nsl = N / kRingCS;
+  const int nstrips = ring_strips(M, N);
+  const int64_t nsteps = (M + kRingR - 1) / kRingR;
+  const int cps = (int)((nsteps + nstrips - 1) / nstrips);
+  const dim3 grid((unsigned)(nstrips * nsl)), block(kRingThreads);
+#define SN_RING_LAUNCH(EPI_, ST_, PART_)                                                                                       \
+  do {                                                                                                                         \
+    if (t_start)                                                                                                               \
+      hipExtLaunchKernelGGL((spmm_ring_k<EPI_, ST_>), grid, block, kRingLds, s, t_start, t_stop, 0, rowptr, colind, vals,       \
+                            (int)M, (int)K, (int)nnz, X, ldx, Y, ldy, nstrips, cps, nsl, epi, PART_);                          \
+    else                                                                                                                       \
+      hipLaunchKernelGGL((spmm_ring_k<EPI_, ST_>), grid, block, kRingLds, s, rowptr, colind, vals, (int)M, (int)K, (int)nnz,    \
+                         X, ldx, Y, ldy, nstrips, cps, nsl, epi, PART_);                                                       \
+  } while (0)
+  if (stats_ws) {
+    SN_RING_LAUNCH(false, true, stats_ws);
+    hipLaunchKernelGGL(spmm_stats_reduce_k, dim3(kSpmmStatsBlocks), dim3(kWG), 0, s, stats_ws, (int64_t)nstrips, stats_out);
+  } else if (epi.e) {
+    SN_RING_LAUNCH(true, false, (float *)nullptr);
+  } else {
+    SN_RING_LAUNCH(false, false, (float *)nullptr);
+  }
+#undef SN_RING_LAUNCH
+  return launch_status();
+}
+
+int sn_spmm_csr_ring_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
+                         const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, void *stream) {
+  return spmm_ring_launch(rowptr, colind, vals, M, K, nnz, X, ldx, N, Y, ldy, SpmmEpi{nullptr, 0, nullptr, 0}, stream);
+}
+
+int sn_spmm_csr_ring_elubwd_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
+                                int64_t nnz, const float *X, int64_t ldx, int32_t N, const float *E, int64_t lde, const float *G,
+                                int64_t ldg, float *Y, int64_t ldy, void *stream) {
+  if (!E) return SN_E_NULL;
+  return spmm_ring_launch(rowptr, colind, vals, M, K, nnz, X, ldx, N, Y, ldy, SpmmEpi{E, lde, G, ldg}, stream);
+}
+
+size_t sn_spmm_csr_ring_stats_workspace_bytes(int64_t M) {
+  if (M < 1) return 0;
+  // (the all-zero operator falls through to the generic kernel: the larger of the two)
+  const size_t a = (size_t)ring_strips(M, 128) * 256 * sizeof(float), b = sn_spmm_csr_stats_workspace_bytes(M);
+  return a > b ? a : b;
+}
+
+int sn_spmm_csr_ring_stats_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
+                               const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, double *stats_part, void *workspace,
+                               size_t workspace_bytes, void *stream) {
+  if (!stats_part || !workspace) return SN_E_NULL;
+  if (M < 1) return SN_E_SHAPE;
+  if (workspace_bytes < sn_spmm_csr_ring_stats_workspace_bytes(M)) return SN_E_WORKSPACE;
+  return spmm_ring_launch(rowptr, colind, vals, M, K, nnz, X, ldx, N, Y, ldy, SpmmEpi{nullptr, 0, nullptr, 0}, stream,
+                          static_cast<float *>(workspace), stats_part);
+}
+
+int32_t sn_spmm_csr_ring_half_window(void) { return kRingH; }
+
+int sn_csr_band_i32(const int32_t *rowptr, const int32_t *colind, int64_t M, int64_t K, int32_t *band_longest_outside, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (M < 0 || K < 0) return SN_E_SHAPE;
+  if (!fits_i32(M + 1) || !fits_i32(K)) return SN_E_RANGE;
+  if (!band_longest_outside || (M > 0 && !rowptr)) return SN_E_NULL;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(band_longest_outside, 0, 3 * sizeof(int32_t), s);
+  if (e != hipSuccess) return (int)e;
+  if (M == 0) return SN_OK;
+  if (!colind) return SN_E_NULL;
+  int64_t blocks = (M + kWG - 1) / kWG;
+  blocks = blocks < 2048 ? blocks : 2048;
+  hipLaunchKernelGGL(csr_band_k, dim3((unsigned)blocks), dim3(kWG), 0, s, rowptr, colind, M, band_longest_outside);
+  return launch_status();
 }
 
 static int spmm_bsr4_launch(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb, int64_t Kb,

@@ -30,9 +30,11 @@ def world_info():
     return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
 
 
-def init_distributed(backend: Optional[str] = None):
+def init_distributed(backend: Optional[str] = None, single_rank_group: bool = False):
     """Join the job described by RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run sets them).
-    backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests.  Returns (rank, local_rank, world, device)."""
+    backend 'nccl' is RCCL on ROCm; 'gloo' is used by the CPU tests.  Returns (rank, local_rank, world, device).
+    single_rank_group: create the process group even when WORLD_SIZE is 1 — a one-rank RCCL communicator (ncclCommInitRank +
+    a real ncclAllReduce per step through FlatGradBucket(always_reduce=True)): what a 1-GPU box can prove of the N > 1 path."""
     rank, local_rank, world = world_info()
     use_gpu = torch.cuda.is_available() and os.environ.get("SN_DP_FORCE_CPU", "0") != "1"
     if use_gpu:
@@ -41,7 +43,7 @@ def init_distributed(backend: Optional[str] = None):
         torch.cuda.set_device(device)
     else:
         device = torch.device("cpu")
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if use_gpu else "gloo")
@@ -72,7 +74,10 @@ def shard_balanced(weights: Sequence[float], rank: int, world: int) -> np.ndarra
 class FlatGradBucket:
     """All gradients of a module in one contiguous fp32 buffer; `.grad` of every parameter is a view into it."""
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    def __init__(self, params: Iterable[torch.nn.Parameter], always_reduce: bool = False):
+        """always_reduce: run the pack + all-reduce even in a one-rank process group (the sum over one rank is the identity;
+        used to put the collective itself on the measured path of a 1-GPU run)."""
+        self.always_reduce = bool(always_reduce)
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -100,7 +105,7 @@ class FlatGradBucket:
 
     def all_reduce(self, async_op: bool = False):
         """SUM over ranks (gradients were computed with the loss normalised by the global batch)."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self._collective():
             return None
         self._work = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
         return self._work
@@ -116,7 +121,7 @@ class FlatGradBucket:
         """After a backward that followed `detach_grads()`: with one rank nothing is copied (the optimizer reads the
         fresh gradients); with several ranks the gradients are packed into the flat buffer by one multi-tensor copy,
         all-reduced (SUM) and the parameters' `.grad` re-pointed at the bucket slices."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        if not self._collective():
             return None
         grads = [p.grad for p in self.params]
         have = [(v, g) for v, g in zip(self._views(), grads) if g is not None]
@@ -129,6 +134,11 @@ class FlatGradBucket:
         for p, v in zip(self.params, self._views()):
             p.grad = v
         return None
+
+    def _collective(self) -> bool:
+        if not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size() > 1 or self.always_reduce
 
     def _views(self):
         if getattr(self, "_view_list", None) is None:

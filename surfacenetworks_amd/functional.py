@@ -24,16 +24,20 @@ __all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg
            "bnlin_backward", "bn_prepare", "avg_stage_forward_ragged", "avg_stage_backward_ragged", "set_dirac_format", "set_laplacian_format", "SpmmTimer", "thin_linear", "thin_linear_supported"]
 
 _DIRAC_FORMAT = "q3"
-_LAPLACIAN_FORMAT = os.environ.get("SN_LAP_FORMAT", "rb4")      # (environment override for A/B measurements)
+_LAPLACIAN_FORMAT = os.environ.get("SN_LAP_FORMAT", "ring")     # (environment override for A/B measurements)
 
 
 def set_laplacian_format(fmt: str) -> None:
     """Kernel / storage form of the group-1 (Laplacian-type) products at 64 / 128 dense columns:
-    'rb4' (default) 4x1 row blocks — four consecutive rows share one gather per distinct column; built from the CSR
+    'ring' (default) the sliding-window kernel straight from the CSR arrays (X rows within +-160 of the current rows in an
+                    LDS ring, everything requested once by LDS-DMA) for square operators of >= 131 072 rows whose entries all
+                    lie in that window (SparseOperator.ring_ok: batches of meshes in a locality-preserving vertex order);
+                    every other operator as 'rb4';
+    'rb4'           4x1 row blocks — four consecutive rows share one gather per distinct column; built from the CSR
                     arrays on the device the first time an operator is used (bit-identical results for finite inputs);
     'csr'           always the generic CSR kernel."""
     global _LAPLACIAN_FORMAT
-    if fmt not in ("rb4", "csr"):
+    if fmt not in ("ring", "rb4", "csr"):
         raise ValueError(fmt)
     _LAPLACIAN_FORMAT = fmt
 
@@ -93,13 +97,27 @@ class SpmmTimer:
         meta = np.zeros((max(n, 1), 5), np.int64)
         written = ctypes.c_int64(0)
         _lib.call("sn_timing_drain", ms.ctypes.data, meta.ctypes.data, n, ctypes.addressof(written))
-        if written.value != len(self.tags):
-            raise RuntimeError(f"timing records ({written.value}) do not match launches ({len(self.tags)})")
+        # Linear-layer launches (kind >= 0x100: forward / input gradient / weight gradient, recorded by their launchers) are
+        # interleaved with the SpMM records; they go to self.linear as (kernel, rows, width, out_width, bytes, ms)
+        lin_names = {0x100: "linear_fwd", 0x200: "linear_dgrad", 0x400: "wgrad"}
+        self.linear = []
+        keep = []
+        for i in range(written.value):
+            kind = int(meta[i][0])
+            if kind >= 0x100:
+                base = kind & 0x700
+                self.linear.append((f"{lin_names.get(base, 'linear')}[{kind & 0xff}]", int(meta[i][1]), int(meta[i][2]), int(meta[i][4]),
+                                    int(meta[i][3]), float(ms[i])))
+            else:
+                keep.append(i)
+        if len(keep) != len(self.tags):
+            raise RuntimeError(f"timing records ({len(keep)}) do not match launches ({len(self.tags)})")
+        meta, ms = meta[keep], ms[keep]
         out = []
         for i, (tag, op) in enumerate(self.tags):
             kind, M, K, _, N = meta[i]
             nnz = op if isinstance(op, int) else op.nnz
-            fmt = ("/rb4" if kind & 32 else "/q3" if kind & 8 else "/bsr4" if kind & 1 else "/csr") + ("+e" if kind & 2 else "") + \
+            fmt = ("/ring" if kind & 64 else "/rb4" if kind & 32 else "/q3" if kind & 8 else "/bsr4" if kind & 1 else "/csr") + ("+e" if kind & 2 else "") + \
                 ("+g" if kind & 4 else "") + ("+s" if kind & 16 else "")
             out.append((tag + fmt, int(M), int(K), int(nnz), int(N), float(ms[i])))
         return out
@@ -139,7 +157,12 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
             kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
         else:
             kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, x, e, g, y, group)
-    elif _LAPLACIAN_FORMAT == "rb4" and kernels.spmm_rb4_supported(y.shape[1] // group, group) and op.rb4() is not None:
+    elif _LAPLACIAN_FORMAT == "ring" and group == 1 and op.ring_ok(y.shape[1]):
+        # banded square operator on a batch that fills the chip: sliding window over X in LDS, straight from the CSR arrays
+        if stats and e is None and y.shape[1] == 128:
+            return kernels.spmm_ring_stats(op.rowptr, op.colind, op.vals, M, K, x, y)
+        kernels.spmm_ring(op.rowptr, op.colind, op.vals, M, K, x, y, e, g)
+    elif _LAPLACIAN_FORMAT in ("ring", "rb4") and kernels.spmm_rb4_supported(y.shape[1] // group, group) and op.rb4() is not None:
         r = op.rb4()                                   # Laplacian-type operator: one gather per listed column of a 4-row group
         if stats and e is None and y.shape[1] == 128:
             return kernels.spmm_rb4_stats(r[0], r[1], r[2], M, K, x, y)

@@ -52,7 +52,11 @@ def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
         if o._csr is not None and not isinstance(o._bsr4, tuple) and not isinstance(o._q3, tuple):
             from . import functional as snF
 
-            if snF._LAPLACIAN_FORMAT == "rb4" and o.is_cuda:
+            if snF._LAPLACIAN_FORMAT in ("ring", "rb4") and o.is_cuda:
+                # (an operator that takes the sliding-window kernel is multiplied straight from its CSR arrays: nothing
+                #  derived to list; the decision — the band of the operator — is measured here, before the capture)
+                if snF._LAPLACIAN_FORMAT == "ring" and (o.ring_ok(128) or o.ring_ok(64)):
+                    continue
                 r = o.rb4()
                 if r is not None:
                     out.extend(r)

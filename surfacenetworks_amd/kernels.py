@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 __all__ = [
-    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged", "validate_csr",
+    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "spmm_ring", "spmm_ring_stats", "spmm_ring_supported", "ring_half_window", "csr_band", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged", "validate_csr",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
@@ -144,6 +144,68 @@ def spmm_rb4_stats(b_ptr, b_col, b_val, M: int, K: int, x, y):
     ws_bytes = int(lib.sn_spmm_rb4_stats_workspace_bytes(M))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=y.device)
     _lib.call("sn_spmm_rb4_stats_f32", _p(b_ptr), _p(b_col), _p(b_val), M, K, int(b_col.numel()), _p(x), ldx, N, _p(y), ldy,
+              _p(part), _p(ws), ws_bytes, _stream())
+    return part
+
+
+# Rows below which the ring kernel's persistent strips are mostly prologue (one workgroup per CU, >= 8 steps of 64 rows each)
+RING_MIN_ROWS = 131072
+# Largest share of rows with an entry outside the window (they gather from global memory inside the kernel: closed meshes'
+# wrap-around rows) for which the ring kernel is still the faster one (a 65 x 106 torus batch has 3 %: 0.67-0.83 of the
+# roofline against the row-blocked kernel's 0.59-0.69)
+RING_MAX_OUTSIDE = 0.05
+
+
+def spmm_ring_supported(N: int, group: int, M: int, K: int) -> bool:
+    from . import kernels as _self      # (RING_MIN_ROWS is read through the module so that tests / tools can lower it)
+
+    return group == 1 and N in (64, 128) and M == K and M >= _self.RING_MIN_ROWS
+
+
+def ring_half_window() -> int:
+    return int(_lib.load().sn_spmm_csr_ring_half_window())
+
+
+def csr_band(rowptr, colind, M: int, K: int):
+    """(max |column - row|, longest row, rows with an entry outside the ring kernel's window) of a CSR operator — reads
+    three ints back from the device (once per operator)."""
+    _dev(rowptr, colind)
+    out = torch.empty(3, dtype=torch.int32, device=rowptr.device)
+    _lib.call("sn_csr_band_i32", _p(rowptr), _p(colind), M, K, _p(out), _stream())
+    band, longest, outside = out.tolist()
+    return int(band), int(longest), int(outside)
+
+
+def spmm_ring(rowptr, colind, vals, M: int, K: int, x, y, e=None, g=None) -> None:
+    """y <- A·x for a banded square CSR operator through the sliding-window kernel (sn_spmm_csr_ring_f32); with e:
+    (A·x) * elu'(e) + g (sn_spmm_csr_ring_elubwd_f32).  Bit-identical to spmm_csr."""
+    _dev(rowptr, colind, vals, x, y, e, g)
+    N = y.shape[1]
+    ldx = _check_dense(x, K, 1, N, "x")
+    ldy = _check_dense(y, M, 1, N, "y")
+    nnz = int(colind.numel())
+    if e is None:
+        _lib.call("sn_spmm_csr_ring_f32", _p(rowptr), _p(colind), _p(vals), M, K, nnz, _p(x), ldx, N, _p(y), ldy, _stream())
+    else:
+        lde = _check_dense(e, M, 1, N, "e")
+        ldg = _check_dense(g, M, 1, N, "g") if g is not None else 0
+        _lib.call("sn_spmm_csr_ring_elubwd_f32", _p(rowptr), _p(colind), _p(vals), M, K, nnz, _p(x), ldx, N, _p(e), lde, _p(g), ldg,
+                  _p(y), ldy, _stream())
+
+
+def spmm_ring_stats(rowptr, colind, vals, M: int, K: int, x, y):
+    """spmm_ring (N = 128) that also returns the (blocks, 2, 128) float64 partial column statistics of y."""
+    _dev(rowptr, colind, vals, x, y)
+    N = y.shape[1]
+    if N != 128:
+        raise ValueError("spmm_ring_stats: 128-column operands only")
+    ldx = _check_dense(x, K, 1, N, "x")
+    ldy = _check_dense(y, M, 1, N, "y")
+    lib = _lib.load()
+    part = torch.empty((int(lib.sn_spmm_q3_stats_blocks()), 2, 128), dtype=torch.float64, device=y.device)
+    ws_bytes = int(lib.sn_spmm_csr_ring_stats_workspace_bytes(M))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=y.device)
+    _lib.call("sn_spmm_csr_ring_stats_f32", _p(rowptr), _p(colind), _p(vals), M, K, int(colind.numel()), _p(x), ldx, N, _p(y), ldy,
               _p(part), _p(ws), ws_bytes, _stream())
     return part
 

@@ -74,6 +74,7 @@ class SparseOperator:
         self._bsr4 = bsr4                        # (b_rowptr, b_colind, b_vals) | None | False (= not worthwhile)
         self._q3 = q3                            # (b_rowptr, q_blk) quaternion-packed form | None (unknown) | False (not a Dirac-type operator)
         self._rb4 = None                         # (b_ptr, b_col, b_val) 4x1 row-blocked form | None (not built) | False (not worthwhile)
+        self._band = None                        # (max |column - row|, longest row, rows outside the ring window) | None (not measured)
 
     @property
     def _t(self) -> "Optional[SparseOperator]":
@@ -149,6 +150,7 @@ class SparseOperator:
         csr = (None, None, None) if self._csr is None else tuple(mv(t) for t in self._csr)
         out = SparseOperator(*csr, self._shape, batch=self.batch, transpose=transpose, bsr4=b, q3=q)
         out._nnz_cache = self._nnz_cache
+        out._band = self._band
         out.row_offsets, out.col_offsets = self.row_offsets, self.col_offsets
         return out
 
@@ -159,6 +161,7 @@ class SparseOperator:
         csr = (None, None, None) if self._csr is None else tuple(cp(t) for t in self._csr)
         out = SparseOperator(*csr, self._shape, batch=self.batch, transpose=transpose, bsr4=b, q3=q)
         out._rb4 = tuple(cp(t) for t in self._rb4) if isinstance(self._rb4, tuple) else self._rb4
+        out._band = self._band
         out._nnz_cache = self._nnz_cache
         out.row_offsets, out.col_offsets = self.row_offsets, self.col_offsets
         return out
@@ -252,6 +255,26 @@ class SparseOperator:
             else:
                 self._rb4 = kernels.csr_to_rb4(self.rowptr, self.colind, self.vals, M, K)
         return self._rb4 or None
+
+    def band(self):
+        """(max |column - row|, longest row, rows with an entry outside the ring kernel's window) of the CSR arrays — what
+        decides between the sliding-window kernel and the gather kernels for Laplacian-type products.  Measured on the device on
+        first use (one host synchronisation per operator); operators assembled by an OperatorPool arrive with the values
+        already attached (maxima / sums over their meshes)."""
+        if self._band is None:
+            M, K = self._shape
+            self._band = kernels.csr_band(self.rowptr, self.colind, M, K)
+        return self._band
+
+    def ring_ok(self, N: int) -> bool:
+        """True when the Laplacian-type product of this operator at N dense columns should take the sliding-window kernel:
+        square, large enough to fill the chip with persistent strips, (nearly) every entry within the kernel's window of its
+        row (the few rows that reach further — the wrap-around rows of closed meshes — gather from global memory in the kernel)."""
+        M, K = self._shape
+        if not kernels.spmm_ring_supported(N, 1, M, K):
+            return False
+        band, longest, outside = self.band()
+        return longest <= 32 and outside <= kernels.RING_MAX_OUTSIDE * M
 
     def bsr4(self):
         """(b_rowptr, b_colind, b_vals) or None when the 4x4-block form is not applicable / not worthwhile."""
@@ -498,6 +521,10 @@ class OperatorPool:
         self.cols = np.array([m.shape[1] for m in fwd], dtype=np.int64)
         self._fwd = self._upload(fwd)
         self._bwd = self._upload([m.T.tocsr() for m in fwd])   # one-time host transpose at load, like the dataset prep
+        # per mesh: (max |column - row|, longest row, rows outside the ring window) of the operator and of its transpose — a
+        # batch whose blocks sit on the diagonal (equal row and column offsets) inherits them without a device pass
+        self._band_fwd = np.array([self._mesh_band(m) for m in fwd], dtype=np.int64).reshape(-1, 3)
+        self._band_bwd = np.array([self._mesh_band(m.T.tocsr()) for m in fwd], dtype=np.int64).reshape(-1, 3)
         self._fwd_b = self._bwd_b = None
         self._fwd_q = self._bwd_q = None
         if self.want_bsr4:
@@ -509,6 +536,24 @@ class OperatorPool:
             if int(ff.item()) == 0 and int(bf.item()) == 0:
                 self._fwd_q = dict(self._fwd_b, vals=fq.reshape(-1), colind=None)
                 self._bwd_q = dict(self._bwd_b, vals=bq.reshape(-1), colind=None)
+
+    @staticmethod
+    def _mesh_band(m):
+        m = m.tocsr()
+        if m.nnz == 0:
+            return (0, 0, 0)
+        counts = np.diff(m.indptr)
+        rows = np.repeat(np.arange(m.shape[0]), counts)
+        far = np.abs(m.indices.astype(np.int64) - rows)
+        outside = np.unique(rows[far > kernels.ring_half_window()]).size if far.max() > 0 else 0
+        return (int(far.max()), int(counts.max()), int(outside))
+
+    def _attach_band(self, op, sel, diagonal: bool):
+        if diagonal and len(sel):
+            f, b = self._band_fwd[sel], self._band_bwd[sel]
+            op._band = (int(f[:, 0].max()), int(f[:, 1].max()), int(f[:, 2].sum()))
+            if op._t is not None:
+                op._t._band = (int(b[:, 0].max()), int(b[:, 1].max()), int(b[:, 2].sum()))
 
     # pooled CSR: dict(rowptr, colind, vals device tensors; rp_off, e_off, cnt host int64 arrays)
     def _upload(self, mats):
@@ -595,6 +640,7 @@ class OperatorPool:
             opt = SparseOperator(*b, (shape[1], shape[0]), batch=B, transpose=op)
             op._t = opt
             op._bsr4 = opt._bsr4 = False
+            self._attach_band(op, sel, bool((rows == cols).all()))
         op.row_offsets, op.col_offsets = ro, co
         op._t.row_offsets, op._t.col_offsets = co, ro
         return op
@@ -631,4 +677,5 @@ class OperatorPool:
         opt = SparseOperator(*b, (B * size1, B * size0), batch=B, transpose=op)
         op._t = opt
         op._bsr4 = opt._bsr4 = False
+        self._attach_band(op, sel, size0 == size1)
         return op

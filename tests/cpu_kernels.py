@@ -417,6 +417,40 @@ def spmm_rb4_stats(b_ptr, b_col, b_val, M, K, x, y):
     return part
 
 
+def spmm_ring_supported(N, group, M, K):
+    from surfacenetworks_amd import kernels
+
+    return group == 1 and N in (64, 128) and M == K and M >= kernels.RING_MIN_ROWS
+
+
+def ring_half_window():
+    return 160
+
+
+def csr_band(rowptr, colind, M, K):
+    rp, ci = _np(rowptr).astype(np.int64), _np(colind).astype(np.int64)
+    if len(ci) == 0:
+        return 0, 0, 0
+    cnt = np.diff(rp)
+    rows = np.repeat(np.arange(M), cnt)
+    far = np.abs(ci - rows)
+    return int(far.max()), int(cnt.max()), int(np.unique(rows[far > ring_half_window()]).size)
+
+
+def spmm_ring(rowptr, colind, vals, M, K, x, y, e=None, g=None):
+    spmm_csr(rowptr, colind, vals, M, K, x, y, 1)                   # (bit-identical to the CSR kernel by contract)
+    if e is not None:
+        _elubwd_epilogue(y, e, g)
+
+
+def spmm_ring_stats(rowptr, colind, vals, M, K, x, y):
+    spmm_csr(rowptr, colind, vals, M, K, x, y, 1)
+    part = torch.zeros((1, 2, 128), dtype=torch.float64)
+    part[0, 0] = y.double().sum(0)
+    part[0, 1] = (y.double() ** 2).sum(0)
+    return part
+
+
 def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y=True, elu_stats=None):
     y = (x.double() @ W.double().t() + bias.double()).float()
     if residual is not None:

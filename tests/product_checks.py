@@ -482,6 +482,12 @@ def check_model_layers(golden_dir, tag, dev, tol=1e-5):
         m, nlayer, x0 = deterministic_init(arap.DirModel(), 7).train().to(dev), 15, t(z["inputs6"])
     elif tag == "arap_lap":
         m, nlayer, x0 = deterministic_init(arap.Model(15), 8).train().to(dev), 15, t(z["inputs6"])
+    elif tag == "faust_lap":                     # one tower of the siamese model (3 input channels)
+        from surfacenetworks_amd import dense_correspondence
+
+        m, nlayer, x0 = deterministic_init(dense_correspondence.Model(15), 11).train().to(dev), 15, t(z["coords"])
+    elif tag == "mnist_dir":
+        m, nlayer, x0 = _bn_train_only(deterministic_init(mesh_mnist.DirModel(), 10)).to(dev), 5, t(z["coords"])
     else:
         m, nlayer, x0 = _bn_train_only(deterministic_init(mesh_mnist.Model(), 9)).to(dev), 5, t(z["coords"])
     worst = 0.0
@@ -493,10 +499,11 @@ def check_model_layers(golden_dir, tag, dev, tol=1e-5):
             blk = m._modules[f"rn{i}"]
             v_in = t(z[f"{tag}_{prev}_v"])
             want_v = z[f"{tag}_rn{i}_v"]
-            if tag == "arap_dir" and i % 2 == 0:
+            if (tag == "arap_dir" and i % 2 == 0) or tag == "mnist_dir":
                 # the face stream entering block i is the f returned by the previous Dirac block (zeros for the first)
-                fkey = f"{tag}_rn{i - 2}_f"
-                f_in = t(z[fkey]) if i >= 2 else torch.zeros(v_in.shape[0], nf, v_in.shape[2], device=dev)
+                back = 2 if tag == "arap_dir" else 1
+                fkey = f"{tag}_rn{i - back}_f"
+                f_in = t(z[fkey]) if i >= back else torch.zeros(v_in.shape[0], nf, v_in.shape[2], device=dev)
                 v_out, f_out = blk(ops["Di"], ops["DiA"], v_in, f_in)
                 ef = rel_err(f_out.cpu().numpy(), z[f"{tag}_rn{i}_f"])
                 assert ef <= max(tol, 4.0 * float(z[f"{tag}_rn{i}_eref"])), (tag, f"rn{i} face stream", ef)

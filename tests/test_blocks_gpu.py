@@ -32,7 +32,7 @@ def test_models_match_reference(golden_dir, tag):
     pc.check_model(golden_dir, tag, DEV)
 
 
-@pytest.mark.parametrize("tag", ["arap_dir", "arap_lap", "mnist_lap"])
+@pytest.mark.parametrize("tag", ["arap_dir", "arap_lap", "mnist_lap", "mnist_dir", "faust_lap"])
 def test_model_layers_match_reference_layer_by_layer(golden_dir, tag):
     """Each layer given the reference's own input of that layer: <= 1e-5 relative (no compounding over 15 layers)."""
     pc.check_model_layers(golden_dir, tag, DEV)

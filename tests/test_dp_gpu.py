@@ -165,7 +165,72 @@ def test_bench_self_launches_two_ranks():
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["config"]["rccl_ranks"] == 2 and rec["config"]["global_batch"] == 8
+    assert rec["n_gpus"] == 2 and rec["config"]["world_size"] == 2 and rec["config"]["global_batch"] == 8
+    assert rec["config"]["rccl_ranks"] == (2 if rec["config"]["collective_backend"] == "nccl" else 0)
     assert rec["value"] > 0 and rec["scaling"] == "weak" and rec["roofline"]["frac"] > 0
     if torch.cuda.device_count() < 2:
         assert rec["config"]["ranks_share_devices"] and rec["config"]["collective_backend"] == "gloo"
+
+
+def _rccl_worker(port, q):
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    from helpers import deterministic_init
+    from surfacenetworks_amd import arap, dp
+
+    r, lr, w, dev = dp.init_distributed("nccl", single_rank_group=True)
+    assert (r, w, dev.type) == (0, 1, "cuda") and dist.is_initialized() and dist.get_backend() == "nccl"
+    ds = arap.ClothSequences([(8, 8)] * 3, frames=44, op_frames=2, seed=5, device=dev, model="dir")
+    model = deterministic_init(arap.DirModel(), 3).to(dev).train()
+    dp.broadcast_parameters(model, 0)                          # (world 1: nothing to send)
+    plain = dp.FlatGradBucket(model.parameters())
+    assert plain.sync() is None and plain.all_reduce() is None # a one-rank group reduces nothing unless asked to
+    bucket = dp.FlatGradBucket(model.parameters(), always_reduce=True)
+    batch = ds.sample_batch(3, None, seq_ids=np.arange(3), offsets=np.zeros(3, dtype=np.int64))
+    bucket.detach_grads()
+    loss, _ = arap.forward_loss(model, batch, 3)
+    loss.backward()
+    stored = [p.grad.clone() for p in bucket.params]
+    assert all(g.untyped_storage().data_ptr() != bucket.flat.untyped_storage().data_ptr() for g in stored)
+    bucket.flat.fill_(float("nan"))
+    bucket.sync()                                              # pack -> ncclAllReduce(SUM) over the one rank -> views
+    torch.cuda.synchronize()
+    same = bucket.check_views() and all(torch.equal(p.grad, g) for p, g in zip(bucket.params, stored))
+    # a second, in-place reduction of the bucket itself (the accumulate-into-views variant)
+    before = bucket.flat.clone()
+    work = bucket.all_reduce()
+    torch.cuda.synchronize()
+    same = same and torch.equal(bucket.flat, before)
+    with open("/proc/self/maps") as fh:
+        rccl = sorted({ln.split()[-1] for ln in fh if "rccl" in ln.lower() or "nccl" in ln.lower()})
+    q.put((bool(same), rccl, bucket.nbytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_all_reduce_of_the_flat_bucket_in_a_one_rank_group():
+    """The most a 1-GPU box can prove of `north_star`'s "RCCL all-reduce of gradients": ncclCommInitRank + ncclAllReduce run on
+    the flat 4 MB bucket (SUM over one rank = identity), librccl is mapped into the process."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_worker, args=(_free_port(), q))
+    p.start()
+    p.join(timeout=600)
+    assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    same, rccl, nbytes = q.get(timeout=10)
+    assert same and nbytes == 4 * 1018872
+    assert any("rccl" in s for s in rccl), rccl
+
+
+def test_bench_runs_its_one_rank_through_rccl():
+    """`python bench.py --gpus 1` puts the gradient bucket through a one-rank RCCL communicator every step."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                          "--meshes", "4", "--no-secondary", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert rec["n_gpus"] == 1 and rec["config"]["collective_backend"] == "nccl" and rec["config"]["rccl_ranks"] == 1
+    assert rec["config"]["collective_per_step"].startswith("pack + ncclAllReduce")

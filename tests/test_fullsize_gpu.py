@@ -113,6 +113,67 @@ def test_config4_faust_laplacian_7000_padded():
     _props(op, 1, 64, 41)
 
 
+def test_config1_mesh_mnist_laplacian_batch32_on_the_gpu():
+    """BASELINE configs[0] (the reference's CPU-runnable case) at its own shape on the GPU: 32 meshes of 140 .. 230 vertices,
+    cotangent Laplacians padded to the batch maximum, C = 64: properties, RB4 (default at this size) == generic CSR kernel,
+    every mesh against the C oracle, padding rows exactly zero."""
+    from surfacenetworks_amd import mesh_ops
+    from surfacenetworks_amd.operators import OperatorPool
+
+    rng = np.random.default_rng(1)
+    nvs = rng.integers(140, 231, size=32)
+    mats = [mesh_ops.laplacian(*mesh_ops.delaunay_disc(int(nv), rng)).astype(np.float32) for nv in nvs]
+    pool = OperatorPool(mats, DEV)
+    size = int(max(nvs))
+    op = pool.assemble(np.arange(32), size, size)
+    assert op.shape == (32 * size, 32 * size) and not op.ring_ok(64)          # (4 800-7 360 rows: the row-blocked kernel)
+    x1, y1, gy, gx = _props(op, 1, 64, 10)
+    _oracle_slice(op, x1, y1, 1, 64, 32 * size)
+    yb = y1.view(32, size, 64)
+    for b, nv in enumerate(nvs):
+        assert not yb[b, int(nv):].any()
+    _props(op, 1, 128, 11)
+
+
+def test_config5_laplacian_batch_takes_the_ring_kernel():
+    """The Laplacians of BASELINE configs[4]'s meshes (128 ragged grids, 1.3 M rows, C = 128): the product's default is the
+    sliding-window kernel; properties, == generic CSR kernel == RB4 bit for bit, first meshes against the C oracle, the fused
+    epilogue and the statistics variant == their unfused compositions."""
+    from surfacenetworks_amd import functional as snF, kernels, mesh_ops
+    from surfacenetworks_amd.operators import OperatorPool
+
+    rng = np.random.default_rng(5)
+    vs = rng.integers(1000, 20001, size=128)
+    Ls = []
+    for v in vs:
+        n = int(np.sqrt(v))
+        Ls.append(mesh_ops.laplacian(*mesh_ops.grid_cloth(n, int(v) // n, rng)).astype(np.float32))
+    op = OperatorPool(Ls, DEV).assemble(np.arange(128))
+    M, K = op.shape
+    assert op.ring_ok(128) and op.t().ring_ok(128) and op.band()[0] <= 160
+    with snF.SpmmTimer() as timer:
+        x1, y1, gy, gx = _props(op, 1, 128, 60)
+        tags = {t[0].split("/")[-1] for t in timer.results()}
+    assert tags == {"ring"}
+    _oracle_slice(op, x1, y1, 1, 128, int(op.row_offsets[3]))
+    r = op.rb4()
+    yr = torch.empty_like(y1)
+    kernels.spmm_rb4(r[0], r[1], r[2], M, K, x1, yr)
+    assert torch.equal(yr, y1)
+    e, g = torch.randn(M, 128, device=DEV), torch.randn(M, 128, device=DEV)
+    fused = torch.empty(M, 128, device=DEV)
+    kernels.spmm_ring(op.rowptr, op.colind, op.vals, M, K, x1, fused, e, g)
+    unfused = torch.empty(M, 128, device=DEV)
+    kernels.elu_bwd(y1, e, unfused, False, None, g)
+    assert torch.equal(fused, unfused)
+    ys = torch.empty(M, 128, device=DEV)
+    part = kernels.spmm_ring_stats(op.rowptr, op.colind, op.vals, M, K, x1, ys)
+    assert torch.equal(ys, y1)
+    ref = kernels.colstats(y1)
+    scale = torch.stack([y1.double().abs().sum(0), ref[1]]) + 1e-30
+    assert ((part.sum(0) - ref).abs() / scale).max().item() < 1e-6
+
+
 def test_config5_ragged_packed_batch_and_int32_limit():
     """BASELINE configs[4]: 128 meshes with 1 000 .. 20 000 vertices, Dirac operators, C = 128 (N = 32), as a PACKED batch
     (no padding): properties + the padded batch of the same meshes gives the same rows; sizes past int32 are refused."""
@@ -121,13 +182,23 @@ def test_config5_ragged_packed_batch_and_int32_limit():
 
     rng = np.random.default_rng(5)
     vs = rng.integers(1000, 20001, size=128)
-    Dis = []
+    Dis, DiAs = [], []
     for v in vs:
         n = int(np.sqrt(v))
         V, F_ = mesh_ops.grid_cloth(n, int(v) // n, rng)
-        Dis.append(mesh_ops.dirac(V, F_)[0].astype(np.float32))
-    pool = OperatorPool(Dis, DEV, want_bsr4=True)
+        Di, DiA = mesh_ops.dirac(V, F_)
+        Dis.append(Di.astype(np.float32))
+        DiAs.append(DiA.astype(np.float32))
     sel = np.arange(128)
+    # DiA (and DiA^T through the adjoint identity) at the ragged full size: properties, every storage form == the generic CSR
+    # kernel bit for bit, the first meshes against the C oracle
+    poolA = OperatorPool(DiAs, DEV, want_bsr4=True)
+    opA = poolA.assemble(sel)
+    assert opA.shape == (int(poolA.rows.sum()), int(poolA.cols.sum())) and opA.nnz == sum(m.nnz for m in DiAs)
+    xa, ya, _, _ = _props(opA, 4, 32, 51)
+    _oracle_slice(opA, xa, ya, 4, 32, int(opA.row_offsets[2]))
+    del opA, poolA, xa, ya
+    pool = OperatorPool(Dis, DEV, want_bsr4=True)
     op = pool.assemble(sel)                                      # packed
     assert op.shape == (int(pool.rows.sum()), int(pool.cols.sum())) and op.nnz == sum(m.nnz for m in Dis)
     x1, y1, gy, gx = _props(op, 4, 32, 50)
@@ -154,6 +225,7 @@ def test_config5_ragged_packed_batch_and_int32_limit():
     assert lib.sn_blockdiag_concat_ragged_i32(None, None, None, None, 1, big, 10, 10, 1, None, None, None, None) == SN_E_RANGE
     assert lib.sn_blockdiag_concat_i32(None, None, None, None, 1024, 4 * 600_000, 10, 10, 1, None, None, None, None) == SN_E_RANGE
     assert lib.sn_spmm_rb4_f32(None, None, None, big, 10, 10, None, 128, 128, None, 128, None) == SN_E_RANGE
+    assert lib.sn_spmm_csr_ring_f32(None, None, None, big, big, 10, None, 128, 128, None, 128, None) == SN_E_RANGE
     # ... and the largest sizes that still fit are accepted as far as the argument checks go (null operands: SN_E_NULL)
     assert lib.sn_spmm_csr_f32(None, None, None, big - 2, 10, 10, None, 32, 1, 32, None, 32, 1, None) == -1
 

@@ -48,7 +48,7 @@ def test_inplace_edit_drops_the_activated_handoff(golden_dir, cpu_kernels):
     pc.check_inplace_edit_drops_handoff(golden_dir, "cpu")
 
 
-@pytest.mark.parametrize("tag", ["arap_dir", "arap_lap", "mnist_lap"])
+@pytest.mark.parametrize("tag", ["arap_dir", "arap_lap", "mnist_lap", "mnist_dir", "faust_lap"])
 def test_model_layers_match_reference_layer_by_layer(golden_dir, cpu_kernels, tag):
     pc.check_model_layers(golden_dir, tag, "cpu")
 

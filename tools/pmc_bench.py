@@ -8,8 +8,11 @@ of these kernels is a 128-byte line: TCC_EA0_RDREQ_32B_sum = 0; FETCH_SIZE talli
 import collections
 import csv
 import json
+import os
 import re
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def short(name):
@@ -57,6 +60,9 @@ def main():
                        "(one counter per pass) over `python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-secondary`; "
                        "bytes = RDREQ*128 + WRREQ*64 (gfx950 correction); the first half of the dispatches (set-up and warm-up) dropped",
            "_total_bytes_counted": {"read": tot_r, "write": tot_w}}
+    from bench import csrc_digest           # the kernel sources these counters belong to (bench.py withholds them on a mismatch)
+
+    res["_csrc_sha256"] = csrc_digest()
     for k, e in agg.items():
         res[k] = {"launches": e["launches"], "read_bytes_mean": e["read_bytes"] / e["launches"],
                   "write_bytes_mean": e["write_bytes"] / e["launches"], "by_grid": e["by_grid"]}
