@@ -1223,12 +1223,25 @@ __global__ __launch_bounds__(kWG) void spmm_rb4_stats(const int *__restrict__ b_
 // row's own first column by 0, as in spmm_csr_v4).  Measured (MI355X, 128 channels): 0.65-0.67 of the HBM roofline on the
 // config-5 Laplacian batch (RB4: 0.55-0.58), 0.83 on the config-3-sized batch (0.72-0.79), 0.81 on config 4's (0.57).
 // ------------------------------------------------------------------------------------------------
+// A/B switches of the ring kernel (measurement builds only; the defaults are the shipped kernel)
+#ifndef SN_X_RING_XAUX
+#define SN_X_RING_XAUX 2             // cache policy of the X DMA: 2 = non-temporal (every X line is requested once per slice: +2-3 %), 0 = default
+#endif
+#ifndef SN_X_RING_EAUX
+#define SN_X_RING_EAUX 0             // ... of the entry / row-pointer DMA
+#endif
+#ifndef SN_X_RING_ST_PLAIN
+#define SN_X_RING_ST_PLAIN 0         // 1: plain instead of non-temporal stores of Y
+#endif
+#ifndef SN_X_RING_NLW
+#define SN_X_RING_NLW 4
+#endif
 constexpr int kRingCS = 64;          // dense columns per slice (one 256-byte piece of an X row)
 constexpr int kRingW = 512;          // ring rows (128 KiB)
 constexpr int kRingR = 64;           // rows per step
 constexpr int kRingH = 160;          // half window: columns within +-H of the row come from the ring
 constexpr int kRingD = 2;            // steps of DMA in flight
-constexpr int kRingNLW = 4;          // loader waves
+constexpr int kRingNLW = SN_X_RING_NLW;   // loader waves
 constexpr int kRingNCW = kRingR / 8; // compute waves
 constexpr int kRingThreads = (kRingNCW + kRingNLW) * 64;
 constexpr int kRingECap = kRingR * 8;                     // entry slots per step buffer
@@ -1299,7 +1312,7 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
     auto issue_rows = [&](int row0, int i) {                          // RPI rows from row0 + RPI*i -> ring
       int row = row0 + RPI * i + lane / LPX;
       row = row < 0 ? 0 : (row < K ? row : K - 1);
-      __builtin_amdgcn_global_load_lds(xg + (int64_t)row * ldx, xs + ((row0 + RPI * i) & (W - 1)) * CS, 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(xg + (int64_t)row * ldx, xs + ((row0 + RPI * i) & (W - 1)) * CS, 16, 0, SN_X_RING_XAUX);
     };
     auto issue_step = [&](int t) {                                    // X piece, entries, row pointers of step t: NSTEP instr.
       const int buf = t % NB;
@@ -1322,8 +1335,8 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
         p = p < ne ? p : (ne > 0 ? ne - 1 : 0);
         int k = k0 + p;
         k = k < nnz ? k : nnz - 1;
-        __builtin_amdgcn_global_load_lds(colind + k, sc + buf * ECAP + p0, 4, 0, 0);
-        __builtin_amdgcn_global_load_lds(vals + k, sv + buf * ECAP + p0, 4, 0, 0);
+        __builtin_amdgcn_global_load_lds(colind + k, sc + buf * ECAP + p0, 4, 0, SN_X_RING_EAUX);
+        __builtin_amdgcn_global_load_lds(vals + k, sv + buf * ECAP + p0, 4, 0, SN_X_RING_EAUX);
       }
       const int r0 = t * R;
       int nr = M - r0;
@@ -1500,7 +1513,8 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
       for (int v = 0; v < NV; ++v) {
         f4 o = acc[v];
         if constexpr (EPI) o = ring_epilogue(o, ev[v], gv[v], epi.g != nullptr);
-        st4_stream(Y + (int64_t)r * ldy + c0 + v * 32 + sub * 4, o);
+        if (SN_X_RING_ST_PLAIN) st4(Y + (int64_t)r * ldy + c0 + v * 32 + sub * 4, o);
+        else st4_stream(Y + (int64_t)r * ldy + c0 + v * 32 + sub * 4, o);
         if constexpr (STATS) {
           ssum[v] += o;
           ssq[v].x = __builtin_fmaf(o.x, o.x, ssq[v].x); ssq[v].y = __builtin_fmaf(o.y, o.y, ssq[v].y);

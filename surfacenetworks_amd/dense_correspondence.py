@@ -152,6 +152,11 @@ class _TwoReaders(torch.autograd.Function):
 
 
 _TOWER_SLOTS = weakref.WeakKeyDictionary()
+_TOWER_STREAMS = weakref.WeakKeyDictionary()      # model -> (side stream, per-BatchNorm capture buffers)
+# The two applications of the shared tower are independent until the score matrix; a 7000-row tower fills 219 of the chip's
+# 512 workgroup slots and its step is ~500 launches of a few microseconds, so running them on two streams (inside the one
+# captured hipGraph: two concurrent kernel chains) hides most of that latency.  SN_TWO_STREAM_TOWERS=0 switches it off.
+_TWO_STREAMS = __import__("os").environ.get("SN_TWO_STREAM_TOWERS", "1") != "0"
 
 
 class SiameseModel(nn.Module):
@@ -205,17 +210,74 @@ class SiameseModel(nn.Module):
             return self.model(*OperationA, inputA), self.model(*OperationB, inputB)
         alias = _TwoReaders.apply(*plist)
         k = len(plist)
+        from . import functional as snF
+
+        # (not with synchronised BatchNorm: its collectives would be issued from two streams)
+        two = _TWO_STREAMS and inputA.is_cuda and snF._BN_SYNC is None
         try:
             for d, key, i in slots:
                 d[key] = alias[i]
+            if two:
+                main = torch.cuda.current_stream()
+                side, bns = self._tower_streams()
+                side.wait_stream(main)                       # (fork: the second tower starts from everything issued so far)
             FA = self.model(*OperationA, inputA)
             for d, key, i in slots:
                 d[key] = alias[k + i]
-            FB = self.model(*OperationB, inputB)
+            if not two:
+                FB = self.model(*OperationB, inputB)
+            else:
+                # The towers share their BatchNorm modules: the reference applies A's running-statistics update, then B's.
+                # On two streams the second application writes ITS batch statistics into capture buffers instead (momentum 1
+                # makes the fold kernel store them as they are) and the update is applied after the join, in that order.
+                saved = []
+                for bn, cap_mean, cap_var in bns:
+                    if not (bn.training and bn.track_running_stats):
+                        continue                             # (eval mode normalises WITH the running statistics: leave them)
+                    saved.append((bn, bn._buffers["running_mean"], bn._buffers["running_var"], bn._buffers["num_batches_tracked"], bn.momentum))
+                    bn._buffers["running_mean"], bn._buffers["running_var"], bn._buffers["num_batches_tracked"] = cap_mean, cap_var, None
+                    bn.momentum = 1.0
+                try:
+                    with torch.cuda.stream(side):
+                        FB = self.model(*OperationB, inputB)
+                finally:
+                    for bn, rm, rv, nbt, mom in saved:
+                        bn._buffers["running_mean"], bn._buffers["running_var"], bn._buffers["num_batches_tracked"] = rm, rv, nbt
+                        bn.momentum = mom
+                main.wait_stream(side)                       # (join)
+                FB.record_stream(main)
+                live = [(bn, cm, cv) for bn, cm, cv in bns if bn.training and bn.track_running_stats]
+                if live:
+                    with torch.no_grad():
+                        means, vars_ = [bn.running_mean for bn, _, _ in live], [bn.running_var for bn, _, _ in live]
+                        moms = {bn.momentum for bn, _, _ in live}
+                        if len(moms) == 1:                   # one multi-tensor launch per operation
+                            m_ = moms.pop()
+                            torch._foreach_mul_(means + vars_, 1.0 - m_)
+                            torch._foreach_add_(means + vars_, [cm for _, cm, _ in live] + [cv for _, _, cv in live], alpha=m_)
+                        else:
+                            for bn, cm, cv in live:
+                                bn.running_mean.mul_(1.0 - bn.momentum).add_(cm, alpha=bn.momentum)
+                                bn.running_var.mul_(1.0 - bn.momentum).add_(cv, alpha=bn.momentum)
+                        torch._foreach_add_([bn.num_batches_tracked for bn, _, _ in live], 1)
         finally:
             for d, key, i in slots:
                 d[key] = plist[i]
         return FA, FB
+
+    def _tower_streams(self):
+        """(side stream, [(BatchNorm module, capture buffer for its batch mean, ... for its unbiased batch variance)]) — kept
+        outside the module (nothing of it is pickled or deep-copied with it), rebuilt when the modules or their device change."""
+        cached = _TOWER_STREAMS.get(self)
+        mods = [m for m in self.model.modules() if isinstance(m, nn.BatchNorm1d) and m.running_mean is not None]
+        if cached is not None and len(cached[1]) == len(mods) and all(
+                a is b and cm.device == b.running_mean.device for (a, cm, _), b in zip(cached[1], mods)):
+            return cached
+        dev = next(self.model.parameters()).device
+        cached = (torch.cuda.Stream(device=dev),
+                  [(m, torch.zeros_like(m.running_mean), torch.zeros_like(m.running_var)) for m in mods])
+        _TOWER_STREAMS[self] = cached
+        return cached
 
     def forward(self, OperationA, OperationB, inputA, inputB):
         FA, FB = self.towers(OperationA, OperationB, inputA, inputB)

@@ -37,6 +37,16 @@ r = op.rb4()
 for _ in range(10):
     kernels.spmm_rb4(r[0], r[1], r[2], M, K, x, y)
 print(f"L rb4: listed columns {int(r[0][-1].item())}")
+# the sliding-window kernel (round 3): plain, statistics, fused ELU-backward epilogue — 10 launches each
+for _ in range(10):
+    kernels.spmm_ring(op.rowptr, op.colind, op.vals, M, K, x, y)
+for _ in range(10):
+    kernels.spmm_ring_stats(op.rowptr, op.colind, op.vals, M, K, x, y)
+for _ in range(10):
+    kernels.spmm_ring(op.rowptr, op.colind, op.vals, M, K, x, y, e, g)
+for _ in range(10):
+    kernels.spmm_rb4(r[0], r[1], r[2], M, K, x, y, e, g)
+print(f"L ring: band {op.band()}")
 print(f"L: M={M} nnz={op.nnz}: compulsory reads {op.nnz * 8 + (M + 1) * 4 + K * 512} B (+ {2 * M * 512} B with E and G), writes {M * 512} B; "
       f"gathered through L1 {op.nnz * 512} B")
 if DiAs:

@@ -1,7 +1,10 @@
 """Step-time measurements of the other BASELINE configs (parity-test cases, not bench lines):
-   python tools/train_bench.py mnist_dir|mnist_lap|faust_lap|arap_lap|arap_ragged [steps]
+   python tools/train_bench.py mnist_dir|mnist_lap|faust_lap|arap_lap|arap_ragged|arap_swap [steps]
 mnist_dir = config 2 (Mesh-MNIST Dirac, batch 512); mnist_lap = config 1 shape on the GPU; faust_lap = config 4 per-GPU
-work (one pair of 6890-vertex bodies padded to 7000); arap_lap = the Laplacian variant of config 3."""
+work (one pair of 6890-vertex bodies padded to 7000); arap_lap = the Laplacian variant of config 3; arap_swap = config 3
+as an UNMODIFIED reference driver runs it after the import swap: per step and per sample sp_sparse_to_pt_sparse on the host,
+sparse_diag_cat (+ coalesce) on the host, .cuda(), and the conversion of the COO batch operators inside the blocks
+(src/as_rigid_as_possible/main.py:156-185) — against the resident OperatorPool of bench.py."""
 import os
 import sys
 import time
@@ -97,6 +100,49 @@ def main():
             rows = int(ds.num_vertices.sum()) if packed else 64 * int(ds.num_vertices.max())
             print(f"{what}: 64 ragged meshes (sum V = {int(ds.num_vertices.sum())}, max V = {int(ds.num_vertices.max())}), "
                   f"{'packed' if packed else 'padded'}: {rows} vertex rows, {dt * 1e3:.2f} ms/step, {64 / dt:.0f} meshes/s")
+    elif what == "arap_swap":
+        import surfacenetworks_amd.utils_pt as utils
+        from surfacenetworks_amd import mesh_ops
+        from surfacenetworks_amd.operators import as_operator
+
+        B = int(os.environ.get("SN_SWAP_MESHES", "64"))
+        grid_rng = np.random.default_rng(3)
+        samples = []
+        for _ in range(B):                                          # the dataset as the reference keeps it: scipy operators per frame
+            V, F = mesh_ops.grid_cloth(71, 71, grid_rng)
+            Di, DiA = mesh_ops.dirac(V, F)
+            samples.append((V.astype(np.float32), Di.astype(np.float32), DiA.astype(np.float32), F.shape[0]))
+        nv, nf = samples[0][0].shape[0], samples[0][3]
+        model = arap.DirModel().to(dev).train()
+        opt = arap.make_optimizer(model)
+        inputs = torch.from_numpy(np.stack([np.concatenate([s_[0], s_[0]], 1) for s_ in samples]))
+        targets = torch.zeros(B, nv, 120)
+        mask = torch.ones(B, nv, 1)
+        t_host, t_h2d, t_conv = [], [], []
+
+        def step():
+            t0 = time.perf_counter()
+            Di = utils.sparse_diag_cat([utils.sp_sparse_to_pt_sparse(s_[1]) for s_ in samples], 4 * nf, 4 * nv)     # main.py:161-181
+            DiA = utils.sparse_diag_cat([utils.sp_sparse_to_pt_sparse(s_[2]) for s_ in samples], 4 * nv, 4 * nf)
+            t1 = time.perf_counter()
+            Di, DiA, x, y, m = Di.cuda(), DiA.cuda(), inputs.cuda(), targets.cuda(), mask.cuda()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            Di, DiA = as_operator(Di), as_operator(DiA)             # (what the blocks do on first touch: COO -> CSR -> blocks, transpose)
+            Di.t(), DiA.t(), Di.q3(), DiA.q3(), Di.t().q3(), DiA.t().q3()
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            t_host.append(t1 - t0), t_h2d.append(t2 - t1), t_conv.append(t3 - t2)
+            out = model(Di, DiA, m, x)
+            loss = arap.loss_fn(out, y, m, B)
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+        dt = timed(step, steps, warm=1)
+        k = len(t_host) - steps
+        print(f"{what}: batch {B} x 71x71 through per-step sparse_diag_cat + .cuda() + as_operator: {dt * 1e3:.1f} ms/step, {B / dt:.1f} meshes/s "
+              f"(host batching {np.mean(t_host[k:]) * 1e3:.1f} ms, H2D {np.mean(t_h2d[k:]) * 1e3:.1f} ms, device conversion of the COO operators "
+              f"{np.mean(t_conv[k:]) * 1e3:.1f} ms, model step {(dt - np.mean(t_host[k:]) - np.mean(t_h2d[k:]) - np.mean(t_conv[k:])) * 1e3:.1f} ms)")
     else:
         raise SystemExit(__doc__)
 
