@@ -634,7 +634,12 @@ def check_siamese_gradients_meet_once(dev):
             else:                               # g + (a + b) against (g + a) + b
                 assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-6 * float(b.grad.abs().max())), n
     for (n, a), (_, b) in zip(model.named_buffers(), plain.named_buffers()):
-        assert torch.equal(a, b), n              # running statistics and counters: advanced by every application
+        # running statistics and counters: advanced by every application.  On the GPU the second application runs on a side
+        # stream and its update is applied after the join from its stored batch statistics (one more fp32 rounding: <= 1 ulp)
+        if a.dtype.is_floating_point:
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-6 * float(b.abs().max())), (n, float((a - b).abs().max()))
+        else:
+            assert torch.equal(a, b), n
     with torch.no_grad():                       # no gradients wanted: the plain double application
         o1 = model(dc._operation(LX, mX), dc._operation(LY, mY), inX, inY)
     assert not o1.requires_grad

@@ -151,10 +151,14 @@ def test_config5_laplacian_batch_takes_the_ring_kernel():
     op = OperatorPool(Ls, DEV).assemble(np.arange(128))
     M, K = op.shape
     assert op.ring_ok(128) and op.t().ring_ok(128) and op.band()[0] <= 160
-    with snF.SpmmTimer() as timer:
-        x1, y1, gy, gx = _props(op, 1, 128, 60)
+    with snF.SpmmTimer() as timer:                       # (only launches that go through the product's dispatch are tagged)
+        x1, y1, gy, gx = _props(op, 1, 128, 60, check_forms=False)
         tags = {t[0].split("/")[-1] for t in timer.results()}
     assert tags == {"ring"}
+    for o, xin, yref in ((op, x1, y1), (op.t(), gy, gx)):
+        yc = torch.empty_like(yref)
+        kernels.spmm_csr(o.rowptr, o.colind, o.vals, o.shape[0], o.shape[1], xin, yc, 1)
+        assert torch.equal(yc, yref)                    # ring == generic CSR kernel, bit for bit
     _oracle_slice(op, x1, y1, 1, 128, int(op.row_offsets[3]))
     r = op.rb4()
     yr = torch.empty_like(y1)
