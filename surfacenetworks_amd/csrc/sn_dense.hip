@@ -802,6 +802,261 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
 #undef SN_BLOCK_BARRIER
 }
 
+// ------------------------------------------------------------------------------------------------
+// wgrad_d_k — the uniform-wave split-bf16 weight gradient with the operands brought in by LDS-DMA (SN_WGRAD_VARIANT=3).
+//
+// What held wgrad_u_k at 4.1-4.4 TB/s is its memory path: the rows in flight live in registers (one 32-row block per
+// workgroup, 49 KB per CU, requested one dword load at a time between MFMAs) — the path alone ran at 4.7 TB/s.  Here the raw
+// fp32 rows never pass through registers on their way in: every wave issues its share of 1-KiB buffer_load ... lds
+// instructions THREE 16-row blocks ahead (a ring of three raw blocks in LDS, 74 KB at C = 256; rows past the slab end read 0
+// through the buffer's extent), the only vector-memory traffic of a wave until the final store — so a partial s_waitcnt
+// vmcnt leaves two blocks in flight behind the barrier.  Conversion reads the raw block column-wise (8 rows of one column per
+// lane: eight conflict-free ds_read_b32) and writes the three bf16 pieces as before; blocks are 16 rows (one MFMA k-step),
+// two images of 2 row groups (77 KB).  Same arithmetic as wgrad_u_k: same pieces, same six products per term, same order
+// inside a tile — bit-identical partials for equal slabs.
+// MEASURED SLOWER (round 3, same box, kernels.wgrad incl. its reduction): 356 against 256 us at 627 200 rows x 256 columns,
+// 199 against 150 us at 322 624 rows — 2.3 us per 16-row block where the matrix work of a block is 0.64 us and its bytes
+// 1.1 us at a CU's share of the bandwidth: with one k-step per barrier the chain barrier -> fragment reads -> MFMAs with the
+// conversion's LDS round trips in between is not covered by the second wave of the SIMD.  Kept as SN_WGRAD_VARIANT=3 (plain
+// slabs only) for the record; wgrad_u_k stays the default.
+// ------------------------------------------------------------------------------------------------
+// 16 bytes per lane from a buffer resource straight into LDS (buffer_load_dwordx4 ... lds: 1 KiB per wave instruction, lane l
+// lands at lds + 16 l; offsets past the resource's extent read 0).  The builtin exists in the device pass only.
+__device__ __forceinline__ void buffer_dma16(__amdgpu_buffer_rsrc_t rs, float *lds, int voff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, voff, 0, 0, 0);
+#else
+  (void)rs, (void)lds, (void)voff;
+#endif
+}
+
+template <int CT /* C / 128: 1 or 2 */>
+__global__ __launch_bounds__(kWgradThreads, 1) void wgrad_d_k(const float *__restrict__ dy, int64_t lddy,
+                                                              const float *__restrict__ x, int64_t ldx,
+                                                              const float *__restrict__ center, int64_t rows, int J, int C,
+                                                              float *__restrict__ partial /* [grid][128][C] */,
+                                                              float *__restrict__ colpart /* [grid][128] | NULL */,
+                                                              int64_t seg_rows /* 0: even split of all rows */, int spm,
+                                                              const int64_t *__restrict__ slab_off /* [grid + 1] | NULL */) {
+  constexpr int NCG = 32 + 32 * CT;          // column groups of 4: 32 of dy, 32·CT of x
+  constexpr int QP = NCG + 4;                // slots per (column % 4) plane; QP % 16 == 4 keeps fragment reads conflict-free
+  constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
+  constexpr int XW = 128 * CT;               // x columns
+  constexpr int NM = 12 * CT;                // MFMAs per wave and 16-row block
+  constexpr int NRAW = 3;                    // raw blocks in the ring
+  constexpr int NPW = 1 + CT;                // DMA instructions per wave and block (8 waves: 8 of dy + 8·CT of x)
+  constexpr int RAWF = 16 * (128 + XW);      // floats of one raw block: dy rows [16][128], then x rows [16][XW]
+  static_assert(QP % 16 == 4, "slot permutation");
+  __shared__ u4 img[2][3][2 * PL];           // [buffer][piece][slot]; one block = 16 rows = 2 row groups
+  __shared__ __attribute__((aligned(16))) float raw[NRAW][RAWF];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  int64_t r0, r1;                            // row slab of this workgroup (as wgrad_u_k)
+  if (slab_off) {
+    r0 = slab_off[blockIdx.x];
+    r1 = slab_off[blockIdx.x + 1];
+  } else if (seg_rows > 0) {
+    const int64_t mesh = blockIdx.x / spm, part = blockIdx.x % spm;
+    int64_t per = (seg_rows + spm - 1) / spm;
+    per = (per + 15) & ~(int64_t)15;
+    const int64_t mend = (mesh + 1) * seg_rows < rows ? (mesh + 1) * seg_rows : rows;
+    r0 = mesh * seg_rows + part * per;
+    r1 = r0 + per < mend ? r0 + per : mend;
+  } else {
+    int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    per = (per + 15) & ~(int64_t)15;
+    r0 = (int64_t)blockIdx.x * per;
+    r1 = r0 + per < rows ? r0 + per : rows;
+  }
+  const int nblocks = r1 > r0 ? (int)((r1 - r0 + 15) / 16) : 0;
+  const int span = r1 > r0 ? (int)(r1 - r0) : 0;
+  float *P = partial + (int64_t)blockIdx.x * 128 * C;
+
+  // ---- matrix role: dy tiles 2·ga, 2·ga + 1  x  x tiles CT·gb .. CT·gb + CT - 1 ----
+  const int i = lane & 31, kh = lane >> 5;
+  const int ga = wave >> 2, gb = wave & 3;
+  const int fo = kh * PL + (i & 3) * QP + (i >> 2);          // my fragment slot: + 8·(tile in column groups of 32)
+  f16v acc[2][CT];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < CT; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+  // ---- DMA role: instruction w of a block = dy rows (2w, 2w+1); then x rows: CT = 2: rows w and w + 8 (one 1-KiB row each),
+  //      CT = 1: rows (2w, 2w+1).  Lane offsets inside the block are constants; a dy column >= J is past every extent. ----
+  const int dy_rstep = 4 * (int)lddy, x_rstep = 4 * (int)ldx;
+  const int dy_c = (lane & 31) * 4;
+  const int dy_voff = (dy_c < J) ? (2 * wave + (lane >> 5)) * dy_rstep + 4 * dy_c : 0x7fffff00;
+  int x_voff[CT];
+  if constexpr (CT == 2) {
+    x_voff[0] = wave * x_rstep + 16 * lane;
+    x_voff[1] = (wave + 8) * x_rstep + 16 * lane;
+  } else {
+    x_voff[0] = (2 * wave + (lane >> 5)) * x_rstep + 16 * (lane & 31);
+  }
+  auto issue_block = [&](int b) {                             // NPW instructions, whatever b (blocks past the slab: extent 0)
+    int left = span - 16 * b;
+    left = left < 0 ? 0 : (left > 16 ? 16 : left);
+    const int slot = b % NRAW;
+    const int e_dy = __builtin_amdgcn_readfirstlane(left * dy_rstep), e_x = __builtin_amdgcn_readfirstlane(left * x_rstep);
+    const int64_t rb = r0 + (int64_t)16 * (left ? b : 0);
+    __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy + rb * lddy), 0, e_dy, 0x00020000);
+    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + rb * ldx), 0, e_x, 0x00020000);
+    float *rw = &raw[slot][0];
+    buffer_dma16(rs_dy, rw + 2 * wave * 128, dy_voff);
+    if constexpr (CT == 2) {
+      buffer_dma16(rs_x, rw + 16 * 128 + wave * XW, x_voff[0]);
+      buffer_dma16(rs_x, rw + 16 * 128 + (wave + 8) * XW, x_voff[1]);
+    } else {
+      buffer_dma16(rs_x, rw + 16 * 128 + 2 * wave * XW, x_voff[0]);
+    }
+  };
+
+  // ---- conversion role: units of 8 rows x 64 columns (one column per lane).  A block has 4 dy units (row group u/2, half
+  //      u%2) and 4·CT x units (row group, 64-column chunk).  Wave w takes unit w; at CT = 2 the other four x units go to waves
+  //      0-3 on even blocks and to waves 4-7 on odd ones. ----
+  float l_sum = 0.f;                                          // running sum of my dy column (waves 0-3: their unit is a dy unit)
+  float rv[8];
+  u4 cH, cM, cL;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+  struct Unit { int src_off; int rstride; int slot; float mu; bool isdy; };      // src_off: floats from the start of a raw block
+  auto unit_of = [&](int u) -> Unit {                         // u in 0 .. 4 + 4·CT - 1
+    Unit t;
+    if (u < 4) {
+      const int rg = u >> 1, c = 64 * (u & 1) + lane;
+      t.src_off = (8 * rg) * 128 + c;
+      t.rstride = 128;
+      t.slot = rg * PL + (c & 3) * QP + (c >> 2);
+      t.mu = 0.f;
+      t.isdy = true;
+    } else {
+      const int v = u - 4, rg = v / (2 * CT), c = 64 * (v % (2 * CT)) + lane;
+      t.src_off = 16 * 128 + (8 * rg) * XW + c;
+      t.rstride = XW;
+      t.slot = rg * PL + ((128 + c) & 3) * QP + ((128 + c) >> 2);
+      t.mu = center ? center[c] : 0.f;
+      t.isdy = false;
+    }
+    return t;
+  };
+  // the units of this wave are fixed (their centres are loaded once, BEFORE any DMA is in flight: the wave's vmcnt then
+  // counts DMA only)
+  const Unit t0 = unit_of(wave);
+  const Unit t1 = unit_of(CT == 2 ? 8 + (wave & 3) : wave);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const float *rbase = nullptr;                                // raw block being converted
+  auto conv_read = [&](const Unit &t) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) rv[j] = rbase[t.src_off + j * t.rstride];
+  };
+  auto conv_pair = [&](const Unit &t, int p) {
+    f2 xv = {rv[2 * p], rv[2 * p + 1]};
+    if (t.isdy) l_sum += xv.x + xv.y;
+    else xv -= f2{t.mu, t.mu};
+    const u2v xb = __builtin_bit_cast(u2v, xv);
+    const f2 r = xv - __builtin_bit_cast(f2, xb & 0xFFFF0000u);
+    const u2v rbits = __builtin_bit_cast(u2v, r);
+    const f2 l = r - __builtin_bit_cast(f2, rbits & 0xFFFF0000u);
+    const u2v lb = __builtin_bit_cast(u2v, l);
+    cH[p] = __builtin_amdgcn_perm(xb.y, xb.x, 0x07060302u);
+    cM[p] = __builtin_amdgcn_perm(rbits.y, rbits.x, 0x07060302u);
+    cL[p] = __builtin_amdgcn_perm(lb.y, lb.x, 0x07060302u);
+  };
+  auto conv_write = [&](const Unit &t, int buf) {
+    img[buf][0][t.slot] = cH;
+    img[buf][1][t.slot] = cM;
+    img[buf][2][t.slot] = cL;
+  };
+  auto convert_unit = [&](const Unit &t, int rawslot, int buf) {      // the whole unit in one go (prologue)
+    rbase = &raw[rawslot][0];
+    conv_read(t);
+#pragma unroll
+    for (int p = 0; p < 4; ++p) conv_pair(t, p);
+    conv_write(t, buf);
+  };
+  // second unit of this wave in block b (CT = 2 only): waves 0-3 on even blocks, 4-7 on odd ones (unit 8 + (wave & 3))
+  auto has_second = [&](int b) -> bool {
+    if constexpr (CT == 1) return false;
+    return (wave >> 2) == (b & 1);
+  };
+
+#define SN_WD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  auto wait_dma = [&]() {                                     // everything but the newest block of this wave's DMA has landed
+    if constexpr (NPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  };
+  auto multiply_block = [&](auto pc, int b) {
+    constexpr int buf = decltype(pc)::value;                  // block b = image buf = b & 1
+    wait_dma();                                               // my share of raw block b + 1 has landed ...
+    SN_WD_BARRIER();                                          // ... everyone's has; image buf is complete; image buf^1 and raw slot b % 3 are free
+    issue_block(b + 3);
+    u4 A[2][3], B[CT][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) A[a][p] = img[buf][p][fo + 8 * (2 * ga + a)];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) B[c][p] = img[buf][p][fo + 32 + 8 * (CT * gb + c)];
+    }
+    // conversion of raw block b + 1 into the other image, dealt out behind the MFMAs
+    rbase = &raw[(b + 1) % NRAW][0];
+    const bool two = has_second(b + 1);
+    wstatic_for<0, NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value, t = m / (2 * CT);
+      constexpr int a = (m % (2 * CT)) / CT, c = m % CT;
+      constexpr int pa = (0x001102 >> (4 * t)) & 15, pb = (0x010120 >> (4 * t)) & 15;
+      acc[a][c] = mfma_bf16(A[a][pa], B[c][pb], acc[a][c]);
+      // first unit: reads behind MFMA 0, a pair of rows behind MFMAs 2, 4, 6, 8 (CT = 1: 2, 4, 6, 8), slots behind MFMA 10
+      if constexpr (m == 0) conv_read(t0);
+      if constexpr (m >= 2 && m <= 8 && m % 2 == 0) conv_pair(t0, (m - 2) / 2);
+      if constexpr (m == 10) conv_write(t0, buf ^ 1);
+      if constexpr (CT == 2) {
+        if (two) {                                            // (wave-uniform)
+          if constexpr (m == 11) conv_read(t1);
+          if constexpr (m >= 13 && m <= 19 && m % 2 == 1) conv_pair(t1, (m - 13) / 2);
+          if constexpr (m == 21) conv_write(t1, buf ^ 1);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  if (nblocks > 0) {
+    issue_block(0);
+    issue_block(1);
+    issue_block(2);
+    if constexpr (NPW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // raw block 0 has landed (mine)
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    SN_WD_BARRIER();                                                              // (everyone's)
+    convert_unit(t0, 0, 0);
+    if (has_second(0)) convert_unit(t1, 0, 0);
+    for (int b = 0; b < nblocks; b += 2) {
+      multiply_block(WIC<0>{}, b);
+      if (b + 1 < nblocks) multiply_block(WIC<1>{}, b + 1);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the workgroup has gone
+  if (colpart) {                             // bias gradient: column sums of dy — waves 0-3 hold (row group, column) entries
+    __syncthreads();
+    float *sm = reinterpret_cast<float *>(&img[0][0][0]);
+    if (wave < 4) sm[(wave >> 1) * 128 + 64 * (wave & 1) + lane] = l_sum;
+    __syncthreads();
+    if (tid < 128) colpart[(int64_t)blockIdx.x * 128 + tid] = sm[tid] + sm[128 + tid];
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int jr = 32 * (2 * ga + a) + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        P[(int64_t)jr * C + 32 * (CT * gb + c) + i] = acc[a][c][e];
+      }
+#undef SN_WD_BARRIER
+}
+
 __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ partial, int nslab, int J, int C,
                                                       float *__restrict__ G, const float *__restrict__ colpart,
                                                       double *__restrict__ dysum,
@@ -1886,11 +2141,20 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
   float *partial = static_cast<float *>(workspace);
   float *colpart = dysum ? partial + (size_t)nslab * 128 * C : nullptr;
   const int64_t sr = segmented ? rows_per_seg : 0;
-  const bool uni = x3 && wgrad_variant() == 2 && lddy < ((int64_t)1 << 24) && ldx < ((int64_t)1 << 24);
+  const bool uni = x3 && wgrad_variant() >= 2 && lddy < ((int64_t)1 << 24) && ldx < ((int64_t)1 << 24);
   if (ragged && !uni) return SN_E_UNSUPPORTED;              // slab tables: the uniform-wave kernel only
+  const bool dma = uni && wgrad_variant() == 3 && !ragged && !segmented;      // (experimental kernel: plain slabs only)
   hipEvent_t t_start = nullptr, t_stop = nullptr;
   if (uni) sn_internal_timing_slot(0x400 | (segmented ? 1 : 0) | (ragged ? 2 : 0), rows, C, rows * 4 * ((int64_t)J + C), J, &t_start, &t_stop);
-  if (uni && C == 128 && t_start)
+  if (dma && C == 128 && t_start)
+    hipExtLaunchKernelGGL((wgrad_d_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
+  else if (dma && t_start)
+    hipExtLaunchKernelGGL((wgrad_d_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
+  else if (dma && C == 128)
+    hipLaunchKernelGGL((wgrad_d_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
+  else if (dma)
+    hipLaunchKernelGGL((wgrad_d_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
+  else if (uni && C == 128 && t_start)
     hipExtLaunchKernelGGL((wgrad_u_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
   else if (uni && t_start)
     hipExtLaunchKernelGGL((wgrad_u_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
