@@ -428,6 +428,25 @@ int sn_pair_ce_fwd_f32(const float *S, int64_t ld, const int64_t *target, int64_
                        void *stream);
 int sn_pair_ce_bwd_f32(const float *S, int64_t ld, const int64_t *target, const float *lse, const float *gloss, int64_t NA,
                        int64_t NB, int64_t rows, int64_t cols, float *dS, int64_t ldd, void *stream);
+/* sn_pair_fused_fwd_f32 / sn_pair_fused_bwd_f32: the same loss computed FROM THE TOWER FEATURES, the score matrix never
+ * written (replaces `torch.bmm(FA, FB.transpose(1, 2))`, src/dense_correspondence/models.py:203, together with the cross
+ * entropy of main.py:238-239 and both their backward passes).  FA: rowsA x K, FB: rowsB x K row-major fp32 (K <= 128; the
+ * towers emit 120), the first NA / NB rows are scored, the rest is the padding of the batch.  Scores are formed tile by tile
+ * on the bf16 matrix pipe from three-piece truncation splits of the features (six exact partial products per term, fp32
+ * accumulation: fp32-accurate, not bit-equal to an fp32 FMA chain) and reduced on the spot.
+ *   forward : lse[r], rowloss[r] (r < NA) as sn_pair_ce_fwd_f32; the split features are left in `workspace`
+ *             (sn_pair_fused_workspace_bytes(rowsA, rowsB) bytes, 16-byte aligned) for the backward pass.
+ *   backward: dFA[r][k] = (*gloss / NA) sum_j (softmax(S[r])[j] - [j == target[r]]) FB[j][k] and
+ *             dFB[j][k] = (*gloss / NA) sum_r (...) FA[r][k]; rows >= NA / NB of dFA / dFB are set to 0.  Reads the workspace
+ *             the forward call filled (same rowsA, rowsB, K) and its lse.  Fixed summation order: run-to-run identical.
+ * 0 <= target[r] < NB is the caller's guarantee. */
+size_t sn_pair_fused_workspace_bytes(int64_t rowsA, int64_t rowsB);
+int sn_pair_fused_fwd_f32(const float *FA, int64_t lda, const float *FB, int64_t ldb, const int64_t *target, int64_t NA,
+                          int64_t NB, int64_t rowsA, int64_t rowsB, int32_t K, float *lse, float *rowloss, void *workspace,
+                          size_t workspace_bytes, void *stream);
+int sn_pair_fused_bwd_f32(const int64_t *target, const float *lse, const float *gloss, int64_t NA, int64_t NB, int64_t rowsA,
+                          int64_t rowsB, int32_t K, float *dFA, int64_t ldda, float *dFB, int64_t lddb, void *workspace,
+                          size_t workspace_bytes, void *stream);
 /* sn_linear_thin_fwd_f32: forward of that first layer, y = x·W^T + bias (x: rows x C, C <= 8; W: J x C), and optionally
  * elu(y) into y_elu (the first half of the next block's concat buffer; replaces the F.elu of utils_pt.py:161,195).  y or
  * y_elu may be NULL (not both).  Ascending-k fp32 FMA chain on top of the bias. */

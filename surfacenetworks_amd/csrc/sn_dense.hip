@@ -2041,6 +2041,390 @@ inline int wgrad_slabs(int64_t rows) {
   return (int)b;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Dense-correspondence loss WITHOUT the score matrix (src/dense_correspondence/models.py:203 bmm(FA, FB^T) and
+// main.py:229-240 argmin-target cross entropy over outputs[0, :NA, :NB]): the 7000 x 7000 scores are formed tile by tile on
+// the fp16 matrix pipe and reduced on the spot; forward and backward never write them.
+//
+// Arithmetic: the two-piece fp16 split of the Linear kernels (sn_gemm.hip).  x·up = h + l with h = rn16(x·up),
+// l = rn16(x·up - h) holds 22+ significant bits, `up` an exact power of two taken from the MATRIX's absolute maximum (so it
+// factors out of every contraction); a product is the three partial products l·h + h·l + h·h, each exact in the fp32
+// accumulator of v_mfma_f32_32x32x16_f16 (the dropped l·l is below 2^-24 of the term).  Elements more than 2^16 below the
+// matrix maximum lose low-order bits of l: an ABSOLUTE error below 2^-39 of the maximum, nothing next to the fp32 rounding of
+// a 120-term sum.  The soft-max factor P = softmax - onehot in [-1, 1] is split the same way after scaling by 2^14.
+//
+// Layout: every operand is stored in MFMA FRAGMENT ORDER, 32 rows (a "tile") at a time — [tile][k-step][piece][lane][8 halfs],
+// lane (i, kh) holding row i's elements 8 kh .. 8 kh + 7 of the k-step — so that one wave-wide LDS-DMA instruction moves 1 KiB
+// of contiguous global memory into 1 KiB of LDS that ds_read_b128 then reads without bank conflicts: no transposition, no
+// address arithmetic per element.  R holds the features for the score product (contraction over the feature index), T holds
+// them transposed for the gradient product (contraction over the streamed rows, in the order the accumulator of the score
+// tile hands them over: pair_perm).
+//   pair_maxabs_k   absolute maximum of both feature matrices -> the two scales
+//   pair_split_k    F -> R, T of both sides
+//   pair_lse_k      a workgroup owns 128 rows of A (4 waves x 32, fragments in registers) and streams a RANGE of B's tiles
+//                   through a double-buffered LDS stage; the tile is computed TRANSPOSED (lane = row of A), so the soft-max
+//                   reductions of a row stay inside a lane; (max, sum, target logit) per row and range -> pair_combine_k
+//   pair_grad_k     both gradients in one launch: a workgroup owns 128 rows of one side and streams a range of the other
+//                   side's tiles (R and T); scores recomputed, P split in registers — the accumulator layout of the transposed
+//                   tile IS the operand layout of the second product — dOwn += P·Other; partial sums per range
+//   pair_reduce_k   sums the ranges in fixed order, applies gloss / NA and the scales, zero-fills the padding rows
+// ------------------------------------------------------------------------------------------------
+constexpr int kPairKP = 128;                       // padded feature count (K <= 128)
+constexpr int kPairTile = 32 * kPairKP * 2;        // halfs of one tile of R (or T): 8 (or 4 x 2) k-steps x 2 pieces x 64 lanes x 8
+constexpr int kPairChunk = 512;                    // halfs per DMA instruction (64 lanes x 16 B)
+constexpr int kPairMaxLseSplits = 8, kPairMaxGradSplits = 4;
+constexpr int kPairHeader = 256;                   // bytes: [0] max|FA| bits, [1] max|FB| bits
+
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h2v __attribute__((ext_vector_type(2)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f16v mfma_f16(const u4 &a, const u4 &b, const f16v &c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+}
+template <int N_>
+__device__ __forceinline__ void pair_wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory");
+}
+// up = 2^(14 - E), down = 2^(E - 14) for an absolute maximum m = f·2^E, f in [0.5, 1)
+__device__ __forceinline__ void pair_scales(unsigned mbits, float &up, float &down) {
+  int e = (int)((mbits >> 23) & 0xffu) - 126;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);       // zero / denormal / non-finite matrices: any finite scale will do
+  up = __uint_as_float((unsigned)(127 + 14 - e) << 23);
+  down = __uint_as_float((unsigned)(127 - 14 + e) << 23);
+}
+
+__global__ __launch_bounds__(kWG) void pair_maxabs_k(const float *__restrict__ FA, int64_t lda, int rowsA, const float *__restrict__ FB,
+                                                     int64_t ldb, int rowsB, int K, unsigned *__restrict__ header) {
+  const float *F = blockIdx.y ? FB : FA;
+  const int64_t ld = blockIdx.y ? ldb : lda;
+  const int64_t total = (int64_t)(blockIdx.y ? rowsB : rowsA) * K;
+  unsigned m = 0;
+  for (int64_t id = (int64_t)blockIdx.x * kWG + threadIdx.x; id < total; id += (int64_t)gridDim.x * kWG) {
+    const unsigned b = __float_as_uint(F[id / K * ld + id % K]) & 0x7fffffffu;
+    m = b > m ? b : m;
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    const unsigned q = (unsigned)__shfl_xor((int)m, o);
+    m = q > m ? q : m;
+  }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(header + blockIdx.y, m);
+}
+
+// one thread per (row, 4 features) of a side (blockIdx.y): rows [0, npad), feature quads [0, 32)
+__global__ __launch_bounds__(kWG) void pair_split_k(const float *__restrict__ FA, int64_t lda, int rowsA, int npadA, unsigned short *__restrict__ RA,
+                                                    unsigned short *__restrict__ TA, const float *__restrict__ FB, int64_t ldb, int rowsB,
+                                                    int npadB, unsigned short *__restrict__ RB, unsigned short *__restrict__ TB, int K,
+                                                    const unsigned *__restrict__ header) {
+  const bool sb = blockIdx.y != 0;
+  const float *F = sb ? FB : FA;
+  const int64_t ld = sb ? ldb : lda;
+  const int n = sb ? rowsB : rowsA, npad = sb ? npadB : npadA;
+  unsigned short *R = sb ? RB : RA, *T = sb ? TB : TA;
+  const int64_t id = (int64_t)blockIdx.x * kWG + threadIdx.x;
+  if (id >= (int64_t)npad * 32) return;
+  float up, down;
+  pair_scales(header[sb ? 1 : 0], up, down);
+  const int row = (int)(id >> 5), kq = (int)(id & 31) * 4;
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const float v = ((row < n && kq + c < K) ? F[(int64_t)row * ld + kq + c] : 0.f) * up;
+    h[c] = (_Float16)v;
+    l[c] = (_Float16)(v - (float)h[c]);
+  }
+  const int t = row >> 5, i = row & 31;
+  {  // R: [t][ks][p][kh*32 + i][j], k = 16 ks + 8 kh + j
+    const int ks = kq >> 4, kh = (kq >> 3) & 1, j = kq & 7;
+    _Float16 *r = reinterpret_cast<_Float16 *>(R) + (size_t)t * kPairTile + ((size_t)(ks * 2) * 64 + kh * 32 + i) * 8 + j;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      r[c] = h[c];
+      r[512 + c] = l[c];
+    }
+  }
+  {  // T: [t][f][s2][p][kh*32 + kfl][j], feature 32 f + kfl, streamed row 16 s2 + 8 (j >> 2) + 4 kh + (j & 3)  (pair_perm)
+    const int s2 = i >> 4, r16 = i & 15, kh = (r16 >> 2) & 1, j = 4 * (r16 >> 3) + (r16 & 3);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int kf = kq + c, f = kf >> 5, kfl = kf & 31;
+      _Float16 *q = reinterpret_cast<_Float16 *>(T) + (size_t)t * kPairTile + ((size_t)((f * 2 + s2) * 2) * 64 + kh * 32 + kfl) * 8 + j;
+      q[0] = h[c];
+      q[512] = l[c];
+    }
+  }
+}
+
+// the wave's share (chunks wave, wave + 4, ...) of NCH 1 KiB chunks from global memory into the LDS stage
+template <int NCH>
+__device__ __forceinline__ void pair_stage(const unsigned short *__restrict__ src, unsigned short *dst, int wave, int lane) {
+#pragma unroll
+  for (int q = 0; q < NCH / 4; ++q) {
+    const int c = wave + 4 * q;
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const u4 *>(src + (size_t)c * kPairChunk) + lane, dst + c * kPairChunk, 16, 0, 0);
+  }
+}
+
+// transposed score tile from the staged R tile: D[i][n] = sum_k Other[i][k] · Own[n][k]   (lane & 31 = n; element e <-> streamed
+// row i = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)); two accumulators (even / odd k-steps) halve the dependent chain
+__device__ __forceinline__ f16v pair_tile(const u4 (&own)[8][2], const unsigned short *st, int lane) {
+  const u4 *s4 = reinterpret_cast<const u4 *>(st) + lane;
+  f16v a0, a1;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) a0[e] = a1[e] = 0.f;
+#pragma unroll
+  for (int ks = 0; ks < 8; ks += 2) {
+    const u4 h0 = s4[(ks * 2) * 64], l0 = s4[(ks * 2 + 1) * 64], h1 = s4[(ks * 2 + 2) * 64], l1 = s4[(ks * 2 + 3) * 64];
+    a0 = mfma_f16(l0, own[ks][0], a0);
+    a1 = mfma_f16(l1, own[ks + 1][0], a1);
+    a0 = mfma_f16(h0, own[ks][1], a0);
+    a1 = mfma_f16(h1, own[ks + 1][1], a1);
+    a0 = mfma_f16(h0, own[ks][0], a0);
+    a1 = mfma_f16(h1, own[ks + 1][0], a1);
+  }
+  return a0 + a1;
+}
+
+__device__ __forceinline__ void pair_load_own(u4 (&own)[8][2], const unsigned short *__restrict__ R, int tile, int lane) {
+  const u4 *g = reinterpret_cast<const u4 *>(R + (size_t)tile * kPairTile) + lane;
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks) {
+    own[ks][0] = g[(ks * 2) * 64];
+    own[ks][1] = g[(ks * 2 + 1) * 64];
+  }
+}
+
+// grid (ceil(tilesA / 4), splits); part[split][row][4] = (max, sum, target logit, -)
+__global__ __launch_bounds__(kWG, 2) void pair_lse_k(const unsigned short *__restrict__ RA, const unsigned short *__restrict__ RB,
+                                                     const int64_t *__restrict__ target, int NA, int NB, int npadA,
+                                                     const unsigned *__restrict__ header, float *__restrict__ part) {
+  __shared__ __attribute__((aligned(16))) unsigned short stage[2][kPairTile];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = lane & 31, kh = lane >> 5;
+  const int tilesA = (NA + 31) / 32, tilesB = (NB + 31) / 32;
+  const int mytile = blockIdx.x * 4 + wave;
+  const int n0 = mytile * 32;
+  u4 own[8][2];
+  pair_load_own(own, RA, mytile < tilesA ? mytile : tilesA - 1, lane);
+  float upA, downA, upB, downB;
+  pair_scales(header[0], upA, downA);
+  pair_scales(header[1], upB, downB);
+  const float sAB = downA * downB;
+  const int tgt = (n0 + n < NA) ? (int)target[n0 + n] : -1;
+  const int per = (tilesB + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int t0 = blockIdx.y * per, t1 = min(tilesB, t0 + per);
+  float m = -INFINITY, l = 0.f, tl = 0.f;
+  pair_wait_vmcnt<0>();                              // (own fragments, target: out of the way of the counted stage loads)
+  if (t0 < t1) pair_stage<16>(RB + (size_t)t0 * kPairTile, stage[0], wave, lane);
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    if (t + 1 < t1) {
+      pair_stage<16>(RB + (size_t)(t + 1) * kPairTile, stage[buf ^ 1], wave, lane);
+      pair_wait_vmcnt<4>();
+    } else {
+      pair_wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();                    // every wave's share of tile t has landed
+    const f16v acc = pair_tile(own, stage[buf], lane);
+    float sv[16], tmax = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int i = t * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+      const float s = acc[e] * sAB;
+      sv[e] = i < NB ? s : -INFINITY;
+      tl += i == tgt ? s : 0.f;
+      tmax = fmaxf(tmax, sv[e]);
+    }
+    if (tmax > -INFINITY) {
+      const float mn = fmaxf(m, tmax);
+      float add = 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) add += __expf(sv[e] - mn);          // (exp(-inf) = 0 for the columns past NB)
+      l = l * __expf(m - mn) + add;
+      m = mn;
+    }
+    __builtin_amdgcn_s_barrier();                    // all waves are done with stage[buf] before tile t + 2 lands in it
+  }
+  // the two half-waves hold different columns of the same row
+  const float m2 = __shfl_xor(m, 32), l2 = __shfl_xor(l, 32), t2 = __shfl_xor(tl, 32);
+  const float mn = fmaxf(m, m2);
+  l = (m > -INFINITY ? l * __expf(m - mn) : 0.f) + (m2 > -INFINITY ? l2 * __expf(m2 - mn) : 0.f);
+  tl += t2;
+  if (kh == 0 && n0 + n < NA) {
+    float *p = part + ((size_t)blockIdx.y * npadA + n0 + n) * 4;
+    *reinterpret_cast<f4 *>(p) = f4{mn, l, tl, 0.f};
+  }
+}
+
+__global__ __launch_bounds__(kWG) void pair_combine_k(const float *__restrict__ part, int splits, int npadA, int NA, float *__restrict__ lse,
+                                                      float *__restrict__ rowloss) {
+  const int r = blockIdx.x * kWG + threadIdx.x;
+  if (r >= NA) return;
+  float mm = -INFINITY;
+  for (int s = 0; s < splits; ++s) mm = fmaxf(mm, part[((size_t)s * npadA + r) * 4]);
+  float ll = 0.f, tt = 0.f;
+  for (int s = 0; s < splits; ++s) {
+    const f4 v = *reinterpret_cast<const f4 *>(part + ((size_t)s * npadA + r) * 4);
+    ll += v.x > -INFINITY ? v.y * __expf(v.x - mm) : 0.f;
+    tt += v.z;
+  }
+  const float ls = mm + __logf(ll);
+  lse[r] = ls;
+  rowloss[r] = ls - tt;
+}
+
+struct PairGradSide {
+  const unsigned short *Rown, *Roth, *Toth;
+  float *part;             // [splits][npad_own][128]
+  int Nown, Noth, npad_own, nblk, splits;
+};
+
+// grid: side A's nblk x splits workgroups, then side B's.  Own rows n of side A carry lse / target themselves; for side B
+// (own rows are COLUMNS of the score matrix) they belong to the streamed rows and come through the stage.
+__global__ __launch_bounds__(kWG, 2) void pair_grad_k(PairGradSide A, PairGradSide B, const int64_t *__restrict__ target,
+                                                      const float *__restrict__ lse, const unsigned *__restrict__ header, int NA) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short gstage[];      // 2 x (R tile | T tile | 4 x 256 B lse / target)
+  constexpr int kStage = 2 * kPairTile + 4 * 128;                              // halfs
+  const bool ownA = blockIdx.x < (unsigned)(A.nblk * A.splits);
+  const PairGradSide &S = ownA ? A : B;
+  const int bid = ownA ? blockIdx.x : blockIdx.x - A.nblk * A.splits;
+  const int blk = bid % S.nblk, split = bid / S.nblk;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n = lane & 31, kh = lane >> 5;
+  const int tiles_own = (S.Nown + 31) / 32, tiles_oth = (S.Noth + 31) / 32;
+  const int mytile = blk * 4 + wave;
+  const int n0 = mytile * 32;
+  const bool own_ok = n0 + n < S.Nown;
+  u4 own[8][2];
+  pair_load_own(own, S.Rown, mytile < tiles_own ? mytile : tiles_own - 1, lane);
+  float upA, downA, upB, downB;
+  pair_scales(header[0], upA, downA);
+  pair_scales(header[1], upB, downB);
+  const float sAB = downA * downB;
+  float my_lse = 0.f;
+  int my_tgt = -1;
+  if (ownA && own_ok) {
+    my_lse = lse[n0 + n];
+    my_tgt = (int)target[n0 + n];
+  }
+  const int per = (tiles_oth + S.splits - 1) / S.splits;
+  const int t0 = split * per, t1 = min(tiles_oth, t0 + per);
+  f16v g[4];                                   // dOwn[n][32 f + (e&3) + 8 (e>>2) + 4 kh], f = 0..3
+#pragma unroll
+  for (int f = 0; f < 4; ++f)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) g[f][e] = 0.f;
+  auto issue = [&](int t, int buf) {
+    unsigned short *st = gstage + buf * kStage;
+    pair_stage<16>(S.Roth + (size_t)t * kPairTile, st, wave, lane);
+    pair_stage<16>(S.Toth + (size_t)t * kPairTile, st + kPairTile, wave, lane);
+    // lanes 0..31: lse of the streamed rows, lanes 32..63: their targets (low words) — a private copy per wave
+    const int i = min(t * 32 + n, NA - 1);
+    const void *src = kh ? static_cast<const void *>(target + i) : static_cast<const void *>(lse + i);
+    __builtin_amdgcn_global_load_lds(static_cast<const unsigned *>(src), st + 2 * kPairTile + wave * 128, 4, 0, 0);
+  };
+  pair_wait_vmcnt<0>();
+  if (t0 < t1) issue(t0, 0);
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    if (t + 1 < t1) {
+      issue(t + 1, buf ^ 1);
+      pair_wait_vmcnt<9>();
+    } else {
+      pair_wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    const unsigned short *st = gstage + buf * kStage;
+    const f16v acc = pair_tile(own, st, lane);
+    const float *aux = reinterpret_cast<const float *>(st + 2 * kPairTile + wave * 128);
+    // P (times 2^14) for my own row and the 16 streamed rows this lane holds, as two fp16 pieces: slot (s2, j) = element 8 s2 + j
+    u4 PH[2], PL[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      float pv[8];
+#pragma unroll
+      for (int jq = 0; jq < 2; ++jq) {
+        const int il = 16 * s2 + 8 * jq + 4 * kh;                       // streamed rows il .. il + 3 of the tile (elements 8 s2 + 4 jq + 0..3)
+        f4 ls4 = f4{my_lse, my_lse, my_lse, my_lse};
+        int tg[4] = {my_tgt, my_tgt, my_tgt, my_tgt};
+        if (!ownA) {
+          ls4 = *reinterpret_cast<const f4 *>(aux + il);
+          const int4 q4 = *reinterpret_cast<const int4 *>(aux + 32 + il);
+          tg[0] = q4.x; tg[1] = q4.y; tg[2] = q4.z; tg[3] = q4.w;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int e = 8 * s2 + 4 * jq + c;
+          const int i = t * 32 + il + c;                                // streamed (other) row
+          const bool hit = ownA ? (i == tg[c]) : (tg[c] == n0 + n);
+          const float p = __expf(acc[e] * sAB - ls4[c]) - (hit ? 1.f : 0.f);
+          pv[4 * jq + c] = (own_ok && i < S.Noth) ? p * 16384.f : 0.f;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const h2v h = __builtin_convertvector(f2v{pv[2 * q], pv[2 * q + 1]}, h2v);
+        const h2v lo = __builtin_convertvector(f2v{pv[2 * q] - (float)h.x, pv[2 * q + 1] - (float)h.y}, h2v);
+        PH[s2][q] = __builtin_bit_cast(unsigned, h);
+        PL[s2][q] = __builtin_bit_cast(unsigned, lo);
+      }
+    }
+    // dOwn[n][kf] += sum_i P[n][i] Other[i][kf]: D2[kf][n], operand A = T tile (feature-major, pair_perm order), operand B = P
+    const u4 *t4 = reinterpret_cast<const u4 *>(st + kPairTile) + lane;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      u4 th[4], tl_[4];
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        th[f] = t4[((f * 2 + s2) * 2) * 64];
+        tl_[f] = t4[((f * 2 + s2) * 2 + 1) * 64];
+      }
+#pragma unroll
+      for (int f = 0; f < 4; ++f) g[f] = mfma_f16(tl_[f], PH[s2], g[f]);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) g[f] = mfma_f16(th[f], PL[s2], g[f]);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) g[f] = mfma_f16(th[f], PH[s2], g[f]);
+    }
+    __builtin_amdgcn_s_barrier();
+  }
+  if (mytile < tiles_own) {
+    float *p = S.part + ((size_t)split * S.npad_own + n0 + n) * kPairKP;
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        *reinterpret_cast<f4 *>(p + 32 * f + 8 * q + 4 * kh) = f4{g[f][4 * q], g[f][4 * q + 1], g[f][4 * q + 2], g[f][4 * q + 3]};
+  }
+}
+
+// dOwn[r][k] = (gloss / NA) 2^-14 down_other · sum_splits part[s][r][k] for r < Nown, 0 for the padding rows; one thread per
+// (row, 4 features) of a side (blockIdx.y)
+__global__ __launch_bounds__(kWG) void pair_reduce_k(PairGradSide A, PairGradSide B, float *__restrict__ dFA, int64_t ldda, int rowsA,
+                                                     float *__restrict__ dFB, int64_t lddb, int rowsB, int K,
+                                                     const float *__restrict__ gloss, const unsigned *__restrict__ header, int NA) {
+  const bool sb = blockIdx.y != 0;
+  const PairGradSide &S = sb ? B : A;
+  float *d = sb ? dFB : dFA;
+  const int64_t ldd = sb ? lddb : ldda;
+  const int rows = sb ? rowsB : rowsA;
+  const int64_t id = (int64_t)blockIdx.x * kWG + threadIdx.x;
+  const int r = (int)(id >> 5), k = (int)(id & 31) * 4;
+  if (r >= rows || k >= K) return;
+  f4 v = f4{0.f, 0.f, 0.f, 0.f};
+  if (r < S.Nown) {
+    for (int s = 0; s < S.splits; ++s) v += *reinterpret_cast<const f4 *>(S.part + ((size_t)s * S.npad_own + r) * kPairKP + k);
+    float up, down;
+    pair_scales(header[sb ? 0 : 1], up, down);      // the OTHER side's features were scaled up
+    v *= gloss[0] / (float)NA * (1.f / 16384.f) * down;
+  }
+  float *o = d + (int64_t)r * ldd + k;
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (k + c < K) o[c] = v[c];
+}
+
 }  // namespace
 
 extern "C" {
@@ -2528,6 +2912,94 @@ int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems
   else
     hipLaunchKernelGGL((gather_segments_k<1>), dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, base,
                        rows_per_item, row_stride, (int)len, total, out);
+  return launch_status();
+}
+
+namespace {
+struct PairWs {
+  int pa, pb;
+  unsigned *header;
+  unsigned short *RA, *TA, *RB, *TB;
+  float *lse_part, *gradA, *gradB;
+  size_t bytes;
+};
+PairWs pair_ws(void *workspace, int64_t rowsA, int64_t rowsB) {
+  PairWs w;
+  w.pa = (int)((rowsA + 31) / 32 * 32);
+  w.pb = (int)((rowsB + 31) / 32 * 32);
+  char *p = static_cast<char *>(workspace);
+  w.header = reinterpret_cast<unsigned *>(p);
+  p += kPairHeader;
+  const size_t fa = (size_t)w.pa * kPairKP * 2 * sizeof(unsigned short), fb = (size_t)w.pb * kPairKP * 2 * sizeof(unsigned short);
+  w.RA = reinterpret_cast<unsigned short *>(p); p += fa;
+  w.TA = reinterpret_cast<unsigned short *>(p); p += fa;
+  w.RB = reinterpret_cast<unsigned short *>(p); p += fb;
+  w.TB = reinterpret_cast<unsigned short *>(p); p += fb;
+  w.lse_part = reinterpret_cast<float *>(p); p += (size_t)kPairMaxLseSplits * w.pa * 4 * sizeof(float);
+  w.gradA = reinterpret_cast<float *>(p); p += (size_t)kPairMaxGradSplits * w.pa * kPairKP * sizeof(float);
+  w.gradB = reinterpret_cast<float *>(p); p += (size_t)kPairMaxGradSplits * w.pb * kPairKP * sizeof(float);
+  w.bytes = (size_t)(p - static_cast<char *>(workspace));
+  return w;
+}
+}  // namespace
+
+size_t sn_pair_fused_workspace_bytes(int64_t rowsA, int64_t rowsB) {
+  if (rowsA < 0 || rowsB < 0 || rowsA > INT_MAX - 64 || rowsB > INT_MAX - 64) return 0;
+  return pair_ws(nullptr, rowsA, rowsB).bytes;
+}
+
+int sn_pair_fused_fwd_f32(const float *FA, int64_t lda, const float *FB, int64_t ldb, const int64_t *target, int64_t NA, int64_t NB,
+                          int64_t rowsA, int64_t rowsB, int32_t K, float *lse, float *rowloss, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (NA < 1 || NB < 1 || rowsA < NA || rowsB < NB || K < 1 || lda < K || ldb < K) return SN_E_SHAPE;
+  if (K > kPairKP) return SN_E_UNSUPPORTED;
+  if (rowsA > INT_MAX - 64 || rowsB > INT_MAX - 64) return SN_E_RANGE;
+  if (!FA || !FB || !target || !workspace || !lse || !rowloss) return SN_E_NULL;
+  if (!aligned16(workspace)) return SN_E_ALIGN;
+  if (workspace_bytes < sn_pair_fused_workspace_bytes(rowsA, rowsB)) return SN_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const PairWs w = pair_ws(workspace, rowsA, rowsB);
+  hipError_t e = hipMemsetAsync(w.header, 0, kPairHeader, s);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(pair_maxabs_k, dim3(64, 2), dim3(kWG), 0, s, FA, lda, (int)rowsA, FB, ldb, (int)rowsB, (int)K, w.header);
+  const int64_t quads = (int64_t)std::max(w.pa, w.pb) * 32;
+  hipLaunchKernelGGL(pair_split_k, dim3((unsigned)((quads + kWG - 1) / kWG), 2), dim3(kWG), 0, s, FA, lda, (int)rowsA, w.pa, w.RA, w.TA, FB, ldb,
+                     (int)rowsB, w.pb, w.RB, w.TB, (int)K, w.header);
+  const int tilesA = (int)((NA + 31) / 32), tilesB = (int)((NB + 31) / 32);
+  const int nblk = (tilesA + 3) / 4;
+  const int splits = std::max(1, std::min({kPairMaxLseSplits, 512 / nblk, tilesB}));
+  hipLaunchKernelGGL(pair_lse_k, dim3((unsigned)nblk, (unsigned)splits), dim3(kWG), 0, s, w.RA, w.RB, target, (int)NA, (int)NB, w.pa, w.header,
+                     w.lse_part);
+  hipLaunchKernelGGL(pair_combine_k, dim3((unsigned)((NA + kWG - 1) / kWG)), dim3(kWG), 0, s, w.lse_part, splits, w.pa, (int)NA, lse, rowloss);
+  return launch_status();
+}
+
+int sn_pair_fused_bwd_f32(const int64_t *target, const float *lse, const float *gloss, int64_t NA, int64_t NB, int64_t rowsA,
+                          int64_t rowsB, int32_t K, float *dFA, int64_t ldda, float *dFB, int64_t lddb, void *workspace,
+                          size_t workspace_bytes, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (NA < 1 || NB < 1 || rowsA < NA || rowsB < NB || K < 1 || K > kPairKP || ldda < K || lddb < K) return SN_E_SHAPE;
+  if (rowsA > INT_MAX - 64 || rowsB > INT_MAX - 64) return SN_E_RANGE;
+  if (!target || !lse || !gloss || !dFA || !dFB || !workspace) return SN_E_NULL;
+  if (workspace_bytes < sn_pair_fused_workspace_bytes(rowsA, rowsB)) return SN_E_WORKSPACE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const PairWs w = pair_ws(workspace, rowsA, rowsB);
+  const int tilesA = (int)((NA + 31) / 32), tilesB = (int)((NB + 31) / 32);
+  PairGradSide A{w.RA, w.RB, w.TB, w.gradA, (int)NA, (int)NB, w.pa, (tilesA + 3) / 4, 1};
+  PairGradSide B{w.RB, w.RA, w.TA, w.gradB, (int)NB, (int)NA, w.pb, (tilesB + 3) / 4, 1};
+  const int want = std::max(1, 512 / (A.nblk + B.nblk));
+  A.splits = std::max(1, std::min({kPairMaxGradSplits, want, tilesB}));
+  B.splits = std::max(1, std::min({kPairMaxGradSplits, want, tilesA}));
+  constexpr size_t lds = (size_t)2 * (2 * kPairTile + 4 * 128) * sizeof(unsigned short);
+  static const hipError_t attr =
+      hipFuncSetAttribute(reinterpret_cast<const void *>(pair_grad_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (attr != hipSuccess) return (int)attr;
+  hipLaunchKernelGGL(pair_grad_k, dim3((unsigned)(A.nblk * A.splits + B.nblk * B.splits)), dim3(kWG), lds, s, A, B, target, lse, w.header,
+                     (int)NA);
+  const int64_t quads = (int64_t)std::max(rowsA, rowsB) * 32;
+  hipLaunchKernelGGL(pair_reduce_k, dim3((unsigned)((quads + kWG - 1) / kWG), 2), dim3(kWG), 0, s, A, B, dFA, ldda, (int)rowsA, dFB, lddb,
+                     (int)rowsB, (int)K, gloss, w.header, (int)NA);
   return launch_status();
 }
 

@@ -7,6 +7,7 @@ score matrix, trained with the argmin-target cross entropy of loss_fun_delta_cro
 """
 from __future__ import annotations
 
+import os
 import weakref
 
 import numpy as np
@@ -374,6 +375,38 @@ class _StreamedCorrespondenceCE(torch.autograd.Function):
         return gFA, gFB, None, None
 
 
+class _FusedCorrespondenceCE(torch.autograd.Function):
+    """mean_r CE(FA[r]·FBᵀ, target[r]) over the NA x NB corner, from the (rows, K) tower features: scores, soft-max and both
+    gradient products in hand-written matrix-pipe kernels, the score matrix never in memory (sn_pair_fused_fwd/bwd_f32;
+    replaces models.py:203 + main.py:238-239 and their backward passes — two 7000 x 7000 x 120 library GEMMs among them)."""
+
+    @staticmethod
+    def forward(ctx, FA, FB, target, NA, NB):
+        lse, rowloss, ws = kernels.pair_fused_fwd(FA, FB, target, NA, NB)
+        ctx.save_for_backward(target, lse, ws)
+        ctx.dims = (NA, NB, FA.shape[0], FB.shape[0], FA.shape[1])
+        return rowloss.sum() / NA
+
+    @staticmethod
+    def backward(ctx, g):
+        target, lse, ws = ctx.saved_tensors
+        dFA, dFB = kernels.pair_fused_bwd(target, lse, g.reshape(1).contiguous(), ws, *ctx.dims)
+        return dFA, dFB, None, None, None
+
+
+_FUSED_SCORES = os.environ.get("SN_PAIR_FUSED", "1") != "0"      # A/B switch: "0" = bmm + sn_pair_ce_* on the score matrix
+
+
+def fused_pair_supported(FA, FB) -> bool:
+    return (_FUSED_SCORES and FA.is_cuda and FA.dtype == torch.float32 and FB.dtype == torch.float32 and FA.dim() == 3
+            and FA.shape[-1] == FB.shape[-1] <= 128 and FA[0].is_contiguous() and FB[0].is_contiguous())
+
+
+def fused_pair_cross_entropy(FA, FB, target, NA: int, NB: int):
+    """The loss of one pair from the (B, N, K) tower outputs — sample 0 is the one scored (main.py:238)."""
+    return _FusedCorrespondenceCE.apply(FA[0], FB[0], target, NA, NB)
+
+
 def streamed_delta_cross_entropy(FA, FB, targetX, targetY, block=1024):
     """loss_fun_delta_cross_entropy (main.py:229-240) computed from the tower features instead of bmm(FA, FBᵀ):
     FA, FB are the (B, N, 120) tower outputs.  Same value/gradients as SiameseModel + loss_fun_delta_cross_entropy,
@@ -479,7 +512,14 @@ class PairBatch:
 
 def forward_loss(model, b: PairBatch):
     """loss_fun_delta_cross_entropy for the one pair of a PairBatch (main.py:229-240 at batch size 1), target precomputed."""
-    out = model(_operation(b.LX, b.mX), _operation(b.LY, b.mY), b.inX, b.inY)
+    if isinstance(model, SiameseModel):
+        # same value as model(...) + pair_cross_entropy, without the (1, N, N) score matrix in between
+        FA, FB = model.towers(_operation(b.LX, b.mX), _operation(b.LY, b.mY), b.inX, b.inY)
+        if fused_pair_supported(FA, FB):
+            return fused_pair_cross_entropy(FA, FB, b.target, b.NA, b.NB).reshape(1)
+        out = torch.bmm(FA, FB.transpose(1, 2))
+    else:
+        out = model(_operation(b.LX, b.mX), _operation(b.LY, b.mY), b.inX, b.inY)
     return pair_cross_entropy(out, b.target, b.NA, b.NB).reshape(1)
 
 

@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "pair_ce_fwd", "pair_ce_bwd", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "pair_ce_fwd", "pair_ce_bwd", "pair_fused_fwd", "pair_fused_bwd", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
 ]
 
 
@@ -921,6 +921,37 @@ def pair_ce_bwd(S, target, lse, gloss, NA: int, NB: int):
     _lib.call("sn_pair_ce_bwd_f32", _p(S), S.stride(0), _p(target.contiguous()), _p(lse), _p(gloss), NA, NB, S.shape[0], S.shape[1],
               _p(dS), dS.stride(0), _stream())
     return dS
+
+
+def pair_fused_fwd(FA, FB, target, NA: int, NB: int):
+    """(lse, rowloss, workspace) of the correspondence cross entropy computed from the tower features FA (rowsA x K), FB
+    (rowsB x K): the scores FA·FBᵀ (models.py:203) are formed tile by tile on the matrix pipe and never written
+    (sn_pair_fused_fwd_f32).  `workspace` holds the split features for pair_fused_bwd."""
+    _dev(FA, FB, target)
+    for t in (FA, FB):
+        if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1:
+            raise TypeError("pair_fused_fwd: row-major float32 feature matrices expected")
+    if target.dtype != torch.int64 or FA.shape[1] != FB.shape[1]:
+        raise TypeError("pair_fused_fwd: int64 targets and features of one width expected")
+    if not (0 < NA <= FA.shape[0] and 0 < NB <= FB.shape[0]) or target.numel() != NA:
+        raise ValueError("pair_fused_fwd: NA / NB do not fit the feature matrices / target vector")
+    nbytes = _lib.load().sn_pair_fused_workspace_bytes(FA.shape[0], FB.shape[0])
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=FA.device)
+    lse = torch.empty(NA, dtype=torch.float32, device=FA.device)
+    rowloss = torch.empty(NA, dtype=torch.float32, device=FA.device)
+    _lib.call("sn_pair_fused_fwd_f32", _p(FA), FA.stride(0), _p(FB), FB.stride(0), _p(target.contiguous()), NA, NB, FA.shape[0], FB.shape[0],
+              FA.shape[1], _p(lse), _p(rowloss), _p(ws), nbytes, _stream())
+    return lse, rowloss, ws
+
+
+def pair_fused_bwd(target, lse, gloss, ws, NA: int, NB: int, rowsA: int, rowsB: int, K: int):
+    """(dFA, dFB) of mean_r rowloss[r] times the device scalar gloss (sn_pair_fused_bwd_f32); rows past NA / NB are zero."""
+    _dev(target, lse, gloss, ws)
+    dFA = torch.empty((rowsA, K), dtype=torch.float32, device=lse.device)
+    dFB = torch.empty((rowsB, K), dtype=torch.float32, device=lse.device)
+    _lib.call("sn_pair_fused_bwd_f32", _p(target.contiguous()), _p(lse), _p(gloss), NA, NB, rowsA, rowsB, K, _p(dFA), K, _p(dFB), K,
+              _p(ws), ws.numel(), _stream())
+    return dFA, dFB
 
 
 def masked_smooth_l1_fwd(out2d, target2d, rowmask, scale: float):

@@ -840,6 +840,67 @@ def test_pair_cross_entropy_matches_torch(N, NA, NB):
         assert gg[:, NB:].abs().max().item() == 0 if N > NB else True
 
 
+@pytest.mark.parametrize("rows,NA,NB,K", [(7, 7, 7, 120), (80, 63, 70, 120), (33, 33, 1, 5), (300, 257, 290, 128), (1024, 1000, 1021, 64),
+                                          (7000, 6890, 6890, 120)])
+def test_fused_pair_cross_entropy_matches_the_score_matrix_path(rows, NA, NB, K):
+    """sn_pair_fused_fwd/bwd_f32 (scores formed on the matrix pipe from three-piece bf16 splits, never written) against the
+    cross entropy of the materialised bmm(FA, FBᵀ) (models.py:203, main.py:238-239) in fp64: value, both feature gradients,
+    exact zeros for the padding rows, targets on the last column / row of the corner, run-to-run identical results."""
+    import torch.nn.functional as F
+
+    from surfacenetworks_amd import dense_correspondence as dc
+
+    g = torch.Generator().manual_seed(rows + K)
+    rowsB = rows + 5
+    FA = (torch.randn(1, rows, K, generator=g) * 0.7).to(DEV).requires_grad_(True)
+    FB = (torch.randn(1, rowsB, K, generator=g) * 0.7).to(DEV).requires_grad_(True)
+    tgt = torch.randint(0, NB, (NA,), generator=g)
+    tgt[0], tgt[-1] = NB - 1, 0
+    tgt = tgt.to(DEV)
+    A64, B64 = FA.detach().double().requires_grad_(True), FB.detach().double().requires_grad_(True)
+    want = F.cross_entropy(torch.bmm(A64, B64.transpose(1, 2))[0, :NA, :NB], tgt)
+    wa, wb = torch.autograd.grad(want * 1.7, (A64, B64))
+    assert dc.fused_pair_supported(FA, FB)
+    got = dc.fused_pair_cross_entropy(FA, FB, tgt, NA, NB)
+    ga, gb = torch.autograd.grad(got * 1.7, (FA, FB))
+    assert abs(got.item() - want.item()) <= 2e-6 * abs(want.item())
+    assert ga.shape == FA.shape and gb.shape == FB.shape
+    assert rel_err(ga.cpu().numpy(), wa.cpu().numpy()) < 5e-6 and rel_err(gb.cpu().numpy(), wb.cpu().numpy()) < 5e-6
+    assert rows == NA or ga[0, NA:].abs().max().item() == 0
+    assert gb[0, NB:].abs().max().item() == 0
+    got2 = dc.fused_pair_cross_entropy(FA, FB, tgt, NA, NB)
+    ga2, gb2 = torch.autograd.grad(got2 * 1.7, (FA, FB))
+    assert torch.equal(got, got2) and torch.equal(ga, ga2) and torch.equal(gb, gb2)
+    # and against the product's other path (library GEMM + sn_pair_ce_*), at fp32 agreement
+    out = torch.bmm(FA, FB.transpose(1, 2))
+    l2 = dc.pair_cross_entropy(out, tgt, NA, NB)
+    assert abs(l2.item() - got.item()) <= 5e-6 * abs(got.item())
+
+
+def test_fused_pair_argument_checks():
+    from surfacenetworks_amd import _lib
+
+    lib = _lib.load()
+    f = torch.zeros(64, 120, device=DEV)
+    t = torch.zeros(64, dtype=torch.int64, device=DEV)
+    o = torch.zeros(64, device=DEV)
+    need = lib.sn_pair_fused_workspace_bytes(64, 64)
+    assert need == 256 + 2 * (64 * 128 * 2 * 2) * 2 + 8 * 64 * 4 * 4 + 4 * 2 * 64 * 128 * 4      # header, R + T of both sides, partials
+    ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
+    p = lambda x: x.data_ptr()
+    SN_E_NULL, SN_E_SHAPE, SN_E_UNSUPPORTED, SN_E_WORKSPACE = -1, -2, -7, -6
+    fw = lib.sn_pair_fused_fwd_f32
+    assert fw(p(f), 120, p(f), 120, p(t), 64, 64, 64, 64, 120, p(o), p(o), p(ws), need, None) == 0
+    assert fw(p(f), 120, p(f), 120, p(t), 65, 64, 64, 64, 120, p(o), p(o), p(ws), need, None) == SN_E_SHAPE       # NA > rowsA
+    assert fw(p(f), 120, p(f), 120, p(t), 64, 64, 64, 64, 129, p(o), p(o), p(ws), need, None) in (SN_E_SHAPE, SN_E_UNSUPPORTED)
+    assert fw(p(f), 200, p(f), 200, p(t), 8, 8, 8, 8, 129, p(o), p(o), p(ws), need, None) == SN_E_UNSUPPORTED
+    assert fw(p(f), 120, p(f), 120, p(t), 64, 64, 64, 64, 120, p(o), p(o), p(ws), need - 1, None) == SN_E_WORKSPACE
+    assert fw(None, 120, p(f), 120, p(t), 64, 64, 64, 64, 120, p(o), p(o), p(ws), need, None) == SN_E_NULL
+    bw = lib.sn_pair_fused_bwd_f32
+    assert bw(p(t), p(o), p(o), 64, 64, 64, 64, 120, p(f), 120, None, 120, p(ws), need, None) == SN_E_NULL
+    assert bw(p(t), p(o), p(o), 64, 64, 64, 64, 120, p(f), 119, p(f), 120, p(ws), need, None) == SN_E_SHAPE
+
+
 @pytest.mark.parametrize("B", [1, 2])
 def test_pair_cross_entropy_takes_the_siamese_output(B):
     """The (B, N, N) output of SiameseModel goes in whole: sample 0 is scored (main.py:238), the gradient comes back in the
