@@ -474,6 +474,21 @@ int sn_bn_fold_f32(const double *stats, int64_t rows, const float *gamma, const 
                    const float *b, int32_t J, int32_t C, double eps, double momentum, int32_t training,
                    float *running_mean, float *running_var, float *mean, float *invstd, float *s, float *t,
                    float *Wf, float *bf, int64_t *num_batches_tracked, void *stream);
+/* sn_bn_fold_parts_f32 : the training-mode fold with the statistics reduction inside — one launch in place of
+ * sn_colstats_merge_f64 (once per half of a concat buffer) + sn_bn_fold_f32.  The C = C_lo + C_hi (128 or 256) channels'
+ * sums / sums of squares arrive as per-workgroup partials of up to two producers: part_lo ([nblk_lo][2][C_lo] fp64) for
+ * channels [0, C_lo), part_hi ([nblk_hi][2][C_hi]) for the rest; a NULL pointer (or 0 blocks) stands for columns that are all
+ * zero.  Outputs and running-statistics update as sn_bn_fold_f32 in training mode; summation order fixed.  `counter`: one
+ * int32 of device memory that is 0 when the launch starts and is left 0 (a ticket for the workgroup that folds the weights
+ * after the last channel's scalars are published); two launches that may run CONCURRENTLY need different counters.
+ * sn_colstats_partial_f32 : the statistics pass over x WITHOUT its final reduction — partial[sn_colstats_blocks(rows)][2][C]
+ * fp64, the producer format above. */
+int sn_bn_fold_parts_f32(const double *part_lo, int32_t nblk_lo, int32_t C_lo, const double *part_hi, int32_t nblk_hi, int32_t C_hi,
+                         int64_t rows, const float *gamma, const float *beta, const float *W, const float *b, int32_t J, double eps,
+                         double momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked, float *mean,
+                         float *invstd, float *s, float *t, float *Wf, float *bf, int32_t *counter, void *stream);
+int32_t sn_colstats_blocks(int64_t rows);
+int sn_colstats_partial_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *partial, void *stream);
 int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W, const float *s, const float *invstd,
                          const float *beta, int64_t rows, int32_t J, int32_t C, float *dW, float *db, float *dgamma,
                          float *dbeta, float *Bc, float *Cc, void *stream);

@@ -1464,6 +1464,119 @@ __global__ __launch_bounds__(kWG) void bn_fold_k(const double *__restrict__ stat
   if (threadIdx.x == 0) bf[j] = (float)((b ? (double)b[j] : 0.0) + red[0]);
 }
 
+// The statistics reduction and the fold in ONE launch (training mode): replaces colstats_final_k (once per half of a concat
+// buffer) + bn_fold_k — three dependent launches of 4-5 us in front of every Linear of a small batch.  The column statistics
+// arrive as per-workgroup partials of up to two producers ([nblk][2][Cx] fp64 each: the ELU epilogue of the previous GEMM, the
+// statistics epilogue of the SpMM, or colstats_k): workgroup b reduces channels 16 b .. 16 b + 15 (both kinds, 8 row groups,
+// fixed order), publishes their mean / invstd / s / t and updates the running statistics; the workgroup that finishes LAST
+// (a ticket from `counter`, which it leaves at 0 for the next launch) folds the weights: no workgroup waits for another.
+struct BnPart {
+  const double *p;       // [nblk][2][C] (NULL / nblk = 0: the columns are all zero)
+  int nblk, C;
+};
+__global__ __launch_bounds__(kWG) void bn_fold_parts_k(BnPart lo, BnPart hi, int64_t rows, const float *__restrict__ gamma,
+                                                       const float *__restrict__ beta, const float *__restrict__ W,
+                                                       const float *__restrict__ b, int J, int C, double eps, double momentum,
+                                                       float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                       int64_t *__restrict__ num_batches_tracked, float *__restrict__ mean_o,
+                                                       float *__restrict__ invstd_o, float *s_o, float *t_o,
+                                                       float *__restrict__ Wf, float *__restrict__ bf, int *counter) {
+  __shared__ double sm[8][32];
+  __shared__ double dots[64][65];
+  __shared__ float ss[256], st[256];
+  __shared__ int ticket;
+  const int tid = threadIdx.x;
+  {
+    const int ch = tid & 15, kind = (tid >> 4) & 1, g = tid >> 5;
+    const int c = blockIdx.x * 16 + ch;
+    double t = 0;
+    if (c < C) {
+      const BnPart &src = c < lo.C ? lo : hi;
+      const int col = c < lo.C ? c : c - lo.C;
+      const double *p = src.p + (int64_t)kind * src.C + col;
+      const int64_t stride = 2 * (int64_t)src.C;
+      int r = g;
+      for (; r + 56 < src.nblk; r += 64) {       // eight loads in flight, added in the original order
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(r + 8 * u) * stride];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t += v[u];
+      }
+      for (; r < src.nblk; r += 8) t += p[(int64_t)r * stride];
+    }
+    sm[g][tid & 31] = t;
+  }
+  __syncthreads();
+  if (tid < 16 && blockIdx.x * 16 + tid < C) {
+    const int c = blockIdx.x * 16 + tid;
+    double sum = 0, sq = 0;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+      sum += sm[g][tid];
+      sq += sm[g][16 + tid];
+    }
+    const double mean = sum / (double)rows;
+    double var = sq / (double)rows - mean * mean;
+    var = var > 0 ? var : 0;
+    const double invstd = 1.0 / sqrt(var + eps);
+    const double sc = (double)gamma[c] * invstd;
+    const double tc = (double)beta[c] - mean * sc;
+    mean_o[c] = (float)mean;
+    invstd_o[c] = (float)invstd;
+    s_o[c] = (float)sc;
+    t_o[c] = (float)tc;
+    if (running_mean) {
+      const double unbiased = var * ((double)rows / (double)(rows > 1 ? rows - 1 : 1));
+      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
+    }
+  }
+  if (blockIdx.x == 0 && tid == 0 && num_batches_tracked) num_batches_tracked[0] += 1;      // nn.BatchNorm1d's counter
+  __threadfence();                               // my channels' scalars are visible device-wide before my ticket is
+  __syncthreads();
+  if (tid == 0) ticket = atomicAdd(counter, 1);
+  __syncthreads();
+  if (ticket != (int)gridDim.x - 1) return;
+  // ---- the last workgroup: every channel's s and t are published ----
+  __threadfence();
+  if (tid == 0) *counter = 0;
+  for (int c = tid; c < C; c += kWG) {           // (read past this CU's vector cache: written by other workgroups of this launch)
+    ss[c] = __builtin_nontemporal_load(s_o + c);
+    st[c] = __builtin_nontemporal_load(t_o + c);
+  }
+  __syncthreads();
+  // Wf = W·diag(s), bf = b + W·t (fp64 sum), 64 rows of W at a time: C/4 lanes per row, every lane's rows loaded at once (one
+  // memory latency per 64 rows), the lanes' partial dot products summed per row through LDS in a fixed order
+  const int lpr = C >> 2, rpi = kWG / lpr;       // lanes per row (32 | 64), rows per pass of the workgroup (8 | 4)
+  const int rl = tid / lpr, ln = tid - rl * lpr, c4 = ln * 4;
+  const f4 s4 = *reinterpret_cast<const f4 *>(ss + c4), t4 = *reinterpret_cast<const f4 *>(st + c4);
+  for (int j0 = 0; j0 < J; j0 += 64) {
+    f4 w[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int jl = rl + rpi * u, j = j0 + jl;
+      w[u] = (jl < 64 && j < J) ? *reinterpret_cast<const f4 *>(W + (int64_t)j * C + c4) : f4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int jl = rl + rpi * u, j = j0 + jl;
+      if (jl < 64 && j < J) {
+        *reinterpret_cast<f4 *>(Wf + (int64_t)j * C + c4) = w[u] * s4;
+        dots[jl][ln] = ((double)w[u].x * (double)t4.x + (double)w[u].y * (double)t4.y) +
+                       ((double)w[u].z * (double)t4.z + (double)w[u].w * (double)t4.w);
+      }
+    }
+    __syncthreads();
+    if (tid < 64 && j0 + tid < J) {
+      double d = 0;
+      for (int k = 0; k < lpr; ++k) d += dots[tid][k];
+      bf[j0 + tid] = (float)((b ? (double)b[j0 + tid] : 0.0) + d);
+    }
+    __syncthreads();
+  }
+}
+
 // 32 channels x 8 row-groups per workgroup: group g handles output rows j = g, g+8, ...; the two per-channel
 // reductions over j are combined across the 8 groups in a fixed order.
 __global__ __launch_bounds__(kWG) void bn_bwd_coeffs_k(const float *__restrict__ Gc, const double *__restrict__ sdy,
@@ -2738,6 +2851,43 @@ int sn_bn_fold_f32(const double *stats, int64_t rows, const float *gamma, const 
   hipLaunchKernelGGL(bn_fold_k, dim3(J), dim3(kWG), 0, static_cast<hipStream_t>(stream), stats, rows, gamma, beta, W,
                      b, (int)C, eps, momentum, (int)training, running_mean, running_var, mean, invstd, s, t, Wf, bf,
                      num_batches_tracked);
+  return launch_status();
+}
+
+int sn_bn_fold_parts_f32(const double *part_lo, int32_t nblk_lo, int32_t C_lo, const double *part_hi, int32_t nblk_hi, int32_t C_hi,
+                         int64_t rows, const float *gamma, const float *beta, const float *W, const float *b, int32_t J, double eps,
+                         double momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked, float *mean,
+                         float *invstd, float *s, float *t, float *Wf, float *bf, int32_t *counter, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (rows < 1 || J < 1 || C_lo < 0 || C_hi < 0 || nblk_lo < 0 || nblk_hi < 0) return SN_E_SHAPE;
+  const int C = C_lo + C_hi;
+  if (C != 128 && C != 256) return SN_E_UNSUPPORTED;
+  if (!gamma || !beta || !W || !mean || !invstd || !s || !t || !Wf || !bf || !counter) return SN_E_NULL;
+  if ((nblk_lo > 0 && !part_lo) || (nblk_hi > 0 && !part_hi) || (!running_mean) != (!running_var)) return SN_E_NULL;
+  if (!aligned16(W) || !aligned16(Wf)) return SN_E_ALIGN;
+  const BnPart lo{part_lo, part_lo ? (int)nblk_lo : 0, (int)C_lo}, hi{part_hi, part_hi ? (int)nblk_hi : 0, (int)C_hi};
+  hipLaunchKernelGGL(bn_fold_parts_k, dim3(C / 16), dim3(kWG), 0, static_cast<hipStream_t>(stream), lo, hi, rows, gamma, beta, W, b,
+                     (int)J, C, eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd, s, t, Wf, bf, counter);
+  return launch_status();
+}
+
+int32_t sn_colstats_blocks(int64_t rows) { return rows > 0 ? stat_blocks(rows) : 0; }
+
+int sn_colstats_partial_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *partial, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (rows < 0 || C < 1 || C > 4096 || ld < C) return SN_E_SHAPE;
+  if (rows == 0) return SN_OK;
+  if (!x || !partial) return SN_E_NULL;
+  const int nblk = stat_blocks(rows);
+  const bool vec = (C % 4 == 0) && (kWG % (C / 4) == 0) && (ld % 4 == 0) && aligned16(x);
+  const int cw = vec ? C / 4 : C;
+  if (!vec && cw > kWG) return SN_E_UNSUPPORTED;
+  const size_t shm = (size_t)(kWG / cw) * 2 * C * sizeof(double);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (vec)
+    hipLaunchKernelGGL((colstats_k<true>), dim3(nblk), dim3(kWG), shm, s, x, ld, rows, (int)C, partial);
+  else
+    hipLaunchKernelGGL((colstats_k<false>), dim3(nblk), dim3(kWG), shm, s, x, ld, rows, (int)C, partial);
   return launch_status();
 }
 

@@ -429,6 +429,21 @@ def _take_counter(running_mean):
     return d.pop("_sn_nbt", None) if d is not None else None
 
 
+def _fold_sources(x, part, part_hi, pre_stats):
+    """(lo, hi) producers of the column statistics of the (rows, C) operand x for kernels.bn_fold_parts: ready statistics as
+    a one-block partial; the partials left by the kernels that wrote the halves of a concat buffer; a statistics pass
+    (without its final reduction) over whatever has none."""
+    rows, C = x.shape
+    if pre_stats is not None:
+        return (pre_stats.reshape(1, 2, C), 1, C), (None, 0, 0)
+    if C == 256 and (part is not None or part_hi is not None):
+        h = C // 2
+        lo = (part, kernels.linear_fwd_stats_blocks(rows), h) if part is not None else (*kernels.colstats_partial(x[:, :h]), h)
+        hi = (part_hi, int(part_hi.shape[0]), h) if part_hi is not None else (*kernels.colstats_partial(x[:, h:]), h)
+        return lo, hi
+    return (*kernels.colstats_partial(x), C), (None, 0, 0)
+
+
 def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual=None, elu_out=None,
                   want_y=True, elu_stats=None, pre_stats=None):
     """Forward of the folded BatchNorm1d("pre") + Linear on a (rows, C) operand (no autograd): statistics in one pass
@@ -439,7 +454,13 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     part, part_hi = getattr(x, "_sn_part", None), getattr(x, "_sn_part_hi", None)   # (hi: left by the SpMM that wrote P·e)
     x = _rows2d(x)
     rows = x.shape[0]
-    if not training:
+    folded = None
+    nbt = _take_counter(running_mean)
+    if training and _BN_SYNC is None and rows > 0 and kernels.fold_parts_supported(x.shape[1]):
+        # statistics reduction + fold in one launch, straight from the producers' partials
+        folded = kernels.bn_fold_parts(*_fold_sources(x, part, part_hi, pre_stats), rows, gamma, beta, W, b, eps, momentum,
+                                       running_mean, running_var, nbt)
+    if folded is not None or not training:
         stats = None
     elif pre_stats is not None:                 # (2, C) float64 statistics of x supplied by its producer
         stats = pre_stats
@@ -448,10 +469,13 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     else:
         stats = kernels.colstats(x)
     rows_g = rows
-    if training:
+    if training and folded is None:
         stats, rows_g = _sync_stats(stats, rows)
-    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
-                                                 running_var, _take_counter(running_mean))
+    if folded is not None:
+        mean, invstd, s, t, Wf, bf = folded
+    else:
+        mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
+                                                     running_var, nbt)
     if residual is not None:
         residual = _rows2d(residual)
     if kernels.linear_fwd_supported(x.shape[1], W.shape[0]):
@@ -537,15 +561,23 @@ def bnlin_forward_zero_first(p, gamma, beta, W, b, running_mean, running_var, tr
     rows, C = p.shape
     stats = None
     rows_g = rows
-    if training:
-        stats = torch.zeros((2, 2 * C), dtype=torch.float64, device=p.device)
-        if part_hi is not None and C == 128:
-            kernels.colstats_merge_into(part_hi, stats, C)
-        else:
-            kernels.colstats_into(p, stats, C)
-        stats, rows_g = _sync_stats(stats, rows)
-    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
-                                                 running_var, _take_counter(running_mean))
+    folded = None
+    nbt = _take_counter(running_mean)
+    if training and _BN_SYNC is None and rows > 0 and kernels.fold_parts_supported(2 * C):
+        hi = (part_hi, int(part_hi.shape[0]), C) if (part_hi is not None and C == 128) else (*kernels.colstats_partial(p), C)
+        folded = kernels.bn_fold_parts((None, 0, C), hi, rows, gamma, beta, W, b, eps, momentum, running_mean, running_var, nbt)
+    if folded is not None:
+        mean, invstd, s, t, Wf, bf = folded
+    else:
+        if training:
+            stats = torch.zeros((2, 2 * C), dtype=torch.float64, device=p.device)
+            if part_hi is not None and C == 128:
+                kernels.colstats_merge_into(part_hi, stats, C)
+            else:
+                kernels.colstats_into(p, stats, C)
+            stats, rows_g = _sync_stats(stats, rows)
+        mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
+                                                     running_var, nbt)
     y = kernels.linear_fwd(p, Wf[:, C:], bf, None, elu_out, want_y, elu_stats)
     return y, (p, W, Wf, s, mean, invstd, beta, training, b is not None, rows_g)
 

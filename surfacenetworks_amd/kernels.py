@@ -16,7 +16,7 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "pair_ce_fwd", "pair_ce_bwd", "pair_fused_fwd", "pair_fused_bwd", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "pair_ce_fwd", "pair_ce_bwd", "pair_fused_fwd", "pair_fused_bwd", "bn_fold_parts", "colstats_partial", "linear_fwd_stats_blocks", "fold_parts_supported", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
 ]
 
 
@@ -456,6 +456,84 @@ def bn_fold(stats, rows: int, gamma, beta, W, b, eps: float, momentum: float, tr
     _lib.call("sn_bn_fold_f32", _p(stats), rows, _p(gamma), _p(beta), _p(W.contiguous()), _p(b), J, C, float(eps),
               float(momentum), 1 if training else 0, _p(running_mean), _p(running_var), _p(vec[0]), _p(vec[1]),
               _p(vec[2]), _p(vec[3]), _p(Wf), _p(bf), _p(num_batches_tracked), _stream())
+    return vec[0], vec[1], vec[2], vec[3], Wf, bf
+
+
+_FOLD_COUNTERS = {}          # device index -> [int32 pool, {stream handle: [first slot, launches so far]}]
+_FOLD_STREAMS, _FOLD_SLOTS = 16, 4096
+
+
+def _fold_counter(device):
+    """Address of a zeroed int32 for one sn_bn_fold_parts_f32 launch on the current stream, or None (then the caller takes
+    the three-launch path).  The kernel leaves its counter at 0, so slots are reused; launches of ONE stream run in order, so a
+    stream's slots (round-robin over 4096: consecutive nodes of a captured graph get different ones) never serve two
+    launches at once, and every stream has its own range.  The pool is created on the first eager call (never during a
+    capture: a fill recorded into a graph would not have run yet)."""
+    dev = torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    ent = _FOLD_COUNTERS.get(key)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ent = _FOLD_COUNTERS[key] = [torch.zeros(_FOLD_STREAMS * _FOLD_SLOTS, dtype=torch.int32, device=dev), {}]
+    sid = torch.cuda.current_stream(dev).cuda_stream
+    slot = ent[1].get(sid)
+    if slot is None:
+        if len(ent[1]) >= _FOLD_STREAMS:
+            return None
+        slot = ent[1][sid] = [len(ent[1]) * _FOLD_SLOTS, 0]
+    idx = slot[0] + slot[1] % _FOLD_SLOTS
+    slot[1] += 1
+    return ent[0].data_ptr() + 4 * idx
+
+
+def fold_parts_supported(C: int) -> bool:
+    import os
+
+    # off by default: measured no faster than the three launches it replaces (LABNOTES.md, "helper launches")
+    return C in (128, 256) and os.environ.get("SN_FOLD_PARTS", "0") == "1"
+
+
+def linear_fwd_stats_blocks(rows: int) -> int:
+    """Partial rows the ELU-statistics epilogue of a forward GEMM over `rows` rows leaves (sn_linear_fwd_stats_blocks)."""
+    return int(_lib.load().sn_linear_fwd_stats_blocks(rows))
+
+
+def colstats_partial(x):
+    """(partials (nblk, 2, C) float64, nblk): the statistics pass over the 2-D view x without its final reduction
+    (sn_colstats_partial_f32) — a producer for bn_fold_parts."""
+    _dev(x)
+    rows, C = x.shape
+    nblk = int(_lib.load().sn_colstats_blocks(rows))
+    part = torch.empty((max(nblk, 1), 2, C), dtype=torch.float64, device=x.device)
+    _lib.call("sn_colstats_partial_f32", _p(x), _ld(x), rows, C, _p(part), _stream())
+    return part, nblk
+
+
+def bn_fold_parts(lo, hi, rows: int, gamma, beta, W, b, eps: float, momentum: float, running_mean, running_var,
+                  num_batches_tracked=None):
+    """Training-mode bn_fold with the statistics reduction inside (sn_bn_fold_parts_f32): lo / hi = (partials or None,
+    nblk, channels) of the two halves of the operand (hi may be (None, 0, 0)).  Returns (mean, invstd, s, t, Wf, bf), or None
+    when no launch counter is to be had (the caller then reduces the statistics and calls bn_fold)."""
+    J, C = W.shape
+    counter = _fold_counter(W.device)
+    if counter is None:
+        return None
+    _dev(lo[0], hi[0], gamma, beta, W, b, running_mean, running_var, num_batches_tracked)
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        raise TypeError("num_batches_tracked must be int64")
+    for p_, nb, cx in (lo, hi):
+        if p_ is not None and (p_.dtype != torch.float64 or not p_.is_contiguous() or p_.shape[0] < nb or tuple(p_.shape[1:]) != (2, cx)):
+            raise ValueError("bn_fold_parts: partials must be contiguous (>= nblk, 2, channels) float64")
+    if lo[2] + hi[2] != C:
+        raise ValueError("bn_fold_parts: the halves do not add up to the Linear's input width")
+    dev = W.device
+    vec = torch.empty((4, C), dtype=torch.float32, device=dev)
+    Wf = torch.empty((J, C), dtype=torch.float32, device=dev)
+    bf = torch.empty(J, dtype=torch.float32, device=dev)
+    _lib.call("sn_bn_fold_parts_f32", _p(lo[0]), lo[1], lo[2], _p(hi[0]), hi[1], hi[2], rows, _p(gamma), _p(beta), _p(W.contiguous()), _p(b),
+              J, float(eps), float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(vec[0]), _p(vec[1]),
+              _p(vec[2]), _p(vec[3]), _p(Wf), _p(bf), counter, _stream())
     return vec[0], vec[1], vec[2], vec[3], Wf, bf
 
 

@@ -334,6 +334,26 @@ def colstats_halves(x, part, part_hi=None):
     return out
 
 
+def fold_parts_supported(C):
+    return C in (128, 256)
+
+
+def linear_fwd_stats_blocks(rows):
+    return 1
+
+
+def colstats_partial(x):
+    return colstats(x).reshape(1, 2, x.shape[1]), 1
+
+
+def bn_fold_parts(lo, hi, rows, gamma, beta, W, b, eps, momentum, running_mean, running_var, num_batches_tracked=None):
+    halves = []
+    for p_, nb, cx in (lo, hi):
+        if cx:
+            halves.append(p_[:nb].sum(0) if (p_ is not None and nb) else torch.zeros((2, cx), dtype=torch.float64))
+    return bn_fold(torch.cat(halves, 1), rows, gamma, beta, W, b, eps, momentum, True, running_mean, running_var, num_batches_tracked)
+
+
 def spmm_q3_stats_supported(N, group):
     return N == 32 and group == 4
 
@@ -558,6 +578,19 @@ def pair_ce_bwd(S, target, lse, gloss, NA, NB):
     p.scatter_add_(1, target[:, None], -torch.ones_like(p[:, :1]))
     dS[:NA, :NB] = p * (gloss.reshape(()) / NA)
     return dS
+
+
+def pair_fused_fwd(FA, FB, target, NA, NB):
+    S = (FA.double() @ FB.double().t()).float()
+    lse, rowloss = pair_ce_fwd(S, target, NA, NB)
+    return lse, rowloss, (FA, FB)
+
+
+def pair_fused_bwd(target, lse, gloss, ws, NA, NB, rowsA, rowsB, K):
+    FA, FB = ws
+    S = (FA.double() @ FB.double().t()).float()
+    dS = pair_ce_bwd(S, target, lse, gloss, NA, NB).double()
+    return (dS @ FB.double()).float(), (dS.t() @ FA.double()).float()
 
 
 def masked_smooth_l1_fwd(out2d, target2d, rowmask, scale):

@@ -148,6 +148,17 @@ def check_model(golden_dir, tag, dev, opkind="pool", tol_out=5e-5, classes=None)
         e_prod = _sig_err(grad_signature(m), s64)
         e_ref = _sig_err({k: g[f"faust_lap_psig_{k}"] for k in s64}, s64)
         assert e_prod <= SLACK * e_ref + sp("grad") + FLOOR, ("faust grad", e_prod, e_ref)
+        if torch.device(dev).type == "cuda":
+            # the product's pair step: the same loss from the towers' features, scores never written (sn_pair_fused_*)
+            m2 = deterministic_init(make["faust_lap"](), 11).train().to(dev)
+            FA2, FB2 = m2.towers([L1, mask], [L1, mask], cA, cB)
+            assert dense_correspondence.fused_pair_supported(FA2, FB2)
+            tgt = dense_correspondence.correspondence_target(*tX[0], *tY[0])
+            loss2 = dense_correspondence.fused_pair_cross_entropy(FA2, FB2, tgt, int(lA.size(0)), int(lB.size(0)))
+            loss2.backward()
+            _as_close_as_reference("faust loss (fused)", loss2.item(), float(g["faust_lap_loss"]), loss64.item(), sp("loss"))
+            e_fused = _sig_err(grad_signature(m2), s64)
+            assert e_fused <= SLACK * e_ref + sp("grad") + FLOOR, ("faust grad (fused)", e_fused, e_ref)
         return
     rb, ops = batch_operators(golden_dir, opkind, dev)
     mask = torch.from_numpy(rb["mask"]).to(dev)

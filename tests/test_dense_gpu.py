@@ -840,6 +840,65 @@ def test_pair_cross_entropy_matches_torch(N, NA, NB):
         assert gg[:, NB:].abs().max().item() == 0 if N > NB else True
 
 
+@pytest.mark.parametrize("C,J,rows", [(256, 128, 7000), (128, 64, 5000), (256, 120, 33), (128, 128, 1), (256, 128, 300000)])
+def test_fold_with_the_statistics_reduction_inside_matches_the_three_launch_path(C, J, rows):
+    """sn_bn_fold_parts_f32 (partials of the producers -> statistics -> fold, one launch) against sn_colstats_merge_f64 per
+    half + sn_bn_fold_f32 on the same partials: identical statistics, scalars, folded weights, running statistics and
+    batch counter (the bias dot product is summed in another fixed order: equal to the last bit or one off); a half that is
+    all zero needs no partials; the launch counter is left at zero (same result again, also from two streams at once)."""
+    from surfacenetworks_amd import kernels
+
+    g = torch.Generator().manual_seed(C + J + rows)
+    x = (torch.randn(rows, C, generator=g) * 2 + 0.7).to(DEV)
+    W = torch.randn(J, C, generator=g).to(DEV)
+    b = torch.randn(J, generator=g).to(DEV)
+    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
+    h = C // 2
+
+    def run(fused, zero_lo, stream=None):
+        xx = x.clone()
+        if zero_lo:
+            xx[:, :h] = 0
+        rm, rv = torch.full((C,), 0.25, device=DEV), torch.full((C,), 2.0, device=DEV)
+        nbt = torch.tensor(3, dtype=torch.int64, device=DEV)
+        lo = (None, 0, h) if zero_lo else (*kernels.colstats_partial(xx[:, :h]), h)
+        hi = (*kernels.colstats_partial(xx[:, h:]), h)
+        if fused:
+            out = kernels.bn_fold_parts(lo, hi, rows, gamma, beta, W, b, 1e-5, 0.1, rm, rv, nbt)
+        else:
+            stats = torch.zeros((2, C), dtype=torch.float64, device=DEV)
+            if not zero_lo:
+                kernels.colstats_merge_into(lo[0][:lo[1]], stats, 0)
+            kernels.colstats_merge_into(hi[0][:hi[1]], stats, h)
+            out = kernels.bn_fold(stats, rows, gamma, beta, W, b, 1e-5, 0.1, True, rm, rv, nbt)
+        return [*out, rm, rv, nbt]
+
+    for zero_lo in (False, True):
+        want = run(False, zero_lo)
+        for rep in range(2):
+            got = run(True, zero_lo)
+            for k, (a, w_) in enumerate(zip(got, want)):
+                if k == 5:                                   # bf
+                    assert torch.allclose(a, w_, rtol=3e-7, atol=0), (k, zero_lo)
+                else:
+                    assert torch.equal(a, w_), (k, zero_lo, rep)
+        assert int(got[-1].item()) == 4
+    # two streams at once: each stream has its own counters
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    torch.cuda.synchronize()
+    outs = []
+    for _ in range(8):
+        for st in (s1, s2):
+            with torch.cuda.stream(st):
+                outs.append(run(True, False))
+    torch.cuda.synchronize()
+    want = run(False, False)
+    for got in outs:
+        assert torch.equal(got[4], want[4]) and torch.equal(got[0], want[0]) and torch.allclose(got[5], want[5], rtol=3e-7, atol=0)
+    pool = kernels._FOLD_COUNTERS[torch.cuda.current_device()][0]
+    assert int(pool.abs().sum().item()) == 0
+
+
 @pytest.mark.parametrize("rows,NA,NB,K", [(7, 7, 7, 120), (80, 63, 70, 120), (33, 33, 1, 5), (300, 257, 290, 128), (1024, 1000, 1021, 64),
                                           (7000, 6890, 6890, 120)])
 def test_fused_pair_cross_entropy_matches_the_score_matrix_path(rows, NA, NB, K):
