@@ -3112,7 +3112,7 @@ int sn_pair_fused_fwd_f32(const float *FA, int64_t lda, const float *FB, int64_t
   const PairWs w = pair_ws(workspace, rowsA, rowsB);
   hipError_t e = hipMemsetAsync(w.header, 0, kPairHeader, s);
   if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(pair_maxabs_k, dim3(64, 2), dim3(kWG), 0, s, FA, lda, (int)rowsA, FB, ldb, (int)rowsB, (int)K, w.header);
+  hipLaunchKernelGGL(pair_maxabs_k, dim3((unsigned)std::min<int64_t>(1024, (std::max(rowsA, rowsB) * K + 4 * kWG - 1) / (4 * kWG)), 2), dim3(kWG), 0, s, FA, lda, (int)rowsA, FB, ldb, (int)rowsB, (int)K, w.header);
   const int64_t quads = (int64_t)std::max(w.pa, w.pb) * 32;
   hipLaunchKernelGGL(pair_split_k, dim3((unsigned)((quads + kWG - 1) / kWG), 2), dim3(kWG), 0, s, FA, lda, (int)rowsA, w.pa, w.RA, w.TA, FB, ldb,
                      (int)rowsB, w.pb, w.RB, w.TB, (int)K, w.header);
