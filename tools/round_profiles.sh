@@ -11,9 +11,9 @@ bash tools/profile_bench.sh $out $tag
 cp $out/${tag}_pmc_traffic_c3.json profiles/ 2>/dev/null          # (this box's copy: bench.py below reads it)
 python bench.py > $out/${tag}_bench_c3_final.json 2> $out/bench_final.err
 python bench.py --graph --no-cpu-baseline --no-secondary > $out/${tag}_bench_c3_graph.json 2>> $out/bench_final.err
-for cfg in faust_lap mnist_dir; do
+for cfg in faust mnist; do          # capture once + N replays, N = 10 and 60: the difference is 50 replayed steps alone
   for n in 10 60; do
-    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/tr_${cfg}_$n -o t -- python $root/tools/train_bench.py $cfg $n > $root/$out/tr_${cfg}_$n.log 2>&1)
+    (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/tr_${cfg}_$n -o t -- python $root/tools/scratch/${cfg}_replay_only.py $n > $root/$out/tr_${cfg}_$n.log 2>&1)
   done
   python tools/scratch/replay_stats.py $(find $out/tr_${cfg}_10 -name "*kernel_stats.csv") 10 $(find $out/tr_${cfg}_60 -name "*kernel_stats.csv") 60 $out/${tag}_replay_${cfg}_kernel_stats.csv >> $out/replay.log 2>&1
   rm -rf $out/tr_${cfg}_10 $out/tr_${cfg}_60

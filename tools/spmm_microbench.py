@@ -103,10 +103,10 @@ def main():
                     actual = tot * 20 + (M // 4 + 1) * 4 + real[tag][1] * N * 4 + real[tag][0] * N * 4
                     print(f"{workload}/{layout} {name:3s} {tag:6s} rb4  N={N:3d} listed={tot} ({tot / max(M, 1):.2f}/row vs {o.nnz / max(M, 1):.2f} entries/row) actualMB={actual / 1e6:.1f} ms={ms:.4f} GB/s(alg)={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f} equal={torch.equal(y, y4)}", flush=True)
             if group == 1 and kernels.spmm_ring_supported(N, 1, M, K):
-                band, longest = o.band()
+                band, longest, outside = o.band()
                 y5 = torch.empty_like(y)
                 ms = time_launch(lambda: kernels.spmm_ring(o.rowptr, o.colind, o.vals, M, K, x, y5))
-                print(f"{workload}/{layout} {name:3s} {tag:6s} ring N={N:3d} band={band} longest_row={longest} ring_ok={o.ring_ok(N)} ms={ms:.4f} "
+                print(f"{workload}/{layout} {name:3s} {tag:6s} ring N={N:3d} band={band} longest_row={longest} rows_outside_window={outside} ring_ok={o.ring_ok(N)} ms={ms:.4f} "
                       f"GB/s(alg)={ab / ms / 1e6:.0f} frac={ab / ms / 1e-3 / PEAK:.3f} equal={torch.equal(y, y5)}", flush=True)
             if group == 4:
                 b = o.bsr4()
