@@ -379,6 +379,13 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
 
+    # The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a version banner through C stdio when
+    # its communicator goes away — after our line, once a one-rank group is part of every run): from here on file
+    # descriptor 1 is stderr for everybody, and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import torch.distributed as dist
 
     from surfacenetworks_amd import arap, dp
@@ -630,9 +637,11 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if dist.is_initialized():
+        if world > 1:
+            dist.barrier()
         dist.destroy_process_group()
 
 

@@ -399,7 +399,7 @@ __device__ __forceinline__ void bst4(rsrc_t r, int voff, const f4 &v) {         
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, 0, 2);
 }
 
-template <int PC, int K, int NT, bool TRANSW, int EPI, bool SIDE, bool ELU>
+template <int PC, int K, int NT, bool TRANSW, int EPI, bool SIDE, bool ELU, bool SMALL = false>
 __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void gemm_rows_split_k(const float *__restrict__ In, int64_t ldi,
                                                          const float *__restrict__ W, int64_t ldw,
                                                          float *__restrict__ Out, int64_t ldo, int64_t rows, EpiArgs ep) {
@@ -445,12 +445,26 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
   for (int t = 0; t < NT; ++t) {
     const int col = 32 * (wave * NT + t) + n;
     float cup = 1.f;
+    // SMALL (operands of at most kSmallRows rows: a FAUST tower, a Mesh-MNIST batch): ONE pass over the weights, a lane's
+    // 16·KS values waiting in registers for the column maximum.  The prologue is 5-9 us of such a launch's 7-12 us
+    // (fragment-shaped loads touch 32 lines per instruction, so the second pass costs as much as the first): 11.3 -> 8.7 us
+    // for a K = 256 forward launch of 32 rows.  Large operands keep the two passes: the held values cost the tile loop of
+    // the register-bound kernels 5-10 % (input gradient through the activation, forward with residual; measured), and
+    // there the prologue is 2 % of the launch.  The two K = 128 forward kernels without a side operand run two
+    // workgroups per CU (256 registers) and would spill: two passes always.
+    constexpr bool ONEPASS = SMALL && !(PC == 2 && K == 128 && NT == 1 && !TRANSW && !SIDE);
+    f4 wp[ONEPASS ? KS : 1], wq[ONEPASS ? KS : 1];
+    if constexpr (ONEPASS) {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) load_w(col, ks, wp[ks], wq[ks]);
+    }
     if constexpr (H2) {                      // column scale from the column's absolute maximum (my half of k, then my partner's)
       float cm = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         f4 p, q;
-        load_w(col, ks, p, q);
+        if constexpr (ONEPASS) p = wp[ks], q = wq[ks];
+        else load_w(col, ks, p, q);
         cm = fmaxf(cm, fmaxf(absmax4(p), absmax4(q)));
       }
       cm = fmaxf(cm, __shfl_xor(cm, 32));
@@ -461,7 +475,8 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       f4 p, q;
-      load_w(col, ks, p, q);
+      if constexpr (ONEPASS) p = wp[ks], q = wq[ks];
+      else load_w(col, ks, p, q);
       if constexpr (H2) split8_h2(p, q, cup, wh[t][ks], wl[t][ks]);
       else split8(p, q, wh[t][ks], wm[t][ks], wl[t][ks]);
     }
@@ -833,12 +848,16 @@ inline int gemm_variant() {
 }
 
 #define SN_UNPAREN(...) __VA_ARGS__
+constexpr int64_t kSmallRows = 131072;      // operands up to this many rows take the one-pass weight prologue (gemm_rows_split_k<…, SMALL>)
 // launch gemm_rows_split_k<PC, TARGS...> with PC chosen by SN_GEMM_VARIANT (2: fp16 pieces, else bf16 pieces); with the
 // timing facility on (sn_timing_enable: t_start / t_stop of the enclosing entry point) the kernel's own start / stop go
 // into two events
 #define SN_SPLIT_LAUNCH(TARGS, ...)                                                                                    \
   do {                                                                                                                 \
-    if (gemm_variant() == 2) {                                                                                         \
+    if (gemm_variant() == 2 && rows <= kSmallRows) {                                                                   \
+      if (t_start) hipExtLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS, true>), dim3(grid), dim3(kWG), 0, s, t_start, t_stop, 0, __VA_ARGS__); \
+      else hipLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS, true>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__); \
+    } else if (gemm_variant() == 2) {                                                                                  \
       if (t_start) hipExtLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, t_start, t_stop, 0, __VA_ARGS__); \
       else hipLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__);     \
     } else {                                                                                                           \
