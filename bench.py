@@ -358,6 +358,9 @@ def main():
                          "kernel from Python (same kernels; pays off when the step is launch-bound: small batches, busy hosts)")
     ap.add_argument("--roofline-steps", type=int, default=5,
                     help="eager steps run AFTER the timed region with per-launch HIP events (graph mode only)")
+    ap.add_argument("--linear-timing-steps", type=int, default=5,
+                    help="timed steps whose Linear-layer launches carry start/stop events as well (roofline.linear_kernels); the "
+                         "sparse products are timed on every step.  An event pair costs a launch ~2 us: 0.3 ms on all of a step's launches")
     ap.add_argument("--format", default="q3", choices=["q3", "bsr4", "csr"],
                     help="Dirac operator form: quaternion-packed blocks (default), 4x4 blocks, generic CSR")
     ap.add_argument("--operators", default="pool", choices=["pool", "device"],
@@ -462,7 +465,9 @@ def main():
     t0 = time.perf_counter()
     if args.no_graph:
         with timer:                                  # per-launch HIP events on every SpMM of the timed steps
-            for _ in range(args.steps):
+            for i in range(args.steps):
+                if i == args.linear_timing_steps:    # the ~120 Linear launches of a step carry events on the first steps only
+                    timer.time_linear(False)
                 loss = one_step().detach()           # (keeping the loss itself would keep the step's autograd graph alive)
     else:
         for _ in range(args.steps):
@@ -550,10 +555,11 @@ def main():
     for name, rows_, width, outw, nbytes, ms_ in getattr(timer, "linear", []):
         lin.setdefault((name, rows_, width, outw, nbytes), []).append(ms_)
     n_steps_timed = args.steps if args.no_graph else max(1, args.roofline_steps)
+    n_lin_steps = min(n_steps_timed, max(1, args.linear_timing_steps)) if args.no_graph else n_steps_timed
     linear_kernels = sorted(({"kernel": k[0], "rows": k[1], "width": k[2], "out_width": k[3], "launches": len(v),
-                              "launches_per_step": len(v) / n_steps_timed, "avg_ms": float(np.mean(v)), "bytes": k[4],
+                              "launches_per_step": len(v) / n_lin_steps, "avg_ms": float(np.mean(v)), "bytes": k[4],
                               "TBps": k[4] / (float(np.mean(v)) * 1e-3) / 1e12, "frac": k[4] / (float(np.mean(v)) * 1e-3) / HBM_PEAK,
-                              "ms_per_step": float(np.sum(v)) / n_steps_timed} for k, v in lin.items()),
+                              "ms_per_step": float(np.sum(v)) / n_lin_steps} for k, v in lin.items()),
                             key=lambda d: -d["ms_per_step"])
 
     out = {
@@ -607,7 +613,9 @@ def main():
                      "linear_kernels": linear_kernels,
                      "linear_kernels_note": "kernel[variant]: linear_fwd bits 1 elu copy, 2 residual, 4 y written, 8 per-mesh bias; "
                                             "linear_dgrad bits 1 BatchNorm tail, 2 through the activation, 4 gadd, 8 per-mesh vector; "
-                                            "bytes = operands read + results written (weights excluded), timed like the SpMM launches",
+                                            "bytes = operands read + results written (weights excluded), timed like the SpMM launches"
+                                            + (f" on the first {n_lin_steps} of the {args.steps} timed steps (an event pair costs a launch ~2 us; "
+                                               "the sparse products carry events on every timed step)" if args.no_graph else ""),
                      "linear_ms_per_step": float(sum(d["ms_per_step"] for d in linear_kernels))},
     }
     if not args.no_secondary:

@@ -589,7 +589,9 @@ int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_
  * sn_timing_drain waits for the recorded launches, writes up to `capacity` durations (ms) and 5 int64 per record
  * {kind (bit 0: 0 csr, 1 blocked; bit 5: RB4 (4x1 row blocks); bit 3: the blocked form is Q3; bit 4: the launch also left column statistics (sn_spmm_q3_stats_f32); bit 1: fused ELU-backward epilogue, E read; bit 2: G read
  *  too), M, K,
- *  nnz (csr) | nblocks (bsr4), N}, and clears the list.
+ *  nnz (csr) | nblocks (bsr4), N}, and clears the list.  The Linear-layer launchers (forward, input gradient, weight gradient)
+ * record themselves the same way: kind 0x100 / 0x200 / 0x400 + a variant number, then rows, input width, operand bytes, output
+ * width.  sn_timing_enable(1): everything; (2): the sparse products only (an event pair costs a launch ~2 us of GPU time); (0): off.
  * ------------------------------------------------------------------------------------------ */
 int     sn_timing_enable(int32_t on);
 int64_t sn_timing_count(void);

@@ -1962,7 +1962,12 @@ inline bool timing_slot(int kind, int64_t M, int64_t K, int64_t nnz, int N, hipE
 // The same timing slot for the Linear-layer launchers of the other translation units (sn_gemm.hip, sn_dense.hip): kind
 // 0x100 forward / 0x200 input gradient / 0x400 weight gradient (+ a variant number in the low byte), then rows, the contraction
 // or input width, the ALGORITHMIC bytes of the launch (operands read + results written, weights excluded) and the output width.
+bool g_timing_linear = true;      // sn_timing_enable(2): the sparse products only
 bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e) {
+  {
+    std::lock_guard<std::mutex> lk(g_timing_mu);
+    if (!g_timing_linear) return false;
+  }
   return timing_slot(kind, rows, width, bytes, outw, s, e);
 }
 
@@ -2751,6 +2756,7 @@ int sn_elu_bwd_acc_f32(const float *gdst, int64_t ldg, const float *gdst2, int64
 int sn_timing_enable(int32_t on) {
   std::lock_guard<std::mutex> lk(g_timing_mu);
   g_timing_on = on != 0;
+  g_timing_linear = on != 2;
   return SN_OK;
 }
 

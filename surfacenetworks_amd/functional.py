@@ -84,6 +84,14 @@ class SpmmTimer:
         SpmmTimer.active = None
         _lib.call("sn_timing_enable", 0)
 
+    @staticmethod
+    def time_linear(on: bool) -> None:
+        """While a timer is active: also time the Linear-layer launches (default) or the sparse products only."""
+        from . import _lib
+
+        if SpmmTimer.active is not None:
+            _lib.call("sn_timing_enable", 1 if on else 2)
+
     def results(self):
         """[(tag, M, K, nnz, N, milliseconds)] for every launch recorded while the timer was active; the tag ends in
         /csr, /bsr4 or /q3, then +e (fused ELU-backward epilogue: E read), +g (G read too), +s (column statistics left)."""
