@@ -399,17 +399,18 @@ __device__ __forceinline__ void bst4(rsrc_t r, int voff, const f4 &v) {         
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, v), r, voff, 0, 2);
 }
 
-template <int PC, int K, int NT, bool TRANSW, int EPI, bool SIDE, bool ELU, bool SMALL = false>
-__global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void gemm_rows_split_k(const float *__restrict__ In, int64_t ldi,
+template <int PC, int K, int NT, bool TRANSW, int EPI, bool SIDE, bool ELU, bool SMALL = false, int WV = 4>
+__global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4) ? 2 : 1) void gemm_rows_split_k(const float *__restrict__ In, int64_t ldi,
                                                          const float *__restrict__ W, int64_t ldw,
                                                          float *__restrict__ Out, int64_t ldo, int64_t rows, EpiArgs ep) {
   constexpr int KS = K / 16;                 // MFMA k-steps per output tile
   constexpr int RS = 2 * K + 16;             // bytes per row of one 16-bit image
   constexpr int PART = 32 * RS;              // bytes per image
   constexpr int SEG = K / 64;                // 256-byte segments per data row (2 | 4)
-  constexpr int NL = 2 * SEG;                // load instructions per wave per tile: chunk p (4 of the wave's 8 rows) x segment
-  constexpr int CSTEP = KS / 2;              // one conversion chunk every CSTEP k-steps
-  constexpr int NOUT = 128 * NT;             // output columns
+  constexpr int NCH = 8 / WV;                // 4-row chunks a wave stages per tile: the workgroup's WV waves (4 | 8) share the 32 rows
+  constexpr int NL = NCH * SEG;              // load instructions per wave per tile: chunk p (4 of the wave's rows) x segment
+  constexpr int CSTEP = KS / 2;              // one conversion chunk every CSTEP k-steps (WV = 8: the one chunk at k-step 0)
+  constexpr int NOUT = 32 * WV * NT;         // output columns: a wave owns 32·NT of them
   constexpr int CPR = 8 * NT;                // 16-byte chunks per row of a wave's output slab (32·NT columns)
   constexpr int SROW = 16 * CPR + 16;        // bytes per staged output row (+16: conflict-free transposition)
   constexpr int RPI = 64 / CPR;              // output rows per store instruction (8 | 4)
@@ -417,9 +418,9 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
   static_assert(PC == 3 || PC == 2, "three bf16 pieces or two fp16 pieces");
   constexpr bool H2 = PC == 2;
   __shared__ __attribute__((aligned(16))) unsigned char img[2][PC][PART];
-  __shared__ __attribute__((aligned(16))) unsigned char stg[4][32 * SROW];
+  __shared__ __attribute__((aligned(16))) unsigned char stg[WV][32 * SROW];
   __shared__ float s_rs[2][32];                         // H2: inverse row scales of the tile held by each image
-  __shared__ __attribute__((aligned(16))) float s_cs[128 * NT];      // H2: inverse column scales of the weights
+  __shared__ __attribute__((aligned(16))) float s_cs[NOUT];          // H2: inverse column scales of the weights
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = lane & 31, h = lane >> 5;
   // ---- stationary weights, split once: w?[t][ks] = pieces of Wmat[col = 32(wave·NT + t) + n][k = 16ks + 8h .. +7] ----
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
   // 256-byte segment of a row): chunk p = rows 4p .. 4p+3, all SEG segments — a row's absolute maximum is then one
   // 16-lane (single DPP row) reduction for four rows at once ----
   const int lr = lane >> 4, lc = lane & 15;
-  const int lrow = 8 * wave + lr;                              // + 4p
+  const int lrow = 4 * NCH * wave + lr;                        // + 4p
   int lvo[SEG];                                                // per segment: + 16·ldi·p; columns past jv (dy of a narrow layer): out
 #pragma unroll
   for (int s = 0; s < SEG; ++s)
@@ -605,14 +606,15 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
   // prologue: tile 0 converted into image 0, tile 1 in flight in the registers; the input window then runs two tiles ahead
   {
     const rsrc_t r0 = w_in.rsrc(to_last);
-    load_chunk(r0, 0);
-    load_chunk(r0, 1);
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) load_chunk(r0, p);
     w_in.next();
     const rsrc_t r1 = w_in.rsrc(to_last - 1);
-    convert_chunk(0, 0);
-    load_chunk(r1, 0);
-    convert_chunk(0, 1);
-    load_chunk(r1, 1);
+#pragma unroll
+    for (int p = 0; p < NCH; ++p) {
+      convert_chunk(0, p);
+      load_chunk(r1, p);
+    }
     w_in.next();
   }
 
@@ -682,7 +684,7 @@ __global__ __launch_bounds__(kWG, (PC == 2 && K == 128 && NT == 1) ? 2 : 1) void
         if constexpr (!H2) nm = *reinterpret_cast<const u4 *>(fp + PART + 32 * (ks + 1));
         nl = *reinterpret_cast<const u4 *>(fp + LOWP + 32 * (ks + 1));
       }
-      if constexpr (ks % CSTEP == 0) {           // conversion of the next tile, one chunk at a time, under the MFMAs
+      if constexpr (ks % CSTEP == 0 && ks / CSTEP < NCH) {      // conversion of the next tile, one chunk at a time, under the MFMAs
         constexpr int p = ks / CSTEP;
         convert_chunk(buf ^ 1, p);
         load_chunk(r_in, p);
@@ -848,6 +850,24 @@ inline int gemm_variant() {
 }
 
 #define SN_UNPAREN(...) __VA_ARGS__
+// SN_GEMM_WV8=1: the 256-output input-gradient kernels as ONE 8-wave workgroup per CU (a wave owns 32 columns instead of 64:
+// half the weight registers per wave, twice the waves to keep loads in flight) — A/B switch
+inline int gemm_wv8() {          // 0 off, 1 large operands, 2 every operand (tests)
+  static const int v = [] {
+    const char *e = getenv("SN_GEMM_WV8");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+#define SN_SPLIT_LAUNCH_NT2(K_, EPI_, SIDE_, ...)                                                                      \
+  do {                                                                                                                 \
+    if (gemm_variant() == 2 && (gemm_wv8() == 2 || (gemm_wv8() == 1 && rows > kSmallRows))) {                                                      \
+      if (t_start) hipExtLaunchKernelGGL((gemm_rows_split_k<2, K_, 1, true, EPI_, SIDE_, false, false, 8>), dim3(grid), dim3(512), 0, s, t_start, t_stop, 0, __VA_ARGS__); \
+      else hipLaunchKernelGGL((gemm_rows_split_k<2, K_, 1, true, EPI_, SIDE_, false, false, 8>), dim3(grid), dim3(512), 0, s, __VA_ARGS__); \
+    } else {                                                                                                           \
+      SN_SPLIT_LAUNCH((K_, 2, true, EPI_, SIDE_, false), __VA_ARGS__);                                                 \
+    }                                                                                                                  \
+  } while (0)
 constexpr int64_t kSmallRows = 131072;      // operands up to this many rows take the one-pass weight prologue (gemm_rows_split_k<…, SMALL>)
 // launch gemm_rows_split_k<PC, TARGS...> with PC chosen by SN_GEMM_VARIANT (2: fp16 pieces, else bf16 pieces); with the
 // timing facility on (sn_timing_enable: t_start / t_stop of the enclosing entry point) the kernel's own start / stop go
@@ -954,9 +974,9 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   hipEvent_t t_start = nullptr, t_stop = nullptr;
   if (x3) sn_internal_timing_slot(0x200 | (B ? 1 : 0), rows, C, rows * 4 * ((int64_t)J + C + (B ? C : 0)), J, &t_start, &t_stop);
   if (C == 256 && x3 && B)
-    SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD, true, false), dy, lddy, W, ldw, dx, lddx, rows, ep);
+    SN_SPLIT_LAUNCH_NT2(128, EPI_DGRAD, true, dy, lddy, W, ldw, dx, lddx, rows, ep);
   else if (C == 256 && x3)
-    SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD, false, false), dy, lddy, W, ldw, dx, lddx, rows, ep);
+    SN_SPLIT_LAUNCH_NT2(128, EPI_DGRAD, false, dy, lddy, W, ldw, dx, lddx, rows, ep);
   else if (C == 256)
     hipLaunchKernelGGL((gemm_rows_k<128, 2, true, EPI_DGRAD>), dim3(grid), dim3(kWG), 0, s, dy, lddy, W, ldw, dx, lddx, rows, ep);
   else if (x3 && B)
@@ -990,7 +1010,7 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
   hipEvent_t t_start = nullptr, t_stop = nullptr;
   sn_internal_timing_slot(0x200 | 2 | (gadd ? 4 : 0), rows, C, rows * 4 * ((int64_t)J + C + C + (gadd ? half : 0)), J, &t_start, &t_stop);
   if (C == 256)
-    SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, out,
+    SN_SPLIT_LAUNCH_NT2(128, EPI_DGRAD_ELU, true, dy, lddy, W, ldw, out,
                        lddx, rows, ep);
   else
     SN_SPLIT_LAUNCH((128, 1, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, out,
@@ -1079,7 +1099,7 @@ static int dgrad_eluseg_launch(const float *dy, int64_t lddy, const float *W, in
   sn_internal_timing_slot(0x200 | 8 | (gadd ? 4 : 0), rows, C, rows * 4 * ((int64_t)J + C + C + (gadd ? C : 0)), J, &t_start, &t_stop);
   float *none = nullptr;               // every column leaves through gact: nothing is written through Out
   if (C == 256)
-    SN_SPLIT_LAUNCH((128, 2, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, none,
+    SN_SPLIT_LAUNCH_NT2(128, EPI_DGRAD_ELU, true, dy, lddy, W, ldw, none,
                        (int64_t)0, rows, ep);
   else
     SN_SPLIT_LAUNCH((128, 1, true, EPI_DGRAD_ELU, true, false), dy, lddy, W, ldw, none,

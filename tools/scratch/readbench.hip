@@ -52,6 +52,33 @@ __global__ __launch_bounds__(64 * NW, 1) void read_k(const float* __restrict__ x
         for (int i = 0; i < 64 / NW; ++i) acc += v[d][i].x + v[d][i].y + v[d][i].z + v[d][i].w;
     }
   }
+  if (MODE == 2 || MODE == 3) {                       // MODE 2: dwordx2 (512 B / instruction); MODE 3: dword with NW waves
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    constexpr int BPI = MODE == 2 ? 512 : 256;        // bytes per instruction
+    const int per_row = C * 4 / BPI;
+    const int n_inst = 32 * per_row / NW;             // per wave and block
+    constexpr int MAXI = (32 * 256 * 4 / BPI) / NW;   // (C = 256)
+    for (long b = r0; b < r1; b += 32 * DEPTH) {
+      float v[DEPTH][MAXI];
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) {
+          const int id = wave * n_inst + i, r = id / per_row, cseg = id % per_row;
+          const long row = b + 32 * d + r;
+          float t = 0.f;
+          if (i < n_inst && row < r1) {
+            if (MODE == 2) { const f2 q = *reinterpret_cast<const f2*>(x + row * C + cseg * 128 + lane * 2); t = q.x + q.y; }
+            else t = x[row * C + cseg * 64 + lane];
+          }
+          v[d][i] = t;
+        }
+#pragma unroll
+      for (int d = 0; d < DEPTH; ++d)
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i) acc += v[d][i];
+    }
+  }
   if (acc == 123.456f) out[0] = acc;
 }
 
@@ -86,5 +113,10 @@ int main() {
   run<1, 2, 4>("4 waves: dwordx4, 2 blocks in flight (C=256)", x, rows, 256, out);
   run<1, 3, 4>("4 waves: dwordx4, 3 blocks in flight (C=256)", x, rows, 256, out);
   run<1, 4, 4>("4 waves: dwordx4, 4 blocks in flight (C=256)", x, rows, 256, out);
+  run<2, 1, 4>("4 waves: dwordx2, 1 block in flight (C=256)", x, rows, 256, out);
+  run<2, 2, 4>("4 waves: dwordx2, 2 blocks in flight (C=256)", x, rows, 256, out);
+  run<3, 1, 4>("4 waves: dword, 1 block in flight (C=256)", x, rows, 256, out);
+  run<3, 2, 4>("4 waves: dword, 2 blocks in flight (C=256)", x, rows, 256, out);
+  run<2, 2, 8>("8 waves: dwordx2, 2 blocks in flight (C=256)", x, rows, 256, out);
   return 0;
 }
