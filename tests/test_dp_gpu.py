@@ -231,6 +231,9 @@ def test_bench_runs_its_one_rank_through_rccl():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
                           "--meshes", "4", "--no-secondary", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-2000:]
-    rec = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), lines       # the contract: ONE JSON line (RCCL's banner etc. go to stderr)
+    rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["collective_backend"] == "nccl" and rec["config"]["rccl_ranks"] == 1
     assert rec["config"]["collective_per_step"].startswith("pack + ncclAllReduce")
+    assert rec["roofline"]["linear_kernels"] and rec["roofline"]["linear_kernels"][0]["launches_per_step"] > 0
