@@ -394,6 +394,18 @@ class _FusedCorrespondenceCE(torch.autograd.Function):
         return dFA, dFB, None, None, None
 
 
+_PREFETCH_TARGET = os.environ.get("SN_PREFETCH_TARGET", "1") != "0"      # A/B switch: "0" = the target on the caller's stream
+_TARGET_STREAMS = {}
+
+
+def _target_stream(device):
+    key = torch.device(device).index
+    st = _TARGET_STREAMS.get(key)
+    if st is None:
+        st = _TARGET_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 _FUSED_SCORES = os.environ.get("SN_PAIR_FUSED", "1") != "0"      # A/B switch: "0" = bmm + sn_pair_ce_* on the score matrix
 
 
@@ -452,6 +464,8 @@ class TorusBodies:
         self.pool_L = OperatorPool(mats, self.device)
         self.n = count
         self._samples = {}
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)        # the frames are read from other streams later (PairBatch's target)
 
     def sample(self, idx):
         """(inputs, target triple, mask, operator) of frame idx, padded to `pad_to`.  A frame never changes, so its padded
@@ -481,7 +495,26 @@ class PairBatch:
         self.inY, self.tY, self.mY, self.LY = ds.sample(ib)
         (GA, lA, liA), (GB, lB, liB) = self.tX[0], self.tY[0]
         self.NA, self.NB = int(lA.size(0)), int(lB.size(0))
-        self.target = correspondence_target(GA, lA, liA, GB, lB, liB)
+        # The target reads two resident 190 MB matrices (~0.14 ms) and depends on nothing of the model: on a device it is
+        # computed on a stream of its own, so that the target of the NEXT pair overlaps the step of the current one; the
+        # consumer waits for `_target_ready` (target_tensor()).
+        self._target_ready = None
+        if GA.is_cuda and _PREFETCH_TARGET:
+            side = _target_stream(GA.device)             # (the datasets synchronise the device once, after building their tensors)
+            with torch.cuda.stream(side):
+                self.target = correspondence_target(GA, lA, liA, GB, lB, liB)
+                self._target_ready = side.record_event()
+        else:
+            self.target = correspondence_target(GA, lA, liA, GB, lB, liB)
+
+    def target_tensor(self):
+        """The loss target, safe to use on the CURRENT stream."""
+        if self._target_ready is not None:
+            cur = torch.cuda.current_stream(self.target.device)
+            cur.wait_event(self._target_ready)
+            self.target.record_stream(cur)
+            self._target_ready = None
+        return self.target
 
     def owned(self) -> "PairBatch":
         """A copy for the static batch of a captured step (overwritten in place by every `load()`): nothing in it is the
@@ -489,7 +522,8 @@ class PairBatch:
         import copy
 
         b = copy.copy(self)
-        b.inX, b.inY, b.mX, b.mY, b.target = (t.clone() for t in (self.inX, self.inY, self.mX, self.mY, self.target))
+        b.inX, b.inY, b.mX, b.mY, b.target = (t.clone() for t in (self.inX, self.inY, self.mX, self.mY, self.target_tensor()))
+        b._target_ready = None
         own = lambda ops: type(ops)(o.clone() for o in ops) if isinstance(ops, (tuple, list)) else ops.clone()
         b.LX, b.LY = own(self.LX), own(self.LY)
         b.tX = b.tY = None
@@ -503,7 +537,7 @@ class PairBatch:
     def graph_tensors(self):
         from .graphs import operator_tensors
 
-        out = [self.inX, self.inY, self.mX, self.mY, self.target]
+        out = [self.inX, self.inY, self.mX, self.mY, self.target_tensor()]
         for ops in (self.LX, self.LY):
             for o in (ops if isinstance(ops, (tuple, list)) else (ops,)):
                 out += operator_tensors(o)
@@ -516,11 +550,11 @@ def forward_loss(model, b: PairBatch):
         # same value as model(...) + pair_cross_entropy, without the (1, N, N) score matrix in between
         FA, FB = model.towers(_operation(b.LX, b.mX), _operation(b.LY, b.mY), b.inX, b.inY)
         if fused_pair_supported(FA, FB):
-            return fused_pair_cross_entropy(FA, FB, b.target, b.NA, b.NB).reshape(1)
+            return fused_pair_cross_entropy(FA, FB, b.target_tensor(), b.NA, b.NB).reshape(1)
         out = torch.bmm(FA, FB.transpose(1, 2))
     else:
         out = model(_operation(b.LX, b.mX), _operation(b.LY, b.mY), b.inX, b.inY)
-    return pair_cross_entropy(out, b.target, b.NA, b.NB).reshape(1)
+    return pair_cross_entropy(out, b.target_tensor(), b.NA, b.NB).reshape(1)
 
 
 def graphed_train_step(model, optimizer, example: PairBatch, bucket=None):
@@ -582,6 +616,8 @@ class FaustFrames:
         else:
             self.pool_L = OperatorPool([fr["L"] for fr in frames], self.device)
         self._samples = {}
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)        # (as TorusBodies: the frames are read from other streams later)
 
     def sample(self, idx):
         """As TorusBodies.sample: built once per frame, the dataset's own tensors from then on."""
