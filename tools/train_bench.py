@@ -48,6 +48,11 @@ def main():
             if g.matches(nb):
                 dtg = timed(lambda: g(ds.sample_batch(B, rng, ids=ids)), steps)
                 print(f"{what}: hipGraph replay of fwd+loss+bwd: {dtg * 1e3:.2f} ms/step, {B / dtg:.0f} meshes/s")
+                from surfacenetworks_amd.graphs import BatchAhead
+
+                ahead = BatchAhead(lambda: ds.sample_batch(B, rng, ids=ids), dev)
+                dta = timed(lambda: g(ahead.get()), steps)
+                print(f"{what}: the same with the batch assembled one step ahead on a side stream: {dta * 1e3:.2f} ms/step, {B / dta:.0f} meshes/s")
             else:
                 print(f"{what}: batches have varying signatures (ragged meshes): no graph replay")
         except Exception as exc:  # noqa: BLE001
