@@ -364,6 +364,10 @@ int sn_colstats_into_f32(const float *x, int64_t ld, int64_t rows, int32_t C, do
                          void *workspace, size_t workspace_bytes, void *stream);
 int sn_colstats_merge_f64(const double *part, int32_t nblk, int32_t C, double *out, int64_t out_ld, int64_t out_off,
                           void *stream);
+/* sn_colstats_merge2_f64 : both halves at once — out (2 x (C_lo + C_hi) fp64, [sums | squares]) from the partials of the two
+ * producers ([nblk_lo][2][C_lo] and [nblk_hi][2][C_hi]); the same sums, bit for bit, as two sn_colstats_merge_f64 calls. */
+int sn_colstats_merge2_f64(const double *part_lo, int32_t nblk_lo, int32_t C_lo, const double *part_hi, int32_t nblk_hi,
+                           int32_t C_hi, double *out, void *stream);
 int32_t sn_linear_fwd_stats_blocks(int64_t rows);
 size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C);
 int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,

@@ -736,6 +736,12 @@ def colstats_halves(x, part, part_hi=None):
             raise ValueError("colstats_halves: expected a (rows, 256) buffer and (nblk, 2, 128) float64 partials")
     lib = _lib.load()
     out = torch.empty((2, C2), dtype=torch.float64, device=x.device)
+    if part is not None and part_hi is not None:            # both producers left partials: one launch for the two halves
+        nlo = int(lib.sn_linear_fwd_stats_blocks(rows))
+        if part.shape[0] < nlo:
+            raise ValueError("colstats_halves: partial buffer smaller than the producing launch's grid")
+        _lib.call("sn_colstats_merge2_f64", _p(part), nlo, C, _p(part_hi), int(part_hi.shape[0]), C, _p(out), _stream())
+        return out
     for half, p_, nblk in ((0, part, int(lib.sn_linear_fwd_stats_blocks(rows))), (1, part_hi, None)):
         if p_ is not None:
             nb = nblk if nblk is not None else int(p_.shape[0])

@@ -977,3 +977,21 @@ def test_pair_cross_entropy_takes_the_siamese_output(B):
     assert gg.shape == out.shape and rel_err(gg.cpu().numpy(), gw.cpu().numpy()) < 5e-6
     if B > 1:
         assert gg[1:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("rows", [1, 33, 7000, 300000])
+def test_both_halves_of_the_statistics_in_one_launch(rows):
+    """sn_colstats_merge2_f64 (colstats_halves with partials of both producers) == two sn_colstats_merge_f64 calls, bit for
+    bit: the statistics of [e | P·e] from the GEMM's and the SpMM's partials."""
+    from surfacenetworks_amd import kernels
+
+    g = torch.Generator().manual_seed(rows)
+    x = (torch.randn(rows, 256, generator=g) * 3 + 1).to(DEV)
+    nlo = kernels.linear_fwd_stats_blocks(rows)
+    lo = torch.randn(max(nlo, 1), 2, 128, generator=g, dtype=torch.float64).to(DEV)       # (any numbers: the reduction is what is tested)
+    hi = torch.randn(37, 2, 128, generator=g, dtype=torch.float64).to(DEV)
+    got = kernels.colstats_halves(x, lo, hi)
+    want = torch.zeros((2, 256), dtype=torch.float64, device=DEV)
+    kernels.colstats_merge_into(lo[:nlo], want, 0)
+    kernels.colstats_merge_into(hi, want, 128)
+    assert torch.equal(got, want)
