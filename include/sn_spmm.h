@@ -120,9 +120,9 @@ int sn_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const flo
 int sn_spmm_q3_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks,
                    const float *X, int64_t ldx, int32_t x_group, int32_t N,
                    float *Y, int64_t ldy, int32_t y_group, void *stream);
-/* sn_spmm_q3_stats_f32: sn_spmm_q3_f32 for N = 32, y_group = 4 (the (rows/4, 128) view of a 128-channel tensor) that ALSO
- * leaves the BatchNorm statistics of its output: stats_part[sn_spmm_q3_stats_blocks()][2][128] fp64 partial column sums /
- * sums of squares (per channel c = 32*component + column), to be combined by sn_colstats_merge_f64 — the statistics pass over
+/* sn_spmm_q3_stats_f32: sn_spmm_q3_f32 for N = 32 or 16, y_group = 4 (the (rows/4, 4N) view of a 128- / 64-channel tensor) that ALSO
+ * leaves the BatchNorm statistics of its output: stats_part[sn_spmm_q3_stats_blocks()][2][4N] fp64 partial column sums /
+ * sums of squares (per channel c = N*component + column), to be combined by sn_colstats_merge_f64 — the statistics pass over
  * the propagated half of a stage's concat buffer (utils_pt.py:204-205,216-217: torch.cat + BatchNorm1d) disappears.
  * Each workgroup's fp32 partial of its 32 output rows goes through `workspace` (sn_spmm_q3_stats_workspace_bytes(Mb)) and is
  * added up in fp64 in a fixed order (deterministic).  Y is bit-identical to sn_spmm_q3_f32. */
@@ -365,9 +365,11 @@ int sn_colstats_into_f32(const float *x, int64_t ld, int64_t rows, int32_t C, do
 int sn_colstats_merge_f64(const double *part, int32_t nblk, int32_t C, double *out, int64_t out_ld, int64_t out_off,
                           void *stream);
 /* sn_colstats_merge2_f64 : both halves at once — out (2 x (C_lo + C_hi) fp64, [sums | squares]) from the partials of the two
- * producers ([nblk_lo][2][C_lo] and [nblk_hi][2][C_hi]); the same sums, bit for bit, as two sn_colstats_merge_f64 calls. */
-int sn_colstats_merge2_f64(const double *part_lo, int32_t nblk_lo, int32_t C_lo, const double *part_hi, int32_t nblk_hi,
-                           int32_t C_hi, double *out, void *stream);
+ * producers ([nblk_lo][2][ld_lo] and [nblk_hi][2][ld_hi], of which the first C_lo / C_hi channels count: ld = C for a
+ * producer's own layout, 128 for the forward GEMM of a 64-output layer); the same sums, bit for bit, as two
+ * sn_colstats_merge_f64 calls on packed partials. */
+int sn_colstats_merge2_f64(const double *part_lo, int32_t nblk_lo, int32_t C_lo, int32_t ld_lo, const double *part_hi,
+                           int32_t nblk_hi, int32_t C_hi, int32_t ld_hi, double *out, void *stream);
 int32_t sn_linear_fwd_stats_blocks(int64_t rows);
 size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C);
 int sn_wgrad_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,

@@ -79,7 +79,7 @@ SIGNATURES = {
     "sn_bn_fold_parts_f32": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.c_double,
                                        C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sn_colstats_blocks": (C.c_int32, [_i64]),
-    "sn_colstats_merge2_f64": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, _vp, _vp]),
+    "sn_colstats_merge2_f64": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "sn_colstats_partial_f32": (C.c_int, [_vp, _i64, _i64, C.c_int32, _vp, _vp]),
     "sn_bn_bwd_coeffs_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sn_segment_colsum_ragged_workspace_bytes": (_sz, [_i64, _i32]),

@@ -60,10 +60,11 @@ def _new_cat(rows, C, device):
     return torch.empty((rows, 2 * C), dtype=torch.float32, device=device)
 
 
-def _new_part(rows, C, device):
+def _new_part(rows, C, device, narrow=False):
     """Workspace in which the GEMM that writes elu(y) into a concat buffer's first half also leaves that half's column
-    statistics (kernels.linear_fwd `elu_stats`), or None where the fused GEMM does not offer it."""
-    if C != 128 or not kernels.elu_stats_supported():
+    statistics (kernels.linear_fwd `elu_stats`), or None where the fused GEMM does not offer it.  narrow: 64-channel stages
+    too (the Dirac blocks, whose other half gets its statistics from the quaternion SpMM: only both together are used)."""
+    if not (C == 128 or (narrow and C == 64 and kernels.linear_fwd_supported(2 * C, C))) or not kernels.elu_stats_supported():
         return None
     return kernels.new_elu_stats_part(rows, device)
 
@@ -110,7 +111,7 @@ class _DiracBlock(torch.autograd.Function):
         rf = opDi.shape[0] // 4
         cat1 = _activated(v, pre_v)
         nxt_f = _new_cat(rf, C, v.device)                        # the next Dirac block's cat0; first half = elu(f_out)
-        pf = _new_part(rf, C, v.device)
+        pf = _new_part(rf, C, v.device, narrow=True)
         ctx.f_zero = f is None
         if f is None:
             # all-zero face features (the first Dirac block of a model): cat0 = [0 | Di·elu(v)] runs at half width
@@ -130,7 +131,7 @@ class _DiracBlock(torch.autograd.Function):
             f_out = torch.full((1, 1), float("nan"), dtype=torch.float32, device=v.device).expand(rf, C)
         _attach_hi(cat1, _launch(opDiA, nxt_f[:, :C], cat1[:, C:], 4, "fwd", stats=tr1))
         nxt_v = _new_cat(rv, C, v.device)
-        pv = _new_part(rv, C, v.device)
+        pv = _new_part(rv, C, v.device, narrow=True)
         v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C], elu_stats=pv)
         _attach_part(nxt_v, pv)
         ctx.ops = (opDi, opDiA)

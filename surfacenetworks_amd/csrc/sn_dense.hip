@@ -169,28 +169,32 @@ __global__ __launch_bounds__(kWG) void colstats_final_k(const double *__restrict
 // Both halves of a concat buffer's statistics in ONE launch: workgroups [0, nb_lo) finish the first producer's partials into
 // out[kind][0 .. C_lo), the rest the second producer's into out[kind][C_lo ..) — colstats_final_k twice, same order of
 // addition, one launch less in front of every Linear of a Dirac / Laplacian stage.
-__global__ __launch_bounds__(kWG) void colstats_final2_k(const double *__restrict__ p_lo, int nblk_lo, int C_lo,
-                                                         const double *__restrict__ p_hi, int nblk_hi, int C_hi,
+__global__ __launch_bounds__(kWG) void colstats_final2_k(const double *__restrict__ p_lo, int nblk_lo, int C_lo, int ld_lo,
+                                                         const double *__restrict__ p_hi, int nblk_hi, int C_hi, int ld_hi,
                                                          double *__restrict__ out) {
+  // a partial row is [sums | squares] of `ld` channels each, of which the first C are the producer's (ld > C: the forward GEMM
+  // of a 64-output layer leaves its partials in the 128-column layout of the kernel)
   __shared__ double sm[8][32];
   const int nb_lo = (2 * C_lo + 31) / 32;
   const bool hi = (int)blockIdx.x >= nb_lo;
   const double *partial = hi ? p_hi : p_lo;
-  const int nblk = hi ? nblk_hi : nblk_lo, C2 = 2 * (hi ? C_hi : C_lo);
+  const int nblk = hi ? nblk_hi : nblk_lo, Cx = hi ? C_hi : C_lo, C2 = 2 * Cx, ld = hi ? ld_hi : ld_lo;
   const int out_off = hi ? C_lo : 0, out_ld = C_lo + C_hi;
   const int cg = threadIdx.x & 31, pg = threadIdx.x >> 5;
   const int i = ((int)blockIdx.x - (hi ? nb_lo : 0)) * 32 + cg;
   double t = 0;
   if (i < C2) {
+    const int64_t rs = 2 * (int64_t)ld;                       // doubles per partial row
+    const double *p = partial + (i >= Cx ? ld + (i - Cx) : i);
     int b = pg;
     for (; b + 56 < nblk; b += 64) {
       double v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = partial[(int64_t)(b + 8 * u) * C2 + i];
+      for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(b + 8 * u) * rs];
 #pragma unroll
       for (int u = 0; u < 8; ++u) t += v[u];
     }
-    for (; b < nblk; b += 8) t += partial[(int64_t)b * C2 + i];
+    for (; b < nblk; b += 8) t += p[(int64_t)b * rs];
   }
   sm[pg][cg] = t;
   __syncthreads();
@@ -2633,14 +2637,14 @@ int sn_colstats_merge_f64(const double *part, int32_t nblk, int32_t C, double *o
   return launch_status();
 }
 
-int sn_colstats_merge2_f64(const double *part_lo, int32_t nblk_lo, int32_t C_lo, const double *part_hi, int32_t nblk_hi,
-                           int32_t C_hi, double *out, void *stream) {
+int sn_colstats_merge2_f64(const double *part_lo, int32_t nblk_lo, int32_t C_lo, int32_t ld_lo, const double *part_hi,
+                           int32_t nblk_hi, int32_t C_hi, int32_t ld_hi, double *out, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
-  if (nblk_lo < 0 || nblk_hi < 0 || C_lo < 1 || C_hi < 1) return SN_E_SHAPE;
+  if (nblk_lo < 0 || nblk_hi < 0 || C_lo < 1 || C_hi < 1 || ld_lo < C_lo || ld_hi < C_hi) return SN_E_SHAPE;
   if (!out || (nblk_lo > 0 && !part_lo) || (nblk_hi > 0 && !part_hi)) return SN_E_NULL;
   const unsigned grid = (unsigned)((2 * C_lo + 31) / 32 + (2 * C_hi + 31) / 32);
   hipLaunchKernelGGL(colstats_final2_k, dim3(grid), dim3(kWG), 0, static_cast<hipStream_t>(stream), part_lo, (int)nblk_lo, (int)C_lo,
-                     part_hi, (int)nblk_hi, (int)C_hi, out);
+                     (int)ld_lo, part_hi, (int)nblk_hi, (int)C_hi, (int)ld_hi, out);
   return launch_status();
 }
 

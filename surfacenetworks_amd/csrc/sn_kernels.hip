@@ -651,33 +651,47 @@ __device__ __forceinline__ void spmm_q3_lds_body(const int *__restrict__ b_rowpt
     st4_stream(yp + 3 * ys, acc3);
   }
   if constexpr (STATS) {
-    static_assert(N == 32 && YG == 4 && !EPI, "statistics: 128-channel rows in the group-4 layout");
-    // wave-private transposition: lane (grp, sub) writes its 16 channel values of block row grp (row stride 160 floats: the
-    // two block rows of a 16-lane group land on disjoint banks), lane l then sums channels 2l, 2l+1 over the 8 block rows
-    constexpr int ST = 160;
+    static_assert((N == 32 || N == 16) && YG == 4 && !EPI, "statistics: 128- or 64-channel rows in the group-4 layout");
+    // wave-private transposition: lane (grp, sub) writes its 16 channel values of block row grp (channel = N·component + 4·sub
+    // + j; row stride ST floats: the block rows a 16-lane write phase touches land on disjoint banks), then every lane sums
+    // its channel(s) — two at N = 32 (128 channels), one at N = 16 (64) — over the RPW block rows of the pass
+    constexpr int CH = 4 * N;                   // channels
+    constexpr int ST = N == 32 ? 160 : 80;
     __shared__ float s_st[WAVES][RPW * ST];
-    __shared__ float s_wv[WAVES][256];
+    __shared__ float s_wv[WAVES][2 * CH];
     float *st = s_st[wave];
     const bool live = br < Mb;
     const f4 z = {0.f, 0.f, 0.f, 0.f};
     f4 *row = reinterpret_cast<f4 *>(st + grp * ST + sub * 4);
     row[0] = live ? acc0 : z;
-    row[8] = live ? acc1 : z;
-    row[16] = live ? acc2 : z;
-    row[24] = live ? acc3 : z;
+    row[N / 4] = live ? acc1 : z;
+    row[2 * N / 4] = live ? acc2 : z;
+    row[3 * N / 4] = live ? acc3 : z;
     __builtin_amdgcn_wave_barrier();            // (same-wave LDS operations complete in order)
-    float sa = 0.f, sb = 0.f, qa = 0.f, qb = 0.f;
+    if constexpr (N == 32) {
+      float sa = 0.f, sb = 0.f, qa = 0.f, qb = 0.f;
 #pragma unroll
-    for (int g = 0; g < RPW; ++g) {
-      const float2 v = *reinterpret_cast<const float2 *>(st + g * ST + 2 * lane);
-      sa += v.x; sb += v.y;
-      qa = __builtin_fmaf(v.x, v.x, qa); qb = __builtin_fmaf(v.y, v.y, qb);
+      for (int g = 0; g < RPW; ++g) {
+        const float2 v = *reinterpret_cast<const float2 *>(st + g * ST + 2 * lane);
+        sa += v.x; sb += v.y;
+        qa = __builtin_fmaf(v.x, v.x, qa); qb = __builtin_fmaf(v.y, v.y, qb);
+      }
+      s_wv[wave][2 * lane] = sa; s_wv[wave][2 * lane + 1] = sb;
+      s_wv[wave][CH + 2 * lane] = qa; s_wv[wave][CH + 2 * lane + 1] = qb;
+    } else {
+      float sa = 0.f, qa = 0.f;
+#pragma unroll
+      for (int g = 0; g < RPW; ++g) {
+        const float v = st[g * ST + lane];
+        sa += v;
+        qa = __builtin_fmaf(v, v, qa);
+      }
+      s_wv[wave][lane] = sa;
+      s_wv[wave][CH + lane] = qa;
     }
-    s_wv[wave][2 * lane] = sa; s_wv[wave][2 * lane + 1] = sb;
-    s_wv[wave][128 + 2 * lane] = qa; s_wv[wave][128 + 2 * lane + 1] = qb;
     __syncthreads();
-    const int t = threadIdx.x;                  // 256 threads = [sums | squares] x 128 channels; waves added in order
-    stats_part[(int64_t)blockIdx.x * 256 + t] = (s_wv[0][t] + s_wv[1][t]) + (s_wv[2][t] + s_wv[3][t]);
+    const int t = threadIdx.x;                  // [sums | squares] x CH channels; waves added in order
+    if (t < 2 * CH) stats_part[(int64_t)blockIdx.x * (2 * CH) + t] = (s_wv[0][t] + s_wv[1][t]) + (s_wv[2][t] + s_wv[3][t]);
   }
 }
 // Two launch shapes of every Q3 kernel (measured on the config-5 and config-3 batches, profiles/r2_q3_variants.txt):
@@ -706,17 +720,18 @@ __global__ __launch_bounds__(kWG) SN_FIVE_WAVES void spmm_q3_lds_stats_wide(cons
 }
 // stage 1 of the reduction of those partials: workgroup b adds rows b, b + gridDim.x, ... (fixed order) in fp64
 __global__ __launch_bounds__(kWG) void spmm_stats_reduce_k(const float *__restrict__ part, int64_t n,
-                                                           double *__restrict__ out /* [gridDim.x][256] */) {
+                                                           double *__restrict__ out /* [gridDim.x][w] */, int w = 256) {
+  if ((int)threadIdx.x >= w) return;            // (w = 256: 128 channels; 128: the 64-channel products)
   double t = 0.0;
   int64_t r = blockIdx.x;
   for (; r + 3 * (int64_t)gridDim.x < n; r += 4 * (int64_t)gridDim.x) {       // four loads in flight, added in row order
-    const float a = part[r * 256 + threadIdx.x], b = part[(r + gridDim.x) * 256 + threadIdx.x],
-                c = part[(r + 2 * (int64_t)gridDim.x) * 256 + threadIdx.x],
-                d = part[(r + 3 * (int64_t)gridDim.x) * 256 + threadIdx.x];
+    const float a = part[r * w + threadIdx.x], b = part[(r + gridDim.x) * w + threadIdx.x],
+                c = part[(r + 2 * (int64_t)gridDim.x) * w + threadIdx.x],
+                d = part[(r + 3 * (int64_t)gridDim.x) * w + threadIdx.x];
     t += (double)a; t += (double)b; t += (double)c; t += (double)d;
   }
-  for (; r < n; r += gridDim.x) t += (double)part[r * 256 + threadIdx.x];
-  out[(int64_t)blockIdx.x * 256 + threadIdx.x] = t;
+  for (; r < n; r += gridDim.x) t += (double)part[r * w + threadIdx.x];
+  out[(int64_t)blockIdx.x * w + threadIdx.x] = t;
 }
 template <int N, int XG, int YG>
 __global__ __launch_bounds__(kWG) SN_FOUR_WAVES void spmm_q3_lds(const int *__restrict__ b_rowptr, const f4 *__restrict__ q_blk,
@@ -2443,8 +2458,19 @@ static int spmm_q3_launch(const int32_t *b_rowptr, const float *q_blk, int64_t M
   // 1 200 workgroups the deep shape leaves a 17 % tail, measured 0.67 -> 0.77 on the config-2 vertex-output products)
   const bool wide = force == 2 || (force == 0 && (nblocks <= 4 * Mb || grid < 8u * kCUs));
   if (stats_part) {
-    if (epi.e || N != 32 || y_group != 4) return SN_E_UNSUPPORTED;
+    if (epi.e || (N != 32 && N != 16) || y_group != 4) return SN_E_UNSUPPORTED;
     if (!stats_out) return SN_E_NULL;
+    if (N == 16) {          // 64-channel operands (the Mesh-MNIST models): partials [grid][2][64]
+      if (wide) {
+        if (x_group == 4) SN_KLAUNCH((spmm_q3_lds_stats_wide<16, 4, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+        else SN_KLAUNCH((spmm_q3_lds_stats_wide<16, 1, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+      } else {
+        if (x_group == 4) SN_KLAUNCH((spmm_q3_lds_stats<16, 4, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+        else SN_KLAUNCH((spmm_q3_lds_stats<16, 1, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
+      }
+      hipLaunchKernelGGL(spmm_stats_reduce_k, dim3(kSpmmStatsBlocks), dim3(kWG), 0, s, stats_part, (int64_t)grid, stats_out, 128);
+      return launch_status();
+    }
     if (wide) {
       if (x_group == 4) SN_KLAUNCH((spmm_q3_lds_stats_wide<32, 4, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);
       else SN_KLAUNCH((spmm_q3_lds_stats_wide<32, 1, 4>), grid, s, b_rowptr, q, (int)Mb, X, ldx, Y, ldy, (int)nchunks, stats_part);

@@ -472,7 +472,8 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
         stats = None
     elif pre_stats is not None:                 # (2, C) float64 statistics of x supplied by its producer
         stats = pre_stats
-    elif (part is not None or part_hi is not None) and x.shape[1] == 256:
+    elif ((part is not None or part_hi is not None) and x.shape[1] == 256) or \
+            (part is not None and part_hi is not None and x.shape[1] == 128):      # (64-channel stages: both producers or none)
         stats = kernels.colstats_halves(x, part, part_hi)
     else:
         stats = kernels.colstats(x)

@@ -259,7 +259,7 @@ def spmm_q3(b_rowptr, q_blk, Mb: int, Kb: int, x, y, group: int = 1, e=None, g=N
 
 
 def spmm_q3_stats_supported(N: int, group: int) -> bool:
-    return N == 32 and group == 4
+    return N in (16, 32) and group == 4
 
 
 def spmm_q3_stats(b_rowptr, q_blk, Mb: int, Kb: int, x, y, group: int = 4):
@@ -268,11 +268,11 @@ def spmm_q3_stats(b_rowptr, q_blk, Mb: int, Kb: int, x, y, group: int = 4):
     _dev(b_rowptr, q_blk, x, y)
     N = y.shape[1] // group
     if not spmm_q3_stats_supported(N, group):
-        raise ValueError("spmm_q3_stats: 128-channel operands in the group-4 layout only")
+        raise ValueError("spmm_q3_stats: 128- or 64-channel operands in the group-4 layout only")
     ldx = _check_dense(x, 4 * Kb, group, N, "x")
     ldy = _check_dense(y, 4 * Mb, group, N, "y")
     lib = _lib.load()
-    part = torch.empty((int(lib.sn_spmm_q3_stats_blocks()), 2, 128), dtype=torch.float64, device=y.device)
+    part = torch.empty((int(lib.sn_spmm_q3_stats_blocks()), 2, 4 * N), dtype=torch.float64, device=y.device)
     ws_bytes = int(lib.sn_spmm_q3_stats_workspace_bytes(Mb))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=y.device)
     _lib.call("sn_spmm_q3_stats_f32", _p(b_rowptr), _p(q_blk), Mb, Kb, int(q_blk.shape[0]), _p(x), ldx, group, N, _p(y), ldy,
@@ -724,30 +724,31 @@ def colstats_into(x, out, offset: int):
 
 
 def colstats_halves(x, part, part_hi=None):
-    """(2, 2C) float64 statistics of a stage's concat buffer x = [e | P·e] (rows, 2C), C = 128: the first half from the
-    partials `part` the GEMM that wrote e left behind (sn_colstats_merge_f64); the second half from the partials `part_hi`
-    of the SpMM that wrote P·e (spmm_q3_stats) or, without them, from one pass over x[:, C:] only (sn_colstats_into_f32).
-    part=None: the first half by a pass over x[:, :C]."""
+    """(2, 2C) float64 statistics of a stage's concat buffer x = [e | P·e] (rows, 2C), C = 128 or 64: the first half from the
+    partials `part` the GEMM that wrote e left behind ((nblk, 2, 128) in the kernel's 128-column layout, of which the first C
+    count); the second half from the partials `part_hi` ((nb, 2, C)) of the SpMM that wrote P·e (spmm_q3_stats) or, without
+    them, from one pass over x[:, C:] only (sn_colstats_into_f32).  part=None: the first half by a pass over x[:, :C]."""
     _dev(x, part, part_hi)
     rows, C2 = x.shape
     C = C2 // 2
-    for p_ in (part, part_hi):
-        if p_ is not None and (C != 128 or p_.dim() != 3 or p_.shape[1:] != (2, 128) or p_.dtype != torch.float64):
-            raise ValueError("colstats_halves: expected a (rows, 256) buffer and (nblk, 2, 128) float64 partials")
+    if part is not None and (C not in (64, 128) or part.dim() != 3 or part.shape[1:] != (2, 128) or part.dtype != torch.float64):
+        raise ValueError("colstats_halves: expected a (rows, 256 | 128) buffer and (nblk, 2, 128) float64 GEMM partials")
+    if part_hi is not None and (C not in (64, 128) or part_hi.dim() != 3 or part_hi.shape[1:] != (2, C) or part_hi.dtype != torch.float64):
+        raise ValueError("colstats_halves: expected (nb, 2, C) float64 partials for the propagated half")
     lib = _lib.load()
     out = torch.empty((2, C2), dtype=torch.float64, device=x.device)
+    nlo = int(lib.sn_linear_fwd_stats_blocks(rows)) if part is not None else 0
+    if part is not None and part.shape[0] < nlo:
+        raise ValueError("colstats_halves: partial buffer smaller than the producing launch's grid")
     if part is not None and part_hi is not None:            # both producers left partials: one launch for the two halves
-        nlo = int(lib.sn_linear_fwd_stats_blocks(rows))
-        if part.shape[0] < nlo:
-            raise ValueError("colstats_halves: partial buffer smaller than the producing launch's grid")
-        _lib.call("sn_colstats_merge2_f64", _p(part), nlo, C, _p(part_hi), int(part_hi.shape[0]), C, _p(out), _stream())
+        _lib.call("sn_colstats_merge2_f64", _p(part), nlo, C, 128, _p(part_hi), int(part_hi.shape[0]), C, C, _p(out), _stream())
         return out
-    for half, p_, nblk in ((0, part, int(lib.sn_linear_fwd_stats_blocks(rows))), (1, part_hi, None)):
-        if p_ is not None:
-            nb = nblk if nblk is not None else int(p_.shape[0])
-            if p_.shape[0] < nb:
-                raise ValueError("colstats_halves: partial buffer smaller than the producing launch's grid")
+    for half, p_ in ((0, part), (1, part_hi)):
+        if p_ is not None and (half == 1 or C == 128):
+            nb = nlo if half == 0 else int(p_.shape[0])
             _lib.call("sn_colstats_merge_f64", _p(p_), nb, C, _p(out), C2, half * C, _stream())
+        elif p_ is not None:                                 # (GEMM partials of a 64-channel half are read by the two-source launch only)
+            raise ValueError("colstats_halves: 64-channel GEMM partials need the SpMM's partials too")
         else:
             xs = x[:, half * C:(half + 1) * C]
             ws_bytes = int(lib.sn_colstats_workspace_bytes(rows, C))

@@ -300,8 +300,9 @@ def linear_fwd_supported(K, J):
 def _fill_part(part, y_elu):
     if part is not None:
         part.zero_()
-        part[0, 0] = y_elu.double().sum(0)
-        part[0, 1] = (y_elu.double() ** 2).sum(0)
+        w = y_elu.shape[1]                       # (64-output layers fill the first 64 of the kernel's 128 columns)
+        part[0, 0, :w] = y_elu.double().sum(0)
+        part[0, 1, :w] = (y_elu.double() ** 2).sum(0)
 
 
 def elu_stats_supported():
@@ -329,7 +330,7 @@ def colstats_into(x, out, offset):
 def colstats_halves(x, part, part_hi=None):
     C = x.shape[1] // 2
     out = torch.empty((2, 2 * C), dtype=torch.float64)
-    out[:, :C] = part.sum(0) if part is not None else colstats(x[:, :C])
+    out[:, :C] = part.sum(0)[:, :C] if part is not None else colstats(x[:, :C])
     out[:, C:] = part_hi.sum(0) if part_hi is not None else colstats(x[:, C:])
     return out
 
@@ -355,12 +356,12 @@ def bn_fold_parts(lo, hi, rows, gamma, beta, W, b, eps, momentum, running_mean, 
 
 
 def spmm_q3_stats_supported(N, group):
-    return N == 32 and group == 4
+    return N in (16, 32) and group == 4
 
 
 def spmm_q3_stats(b_rowptr, q_blk, Mb, Kb, x, y, group=4):
     spmm_q3(b_rowptr, q_blk, Mb, Kb, x, y, group)
-    part = torch.zeros((1, 2, 128), dtype=torch.float64)
+    part = torch.zeros((1, 2, y.shape[1]), dtype=torch.float64)
     part[0, 0] = y.double().sum(0)
     part[0, 1] = (y.double() ** 2).sum(0)
     return part

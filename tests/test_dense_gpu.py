@@ -995,3 +995,30 @@ def test_both_halves_of_the_statistics_in_one_launch(rows):
     kernels.colstats_merge_into(lo[:nlo], want, 0)
     kernels.colstats_merge_into(hi, want, 128)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("rows", [33, 77000])
+def test_statistics_of_a_64_channel_concat_buffer_from_both_producers(rows):
+    """The 64-channel stages (Mesh-MNIST): the forward GEMM of a 64-output layer leaves its ELU statistics in the kernel's
+    128-column partial layout, the quaternion SpMM in its own 64-column one; colstats_halves reads both in one launch and
+    equals the statistics pass over the buffer.  The GEMM partials come from the real kernel here."""
+    from surfacenetworks_amd import kernels
+
+    g = torch.Generator().manual_seed(rows)
+    x = torch.randn(rows, 128, generator=g).to(DEV)
+    W = (torch.randn(64, 128, generator=g) * 0.2).to(DEV)
+    b = torch.randn(64, generator=g).to(DEV)
+    cat = torch.full((rows, 128), float("nan"), device=DEV)
+    part = kernels.new_elu_stats_part(rows, DEV)
+    kernels.linear_fwd(x, W, b, None, cat[:, :64], False, part)            # elu(y) -> first half, statistics -> part
+    hi_vals = (torch.randn(rows, 64, generator=g) * 2 - 0.3).to(DEV)
+    cat[:, 64:] = hi_vals
+    # partials of the second half in the SpMM's layout: (blocks, 2, 64)
+    nb = 5
+    bounds = np.linspace(0, rows, nb + 1).astype(int)
+    hi = torch.stack([torch.stack([hi_vals[a:z].double().sum(0), (hi_vals[a:z].double() ** 2).sum(0)]) for a, z in zip(bounds[:-1], bounds[1:])])
+    got = kernels.colstats_halves(cat, part, hi.contiguous())
+    want = kernels.colstats(cat)
+    assert got.shape == (2, 128)
+    assert torch.allclose(got, want, rtol=1e-9, atol=1e-9 * float(want.abs().max()))
+

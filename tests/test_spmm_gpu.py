@@ -413,14 +413,16 @@ def test_pool_assembles_quaternion_packed_batches():
 
 @pytest.mark.parametrize("kind", ["cloth", "cloth_perm", "torus", "delaunay"])
 @pytest.mark.parametrize("which", ["Di", "DiA"])
-def test_spmm_leaves_the_column_statistics_of_its_output(kind, which):
+@pytest.mark.parametrize("N", [32, 16])
+def test_spmm_leaves_the_column_statistics_of_its_output(kind, which, N):
     """sn_spmm_q3_stats_f32: Y bit-identical to sn_spmm_q3_f32 (hence to the CSR oracle), and the partials it leaves add up
-    to the column sums / sums of squares of Y — contiguous and into one half of a concat buffer, ragged tails included."""
+    to the column sums / sums of squares of Y — contiguous and into one half of a concat buffer, ragged tails included; at 128
+    channels (N = 32) and at 64 (N = 16, the Mesh-MNIST models)."""
     _, _, ops = mesh_fixture(kind)
     A = ops[which]
     A.sort_indices()
     M, K = A.shape
-    N, C = 32, 128
+    C = 4 * N
     rng = np.random.default_rng(7)
     xcat = (rng.standard_normal((K // 4, 2 * C)) * 2 + 0.5).astype(np.float32)
     want = c_oracle.spmm_csr(A.indptr, A.indices, A.data, np.ascontiguousarray(xcat[:, :C]).ravel(), N).reshape(M // 4, C)
@@ -431,6 +433,7 @@ def test_spmm_leaves_the_column_statistics_of_its_output(kind, which):
         ybuf = torch.full((M // 4, 2 * C), float("nan"), device=DEV)
         y = ybuf[:, C:] if strided else torch.empty((M // 4, C), device=DEV)
         part = kernels.spmm_q3_stats(b[0], q, M // 4, K // 4, dev(xcat)[:, :C], y, 4)
+        assert part.shape[1:] == (2, C)
         assert np.array_equal(y.cpu().numpy(), want)
         got = part.sum(0).cpu().numpy()
         w64 = want.astype(np.float64)
