@@ -187,6 +187,13 @@ __global__ __launch_bounds__(kWG) void colstats_final2_k(const double *__restric
     const int64_t rs = 2 * (int64_t)ld;                       // doubles per partial row
     const double *p = partial + (i >= Cx ? ld + (i - Cx) : i);
     int b = pg;
+    for (; b + 120 < nblk; b += 128) {          // sixteen, then eight loads in flight (in the step the partials are cold)
+      double v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = p[(int64_t)(b + 8 * u) * rs];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) t += v[u];
+    }
     for (; b + 56 < nblk; b += 64) {
       double v[8];
 #pragma unroll
