@@ -281,7 +281,7 @@ def _timed_steps(step, steps, warm):
     return (time.perf_counter() - t0) / steps
 
 
-def c2_secondary(device, steps: int = 30, warm: int = 5):
+def c2_secondary(device, steps: int = 60, warm: int = 10):
     """BASELINE configs[1]: Mesh-MNIST Dirac model (5 Dirac blocks at 64 channels, src/mesh_mnist/models.py:122-159), batch 512 of
     ~150-vertex meshes, fp32; a step = batch assembly + forward + NLL + backward + Adam (src/mesh_mnist/main.py:151-167),
     forward+loss+backward replayed from one hipGraph (the step is ~250 launches of a few microseconds)."""
@@ -307,7 +307,7 @@ def c2_secondary(device, steps: int = 30, warm: int = 5):
             "ms_per_step_assembly_on_the_compute_stream": serial * 1e3, "eager_ms_per_step": eager * 1e3}
 
 
-def c4_pair_secondary(device, steps: int = 30, warm: int = 5):
+def c4_pair_secondary(device, steps: int = 60, warm: int = 10):
     """The per-GPU work of BASELINE configs[3] (FAUST dense correspondence, 8 GPUs data parallel, one pair per GPU and step:
     src/dense_correspondence/main.py:40,310-327): two 6890-vertex bodies padded to 7000 vertices, Laplacian towers (15 blocks at
     128 channels), the 7000 x 7000 score matrix, argmin-target cross entropy, backward, Adam; replayed from one hipGraph."""

@@ -32,11 +32,11 @@ torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
     step()
     torch.cuda.synchronize()
-want = ("aten::zero_", "aten::copy_", "aten::fill_", "aten::zeros", "aten::clone", "aten::contiguous", "aten::zeros_like", "aten::cat")
+want = ("aten::zero_", "aten::fill_", "aten::zeros", "aten::zeros_like", "aten::full", "aten::new_zeros")
 cnt = collections.Counter()
 for ev in prof.events():
     if ev.name in want:
-        frames = [s for s in ev.stack if "surfacenetworks_amd" in s or "bench" in s or "arap" in s][:2]
-        cnt[(ev.name, " <- ".join(f.split("/")[-1] for f in frames))] += 1
-for (name, where), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:60]:
-    print(f"{c:4d} {name:18s} {where}")
+        frames = [f for f in (ev.stack or []) if ("surfacenetworks_amd" in f or "bench" in f)][:3]
+        cnt[(ev.name, " <- ".join(f.split("/")[-1][:70] for f in frames) or "(autograd engine / no python frame)")] += 1
+for (name, where), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:40]:
+    print(f"{c:4d} {name:14s} {where}")
