@@ -138,3 +138,27 @@ def test_batches_assembled_one_step_ahead_train_the_same_model():
     assert all(torch.equal(a, b) for a, b in zip(params[0], params[1]))
     # the replayed run skipped batch 0 (used as the capture example) and its dropout masks differ: finite, same batches' scale
     assert torch.isfinite(losses[2]).all()
+
+
+def test_the_pair_step_issues_no_library_matrix_product():
+    """One FAUST-style pair step (towers, correspondence loss, backward) on the device: every matrix product is one of the
+    package's own kernels — no aten::mm / bmm / addmm / matmul reaches the library GEMM (models.py:203 and main.py:238-239 are
+    sn_pair_fused_*; the towers' Linear layers the fused BatchNorm+Linear kernels)."""
+    from torch.profiler import ProfilerActivity, profile
+
+    from surfacenetworks_amd import dense_correspondence as dc
+
+    torch.manual_seed(5)
+    ds = dc.TorusBodies(2, n=8, m=9, pad_to=80, seed=4, device=DEV)
+    model = dc.SiameseModel("lap", 15).to(DEV).train()
+    batch = dc.PairBatch(ds, 0, 1)
+    dc.forward_loss(model, batch).sum().backward()            # (lazy initialisations outside the profile)
+    model.zero_grad(set_to_none=True)
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        loss = dc.forward_loss(model, dc.PairBatch(ds, 1, 0)).sum()
+        loss.backward()
+        torch.cuda.synchronize()
+    names = {ev.name for ev in prof.events()}
+    assert not names & {"aten::mm", "aten::bmm", "aten::addmm", "aten::matmul", "aten::baddbmm", "aten::linear"}, sorted(
+        n for n in names if "mm" in n or "linear" in n or "matmul" in n)
+    assert torch.isfinite(loss).item()
