@@ -162,3 +162,26 @@ def test_the_pair_step_issues_no_library_matrix_product():
     assert not names & {"aten::mm", "aten::bmm", "aten::addmm", "aten::matmul", "aten::baddbmm", "aten::linear"}, sorted(
         n for n in names if "mm" in n or "linear" in n or "matmul" in n)
     assert torch.isfinite(loss).item()
+
+
+@pytest.mark.parametrize("kind", ["dir", "lap"])
+def test_the_arap_step_issues_no_library_matrix_product(kind):
+    """The ARAP training step (Dirac / Laplacian model, 120-output last layer, 6-channel first layer included) on the device:
+    no aten::mm / addmm / bmm / linear — every Linear layer, weight gradient and sparse product is one of the package's kernels."""
+    from torch.profiler import ProfilerActivity, profile
+
+    from surfacenetworks_amd import arap
+
+    torch.manual_seed(2)
+    ds = arap.ClothSequences([(9, 8)] * 4, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 2, op_frames=2, seed=3, device=DEV, model=kind)
+    model = (arap.DirModel() if kind == "dir" else arap.Model(15)).to(DEV).train()
+    opt = arap.make_optimizer(model)
+    rng = np.random.default_rng(1)
+    arap.train_step(model, opt, ds.sample_batch(4, rng))
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        loss = arap.train_step(model, opt, ds.sample_batch(4, rng))
+        torch.cuda.synchronize()
+    names = {ev.name for ev in prof.events()}
+    assert not names & {"aten::mm", "aten::bmm", "aten::addmm", "aten::matmul", "aten::baddbmm", "aten::linear"}, sorted(
+        n for n in names if "mm" in n or "linear" in n or "matmul" in n)
+    assert torch.isfinite(loss).item()
