@@ -56,6 +56,54 @@ int sn_host_spmm_csr_f32(const int32_t *rowptr, const int32_t *colind, const flo
   return SN_OK;
 }
 
+/* sn_spmm_csr_ring_f32 (the sliding-window Laplacian product): the same k-ordered FMA chain as sn_spmm_csr_f32 on a square
+ * operator at N = 64 | 128, contiguous rows; the window is an implementation detail of the device kernel, the result is not. */
+#define SN_HOST_RING_R 64
+#define SN_HOST_RING_H 160
+int sn_host_spmm_csr_ring_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
+                              const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, void *stream) {
+  (void)stream;
+  if (M < 0 || K < 0 || nnz < 0 || N < 1) return SN_E_SHAPE;
+  if (!fits_i32(M + SN_HOST_RING_R + 1) || !fits_i32(K) || !fits_i32(nnz)) return SN_E_RANGE;
+  if (M != K) return SN_E_UNSUPPORTED;
+  if (N != 64 && N != 128) return SN_E_UNSUPPORTED;
+  if (M == 0) return SN_OK;
+  if (!rowptr || (nnz > 0 && (!colind || !vals))) return SN_E_NULL;
+  int st = check_dense(Y, ldy, 1, N);
+  if (!st) st = check_dense(X, ldx, 1, N);
+  if (st) return st;
+  if (!aligned16(X) || !aligned16(Y) || ldx % 4 || ldy % 4) return SN_E_ALIGN;
+  for (int64_t r = 0; r < M; ++r)
+    for (int j = 0; j < N; ++j) {
+      float acc = 0.f;
+      for (int k = rowptr[r]; k < rowptr[r + 1]; ++k) acc = fmaf(vals[k], X[(int64_t)colind[k] * ldx + j], acc);
+      Y[r * ldy + j] = acc;
+    }
+  return SN_OK;
+}
+
+/* sn_csr_band_i32: out = { max |column - row| over the rows' first / last entries, longest row, rows reaching past the half window } */
+int sn_host_csr_band_i32(const int32_t *rowptr, const int32_t *colind, int64_t M, int64_t K, int32_t *out, void *stream) {
+  (void)stream;
+  if (M < 0 || K < 0) return SN_E_SHAPE;
+  if (!fits_i32(M + 1) || !fits_i32(K)) return SN_E_RANGE;
+  if (!out || (M > 0 && !rowptr)) return SN_E_NULL;
+  out[0] = out[1] = out[2] = 0;
+  if (M == 0) return SN_OK;
+  if (!colind) return SN_E_NULL;
+  for (int64_t r = 0; r < M; ++r) {
+    const int kb = rowptr[r], ke = rowptr[r + 1];
+    if (ke > kb) {
+      const int lo = (int)r - colind[kb], hi = colind[ke - 1] - (int)r;
+      const int far = lo > hi ? lo : hi;
+      if (far > out[0]) out[0] = far;
+      if (ke - kb > out[1]) out[1] = ke - kb;
+      if (far > SN_HOST_RING_H) out[2] += 1;
+    }
+  }
+  return SN_OK;
+}
+
 int sn_host_spmm_bsr4_f32(const int32_t *b_rowptr, const int32_t *b_colind, const float *b_vals, int64_t Mb, int64_t Kb,
                           int64_t nblocks, const float *X, int64_t ldx, int32_t x_group, int32_t N, float *Y, int64_t ldy,
                           int32_t y_group, void *stream) {

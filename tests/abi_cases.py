@@ -9,7 +9,7 @@ import scipy.sparse as sp
 SN_OK, SN_E_NULL, SN_E_SHAPE, SN_E_RANGE, SN_E_LD, SN_E_ALIGN, SN_E_WORKSPACE, SN_E_UNSUPPORTED = 0, -1, -2, -3, -4, -5, -6, -7
 TWINS = ["sn_spmm_csr_f32", "sn_spmm_bsr4_f32", "sn_spmm_q3_f32", "sn_coo_to_csr_i32", "sn_csr_transpose_f32",
          "sn_blockdiag_concat_i32", "sn_blockdiag_concat_ragged_i32", "sn_validate_csr_i32", "sn_rb4_count", "sn_rb4_fill",
-         "sn_spmm_rb4_f32", "sn_elu_into_f32"]
+         "sn_spmm_rb4_f32", "sn_elu_into_f32", "sn_spmm_csr_ring_f32", "sn_csr_band_i32"]
 
 
 class Backend:
@@ -116,6 +116,21 @@ def run_valid(be: Backend):
     y128p, y128h = be.buf(np.full((M, 128), np.nan, np.float32))
     assert be.fn("sn_spmm_rb4_f32")(bpp, bcp, bvp, M, K, nnz, x128p, 128, 128, y128p, 128, None) == SN_OK
     out["spmm_rb4"] = be.fetch(y128h)
+    # the sliding-window product on a square operator (some rows reach past the half window) and the band probe
+    Ms = 700
+    As = _mesh_like_csr(Ms, Ms, rng, per_row=7)
+    As.sort_indices()
+    srp, _ = be.buf(As.indptr.astype(np.int32))
+    sci, _ = be.buf(As.indices.astype(np.int32))
+    sva, _ = be.buf(As.data)
+    xs = rng.standard_normal((Ms, 128)).astype(np.float32)
+    xsp, _ = be.buf(xs)
+    ysp, ysh = be.buf(np.full((Ms, 128), np.nan, np.float32))
+    assert be.fn("sn_spmm_csr_ring_f32")(srp, sci, sva, Ms, Ms, As.nnz, xsp, 128, 128, ysp, 128, None) == SN_OK
+    out["spmm_ring"] = be.fetch(ysh)
+    bdp, bdh = be.buf(np.full(3, -1, np.int32))
+    assert be.fn("sn_csr_band_i32")(srp, sci, Ms, Ms, bdp, None) == SN_OK
+    out["band"] = be.fetch(bdh)
     # block forms of a Dirac-like operator (4x4 blocks of M(p))
     Mb, Kb, per = 40, 30, 3
     brp_ = np.arange(0, (Mb + 1) * per, per, dtype=np.int32)
@@ -214,6 +229,14 @@ def invalid_calls(be: Backend):
         ("q3: N = 8", f("sn_spmm_q3_f32")(onei, one, 1, 1, 1, one, 32, 4, 8, one, 32, 4, None), SN_E_UNSUPPORTED),
         ("rb4: N = 32", f("sn_spmm_rb4_f32")(onei, onei, one, 4, 4, 4, one, 32, 32, one, 32, None), SN_E_UNSUPPORTED),
         ("rb4: M past int32", f("sn_spmm_rb4_f32")(onei, onei, one, big, 4, 4, one, 128, 128, one, 128, None), SN_E_RANGE),
+        ("ring: not square", f("sn_spmm_csr_ring_f32")(onei, onei, one, 4, 5, 4, one, 128, 128, one, 128, None), SN_E_UNSUPPORTED),
+        ("ring: N = 32", f("sn_spmm_csr_ring_f32")(onei, onei, one, 4, 4, 4, one, 32, 32, one, 32, None), SN_E_UNSUPPORTED),
+        ("ring: M past int32", f("sn_spmm_csr_ring_f32")(onei, onei, one, big, big, 4, one, 128, 128, one, 128, None), SN_E_RANGE),
+        ("ring: null rowptr", f("sn_spmm_csr_ring_f32")(None, onei, one, 4, 4, 4, one, 128, 128, one, 128, None), SN_E_NULL),
+        ("ring: ld % 4", f("sn_spmm_csr_ring_f32")(onei, onei, one, 4, 4, 4, one, 130, 128, one, 128, None), SN_E_ALIGN),
+        ("ring: M == 0 is a no-op", f("sn_spmm_csr_ring_f32")(None, None, None, 0, 0, 0, None, 128, 128, None, 128, None), SN_OK),
+        ("band: null output", f("sn_csr_band_i32")(onei, onei, 4, 4, None, None), SN_E_NULL),
+        ("band: M past int32", f("sn_csr_band_i32")(onei, onei, big, 4, onei, None), SN_E_RANGE),
         ("coo: B < 1", f("sn_coo_to_csr_i32")(None, None, None, 0, 0, 4, 4, onei, onei, None), SN_E_SHAPE),
         ("coo: B*R past int32", f("sn_coo_to_csr_i32")(None, None, None, 0, 4096, 2**20, 4, onei, onei, None), SN_E_RANGE),
         ("coo: null rowptr", f("sn_coo_to_csr_i32")(None, None, None, 0, 1, 4, 4, None, onei, None), SN_E_NULL),

@@ -43,3 +43,10 @@ def test_twins_compute_the_oracle_results():
     assert out["coo_to_csr"][0].tolist() == [0, 2, 2, 2, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 6]
     assert np.isnan(out["elu"][:, 8:]).all()                          # the strided destination's other half is untouched
     assert np.allclose(out["elu"][:, :8], c_oracle.elu(out["elu_src"]), rtol=1e-6, atol=1e-7)
+
+
+def test_ring_twin_is_the_csr_product_and_the_band_of_the_operator():
+    out = ac.run_valid(ac.Backend("host"))
+    assert not np.isnan(out["spmm_ring"]).any()
+    band, longest, outside = (int(v) for v in out["band"])
+    assert band > 160 and longest >= 7 and 0 < outside <= 700          # a 700-row operator with columns anywhere: rows past the window
