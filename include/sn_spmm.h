@@ -244,7 +244,8 @@ int sn_spmm_rb4_stats_f32(const int32_t *b_ptr, const int32_t *b_col, const floa
  * rows in an LDS ring: every X line and every entry is requested once per 64-column slice, by LDS-DMA.  Columns outside
  * the window are gathered from global memory (correct for ANY operator, fast for banded ones): callers decide with
  * sn_csr_band_i32, which leaves max |column - row|, the longest row and the number of rows with an entry outside the window
- * in band_longest_outside[0..2] (device memory).
+ * in band_longest_outside[0..2] (device memory); an operator with a row whose columns do not ascend strictly reports
+ * INT32_MAX as its longest row (the ring kernel bounds a row by its first and last entry: such an operator must not take it).
  * Requirements: M == K, N in {64, 128}, columns ascending inside each row; SN_E_UNSUPPORTED otherwise.
  * Results are bit-identical to sn_spmm_csr_f32 (same k-ascending FMA order per row).
  * ------------------------------------------------------------------------------------------ */

@@ -82,7 +82,7 @@ int sn_host_spmm_csr_ring_f32(const int32_t *rowptr, const int32_t *colind, cons
   return SN_OK;
 }
 
-/* sn_csr_band_i32: out = { max |column - row| over the rows' first / last entries, longest row, rows reaching past the half window } */
+/* sn_csr_band_i32: out = { max |column - row|, longest row (INT32_MAX when a row's columns do not ascend), rows reaching past the half window } */
 int sn_host_csr_band_i32(const int32_t *rowptr, const int32_t *colind, int64_t M, int64_t K, int32_t *out, void *stream) {
   (void)stream;
   if (M < 0 || K < 0) return SN_E_SHAPE;
@@ -94,10 +94,17 @@ int sn_host_csr_band_i32(const int32_t *rowptr, const int32_t *colind, int64_t M
   for (int64_t r = 0; r < M; ++r) {
     const int kb = rowptr[r], ke = rowptr[r + 1];
     if (ke > kb) {
-      const int lo = (int)r - colind[kb], hi = colind[ke - 1] - (int)r;
+      int cmin = colind[kb], cmax = cmin, asc = 1;
+      for (int k = kb + 1; k < ke; ++k) {          /* a row whose columns do not ascend strictly reports INT32_MAX as its length */
+        if (colind[k] <= colind[k - 1]) asc = 0;
+        if (colind[k] < cmin) cmin = colind[k];
+        if (colind[k] > cmax) cmax = colind[k];
+      }
+      const int lo = (int)r - cmin, hi = cmax - (int)r;
       const int far = lo > hi ? lo : hi;
+      const int len = asc ? ke - kb : 0x7fffffff;
       if (far > out[0]) out[0] = far;
-      if (ke - kb > out[1]) out[1] = ke - kb;
+      if (len > out[1]) out[1] = len;
       if (far > SN_HOST_RING_H) out[2] += 1;
     }
   }

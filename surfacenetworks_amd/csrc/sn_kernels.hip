@@ -1389,6 +1389,11 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
       __builtin_amdgcn_s_barrier();
     }
     wait_vmcnt_imm<0>();                                              // nothing may land in LDS after the workgroup has gone
+    // STATS: the compute waves re-use ring rows 0..127 as scratch for the column sums.  The DMA of the steps past t1 (issued
+    // above with clamped addresses to keep the instruction counts uniform) targets ring rows that can overlap that scratch, so
+    // every loader drains FIRST (the wait above) and only then meets the compute waves at one more barrier, which they pass
+    // before their first scratch store.
+    if constexpr (STATS) __builtin_amdgcn_s_barrier();
     return;
   }
 
@@ -1551,8 +1556,10 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
   }
   if constexpr (STATS) {
     // column sums / sums of squares of this workgroup's output rows -> stats_part[strip][sum | squares][128] (fp32 over the
-    // strip per lane, then a fixed-order sum; fp64 above).  The loader waves have left: a finished wave no longer counts at
-    // s_barrier.
+    // strip per lane, then a fixed-order sum; fp64 above).  First the loaders' drain barrier (every DMA they issued has
+    // landed: nothing can overwrite the scratch below); after it the loader waves leave, and a finished wave no longer counts
+    // at s_barrier.
+    __builtin_amdgcn_s_barrier();
     float *st = xs + (wave * 8 + g) * (2 * CS);                       // [NCW*8][sum | squares][CS] in the (now free) ring
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
@@ -1579,12 +1586,25 @@ __global__ __launch_bounds__(kWG) void csr_band_k(const int *__restrict__ rowptr
   int band = 0, longest = 0, outside = 0;
   for (int64_t r = (int64_t)blockIdx.x * kWG + threadIdx.x; r < M; r += (int64_t)gridDim.x * kWG) {
     const int kb = rowptr[r], ke = rowptr[r + 1];
-    if (ke > kb) {                                                    // columns ascend: the first and the last entry bound the row
-      const int lo = (int)r - colind[kb], hi = colind[ke - 1] - (int)r;
+    if (ke > kb) {
+      // The ring kernel bounds a row by its first and last entry, i.e. it needs strictly ascending columns.  A row that is
+      // not (an operator built straight from unsorted CSR arrays) reports INT32_MAX as the longest row, which no caller's
+      // "longest row <= 32" rule lets through to the ring kernel; the band is measured over all entries of the row.
+      int cmin = colind[kb], cmax = cmin, prev = cmin;
+      bool asc = true;
+      for (int k = kb + 1; k < ke; ++k) {
+        const int c = colind[k];
+        asc = asc && c > prev;
+        prev = c;
+        cmin = c < cmin ? c : cmin;
+        cmax = c > cmax ? c : cmax;
+      }
+      const int lo = (int)r - cmin, hi = cmax - (int)r;
       const int far = lo > hi ? lo : hi;
       band = far > band ? far : band;
       outside += far > kRingH ? 1 : 0;
-      longest = ke - kb > longest ? ke - kb : longest;
+      const int len = asc ? ke - kb : 0x7fffffff;
+      longest = len > longest ? len : longest;
     }
   }
   for (int o = 32; o > 0; o >>= 1) {

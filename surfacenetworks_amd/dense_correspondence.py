@@ -215,6 +215,17 @@ class SiameseModel(nn.Module):
 
         # (not with synchronised BatchNorm: its collectives would be issued from two streams)
         two = _TWO_STREAMS and inputA.is_cuda and snF._BN_SYNC is None
+        if two:
+            # Two streams need two INDEPENDENT applications.  (i) A pair of the same frame (`PairBatch(ds, i, i)`: the reference
+            # samples the two frames independently, main.py:106-191) hands both towers the same operator / mask objects, whose
+            # derived forms (row-blocked arrays, transposes, the mask's 1/count) are built lazily by the first application on
+            # ITS stream and would be read by the other without an ordering edge.  (ii) A BatchNorm with momentum=None keeps
+            # a cumulative average that the capture-buffer trick below (momentum 1) cannot express.
+            flat = lambda ops: [o for o in (ops if isinstance(ops, (tuple, list)) else (ops,)) if o is not None]
+            ida = {id(o) for o in flat(OperationA)} | {id(inputA)}
+            shared = any(id(o) in ida for o in flat(OperationB)) or inputB is inputA
+            cumulative = any(isinstance(m, torch.nn.modules.batchnorm._BatchNorm) and m.momentum is None for m in self.model.modules())
+            two = not shared and not cumulative
         try:
             for d, key, i in slots:
                 d[key] = alias[i]

@@ -26,6 +26,38 @@ from .operators import SparseOperator
 __all__ = ["operator_tensors", "batch_tensors", "batch_signature", "GraphedStep", "GraphedTrainStep"]
 
 
+# The ring-vs-row-blocked choice of a Laplacian-type operator (SparseOperator.ring_ok) depends on the band of the batch's
+# VALUES, not on its shapes, and it decides whether the row-blocked arrays are graph inputs.  A capture therefore FREEZES the
+# choice of every operator of its example (in listing order) and every later batch is listed — and, were it multiplied
+# eagerly, dispatched — with those choices: `_ring_choices` is ("record", list) while the example is listed, ("apply", iterator)
+# while a later batch is, None otherwise.
+_ring_choices = None
+
+
+class _RingChoices:
+    def __init__(self, mode, store):
+        self.state = (mode, store if mode == "record" else iter(store))
+
+    def __enter__(self):
+        global _ring_choices
+        self.prev, _ring_choices = _ring_choices, self.state
+
+    def __exit__(self, *exc):
+        global _ring_choices
+        _ring_choices = self.prev
+
+
+def _ring_choice(o: SparseOperator) -> bool:
+    if _ring_choices is not None and _ring_choices[0] == "apply":
+        o._ring_forced = next(_ring_choices[1])
+        return o._ring_forced
+    take = bool(o.ring_ok(128) or o.ring_ok(64))
+    if _ring_choices is not None:
+        _ring_choices[1].append(take)
+        o._ring_forced = take
+    return take
+
+
 def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
     """Every materialised device array of an operator and its attached transpose, in a fixed order."""
     if op is None:
@@ -55,7 +87,7 @@ def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
             if snF._LAPLACIAN_FORMAT in ("ring", "rb4") and o.is_cuda:
                 # (an operator that takes the sliding-window kernel is multiplied straight from its CSR arrays: nothing
                 #  derived to list; the decision — the band of the operator — is measured here, before the capture)
-                if snF._LAPLACIAN_FORMAT == "ring" and (o.ring_ok(128) or o.ring_ok(64)):
+                if snF._LAPLACIAN_FORMAT == "ring" and _ring_choice(o):
                     continue
                 r = o.rb4()
                 if r is not None:
@@ -137,8 +169,11 @@ class GraphedStep:
         if not batch_tensors(example)[0].is_cuda:
             raise RuntimeError("GraphedStep needs a GPU batch (hipGraph capture)")
         self.static = example
-        self._static_tensors = batch_tensors(example)
-        self.signature = batch_signature(example)
+        self._ring = []                                    # frozen ring-vs-row-blocked choices of the example's operators
+        with _RingChoices("record", self._ring):
+            self._static_tensors = batch_tensors(example)
+        with _RingChoices("apply", self._ring):
+            self.signature = batch_signature(example)
         self._body, self._zero = body, zero_grads
         # eager warm-up on a side stream (lazy conversions, allocator, autotuned library kernels), then capture
         saved = [t.clone() for t in (preserve or [])]
@@ -175,11 +210,19 @@ class GraphedStep:
         return self._body(self.static)
 
     def matches(self, batch) -> bool:
-        return batch_signature(batch) == self.signature
+        try:
+            with _RingChoices("apply", self._ring):
+                return batch_signature(batch) == self.signature
+        except StopIteration:                              # more Laplacian-type operators than the example had
+            return False
 
     def load(self, batch) -> None:
         """Copy a freshly sampled batch into the static buffers (device-to-device, on the current stream)."""
-        src = batch_tensors(batch)
+        try:
+            with _RingChoices("apply", self._ring):
+                src = batch_tensors(batch)
+        except StopIteration:
+            raise ValueError("batch does not match the captured signature; capture a new GraphedStep") from None
         if len(src) != len(self._static_tensors) or any(
                 s.shape != d.shape or s.dtype != d.dtype for s, d in zip(src, self._static_tensors)):
             raise ValueError("batch does not match the captured signature; capture a new GraphedStep")

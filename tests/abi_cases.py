@@ -131,6 +131,14 @@ def run_valid(be: Backend):
     bdp, bdh = be.buf(np.full(3, -1, np.int32))
     assert be.fn("sn_csr_band_i32")(srp, sci, Ms, Ms, bdp, None) == SN_OK
     out["band"] = be.fetch(bdh)
+    # the same operator with the entries of every row reversed (columns descending): the probe must flag it — the ring kernel
+    # bounds a row by its first and last entry — by reporting INT32_MAX as the longest row; the band is over all entries
+    rev = np.concatenate([As.indices[As.indptr[r]:As.indptr[r + 1]][::-1] for r in range(Ms)]).astype(np.int32)
+    rci, _ = be.buf(rev)
+    bdp2, bdh2 = be.buf(np.full(3, -1, np.int32))
+    assert be.fn("sn_csr_band_i32")(srp, rci, Ms, Ms, bdp2, None) == SN_OK
+    out["band_unsorted"] = be.fetch(bdh2)
+    assert out["band_unsorted"][1] == 0x7fffffff and out["band_unsorted"][0] == out["band"][0] and out["band"][1] < 64
     # block forms of a Dirac-like operator (4x4 blocks of M(p))
     Mb, Kb, per = 40, 30, 3
     brp_ = np.arange(0, (Mb + 1) * per, per, dtype=np.int32)

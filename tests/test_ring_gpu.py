@@ -148,6 +148,17 @@ def test_band_of_an_operator_and_the_dispatch_rule(monkeypatch):
     few = SparseOperator.from_scipy(_banded(3000, rng, 161), DEV)          # a handful of rows one column past the window
     assert few.band()[0] == 161 and 0 < few.band()[2] <= 0.05 * 3000 and few.ring_ok(128)
     assert not SparseOperator.from_scipy(_banded(3000, rng, 50, long_rows=((7, 33),)), DEV).ring_ok(128)
+    # an operator built straight from UNSORTED CSR arrays (columns descending inside every row) must not take the ring kernel —
+    # it bounds a row by its first and last entry; the probe reports INT32_MAX as the longest row and the product, through the
+    # generic kernels, equals the sorted operator's up to the summation order
+    rev = np.concatenate([A.indices[A.indptr[r]:A.indptr[r + 1]][::-1] for r in range(3000)]).astype(np.int32)
+    rvals = np.concatenate([A.data[A.indptr[r]:A.indptr[r + 1]][::-1] for r in range(3000)]).astype(np.float32)
+    uns = SparseOperator(torch.from_numpy(A.indptr.astype(np.int32)).to(DEV), torch.from_numpy(rev).to(DEV),
+                         torch.from_numpy(rvals).to(DEV), (3000, 3000))
+    assert uns.band()[1] == 0x7fffffff and uns.band()[0] == op.band()[0] and not uns.ring_ok(128)
+    xu = torch.randn(3000, 128, device=DEV)
+    snF.set_laplacian_format("ring")
+    torch.testing.assert_close(snF.spmm(uns, xu), snF.spmm(op, xu), rtol=1e-5, atol=1e-5)
     # pools hand the band of a batch over without a device pass: the maximum over the selected meshes
     mats = _mesh_batch("cloth", rng)
     pool = OperatorPool(mats, DEV)
