@@ -135,6 +135,14 @@ int sn_spmm_q3_elubwd_f32(const int32_t *b_rowptr, const float *q_blk, int64_t M
                           const float *X, int64_t ldx, int32_t x_group, int32_t N,
                           const float *E, int64_t lde, const float *G, int64_t ldg,
                           float *Y, int64_t ldy, int32_t y_group, void *stream);
+/* The same product, which also leaves an upper bound of max |Y| for the two-piece weight gradient that reads Y as its dy
+ * operand (sn_wgrad_*_bounded_f32): y_absmax — device, sn_spmm_q3_absmax_blocks(Mb, N) floats, one maximum per workgroup;
+ * the consumer takes the maximum of all of them.  No atomics, nothing to zero beforehand; deterministic. */
+int64_t sn_spmm_q3_absmax_blocks(int64_t Mb, int32_t N);
+int sn_spmm_q3_elubwd_absmax_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks,
+                                 const float *X, int64_t ldx, int32_t x_group, int32_t N, const float *E, int64_t lde,
+                                 const float *G, int64_t ldg, float *Y, int64_t ldy, int32_t y_group, float *y_absmax,
+                                 void *stream);
 int sn_bsr4_to_q3_f32(const int32_t *b_colind, const float *b_vals, int64_t nblocks, float *q_blk,
                       int32_t *not_quaternion, void *stream);
 
@@ -391,6 +399,32 @@ int sn_wgrad_seg_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx,
 int sn_wgrad_slabs_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                        const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg, int32_t J, int32_t C,
                        float *G, double *dysum, float *seg_dysum, void *workspace, size_t workspace_bytes, void *stream);
+/* sn_wgrad_*_bounded_f32: the three weight gradients above on TWO fp16 pieces per operand (three exact partial products
+ * instead of the six of the three-piece bf16 split: half the matrix work; measured -20 % per launch, round 4).  fp16 has
+ * five exponent bits, and the contraction runs over the rows, so the powers of two that bring the operands into range must be
+ * constant along a column and known before the first row is read.  The caller supplies the bounds they follow from:
+ *   dybound   device, n_dybound floats whose maximum is >= max |dy| over the whole operand — the per-workgroup maxima left by
+ *             the kernel that produced dy (sn_linear_dgrad_elu_absmax_f32, sn_linear_dgrad_eluseg_absmax_f32,
+ *             sn_spmm_q3_elubwd_absmax_f32), or one number from any other source; the kernel takes their maximum itself;
+ *   xinvstd   device, C floats: BatchNorm's inverse standard deviations 1 / sqrt(var + eps) of x's columns about `center`
+ *             (the biased batch variance, src/utils/utils_pt.py:83-99 nn.BatchNorm1d), over stat_rows >= rows rows that include
+ *             every row of x:  |x[r][c] - center[c]| <= sqrt(stat_rows) / xinvstd[c]  holds for every row, rigorously.
+ * Both operands are scaled so that their bound lands in [2^14, 2^15) (nothing can overflow); an element keeps 22 significant
+ * bits down to 2^-17 of its operand's bound and 2^-25 of the scaled unit (2^-39 of the bound) in absolute terms below that
+ * (SN_WGRAD_H=1: a second accumulator for low pieces scaled by a further 2^11 — 2^-28 / 2^-50 — at the cost of the second row
+ * block in flight); results leave multiplied by the exact inverse scales.  Eval-mode BatchNorm (running statistics) offers no such bound: use the unbounded forms.
+ * Same arguments, workspace and status codes as the forms above; SN_E_SHAPE when stat_rows < rows, SN_E_NULL without bounds. */
+int sn_wgrad_bounded_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                         int32_t J, int32_t C, float *G, double *dysum, void *workspace, size_t workspace_bytes,
+                         const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows, void *stream);
+int sn_wgrad_seg_bounded_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                             int64_t rows_per_seg, int32_t J, int32_t C, float *G, double *dysum, float *seg_dysum,
+                             void *workspace, size_t workspace_bytes, const float *dybound, int64_t n_dybound,
+                             const float *xinvstd, int64_t stat_rows, void *stream);
+int sn_wgrad_slabs_bounded_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                               const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg, int32_t J,
+                               int32_t C, float *G, double *dysum, float *seg_dysum, void *workspace, size_t workspace_bytes,
+                               const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows, void *stream);
 /* sn_wgrad_thin_f32: weight and bias gradient of a Linear with 1..8 input channels — the models' first layer,
  * GraphConv1x1(6 | 3 -> C, batch_norm=None) (src/as_rigid_as_possible/models.py:113, src/utils/utils_pt.py:99) — on
  * rows ~ 1e5..1e6:  G (J x C, row-major, fp32) = dy^T x,  db (J, optional) = colsum(dy).  One pass over dy; fp32
@@ -671,6 +705,15 @@ int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64
                             const float *center, const float *B, const float *Cc, float *dx_hi, int64_t lddx,
                             float *gact, int64_t ldga, const float *gadd, int64_t ldgadd,
                             int64_t rows, int32_t J, int32_t C, void *stream);
+/* The same launch, which also leaves an upper bound of max |gact| — gact is the dy operand of the layer below, and the
+ * two-piece weight gradient (sn_wgrad_*_bounded_f32) needs that bound before it reads the first row.  gact_absmax: device,
+ * sn_linear_dgrad_absmax_blocks() floats, one maximum per workgroup (entries past the grid zeroed): the consumer takes the
+ * maximum of all of them.  No atomics, no zero-fill before the launch; deterministic.  NULL: as the plain entry point. */
+int32_t sn_linear_dgrad_absmax_blocks(void);
+int sn_linear_dgrad_elu_absmax_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                                   const float *center, const float *B, const float *Cc, float *dx_hi, int64_t lddx,
+                                   float *gact, int64_t ldga, const float *gadd, int64_t ldgadd,
+                                   int64_t rows, int32_t J, int32_t C, float *gact_absmax, void *stream);
 int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
                               int64_t rows_per_seg, const float *residual, int64_t ldr, float *y, int64_t ldy,
                               float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J, double *elu_stats_part,
@@ -690,6 +733,17 @@ int sn_linear_dgrad_eluseg_ragged_f32(const float *dy, int64_t lddy, const float
                                       const float *center, const float *B, const float *Cc, const float *segvec,
                                       const int64_t *segoff, int32_t nseg, float *gact, int64_t ldga, const float *gadd,
                                       int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream);
+/* ... and with the bound of |gact| for the two-piece weight gradient of the layer below (see sn_linear_dgrad_elu_absmax_f32:
+ * gact_absmax holds sn_linear_dgrad_absmax_blocks() floats, one maximum per workgroup). */
+int sn_linear_dgrad_eluseg_absmax_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                                      const float *center, const float *B, const float *Cc, const float *segvec,
+                                      int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,
+                                      int64_t ldgadd, int64_t rows, int32_t J, int32_t C, float *gact_absmax, void *stream);
+int sn_linear_dgrad_eluseg_ragged_absmax_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x,
+                                             int64_t ldx, const float *center, const float *B, const float *Cc,
+                                             const float *segvec, const int64_t *segoff, int32_t nseg, float *gact, int64_t ldga,
+                                             const float *gadd, int64_t ldgadd, int64_t rows, int32_t J, int32_t C,
+                                             float *gact_absmax, void *stream);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,21 @@ SIGNATURES = {
     "sn_wgrad_seg_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "sn_wgrad_seg_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sn_wgrad_slabs_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "sn_wgrad_bounded_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _i64, _vp, _i64, _vp]),
+    "sn_wgrad_seg_bounded_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp, _i64, _vp,
+                                           _i64, _vp]),
+    "sn_wgrad_slabs_bounded_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz,
+                                             _vp, _i64, _vp, _i64, _vp]),
+    "sn_linear_dgrad_absmax_blocks": (_i32, []),
+    "sn_linear_dgrad_elu_absmax_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64,
+                                                 _i32, _i32, _vp, _vp]),
+    "sn_linear_dgrad_eluseg_absmax_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _i64, _vp,
+                                                    _i64, _i64, _i32, _i32, _vp, _vp]),
+    "sn_linear_dgrad_eluseg_ragged_absmax_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _i64,
+                                                           _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "sn_spmm_q3_absmax_blocks": (_i64, [_i64, _i32]),
+    "sn_spmm_q3_elubwd_absmax_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i32,
+                                               _vp, _vp]),
     "sn_wgrad_thin_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "sn_wgrad_thin_f32": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "sn_masked_smooth_l1_workspace_bytes": (_sz, [_i64, _i32]),

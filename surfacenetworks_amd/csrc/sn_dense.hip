@@ -50,6 +50,9 @@ __device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
 #ifndef SN_X_WGU_NT
 #define SN_X_WGU_NT 0
 #endif
+#ifndef SN_X_WGU_HALF
+#define SN_X_WGU_HALF 0        // ablation only (wrong numbers): issue 3 of the 6 partial products, everything else unchanged
+#endif
 #ifndef SN_X_WGU_PERM
 #define SN_X_WGU_PERM 0
 #endif
@@ -809,7 +812,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
       constexpr int a = (m % (2 * CT)) / CT, c = m % CT;
       constexpr int pa = (0x001102 >> (4 * t)) & 15, pb = (0x010120 >> (4 * t)) & 15;
 #if !SN_X_WGU_NOMFMA
-      acc[a][c] = mfma_bf16(A[st][a][pa], B[st][c][pb], acc[a][c]);
+      if constexpr (!SN_X_WGU_HALF || t < 3) acc[a][c] = mfma_bf16(A[st][a][pa], B[st][c][pb], acc[a][c]);
 #else
       acc[a][c][m % 16] += __uint_as_float(A[st][a][pa].x ^ B[st][c][pb].x);
 #endif
@@ -2586,6 +2589,255 @@ __global__ __launch_bounds__(kWG) void pair_reduce_k(PairGradSide A, PairGradSid
     if (k + c < K) o[c] = v[c];
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// wgrad_h_k — the uniform-wave weight gradient on TWO fp16 pieces (three partial products instead of six).
+//
+// Ablation of wgrad_u_k on one box (round 4, tools/scratch/wgrad_ab.sh, 627 200 rows x 256 columns): the six bf16 products
+// alone (no loads, no conversion) take 150 of the kernel's 293 us at the 1.8 GHz the chip sustains under it, the memory path
+// alone 191, and the two do not hide each other; with three of the six products issued the kernel runs in 232.  Halving the
+// matrix work needs the fp16 split of the forward kernels (sn_gemm.hip: x = h + l, h = rn16(x), l = rn16(x - h), three exact
+// products h·h + (h·l + l·h)), and fp16 needs RANGE control.  The contraction runs over the rows, so the powers of two
+// that bring the operands into range must be constant along a COLUMN, and they must be known before the first row is
+// converted.  Both come from bounds the callers already hold:
+//   x - mean   BatchNorm's own statistics: sum_r (x[r][c] - mean[c])^2 = n·var[c], hence |x[r][c] - mean[c]| <= sqrt(n / invstd[c]^2)
+//              for EVERY row — rigorous, no pass over x (n = rows behind the statistics; the caller passes xfac >= sqrt(n));
+//   dy         one number for the whole operand, an upper bound of max |dy| left by the kernel that PRODUCED dy (the
+//              input-gradient GEMM's epilogue, the transposed sparse product's store, the loss backward: sn_absmax_* in
+//              sn_spmm.h); one global scale suffices for rigour, and accuracy survives it — below.
+// Scaled operands: bound -> [2^14, 2^15) (fp16 tops out at 65504), so nothing can overflow.  LOW11: the low pieces carry a
+// further 2^11 (their two products go to a second accumulator, folded in with 2^-11 at the end, as in sn_gemm.hip): an
+// element keeps 22 significant bits while its scaled magnitude is >= 2^-14, i.e. down to 2^-28 of the operand's bound, and
+// 2^-36 of the bound in absolute terms below that.  !LOW11: one accumulator, the low piece unscaled: 22 bits down to 2^-17
+// of the bound, 2^-25 (scaled) absolute below.  Results leave multiplied by the exact inverse scales.
+// Structure (slots, images, barriers, slab tables, column sums of dy) as wgrad_u_k; two pieces: two LDS images of 51 KB at
+// C = 256 instead of three.  SETS = 2: two 32-row blocks in flight in registers instead of one.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float pow2_up_for(float bound) {      // 2^(15 - E) for bound = f·2^E, f in [0.5, 1): bound -> [2^14, 2^15)
+  int e = (int)((__float_as_uint(bound) >> 23) & 0xffu) - 126;
+  e = e < -100 ? -100 : (e > 100 ? 100 : e);                     // zero / denormal / non-finite bounds: any finite scale
+  return __uint_as_float((unsigned)(127 + 15 - e) << 23);
+}
+__device__ __forceinline__ float pow2_inv(float p) {             // 1 / p for p = 2^k, k in [-115, 115]
+  return __uint_as_float((254u << 23) - __float_as_uint(p));
+}
+
+template <int CT /* C / 128 */, bool LOW11, int SETS>
+__global__ __launch_bounds__(kWgradThreads, 1) void wgrad_h_k(const float *__restrict__ dy, int64_t lddy,
+                                                              const float *__restrict__ x, int64_t ldx,
+                                                              const float *__restrict__ center, int64_t rows, int J, int C,
+                                                              float *__restrict__ partial /* [grid][128][C] */,
+                                                              float *__restrict__ colpart /* [grid][128] | NULL */,
+                                                              int64_t seg_rows, int spm, const int64_t *__restrict__ slab_off,
+                                                              const float *__restrict__ dybound /* [ndy]: max >= max |dy| */,
+                                                              int ndy, const float *__restrict__ xinvstd /* [C] */, float xfac) {
+  constexpr int NCG = 32 + 32 * CT;          // column groups of 4: 32 of dy, 32·CT of x
+  constexpr int QP = NCG + 4;                // slots per (column % 4) plane; QP % 16 == 4 keeps fragment reads conflict-free
+  constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
+  constexpr int NK = 1 + CT;                 // conversion slots per wave and block: one of dy, CT of x
+  constexpr int NM = 12 * CT;                // MFMAs per wave and block: 2 steps x 3 products x 2·CT tiles
+  constexpr int NPAIR = 4 * NK, NLOAD = 8 * NK;
+  constexpr int NACC = LOW11 ? 2 : 1;
+  static_assert(QP % 16 == 4, "slot permutation");
+  __shared__ u4 img[2][2][4 * PL];           // [buffer][piece][slot]; one block = 32 rows = 4 row groups
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  int64_t r0, r1;                            // row slab of this workgroup (as wgrad_u_k)
+  if (slab_off) {
+    r0 = slab_off[blockIdx.x];
+    r1 = slab_off[blockIdx.x + 1];
+  } else if (seg_rows > 0) {
+    const int64_t mesh = blockIdx.x / spm, part = blockIdx.x % spm;
+    int64_t per = (seg_rows + spm - 1) / spm;
+    per = (per + 15) & ~(int64_t)15;
+    const int64_t mend = (mesh + 1) * seg_rows < rows ? (mesh + 1) * seg_rows : rows;
+    r0 = mesh * seg_rows + part * per;
+    r1 = r0 + per < mend ? r0 + per : mend;
+  } else {
+    int64_t per = (rows + gridDim.x - 1) / gridDim.x;
+    per = (per + 15) & ~(int64_t)15;
+    r0 = (int64_t)blockIdx.x * per;
+    r1 = r0 + per < rows ? r0 + per : rows;
+  }
+  const int nblocks = r1 > r0 ? (int)((r1 - r0 + 31) / 32) : 0;
+  const int span = r1 > r0 ? (int)(r1 - r0) : 0;
+  float *P = partial + (int64_t)blockIdx.x * 128 * C;
+
+  // ---- matrix role: dy tiles 2·ga, 2·ga + 1  x  x tiles CT·gb .. CT·gb + CT - 1 ----
+  const int i = lane & 31, kh = lane >> 5;
+  const int ga = wave >> 2, gb = wave & 3;
+  const int fo = kh * PL + (i & 3) * QP + (i >> 2);
+  f16v acc[NACC][2][CT];
+#pragma unroll
+  for (int n = 0; n < NACC; ++n)
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < CT; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[n][a][b][e] = 0.f;
+  // scales: one for dy — from the maximum of the producer's per-workgroup maxima —, one per x column (mine as a converter,
+  // mine as the owner of output columns)
+  float sdy;
+  {
+    float *sb = reinterpret_cast<float *>(&img[0][0][0]);             // (the images are not in use yet)
+    float m = 0.f;
+    for (int q = tid; q < ndy; q += kWgradThreads) m = fmaxf(m, dybound[q]);
+    unsigned mb = __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned other = (unsigned)__shfl_xor((int)mb, o);
+      mb = other > mb ? other : mb;
+    }
+    if (lane == 0) sb[wave] = __uint_as_float(mb);
+    __syncthreads();
+    m = fmaxf(fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3])), fmaxf(fmaxf(sb[4], sb[5]), fmaxf(sb[6], sb[7])));
+    __syncthreads();                                                   // (all have read before the first image write)
+    sdy = pow2_up_for(m);
+  }
+  float osc[CT];                             // inverse scale of my output column in each of my x tiles, times dy's
+#pragma unroll
+  for (int c = 0; c < CT; ++c) osc[c] = pow2_inv(pow2_up_for(xfac / xinvstd[32 * (CT * gb + c) + i])) * pow2_inv(sdy);
+
+  // ---- conversion role (as wgrad_u_k: slot 0 = a dy half-block, slots 1.. = x half-blocks) ----
+  const int lcol = lane;
+  int s_rg[NK];
+  const float *s_cur[NK];
+  int l_voff[NK];
+  int l_slot[NK];
+  float l_mu[NK], l_sc[NK];
+  float l_sum = 0.f;
+  const int dy_rstep = 4 * (int)lddy, x_rstep = 4 * (int)ldx;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int xhb = wave + 8 * (k - 1);
+    const int rg = k == 0 ? wave >> 1 : xhb / (2 * CT);
+    const int c = k == 0 ? 64 * (wave & 1) + lcol : 128 + 64 * (xhb % (2 * CT)) + lcol;      // column in the image
+    s_rg[k] = rg;
+    s_cur[k] = k == 0 ? dy + 64 * (wave & 1) + (r0 + 8 * rg) * lddy : x + 64 * (xhb % (2 * CT)) + (r0 + 8 * rg) * ldx;
+    l_voff[k] = (k == 0 && c >= J) ? 0x7fffff00 : 4 * lcol;
+    l_mu[k] = (k > 0 && center) ? center[c - 128] : 0.f;
+    l_sc[k] = k == 0 ? sdy : pow2_up_for(xfac / xinvstd[c - 128]);
+    l_slot[k] = rg * PL + (c & 3) * QP + (c >> 2);
+  }
+  float raw[SETS][NK][8];
+  u4 cH[NK], cL[NK];
+  auto conv_pair = [&](auto sc, auto kc, auto pc) {
+    constexpr int set = decltype(sc)::value, k = decltype(kc)::value, p = decltype(pc)::value;
+    f2v xv = {raw[set][k][2 * p], raw[set][k][2 * p + 1]};
+    if constexpr (k == 0) l_sum += xv.x + xv.y;
+    else xv -= f2v{l_mu[k], l_mu[k]};
+    xv *= l_sc[k];                                                   // exact (power of two; the bound keeps it below 2^15)
+    const h2v h = __builtin_convertvector(xv, h2v);                  // round to nearest
+    f2v r = xv - __builtin_convertvector(h, f2v);                    // exact remainder
+    if constexpr (LOW11) r *= 2048.f;
+    const h2v l = __builtin_convertvector(r, h2v);
+    cH[k][p] = __builtin_bit_cast(unsigned, h);
+    cL[k][p] = __builtin_bit_cast(unsigned, l);
+  };
+  auto conv_write = [&](auto kc, int buf) {
+    constexpr int k = decltype(kc)::value;
+    img[buf][0][l_slot[k]] = cH[k];
+    img[buf][1][l_slot[k]] = cL[k];
+  };
+  __amdgpu_buffer_rsrc_t s_rs[NK];
+  auto open_slot = [&](auto kc, int b) {
+    constexpr int k = decltype(kc)::value;
+    const int rstep = k == 0 ? dy_rstep : x_rstep;
+    int left = span - 32 * b - 8 * s_rg[k];
+    left = left < 0 ? 0 : (left > 8 ? 8 : left);
+    const int extent = __builtin_amdgcn_readfirstlane(left * rstep);
+    s_rs[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s_cur[k]), 0, extent, 0x00020000);
+    s_cur[k] += 8 * rstep;
+  };
+  auto load_row = [&](auto sc, auto kc, auto jc) {
+    constexpr int set = decltype(sc)::value, k = decltype(kc)::value, j = decltype(jc)::value;
+    const int rstep = k == 0 ? dy_rstep : x_rstep;
+    raw[set][k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rs[k], l_voff[k] + j * rstep, 0, 0));
+  };
+  // Work dealt out behind MFMA m of a block: pair q of the conversion at m_pair(q), the reload of the two rows it freed right
+  // behind it (load L = 8k + j at m_pair(4k + j/2) + j % 2), the two LDS slots of a unit after its fourth pair.
+  auto behind_mfma = [&](auto sc, auto ic, auto mc, int b) {
+    constexpr int image = decltype(ic)::value, m = decltype(mc)::value;
+    wstatic_for<0, NPAIR>([&](auto qc) {
+      constexpr int q = decltype(qc)::value, k = q / 4, p = q % 4;
+      constexpr int mq = q * NM / NPAIR;
+      if constexpr (mq == m) {
+        conv_pair(sc, WIC<k>{}, WIC<p>{});
+        if constexpr (p == 3) conv_write(WIC<k>{}, image);
+      }
+      // (j = 2p reloads with its pair, j = 2p + 1 one MFMA later; the last slot's last row stays inside the block)
+      constexpr int m0 = mq, m1 = mq + 1 < NM ? mq + 1 : NM - 1;
+      if constexpr (m0 == m) {
+        if constexpr (p == 0) open_slot(WIC<k>{}, b);
+        load_row(sc, WIC<k>{}, WIC<2 * p>{});
+      }
+      if constexpr (m1 == m) load_row(sc, WIC<k>{}, WIC<2 * p + 1>{});
+    });
+  };
+#define SN_BLOCK_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+  auto multiply_block = [&](auto uc, int b) {
+    constexpr int u = decltype(uc)::value;             // b % lcm(2, SETS): block b = image b & 1, block n lives in set n % SETS
+    constexpr int buf = u & 1, set = (u + 1) % SETS;   // block b + 1 converts from its set while block b is multiplied
+    SN_BLOCK_BARRIER();
+    u4 A[2][2][2], B[2][CT][2];
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) A[st][a][p] = img[buf][p][fo + 2 * st * PL + 8 * (2 * ga + a)];
+#pragma unroll
+        for (int c = 0; c < CT; ++c) B[st][c][p] = img[buf][p][fo + 2 * st * PL + 32 + 8 * (CT * gb + c)];
+      }
+    // three products per step and tile, small terms first: (l, h), (h, l) -> the correction accumulator (LOW11) | the one
+    // accumulator; (h, h) last; tile-inner, so consecutive MFMAs never share an accumulator
+    wstatic_for<0, NM>([&](auto mc) {
+      constexpr int m = decltype(mc)::value, g = m / (2 * CT), st = g / 3, t = g % 3;
+      constexpr int a = (m % (2 * CT)) / CT, c = m % CT;
+      constexpr int pa = t == 0 ? 1 : 0, pb = t == 1 ? 1 : 0;
+      constexpr int n = (LOW11 && t < 2) ? 1 : 0;
+      acc[n][a][c] = mfma_f16(A[st][a][pa], B[st][c][pb], acc[n][a][c]);
+      behind_mfma(WIC<set>{}, WIC<buf ^ 1>{}, mc, b + 1 + SETS);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  if (nblocks > 0) {
+    wstatic_for<0, SETS>([&](auto sc) {
+      wstatic_for<0, NK>([&](auto kc) {
+        open_slot(kc, decltype(sc)::value);
+        wstatic_for<0, 8>([&](auto jc) { load_row(sc, kc, jc); });
+      });
+    });
+    wstatic_for<0, NM>([&](auto mc) { behind_mfma(WIC<0>{}, WIC<0>{}, mc, SETS); });      // block 0 -> image 0, block SETS requested
+    constexpr int U = (SETS % 2 == 0) ? SETS : 2 * SETS;                                    // lcm(2, SETS)
+    for (int b = 0; b < nblocks; b += U) {
+      wstatic_for<0, U>([&](auto uc) {
+        if (b + decltype(uc)::value < nblocks) multiply_block(uc, b + decltype(uc)::value);
+      });
+    }
+  }
+  if (colpart) {
+    __syncthreads();
+    float *sm = reinterpret_cast<float *>(&img[0][0][0]);
+    sm[s_rg[0] * 128 + 64 * (wave & 1) + lcol] = l_sum;
+    __syncthreads();
+    if (tid < 128) colpart[(int64_t)blockIdx.x * 128 + tid] = (sm[tid] + sm[128 + tid]) + (sm[256 + tid] + sm[384 + tid]);
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int jr = 32 * (2 * ga + a) + (e & 3) + 8 * (e >> 2) + 4 * kh;
+        float v = acc[0][a][c][e];
+        if constexpr (LOW11) v = __builtin_fmaf(acc[1][a][c][e], 1.f / 2048.f, v);
+        P[(int64_t)jr * C + 32 * (CT * gb + c) + i] = v * osc[c];
+      }
+#undef SN_BLOCK_BARRIER
+}
+
 }  // namespace
 
 extern "C" {
@@ -2661,10 +2913,29 @@ size_t sn_wgrad_workspace_bytes(int64_t rows, int32_t J, int32_t C) {
   return (size_t)wgrad_slabs(rows) * 128 * ((size_t)C + 1) * sizeof(float);      // tile partials + column-sum partials
 }
 
+// Bounds that let the weight gradient run on two fp16 pieces (wgrad_h_k): dybound[0] >= max |dy| (device), xinvstd[C] the
+// BatchNorm inverse standard deviations of x's columns about `center` (device), xfac >= sqrt(rows behind those statistics).
+struct WgradBounds {
+  const float *dybound;      // ndy floats: their maximum bounds |dy|
+  int ndy;
+  const float *xinvstd;
+  float xfac;
+};
+// SN_WGRAD_H: -1 never use wgrad_h_k; -2 (default) = 2; else bit 0 = LOW11 (second accumulator, low pieces x 2^11), bit 1 =
+// two blocks in flight instead of one — A/B switch
+inline int wgrad_h_mode() {
+  static const int v = [] {
+    const char *e = getenv("SN_WGRAD_H");
+    return e ? atoi(e) : -2;
+  }();
+  return v;
+}
+
 static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                         int32_t J, int32_t C, float *G, double *dysum, int64_t rows_per_seg, float *seg_dysum,
                         void *workspace, size_t workspace_bytes, void *stream, const int64_t *slab_off = nullptr,
-                        int32_t nslab_tab = 0, const int64_t *seg_slab_ptr = nullptr, int32_t nseg_tab = 0) {
+                        int32_t nslab_tab = 0, const int64_t *seg_slab_ptr = nullptr, int32_t nseg_tab = 0,
+                        const WgradBounds *bounds = nullptr) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldx < C) return SN_E_SHAPE;
   if (J > 128 || (J % 4) || (C != 128 && C != 256)) return SN_E_UNSUPPORTED;
@@ -2702,6 +2973,41 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
   const bool dma = uni && wgrad_variant() == 3 && !ragged && !segmented;      // (experimental kernel: plain slabs only)
   hipEvent_t t_start = nullptr, t_stop = nullptr;
   if (uni) sn_internal_timing_slot(0x400 | (segmented ? 1 : 0) | (ragged ? 2 : 0), rows, C, rows * 4 * ((int64_t)J + C), J, &t_start, &t_stop);
+  const bool half = uni && !dma && bounds && wgrad_h_mode() != -1;
+  if (bounds && ((bounds->ndy > 0 && !bounds->dybound) || bounds->ndy < 0 || !bounds->xinvstd || !(bounds->xfac > 0.f))) return SN_E_NULL;
+  if (half) {
+#define SN_WGH(CT_, L_, S_)                                                                                                            \
+  do {                                                                                                                                 \
+    if (t_start)                                                                                                                       \
+      hipExtLaunchKernelGGL((wgrad_h_k<CT_, L_, S_>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx,   \
+                            center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off, bounds->dybound, bounds->ndy, bounds->xinvstd, \
+                            bounds->xfac);                                                                                             \
+    else                                                                                                                               \
+      hipLaunchKernelGGL((wgrad_h_k<CT_, L_, S_>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J,    \
+                         (int)C, partial, colpart, sr, spm, slab_off, bounds->dybound, bounds->ndy, bounds->xinvstd, bounds->xfac);  \
+  } while (0)
+    // default: one accumulator, two blocks in flight.  Same box, us per launch incl. the reduction, 627 200 / 322 624 rows:
+    // C = 256: three-piece bf16 335 / 163; this kernel with one block in flight 212 / 111, two 199 / 106, second accumulator
+    // (one block: no registers for two) 222 / 123; C = 128: bf16 187 / 82; one block 152 / 87, two 126 / 74, three 137 / 78,
+    // second accumulator + two blocks 136 / 87.
+    int mode = wgrad_h_mode();
+    if (mode < 0) mode = 2;
+    const int low = mode & 1;
+    int sets = (mode >> 1) + 1;
+    if (sets > 2) sets = 2;
+    if (C == 256 && low) sets = 1;                     // (the second accumulator leaves no registers for a second block at C = 256)
+    const int sel = (C == 256 ? 4 : 0) + 2 * (sets - 1) + low;
+    switch (sel) {
+      case 0: SN_WGH(1, false, 1); break;
+      case 1: SN_WGH(1, true, 1); break;
+      case 2: SN_WGH(1, false, 2); break;
+      case 3: SN_WGH(1, true, 2); break;
+      case 4: SN_WGH(2, false, 1); break;
+      case 5: SN_WGH(2, true, 1); break;
+      default: SN_WGH(2, false, 2); break;
+    }
+#undef SN_WGH
+  } else
   if (dma && C == 128 && t_start)
     hipExtLaunchKernelGGL((wgrad_d_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
   else if (dma && t_start)
@@ -2766,6 +3072,46 @@ int sn_wgrad_slabs_f32(const float *dy, int64_t lddy, const float *x, int64_t ld
   if (!slab_off || !seg_slab_ptr) return SN_E_NULL;
   return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, 0, seg_dysum, workspace, workspace_bytes, stream, slab_off,
                       nslab, seg_slab_ptr, nseg);
+}
+
+// The same three products with bounds (see WgradBounds / wgrad_h_k): two fp16 pieces, half the matrix work.  dybound: one
+// float on the device, >= max |dy| over the operand (sn_absmax_* leave it); xinvstd: the BatchNorm inverse standard deviations
+// of x's columns about `center`, from statistics over stat_rows rows that include every row of x (the local rows, or the
+// global batch under synchronised statistics).  Results agree with the bf16 forms to fp32 rounding.
+static WgradBounds make_bounds(const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows) {
+  // |x - mean| <= sqrt(n·var) <= sqrt(n) / invstd; the factor 1.0625 covers the rounding of the statistics and of this product
+  return WgradBounds{dybound, (n_dybound < 0 || n_dybound > INT_MAX) ? -1 : (int)n_dybound, xinvstd,
+                     stat_rows > 0 ? sqrtf((float)stat_rows) * 1.0625f : 0.f};
+}
+int sn_wgrad_bounded_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                         int32_t J, int32_t C, float *G, double *dysum, void *workspace, size_t workspace_bytes,
+                         const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows, void *stream) {
+  (void)hipGetLastError();
+  if (stat_rows < rows) return SN_E_SHAPE;
+  const WgradBounds b = make_bounds(dybound, n_dybound, xinvstd, stat_rows);
+  return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, 0, nullptr, workspace, workspace_bytes, stream, nullptr, 0,
+                      nullptr, 0, &b);
+}
+int sn_wgrad_seg_bounded_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                             int64_t rows_per_seg, int32_t J, int32_t C, float *G, double *dysum, float *seg_dysum,
+                             void *workspace, size_t workspace_bytes, const float *dybound, int64_t n_dybound,
+                             const float *xinvstd, int64_t stat_rows, void *stream) {
+  (void)hipGetLastError();
+  if (rows_per_seg < 1 || stat_rows < rows) return SN_E_SHAPE;
+  const WgradBounds b = make_bounds(dybound, n_dybound, xinvstd, stat_rows);
+  return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, rows_per_seg, seg_dysum, workspace, workspace_bytes, stream,
+                      nullptr, 0, nullptr, 0, &b);
+}
+int sn_wgrad_slabs_bounded_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
+                               const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg, int32_t J,
+                               int32_t C, float *G, double *dysum, float *seg_dysum, void *workspace, size_t workspace_bytes,
+                               const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows, void *stream) {
+  (void)hipGetLastError();
+  if (!slab_off || !seg_slab_ptr) return SN_E_NULL;
+  if (stat_rows < rows) return SN_E_SHAPE;
+  const WgradBounds b = make_bounds(dybound, n_dybound, xinvstd, stat_rows);
+  return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, 0, seg_dysum, workspace, workspace_bytes, stream, slab_off,
+                      nslab, seg_slab_ptr, nseg, &b);
 }
 
 static int thin_blocks(int64_t rows, int J) {

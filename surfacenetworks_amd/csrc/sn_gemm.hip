@@ -75,7 +75,12 @@ struct EpiArgs {
   // place of `period` (then 0) for the per-mesh vectors.  NULL: equal meshes of `period` rows.
   const int64_t *segoff;
   int nseg;
+  // input gradient through the activation: absmax[blockIdx.x] <- max |gact| over the rows this workgroup wrote (entries from
+  // the grid's size up to kAbsmaxBlocks are zeroed) — the bound the two-piece weight gradient of the layer BELOW needs for its
+  // dy operand (sn_wgrad_bounded_f32).  NULL: not wanted.
+  float *absmax;
 };
+constexpr int kAbsmaxBlocks = 512;      // >= the largest grid of any input-gradient launch (2 workgroups per CU)
 
 template <int K, int NT, bool TRANSW, int EPI>
 __global__ __launch_bounds__(kWG, 1) void gemm_rows_k(const float *__restrict__ In, int64_t ldi,
@@ -420,6 +425,7 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
   __shared__ __attribute__((aligned(16))) unsigned char img[2][PC][PART];
   __shared__ __attribute__((aligned(16))) unsigned char stg[WV][32 * SROW];
   __shared__ float s_rs[2][32];                         // H2: inverse row scales of the tile held by each image
+  __shared__ float s_amax[WV];                          // dgrad+elu: per-wave max |gact| (EpiArgs::absmax)
   __shared__ __attribute__((aligned(16))) float s_cs[NOUT];          // H2: inverse column scales of the weights
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = lane & 31, h = lane >> 5;
@@ -492,8 +498,12 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
     if constexpr (STATS)
       if (ep.stats)                                                                  // a workgroup without tiles adds nothing
         for (int64_t b = blockIdx.x; b < ep.stats_blocks; b += gridDim.x) ep.stats[b * 256 + threadIdx.x] = 0.0;
+    if constexpr (EPI == EPI_DGRAD_ELU)
+      if (ep.absmax && threadIdx.x == 0)
+        for (int b = blockIdx.x; b < kAbsmaxBlocks; b += gridDim.x) ep.absmax[b] = 0.f;
     return;
   }
+  float amax = 0.f;                                     // dgrad+elu: max |gact| over my share of the stored rows
   double ssum[STATS ? 4 : 1], ssq[STATS ? 4 : 1];
 #pragma unroll
   for (int i = 0; i < (STATS ? 4 : 1); ++i) ssum[i] = ssq[i] = 0.0;
@@ -780,6 +790,9 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
                  __builtin_fmaf(v.z, fminf(o.z, 0.f), v.z), __builtin_fmaf(v.w, fminf(o.w, 0.f), v.w)};
           v += ga[j];                    // (no such operand: the empty window read zeros)
           bst4(r_o2, vo_o2 + j * js_o2, v);
+          // (rows past the matrix's end are computed — from zeros — but not stored: they must not enter the bound)
+          const float m4 = fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w)));
+          amax = (erow + RPI * j < nrt) ? fmaxf(amax, m4) : amax;
         }
       } else {
 #pragma unroll
@@ -817,6 +830,25 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
     if (++tile >= tend) break;
     do_tile(IC<1>{}, tile);
     if (++tile >= tend) break;
+  }
+  if constexpr (EPI == EPI_DGRAD_ELU) {
+    if (ep.absmax) {                       // workgroup maximum of |gact| (non-negative floats order like their bit patterns)
+      unsigned mb = __float_as_uint(amax);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)mb, o);
+        mb = other > mb ? other : mb;
+      }
+      if (lane == 0) s_amax[wave] = __uint_as_float(mb);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float m = s_amax[0];
+#pragma unroll
+        for (int w = 1; w < WV; ++w) m = fmaxf(m, s_amax[w]);
+        ep.absmax[blockIdx.x] = m;
+        for (int b = blockIdx.x + gridDim.x; b < kAbsmaxBlocks; b += gridDim.x) ep.absmax[b] = 0.f;
+      }
+    }
   }
   if constexpr (STATS) {
     if (ep.stats) {
@@ -925,7 +957,7 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
     return SN_E_ALIGN;
   if (elu_stats_part && (!y_elu || gemm_variant() == 0)) return SN_E_UNSUPPORTED;
   EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr, elu_stats_part,
-             sn_linear_fwd_stats_blocks(rows), (int)J, nullptr, 0};
+             sn_linear_fwd_stats_blocks(rows), (int)J, nullptr, 0, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const bool x3 = gemm_variant() != 0;
@@ -967,7 +999,7 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx) || (lddy % 4) || (ldw % 4) || (lddx % 4)) return SN_E_ALIGN;
   if (B && (!aligned16(x) || !aligned16(B) || !aligned16(Cc) || (center && !aligned16(center)) || (ldx % 4) || ldx < C))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0};
+  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   const bool x3 = gemm_variant() != 0;
@@ -988,22 +1020,36 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   return launch_status();
 }
 
+int32_t sn_linear_dgrad_absmax_blocks(void) { return kAbsmaxBlocks; }
+
 int sn_linear_dgrad_elu_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
                             const float *center, const float *B, const float *Cc, float *dx_hi, int64_t lddx, float *gact,
                             int64_t ldga, const float *gadd, int64_t ldgadd, int64_t rows, int32_t J, int32_t C,
                             void *stream) {
+  return sn_linear_dgrad_elu_absmax_f32(dy, lddy, W, ldw, x, ldx, center, B, Cc, dx_hi, lddx, gact, ldga, gadd, ldgadd, rows, J, C,
+                                        nullptr, stream);
+}
+
+int sn_linear_dgrad_elu_absmax_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                                   const float *center, const float *B, const float *Cc, float *dx_hi, int64_t lddx, float *gact,
+                                   int64_t ldga, const float *gadd, int64_t ldgadd, int64_t rows, int32_t J, int32_t C,
+                                   float *gact_absmax, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 2 || lddy < J || ldw < C || lddx < C / 2 || ldga < C / 2 || ldx < C) return SN_E_SHAPE;
   if (J > 128 || (J % 4) || (C != 128 && C != 256) || gemm_variant() == 0 || !ld32(lddy, ldx, lddx, ldga, ldgadd))
     return SN_E_UNSUPPORTED;
-  if (rows == 0) return SN_OK;
+  if (rows == 0) {                     // nothing to launch; the bound of an empty operand is 0
+    if (gact_absmax && hipMemsetAsync(gact_absmax, 0, kAbsmaxBlocks * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
+      return (int)hipGetLastError();
+    return SN_OK;
+  }
   if (!dy || !W || !dx_hi || !gact || !x || !B || !Cc) return SN_E_NULL;
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx_hi) || !aligned16(gact) || !aligned16(x) || !aligned16(B) ||
       !aligned16(Cc) || (center && !aligned16(center)) || (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C / 2)) ||
       (lddy % 4) || (ldw % 4) || (lddx % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   const int half = C / 2;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, gact_absmax};
   float *out = dx_hi - half;           // the kernel indexes absolute columns; only columns >= half are written through `out`
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
@@ -1037,7 +1083,7 @@ static int fwd_segbias_launch(const float *x, int64_t ldx, const float *W, int64
     return SN_E_ALIGN;
   if (elu_stats_part && !y_elu) return SN_E_UNSUPPORTED;
   EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, segoff ? 0 : rows_per_seg, J, nullptr,
-             elu_stats_part, sn_linear_fwd_stats_blocks(rows), (int)J, segoff, nseg};
+             elu_stats_part, sn_linear_fwd_stats_blocks(rows), (int)J, segoff, nseg, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   hipEvent_t t_start = nullptr, t_stop = nullptr;
@@ -1077,7 +1123,7 @@ static int dgrad_eluseg_launch(const float *dy, int64_t lddy, const float *W, in
                                const float *center, const float *B, const float *Cc, const float *segvec,
                                int64_t rows_per_seg, const int64_t *segoff, int32_t nseg, const float *rowmask, float *gact,
                                int64_t ldga, const float *gadd, int64_t ldgadd, int64_t rows, int32_t J, int32_t C,
-                               void *stream) {
+                               void *stream, float *gact_absmax = nullptr) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldw < C || ldga < C || ldx < C || (segvec && !segoff && rows_per_seg < 1) ||
       (segoff && (nseg < 1 || !segvec)))
@@ -1085,14 +1131,18 @@ static int dgrad_eluseg_launch(const float *dy, int64_t lddy, const float *W, in
   if (J > 128 || (J % 4) || (C != 128 && C != 256) || gemm_variant() == 0 || !ld32(lddy, ldx, ldga, ldgadd) ||
       (segvec && !segoff && (rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL)))
     return SN_E_UNSUPPORTED;
-  if (rows == 0) return SN_OK;
+  if (rows == 0) {                     // nothing to launch; the bound of an empty operand is 0
+    if (gact_absmax && hipMemsetAsync(gact_absmax, 0, kAbsmaxBlocks * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
+      return (int)hipGetLastError();
+    return SN_OK;
+  }
   if (!dy || !W || !gact || !x || !B || !Cc || (rowmask && !segvec)) return SN_E_NULL;      // segvec may be NULL: no per-mesh vector
   if (!aligned16(dy) || !aligned16(W) || !aligned16(gact) || !aligned16(x) || !aligned16(B) || !aligned16(Cc) ||
       (segvec && !aligned16(segvec)) || (center && !aligned16(center)) ||
       (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C)) || (lddy % 4) || (ldw % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, (segvec && !segoff) ? rows_per_seg : 0, C, rowmask,
-             nullptr, 0, (int)J, segoff, nseg};
+             nullptr, 0, (int)J, segoff, nseg, gact_absmax};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   hipEvent_t t_start = nullptr, t_stop = nullptr;
@@ -1113,6 +1163,24 @@ int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, in
                                int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream) {
   return dgrad_eluseg_launch(dy, lddy, W, ldw, x, ldx, center, B, Cc, segvec, rows_per_seg, nullptr, 0, rowmask, gact, ldga, gadd,
                              ldgadd, rows, J, C, stream);
+}
+
+int sn_linear_dgrad_eluseg_absmax_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                                      const float *center, const float *B, const float *Cc, const float *segvec,
+                                      int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,
+                                      int64_t ldgadd, int64_t rows, int32_t J, int32_t C, float *gact_absmax, void *stream) {
+  return dgrad_eluseg_launch(dy, lddy, W, ldw, x, ldx, center, B, Cc, segvec, rows_per_seg, nullptr, 0, rowmask, gact, ldga, gadd,
+                             ldgadd, rows, J, C, stream, gact_absmax);
+}
+
+int sn_linear_dgrad_eluseg_ragged_absmax_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
+                                             const float *center, const float *B, const float *Cc, const float *segvec,
+                                             const int64_t *segoff, int32_t nseg, float *gact, int64_t ldga, const float *gadd,
+                                             int64_t ldgadd, int64_t rows, int32_t J, int32_t C, float *gact_absmax,
+                                             void *stream) {
+  if (!segoff) return SN_E_NULL;
+  return dgrad_eluseg_launch(dy, lddy, W, ldw, x, ldx, center, B, Cc, segvec, 0, segoff, nseg, nullptr, gact, ldga, gadd, ldgadd,
+                             rows, J, C, stream, gact_absmax);
 }
 
 int sn_linear_dgrad_eluseg_ragged_f32(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,

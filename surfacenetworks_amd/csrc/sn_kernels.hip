@@ -134,7 +134,11 @@ struct SpmmEpi {
   int64_t lde;
   const float *g;
   int64_t ldg;
+  float *absmax = nullptr;      // (quaternion-packed kernel) [gridDim.x]: max |Y| over the rows of each workgroup — sn_spmm_q3_elubwd_absmax_f32
 };
+__device__ __forceinline__ f4 fabs4(const f4 &a) {
+  return f4{__builtin_fabsf(a.x), __builtin_fabsf(a.y), __builtin_fabsf(a.z), __builtin_fabsf(a.w)};
+}
 __device__ __forceinline__ f4 elu_bwd4(const f4 &a, const f4 &o) {
   return f4{a.x * (o.x > 0.f ? 1.f : o.x + 1.f), a.y * (o.y > 0.f ? 1.f : o.y + 1.f), a.z * (o.z > 0.f ? 1.f : o.z + 1.f),
             a.w * (o.w > 0.f ? 1.f : o.w + 1.f)};
@@ -595,7 +599,8 @@ __device__ __forceinline__ void spmm_q3_lds_body(const int *__restrict__ b_rowpt
   const float *xb = X + sub * 4;
   f4 *sv = s_blk[wave];
   const int r0 = (my_chunk(nchunks) * WAVES + wave) * RPW;    // first block row of this wave
-  if constexpr (!STATS) {
+  const bool stays = STATS || (EPI && epi.absmax != nullptr);  // the workgroup meets again after the product (uniform)
+  if (!stays) {
     if (r0 >= Mb) return;                                     // wave-uniform
   }
   const int br = r0 + grp;
@@ -603,7 +608,7 @@ __device__ __forceinline__ void spmm_q3_lds_body(const int *__restrict__ b_rowpt
   const int kb = b_rowptr[brc];
   const int ke = b_rowptr[brc + 1 <= Mb ? brc + 1 : Mb];
   const int k0 = __builtin_amdgcn_readfirstlane(kb);
-  const int k1 = (STATS && r0 >= Mb) ? k0 : __builtin_amdgcn_readlane(ke, 63);   // (a wave past the end has no blocks)
+  const int k1 = (stays && r0 >= Mb) ? k0 : __builtin_amdgcn_readlane(ke, 63);   // (a wave past the end has no blocks)
   f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
   for (int t0 = k0; t0 < k1; t0 += TILE) {
     const int nt = (k1 - t0) < TILE ? (k1 - t0) : TILE;
@@ -649,6 +654,31 @@ __device__ __forceinline__ void spmm_q3_lds_body(const int *__restrict__ b_rowpt
     st4_stream(yp + ys, acc1);
     st4_stream(yp + 2 * ys, acc2);
     st4_stream(yp + 3 * ys, acc3);
+  }
+  if constexpr (EPI) {
+    if (epi.absmax) {                 // max |Y| over this workgroup's rows (non-negative floats order like their bit patterns)
+      __shared__ float s_am[WAVES];
+      float m = 0.f;
+      if (br < Mb) {
+        const f4 a = fabs4(acc0), b = fabs4(acc1), c = fabs4(acc2), d = fabs4(acc3);
+        m = fmaxf(fmaxf(fmaxf(fmaxf(a.x, a.y), fmaxf(a.z, a.w)), fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w))),
+                  fmaxf(fmaxf(fmaxf(c.x, c.y), fmaxf(c.z, c.w)), fmaxf(fmaxf(d.x, d.y), fmaxf(d.z, d.w))));
+      }
+      unsigned mb = __float_as_uint(m);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned other = (unsigned)__shfl_xor((int)mb, o);
+        mb = other > mb ? other : mb;
+      }
+      if (lane == 0) s_am[wave] = __uint_as_float(mb);
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        float t = s_am[0];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) t = fmaxf(t, s_am[w]);
+        epi.absmax[blockIdx.x] = t;
+      }
+    }
   }
   if constexpr (STATS) {
     static_assert((N == 32 || N == 16) && YG == 4 && !EPI, "statistics: 128- or 64-channel rows in the group-4 layout");
@@ -2548,6 +2578,21 @@ int sn_spmm_q3_elubwd_f32(const int32_t *b_rowptr, const float *q_blk, int64_t M
                           const float *G, int64_t ldg, float *Y, int64_t ldy, int32_t y_group, void *stream) {
   if (!E) return SN_E_NULL;
   return spmm_q3_launch(b_rowptr, q_blk, Mb, Kb, nblocks, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{E, lde, G, ldg}, stream);
+}
+
+int64_t sn_spmm_q3_absmax_blocks(int64_t Mb, int32_t N) {
+  if (Mb < 1 || !(N == 16 || N == 32 || N == 64 || N == 128)) return 0;
+  const int rpb = kWG / (N / 4);
+  return (int64_t)chunk_grid((Mb + rpb - 1) / rpb);
+}
+
+int sn_spmm_q3_elubwd_absmax_f32(const int32_t *b_rowptr, const float *q_blk, int64_t Mb, int64_t Kb, int64_t nblocks,
+                                 const float *X, int64_t ldx, int32_t x_group, int32_t N, const float *E, int64_t lde,
+                                 const float *G, int64_t ldg, float *Y, int64_t ldy, int32_t y_group, float *y_absmax,
+                                 void *stream) {
+  if (!E) return SN_E_NULL;
+  return spmm_q3_launch(b_rowptr, q_blk, Mb, Kb, nblocks, X, ldx, x_group, N, Y, ldy, y_group, SpmmEpi{E, lde, G, ldg, y_absmax},
+                        stream);
 }
 
 int sn_bsr4_to_q3_f32(const int32_t *b_colind, const float *b_vals, int64_t nblocks, float *q_blk, int32_t *not_quaternion,

@@ -157,7 +157,9 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
         if q is not None:
             if stats and e is None and kernels.spmm_q3_stats_supported(y.shape[1] // group, group):
                 return kernels.spmm_q3_stats(q[0], q[1], M // 4, K // 4, x, y, group)
-            kernels.spmm_q3(q[0], q[1], M // 4, K // 4, x, y, group, e, g)
+            am = kernels.spmm_q3(q[0], q[1], M // 4, K // 4, x, y, group, e, g, want_absmax=e is not None and kernels.absmax_wanted())
+            if am is not None:
+                kernels.note_absmax(y, am)           # a fused ELU-backward product writes a gradient: the dy of the layer below
             return None
     b = op.bsr4() if (_DIRAC_FORMAT != "csr" and group == 4 and vec) else None
     if b is not None:
@@ -500,7 +502,19 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     return y, (x, W, Wf, s, mean, invstd, beta, training, b is not None, rows_g)
 
 
-def _centered_wgrad(dy, x, mean):
+def _dy_bounds(dy, invstd, rows_g, training):
+    """Bounds for the two-piece weight gradient (kernels.wgrad(bounds=...)): the maxima the producer of dy left for it, BatchNorm's
+    inverse standard deviations of the operand's columns and the row count behind them — or None (eval-mode BatchNorm has no
+    batch statistics; dy from a kernel that leaves no maxima): then the three-piece bf16 form runs."""
+    if not training or not kernels.absmax_wanted():
+        return None
+    am = kernels.take_absmax(dy)
+    if am is None:
+        return None
+    return am, invstd, rows_g
+
+
+def _centered_wgrad(dy, x, mean, bounds=None):
     """G = dyᵀ·(x - mean) and colsum(dy) (fp64 statistics layout of kernels.wgrad).  Widths the split-K kernel takes go to it
     directly.  A 64-wide x (the classifier head of the Mesh-MNIST models, mesh_mnist/models.py: bn_conv2) is read as rows/2
     rows of 128 — two consecutive rows side by side, dy likewise — so the same kernel applies: the product of the paired
@@ -509,9 +523,12 @@ def _centered_wgrad(dy, x, mean):
     rows, C = x.shape
     J = dy.shape[1]
     if kernels.wgrad_supported(J, C):
-        return kernels.wgrad(dy, x, mean, want_colsum=True)       # colsum(dy) rides on the same pass over dy
+        return kernels.wgrad(dy, x, mean, want_colsum=True, bounds=bounds)       # colsum(dy) rides on the same pass over dy
     if C == 64 and rows % 2 == 0 and rows > 0 and x.is_contiguous() and dy.is_contiguous() and kernels.wgrad_supported(2 * J, 2 * C):
-        G2, s2 = kernels.wgrad(dy.view(rows // 2, 2 * J), x.view(rows // 2, 2 * C), torch.cat([mean, mean]), want_colsum=True)
+        if bounds is not None:
+            bounds = (bounds[0], torch.cat([bounds[1], bounds[1]]), bounds[2])
+        G2, s2 = kernels.wgrad(dy.view(rows // 2, 2 * J), x.view(rows // 2, 2 * C), torch.cat([mean, mean]), want_colsum=True,
+                               bounds=bounds)
         return G2[:J, :C] + G2[J:, C:], s2[:J] + s2[J:]
     return dy.t().mm(x - mean), kernels.colstats(dy)
 
@@ -529,7 +546,7 @@ def bnlin_backward(state, dy, need_dx=True, through_elu=None):
     rows, C = x.shape
     J = dy.shape[1]
     # centring inside the kernel leaves no fp32 cancellation against mean·colsum(dy)
-    Gc, sdy = _centered_wgrad(dy, x, mean)
+    Gc, sdy = _centered_wgrad(dy, x, mean, _dy_bounds(dy, invstd, rows_g, training))
     scale = 1.0
     if training:
         Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
@@ -598,7 +615,8 @@ def bnlin_backward_zero_first(state, dy):
     dy = dy.contiguous()
     rows, C = p.shape
     J = dy.shape[1]
-    G2, sdy = kernels.wgrad(dy, p, mean[C:], want_colsum=True)
+    b2 = _dy_bounds(dy, invstd[C:], rows_g, training)
+    G2, sdy = kernels.wgrad(dy, p, mean[C:], want_colsum=True, bounds=b2)
     # zero half: x - mean = -mean there, i.e. G[:, :C] = -colsum(dy) (x) mean[:C] — zero with batch statistics (mean = 0),
     # the running mean in eval mode
     G1 = torch.zeros_like(G2) if training else -(sdy.to(torch.float32)[:, None] * mean[None, :C])
@@ -620,7 +638,7 @@ def bnlin_backward_elu_input(state, dy):
     x, W, Wf, s, mean, invstd, beta, training, has_bias, rows_g = state
     dy = dy.contiguous()
     J, C = dy.shape[1], x.shape[1]
-    Gc, sdy = _centered_wgrad(dy, x, mean)
+    Gc, sdy = _centered_wgrad(dy, x, mean, _dy_bounds(dy, invstd, rows_g, training))
     scale = 1.0
     if training:
         Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
@@ -664,7 +682,7 @@ def avg_stage_backward(state, mask_rows, inv_count, nseg, per, dy, gadd):
     e, m, W, Wf, s, mean, invstd, beta, has_bias, rows_g = state
     dy = dy.contiguous()
     rows, C = e.shape
-    G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per)          # per-mesh column sums of dy from the same pass
+    G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per, bounds=_dy_bounds(dy, invstd[:C], rows_g, True))   # per-mesh column sums of dy from the same pass
     Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
     Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
     dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
@@ -703,7 +721,7 @@ def avg_stage_backward_ragged(state, seg, dy, gadd):
     e, m, W, Wf, s, mean, invstd, beta, has_bias, rows_g = state
     dy = dy.contiguous()
     rows, C = e.shape
-    G1, sdy, Sg = kernels.wgrad_slabs(dy, e, mean[:C], seg)
+    G1, sdy, Sg = kernels.wgrad_slabs(dy, e, mean[:C], seg, bounds=_dy_bounds(dy, invstd[:C], rows_g, True))
     Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
     Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
     dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)

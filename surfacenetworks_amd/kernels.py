@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 __all__ = [
-    "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "spmm_ring", "spmm_ring_stats", "spmm_ring_supported", "ring_half_window", "csr_band", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged", "validate_csr",
+    "note_absmax", "take_absmax", "absmax_wanted", "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "spmm_ring", "spmm_ring_stats", "spmm_ring_supported", "ring_half_window", "csr_band", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged", "validate_csr",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
@@ -242,8 +242,9 @@ def spmm_bsr4_elubwd(b_rowptr, b_colind, b_vals, Mb: int, Kb: int, x, e, g, y, g
               _p(x), ldx, group, N, _p(e), lde, _p(g), ldg, _p(y), ldy, group, _stream())
 
 
-def spmm_q3(b_rowptr, q_blk, Mb: int, Kb: int, x, y, group: int = 1, e=None, g=None) -> None:
-    """y <- A·x for a quaternion-packed Dirac operator (sn_spmm_q3_f32); with e: (A·x) * elu'(e) + g (sn_spmm_q3_elubwd_f32)."""
+def spmm_q3(b_rowptr, q_blk, Mb: int, Kb: int, x, y, group: int = 1, e=None, g=None, want_absmax: bool = False):
+    """y <- A·x for a quaternion-packed Dirac operator (sn_spmm_q3_f32); with e: (A·x) * elu'(e) + g (sn_spmm_q3_elubwd_f32).
+    want_absmax (with e): also returns the per-workgroup maxima of |y| (sn_spmm_q3_elubwd_absmax_f32), else None."""
     _dev(b_rowptr, q_blk, x, y, e, g)
     N = y.shape[1] // group
     ldx = _check_dense(x, 4 * Kb, group, N, "x")
@@ -254,8 +255,14 @@ def spmm_q3(b_rowptr, q_blk, Mb: int, Kb: int, x, y, group: int = 1, e=None, g=N
     else:
         lde = _check_dense(e, 4 * Mb, group, N, "e")
         ldg = _check_dense(g, 4 * Mb, group, N, "g") if g is not None else 0
+        if want_absmax and Mb > 0:
+            am = torch.empty(int(_lib.load().sn_spmm_q3_absmax_blocks(Mb, N)), dtype=torch.float32, device=y.device)
+            _lib.call("sn_spmm_q3_elubwd_absmax_f32", _p(b_rowptr), _p(q_blk), Mb, Kb, nblk, _p(x), ldx, group, N, _p(e), lde, _p(g),
+                      ldg, _p(y), ldy, group, _p(am), _stream())
+            return am
         _lib.call("sn_spmm_q3_elubwd_f32", _p(b_rowptr), _p(q_blk), Mb, Kb, nblk, _p(x), ldx, group, N, _p(e), lde, _p(g), ldg,
                   _p(y), ldy, group, _stream())
+    return None
 
 
 def spmm_q3_stats_supported(N: int, group: int) -> bool:
@@ -406,9 +413,63 @@ def wgrad_supported(J: int, C: int) -> bool:
     return C in (128, 256) and J <= 128 and J % 4 == 0
 
 
-def wgrad(dy, x, center=None, want_colsum: bool = False):
-    """G = dy^T · (x - center) (J x C, fp32) for tall-skinny operands on the fp32 MFMA; see sn_wgrad_f32.
-    want_colsum: also return colsum(dy) as a (J,) float64 tensor, accumulated by the same pass."""
+# ---- bounds of gradient tensors (max |dy|) for the two-piece weight gradient ------------------------------------------------
+# A kernel that PRODUCES a gradient tensor (the input-gradient GEMM through the activation, the transposed quaternion product
+# with the fused ELU backward) also leaves the per-workgroup maxima of what it wrote; the weight gradient of the layer below
+# reads that tensor as its dy operand and needs the bound before its first row (sn_wgrad_*_bounded_f32).  Between the two
+# lie autograd's view nodes (a block returns (rows, C), the next one receives (B, V, C).reshape(...): new tensor objects, same
+# memory), so the bound travels in a small table keyed by the data pointer.  An entry holds a strong reference to the tensor it
+# describes — its memory cannot be handed to another tensor while the entry lives — and the tensor's version counter (an
+# in-place edit invalidates it); only the last few entries are kept (a gradient is consumed within a few launches).
+_ABSMAX_KEEP = 8
+_absmax_table = {}          # data_ptr -> (tensor, version, maxima)
+_absmax_enabled = __import__("os").environ.get("SN_WGRAD_H", "-2") != "-1" and __import__("os").environ.get("SN_GEMM_VARIANT", "2") != "0" \
+    and __import__("os").environ.get("SN_WGRAD_VARIANT", "2") == "2"
+
+
+def absmax_wanted() -> bool:
+    return _absmax_enabled
+
+
+def note_absmax(t, maxima) -> None:
+    """Record that max |t| <= max(maxima) (a device tensor of per-workgroup maxima left by the kernel that wrote t)."""
+    if maxima is None:
+        return
+    if len(_absmax_table) >= _ABSMAX_KEEP:
+        for k in list(_absmax_table)[: len(_absmax_table) - _ABSMAX_KEEP + 1]:      # dicts keep insertion order: oldest first
+            del _absmax_table[k]
+    _absmax_table.pop(t.data_ptr(), None)
+    _absmax_table[t.data_ptr()] = (t, t._version if not t.is_inference() else None, maxima)
+
+
+def take_absmax(t):
+    """The maxima recorded for exactly this memory (same first element, element count and contents), or None."""
+    ent = _absmax_table.pop(t.data_ptr(), None)
+    if ent is None:
+        return None
+    src, version, maxima = ent
+    if src.numel() != t.numel() or not t.is_contiguous() or src.dtype != t.dtype or \
+            (version is not None and src._version != version):
+        return None
+    return maxima
+
+
+def _bounds_args(bounds, C: int):
+    """(dybound (n,) fp32, invstd (C,) fp32, stat_rows) -> the trailing arguments of the sn_wgrad_*_bounded_f32 calls."""
+    dyb, invstd, stat_rows = bounds
+    _dev(dyb, invstd)
+    if dyb.dtype != torch.float32 or not dyb.is_contiguous() or invstd.dtype != torch.float32 or invstd.numel() != C or \
+            not invstd.is_contiguous():
+        raise ValueError("wgrad bounds: fp32 maxima of |dy| (contiguous) and the (C,) fp32 inverse standard deviations of x")
+    return _p(dyb), int(dyb.numel()), _p(invstd), int(stat_rows)
+
+
+def wgrad(dy, x, center=None, want_colsum: bool = False, bounds=None):
+    """G = dy^T · (x - center) (J x C, fp32) for tall-skinny operands on the 16-bit matrix pipe (exact splits); see sn_wgrad_f32.
+    want_colsum: also return colsum(dy) as a (J,) float64 tensor, accumulated by the same pass.
+    bounds = (dybound, invstd, stat_rows): an upper bound of max |dy| (device, one float), BatchNorm's inverse standard
+    deviations of x's columns about `center` and the row count behind them — the product then runs on two fp16 pieces
+    (sn_wgrad_bounded_f32: half the matrix work of the three-piece bf16 form)."""
     _dev(dy, x, center)
     rows, J = dy.shape
     C = x.shape[1]
@@ -418,8 +479,12 @@ def wgrad(dy, x, center=None, want_colsum: bool = False):
     dysum = torch.empty(J, dtype=torch.float64, device=x.device) if want_colsum else None
     ws_bytes = int(_lib.load().sn_wgrad_workspace_bytes(rows, J, C))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-    _lib.call("sn_wgrad_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, J, C, _p(G), _p(dysum), _p(ws), ws_bytes,
-              _stream())
+    if bounds is not None:
+        _lib.call("sn_wgrad_bounded_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, J, C, _p(G), _p(dysum), _p(ws), ws_bytes,
+                  *_bounds_args(bounds, C), _stream())
+    else:
+        _lib.call("sn_wgrad_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, J, C, _p(G), _p(dysum), _p(ws), ws_bytes,
+                  _stream())
     return (G, dysum) if want_colsum else G
 
 
@@ -777,9 +842,18 @@ def linear_dgrad_elu(dy, W, x, center, B, Cc, gadd=None):
     h = C // 2
     dx_hi = torch.empty((rows, h), dtype=torch.float32, device=dy.device)
     gact = torch.empty((rows, h), dtype=torch.float32, device=dy.device)
-    _lib.call("sn_linear_dgrad_elu_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x), _p(center), _p(B), _p(Cc),
-              _p(dx_hi), h, _p(gact), h, _p(gadd), _ld(gadd) if gadd is not None else 0, rows, J, C, _stream())
+    am = _new_dgrad_absmax(dy.device)
+    _lib.call("sn_linear_dgrad_elu_absmax_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x), _p(center), _p(B), _p(Cc),
+              _p(dx_hi), h, _p(gact), h, _p(gadd), _ld(gadd) if gadd is not None else 0, rows, J, C, _p(am), _stream())
+    note_absmax(gact, am)                # gact is the dy operand of the layer below
     return dx_hi, gact
+
+
+def _new_dgrad_absmax(device):
+    """Buffer for the per-workgroup maxima an input-gradient launch leaves (None when the two-piece weight gradient is off)."""
+    if not _absmax_enabled:
+        return None
+    return torch.empty(int(_lib.load().sn_linear_dgrad_absmax_blocks()), dtype=torch.float32, device=device)
 
 
 def linear_dgrad(dy, W, x=None, center=None, B=None, Cc=None):
@@ -852,8 +926,8 @@ def avg_bwd_segvec(seg_dy, Wf2, m, mu2, B2, C2, inv_count, rows_per_seg: int):
     return out
 
 
-def wgrad_seg(dy, x, center, rows_per_seg: int):
-    """(G, colsum(dy) fp64, per-mesh colsum(dy) (nseg, J) fp32) in one pass (sn_wgrad_seg_f32)."""
+def wgrad_seg(dy, x, center, rows_per_seg: int, bounds=None):
+    """(G, colsum(dy) fp64, per-mesh colsum(dy) (nseg, J) fp32) in one pass (sn_wgrad_seg_f32; bounds: as kernels.wgrad)."""
     _dev(dy, x, center)
     rows, J = dy.shape
     C = x.shape[1]
@@ -864,12 +938,16 @@ def wgrad_seg(dy, x, center, rows_per_seg: int):
     seg = torch.empty((nseg, J), dtype=torch.float32, device=dev)
     ws_bytes = int(_lib.load().sn_wgrad_seg_workspace_bytes(rows, rows_per_seg, J, C))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-    _lib.call("sn_wgrad_seg_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, rows_per_seg, J, C, _p(G), _p(dysum), _p(seg),
-              _p(ws), ws_bytes, _stream())
+    if bounds is not None:
+        _lib.call("sn_wgrad_seg_bounded_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, rows_per_seg, J, C, _p(G), _p(dysum),
+                  _p(seg), _p(ws), ws_bytes, *_bounds_args(bounds, C), _stream())
+    else:
+        _lib.call("sn_wgrad_seg_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, rows_per_seg, J, C, _p(G), _p(dysum), _p(seg),
+                  _p(ws), ws_bytes, _stream())
     return G, dysum, seg
 
 
-def wgrad_slabs(dy, x, center, seg):
+def wgrad_slabs(dy, x, center, seg, bounds=None):
     """wgrad_seg for RAGGED meshes (`seg`: operators.PackedSegments): (G, colsum(dy) fp64, per-mesh colsum(dy) (nseg, J))
     from one pass, the row slabs taken from seg's table (sn_wgrad_slabs_f32)."""
     _dev(dy, x, center)
@@ -881,8 +959,13 @@ def wgrad_slabs(dy, x, center, seg):
     segsum = torch.empty((seg.nseg, J), dtype=torch.float32, device=dev)
     ws_bytes = seg.nslab * 128 * (C + 1) * 4
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _lib.call("sn_wgrad_slabs_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, _p(seg.slab_off), seg.nslab,
-              _p(seg.seg_slab_ptr), seg.nseg, J, C, _p(G), _p(dysum), _p(segsum), _p(ws), ws_bytes, _stream())
+    if bounds is not None:
+        _lib.call("sn_wgrad_slabs_bounded_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, _p(seg.slab_off), seg.nslab,
+                  _p(seg.seg_slab_ptr), seg.nseg, J, C, _p(G), _p(dysum), _p(segsum), _p(ws), ws_bytes, *_bounds_args(bounds, C),
+                  _stream())
+    else:
+        _lib.call("sn_wgrad_slabs_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, _p(seg.slab_off), seg.nslab,
+                  _p(seg.seg_slab_ptr), seg.nseg, J, C, _p(G), _p(dysum), _p(segsum), _p(ws), ws_bytes, _stream())
     return G, dysum, segsum
 
 
@@ -914,9 +997,11 @@ def linear_dgrad_eluseg_ragged(dy, W, x, center, B, Cc, segvec, seg, gadd=None):
     rows, J = dy.shape
     C = x.shape[1]
     gact = torch.empty((rows, C), dtype=torch.float32, device=dy.device)
-    _lib.call("sn_linear_dgrad_eluseg_ragged_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x), _p(center), _p(B), _p(Cc),
+    am = _new_dgrad_absmax(dy.device)
+    _lib.call("sn_linear_dgrad_eluseg_ragged_absmax_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x), _p(center), _p(B), _p(Cc),
               _p(segvec), _p(seg.off_dev), seg.nseg, _p(gact), C, _p(gadd), _ld(gadd) if gadd is not None else 0, rows, J, C,
-              _stream())
+              _p(am), _stream())
+    note_absmax(gact, am)
     return gact
 
 
@@ -1080,6 +1165,9 @@ def linear_dgrad_eluseg(dy, W, x, center, B, Cc, segvec, rows_per_seg: int, rowm
     rows, J = dy.shape
     C = x.shape[1]
     gact = torch.empty((rows, C), dtype=torch.float32, device=dy.device)
-    _lib.call("sn_linear_dgrad_eluseg_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x), _p(center), _p(B), _p(Cc), _p(segvec),
-              rows_per_seg, _p(rowmask), _p(gact), C, _p(gadd), _ld(gadd) if gadd is not None else 0, rows, J, C, _stream())
+    am = _new_dgrad_absmax(dy.device)
+    _lib.call("sn_linear_dgrad_eluseg_absmax_f32", _p(dy), _ld(dy), _p(W), _ld(W), _p(x), _ld(x), _p(center), _p(B), _p(Cc),
+              _p(segvec), rows_per_seg, _p(rowmask), _p(gact), C, _p(gadd), _ld(gadd) if gadd is not None else 0, rows, J, C,
+              _p(am), _stream())
+    note_absmax(gact, am)
     return gact

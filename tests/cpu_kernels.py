@@ -64,7 +64,7 @@ def _q3_to_bsr4(q_blk):
     return torch.from_numpy(col), torch.from_numpy(blocks.reshape(-1))
 
 
-def spmm_q3(b_rowptr, q_blk, Mb, Kb, x, y, group=1, e=None, g=None):
+def spmm_q3(b_rowptr, q_blk, Mb, Kb, x, y, group=1, e=None, g=None, want_absmax=False):
     bci, bv = _q3_to_bsr4(q_blk)
     spmm_bsr4(b_rowptr, bci, bv, Mb, Kb, x, y, group)
     if e is not None:
@@ -193,7 +193,19 @@ def wgrad_supported(J, C):
     return C in (128, 256) and J <= 128 and J % 4 == 0
 
 
-def wgrad(dy, x, center=None, want_colsum=False):
+def absmax_wanted():
+    return False          # the host twins have one weight gradient (exact): no bounds are produced or consumed
+
+
+def note_absmax(t, maxima):
+    pass
+
+
+def take_absmax(t):
+    return None
+
+
+def wgrad(dy, x, center=None, want_colsum=False, bounds=None):
     G = c_oracle.wgrad_raw(dy.data_ptr(), _ld(dy), x.data_ptr(), _ld(x), x.shape[0], dy.shape[1], x.shape[1],
                            None if center is None else _np(center))
     G = torch.from_numpy(G.astype(np.float32))
@@ -535,7 +547,7 @@ def avg_bwd_segvec(seg_dy, Wf2, m, mu2, B2, C2, inv_count, rows_per_seg):
     return (v * inv_count.double().reshape(-1, 1)).float()
 
 
-def wgrad_seg(dy, x, center, rows_per_seg):
+def wgrad_seg(dy, x, center, rows_per_seg, bounds=None):
     G, sdy = wgrad(dy, x, center, want_colsum=True)
     nseg = dy.shape[0] // rows_per_seg
     return G, sdy, dy.double().reshape(nseg, rows_per_seg, -1).sum(1).float()
@@ -635,7 +647,7 @@ def avg_stage_ragged_supported(C, J, seg):
     return C == 128 and J == 128 and seg.min_len >= 32
 
 
-def wgrad_slabs(dy, x, center, seg):
+def wgrad_slabs(dy, x, center, seg, bounds=None):
     G, sdy = wgrad(dy, x, center, want_colsum=True)
     out = torch.zeros((seg.nseg, dy.shape[1]), dtype=torch.float64)
     out.index_add_(0, _seg_of_rows(seg), dy.double())
