@@ -2630,7 +2630,8 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_h_k(const float *__res
                                                               float *__restrict__ colpart /* [grid][128] | NULL */,
                                                               int64_t seg_rows, int spm, const int64_t *__restrict__ slab_off,
                                                               const float *__restrict__ dybound /* [ndy]: max >= max |dy| */,
-                                                              int ndy, const float *__restrict__ xinvstd /* [C] */, float xfac) {
+                                                              int ndy, const float *__restrict__ xinvstd /* [C] */, float xfac,
+                                                              int interleave /* plain slabs only: 32-row blocks b, b + grid, ... */) {
   constexpr int NCG = 32 + 32 * CT;          // column groups of 4: 32 of dy, 32·CT of x
   constexpr int QP = NCG + 4;                // slots per (column % 4) plane; QP % 16 == 4 keeps fragment reads conflict-free
   constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
@@ -2653,13 +2654,17 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_h_k(const float *__res
     const int64_t mend = (mesh + 1) * seg_rows < rows ? (mesh + 1) * seg_rows : rows;
     r0 = mesh * seg_rows + part * per;
     r1 = r0 + per < mend ? r0 + per : mend;
+  } else if (interleave) {
+    r0 = 32 * (int64_t)blockIdx.x;             // my first block; the following ones lie G blocks apart, up to the operand's end
+    r1 = rows;
   } else {
     int64_t per = (rows + gridDim.x - 1) / gridDim.x;
     per = (per + 15) & ~(int64_t)15;
     r0 = (int64_t)blockIdx.x * per;
     r1 = r0 + per < rows ? r0 + per : rows;
   }
-  const int nblocks = r1 > r0 ? (int)((r1 - r0 + 31) / 32) : 0;
+  const int G = (interleave && !slab_off && seg_rows <= 0) ? (int)gridDim.x : 1;      // 32-row blocks between two of mine
+  const int nblocks = r1 > r0 ? (int)(((r1 - r0 + 31) / 32 + G - 1) / G) : 0;
   const int span = r1 > r0 ? (int)(r1 - r0) : 0;
   float *P = partial + (int64_t)blockIdx.x * 128 * C;
 
@@ -2744,11 +2749,11 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_h_k(const float *__res
   auto open_slot = [&](auto kc, int b) {
     constexpr int k = decltype(kc)::value;
     const int rstep = k == 0 ? dy_rstep : x_rstep;
-    int left = span - 32 * b - 8 * s_rg[k];
+    int left = span - 32 * G * b - 8 * s_rg[k];
     left = left < 0 ? 0 : (left > 8 ? 8 : left);
     const int extent = __builtin_amdgcn_readfirstlane(left * rstep);
     s_rs[k] = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(s_cur[k]), 0, extent, 0x00020000);
-    s_cur[k] += 8 * rstep;
+    s_cur[k] += (int64_t)8 * rstep * G;
   };
   auto load_row = [&](auto sc, auto kc, auto jc) {
     constexpr int set = decltype(sc)::value, k = decltype(kc)::value, j = decltype(jc)::value;
@@ -2931,6 +2936,16 @@ inline int wgrad_h_mode() {
   return v;
 }
 
+// SN_WGRAD_INTERLEAVE=1: plain slabs: workgroup b takes the 32-row blocks b, b + grid, ... instead of a contiguous range of
+// rows (what pays for the forward / input-gradient kernels, sn_gemm.hip EpiArgs::interleave).  Default 0: same-box A/B of the
+// config-3 step on three boxes, round 4: -0.07, +0.03, +0.15 ms per step — A/B switch only
+inline int wgrad_interleave() {
+  static const int v = [] {
+    const char *e = getenv("SN_WGRAD_INTERLEAVE");
+    return e ? atoi(e) : 0;
+  }();
+  return v;
+}
 static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                         int32_t J, int32_t C, float *G, double *dysum, int64_t rows_per_seg, float *seg_dysum,
                         void *workspace, size_t workspace_bytes, void *stream, const int64_t *slab_off = nullptr,
@@ -2981,10 +2996,10 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
     if (t_start)                                                                                                                       \
       hipExtLaunchKernelGGL((wgrad_h_k<CT_, L_, S_>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx,   \
                             center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off, bounds->dybound, bounds->ndy, bounds->xinvstd, \
-                            bounds->xfac);                                                                                             \
+                            bounds->xfac, wgrad_interleave());                                                                                             \
     else                                                                                                                               \
       hipLaunchKernelGGL((wgrad_h_k<CT_, L_, S_>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J,    \
-                         (int)C, partial, colpart, sr, spm, slab_off, bounds->dybound, bounds->ndy, bounds->xinvstd, bounds->xfac);  \
+                         (int)C, partial, colpart, sr, spm, slab_off, bounds->dybound, bounds->ndy, bounds->xinvstd, bounds->xfac, wgrad_interleave());  \
   } while (0)
     // default: one accumulator, two blocks in flight.  Same box, us per launch incl. the reduction, 627 200 / 322 624 rows:
     // C = 256: three-piece bf16 335 / 163; this kernel with one block in flight 212 / 111, two 199 / 106, second accumulator

@@ -79,6 +79,10 @@ struct EpiArgs {
   // the grid's size up to kAbsmaxBlocks are zeroed) — the bound the two-piece weight gradient of the layer BELOW needs for its
   // dy operand (sn_wgrad_bounded_f32).  NULL: not wanted.
   float *absmax;
+  // tile assignment: 0 — workgroup b owns a contiguous range of tiles; 1 — tiles b, b + grid, b + 2 grid, ... (all workgroups
+  // walk ONE contiguous window of every operand together instead of 256 separate streams each: same-box A/B of the config-3
+  // step on three boxes, round 4: 19.99 -> 19.46, 20.38 -> 19.80, 19.84 -> 19.77 ms).
+  int interleave;
 };
 constexpr int kAbsmaxBlocks = 512;      // >= the largest grid of any input-gradient launch (2 workgroups per CU)
 
@@ -391,6 +395,7 @@ struct RowWindow {
     n_full = n_last = 0;
   }
   __device__ __forceinline__ void next() { p += step; }
+  __device__ __forceinline__ void stride(int g) { step *= g; }      // advance g tiles per next()
   // to_last = tiles between the window's tile and the matrix's last tile (0: it is the last, < 0: past the matrix)
   __device__ __forceinline__ rsrc_t rsrc(int to_last) const {
     const int n = to_last > 0 ? n_full : (to_last == 0 ? n_last : 0);
@@ -491,8 +496,9 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
   if constexpr (H2) __syncthreads();        // s_cs complete (read once below, by other lanes)
   const int64_t ntiles = (rows + 31) / 32;
   const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
-  int64_t tile = (int64_t)blockIdx.x * per;
-  const int64_t tend = tile + per < ntiles ? tile + per : ntiles;
+  const int G = ep.interleave ? (int)gridDim.x : 1;                 // tiles between two of mine
+  int64_t tile = G > 1 ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * per;
+  const int64_t tend = G > 1 ? ntiles : (tile + per < ntiles ? tile + per : ntiles);
   constexpr bool STATS = (EPI == EPI_FWD) && ELU && NT == 1;
   if (tile >= tend) {
     if constexpr (STATS)
@@ -550,6 +556,13 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
   if constexpr (DGE) {
     if (has_ga) w_ga.init(ep.v4, ep.ld3, row0, last_nrt, ep.half);
     else w_ga.init_empty();
+  }
+  if (G > 1) {
+    w_in.stride(G);
+    if constexpr (SIDE) w_side.stride(G);
+    w_out.stride(G);
+    if constexpr (DGE || (EPI == EPI_FWD && ELU)) w_o2.stride(G);
+    if constexpr (DGE) w_ga.stride(G);
   }
   // per-mesh vectors: the mesh of the tile's first row and the row where the next mesh starts, kept up as tiles advance
   const bool useseg = (ep.period > 0 || ep.segoff != nullptr) && (EPI == EPI_FWD || (DGE && lowhalf));      // wave-uniform
@@ -619,7 +632,7 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
 #pragma unroll
     for (int p = 0; p < NCH; ++p) load_chunk(r0, p);
     w_in.next();
-    const rsrc_t r1 = w_in.rsrc(to_last - 1);
+    const rsrc_t r1 = w_in.rsrc(to_last - G);
 #pragma unroll
     for (int p = 0; p < NCH; ++p) {
       convert_chunk(0, p);
@@ -631,7 +644,7 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
   auto do_tile = [&](auto bufc, int64_t tl) {
     constexpr int buf = decltype(bufc)::value;
     SN_LDS_BARRIER();                  // image `buf` complete and visible; every wave is done reading image buf^1
-    const rsrc_t r_in = w_in.rsrc(to_last - 2);          // tile tl + 2 (past the matrix: reads 0, no traffic)
+    const rsrc_t r_in = w_in.rsrc(to_last - 2 * G);      // my tile after next (past the matrix: reads 0, no traffic)
     const int nrt = to_last == 0 ? last_nrt : 32;        // valid rows of this tile
     // side operand in the epilogue layout (full lines), requested now, consumed after the k loop
     f4 sd[NST];
@@ -648,7 +661,7 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
     int nb = 32;
     const bool usemask = DGE && useseg && ep.rowmask != nullptr;
     if (useseg) {
-      if (seg_left <= 0) {
+      while (seg_left <= 0) {          // (one step with contiguous tiles; a stride of G tiles may pass several meshes)
         ++seg_m;
         seg_left += ep.segoff ? (int)(ep.segoff[seg_m + 1] - ep.segoff[seg_m]) : (int)ep.period;
       }
@@ -818,8 +831,8 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
       }
     }
     w_in.next();
-    --to_last;
-    seg_left -= 32;
+    to_last -= G;
+    seg_left -= 32 * G;
     if constexpr (SIDE) w_side.next();
     w_out.next();
     if constexpr (DGE || (EPI == EPI_FWD && ELU)) w_o2.next();
@@ -827,9 +840,9 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
   };
   while (true) {
     do_tile(IC<0>{}, tile);
-    if (++tile >= tend) break;
+    if ((tile += G) >= tend) break;
     do_tile(IC<1>{}, tile);
-    if (++tile >= tend) break;
+    if ((tile += G) >= tend) break;
   }
   if constexpr (EPI == EPI_DGRAD_ELU) {
     if (ep.absmax) {                       // workgroup maximum of |gact| (non-negative floats order like their bit patterns)
@@ -871,6 +884,246 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// gemm_fwd_w8_k — the forward kernel as EIGHT waves of 16 output columns (two waves per SIMD).
+//
+// gemm_rows_split_k keeps a wave's 32 output columns of the split weights in registers: 128 VGPRs at K = 256, and with the
+// accumulators, the rows in flight and the epilogue that is one wave per SIMD (272-325 registers) — every instruction of the
+// tile loop then costs an issue slot nobody else can fill, and the K = 256 forward launches ran at 4.6-4.7 TB/s where the
+// K = 128 ones (two workgroups per CU) reach 5.1-5.5.  Here a wave owns SIXTEEN columns (v_mfma_f32_16x16x32_f16: i = output
+// column, n = data row, 32 k per instruction), 64 weight registers, and a workgroup of eight such waves covers the 128
+// outputs: two waves per SIMD, whose scalar / vector / LDS / matrix instructions issue side by side.  The price is that every
+// wave reads all of the tile's fragments (256 KB of LDS reads per tile instead of 128: 1 k cycles of a 4 k-cycle tile).
+// No accumulator exchange, no second barrier: the tile loop is gemm_rows_split_k's (image t+1 converted and tile t+2
+// requested under the k loop of tile t — one 4-row chunk per wave —, one barrier per tile, the slab through a per-wave LDS
+// transposition so that a quad of lanes stores one row's 64 bytes).  Forward only, two fp16 pieces, J = 128, plain bias.
+// ------------------------------------------------------------------------------------------------------------------
+typedef float f4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f4 mfma16_f16(const u4 &a, const u4 &b, const f4 &c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8v, a), __builtin_bit_cast(h8v, b), c, 0, 0, 0);
+}
+
+template <int K, bool SIDE, bool ELU>
+__global__ __launch_bounds__(512, 1) void gemm_fwd_w8_k(const float *__restrict__ In, int64_t ldi, const float *__restrict__ W,
+                                                        int64_t ldw, float *__restrict__ Out, int64_t ldo, int64_t rows,
+                                                        EpiArgs ep) {
+  constexpr int WV = 8;
+  constexpr int KS = K / 32;                 // MFMA k-steps per tile
+  constexpr int RS = 2 * K + 16;             // bytes per row of one fp16 image
+  constexpr int PART = 32 * RS;              // bytes per image
+  constexpr int SEG = K / 64;                // 256-byte segments per data row
+  constexpr int SROW = 64 + 16;              // bytes per staged output row of a wave's 16-column slab
+  constexpr int NST = 2;                     // store instructions per slab: 16 rows x 64 bytes each
+  __shared__ __attribute__((aligned(16))) unsigned char img[2][2][PART];
+  __shared__ __attribute__((aligned(16))) unsigned char stg[WV][32 * SROW];
+  __shared__ float s_rs[2][32];
+  __shared__ __attribute__((aligned(16))) float s_cs[128];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int n16 = lane & 15, kg = lane >> 4;
+  // ---- stationary weights: pieces of Wmat[col = 16 wave + n16][k = 32 ks + 8 kg .. +7], scaled by the column's power of two ----
+  u4 wh[KS], wl[KS];
+  {
+    const float *wr = W + (int64_t)(16 * wave + n16) * ldw + 8 * kg;
+    float cm = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f4 p = *reinterpret_cast<const f4 *>(wr + 32 * ks), q = *reinterpret_cast<const f4 *>(wr + 32 * ks + 4);
+      cm = fmaxf(cm, fmaxf(absmax4(p), absmax4(q)));
+    }
+    cm = fmaxf(cm, __shfl_xor(cm, 16));
+    cm = fmaxf(cm, __shfl_xor(cm, 32));
+    float cup, cdown;
+    pow2_scales(cm, cup, cdown);
+    if (kg == 0) s_cs[16 * wave + n16] = cdown;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const f4 p = *reinterpret_cast<const f4 *>(wr + 32 * ks), q = *reinterpret_cast<const f4 *>(wr + 32 * ks + 4);
+      split8_h2(p, q, cup, wh[ks], wl[ks]);
+    }
+  }
+  __syncthreads();
+  const int64_t ntiles = (rows + 31) / 32;
+  const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
+  const int G = ep.interleave ? (int)gridDim.x : 1;                 // tiles between two of mine
+  int64_t tile = G > 1 ? (int64_t)blockIdx.x : (int64_t)blockIdx.x * per;
+  const int64_t tend = G > 1 ? ntiles : (tile + per < ntiles ? tile + per : ntiles);
+  constexpr bool STATS = ELU;
+  if (tile >= tend) {
+    if constexpr (STATS)
+      if (ep.stats && threadIdx.x < 256)
+        for (int64_t b = blockIdx.x; b < ep.stats_blocks; b += gridDim.x) ep.stats[b * 256 + threadIdx.x] = 0.0;
+    return;
+  }
+  double ssum[STATS ? 4 : 1], ssq[STATS ? 4 : 1];
+#pragma unroll
+  for (int i = 0; i < (STATS ? 4 : 1); ++i) ssum[i] = ssq[i] = 0.0;
+  // ---- epilogue geometry: lane l stores the 16 bytes at chunk (l % 4) of rows (l / 4) + 16 j of its wave's slab ----
+  const int erow = lane >> 2, echunk = lane & 3;
+  const int ecol = 16 * wave + 4 * echunk;
+  const f4 k0 = *reinterpret_cast<const f4 *>(ep.v0 + ecol);                         // bias
+  const f4 kcs = *reinterpret_cast<const f4 *>(s_cs + ecol);                         // inverse column scales
+  unsigned char *const sw = &stg[wave][0] + n16 * SROW + 16 * kg;                    // my accumulators: row n16 (+16), columns 4 kg ..
+  const unsigned char *const sr = &stg[wave][0] + erow * SROW + 16 * echunk;         // what I read back (+ 16 SROW j)
+  const bool has_out = Out != nullptr;
+  const int vo_side = 4 * (erow * (int)ep.ld1 + ecol), js_side = 64 * (int)ep.ld1;
+  const int vo_out = 4 * (erow * (int)ldo + ecol), js_out = 64 * (int)ldo;
+  const int vo_o2 = 4 * (erow * (int)ep.ld2 + ecol), js_o2 = 64 * (int)ep.ld2;
+  RowWindow w_in, w_side, w_out, w_o2;
+  const int64_t row0 = tile * 32;
+  const int last_nrt = (int)(rows - (ntiles - 1) * 32);
+  int to_last = (int)(ntiles - 1 - tile);
+  w_in.init(In, ldi, row0, last_nrt, K);
+  if constexpr (SIDE) w_side.init(ep.v1, ep.ld1, row0, last_nrt, 128);
+  if (has_out) w_out.init(Out, ldo, row0, last_nrt, 128);
+  else w_out.init_empty();
+  if constexpr (ELU) w_o2.init(ep.o2, ep.ld2, row0, last_nrt, 128);
+  if (G > 1) {
+    w_in.stride(G);
+    if constexpr (SIDE) w_side.stride(G);
+    w_out.stride(G);
+    if constexpr (ELU) w_o2.stride(G);
+  }
+
+  // ---- loader: this wave stages rows 4 wave .. +3 of a tile (16 lanes x 16 bytes = one 256-byte segment of a row) ----
+  const int lr = lane >> 4, lc = lane & 15;
+  const int lrow = 4 * wave + lr;
+  int lvo[SEG];
+#pragma unroll
+  for (int s = 0; s < SEG; ++s) lvo[s] = 4 * (lrow * (int)ldi + 4 * lc) + 256 * s;
+  f4 raw[SEG];
+  auto load_rows = [&](rsrc_t r) {
+#pragma unroll
+    for (int s = 0; s < SEG; ++s) raw[s] = bld4(r, lvo[s]);
+  };
+  auto convert_rows = [&](int buf) {
+    unsigned char *d = &img[buf][0][0] + lrow * RS + 8 * lc;
+    float m = absmax4(raw[0]);
+#pragma unroll
+    for (int s = 1; s < SEG; ++s) m = fmaxf(m, absmax4(raw[s]));
+    float up, down;
+    pow2_scales(__uint_as_float(row16_umax(__float_as_uint(m))), up, down);
+#pragma unroll
+    for (int s = 0; s < SEG; ++s) {
+      u2 H, L;
+      split4_h2(raw[s], up, H, L);
+      *reinterpret_cast<u2 *>(d + 128 * s) = H;
+      *reinterpret_cast<u2 *>(d + 128 * s + PART) = L;
+    }
+    if (lc == 0) s_rs[buf][lrow] = down;
+  };
+  {
+    load_rows(w_in.rsrc(to_last));
+    w_in.next();
+    const rsrc_t r1 = w_in.rsrc(to_last - G);
+    convert_rows(0);
+    load_rows(r1);
+    w_in.next();
+  }
+
+  auto do_tile = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    SN_LDS_BARRIER();
+    const rsrc_t r_in = w_in.rsrc(to_last - 2 * G);
+    const int nrt = to_last == 0 ? last_nrt : 32;
+    f4 sd[NST];
+    if constexpr (SIDE) {
+      const rsrc_t r_side = w_side.rsrc(to_last);
+#pragma unroll
+      for (int j = 0; j < NST; ++j) sd[j] = bld4(r_side, vo_side + j * js_side);
+    }
+    const f4 zero = {0.f, 0.f, 0.f, 0.f};
+    f4 acc0[2], acc1[2];
+    const unsigned char *fp = &img[buf][0][0] + n16 * RS + 16 * kg;          // my fragments: rows n16 | n16 + 16, + 64 ks
+    const float rs0 = s_rs[buf][n16], rs1 = s_rs[buf][n16 + 16];
+    u4 dh0 = *reinterpret_cast<const u4 *>(fp), dl0 = *reinterpret_cast<const u4 *>(fp + PART),
+       dh1 = *reinterpret_cast<const u4 *>(fp + 16 * RS), dl1 = *reinterpret_cast<const u4 *>(fp + 16 * RS + PART);
+    static_for<0, KS>([&](auto ic) {
+      constexpr int ks = decltype(ic)::value;
+      __builtin_amdgcn_sched_barrier(0);
+      u4 nh0, nl0, nh1, nl1;
+      if constexpr (ks + 1 < KS) {
+        nh0 = *reinterpret_cast<const u4 *>(fp + 64 * (ks + 1));
+        nl0 = *reinterpret_cast<const u4 *>(fp + PART + 64 * (ks + 1));
+        nh1 = *reinterpret_cast<const u4 *>(fp + 16 * RS + 64 * (ks + 1));
+        nl1 = *reinterpret_cast<const u4 *>(fp + 16 * RS + PART + 64 * (ks + 1));
+      }
+      if constexpr (ks == 0) {                 // my four rows of the next tile, then the same rows of the tile after it
+        convert_rows(buf ^ 1);
+        load_rows(r_in);
+      }
+      acc1[0] = mfma16_f16(wl[ks], dh0, ks == 0 ? zero : acc1[0]);
+      acc1[1] = mfma16_f16(wl[ks], dh1, ks == 0 ? zero : acc1[1]);
+      acc0[0] = mfma16_f16(wh[ks], dh0, ks == 0 ? zero : acc0[0]);
+      acc0[1] = mfma16_f16(wh[ks], dh1, ks == 0 ? zero : acc0[1]);
+      acc1[0] = mfma16_f16(wh[ks], dl0, acc1[0]);
+      acc1[1] = mfma16_f16(wh[ks], dl1, acc1[1]);
+      if constexpr (ks + 1 < KS) {
+        dh0 = nh0; dl0 = nl0; dh1 = nh1; dl1 = nl1;
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    // accumulator layout: lane (n16, kg) holds rows n16 / n16 + 16, columns 4 kg .. +3 of the wave's slab
+    *reinterpret_cast<f4 *>(sw) = f4{__builtin_fmaf(acc1[0].x, kLowDown, acc0[0].x) * rs0, __builtin_fmaf(acc1[0].y, kLowDown, acc0[0].y) * rs0,
+                                     __builtin_fmaf(acc1[0].z, kLowDown, acc0[0].z) * rs0, __builtin_fmaf(acc1[0].w, kLowDown, acc0[0].w) * rs0};
+    *reinterpret_cast<f4 *>(sw + 16 * SROW) =
+        f4{__builtin_fmaf(acc1[1].x, kLowDown, acc0[1].x) * rs1, __builtin_fmaf(acc1[1].y, kLowDown, acc0[1].y) * rs1,
+           __builtin_fmaf(acc1[1].z, kLowDown, acc0[1].z) * rs1, __builtin_fmaf(acc1[1].w, kLowDown, acc0[1].w) * rs1};
+    const rsrc_t r_out = w_out.rsrc(to_last);
+    rsrc_t r_o2 = r_out;
+    if constexpr (ELU) r_o2 = w_o2.rsrc(to_last);
+#pragma unroll
+    for (int j = 0; j < NST; ++j) {
+      f4 v = *reinterpret_cast<const f4 *>(sr + 16 * j * SROW);
+      v = v * kcs + k0;
+      if constexpr (SIDE) v += sd[j];
+      bst4(r_out, vo_out + j * js_out, v);
+      if constexpr (ELU) {
+        const f4 ev = f4{elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w)};
+        bst4(r_o2, vo_o2 + j * js_o2, ev);
+        if (erow + 16 * j < nrt) {               // rows past the end hold elu(bias): not part of the statistics
+          const double e0 = ev.x, e1 = ev.y, e2 = ev.z, e3 = ev.w;      // fp64 from the first addition on (as gemm_rows_split_k)
+          ssum[0] += e0; ssum[1] += e1; ssum[2] += e2; ssum[3] += e3;
+          ssq[0] = __builtin_fma(e0, e0, ssq[0]); ssq[1] = __builtin_fma(e1, e1, ssq[1]);
+          ssq[2] = __builtin_fma(e2, e2, ssq[2]); ssq[3] = __builtin_fma(e3, e3, ssq[3]);
+        }
+      }
+    }
+    w_in.next();
+    to_last -= G;
+    if constexpr (SIDE) w_side.next();
+    w_out.next();
+    if constexpr (ELU) w_o2.next();
+  };
+  while (true) {
+    do_tile(IC<0>{});
+    if ((tile += G) >= tend) break;
+    do_tile(IC<1>{});
+    if ((tile += G) >= tend) break;
+  }
+  if constexpr (STATS) {
+    if (ep.stats) {
+      // lane (erow, chunk) holds the sums of its 4 columns over its rows of every tile: add the 16 row lanes of a chunk (lanes
+      // 4 erow + chunk) in a fixed butterfly order
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) {
+          ssum[i] += __shfl_xor(ssum[i], o);
+          ssq[i] += __shfl_xor(ssq[i], o);
+        }
+      if (erow == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          ep.stats[(int64_t)blockIdx.x * 256 + ecol + i] = ssum[i];
+          ep.stats[(int64_t)blockIdx.x * 256 + 128 + ecol + i] = ssq[i];
+        }
+      }
+      if (threadIdx.x < 256)
+        for (int64_t b = blockIdx.x + gridDim.x; b < ep.stats_blocks; b += gridDim.x) ep.stats[b * 256 + threadIdx.x] = 0.0;
+    }
+  }
+}
+
 // SN_GEMM_VARIANT: 2 (default) two scaled fp16 pieces, 1 three bf16 pieces (both exact splits on the 16-bit matrix pipe; the
 // fp16 form issues half the MFMAs: -2.5 % on the ARAP step), 0 the fp32-MFMA kernel above (A/B baselines)
 inline int gemm_variant() {
@@ -888,6 +1141,21 @@ inline int gemm_wv8() {          // 0 off, 1 large operands, 2 every operand (te
   static const int v = [] {
     const char *e = getenv("SN_GEMM_WV8");
     return e ? atoi(e) : 0;
+  }();
+  return v;
+}
+// SN_GEMM_INTERLEAVE (default 1): workgroup b takes tiles b, b + grid, ... ; 0: a contiguous range per workgroup (A/B switch)
+inline int gemm_interleave() {
+  static const int v = [] {
+    const char *e = getenv("SN_GEMM_INTERLEAVE");
+    return e ? atoi(e) : 1;
+  }();
+  return v;
+}
+inline int gemm_w8() {
+  static const int v = [] {
+    const char *e = getenv("SN_GEMM_W8");
+    return e ? atoi(e) : 1;
   }();
   return v;
 }
@@ -957,7 +1225,7 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
     return SN_E_ALIGN;
   if (elu_stats_part && (!y_elu || gemm_variant() == 0)) return SN_E_UNSUPPORTED;
   EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr, elu_stats_part,
-             sn_linear_fwd_stats_blocks(rows), (int)J, nullptr, 0, nullptr};
+             sn_linear_fwd_stats_blocks(rows), (int)J, nullptr, 0, nullptr, gemm_interleave()};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const bool x3 = gemm_variant() != 0;
@@ -966,6 +1234,32 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
     sn_internal_timing_slot(0x100 | (residual ? 2 : 0) | (y_elu ? 1 : 0) | (y ? 4 : 0), rows, K,
                             rows * 4 * ((int64_t)K + (y ? J : 0) + (residual ? J : 0) + (y_elu ? J : 0)), J, &t_start, &t_stop);
 #define SN_X3_FWD(KK, RES, EL) SN_SPLIT_LAUNCH((KK, 1, false, EPI_FWD, RES, EL), x, ldx, W, ldw, y, ldy, rows, ep)
+#define SN_W8_FWD(KK, RES, EL)                                                                                         \
+  do {                                                                                                                 \
+    if (t_start) hipExtLaunchKernelGGL((gemm_fwd_w8_k<KK, RES, EL>), dim3(grid8), dim3(512), 0, s, t_start, t_stop, 0, x, ldx, W, ldw, y, ldy, rows, ep); \
+    else hipLaunchKernelGGL((gemm_fwd_w8_k<KK, RES, EL>), dim3(grid8), dim3(512), 0, s, x, ldx, W, ldw, y, ldy, rows, ep); \
+  } while (0)
+  // eight waves of 16 columns (gemm_fwd_w8_k), large operands.  SN_GEMM_W8: 0 off; 1 (default) the K = 256 launches that write
+  // only the activated copy (the one shape it wins: one output stream — a wave's rows are 64-byte segments, and with a
+  // residual and two outputs the three half-line streams cost more than the second wave per SIMD gains); 3 every K = 256
+  // launch; 2 every launch (A/B)
+  const int w8 = gemm_w8();
+  if (gemm_variant() == 2 && J == 128 && rows > kSmallRows &&
+      (w8 == 2 || (w8 == 3 && K == 256) || (w8 == 1 && K == 256 && !residual && y_elu && !y))) {
+    const unsigned grid8 = gemm_grid(rows, 1);
+    const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
+    switch (sel) {
+      case 0: SN_W8_FWD(128, false, false); break;
+      case 1: SN_W8_FWD(128, false, true); break;
+      case 2: SN_W8_FWD(128, true, false); break;
+      case 3: SN_W8_FWD(128, true, true); break;
+      case 4: SN_W8_FWD(256, false, false); break;
+      case 5: SN_W8_FWD(256, false, true); break;
+      case 6: SN_W8_FWD(256, true, false); break;
+      default: SN_W8_FWD(256, true, true); break;
+    }
+    return launch_status();
+  }
   if (x3) {
     const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
     switch (sel) {
@@ -999,7 +1293,7 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx) || (lddy % 4) || (ldw % 4) || (lddx % 4)) return SN_E_ALIGN;
   if (B && (!aligned16(x) || !aligned16(B) || !aligned16(Cc) || (center && !aligned16(center)) || (ldx % 4) || ldx < C))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, nullptr};
+  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, nullptr, gemm_interleave()};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   const bool x3 = gemm_variant() != 0;
@@ -1049,7 +1343,7 @@ int sn_linear_dgrad_elu_absmax_f32(const float *dy, int64_t lddy, const float *W
       (lddy % 4) || (ldw % 4) || (lddx % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   const int half = C / 2;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, gact_absmax};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, gact_absmax, gemm_interleave()};
   float *out = dx_hi - half;           // the kernel indexes absolute columns; only columns >= half are written through `out`
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
@@ -1083,7 +1377,7 @@ static int fwd_segbias_launch(const float *x, int64_t ldx, const float *W, int64
     return SN_E_ALIGN;
   if (elu_stats_part && !y_elu) return SN_E_UNSUPPORTED;
   EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, segoff ? 0 : rows_per_seg, J, nullptr,
-             elu_stats_part, sn_linear_fwd_stats_blocks(rows), (int)J, segoff, nseg, nullptr};
+             elu_stats_part, sn_linear_fwd_stats_blocks(rows), (int)J, segoff, nseg, nullptr, gemm_interleave()};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   hipEvent_t t_start = nullptr, t_stop = nullptr;
@@ -1142,7 +1436,7 @@ static int dgrad_eluseg_launch(const float *dy, int64_t lddy, const float *W, in
       (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C)) || (lddy % 4) || (ldw % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, (segvec && !segoff) ? rows_per_seg : 0, C, rowmask,
-             nullptr, 0, (int)J, segoff, nseg, gact_absmax};
+             nullptr, 0, (int)J, segoff, nseg, gact_absmax, gemm_interleave()};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   hipEvent_t t_start = nullptr, t_stop = nullptr;
