@@ -335,6 +335,136 @@ def c4_pair_secondary(device, steps: int = 60, warm: int = 10):
             "eager_ms_per_step": eager * 1e3}
 
 
+def c4_dp_step(device, rank: int, world: int, steps: int = 40, warm: int = 8):
+    """BASELINE configs[3] as the N-rank job it is (src/dense_correspondence/main.py:40,299-327: batch 1 per device): every
+    rank trains on ITS OWN pair of FAUST-sized bodies per step — forward + loss + backward replayed from one hipGraph —, then
+    one flat-bucket all-reduce (SUM; the loss is normalised by the number of pairs in the job) and Adam.  Returns the local
+    seconds per step and the bookkeeping of the run; the caller takes the MAX over ranks."""
+    import torch.distributed as dist
+
+    from surfacenetworks_amd import dense_correspondence as dc
+    from surfacenetworks_amd import dp
+
+    ds = dc.TorusBodies(4, device=device, seed=4 + 1000 * rank)
+    torch.manual_seed(4321)
+    model = dc.SiameseModel("lap", 15).to(device).train()
+    dp.broadcast_parameters(model, 0)
+    opt = dc.make_optimizer(model)
+    bucket = dp.FlatGradBucket(model.parameters(), always_reduce=dist.is_initialized())
+    g = dc.graphed_train_step(model, opt, dc.PairBatch(ds, 0, 1), bucket=bucket, global_pairs=world)
+    k = [0]
+
+    def step():
+        k[0] += 1
+        return g(dc.PairBatch(ds, k[0] % 4, (k[0] + 1) % 4))
+
+    for _ in range(warm):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    t_enq = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(loss.detach()).item(), "FAUST step diverged"
+    return dt / steps, {"steps": steps, "warmup": warm, "host_enqueue_ms_per_step": t_enq / steps * 1e3,
+                        "grad_bucket_bytes": bucket.nbytes}
+
+
+def pin_to_gpu_numa(local_rank: int, n_local: int):
+    """Keep this rank's host threads on the cores next to its GPU: eight eager-launching Python processes on a two-socket
+    host otherwise migrate across sockets.  The PCI address of the HIP device gives its NUMA node (/sys/bus/pci/devices/
+    <bdf>/numa_node); without one (-1: single-node hosts, containers) the visible CPUs are dealt out evenly among the node's
+    ranks.  Returns a short description for the JSON line."""
+    try:
+        import ctypes
+
+        cpus_all = sorted(os.sched_getaffinity(0))
+        node = -1
+        try:
+            hip = ctypes.CDLL("libamdhip64.so")
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(torch.cuda.current_device())) == 0:
+                bdf = buf.value.decode().lower()
+                with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as fh:
+                    node = int(fh.read().strip())
+        except (OSError, ValueError, AttributeError):
+            node = -1
+        cpus = None
+        if node >= 0:
+            try:
+                with open(f"/sys/devices/system/node/node{node}/cpulist") as fh:
+                    want = set()
+                    for part in fh.read().strip().split(","):
+                        a, _, b = part.partition("-")
+                        want.update(range(int(a), int(b or a) + 1))
+                cpus = [c for c in cpus_all if c in want]
+            except (OSError, ValueError):
+                cpus = None
+        if cpus:
+            share = cpus                              # (the ranks of one NUMA node share its cores)
+            how = f"numa node {node}: {len(share)} cpus"
+        else:
+            per = max(1, len(cpus_all) // max(1, n_local))
+            share = cpus_all[local_rank * per:(local_rank + 1) * per] or cpus_all
+            how = f"no numa node for the device: cpus {share[0]}-{share[-1]} ({len(share)}) of {len(cpus_all)}"
+        os.sched_setaffinity(0, share)
+        torch.set_num_threads(max(1, min(8, len(share))))
+        return how
+    except Exception as exc:  # noqa: BLE001 — affinity is an optimisation, never a reason to fail the run
+        return f"not pinned: {exc!r}"[:120]
+
+
+PMC_RD, PMC_WR = "TCC_EA0_RDREQ_sum", "TCC_EA0_WRREQ_sum"
+
+
+def pmc_in_run(args, steps: int = 4):
+    """HBM traffic of THIS run's kernels: re-execute this file for a few steps of the same workload under rocprofv3, one
+    counter per pass (MI355X_MICROARCH.md: requests counted at the L2's memory side; bytes = RDREQ*128 + WRREQ*64 on gfx950),
+    and condense the per-dispatch counters with tools/pmc_bench.py.  Returns (table, source note); (None, reason) when
+    rocprofv3 is missing or a pass fails — the caller then falls back to the stamped file under profiles/."""
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="sn_pmc_", dir="/tmp")
+    child = [sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", "1", "--no-cpu-baseline", "--no-secondary",
+             "--no-pmc", "--backend", "none", "--meshes", str(args.meshes), "--format", args.format, "--operators", args.operators,
+             "--linear-timing-steps", "0"]
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    found = {}
+    try:
+        for ctr in (PMC_RD, PMC_WR):
+            out = os.path.join(tmp, ctr)
+            r = subprocess.run([exe, "--pmc", ctr, "-d", out, "-o", "pmc", "--output-format", "csv", "--", *child], cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=420)
+            hits = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not hits:
+                return None, f"rocprofv3 --pmc {ctr} failed (rc {r.returncode}): {r.stderr[-160:]!r}"
+            found[ctr] = hits[0]
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import pmc_bench
+
+        # the child runs data set-up, 3 untimed eager steps, 1 warm-up and `steps` timed steps: keep exactly the timed steps
+        res, _agg, _rd, _wr, _n0, tot_r, tot_w = pmc_bench.summarize(found[PMC_RD], found[PMC_WR], last_steps=steps)
+        res["_steps_counted"] = steps
+        return res, (f"in-run: this bench invocation re-executed itself for {steps} steps under rocprofv3 --pmc {PMC_RD} / --pmc {PMC_WR} "
+                     f"(one counter per pass); bytes = RDREQ*128 + WRREQ*64")
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError, ImportError) as exc:
+        return None, f"in-run PMC pass failed: {exc!r}"[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks here, through the same
     launcher the contract names (python -m torch.distributed.run, rendezvous on 127.0.0.1).  With fewer visible GPUs than
@@ -361,7 +491,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+loss+backward from one captured hipGraph per step instead of launching every "
-                         "kernel from Python (same kernels; pays off when the step is launch-bound: small batches, busy hosts)")
+                         "kernel from Python (same kernels; pays off when the step is launch-bound: small batches, busy hosts). "
+                         "Default with more than one rank (N eager-launching Python processes share one host); --eager overrides")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from Python also with more than one rank")
+    ap.add_argument("--workload", default="arap", choices=["arap", "faust"],
+                    help="arap (default): BASELINE configs[2], the headline; faust: BASELINE configs[3] — dense correspondence, one "
+                         "pair of 6890-vertex bodies per rank and step, Laplacian towers, hipGraph replay + flat-bucket all-reduce")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="skip the in-run counter passes (rocprofv3 --pmc over a few steps of this same workload, N = 1 only)")
     ap.add_argument("--roofline-steps", type=int, default=5,
                     help="eager steps run AFTER the timed region with per-launch HIP events (graph mode only)")
     ap.add_argument("--linear-timing-steps", type=int, default=5,
@@ -379,7 +516,16 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-5 SpMM roofline block")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)      # internal: one time-boxed leg of cpu_baseline()
     args = ap.parse_args()
-    args.no_graph = not args.graph
+    world_hint = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
+    # N ranks on N devices: replay unless --eager (N eager-launching Python processes share one host).  Ranks that SHARE a
+    # device (the functional run of the N > 1 path on a 1-GPU box) stay eager: replaying two processes' graphs on one device
+    # measured 1.4 s per step against 42 ms eager
+    try:
+        n_dev = torch.cuda.device_count()
+    except Exception:  # noqa: BLE001
+        n_dev = 0
+    args.graph_default = (world_hint > 1 and not args.eager and n_dev >= world_hint)
+    args.no_graph = not (args.graph or args.graph_default)
     if args.cpu_leg:
         n_, seed_, thr_, bud_, reps_ = args.cpu_leg.split(",")
         v, reps = _cpu_leg(int(n_), int(seed_), int(thr_), float(bud_), int(reps_))
@@ -423,8 +569,39 @@ def main():
         rank, local_rank, world, device = dp.init_distributed(None if backend == "none" else backend)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    n_local_ranks = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    affinity = pin_to_gpu_numa(local_rank, n_local_ranks) if world > 1 else "single rank: not pinned"
     snF.set_dirac_format(args.format)
     torch.manual_seed(1234)
+    if args.workload == "faust":
+        # BASELINE configs[3] as its own line: N ranks, one pair per rank and step (same contract: barrier + synchronize on both
+        # sides inside c4_dp_step, MAX over ranks, rank 0 prints)
+        steps_f, warm_f = args.steps, args.warmup
+        dt_f, info = c4_dp_step(device, rank, world, steps_f, warm_f)
+        t = torch.tensor([dt_f], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt_f = float(t.item())
+        line = {"metric": "pairs/sec fwd+bwd, FAUST dense correspondence (BASELINE configs[3])", "value": world / dt_f, "unit": "pairs/s",
+                "n_gpus": world, "steps": steps_f, "warmup": warm_f, "ms_per_step": dt_f * 1e3, "higher_is_better": True,
+                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "meshes_per_s": 2 * world / dt_f,
+                "config": {"workload": "FAUST dense correspondence: one pair of torus-grid bodies (6890 vertices padded to 7000) per rank "
+                                       "and step, Laplacian towers C=128, 15 blocks, score matrix never materialised, delta cross entropy, "
+                                       "hipGraph replay of fwd+loss+bwd, pack + all-reduce(SUM) of the flat gradient bucket, Adam",
+                           "global_pairs": world, "parallelism": f"dp{world} (one pair per rank, flat-bucket all-reduce)",
+                           "world_size": world, "rccl_ranks": world if (dist.is_initialized() and dist.get_backend() == "nccl") else 0,
+                           "collective_backend": dist.get_backend() if dist.is_initialized() else "none",
+                           "devices_visible": torch.cuda.device_count(), "ranks_share_devices": bool(oversubscribed),
+                           "host_affinity": affinity, **info},
+                "roofline": None, "cpu_baseline": None}
+        if rank == 0:
+            sys.stdout.flush()
+            os.write(result_fd, (json.dumps(line) + "\n").encode())
+        if dist.is_initialized():
+            if world > 1:
+                dist.barrier()
+            dist.destroy_process_group()
+        return
 
     # ---- data: this rank's shard (own meshes; weak scaling) -----------------------------------------
     n_local = args.meshes
@@ -478,6 +655,7 @@ def main():
     else:
         for _ in range(args.steps):
             loss = one_step().detach()
+    t_enqueue = time.perf_counter() - t0               # the host has issued every step; the device may still be running
     sync()
     dt = time.perf_counter() - t0
     ms1 = torch.cuda.memory_stats()
@@ -532,23 +710,40 @@ def main():
     # The file carries the sha256 of the kernel sources it was measured on (tools/pmc_bench.py): on any other sources the
     # figure is withheld (traffic: null) instead of quoted stale.
     traffic = traffic_src = None
-    pmc_file = os.path.join("profiles", "r3_pmc_traffic_c3.json")
+    step_traffic = None
+    pmc_file = os.path.join("profiles", "r4_pmc_traffic_c3.json")
+    table, in_run_note = (None, "not requested")
+    if rank == 0 and world == 1 and not args.no_pmc:
+        # release the device memory of the timed run first: the counter passes are child processes on the same GPU
+        torch.cuda.empty_cache()
+        table, in_run_note = pmc_in_run(args)
     try:
-        with open(os.path.join(ROOT, pmc_file)) as fh:
-            table = json.load(fh)
-        if table.get("_csrc_sha256") != csrc_digest():
-            traffic_src = f"{pmc_file} was measured on other kernel sources (sha256 mismatch): withheld"
+        if table is None:
+            with open(os.path.join(ROOT, pmc_file)) as fh:
+                table = json.load(fh)
+            file_note = f"{pmc_file} (kernel sources {table.get('_csrc_sha256', '?')[:12]}; in-run pass: {in_run_note})"
         else:
+            file_note = None
+            table["_csrc_sha256"] = csrc_digest()
+        if table.get("_csrc_sha256") != csrc_digest():
+            traffic_src = f"{pmc_file} was measured on other kernel sources (sha256 mismatch): withheld; in-run pass: {in_run_note}"
+        else:
+            tot = table.get("_total_bytes_counted")
+            n_counted = table.get("_steps_counted", 4)
+            if tot:
+                step_traffic = {"GB_per_step": (tot["read"] + tot["write"]) / n_counted / 1e9, "read_GB": tot["read"] / n_counted / 1e9,
+                                "write_GB": tot["write"] / n_counted / 1e9, "steps_counted": n_counted}
             base = dom_name.split("<")[0]
             # (the library launches every Q3 kernel in two shapes, <name> and <name>_wide; the timing tags do not distinguish them)
             hits = [v for k, v in table.items() if not k.startswith("_") and k.split("<")[0] in (base, base + "_wide") and f"<{dom[0][4]}," in k]
             if hits:
                 n_l = sum(h["launches"] for h in hits)
                 traffic = sum((h["read_bytes_mean"] + h["write_bytes_mean"]) * h["launches"] for h in hits) / n_l
-                traffic_src = (f"{pmc_file} (kernel sources {table['_csrc_sha256'][:12]}): rocprofv3 --pmc TCC_EA0_RDREQ_sum / TCC_EA0_WRREQ_sum "
-                               f"over this bench command (in-step), bytes = RDREQ*128 + WRREQ*64, mean over {n_l} launches of {base}")
+                traffic_src = ((file_note + ": rocprofv3 --pmc TCC_EA0_RDREQ_sum / TCC_EA0_WRREQ_sum over this bench command (in-step), "
+                                "bytes = RDREQ*128 + WRREQ*64") if file_note else in_run_note) + f"; mean over {n_l} launches of {base}"
     except (OSError, ValueError, KeyError):
-        pass
+        if traffic_src is None:
+            traffic_src = f"no counter data: in-run pass: {in_run_note}; {pmc_file} not readable"
     product_bytes = sum(alg_bytes(r[1], r[2], r[3], r[4], "") for r in dom)       # SURVEY §8(d) bytes of the products alone
     frac_alg = achieved / HBM_PEAK
     frac_meas = (traffic / (avg_ms * 1e-3) / HBM_PEAK) if traffic else None
@@ -591,6 +786,7 @@ def main():
                                      "error <= 2^-23 per term: fp32-accurate, tests/test_dense_gpu.py); SN_GEMM_VARIANT=1 selects the "
                                      "three-piece bf16 form, 0 the fp32-MFMA kernels; the weight gradient uses three bf16 pieces"),
                    "allocator": alloc, "operator_format": args.format, "operators": args.operators,
+                   "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3, "host_affinity": affinity,
                    "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager", "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": dom_name + (" (the backward products Di^T, DiA^T, ELU backward fused into the store)" if "_epi" in dom_name
                                                           else " (the Dirac products launched without epilogue)"),
@@ -599,7 +795,7 @@ def main():
                      # the HBM traffic the counters measured; the three conventions stay side by side below
                      "achieved": frac_top * HBM_PEAK / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": frac_top,
                      "frac_convention": frac_conv,
-                     "traffic": traffic, "traffic_source": traffic_src,
+                     "traffic": traffic, "traffic_source": traffic_src, "step_traffic": step_traffic,
                      "algorithmic_bytes_definition": "SURVEY.md §8(d) CSR/int32/fp32 bytes of the product (nnz*8 + (M+1)*4 + K*N*4 + M*N*4) "
                                                      "plus, for the fused ELU-backward launches, the epilogue operands E and G (M*N*4 each) "
                                                      "that the fused kernel must read; the three figures below separate the conventions",
@@ -637,6 +833,25 @@ def main():
         if world > 1:
             dist.all_reduce(agg)                  # (every rank reaches this, failed or not)
         sec["aggregate_GBps_all_ranks_packed_mean"] = float(agg.item())
+        # BASELINE configs[3] as the sharded job it is: one pair per rank and step, every rank takes part (also at N = 1)
+        try:
+            del ds, model, opt, bucket
+        except NameError:
+            pass
+        torch.cuda.empty_cache()
+        try:
+            dt_f, info = c4_dp_step(device, rank, world, 30, 6)
+            t = torch.tensor([dt_f], dtype=torch.float64, device=device)
+            if world > 1:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt_f = float(t.item())
+            sec["config4_dp"] = {"workload": "BASELINE configs[3]: FAUST dense correspondence, one pair (2 x 6890 vertices padded to 7000) per "
+                                             "rank and step, hipGraph replay + flat-bucket all-reduce + Adam; max over ranks",
+                                 "n_gpus": world, "ms_per_step": dt_f * 1e3, "pairs_per_s": world / dt_f, "meshes_per_s": 2 * world / dt_f, **info}
+        except Exception as exc:  # noqa: BLE001
+            sec["config4_dp"] = {"error": repr(exc)[:300]}
+            if world > 1:
+                raise                               # (a rank that left the collectives would hang the others)
         if rank == 0 and world == 1:
             # the small-batch configurations, driver-visible (rank 0 of a one-GPU run only: they are replicas, not a sharded job)
             for key, fn in (("config2", c2_secondary), ("config4_pair", c4_pair_secondary)):

@@ -568,12 +568,18 @@ def forward_loss(model, b: PairBatch):
     return pair_cross_entropy(out, b.target_tensor(), b.NA, b.NB).reshape(1)
 
 
-def graphed_train_step(model, optimizer, example: PairBatch, bucket=None):
+def graphed_train_step(model, optimizer, example: PairBatch, bucket=None, global_pairs: int = 1):
     """Training step with forward + loss + backward replayed from one hipGraph: a pair of 7000-row shapes is ~1000 launches
-    of a few microseconds, i.e. launch-bound when issued from Python."""
+    of a few microseconds, i.e. launch-bound when issued from Python.
+    Data parallel (BASELINE config 4, one pair per GPU and step, main.py:40,310-327): every rank captures its own step with
+    global_pairs = the number of ranks (the loss is the mean over the job's pairs) and a `bucket` (dp.FlatGradBucket): the
+    replay is followed by pack + SUM all-reduce + Adam."""
     from .graphs import GraphedTrainStep
 
-    return GraphedTrainStep(model, optimizer, example.owned(), forward_loss, bucket)
+    if global_pairs == 1:
+        return GraphedTrainStep(model, optimizer, example.owned(), forward_loss, bucket)
+    scale = 1.0 / float(global_pairs)
+    return GraphedTrainStep(model, optimizer, example.owned(), lambda m, b: forward_loss(m, b) * scale, bucket)
 
 
 class LSequence(list):

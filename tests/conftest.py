@@ -1,3 +1,4 @@
+import importlib.util
 import os
 import sys
 
@@ -34,3 +35,32 @@ def cpu_kernels(monkeypatch):
 
     ck.install(monkeypatch)
     return ck
+
+
+REF_SRC = "/root/reference/src"
+
+
+@pytest.fixture
+def reference_models(cpu_kernels, monkeypatch):
+    import surfacenetworks_amd.utils_pt as U
+
+    monkeypatch.setattr(sys, "dont_write_bytecode", True)        # (the reference mount is read-only)
+    monkeypatch.syspath_prepend(REF_SRC)
+    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        monkeypatch.delitem(sys.modules, k)
+    import utils                                                  # the reference's package (graph.py, mesh.py stay its own)
+
+    assert os.path.realpath(os.path.dirname(utils.__file__)) == os.path.realpath(os.path.join(REF_SRC, "utils"))
+    # ---- the import swap: the one line a maintainer changes in each models.py / main.py --------------------------------
+    monkeypatch.setitem(sys.modules, "utils.utils_pt", U)
+    monkeypatch.setattr(utils, "utils_pt", U, raising=False)
+    mods = {}
+    for task in ("as_rigid_as_possible", "mesh_mnist", "dense_correspondence"):
+        spec = importlib.util.spec_from_file_location(f"ref_{task}_models", os.path.join(REF_SRC, task, "models.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        assert mod.utils is U, "the reference model file did not pick up the swapped operator layer"
+        mods[task] = mod
+    yield mods
+    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
+        monkeypatch.delitem(sys.modules, k, raising=False)

@@ -237,3 +237,85 @@ def test_bench_runs_its_one_rank_through_rccl():
     assert rec["n_gpus"] == 1 and rec["config"]["collective_backend"] == "nccl" and rec["config"]["rccl_ranks"] == 1
     assert rec["config"]["collective_per_step"].startswith("pack + ncclAllReduce")
     assert rec["roofline"]["linear_kernels"] and rec["roofline"]["linear_kernels"][0]["launches_per_step"] > 0
+
+
+def _pair_worker(rank, world, port, q):
+    """BASELINE config 4 on the device (the GPU twin of test_dp_gloo.py::test_correspondence_pairs_sharded_over_two_ranks): one
+    pair per rank and step with the real HIP kernels, eager and replayed from a hipGraph; the all-reduced gradients must
+    equal the single-process gradient of the mean loss over both pairs."""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import copy
+
+    from helpers import deterministic_init
+    from surfacenetworks_amd import dense_correspondence as dc, dp
+
+    backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
+    _, _, _, dev = dp.init_distributed(backend)
+    ds = dc.TorusBodies(3, n=13, m=17, pad_to=256, seed=5, device=dev)          # every rank holds the (small) dataset
+    model = deterministic_init(dc.SiameseModel("lap", 3), 11 + rank).to(dev).eval()   # BatchNorm frozen: pairs are exactly additive
+    dp.broadcast_parameters(model, 0)
+    ref = deterministic_init(dc.SiameseModel("lap", 3), 11).to(dev).eval()
+    model_g = copy.deepcopy(model)
+    pairs = [(0, 1), (1, 2)]
+    ia, ib = pairs[rank]
+    # single-process reference: mean loss over both pairs
+    total = sum(dc.forward_pair_loss(ref, ds, a, b) for a, b in pairs) / len(pairs)
+    total.backward()
+    g_full = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+    # eager rank step
+    bucket = dp.FlatGradBucket(model.parameters())
+    opt = dc.make_optimizer(model)
+    loss = dc.train_step(model, opt, ds, ia, ib, grad_sync=bucket.sync, global_pairs=world, zero_grads=bucket.detach_grads)
+    g_dp = bucket.flat.clone()
+    err = ((g_dp - g_full).norm() / g_full.norm()).item()
+    lsum = loss.detach().clone()
+    dist.all_reduce(lsum)
+    # replayed rank step (what bench.py --workload faust runs): same reduced gradients, same parameters afterwards
+    bucket_g = dp.FlatGradBucket(model_g.parameters())
+    opt_g = dc.make_optimizer(model_g)
+    step = dc.graphed_train_step(model_g, opt_g, dc.PairBatch(ds, ia, ib), bucket=bucket_g, global_pairs=world)
+    step(dc.PairBatch(ds, ia, ib))
+    err_g = ((bucket_g.flat - g_full).norm() / g_full.norm()).item()
+    pe = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    pg = torch.cat([p.detach().reshape(-1) for p in model_g.parameters()])
+    other = pg.clone()
+    dist.broadcast(other, 0)
+    q.put((rank, err, err_g, abs(lsum.item() - total.item()) / abs(total.item()), float((pe - pg).abs().max()),
+           bool(torch.equal(other, pg)), backend))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_correspondence_pairs_on_two_ranks_on_the_gpu():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pair_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=900)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    for rank, err, err_g, lerr, pdiff, same, backend in sorted(q.get(timeout=10) for _ in range(2)):
+        assert err < 2e-5, f"rank {rank} ({backend}): all-reduced pair gradients differ from the two-pair gradient by {err:.2e}"
+        assert err_g < 2e-5, f"rank {rank} ({backend}): replayed step: {err_g:.2e}"
+        assert lerr < 1e-5 and same and pdiff < 1e-6, (rank, lerr, pdiff, same)
+
+
+def test_bench_faust_workload_starts_two_ranks():
+    """`python bench.py --workload faust --gpus 2` (BASELINE configs[3] as an N-rank job): self-launch, one JSON line,
+    pairs/s over both ranks; on the 1-GPU box the ranks share the device and the collective is gloo (flagged)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "faust", "--gpus", "2", "--steps", "3",
+                          "--warmup", "2"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = out.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), lines
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["unit"] == "pairs/s" and rec["value"] > 0 and rec["config"]["global_pairs"] == 2
+    shared = torch.cuda.device_count() < 2
+    assert rec["config"]["ranks_share_devices"] == shared
+    assert rec["config"]["collective_backend"] == ("gloo" if shared else "nccl")

@@ -6,9 +6,7 @@ sparse_diag_cat / sparse_cat), run forward + backward on the golden batch (oracl
 the same criterion as the product's own model classes: as close to the float64 oracle as the reference's stored fp32 run.
 
 The reference checkout never travels to the GPU box: skipped when /root/reference is absent."""
-import importlib.util
 import os
-import sys
 
 import pytest
 
@@ -16,32 +14,6 @@ import product_checks as pc
 
 REF_SRC = "/root/reference/src"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF_SRC), reason="reference checkout not present (it never travels)")
-
-
-@pytest.fixture
-def reference_models(cpu_kernels, monkeypatch):
-    import surfacenetworks_amd.utils_pt as U
-
-    monkeypatch.setattr(sys, "dont_write_bytecode", True)        # (the reference mount is read-only)
-    monkeypatch.syspath_prepend(REF_SRC)
-    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
-        monkeypatch.delitem(sys.modules, k)
-    import utils                                                  # the reference's package (graph.py, mesh.py stay its own)
-
-    assert os.path.realpath(os.path.dirname(utils.__file__)) == os.path.realpath(os.path.join(REF_SRC, "utils"))
-    # ---- the import swap: the one line a maintainer changes in each models.py / main.py --------------------------------
-    monkeypatch.setitem(sys.modules, "utils.utils_pt", U)
-    monkeypatch.setattr(utils, "utils_pt", U, raising=False)
-    mods = {}
-    for task in ("as_rigid_as_possible", "mesh_mnist", "dense_correspondence"):
-        spec = importlib.util.spec_from_file_location(f"ref_{task}_models", os.path.join(REF_SRC, task, "models.py"))
-        mod = importlib.util.module_from_spec(spec)
-        spec.loader.exec_module(mod)
-        assert mod.utils is U, "the reference model file did not pick up the swapped operator layer"
-        mods[task] = mod
-    yield mods
-    for k in [k for k in sys.modules if k == "utils" or k.startswith("utils.")]:
-        monkeypatch.delitem(sys.modules, k, raising=False)
 
 
 @pytest.mark.parametrize("tag,opkind", [("arap_dir", "coo2d"), ("arap_lap", "coo2d"), ("mnist_lap", "coo2d"),

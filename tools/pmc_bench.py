@@ -33,14 +33,44 @@ def load(path, counter):
 def main():
     out, rd_csv, wr_csv = sys.argv[1:4]
     skip = float(sys.argv[4]) if len(sys.argv) > 4 else 0.5        # drop the first half of the dispatches (set-up, warm-up)
+    res, agg, rd, wr, n0, tot_r, tot_w = summarize(rd_csv, wr_csv, skip)
+    json.dump(res, open(out + ".json", "w"), indent=1)
+    with open(out + "_raw.csv", "w") as fh:
+        fh.write("dispatch,kernel,grid,TCC_EA0_RDREQ_sum,TCC_EA0_WRREQ_sum\n")
+        wmap = {(d, k, g): v for d, k, g, v in wr}
+        for d, k, g, v in rd[n0:]:
+            if "spmm" in k:
+                fh.write(f'{d},"{k}",{g},{v:.0f},{wmap.get((d, k, g), float("nan")):.0f}\n')
+    top = sorted(((e["read_bytes"] + e["write_bytes"], k) for k, e in agg.items()), reverse=True)[:12]
+    for b, k in top:
+        print(f"{b / 1e9:9.3f} GB  {k}")
+    print(f"total counted: read {tot_r / 1e9:.2f} GB write {tot_w / 1e9:.2f} GB")
+
+
+def step_start(rows, last_steps):
+    """Index of the first dispatch of the `last_steps`-th step from the end: a step starts with the batch assembly of
+    sample_batch (a burst of blockdiag_rowptr launches); bursts more than 50 dispatches apart are different steps."""
+    marks = [i for i, r in enumerate(rows) if "blockdiag_rowptr" in r[1]]
+    starts = [m for j, m in enumerate(marks) if j == 0 or m - marks[j - 1] > 50]
+    if len(starts) < last_steps:
+        raise ValueError(f"only {len(starts)} steps found in the counter file, {last_steps} wanted")
+    return starts[-last_steps]
+
+
+def summarize(rd_csv, wr_csv, skip=0.5, last_steps=None):
+    """The per-kernel table of two counter passes (read requests, write requests) of the same deterministic command.
+    last_steps: keep exactly the dispatches of the last N training steps (else: drop the first `skip` of all dispatches)."""
     rd, wr = load(rd_csv, "TCC_EA0_RDREQ_sum"), load(wr_csv, "TCC_EA0_WRREQ_sum")
+    if last_steps is not None:
+        n0, w0 = step_start(rd, last_steps), step_start(wr, last_steps)
+    else:
+        n0, w0 = int(len(rd) * skip), int(len(wr) * skip)
     if [r[1:3] for r in rd] != [w[1:3] for w in wr]:
         # the two passes are two runs of the same deterministic command: align by (kernel, grid) order per kernel
         print("warning: dispatch sequences differ between the passes; aligning per kernel", file=sys.stderr)
-    n0 = int(len(rd) * skip)
     agg = collections.OrderedDict()
     per_k_wr = collections.defaultdict(list)
-    for d, k, g, v in wr[int(len(wr) * skip):]:
+    for d, k, g, v in wr[w0:]:
         per_k_wr[(k, g)].append(v)
     per_k_rd = collections.defaultdict(list)
     for d, k, g, v in rd[n0:]:
@@ -66,17 +96,7 @@ def main():
     for k, e in agg.items():
         res[k] = {"launches": e["launches"], "read_bytes_mean": e["read_bytes"] / e["launches"],
                   "write_bytes_mean": e["write_bytes"] / e["launches"], "by_grid": e["by_grid"]}
-    json.dump(res, open(out + ".json", "w"), indent=1)
-    with open(out + "_raw.csv", "w") as fh:
-        fh.write("dispatch,kernel,grid,TCC_EA0_RDREQ_sum,TCC_EA0_WRREQ_sum\n")
-        wmap = {(d, k, g): v for d, k, g, v in wr}
-        for d, k, g, v in rd[n0:]:
-            if "spmm" in k:
-                fh.write(f'{d},"{k}",{g},{v:.0f},{wmap.get((d, k, g), float("nan")):.0f}\n')
-    top = sorted(((e["read_bytes"] + e["write_bytes"], k) for k, e in agg.items()), reverse=True)[:12]
-    for b, k in top:
-        print(f"{b / 1e9:9.3f} GB  {k}")
-    print(f"total counted: read {tot_r / 1e9:.2f} GB write {tot_w / 1e9:.2f} GB")
+    return res, agg, rd, wr, n0, tot_r, tot_w
 
 
 if __name__ == "__main__":
