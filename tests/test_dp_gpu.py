@@ -255,9 +255,23 @@ def _pair_worker(rank, world, port, q):
     backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
     _, _, _, dev = dp.init_distributed(backend)
     ds = dc.TorusBodies(3, n=13, m=17, pad_to=256, seed=5, device=dev)          # every rank holds the (small) dataset
-    model = deterministic_init(dc.SiameseModel("lap", 3), 11 + rank).to(dev).eval()   # BatchNorm frozen: pairs are exactly additive
+
+    def calm(m):
+        # frozen BatchNorm normalises with made-up running statistics: keep the activations (and the scores) of order one,
+        # or the loss is 1e11 and no two fp32 evaluation orders agree
+        with torch.no_grad():
+            for k, v in m.state_dict().items():
+                if k.endswith("fc.weight"):
+                    v.mul_(0.2)
+                elif k.endswith("running_mean"):
+                    v.zero_()
+                elif k.endswith("running_var"):
+                    v.fill_(4.0)
+        return m
+
+    model = calm(deterministic_init(dc.SiameseModel("lap", 3), 11 + rank)).to(dev).eval()   # BatchNorm frozen: pairs are exactly additive
     dp.broadcast_parameters(model, 0)
-    ref = deterministic_init(dc.SiameseModel("lap", 3), 11).to(dev).eval()
+    ref = calm(deterministic_init(dc.SiameseModel("lap", 3), 11)).to(dev).eval()
     model_g = copy.deepcopy(model)
     pairs = [(0, 1), (1, 2)]
     ia, ib = pairs[rank]
@@ -302,7 +316,9 @@ def test_correspondence_pairs_on_two_ranks_on_the_gpu():
     for rank, err, err_g, lerr, pdiff, same, backend in sorted(q.get(timeout=10) for _ in range(2)):
         assert err < 2e-5, f"rank {rank} ({backend}): all-reduced pair gradients differ from the two-pair gradient by {err:.2e}"
         assert err_g < 2e-5, f"rank {rank} ({backend}): replayed step: {err_g:.2e}"
-        assert lerr < 1e-5 and same and pdiff < 1e-6, (rank, lerr, pdiff, same)
+        # (the first Adam update is +-lr per parameter: where a gradient component is ~0 the two evaluation orders may disagree
+        #  on its sign, so eager and replayed parameters are compared to 2 lr; the replicas themselves must stay identical)
+        assert lerr < 1e-5 and same and pdiff <= 2.1e-3, (rank, lerr, pdiff, same)
 
 
 def test_bench_faust_workload_starts_two_ranks():
