@@ -722,6 +722,23 @@ int sn_linear_dgrad_eluseg_f32(const float *dy, int64_t lddy, const float *W, in
                                const float *center, const float *B, const float *Cc, const float *segvec,
                                int64_t rows_per_seg, const float *rowmask, float *gact, int64_t ldga, const float *gadd,
                                int64_t ldgadd, int64_t rows, int32_t J, int32_t C, void *stream);
+/* sn_linear_fwd_tiles_f32 / sn_linear_fwd_segbias_tiles_f32: the two forward launches above, which also leave the column sums of
+ * the ACTIVATED output per 32-row tile: tile_sums[(rows + 31) / 32][128] floats (every tile written; J = 128, with y_elu and
+ * elu_stats_part).  The half-width global-average stage that consumes y_elu (AvgResNet2, src/utils/utils_pt.py:230-243) then needs
+ * no statistics pass over it: sn_avg_stats_from_tiles_f32 forms the per-mesh masked sums from the tiles inside each mesh (rows
+ * of tiles shared by two meshes, and of tiles that hold a masked-out row, are read from e) and the BatchNorm sums from the
+ * statistics partials — the outputs of sn_avg_stats_f32 (m: nseg x C, stats: 2 x 2C fp64) without reading e
+ * (165 MB per stage at the ARAP batch).  workspace: nseg * C floats.  C = 128. */
+int sn_linear_fwd_tiles_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias, const float *residual,
+                            int64_t ldr, float *y, int64_t ldy, float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J,
+                            double *elu_stats_part, float *tile_sums, void *stream);
+int sn_linear_fwd_segbias_tiles_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
+                                    int64_t rows_per_seg, const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu,
+                                    int64_t lde, int64_t rows, int32_t K, int32_t J, double *elu_stats_part, float *tile_sums,
+                                    void *stream);
+int sn_avg_stats_from_tiles_f32(const float *tile_sums, const double *stats_part, int32_t nblk, const float *e, int64_t ld,
+                                const float *mask, const float *inv_count, int64_t rows_per_seg, int64_t nseg, int32_t C,
+                                float *m, double *stats, float *workspace, void *stream);
 /* The two per-mesh-vector kernels for RAGGED meshes (packed batches): mesh g owns rows [segoff[g], segoff[g+1]) (device
  * int64[nseg + 1], segoff[0] = 0, segoff[nseg] = rows, every mesh at least 32 rows — the caller's responsibility: a device
  * array is not validated here); no row mask (a packed batch has no padding rows). */

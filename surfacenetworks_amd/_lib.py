@@ -113,6 +113,10 @@ SIGNATURES = {
     "sn_laplacian_csr_from_mesh": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "sn_linear_fwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp]),
     "sn_linear_fwd_stats_blocks": (_i32, [_i64]),
+    "sn_linear_fwd_tiles_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
+    "sn_linear_fwd_segbias_tiles_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32,
+                                                  _vp, _vp, _vp]),
+    "sn_avg_stats_from_tiles_f32": (C.c_int, [_vp, _vp, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sn_colstats_into_f32": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _sz, _vp]),
     "sn_colstats_merge_f64": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _i64, _vp]),
     "sn_linear_dgrad_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32, _vp]),

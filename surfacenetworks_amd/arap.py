@@ -57,7 +57,11 @@ class Model(nn.Module):
     def forward(self, L, mask, inputs):
         x = self.conv1(inputs)
         for i in range(self.layer):
-            x = self._modules["rn{}".format(i)](L, mask, x)
+            blk = self._modules["rn{}".format(i)]
+            if i % 2 == 0 and isinstance(blk, utils.LapResNet2):
+                x = blk(L, mask, x, avg_next=i + 1 < self.layer)      # (a global-average block follows: hand it the tile sums)
+            else:
+                x = blk(L, mask, x)
         x = utils.elu_conv1x1(self.conv2, x)
         return _add_last_frame(x, inputs, OUTPUT_FRAMES)
 
@@ -118,7 +122,8 @@ class DirModel(nn.Module):
         for i in range(15):
             blk = self._modules["rn{}".format(i)]
             if i % 2 == 0:
-                v, f = blk(Di, DiA, v, f, f_out_needed=False, num_faces=nf)   # f only feeds the next Dirac block (models.py:139-147)
+                v, f = blk(Di, DiA, v, f, f_out_needed=False, num_faces=nf,   # f only feeds the next Dirac block (models.py:139-147)
+                           avg_next=i + 1 < 15)                                # (a global-average block follows: hand it the tile sums)
             else:
                 v = blk(None, mask, v)
         x = utils.elu_conv1x1(self.conv2, v)

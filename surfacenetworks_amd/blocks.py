@@ -69,10 +69,27 @@ def _new_part(rows, C, device, narrow=False):
     return kernels.new_elu_stats_part(rows, device)
 
 
-def _attach_part(cat, part):
-    """The statistics travel with the buffer object: bnlin_forward(cat, ...) then reads only the propagated half."""
+def _attach_part(cat, part, tiles=None):
+    """The statistics travel with the buffer object: bnlin_forward(cat, ...) then reads only the propagated half.
+    tiles: the per-tile column sums the same GEMM left (kernels.new_tile_sums) — a global-average block that consumes the buffer
+    then needs no statistics pass over it (functional.avg_stage_forward)."""
     if part is not None:
         cat._sn_part = part
+        if tiles is not None:
+            cat._sn_tiles = tiles
+
+
+def _new_tiles(rows, C, device, part, wanted):
+    """Tile-sum buffer for a forward GEMM whose activated output feeds a global-average block (or None)."""
+    if not wanted or part is None or C != 128 or not kernels.tile_sums_supported():
+        return None
+    return kernels.new_tile_sums(rows, device)
+
+
+def _tiles_of(cat):
+    """(tile sums, statistics partials) left on a concat buffer by the GEMM that wrote its first half, or None."""
+    t, p = getattr(cat, "_sn_tiles", None), getattr(cat, "_sn_part", None)
+    return (t, p) if (t is not None and p is not None) else None
 
 
 def _attach_hi(cat, part):
@@ -104,8 +121,8 @@ class _DiracBlock(torch.autograd.Function):
          cat0 = [elu(f), Di·elu(v)]  -> f_out = Lin(BN(cat0));   cat1 = [elu(v), DiA·elu(f_out)] -> v + Lin(BN(cat1))."""
 
     @staticmethod
-    def forward(ctx, v, f, opDi, opDiA, pre_v, pre_f, need_f, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1, rm1,
-                rv1, tr1, mo1, ep1):
+    def forward(ctx, v, f, opDi, opDiA, pre_v, pre_f, need_f, avg_next, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1,
+                rm1, rv1, tr1, mo1, ep1):
         v = _rows2d(v)
         rv, C = v.shape
         rf = opDi.shape[0] // 4
@@ -132,8 +149,9 @@ class _DiracBlock(torch.autograd.Function):
         _attach_hi(cat1, _launch(opDiA, nxt_f[:, :C], cat1[:, C:], 4, "fwd", stats=tr1))
         nxt_v = _new_cat(rv, C, v.device)
         pv = _new_part(rv, C, v.device, narrow=True)
-        v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C], elu_stats=pv)
-        _attach_part(nxt_v, pv)
+        tv = _new_tiles(rv, C, v.device, pv, avg_next)
+        v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C], elu_stats=pv, tile_sums=tv)
+        _attach_part(nxt_v, pv, tv)
         ctx.ops = (opDi, opDiA)
         stash(ctx, (cat0, cat1, nxt_f), st0, st1)
         ctx.mark_non_differentiable(nxt_v, nxt_f)
@@ -148,7 +166,7 @@ class _DiracBlock(torch.autograd.Function):
         dev = cat1.device
         none9 = (None,) * 9
         if g_vnew is None and g_fout is None:
-            return (None,) * 25
+            return (None,) * 26
         # Every ELU backward of the block is fused: the dgrad GEMM's epilogue sends the first half of a stage's input
         # gradient through the activation (h = dx[:, :C]·elu'(e) + the gradient of the other branch), and the transposed
         # product's store does the same for the propagated half:  (opᵀ·dx[:, C:])·elu'(e) + h.
@@ -182,13 +200,15 @@ class _DiracBlock(torch.autograd.Function):
                 g_v = h1
         if ctx.f_zero or not ctx.needs_input_grad[1]:
             g_f = None
-        return (g_v, g_f, None, None, None, None, None) + gp0 + gp1
+        return (g_v, g_f, None, None, None, None, None, None) + gp0 + gp1
 
 
-def dirac_block(mod, Di, DiA, v, f, need_f=True, num_faces=None):
+def dirac_block(mod, Di, DiA, v, f, need_f=True, num_faces=None, avg_next=False):
     """DirResNet2.forward on (B, V, C) / (B, F, C) tensors; `mod` supplies bn_fc0 / bn_fc1.  need_f=False: the returned
     face features are only a carrier of the activated hand-off for the next Dirac block (see _DiracBlock.forward).
-    f=None (with num_faces): all-zero face features, never materialised (zero_faces_ok says when)."""
+    f=None (with num_faces): all-zero face features, never materialised (zero_faces_ok says when).
+    avg_next: the vertex output feeds a global-average block next: the GEMM that writes its activated copy also leaves the
+    per-tile column sums that block needs (no statistics pass over its operand)."""
     B, V, C = v.shape
     F_ = f.shape[1] if f is not None else int(num_faces)
     rv, rf = B * V, B * F_
@@ -198,7 +218,7 @@ def dirac_block(mod, Di, DiA, v, f, need_f=True, num_faces=None):
     v_new, f_out, nxt_v, nxt_f = _DiracBlock.apply(v.reshape(rv, C), f.reshape(rf, C) if f is not None else None, opDi, opDiA,
                                                   take_activated(v, rv, C),
                                                   take_activated(f, rf, C) if f is not None else None, bool(need_f),
-                                                  *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+                                                  bool(avg_next), *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
     return attach_activated(v_new.view(B, V, C), nxt_v), attach_activated(f_out.view(B, F_, C), nxt_f)
 
 
@@ -213,8 +233,8 @@ class _PropagateBlock(torch.autograd.Function):
     same propagation P — the sparse product with L, or the per-mesh masked mean broadcast back (global_average)."""
 
     @staticmethod
-    def forward(ctx, x, op, mask_rows, inv_count, nseg, pre, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1, rm1,
-                rv1, tr1, mo1, ep1):
+    def forward(ctx, x, op, mask_rows, inv_count, nseg, pre, avg_next, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1,
+                rm1, rv1, tr1, mo1, ep1):
         x = _rows2d(x)
         rows, C = x.shape
         per = rows // nseg if nseg else 0
@@ -237,8 +257,9 @@ class _PropagateBlock(torch.autograd.Function):
         propagate(cat_b, tr1)
         nxt = _new_cat(rows, C, x.device)
         pn = _new_part(rows, C, x.device)
-        out, st1 = bnlin_forward(cat_b, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x, nxt[:, :C], elu_stats=pn)
-        _attach_part(nxt, pn)
+        tn = _new_tiles(rows, C, x.device, pn, avg_next)
+        out, st1 = bnlin_forward(cat_b, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x, nxt[:, :C], elu_stats=pn, tile_sums=tn)
+        _attach_part(nxt, pn, tn)
         ctx.op, ctx.seg = op, (mask_rows, inv_count, nseg, per)
         stash(ctx, (cat_a, cat_b), st0, st1)
         ctx.mark_non_differentiable(nxt)
@@ -252,7 +273,7 @@ class _PropagateBlock(torch.autograd.Function):
         (cat_a, cat_b), st0, st1 = unstash(ctx)
         C = cat_a.shape[1] // 2
         if g_out is None:
-            return (None,) * 24
+            return (None,) * 25
         g_out = g_out.contiguous()
 
         def stage_backward(st, g_in, cat, gadd):
@@ -273,7 +294,7 @@ class _PropagateBlock(torch.autograd.Function):
         g_x, dg0, db0, dW0, dc0 = stage_backward(st0, g_h, cat_a, g_out)              # + residual-path gradient
         if not ctx.needs_input_grad[0]:
             g_x = None
-        return (g_x, None, None, None, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None,
+        return (g_x, None, None, None, None, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None,
                 None, None, None, None)
 
 
@@ -288,14 +309,20 @@ class _AvgBlock(torch.autograd.Function):
         x = _rows2d(x)
         rows, C = x.shape
         per = rows // nseg
-        e_a = _activated(x, pre)[:, :C]
+        cat = _activated(x, pre)
+        e_a = cat[:, :C]
         e_b = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+        # per-mesh means and BatchNorm sums of a stage's operand: from what the GEMM that wrote it left (per-tile column sums +
+        # statistics partials) when there is such a producer — else one statistics pass over the operand
+        pb = _new_part(rows, C, x.device)
+        tb = _new_tiles(rows, C, x.device, pb, True)
         _, st0 = avg_stage_forward(e_a, mask_rows, inv_count, nseg, per, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, e_b,
-                                   want_y=False)                      # only elu(h) is needed downstream
+                                   want_y=False, elu_stats=pb if tb is not None else None, tile_sums=tb,
+                                   e_tiles=_tiles_of(cat))             # only elu(h) is needed downstream
         nxt = _new_cat(rows, C, x.device)
         pn = _new_part(rows, C, x.device)
         out, st1 = avg_stage_forward(e_b, mask_rows, inv_count, nseg, per, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x,
-                                     nxt[:, :C], elu_stats=pn)
+                                     nxt[:, :C], elu_stats=pn, e_tiles=(tb, pb) if tb is not None else None)
         _attach_part(nxt, pn)
         stash(ctx, st0, st1, (mask_rows, inv_count))
         ctx.seg = (nseg, per)
@@ -412,13 +439,13 @@ def elu_conv_ok(conv, v) -> bool:
         conv.bn.affine and conv.bn.momentum is not None and conv.bn.track_running_stats
 
 
-def lap_block(mod, L, inputs):
+def lap_block(mod, L, inputs, avg_next=False):
     B, V, C = inputs.shape
     rows = B * V
     op = as_operator(L)
     if op.shape != (rows, rows):
         raise ValueError(f"LapResNet2: operator {tuple(op.shape)} vs {rows} rows")
-    out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), op, None, None, 0, take_activated(inputs, rows, C),
+    out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), op, None, None, 0, take_activated(inputs, rows, C), bool(avg_next),
                                      *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
     return attach_activated(out.view(B, V, C), nxt)
 
@@ -453,5 +480,5 @@ def avg_block(mod, mask, inputs):
         out, nxt = _AvgBlock.apply(inputs.reshape(rows, C), mask_rows, inv_count, B, take_activated(inputs, rows, C), *a0, *a1)
     else:
         out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), None, mask_rows, inv_count, B, take_activated(inputs, rows, C),
-                                         *a0, *a1)
+                                         False, *a0, *a1)
     return attach_activated(out.view(B, V, C), nxt)

@@ -1786,6 +1786,109 @@ __global__ __launch_bounds__(kWG) void avg_bwd_segvec_k(const float *__restrict_
   out[t] = (float)(acc * (double)inv_count[g]);
 }
 
+// The same quantities WITHOUT a pass over e, when the GEMM that wrote e left (a) the column sums of every 32-row tile
+// (EpiArgs::tile_sums, sn_linear_fwd_tiles_f32) and (b) its per-workgroup column sums / sums of squares (the statistics
+// partials).  Mesh g owns rows [g·per, (g+1)·per): the tiles that lie entirely inside it contribute their stored sums, the
+// rows of the (at most two) tiles it shares with its neighbours are read from e; with a row mask every tile's 32 mask values
+// are read first and a tile that holds a masked-out row is summed from e as well (prefix masks: one tile per mesh).
+// grid (C / 32, nseg), 256 threads = 8 four-column chunks x 32 tile lanes; ssum[nseg][C] fp32 (fp64 across tiles).
+__global__ __launch_bounds__(kWG) void segsum_tiles_k(const float *__restrict__ tile_sums, const float *__restrict__ e, int64_t lde,
+                                                      const float *__restrict__ mask, int64_t per, int C,
+                                                      float *__restrict__ ssum) {
+  __shared__ double sm[32][8][4];
+  const int chunk = threadIdx.x & 7, tl = threadIdx.x >> 3;
+  const int c = blockIdx.x * 32 + 4 * chunk;
+  const int64_t g = blockIdx.y;
+  const int64_t a = g * per, b = a + per;                      // rows of the mesh
+  const int64_t t0 = (a + 31) / 32, t1 = b / 32;                 // whole tiles: [t0, t1)
+  double s[4] = {0, 0, 0, 0};
+  auto rows_from_e = [&](int64_t r0, int64_t r1) {               // masked sums of rows [r0, r1) of e, my 4 columns
+    for (int64_t r = r0; r < r1; ++r) {
+      const float mk = mask ? mask[r] : 1.f;
+      if (mk != 0.f) {
+        const f4 v = *reinterpret_cast<const f4 *>(e + r * lde + c);
+        s[0] += (double)(mk * v.x); s[1] += (double)(mk * v.y); s[2] += (double)(mk * v.z); s[3] += (double)(mk * v.w);
+      }
+    }
+  };
+  if (t0 >= t1) {                                                // (a mesh shorter than a tile)
+    if (tl == 0) rows_from_e(a, b);
+  } else {
+    const int64_t nt = t1 - t0;
+    for (int64_t i = 0; i < (nt + 31) / 32 * 32; i += 32) {      // (uniform trip count: the vote below needs the whole wave)
+      const int64_t t = t0 + i + tl;
+      bool clean = true;
+      if (mask) {
+        // the tile's 32 mask values: one 16-byte piece per chunk lane, combined by a vote among the 8 lanes of the tile
+        bool mine = true;
+        if (t < t1) {
+          const f4 mv = *reinterpret_cast<const f4 *>(mask + 32 * t + 4 * chunk);      // (32 t: 128-byte aligned)
+          mine = mv.x == 1.f && mv.y == 1.f && mv.z == 1.f && mv.w == 1.f;
+        }
+        const unsigned long long votes = __ballot(mine);
+        clean = ((votes >> (8 * ((threadIdx.x & 63) >> 3))) & 0xffull) == 0xffull;
+      }
+      if (t >= t1) continue;
+      if (clean) {
+        const f4 v = *reinterpret_cast<const f4 *>(tile_sums + t * 128 + c);
+        s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+      } else {
+        rows_from_e(32 * t, 32 * t + 32);                        // (a tile with masked-out rows: one per mesh with prefix masks)
+      }
+    }
+    // the rows before the first / after the last whole tile (fewer than 32 each): one row per tile lane, all in flight at once
+    if (a + tl < 32 * t0) rows_from_e(a + tl, a + tl + 1);
+    if (32 * t1 + tl < b) rows_from_e(32 * t1 + tl, 32 * t1 + tl + 1);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) sm[tl][chunk][k] = s[k];
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int ch = threadIdx.x >> 2, k = threadIdx.x & 3;
+    double t = 0;
+#pragma unroll 8
+    for (int l = 0; l < 32; ++l) t += sm[l][ch][k];
+    ssum[g * C + blockIdx.x * 32 + 4 * ch + k] = (float)t;
+  }
+}
+// m and the BatchNorm statistics of [e | m broadcast] from the per-mesh sums and the producer's statistics partials
+// (part[nblk][2][C] fp64): avg_fwd_prep_k with the merge of the partials in front.  8 columns x 32 lanes per workgroup: the
+// lanes share the partial blocks and the meshes (a few dozen independent loads each), fixed-order sums through LDS.
+__global__ __launch_bounds__(kWG) void avg_prep_parts_k(const float *__restrict__ ssum, const float *__restrict__ inv_count, int nseg,
+                                                        int C, double per, const double *__restrict__ part, int nblk,
+                                                        float *__restrict__ m, double *__restrict__ stats) {
+  __shared__ double sm[4][32][8];
+  const int cl = threadIdx.x & 7, ln = threadIdx.x >> 3;
+  const int c = blockIdx.x * 8 + cl;
+  double u = 0, q = 0, s1 = 0, s2 = 0;
+#pragma unroll 4
+  for (int b = ln; b < nblk; b += 32) {
+    u += part[(int64_t)b * 2 * C + c];
+    q += part[(int64_t)b * 2 * C + C + c];
+  }
+#pragma unroll 2
+  for (int g = ln; g < nseg; g += 32) {
+    const float mv = ssum[(int64_t)g * C + c] * inv_count[g];
+    m[(int64_t)g * C + c] = mv;
+    s1 += (double)mv;
+    s2 += (double)mv * (double)mv;
+  }
+  sm[0][ln][cl] = u; sm[1][ln][cl] = q; sm[2][ln][cl] = s1; sm[3][ln][cl] = s2;
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int what = threadIdx.x >> 3, col = threadIdx.x & 7;
+    double t = 0;
+#pragma unroll 8
+    for (int l = 0; l < 32; ++l) t += sm[what][l][col];
+    const int cc = blockIdx.x * 8 + col;
+    // stats layout (2 x 2C): [ sum e | per sum m ; sum e^2 | per sum m^2 ]
+    if (what == 0) stats[cc] = t;
+    else if (what == 1) stats[2 * C + cc] = t;
+    else if (what == 2) stats[C + cc] = per * t;
+    else stats[3 * C + cc] = per * t;
+  }
+}
+
 // One pass over e for everything the half-width global-average stage needs from it: per-mesh MASKED column sums (-> the
 // mean m), and the unmasked column sums / sums of squares of all rows (-> BatchNorm statistics of the first half).
 // Stage 1: grid (kSegSlabs, nseg), partial[mesh][slab][3][C] fp64 (masked sum | sum | sum of squares).
@@ -3377,6 +3480,23 @@ int sn_avg_stats_f32(const float *e, int64_t ld, const float *mask, const float 
   hipLaunchKernelGGL(segstats_k, dim3(nslab, (unsigned)nseg), dim3(kWG), shm, s, e, ld, mask, rows_per_seg, (int)C, partial);
   hipLaunchKernelGGL(segstats_final_k, dim3((unsigned)((C + kSegFinalCols - 1) / kSegFinalCols)), dim3(kSegFinalCols * kSegFinalLanes), 0, s, partial, nslab, (int)nseg, (int)C,
                      inv_count, (double)rows_per_seg, m, stats);
+  return launch_status();
+}
+
+int sn_avg_stats_from_tiles_f32(const float *tile_sums, const double *stats_part, int32_t nblk, const float *e, int64_t ld,
+                                const float *mask, const float *inv_count, int64_t rows_per_seg, int64_t nseg, int32_t C,
+                                float *m, double *stats, float *workspace, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (rows_per_seg < 1 || nseg < 1 || C != 128 || ld < C || nblk < 0) return SN_E_SHAPE;
+  if (ld % 4) return SN_E_UNSUPPORTED;
+  if (!tile_sums || !stats_part || !e || !inv_count || !m || !stats || !workspace) return SN_E_NULL;
+  if (!aligned16(e) || !aligned16(tile_sums) || (mask && !aligned16(mask))) return SN_E_ALIGN;
+  if (nseg > 65535) return SN_E_RANGE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(segsum_tiles_k, dim3((unsigned)(C / 32), (unsigned)nseg), dim3(kWG), 0, s, tile_sums, e, ld, mask, rows_per_seg,
+                     (int)C, workspace);
+  hipLaunchKernelGGL(avg_prep_parts_k, dim3((unsigned)(C / 8)), dim3(kWG), 0, s, workspace, inv_count, (int)nseg, (int)C,
+                     (double)rows_per_seg, stats_part, (int)nblk, m, stats);
   return launch_status();
 }
 

@@ -83,6 +83,11 @@ struct EpiArgs {
   // walk ONE contiguous window of every operand together instead of 256 separate streams each: same-box A/B of the config-3
   // step on three boxes, round 4: 19.99 -> 19.46, 20.38 -> 19.80, 19.84 -> 19.77 ms).
   int interleave;
+  // forward with an ELU copy (one-tile kernels): tile_sums[tile][128] <- column sums of the ACTIVATED output over the tile's
+  // valid rows (fp32; every tile written exactly once).  What the half-width global-average stage needs of its operand beyond
+  // the BatchNorm sums: per-mesh column sums follow from the tiles inside a mesh (sn_avg_stats_from_tiles_f32), so the
+  // statistics pass over the operand (segstats_k: 165 MB per stage at the ARAP batch) disappears.  NULL: not wanted.
+  float *tile_sums;
 };
 constexpr int kAbsmaxBlocks = 512;      // >= the largest grid of any input-gradient launch (2 workgroups per CU)
 
@@ -812,6 +817,7 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
         for (int j = 0; j < NST; ++j) bst4(r_out, vo_out + j * js_out, out_row(j));
       }
     } else {
+      f4 tsum = {0.f, 0.f, 0.f, 0.f};                // STATS: this tile's column sums of elu(y) over my rows (EpiArgs::tile_sums)
 #pragma unroll
       for (int j = 0; j < NST; ++j) {
         const f4 v = out_row(j);
@@ -825,8 +831,19 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
               ssum[0] += e0; ssum[1] += e1; ssum[2] += e2; ssum[3] += e3;
               ssq[0] = __builtin_fma(e0, e0, ssq[0]); ssq[1] = __builtin_fma(e1, e1, ssq[1]);
               ssq[2] = __builtin_fma(e2, e2, ssq[2]); ssq[3] = __builtin_fma(e3, e3, ssq[3]);
+              tsum += ev;
             }
           }
+        }
+      }
+      if constexpr (STATS) {
+        if (ep.tile_sums) {                          // add the 8 row lanes of a chunk (lanes chunk + 8 erow), fixed butterfly
+#pragma unroll
+          for (int o = CPR; o < 64; o <<= 1) {
+            tsum.x += __shfl_xor(tsum.x, o); tsum.y += __shfl_xor(tsum.y, o);
+            tsum.z += __shfl_xor(tsum.z, o); tsum.w += __shfl_xor(tsum.w, o);
+          }
+          if (erow == 0) *reinterpret_cast<f4 *>(ep.tile_sums + tl * 128 + ecol) = tsum;
         }
       }
     }
@@ -1214,7 +1231,14 @@ int32_t sn_linear_fwd_stats_blocks(int64_t rows) { return rows > 0 ? (int32_t)ge
 int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias,
                       const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu, int64_t lde,
                       int64_t rows, int32_t K, int32_t J, double *elu_stats_part, void *stream) {
+  return sn_linear_fwd_tiles_f32(x, ldx, W, ldw, bias, residual, ldr, y, ldy, y_elu, lde, rows, K, J, elu_stats_part, nullptr, stream);
+}
+
+int sn_linear_fwd_tiles_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *bias,
+                            const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu, int64_t lde,
+                            int64_t rows, int32_t K, int32_t J, double *elu_stats_part, float *tile_sums, void *stream) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (tile_sums && (!elu_stats_part || J != 128)) return SN_E_UNSUPPORTED;      // (rides on the statistics epilogue, full width)
   if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J)) return SN_E_SHAPE;
   if (J > 128 || (J % 4) || (J != 128 && gemm_variant() == 0) || (K != 128 && K != 256) || !ld32(ldx, ldy, ldr, lde))
     return SN_E_UNSUPPORTED;
@@ -1225,7 +1249,7 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
     return SN_E_ALIGN;
   if (elu_stats_part && (!y_elu || gemm_variant() == 0)) return SN_E_UNSUPPORTED;
   EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr, elu_stats_part,
-             sn_linear_fwd_stats_blocks(rows), (int)J, nullptr, 0, nullptr, gemm_interleave()};
+             sn_linear_fwd_stats_blocks(rows), (int)J, nullptr, 0, nullptr, gemm_interleave(), tile_sums};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const bool x3 = gemm_variant() != 0;
@@ -1244,7 +1268,7 @@ int sn_linear_fwd_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, 
   // residual and two outputs the three half-line streams cost more than the second wave per SIMD gains); 3 every K = 256
   // launch; 2 every launch (A/B)
   const int w8 = gemm_w8();
-  if (gemm_variant() == 2 && J == 128 && rows > kSmallRows &&
+  if (gemm_variant() == 2 && J == 128 && rows > kSmallRows && !tile_sums &&
       (w8 == 2 || (w8 == 3 && K == 256) || (w8 == 1 && K == 256 && !residual && y_elu && !y))) {
     const unsigned grid8 = gemm_grid(rows, 1);
     const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
@@ -1293,7 +1317,7 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx) || (lddy % 4) || (ldw % 4) || (lddx % 4)) return SN_E_ALIGN;
   if (B && (!aligned16(x) || !aligned16(B) || !aligned16(Cc) || (center && !aligned16(center)) || (ldx % 4) || ldx < C))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, nullptr, gemm_interleave()};
+  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, nullptr, gemm_interleave(), nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   const bool x3 = gemm_variant() != 0;
@@ -1343,7 +1367,7 @@ int sn_linear_dgrad_elu_absmax_f32(const float *dy, int64_t lddy, const float *W
       (lddy % 4) || (ldw % 4) || (lddx % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   const int half = C / 2;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, gact_absmax, gemm_interleave()};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, gact_absmax, gemm_interleave(), nullptr};
   float *out = dx_hi - half;           // the kernel indexes absolute columns; only columns >= half are written through `out`
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
@@ -1363,7 +1387,7 @@ int sn_linear_dgrad_elu_absmax_f32(const float *dy, int64_t lddy, const float *W
 static int fwd_segbias_launch(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
                               int64_t rows_per_seg, const int64_t *segoff, int32_t nseg, const float *residual, int64_t ldr,
                               float *y, int64_t ldy, float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J,
-                              double *elu_stats_part, void *stream) {
+                              double *elu_stats_part, void *stream, float *tile_sums = nullptr) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || K < 1 || J < 1 || ldx < K || ldw < K || (y && ldy < J) || (!segoff && rows_per_seg < 1) || (segoff && nseg < 1))
     return SN_E_SHAPE;
@@ -1376,8 +1400,9 @@ static int fwd_segbias_launch(const float *x, int64_t ldx, const float *W, int64
       (residual && (!aligned16(residual) || (ldr % 4) || ldr < J)) || (y_elu && (!aligned16(y_elu) || (lde % 4) || lde < J)))
     return SN_E_ALIGN;
   if (elu_stats_part && !y_elu) return SN_E_UNSUPPORTED;
+  if (tile_sums && (!elu_stats_part || J != 128)) return SN_E_UNSUPPORTED;
   EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, segoff ? 0 : rows_per_seg, J, nullptr,
-             elu_stats_part, sn_linear_fwd_stats_blocks(rows), (int)J, segoff, nseg, nullptr, gemm_interleave()};
+             elu_stats_part, sn_linear_fwd_stats_blocks(rows), (int)J, segoff, nseg, nullptr, gemm_interleave(), tile_sums};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   hipEvent_t t_start = nullptr, t_stop = nullptr;
@@ -1402,6 +1427,14 @@ int sn_linear_fwd_segbias_f32(const float *x, int64_t ldx, const float *W, int64
                               int64_t lde, int64_t rows, int32_t K, int32_t J, double *elu_stats_part, void *stream) {
   return fwd_segbias_launch(x, ldx, W, ldw, segbias, rows_per_seg, nullptr, 0, residual, ldr, y, ldy, y_elu, lde, rows, K, J,
                             elu_stats_part, stream);
+}
+
+int sn_linear_fwd_segbias_tiles_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
+                                    int64_t rows_per_seg, const float *residual, int64_t ldr, float *y, int64_t ldy, float *y_elu,
+                                    int64_t lde, int64_t rows, int32_t K, int32_t J, double *elu_stats_part, float *tile_sums,
+                                    void *stream) {
+  return fwd_segbias_launch(x, ldx, W, ldw, segbias, rows_per_seg, nullptr, 0, residual, ldr, y, ldy, y_elu, lde, rows, K, J,
+                            elu_stats_part, stream, tile_sums);
 }
 
 int sn_linear_fwd_segbias_ragged_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
@@ -1436,7 +1469,7 @@ static int dgrad_eluseg_launch(const float *dy, int64_t lddy, const float *W, in
       (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C)) || (lddy % 4) || (ldw % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, (segvec && !segoff) ? rows_per_seg : 0, C, rowmask,
-             nullptr, 0, (int)J, segoff, nseg, gact_absmax, gemm_interleave()};
+             nullptr, 0, (int)J, segoff, nseg, gact_absmax, gemm_interleave(), nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   hipEvent_t t_start = nullptr, t_stop = nullptr;

@@ -455,7 +455,7 @@ def _fold_sources(x, part, part_hi, pre_stats):
 
 
 def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual=None, elu_out=None,
-                  want_y=True, elu_stats=None, pre_stats=None):
+                  want_y=True, elu_stats=None, pre_stats=None, tile_sums=None):
     """Forward of the folded BatchNorm1d("pre") + Linear on a (rows, C) operand (no autograd): statistics in one pass
     (fp64 accumulation), BN folded into the weights  y = x·(W·diag(s))ᵀ + (b + W·t),  s = gamma*invstd, t = beta - mean*s,
     optional residual add and ELU copy in the GEMM epilogue.  Returns (y, state) with `state` for bnlin_backward."""
@@ -490,7 +490,7 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     if residual is not None:
         residual = _rows2d(residual)
     if kernels.linear_fwd_supported(x.shape[1], W.shape[0]):
-        y = kernels.linear_fwd(x, Wf, bf, residual, elu_out, want_y, elu_stats)   # row-streaming GEMM, weights in registers
+        y = kernels.linear_fwd(x, Wf, bf, residual, elu_out, want_y, elu_stats, tile_sums)   # row-streaming GEMM, weights in registers
     else:
         if elu_stats is not None:
             raise ValueError("bnlin_forward: elu_stats needs a shape the fused GEMM covers")
@@ -657,21 +657,25 @@ def bnlin_backward_elu_input(state, dy):
 
 
 def avg_stage_forward(e, mask_rows, inv_count, nseg, per, gamma, beta, W, b, running_mean, running_var, training, momentum,
-                      eps, residual=None, elu_out=None, want_y=True, elu_stats=None):
+                      eps, residual=None, elu_out=None, want_y=True, elu_stats=None, tile_sums=None, e_tiles=None):
     """One stage of AvgResNet2 (utils_pt.py:230-243), Lin(BN([e | global_average(e) broadcast])), at HALF width: the second
     half of the concat buffer is a per-mesh constant m, so it is never materialised — its BatchNorm statistics follow from
     m (nseg x C numbers), its share of the Linear product is a per-mesh bias m·Wf[:, C:]^T + bf, and the GEMM runs over the
     C real columns only.  Training-mode BatchNorm only (the caller checks kernels.avg_stage_supported)."""
     e = _rows2d(e)
     rows, C = e.shape
-    m, stats = kernels.avg_stats(e, mask_rows, inv_count, per, nseg)       # per-mesh mean + BatchNorm statistics, one pass over e
+    if e_tiles is not None:
+        # the GEMM that wrote e left its per-tile column sums and its statistics partials: no pass over e
+        m, stats = kernels.avg_stats_from_tiles(e_tiles[0], e_tiles[1], e, mask_rows, inv_count, per, nseg)
+    else:
+        m, stats = kernels.avg_stats(e, mask_rows, inv_count, per, nseg)       # per-mesh mean + BatchNorm statistics, one pass over e
     stats, rows_g = _sync_stats(stats, rows)
     mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, True, running_mean, running_var,
                                                  _take_counter(running_mean))
     segb = kernels.seg_affine(m, Wf[:, C:], bf)
     if residual is not None:
         residual = _rows2d(residual)
-    y = kernels.linear_fwd_segbias(e, Wf[:, :C], segb, per, residual, elu_out, want_y, elu_stats)
+    y = kernels.linear_fwd_segbias(e, Wf[:, :C], segb, per, residual, elu_out, want_y, elu_stats, tile_sums)
     return y, (e, m, W, Wf, s, mean, invstd, beta, b is not None, rows_g)
 
 

@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 __all__ = [
-    "note_absmax", "take_absmax", "absmax_wanted", "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "spmm_ring", "spmm_ring_stats", "spmm_ring_supported", "ring_half_window", "csr_band", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged", "validate_csr",
+    "note_absmax", "take_absmax", "absmax_wanted", "tile_sums_supported", "new_tile_sums", "avg_stats_from_tiles", "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "spmm_ring", "spmm_ring_stats", "spmm_ring_supported", "ring_half_window", "csr_band", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged", "validate_csr",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
@@ -735,20 +735,51 @@ def new_elu_stats_part(rows: int, device):
     return torch.empty((max(nblk, 1), 2, 128), dtype=torch.float64, device=device)
 
 
-def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y: bool = True, elu_stats=None):
+def tile_sums_supported() -> bool:
+    """The forward kernels can leave per-tile column sums of their ELU output (sn_linear_fwd_tiles_f32): split kernels only."""
+    import os
+
+    return elu_stats_supported() and os.environ.get("SN_TILE_SUMS", "1") != "0"
+
+
+def new_tile_sums(rows: int, device):
+    """Buffer for the per-tile column sums of a forward GEMM's ELU output: ((rows + 31) // 32, 128) fp32."""
+    return torch.empty(((rows + 31) // 32, 128), dtype=torch.float32, device=device)
+
+
+def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y: bool = True, elu_stats=None, tile_sums=None):
     """y = x·Wᵀ + bias (+ residual); optionally also writes elu(y) into the 2-D view `y_elu` (sn_linear_fwd_f32).
     want_y=False (with y_elu): only the activated copy is written and None is returned.
-    elu_stats (from new_elu_stats_part): receives the column statistics of elu(y), see colstats_halves."""
-    _dev(x, W, bias, residual, y_elu, elu_stats)
+    elu_stats (from new_elu_stats_part): receives the column statistics of elu(y), see colstats_halves.
+    tile_sums (from new_tile_sums, with elu_stats): receives the column sums of elu(y) per 32-row tile (avg_stats_from_tiles)."""
+    _dev(x, W, bias, residual, y_elu, elu_stats, tile_sums)
     rows, K = x.shape
     J = W.shape[0]
     # (the fp32-MFMA A/B kernels, SN_GEMM_VARIANT=0, always write y)
     keep = want_y or y_elu is None
     y = torch.empty((rows, J), dtype=torch.float32, device=x.device) if (keep or not elu_stats_supported()) else None
-    _lib.call("sn_linear_fwd_f32", _p(x), _ld(x), _p(W), _ld(W), _p(bias), _p(residual),
+    _lib.call("sn_linear_fwd_tiles_f32", _p(x), _ld(x), _p(W), _ld(W), _p(bias), _p(residual),
               _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu), _ld(y_elu) if y_elu is not None else 0,
-              rows, K, J, _p(elu_stats), _stream())
+              rows, K, J, _p(elu_stats), _p(tile_sums), _stream())
     return y if keep else None
+
+
+def avg_stats_from_tiles(tile_sums, part, e, mask, inv_count, rows_per_seg: int, nseg: int):
+    """(m, stats) of avg_stats WITHOUT a pass over e: from the per-tile column sums and the statistics partials the GEMM that
+    wrote e left (sn_avg_stats_from_tiles_f32)."""
+    _dev(tile_sums, part, e, mask, inv_count)
+    rows, C = e.shape
+    if tile_sums.shape != ((rows + 31) // 32, 128) or part.dim() != 3 or part.shape[1:] != (2, 128) or part.dtype != torch.float64:
+        raise ValueError("avg_stats_from_tiles: tile sums / statistics partials of another operand")
+    nblk = int(_lib.load().sn_linear_fwd_stats_blocks(rows))
+    if part.shape[0] < nblk:
+        raise ValueError("avg_stats_from_tiles: partial buffer smaller than the producing launch's grid")
+    m = torch.empty((nseg, C), dtype=torch.float32, device=e.device)
+    stats = torch.empty((2, 2 * C), dtype=torch.float64, device=e.device)
+    ws = torch.empty((nseg, C), dtype=torch.float32, device=e.device)
+    _lib.call("sn_avg_stats_from_tiles_f32", _p(tile_sums), _p(part), nblk, _p(e), _ld(e), _p(mask), _p(inv_count.contiguous()),
+              rows_per_seg, nseg, C, _p(m), _p(stats), _p(ws), _stream())
+    return m, stats
 
 
 def colstats_from_part(part, rows: int):
@@ -1146,15 +1177,17 @@ def masked_smooth_l1_bwd(out2d, target2d, rowmask, scale: float, gloss):
     return g
 
 
-def linear_fwd_segbias(x, W, segbias, rows_per_seg: int, residual=None, y_elu=None, want_y: bool = True, elu_stats=None):
-    """y = x·W^T + segbias[row // rows_per_seg] (+ residual), optionally elu(y) into y_elu; want_y=False: only y_elu is written."""
-    _dev(x, W, segbias, residual, y_elu)
+def linear_fwd_segbias(x, W, segbias, rows_per_seg: int, residual=None, y_elu=None, want_y: bool = True, elu_stats=None,
+                       tile_sums=None):
+    """y = x·W^T + segbias[row // rows_per_seg] (+ residual), optionally elu(y) into y_elu; want_y=False: only y_elu is written.
+    tile_sums: as linear_fwd."""
+    _dev(x, W, segbias, residual, y_elu, tile_sums)
     rows, K = x.shape
     J = W.shape[0]
     y = torch.empty((rows, J), dtype=torch.float32, device=x.device) if want_y else None
-    _lib.call("sn_linear_fwd_segbias_f32", _p(x), _ld(x), _p(W), _ld(W), _p(segbias), rows_per_seg, _p(residual),
+    _lib.call("sn_linear_fwd_segbias_tiles_f32", _p(x), _ld(x), _p(W), _ld(W), _p(segbias), rows_per_seg, _p(residual),
               _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu), _ld(y_elu) if y_elu is not None else 0,
-              rows, K, J, _p(elu_stats), _stream())
+              rows, K, J, _p(elu_stats), _p(tile_sums), _stream())
     return y
 
 

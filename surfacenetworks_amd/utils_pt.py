@@ -189,13 +189,15 @@ class DenseLapResNet2(_TwoStage):
 class LapResNet2(_TwoStage):
     """x + Lin(BN([e1, L e1])), e1 = elu(Lin(BN([e0, L e0]))), e0 = elu(x)   (utils_pt.py:151-180)."""
 
-    def forward(self, L, mask, inputs):
+    def forward(self, L, mask, inputs, avg_next=False):
+        """avg_next=True (not in the reference's signature): the output feeds an AvgResNet2 next — the second GEMM then also
+        leaves the per-tile column sums that block needs of its operand (no statistics pass over it)."""
         if isinstance(L, torch.Tensor) and L.layout == torch.strided:
             return DenseLapResNet2.forward(self, L, mask, inputs)
         batch, node, feat = inputs.size()
         op = as_operator(L)
         if _blocks_ok(self, inputs):
-            return snB.lap_block(self, op, inputs)                              # the whole block as one autograd node
+            return snB.lap_block(self, op, inputs, avg_next)                    # the whole block as one autograd node
         x2d = inputs.reshape(batch * node, feat)
         h = self.bn_fc0.forward2d(snF.lap_propagate(op, x2d))
         h = self.bn_fc1.forward2d(snF.lap_propagate(op, h), residual=x2d)        # "+ inputs" rides in the GEMM epilogue
@@ -210,23 +212,25 @@ class DirResNet2(_TwoStage):
         super().__init__(num_outputs)
         self.res_f = res_f          # accepted and unused, as in the reference (utils_pt.py:189)
 
-    def forward(self, Di, DiA, v, f, f_out_needed=True, num_faces=None):
+    def forward(self, Di, DiA, v, f, f_out_needed=True, num_faces=None, avg_next=False):
         """f_out_needed=False (not in the reference's signature): the caller promises to use the returned face features ONLY
         as the `f` argument of the next DirResNet2 — the block then skips writing them (the next block reads the activated
         copy handed over internally) and returns a NaN placeholder of the right shape in their place.
         f=None with num_faces=F (not in the reference's signature either): the face features are all zero — what every
         model of the reference feeds its first Dirac block (as_rigid_as_possible/models.py:138) — and are not materialised:
-        the face stage runs over the propagated half only (same values)."""
+        the face stage runs over the propagated half only (same values).
+        avg_next=True (not in the reference's signature): the vertex output feeds an AvgResNet2 next (as in every model of the
+        reference): the vertex-stage GEMM also leaves the per-tile column sums that block needs of its operand."""
         batch_size, num_nodes, num_inputs = v.size()
         if f is None:
             if num_faces is None:
                 raise ValueError("DirResNet2: f=None needs num_faces")
             if _blocks_ok(self, v) and snB.zero_faces_ok(self, num_inputs):
-                return snB.dirac_block(self, Di, DiA, v, None, f_out_needed, num_faces)
+                return snB.dirac_block(self, Di, DiA, v, None, f_out_needed, num_faces, avg_next)
             f = torch.zeros(batch_size, int(num_faces), num_inputs, dtype=v.dtype, device=v.device)
         _, num_faces, _ = f.size()
         if _blocks_ok(self, v):
-            return snB.dirac_block(self, Di, DiA, v, f, f_out_needed)           # the whole block as one autograd node
+            return snB.dirac_block(self, Di, DiA, v, f, f_out_needed, None, avg_next)   # the whole block as one autograd node
         v2d = v.reshape(batch_size * num_nodes, num_inputs)
         cat0, e_v = snF.dirac_face_stage(as_operator(Di), v2d, f.reshape(batch_size * num_faces, num_inputs))
         f_out = self.bn_fc0.forward2d(cat0)

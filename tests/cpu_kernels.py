@@ -197,6 +197,18 @@ def absmax_wanted():
     return False          # the host twins have one weight gradient (exact): no bounds are produced or consumed
 
 
+def tile_sums_supported():
+    return False          # the host twins always take the statistics pass over the operand
+
+
+def new_tile_sums(rows, device):
+    return None
+
+
+def avg_stats_from_tiles(*a, **k):
+    raise RuntimeError("host twins: no tile sums")
+
+
 def note_absmax(t, maxima):
     pass
 
@@ -484,7 +496,7 @@ def spmm_ring_stats(rowptr, colind, vals, M, K, x, y):
     return part
 
 
-def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y=True, elu_stats=None):
+def linear_fwd(x, W, bias, residual=None, y_elu=None, want_y=True, elu_stats=None, tile_sums=None):
     y = (x.double() @ W.double().t() + bias.double()).float()
     if residual is not None:
         y = y + residual
@@ -618,7 +630,7 @@ def masked_smooth_l1_bwd(out2d, target2d, rowmask, scale, gloss):
     return (gloss * scale) * m * d.clamp(-1, 1)
 
 
-def linear_fwd_segbias(x, W, segbias, rows_per_seg, residual=None, y_elu=None, want_y=True, elu_stats=None):
+def linear_fwd_segbias(x, W, segbias, rows_per_seg, residual=None, y_elu=None, want_y=True, elu_stats=None, tile_sums=None):
     seg = torch.arange(x.shape[0]) // rows_per_seg
     y = (x.double() @ W.double().t()).float() + segbias[seg]
     if residual is not None:

@@ -1022,3 +1022,73 @@ def test_statistics_of_a_64_channel_concat_buffer_from_both_producers(rows):
     assert got.shape == (2, 128)
     assert torch.allclose(got, want, rtol=1e-9, atol=1e-9 * float(want.abs().max()))
 
+
+
+# ---- per-mesh sums of a global-average operand from the producing GEMM's per-tile column sums -----------------------------
+@pytest.mark.parametrize("per,nseg,maskkind", [(5041, 8, "none"), (5041, 8, "prefix"), (1000, 5, "random"), (40, 6, "prefix"),
+                                               (4096, 4, "none"), (33, 3, "none")])
+@pytest.mark.parametrize("segbias", [False, True])
+def test_average_stage_statistics_from_tile_sums_match_the_pass_over_the_operand(per, nseg, maskkind, segbias):
+    """sn_linear_fwd_tiles_f32 / sn_linear_fwd_segbias_tiles_f32 + sn_avg_stats_from_tiles_f32 against sn_avg_stats_f32 on the
+    activated output: same per-mesh means and BatchNorm sums (fp32 tile sums, fp64 across tiles), meshes that do not start on
+    tile boundaries, row masks (prefix masks as the samplers build them, arbitrary ones)."""
+    if not kernels.tile_sums_supported():
+        pytest.skip("split kernels only")
+    rows = per * nseg
+    torch.manual_seed(per + nseg)
+    x = torch.randn(rows, 128, device=DEV)
+    W = torch.randn(128, 128, device=DEV) / np.sqrt(128)
+    b = torch.randn(128, device=DEV)
+    r = torch.randn(rows, 128, device=DEV)
+    cat = torch.full((rows, 256), float("nan"), device=DEV)
+    part = kernels.new_elu_stats_part(rows, DEV)
+    tiles = kernels.new_tile_sums(rows, DEV)
+    tiles.fill_(float("nan"))                                    # every tile must be written
+    if segbias:
+        segb = torch.randn(nseg, 128, device=DEV)
+        kernels.linear_fwd_segbias(x, W, segb, per, r, cat[:, :128], False, part, tiles)
+    else:
+        kernels.linear_fwd(x, W, b, r, cat[:, :128], False, part, tiles)
+    assert torch.isfinite(tiles).all()
+    e = cat[:, :128]
+    if maskkind == "none":
+        mask = None
+        cnt = torch.full((nseg,), float(per), device=DEV)
+    elif maskkind == "prefix":
+        valid = torch.randint(max(1, per // 2), per + 1, (nseg,), device=DEV)
+        mask = (torch.arange(per, device=DEV)[None, :] < valid[:, None]).float().reshape(-1).contiguous()
+        cnt = valid.float()
+    else:
+        mask = (torch.rand(rows, device=DEV) > 0.2).float()
+        cnt = mask.reshape(nseg, per).sum(1)
+    inv = (1.0 / cnt).reshape(nseg, 1)
+    m_ref, st_ref = kernels.avg_stats(e, mask, inv, per, nseg)
+    m, st = kernels.avg_stats_from_tiles(tiles, part, e, mask, inv, per, nseg)
+    assert torch.allclose(m, m_ref, rtol=2e-6, atol=2e-6 * float(m_ref.abs().max()))
+    assert np.allclose(st.cpu().numpy(), st_ref.cpu().numpy(), rtol=1e-6, atol=1e-6 * float(st_ref.abs().max()))
+    # the per-tile sums themselves, against float64
+    want = e.double().reshape(-1, 128)
+    ntile = (rows + 31) // 32
+    pad = torch.zeros(ntile * 32 - rows, 128, dtype=torch.float64, device=DEV)
+    want = torch.cat([want, pad]).reshape(ntile, 32, 128).sum(1)
+    assert torch.allclose(tiles.double(), want, rtol=1e-5, atol=1e-5 * float(want.abs().max()))
+
+
+def test_arap_model_with_and_without_tile_sums(monkeypatch):
+    """The whole ARAP Dirac model with the tile-sum hand-off (default) and with the statistics pass over every global-average
+    operand (SN_TILE_SUMS=0 semantics): same loss and gradients up to the summation order of the per-mesh means."""
+    from helpers import deterministic_init
+    from surfacenetworks_amd import arap
+
+    ds = arap.ClothSequences([(12, 11), (9, 13), (10, 10)], frames=45, op_frames=2, seed=3, device=DEV, model="dir")
+    seq, off = np.array([0, 1, 2, 1]), np.array([0, 1, 0, 0])
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(kernels, "tile_sums_supported", (lambda: True) if on else (lambda: False))
+        model = deterministic_init(arap.DirModel(), 4).to(DEV).train()
+        b = ds.sample_batch(4, None, seq_ids=seq, offsets=off)
+        loss, _ = arap.forward_loss(model, b, 4)
+        loss.backward()
+        res.append((loss.item(), torch.cat([p.grad.reshape(-1) for p in model.parameters()])))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[1][0])
+    assert float((res[0][1] - res[1][1]).norm() / res[1][1].norm()) < 2e-5
