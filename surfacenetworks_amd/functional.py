@@ -494,12 +494,26 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     else:
         if elu_stats is not None:
             raise ValueError("bnlin_forward: elu_stats needs a shape the fused GEMM covers")
+        _library_gemm("the forward", x.shape[1], W.shape[0])
         y = torch.addmm(bf, x, Wf.t())
         if residual is not None:
             y += residual
         if elu_out is not None:
             kernels.elu_into(y, elu_out)
     return y, (x, W, Wf, s, mean, invstd, beta, training, b is not None, rows_g)
+
+
+_STRICT = os.environ.get("SN_STRICT", "0") == "1"
+
+
+def _library_gemm(what: str, K: int, J: int) -> None:
+    """A Linear of this shape is not covered by the hand-written kernels (forward / input gradient: K in {128, 256} inputs and
+    J <= 128 outputs, J a multiple of 4; weight gradient: J <= 128, C in {128, 256}, or the 64 x 64 head of Mesh-MNIST) and takes
+    torch's GEMM (hipBLASLt).  None of the reference's models has such a layer (their widths are 3/6 -> C, 2C -> C, C -> 10/120
+    with C in {64, 128}; the 3/6-input and 10-output ones have kernels of their own).  SN_STRICT=1 turns the silent library
+    call into an error, so that a model landing on it is visible."""
+    if _STRICT:
+        raise RuntimeError(f"SN_STRICT: {what} of a {K} -> {J} Linear would run on the library GEMM (no hand-written kernel for this shape)")
 
 
 def _dy_bounds(dy, invstd, rows_g, training):
@@ -530,6 +544,7 @@ def _centered_wgrad(dy, x, mean, bounds=None):
         G2, s2 = kernels.wgrad(dy.view(rows // 2, 2 * J), x.view(rows // 2, 2 * C), torch.cat([mean, mean]), want_colsum=True,
                                bounds=bounds)
         return G2[:J, :C] + G2[J:, C:], s2[:J] + s2[J:]
+    _library_gemm("the weight gradient", C, J)
     return dy.t().mm(x - mean), kernels.colstats(dy)
 
 
@@ -559,6 +574,7 @@ def bnlin_backward(state, dy, need_dx=True, through_elu=None):
         if kernels.linear_dgrad_supported(J, C):
             dx = kernels.linear_dgrad(dy, Wf, x, mean, Bc, Cc) if training else kernels.linear_dgrad(dy, Wf)
         else:
+            _library_gemm("the input gradient", C, J)
             dx = dy.mm(Wf)
             if training:
                 kernels.affine_cols_acc(dx, x, Bc, Cc, mean)
