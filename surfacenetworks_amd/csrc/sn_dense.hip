@@ -2784,29 +2784,6 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_h_k(const float *__res
       for (int b = 0; b < CT; ++b)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[n][a][b][e] = 0.f;
-  // scales: one for dy — from the maximum of the producer's per-workgroup maxima —, one per x column (mine as a converter,
-  // mine as the owner of output columns)
-  float sdy;
-  {
-    float *sb = reinterpret_cast<float *>(&img[0][0][0]);             // (the images are not in use yet)
-    float m = 0.f;
-    for (int q = tid; q < ndy; q += kWgradThreads) m = fmaxf(m, dybound[q]);
-    unsigned mb = __float_as_uint(m);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const unsigned other = (unsigned)__shfl_xor((int)mb, o);
-      mb = other > mb ? other : mb;
-    }
-    if (lane == 0) sb[wave] = __uint_as_float(mb);
-    __syncthreads();
-    m = fmaxf(fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3])), fmaxf(fmaxf(sb[4], sb[5]), fmaxf(sb[6], sb[7])));
-    __syncthreads();                                                   // (all have read before the first image write)
-    sdy = pow2_up_for(m);
-  }
-  float osc[CT];                             // inverse scale of my output column in each of my x tiles, times dy's
-#pragma unroll
-  for (int c = 0; c < CT; ++c) osc[c] = pow2_inv(pow2_up_for(xfac / xinvstd[32 * (CT * gb + c) + i])) * pow2_inv(sdy);
-
   // ---- conversion role (as wgrad_u_k: slot 0 = a dy half-block, slots 1.. = x half-blocks) ----
   const int lcol = lane;
   int s_rg[NK];
@@ -2825,7 +2802,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_h_k(const float *__res
     s_cur[k] = k == 0 ? dy + 64 * (wave & 1) + (r0 + 8 * rg) * lddy : x + 64 * (xhb % (2 * CT)) + (r0 + 8 * rg) * ldx;
     l_voff[k] = (k == 0 && c >= J) ? 0x7fffff00 : 4 * lcol;
     l_mu[k] = (k > 0 && center) ? center[c - 128] : 0.f;
-    l_sc[k] = k == 0 ? sdy : pow2_up_for(xfac / xinvstd[c - 128]);
+    l_sc[k] = k == 0 ? 1.f : pow2_up_for(xfac / xinvstd[c - 128]);          // (slot 0: dy's scale, set after the first loads are out)
     l_slot[k] = rg * PL + (c & 3) * QP + (c >> 2);
   }
   float raw[SETS][NK][8];
@@ -2910,6 +2887,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_h_k(const float *__res
       __builtin_amdgcn_sched_barrier(0);
     });
   };
+  // the first blocks' rows are requested BEFORE the scales are formed (the reduction of dy's maxima then runs under them)
   if (nblocks > 0) {
     wstatic_for<0, SETS>([&](auto sc) {
       wstatic_for<0, NK>([&](auto kc) {
@@ -2917,6 +2895,48 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_h_k(const float *__res
         wstatic_for<0, 8>([&](auto jc) { load_row(sc, kc, jc); });
       });
     });
+  }
+  // scales: one for dy — from the maximum of the producer's per-workgroup maxima —, one per x column (mine as a converter,
+  // mine as the owner of output columns)
+  float sdy;
+  {
+    float *sb = reinterpret_cast<float *>(&img[0][0][0]);             // (the images are not in use yet)
+    // up to ~20 000 maxima (one per workgroup of the transposed product that wrote dy): 16-byte loads, eight in flight per
+    // lane — one dependent load per iteration cost this prologue ≈12 us per launch (fixed cost 17 -> 29 us against the bf16
+    // kernel, from the launch times at two row counts)
+    float m = 0.f;
+    const int n4 = (reinterpret_cast<uintptr_t>(dybound) & 15u) == 0 ? ndy / 4 : 0;
+    const f4 *d4 = reinterpret_cast<const f4 *>(dybound);
+    int q = tid;
+    for (; q + 7 * kWgradThreads < n4; q += 8 * kWgradThreads) {
+      f4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = d4[q + u * kWgradThreads];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) m = fmaxf(m, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+    }
+    for (; q < n4; q += kWgradThreads) {
+      const f4 v = d4[q];
+      m = fmaxf(m, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+    }
+    for (int r = 4 * n4 + tid; r < ndy; r += kWgradThreads) m = fmaxf(m, dybound[r]);
+    unsigned mb = __float_as_uint(m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const unsigned other = (unsigned)__shfl_xor((int)mb, o);
+      mb = other > mb ? other : mb;
+    }
+    if (lane == 0) sb[wave] = __uint_as_float(mb);
+    __syncthreads();
+    m = fmaxf(fmaxf(fmaxf(sb[0], sb[1]), fmaxf(sb[2], sb[3])), fmaxf(fmaxf(sb[4], sb[5]), fmaxf(sb[6], sb[7])));
+    __syncthreads();                                                   // (all have read before the first image write)
+    sdy = pow2_up_for(m);
+  }
+  float osc[CT];                             // inverse scale of my output column in each of my x tiles, times dy's
+#pragma unroll
+  for (int c = 0; c < CT; ++c) osc[c] = pow2_inv(pow2_up_for(xfac / xinvstd[32 * (CT * gb + c) + i])) * pow2_inv(sdy);
+  l_sc[0] = sdy;
+  if (nblocks > 0) {
     wstatic_for<0, NM>([&](auto mc) { behind_mfma(WIC<0>{}, WIC<0>{}, mc, SETS); });      // block 0 -> image 0, block SETS requested
     constexpr int U = (SETS % 2 == 0) ? SETS : 2 * SETS;                                    // lcm(2, SETS)
     for (int b = 0; b < nblocks; b += U) {

@@ -32,8 +32,14 @@ def load(path, counter):
 
 def main():
     out, rd_csv, wr_csv = sys.argv[1:4]
-    skip = float(sys.argv[4]) if len(sys.argv) > 4 else 0.5        # drop the first half of the dispatches (set-up, warm-up)
-    res, agg, rd, wr, n0, tot_r, tot_w = summarize(rd_csv, wr_csv, skip)
+    # 4th argument: `last=N` keeps exactly the last N training steps; a number drops that fraction of all dispatches
+    # (default: the first half — set-up and warm-up)
+    arg = sys.argv[4] if len(sys.argv) > 4 else "0.5"
+    if arg.startswith("last="):
+        res, agg, rd, wr, n0, tot_r, tot_w = summarize(rd_csv, wr_csv, last_steps=int(arg[5:]))
+        res["_steps_counted"] = int(arg[5:])
+    else:
+        res, agg, rd, wr, n0, tot_r, tot_w = summarize(rd_csv, wr_csv, float(arg))
     json.dump(res, open(out + ".json", "w"), indent=1)
     with open(out + "_raw.csv", "w") as fh:
         fh.write("dispatch,kernel,grid,TCC_EA0_RDREQ_sum,TCC_EA0_WRREQ_sum\n")

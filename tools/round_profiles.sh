@@ -1,7 +1,7 @@
 #!/bin/bash
 # Every profile artefact of a round in one GPU call (run through gpurun from the repo root):
-#   tools/round_profiles.sh r3        -> gpurun_out/prof_r3/*  (copy what is to be judged into profiles/)
-tag=${1:-r3}
+#   tools/round_profiles.sh r4        -> gpurun_out/prof_r4/*  (copy what is to be judged into profiles/)
+tag=${1:-r4}
 root=$GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag
 mkdir -p $root/$out
@@ -10,7 +10,11 @@ python -m pytest tests -q -m gpu -x 2>&1 | tail -3 > $out/${tag}_gpu_tests.txt
 bash tools/profile_bench.sh $out $tag
 cp $out/${tag}_pmc_traffic_c3.json profiles/ 2>/dev/null          # (this box's copy: bench.py below reads it)
 python bench.py > $out/${tag}_bench_c3_final.json 2> $out/bench_final.err
-python bench.py --graph --no-cpu-baseline --no-secondary > $out/${tag}_bench_c3_graph.json 2>> $out/bench_final.err
+python bench.py --graph --no-cpu-baseline --no-secondary --no-pmc > $out/${tag}_bench_c3_graph.json 2>> $out/bench_final.err
+# BASELINE configs[3] as the N-rank job: one rank (RCCL), and two ranks sharing this box's one device (gloo, flagged)
+python bench.py --workload faust > $out/${tag}_bench_faust_n1.json 2>> $out/bench_final.err
+python bench.py --workload faust --gpus 2 > $out/${tag}_bench_faust_n2_one_device.json 2>> $out/bench_final.err
+python bench.py --gpus 2 --no-cpu-baseline --no-secondary > $out/${tag}_bench_gpus2_gloo_one_device.json 2>> $out/bench_final.err
 for cfg in faust mnist; do          # capture once + N replays, N = 10 and 60: the difference is 50 replayed steps alone
   for n in 10 60; do
     (cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $root/$out/tr_${cfg}_$n -o t -- python $root/tools/scratch/${cfg}_replay_only.py $n > $root/$out/tr_${cfg}_$n.log 2>&1)
