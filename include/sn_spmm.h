@@ -425,6 +425,27 @@ int sn_wgrad_slabs_bounded_f32(const float *dy, int64_t lddy, const float *x, in
                                const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg, int32_t J,
                                int32_t C, float *G, double *dysum, float *seg_dysum, void *workspace, size_t workspace_bytes,
                                const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows, void *stream);
+/* sn_wgrad_bn_f32: the weight gradient of a folded BatchNorm + Linear AND everything the training step derives from it, in
+ * two launches (the split-K product, then one finishing kernel) instead of four to six: what sn_wgrad_[seg_|slabs_][bounded_]f32
+ * + [sn_avg_bwd_gc_f32 +] sn_bn_bwd_coeffs_f32 return — dW, db, dgamma, dbeta and the coefficients B, C of the input
+ * gradient's BatchNorm tail — bit for bit.  Replaces, per GraphConv1x1 of the reference (src/utils/utils_pt.py:83-99), the
+ * autograd nodes MmBackward (weight half), SumBackward (bias) and NativeBatchNormBackward's three reductions.  Local
+ * statistics only (the sums are finished on this device; synchronised BatchNorm all-reduces G between the steps and keeps the
+ * separate calls).
+ *   rows_per_seg > 0: equal meshes (as sn_wgrad_seg_f32); slab_off != NULL: ragged meshes (as sn_wgrad_slabs_f32; then nslab,
+ *   seg_slab_ptr, nseg as there); neither: plain rows.  dybound != NULL: the two-piece fp16 product (as sn_wgrad_bounded_f32).
+ *   Ct == C: W (J x Ct), s, invstd, beta (Ct) over the C columns of x.  Ct == 2 C (needs meshes): a global-average stage
+ *   (AvgResNet2, utils_pt.py:230-243) — the second C columns are the per-mesh means m[nseg][C] about mu2[C]; seg_dysum[nseg][J]
+ *   receives the per-mesh column sums of dy.  Gc (J x Ct) receives the centred product itself; db, dysum (J doubles) optional.
+ *   bn_rows: rows behind the BatchNorm statistics.  workspace: sn_wgrad_bn_workspace_bytes (nslab_ragged: 0 unless ragged).
+ *   counters: Ct / 32 ints on the device, zero on entry; zero again once the launch has run (one set per launch in flight). */
+size_t sn_wgrad_bn_workspace_bytes(int64_t rows, int64_t rows_per_seg, int32_t nslab_ragged, int32_t J, int32_t C, int32_t Ct);
+int sn_wgrad_bn_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows, int32_t J, int32_t C,
+                    int64_t rows_per_seg, const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg,
+                    const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows, const float *W, const float *s,
+                    const float *invstd, const float *beta, int64_t bn_rows, int32_t Ct, const float *m, const float *mu2, float *Gc,
+                    float *dW, float *db, float *dgamma, float *dbeta, float *Bc, float *Cc, float *seg_dysum, double *dysum,
+                    void *workspace, size_t workspace_bytes, int32_t *counters, void *stream);
 /* sn_wgrad_thin_f32: weight and bias gradient of a Linear with 1..8 input channels — the models' first layer,
  * GraphConv1x1(6 | 3 -> C, batch_norm=None) (src/as_rigid_as_possible/models.py:113, src/utils/utils_pt.py:99) — on
  * rows ~ 1e5..1e6:  G (J x C, row-major, fp32) = dy^T x,  db (J, optional) = colsum(dy).  One pass over dy; fp32

@@ -1154,6 +1154,182 @@ __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ 
   }
 }
 
+// The split-K reduction AND the BatchNorm backward coefficients in one launch (training step, local statistics): replaces
+// wgrad_reduce_k -> [avg_bwd_gc_k ->] bn_bwd_coeffs_k, a chain of dependent 5-6 us launches behind every weight gradient.
+// grid (Ct / 32, ceil(J / 2)): workgroup (bx, by) owns channels 32 bx .. +31 of rows j = 2 by, 2 by + 1 — lane o: channel o & 31,
+// row o >> 5 — and
+//   * sums its 64 elements of G over the slabs (channels < C; the four waves take every fourth slab, eight loads in flight:
+//     wgrad_reduce_k's order of addition) or forms them from the per-mesh column sums of dy (channels >= C, the broadcast half
+//     of a global-average stage: sum_mesh Sg[mesh][j] (m[mesh][c] - mu2[c]), avg_bwd_gc_k's order), the column sums of dy of
+//     its two rows alongside (every workgroup its own copy: the same loads, broadcast);
+//   * writes dW = G s + colsum(dy) beta for its elements, G itself and its copy of the column sums to scratch;
+//   * takes a ticket of its channel group; the workgroup that draws the LAST one of the group (all rows of these 32 channels
+//     are then in scratch) finishes them as bn_bwd_coeffs_k does — the two sums over j in that kernel's order (8 row groups,
+//     fixed combination) -> dgamma, dbeta, B, C.  No workgroup waits for another; the counters return to 0.
+// Results are bit-identical to the launches replaced (tests/test_dense_gpu.py).
+struct WgradFinish {
+  const float *W;                            // [J][Ct]
+  const float *s, *invstd, *beta;            // [Ct]
+  int64_t rows;                              // rows behind the BatchNorm statistics
+  int Ct;                                    // C, or 2 C (global-average stage: the second half is the per-mesh constant)
+  const float *m, *mu2;                      // Ct == 2 C: per-mesh means [nseg][C], their BatchNorm mean [C]
+  int nseg;
+  float *Gc;                                 // [J][Ct] out (scratch for the tail; also what wgrad_reduce_k + avg_bwd_gc_k left)
+  double *sdyc;                              // [Ct / 32][J] scratch: every channel group's copy of colsum(dy)
+  float *dW, *db, *dgamma, *dbeta, *Bc, *Cc;
+  int *counters;                             // [Ct / 32], zero on entry and on exit
+};
+__device__ __forceinline__ float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ __launch_bounds__(kWG) void wgrad_finish_k(const float *__restrict__ partial, const float *__restrict__ colpart, int nslab,
+                                                      int J, int C, double *__restrict__ dysum,
+                                                      float *__restrict__ segsum /* [nseg][J] | NULL */, int spm,
+                                                      const int64_t *__restrict__ seg_slab_ptr /* [nseg + 1] | NULL */,
+                                                      WgradFinish a) {
+  __shared__ double sm[4][64], sd[4][64];
+  __shared__ float s_sg[2][128];
+  __shared__ double sa[8][32], sp[8][32];
+  __shared__ int ticket;
+  const int tid = threadIdx.x, o = tid & 63, g = tid >> 6;
+  const int bx = blockIdx.x, Ct = a.Ct;
+  const int c = 32 * bx + (o & 31), j = 2 * (int)blockIdx.y + (o >> 5);
+  const bool jok = j < J;
+  const bool first = 32 * bx < C;               // (workgroup-uniform)
+  double t = 0, td = 0;
+  if (jok) {
+    const float *cp = colpart + j;              // [slab][128]
+    int sl = g;
+    if (first) {                                // (two loops, branch-free inside: a select on `first` serialised the loads)
+      const float *src = partial + (int64_t)j * C + c;
+      const int64_t stride = (int64_t)128 * C;
+      for (; sl + 28 < nslab; sl += 32) {
+        float v[8], w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          v[u] = src[(int64_t)(sl + 4 * u) * stride];
+          w[u] = cp[(int64_t)(sl + 4 * u) * 128];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          t += (double)v[u];
+          td += (double)w[u];
+        }
+      }
+      for (; sl < nslab; sl += 4) {
+        t += (double)src[(int64_t)sl * stride];
+        td += (double)cp[(int64_t)sl * 128];
+      }
+    } else {
+      for (; sl + 28 < nslab; sl += 32) {
+        float w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = cp[(int64_t)(sl + 4 * u) * 128];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) td += (double)w[u];
+      }
+      for (; sl < nslab; sl += 4) td += (double)cp[(int64_t)sl * 128];
+    }
+  }
+  sm[g][o] = t;
+  sd[g][o] = td;
+  __syncthreads();
+  double gacc = 0;
+  if (!first) {
+    // the broadcast half: per-mesh column sums of dy of my two rows (a mesh's consecutive slabs, wgrad_reduce_k's order), 128
+    // meshes at a time through LDS; the first such channel group also publishes them
+    const int C2 = Ct - C, c2 = c - C;
+    const int mj = 2 * (int)blockIdx.y + (tid >> 7);
+    for (int base = 0; base < a.nseg; base += 128) {
+      const int mesh = base + (tid & 127);
+      if (mesh < a.nseg && mj < J) {
+        const int64_t p0 = seg_slab_ptr ? seg_slab_ptr[mesh] : (int64_t)mesh * spm;
+        const int cnt = (int)((seg_slab_ptr ? seg_slab_ptr[mesh + 1] : p0 + spm) - p0);
+        const float *q = colpart + p0 * 128 + mj;
+        double tw[4] = {0, 0, 0, 0};
+        for (int k = 0; k < cnt; ++k) tw[k & 3] += (double)q[(int64_t)k * 128];
+        const float r = (float)(tw[0] + tw[1] + tw[2] + tw[3]);
+        s_sg[tid >> 7][tid & 127] = r;
+        if (32 * bx == C && segsum) segsum[(int64_t)mesh * J + mj] = r;
+      }
+      __syncthreads();
+      if (g == 0 && jok) {
+        const int lim = a.nseg - base < 128 ? a.nseg - base : 128;
+        const double mu = (double)a.mu2[c2];
+#pragma unroll 16
+        for (int k = 0; k < lim; ++k) gacc += (double)s_sg[o >> 5][k] * ((double)a.m[(int64_t)(base + k) * C2 + c2] - mu);
+      }
+      __syncthreads();
+    }
+  }
+  if (g == 0 && jok) {
+    const double r = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
+    const double sdy = sd[0][o] + sd[1][o] + sd[2][o] + sd[3][o];
+    const float ggf = first ? (float)r : (float)gacc;
+    const double gg = ggf, sc = a.s[c], bc = a.beta[c];
+    st_agent(a.Gc + (int64_t)j * Ct + c, ggf);
+    a.dW[(int64_t)j * Ct + c] = (float)(gg * sc + sdy * bc);
+    if ((o & 31) == 0) {
+      st_agent(a.sdyc + (int64_t)bx * J + j, sdy);
+      if (bx == 0) {
+        if (a.db) a.db[j] = (float)sdy;
+        if (dysum) dysum[j] = sdy;
+      }
+    }
+  }
+  // My rows of this channel group must be visible device-wide before my ticket is.  A release fence at agent scope would write
+  // back this XCD's whole L2 — 33 MB of split-K partials the product has just left there — once per workgroup (measured: 60-68
+  // us per launch instead of 6).  Instead the two scratch arrays are written with agent-scope stores (write-through to the
+  // memory side, where the XCDs meet), the ticket is drawn once those have been acknowledged, and the last workgroup reads them
+  // with agent-scope loads (past its own L2).
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) ticket = __hip_atomic_fetch_add(a.counters + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (ticket != (int)gridDim.y - 1) return;
+  // ---- the last workgroup of the channel group: bn_bwd_coeffs_k for its 32 channels ----
+  if (tid == 0) __hip_atomic_store(a.counters + bx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int cl = tid & 31, gq = tid >> 5;
+  const int cc = 32 * bx + cl;
+  double aa = 0, pp = 0;
+  for (int j0 = gq; j0 < J; j0 += 64) {          // eight rows of the group at a time, their loads in flight together
+    float w[8], gv[8];
+    double sv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {              // (unconditional loads from a clamped row: a select would serialise them)
+      const int jj = j0 + 8 * u < J ? j0 + 8 * u : J - 1;
+      w[u] = a.W[(int64_t)jj * Ct + cc];
+      gv[u] = ld_agent(a.Gc + (int64_t)jj * Ct + cc);      // (written by other workgroups of this launch)
+      sv[u] = ld_agent(a.sdyc + (int64_t)bx * J + jj);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (j0 + 8 * u < J) {
+        const double wd = w[u], gd = gv[u];
+        aa += sv[u] * wd;
+        pp += wd * gd;
+      }
+  }
+  sa[gq][cl] = aa;
+  sp[gq][cl] = pp;
+  __syncthreads();
+  if (gq == 0) {
+    double at = 0, pt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      at += sa[i][cl];
+      pt += sp[i][cl];
+    }
+    const double sc = a.s[cc], is = a.invstd[cc];
+    const double dg = is * pt;
+    a.dgamma[cc] = (float)dg;
+    a.dbeta[cc] = (float)at;
+    a.Bc[cc] = (float)(-(sc * is * dg) / (double)a.rows);
+    a.Cc[cc] = (float)(-(sc * at) / (double)a.rows);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Weight gradient of a Linear with a handful of input channels (the models' first layer, 3 or 6 coordinates -> C
 // features):  G (J x C) = dy^T x,  db = colsum(dy).  One pass over dy at HBM rate — a GEMM library sees a 128 x 6 output
@@ -2813,6 +2989,13 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_h_k(const float *__res
     if constexpr (k == 0) l_sum += xv.x + xv.y;
     else xv -= f2v{l_mu[k], l_mu[k]};
     xv *= l_sc[k];                                                   // exact (power of two; the bound keeps it below 2^15)
+    if constexpr (k > 0) {
+      // rows past the slab's end load as 0 and leave the centring as -mean, which no bound covers (a column sitting at
+      // -1 +- 1e-4 behind an ELU: |mean| / bound = 17): scaled it may pass fp16's range, and inf x the exact 0 of the padded dy row
+      // is NaN.  Clamped to the largest fp16 value the product with 0 is 0; rows inside the bound are untouched.
+      xv.x = __builtin_amdgcn_fmed3f(xv.x, -65504.f, 65504.f);
+      xv.y = __builtin_amdgcn_fmed3f(xv.y, -65504.f, 65504.f);
+    }
     const h2v h = __builtin_convertvector(xv, h2v);                  // round to nearest
     f2v r = xv - __builtin_convertvector(h, f2v);                    // exact remainder
     if constexpr (LOW11) r *= 2048.f;
@@ -3073,17 +3256,18 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
                         int32_t J, int32_t C, float *G, double *dysum, int64_t rows_per_seg, float *seg_dysum,
                         void *workspace, size_t workspace_bytes, void *stream, const int64_t *slab_off = nullptr,
                         int32_t nslab_tab = 0, const int64_t *seg_slab_ptr = nullptr, int32_t nseg_tab = 0,
-                        const WgradBounds *bounds = nullptr) {
+                        const WgradBounds *bounds = nullptr, const WgradFinish *fin = nullptr) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldx < C) return SN_E_SHAPE;
   if (J > 128 || (J % 4) || (C != 128 && C != 256)) return SN_E_UNSUPPORTED;
-  if (!G) return SN_E_NULL;
+  if (!G && !fin) return SN_E_NULL;
+  if (fin && rows == 0) return SN_E_SHAPE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool x3 = gemm_variant() != 0;
   const bool ragged = slab_off != nullptr;                  // slabs and their meshes from the caller's tables
   const bool segmented = rows_per_seg > 0 && !ragged;
-  if (segmented && (!x3 || !dysum || !seg_dysum || rows % rows_per_seg)) return x3 ? SN_E_SHAPE : SN_E_UNSUPPORTED;
-  if (ragged && (nslab_tab < 1 || nseg_tab < 1 || !seg_slab_ptr || !dysum || !seg_dysum)) return SN_E_SHAPE;
+  if (segmented && (!x3 || (!dysum && !fin) || !seg_dysum || rows % rows_per_seg)) return x3 ? SN_E_SHAPE : SN_E_UNSUPPORTED;
+  if (ragged && (nslab_tab < 1 || nseg_tab < 1 || !seg_slab_ptr || (!dysum && !fin) || !seg_dysum)) return SN_E_SHAPE;
   if (rows == 0) {
     hipError_t e = hipMemsetAsync(G, 0, (size_t)J * C * sizeof(float), s);
     if (e == hipSuccess && dysum) e = hipMemsetAsync(dysum, 0, (size_t)J * sizeof(double), s);
@@ -3104,7 +3288,7 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
   if (ragged) nslab = nslab_tab;
   if (workspace_bytes < (size_t)nslab * 128 * ((size_t)C + 1) * sizeof(float)) return SN_E_WORKSPACE;
   float *partial = static_cast<float *>(workspace);
-  float *colpart = dysum ? partial + (size_t)nslab * 128 * C : nullptr;
+  float *colpart = (dysum || fin) ? partial + (size_t)nslab * 128 * C : nullptr;
   const int64_t sr = segmented ? rows_per_seg : 0;
   const bool uni = x3 && wgrad_variant() >= 2 && lddy < ((int64_t)1 << 24) && ldx < ((int64_t)1 << 24);
   if (ragged && !uni) return SN_E_UNSUPPORTED;              // slab tables: the uniform-wave kernel only
@@ -3170,6 +3354,13 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
     hipLaunchKernelGGL((wgrad_mfma_k<1>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
   else
     hipLaunchKernelGGL((wgrad_mfma_k<2>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
+  if (fin) {
+    WgradFinish a = *fin;
+    if (a.Ct != C) a.nseg = ragged ? (int)nseg_tab : nslab / spm;
+    hipLaunchKernelGGL(wgrad_finish_k, dim3((unsigned)(a.Ct / 32), (unsigned)((J + 1) / 2)), dim3(kWG), 0, s, partial, colpart,
+                       nslab, (int)J, (int)C, dysum, (segmented || ragged) ? seg_dysum : nullptr, spm, ragged ? seg_slab_ptr : nullptr, a);
+    return launch_status();
+  }
   const int64_t extra = (dysum ? J : 0) + (segmented ? (int64_t)(nslab / spm) * J : 0) + (ragged ? (int64_t)nseg_tab * J : 0);
   hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)((J * C + extra + 63) / 64)), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G,
                      colpart, dysum, (segmented || ragged) ? seg_dysum : nullptr, spm, ragged ? seg_slab_ptr : nullptr,
@@ -3250,6 +3441,49 @@ int sn_wgrad_slabs_bounded_f32(const float *dy, int64_t lddy, const float *x, in
   const WgradBounds b = make_bounds(dybound, n_dybound, xinvstd, stat_rows);
   return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, 0, seg_dysum, workspace, workspace_bytes, stream, slab_off,
                       nslab, seg_slab_ptr, nseg, &b);
+}
+
+// Weight gradient of a folded BatchNorm + Linear AND everything the step derives from it, in two launches (the split-K product,
+// then wgrad_finish_k) instead of four to six: dW, db, dgamma, dbeta and the coefficients B, C of the input gradient's BatchNorm
+// tail (what sn_wgrad_*_f32 + [sn_avg_bwd_gc_f32 +] sn_bn_bwd_coeffs_f32 return, bit for bit).  Local statistics only: the
+// sums are finished on this device (synchronised BatchNorm all-reduces G between the two steps and keeps the separate calls).
+//   rows_per_seg > 0: equal meshes (sn_wgrad_seg_f32); slab_off != NULL: ragged meshes (sn_wgrad_slabs_f32); else plain.
+//   dybound != NULL: the two-piece fp16 product (sn_wgrad_bounded_f32).
+//   Ct == C: W, s, invstd, beta over the C columns of x.  Ct == 2 C (needs meshes): the global-average stage — the second C
+//   columns are the per-mesh means m[nseg][C] about mu2[C]; seg_dysum[nseg][J] receives the per-mesh column sums of dy.
+//   Gc (J x Ct) receives the centred product itself (scratch of the second launch); dysum (J doubles) optional.
+//   workspace: sn_wgrad_bn_workspace_bytes; counters: Ct / 32 ints, zero on entry, zero again when the launch has run.
+size_t sn_wgrad_bn_workspace_bytes(int64_t rows, int64_t rows_per_seg, int32_t nslab_ragged, int32_t J, int32_t C, int32_t Ct) {
+  if (C < 1 || Ct < C || J < 1) return 0;
+  size_t base = nslab_ragged > 0 ? (size_t)nslab_ragged * 128 * ((size_t)C + 1) * sizeof(float)
+                                 : (rows_per_seg > 0 ? sn_wgrad_seg_workspace_bytes(rows, rows_per_seg, J, C) : sn_wgrad_workspace_bytes(rows, J, C));
+  base = (base + 15) & ~(size_t)15;
+  return base + (size_t)(Ct / 32) * J * sizeof(double);
+}
+int sn_wgrad_bn_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows, int32_t J, int32_t C,
+                    int64_t rows_per_seg, const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg,
+                    const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows, const float *W, const float *s,
+                    const float *invstd, const float *beta, int64_t bn_rows, int32_t Ct, const float *m, const float *mu2, float *Gc,
+                    float *dW, float *db, float *dgamma, float *dbeta, float *Bc, float *Cc, float *seg_dysum, double *dysum,
+                    void *workspace, size_t workspace_bytes, int32_t *counters, void *stream) {
+  (void)hipGetLastError();
+  if (rows < 1 || bn_rows < 1 || J < 1 || C < 1 || (Ct != C && Ct != 2 * C) || (Ct % 32)) return SN_E_SHAPE;
+  if (!W || !s || !invstd || !beta || !Gc || !dW || !dgamma || !dbeta || !Bc || !Cc || !counters || !workspace) return SN_E_NULL;
+  const bool ragged = slab_off != nullptr, meshes = ragged || rows_per_seg > 0;
+  if (Ct != C && (!meshes || !m || !mu2 || !seg_dysum)) return SN_E_NULL;
+  if (ragged && !seg_slab_ptr) return SN_E_NULL;
+  if (dybound && stat_rows < rows) return SN_E_SHAPE;
+  const size_t need = sn_wgrad_bn_workspace_bytes(rows, rows_per_seg, ragged ? nslab : 0, J, C, Ct);
+  if (workspace_bytes < need) return SN_E_WORKSPACE;
+  const size_t tail = (size_t)(Ct / 32) * J * sizeof(double);
+  WgradFinish a{};
+  a.W = W, a.s = s, a.invstd = invstd, a.beta = beta, a.rows = bn_rows, a.Ct = Ct, a.m = m, a.mu2 = mu2, a.nseg = 0;
+  a.Gc = Gc, a.sdyc = reinterpret_cast<double *>(static_cast<char *>(workspace) + (need - tail));
+  a.dW = dW, a.db = db, a.dgamma = dgamma, a.dbeta = dbeta, a.Bc = Bc, a.Cc = Cc, a.counters = counters;
+  WgradBounds b{};
+  if (dybound) b = make_bounds(dybound, n_dybound, xinvstd, stat_rows);
+  return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, nullptr, dysum, ragged ? 0 : rows_per_seg, seg_dysum, workspace, need - tail,
+                      stream, slab_off, ragged ? nslab : 0, seg_slab_ptr, ragged ? nseg : 0, dybound ? &b : nullptr, &a);
 }
 
 static int thin_blocks(int64_t rows, int J) {

@@ -548,6 +548,25 @@ def _centered_wgrad(dy, x, mean, bounds=None):
     return dy.t().mm(x - mean), kernels.colstats(dy)
 
 
+def _wgrad_and_coeffs(dy, x, W, s, mean, invstd, beta, training, has_bias, rows_g):
+    """(dW, db, dgamma, dbeta, Bc, Cc) of a folded BatchNorm+Linear: the centred weight gradient G = dyᵀ·(x - mean), colsum(dy) and
+    every BatchNorm reduction they give algebraically.  Training step with local statistics: the product and ONE finishing
+    launch (kernels.wgrad_bn); otherwise the product, [the all-reduce of synchronised statistics,] the coefficients."""
+    J, C = dy.shape[1], x.shape[1]
+    bounds = _dy_bounds(dy, invstd, rows_g, training)
+    if training and _BN_SYNC is None and x.shape[0] > 0 and kernels.wgrad_bn_supported(J, C):
+        r = kernels.wgrad_bn(dy, x, mean, W, s, invstd, beta, rows_g, has_bias, bounds)
+        if r is not None:
+            return r[:6]
+    Gc, sdy = _centered_wgrad(dy, x, mean, bounds)
+    scale = 1.0
+    if training:
+        Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
+    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    return dW, db, dgamma, dbeta, Bc, Cc
+
+
 def bnlin_backward(state, dy, need_dx=True, through_elu=None):
     """Backward of bnlin_forward: G = dyᵀ·(x - mean) (split-K MFMA kernel) and colsum(dy) give every BatchNorm
     reduction algebraically (sum_r dz = colsum(dy)·W, sum_r dz∘(x-mean) = sum_j W∘G); dx = dy·(W·diag(s)) + (x-mean)∘B + C
@@ -561,12 +580,7 @@ def bnlin_backward(state, dy, need_dx=True, through_elu=None):
     rows, C = x.shape
     J = dy.shape[1]
     # centring inside the kernel leaves no fp32 cancellation against mean·colsum(dy)
-    Gc, sdy = _centered_wgrad(dy, x, mean, _dy_bounds(dy, invstd, rows_g, training))
-    scale = 1.0
-    if training:
-        Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
-    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
-    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    dW, db, dgamma, dbeta, Bc, Cc = _wgrad_and_coeffs(dy, x, W, s, mean, invstd, beta, training, has_bias, rows_g)
     dx = None
     if through_elu is not None and training and kernels.linear_dgrad_elu_supported(J, C):
         dx = kernels.linear_dgrad_elu(dy, Wf, x, mean, Bc, Cc, through_elu[0])
@@ -654,12 +668,7 @@ def bnlin_backward_elu_input(state, dy):
     x, W, Wf, s, mean, invstd, beta, training, has_bias, rows_g = state
     dy = dy.contiguous()
     J, C = dy.shape[1], x.shape[1]
-    Gc, sdy = _centered_wgrad(dy, x, mean, _dy_bounds(dy, invstd, rows_g, training))
-    scale = 1.0
-    if training:
-        Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
-    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
-    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    dW, db, dgamma, dbeta, Bc, Cc = _wgrad_and_coeffs(dy, x, W, s, mean, invstd, beta, training, has_bias, rows_g)
     if training and kernels.linear_dgrad_elu_supported(128, C) and kernels.linear_dgrad_supported(J, C):
         # product, BatchNorm tail and activation derivative in one kernel (epilogue of the input-gradient GEMM)
         dx = kernels.linear_dgrad_eluseg(dy, Wf, x, mean, Bc, Cc, None, 0)
@@ -702,11 +711,18 @@ def avg_stage_backward(state, mask_rows, inv_count, nseg, per, dy, gadd):
     e, m, W, Wf, s, mean, invstd, beta, has_bias, rows_g = state
     dy = dy.contiguous()
     rows, C = e.shape
-    G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per, bounds=_dy_bounds(dy, invstd[:C], rows_g, True))   # per-mesh column sums of dy from the same pass
-    Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
-    Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
-    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
-    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    bounds = _dy_bounds(dy, invstd[:C], rows_g, True)
+    r = None
+    if _BN_SYNC is None and rows > 0 and kernels.wgrad_bn_supported(dy.shape[1], C):
+        r = kernels.wgrad_bn(dy, e, mean[:C], W, s, invstd, beta, rows_g, has_bias, bounds, rows_per_seg=per, m=m, mu2=mean[C:])
+    if r is not None:
+        dW, db, dgamma, dbeta, Bc, Cc, Sg = r
+    else:
+        G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per, bounds=bounds)   # per-mesh column sums of dy from the same pass
+        Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
+        Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
+        dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
+        dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
     segvec = kernels.avg_bwd_segvec(Sg, Wf[:, C:], m, mean[C:], Bc[C:], Cc[C:], inv_count, per)
     g = kernels.linear_dgrad_eluseg(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, per, mask_rows, gadd)
     return g, dgamma, dbeta, dW, db
@@ -741,11 +757,18 @@ def avg_stage_backward_ragged(state, seg, dy, gadd):
     e, m, W, Wf, s, mean, invstd, beta, has_bias, rows_g = state
     dy = dy.contiguous()
     rows, C = e.shape
-    G1, sdy, Sg = kernels.wgrad_slabs(dy, e, mean[:C], seg, bounds=_dy_bounds(dy, invstd[:C], rows_g, True))
-    Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
-    Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
-    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
-    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    bounds = _dy_bounds(dy, invstd[:C], rows_g, True)
+    r = None
+    if _BN_SYNC is None and rows > 0 and kernels.wgrad_bn_supported(dy.shape[1], C):
+        r = kernels.wgrad_bn(dy, e, mean[:C], W, s, invstd, beta, rows_g, has_bias, bounds, seg=seg, m=m, mu2=mean[C:])
+    if r is not None:
+        dW, db, dgamma, dbeta, Bc, Cc, Sg = r
+    else:
+        G1, sdy, Sg = kernels.wgrad_slabs(dy, e, mean[:C], seg, bounds=bounds)
+        Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
+        Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
+        dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
+        dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
     segvec = kernels.avg_bwd_segvec_ragged(Sg, Wf[:, C:], m, mean[C:], Bc[C:], Cc[C:], seg)
     g = kernels.linear_dgrad_eluseg_ragged(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, seg, gadd)
     return g, dgamma, dbeta, dW, db

@@ -528,12 +528,12 @@ _FOLD_COUNTERS = {}          # device index -> [int32 pool, {stream handle: [fir
 _FOLD_STREAMS, _FOLD_SLOTS = 16, 4096
 
 
-def _fold_counter(device):
-    """Address of a zeroed int32 for one sn_bn_fold_parts_f32 launch on the current stream, or None (then the caller takes
-    the three-launch path).  The kernel leaves its counter at 0, so slots are reused; launches of ONE stream run in order, so a
-    stream's slots (round-robin over 4096: consecutive nodes of a captured graph get different ones) never serve two
-    launches at once, and every stream has its own range.  The pool is created on the first eager call (never during a
-    capture: a fill recorded into a graph would not have run yet)."""
+def _fold_counter(device, n: int = 1):
+    """Address of n zeroed int32 for one ticketed launch (sn_bn_fold_parts_f32, sn_wgrad_bn_f32) on the current stream, or None
+    (then the caller takes the separate launches).  The kernel leaves its counters at 0, so slots are reused; launches of ONE
+    stream run in order, so a stream's slots (round-robin over 4096: consecutive nodes of a captured graph get different ones)
+    never serve two launches at once, and every stream has its own range.  The pool is created on the first eager call (never
+    during a capture: a fill recorded into a graph would not have run yet)."""
     dev = torch.device(device)
     key = dev.index if dev.index is not None else torch.cuda.current_device()
     ent = _FOLD_COUNTERS.get(key)
@@ -547,8 +547,10 @@ def _fold_counter(device):
         if len(ent[1]) >= _FOLD_STREAMS:
             return None
         slot = ent[1][sid] = [len(ent[1]) * _FOLD_SLOTS, 0]
+    if slot[1] % _FOLD_SLOTS + n > _FOLD_SLOTS:      # (a group of counters does not wrap around the stream's range)
+        slot[1] += _FOLD_SLOTS - slot[1] % _FOLD_SLOTS
     idx = slot[0] + slot[1] % _FOLD_SLOTS
-    slot[1] += 1
+    slot[1] += n
     return ent[0].data_ptr() + 4 * idx
 
 
@@ -613,6 +615,51 @@ def bn_bwd_coeffs(Gc, dystats, W, s, invstd, beta, rows: int, has_bias: bool):
     _lib.call("sn_bn_bwd_coeffs_f32", _p(Gc), _p(dystats), _p(W.contiguous()), _p(s), _p(invstd), _p(beta.contiguous()),
               rows, J, C, _p(dW), _p(db), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _stream())
     return dW, db, vec[0], vec[1], vec[2], vec[3]
+
+
+def wgrad_bn_supported(J: int, C: int) -> bool:
+    """Shapes (and the switch SN_WGRAD_BN=1; OFF by default) for which the weight gradient and the BatchNorm backward coefficients
+    come from two launches (wgrad_bn) instead of the product, its reduction, [the global-average half] and the coefficients.
+    Bit-identical, and measured no faster (LABNOTES.md, "helper launches, round 4"): a helper launch costs 3.4 us in the step,
+    the hand-over inside one kernel (write-through stores, ticket, loads past the L2) about the same — config-3 step 19.43 ->
+    19.58 ms, FAUST pair 3.45 -> 4.38 ms replayed."""
+    import os
+
+    return wgrad_supported(J, C) and os.environ.get("SN_WGRAD_BN", "0") == "1"
+
+
+def wgrad_bn(dy, x, center, W, s, invstd, beta, bn_rows: int, has_bias: bool, bounds=None, rows_per_seg: int = 0, seg=None, m=None,
+             mu2=None):
+    """(dW, db, dgamma, dbeta, Bc, Cc, per-mesh colsum(dy) | None) of the folded BatchNorm+Linear backward, or None when no
+    counters are to be had (the caller then takes wgrad + bn_bwd_coeffs): the split-K product of dy and x - center and ONE
+    finishing launch (sn_wgrad_bn_f32).  W is (J, Ct) with Ct = C, or 2 C for a global-average stage (then m (nseg, C), mu2 (C)
+    and meshes — rows_per_seg > 0 for equal ones, seg = operators.PackedSegments for ragged ones)."""
+    _dev(dy, x, center, W, s, invstd, beta, m, mu2)
+    rows, J = dy.shape
+    C = x.shape[1]
+    Ct = W.shape[1]
+    dev = dy.device
+    if x.shape[0] != rows or W.shape[0] != J or Ct not in (C, 2 * C):
+        raise ValueError("wgrad_bn: shape mismatch")
+    counters = _fold_counter(dev, Ct // 32)
+    if counters is None:
+        return None
+    nseg = seg.nseg if seg is not None else (rows // rows_per_seg if rows_per_seg > 0 else 0)
+    nslab_r = seg.nslab if seg is not None else 0
+    ws_bytes = int(_lib.load().sn_wgrad_bn_workspace_bytes(rows, rows_per_seg if seg is None else 0, nslab_r, J, C, Ct))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    Gc = torch.empty((J, Ct), dtype=torch.float32, device=dev)
+    dW = torch.empty((J, Ct), dtype=torch.float32, device=dev)
+    db = torch.empty(J, dtype=torch.float32, device=dev) if has_bias else None
+    vec = torch.empty((4, Ct), dtype=torch.float32, device=dev)
+    Sg = torch.empty((nseg, J), dtype=torch.float32, device=dev) if nseg > 0 else None
+    b = _bounds_args(bounds, C) if bounds is not None else (None, 0, None, 0)
+    _lib.call("sn_wgrad_bn_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, J, C, rows_per_seg if seg is None else 0,
+              _p(seg.slab_off) if seg is not None else None, nslab_r, _p(seg.seg_slab_ptr) if seg is not None else None,
+              seg.nseg if seg is not None else 0, *b, _p(W.contiguous()), _p(s), _p(invstd), _p(beta.contiguous()), bn_rows, Ct,
+              _p(m), _p(mu2), _p(Gc), _p(dW), _p(db), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(Sg), None, _p(ws), ws_bytes,
+              counters, _stream())
+    return dW, db, vec[0], vec[1], vec[2], vec[3], Sg
 
 
 def segment_colsum(x, mask, rows_per_seg: int, nseg: int):

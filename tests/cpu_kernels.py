@@ -193,6 +193,10 @@ def wgrad_supported(J, C):
     return C in (128, 256) and J <= 128 and J % 4 == 0
 
 
+def wgrad_bn_supported(J, C):
+    return False          # the host twins keep the separate steps (product, reduction, coefficients)
+
+
 def absmax_wanted():
     return False          # the host twins have one weight gradient (exact): no bounds are produced or consumed
 

@@ -1092,3 +1092,127 @@ def test_arap_model_with_and_without_tile_sums(monkeypatch):
         res.append((loss.item(), torch.cat([p.grad.reshape(-1) for p in model.parameters()])))
     assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[1][0])
     assert float((res[0][1] - res[1][1]).norm() / res[1][1].norm()) < 2e-5
+
+
+# ---- weight gradient + BatchNorm backward coefficients in two launches (sn_wgrad_bn_f32) -------------------------------------
+def _bn_operands(rng, rows, J, C, Ct):
+    dy = dev(rng.standard_normal((rows, J)).astype(np.float32))
+    x = dev((rng.standard_normal((rows, C)) * 1.5 + rng.standard_normal(C)).astype(np.float32))
+    W = dev((rng.standard_normal((J, Ct)) / 9).astype(np.float32))
+    gamma, beta = [dev(rng.standard_normal(Ct).astype(np.float32)) for _ in range(2)]
+    return dy, x, W, gamma, beta
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+@pytest.mark.parametrize("rows,J,C", [(1, 128, 128), (37, 128, 256), (5000, 120, 128), (40001, 128, 256), (322624, 128, 128), (9000, 4, 256)])
+def test_weight_gradient_and_batchnorm_coefficients_in_two_launches(rows, J, C, bounded):
+    """kernels.wgrad_bn (product + ONE finishing launch with per-channel-group tickets) against the launches it replaces —
+    product, split-K reduction, coefficients — bit for bit, and against fp64."""
+    rng = np.random.default_rng(rows + J + C)
+    dy, x, W, gamma, beta = _bn_operands(rng, rows, J, C, C)
+    st = kernels.colstats(x)
+    mean64 = st[0] / rows
+    var64 = (st[1] / rows - mean64 * mean64).clamp_min(0)
+    invstd = (1.0 / torch.sqrt(var64 + 1e-5)).float()
+    mean = mean64.float()
+    s = (gamma.double() * invstd.double()).float()
+    bounds = (dy.abs().max().reshape(1), invstd, rows) if bounded else None
+    G, sdy = kernels.wgrad(dy, x, mean, want_colsum=True, bounds=bounds)
+    want = kernels.bn_bwd_coeffs(G, sdy, W, s, invstd, beta, rows, True)
+    for rep in range(3):                      # (the counters return to zero: repeated launches draw fresh tickets)
+        got = kernels.wgrad_bn(dy, x, mean, W, s, invstd, beta, rows, True, bounds)
+        assert got is not None and got[6] is None
+        for a, b, name in zip(got[:6], want, ("dW", "db", "dgamma", "dbeta", "Bc", "Cc")):
+            assert torch.equal(a, b), (name, rep, float((a - b).abs().max()))
+    G64 = dy.double().t() @ (x.double() - mean.double())
+    dW64 = G64 * s.double() + dy.double().sum(0)[:, None] * beta.double()
+    assert float((got[0].double() - dW64).abs().max()) <= 2e-5 * float(dW64.abs().max()) + 1e-6
+    assert kernels.wgrad_bn(dy, x, mean, W, s, invstd, beta, rows, False, bounds)[1] is None       # no bias: no db
+
+
+@pytest.mark.parametrize("bounded", [False, True])
+@pytest.mark.parametrize("nseg,per", [(3, 150), (7, 33), (2, 5041), (64, 300), (300, 40)])
+def test_global_average_stage_backward_in_two_launches(nseg, per, bounded):
+    """The same for a global-average stage (W over [e | per-mesh mean]): equal meshes and the ragged form of the same batch
+    against wgrad_seg / wgrad_slabs + avg_bwd_gc + bn_bwd_coeffs, bit for bit (the per-mesh column sums of dy included)."""
+    from surfacenetworks_amd.operators import PackedSegments
+
+    J = C = 128
+    rows = nseg * per
+    rng = np.random.default_rng(nseg * 1000 + per)
+    dy, e, W, gamma, beta = _bn_operands(rng, rows, J, C, 2 * C)
+    m = e.view(nseg, per, C).mean(1).contiguous()
+    mean = torch.cat([e.mean(0), m.mean(0)]).contiguous()
+    var = torch.cat([e.var(0, unbiased=False), m.var(0, unbiased=False)]) if rows > 1 else torch.ones(2 * C, device=DEV)
+    invstd = (1.0 / torch.sqrt(var + 1e-5)).contiguous()
+    s = (gamma * invstd).contiguous()
+    bounds = (dy.abs().max().reshape(1), invstd[:C].contiguous(), rows) if bounded else None
+    G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per, bounds=bounds)
+    want = kernels.bn_bwd_coeffs(kernels.avg_bwd_gc(G1, Sg, m, mean[C:]), sdy, W, s, invstd, beta, rows, True)
+    got = kernels.wgrad_bn(dy, e, mean[:C], W, s, invstd, beta, rows, True, bounds, rows_per_seg=per, m=m, mu2=mean[C:])
+    for a, b, name in zip(got[:6], want, ("dW", "db", "dgamma", "dbeta", "Bc", "Cc")):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    assert torch.equal(got[6], Sg)
+    # ragged form of the same batch (slabs from the segment table)
+    seg = PackedSegments([per] * nseg, DEV)
+    G1r, sdyr, Sgr = kernels.wgrad_slabs(dy, e, mean[:C], seg, bounds=bounds)
+    wantr = kernels.bn_bwd_coeffs(kernels.avg_bwd_gc(G1r, Sgr, m, mean[C:]), sdyr, W, s, invstd, beta, rows, True)
+    gotr = kernels.wgrad_bn(dy, e, mean[:C], W, s, invstd, beta, rows, True, bounds, seg=seg, m=m, mu2=mean[C:])
+    for a, b, name in zip(gotr[:6], wantr, ("dW", "db", "dgamma", "dbeta", "Bc", "Cc")):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    assert torch.equal(gotr[6], Sgr)
+
+
+def test_two_launch_backward_argument_checks():
+    from surfacenetworks_amd import _lib
+    from surfacenetworks_amd.kernels import _p, _ld, _stream
+
+    lib = _lib.load()
+    rows, J, C = 100, 128, 128
+    rng = np.random.default_rng(5)
+    dy, x, W, gamma, beta = _bn_operands(rng, rows, J, C, C)
+    v = torch.ones(C, device=DEV)
+    out = torch.empty(J, C, device=DEV)
+    o4 = torch.empty(4, C, device=DEV)
+    nbytes = int(lib.sn_wgrad_bn_workspace_bytes(rows, 0, 0, J, C, C))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+    cnt = torch.zeros(8, dtype=torch.int32, device=DEV)
+
+    def call(rows_=rows, Ct=C, ws_bytes=nbytes, counters=cnt, m=None):
+        return lib.sn_wgrad_bn_f32(_p(dy), _ld(dy), _p(x), _ld(x), _p(v), rows_, J, C, 0, None, 0, None, 0, None, 0, None, 0, _p(W), _p(v),
+                                   _p(v), _p(v), rows, Ct, m, None, _p(out), _p(out), None, _p(o4[0]), _p(o4[1]), _p(o4[2]), _p(o4[3]),
+                                   None, None, _p(ws), ws_bytes, _p(counters) if counters is not None else None, _stream())
+
+    assert call() == 0
+    assert call(rows_=0) == -2                  # SN_E_SHAPE: nothing to finish
+    assert call(Ct=96) == -2                    # neither C nor 2 C
+    assert call(Ct=2 * C) == -1                 # SN_E_NULL: the global-average form needs meshes and their means
+    assert call(ws_bytes=nbytes - 16) == -6     # SN_E_WORKSPACE
+    assert call(counters=None) == -1
+    torch.cuda.synchronize()
+    assert int(cnt.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("rows", [1, 2, 3, 31, 33, 1000])
+def test_two_piece_weight_gradient_ignores_the_rows_past_the_end(rows):
+    """The two-piece fp16 weight gradient pads a slab's last block with zero rows; centred they are -mean, which the bound on
+    |x - mean| does not cover — a column far from zero with a tiny spread (an ELU unit sitting at -1) scaled past fp16's range
+    and met the padded dy rows' exact zeros as inf x 0.  Must agree with the three-piece form for such columns too."""
+    rng = np.random.default_rng(rows)
+    J = C = 128
+    dy = dev(rng.standard_normal((rows, J)).astype(np.float32))
+    xn = rng.standard_normal((rows, C)).astype(np.float32)
+    xn[:, ::3] = -1.0 + 1e-4 * xn[:, ::3]                 # saturated units
+    xn[:, 1::3] = 1000.0 + 0.5 * xn[:, 1::3]              # large offset, small spread
+    x = dev(xn)
+    mean = x.double().mean(0)
+    var = ((x.double() - mean) ** 2).mean(0)
+    invstd = (1.0 / torch.sqrt(var + 1e-5)).float()
+    meanf = mean.float()
+    bounds = (dy.abs().max().reshape(1), invstd, rows)
+    G, sdy = kernels.wgrad(dy, x, meanf, want_colsum=True, bounds=bounds)
+    G0, sdy0 = kernels.wgrad(dy, x, meanf, want_colsum=True)
+    assert bool(torch.isfinite(G).all())
+    ref = dy.double().t() @ (x.double() - meanf.double())
+    assert float((G.double() - ref).abs().max()) <= 2.0 * float((G0.double() - ref).abs().max()) + 1e-5 * float(ref.abs().max()) + 1e-6
+    assert torch.equal(sdy, sdy0)
