@@ -385,3 +385,67 @@ def test_siamese_gradients_meet_once():
 
 def test_mnist_driver_evaluation_mode():
     pc.check_mnist_evaluation_mode(DEV)
+
+
+@pytest.mark.parametrize("cname", ["LapResNet2", "DirResNet2", "AvgResNet2"])
+def test_blocks_survive_degenerate_column_statistics(golden_dir, cname):
+    """Feature columns a trained network does produce and random tests do not: units saturated behind the ELU (exactly -1 in
+    fp32), a large offset with a small spread, an exactly constant column.  The two-piece fp16 kernels scale their operands by
+    bounds derived from BatchNorm's statistics; padded rows, zero variance and |mean| >> spread must neither overflow nor turn
+    into NaN (a padded row did, tests/test_dense_gpu.py::test_two_piece_weight_gradient_ignores_the_rows_past_the_end).
+    Two blocks deep; whole-block nodes (bounded two-piece products) and per-stage functions (three-piece products) are each held
+    to the model criterion: as close to the float64 oracle as the reference composition in float32 is (x 4) — the problem
+    itself is ill-conditioned here (BatchNorm of a nearly constant column), so a flat tolerance would measure the data."""
+    import surfacenetworks_amd.utils_pt as U
+    from helpers import deterministic_init, det_tensor, rel_err
+    from oracle import ref_blocks as OB
+
+    rb, ops = pc.batch_operators(golden_dir, "pool", DEV)
+    B, nv, nf, C = rb["mask"].shape[0], int(rb["nv"]), int(rb["nf"]), 128
+    base = det_tensor((B, nv, C), 1)
+    hostile = base.copy()
+    hostile[:, :, 0::4] = -30.0 + 1e-3 * base[:, :, 0::4]            # saturated behind the activation
+    hostile[:, :, 1::4] = 1000.0 + 0.5 * base[:, :, 1::4]            # |mean| >> spread
+    hostile[:, :, 2::4] = 3.0                                        # constant: zero variance
+    hostile = hostile * rb["mask"]
+    fh = det_tensor((B, nf, C), 2)
+    fh[:, :, 0::2] = -25.0 + 1e-3 * fh[:, :, 0::2]
+
+    def run(make, dtype, dev, opsd, mask):
+        b1 = deterministic_init(make(C), 3).train().to(dev).to(dtype)
+        b2 = deterministic_init(make(C), 4).train().to(dev).to(dtype)
+        v = torch.from_numpy(hostile).to(dev).to(dtype).requires_grad_(True)
+        if cname == "DirResNet2":
+            f = torch.from_numpy(fh).to(dev).to(dtype).requires_grad_(True)
+            v1, f1 = b1(opsd["Di"], opsd["DiA"], v, f)
+            v2, f2 = b2(opsd["Di"], opsd["DiA"], v1, f1)
+            loss = (v2 * v2).mean() + f2.sum() * 1e-3 + v1.mean()
+            outs, gins = [v2, f2], [v, f]
+        else:
+            arg = opsd["L"] if cname == "LapResNet2" else None
+            v1 = b1(arg, mask, v)
+            v2 = b2(arg, mask, v1)
+            loss = (v2 * v2).mean() + v1.mean()
+            outs, gins = [v2], [v]
+        loss.backward()
+        return [t.detach().double().cpu().numpy() for t in outs] + [t.grad.double().cpu().numpy() for t in gins] + \
+            [b1.bn_fc0.fc.weight.grad.double().cpu().numpy(), b2.bn_fc1.fc.weight.grad.double().cpu().numpy(),
+             b2.bn_fc0.bn.weight.grad.double().cpu().numpy(), b1.bn_fc1.bn.running_var.double().cpu().numpy()]
+
+    def cpu_ops(dt):
+        return {k: torch.sparse_coo_tensor(torch.from_numpy(rb[f"{k}_bd_indices"]), torch.from_numpy(rb[f"{k}_bd_values"]).to(dt),
+                                           tuple(rb[f"{k}_bd_shape"])).coalesce() for k in ("L", "Di", "DiA")}
+
+    truth = run(getattr(OB, cname), torch.float64, "cpu", cpu_ops(torch.float64), torch.from_numpy(rb["mask"]).double())
+    ref32 = run(getattr(OB, cname), torch.float32, "cpu", cpu_ops(torch.float32), torch.from_numpy(rb["mask"]))
+    mask = torch.from_numpy(rb["mask"]).to(DEV)
+    for whole in (True, False):
+        U.USE_WHOLE_BLOCKS = whole
+        try:
+            got = run(getattr(U, cname), torch.float32, DEV, ops, mask)
+        finally:
+            U.USE_WHOLE_BLOCKS = True
+        for k, (a, r, t) in enumerate(zip(got, ref32, truth)):
+            assert np.isfinite(a).all(), (whole, k)
+            ea, er = rel_err(a, t), rel_err(r, t)
+            assert ea <= max(4 * er, 2e-5), (whole, k, "product", ea, "reference fp32", er)
