@@ -239,6 +239,13 @@ int sn_spmm_rb4_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_v
 int sn_spmm_rb4_elubwd_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K,
                            int64_t capacity, const float *X, int64_t ldx, int32_t N, const float *E, int64_t lde,
                            const float *G, int64_t ldg, float *Y, int64_t ldy, void *stream);
+/* ... and max |Y| per wave into y_absmax[sn_spmm_rb4_absmax_blocks(M, N)] floats (every entry written): the bound the two-piece
+ * weight gradient of the layer below needs for its dy operand (sn_wgrad_bounded_f32) — the fused backward of a Laplacian stage
+ * (SparseBMMFunc.backward + ELUBackward, sparse_bmm_func.py:60-71) writes exactly that operand. */
+int64_t sn_spmm_rb4_absmax_blocks(int64_t M, int32_t N);
+int sn_spmm_rb4_elubwd_absmax_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K,
+                                  int64_t capacity, const float *X, int64_t ldx, int32_t N, const float *E, int64_t lde,
+                                  const float *G, int64_t ldg, float *Y, int64_t ldy, float *y_absmax, void *stream);
 size_t sn_spmm_rb4_stats_workspace_bytes(int64_t M);
 int sn_spmm_rb4_stats_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K,
                           int64_t capacity, const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy,
@@ -262,6 +269,12 @@ int sn_spmm_csr_ring_f32(const int32_t *rowptr, const int32_t *colind, const flo
 int sn_spmm_csr_ring_elubwd_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
                                 int64_t nnz, const float *X, int64_t ldx, int32_t N, const float *E, int64_t lde, const float *G,
                                 int64_t ldg, float *Y, int64_t ldy, void *stream);
+/* ... and max |Y| per compute wave into y_absmax[sn_spmm_csr_ring_absmax_blocks(M, N)] floats (every entry written; as
+ * sn_spmm_rb4_elubwd_absmax_f32).  An operator without entries is not taken (SN_E_UNSUPPORTED). */
+int64_t sn_spmm_csr_ring_absmax_blocks(int64_t M, int32_t N);
+int sn_spmm_csr_ring_elubwd_absmax_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
+                                       int64_t nnz, const float *X, int64_t ldx, int32_t N, const float *E, int64_t lde,
+                                       const float *G, int64_t ldg, float *Y, int64_t ldy, float *y_absmax, void *stream);
 size_t sn_spmm_csr_ring_stats_workspace_bytes(int64_t M);
 int sn_spmm_csr_ring_stats_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K, int64_t nnz,
                                const float *X, int64_t ldx, int32_t N, float *Y, int64_t ldy, double *stats_part, void *workspace,

@@ -41,10 +41,15 @@ SIGNATURES = {
     "sn_rb4_fill": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _vp]),
     "sn_spmm_rb4_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
     "sn_spmm_rb4_elubwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "sn_spmm_rb4_absmax_blocks": (_i64, [_i64, _i32]),
+    "sn_spmm_rb4_elubwd_absmax_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
     "sn_spmm_rb4_stats_workspace_bytes": (_sz, [_i64]),
     "sn_spmm_rb4_stats_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sn_spmm_csr_ring_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp]),
     "sn_spmm_csr_ring_elubwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp]),
+    "sn_spmm_csr_ring_absmax_blocks": (_i64, [_i64, _i32]),
+    "sn_spmm_csr_ring_elubwd_absmax_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _vp,
+                                                     _vp]),
     "sn_spmm_csr_ring_stats_workspace_bytes": (_sz, [_i64]),
     "sn_spmm_csr_ring_stats_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _vp, _i64, _i32, _vp, _i64, _vp, _vp, _sz, _vp]),
     "sn_spmm_csr_ring_half_window": (_i32, []),

@@ -134,10 +134,25 @@ struct SpmmEpi {
   int64_t lde;
   const float *g;
   int64_t ldg;
-  float *absmax = nullptr;      // (quaternion-packed kernel) [gridDim.x]: max |Y| over the rows of each workgroup — sn_spmm_q3_elubwd_absmax_f32
+  // max |Y| over the rows a workgroup (quaternion-packed kernel: [gridDim.x]) or a wave (row-blocked and sliding-window Laplacian
+  // kernels: [gridDim.x * waves]) wrote — sn_spmm_q3_elubwd_absmax_f32, sn_spmm_rb4_elubwd_absmax_f32, sn_spmm_csr_ring_elubwd_absmax_f32
+  float *absmax = nullptr;
 };
 __device__ __forceinline__ f4 fabs4(const f4 &a) {
   return f4{__builtin_fabsf(a.x), __builtin_fabsf(a.y), __builtin_fabsf(a.z), __builtin_fabsf(a.w)};
+}
+__device__ __forceinline__ float hmax_abs4(const f4 &a) {
+  return fmaxf(fmaxf(__builtin_fabsf(a.x), __builtin_fabsf(a.y)), fmaxf(__builtin_fabsf(a.z), __builtin_fabsf(a.w)));
+}
+// the maximum of a non-negative float over the wave (non-negative floats order like their bit patterns), in every lane
+__device__ __forceinline__ float wave_max_nonneg(float m) {
+  unsigned mb = __float_as_uint(m);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned other = (unsigned)__shfl_xor((int)mb, o);
+    mb = other > mb ? other : mb;
+  }
+  return __uint_as_float(mb);
 }
 __device__ __forceinline__ f4 elu_bwd4(const f4 &a, const f4 &o) {
   return f4{a.x * (o.x > 0.f ? 1.f : o.x + 1.f), a.y * (o.y > 0.f ? 1.f : o.y + 1.f), a.z * (o.z > 0.f ? 1.f : o.z + 1.f),
@@ -1127,8 +1142,13 @@ __device__ __forceinline__ void spmm_rb4_body(const int *__restrict__ b_ptr, con
   const int R = P * iters;                                        // groups of this wave (<= 64)
   const int g0 = (my_chunk(nchunks) * WAVES + wave) * R;
   if constexpr (!STATS) {
-    if (g0 >= Mb) return;                                         // wave-uniform
+    if (g0 >= Mb) {                                               // wave-uniform
+      if constexpr (EPI)
+        if (epi.absmax && lane == 0) epi.absmax[(int64_t)blockIdx.x * WAVES + wave] = 0.f;
+      return;
+    }
   }
+  float am = 0.f;                                                 // EPI with epi.absmax: max |Y| over this wave's rows
   {
     int gl = g0 + lane;
     gl = gl < Mb ? gl : Mb;
@@ -1207,6 +1227,7 @@ __device__ __forceinline__ void spmm_rb4_body(const int *__restrict__ b_ptr, con
           if constexpr (EPI) {
             v = elu_bwd4(v, ld4_s(epi.e + (int64_t)rr * epi.lde + sub * 4, kStreamNT));
             if (epi.g) v += ld4_s(epi.g + (int64_t)rr * epi.ldg + sub * 4, kStreamNT);
+            if (epi.absmax) am = fmaxf(am, hmax_abs4(v));
           }
           st4_stream(Y + (int64_t)rr * ldy + sub * 4, v);
           if constexpr (STATS) {
@@ -1220,6 +1241,12 @@ __device__ __forceinline__ void spmm_rb4_body(const int *__restrict__ b_ptr, con
       finish(acc1, r + 1);
       finish(acc2, r + 2);
       finish(acc3, r + 3);
+    }
+  }
+  if constexpr (EPI) {
+    if (epi.absmax) {
+      am = wave_max_nonneg(am);
+      if (lane == 0) epi.absmax[(int64_t)blockIdx.x * WAVES + wave] = am;
     }
   }
   if constexpr (STATS) {
@@ -1356,6 +1383,9 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
       if (li / nsl < spx && threadIdx.x < 2 * CS)
         stats_part[(int64_t)strip * 256 + (threadIdx.x / CS) * 128 + c0 + (threadIdx.x % CS)] = 0.f;
     }
+    if constexpr (EPI) {
+      if (epi.absmax && threadIdx.x < NCW) epi.absmax[(int64_t)blockIdx.x * NCW + threadIdx.x] = 0.f;
+    }
     return;
   }
 
@@ -1434,6 +1464,7 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
   f4 ssum[NV], ssq[NV];
 #pragma unroll
   for (int v = 0; v < NV; ++v) ssum[v] = ssq[v] = f4{0.f, 0.f, 0.f, 0.f};
+  float am = 0.f;                                                     // EPI with epi.absmax: max |Y| over this wave's rows
   f4 evn[NV], gvn[NV];                                                // epilogue operands of the NEXT step (requested a step ahead)
   if constexpr (EPI) {
     const int rf = t0 * R + wave * 8 + g;
@@ -1571,7 +1602,10 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
 #pragma unroll
       for (int v = 0; v < NV; ++v) {
         f4 o = acc[v];
-        if constexpr (EPI) o = ring_epilogue(o, ev[v], gv[v], epi.g != nullptr);
+        if constexpr (EPI) {
+          o = ring_epilogue(o, ev[v], gv[v], epi.g != nullptr);
+          if (epi.absmax) am = fmaxf(am, hmax_abs4(o));
+        }
         if (SN_X_RING_ST_PLAIN) st4(Y + (int64_t)r * ldy + c0 + v * 32 + sub * 4, o);
         else st4_stream(Y + (int64_t)r * ldy + c0 + v * 32 + sub * 4, o);
         if constexpr (STATS) {
@@ -1583,6 +1617,12 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                // every LDS read of this step has returned
     __builtin_amdgcn_s_barrier();
+  }
+  if constexpr (EPI) {
+    if (epi.absmax) {                                                 // one slot per compute wave: no meeting, no scratch
+      am = wave_max_nonneg(am);
+      if (lane == 0) epi.absmax[(int64_t)blockIdx.x * NCW + wave] = am;
+    }
   }
   if constexpr (STATS) {
     // column sums / sums of squares of this workgroup's output rows -> stats_part[strip][sum | squares][128] (fp32 over the
@@ -2290,6 +2330,21 @@ int sn_spmm_rb4_elubwd_f32(const int32_t *b_ptr, const int32_t *b_col, const flo
   return spmm_rb4_launch(b_ptr, b_col, b_val, M, K, capacity, X, ldx, N, Y, ldy, SpmmEpi{E, lde, G, ldg}, stream);
 }
 
+// the same launch, and max |Y| of every wave in y_absmax[sn_spmm_rb4_absmax_blocks(M, N)] (all entries written): the bound the
+// two-piece weight gradient of the layer below needs for its dy operand (sn_wgrad_bounded_f32)
+int64_t sn_spmm_rb4_absmax_blocks(int64_t M, int32_t N) {
+  if (M < 1 || (N != 64 && N != 128)) return 0;
+  const int64_t Mb = (M + 3) / 4;
+  return (int64_t)chunk_grid(rb4_chunks(Mb, N, rb4_iters(Mb, N))) * (kWG / 64);
+}
+int sn_spmm_rb4_elubwd_absmax_f32(const int32_t *b_ptr, const int32_t *b_col, const float *b_val, int64_t M, int64_t K,
+                                  int64_t capacity, const float *X, int64_t ldx, int32_t N, const float *E, int64_t lde,
+                                  const float *G, int64_t ldg, float *Y, int64_t ldy, float *y_absmax, void *stream) {
+  if (!E || !y_absmax) return SN_E_NULL;
+  if (M < 1) return SN_E_SHAPE;
+  return spmm_rb4_launch(b_ptr, b_col, b_val, M, K, capacity, X, ldx, N, Y, ldy, SpmmEpi{E, lde, G, ldg, y_absmax}, stream);
+}
+
 size_t sn_spmm_rb4_stats_workspace_bytes(int64_t M) {
   if (M < 1) return 0;
   const int64_t Mb = (M + 3) / 4;
@@ -2390,6 +2445,21 @@ int sn_spmm_csr_ring_elubwd_f32(const int32_t *rowptr, const int32_t *colind, co
                                 int64_t ldg, float *Y, int64_t ldy, void *stream) {
   if (!E) return SN_E_NULL;
   return spmm_ring_launch(rowptr, colind, vals, M, K, nnz, X, ldx, N, Y, ldy, SpmmEpi{E, lde, G, ldg}, stream);
+}
+
+// the same launch, and max |Y| of every compute wave in y_absmax[sn_spmm_csr_ring_absmax_blocks(M, N)] (all entries written);
+// an operator without entries is not taken (SN_E_UNSUPPORTED: that launch goes through the generic kernel)
+int64_t sn_spmm_csr_ring_absmax_blocks(int64_t M, int32_t N) {
+  if (M < 1 || (N != 64 && N != 128)) return 0;
+  return (int64_t)ring_strips(M, N) * (N / kRingCS) * kRingNCW;
+}
+int sn_spmm_csr_ring_elubwd_absmax_f32(const int32_t *rowptr, const int32_t *colind, const float *vals, int64_t M, int64_t K,
+                                       int64_t nnz, const float *X, int64_t ldx, int32_t N, const float *E, int64_t lde,
+                                       const float *G, int64_t ldg, float *Y, int64_t ldy, float *y_absmax, void *stream) {
+  if (!E || !y_absmax) return SN_E_NULL;
+  if (M < 1) return SN_E_SHAPE;
+  if (nnz == 0) return SN_E_UNSUPPORTED;
+  return spmm_ring_launch(rowptr, colind, vals, M, K, nnz, X, ldx, N, Y, ldy, SpmmEpi{E, lde, G, ldg, y_absmax}, stream);
 }
 
 size_t sn_spmm_csr_ring_stats_workspace_bytes(int64_t M) {

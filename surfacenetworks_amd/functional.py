@@ -131,6 +131,11 @@ class SpmmTimer:
         return out
 
 
+# SN_LAP_ABSMAX=0: the fused transposed Laplacian products leave no maxima (the weight gradients behind them then take three
+# bf16 pieces) — A/B switch
+_LAP_ABSMAX = os.environ.get("SN_LAP_ABSMAX", "1") != "0"
+
+
 def _ctypes_i64_ref():
     import ctypes
 
@@ -171,12 +176,16 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
         # banded square operator on a batch that fills the chip: sliding window over X in LDS, straight from the CSR arrays
         if stats and e is None and y.shape[1] == 128:
             return kernels.spmm_ring_stats(op.rowptr, op.colind, op.vals, M, K, x, y)
-        kernels.spmm_ring(op.rowptr, op.colind, op.vals, M, K, x, y, e, g)
+        am = kernels.spmm_ring(op.rowptr, op.colind, op.vals, M, K, x, y, e, g, want_absmax=e is not None and _LAP_ABSMAX and kernels.absmax_wanted())
+        if am is not None:
+            kernels.note_absmax(y, am)               # (as the packed Dirac product above: y is the dy of the layer below)
     elif _LAPLACIAN_FORMAT in ("ring", "rb4") and kernels.spmm_rb4_supported(y.shape[1] // group, group) and op.rb4() is not None:
         r = op.rb4()                                   # Laplacian-type operator: one gather per listed column of a 4-row group
         if stats and e is None and y.shape[1] == 128:
             return kernels.spmm_rb4_stats(r[0], r[1], r[2], M, K, x, y)
-        kernels.spmm_rb4(r[0], r[1], r[2], M, K, x, y, e, g)
+        am = kernels.spmm_rb4(r[0], r[1], r[2], M, K, x, y, e, g, want_absmax=e is not None and _LAP_ABSMAX and kernels.absmax_wanted())
+        if am is not None:
+            kernels.note_absmax(y, am)
     elif elubwd is None:
         if stats and kernels.spmm_csr_stats_supported(y.shape[1] // group, group):
             return kernels.spmm_csr_stats(op.rowptr, op.colind, op.vals, M, K, x, y)

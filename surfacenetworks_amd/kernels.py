@@ -115,8 +115,9 @@ def spmm_rb4_supported(N: int, group: int) -> bool:
     return group == 1 and N in (64, 128)
 
 
-def spmm_rb4(b_ptr, b_col, b_val, M: int, K: int, x, y, e=None, g=None) -> None:
-    """y <- A·x for an RB4 operator (sn_spmm_rb4_f32); with e: (A·x) * elu'(e) + g (sn_spmm_rb4_elubwd_f32)."""
+def spmm_rb4(b_ptr, b_col, b_val, M: int, K: int, x, y, e=None, g=None, want_absmax: bool = False):
+    """y <- A·x for an RB4 operator (sn_spmm_rb4_f32); with e: (A·x) * elu'(e) + g (sn_spmm_rb4_elubwd_f32).
+    want_absmax (with e): also returns the per-wave maxima of |y| (sn_spmm_rb4_elubwd_absmax_f32), else None."""
     _dev(b_ptr, b_col, b_val, x, y, e, g)
     N = y.shape[1]
     ldx = _check_dense(x, K, 1, N, "x")
@@ -127,8 +128,14 @@ def spmm_rb4(b_ptr, b_col, b_val, M: int, K: int, x, y, e=None, g=None) -> None:
     else:
         lde = _check_dense(e, M, 1, N, "e")
         ldg = _check_dense(g, M, 1, N, "g") if g is not None else 0
+        if want_absmax and M > 0:
+            am = torch.empty(int(_lib.load().sn_spmm_rb4_absmax_blocks(M, N)), dtype=torch.float32, device=y.device)
+            _lib.call("sn_spmm_rb4_elubwd_absmax_f32", _p(b_ptr), _p(b_col), _p(b_val), M, K, cap, _p(x), ldx, N, _p(e), lde, _p(g),
+                      ldg, _p(y), ldy, _p(am), _stream())
+            return am
         _lib.call("sn_spmm_rb4_elubwd_f32", _p(b_ptr), _p(b_col), _p(b_val), M, K, cap, _p(x), ldx, N, _p(e), lde, _p(g), ldg,
                   _p(y), ldy, _stream())
+    return None
 
 
 def spmm_rb4_stats(b_ptr, b_col, b_val, M: int, K: int, x, y):
@@ -176,9 +183,10 @@ def csr_band(rowptr, colind, M: int, K: int):
     return int(band), int(longest), int(outside)
 
 
-def spmm_ring(rowptr, colind, vals, M: int, K: int, x, y, e=None, g=None) -> None:
+def spmm_ring(rowptr, colind, vals, M: int, K: int, x, y, e=None, g=None, want_absmax: bool = False):
     """y <- A·x for a banded square CSR operator through the sliding-window kernel (sn_spmm_csr_ring_f32); with e:
-    (A·x) * elu'(e) + g (sn_spmm_csr_ring_elubwd_f32).  Bit-identical to spmm_csr."""
+    (A·x) * elu'(e) + g (sn_spmm_csr_ring_elubwd_f32).  Bit-identical to spmm_csr.
+    want_absmax (with e): also returns the per-wave maxima of |y| (sn_spmm_csr_ring_elubwd_absmax_f32), else None."""
     _dev(rowptr, colind, vals, x, y, e, g)
     N = y.shape[1]
     ldx = _check_dense(x, K, 1, N, "x")
@@ -189,8 +197,14 @@ def spmm_ring(rowptr, colind, vals, M: int, K: int, x, y, e=None, g=None) -> Non
     else:
         lde = _check_dense(e, M, 1, N, "e")
         ldg = _check_dense(g, M, 1, N, "g") if g is not None else 0
+        if want_absmax and M > 0 and nnz > 0:
+            am = torch.empty(int(_lib.load().sn_spmm_csr_ring_absmax_blocks(M, N)), dtype=torch.float32, device=y.device)
+            _lib.call("sn_spmm_csr_ring_elubwd_absmax_f32", _p(rowptr), _p(colind), _p(vals), M, K, nnz, _p(x), ldx, N, _p(e), lde,
+                      _p(g), ldg, _p(y), ldy, _p(am), _stream())
+            return am
         _lib.call("sn_spmm_csr_ring_elubwd_f32", _p(rowptr), _p(colind), _p(vals), M, K, nnz, _p(x), ldx, N, _p(e), lde, _p(g), ldg,
                   _p(y), ldy, _stream())
+    return None
 
 
 def spmm_ring_stats(rowptr, colind, vals, M: int, K: int, x, y):

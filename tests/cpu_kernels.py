@@ -451,7 +451,7 @@ def _rb4_to_csr(b_ptr, b_col, b_val, M):
     return torch.from_numpy(rowptr), torch.from_numpy(colind), torch.from_numpy(vals)
 
 
-def spmm_rb4(b_ptr, b_col, b_val, M, K, x, y, e=None, g=None):
+def spmm_rb4(b_ptr, b_col, b_val, M, K, x, y, e=None, g=None, want_absmax=False):
     rp, ci, va = _rb4_to_csr(b_ptr, b_col, b_val, M)
     spmm_csr(rp, ci, va, M, K, x, y, 1)
     if e is not None:
@@ -486,7 +486,7 @@ def csr_band(rowptr, colind, M, K):
     return int(far.max()), int(cnt.max()), int(np.unique(rows[far > ring_half_window()]).size)
 
 
-def spmm_ring(rowptr, colind, vals, M, K, x, y, e=None, g=None):
+def spmm_ring(rowptr, colind, vals, M, K, x, y, e=None, g=None, want_absmax=False):
     spmm_csr(rowptr, colind, vals, M, K, x, y, 1)                   # (bit-identical to the CSR kernel by contract)
     if e is not None:
         _elubwd_epilogue(y, e, g)

@@ -102,6 +102,10 @@ def main():
                 kernels.spmm_rb4(b[0], b[1], b[2], M, K, dev(x), ye, dev(e), dev(gg) if gg is not None else None)
                 w = want * d if gg is None else want * d + gg
                 assert np.array_equal(ye.cpu().numpy(), w.astype(np.float32)), ("rb4 epi", N, M)
+                ya = torch.full((M, N), float("nan"), device=DEV)          # ... and the maxima of |y| (one per wave)
+                am = kernels.spmm_rb4(b[0], b[1], b[2], M, K, dev(x), ya, dev(e), dev(gg) if gg is not None else None, want_absmax=True)
+                assert am is not None and torch.equal(ya, ye) and bool(torch.isfinite(am).all()) and float(am.min()) >= 0.0
+                assert float(am.max()) == float(np.abs(w.astype(np.float32)).max()), ("rb4 epi maxima", N, M)
             if N == 128:
                 ys = torch.full((M, N), float("nan"), device=DEV)
                 part = kernels.spmm_rb4_stats(b[0], b[1], b[2], M, K, dev(x), ys)

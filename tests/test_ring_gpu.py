@@ -88,6 +88,14 @@ def _check(A, rng, N, tag):
         kernels.spmm_ring(rp, ci, va, M, M, dev(x), ye, dev(e), dev(gg) if gg is not None else None)
         w = want * d if gg is None else want * d + gg                  # (a x) * elu'(e) + g, each step rounded to fp32
         assert np.array_equal(ye.cpu().numpy(), w.astype(np.float32)), (tag, N, "epilogue", gg is not None)
+        # the same launch leaving the maxima of |y| (one per compute wave; every slot written): the bound the two-piece weight
+        # gradient of the layer below takes for its dy operand
+        ya = torch.full((M, N), float("nan"), device=DEV)
+        am = kernels.spmm_ring(rp, ci, va, M, M, dev(x), ya, dev(e), dev(gg) if gg is not None else None, want_absmax=True)
+        if A.nnz > 0:
+            assert am is not None and torch.equal(ya, ye), (tag, N, "epilogue with maxima")
+            assert bool(torch.isfinite(am).all()) and float(am.min()) >= 0.0
+            assert float(am.max()) == float(np.abs(w.astype(np.float32)).max()), (tag, N, "maximum")
     if N == 128:
         ys = torch.full((M, N), float("nan"), device=DEV)
         part = kernels.spmm_ring_stats(rp, ci, va, M, M, dev(x), ys)
