@@ -594,7 +594,22 @@ int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W,
  * sn_avg_bwd_segvec_f32 : v[mesh, c] = inv_count[mesh] * ( seg_dy[mesh]·Wf2[:, c] + rows_per_seg * ((m[mesh,c] - mu2[c]) *
  *                         B2[c] + C2[c]) ): gradient of the mean path, added per row (times the row mask) inside
  *                         sn_linear_dgrad_eluseg_f32.
+ * sn_bn_fold_seg_f32    : sn_bn_fold_f32 (training mode) of the stage's 2C-wide layer AND sn_seg_affine_f32 in one launch: the
+ *                         workgroup that folds output row j also forms segbias[g, j] = bf[j] + m[g]·Wf[j, C:] (same operands,
+ *                         same order: the same numbers).  C = the layer's full width (2 x channels of e), <= 256.
+ * sn_avg_bn_bwd_f32     : sn_avg_bwd_gc_f32 + sn_bn_bwd_coeffs_f32 + sn_avg_bwd_segvec_f32 in one launch — all three are per
+ *                         channel, so the workgroup of 32 channels runs them for its own; bit-identical.  G1 (J x C), dystats,
+ *                         seg_dy (nseg x J) from sn_wgrad_seg_f32 / sn_wgrad_slabs_f32; segoff != NULL: ragged meshes (their
+ *                         row counts from the offsets) instead of rows_per_seg.  J <= 128, C % 32 == 0.
  * ------------------------------------------------------------------------------------------ */
+int sn_bn_fold_seg_f32(const double *stats, int64_t rows, const float *gamma, const float *beta, const float *W, const float *b,
+                       int32_t J, int32_t C, double eps, double momentum, float *running_mean, float *running_var, float *mean,
+                       float *invstd, float *s, float *t, float *Wf, float *bf, int64_t *num_batches_tracked, const float *seg_mean,
+                       int64_t nseg, float *segbias, void *stream);
+int sn_avg_bn_bwd_f32(const float *G1, const double *dystats, const float *seg_dy, const float *seg_mean, const float *mu2,
+                      const float *W, const float *s, const float *invstd, const float *beta, int64_t rows, int32_t J, int32_t C,
+                      int64_t nseg, const float *Wf2, int64_t ldw, const float *inv_count, int64_t rows_per_seg, const int64_t *segoff,
+                      float *dW, float *db, float *dgamma, float *dbeta, float *Bc, float *Cc, float *segvec, void *stream);
 /* Ragged forms for PACKED batches (meshes of different sizes, no padding): the rows of mesh g are cut into tiles of at most
  * 256 rows; tiles is an (ntiles x 3) int64 device table {mesh, first row, rows}, tiles of one mesh consecutive,
  * seg_tile_ptr[nseg + 1] the first tile of every mesh.

@@ -71,6 +71,10 @@ SIGNATURES = {
                                            _i64, _vp]),
     "sn_wgrad_slabs_bounded_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz,
                                              _vp, _i64, _vp, _i64, _vp]),
+    "sn_bn_fold_seg_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _vp, _vp, _vp, _i64, _vp, _vp]),
+    "sn_avg_bn_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sn_wgrad_bn_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32, _i32]),
     "sn_wgrad_bn_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i32, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp,
                                   _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),

@@ -1643,7 +1643,9 @@ __global__ __launch_bounds__(kWG) void bn_fold_k(const double *__restrict__ stat
                                                  float *__restrict__ mean_o, float *__restrict__ invstd_o,
                                                  float *__restrict__ s_o, float *__restrict__ t_o,
                                                  float *__restrict__ Wf, float *__restrict__ bf,
-                                                 int64_t *__restrict__ num_batches_tracked) {
+                                                 int64_t *__restrict__ num_batches_tracked,
+                                                 const float *__restrict__ seg_m = nullptr /* [nseg][C/2] */, int nseg = 0,
+                                                 float *__restrict__ segb = nullptr /* [nseg][J] */, int J = 0) {
   __shared__ float ss[1024], st[1024];
   __shared__ double red[kWG];
   const int j = blockIdx.x;
@@ -1689,6 +1691,28 @@ __global__ __launch_bounds__(kWG) void bn_fold_k(const double *__restrict__ stat
     __syncthreads();
   }
   if (threadIdx.x == 0) bf[j] = (float)((b ? (double)b[j] : 0.0) + red[0]);
+  if (seg_m) {
+    // A global-average stage (sn_bn_fold_seg_f32): the per-mesh bias  segb[g][j] = bf[j] + sum_c m[g][c] Wf[j][C/2 + c]  of MY
+    // output row, from the folded row this workgroup has just formed — sn_seg_affine_f32's numbers (same operands, same order)
+    // without its launch.  64 meshes at a time through LDS (coalesced), one thread per mesh walks the row.
+    const int C2 = C >> 1;                        // (C2 <= 128: checked by the launcher)
+    __shared__ float s_w[128], s_mt[64][129];
+    __shared__ float s_bf;
+    if (threadIdx.x == 0) s_bf = (float)((b ? (double)b[j] : 0.0) + red[0]);
+    for (int c = threadIdx.x; c < C2; c += kWG) s_w[c] = W[(int64_t)j * C + C2 + c] * ss[C2 + c];
+    for (int g0 = 0; g0 < nseg; g0 += 64) {
+      __syncthreads();                            // (s_w, s_bf written; the previous tile read)
+      const int ng = nseg - g0 < 64 ? nseg - g0 : 64;
+      for (int i = threadIdx.x; i < ng * C2; i += kWG) s_mt[i / C2][i % C2] = seg_m[(int64_t)g0 * C2 + i];
+      __syncthreads();
+      if ((int)threadIdx.x < ng) {
+        double acc = (double)s_bf;
+#pragma unroll 16
+        for (int c = 0; c < C2; ++c) acc += (double)s_mt[threadIdx.x][c] * (double)s_w[c];
+        segb[(int64_t)(g0 + threadIdx.x) * J + j] = (float)acc;
+      }
+    }
+  }
 }
 
 // The statistics reduction and the fold in ONE launch (training mode): replaces colstats_final_k (once per half of a concat
@@ -1960,6 +1984,115 @@ __global__ __launch_bounds__(kWG) void avg_bwd_segvec_k(const float *__restrict_
   for (int j = 0; j < J; ++j) acc += (double)Sg[(int64_t)g * J + j] * (double)Wf2[(int64_t)j * ldw + c];
   acc += per * (((double)m[t] - (double)mu2[c]) * (double)B2[c] + (double)C2[c]);
   out[t] = (float)(acc * (double)inv_count[g]);
+}
+
+// A global-average stage's  avg_bwd_gc_k -> bn_bwd_coeffs_k -> avg_bwd_segvec_k  in ONE launch (sn_avg_bn_bwd_f32): each of the
+// three is per channel — the broadcast half of G, the BatchNorm sums over j, the per-mesh vector of the mean path —, so the
+// workgroup that owns 32 channels runs all three for them; nothing passes between workgroups (no ticket, no fence).  Same
+// operands, same order of every sum as the three kernels: bit-identical (tests/test_dense_gpu.py).  grid 2 C / 32; the first
+// C / 32 workgroups are bn_bwd_coeffs_k over G1, the others also form their columns of the broadcast half (64 meshes at a time
+// through LDS) before and the per-mesh vector after.
+__global__ __launch_bounds__(kWG) void avg_bn_bwd_k(const float *__restrict__ G1, const double *__restrict__ sdy,
+                                                    const float *__restrict__ Sg, const float *__restrict__ m,
+                                                    const float *__restrict__ mu2v, const float *__restrict__ W,
+                                                    const float *__restrict__ s, const float *__restrict__ invstd,
+                                                    const float *__restrict__ beta, int64_t rows, int J, int C, int nseg,
+                                                    const float *__restrict__ Wf2, int64_t ldw, const float *__restrict__ inv_count,
+                                                    double per, const int64_t *__restrict__ segoff, float *__restrict__ dW,
+                                                    float *__restrict__ db, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                    float *__restrict__ Bc, float *__restrict__ Cc, float *__restrict__ segvec) {
+  __shared__ double sa[8][32], sp[8][32];
+  __shared__ float s_sg[64][129];                // per-mesh column sums of dy, 64 meshes at a time
+  __shared__ float s_m[64][33];                  // per-mesh means of my 32 channels, the same meshes
+  __shared__ float s_wf[128][33];                // my 32 columns of Wf2
+  __shared__ float s_b[32], s_c[32];
+  const int tid = threadIdx.x, cl = tid & 31, gq = tid >> 5;
+  const int Ct = 2 * C;
+  const int c = blockIdx.x * 32 + cl;            // < Ct (C % 32 == 0)
+  const bool first = (int)blockIdx.x * 32 < C;   // (workgroup-uniform)
+  const int c2 = c - C;
+  if (blockIdx.x == 0 && db)
+    for (int j = tid; j < J; j += kWG) db[j] = (float)sdy[j];
+  float gv[16];                                  // G of my channel in rows gq, gq + 8, ... (J <= 128)
+  if (first) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gv[i] = gq + 8 * i < J ? G1[(int64_t)(gq + 8 * i) * C + c] : 0.f;
+  } else {
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    const double mu = (double)mu2v[c2];
+    for (int g0 = 0; g0 < nseg; g0 += 64) {
+      const int ng = nseg - g0 < 64 ? nseg - g0 : 64;
+      __syncthreads();
+      for (int i = tid; i < ng * J; i += kWG) s_sg[i / J][i % J] = Sg[(int64_t)g0 * J + i];
+      for (int i = tid; i < ng * 32; i += kWG) s_m[i >> 5][i & 31] = m[(int64_t)(g0 + (i >> 5)) * C + (int)blockIdx.x * 32 - C + (i & 31)];
+      __syncthreads();
+      for (int k = 0; k < ng; ++k) {             // meshes in ascending order: avg_bwd_gc_k's sum
+        const double d = (double)s_m[k][cl] - mu;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (gq + 8 * i < J) acc[i] += (double)s_sg[k][gq + 8 * i] * d;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) gv[i] = (float)acc[i];
+  }
+  // ---- bn_bwd_coeffs_k for my 32 channels ----
+  double a = 0, p = 0;
+  {
+    const double sc = s[c], bc = beta[c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int j = gq + 8 * i;
+      if (j < J) {
+        const double w = W[(int64_t)j * Ct + c], gg = gv[i];
+        a += sdy[j] * w;
+        p += w * gg;
+        dW[(int64_t)j * Ct + c] = (float)(gg * sc + sdy[j] * bc);
+      }
+    }
+  }
+  sa[gq][cl] = a;
+  sp[gq][cl] = p;
+  __syncthreads();
+  if (gq == 0) {
+    double at = 0, pt = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      at += sa[i][cl];
+      pt += sp[i][cl];
+    }
+    const double sc = s[c], is = invstd[c];
+    const double dg = is * pt;
+    dgamma[c] = (float)dg;
+    dbeta[c] = (float)at;
+    const float bq = (float)(-(sc * is * dg) / (double)rows), cq = (float)(-(sc * at) / (double)rows);
+    Bc[c] = bq;
+    Cc[c] = cq;
+    s_b[cl] = bq;
+    s_c[cl] = cq;
+  }
+  if (first) return;
+  // ---- avg_bwd_segvec_k for my 32 channels: segvec[g][c2] = inv_count[g] (sum_j Sg[g][j] Wf2[j][c2] + per ((m - mu2) B2 + C2)) ----
+  for (int i = tid; i < J * 32; i += kWG) s_wf[i >> 5][i & 31] = Wf2[(int64_t)(i >> 5) * ldw + (int)blockIdx.x * 32 - C + (i & 31)];
+  const double mu = (double)mu2v[c2];
+  for (int g0 = 0; g0 < nseg; g0 += 64) {
+    const int ng = nseg - g0 < 64 ? nseg - g0 : 64;
+    __syncthreads();                             // (s_b, s_c, s_wf written; the tiles of the previous round read)
+    for (int i = tid; i < ng * J; i += kWG) s_sg[i / J][i % J] = Sg[(int64_t)g0 * J + i];
+    for (int i = tid; i < ng * 32; i += kWG) s_m[i >> 5][i & 31] = m[(int64_t)(g0 + (i >> 5)) * C + (int)blockIdx.x * 32 - C + (i & 31)];
+    __syncthreads();
+    for (int k = gq; k < ng; k += 8) {
+      const int g = g0 + k;
+      double acc = 0;
+#pragma unroll 16
+      for (int j = 0; j < J; ++j) acc += (double)s_sg[k][j] * (double)s_wf[j][cl];
+      const double pr = segoff ? (double)(segoff[g + 1] - segoff[g]) : per;
+      acc += pr * (((double)s_m[k][cl] - mu) * (double)s_b[cl] + (double)s_c[cl]);
+      segvec[(int64_t)g * C + c2] = (float)(acc * (double)inv_count[g]);
+    }
+  }
 }
 
 // The same quantities WITHOUT a pass over e, when the GEMM that wrote e left (a) the column sums of every 32-row tile
@@ -3628,6 +3761,36 @@ int sn_bn_fold_f32(const double *stats, int64_t rows, const float *gamma, const 
   hipLaunchKernelGGL(bn_fold_k, dim3(J), dim3(kWG), 0, static_cast<hipStream_t>(stream), stats, rows, gamma, beta, W,
                      b, (int)C, eps, momentum, (int)training, running_mean, running_var, mean, invstd, s, t, Wf, bf,
                      num_batches_tracked);
+  return launch_status();
+}
+
+int sn_bn_fold_seg_f32(const double *stats, int64_t rows, const float *gamma, const float *beta, const float *W, const float *b,
+                       int32_t J, int32_t C, double eps, double momentum, float *running_mean, float *running_var, float *mean,
+                       float *invstd, float *s, float *t, float *Wf, float *bf, int64_t *num_batches_tracked, const float *seg_mean,
+                       int64_t nseg, float *segbias, void *stream) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
+  if (rows < 1 || J < 1 || C < 2 || (C & 1) || nseg < 1 || nseg > INT_MAX) return SN_E_SHAPE;
+  if (C > 256) return SN_E_UNSUPPORTED;          // (the folded half row is held in LDS)
+  if (!stats || !gamma || !beta || !W || !mean || !invstd || !s || !t || !Wf || !bf || !seg_mean || !segbias) return SN_E_NULL;
+  hipLaunchKernelGGL(bn_fold_k, dim3(J), dim3(kWG), 0, static_cast<hipStream_t>(stream), stats, rows, gamma, beta, W, b, (int)C, eps,
+                     momentum, 1, running_mean, running_var, mean, invstd, s, t, Wf, bf, num_batches_tracked, seg_mean, (int)nseg,
+                     segbias, (int)J);
+  return launch_status();
+}
+
+int sn_avg_bn_bwd_f32(const float *G1, const double *dystats, const float *seg_dy, const float *seg_mean, const float *mu2,
+                      const float *W, const float *s, const float *invstd, const float *beta, int64_t rows, int32_t J, int32_t C,
+                      int64_t nseg, const float *Wf2, int64_t ldw, const float *inv_count, int64_t rows_per_seg, const int64_t *segoff,
+                      float *dW, float *db, float *dgamma, float *dbeta, float *Bc, float *Cc, float *segvec, void *stream) {
+  (void)hipGetLastError();
+  if (rows < 1 || J < 1 || C < 1 || nseg < 1 || nseg > INT_MAX || ldw < C || (!segoff && rows_per_seg < 1)) return SN_E_SHAPE;
+  if (J > 128 || (C % 32)) return SN_E_UNSUPPORTED;
+  if (!G1 || !dystats || !seg_dy || !seg_mean || !mu2 || !W || !s || !invstd || !beta || !Wf2 || !inv_count || !dW || !dgamma ||
+      !dbeta || !Bc || !Cc || !segvec)
+    return SN_E_NULL;
+  hipLaunchKernelGGL(avg_bn_bwd_k, dim3((unsigned)(2 * C / 32)), dim3(kWG), 0, static_cast<hipStream_t>(stream), G1, dystats, seg_dy,
+                     seg_mean, mu2, W, s, invstd, beta, rows, (int)J, (int)C, (int)nseg, Wf2, ldw, inv_count, (double)rows_per_seg,
+                     segoff, dW, db, dgamma, dbeta, Bc, Cc, segvec);
   return launch_status();
 }
 

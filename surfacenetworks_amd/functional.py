@@ -704,9 +704,13 @@ def avg_stage_forward(e, mask_rows, inv_count, nseg, per, gamma, beta, W, b, run
     else:
         m, stats = kernels.avg_stats(e, mask_rows, inv_count, per, nseg)       # per-mesh mean + BatchNorm statistics, one pass over e
     stats, rows_g = _sync_stats(stats, rows)
-    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, True, running_mean, running_var,
-                                                 _take_counter(running_mean))
-    segb = kernels.seg_affine(m, Wf[:, C:], bf)
+    if kernels.avg_merged_supported(W.shape[0], C, m.shape[0]):
+        mean, invstd, s, t, Wf, bf, segb = kernels.bn_fold_seg(stats, rows_g, gamma, beta, W, b, eps, momentum, running_mean,
+                                                               running_var, m, _take_counter(running_mean))
+    else:
+        mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, True, running_mean, running_var,
+                                                     _take_counter(running_mean))
+        segb = kernels.seg_affine(m, Wf[:, C:], bf)
     if residual is not None:
         residual = _rows2d(residual)
     y = kernels.linear_fwd_segbias(e, Wf[:, :C], segb, per, residual, elu_out, want_y, elu_stats, tile_sums)
@@ -728,6 +732,11 @@ def avg_stage_backward(state, mask_rows, inv_count, nseg, per, dy, gadd):
         dW, db, dgamma, dbeta, Bc, Cc, Sg = r
     else:
         G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per, bounds=bounds)   # per-mesh column sums of dy from the same pass
+        if _BN_SYNC is None and kernels.avg_merged_supported(dy.shape[1], C, m.shape[0], 2):
+            dW, db, dgamma, dbeta, Bc, Cc, segvec = kernels.avg_bn_bwd(G1, sdy, Sg, m, mean[C:], W, s, invstd, beta, rows_g, has_bias,
+                                                                       Wf[:, C:], inv_count, rows_per_seg=per)
+            g = kernels.linear_dgrad_eluseg(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, per, mask_rows, gadd)
+            return g, dgamma, dbeta, dW, db
         Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
         Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
         dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
@@ -751,9 +760,13 @@ def avg_stage_forward_ragged(e, seg, gamma, beta, W, b, running_mean, running_va
     s2 = torch.stack([(md * seg.len_f64[:, None]).sum(0), (md * md * seg.len_f64[:, None]).sum(0)])
     stats = torch.cat([s1, s2], 1)
     stats, rows_g = _sync_stats(stats, rows)
-    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, True, running_mean, running_var,
-                                                 _take_counter(running_mean))
-    segb = kernels.seg_affine(m, Wf[:, C:], bf)
+    if kernels.avg_merged_supported(W.shape[0], C, m.shape[0]):
+        mean, invstd, s, t, Wf, bf, segb = kernels.bn_fold_seg(stats, rows_g, gamma, beta, W, b, eps, momentum, running_mean,
+                                                               running_var, m.contiguous(), _take_counter(running_mean))
+    else:
+        mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, True, running_mean, running_var,
+                                                     _take_counter(running_mean))
+        segb = kernels.seg_affine(m, Wf[:, C:], bf)
     if residual is not None:
         residual = _rows2d(residual)
     y = kernels.linear_fwd_segbias_ragged(e, Wf[:, :C], segb, seg, residual, elu_out, want_y, elu_stats)
@@ -774,6 +787,11 @@ def avg_stage_backward_ragged(state, seg, dy, gadd):
         dW, db, dgamma, dbeta, Bc, Cc, Sg = r
     else:
         G1, sdy, Sg = kernels.wgrad_slabs(dy, e, mean[:C], seg, bounds=bounds)
+        if _BN_SYNC is None and kernels.avg_merged_supported(dy.shape[1], C, m.shape[0], 2):
+            dW, db, dgamma, dbeta, Bc, Cc, segvec = kernels.avg_bn_bwd(G1, sdy, Sg, m.contiguous(), mean[C:], W, s, invstd, beta, rows_g,
+                                                                       has_bias, Wf[:, C:], seg.inv_count, segoff=seg.off_dev)
+            g = kernels.linear_dgrad_eluseg_ragged(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, seg, gadd)
+            return g, dgamma, dbeta, dW, db
         Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
         Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
         dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)

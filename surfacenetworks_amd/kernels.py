@@ -17,6 +17,7 @@ __all__ = [
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
     "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "pair_ce_fwd", "pair_ce_bwd", "pair_fused_fwd", "pair_fused_bwd", "bn_fold_parts", "colstats_partial", "linear_fwd_stats_blocks", "fold_parts_supported", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
+    "wgrad_bn_supported", "avg_merged_supported",
 ]
 
 
@@ -998,6 +999,60 @@ def seg_affine(A, W, bias):
     out = torch.empty((nseg, J), dtype=torch.float32, device=A.device)
     _lib.call("sn_seg_affine_f32", _p(A), nseg, K, _p(W), _ld(W), _p(bias), J, _p(out), _stream())
     return out
+
+
+def avg_merged_supported(J: int, C: int, nseg: int, which: int = 1) -> bool:
+    """Shapes (and the switch SN_AVG_MERGED: bit 0 — forward, bit 1 — backward) for which a global-average stage folds its per-mesh
+    bias into the fold launch (bn_fold_seg, which = 1) / runs gc + coefficients + per-mesh vector of its backward as one launch
+    (avg_bn_bwd, which = 2)."""
+    import os
+
+    # The merged launches run per-channel (backward) / per-output-row (forward) work that the separate kernels spread over many
+    # more workgroups: they win while the per-mesh algebra is small.  Same box, config-3 step (64 meshes): forward merge 18.94 ->
+    # 18.89 ms, backward merge 18.94 -> 19.63 (its 4 workgroups of the broadcast half walk 64 meshes x 128 rows each); FAUST pair
+    # (one mesh per tower) with both 3.44 -> 3.35 ms.  Hence: forward up to 64 meshes, backward up to 8.
+    lim = 64 if which == 1 else 8
+    return J <= 128 and C % 32 == 0 and 2 * C <= 256 and 0 < nseg <= lim and (int(os.environ.get("SN_AVG_MERGED", "3")) & which) != 0
+
+
+def bn_fold_seg(stats, rows: int, gamma, beta, W, b, eps: float, momentum: float, running_mean, running_var, m, num_batches_tracked=None):
+    """bn_fold (training mode) of a global-average stage's 2C-wide layer and its per-mesh bias m·Wf[:, C:]ᵀ + bf in one launch
+    (sn_bn_fold_seg_f32).  Returns (mean, invstd, s, t, Wf, bf, segbias (nseg, J))."""
+    _dev(stats, gamma, beta, W, b, running_mean, running_var, num_batches_tracked, m)
+    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
+        raise TypeError("num_batches_tracked must be int64")
+    J, C = W.shape
+    nseg = m.shape[0]
+    if m.shape[1] * 2 != C or not m.is_contiguous():
+        raise ValueError("bn_fold_seg: per-mesh means of half the layer's width, contiguous")
+    dev = W.device
+    vec = torch.empty((4, C), dtype=torch.float32, device=dev)
+    Wf = torch.empty((J, C), dtype=torch.float32, device=dev)
+    bf = torch.empty(J, dtype=torch.float32, device=dev)
+    segb = torch.empty((nseg, J), dtype=torch.float32, device=dev)
+    _lib.call("sn_bn_fold_seg_f32", _p(stats), rows, _p(gamma), _p(beta), _p(W.contiguous()), _p(b), J, C, float(eps), float(momentum),
+              _p(running_mean), _p(running_var), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(Wf), _p(bf),
+              _p(num_batches_tracked), _p(m), nseg, _p(segb), _stream())
+    return vec[0], vec[1], vec[2], vec[3], Wf, bf, segb
+
+
+def avg_bn_bwd(G1, dystats, seg_dy, m, mu2, W, s, invstd, beta, rows: int, has_bias: bool, Wf2, inv_count, rows_per_seg: int = 0,
+               segoff=None):
+    """(dW, db, dgamma, dbeta, Bc, Cc, segvec) of a global-average stage's backward from the first half's weight gradient G1, the
+    column sums of dy and their per-mesh parts: avg_bwd_gc + bn_bwd_coeffs + avg_bwd_segvec[_ragged] in one launch
+    (sn_avg_bn_bwd_f32; segoff: the row offsets of ragged meshes)."""
+    _dev(G1, dystats, seg_dy, m, mu2, W, s, invstd, beta, Wf2, inv_count, segoff)
+    J, C = G1.shape
+    nseg = m.shape[0]
+    dev = W.device
+    dW = torch.empty((J, 2 * C), dtype=torch.float32, device=dev)
+    db = torch.empty(J, dtype=torch.float32, device=dev) if has_bias else None
+    vec = torch.empty((4, 2 * C), dtype=torch.float32, device=dev)
+    segvec = torch.empty((nseg, C), dtype=torch.float32, device=dev)
+    _lib.call("sn_avg_bn_bwd_f32", _p(G1), _p(dystats), _p(seg_dy), _p(m), _p(mu2), _p(W.contiguous()), _p(s), _p(invstd),
+              _p(beta.contiguous()), rows, J, C, nseg, _p(Wf2), _ld(Wf2), _p(inv_count.contiguous()), rows_per_seg, _p(segoff),
+              _p(dW), _p(db), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(segvec), _stream())
+    return dW, db, vec[0], vec[1], vec[2], vec[3], segvec
 
 
 def avg_bwd_gc(G1, seg_dy, m, mu2):

@@ -193,6 +193,10 @@ def wgrad_supported(J, C):
     return C in (128, 256) and J <= 128 and J % 4 == 0
 
 
+def avg_merged_supported(J, C, nseg, which=1):
+    return False          # the host twins keep the separate steps of a global-average stage
+
+
 def wgrad_bn_supported(J, C):
     return False          # the host twins keep the separate steps (product, reduction, coefficients)
 

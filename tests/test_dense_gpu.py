@@ -1216,3 +1216,44 @@ def test_two_piece_weight_gradient_ignores_the_rows_past_the_end(rows):
     ref = dy.double().t() @ (x.double() - meanf.double())
     assert float((G.double() - ref).abs().max()) <= 2.0 * float((G0.double() - ref).abs().max()) + 1e-5 * float(ref.abs().max()) + 1e-6
     assert torch.equal(sdy, sdy0)
+
+
+@pytest.mark.parametrize("nseg,per", [(1, 40), (3, 150), (7, 33), (64, 300), (65, 40), (200, 17)])
+def test_global_average_stage_merged_launches(nseg, per):
+    """sn_bn_fold_seg_f32 (fold + per-mesh bias) and sn_avg_bn_bwd_f32 (broadcast half of G + BatchNorm coefficients + per-mesh
+    vector) against the launches they merge, bit for bit — equal meshes and the ragged form."""
+    from surfacenetworks_amd.operators import PackedSegments
+
+    J = C = 128
+    rows = nseg * per
+    rng = np.random.default_rng(nseg * 100 + per)
+    dy, e, W, gamma, beta = _bn_operands(rng, rows, J, C, 2 * C)
+    b = dev(rng.standard_normal(J).astype(np.float32))
+    m = e.view(nseg, per, C).mean(1).contiguous()
+    inv_count = torch.full((nseg,), 1.0 / per, device=DEV)
+    st = torch.cat([kernels.colstats(e), torch.stack([(m.double() * per).sum(0), (m.double() ** 2 * per).sum(0)])], 1).contiguous()
+    rm, rv = torch.zeros(2 * C, device=DEV), torch.ones(2 * C, device=DEV)
+    rm2, rv2 = rm.clone(), rv.clone()
+    nbt, nbt2 = torch.zeros(1, dtype=torch.int64, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+    want = kernels.bn_fold(st, rows, gamma, beta, W, b, 1e-5, 0.1, True, rm, rv, nbt)
+    want_segb = kernels.seg_affine(m, want[4][:, C:], want[5])
+    got = kernels.bn_fold_seg(st, rows, gamma, beta, W, b, 1e-5, 0.1, rm2, rv2, m, nbt2)
+    for a, w_, name in zip(got[:6], want, ("mean", "invstd", "s", "t", "Wf", "bf")):
+        assert torch.equal(a, w_), name
+    assert torch.equal(got[6], want_segb) and torch.equal(rm, rm2) and torch.equal(rv, rv2) and int(nbt) == int(nbt2) == 1
+    mean, invstd, s, t, Wf, bf = want
+    # backward
+    G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per)
+    w6 = kernels.bn_bwd_coeffs(kernels.avg_bwd_gc(G1, Sg, m, mean[C:]), sdy, W, s, invstd, beta, rows, True)
+    wv = kernels.avg_bwd_segvec(Sg, Wf[:, C:], m, mean[C:], w6[4][C:], w6[5][C:], inv_count, per)
+    g7 = kernels.avg_bn_bwd(G1, sdy, Sg, m, mean[C:], W, s, invstd, beta, rows, True, Wf[:, C:], inv_count, rows_per_seg=per)
+    for a, w_, name in zip(g7, (*w6, wv), ("dW", "db", "dgamma", "dbeta", "Bc", "Cc", "segvec")):
+        assert torch.equal(a, w_), (name, float((a - w_).abs().max()))
+    assert kernels.avg_bn_bwd(G1, sdy, Sg, m, mean[C:], W, s, invstd, beta, rows, False, Wf[:, C:], inv_count, rows_per_seg=per)[1] is None
+    # ragged form: the row counts come from the offsets
+    lengths = [per + (3 * i) % 7 for i in range(nseg)]
+    seg = PackedSegments(lengths, DEV)
+    wvr = kernels.avg_bwd_segvec_ragged(Sg, Wf[:, C:], m, mean[C:], w6[4][C:], w6[5][C:], seg)
+    g7r = kernels.avg_bn_bwd(G1, sdy, Sg, m, mean[C:], W, s, invstd, beta, rows, True, Wf[:, C:], seg.inv_count, segoff=seg.off_dev)
+    for a, w_, name in zip(g7r, (*w6, wvr), ("dW", "db", "dgamma", "dbeta", "Bc", "Cc", "segvec ragged")):
+        assert torch.equal(a, w_), (name, float((a - w_).abs().max()))
