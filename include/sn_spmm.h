@@ -616,6 +616,12 @@ int sn_avg_bn_bwd_f32(const float *G1, const double *dystats, const float *seg_d
  * sn_segment_colsum_ragged_f32 : out[g, c] = scale[g] * sum over the rows r of mesh g of x[r, c]  (fp64, two deterministic
  *                                stages; scale may be NULL).  With scale = 1 / vertex count: global_average on a packed batch.
  * sn_bcast_rows_ragged_f32     : dst[r, :] = src[mesh(r), :]. */
+/* sn_avg_prep_ragged_f32        : BatchNorm statistics (2 x 2C fp64, the layout sn_bn_fold_f32 reads) of [e | per-mesh mean
+ *                                broadcast] on a packed batch: first half from the statistics partials ([nblk][2][C] fp64) of the
+ *                                kernel that wrote e, second half  sum_g len_g m_g,  sum_g len_g m_g^2  from the means and the
+ *                                row offsets segoff[nseg + 1]. */
+int sn_avg_prep_ragged_f32(const float *seg_mean, const int64_t *segoff, int64_t nseg, int32_t C, const double *stats_part,
+                           int32_t nblk, double *stats, void *stream);
 size_t sn_segment_colsum_ragged_workspace_bytes(int64_t ntiles, int32_t C);
 int sn_segment_colsum_ragged_f32(const float *x, int64_t ld, const int64_t *tiles, int64_t ntiles, const int64_t *seg_tile_ptr,
                                  int64_t nseg, int32_t C, const float *scale, float *out, void *workspace,
@@ -788,6 +794,16 @@ int sn_linear_fwd_segbias_tiles_f32(const float *x, int64_t ldx, const float *W,
 int sn_avg_stats_from_tiles_f32(const float *tile_sums, const double *stats_part, int32_t nblk, const float *e, int64_t ld,
                                 const float *mask, const float *inv_count, int64_t rows_per_seg, int64_t nseg, int32_t C,
                                 float *m, double *stats, float *workspace, void *stream);
+/* ... and for RAGGED meshes (mesh g = rows [segoff[g], segoff[g+1]), inv_count[g] = 1 / its row count, no mask): the per-mesh means
+ * and the statistics of [e | mean broadcast] without a pass over e; sn_linear_fwd_segbias_ragged_tiles_f32 is the ragged
+ * per-mesh-bias launch that leaves the tile sums. */
+int sn_avg_stats_from_tiles_ragged_f32(const float *tile_sums, const double *stats_part, int32_t nblk, const float *e, int64_t ld,
+                                       const int64_t *segoff, const float *inv_count, int64_t nseg, int32_t C, float *m,
+                                       double *stats, float *workspace, void *stream);
+int sn_linear_fwd_segbias_ragged_tiles_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
+                                           const int64_t *segoff, int32_t nseg, const float *residual, int64_t ldr, float *y,
+                                           int64_t ldy, float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J,
+                                           double *elu_stats_part, float *tile_sums, void *stream);
 /* The two per-mesh-vector kernels for RAGGED meshes (packed batches): mesh g owns rows [segoff[g], segoff[g+1]) (device
  * int64[nseg + 1], segoff[0] = 0, segoff[nseg] = rows, every mesh at least 32 rows — the caller's responsibility: a device
  * array is not validated here); no row mask (a packed batch has no padding rows). */

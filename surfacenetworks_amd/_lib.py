@@ -71,6 +71,7 @@ SIGNATURES = {
                                            _i64, _vp]),
     "sn_wgrad_slabs_bounded_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz,
                                              _vp, _i64, _vp, _i64, _vp]),
+    "sn_avg_prep_ragged_f32": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _vp]),
     "sn_bn_fold_seg_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _vp, _vp, _i64, _vp, _vp]),
     "sn_avg_bn_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
@@ -128,6 +129,9 @@ SIGNATURES = {
     "sn_linear_fwd_tiles_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _vp, _vp]),
     "sn_linear_fwd_segbias_tiles_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32, _i32,
                                                   _vp, _vp, _vp]),
+    "sn_avg_stats_from_tiles_ragged_f32": (C.c_int, [_vp, _vp, _i32, _vp, _i64, _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "sn_linear_fwd_segbias_ragged_tiles_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _i64, _i64, _i32,
+                                                         _i32, _vp, _vp, _vp]),
     "sn_avg_stats_from_tiles_f32": (C.c_int, [_vp, _vp, _i32, _vp, _i64, _vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sn_colstats_into_f32": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _i64, _i64, _vp, _sz, _vp]),
     "sn_colstats_merge_f64": (C.c_int, [_vp, _i32, _i32, _vp, _i64, _i64, _vp]),

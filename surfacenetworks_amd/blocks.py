@@ -357,11 +357,13 @@ class _AvgBlockRagged(torch.autograd.Function):
         e_a = cat[:, :C]
         e_b = torch.empty((rows, C), dtype=torch.float32, device=x.device)
         pb = _new_part(rows, C, x.device)
+        tb = _new_tiles(rows, C, x.device, pb, True)      # (as _AvgBlock: means and statistics from what the producing GEMM left)
         _, st0 = avg_stage_forward_ragged(e_a, seg, g0, b0, W0, c0, rm0, rv0, mo0, ep0, None, e_b, want_y=False, elu_stats=pb,
-                                          part=getattr(cat, "_sn_part", None))
+                                          part=getattr(cat, "_sn_part", None), tile_sums=tb, e_tiles=_tiles_of(cat))
         nxt = _new_cat(rows, C, x.device)
         pn = _new_part(rows, C, x.device)
-        out, st1 = avg_stage_forward_ragged(e_b, seg, g1, b1, W1, c1, rm1, rv1, mo1, ep1, x, nxt[:, :C], elu_stats=pn, part=pb)
+        out, st1 = avg_stage_forward_ragged(e_b, seg, g1, b1, W1, c1, rm1, rv1, mo1, ep1, x, nxt[:, :C], elu_stats=pn, part=pb,
+                                            e_tiles=(tb, pb) if tb is not None else None)
         _attach_part(nxt, pn)
         stash(ctx, st0, st1)
         ctx.seg = seg

@@ -2101,14 +2101,15 @@ __global__ __launch_bounds__(kWG) void avg_bn_bwd_k(const float *__restrict__ G1
 // rows of the (at most two) tiles it shares with its neighbours are read from e; with a row mask every tile's 32 mask values
 // are read first and a tile that holds a masked-out row is summed from e as well (prefix masks: one tile per mesh).
 // grid (C / 32, nseg), 256 threads = 8 four-column chunks x 32 tile lanes; ssum[nseg][C] fp32 (fp64 across tiles).
+// segoff != NULL: ragged meshes — mesh g owns rows [segoff[g], segoff[g+1]) (no mask).
 __global__ __launch_bounds__(kWG) void segsum_tiles_k(const float *__restrict__ tile_sums, const float *__restrict__ e, int64_t lde,
                                                       const float *__restrict__ mask, int64_t per, int C,
-                                                      float *__restrict__ ssum) {
+                                                      float *__restrict__ ssum, const int64_t *__restrict__ segoff = nullptr) {
   __shared__ double sm[32][8][4];
   const int chunk = threadIdx.x & 7, tl = threadIdx.x >> 3;
   const int c = blockIdx.x * 32 + 4 * chunk;
   const int64_t g = blockIdx.y;
-  const int64_t a = g * per, b = a + per;                      // rows of the mesh
+  const int64_t a = segoff ? segoff[g] : g * per, b = segoff ? segoff[g + 1] : a + per;      // rows of the mesh
   const int64_t t0 = (a + 31) / 32, t1 = b / 32;                 // whole tiles: [t0, t1)
   double s[4] = {0, 0, 0, 0};
   auto rows_from_e = [&](int64_t r0, int64_t r1) {               // masked sums of rows [r0, r1) of e, my 4 columns
@@ -2163,9 +2164,12 @@ __global__ __launch_bounds__(kWG) void segsum_tiles_k(const float *__restrict__ 
 // m and the BatchNorm statistics of [e | m broadcast] from the per-mesh sums and the producer's statistics partials
 // (part[nblk][2][C] fp64): avg_fwd_prep_k with the merge of the partials in front.  8 columns x 32 lanes per workgroup: the
 // lanes share the partial blocks and the meshes (a few dozen independent loads each), fixed-order sums through LDS.
+// segoff != NULL (ragged meshes, sn_avg_prep_ragged_f32): `ssum` holds the per-mesh MEANS already (nothing is written to m) and
+// mesh g counts segoff[g+1] - segoff[g] rows in the statistics of the broadcast half.
 __global__ __launch_bounds__(kWG) void avg_prep_parts_k(const float *__restrict__ ssum, const float *__restrict__ inv_count, int nseg,
                                                         int C, double per, const double *__restrict__ part, int nblk,
-                                                        float *__restrict__ m, double *__restrict__ stats) {
+                                                        float *__restrict__ m, double *__restrict__ stats,
+                                                        const int64_t *__restrict__ segoff = nullptr) {
   __shared__ double sm[4][32][8];
   const int cl = threadIdx.x & 7, ln = threadIdx.x >> 3;
   const int c = blockIdx.x * 8 + cl;
@@ -2175,6 +2179,18 @@ __global__ __launch_bounds__(kWG) void avg_prep_parts_k(const float *__restrict_
     u += part[(int64_t)b * 2 * C + c];
     q += part[(int64_t)b * 2 * C + C + c];
   }
+  if (segoff) {
+    per = 1.0;
+#pragma unroll 2
+    for (int g = ln; g < nseg; g += 32) {
+      float mf = ssum[(int64_t)g * C + c];
+      if (inv_count) mf *= inv_count[g];          // (sums in, means out: sn_avg_stats_from_tiles_ragged_f32)
+      if (m) m[(int64_t)g * C + c] = mf;
+      const double mv = (double)mf, len = (double)(segoff[g + 1] - segoff[g]);
+      s1 += len * mv;
+      s2 += len * mv * mv;
+    }
+  } else
 #pragma unroll 2
   for (int g = ln; g < nseg; g += 32) {
     const float mv = ssum[(int64_t)g * C + c] * inv_count[g];
@@ -3914,6 +3930,40 @@ int sn_avg_stats_from_tiles_f32(const float *tile_sums, const double *stats_part
                      (int)C, workspace);
   hipLaunchKernelGGL(avg_prep_parts_k, dim3((unsigned)(C / 8)), dim3(kWG), 0, s, workspace, inv_count, (int)nseg, (int)C,
                      (double)rows_per_seg, stats_part, (int)nblk, m, stats);
+  return launch_status();
+}
+
+// BatchNorm statistics (2 x 2C fp64, sn_bn_fold_f32's layout) of [e | per-mesh mean broadcast] for RAGGED meshes from the means
+// (sn_segment_colsum_ragged_f32 with scale = 1 / rows), the meshes' row offsets and the statistics partials of the kernel that
+// wrote e ([nblk][2][C] fp64; one block holding ready statistics works too) — one launch for what was a merge launch and six
+// elementwise / reduction launches of the framework.
+int sn_avg_prep_ragged_f32(const float *seg_mean, const int64_t *segoff, int64_t nseg, int32_t C, const double *stats_part,
+                           int32_t nblk, double *stats, void *stream) {
+  (void)hipGetLastError();
+  if (nseg < 1 || nseg > INT_MAX || C < 8 || (C % 8) || nblk < 0) return SN_E_SHAPE;
+  if (!seg_mean || !segoff || !stats || (nblk > 0 && !stats_part)) return SN_E_NULL;
+  hipLaunchKernelGGL(avg_prep_parts_k, dim3((unsigned)(C / 8)), dim3(kWG), 0, static_cast<hipStream_t>(stream), seg_mean,
+                     (const float *)nullptr, (int)nseg, (int)C, 1.0, stats_part, (int)nblk, (float *)nullptr, stats, segoff);
+  return launch_status();
+}
+
+// sn_avg_stats_from_tiles_f32 for RAGGED meshes: per-mesh means (inv_count[g] = 1 / rows of mesh g) and the statistics of
+// [e | mean broadcast] from the per-tile column sums and statistics partials of the GEMM that wrote e — no pass over e (the rows
+// of the two tiles a mesh shares with its neighbours are read from e).
+int sn_avg_stats_from_tiles_ragged_f32(const float *tile_sums, const double *stats_part, int32_t nblk, const float *e, int64_t ld,
+                                       const int64_t *segoff, const float *inv_count, int64_t nseg, int32_t C, float *m,
+                                       double *stats, float *workspace, void *stream) {
+  (void)hipGetLastError();
+  if (nseg < 1 || C != 128 || ld < C || nblk < 0) return SN_E_SHAPE;
+  if (ld % 4) return SN_E_UNSUPPORTED;
+  if (!tile_sums || !stats_part || !e || !segoff || !inv_count || !m || !stats || !workspace) return SN_E_NULL;
+  if (!aligned16(e) || !aligned16(tile_sums)) return SN_E_ALIGN;
+  if (nseg > 65535) return SN_E_RANGE;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(segsum_tiles_k, dim3((unsigned)(C / 32), (unsigned)nseg), dim3(kWG), 0, s, tile_sums, e, ld, (const float *)nullptr,
+                     (int64_t)0, (int)C, workspace, segoff);
+  hipLaunchKernelGGL(avg_prep_parts_k, dim3((unsigned)(C / 8)), dim3(kWG), 0, s, workspace, inv_count, (int)nseg, (int)C, 1.0,
+                     stats_part, (int)nblk, m, stats, segoff);
   return launch_status();
 }
 

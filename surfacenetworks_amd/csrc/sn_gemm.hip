@@ -1446,6 +1446,15 @@ int sn_linear_fwd_segbias_ragged_f32(const float *x, int64_t ldx, const float *W
                             elu_stats_part, stream);
 }
 
+int sn_linear_fwd_segbias_ragged_tiles_f32(const float *x, int64_t ldx, const float *W, int64_t ldw, const float *segbias,
+                                           const int64_t *segoff, int32_t nseg, const float *residual, int64_t ldr, float *y,
+                                           int64_t ldy, float *y_elu, int64_t lde, int64_t rows, int32_t K, int32_t J,
+                                           double *elu_stats_part, float *tile_sums, void *stream) {
+  if (!segoff) return SN_E_NULL;
+  return fwd_segbias_launch(x, ldx, W, ldw, segbias, 0, segoff, nseg, residual, ldr, y, ldy, y_elu, lde, rows, K, J,
+                            elu_stats_part, stream, tile_sums);
+}
+
 static int dgrad_eluseg_launch(const float *dy, int64_t lddy, const float *W, int64_t ldw, const float *x, int64_t ldx,
                                const float *center, const float *B, const float *Cc, const float *segvec,
                                int64_t rows_per_seg, const int64_t *segoff, int32_t nseg, const float *rowmask, float *gact,

@@ -747,18 +747,26 @@ def avg_stage_backward(state, mask_rows, inv_count, nseg, per, dy, gadd):
 
 
 def avg_stage_forward_ragged(e, seg, gamma, beta, W, b, running_mean, running_var, momentum, eps, residual=None, elu_out=None,
-                             want_y=True, elu_stats=None, part=None):
+                             want_y=True, elu_stats=None, part=None, tile_sums=None, e_tiles=None):
     """avg_stage_forward on a PACKED batch (`seg`: operators.PackedSegments — ragged meshes, no padding rows, every row
     real): per-mesh means by sn_segment_colsum_ragged_f32; BatchNorm statistics of the first half from the partials `part`
     the GEMM that wrote e left (else one more pass over e), of the broadcast half from the means (mesh i contributes
     len_i·m_i and len_i·m_i²); the per-mesh bias enters the GEMM by mesh offsets (sn_linear_fwd_segbias_ragged_f32)."""
     e = _rows2d(e)
     rows, C = e.shape
-    m = seg.mean(e)
-    s1 = kernels.colstats_from_part(part, rows) if part is not None else kernels.colstats(e)
-    md = m.to(torch.float64)
-    s2 = torch.stack([(md * seg.len_f64[:, None]).sum(0), (md * md * seg.len_f64[:, None]).sum(0)])
-    stats = torch.cat([s1, s2], 1)
+    if e_tiles is not None:
+        # the GEMM that wrote e left its per-tile column sums and its statistics partials: no pass over e at all
+        m, stats = kernels.avg_stats_from_tiles_ragged(e_tiles[0], e_tiles[1], e, seg)
+    else:
+        m = seg.mean(e).contiguous()
+    # statistics of [e | mean broadcast] in one launch: the partials of the kernel that wrote e (or one more pass over e) and
+    # len_i m_i, len_i m_i^2 per mesh
+    if e_tiles is not None:
+        pass
+    elif part is not None and C == 128:
+        stats = kernels.avg_stats_ragged(m, seg, part, kernels.linear_fwd_stats_blocks(rows))
+    else:
+        stats = kernels.avg_stats_ragged(m, seg, kernels.colstats(e).reshape(1, 2, C), 1)
     stats, rows_g = _sync_stats(stats, rows)
     if kernels.avg_merged_supported(W.shape[0], C, m.shape[0]):
         mean, invstd, s, t, Wf, bf, segb = kernels.bn_fold_seg(stats, rows_g, gamma, beta, W, b, eps, momentum, running_mean,
@@ -769,7 +777,7 @@ def avg_stage_forward_ragged(e, seg, gamma, beta, W, b, running_mean, running_va
         segb = kernels.seg_affine(m, Wf[:, C:], bf)
     if residual is not None:
         residual = _rows2d(residual)
-    y = kernels.linear_fwd_segbias_ragged(e, Wf[:, :C], segb, seg, residual, elu_out, want_y, elu_stats)
+    y = kernels.linear_fwd_segbias_ragged(e, Wf[:, :C], segb, seg, residual, elu_out, want_y, elu_stats, tile_sums)
     return y, (e, m, W, Wf, s, mean, invstd, beta, b is not None, rows_g)
 
 

@@ -17,7 +17,7 @@ __all__ = [
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
     "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "pair_ce_fwd", "pair_ce_bwd", "pair_fused_fwd", "pair_fused_bwd", "bn_fold_parts", "colstats_partial", "linear_fwd_stats_blocks", "fold_parts_supported", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
-    "wgrad_bn_supported", "avg_merged_supported",
+    "wgrad_bn_supported", "avg_merged_supported", "avg_stats_ragged", "avg_stats_from_tiles_ragged",
 ]
 
 
@@ -844,6 +844,24 @@ def avg_stats_from_tiles(tile_sums, part, e, mask, inv_count, rows_per_seg: int,
     return m, stats
 
 
+def avg_stats_from_tiles_ragged(tile_sums, part, e, seg):
+    """(m, stats) of a global-average stage on a packed batch WITHOUT a pass over e (sn_avg_stats_from_tiles_ragged_f32): from the
+    per-tile column sums and the statistics partials the GEMM that wrote e left; seg = operators.PackedSegments."""
+    _dev(tile_sums, part, e)
+    rows, C = e.shape
+    if tile_sums.shape != ((rows + 31) // 32, 128) or part.dim() != 3 or part.shape[1:] != (2, 128) or part.dtype != torch.float64:
+        raise ValueError("avg_stats_from_tiles_ragged: tile sums / statistics partials of another operand")
+    nblk = int(_lib.load().sn_linear_fwd_stats_blocks(rows))
+    if part.shape[0] < nblk or seg.rows != rows:
+        raise ValueError("avg_stats_from_tiles_ragged: partial buffer smaller than the producing launch's grid / another batch")
+    m = torch.empty((seg.nseg, C), dtype=torch.float32, device=e.device)
+    stats = torch.empty((2, 2 * C), dtype=torch.float64, device=e.device)
+    ws = torch.empty((seg.nseg, C), dtype=torch.float32, device=e.device)
+    _lib.call("sn_avg_stats_from_tiles_ragged_f32", _p(tile_sums), _p(part), nblk, _p(e), _ld(e), _p(seg.off_dev), _p(seg.inv_count),
+              seg.nseg, C, _p(m), _p(stats), _p(ws), _stream())
+    return m, stats
+
+
 def colstats_from_part(part, rows: int):
     """(2, 128) float64 statistics of a forward GEMM's ELU output from the partials it left (sn_colstats_merge_f64)."""
     _dev(part)
@@ -1001,6 +1019,19 @@ def seg_affine(A, W, bias):
     return out
 
 
+def avg_stats_ragged(m, seg, part, nblk: int):
+    """(2, 2C) float64 BatchNorm statistics of [e | per-mesh mean broadcast] on a packed batch (sn_avg_prep_ragged_f32): m (nseg, C)
+    the per-mesh means, seg = operators.PackedSegments, part the (>= nblk, 2, C) float64 statistics partials of e (ready (2, C)
+    statistics: pass them as one block)."""
+    _dev(m, part)
+    nseg, C = m.shape
+    if part.dtype != torch.float64 or part.shape[-1] != C or not part.is_contiguous() or not m.is_contiguous():
+        raise ValueError("avg_stats_ragged: float64 partials (nblk, 2, C) and contiguous means (nseg, C)")
+    stats = torch.empty((2, 2 * C), dtype=torch.float64, device=m.device)
+    _lib.call("sn_avg_prep_ragged_f32", _p(m), _p(seg.off_dev), nseg, C, _p(part), nblk, _p(stats), _stream())
+    return stats
+
+
 def avg_merged_supported(J: int, C: int, nseg: int, which: int = 1) -> bool:
     """Shapes (and the switch SN_AVG_MERGED: bit 0 — forward, bit 1 — backward) for which a global-average stage folds its per-mesh
     bias into the fold launch (bn_fold_seg, which = 1) / runs gc + coefficients + per-mesh vector of its backward as one launch
@@ -1126,15 +1157,15 @@ def avg_bwd_segvec_ragged(seg_dy, Wf2, m, mu2, B2, C2, seg):
     return out
 
 
-def linear_fwd_segbias_ragged(x, W, segbias, seg, residual=None, y_elu=None, want_y: bool = True, elu_stats=None):
-    """linear_fwd_segbias with the bias row of each RAGGED mesh (`seg`: operators.PackedSegments)."""
-    _dev(x, W, segbias, residual, y_elu)
+def linear_fwd_segbias_ragged(x, W, segbias, seg, residual=None, y_elu=None, want_y: bool = True, elu_stats=None, tile_sums=None):
+    """linear_fwd_segbias with the bias row of each RAGGED mesh (`seg`: operators.PackedSegments); tile_sums: as linear_fwd."""
+    _dev(x, W, segbias, residual, y_elu, tile_sums)
     rows, K = x.shape
     J = W.shape[0]
     y = torch.empty((rows, J), dtype=torch.float32, device=x.device) if want_y else None
-    _lib.call("sn_linear_fwd_segbias_ragged_f32", _p(x), _ld(x), _p(W), _ld(W), _p(segbias), _p(seg.off_dev), seg.nseg,
+    _lib.call("sn_linear_fwd_segbias_ragged_tiles_f32", _p(x), _ld(x), _p(W), _ld(W), _p(segbias), _p(seg.off_dev), seg.nseg,
               _p(residual), _ld(residual) if residual is not None else 0, _p(y), J, _p(y_elu),
-              _ld(y_elu) if y_elu is not None else 0, rows, K, J, _p(elu_stats), _stream())
+              _ld(y_elu) if y_elu is not None else 0, rows, K, J, _p(elu_stats), _p(tile_sums), _stream())
     return y
 
 

@@ -217,6 +217,10 @@ def avg_stats_from_tiles(*a, **k):
     raise RuntimeError("host twins: no tile sums")
 
 
+def avg_stats_from_tiles_ragged(*a, **k):
+    raise RuntimeError("host twins: no tile sums")
+
+
 def note_absmax(t, maxima):
     pass
 
@@ -347,6 +351,13 @@ def new_elu_stats_part(rows, device):
 
 def colstats_from_part(part, rows):
     return part.sum(0)
+
+
+def avg_stats_ragged(m, seg, part, nblk):
+    s1 = part[:nblk].sum(0)
+    md = m.to(torch.float64)
+    ln = torch.from_numpy(np.asarray(seg.lengths, dtype=np.float64))[:, None]
+    return torch.cat([s1, torch.stack([(md * ln).sum(0), (md * md * ln).sum(0)])], 1)
 
 
 def colstats_merge_into(part, out, offset):
@@ -680,7 +691,7 @@ def avg_bwd_segvec_ragged(seg_dy, Wf2, m, mu2, B2, C2, seg):
     return (v * seg.inv_count.double().reshape(-1, 1)).float()
 
 
-def linear_fwd_segbias_ragged(x, W, segbias, seg, residual=None, y_elu=None, want_y=True, elu_stats=None):
+def linear_fwd_segbias_ragged(x, W, segbias, seg, residual=None, y_elu=None, want_y=True, elu_stats=None, tile_sums=None):
     y = (x.double() @ W.double().t()).float() + segbias[_seg_of_rows(seg)]
     if residual is not None:
         y = y + residual

@@ -1257,3 +1257,57 @@ def test_global_average_stage_merged_launches(nseg, per):
     g7r = kernels.avg_bn_bwd(G1, sdy, Sg, m, mean[C:], W, s, invstd, beta, rows, True, Wf[:, C:], seg.inv_count, segoff=seg.off_dev)
     for a, w_, name in zip(g7r, (*w6, wvr), ("dW", "db", "dgamma", "dbeta", "Bc", "Cc", "segvec ragged")):
         assert torch.equal(a, w_), (name, float((a - w_).abs().max()))
+
+
+@pytest.mark.parametrize("lengths", [[32, 700, 45, 33, 2000], [5041] * 3, [40] * 70])
+def test_ragged_global_average_statistics_in_one_launch(lengths):
+    """sn_avg_prep_ragged_f32 against the composition it replaces (merge of the partials, then len_i m_i / len_i m_i^2 sums
+    in float64 by the framework)."""
+    from surfacenetworks_amd.operators import PackedSegments
+
+    seg = PackedSegments(lengths, DEV)
+    rows, C = seg.rows, 128
+    rng = np.random.default_rng(len(lengths))
+    x = dev(rng.standard_normal((rows, C)).astype(np.float32))
+    W = dev((rng.standard_normal((C, C)) / 11).astype(np.float32))
+    cat = torch.zeros(rows, 2 * C, device=DEV)
+    part = kernels.new_elu_stats_part(rows, DEV)
+    kernels.linear_fwd(x, W, dev(np.zeros(C, np.float32)), None, cat[:, :C], False, part)
+    e = cat[:, :C]
+    m = seg.mean(e).contiguous()
+    md = m.double()
+    s1 = kernels.colstats_from_part(part, rows)
+    want = torch.cat([s1, torch.stack([(md * seg.len_f64[:, None]).sum(0), (md * md * seg.len_f64[:, None]).sum(0)])], 1)
+    got = kernels.avg_stats_ragged(m, seg, part, kernels.linear_fwd_stats_blocks(rows))
+    assert torch.allclose(got, want, rtol=1e-13, atol=1e-9)
+    got1 = kernels.avg_stats_ragged(m, seg, kernels.colstats(e).reshape(1, 2, C), 1)
+    assert torch.allclose(got1[:, C:], want[:, C:], rtol=1e-13, atol=1e-9) and torch.allclose(got1[:, :C], want[:, :C], rtol=1e-11, atol=1e-7)
+
+
+@pytest.mark.parametrize("lengths", [[32, 700, 45, 33, 2000], [5041] * 3, [40] * 70, [33, 31 + 32, 64, 95]])
+def test_ragged_global_average_statistics_from_tile_sums(lengths):
+    """sn_avg_stats_from_tiles_ragged_f32 (per-mesh means and BatchNorm statistics from the producing GEMM's tile sums and
+    partials, mesh boundaries anywhere inside a tile) against the pass over the operand."""
+    from surfacenetworks_amd.operators import PackedSegments
+
+    seg = PackedSegments(lengths, DEV)
+    rows, C = seg.rows, 128
+    rng = np.random.default_rng(len(lengths) + rows)
+    x = dev(rng.standard_normal((rows, C)).astype(np.float32))
+    W = dev((rng.standard_normal((C, C)) / 11).astype(np.float32))
+    segb = dev(rng.standard_normal((seg.nseg, C)).astype(np.float32))
+    for ragged_producer in (False, True):
+        cat = torch.zeros(rows, 2 * C, device=DEV)
+        part = kernels.new_elu_stats_part(rows, DEV)
+        tiles = kernels.new_tile_sums(rows, DEV)
+        if ragged_producer:
+            kernels.linear_fwd_segbias_ragged(x, W, segb, seg, None, cat[:, :C], False, part, tiles)
+        else:
+            kernels.linear_fwd(x, W, dev(np.zeros(C, np.float32)), None, cat[:, :C], False, part, tiles)
+        e = cat[:, :C]
+        m_ref = seg.mean(e)
+        want = kernels.avg_stats_ragged(m_ref.contiguous(), seg, part, kernels.linear_fwd_stats_blocks(rows))
+        m, stats = kernels.avg_stats_from_tiles_ragged(tiles, part, e, seg)
+        assert float((m - m_ref).abs().max()) <= 2e-6 * float(m_ref.abs().max()) + 1e-7
+        assert torch.allclose(stats[:, :C], want[:, :C], rtol=1e-13, atol=1e-9)
+        assert torch.allclose(stats[:, C:], want[:, C:], rtol=1e-5, atol=1e-5)
