@@ -484,6 +484,11 @@ int sn_masked_smooth_l1_bwd_f32(const float *out, int64_t ldo, const float *targ
  * i < nitems, r < rows_per_item, c < len; base is a DEVICE array of element offsets into the resident dataset. */
 int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems, int64_t rows_per_item, int64_t row_stride,
                            int32_t len, float *out, void *stream);
+/* ... straight into a PACKED batch (no padded intermediate, no boolean-mask gather): item i supplies its first
+ * item_off[i+1] - item_off[i] rows, written to output rows item_off[i] ..; item_off: int64[nitems + 1] on the device,
+ * total_rows = item_off[nitems] (known to the caller, who built the table). */
+int sn_gather_segments_ragged_f32(const float *src, const int64_t *base, const int64_t *item_off, int64_t nitems,
+                                  int64_t total_rows, int64_t row_stride, int32_t len, float *out, void *stream);
 /* sn_pair_argmin_f32: target of the dense-correspondence loss (src/dense_correspondence/main.py:236-237,
  * `_, GAB = torch.min(GA[:, liA[lB]] + GB[liB[lA], :], dim=1)`):  out[r] = argmin_j ( GA[r*ldA + pa[j]] + GB[pb[r]*ldB + j] ),
  * r < NA, j < NB, with pa = liA[lB] (NB entries) and pb = liB[lA] (NA entries) as DEVICE int64 arrays; the two gathered

@@ -101,6 +101,7 @@ SIGNATURES = {
     "sn_pair_fused_fwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i64, _i64, _i64, C.c_int32, _vp, _vp, _vp, C.c_size_t, _vp]),
     "sn_pair_fused_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, C.c_int32, _vp, _i64, _vp, _i64, _vp, C.c_size_t, _vp]),
     "sn_gather_segments_f32": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
+    "sn_gather_segments_ragged_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _vp, _vp]),
     "sn_linear_thin_fwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "sn_bn_fold_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, C.c_double, _i32, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

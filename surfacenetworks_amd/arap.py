@@ -295,22 +295,23 @@ class ClothSequences:
         vm = self._vertex_major()                                  # (n, vmax, frames*3)
         vmax, f3 = vm.shape[1], vm.shape[2]
         base = (sid * vmax) * f3 + 3 * off                         # element offset of (sample, vertex 0, start frame)
-        inputs = kernels.gather_segments(vm, base, nv, f3, 3 * INPUT_FRAMES)
-        targets = kernels.gather_segments(vm, base + 3 * INPUT_FRAMES, nv, f3, 3 * OUTPUT_FRAMES)
-        mask = (torch.arange(nv, device=self.device)[None, :] < self.vcount[sid][:, None]).float().unsqueeze(2)
         op_ids = seq_ids * self.op_frames + (offsets + INPUT_FRAMES - 1)
         L = Di = DiA = None
         if packed:
             if self.operators == "device":
                 raise ValueError("packed batches need pooled operators")
-            keep = mask.reshape(B, nv) > 0                                             # real rows, mesh-major order
-            inputs, targets = inputs[keep].unsqueeze(0), targets[keep].unsqueeze(0)
+            # the real rows of every sample, mesh-major, gathered straight into the packed layout (no padded intermediate)
             seg = PackedSegments.cached(self.num_vertices[seq_ids], self.device)
+            inputs = kernels.gather_segments_ragged(vm, base, seg, f3, 3 * INPUT_FRAMES).unsqueeze(0)
+            targets = kernels.gather_segments_ragged(vm, base + 3 * INPUT_FRAMES, seg, f3, 3 * OUTPUT_FRAMES).unsqueeze(0)
             if self.kind == "dir":
                 Di, DiA = self.pool_Di.assemble(op_ids), self.pool_DiA.assemble(op_ids)
             else:
                 L = self.pool_L.assemble(op_ids)
             return Batch(inputs, targets, seg, L, Di, DiA, B)
+        inputs = kernels.gather_segments(vm, base, nv, f3, 3 * INPUT_FRAMES)
+        targets = kernels.gather_segments(vm, base + 3 * INPUT_FRAMES, nv, f3, 3 * OUTPUT_FRAMES)
+        mask = (torch.arange(nv, device=self.device)[None, :] < self.vcount[sid][:, None]).float().unsqueeze(2)
         if self.operators == "device":
             from .operators import dirac_operators_from_mesh
 

@@ -1547,6 +1547,32 @@ __global__ __launch_bounds__(kWG) void gather_segments_k(const float *__restrict
   }
 }
 
+// The same gather straight into a PACKED batch: item i contributes item_off[i+1] - item_off[i] segments (its real rows), written
+// to output rows item_off[i] ..; a thread finds its item by bisection of the (short) offset table.
+template <int W>
+__global__ __launch_bounds__(kWG) void gather_segments_ragged_k(const float *__restrict__ src, const int64_t *__restrict__ base,
+                                                                const int64_t *__restrict__ item_off, int nitems,
+                                                                int64_t row_stride, int len, int64_t total,
+                                                                float *__restrict__ out) {
+  const int lw = len / W;
+  for (int64_t i = (int64_t)blockIdx.x * kWG + threadIdx.x; i < total; i += (int64_t)gridDim.x * kWG) {
+    const int64_t row = i / lw;
+    const int c = (int)(i - row * lw) * W;
+    int lo = 0, hi = nitems - 1;
+    while (lo < hi) {                              // last item with item_off[item] <= row
+      const int mid = (lo + hi + 1) >> 1;
+      if (item_off[mid] <= row) lo = mid;
+      else hi = mid - 1;
+    }
+    const float *p = src + base[lo] + (row - item_off[lo]) * row_stride + c;
+    if constexpr (W == 4) {
+      __builtin_nontemporal_store(f4{p[0], p[1], p[2], p[3]}, reinterpret_cast<f4 *>(out) + i);
+    } else {
+      __builtin_nontemporal_store(p[0], out + i);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Forward of the same first layer: y = x·W^T + b with 1..8 input channels, and optionally elu(y) straight into the next
 // block's concat buffer.  Pure output streaming (a thread owns 4 adjacent output columns, its 4 x C weights stay in
@@ -4069,6 +4095,27 @@ int sn_gather_segments_f32(const float *src, const int64_t *base, int64_t nitems
   else
     hipLaunchKernelGGL((gather_segments_k<1>), dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src, base,
                        rows_per_item, row_stride, (int)len, total, out);
+  return launch_status();
+}
+
+// sn_gather_segments_f32 into a packed batch: item i supplies rows [0, item_off[i+1] - item_off[i]) of its window (item_off:
+// int64[nitems + 1] on the device, item_off[0] = 0, total_rows = item_off[nitems] — passed by the caller, who built the table).
+int sn_gather_segments_ragged_f32(const float *src, const int64_t *base, const int64_t *item_off, int64_t nitems,
+                                  int64_t total_rows, int64_t row_stride, int32_t len, float *out, void *stream) {
+  (void)hipGetLastError();
+  if (nitems < 0 || nitems > INT_MAX || total_rows < 0 || len < 1 || row_stride < 0) return SN_E_SHAPE;
+  if (nitems == 0 || total_rows == 0) return SN_OK;
+  if (!src || !base || !item_off || !out) return SN_E_NULL;
+  const bool vec = (len % 4 == 0) && aligned16(out);
+  const int64_t total = total_rows * (vec ? len / 4 : len);
+  int64_t blocks = (total + kWG - 1) / kWG;
+  if (blocks > 64 * 1024) blocks = 64 * 1024;
+  if (vec)
+    hipLaunchKernelGGL((gather_segments_ragged_k<4>), dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src,
+                       base, item_off, (int)nitems, row_stride, (int)len, total, out);
+  else
+    hipLaunchKernelGGL((gather_segments_ragged_k<1>), dim3((unsigned)blocks), dim3(kWG), 0, static_cast<hipStream_t>(stream), src,
+                       base, item_off, (int)nitems, row_stride, (int)len, total, out);
   return launch_status();
 }
 

@@ -17,7 +17,7 @@ __all__ = [
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
     "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "pair_ce_fwd", "pair_ce_bwd", "pair_fused_fwd", "pair_fused_bwd", "bn_fold_parts", "colstats_partial", "linear_fwd_stats_blocks", "fold_parts_supported", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
-    "wgrad_bn_supported", "avg_merged_supported", "avg_stats_ragged", "avg_stats_from_tiles_ragged",
+    "wgrad_bn_supported", "avg_merged_supported", "avg_stats_ragged", "avg_stats_from_tiles_ragged", "gather_segments_ragged",
 ]
 
 
@@ -1228,6 +1228,18 @@ def gather_segments(src, base, rows_per_item: int, row_stride: int, length: int)
     n = base.numel()
     out = torch.empty((n, rows_per_item, length), dtype=torch.float32, device=src.device)
     _lib.call("sn_gather_segments_f32", _p(src), _p(base.contiguous()), n, rows_per_item, row_stride, length, _p(out), _stream())
+    return out
+
+
+def gather_segments_ragged(src, base, seg, row_stride: int, length: int):
+    """(seg.rows, length) fp32: the packed counterpart of gather_segments — item i supplies its first len_i rows, stored at the
+    rows of mesh i of the packed batch `seg` (operators.PackedSegments); sn_gather_segments_ragged_f32."""
+    _dev(src, base)
+    if not src.is_contiguous() or src.dtype != torch.float32 or base.dtype != torch.int64 or base.numel() != seg.nseg:
+        raise TypeError("gather_segments_ragged: contiguous float32 source and one int64 offset per mesh expected")
+    out = torch.empty((seg.rows, length), dtype=torch.float32, device=src.device)
+    _lib.call("sn_gather_segments_ragged_f32", _p(src), _p(base.contiguous()), _p(seg.off_dev), seg.nseg, seg.rows, row_stride, length,
+              _p(out), _stream())
     return out
 
 

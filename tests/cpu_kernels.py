@@ -606,6 +606,13 @@ def gather_segments(src, base, rows_per_item, row_stride, length):
     return flat[idx]
 
 
+def gather_segments_ragged(src, base, seg, row_stride, length):
+    flat = src.reshape(-1)
+    lens = [int(v) for v in seg.lengths]
+    parts = [flat[(int(b) + torch.arange(n).reshape(-1, 1) * row_stride + torch.arange(length).reshape(1, -1))] for b, n in zip(base, lens)]
+    return torch.cat(parts, 0)
+
+
 def pair_argmin(GA, pa, GB, pb):
     return torch.argmin(GA[:pb.numel()][:, pa] + GB[pb][:, :pa.numel()], dim=1)
 

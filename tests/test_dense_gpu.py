@@ -1311,3 +1311,23 @@ def test_ragged_global_average_statistics_from_tile_sums(lengths):
         assert float((m - m_ref).abs().max()) <= 2e-6 * float(m_ref.abs().max()) + 1e-7
         assert torch.allclose(stats[:, :C], want[:, :C], rtol=1e-13, atol=1e-9)
         assert torch.allclose(stats[:, C:], want[:, C:], rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("length", [6, 120, 7])
+def test_gather_segments_into_a_packed_batch(length):
+    """sn_gather_segments_ragged_f32 against the padded gather followed by the boolean-mask selection it replaces."""
+    from surfacenetworks_amd.operators import PackedSegments
+
+    rng = np.random.default_rng(length)
+    n, vmax, f3 = 5, 300, 135
+    src = dev(rng.standard_normal((n, vmax, f3)).astype(np.float32))
+    lengths = [300, 32, 77, 1, 250]
+    items = np.array([3, 0, 4, 2, 1])
+    seg = PackedSegments([lengths[i] for i in items], DEV)
+    base = dev((items * vmax * f3 + 3 * np.array([0, 2, 1, 4, 3])).astype(np.int64))
+    nv = max(lengths)
+    padded = kernels.gather_segments(src, base, nv, f3, length)
+    keep = torch.arange(nv, device=DEV)[None, :] < dev(np.array([lengths[i] for i in items]))[:, None]
+    want = padded[keep]
+    got = kernels.gather_segments_ragged(src, base, seg, f3, length)
+    assert got.shape == (seg.rows, length) and torch.equal(got, want)
