@@ -41,7 +41,11 @@ class Model(nn.Module):
     def forward(self, L, mask, inputs):
         x = self.conv1(inputs)
         for i in range(self.layer):
-            x = self._modules["rn{}".format(i)](L, mask, x)
+            blk = self._modules["rn{}".format(i)]
+            if i % 2 == 0:
+                x = blk(L, mask, x, avg_next=i + 1 < self.layer)      # (a global-average block follows: hand it the tile sums)
+            else:
+                x = blk(L, mask, x)
         x = utils.elu_conv1x1(self.conv2, x)
         return _add_last_frame(x, inputs, 40)
 
@@ -64,7 +68,7 @@ class DirModel(nn.Module):
         for i in range(self.layer):
             blk = self._modules["rn{}".format(i)]
             if i % 2 == 0:
-                v, f = blk(Di, DiA, v, f, num_faces=num_faces)
+                v, f = blk(Di, DiA, v, f, num_faces=num_faces, avg_next=i + 1 < self.layer)
             else:
                 v = blk(None, mask, v)
         x = utils.elu_conv1x1(self.conv2, v)

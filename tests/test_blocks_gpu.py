@@ -468,3 +468,26 @@ def test_blocks_with_the_two_launch_backward(golden_dir, cname, monkeypatch):
     monkeypatch.setattr(kernels, "wgrad_bn", counted)
     pc.check_block(golden_dir, cname, 128, "pool", DEV)
     assert len(calls) == 2          # both Linear layers of the block took it
+
+
+def test_packed_model_with_and_without_tile_sums(monkeypatch):
+    """The ARAP Dirac model on a PACKED batch with the tile-sum hand-off through the ragged global-average stages (forced: it is
+    used from 32 768 rows on) and with the pass over every stage's operand: same loss, gradients equal up to what the fp32 tile
+    sums do to the per-mesh means (1e-7 of a mesh's mean |e|, tests/test_dense_gpu.py) — which this toy batch amplifies: BatchNorm
+    of the broadcast half normalises over FOUR meshes' means here (padded form of the same batch: 3e-5, packed: 4e-4)."""
+    from helpers import deterministic_init
+    from surfacenetworks_amd import arap, blocks as snB, kernels
+
+    ds = arap.ClothSequences([(12, 11), (9, 13), (10, 10)], frames=45, op_frames=2, seed=3, device=DEV, model="dir")
+    seq, off = np.array([0, 1, 2, 1]), np.array([0, 0, 0, 0])       # (op_frames = 2: the operator of the last input frame exists for start 0)
+    monkeypatch.setattr(snB, "_TILE_SUMS_MIN_ROWS", 0)
+    res = []
+    for on in (True, False):
+        monkeypatch.setattr(kernels, "tile_sums_supported", (lambda: True) if on else (lambda: False))
+        model = deterministic_init(arap.DirModel(), 4).to(DEV).train()
+        b = ds.sample_batch(4, None, seq_ids=seq, offsets=off, packed=True)
+        loss, _ = arap.forward_loss(model, b, 4)
+        loss.backward()
+        res.append((loss.item(), torch.cat([p.grad.reshape(-1) for p in model.parameters()])))
+    assert abs(res[0][0] - res[1][0]) <= 2e-6 * abs(res[1][0])
+    assert float((res[0][1] - res[1][1]).norm() / res[1][1].norm()) < 2e-3

@@ -1083,6 +1083,9 @@ def test_arap_model_with_and_without_tile_sums(monkeypatch):
     ds = arap.ClothSequences([(12, 11), (9, 13), (10, 10)], frames=45, op_frames=2, seed=3, device=DEV, model="dir")
     seq, off = np.array([0, 1, 2, 1]), np.array([0, 1, 0, 0])
     res = []
+    from surfacenetworks_amd import blocks as snB
+
+    monkeypatch.setattr(snB, "_TILE_SUMS_MIN_ROWS", 0)            # (the hand-off is used from 32 768 rows on: force it here)
     for on in (True, False):
         monkeypatch.setattr(kernels, "tile_sums_supported", (lambda: True) if on else (lambda: False))
         model = deterministic_init(arap.DirModel(), 4).to(DEV).train()
@@ -1309,6 +1312,11 @@ def test_ragged_global_average_statistics_from_tile_sums(lengths):
         want = kernels.avg_stats_ragged(m_ref.contiguous(), seg, part, kernels.linear_fwd_stats_blocks(rows))
         m, stats = kernels.avg_stats_from_tiles_ragged(tiles, part, e, seg)
         assert float((m - m_ref).abs().max()) <= 2e-6 * float(m_ref.abs().max()) + 1e-7
+        # the tiles are fp32 sums of 32 rows: a mean is good to ~1e-7 of the mesh's mean |e|, whatever its own size
+        mesh = torch.from_numpy(np.repeat(np.arange(seg.nseg), seg.lengths)).to(DEV)
+        m64 = torch.zeros(seg.nseg, C, dtype=torch.float64, device=DEV).index_add_(0, mesh, e.double()) * seg.inv_count.double()[:, None]
+        a64 = torch.zeros(seg.nseg, C, dtype=torch.float64, device=DEV).index_add_(0, mesh, e.double().abs()) * seg.inv_count.double()[:, None]
+        assert bool(((m.double() - m64).abs() <= 4e-7 * a64 + 1e-12).all())
         assert torch.allclose(stats[:, :C], want[:, :C], rtol=1e-13, atol=1e-9)
         assert torch.allclose(stats[:, C:], want[:, C:], rtol=1e-5, atol=1e-5)
 
