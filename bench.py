@@ -351,12 +351,25 @@ def c4_dp_step(device, rank: int, world: int, steps: int = 40, warm: int = 8):
     dp.broadcast_parameters(model, 0)
     opt = dc.make_optimizer(model)
     bucket = dp.FlatGradBucket(model.parameters(), always_reduce=dist.is_initialized())
-    g = dc.graphed_train_step(model, opt, dc.PairBatch(ds, 0, 1), bucket=bucket, global_pairs=world)
     k = [0]
+    launch = "hipGraph replay of fwd+loss+bwd; pair selection, all-reduce, Adam eager"
+    try:
+        g = dc.graphed_train_step(model, opt, dc.PairBatch(ds, 0, 1), bucket=bucket, global_pairs=world)
 
-    def step():
-        k[0] += 1
-        return g(dc.PairBatch(ds, k[0] % 4, (k[0] + 1) % 4))
+        def step():
+            k[0] += 1
+            return g(dc.PairBatch(ds, k[0] % 4, (k[0] + 1) % 4))
+    except Exception as exc:  # noqa: BLE001  (a rank whose capture fails runs the same step eagerly: same collective per step)
+        launch = f"eager (graph capture failed: {type(exc).__name__}: {exc})"[:300]
+        try:
+            torch.cuda.synchronize()
+        except Exception:  # noqa: BLE001
+            pass
+
+        def step():
+            k[0] += 1
+            return dc.train_step(model, opt, ds, k[0] % 4, (k[0] + 1) % 4, grad_sync=bucket.sync, global_pairs=world,
+                                 zero_grads=bucket.detach_grads)
 
     for _ in range(warm):
         step()
@@ -373,7 +386,7 @@ def c4_dp_step(device, rank: int, world: int, steps: int = 40, warm: int = 8):
     dt = time.perf_counter() - t0
     assert torch.isfinite(loss.detach()).item(), "FAUST step diverged"
     return dt / steps, {"steps": steps, "warmup": warm, "host_enqueue_ms_per_step": t_enq / steps * 1e3,
-                        "grad_bucket_bytes": bucket.nbytes}
+                        "grad_bucket_bytes": bucket.nbytes, "launch": launch}
 
 
 def pin_to_gpu_numa(local_rank: int, n_local: int):
@@ -637,9 +650,20 @@ def main():
     # forward+loss+backward follows), then the W warm-up steps asked for
     for _ in range(3):
         eager_step()
+    graph_fallback = None
     if not args.no_graph:
-        graphed = arap.GraphedTrainStep(model, opt, ds.sample_batch(n_local, rng, seq_ids=seq_ids),
-                                        global_batch=global_batch, bucket=bucket)
+        try:
+            graphed = arap.GraphedTrainStep(model, opt, ds.sample_batch(n_local, rng, seq_ids=seq_ids),
+                                            global_batch=global_batch, bucket=bucket)
+        except Exception as exc:  # noqa: BLE001  (a rank whose capture fails runs eagerly: same step, same collective; the line says so)
+            graph_fallback = f"{type(exc).__name__}: {exc}"[:300]
+            graphed = None
+            args.no_graph = True
+            one_step = eager_step
+            try:
+                torch.cuda.synchronize()
+            except Exception:  # noqa: BLE001
+                pass
     for _ in range(args.warmup):
         one_step()
     sync()
@@ -787,7 +811,8 @@ def main():
                                      "three-piece bf16 form, 0 the fp32-MFMA kernels; the weight gradient uses three bf16 pieces"),
                    "allocator": alloc, "operator_format": args.format, "operators": args.operators,
                    "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3, "host_affinity": affinity,
-                   "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager", "grad_bucket_bytes": bucket.nbytes},
+                   "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager",
+                   "graph_fallback": graph_fallback, "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": dom_name + (" (the backward products Di^T, DiA^T, ELU backward fused into the store)" if "_epi" in dom_name
                                                           else " (the Dirac products launched without epilogue)"),
                      # `frac` is the MORE CONSERVATIVE of the two defensible readings of the fused launch: algorithmic bytes of the
