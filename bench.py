@@ -515,8 +515,12 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=5,
                     help="eager steps run AFTER the timed region with per-launch HIP events (graph mode only)")
     ap.add_argument("--linear-timing-steps", type=int, default=5,
-                    help="timed steps whose Linear-layer launches carry start/stop events as well (roofline.linear_kernels); the "
-                         "sparse products are timed on every step.  An event pair costs a launch ~2 us: 0.3 ms on all of a step's launches")
+                    help="timed steps whose Linear-layer launches carry start/stop events as well (roofline.linear_kernels).  An event "
+                         "pair costs a launch ~2 us: 0.3 ms on all of a step's launches")
+    ap.add_argument("--spmm-timing-steps", type=int, default=5,
+                    help="timed steps (the first ones of the timed region) whose sparse products carry start/stop events (roofline."
+                         "achieved): 32 launches per step, 0.10-0.15 ms per step when carried on all 20 (same box, three reps: 19.17 / "
+                         "19.24 / 19.30 ms against 19.08 / 19.11 / 19.15 with 5); 0 or less: every timed step")
     ap.add_argument("--format", default="q3", choices=["q3", "bsr4", "csr"],
                     help="Dirac operator form: quaternion-packed blocks (default), 4x4 blocks, generic CSR")
     ap.add_argument("--operators", default="pool", choices=["pool", "device"],
@@ -671,11 +675,14 @@ def main():
     ms0 = torch.cuda.memory_stats()
     t0 = time.perf_counter()
     if args.no_graph:
-        with timer:                                  # per-launch HIP events on every SpMM of the timed steps
-            for i in range(args.steps):
+        n_ev = args.steps if args.spmm_timing_steps <= 0 else min(args.spmm_timing_steps, args.steps)
+        with timer:                                  # per-launch HIP events on every SpMM of the first n_ev timed steps
+            for i in range(n_ev):
                 if i == args.linear_timing_steps:    # the ~120 Linear launches of a step carry events on the first steps only
                     timer.time_linear(False)
                 loss = one_step().detach()           # (keeping the loss itself would keep the step's autograd graph alive)
+        for i in range(n_ev, args.steps):            # the rest of the timed region without events
+            loss = one_step().detach()
     else:
         for _ in range(args.steps):
             loss = one_step().detach()
@@ -719,7 +726,8 @@ def main():
     avg_ms = tot_ms / len(dom)
     ab = tot_bytes / len(dom)                      # average algorithmic bytes per launch of this kernel
     achieved = tot_bytes / (tot_ms * 1e-3)
-    spmm_ms_per_step = sum(r[5] for r in recs) / (args.steps if args.no_graph else max(1, args.roofline_steps))
+    n_ev_steps = (args.steps if args.spmm_timing_steps <= 0 else min(args.spmm_timing_steps, args.steps)) if args.no_graph else max(1, args.roofline_steps)
+    spmm_ms_per_step = sum(r[5] for r in recs) / n_ev_steps
     shapes = {}
     for tag, M, K, nnz, N, ms in dom:
         shapes.setdefault((tag, M, K, nnz, N), []).append(ms)
@@ -779,7 +787,7 @@ def main():
     lin = {}
     for name, rows_, width, outw, nbytes, ms_ in getattr(timer, "linear", []):
         lin.setdefault((name, rows_, width, outw, nbytes), []).append(ms_)
-    n_steps_timed = args.steps if args.no_graph else max(1, args.roofline_steps)
+    n_steps_timed = n_ev_steps
     n_lin_steps = min(n_steps_timed, max(1, args.linear_timing_steps)) if args.no_graph else n_steps_timed
     linear_kernels = sorted(({"kernel": k[0], "rows": k[1], "width": k[2], "out_width": k[3], "launches": len(v),
                               "launches_per_step": len(v) / n_lin_steps, "avg_ms": float(np.mean(v)), "bytes": k[4],
@@ -830,7 +838,7 @@ def main():
                          "measured_hbm_traffic": frac_meas},
                      "algorithmic_bytes_per_launch": ab, "avg_launch_ms": avg_ms,
                      "timing": "hipExtLaunchKernelGGL start/stop events on the launch stream, " +
-                               ("every launch of the timed steps" if args.no_graph else
+                               (f"every launch of the first {n_ev_steps} of the {args.steps} timed steps" if args.no_graph else
                                 f"every launch of {max(1, args.roofline_steps)} eager steps run right after the timed hipGraph replays"),
                      "launches_timed": len(dom), "spmm_ms_per_step_all_kernels": spmm_ms_per_step, "per_product": per_shape,
                      "other_spmm_kernels": [
@@ -842,7 +850,7 @@ def main():
                                             "linear_dgrad bits 1 BatchNorm tail, 2 through the activation, 4 gadd, 8 per-mesh vector; "
                                             "bytes = operands read + results written (weights excluded), timed like the SpMM launches"
                                             + (f" on the first {n_lin_steps} of the {args.steps} timed steps (an event pair costs a launch ~2 us; "
-                                               "the sparse products carry events on every timed step)" if args.no_graph else ""),
+                                               f"the sparse products on the first {n_ev_steps})" if args.no_graph else ""),
                      "linear_ms_per_step": float(sum(d["ms_per_step"] for d in linear_kernels))},
     }
     if not args.no_secondary:
