@@ -255,6 +255,7 @@ class ClothSequences:
             xyz[s, :, : c.shape[1]] = c
         self.xyz = torch.from_numpy(xyz).to(self.device)
         self.vcount = torch.from_numpy(self.num_vertices).to(self.device)
+        self._mask_cache = {}
         if operators == "device":
             self.faces = torch.from_numpy(np.stack(faces_all)).to(self.device)          # (S, F, 3) int32
         elif model == "dir":
@@ -262,6 +263,21 @@ class ClothSequences:
             self.pool_DiA = OperatorPool(mats["DiA"], self.device, want_bsr4=True)
         else:
             self.pool_L = OperatorPool(mats["L"], self.device, want_bsr4=False)
+
+    def _mask_of(self, seq_ids, nv):
+        """(B, nv, 1) float mask of the real vertex rows of the padded batch (main.py:126-130 pads to the batch maximum).  It
+        depends on the SELECTION only, and loops that visit every mesh once per step pass the same selection each time: the
+        last few masks are kept (read-only downstream) — four elementwise launches per step otherwise."""
+        cache = self.__dict__.setdefault("_mask_cache", {})      # (datasets.arap_from_files builds the object field by field)
+        key = (seq_ids.tobytes(), int(nv))
+        hit = cache.get(key)
+        if hit is None:
+            sid = h2d_async(seq_ids, self.device)
+            hit = (torch.arange(nv, device=self.device)[None, :] < self.vcount[sid][:, None]).float().unsqueeze(2)
+            if len(cache) >= 8:
+                cache.pop(next(iter(cache)))
+            cache[key] = hit
+        return hit
 
     def _vertex_major(self):
         """Vertex-major (n, vmax, frames*3) copy of self.xyz (n, frames, vmax, 3): the 42 frames a sample needs of one
@@ -288,13 +304,15 @@ class ClothSequences:
         B = len(seq_ids)
         nv = int(self.num_vertices[seq_ids].max())
         nf = int(self.num_faces[seq_ids].max())
-        sid = h2d_async(seq_ids, self.device)
-        off = h2d_async(offsets, self.device)
         # a sample's 42 frames of a vertex are one contiguous run of the vertex-major copy: inputs and targets are gathered
         # straight into their final (B, nv, frames*3) layout (no permute / slice copies of the 160 MB window)
         vm = self._vertex_major()                                  # (n, vmax, frames*3)
         vmax, f3 = vm.shape[1], vm.shape[2]
-        base = (sid * vmax) * f3 + 3 * off                         # element offset of (sample, vertex 0, start frame)
+        # element offsets of (sample, vertex 0, start frame) for the input and the target window: host arithmetic on the B
+        # sample indices, ONE small upload (was: two uploads and four elementwise launches per step)
+        hb = (seq_ids.astype(np.int64) * vmax) * f3 + 3 * offsets.astype(np.int64)
+        bases = h2d_async(np.stack([hb, hb + 3 * INPUT_FRAMES]), self.device)
+        base, base_t = bases[0], bases[1]
         op_ids = seq_ids * self.op_frames + (offsets + INPUT_FRAMES - 1)
         L = Di = DiA = None
         if packed:
@@ -303,18 +321,20 @@ class ClothSequences:
             # the real rows of every sample, mesh-major, gathered straight into the packed layout (no padded intermediate)
             seg = PackedSegments.cached(self.num_vertices[seq_ids], self.device)
             inputs = kernels.gather_segments_ragged(vm, base, seg, f3, 3 * INPUT_FRAMES).unsqueeze(0)
-            targets = kernels.gather_segments_ragged(vm, base + 3 * INPUT_FRAMES, seg, f3, 3 * OUTPUT_FRAMES).unsqueeze(0)
+            targets = kernels.gather_segments_ragged(vm, base_t, seg, f3, 3 * OUTPUT_FRAMES).unsqueeze(0)
             if self.kind == "dir":
                 Di, DiA = self.pool_Di.assemble(op_ids), self.pool_DiA.assemble(op_ids)
             else:
                 L = self.pool_L.assemble(op_ids)
             return Batch(inputs, targets, seg, L, Di, DiA, B)
         inputs = kernels.gather_segments(vm, base, nv, f3, 3 * INPUT_FRAMES)
-        targets = kernels.gather_segments(vm, base + 3 * INPUT_FRAMES, nv, f3, 3 * OUTPUT_FRAMES)
-        mask = (torch.arange(nv, device=self.device)[None, :] < self.vcount[sid][:, None]).float().unsqueeze(2)
+        targets = kernels.gather_segments(vm, base_t, nv, f3, 3 * OUTPUT_FRAMES)
+        mask = self._mask_of(seq_ids, nv)
         if self.operators == "device":
             from .operators import dirac_operators_from_mesh
 
+            sid = h2d_async(seq_ids, self.device)
+            off = h2d_async(offsets, self.device)
             Vop = self.xyz[sid, off + INPUT_FRAMES - 1]                                   # (B, nv, 3): last input frame
             Di, DiA = dirac_operators_from_mesh(Vop, self.faces[sid])
         elif self.kind == "dir":
