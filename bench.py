@@ -173,39 +173,46 @@ C5_MESHES_PER_GPU = 128
 C5_VMIN, C5_VMAX = 1000, 20000
 
 
-def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10):
-    """Config 5 (SURVEY.md §8d): 128 grid-cloth meshes per GPU, V_i uniform in [1000, 20000] (seed 5 + rank), Dirac
-    operators, N = 32 (C = 128).  The four products Di, Di^T, DiA, DiA^T are launched back to back (>= 50 timed launches
-    after >= 10 warm-ups, the kernel's own start/stop in HIP events on the launch stream) on
-      packed  the ragged batch without padding (OperatorPool.assemble(sel): prefix-sum offsets, operands (sum V_i, C));
-      padded  every mesh padded to the batch maximum as the reference's sparse_diag_cat does (utils_pt.py:41-53).
-    Algorithmic bytes = nnz*8 + (M+1)*4 + K*N*4 + M*N*4 with M, K from the REAL sum of 4*F_i / 4*V_i in both cases, so the
-    padded variant gets no credit for the zeros it writes."""
-    from surfacenetworks_amd import functional as snF
+def _c5_meshes(rank: int, permute=False, reorder=False):
+    """The 128 config-5 meshes of this rank (sizes from seed 5 + rank, the same in every variant): per-mesh Di, DiA, L and
+    (sum V, sum F).  permute / reorder as arap.ClothSequences takes them."""
     from surfacenetworks_amd import mesh_ops
-    from surfacenetworks_amd.operators import OperatorPool
 
     rng = np.random.default_rng(5 + rank)
     vs = rng.integers(C5_VMIN, C5_VMAX + 1, size=C5_MESHES_PER_GPU)
-    Dis, DiAs, Ls, sumV, sumF = [], [], [], 0, 0
+    Dis, DiAs, Ls, sumV, sumF, spans = [], [], [], 0, 0, []
     for v in vs:
         n = int(np.sqrt(v))
-        V, F_ = mesh_ops.grid_cloth(n, int(v) // n, rng)
+        V, F_ = mesh_ops.grid_cloth(n, int(v) // n, rng, permute=permute)
+        order = mesh_ops.MeshOrder.of_mesh(F_, V.shape[0], reorder)
+        V, F_ = order.mesh(V, F_)
+        spans.append(mesh_ops.edge_span(F_)[0])
         Di, DiA = mesh_ops.dirac(V, F_)
         Dis.append(Di.astype(np.float32))
         DiAs.append(DiA.astype(np.float32))
         Ls.append(mesh_ops.laplacian(V, F_).astype(np.float32))
         sumV += V.shape[0]
         sumF += F_.shape[0]
-    pools = {"Di": OperatorPool(Dis, device, want_bsr4=True), "DiA": OperatorPool(DiAs, device, want_bsr4=True)}
+    return Dis, DiAs, Ls, sumV, sumF, float(np.mean(spans))
+
+
+def _c5_time(o, x, y, group, iters, warm):
+    from surfacenetworks_amd import functional as snF
+
+    for _ in range(warm):
+        snF._launch(o, x, y, group, "c5")
+    timer = snF.SpmmTimer()
+    with timer:
+        for _ in range(iters):
+            snF._launch(o, x, y, group, "c5")
+    recs = timer.results()
+    return np.array([r[5] for r in recs]), recs[0][0].split("/")[-1]
+
+
+def _c5_dirac_products(pools, layouts, order, g, device, iters, warm, N=32):
     sel = np.arange(C5_MESHES_PER_GPU)
-    N = 32
-    out = {"workload": f"BASELINE configs[4]: {C5_MESHES_PER_GPU} grid-cloth meshes per GPU, V in [{C5_VMIN}, {C5_VMAX}] "
-                       f"(sum V = {sumV}, sum F = {sumF}), Dirac operators, C = 128 (N = {N}), quaternion-packed records",
-           "timing": f"{iters} back-to-back launches after {warm} warm-ups; hipExtLaunchKernelGGL start/stop events per launch",
-           "peak_GBps": HBM_PEAK / 1e9, "products": []}
-    g = torch.Generator(device=device).manual_seed(7)
-    for layout in ("packed", "padded"):
+    out = []
+    for layout in layouts:
         for name in ("Di", "DiA"):
             pool = pools[name]
             if layout == "packed":
@@ -218,55 +225,120 @@ def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10):
                 real_K = int((pool.cols if prod == name else pool.rows).sum())
                 x = torch.randn(K // 4, 4 * N, device=device, generator=g)
                 y = torch.empty(M // 4, 4 * N, device=device)
-                for _ in range(warm):
-                    snF._launch(o, x, y, 4, "c5")
-                timer = snF.SpmmTimer()
-                with timer:
-                    for _ in range(iters):
-                        snF._launch(o, x, y, 4, "c5")
-                ms = np.array([r[5] for r in timer.results()])
+                ms, _ = _c5_time(o, x, y, 4, iters, warm)
                 ab = alg_bytes(real_M, real_K, o.nnz, N)
                 # what the packed form really moves: 16-byte quaternion records + block-row pointers + X + Y (real rows only:
                 # the padded layout also WRITES its padding rows — charged to its time, not credited)
                 q = o.q3()
                 actual = (int(q[1].shape[0]) * 16 + (M // 4 + 1) * 4 + real_K * N * 4 + real_M * N * 4) if q is not None else None
                 med = float(np.median(ms)) * 1e-3
-                out["products"].append({
-                    "layout": layout, "product": prod, "M": M, "K": K, "real_M": real_M, "real_K": real_K, "nnz": o.nnz,
+                out.append({
+                    "layout": layout, "order": order, "product": prod, "M": M, "K": K, "real_M": real_M, "real_K": real_K, "nnz": o.nnz,
                     "algorithmic_bytes": ab, "actual_bytes": actual, "ms_median": float(np.median(ms)), "ms_min": float(ms.min()),
                     "ms_mean": float(ms.mean()), "GBps": ab / med / 1e9, "frac": ab / med / HBM_PEAK,
                     "frac_actual": (actual / med / HBM_PEAK) if actual else None})
                 del x, y
             del op
-    # the same meshes' cotangent Laplacians at 128 channels, packed (the operator of the Laplacian models; default: the
-    # sliding-window kernel straight from the CSR arrays) — reported next to the Dirac products, not part of frac_min_packed
-    # (north_star's bar names the Dirac)
+    return out
+
+
+def _c5_laplacian_products(Ls, order, g, device, iters, warm):
+    from surfacenetworks_amd.operators import OperatorPool
+
     pool = OperatorPool(Ls, device)
-    op = pool.assemble(sel)
-    out["laplacian"] = []
+    op = pool.assemble(np.arange(C5_MESHES_PER_GPU))
+    out = []
     for prod, o in (("L", op), ("L^T", op.t())):
         M, K = o.shape
         x = torch.randn(K, 128, device=device, generator=g)
         y = torch.empty(M, 128, device=device)
-        for _ in range(warm):
-            snF._launch(o, x, y, 1, "c5")
-        timer = snF.SpmmTimer()
-        with timer:
-            for _ in range(iters):
-                snF._launch(o, x, y, 1, "c5")
-        recs_l = timer.results()
-        ms = np.array([r[5] for r in recs_l])
+        ms, kernel = _c5_time(o, x, y, 1, iters, warm)
         ab = alg_bytes(M, K, o.nnz, 128)
-        out["laplacian"].append({"layout": "packed", "product": prod, "kernel": recs_l[0][0].split("/")[-1], "band": list(o.band()),
-                                 "M": M, "K": K, "nnz": o.nnz, "algorithmic_bytes": ab,
-                                 "ms_median": float(np.median(ms)), "ms_min": float(ms.min()),
-                                 "GBps": ab / (float(np.median(ms)) * 1e-3) / 1e9,
-                                 "frac": ab / (float(np.median(ms)) * 1e-3) / HBM_PEAK})
+        out.append({"layout": "packed", "order": order, "product": prod, "kernel": kernel, "band": list(o.band()),
+                    "M": M, "K": K, "nnz": o.nnz, "algorithmic_bytes": ab,
+                    "ms_median": float(np.median(ms)), "ms_min": float(ms.min()),
+                    "GBps": ab / (float(np.median(ms)) * 1e-3) / 1e9,
+                    "frac": ab / (float(np.median(ms)) * 1e-3) / HBM_PEAK})
         del x, y
-    del op, pool
-    packed = [p_ for p_ in out["products"] if p_["layout"] == "packed"]
+    return out
+
+
+# vertex / face numberings the config-5 products are measured on ("row-major grid, plus a random-permuted
+# variant (seeded) to expose gather locality"): tag -> (permute, reorder) of _c5_meshes
+C5_ORDERS = {
+    "grid": (False, False),                           # the generator's row-major numbering
+    "permuted": ("vertices", False),                  # §8d's variant: vertices renumbered at random, face list as generated
+    "permuted_both": ("both", False),                 # faces shuffled too (a scanned mesh), dataset order kept as stored
+    "permuted_both+reorder": ("both", True),          # the same meshes stored in the product's locality numbering (MeshOrder)
+}
+
+
+def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10):
+    """Config 5 (SURVEY.md §8d): 128 grid-cloth meshes per GPU, V_i uniform in [1000, 20000] (seed 5 + rank), Dirac
+    operators, N = 32 (C = 128).  The four products Di, Di^T, DiA, DiA^T are launched back to back (>= 50 timed launches
+    after >= 10 warm-ups, the kernel's own start/stop in HIP events on the launch stream) on
+      packed  the ragged batch without padding (OperatorPool.assemble(sel): prefix-sum offsets, operands (sum V_i, C));
+      padded  every mesh padded to the batch maximum as the reference's sparse_diag_cat does (utils_pt.py:41-53).
+    Algorithmic bytes = nnz*8 + (M+1)*4 + K*N*4 + M*N*4 with M, K from the REAL sum of 4*F_i / 4*V_i in both cases, so the
+    padded variant gets no credit for the zeros it writes.  Every entry names the vertex / face ORDER it was measured on
+    (C5_ORDERS): the generator's grid order, §8d's random vertex permutation, vertices and faces both shuffled, and the latter
+    stored in the product's locality numbering."""
+    from surfacenetworks_amd.operators import OperatorPool
+
+    N = 32
+    g = torch.Generator(device=device).manual_seed(7)
+    out = None
+    for order, (permute, reorder) in C5_ORDERS.items():
+        Dis, DiAs, Ls, sumV, sumF, span = _c5_meshes(rank, permute, reorder)
+        if out is None:
+            out = {"workload": f"BASELINE configs[4]: {C5_MESHES_PER_GPU} grid-cloth meshes per GPU, V in [{C5_VMIN}, {C5_VMAX}] "
+                               f"(sum V = {sumV}, sum F = {sumF}), Dirac operators, C = 128 (N = {N}), quaternion-packed records",
+                   "timing": f"{iters} back-to-back launches after {warm} warm-ups; hipExtLaunchKernelGGL start/stop events per launch",
+                   "orders": {"grid": "row-major grid numbering (generator order)",
+                              "permuted": "seeded random vertex numbering, face list as generated (SURVEY.md §8d), seed 5 + rank",
+                              "permuted_both": "vertices renumbered and faces shuffled at random, used as stored",
+                              "permuted_both+reorder": "the same shuffled meshes stored in mesh_ops.MeshOrder's locality numbering "
+                                                       "(reverse Cuthill-McKee, one-time at pool construction)"},
+                   "mean_edge_span": {}, "peak_GBps": HBM_PEAK / 1e9, "products": [], "laplacian": []}
+        out["mean_edge_span"][order] = span
+        pools = {"Di": OperatorPool(Dis, device, want_bsr4=True), "DiA": OperatorPool(DiAs, device, want_bsr4=True)}
+        out["products"] += _c5_dirac_products(pools, ("packed", "padded") if order == "grid" else ("packed",), order, g, device, iters, warm, N)
+        del pools
+        # the same meshes' cotangent Laplacians at 128 channels, packed (the operator of the Laplacian models; default: the
+        # sliding-window kernel straight from the CSR arrays where the band allows, else the row-blocked form) — reported
+        # next to the Dirac products, not part of frac_min_packed (north_star's bar names the Dirac)
+        out["laplacian"] += _c5_laplacian_products(Ls, order, g, device, iters, warm)
+        del Dis, DiAs, Ls
+        torch.cuda.empty_cache()
+    packed = [p_ for p_ in out["products"] if p_["layout"] == "packed" and p_["order"] == "grid"]
     out["frac_min_packed"] = min(p_["frac"] for p_ in packed)
     out["GBps_mean_packed"] = float(np.mean([p_["GBps"] for p_ in packed]))
+    out["frac_min_packed_by_order"] = {o: min(p_["frac"] for p_ in out["products"] if p_["layout"] == "packed" and p_["order"] == o)
+                                       for o in C5_ORDERS}
+    out["laplacian_frac_min_by_order"] = {o: min(p_["frac"] for p_ in out["laplacian"] if p_["order"] == o) for o in C5_ORDERS}
+    return out
+
+
+def c3_order_secondary(device, meshes: int = MESHES_PER_GPU, steps: int = 10, warm: int = 4):
+    """The headline step (config 3) on meshes that do NOT arrive in grid order: 64 grid-cloth meshes 71x71 with vertices and
+    faces shuffled (seed 3), trained (a) as stored and (b) stored in the product's locality numbering (ClothSequences(reorder=
+    True): one-time host work at dataset construction, nothing per step).  Eager steps, same step definition as the headline."""
+    from surfacenetworks_amd import arap
+
+    out = {"workload": f"config 3 with shuffled vertex and face numbering: {meshes} meshes {GRID[0]}x{GRID[1]}, Dirac model, "
+                       "assembly + fwd + loss + bwd + Adam, eager", "steps": steps, "warmup": warm}
+    for tag, permute, reorder in (("permuted_both", "both", False), ("permuted_both+reorder", "both", True), ("permuted", "vertices", False)):
+        ds = arap.ClothSequences([GRID] * meshes, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 2, op_frames=2, seed=3,
+                                 device=device, model="dir", permute=permute, reorder=reorder)
+        torch.manual_seed(1234)
+        model = arap.DirModel().to(device).train()
+        opt = arap.make_optimizer(model)
+        rng = np.random.default_rng(10)
+        ids = np.arange(meshes)
+        dt = _timed_steps(lambda: arap.train_step(model, opt, ds.sample_batch(meshes, rng, seq_ids=ids)), steps, warm)
+        out[tag] = {"ms_per_step": dt * 1e3, "meshes_per_s": meshes / dt}
+        del ds, model, opt
+        torch.cuda.empty_cache()
     return out
 
 
@@ -859,7 +931,7 @@ def main():
         torch.cuda.empty_cache()
         try:
             sec = c5_secondary(device, rank)
-            mine = sum(p_["GBps"] for p_ in sec["products"] if p_["layout"] == "packed") / 4.0
+            mine = sec["GBps_mean_packed"]
         except Exception as exc:  # noqa: BLE001 — the headline line must survive a failure of the secondary block
             sec, mine = {"error": repr(exc)[:300]}, 0.0
         agg = torch.tensor([mine], dtype=torch.float64, device=device)
@@ -887,7 +959,7 @@ def main():
                 raise                               # (a rank that left the collectives would hang the others)
         if rank == 0 and world == 1:
             # the small-batch configurations, driver-visible (rank 0 of a one-GPU run only: they are replicas, not a sharded job)
-            for key, fn in (("config2", c2_secondary), ("config4_pair", c4_pair_secondary)):
+            for key, fn in (("config3_order", c3_order_secondary), ("config2", c2_secondary), ("config4_pair", c4_pair_secondary)):
                 torch.cuda.empty_cache()
                 try:
                     sec[key] = fn(device)

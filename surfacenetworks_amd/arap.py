@@ -209,8 +209,15 @@ class ClothSequences:
     operators in OperatorPools (entry s*op_frames + t is sequence s at frame t)."""
 
     def __init__(self, grids, frames=50, op_frames=2, seed=3, device="cuda", model="dir", permute=False,
-                 operators="pool"):
-        """operators="pool": per-frame operators precomputed (host, fp64 coordinates) and pooled in HBM, as the
+                 operators="pool", reorder="auto"):
+        """permute: False (row-major grid numbering), True / "vertices" (seeded random vertex numbering) or
+        "both" (faces shuffled too: what a scanned mesh looks like).
+        reorder: "auto" (default) / True / False — the dataset is STORED in a locality numbering of its vertices and faces
+        (mesh_ops.MeshOrder: reverse Cuthill-McKee; "auto" keeps a numbering that is already local, e.g. a generated grid), so
+        that every operator is banded and the products' gathers stay in cache whatever order the meshes arrive in.  The model
+        is equivariant to the numbering and the loss invariant, so training is unchanged; `to_dataset_order` maps per-vertex
+        outputs back for callers that index vertices by the dataset's own numbers.
+        operators="pool": per-frame operators precomputed (host, fp64 coordinates) and pooled in HBM, as the
         reference's dataset does.  operators="device": nothing is precomputed — the Dirac operators of the sampled
         frames are built on the GPU every step from the stored fp32 coordinates (sn_dirac_bsr4_from_mesh); needs
         meshes of one size (no padding) and model="dir"."""
@@ -224,9 +231,12 @@ class ClothSequences:
             raise ValueError("on-device operator construction supports the Dirac model on equally sized meshes")
         assert frames >= INPUT_FRAMES + OUTPUT_FRAMES + 1 and 1 <= op_frames
         Vs, Fs, mats = [], [], {"L": [], "Di": [], "DiA": []}
-        coords, faces_all = [], []
+        coords, faces_all, orders = [], [], []
         for (n, m) in grids:
             V0, F_ = mesh_ops.grid_cloth(n, m, rng, permute=permute)
+            order = mesh_ops.MeshOrder.of_mesh(F_, V0.shape[0], reorder)
+            V0, F_ = order.mesh(V0, F_)
+            orders.append(order)
             amp = 0.03 * (0.5 + rng.random())
             k = 2 * np.pi * (1 + rng.integers(0, 3))
             ph = rng.random() * 2 * np.pi
@@ -249,6 +259,7 @@ class ClothSequences:
         self.num_vertices = np.array(Vs)
         self.num_faces = np.array(Fs)
         self.n = len(grids)
+        self.orders = orders
         vmax = int(self.num_vertices.max())
         xyz = np.zeros((self.n, frames, vmax, 3), np.float32)
         for s, c in enumerate(coords):
@@ -278,6 +289,15 @@ class ClothSequences:
                 cache.pop(next(iter(cache)))
             cache[key] = hit
         return hit
+
+    def to_dataset_order(self, x: torch.Tensor, seq_ids) -> torch.Tensor:
+        """Per-vertex rows (B, nv, C) of the samples `seq_ids` from the STORED numbering (what sample_batch hands out and the
+        model returns) back into the dataset's own vertex numbering; padding rows stay where they are."""
+        return reorder_rows(x, self.orders, seq_ids, "vrank")
+
+    def from_dataset_order(self, x: torch.Tensor, seq_ids) -> torch.Tensor:
+        """The inverse: per-vertex rows given in the dataset's numbering, as the stored numbering wants them."""
+        return reorder_rows(x, self.orders, seq_ids, "vorder")
 
     def _vertex_major(self):
         """Vertex-major (n, vmax, frames*3) copy of self.xyz (n, frames, vmax, 3): the 42 frames a sample needs of one
@@ -345,6 +365,21 @@ class ClothSequences:
         return Batch(inputs, targets, mask, L, Di, DiA, B)
 
 
+def reorder_rows(x: torch.Tensor, orders, seq_ids, which: str) -> torch.Tensor:
+    """out[b, k] = x[b, table_b[k]] for k < V_b (table = MeshOrder.vrank: stored -> dataset order; .vorder: the inverse), rows
+    past a mesh's size unchanged.  One gather over the tensor; evaluation / export only — training never needs it."""
+    seq_ids = np.asarray(seq_ids)
+    if all(orders[int(s_)].identity for s_ in seq_ids):
+        return x
+    B, nv = x.shape[0], x.shape[1]
+    idx = np.tile(np.arange(nv, dtype=np.int64), (B, 1))
+    for b, s_ in enumerate(seq_ids):
+        t = getattr(orders[int(s_)], which)
+        idx[b, : t.size] = t
+    idx_d = h2d_async(idx, x.device)
+    return torch.gather(x, 1, idx_d[:, :, None].expand(-1, -1, x.shape[2]))
+
+
 def forward_loss(model, batch: Batch, global_batch: Optional[int] = None):
     if batch.Di is not None:
         out = model(batch.Di, batch.DiA, batch.mask, batch.inputs)
@@ -358,8 +393,14 @@ class GraphedTrainStep:
     all-reduce and the optimizer stay eager.  `example` fixes the batch signature (and becomes the static batch)."""
 
     def __init__(self, model, optimizer, example: Batch, global_batch: Optional[int] = None, bucket=None):
+        import dataclasses
+
         from .graphs import GraphedTrainStep as _G
 
+        # the example's tensors become the graph's static inputs and every load() overwrites them: the sampler's CACHED mask
+        # (ClothSequences._mask_of hands the same tensor out again when a selection recurs) must not be one of them
+        if isinstance(example.mask, torch.Tensor):
+            example = dataclasses.replace(example, mask=example.mask.clone())
         self._g = _G(model, optimizer, example, lambda m, b: forward_loss(m, b, global_batch)[0], bucket)
         self.step, self.optimizer = self._g.step, optimizer
 

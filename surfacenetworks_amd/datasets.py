@@ -35,9 +35,12 @@ def load_arap_sequence(path: str) -> List[Dict]:
     return list(seq)
 
 
-def arap_from_files(paths: Sequence[str], device="cuda", model="dir") -> "_arap.ClothSequences":
+def arap_from_files(paths: Sequence[str], device="cuda", model="dir", reorder="auto") -> "_arap.ClothSequences":
     """Build the resident ARAP dataset (frame coordinates + operator pools) from reference sequence files.
-    Returns an object with the ClothSequences interface (sample_batch, ...)."""
+    Returns an object with the ClothSequences interface (sample_batch, ...).
+    reorder ("auto" / True / False): the sequences are STORED in a locality numbering of their vertices and faces
+    (mesh_ops.MeshOrder; the files keep whatever order the scanner / simulator wrote): coordinates are permuted once, the
+    stored operators become P_r A P_c^T; `ds.to_dataset_order(outputs, seq_ids)` maps per-vertex results back."""
     seqs = [load_arap_sequence(p) for p in paths]
     ds = _arap.ClothSequences.__new__(_arap.ClothSequences)
     ds.device = torch.device(device)
@@ -47,19 +50,27 @@ def arap_from_files(paths: Sequence[str], device="cuda", model="dir") -> "_arap.
     ds.op_frames = min(sum(1 for fr in s if fr.get("Di" if model == "dir" else "L") is not None) for s in seqs)
     ds.num_vertices = np.array([s[0]["V"].shape[0] for s in seqs])
     ds.num_faces = np.array([s[0]["F"].shape[0] for s in seqs])
+    ds.orders = [mesh_ops.MeshOrder.of_mesh(np.asarray(s[0]["F"]), s[0]["V"].shape[0], reorder) for s in seqs]
     vmax = int(ds.num_vertices.max())
     xyz = np.zeros((ds.n, ds.frames, vmax, 3), np.float32)
     for i, s in enumerate(seqs):
         for t in range(ds.frames):
-            xyz[i, t, : s[t]["V"].shape[0]] = np.asarray(s[t]["V"], dtype=np.float32)
+            xyz[i, t, : s[t]["V"].shape[0]] = ds.orders[i].vertex_rows(np.asarray(s[t]["V"], dtype=np.float32))
     ds.xyz = torch.from_numpy(xyz).to(ds.device)
     ds.vcount = torch.from_numpy(ds.num_vertices).to(ds.device)
-    pick = lambda key: [s[t][key].astype(np.float32) for s in seqs for t in range(ds.op_frames)]
+
+    def pick(key, rows, cols, group):
+        out = []
+        for s, o in zip(seqs, ds.orders):
+            for t in range(ds.op_frames):
+                A = s[t][key].astype(np.float32)
+                out.append(A if o.identity else mesh_ops.permute_operator(A, getattr(o, rows), getattr(o, cols), group))
+        return out
     if model == "dir":
-        ds.pool_Di = OperatorPool(pick("Di"), ds.device, want_bsr4=True)
-        ds.pool_DiA = OperatorPool(pick("DiA"), ds.device, want_bsr4=True)
+        ds.pool_Di = OperatorPool(pick("Di", "forder", "vorder", 4), ds.device, want_bsr4=True)
+        ds.pool_DiA = OperatorPool(pick("DiA", "vorder", "forder", 4), ds.device, want_bsr4=True)
     else:
-        ds.pool_L = OperatorPool(pick("L"), ds.device)
+        ds.pool_L = OperatorPool(pick("L", "vorder", "vorder", 1), ds.device)
     return ds
 
 

@@ -47,14 +47,24 @@ class _RingChoices:
         _ring_choices = self.prev
 
 
+class _SignatureMismatch(Exception):
+    """A batch whose operators cannot take the kernels the capture froze (listing aborted: the batch does not match)."""
+
+
 def _ring_choice(o: SparseOperator) -> bool:
+    """The ring-vs-row-blocked choice used to LIST an operator's arrays.  The frozen choices live on the GraphedStep (the
+    `_RingChoices` context), never on the operator: an operator that was merely compared with, or loaded into, a capture keeps
+    dispatching by its own band when it is multiplied eagerly later."""
     if _ring_choices is not None and _ring_choices[0] == "apply":
-        o._ring_forced = next(_ring_choices[1])
-        return o._ring_forced
+        take = next(_ring_choices[1])
+        # the sliding-window kernel bounds a row by its first and last entry: an operator with non-ascending columns must
+        # never be loaded into a capture that multiplies with it (band()[1] == 0x7fffffff marks such rows)
+        if take and o.band()[1] == 0x7fffffff:
+            raise _SignatureMismatch()
+        return take
     take = bool(o.ring_ok(128) or o.ring_ok(64))
     if _ring_choices is not None:
         _ring_choices[1].append(take)
-        o._ring_forced = take
     return take
 
 
@@ -213,7 +223,7 @@ class GraphedStep:
         try:
             with _RingChoices("apply", self._ring):
                 return batch_signature(batch) == self.signature
-        except StopIteration:                              # more Laplacian-type operators than the example had
+        except (StopIteration, _SignatureMismatch):        # more Laplacian-type operators than the example had / unsorted rows
             return False
 
     def load(self, batch) -> None:
@@ -221,7 +231,7 @@ class GraphedStep:
         try:
             with _RingChoices("apply", self._ring):
                 src = batch_tensors(batch)
-        except StopIteration:
+        except (StopIteration, _SignatureMismatch):
             raise ValueError("batch does not match the captured signature; capture a new GraphedStep") from None
         if len(src) != len(self._static_tensors) or any(
                 s.shape != d.shape or s.dtype != d.dtype for s, d in zip(src, self._static_tensors)):

@@ -25,6 +25,7 @@ import scipy.sparse as sp
 __all__ = [
     "edge_lengths", "heron_areas", "cotangent_weights", "laplacian", "dirac", "mesh_operators",
     "grid_cloth", "torus_grid", "delaunay_disc", "read_ply_ascii",
+    "locality_order", "edge_span", "MeshOrder", "permute_operator",
 ]
 
 _PERMS = np.array([[0, 1, 2], [0, 2, 1], [1, 0, 2], [1, 2, 0], [2, 0, 1], [2, 1, 0]])  # itertools.permutations order
@@ -200,12 +201,105 @@ def delaunay_disc(num_vertices: int, rng: np.random.Generator):
 
 
 def _maybe_permute(V, F, rng, permute):
+    """permute=True / "vertices": a seeded random renumbering of the vertices (SURVEY.md §8d's "random-permuted variant"; the
+    face list keeps the generator's order); "both": the face list is shuffled as well (what a scanned mesh looks like)."""
     if not permute:
         return V, F
     perm = rng.permutation(V.shape[0])       # new index of old vertex i is inv[i]
     inv = np.empty_like(perm)
     inv[perm] = np.arange(perm.size)
-    return V[perm], inv[F]
+    V, F = V[perm], inv[F]
+    if permute == "both":
+        F = F[rng.permutation(F.shape[0])]
+    return V, F
+
+
+# --------------------------------------------------------------------------------------------------
+# locality order: datasets number their vertices arbitrarily (src/utils/mesh.py:35-64 builds every operator in the
+# dataset's own order; FAUST scans are loaded as stored, src/dense_correspondence/main.py:66-102)
+# --------------------------------------------------------------------------------------------------
+def edge_span(F: np.ndarray, rank=None):
+    """(mean, max) of |rank_i - rank_j| over the mesh edges: how far apart in memory the dense rows are that one operator row
+    touches.  A row-major n x m grid has (2(m+1)/3, m+1); a random numbering about (V/3, V)."""
+    F = np.asarray(F)
+    r = F if rank is None else np.asarray(rank)[F]
+    e = np.abs(np.concatenate([r[:, 0] - r[:, 1], r[:, 1] - r[:, 2], r[:, 2] - r[:, 0]]))
+    return (float(e.mean()), int(e.max())) if e.size else (0.0, 0)
+
+
+def locality_order(F: np.ndarray, num_vertices: int, num_faces_rows=None):
+    """(vorder, forder): a numbering of the vertices and faces of a mesh under which every operator of the path is banded.
+    vorder[k] = the dataset's index of the vertex stored at position k (reverse Cuthill-McKee on the vertex adjacency: the
+    band of a 2-D mesh becomes ~ the width of its breadth-first level sets, <= the row-major band of a grid); forder[k]
+    likewise for faces, sorted by the ranks of their corners (smallest first), so that face row ~ 2 x vertex row as in a
+    generated grid.  One-time host work per mesh (milliseconds at 20 000 vertices)."""
+    from scipy.sparse.csgraph import reverse_cuthill_mckee
+
+    F = np.asarray(F, dtype=np.int64)
+    nV = int(num_vertices)
+    i = np.concatenate([F[:, 0], F[:, 1], F[:, 2]])
+    j = np.concatenate([F[:, 1], F[:, 2], F[:, 0]])
+    A = sp.coo_matrix((np.ones(i.size, np.int8), (i, j)), shape=(nV, nV)).tocsr()
+    A = (A + A.T).tocsr()
+    vorder = np.asarray(reverse_cuthill_mckee(A, symmetric_mode=True), dtype=np.int64)
+    rank = np.empty(nV, np.int64)
+    rank[vorder] = np.arange(nV)
+    r = np.sort(rank[F], axis=1)
+    forder = np.lexsort((r[:, 2], r[:, 1], r[:, 0])).astype(np.int64)
+    return vorder, forder
+
+
+class MeshOrder:
+    """The stored numbering of one mesh: `vorder` / `forder` (stored position -> dataset index) and the inverse `vrank`
+    (dataset index -> stored position).  `identity` when the dataset's own numbering was kept."""
+
+    __slots__ = ("vorder", "forder", "vrank", "identity", "span_before", "span_after")
+
+    def __init__(self, vorder, forder, identity=False, span_before=None, span_after=None):
+        self.vorder, self.forder = np.asarray(vorder, np.int64), np.asarray(forder, np.int64)
+        self.vrank = np.empty_like(self.vorder)
+        self.vrank[self.vorder] = np.arange(self.vorder.size)
+        self.identity = bool(identity)
+        self.span_before, self.span_after = span_before, span_after
+
+    @classmethod
+    def of_mesh(cls, F, num_vertices: int, mode="auto", gain: float = 2.0) -> "MeshOrder":
+        """mode False / "off": keep the dataset's numbering; True / "rcm": always renumber; "auto" (default): renumber when
+        the mean edge span shrinks by more than `gain` x (a generated grid stays as it is, a scan or a permuted grid does
+        not)."""
+        F = np.asarray(F)
+        nV, nF = int(num_vertices), int(F.shape[0])
+        if mode in (False, None, "off"):
+            return cls(np.arange(nV), np.arange(nF), identity=True)
+        vorder, forder = locality_order(F, nV)
+        rank = np.empty(nV, np.int64)
+        rank[vorder] = np.arange(nV)
+        before, after = edge_span(F)[0], edge_span(F, rank)[0]
+        if mode == "auto" and before <= gain * after:
+            return cls(np.arange(nV), np.arange(nF), identity=True, span_before=before, span_after=before)
+        return cls(vorder, forder, span_before=before, span_after=after)
+
+    def mesh(self, V, F):
+        """(V, F) in the stored numbering; V may carry leading axes (frames): (..., nV, 3)."""
+        if self.identity:
+            return V, F
+        return np.asarray(V)[..., self.vorder, :], self.vrank[np.asarray(F)[self.forder]]
+
+    def vertex_rows(self, x):
+        """Per-vertex data (nV, ...) from the dataset's numbering into the stored one."""
+        return x if self.identity else np.asarray(x)[self.vorder]
+
+
+def permute_operator(A, row_order, col_order, group: int = 1):
+    """P_r A P_c^T for a stored operator (the reference's dataset files hold L, Di, DiA per frame): row k of the result is row
+    row_order[k] of A, likewise columns; group = 4 for the quaternion operators (blocks of 4 rows / columns move together)."""
+    def expand(o):
+        o = np.asarray(o, np.int64)
+        return o if group == 1 else (group * o[:, None] + np.arange(group)[None, :]).ravel()
+    A = A.tocsr()
+    out = A[expand(row_order)][:, expand(col_order)].tocsr()
+    out.sort_indices()
+    return out
 
 
 def read_ply_ascii(path: str):

@@ -75,7 +75,6 @@ class SparseOperator:
         self._q3 = q3                            # (b_rowptr, q_blk) quaternion-packed form | None (unknown) | False (not a Dirac-type operator)
         self._rb4 = None                         # (b_ptr, b_col, b_val) 4x1 row-blocked form | None (not built) | False (not worthwhile)
         self._band = None                        # (max |column - row|, longest row, rows outside the ring window) | None (not measured)
-        self._ring_forced = None                 # True / False: the ring-vs-gather choice frozen by a graph capture (graphs.py)
 
     @property
     def _t(self) -> "Optional[SparseOperator]":
@@ -276,11 +275,6 @@ class SparseOperator:
         M, K = self._shape
         if not kernels.spmm_ring_supported(N, 1, M, K):
             return False
-        if self._ring_forced is not None:
-            # frozen by a graph capture (graphs.GraphedStep): the choice is a property of the batch's VALUES, and a replayed
-            # batch must take the captured kernel whatever its own band is (the ring kernel is correct for any band with
-            # ascending columns — entries outside its window gather from global memory; frozen choices come from ring_ok itself)
-            return self._ring_forced
         if self._band is None and self.is_cuda and torch.cuda.is_current_stream_capturing():
             return False                                   # measuring the band reads back to the host: never inside a capture
         band, longest, outside = self.band()

@@ -192,3 +192,42 @@ def test_the_arap_step_issues_no_library_matrix_product(kind):
     assert not names & {"aten::mm", "aten::bmm", "aten::addmm", "aten::matmul", "aten::baddbmm", "aten::linear"}, sorted(
         n for n in names if "mm" in n or "linear" in n or "matmul" in n)
     assert torch.isfinite(loss).item()
+
+
+def test_the_samplers_cached_mask_is_never_a_graph_buffer():
+    """ClothSequences keeps the masks of its last selections and hands the same tensor out when a selection recurs; the
+    example batch of a capture must not make that tensor a static graph input (every load() would overwrite it, and the next
+    batch of the example's selection would carry the previous batch's mask).  Ragged meshes, the example's selection coming
+    back after another one: the replay equals an eager step on an INDEPENDENTLY built mask."""
+    from surfacenetworks_amd import arap
+
+    torch.manual_seed(8)
+    grids = [(9, 8), (7, 6), (8, 8)]
+    ds = arap.ClothSequences(grids, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 3, op_frames=3, seed=13, device=DEV,
+                             model="dir")
+    model_e = arap.DirModel().to(DEV).train()
+    model_g = copy.deepcopy(model_e)
+    opt_e, opt_g = arap.make_optimizer(model_e), arap.make_optimizer(model_g)
+    offs = np.zeros(3, dtype=np.int64)
+    first = np.array([0, 1, 2])
+    example = ds.sample_batch(3, None, seq_ids=first, offsets=offs)
+    cached = example.mask
+    graphed = arap.GraphedTrainStep(model_g, opt_g, example, global_batch=3)
+    assert graphed._g.step.static.mask is not cached
+    nv = int(ds.num_vertices.max())
+
+    def fresh_mask(ids):
+        cnt = torch.from_numpy(ds.num_vertices[ids]).to(DEV)
+        return (torch.arange(nv, device=DEV)[None, :] < cnt[:, None]).float().unsqueeze(2)
+
+    for ids in ([2, 0, 1], [0, 1, 2], [1, 2, 0], [0, 1, 2]):
+        ids = np.array(ids)
+        bg = ds.sample_batch(3, None, seq_ids=ids, offsets=offs)
+        assert torch.equal(bg.mask, fresh_mask(ids)), f"the sampler handed out a stale mask for {ids}"
+        be = ds.sample_batch(3, None, seq_ids=ids, offsets=offs)
+        be.mask = fresh_mask(ids)
+        le = arap.train_step(model_e, opt_e, be, global_batch=3)
+        lg = graphed(bg)
+        assert torch.equal(le.detach(), lg.detach()), f"loss differs for selection {ids}"
+        for (name, pe), pg in zip(model_e.named_parameters(), model_g.parameters()):
+            assert torch.equal(pe.detach(), pg.detach()), f"{name} differs after selection {ids}"
