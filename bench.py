@@ -342,6 +342,16 @@ def c3_order_secondary(device, meshes: int = MESHES_PER_GPU, steps: int = 10, wa
     return out
 
 
+def c3_swap_secondary(device, steps: int = 10):
+    """Config 3 behind the reference's OWN names (north_star: the training scripts "run unmodified apart from an import swap"):
+    tools/train_bench.py arap_swap — per step sp_sparse_to_pt_sparse per sample, sparse_diag_cat, .cuda(), the reference's model
+    calling sequence and loss — next to the headline, which uses the product's own sampler (ClothSequences / OperatorPool)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import train_bench
+
+    return train_bench.arap_swap(str(device), steps, MESHES_PER_GPU)
+
+
 def _timed_steps(step, steps, warm):
     for _ in range(warm):
         step()
@@ -959,7 +969,8 @@ def main():
                 raise                               # (a rank that left the collectives would hang the others)
         if rank == 0 and world == 1:
             # the small-batch configurations, driver-visible (rank 0 of a one-GPU run only: they are replicas, not a sharded job)
-            for key, fn in (("config3_order", c3_order_secondary), ("config2", c2_secondary), ("config4_pair", c4_pair_secondary)):
+            for key, fn in (("config3_order", c3_order_secondary), ("config3_swap", c3_swap_secondary), ("config2", c2_secondary),
+                            ("config4_pair", c4_pair_secondary)):
                 torch.cuda.empty_cache()
                 try:
                     sec[key] = fn(device)

@@ -514,10 +514,13 @@ class OperatorPool:
     transpose attached, so neither forward nor backward ever sorts, transposes or touches the host.
     """
 
-    def __init__(self, mats: Sequence, device="cuda", want_bsr4: bool = False):
+    def __init__(self, mats: Sequence, device="cuda", want_bsr4: bool = False, lean: bool = False):
+        """lean=True: keep only the arrays batches are assembled from — for pools of Dirac operators that turn out to be
+        quaternion-packed, the pooled CSR and BSR4 device arrays are dropped (the CSR entry counts stay on the host)."""
         self.device = torch.device(device)
         self.n = len(mats)
         self.want_bsr4 = bool(want_bsr4)
+        self.lean = bool(lean)
         fwd = [m.tocsr() for m in mats]
         for m in fwd:
             m.sort_indices()
@@ -540,6 +543,86 @@ class OperatorPool:
             if int(ff.item()) == 0 and int(bf.item()) == 0:
                 self._fwd_q = dict(self._fwd_b, vals=fq.reshape(-1), colind=None)
                 self._bwd_q = dict(self._bwd_b, vals=bq.reshape(-1), colind=None)
+            if self.lean and self._fwd_q is not None:
+                self._fwd_b = self._bwd_b = None
+                for pool in (self._fwd, self._bwd):
+                    pool["rowptr"] = pool["colind"] = pool["vals"] = None
+
+    # ---- growing pools (utils_pt's resident cache appends the operators a driver shows it for the first time) -----------
+    @staticmethod
+    def _arena_append(buf, used: int, new):
+        """`new` copied behind the first `used` elements of `buf`; the buffer doubles when it is full (offsets into it stay
+        valid: the assembly kernels address pooled arrays by element offsets, never by their length)."""
+        need = used + int(new.numel())
+        if buf is None or need > buf.numel():
+            cap = max(need, 2 * (int(buf.numel()) if buf is not None else 0), 1 << 16)
+            grown = torch.empty(cap, dtype=new.dtype, device=new.device)
+            if used:
+                grown[:used].copy_(buf[:used])
+            buf = grown
+        buf[used:need].copy_(new.reshape(-1))
+        return buf
+
+    @classmethod
+    def _merge(cls, dst, src, vpe: int):
+        if src is None or dst is None:
+            return None
+        used_rp, used_e = int(dst["rp_off"][-1]), int(dst["e_off"][-1])
+        for key, used, n_src in (("rowptr", used_rp, int(src["rp_off"][-1])), ("colind", used_e, int(src["e_off"][-1])),
+                                 ("vals", used_e * vpe, int(src["e_off"][-1]) * vpe)):
+            if dst[key] is not None and src[key] is not None:
+                dst[key] = cls._arena_append(dst[key], used, src[key][:n_src])
+        dst["rp_off"] = np.concatenate([dst["rp_off"], used_rp + src["rp_off"][1:]])
+        dst["e_off"] = np.concatenate([dst["e_off"], used_e + src["e_off"][1:]])
+        dst["cnt"] = np.diff(dst["e_off"])
+        return dst
+
+    def append(self, mats: Sequence) -> np.ndarray:
+        """Add operators to the pool (converted like the constructor's: one-time host transpose, device BSR4 / quaternion
+        packing); returns their indices for assemble().  A pool that was quaternion-packed stays so only while every added
+        operator is — the caller (utils_pt's resident cache) keeps such operators in a pool of their own."""
+        if not len(mats):
+            return np.zeros(0, dtype=np.int64)
+        return self.absorb(OperatorPool(mats, self.device, self.want_bsr4, self.lean))
+
+    def absorb(self, chunk: "OperatorPool") -> np.ndarray:
+        """Merge another pool of the same kind into this one (its arrays are copied behind this pool's); returns the indices
+        its operators now have here."""
+        if chunk.want_bsr4 != self.want_bsr4 or chunk.device != self.device:
+            raise ValueError("OperatorPool.absorb: pools of different kinds")
+        if (chunk._fwd_q is None) != (self._fwd_q is None) or (chunk._fwd_b is None) != (self._fwd_b is None):
+            raise ValueError("OperatorPool.append: the new operators do not pack the way this pool's do")
+        first = self.n
+        self._fwd = self._merge(self._fwd, chunk._fwd, 1)
+        self._bwd = self._merge(self._bwd, chunk._bwd, 1)
+        fwd_rowptr_shared = self._fwd_q is not None and self._fwd_b is not None
+        self._fwd_b = self._merge(self._fwd_b, chunk._fwd_b, 16)
+        self._bwd_b = self._merge(self._bwd_b, chunk._bwd_b, 16)
+        if fwd_rowptr_shared:                                 # (the quaternion dicts share block-row pointers and offsets)
+            for q, b, cq in ((self._fwd_q, self._fwd_b, chunk._fwd_q), (self._bwd_q, self._bwd_b, chunk._bwd_q)):
+                used = int(q["e_off"][-1])
+                q["vals"] = self._arena_append(q["vals"], used * 4, cq["vals"][: int(cq["e_off"][-1]) * 4])
+                q["rowptr"], q["rp_off"], q["e_off"], q["cnt"] = b["rowptr"], b["rp_off"], b["e_off"], b["cnt"]
+        else:
+            self._fwd_q = self._merge(self._fwd_q, chunk._fwd_q, 4)
+            self._bwd_q = self._merge(self._bwd_q, chunk._bwd_q, 4)
+        self.rows = np.concatenate([self.rows, chunk.rows])
+        self.cols = np.concatenate([self.cols, chunk.cols])
+        self._band_fwd = np.concatenate([self._band_fwd, chunk._band_fwd])
+        self._band_bwd = np.concatenate([self._band_bwd, chunk._band_bwd])
+        self.n += chunk.n
+        return np.arange(first, self.n, dtype=np.int64)
+
+    def device_bytes(self) -> int:
+        tot = 0
+        seen = set()
+        for pool in (self._fwd, self._bwd, self._fwd_b, self._bwd_b, self._fwd_q, self._bwd_q):
+            for key in ("rowptr", "colind", "vals"):
+                t = pool[key] if pool is not None else None
+                if t is not None and t.data_ptr() not in seen:
+                    seen.add(t.data_ptr())
+                    tot += t.numel() * t.element_size()
+        return tot
 
     @staticmethod
     def _mesh_band(m):
@@ -628,7 +711,7 @@ class OperatorPool:
         if self.want_bsr4:
             if (rows % 4).any() or (cols % 4).any():
                 raise ValueError("BSR4 pools need every mesh's sizes to be multiples of 4")
-            if self._fwd_q is not None and _POOL_FORMAT == "q3":
+            if self._fwd_q is not None and (_POOL_FORMAT == "q3" or self._fwd_b is None):
                 fr, _, fq = self._concat_ragged(self._fwd_q, sel, rows // 4, ro // 4, co // 4, 4)
                 br_, _, bq = self._concat_ragged(self._bwd_q, sel, cols // 4, co // 4, ro // 4, 4)
                 op = SparseOperator.from_q3((fr, fq.view(-1, 4)), (br_, bq.view(-1, 4)), shape, batch=B)
@@ -665,7 +748,7 @@ class OperatorPool:
             # view of the batch is expanded from the blocks on demand (export / generic-kernel fallback).
             if size0 % 4 or size1 % 4:
                 raise ValueError("BSR4 pools need size0 and size1 to be multiples of 4")
-            if self._fwd_q is not None and _POOL_FORMAT == "q3":
+            if self._fwd_q is not None and (_POOL_FORMAT == "q3" or self._fwd_b is None):
                 fr, _, fq = self._concat(self._fwd_q, sel, rows // 4, size0 // 4, size1 // 4, 4)
                 br_, _, bq = self._concat(self._bwd_q, sel, cols // 4, size1 // 4, size0 // 4, 4)
                 op = SparseOperator.from_q3((fr, fq.view(-1, 4)), (br_, bq.view(-1, 4)), (B * size0, B * size1), batch=B)

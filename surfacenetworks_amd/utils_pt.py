@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from . import blocks as snB
 from . import functional as snF
 from .operators import PackedSegments, SparseOperator, as_operator
+from .resident import LazySparse, batch_operator, reference_cat, reference_diag_cat
 
 __all__ = [
     "sparse_cat", "sparse_diag_cat", "sp_sparse_to_pt_sparse", "to_dense_batched", "GraphConv1x1",
@@ -36,28 +37,33 @@ __all__ = [
 # host-side operator batching with the reference's return types (torch sparse COO, coalesced)
 # --------------------------------------------------------------------------------------------------
 def sp_sparse_to_pt_sparse(L):
-    """scipy sparse matrix -> torch sparse COO (uncoalesced, dtype kept), as utils_pt.py:56-69."""
-    coo = L.tocoo()
-    index = torch.from_numpy(np.stack([coo.row, coo.col]).astype(np.int64))
-    return torch.sparse_coo_tensor(index, torch.from_numpy(coo.data), torch.Size(coo.shape))
+    """scipy sparse matrix -> torch sparse COO (uncoalesced, dtype kept), as utils_pt.py:56-69 — returned as a `LazySparse`
+    handle of the scipy matrix (resident.py): the index arrays are built only if something reads them; sparse_diag_cat /
+    sparse_cat assemble batches of such handles on the device from resident copies."""
+    return LazySparse.of_scipy(L)
 
 
 def sparse_diag_cat(tensors, size0, size1):
     """Block-diagonal (len*size0, len*size1) operator from per-mesh COO operators, as utils_pt.py:41-53.
-    (The fast path never calls this per step: see operators.OperatorPool.assemble.)"""
-    shift = torch.tensor([[size0], [size1]], dtype=torch.int64)
-    index = torch.cat([t._indices() + i * shift for i, t in enumerate(tensors)], dim=1)
-    values = torch.cat([t._values() for t in tensors], dim=0)
-    n = len(tensors)
-    return torch.sparse_coo_tensor(index, values, torch.Size((n * size0, n * size1))).coalesce()
+    Members that are handles of scipy matrices (what sp_sparse_to_pt_sparse returns) are batched ON THE DEVICE from their
+    resident copies when a GPU is present (one offset-concatenation launch, no host sort, no index upload): the result is a
+    `LazySparse` that stands for the reference's coalesced CPU tensor, whose `.cuda()` carries the assembled operator to the
+    residual blocks.  Any other member list takes the reference's host path."""
+    if len(tensors) and all(isinstance(t, LazySparse) for t in tensors):
+        op = batch_operator(tensors, size0, size1)
+        if op is not None:
+            return LazySparse.of_batch("diag", tensors, size0, size1, op)
+    return reference_diag_cat([t.materialize() if isinstance(t, LazySparse) else t for t in tensors], size0, size1)
 
 
 def sparse_cat(tensors, size0, size1):
-    """3-D batched (len, size0, size1) COO operator, as utils_pt.py:21-39."""
-    index = torch.cat([torch.cat([torch.full((1, t._nnz()), i, dtype=torch.int64), t._indices()], dim=0)
-                       for i, t in enumerate(tensors)], dim=1)
-    values = torch.cat([t._values() for t in tensors], dim=0)
-    return torch.sparse_coo_tensor(index, values, torch.Size((len(tensors), size0, size1))).coalesce()
+    """3-D batched (len, size0, size1) COO operator, as utils_pt.py:21-39 (same resident path as sparse_diag_cat: the batch
+    operator the blocks multiply with is the block-diagonal one either way)."""
+    if len(tensors) and all(isinstance(t, LazySparse) for t in tensors):
+        op = batch_operator(tensors, size0, size1)
+        if op is not None:
+            return LazySparse.of_batch("cat", tensors, size0, size1, op)
+    return reference_cat([t.materialize() if isinstance(t, LazySparse) else t for t in tensors], size0, size1)
 
 
 def to_dense_batched(x, batch_size):

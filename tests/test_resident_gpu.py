@@ -1,0 +1,185 @@
+"""The fast path behind the reference's batching names (utils_pt.sp_sparse_to_pt_sparse / sparse_diag_cat / sparse_cat,
+src/utils/utils_pt.py:21-69; callers src/as_rigid_as_possible/main.py:156-185, src/mesh_mnist/main.py:100-117,
+src/dense_correspondence/main.py:180-190): batches assembled on the device from resident copies equal the reference's
+host-built coalesced tensors, the residual blocks give the same results on either, and everything the reference's API
+promises of the returned tensors still holds (they materialise on demand)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _meshes(rng, grids, permute=False):
+    from surfacenetworks_amd import mesh_ops as mo
+
+    out = []
+    for n, m in grids:
+        V, F = mo.grid_cloth(n, m, rng, permute=permute)
+        ops = mo.mesh_operators(V, F)
+        out.append((V.astype(np.float32), F, ops))
+    return out
+
+
+def _dense(t):
+    return t.to_dense().cpu().numpy()
+
+
+@pytest.mark.parametrize("which,group", [("Di", 4), ("DiA", 4), ("L", 1)])
+def test_diag_cat_of_handles_is_the_references_tensor(which, group):
+    import surfacenetworks_amd.utils_pt as U
+    from surfacenetworks_amd.operators import SparseOperator, as_operator
+    from surfacenetworks_amd.resident import LazySparse, reference_diag_cat, reference_sp_to_coo, resident_cache
+
+    rng = np.random.default_rng(1)
+    ms = _meshes(rng, [(7, 6), (9, 8), (5, 5)])
+    mats = [m[2][which] for m in ms]
+    s0 = max(a.shape[0] for a in mats) + 4 * (group == 4)
+    s1 = max(a.shape[1] for a in mats)
+    sel = [2, 0, 1, 0]                                                 # a mesh twice in one batch
+    want = reference_diag_cat([reference_sp_to_coo(mats[i]) for i in sel], s0, s1)
+    handles = [U.sp_sparse_to_pt_sparse(mats[i]) for i in sel]
+    assert all(isinstance(h, LazySparse) and h.device.type == "cpu" and not h.is_coalesced() for h in handles)
+    cache = resident_cache()
+    m0 = cache.misses
+    got = U.sparse_diag_cat(handles, s0, s1)
+    assert isinstance(got, LazySparse) and got.device.type == "cpu" and got.is_coalesced() and got.coalesce() is got
+    assert tuple(got.shape) == tuple(want.shape) and got.dtype == want.dtype and got.layout == torch.sparse_coo
+    assert cache.misses - m0 <= 3
+    g = got.cuda()
+    assert g.is_cuda and g.cuda() is g and isinstance(g._sn_operator, SparseOperator)
+    op = as_operator(g)
+    assert op is g._sn_operator and op.shape == want.shape and op.batch == len(sel)
+    A = op.to_scipy()
+    W = want.to_dense().numpy()
+    assert np.array_equal(np.asarray(A.todense()), W)                   # the device-assembled batch IS the reference's operator
+    # a second step over the same dataset objects: cache hits only, no conversion
+    m1, h1 = cache.misses, cache.hits
+    U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(mats[i]) for i in sel], s0, s1)
+    assert cache.misses == m1 and cache.hits == h1 + len(sel)
+    # anything else reads the real tensor, built as the reference builds it
+    assert np.array_equal(_dense(got), W) and np.array_equal(_dense(g), W)
+    assert torch.equal(got._indices(), want._indices()) and torch.equal(got._values(), want._values())
+    assert got._nnz() == want._nnz()
+    x = torch.randn(want.shape[1], 8)
+    assert torch.equal(torch.mm(got, x), torch.mm(want, x))
+    # transposed product through the operator (what the blocks' backward uses)
+    N = 32 if group == 4 else 128
+    xd = torch.randn(op.shape[1] // group, group * N, device=DEV, requires_grad=True)
+    from surfacenetworks_amd import functional as snF
+
+    y = snF.spmm(op, xd, group=group)
+    ref_op = SparseOperator.from_torch_coo(want.to(DEV))
+    xr = xd.detach().clone().requires_grad_(True)
+    yr = snF.spmm(ref_op, xr, group=group)
+    assert torch.equal(y, yr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    yr.backward(gy)
+    assert torch.equal(xd.grad, xr.grad)
+
+
+def test_sparse_cat_handles_and_variable():
+    """The Mesh-MNIST driver converts its dataset at load (main.py:58-72), batches with sparse_cat and wraps in Variable()."""
+    import surfacenetworks_amd.utils_pt as U
+    from torch.autograd import Variable
+
+    from surfacenetworks_amd.operators import as_operator
+    from surfacenetworks_amd.resident import LazySparse, reference_cat, reference_sp_to_coo
+
+    rng = np.random.default_rng(2)
+    ms = _meshes(rng, [(6, 6), (7, 5)])
+    for which, group in (("L", 1), ("Di", 4)):
+        mats = [m[2][which] for m in ms]
+        s0 = max(a.shape[0] for a in mats)
+        s1 = max(a.shape[1] for a in mats)
+        handles = [U.sp_sparse_to_pt_sparse(a) for a in mats]          # kept in the dataset, as convert() does
+        got = Variable(U.sparse_cat(handles, s0, s1)).cuda()
+        want = reference_cat([reference_sp_to_coo(a) for a in mats], s0, s1)
+        assert isinstance(got, LazySparse) and got.dim() == 3 and tuple(got.size()) == tuple(want.size())
+        op = as_operator(got)
+        assert op.batch == 2 and op.shape == (2 * s0, 2 * s1)
+        D = np.asarray(op.to_scipy().todense())
+        Wd = want.to_dense().numpy()
+        for b in range(2):
+            assert np.array_equal(D[b * s0:(b + 1) * s0, b * s1:(b + 1) * s1], Wd[b])
+        assert np.array_equal(_dense(got), Wd)
+
+
+def test_blocks_agree_on_resident_and_host_built_batches():
+    """One Dirac block + one Laplacian block, forward and backward: the batch from the resident path against the same batch
+    built by the reference's host arithmetic (what the package did before: real COO tensors converted on the device)."""
+    import surfacenetworks_amd.utils_pt as U
+    from surfacenetworks_amd.resident import reference_diag_cat, reference_sp_to_coo
+
+    rng = np.random.default_rng(3)
+    ms = _meshes(rng, [(9, 7), (8, 8), (6, 10)], permute=True)
+    nv = max(m[0].shape[0] for m in ms)
+    nf = max(m[1].shape[0] for m in ms)
+    B, C = len(ms), 128
+    torch.manual_seed(0)
+    v0 = torch.randn(B, nv, C, device=DEV)
+    f0 = torch.randn(B, nf, C, device=DEV)
+
+    def run(resident: bool):
+        torch.manual_seed(1)
+        dblk, lblk = U.DirResNet2(C).to(DEV).train(), U.LapResNet2(C).to(DEV).train()
+        if resident:
+            mk = lambda key, a, b: U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(m[2][key]) for m in ms], a, b).cuda()
+        else:
+            mk = lambda key, a, b: reference_diag_cat([reference_sp_to_coo(m[2][key]) for m in ms], a, b).to(DEV)
+        Di, DiA, L = mk("Di", 4 * nf, 4 * nv), mk("DiA", 4 * nv, 4 * nf), mk("L", nv, nv)
+        v = v0.clone().requires_grad_(True)
+        f = f0.clone().requires_grad_(True)
+        vo, fo = dblk(Di, DiA, v, f)
+        xo = lblk(L, None, vo)
+        (xo.square().mean() + fo.square().mean()).backward()
+        grads = [p.grad.clone() for p in list(dblk.parameters()) + list(lblk.parameters())]
+        return xo.detach(), fo.detach(), v.grad.clone(), f.grad.clone(), grads
+
+    a, b = run(True), run(False)
+    for x, y in zip(a[:4], b[:4]):
+        assert torch.equal(x, y)
+    for x, y in zip(a[4], b[4]):
+        assert torch.equal(x, y)
+
+
+def test_members_that_cannot_be_resident_take_the_host_path():
+    import scipy.sparse as sp
+
+    import surfacenetworks_amd.utils_pt as U
+    from surfacenetworks_amd.resident import LazySparse, reference_diag_cat, reference_sp_to_coo
+
+    rng = np.random.default_rng(4)
+    A64 = sp.random(12, 10, density=0.3, format="csr", dtype=np.float64, random_state=1)
+    A32 = sp.random(12, 10, density=0.3, format="coo", dtype=np.float32, random_state=2)      # not CSR: converted, still resident
+    h64, h32 = U.sp_sparse_to_pt_sparse(A64), U.sp_sparse_to_pt_sparse(A32)
+    assert h64.dtype == torch.float64 and h32.dtype == torch.float32
+    out = U.sparse_diag_cat([h64, h64], 12, 10)                        # float64: the reference's host path, a real tensor
+    assert not isinstance(out, LazySparse)
+    assert torch.equal(out.to_dense(), reference_diag_cat([reference_sp_to_coo(A64)] * 2, 12, 10).to_dense())
+    out32 = U.sparse_diag_cat([h32, h32], 12, 10)
+    assert isinstance(out32, LazySparse)
+    assert np.array_equal(np.asarray(out32.cuda()._sn_operator.to_scipy().todense()),
+                          reference_diag_cat([reference_sp_to_coo(A32)] * 2, 12, 10).to_dense().numpy())
+    real = reference_sp_to_coo(A32.tocsr())
+    mixed = U.sparse_diag_cat([h32, real], 12, 10)                     # a real tensor among the members: host path
+    assert not isinstance(mixed, LazySparse)
+    # a Dirac operator and a Laplacian in one list (different packings): host path, same result
+    ms = _meshes(rng, [(5, 5)])
+    hs = [U.sp_sparse_to_pt_sparse(ms[0][2]["Di"]), U.sp_sparse_to_pt_sparse(sp.random(64, 100, 0.1, "csr", np.float32, random_state=3))]
+    odd = U.sparse_diag_cat(hs, 64, 100)
+    assert not isinstance(odd, LazySparse) and odd.shape == (128, 200)
+
+
+def test_in_place_replacement_of_a_dataset_matrix_is_noticed():
+    import surfacenetworks_amd.utils_pt as U
+
+    rng = np.random.default_rng(6)
+    ms = _meshes(rng, [(6, 6)])
+    L = ms[0][2]["L"].copy()
+    a = U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(L)], L.shape[0], L.shape[1]).cuda()._sn_operator.to_scipy()
+    L.data = L.data * 2                                                # new array object: noticed (an in-place `*=` would not be)
+    b = U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(L)], L.shape[0], L.shape[1]).cuda()._sn_operator.to_scipy()
+    assert np.array_equal(b.data, 2 * a.data)

@@ -2,9 +2,11 @@
    python tools/train_bench.py mnist_dir|mnist_lap|faust_lap|arap_lap|arap_ragged|arap_swap [steps]
 mnist_dir = config 2 (Mesh-MNIST Dirac, batch 512); mnist_lap = config 1 shape on the GPU; faust_lap = config 4 per-GPU
 work (one pair of 6890-vertex bodies padded to 7000); arap_lap = the Laplacian variant of config 3; arap_swap = config 3
-as an UNMODIFIED reference driver runs it after the import swap: per step and per sample sp_sparse_to_pt_sparse on the host,
-sparse_diag_cat (+ coalesce) on the host, .cuda(), and the conversion of the COO batch operators inside the blocks
-(src/as_rigid_as_possible/main.py:156-185) — against the resident OperatorPool of bench.py."""
+as an UNMODIFIED reference driver runs it after the import swap: per step and per sample sp_sparse_to_pt_sparse,
+sparse_diag_cat, .cuda() of operators / inputs / targets, the reference's model calling sequence and loss
+(src/as_rigid_as_possible/main.py:156-232) — served from the resident cache behind those names (surfacenetworks_amd/resident.py);
+SN_RESIDENT=0 runs the reference's host arithmetic instead (use SN_SWAP_MESHES=8: 3 s per step at 64);
+SN_SWAP_MODEL=product puts the product's own DirModel on the same batches."""
 import os
 import sys
 import time
@@ -25,6 +27,83 @@ def timed(step, steps, warm=3):
         step()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps
+
+
+def arap_swap(dev="cuda", steps=10, B=64):
+    """BASELINE configs[2] through the reference's own batching names (module docstring: arap_swap)."""
+    import torch.nn as nn
+    import torch.nn.functional as F
+
+    import surfacenetworks_amd.utils_pt as utils
+    from surfacenetworks_amd import mesh_ops
+    from surfacenetworks_amd.resident import resident_cache
+
+    class RefStyleDirModel(nn.Module):
+        """The calling sequence of the reference's DirModel (src/as_rigid_as_possible/models.py:108-152) on the swapped
+        `utils`: zero face features as a tensor, every block with the reference's four arguments, conv2(F.elu(v)), the
+        repeated last frame — none of the product's own hints (f=None, f_out_needed, avg_next, elu_conv1x1)."""
+
+        def __init__(self):
+            super().__init__()
+            self.conv1 = utils.GraphConv1x1(6, 128, batch_norm=None)
+            for i in range(15):
+                self.add_module("rn{}".format(i), utils.DirResNet2(128) if i % 2 == 0 else utils.AvgResNet2(128))
+            self.do = nn.Dropout2d()
+            self.conv2 = utils.GraphConv1x1(128, 120, batch_norm="pre")
+
+        def forward(self, Di, DiA, mask, inputs):
+            batch_size, num_nodes, _ = inputs.size()
+            v = self.conv1(inputs)
+            num_faces = DiA.size(2) // 4 if len(Di.size()) == 3 else DiA.size(1) // 4 // batch_size
+            f = torch.zeros(batch_size, num_faces, 128, device=v.device)
+            for i in range(15):
+                if i % 2 == 0:
+                    v, f = self._modules["rn{}".format(i)](Di, DiA, v, f)
+                else:
+                    v = self._modules["rn{}".format(i)](None, mask, v)
+            x = self.conv2(F.elu(v))
+            return x + inputs[:, :, -3:].repeat(1, 1, 40)
+
+    grid_rng = np.random.default_rng(3)
+    samples = []
+    for _ in range(B):                                          # the dataset as the reference keeps it: scipy operators per frame
+        V, F_ = mesh_ops.grid_cloth(71, 71, grid_rng)
+        Di, DiA = mesh_ops.dirac(V, F_)
+        samples.append((V.astype(np.float32), Di.astype(np.float32), DiA.astype(np.float32), F_.shape[0]))
+    nv, nf = samples[0][0].shape[0], samples[0][3]
+    model = (arap.DirModel() if os.environ.get("SN_SWAP_MODEL", "ref") == "product" else RefStyleDirModel()).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), 1e-3, weight_decay=1e-5)                    # main.py:207
+    inputs = torch.from_numpy(np.stack([np.concatenate([s_[0], s_[0]], 1) for s_ in samples]))
+    targets = torch.zeros(B, nv, 120)
+    mask = torch.ones(B, nv, 1)
+    t_host, t_h2d = [], []
+
+    def step():
+        t0 = time.perf_counter()
+        Di = utils.sparse_diag_cat([utils.sp_sparse_to_pt_sparse(s_[1]) for s_ in samples], 4 * nf, 4 * nv)     # main.py:161-181
+        DiA = utils.sparse_diag_cat([utils.sp_sparse_to_pt_sparse(s_[2]) for s_ in samples], 4 * nv, 4 * nf)
+        t1 = time.perf_counter()
+        Di, DiA, x, y, m = Di.cuda(), DiA.cuda(), inputs.cuda(), targets.cuda(), mask.cuda()                 # main.py:184
+        t2 = time.perf_counter()
+        t_host.append(t1 - t0), t_h2d.append(t2 - t1)
+        outputs = model(Di, DiA, m, x)                                                                         # main.py:222-232
+        outputs = outputs * m.expand_as(outputs)
+        loss = F.smooth_l1_loss(outputs, y, reduction="sum") / B
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    dt = timed(step, steps, warm=2)
+    k = len(t_host) - steps
+    c = resident_cache()
+    return {"workload": f"config 3 as an UNMODIFIED reference driver runs it after the import swap: per step {2 * B} x sp_sparse_to_pt_sparse, "
+                        "2 x sparse_diag_cat, .cuda() of operators / inputs / targets / mask (host tensors, pageable), the reference's "
+                        "DirModel calling sequence, mask multiply + smooth_l1_loss + Adam (src/as_rigid_as_possible/main.py:156-232)",
+            "meshes": B, "model": type(model).__name__, "resident": os.environ.get("SN_RESIDENT", "1") != "0",
+            "steps": steps, "ms_per_step": dt * 1e3, "meshes_per_s": B / dt,
+            "host_batching_calls_ms": float(np.mean(t_host[k:]) * 1e3), "driver_cuda_calls_host_ms": float(np.mean(t_h2d[k:]) * 1e3),
+            "pageable_MB_per_step": (inputs.numel() + targets.numel() + mask.numel()) * 4 / 1e6,
+            "resident_cache": None if c is None else {"hits": c.hits, "misses": c.misses,
+                                                      "MB_in_HBM": sum(p_.device_bytes() for p_ in c.pools.values()) / 1e6}}
 
 
 def main():
@@ -106,48 +185,11 @@ def main():
             print(f"{what}: 64 ragged meshes (sum V = {int(ds.num_vertices.sum())}, max V = {int(ds.num_vertices.max())}), "
                   f"{'packed' if packed else 'padded'}: {rows} vertex rows, {dt * 1e3:.2f} ms/step, {64 / dt:.0f} meshes/s")
     elif what == "arap_swap":
-        import surfacenetworks_amd.utils_pt as utils
-        from surfacenetworks_amd import mesh_ops
-        from surfacenetworks_amd.operators import as_operator
-
-        B = int(os.environ.get("SN_SWAP_MESHES", "64"))
-        grid_rng = np.random.default_rng(3)
-        samples = []
-        for _ in range(B):                                          # the dataset as the reference keeps it: scipy operators per frame
-            V, F = mesh_ops.grid_cloth(71, 71, grid_rng)
-            Di, DiA = mesh_ops.dirac(V, F)
-            samples.append((V.astype(np.float32), Di.astype(np.float32), DiA.astype(np.float32), F.shape[0]))
-        nv, nf = samples[0][0].shape[0], samples[0][3]
-        model = arap.DirModel().to(dev).train()
-        opt = arap.make_optimizer(model)
-        inputs = torch.from_numpy(np.stack([np.concatenate([s_[0], s_[0]], 1) for s_ in samples]))
-        targets = torch.zeros(B, nv, 120)
-        mask = torch.ones(B, nv, 1)
-        t_host, t_h2d, t_conv = [], [], []
-
-        def step():
-            t0 = time.perf_counter()
-            Di = utils.sparse_diag_cat([utils.sp_sparse_to_pt_sparse(s_[1]) for s_ in samples], 4 * nf, 4 * nv)     # main.py:161-181
-            DiA = utils.sparse_diag_cat([utils.sp_sparse_to_pt_sparse(s_[2]) for s_ in samples], 4 * nv, 4 * nf)
-            t1 = time.perf_counter()
-            Di, DiA, x, y, m = Di.cuda(), DiA.cuda(), inputs.cuda(), targets.cuda(), mask.cuda()
-            torch.cuda.synchronize()
-            t2 = time.perf_counter()
-            Di, DiA = as_operator(Di), as_operator(DiA)             # (what the blocks do on first touch: COO -> CSR -> blocks, transpose)
-            Di.t(), DiA.t(), Di.q3(), DiA.q3(), Di.t().q3(), DiA.t().q3()
-            torch.cuda.synchronize()
-            t3 = time.perf_counter()
-            t_host.append(t1 - t0), t_h2d.append(t2 - t1), t_conv.append(t3 - t2)
-            out = model(Di, DiA, m, x)
-            loss = arap.loss_fn(out, y, m, B)
-            opt.zero_grad(set_to_none=True)
-            loss.backward()
-            opt.step()
-        dt = timed(step, steps, warm=1)
-        k = len(t_host) - steps
-        print(f"{what}: batch {B} x 71x71 through per-step sparse_diag_cat + .cuda() + as_operator: {dt * 1e3:.1f} ms/step, {B / dt:.1f} meshes/s "
-              f"(host batching {np.mean(t_host[k:]) * 1e3:.1f} ms, H2D {np.mean(t_h2d[k:]) * 1e3:.1f} ms, device conversion of the COO operators "
-              f"{np.mean(t_conv[k:]) * 1e3:.1f} ms, model step {(dt - np.mean(t_host[k:]) - np.mean(t_h2d[k:]) - np.mean(t_conv[k:])) * 1e3:.1f} ms)")
+        r = arap_swap(dev, steps, int(os.environ.get("SN_SWAP_MESHES", "64")))
+        print(f"{what}: batch {r['meshes']} x 71x71 behind the reference's names (resident={r['resident']}, model {r['model']}): "
+              f"{r['ms_per_step']:.1f} ms/step, {r['meshes_per_s']:.1f} meshes/s (host batching calls {r['host_batching_calls_ms']:.2f} ms, the driver's "
+              f".cuda() calls incl. {r['pageable_MB_per_step']:.0f} MB of pageable inputs/targets {r['driver_cuda_calls_host_ms']:.2f} ms host time; "
+              f"resident cache {r['resident_cache']})")
     else:
         raise SystemExit(__doc__)
 
