@@ -468,46 +468,54 @@ def c4_dp_step(device, rank: int, world: int, steps: int = 40, warm: int = 8):
     dt = time.perf_counter() - t0
     assert torch.isfinite(loss.detach()).item(), "FAUST step diverged"
     return dt / steps, {"steps": steps, "warmup": warm, "host_enqueue_ms_per_step": t_enq / steps * 1e3,
-                        "grad_bucket_bytes": bucket.nbytes, "launch": launch}
+                        "grad_bucket_bytes": bucket.nbytes, "launch": launch,
+                        "replicas_identical_after_the_run": replicas_agree(model, world)}
+
+
+def gpu_numa_node(device_index: int, sysfs: str = "/sys") -> int:
+    """NUMA node of a HIP device from its PCI address (hipDeviceGetPCIBusId -> <sysfs>/bus/pci/devices/<bdf>/numa_node);
+    -1 when the platform does not say (single-node hosts, containers, a missing sysfs entry, no HIP runtime)."""
+    try:
+        import ctypes
+
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 64, int(device_index)) != 0:
+            return -1
+        with open(os.path.join(sysfs, "bus/pci/devices", buf.value.decode().lower(), "numa_node")) as fh:
+            return int(fh.read().strip())
+    except (OSError, ValueError, AttributeError):
+        return -1
+
+
+def cpus_for_rank(node: int, cpus_all, local_rank: int, n_local: int, sysfs: str = "/sys"):
+    """(cpus, description): the cores of NUMA node `node` that this process may use; without a node (-1), or when its cpulist
+    is missing / disjoint from the allowed set, the allowed CPUs are dealt out evenly among the node's ranks (a rank beyond the
+    last CPU shares them all)."""
+    cpus_all = sorted(cpus_all)
+    cpus = None
+    if node >= 0:
+        try:
+            with open(os.path.join(sysfs, f"devices/system/node/node{node}/cpulist")) as fh:
+                want = set()
+                for part in fh.read().strip().split(","):
+                    a, _, b = part.partition("-")
+                    want.update(range(int(a), int(b or a) + 1))
+            cpus = [c for c in cpus_all if c in want]
+        except (OSError, ValueError):
+            cpus = None
+    if cpus:
+        return cpus, f"numa node {node}: {len(cpus)} cpus"           # (the ranks of one NUMA node share its cores)
+    per = max(1, len(cpus_all) // max(1, n_local))
+    share = cpus_all[local_rank * per:(local_rank + 1) * per] or cpus_all
+    return share, f"no numa node for the device: cpus {share[0]}-{share[-1]} ({len(share)}) of {len(cpus_all)}"
 
 
 def pin_to_gpu_numa(local_rank: int, n_local: int):
     """Keep this rank's host threads on the cores next to its GPU: eight eager-launching Python processes on a two-socket
-    host otherwise migrate across sockets.  The PCI address of the HIP device gives its NUMA node (/sys/bus/pci/devices/
-    <bdf>/numa_node); without one (-1: single-node hosts, containers) the visible CPUs are dealt out evenly among the node's
-    ranks.  Returns a short description for the JSON line."""
+    host otherwise migrate across sockets (gpu_numa_node / cpus_for_rank).  Returns a short description for the JSON line."""
     try:
-        import ctypes
-
-        cpus_all = sorted(os.sched_getaffinity(0))
-        node = -1
-        try:
-            hip = ctypes.CDLL("libamdhip64.so")
-            buf = ctypes.create_string_buffer(64)
-            if hip.hipDeviceGetPCIBusId(buf, 64, int(torch.cuda.current_device())) == 0:
-                bdf = buf.value.decode().lower()
-                with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as fh:
-                    node = int(fh.read().strip())
-        except (OSError, ValueError, AttributeError):
-            node = -1
-        cpus = None
-        if node >= 0:
-            try:
-                with open(f"/sys/devices/system/node/node{node}/cpulist") as fh:
-                    want = set()
-                    for part in fh.read().strip().split(","):
-                        a, _, b = part.partition("-")
-                        want.update(range(int(a), int(b or a) + 1))
-                cpus = [c for c in cpus_all if c in want]
-            except (OSError, ValueError):
-                cpus = None
-        if cpus:
-            share = cpus                              # (the ranks of one NUMA node share its cores)
-            how = f"numa node {node}: {len(share)} cpus"
-        else:
-            per = max(1, len(cpus_all) // max(1, n_local))
-            share = cpus_all[local_rank * per:(local_rank + 1) * per] or cpus_all
-            how = f"no numa node for the device: cpus {share[0]}-{share[-1]} ({len(share)}) of {len(cpus_all)}"
+        share, how = cpus_for_rank(gpu_numa_node(torch.cuda.current_device()), os.sched_getaffinity(0), local_rank, n_local)
         os.sched_setaffinity(0, share)
         torch.set_num_threads(max(1, min(8, len(share))))
         return how
@@ -558,6 +566,20 @@ def pmc_in_run(args, steps: int = 4):
         return None, f"in-run PMC pass failed: {exc!r}"[:200]
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def replicas_agree(model, world: int) -> bool:
+    """After the timed steps every rank must hold the same parameters, bit for bit (same initial broadcast, same all-reduced
+    gradients, same Adam): compared through an all-gather of two checksums per rank."""
+    import torch.distributed as dist
+
+    flat = torch.cat([p.detach().reshape(-1).double() for p in model.parameters()])
+    mine = torch.stack([flat.sum(), (flat * torch.arange(1, flat.numel() + 1, device=flat.device, dtype=torch.float64)).sum()])
+    if world == 1 or not dist.is_initialized():
+        return True
+    got = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(got, mine)
+    return bool(all(torch.equal(g, got[0]) for g in got))
 
 
 def self_launch(args, argv):
@@ -790,6 +812,7 @@ def main():
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt = float(dt_t.item())
     assert torch.isfinite(loss).item(), "training diverged"
+    replicas_identical = replicas_agree(model, world)
 
     # ---- roofline of the dominant kernel, from the HIP events recorded during the timed steps ---------
     recs = timer.results()
@@ -895,6 +918,7 @@ def main():
                                             if dist.get_backend() == "nccl" else f"pack + {dist.get_backend()} all-reduce of the flat bucket")
                                            if dist.is_initialized() else "none"),
                    "devices_visible": torch.cuda.device_count(), "ranks_share_devices": bool(oversubscribed),
+                   "replicas_identical_after_the_run": replicas_identical,
                    "linear_layers": ("fp32 operands and fp32 accumulation; products formed on the 16-bit matrix pipe from an exact split of "
                                      "every operand into two fp16 pieces after a power-of-two row / column scaling (3 partial products, "
                                      "error <= 2^-23 per term: fp32-accurate, tests/test_dense_gpu.py); SN_GEMM_VARIANT=1 selects the "

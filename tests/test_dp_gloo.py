@@ -249,3 +249,94 @@ def test_correspondence_pairs_sharded_over_two_ranks():
     for rank, err, lerr, same in sorted(q.get(timeout=10) for _ in range(2)):
         assert err < 1e-5, f"rank {rank}: all-reduced pair gradients differ from the two-pair gradient by {err:.2e}"
         assert lerr < 1e-6 and same
+
+
+def _worker8(rank, world, port, q):
+    """World size 8 on a RAGGED pool sharded by shard_balanced (size-balanced bins by entry count, what DESIGN §7 prescribes
+    for ragged batches): the sum of the eight shard gradients is the full-batch gradient."""
+    for p in (ROOT, HERE):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), SN_DP_FORCE_CPU="1")
+    torch.set_num_threads(1)
+    import cpu_kernels
+
+    cpu_kernels.install()
+    from helpers import deterministic_init
+    from surfacenetworks_amd import arap, dp
+
+    r, lr, w, dev = dp.init_distributed("gloo")
+    assert (r, w, dev.type) == (rank, world, "cpu")
+    grids = [(4, 4), (7, 6), (5, 4), (9, 5), (4, 5), (6, 6), (8, 4), (5, 5), (10, 6), (4, 6), (7, 4)]
+    ds = arap.ClothSequences(grids, frames=44, op_frames=2, seed=7, device="cpu", model="dir", permute="both")
+    G = len(grids)
+    seq, off = np.arange(G), np.zeros(G, dtype=np.int64)
+    weights = ds.pool_Di._fwd["cnt"][::ds.op_frames]                      # entries of every mesh's operator
+    mine = dp.shard_balanced(weights, rank, world)
+    owners = [dp.shard_balanced(weights, r_, world) for r_ in range(world)]
+    assert sorted(np.concatenate(owners).tolist()) == list(range(G)) and all(len(o) >= 1 for o in owners)
+    loads = np.array([weights[o].sum() for o in owners])
+    assert loads.max() <= loads.mean() + weights.max()                    # LPT bound
+    model = deterministic_init(arap.DirModel(), 3 + rank).eval()
+    dp.broadcast_parameters(model, 0)
+    bucket = dp.FlatGradBucket(model.parameters())
+    opt = arap.make_optimizer(model)
+    batch = ds.sample_batch(len(mine), None, seq_ids=seq[mine], offsets=off[mine])
+    loss = arap.train_step(model, opt, batch, global_batch=G, grad_sync=bucket.sync, zero_grads=bucket.detach_grads)
+    g_dp = bucket.flat.clone()
+    err = lerr = 0.0
+    if rank == 0:
+        ref = deterministic_init(arap.DirModel(), 3).eval()
+        l_full, _ = arap.forward_loss(ref, ds.sample_batch(G, None, seq_ids=seq, offsets=off), G)
+        l_full.backward()
+        g_full = torch.cat([p.grad.reshape(-1) for p in ref.parameters()])
+        err = ((g_dp - g_full).norm() / g_full.norm()).item()
+    lsum = loss.detach().clone()
+    dist.all_reduce(lsum)
+    if rank == 0:
+        lerr = abs(lsum.item() - l_full.item()) / abs(l_full.item())
+    flat_p = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+    other = flat_p.clone()
+    dist.broadcast(other, 0)
+    q.put((rank, err, lerr, bool(torch.equal(other, flat_p)), len(mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_gradients_sum_to_full_batch_world8_balanced_ragged():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+        assert p.exitcode == 0, f"worker exited with {p.exitcode}"
+    res = sorted(q.get(timeout=10) for _ in range(8))
+    assert sum(r[4] for r in res) == 11
+    assert res[0][1] < 2e-5 and res[0][2] < 1e-5, res[0]
+    assert all(r[3] for r in res)
+
+
+def test_rank_affinity_without_a_numa_node(tmp_path):
+    """bench.cpus_for_rank / gpu_numa_node: a device whose sysfs numa_node is -1 or missing, a node without a cpulist, more
+    ranks than CPUs — every rank still gets a non-empty CPU set, disjoint where the CPUs suffice."""
+    import bench
+
+    cpus = list(range(16))
+    shares = [bench.cpus_for_rank(-1, cpus, r, 8)[0] for r in range(8)]
+    assert all(len(s) == 2 for s in shares) and sorted(sum(shares, [])) == cpus
+    assert "no numa node" in bench.cpus_for_rank(-1, cpus, 3, 8)[1]
+    few = [bench.cpus_for_rank(-1, [0, 1, 2, 3], r, 8)[0] for r in range(8)]
+    assert all(len(s) >= 1 for s in few) and few[0] == [0] and few[7] == [0, 1, 2, 3]
+    # a node whose cpulist exists: its CPUs (intersected with the allowed set); one whose cpulist is missing: dealt out
+    node_dir = tmp_path / "devices/system/node/node1"
+    node_dir.mkdir(parents=True)
+    (node_dir / "cpulist").write_text("4-7,12-13\n")
+    got, how = bench.cpus_for_rank(1, cpus, 5, 8, sysfs=str(tmp_path))
+    assert got == [4, 5, 6, 7, 12, 13] and how.startswith("numa node 1")
+    assert bench.cpus_for_rank(1, [0, 1], 0, 2, sysfs=str(tmp_path))[0] == [0]         # node CPUs not allowed here: dealt out
+    assert bench.cpus_for_rank(2, cpus, 1, 8, sysfs=str(tmp_path))[0] == [2, 3]
+    assert bench.gpu_numa_node(0, sysfs=str(tmp_path)) == -1                            # no such device entry / no HIP device

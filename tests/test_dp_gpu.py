@@ -335,3 +335,28 @@ def test_bench_faust_workload_starts_two_ranks():
     shared = torch.cuda.device_count() < 2
     assert rec["config"]["ranks_share_devices"] == shared
     assert rec["config"]["collective_backend"] == ("gloo" if shared else "nccl")
+
+
+@pytest.mark.parametrize("workload", ["arap", "faust"])
+def test_bench_starts_eight_ranks_on_the_one_device(workload):
+    """`python bench.py --gpus 8` as the driver will run it on an 8-GPU node — here functionally, on the one device (gloo,
+    eager, ranks sharing cuda:0): eight ranks come up, rendezvous, shard, all-reduce and step; ONE JSON line with
+    n_gpus = world_size = 8, a finite value, and replicas that are still bit-identical after the run."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"]
+    cmd += ["--workload", "faust"] if workload == "faust" else ["--meshes", "2", "--no-secondary", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1500)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    rec = json.loads(lines[0])
+    cfg = rec["config"]
+    assert rec["n_gpus"] == 8 and cfg["world_size"] == 8 and rec["value"] > 0 and np.isfinite(rec["ms_per_step"])
+    assert cfg["replicas_identical_after_the_run"] is True
+    assert "cpus" in cfg["host_affinity"]                                   # every rank pinned itself (NUMA node or dealt out)
+    if torch.cuda.device_count() < 8:
+        assert cfg["ranks_share_devices"] and cfg["collective_backend"] == "gloo"
+    if workload == "arap":
+        assert cfg["global_batch"] == 16 and cfg["launch"] == "eager" if torch.cuda.device_count() < 8 else True
+    else:
+        assert cfg["global_pairs"] == 8 and rec["unit"] == "pairs/s"
