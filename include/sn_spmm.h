@@ -14,11 +14,21 @@
  *     (reference: launch on torch.cuda.current_stream(), sparse_bmm.py:59, batch_csr.py:56).
  *   - No per-operator or per-shape caches (the reference keeps module-level kernel / handle caches, sparse_bmm_func.py:20-21,
  *     sparse_bmm.py:26,63 — deliberately not kept); re-entrant; safe from several host threads on different streams.
- *     The ONLY process-global state of the library: (a) the A/B switches SN_BSR4_VARIANT, SN_CSR_VARIANT, SN_CSR_ITERS,
- *     SN_RB4_ITERS, SN_GEMM_VARIANT, SN_GEMM_WGS, SN_WGRAD_VARIANT, read ONCE from the environment (they select between
- *     kernels / launch shapes that compute the same result, for measurements); (b) the opt-in per-launch timing facility sn_timing_* below (a mutex-guarded list, off by
- *     default).  Neither affects results.  The Python layer adds three process-wide selectors with the same property:
- *     functional.set_dirac_format / set_laplacian_format (kernel form) and set_bn_sync (opt-in global BatchNorm statistics).
+ *     The ONLY process-global state: (a) environment switches, read ONCE per process — the complete list, asserted against the
+ *     sources by tests/test_boundary.py::test_environment_switches_are_the_documented_ones:
+ *       library  SN_GEMM_VARIANT      0 = the fp32-MFMA kernels (gemm_rows_k, wgrad_mfma_k): the ONE A/B baseline of the Linear
+ *                                     kernels (exact fp32 products, no fused epilogues); anything else / unset = the shipped kernels
+ *       package  SN_PAIR_FUSED        0 = dense-correspondence loss on the materialised score matrix (baseline of sn_pair_fused_*)
+ *                SN_STRICT            1 = raise where a shape falls back to a library GEMM / an unfused composition
+ *                SN_DEBUG_VALIDATE    1 = sn_validate_csr_i32 on every operator built from CSR arrays
+ *                SN_RESIDENT          0 = utils_pt's batching functions take the reference's host path (no resident cache)
+ *                SN_RESIDENT_MAX_GB   HBM budget of that cache (default 96)
+ *                SN_DP_FORCE_CPU      1 = dp.init_distributed ignores the GPU (CPU gloo tests)
+ *     SWITCHES: SN_GEMM_VARIANT SN_PAIR_FUSED SN_STRICT SN_DEBUG_VALIDATE SN_RESIDENT SN_RESIDENT_MAX_GB SN_DP_FORCE_CPU
+ *     (b) the opt-in per-launch timing facility sn_timing_* below (a mutex-guarded list, off by default).  Neither affects
+ *     results.  The Python layer adds process-wide DEFAULTS with the same property: functional.set_dirac_format /
+ *     set_laplacian_format (kernel form; one operator can choose for itself, SparseOperator.format) and set_bn_sync (opt-in
+ *     global BatchNorm statistics).
  *   - Return value: 0 = success; negative = SN_E_* invalid argument; positive = hipError_t of the
  *     failed launch.  sn_status_string() renders either.
  *   - Indices are int32 (the reference uses int64, utils_pt.py:62, sparse_bmm.cu:17); an operator
@@ -438,27 +448,6 @@ int sn_wgrad_slabs_bounded_f32(const float *dy, int64_t lddy, const float *x, in
                                const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg, int32_t J,
                                int32_t C, float *G, double *dysum, float *seg_dysum, void *workspace, size_t workspace_bytes,
                                const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows, void *stream);
-/* sn_wgrad_bn_f32: the weight gradient of a folded BatchNorm + Linear AND everything the training step derives from it, in
- * two launches (the split-K product, then one finishing kernel) instead of four to six: what sn_wgrad_[seg_|slabs_][bounded_]f32
- * + [sn_avg_bwd_gc_f32 +] sn_bn_bwd_coeffs_f32 return — dW, db, dgamma, dbeta and the coefficients B, C of the input
- * gradient's BatchNorm tail — bit for bit.  Replaces, per GraphConv1x1 of the reference (src/utils/utils_pt.py:83-99), the
- * autograd nodes MmBackward (weight half), SumBackward (bias) and NativeBatchNormBackward's three reductions.  Local
- * statistics only (the sums are finished on this device; synchronised BatchNorm all-reduces G between the steps and keeps the
- * separate calls).
- *   rows_per_seg > 0: equal meshes (as sn_wgrad_seg_f32); slab_off != NULL: ragged meshes (as sn_wgrad_slabs_f32; then nslab,
- *   seg_slab_ptr, nseg as there); neither: plain rows.  dybound != NULL: the two-piece fp16 product (as sn_wgrad_bounded_f32).
- *   Ct == C: W (J x Ct), s, invstd, beta (Ct) over the C columns of x.  Ct == 2 C (needs meshes): a global-average stage
- *   (AvgResNet2, utils_pt.py:230-243) — the second C columns are the per-mesh means m[nseg][C] about mu2[C]; seg_dysum[nseg][J]
- *   receives the per-mesh column sums of dy.  Gc (J x Ct) receives the centred product itself; db, dysum (J doubles) optional.
- *   bn_rows: rows behind the BatchNorm statistics.  workspace: sn_wgrad_bn_workspace_bytes (nslab_ragged: 0 unless ragged).
- *   counters: Ct / 32 ints on the device, zero on entry; zero again once the launch has run (one set per launch in flight). */
-size_t sn_wgrad_bn_workspace_bytes(int64_t rows, int64_t rows_per_seg, int32_t nslab_ragged, int32_t J, int32_t C, int32_t Ct);
-int sn_wgrad_bn_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows, int32_t J, int32_t C,
-                    int64_t rows_per_seg, const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg,
-                    const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows, const float *W, const float *s,
-                    const float *invstd, const float *beta, int64_t bn_rows, int32_t Ct, const float *m, const float *mu2, float *Gc,
-                    float *dW, float *db, float *dgamma, float *dbeta, float *Bc, float *Cc, float *seg_dysum, double *dysum,
-                    void *workspace, size_t workspace_bytes, int32_t *counters, void *stream);
 /* sn_wgrad_thin_f32: weight and bias gradient of a Linear with 1..8 input channels — the models' first layer,
  * GraphConv1x1(6 | 3 -> C, batch_norm=None) (src/as_rigid_as_possible/models.py:113, src/utils/utils_pt.py:99) — on
  * rows ~ 1e5..1e6:  G (J x C, row-major, fp32) = dy^T x,  db (J, optional) = colsum(dy).  One pass over dy; fp32
@@ -554,19 +543,13 @@ int sn_bn_fold_f32(const double *stats, int64_t rows, const float *gamma, const 
                    const float *b, int32_t J, int32_t C, double eps, double momentum, int32_t training,
                    float *running_mean, float *running_var, float *mean, float *invstd, float *s, float *t,
                    float *Wf, float *bf, int64_t *num_batches_tracked, void *stream);
-/* sn_bn_fold_parts_f32 : the training-mode fold with the statistics reduction inside — one launch in place of
- * sn_colstats_merge_f64 (once per half of a concat buffer) + sn_bn_fold_f32.  The C = C_lo + C_hi (128 or 256) channels'
- * sums / sums of squares arrive as per-workgroup partials of up to two producers: part_lo ([nblk_lo][2][C_lo] fp64) for
- * channels [0, C_lo), part_hi ([nblk_hi][2][C_hi]) for the rest; a NULL pointer (or 0 blocks) stands for columns that are all
- * zero.  Outputs and running-statistics update as sn_bn_fold_f32 in training mode; summation order fixed.  `counter`: one
- * int32 of device memory that is 0 when the launch starts and is left 0 (a ticket for the workgroup that folds the weights
- * after the last channel's scalars are published); two launches that may run CONCURRENTLY need different counters.
- * sn_colstats_partial_f32 : the statistics pass over x WITHOUT its final reduction — partial[sn_colstats_blocks(rows)][2][C]
- * fp64, the producer format above. */
-int sn_bn_fold_parts_f32(const double *part_lo, int32_t nblk_lo, int32_t C_lo, const double *part_hi, int32_t nblk_hi, int32_t C_hi,
-                         int64_t rows, const float *gamma, const float *beta, const float *W, const float *b, int32_t J, double eps,
-                         double momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked, float *mean,
-                         float *invstd, float *s, float *t, float *Wf, float *bf, int32_t *counter, void *stream);
+/* sn_colstats_partial_f32 : the statistics pass over x WITHOUT its final reduction — partial[sn_colstats_blocks(rows)][2][C]
+ * fp64, the producer format of sn_colstats_merge_f64.
+ * sn_wgrad_bounded_enabled / sn_gemm_variant : what the process-wide baseline switch SN_GEMM_VARIANT resolved to (read once):
+ * 1 / 2 with the shipped 16-bit matrix-pipe kernels, 0 / 0 with the fp32-MFMA A/B baseline — launchers ask the library
+ * instead of parsing the environment themselves. */
+int32_t sn_wgrad_bounded_enabled(void);
+int32_t sn_gemm_variant(void);
 int32_t sn_colstats_blocks(int64_t rows);
 int sn_colstats_partial_f32(const float *x, int64_t ld, int64_t rows, int32_t C, double *partial, void *stream);
 int sn_bn_bwd_coeffs_f32(const float *Gc, const double *dystats, const float *W, const float *s, const float *invstd,

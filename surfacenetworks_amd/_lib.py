@@ -76,9 +76,6 @@ SIGNATURES = {
                                      _vp, _vp, _vp, _i64, _vp, _vp]),
     "sn_avg_bn_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i64, _vp, _i64, _vp, _i64, _vp, _vp,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "sn_wgrad_bn_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32, _i32, _i32]),
-    "sn_wgrad_bn_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i64, _vp, _i32, _vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp,
-                                  _vp, _vp, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "sn_linear_dgrad_absmax_blocks": (_i32, []),
     "sn_linear_dgrad_elu_absmax_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _i64,
                                                  _i32, _i32, _vp, _vp]),
@@ -105,9 +102,9 @@ SIGNATURES = {
     "sn_linear_thin_fwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i64, _vp]),
     "sn_bn_fold_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _i32, _i32, C.c_double, C.c_double, _i32, _vp, _vp, _vp,
                                  _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "sn_bn_fold_parts_f32": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.c_double,
-                                       C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "sn_colstats_blocks": (C.c_int32, [_i64]),
+    "sn_wgrad_bounded_enabled": (C.c_int32, []),
+    "sn_gemm_variant": (C.c_int32, []),
     "sn_colstats_merge2_f64": (C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     "sn_colstats_partial_f32": (C.c_int, [_vp, _i64, _i64, C.c_int32, _vp, _vp]),
     "sn_bn_bwd_coeffs_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -29,42 +29,12 @@ typedef float f16v __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
   return nt ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p);
 }
-#ifndef SN_X_EW_ST_PLAIN
-#define SN_X_EW_ST_PLAIN 0
-#endif
-#ifndef SN_X_STATS_NT
-#define SN_X_STATS_NT 0
-#endif
-#ifndef SN_X_WGRAD_NT
-#define SN_X_WGRAD_NT 0
-#endif
-#ifndef SN_X_WGU_NOCONV
-#define SN_X_WGU_NOCONV 0
-#endif
-#ifndef SN_X_WGU_NOMFMA
-#define SN_X_WGU_NOMFMA 0
-#endif
-#ifndef SN_X_WGU_NOLOAD
-#define SN_X_WGU_NOLOAD 0
-#endif
-#ifndef SN_X_WGU_NT
-#define SN_X_WGU_NT 0
-#endif
-#ifndef SN_X_WGU_HALF
-#define SN_X_WGU_HALF 0        // ablation only (wrong numbers): issue 3 of the 6 partial products, everything else unchanged
-#endif
-#ifndef SN_X_WGU_PERM
-#define SN_X_WGU_PERM 0
-#endif
-#ifndef SN_X_WGRAD_PAIRS
-#define SN_X_WGRAD_PAIRS 1     // wgrad_x3_k: one workgroup barrier per PAIR of 16-row steps (four LDS images); 0: per step
-#endif
 __device__ __forceinline__ void st4_s(float *p, f4 v, int nt) {
-  if (nt && !SN_X_EW_ST_PLAIN) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
   else *reinterpret_cast<f4 *>(p) = v;
 }
 // statistics passes (colstats_k, segstats_k): read-once operands
-__device__ __forceinline__ f4 ld4_stat(const float *p) { return ld4_s(p, SN_X_STATS_NT); }
+__device__ __forceinline__ f4 ld4_stat(const float *p) { return ld4_s(p, 0); }
 
 constexpr int kStreamNT = 1;     // elementwise passes stream with non-temporal loads/stores (see sn_kernels.hip)
 
@@ -77,10 +47,7 @@ inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 
 // ------------------------------------------------------------------------------------------------
 // column statistics
 // ------------------------------------------------------------------------------------------------
-#ifndef SN_X_STAT_BLOCKS
-#define SN_X_STAT_BLOCKS 512
-#endif
-constexpr int kStatBlocks = SN_X_STAT_BLOCKS;
+constexpr int kStatBlocks = 512;
 
 // VEC: C % 4 == 0 and (C/4) divides 256: a thread owns 4 adjacent columns and every (256/(C/4))-th row.
 template <bool VEC>
@@ -329,19 +296,14 @@ __global__ __launch_bounds__(kWG, 2) void wgrad_mfma_k(const float *__restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// weight gradient on the bf16 matrix pipe (default): the exact three-piece bf16 split of sn_gemm.hip (six exact partial
-// products per term, fp32 accumulation), 16 rows of the operands per step.  All six products of a term go into the tile's
-// single accumulator (8 tiles per wave leave no registers for separate correction accumulators), so the rounding is up to
-// ~2.5x that of one fp32 chain — measured against fp64 it stays below hipBLASLt's fp32 GEMM on the same operands
-// (tests/test_dense_gpu.py::test_split_bf16_is_as_accurate_as_an_fp32_fma_chain).
-//
-// v_mfma_f32_32x32x16_bf16 takes, per lane, EIGHT CONSECUTIVE k of one row/column: with k = operand rows that is a column
-// walk, so the operands go through LDS transposed.  A loader thread owns 8 rows x 4 columns of the step (8 full-line
-// 16-byte loads, prefetched one step ahead), splits its 32 values and writes, per column and piece, the 8 rows as one
-// 16-byte slot.  Slot of (column c, row group g): g·PL + (c%4)·QP + c/4 with QP = (#columns/4) + 4 — consecutive loader
-// lanes write consecutive slots, and the 16-lane groups of a fragment ds_read_b128 (lane = column within the tile) fall on
-// 16 different slot residues mod 16: both directions are conflict-free.  Columns 0..127 are dy (zero past J), the rest
-// x - center.  Waves are 2 (dy tiles) x 2 (x tiles): 2 x 2·CT accumulators each, 18 fragment reads per 48 MFMAs (CT = 2).
+// Weight gradient G = dy^T (x - center) on the 16-bit matrix pipe: the operands' rows are the contraction index, so a lane's
+// MFMA fragment (EIGHT CONSECUTIVE k of one column) is a column walk and the operands go through LDS transposed — a unit of
+// 8 rows x 1 column becomes one 16-byte slot per piece.  Slot of (column c, row group g): g·PL + (c%4)·QP + c/4 with QP =
+// (#columns/4) + 4: consecutive writer lanes hit consecutive slots, the 16-lane groups of a fragment ds_read_b128 fall on 16
+// different slot residues mod 16 — both directions conflict-free.  Columns 0..127 are dy (zero past J), the rest x - center.
+// Two kernels: wgrad_h_k (two scaled fp16 pieces, needs bounds on its operands; the default of the training step) and
+// wgrad_u_k (three bf16 pieces, no bounds needed: eval-mode BatchNorm, dy from a kernel that leaves no maxima).  Rounds 1-3's
+// wave-specialised and LDS-DMA forms are described in LABNOTES (k23, wgrad_d).
 // ------------------------------------------------------------------------------------------------
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
@@ -349,267 +311,15 @@ typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f16v mfma_bf16(const u4 &a, const u4 &b, const f16v &c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
 }
+constexpr int kWgradThreads = 512;          // 8 waves, two per SIMD
 
-// Workgroup = 8 waves with two roles (two waves per SIMD, so the SIMD interleaves them by itself):
-//   waves 0-3  matrix waves, 2 (dy tiles) x 2 (x tiles): fragments of the current image, 2 x 2·CT accumulators each,
-//              18 fragment reads per 48 MFMAs (CT = 2);
-//   waves 4-7  loader waves: 8 rows x 4 columns per thread and step, requested FOUR steps ahead (four register sets),
-//              split on the vector ALU while the matrix waves multiply, written to the other image.
-// One workgroup barrier per PAIR of steps (four LDS images, 150 KB at CT = 2: two being read, two being written) — the
-// two roles then meet half as often: -1..2 % of the training step against a barrier per step (SN_X_WGRAD_PAIRS=0).
-constexpr int kWgradThreads = 512;
-
-template <int CT /* C / 128: 1 or 2 */>
-__global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__restrict__ dy, int64_t lddy,
-                                                               const float *__restrict__ x, int64_t ldx,
-                                                               const float *__restrict__ center, int64_t rows, int J, int C,
-                                                               float *__restrict__ partial /* [grid][128][C] */,
-                                                               float *__restrict__ colpart /* [grid][128] | NULL */,
-                                                               int64_t seg_rows /* 0: even split of all rows */, int spm) {
-  constexpr int NCG = 32 + 32 * CT;          // column groups of 4: 32 of dy, 32·CT of x
-  constexpr int QP = NCG + 4;                // slots per (column % 4) plane; QP % 16 == 4 keeps fragment reads conflict-free
-  constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
-  constexpr int NB = 2 * CT;                 // x tiles per matrix wave
-  static_assert(QP % 16 == 4, "slot permutation");
-#if SN_X_WGRAD_PAIRS
-  constexpr int NBUF = 4;                    // one barrier per PAIR of steps: two images being read, two being written
-#else
-  constexpr int NBUF = 2;
-#endif
-  __shared__ u4 img[NBUF][3][2 * PL];        // [buffer][piece][slot]; one step = 16 rows = 2 row groups
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  // row slab of this workgroup: an even split of all rows, or — seg_rows > 0 — `spm` slabs per mesh that never cross a mesh
-  // boundary, so that the per-slab column sums of dy also add up to PER-MESH sums (the global-average stage needs them)
-  int64_t r0, r1;
-  if (seg_rows > 0) {
-    const int64_t mesh = blockIdx.x / spm, part = blockIdx.x % spm;
-    int64_t per = (seg_rows + spm - 1) / spm;
-    per = (per + 15) & ~(int64_t)15;
-    const int64_t mend = (mesh + 1) * seg_rows < rows ? (mesh + 1) * seg_rows : rows;
-    r0 = mesh * seg_rows + part * per;
-    r1 = r0 + per < mend ? r0 + per : mend;
-  } else {
-    int64_t per = (rows + gridDim.x - 1) / gridDim.x;
-    per = (per + 15) & ~(int64_t)15;
-    r0 = (int64_t)blockIdx.x * per;
-    r1 = r0 + per < rows ? r0 + per : rows;
-  }
-  const int64_t nsteps = r1 > r0 ? (r1 - r0 + 15) / 16 : 0;
-  float *P = partial + (int64_t)blockIdx.x * 128 * C;
-#define SN_STEP_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-
-  if (wave >= 4) {
-    // ======================= loader waves =======================
-    // Tasks: 64 dy tasks (2 row groups x 32 column groups) = wave 4, then 64·CT x tasks = waves 5.. — a wave is all-dy or
-    // all-x, so the role-dependent work (column sums | centring) is wave-uniform control flow.
-    const int task = tid - 256;
-    const bool active = task < 64 + 64 * CT;
-    const bool isdy = __builtin_amdgcn_readfirstlane(task) < 64;                       // wave-uniform
-    const int tl_ = isdy ? task : task - 64;
-    const int ncgt = isdy ? 32 : 32 * CT;                                               // column groups of my operand
-    const int rg = active ? tl_ / ncgt : 0, cgl = active ? tl_ % ncgt : 0;
-    const int cg = isdy ? cgl : 32 + cgl;                                               // column group in the image
-    const bool colok = active && (isdy ? 4 * cgl < J : true);
-    // address = wave-uniform row base (scalar arithmetic) + a 32-bit lane offset: no per-load vector address math
-    const float *opnd = isdy ? dy : x;
-    const int64_t ld = isdy ? lddy : ldx;
-    const int lane_off = (int)(8 * rg * ld) + (colok ? 4 * cgl : 0);
-    const f4 mu = (!isdy && center) ? *reinterpret_cast<const f4 *>(center + 4 * cgl) : f4{0.f, 0.f, 0.f, 0.f};
-    const bool all_cols = __all(colok) != 0;                                            // wave-uniform: no column masking needed
-    f4 dsum = {0.f, 0.f, 0.f, 0.f};          // dy loaders: column sums of their rows (the bias gradient)
-    f4 ra[8], rb[8], rc[8], rd[8];           // rows of four consecutive steps
-    // The registers receive the raw loads only: anything computed from them here would make the compiler wait for the
-    // data in the step that requests it.  Centring and the zeroing of rows past the slab happen at conversion time.
-    auto load_step = [&](f4 (&raw)[8], int64_t s) {
-      const int64_t base = r0 + 16 * s;
-      if (base + 16 <= r1) {                 // whole step inside the slab (wave-uniform): plain strided rows
-        const float *sb = opnd + base * ld;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = ld4_s(sb + j * ld + lane_off, SN_X_WGRAD_NT);
-      } else {                               // last (or a prefetched, empty) step: rows past the slab re-read its last row
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const int64_t row = base + 8 * rg + j;
-          raw[j] = *reinterpret_cast<const f4 *>(opnd + (row < r1 ? row : r1 - 1) * ld + (colok ? 4 * cgl : 0));
-        }
-      }
-    };
-    auto convert_step = [&](f4 (&raw)[8], int64_t s, int buf) {
-      const int64_t base = r0 + 16 * s;
-      if (base + 16 > r1 || !all_cols) {     // partial step / narrow dy: mask
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = (colok && base + 8 * rg + j < r1) ? raw[j] : f4{0.f, 0.f, 0.f, 0.f};
-        if (!isdy) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) raw[j] = (base + 8 * rg + j < r1) ? raw[j] - mu : raw[j];
-        }
-      } else if (!isdy) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] -= mu;
-      }
-      if (isdy) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) dsum += raw[j];
-      }
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {          // column 4cg+q: rows 8rg .. 8rg+7 of each piece as one 16-byte slot
-        unsigned hb[8], mb[8], lb[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xv = raw[j][q];
-          hb[j] = __float_as_uint(xv);
-          const float r = xv - __uint_as_float(hb[j] & 0xFFFF0000u);
-          mb[j] = __float_as_uint(r);
-          lb[j] = __float_as_uint(r - __uint_as_float(mb[j] & 0xFFFF0000u));
-        }
-        u4 H, M, L;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-          H[p] = __builtin_amdgcn_perm(hb[2 * p + 1], hb[2 * p], 0x07060302u);
-          M[p] = __builtin_amdgcn_perm(mb[2 * p + 1], mb[2 * p], 0x07060302u);
-          L[p] = __builtin_amdgcn_perm(lb[2 * p + 1], lb[2 * p], 0x07060302u);
-        }
-        const int slot = rg * PL + q * QP + cg;
-        if (active) {
-          img[buf][0][slot] = H;
-          img[buf][1][slot] = M;
-          img[buf][2][slot] = L;
-        }
-      }
-    };
-#if SN_X_WGRAD_PAIRS
-    if (nsteps > 0) {
-      // pair k = steps 2k, 2k+1 read by the matrix waves from images (2k)&3, (2k+1)&3 while this wave converts steps
-      // 2k+2, 2k+3 into the other two; step t lives in register set t & 3 and is re-filled with step t+4 once converted
-      load_step(ra, 0);
-      load_step(rb, 1);
-      load_step(rc, 2);
-      load_step(rd, 3);
-      convert_step(ra, 0, 0);
-      load_step(ra, 4);
-      convert_step(rb, 1, 1);
-      load_step(rb, 5);
-      for (int64_t s = 0; s < nsteps; s += 4) {
-        SN_STEP_BARRIER();
-        convert_step(rc, s + 2, 2);
-        load_step(rc, s + 6);
-        convert_step(rd, s + 3, 3);
-        load_step(rd, s + 7);
-        if (s + 2 >= nsteps) break;
-        SN_STEP_BARRIER();
-        convert_step(ra, s + 4, 0);
-        load_step(ra, s + 8);
-        convert_step(rb, s + 5, 1);
-        load_step(rb, s + 9);
-      }
-    }
-#else
-    if (nsteps > 0) {
-      load_step(ra, 0);
-      load_step(rb, 1);
-      load_step(rc, 2);
-      load_step(rd, 3);
-      convert_step(ra, 0, 0);
-      load_step(ra, 4);
-      // step s: the matrix waves work on image s&1; this wave converts step s+1 into the other image and re-fills the
-      // registers it frees with step s+5 (four register sets: up to four steps of rows in flight per thread)
-      int64_t s = 0;
-      while (true) {
-        SN_STEP_BARRIER();
-        convert_step(rb, s + 1, (int)((s + 1) & 1));
-        load_step(rb, s + 5);
-        if (++s >= nsteps) break;
-        SN_STEP_BARRIER();
-        convert_step(rc, s + 1, (int)((s + 1) & 1));
-        load_step(rc, s + 5);
-        if (++s >= nsteps) break;
-        SN_STEP_BARRIER();
-        convert_step(rd, s + 1, (int)((s + 1) & 1));
-        load_step(rd, s + 5);
-        if (++s >= nsteps) break;
-        SN_STEP_BARRIER();
-        convert_step(ra, s + 1, (int)((s + 1) & 1));
-        load_step(ra, s + 5);
-        if (++s >= nsteps) break;
-      }
-    }
-#endif
-    if (colpart) {                           // (rows past the slab were read as zero: they add nothing)
-      __syncthreads();
-      float *sm = reinterpret_cast<float *>(&img[0][0][0]);
-      if (active && isdy) *reinterpret_cast<f4 *>(sm + rg * 128 + 4 * cg) = dsum;
-      __syncthreads();
-    }
-  } else {
-    // ======================= matrix waves =======================
-    const int i = lane & 31, kh = lane >> 5;
-    const int wj = wave >> 1, wc = wave & 1;
-    const int fo = kh * PL + (i & 3) * QP + (i >> 2);        // my fragment slot, + 8·(tile index in column groups of 32)
-    f16v acc[2][NB];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-    for (int64_t s = 0; s < nsteps; ++s) {
-#if SN_X_WGRAD_PAIRS
-      const int buf = (int)(s & 3);
-      if (!(s & 1)) SN_STEP_BARRIER();       // images of this pair complete; the previous pair's may be overwritten
-#else
-      const int buf = (int)(s & 1);
-      SN_STEP_BARRIER();                     // image `buf` complete; image buf^1 may be overwritten
-#endif
-      u4 A[2][3], B[NB][3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a) A[a][p] = img[buf][p][fo + 8 * (2 * wj + a)];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) B[b][p] = img[buf][p][fo + 32 + 8 * (NB * wc + b)];
-      }
-      // six partial products (pieces of dy, x): (l,h) (h,l) (m,m) (m,h) (h,m) (h,h) — small terms first; tile-inner, so
-      // consecutive MFMAs never share an accumulator
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        const int pa = (0x001102 >> (4 * t)) & 15, pb = (0x010120 >> (4 * t)) & 15;
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < NB; ++b) acc[a][b] = mfma_bf16(A[a][pa], B[b][pb], acc[a][b]);
-      }
-    }
-    if (colpart) {
-      __syncthreads();
-      __syncthreads();
-      const float *sm = reinterpret_cast<const float *>(&img[0][0][0]);
-      if (tid < 128) colpart[(int64_t)blockIdx.x * 128 + tid] = sm[tid] + sm[128 + tid];
-    }
-    // D layout (32x32): column n = lane & 31 (x column within its tile), row (dy column within its tile)
-    // = (e & 3) + 8 (e >> 2) + 4 (lane >> 5), e = 0..15
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-      for (int b = 0; b < NB; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int jr = 32 * (2 * wj + a) + (e & 3) + 8 * (e >> 2) + 4 * kh;
-          P[(int64_t)jr * C + 32 * (NB * wc + b) + i] = acc[a][b][e];
-        }
-  }
-#undef SN_STEP_BARRIER
-}
 
 // ------------------------------------------------------------------------------------------------
-// wgrad_u_k — the same split-bf16 weight gradient with UNIFORM waves (default, SN_WGRAD_VARIANT=2).
+// wgrad_u_k — the three-piece bf16 weight gradient (six exact partial products per term), uniform waves.
 //
-// PMC of wgrad_x3_k (profiles/r2_pmc_wgrad.txt): matrix pipe 38 % busy, vector ALU 29 %, the three loader waves 94 % busy —
-// the wave-specialised kernel is paced by the instruction stream of ONE loader wave (≈350 instructions per 16-row step: 32
-// values per lane) while the matrix waves wait at the barrier, and the fourth loader wave (at C = 128: two of them) has no
-// task.  Here all 8 waves do both jobs: per 32-row block a wave converts its share of the operands — units of 8 rows x 1
-// column, one 16-byte LDS slot per piece: 3 units per lane at C = 256, 2 at C = 128, every lane of every wave busy — and
-// multiplies 2 x CT output tiles (2 dy tiles x CT x tiles).
+// All 8 waves do both jobs: per 32-row block a wave converts its share of the operands — units of 8 rows x 1 column, one
+// 16-byte LDS slot per piece: 3 units per lane at C = 256, 2 at C = 128, every lane of every wave busy — and multiplies
+// 2 x CT output tiles (2 dy tiles x CT x tiles).
 //   * conversion slot 0 of wave w = the dy half-block (row group w/2, 64 columns (w%2)·64 ..), slots 1.. = x half-blocks
 //     w + 8(k-1) of the 4 row groups x 2·CT half-blocks: roles are compile-time, a slot has one row group; global loads are
 //     dword-per-lane over 64 consecutive columns (256 contiguous bytes per row and instruction) through a raw buffer
@@ -619,15 +329,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_x3_k(const float *__re
 //   * the two co-resident waves of a SIMD run the same stream, and a wave is in-order: what overlaps the matrix pipe, the
 //     vector ALU and the memory pipe is the MIX inside the stream — a pair of rows converted every few MFMAs, one load at a
 //     time behind it (program order pinned by sched_barrier).
-// Measured (same box each, µs per launch at C = 256 / 128, in the training step): wgrad_x3_k 190 / 108, this kernel 179 / 81.
-// Structures tried on the way: conversion in three lumps between groups of four MFMAs 179 / 81; conversion and MFMAs in
-// separate halves of the block 222 / 100, ping-ponged between the two waves of a SIMD 209 / 95; a second register set
-// (requests two blocks ahead): no change; non-temporal loads (SN_X_WGU_NT=1): within the run-to-run spread; two fp16 pieces with online per-column power-of-two scales (three products instead
-// of six, exact, more accurate against fp64 than this kernel — commit 60f60e6): 186 / 95, i.e. halving the matrix work buys
-// nothing.  Ablations at 322 624 rows, C = 256 (tools/scratch/wgrad_ab.sh, builds with SN_X_WGU_*): memory path alone (no
-// conversion, no MFMA) 101-107 µs, everything but the global loads 93 µs, loads + MFMAs 134-158 µs, all of it 157-175 µs:
-// the matrix work and the HBM stream do not hide each other on this chip (the same "components add" the forward GEMMs
-// showed, §6 of DESIGN.md) — what is left to gain is fewer instructions, not a better overlap.
+// Measurements, the structures tried on the way and the ablation builds: LABNOTES k22.
 // ------------------------------------------------------------------------------------------------
 template <int I>
 struct WIC {
@@ -658,7 +360,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
   __shared__ u4 img[2][3][4 * PL];           // [buffer][piece][slot]; one block = 32 rows = 4 row groups
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  int64_t r0, r1;                            // row slab of this workgroup: from the caller's table (ragged meshes), or as wgrad_x3_k
+  int64_t r0, r1;                            // row slab of this workgroup: from the caller's table (ragged meshes), or an even split
   if (slab_off) {
     r0 = slab_off[blockIdx.x];
     r1 = slab_off[blockIdx.x + 1];
@@ -695,8 +397,8 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
   // my column inside a 64-column half-block = my lane: consecutive lanes read consecutive dwords (a permutation that made
   // the ds_write_b128 groups conflict-free — lane = column is two-way conflicted on 30 % of the LDS cycles, still under the
   // store's own VGPR-transfer time — left each lane quad 16 bytes apart and cost the loads 20 %: 127 against 101 µs for the
-  // memory path alone at 322 624 rows, SN_X_WGU_PERM=1)
-  const int lcol = SN_X_WGU_PERM ? 4 * (4 * (lane >> 4) + (lane & 3)) + 2 * ((lane >> 3) & 1) + ((lane >> 2) & 1) : lane;
+  // memory path alone at 322 624 rows)
+  const int lcol = lane;
   int s_rg[NK];                  // row group of the block (scalar)
   const float *s_cur[NK];        // operand + first column of the half-block + first row of the slot in the block to load next
   int l_voff[NK];                // my byte offset in a row of the half-block; past any extent if my dy column does not exist
@@ -726,10 +428,6 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
   auto conv_pair = [&](auto sc, auto kc, auto pc) {
     constexpr int set = decltype(sc)::value, k = decltype(kc)::value, p = decltype(pc)::value;
     f2 xv = {raw[set][k][2 * p], raw[set][k][2 * p + 1]};
-#if SN_X_WGU_NOCONV          // ablation builds only (tools/scratch/wgrad_ab.sh)
-    cH[k][p] = cM[k][p] = cL[k][p] = __float_as_uint(xv.x + xv.y);
-    return;
-#endif
     if constexpr (k == 0) l_sum += xv.x + xv.y;
     else xv -= f2{l_mu[k], l_mu[k]};
     const u2v xb = __builtin_bit_cast(u2v, xv);
@@ -764,10 +462,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
   auto load_row = [&](auto sc, auto kc, auto jc) {
     constexpr int set = decltype(sc)::value, k = decltype(kc)::value, j = decltype(jc)::value;
     const int rstep = k == 0 ? dy_rstep : x_rstep;
-#if SN_X_WGU_NOLOAD
-    if (s_rg[k] >= 0) return;
-#endif
-    raw[set][k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rs[k], l_voff[k] + j * rstep, 0, SN_X_WGU_NT ? 2 : 0));
+    raw[set][k][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rs[k], l_voff[k] + j * rstep, 0, 0));
   };
   // The other work of a block, dealt out behind its MFMAs (m = 0 .. NM-1) — the two co-resident waves of a SIMD run this
   // same stream and a wave is in-order, so what overlaps the matrix pipe, the vector ALU and the memory pipe is the mix
@@ -811,11 +506,7 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
       constexpr int m = decltype(mc)::value, g = m / (2 * CT), st = g / 6, t = g % 6;
       constexpr int a = (m % (2 * CT)) / CT, c = m % CT;
       constexpr int pa = (0x001102 >> (4 * t)) & 15, pb = (0x010120 >> (4 * t)) & 15;
-#if !SN_X_WGU_NOMFMA
-      if constexpr (!SN_X_WGU_HALF || t < 3) acc[a][c] = mfma_bf16(A[st][a][pa], B[st][c][pb], acc[a][c]);
-#else
-      acc[a][c][m % 16] += __uint_as_float(A[st][a][pa].x ^ B[st][c][pb].x);
-#endif
+      acc[a][c] = mfma_bf16(A[st][a][pa], B[st][c][pb], acc[a][c]);
       behind_mfma(WIC<0>{}, WIC<buf ^ 1>{}, mc, b + 2);
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -851,261 +542,6 @@ __global__ __launch_bounds__(kWgradThreads, 1) void wgrad_u_k(const float *__res
         P[(int64_t)jr * C + 32 * (CT * gb + c) + i] = acc[a][c][e];
       }
 #undef SN_BLOCK_BARRIER
-}
-
-// ------------------------------------------------------------------------------------------------
-// wgrad_d_k — the uniform-wave split-bf16 weight gradient with the operands brought in by LDS-DMA (SN_WGRAD_VARIANT=3).
-//
-// What held wgrad_u_k at 4.1-4.4 TB/s is its memory path: the rows in flight live in registers (one 32-row block per
-// workgroup, 49 KB per CU, requested one dword load at a time between MFMAs) — the path alone ran at 4.7 TB/s.  Here the raw
-// fp32 rows never pass through registers on their way in: every wave issues its share of 1-KiB buffer_load ... lds
-// instructions THREE 16-row blocks ahead (a ring of three raw blocks in LDS, 74 KB at C = 256; rows past the slab end read 0
-// through the buffer's extent), the only vector-memory traffic of a wave until the final store — so a partial s_waitcnt
-// vmcnt leaves two blocks in flight behind the barrier.  Conversion reads the raw block column-wise (8 rows of one column per
-// lane: eight conflict-free ds_read_b32) and writes the three bf16 pieces as before; blocks are 16 rows (one MFMA k-step),
-// two images of 2 row groups (77 KB).  Same arithmetic as wgrad_u_k: same pieces, same six products per term, same order
-// inside a tile — bit-identical partials for equal slabs.
-// MEASURED SLOWER (round 3, same box, kernels.wgrad incl. its reduction): 356 against 256 us at 627 200 rows x 256 columns,
-// 199 against 150 us at 322 624 rows — 2.3 us per 16-row block where the matrix work of a block is 0.64 us and its bytes
-// 1.1 us at a CU's share of the bandwidth: with one k-step per barrier the chain barrier -> fragment reads -> MFMAs with the
-// conversion's LDS round trips in between is not covered by the second wave of the SIMD.  Kept as SN_WGRAD_VARIANT=3 (plain
-// slabs only) for the record; wgrad_u_k stays the default.
-// ------------------------------------------------------------------------------------------------
-// 16 bytes per lane from a buffer resource straight into LDS (buffer_load_dwordx4 ... lds: 1 KiB per wave instruction, lane l
-// lands at lds + 16 l; offsets past the resource's extent read 0).  The builtin exists in the device pass only.
-__device__ __forceinline__ void buffer_dma16(__amdgpu_buffer_rsrc_t rs, float *lds, int voff) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds, 16, voff, 0, 0, 0);
-#else
-  (void)rs, (void)lds, (void)voff;
-#endif
-}
-
-template <int CT /* C / 128: 1 or 2 */>
-__global__ __launch_bounds__(kWgradThreads, 1) void wgrad_d_k(const float *__restrict__ dy, int64_t lddy,
-                                                              const float *__restrict__ x, int64_t ldx,
-                                                              const float *__restrict__ center, int64_t rows, int J, int C,
-                                                              float *__restrict__ partial /* [grid][128][C] */,
-                                                              float *__restrict__ colpart /* [grid][128] | NULL */,
-                                                              int64_t seg_rows /* 0: even split of all rows */, int spm,
-                                                              const int64_t *__restrict__ slab_off /* [grid + 1] | NULL */) {
-  constexpr int NCG = 32 + 32 * CT;          // column groups of 4: 32 of dy, 32·CT of x
-  constexpr int QP = NCG + 4;                // slots per (column % 4) plane; QP % 16 == 4 keeps fragment reads conflict-free
-  constexpr int PL = 4 * QP;                 // slots per row group (8 rows)
-  constexpr int XW = 128 * CT;               // x columns
-  constexpr int NM = 12 * CT;                // MFMAs per wave and 16-row block
-  constexpr int NRAW = 3;                    // raw blocks in the ring
-  constexpr int NPW = 1 + CT;                // DMA instructions per wave and block (8 waves: 8 of dy + 8·CT of x)
-  constexpr int RAWF = 16 * (128 + XW);      // floats of one raw block: dy rows [16][128], then x rows [16][XW]
-  static_assert(QP % 16 == 4, "slot permutation");
-  __shared__ u4 img[2][3][2 * PL];           // [buffer][piece][slot]; one block = 16 rows = 2 row groups
-  __shared__ __attribute__((aligned(16))) float raw[NRAW][RAWF];
-  const int tid = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  int64_t r0, r1;                            // row slab of this workgroup (as wgrad_u_k)
-  if (slab_off) {
-    r0 = slab_off[blockIdx.x];
-    r1 = slab_off[blockIdx.x + 1];
-  } else if (seg_rows > 0) {
-    const int64_t mesh = blockIdx.x / spm, part = blockIdx.x % spm;
-    int64_t per = (seg_rows + spm - 1) / spm;
-    per = (per + 15) & ~(int64_t)15;
-    const int64_t mend = (mesh + 1) * seg_rows < rows ? (mesh + 1) * seg_rows : rows;
-    r0 = mesh * seg_rows + part * per;
-    r1 = r0 + per < mend ? r0 + per : mend;
-  } else {
-    int64_t per = (rows + gridDim.x - 1) / gridDim.x;
-    per = (per + 15) & ~(int64_t)15;
-    r0 = (int64_t)blockIdx.x * per;
-    r1 = r0 + per < rows ? r0 + per : rows;
-  }
-  const int nblocks = r1 > r0 ? (int)((r1 - r0 + 15) / 16) : 0;
-  const int span = r1 > r0 ? (int)(r1 - r0) : 0;
-  float *P = partial + (int64_t)blockIdx.x * 128 * C;
-
-  // ---- matrix role: dy tiles 2·ga, 2·ga + 1  x  x tiles CT·gb .. CT·gb + CT - 1 ----
-  const int i = lane & 31, kh = lane >> 5;
-  const int ga = wave >> 2, gb = wave & 3;
-  const int fo = kh * PL + (i & 3) * QP + (i >> 2);          // my fragment slot: + 8·(tile in column groups of 32)
-  f16v acc[2][CT];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < CT; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
-
-  // ---- DMA role: instruction w of a block = dy rows (2w, 2w+1); then x rows: CT = 2: rows w and w + 8 (one 1-KiB row each),
-  //      CT = 1: rows (2w, 2w+1).  Lane offsets inside the block are constants; a dy column >= J is past every extent. ----
-  const int dy_rstep = 4 * (int)lddy, x_rstep = 4 * (int)ldx;
-  const int dy_c = (lane & 31) * 4;
-  const int dy_voff = (dy_c < J) ? (2 * wave + (lane >> 5)) * dy_rstep + 4 * dy_c : 0x7fffff00;
-  int x_voff[CT];
-  if constexpr (CT == 2) {
-    x_voff[0] = wave * x_rstep + 16 * lane;
-    x_voff[1] = (wave + 8) * x_rstep + 16 * lane;
-  } else {
-    x_voff[0] = (2 * wave + (lane >> 5)) * x_rstep + 16 * (lane & 31);
-  }
-  auto issue_block = [&](int b) {                             // NPW instructions, whatever b (blocks past the slab: extent 0)
-    int left = span - 16 * b;
-    left = left < 0 ? 0 : (left > 16 ? 16 : left);
-    const int slot = b % NRAW;
-    const int e_dy = __builtin_amdgcn_readfirstlane(left * dy_rstep), e_x = __builtin_amdgcn_readfirstlane(left * x_rstep);
-    const int64_t rb = r0 + (int64_t)16 * (left ? b : 0);
-    __amdgpu_buffer_rsrc_t rs_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(dy + rb * lddy), 0, e_dy, 0x00020000);
-    __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + rb * ldx), 0, e_x, 0x00020000);
-    float *rw = &raw[slot][0];
-    buffer_dma16(rs_dy, rw + 2 * wave * 128, dy_voff);
-    if constexpr (CT == 2) {
-      buffer_dma16(rs_x, rw + 16 * 128 + wave * XW, x_voff[0]);
-      buffer_dma16(rs_x, rw + 16 * 128 + (wave + 8) * XW, x_voff[1]);
-    } else {
-      buffer_dma16(rs_x, rw + 16 * 128 + 2 * wave * XW, x_voff[0]);
-    }
-  };
-
-  // ---- conversion role: units of 8 rows x 64 columns (one column per lane).  A block has 4 dy units (row group u/2, half
-  //      u%2) and 4·CT x units (row group, 64-column chunk).  Wave w takes unit w; at CT = 2 the other four x units go to waves
-  //      0-3 on even blocks and to waves 4-7 on odd ones. ----
-  float l_sum = 0.f;                                          // running sum of my dy column (waves 0-3: their unit is a dy unit)
-  float rv[8];
-  u4 cH, cM, cL;
-  typedef float f2 __attribute__((ext_vector_type(2)));
-  typedef unsigned int u2v __attribute__((ext_vector_type(2)));
-  struct Unit { int src_off; int rstride; int slot; float mu; bool isdy; };      // src_off: floats from the start of a raw block
-  auto unit_of = [&](int u) -> Unit {                         // u in 0 .. 4 + 4·CT - 1
-    Unit t;
-    if (u < 4) {
-      const int rg = u >> 1, c = 64 * (u & 1) + lane;
-      t.src_off = (8 * rg) * 128 + c;
-      t.rstride = 128;
-      t.slot = rg * PL + (c & 3) * QP + (c >> 2);
-      t.mu = 0.f;
-      t.isdy = true;
-    } else {
-      const int v = u - 4, rg = v / (2 * CT), c = 64 * (v % (2 * CT)) + lane;
-      t.src_off = 16 * 128 + (8 * rg) * XW + c;
-      t.rstride = XW;
-      t.slot = rg * PL + ((128 + c) & 3) * QP + ((128 + c) >> 2);
-      t.mu = center ? center[c] : 0.f;
-      t.isdy = false;
-    }
-    return t;
-  };
-  // the units of this wave are fixed (their centres are loaded once, BEFORE any DMA is in flight: the wave's vmcnt then
-  // counts DMA only)
-  const Unit t0 = unit_of(wave);
-  const Unit t1 = unit_of(CT == 2 ? 8 + (wave & 3) : wave);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  const float *rbase = nullptr;                                // raw block being converted
-  auto conv_read = [&](const Unit &t) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) rv[j] = rbase[t.src_off + j * t.rstride];
-  };
-  auto conv_pair = [&](const Unit &t, int p) {
-    f2 xv = {rv[2 * p], rv[2 * p + 1]};
-    if (t.isdy) l_sum += xv.x + xv.y;
-    else xv -= f2{t.mu, t.mu};
-    const u2v xb = __builtin_bit_cast(u2v, xv);
-    const f2 r = xv - __builtin_bit_cast(f2, xb & 0xFFFF0000u);
-    const u2v rbits = __builtin_bit_cast(u2v, r);
-    const f2 l = r - __builtin_bit_cast(f2, rbits & 0xFFFF0000u);
-    const u2v lb = __builtin_bit_cast(u2v, l);
-    cH[p] = __builtin_amdgcn_perm(xb.y, xb.x, 0x07060302u);
-    cM[p] = __builtin_amdgcn_perm(rbits.y, rbits.x, 0x07060302u);
-    cL[p] = __builtin_amdgcn_perm(lb.y, lb.x, 0x07060302u);
-  };
-  auto conv_write = [&](const Unit &t, int buf) {
-    img[buf][0][t.slot] = cH;
-    img[buf][1][t.slot] = cM;
-    img[buf][2][t.slot] = cL;
-  };
-  auto convert_unit = [&](const Unit &t, int rawslot, int buf) {      // the whole unit in one go (prologue)
-    rbase = &raw[rawslot][0];
-    conv_read(t);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) conv_pair(t, p);
-    conv_write(t, buf);
-  };
-  // second unit of this wave in block b (CT = 2 only): waves 0-3 on even blocks, 4-7 on odd ones (unit 8 + (wave & 3))
-  auto has_second = [&](int b) -> bool {
-    if constexpr (CT == 1) return false;
-    return (wave >> 2) == (b & 1);
-  };
-
-#define SN_WD_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-  auto wait_dma = [&]() {                                     // everything but the newest block of this wave's DMA has landed
-    if constexpr (NPW == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  };
-  auto multiply_block = [&](auto pc, int b) {
-    constexpr int buf = decltype(pc)::value;                  // block b = image buf = b & 1
-    wait_dma();                                               // my share of raw block b + 1 has landed ...
-    SN_WD_BARRIER();                                          // ... everyone's has; image buf is complete; image buf^1 and raw slot b % 3 are free
-    issue_block(b + 3);
-    u4 A[2][3], B[CT][3];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-#pragma unroll
-      for (int a = 0; a < 2; ++a) A[a][p] = img[buf][p][fo + 8 * (2 * ga + a)];
-#pragma unroll
-      for (int c = 0; c < CT; ++c) B[c][p] = img[buf][p][fo + 32 + 8 * (CT * gb + c)];
-    }
-    // conversion of raw block b + 1 into the other image, dealt out behind the MFMAs
-    rbase = &raw[(b + 1) % NRAW][0];
-    const bool two = has_second(b + 1);
-    wstatic_for<0, NM>([&](auto mc) {
-      constexpr int m = decltype(mc)::value, t = m / (2 * CT);
-      constexpr int a = (m % (2 * CT)) / CT, c = m % CT;
-      constexpr int pa = (0x001102 >> (4 * t)) & 15, pb = (0x010120 >> (4 * t)) & 15;
-      acc[a][c] = mfma_bf16(A[a][pa], B[c][pb], acc[a][c]);
-      // first unit: reads behind MFMA 0, a pair of rows behind MFMAs 2, 4, 6, 8 (CT = 1: 2, 4, 6, 8), slots behind MFMA 10
-      if constexpr (m == 0) conv_read(t0);
-      if constexpr (m >= 2 && m <= 8 && m % 2 == 0) conv_pair(t0, (m - 2) / 2);
-      if constexpr (m == 10) conv_write(t0, buf ^ 1);
-      if constexpr (CT == 2) {
-        if (two) {                                            // (wave-uniform)
-          if constexpr (m == 11) conv_read(t1);
-          if constexpr (m >= 13 && m <= 19 && m % 2 == 1) conv_pair(t1, (m - 13) / 2);
-          if constexpr (m == 21) conv_write(t1, buf ^ 1);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    });
-  };
-  if (nblocks > 0) {
-    issue_block(0);
-    issue_block(1);
-    issue_block(2);
-    if constexpr (NPW == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");      // raw block 0 has landed (mine)
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    SN_WD_BARRIER();                                                              // (everyone's)
-    convert_unit(t0, 0, 0);
-    if (has_second(0)) convert_unit(t1, 0, 0);
-    for (int b = 0; b < nblocks; b += 2) {
-      multiply_block(WIC<0>{}, b);
-      if (b + 1 < nblocks) multiply_block(WIC<1>{}, b + 1);
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // nothing may land in LDS after the workgroup has gone
-  if (colpart) {                             // bias gradient: column sums of dy — waves 0-3 hold (row group, column) entries
-    __syncthreads();
-    float *sm = reinterpret_cast<float *>(&img[0][0][0]);
-    if (wave < 4) sm[(wave >> 1) * 128 + 64 * (wave & 1) + lane] = l_sum;
-    __syncthreads();
-    if (tid < 128) colpart[(int64_t)blockIdx.x * 128 + tid] = sm[tid] + sm[128 + tid];
-  }
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int c = 0; c < CT; ++c)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int jr = 32 * (2 * ga + a) + (e & 3) + 8 * (e >> 2) + 4 * kh;
-        P[(int64_t)jr * C + 32 * (CT * gb + c) + i] = acc[a][c][e];
-      }
-#undef SN_WD_BARRIER
 }
 
 __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ partial, int nslab, int J, int C,
@@ -1151,182 +587,6 @@ __global__ __launch_bounds__(kWG) void wgrad_reduce_k(const float *__restrict__ 
     if (i < nG) G[i] = (float)r;
     else if (colpart && i < nG + J) dysum[i - nG] = r;
     else if (src) segsum[i - nG - J] = (float)r;
-  }
-}
-
-// The split-K reduction AND the BatchNorm backward coefficients in one launch (training step, local statistics): replaces
-// wgrad_reduce_k -> [avg_bwd_gc_k ->] bn_bwd_coeffs_k, a chain of dependent 5-6 us launches behind every weight gradient.
-// grid (Ct / 32, ceil(J / 2)): workgroup (bx, by) owns channels 32 bx .. +31 of rows j = 2 by, 2 by + 1 — lane o: channel o & 31,
-// row o >> 5 — and
-//   * sums its 64 elements of G over the slabs (channels < C; the four waves take every fourth slab, eight loads in flight:
-//     wgrad_reduce_k's order of addition) or forms them from the per-mesh column sums of dy (channels >= C, the broadcast half
-//     of a global-average stage: sum_mesh Sg[mesh][j] (m[mesh][c] - mu2[c]), avg_bwd_gc_k's order), the column sums of dy of
-//     its two rows alongside (every workgroup its own copy: the same loads, broadcast);
-//   * writes dW = G s + colsum(dy) beta for its elements, G itself and its copy of the column sums to scratch;
-//   * takes a ticket of its channel group; the workgroup that draws the LAST one of the group (all rows of these 32 channels
-//     are then in scratch) finishes them as bn_bwd_coeffs_k does — the two sums over j in that kernel's order (8 row groups,
-//     fixed combination) -> dgamma, dbeta, B, C.  No workgroup waits for another; the counters return to 0.
-// Results are bit-identical to the launches replaced (tests/test_dense_gpu.py).
-struct WgradFinish {
-  const float *W;                            // [J][Ct]
-  const float *s, *invstd, *beta;            // [Ct]
-  int64_t rows;                              // rows behind the BatchNorm statistics
-  int Ct;                                    // C, or 2 C (global-average stage: the second half is the per-mesh constant)
-  const float *m, *mu2;                      // Ct == 2 C: per-mesh means [nseg][C], their BatchNorm mean [C]
-  int nseg;
-  float *Gc;                                 // [J][Ct] out (scratch for the tail; also what wgrad_reduce_k + avg_bwd_gc_k left)
-  double *sdyc;                              // [Ct / 32][J] scratch: every channel group's copy of colsum(dy)
-  float *dW, *db, *dgamma, *dbeta, *Bc, *Cc;
-  int *counters;                             // [Ct / 32], zero on entry and on exit
-};
-__device__ __forceinline__ float ld_agent(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ double ld_agent(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_agent(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__global__ __launch_bounds__(kWG) void wgrad_finish_k(const float *__restrict__ partial, const float *__restrict__ colpart, int nslab,
-                                                      int J, int C, double *__restrict__ dysum,
-                                                      float *__restrict__ segsum /* [nseg][J] | NULL */, int spm,
-                                                      const int64_t *__restrict__ seg_slab_ptr /* [nseg + 1] | NULL */,
-                                                      WgradFinish a) {
-  __shared__ double sm[4][64], sd[4][64];
-  __shared__ float s_sg[2][128];
-  __shared__ double sa[8][32], sp[8][32];
-  __shared__ int ticket;
-  const int tid = threadIdx.x, o = tid & 63, g = tid >> 6;
-  const int bx = blockIdx.x, Ct = a.Ct;
-  const int c = 32 * bx + (o & 31), j = 2 * (int)blockIdx.y + (o >> 5);
-  const bool jok = j < J;
-  const bool first = 32 * bx < C;               // (workgroup-uniform)
-  double t = 0, td = 0;
-  if (jok) {
-    const float *cp = colpart + j;              // [slab][128]
-    int sl = g;
-    if (first) {                                // (two loops, branch-free inside: a select on `first` serialised the loads)
-      const float *src = partial + (int64_t)j * C + c;
-      const int64_t stride = (int64_t)128 * C;
-      for (; sl + 28 < nslab; sl += 32) {
-        float v[8], w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          v[u] = src[(int64_t)(sl + 4 * u) * stride];
-          w[u] = cp[(int64_t)(sl + 4 * u) * 128];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          t += (double)v[u];
-          td += (double)w[u];
-        }
-      }
-      for (; sl < nslab; sl += 4) {
-        t += (double)src[(int64_t)sl * stride];
-        td += (double)cp[(int64_t)sl * 128];
-      }
-    } else {
-      for (; sl + 28 < nslab; sl += 32) {
-        float w[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = cp[(int64_t)(sl + 4 * u) * 128];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) td += (double)w[u];
-      }
-      for (; sl < nslab; sl += 4) td += (double)cp[(int64_t)sl * 128];
-    }
-  }
-  sm[g][o] = t;
-  sd[g][o] = td;
-  __syncthreads();
-  double gacc = 0;
-  if (!first) {
-    // the broadcast half: per-mesh column sums of dy of my two rows (a mesh's consecutive slabs, wgrad_reduce_k's order), 128
-    // meshes at a time through LDS; the first such channel group also publishes them
-    const int C2 = Ct - C, c2 = c - C;
-    const int mj = 2 * (int)blockIdx.y + (tid >> 7);
-    for (int base = 0; base < a.nseg; base += 128) {
-      const int mesh = base + (tid & 127);
-      if (mesh < a.nseg && mj < J) {
-        const int64_t p0 = seg_slab_ptr ? seg_slab_ptr[mesh] : (int64_t)mesh * spm;
-        const int cnt = (int)((seg_slab_ptr ? seg_slab_ptr[mesh + 1] : p0 + spm) - p0);
-        const float *q = colpart + p0 * 128 + mj;
-        double tw[4] = {0, 0, 0, 0};
-        for (int k = 0; k < cnt; ++k) tw[k & 3] += (double)q[(int64_t)k * 128];
-        const float r = (float)(tw[0] + tw[1] + tw[2] + tw[3]);
-        s_sg[tid >> 7][tid & 127] = r;
-        if (32 * bx == C && segsum) segsum[(int64_t)mesh * J + mj] = r;
-      }
-      __syncthreads();
-      if (g == 0 && jok) {
-        const int lim = a.nseg - base < 128 ? a.nseg - base : 128;
-        const double mu = (double)a.mu2[c2];
-#pragma unroll 16
-        for (int k = 0; k < lim; ++k) gacc += (double)s_sg[o >> 5][k] * ((double)a.m[(int64_t)(base + k) * C2 + c2] - mu);
-      }
-      __syncthreads();
-    }
-  }
-  if (g == 0 && jok) {
-    const double r = sm[0][o] + sm[1][o] + sm[2][o] + sm[3][o];
-    const double sdy = sd[0][o] + sd[1][o] + sd[2][o] + sd[3][o];
-    const float ggf = first ? (float)r : (float)gacc;
-    const double gg = ggf, sc = a.s[c], bc = a.beta[c];
-    st_agent(a.Gc + (int64_t)j * Ct + c, ggf);
-    a.dW[(int64_t)j * Ct + c] = (float)(gg * sc + sdy * bc);
-    if ((o & 31) == 0) {
-      st_agent(a.sdyc + (int64_t)bx * J + j, sdy);
-      if (bx == 0) {
-        if (a.db) a.db[j] = (float)sdy;
-        if (dysum) dysum[j] = sdy;
-      }
-    }
-  }
-  // My rows of this channel group must be visible device-wide before my ticket is.  A release fence at agent scope would write
-  // back this XCD's whole L2 — 33 MB of split-K partials the product has just left there — once per workgroup (measured: 60-68
-  // us per launch instead of 6).  Instead the two scratch arrays are written with agent-scope stores (write-through to the
-  // memory side, where the XCDs meet), the ticket is drawn once those have been acknowledged, and the last workgroup reads them
-  // with agent-scope loads (past its own L2).
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) ticket = __hip_atomic_fetch_add(a.counters + bx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  if (ticket != (int)gridDim.y - 1) return;
-  // ---- the last workgroup of the channel group: bn_bwd_coeffs_k for its 32 channels ----
-  if (tid == 0) __hip_atomic_store(a.counters + bx, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const int cl = tid & 31, gq = tid >> 5;
-  const int cc = 32 * bx + cl;
-  double aa = 0, pp = 0;
-  for (int j0 = gq; j0 < J; j0 += 64) {          // eight rows of the group at a time, their loads in flight together
-    float w[8], gv[8];
-    double sv[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {              // (unconditional loads from a clamped row: a select would serialise them)
-      const int jj = j0 + 8 * u < J ? j0 + 8 * u : J - 1;
-      w[u] = a.W[(int64_t)jj * Ct + cc];
-      gv[u] = ld_agent(a.Gc + (int64_t)jj * Ct + cc);      // (written by other workgroups of this launch)
-      sv[u] = ld_agent(a.sdyc + (int64_t)bx * J + jj);
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (j0 + 8 * u < J) {
-        const double wd = w[u], gd = gv[u];
-        aa += sv[u] * wd;
-        pp += wd * gd;
-      }
-  }
-  sa[gq][cl] = aa;
-  sp[gq][cl] = pp;
-  __syncthreads();
-  if (gq == 0) {
-    double at = 0, pt = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      at += sa[i][cl];
-      pt += sp[i][cl];
-    }
-    const double sc = a.s[cc], is = a.invstd[cc];
-    const double dg = is * pt;
-    a.dgamma[cc] = (float)dg;
-    a.dbeta[cc] = (float)at;
-    a.Bc[cc] = (float)(-(sc * is * dg) / (double)a.rows);
-    a.Cc[cc] = (float)(-(sc * at) / (double)a.rows);
   }
 }
 
@@ -1440,10 +700,7 @@ __global__ __launch_bounds__(kWG) void wgrad_thin_final_k(const double *__restri
 // backward: gout = (gloss*scale) * mask[r] * clamp(out*mask - target, -1, 1), one pass.
 // (torch runs mask-multiply, loss, reduction, loss-backward, mask-multiply as five elementwise passes.)
 // ------------------------------------------------------------------------------------------------
-#ifndef SN_X_LOSS_BLOCKS
-#define SN_X_LOSS_BLOCKS 1024
-#endif
-constexpr int kLossBlocks = SN_X_LOSS_BLOCKS;
+constexpr int kLossBlocks = 1024;
 
 __device__ __forceinline__ double sl1(float d) {
   const float a = fabsf(d);
@@ -1738,119 +995,6 @@ __global__ __launch_bounds__(kWG) void bn_fold_k(const double *__restrict__ stat
         segb[(int64_t)(g0 + threadIdx.x) * J + j] = (float)acc;
       }
     }
-  }
-}
-
-// The statistics reduction and the fold in ONE launch (training mode): replaces colstats_final_k (once per half of a concat
-// buffer) + bn_fold_k — three dependent launches of 4-5 us in front of every Linear of a small batch.  The column statistics
-// arrive as per-workgroup partials of up to two producers ([nblk][2][Cx] fp64 each: the ELU epilogue of the previous GEMM, the
-// statistics epilogue of the SpMM, or colstats_k): workgroup b reduces channels 16 b .. 16 b + 15 (both kinds, 8 row groups,
-// fixed order), publishes their mean / invstd / s / t and updates the running statistics; the workgroup that finishes LAST
-// (a ticket from `counter`, which it leaves at 0 for the next launch) folds the weights: no workgroup waits for another.
-struct BnPart {
-  const double *p;       // [nblk][2][C] (NULL / nblk = 0: the columns are all zero)
-  int nblk, C;
-};
-__global__ __launch_bounds__(kWG) void bn_fold_parts_k(BnPart lo, BnPart hi, int64_t rows, const float *__restrict__ gamma,
-                                                       const float *__restrict__ beta, const float *__restrict__ W,
-                                                       const float *__restrict__ b, int J, int C, double eps, double momentum,
-                                                       float *__restrict__ running_mean, float *__restrict__ running_var,
-                                                       int64_t *__restrict__ num_batches_tracked, float *__restrict__ mean_o,
-                                                       float *__restrict__ invstd_o, float *s_o, float *t_o,
-                                                       float *__restrict__ Wf, float *__restrict__ bf, int *counter) {
-  __shared__ double sm[8][32];
-  __shared__ double dots[64][65];
-  __shared__ float ss[256], st[256];
-  __shared__ int ticket;
-  const int tid = threadIdx.x;
-  {
-    const int ch = tid & 15, kind = (tid >> 4) & 1, g = tid >> 5;
-    const int c = blockIdx.x * 16 + ch;
-    double t = 0;
-    if (c < C) {
-      const BnPart &src = c < lo.C ? lo : hi;
-      const int col = c < lo.C ? c : c - lo.C;
-      const double *p = src.p + (int64_t)kind * src.C + col;
-      const int64_t stride = 2 * (int64_t)src.C;
-      int r = g;
-      for (; r + 56 < src.nblk; r += 64) {       // eight loads in flight, added in the original order
-        double v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[(int64_t)(r + 8 * u) * stride];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) t += v[u];
-      }
-      for (; r < src.nblk; r += 8) t += p[(int64_t)r * stride];
-    }
-    sm[g][tid & 31] = t;
-  }
-  __syncthreads();
-  if (tid < 16 && blockIdx.x * 16 + tid < C) {
-    const int c = blockIdx.x * 16 + tid;
-    double sum = 0, sq = 0;
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {
-      sum += sm[g][tid];
-      sq += sm[g][16 + tid];
-    }
-    const double mean = sum / (double)rows;
-    double var = sq / (double)rows - mean * mean;
-    var = var > 0 ? var : 0;
-    const double invstd = 1.0 / sqrt(var + eps);
-    const double sc = (double)gamma[c] * invstd;
-    const double tc = (double)beta[c] - mean * sc;
-    mean_o[c] = (float)mean;
-    invstd_o[c] = (float)invstd;
-    s_o[c] = (float)sc;
-    t_o[c] = (float)tc;
-    if (running_mean) {
-      const double unbiased = var * ((double)rows / (double)(rows > 1 ? rows - 1 : 1));
-      running_mean[c] = (float)((1.0 - momentum) * (double)running_mean[c] + momentum * mean);
-      running_var[c] = (float)((1.0 - momentum) * (double)running_var[c] + momentum * unbiased);
-    }
-  }
-  if (blockIdx.x == 0 && tid == 0 && num_batches_tracked) num_batches_tracked[0] += 1;      // nn.BatchNorm1d's counter
-  __threadfence();                               // my channels' scalars are visible device-wide before my ticket is
-  __syncthreads();
-  if (tid == 0) ticket = atomicAdd(counter, 1);
-  __syncthreads();
-  if (ticket != (int)gridDim.x - 1) return;
-  // ---- the last workgroup: every channel's s and t are published ----
-  __threadfence();
-  if (tid == 0) *counter = 0;
-  for (int c = tid; c < C; c += kWG) {           // (read past this CU's vector cache: written by other workgroups of this launch)
-    ss[c] = __builtin_nontemporal_load(s_o + c);
-    st[c] = __builtin_nontemporal_load(t_o + c);
-  }
-  __syncthreads();
-  // Wf = W·diag(s), bf = b + W·t (fp64 sum), 64 rows of W at a time: C/4 lanes per row, every lane's rows loaded at once (one
-  // memory latency per 64 rows), the lanes' partial dot products summed per row through LDS in a fixed order
-  const int lpr = C >> 2, rpi = kWG / lpr;       // lanes per row (32 | 64), rows per pass of the workgroup (8 | 4)
-  const int rl = tid / lpr, ln = tid - rl * lpr, c4 = ln * 4;
-  const f4 s4 = *reinterpret_cast<const f4 *>(ss + c4), t4 = *reinterpret_cast<const f4 *>(st + c4);
-  for (int j0 = 0; j0 < J; j0 += 64) {
-    f4 w[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int jl = rl + rpi * u, j = j0 + jl;
-      w[u] = (jl < 64 && j < J) ? *reinterpret_cast<const f4 *>(W + (int64_t)j * C + c4) : f4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const int jl = rl + rpi * u, j = j0 + jl;
-      if (jl < 64 && j < J) {
-        *reinterpret_cast<f4 *>(Wf + (int64_t)j * C + c4) = w[u] * s4;
-        dots[jl][ln] = ((double)w[u].x * (double)t4.x + (double)w[u].y * (double)t4.y) +
-                       ((double)w[u].z * (double)t4.z + (double)w[u].w * (double)t4.w);
-      }
-    }
-    __syncthreads();
-    if (tid < 64 && j0 + tid < J) {
-      double d = 0;
-      for (int k = 0; k < lpr; ++k) d += dots[tid][k];
-      bf[j0 + tid] = (float)((b ? (double)b[j0 + tid] : 0.0) + d);
-    }
-    __syncthreads();
   }
 }
 
@@ -2416,22 +1560,12 @@ inline int stat_blocks(int64_t rows) {
   return (int)b;
 }
 
-// SN_GEMM_VARIANT (shared with sn_gemm.hip): 0 = the fp32-MFMA kernels (A/B baseline); anything else = the split kernels —
-// the weight gradient always takes three bf16 pieces (its contraction runs over the ROWS, so the per-row power-of-two
-// scaling that makes the two-piece fp16 form of sn_gemm.hip safe does not factor out of it)
+// SN_GEMM_VARIANT (shared with sn_gemm.hip): 0 = the fp32-MFMA kernels, the ONE A/B baseline of the Linear kernels; anything
+// else (default) = the 16-bit matrix-pipe kernels
 inline int gemm_variant() {
   static const int v = [] {
     const char *e = getenv("SN_GEMM_VARIANT");
-    return e ? atoi(e) : 2;
-  }();
-  return v;
-}
-
-// SN_WGRAD_VARIANT: 2 (default) uniform waves (wgrad_u_k), 1 the wave-specialised kernel (wgrad_x3_k); both split-bf16
-inline int wgrad_variant() {
-  static const int v = [] {
-    const char *e = getenv("SN_WGRAD_VARIANT");
-    return e ? atoi(e) : 2;
+    return (e && atoi(e) == 0) ? 0 : 2;
   }();
   return v;
 }
@@ -3407,42 +2541,21 @@ struct WgradBounds {
   const float *xinvstd;
   float xfac;
 };
-// SN_WGRAD_H: -1 never use wgrad_h_k; -2 (default) = 2; else bit 0 = LOW11 (second accumulator, low pieces x 2^11), bit 1 =
-// two blocks in flight instead of one — A/B switch
-inline int wgrad_h_mode() {
-  static const int v = [] {
-    const char *e = getenv("SN_WGRAD_H");
-    return e ? atoi(e) : -2;
-  }();
-  return v;
-}
-
-// SN_WGRAD_INTERLEAVE=1: plain slabs: workgroup b takes the 32-row blocks b, b + grid, ... instead of a contiguous range of
-// rows (what pays for the forward / input-gradient kernels, sn_gemm.hip EpiArgs::interleave).  Default 0: same-box A/B of the
-// config-3 step on three boxes, round 4: -0.07, +0.03, +0.15 ms per step — A/B switch only
-inline int wgrad_interleave() {
-  static const int v = [] {
-    const char *e = getenv("SN_WGRAD_INTERLEAVE");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
 static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows,
                         int32_t J, int32_t C, float *G, double *dysum, int64_t rows_per_seg, float *seg_dysum,
                         void *workspace, size_t workspace_bytes, void *stream, const int64_t *slab_off = nullptr,
                         int32_t nslab_tab = 0, const int64_t *seg_slab_ptr = nullptr, int32_t nseg_tab = 0,
-                        const WgradBounds *bounds = nullptr, const WgradFinish *fin = nullptr) {
+                        const WgradBounds *bounds = nullptr) {
   (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows < 0 || J < 1 || C < 1 || lddy < J || ldx < C) return SN_E_SHAPE;
   if (J > 128 || (J % 4) || (C != 128 && C != 256)) return SN_E_UNSUPPORTED;
-  if (!G && !fin) return SN_E_NULL;
-  if (fin && rows == 0) return SN_E_SHAPE;
+  if (!G) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const bool x3 = gemm_variant() != 0;
   const bool ragged = slab_off != nullptr;                  // slabs and their meshes from the caller's tables
   const bool segmented = rows_per_seg > 0 && !ragged;
-  if (segmented && (!x3 || (!dysum && !fin) || !seg_dysum || rows % rows_per_seg)) return x3 ? SN_E_SHAPE : SN_E_UNSUPPORTED;
-  if (ragged && (nslab_tab < 1 || nseg_tab < 1 || !seg_slab_ptr || (!dysum && !fin) || !seg_dysum)) return SN_E_SHAPE;
+  if (segmented && (!x3 || !dysum || !seg_dysum || rows % rows_per_seg)) return x3 ? SN_E_SHAPE : SN_E_UNSUPPORTED;
+  if (ragged && (nslab_tab < 1 || nseg_tab < 1 || !seg_slab_ptr || !dysum || !seg_dysum)) return SN_E_SHAPE;
   if (rows == 0) {
     hipError_t e = hipMemsetAsync(G, 0, (size_t)J * C * sizeof(float), s);
     if (e == hipSuccess && dysum) e = hipMemsetAsync(dysum, 0, (size_t)J * sizeof(double), s);
@@ -3463,56 +2576,31 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
   if (ragged) nslab = nslab_tab;
   if (workspace_bytes < (size_t)nslab * 128 * ((size_t)C + 1) * sizeof(float)) return SN_E_WORKSPACE;
   float *partial = static_cast<float *>(workspace);
-  float *colpart = (dysum || fin) ? partial + (size_t)nslab * 128 * C : nullptr;
+  float *colpart = dysum ? partial + (size_t)nslab * 128 * C : nullptr;
   const int64_t sr = segmented ? rows_per_seg : 0;
-  const bool uni = x3 && wgrad_variant() >= 2 && lddy < ((int64_t)1 << 24) && ldx < ((int64_t)1 << 24);
-  if (ragged && !uni) return SN_E_UNSUPPORTED;              // slab tables: the uniform-wave kernel only
-  const bool dma = uni && wgrad_variant() == 3 && !ragged && !segmented;      // (experimental kernel: plain slabs only)
+  const bool uni = x3;                                      // the 16-bit matrix-pipe kernels (raw buffer windows)
+  if (uni && (lddy >= ((int64_t)1 << 24) || ldx >= ((int64_t)1 << 24))) return SN_E_UNSUPPORTED;
+  if (ragged && !uni) return SN_E_UNSUPPORTED;              // slab tables: not in the fp32-MFMA baseline
   hipEvent_t t_start = nullptr, t_stop = nullptr;
   if (uni) sn_internal_timing_slot(0x400 | (segmented ? 1 : 0) | (ragged ? 2 : 0), rows, C, rows * 4 * ((int64_t)J + C), J, &t_start, &t_stop);
-  const bool half = uni && !dma && bounds && wgrad_h_mode() != -1;
+  const bool half = uni && bounds;
   if (bounds && ((bounds->ndy > 0 && !bounds->dybound) || bounds->ndy < 0 || !bounds->xinvstd || !(bounds->xfac > 0.f))) return SN_E_NULL;
   if (half) {
-#define SN_WGH(CT_, L_, S_)                                                                                                            \
+#define SN_WGH(CT_)                                                                                                                    \
   do {                                                                                                                                 \
     if (t_start)                                                                                                                       \
-      hipExtLaunchKernelGGL((wgrad_h_k<CT_, L_, S_>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx,   \
+      hipExtLaunchKernelGGL((wgrad_h_k<CT_, false, 2>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx,  \
                             center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off, bounds->dybound, bounds->ndy, bounds->xinvstd, \
-                            bounds->xfac, wgrad_interleave());                                                                                             \
+                            bounds->xfac, 0);                                                                                          \
     else                                                                                                                               \
-      hipLaunchKernelGGL((wgrad_h_k<CT_, L_, S_>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J,    \
-                         (int)C, partial, colpart, sr, spm, slab_off, bounds->dybound, bounds->ndy, bounds->xinvstd, bounds->xfac, wgrad_interleave());  \
+      hipLaunchKernelGGL((wgrad_h_k<CT_, false, 2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J,   \
+                         (int)C, partial, colpart, sr, spm, slab_off, bounds->dybound, bounds->ndy, bounds->xinvstd, bounds->xfac, 0); \
   } while (0)
-    // default: one accumulator, two blocks in flight.  Same box, us per launch incl. the reduction, 627 200 / 322 624 rows:
-    // C = 256: three-piece bf16 335 / 163; this kernel with one block in flight 212 / 111, two 199 / 106, second accumulator
-    // (one block: no registers for two) 222 / 123; C = 128: bf16 187 / 82; one block 152 / 87, two 126 / 74, three 137 / 78,
-    // second accumulator + two blocks 136 / 87.
-    int mode = wgrad_h_mode();
-    if (mode < 0) mode = 2;
-    const int low = mode & 1;
-    int sets = (mode >> 1) + 1;
-    if (sets > 2) sets = 2;
-    if (C == 256 && low) sets = 1;                     // (the second accumulator leaves no registers for a second block at C = 256)
-    const int sel = (C == 256 ? 4 : 0) + 2 * (sets - 1) + low;
-    switch (sel) {
-      case 0: SN_WGH(1, false, 1); break;
-      case 1: SN_WGH(1, true, 1); break;
-      case 2: SN_WGH(1, false, 2); break;
-      case 3: SN_WGH(1, true, 2); break;
-      case 4: SN_WGH(2, false, 1); break;
-      case 5: SN_WGH(2, true, 1); break;
-      default: SN_WGH(2, false, 2); break;
-    }
+    // one accumulator, two 32-row blocks in flight (LABNOTES r4wgrad: the other combinations measured slower)
+    if (C == 256) SN_WGH(2);
+    else SN_WGH(1);
 #undef SN_WGH
-  } else
-  if (dma && C == 128 && t_start)
-    hipExtLaunchKernelGGL((wgrad_d_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
-  else if (dma && t_start)
-    hipExtLaunchKernelGGL((wgrad_d_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
-  else if (dma && C == 128)
-    hipLaunchKernelGGL((wgrad_d_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
-  else if (dma)
-    hipLaunchKernelGGL((wgrad_d_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
+  }
   else if (uni && C == 128 && t_start)
     hipExtLaunchKernelGGL((wgrad_u_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, t_start, t_stop, 0, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
   else if (uni && t_start)
@@ -3521,21 +2609,10 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
     hipLaunchKernelGGL((wgrad_u_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
   else if (uni)
     hipLaunchKernelGGL((wgrad_u_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm, slab_off);
-  else if (x3 && C == 128)
-    hipLaunchKernelGGL((wgrad_x3_k<1>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
-  else if (x3)
-    hipLaunchKernelGGL((wgrad_x3_k<2>), dim3(nslab), dim3(kWgradThreads), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart, sr, spm);
   else if (C == 128)
     hipLaunchKernelGGL((wgrad_mfma_k<1>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
   else
     hipLaunchKernelGGL((wgrad_mfma_k<2>), dim3(nslab), dim3(kWG), 0, s, dy, lddy, x, ldx, center, rows, (int)J, (int)C, partial, colpart);
-  if (fin) {
-    WgradFinish a = *fin;
-    if (a.Ct != C) a.nseg = ragged ? (int)nseg_tab : nslab / spm;
-    hipLaunchKernelGGL(wgrad_finish_k, dim3((unsigned)(a.Ct / 32), (unsigned)((J + 1) / 2)), dim3(kWG), 0, s, partial, colpart,
-                       nslab, (int)J, (int)C, dysum, (segmented || ragged) ? seg_dysum : nullptr, spm, ragged ? seg_slab_ptr : nullptr, a);
-    return launch_status();
-  }
   const int64_t extra = (dysum ? J : 0) + (segmented ? (int64_t)(nslab / spm) * J : 0) + (ragged ? (int64_t)nseg_tab * J : 0);
   hipLaunchKernelGGL(wgrad_reduce_k, dim3((unsigned)((J * C + extra + 63) / 64)), dim3(kWG), 0, s, partial, nslab, (int)J, (int)C, G,
                      colpart, dysum, (segmented || ragged) ? seg_dysum : nullptr, spm, ragged ? seg_slab_ptr : nullptr,
@@ -3616,49 +2693,6 @@ int sn_wgrad_slabs_bounded_f32(const float *dy, int64_t lddy, const float *x, in
   const WgradBounds b = make_bounds(dybound, n_dybound, xinvstd, stat_rows);
   return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, G, dysum, 0, seg_dysum, workspace, workspace_bytes, stream, slab_off,
                       nslab, seg_slab_ptr, nseg, &b);
-}
-
-// Weight gradient of a folded BatchNorm + Linear AND everything the step derives from it, in two launches (the split-K product,
-// then wgrad_finish_k) instead of four to six: dW, db, dgamma, dbeta and the coefficients B, C of the input gradient's BatchNorm
-// tail (what sn_wgrad_*_f32 + [sn_avg_bwd_gc_f32 +] sn_bn_bwd_coeffs_f32 return, bit for bit).  Local statistics only: the
-// sums are finished on this device (synchronised BatchNorm all-reduces G between the two steps and keeps the separate calls).
-//   rows_per_seg > 0: equal meshes (sn_wgrad_seg_f32); slab_off != NULL: ragged meshes (sn_wgrad_slabs_f32); else plain.
-//   dybound != NULL: the two-piece fp16 product (sn_wgrad_bounded_f32).
-//   Ct == C: W, s, invstd, beta over the C columns of x.  Ct == 2 C (needs meshes): the global-average stage — the second C
-//   columns are the per-mesh means m[nseg][C] about mu2[C]; seg_dysum[nseg][J] receives the per-mesh column sums of dy.
-//   Gc (J x Ct) receives the centred product itself (scratch of the second launch); dysum (J doubles) optional.
-//   workspace: sn_wgrad_bn_workspace_bytes; counters: Ct / 32 ints, zero on entry, zero again when the launch has run.
-size_t sn_wgrad_bn_workspace_bytes(int64_t rows, int64_t rows_per_seg, int32_t nslab_ragged, int32_t J, int32_t C, int32_t Ct) {
-  if (C < 1 || Ct < C || J < 1) return 0;
-  size_t base = nslab_ragged > 0 ? (size_t)nslab_ragged * 128 * ((size_t)C + 1) * sizeof(float)
-                                 : (rows_per_seg > 0 ? sn_wgrad_seg_workspace_bytes(rows, rows_per_seg, J, C) : sn_wgrad_workspace_bytes(rows, J, C));
-  base = (base + 15) & ~(size_t)15;
-  return base + (size_t)(Ct / 32) * J * sizeof(double);
-}
-int sn_wgrad_bn_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx, const float *center, int64_t rows, int32_t J, int32_t C,
-                    int64_t rows_per_seg, const int64_t *slab_off, int32_t nslab, const int64_t *seg_slab_ptr, int32_t nseg,
-                    const float *dybound, int64_t n_dybound, const float *xinvstd, int64_t stat_rows, const float *W, const float *s,
-                    const float *invstd, const float *beta, int64_t bn_rows, int32_t Ct, const float *m, const float *mu2, float *Gc,
-                    float *dW, float *db, float *dgamma, float *dbeta, float *Bc, float *Cc, float *seg_dysum, double *dysum,
-                    void *workspace, size_t workspace_bytes, int32_t *counters, void *stream) {
-  (void)hipGetLastError();
-  if (rows < 1 || bn_rows < 1 || J < 1 || C < 1 || (Ct != C && Ct != 2 * C) || (Ct % 32)) return SN_E_SHAPE;
-  if (!W || !s || !invstd || !beta || !Gc || !dW || !dgamma || !dbeta || !Bc || !Cc || !counters || !workspace) return SN_E_NULL;
-  const bool ragged = slab_off != nullptr, meshes = ragged || rows_per_seg > 0;
-  if (Ct != C && (!meshes || !m || !mu2 || !seg_dysum)) return SN_E_NULL;
-  if (ragged && !seg_slab_ptr) return SN_E_NULL;
-  if (dybound && stat_rows < rows) return SN_E_SHAPE;
-  const size_t need = sn_wgrad_bn_workspace_bytes(rows, rows_per_seg, ragged ? nslab : 0, J, C, Ct);
-  if (workspace_bytes < need) return SN_E_WORKSPACE;
-  const size_t tail = (size_t)(Ct / 32) * J * sizeof(double);
-  WgradFinish a{};
-  a.W = W, a.s = s, a.invstd = invstd, a.beta = beta, a.rows = bn_rows, a.Ct = Ct, a.m = m, a.mu2 = mu2, a.nseg = 0;
-  a.Gc = Gc, a.sdyc = reinterpret_cast<double *>(static_cast<char *>(workspace) + (need - tail));
-  a.dW = dW, a.db = db, a.dgamma = dgamma, a.dbeta = dbeta, a.Bc = Bc, a.Cc = Cc, a.counters = counters;
-  WgradBounds b{};
-  if (dybound) b = make_bounds(dybound, n_dybound, xinvstd, stat_rows);
-  return wgrad_launch(dy, lddy, x, ldx, center, rows, J, C, nullptr, dysum, ragged ? 0 : rows_per_seg, seg_dysum, workspace, need - tail,
-                      stream, slab_off, ragged ? nslab : 0, seg_slab_ptr, ragged ? nseg : 0, dybound ? &b : nullptr, &a);
 }
 
 static int thin_blocks(int64_t rows, int J) {
@@ -3836,22 +2870,9 @@ int sn_avg_bn_bwd_f32(const float *G1, const double *dystats, const float *seg_d
   return launch_status();
 }
 
-int sn_bn_fold_parts_f32(const double *part_lo, int32_t nblk_lo, int32_t C_lo, const double *part_hi, int32_t nblk_hi, int32_t C_hi,
-                         int64_t rows, const float *gamma, const float *beta, const float *W, const float *b, int32_t J, double eps,
-                         double momentum, float *running_mean, float *running_var, int64_t *num_batches_tracked, float *mean,
-                         float *invstd, float *s, float *t, float *Wf, float *bf, int32_t *counter, void *stream) {
-  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
-  if (rows < 1 || J < 1 || C_lo < 0 || C_hi < 0 || nblk_lo < 0 || nblk_hi < 0) return SN_E_SHAPE;
-  const int C = C_lo + C_hi;
-  if (C != 128 && C != 256) return SN_E_UNSUPPORTED;
-  if (!gamma || !beta || !W || !mean || !invstd || !s || !t || !Wf || !bf || !counter) return SN_E_NULL;
-  if ((nblk_lo > 0 && !part_lo) || (nblk_hi > 0 && !part_hi) || (!running_mean) != (!running_var)) return SN_E_NULL;
-  if (!aligned16(W) || !aligned16(Wf)) return SN_E_ALIGN;
-  const BnPart lo{part_lo, part_lo ? (int)nblk_lo : 0, (int)C_lo}, hi{part_hi, part_hi ? (int)nblk_hi : 0, (int)C_hi};
-  hipLaunchKernelGGL(bn_fold_parts_k, dim3(C / 16), dim3(kWG), 0, static_cast<hipStream_t>(stream), lo, hi, rows, gamma, beta, W, b,
-                     (int)J, C, eps, momentum, running_mean, running_var, num_batches_tracked, mean, invstd, s, t, Wf, bf, counter);
-  return launch_status();
-}
+// 1 when sn_wgrad_*bounded_f32 take the two-piece fp16 kernel (i.e. producers of dy should leave their maxima), 0 when the
+// bounds would be ignored (SN_GEMM_VARIANT=0: the fp32-MFMA baseline) — the ONE place that decision is made
+int32_t sn_wgrad_bounded_enabled(void) { return gemm_variant() != 0 ? 1 : 0; }
 
 int32_t sn_colstats_blocks(int64_t rows) { return rows > 0 ? stat_blocks(rows) : 0; }
 

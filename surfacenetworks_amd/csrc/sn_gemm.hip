@@ -223,55 +223,18 @@ __global__ __launch_bounds__(kWG, 1) void gemm_rows_k(const float *__restrict__ 
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Split-bf16 variant (default): the same product on the bf16 matrix pipe, 16x the fp32 MFMA rate per instruction.
-//
-// Every fp32 value is split EXACTLY into three bf16 pieces by truncation, x = xh + xm + xl (8 + 8 + 8 significant bits;
-// each remainder is formed by an exact fp32 subtraction), and x·w is evaluated as the six partial products
-//     xh·wh + (xh·wm + xm·wh) + (xh·wl + xl·wh + xm·wm)
-// each of them EXACT in the fp32 accumulator's product (8x8 bits), accumulated in fp32 by v_mfma_f32_32x32x16_bf16.  The
-// three dropped products (xm·wl, xl·wm, xl·wl) are <= 2^-23 |x·w| in total — the size of ONE fp32 rounding of the product,
-// i.e. the result is as accurate as the fp32 MFMA / an fmaf chain (tests/test_dense_gpu.py bounds both against fp64) —
-// while the matrix pipe needs 6 x 32 cycles per 16 k instead of 8 x 64: the kernel turns from MFMA-bound into HBM-bound.
-// Inf inputs give NaN (inf - inf in the remainder); denormal low pieces may flush (absolute error < 1e-38·|w|).
-//
-// v_mfma_f32_32x32x16_bf16: lane l supplies A[i = l&31][k = 8(l>>5) .. +7] and B[k = 8(l>>5) .. +7][n = l&31] (8 bf16 =
-// 4 VGPRs each); C/D layout as the fp32 form.  i = output column, n = data row as above: the weights' three pieces stay in
-// registers (NT·K·3/4 = 192 VGPRs), a lane reads 32 contiguous bytes of its data row per k-step, splits them (44 VALU
-// operations, issued in the shadow of the 6·NT MFMAs) and the consumed registers are re-filled with the next tile's data.
-typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 typedef unsigned int u4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void split8(const f4 &p, const f4 &q, u4 &H, u4 &M, u4 &L) {
-  const float x[8] = {p.x, p.y, p.z, p.w, q.x, q.y, q.z, q.w};
-  unsigned hb[8], mb[8], lb[8];
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    hb[e] = __float_as_uint(x[e]);
-    const float r = x[e] - __uint_as_float(hb[e] & 0xFFFF0000u);
-    mb[e] = __float_as_uint(r);
-    lb[e] = __float_as_uint(r - __uint_as_float(mb[e] & 0xFFFF0000u));
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {          // pack the upper halves of two words: (w1 & 0xffff0000) | (w0 >> 16)
-    H[j] = __builtin_amdgcn_perm(hb[2 * j + 1], hb[2 * j], 0x07060302u);
-    M[j] = __builtin_amdgcn_perm(mb[2 * j + 1], mb[2 * j], 0x07060302u);
-    L[j] = __builtin_amdgcn_perm(lb[2 * j + 1], lb[2 * j], 0x07060302u);
-  }
-}
-
-__device__ __forceinline__ f16v mfma_bf16(const u4 &a, const u4 &b, const f16v &c) {
-  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8v, a), __builtin_bit_cast(bf8v, b), c, 0, 0, 0);
-}
-
 // ------------------------------------------------------------------------------------------------
-// Two-piece fp16 form of the same exact split (PC = 2; SN_GEMM_VARIANT=2): half the matrix-pipe work of the bf16 form.
+// The Linear layers' products on the 16-bit matrix pipe (16x the fp32 MFMA rate per instruction) from an EXACT two-piece split.
 //
 // fp16 carries 11 significant bits, so TWO round-to-nearest pieces hold an fp32 value to 2^-23: x = h + l, h = rn16(x),
 // l = rn16(x - h) (the remainder is an exact fp32 subtraction), and x·w needs three partial products
 //     xh·wh + (xh·wl + xl·wh)                  (the dropped xl·wl is <= 2^-24 |x·w|)
-// each exact in the fp32 accumulator (11 x 11 bits), against six for the three bf16 pieces.  What fp16 lacks is RANGE
+// each exact in the fp32 accumulator (11 x 11 bits) — the result is as accurate as the fp32 MFMA / an fmaf chain
+// (tests/test_dense_gpu.py bounds both against fp64) while the kernel turns from MFMA-bound into HBM-bound.  (Round 1-3 used
+// three bf16 pieces, six partial products: LABNOTES k20.)  What fp16 lacks is RANGE
 // (5 exponent bits: activations behind a cotangent Laplacian reach 1e5, gradients sit at 1e-6), so both operands are
 // scaled by exact powers of two that factor out of the contraction over k: every data ROW by 2^(14 - E_row) from its own
 // absolute maximum (found by the loader wave with four DPP steps, a few VALU operations per 1 KiB load), every weight
@@ -350,22 +313,6 @@ __device__ __forceinline__ void static_for(F &&f) {          // f(IC<I>{}) for I
   }
 }
 
-// x (4 floats) -> 4 bf16 of each piece
-__device__ __forceinline__ void split4(const f4 &x, u2 &H, u2 &M, u2 &L) {
-  const float xs[4] = {x.x, x.y, x.z, x.w};
-  unsigned hb[4], mb[4], lb[4];
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    hb[e] = __float_as_uint(xs[e]);
-    const float r = xs[e] - __uint_as_float(hb[e] & 0xFFFF0000u);
-    mb[e] = __float_as_uint(r);
-    lb[e] = __float_as_uint(r - __uint_as_float(mb[e] & 0xFFFF0000u));
-  }
-  H = u2{__builtin_amdgcn_perm(hb[1], hb[0], 0x07060302u), __builtin_amdgcn_perm(hb[3], hb[2], 0x07060302u)};
-  M = u2{__builtin_amdgcn_perm(mb[1], mb[0], 0x07060302u), __builtin_amdgcn_perm(mb[3], mb[2], 0x07060302u)};
-  L = u2{__builtin_amdgcn_perm(lb[1], lb[0], 0x07060302u), __builtin_amdgcn_perm(lb[3], lb[2], 0x07060302u)};
-}
-
 // LDS writes of this wave done, then the workgroup barrier — without the vmcnt(0) a __syncthreads() fence would add
 // (it would drain the global prefetch and wait for the previous tile's stores to be acknowledged).
 #define SN_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
@@ -430,17 +377,16 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
   constexpr int SROW = 16 * CPR + 16;        // bytes per staged output row (+16: conflict-free transposition)
   constexpr int RPI = 64 / CPR;              // output rows per store instruction (8 | 4)
   constexpr int NST = 32 / RPI;              // store instructions per slab (4 | 8)
-  static_assert(PC == 3 || PC == 2, "three bf16 pieces or two fp16 pieces");
-  constexpr bool H2 = PC == 2;
+  static_assert(PC == 2, "two fp16 pieces");
   __shared__ __attribute__((aligned(16))) unsigned char img[2][PC][PART];
   __shared__ __attribute__((aligned(16))) unsigned char stg[WV][32 * SROW];
-  __shared__ float s_rs[2][32];                         // H2: inverse row scales of the tile held by each image
+  __shared__ float s_rs[2][32];                         // inverse row scales of the tile held by each image
   __shared__ float s_amax[WV];                          // dgrad+elu: per-wave max |gact| (EpiArgs::absmax)
-  __shared__ __attribute__((aligned(16))) float s_cs[NOUT];          // H2: inverse column scales of the weights
+  __shared__ __attribute__((aligned(16))) float s_cs[NOUT];          // inverse column scales of the weights
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int n = lane & 31, h = lane >> 5;
   // ---- stationary weights, split once: w?[t][ks] = pieces of Wmat[col = 32(wave·NT + t) + n][k = 16ks + 8h .. +7] ----
-  u4 wh[NT][KS], wm[H2 ? 1 : NT][H2 ? 1 : KS], wl[NT][KS];
+  u4 wh[NT][KS], wl[NT][KS];
   constexpr int kOob = 0x7fffff00;          // a byte offset past every buffer extent: loads return 0, stores are dropped
   const f4 zero4 = {0.f, 0.f, 0.f, 0.f};
   auto load_w = [&](int col, int ks, f4 &p, f4 &q) {
@@ -475,7 +421,7 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) load_w(col, ks, wp[ks], wq[ks]);
     }
-    if constexpr (H2) {                      // column scale from the column's absolute maximum (my half of k, then my partner's)
+    {                                        // column scale from the column's absolute maximum (my half of k, then my partner's)
       float cm = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
@@ -494,11 +440,10 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
       f4 p, q;
       if constexpr (ONEPASS) p = wp[ks], q = wq[ks];
       else load_w(col, ks, p, q);
-      if constexpr (H2) split8_h2(p, q, cup, wh[t][ks], wl[t][ks]);
-      else split8(p, q, wh[t][ks], wm[t][ks], wl[t][ks]);
+      split8_h2(p, q, cup, wh[t][ks], wl[t][ks]);
     }
   }
-  if constexpr (H2) __syncthreads();        // s_cs complete (read once below, by other lanes)
+  __syncthreads();                          // s_cs complete (read once below, by other lanes)
   const int64_t ntiles = (rows + 31) / 32;
   const int64_t per = (ntiles + gridDim.x - 1) / gridDim.x;
   const int G = ep.interleave ? (int)gridDim.x : 1;                 // tiles between two of mine
@@ -534,8 +479,7 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
     k1 = *reinterpret_cast<const f4 *>(ep.v2 + ecol);                                // B
     k2 = *reinterpret_cast<const f4 *>(ep.v3 + ecol);                                // Cc
   }
-  f4 kcs = {1.f, 1.f, 1.f, 1.f};                                                       // H2: inverse scales of my 4 columns
-  if constexpr (H2) kcs = *reinterpret_cast<const f4 *>(s_cs + ecol);
+  const f4 kcs = *reinterpret_cast<const f4 *>(s_cs + ecol);                           // inverse scales of my 4 columns
   unsigned char *const sw = &stg[wave][0] + n * SROW + 16 * h;                       // where my accumulators go (+128t + 32g)
   const unsigned char *const sr = &stg[wave][0] + erow * SROW + 16 * (lane % CPR);   // what I read back (+ RPI·j·SROW)
   // my byte offset inside a tile of each epilogue matrix (row erow, + RPI rows per store instruction), and the windows
@@ -606,30 +550,19 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
   };
   auto convert_chunk = [&](int buf, int p) {
     unsigned char *d = &img[buf][0][0] + (lrow + 4 * p) * RS + 8 * lc;          // segment s at + 128·s
-    if constexpr (H2) {
-      float m = absmax4(raw[p * SEG]);
+    float m = absmax4(raw[p * SEG]);
 #pragma unroll
-      for (int s = 1; s < SEG; ++s) m = fmaxf(m, absmax4(raw[p * SEG + s]));
-      float up, down;
-      pow2_scales(__uint_as_float(row16_umax(__float_as_uint(m))), up, down);
+    for (int s = 1; s < SEG; ++s) m = fmaxf(m, absmax4(raw[p * SEG + s]));
+    float up, down;
+    pow2_scales(__uint_as_float(row16_umax(__float_as_uint(m))), up, down);
 #pragma unroll
-      for (int s = 0; s < SEG; ++s) {
-        u2 H, L;
-        split4_h2(raw[p * SEG + s], up, H, L);
-        *reinterpret_cast<u2 *>(d + 128 * s) = H;
-        *reinterpret_cast<u2 *>(d + 128 * s + PART) = L;
-      }
-      if (lc == 0) s_rs[buf][lrow + 4 * p] = down;
-    } else {
-#pragma unroll
-      for (int s = 0; s < SEG; ++s) {
-        u2 H, M, L;
-        split4(raw[p * SEG + s], H, M, L);
-        *reinterpret_cast<u2 *>(d + 128 * s) = H;
-        *reinterpret_cast<u2 *>(d + 128 * s + PART) = M;
-        *reinterpret_cast<u2 *>(d + 128 * s + 2 * PART) = L;
-      }
+    for (int s = 0; s < SEG; ++s) {
+      u2 H, L;
+      split4_h2(raw[p * SEG + s], up, H, L);
+      *reinterpret_cast<u2 *>(d + 128 * s) = H;
+      *reinterpret_cast<u2 *>(d + 128 * s + PART) = L;
     }
+    if (lc == 0) s_rs[buf][lrow + 4 * p] = down;
   };
   // prologue: tile 0 converted into image 0, tile 1 in flight in the registers; the input window then runs two tiles ahead
   {
@@ -694,22 +627,19 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
         for (int j = 0; j < NST; ++j) ga[j] = bld4(r_ga, vo_ga + j * js_ga);
       }
     }
-    // accumulators per output tile: leading products | correction products (three for the bf16 form); the first k-step
-    // starts them from a zero operand
-    f16v acc0[NT], acc1[NT], acc2[H2 ? 1 : NT];
+    // accumulators per output tile: leading products | the two cross products; the first k-step starts them from a zero operand
+    f16v acc0[NT], acc1[NT];
     const f16v zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const unsigned char *fp = &img[buf][0][0] + n * RS + 16 * h;
-    constexpr int LOWP = (PC - 1) * PART;       // offset of the lowest piece's image
-    const float rs = H2 ? s_rs[buf][n] : 1.f;   // inverse scale of MY data row (accumulator layout: lane (n, h) holds row n)
-    u4 dh = *reinterpret_cast<const u4 *>(fp), dm = *reinterpret_cast<const u4 *>(fp + PART),
-       dl = *reinterpret_cast<const u4 *>(fp + LOWP);
+    constexpr int LOWP = PART;                  // offset of the low piece's image
+    const float rs = s_rs[buf][n];              // inverse scale of MY data row (accumulator layout: lane (n, h) holds row n)
+    u4 dh = *reinterpret_cast<const u4 *>(fp), dl = *reinterpret_cast<const u4 *>(fp + LOWP);
     static_for<0, KS>([&](auto ic) {
       constexpr int ks = decltype(ic)::value;
       __builtin_amdgcn_sched_barrier(0);
-      u4 nh, nm, nl;                              // fragments of the next k-step: read while this one is multiplied
+      u4 nh, nl;                                  // fragments of the next k-step: read while this one is multiplied
       if constexpr (ks + 1 < KS) {
         nh = *reinterpret_cast<const u4 *>(fp + 32 * (ks + 1));
-        if constexpr (!H2) nm = *reinterpret_cast<const u4 *>(fp + PART + 32 * (ks + 1));
         nl = *reinterpret_cast<const u4 *>(fp + LOWP + 32 * (ks + 1));
       }
       if constexpr (ks % CSTEP == 0 && ks / CSTEP < NCH) {      // conversion of the next tile, one chunk at a time, under the MFMAs
@@ -717,37 +647,15 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
         convert_chunk(buf ^ 1, p);
         load_chunk(r_in, p);
       }
-      if constexpr (H2) {                        // three exact products: leading | the two cross terms (one accumulator)
+      // three exact products: leading | the two cross terms (one accumulator)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc1[t] = mfma_f16(wl[t][ks], dh, ks == 0 ? zero : acc1[t]);
+      for (int t = 0; t < NT; ++t) acc1[t] = mfma_f16(wl[t][ks], dh, ks == 0 ? zero : acc1[t]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc0[t] = mfma_f16(wh[t][ks], dh, ks == 0 ? zero : acc0[t]);
+      for (int t = 0; t < NT; ++t) acc0[t] = mfma_f16(wh[t][ks], dh, ks == 0 ? zero : acc0[t]);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc1[t] = mfma_f16(wh[t][ks], dl, acc1[t]);
-      } else if constexpr (NT == 1) {
-        acc1[0] = mfma_bf16(wl[0][ks], dh, ks == 0 ? zero : acc1[0]);
-        acc2[0] = mfma_bf16(wh[0][ks], dl, ks == 0 ? zero : acc2[0]);
-        acc1[0] = mfma_bf16(wm[0][ks], dm, acc1[0]);
-        acc0[0] = mfma_bf16(wh[0][ks], dh, ks == 0 ? zero : acc0[0]);
-        acc1[0] = mfma_bf16(wm[0][ks], dh, acc1[0]);
-        acc2[0] = mfma_bf16(wh[0][ks], dm, acc2[0]);
-      } else {                         // several tiles: product-outer, tile-inner — two accumulators per tile are enough
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wl[t][ks], dh, ks == 0 ? zero : acc1[t]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wh[t][ks], dl, acc1[t]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wm[t][ks], dm, acc1[t]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc0[t] = mfma_bf16(wh[t][ks], dh, ks == 0 ? zero : acc0[t]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wm[t][ks], dh, acc1[t]);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc1[t] = mfma_bf16(wh[t][ks], dm, acc1[t]);
-      }
+      for (int t = 0; t < NT; ++t) acc1[t] = mfma_f16(wh[t][ks], dl, acc1[t]);
       if constexpr (ks + 1 < KS) {
         dh = nh; dl = nl;
-        if constexpr (!H2) dm = nm;
       }
     });
     __builtin_amdgcn_sched_barrier(0);
@@ -757,28 +665,19 @@ __global__ __launch_bounds__(64 * WV, (PC == 2 && K == 128 && NT == 1 && WV == 4
     for (int t = 0; t < NT; ++t)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        if constexpr (H2)            // leading products + 2^-11 x cross products, then the row's inverse scale (all exact factors)
-          *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
-              f4{__builtin_fmaf(acc1[t][4 * g], kLowDown, acc0[t][4 * g]) * rs,
-                 __builtin_fmaf(acc1[t][4 * g + 1], kLowDown, acc0[t][4 * g + 1]) * rs,
-                 __builtin_fmaf(acc1[t][4 * g + 2], kLowDown, acc0[t][4 * g + 2]) * rs,
-                 __builtin_fmaf(acc1[t][4 * g + 3], kLowDown, acc0[t][4 * g + 3]) * rs};
-        else if constexpr (NT == 1)
-          *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
-              f4{acc0[t][4 * g] + (acc1[t][4 * g] + acc2[t][4 * g]), acc0[t][4 * g + 1] + (acc1[t][4 * g + 1] + acc2[t][4 * g + 1]),
-                 acc0[t][4 * g + 2] + (acc1[t][4 * g + 2] + acc2[t][4 * g + 2]),
-                 acc0[t][4 * g + 3] + (acc1[t][4 * g + 3] + acc2[t][4 * g + 3])};
-        else
-          *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
-              f4{acc0[t][4 * g] + acc1[t][4 * g], acc0[t][4 * g + 1] + acc1[t][4 * g + 1], acc0[t][4 * g + 2] + acc1[t][4 * g + 2],
-                 acc0[t][4 * g + 3] + acc1[t][4 * g + 3]};
+        // leading products + 2^-11 x cross products, then the row's inverse scale (all exact factors)
+        *reinterpret_cast<f4 *>(sw + 128 * t + 32 * g) =
+            f4{__builtin_fmaf(acc1[t][4 * g], kLowDown, acc0[t][4 * g]) * rs,
+               __builtin_fmaf(acc1[t][4 * g + 1], kLowDown, acc0[t][4 * g + 1]) * rs,
+               __builtin_fmaf(acc1[t][4 * g + 2], kLowDown, acc0[t][4 * g + 2]) * rs,
+               __builtin_fmaf(acc1[t][4 * g + 3], kLowDown, acc0[t][4 * g + 3]) * rs};
     const rsrc_t r_out = w_out.rsrc(to_last);
     rsrc_t r_o2 = r_out;                          // (placeholder unless the kernel has the second output)
     if constexpr (DGE || (EPI == EPI_FWD && ELU)) r_o2 = w_o2.rsrc(to_last);
     // output rows RPI·j + erow, my 4 columns: the product (inverse column scales applied) + the epilogue's linear part
     auto out_row = [&](int j) {
       f4 v = *reinterpret_cast<const f4 *>(sr + RPI * j * SROW);
-      if constexpr (H2) v *= kcs;
+      v *= kcs;
       if constexpr (EPI == EPI_FWD) {
         if (useseg) v += (erow + RPI * j < nb ? sg0 : sg1);          // (scalar condition: a branch, not a select)
         else v += k0;
@@ -1141,79 +1040,37 @@ __global__ __launch_bounds__(512, 1) void gemm_fwd_w8_k(const float *__restrict_
   }
 }
 
-// SN_GEMM_VARIANT: 2 (default) two scaled fp16 pieces, 1 three bf16 pieces (both exact splits on the 16-bit matrix pipe; the
-// fp16 form issues half the MFMAs: -2.5 % on the ARAP step), 0 the fp32-MFMA kernel above (A/B baselines)
+// SN_GEMM_VARIANT: default (unset / anything but 0) the two-piece fp16 kernels; 0 = the fp32-MFMA kernel above, the ONE A/B
+// baseline of the Linear kernels (exact fp32 products; no fused epilogues).  Read once per process.
 inline int gemm_variant() {
   static const int v = [] {
     const char *e = getenv("SN_GEMM_VARIANT");
-    return e ? atoi(e) : 2;
+    return (e && atoi(e) == 0) ? 0 : 2;
   }();
   return v;
 }
 
 #define SN_UNPAREN(...) __VA_ARGS__
-// SN_GEMM_WV8=1: the 256-output input-gradient kernels as ONE 8-wave workgroup per CU (a wave owns 32 columns instead of 64:
-// half the weight registers per wave, twice the waves to keep loads in flight) — A/B switch
-inline int gemm_wv8() {          // 0 off, 1 large operands, 2 every operand (tests)
-  static const int v = [] {
-    const char *e = getenv("SN_GEMM_WV8");
-    return e ? atoi(e) : 0;
-  }();
-  return v;
-}
-// SN_GEMM_INTERLEAVE (default 1): workgroup b takes tiles b, b + grid, ... ; 0: a contiguous range per workgroup (A/B switch)
-inline int gemm_interleave() {
-  static const int v = [] {
-    const char *e = getenv("SN_GEMM_INTERLEAVE");
-    return e ? atoi(e) : 1;
-  }();
-  return v;
-}
-inline int gemm_w8() {
-  static const int v = [] {
-    const char *e = getenv("SN_GEMM_W8");
-    return e ? atoi(e) : 1;
-  }();
-  return v;
-}
-#define SN_SPLIT_LAUNCH_NT2(K_, EPI_, SIDE_, ...)                                                                      \
-  do {                                                                                                                 \
-    if (gemm_variant() == 2 && (gemm_wv8() == 2 || (gemm_wv8() == 1 && rows > kSmallRows))) {                                                      \
-      if (t_start) hipExtLaunchKernelGGL((gemm_rows_split_k<2, K_, 1, true, EPI_, SIDE_, false, false, 8>), dim3(grid), dim3(512), 0, s, t_start, t_stop, 0, __VA_ARGS__); \
-      else hipLaunchKernelGGL((gemm_rows_split_k<2, K_, 1, true, EPI_, SIDE_, false, false, 8>), dim3(grid), dim3(512), 0, s, __VA_ARGS__); \
-    } else {                                                                                                           \
-      SN_SPLIT_LAUNCH((K_, 2, true, EPI_, SIDE_, false), __VA_ARGS__);                                                 \
-    }                                                                                                                  \
-  } while (0)
 constexpr int64_t kSmallRows = 131072;      // operands up to this many rows take the one-pass weight prologue (gemm_rows_split_k<…, SMALL>)
-// launch gemm_rows_split_k<PC, TARGS...> with PC chosen by SN_GEMM_VARIANT (2: fp16 pieces, else bf16 pieces); with the
-// timing facility on (sn_timing_enable: t_start / t_stop of the enclosing entry point) the kernel's own start / stop go
-// into two events
+// launch gemm_rows_split_k<2, TARGS...> (SMALL form for operands of at most kSmallRows rows); with the timing facility on
+// (sn_timing_enable: t_start / t_stop of the enclosing entry point) the kernel's own start / stop go into two events
 #define SN_SPLIT_LAUNCH(TARGS, ...)                                                                                    \
   do {                                                                                                                 \
-    if (gemm_variant() == 2 && rows <= kSmallRows) {                                                                   \
+    if (rows <= kSmallRows) {                                                                                          \
       if (t_start) hipExtLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS, true>), dim3(grid), dim3(kWG), 0, s, t_start, t_stop, 0, __VA_ARGS__); \
       else hipLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS, true>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__); \
-    } else if (gemm_variant() == 2) {                                                                                  \
+    } else {                                                                                                           \
       if (t_start) hipExtLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, t_start, t_stop, 0, __VA_ARGS__); \
       else hipLaunchKernelGGL((gemm_rows_split_k<2, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__);     \
-    } else {                                                                                                           \
-      if (t_start) hipExtLaunchKernelGGL((gemm_rows_split_k<3, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, t_start, t_stop, 0, __VA_ARGS__); \
-      else hipLaunchKernelGGL((gemm_rows_split_k<3, SN_UNPAREN TARGS>), dim3(grid), dim3(kWG), 0, s, __VA_ARGS__);     \
     }                                                                                                                  \
   } while (0)
+#define SN_SPLIT_LAUNCH_NT2(K_, EPI_, SIDE_, ...) SN_SPLIT_LAUNCH((K_, 2, true, EPI_, SIDE_, false), __VA_ARGS__)
 
 // Workgroups per CU.  One 4-wave workgroup per CU is a single wave per SIMD that owns the register file; the K = 128, one-tile
 // kernels of the fp16 form need <= 256 registers and run TWO per CU (2 waves per SIMD): -14 % on the plain forward, -10 % on
 // the input gradient through the activation, neutral with a residual (same box, r2); the others lose 3-7 % when their grid is
-// doubled (the second round of workgroups re-loads and re-splits the weights).  SN_GEMM_WGS=1 forces one per CU everywhere.
-inline int gemm_wgs(int K, int NT) {
-  static const int cap = [] {
-    const char *e = getenv("SN_GEMM_WGS");
-    return e ? atoi(e) : 2;
-  }();
-  return (gemm_variant() == 2 && K == 128 && NT == 1 && cap >= 2) ? 2 : 1;
-}
+// doubled (the second round of workgroups re-loads and re-splits the weights).
+inline int gemm_wgs(int K, int NT) { return (gemm_variant() == 2 && K == 128 && NT == 1) ? 2 : 1; }
 inline unsigned gemm_grid(int64_t rows, int wgs) {
   const int64_t ntiles = (rows + 31) / 32;
   int64_t b = (int64_t)kCUs * wgs;
@@ -1224,6 +1081,10 @@ inline unsigned gemm_grid(int64_t rows, int wgs) {
 }  // namespace
 
 extern "C" {
+
+// 0: the process runs the fp32-MFMA A/B baseline of the Linear kernels (SN_GEMM_VARIANT=0), 2: the shipped 16-bit matrix-pipe
+// kernels — what the Python launchers ask instead of reading the environment themselves
+int32_t sn_gemm_variant(void) { return gemm_variant(); }
 
 // (the largest grid any forward kernel uses: a kernel with a smaller one zeroes the blocks past its own)
 int32_t sn_linear_fwd_stats_blocks(int64_t rows) { return rows > 0 ? (int32_t)gemm_grid(rows, 2) : 0; }
@@ -1249,7 +1110,7 @@ int sn_linear_fwd_tiles_f32(const float *x, int64_t ldx, const float *W, int64_t
     return SN_E_ALIGN;
   if (elu_stats_part && (!y_elu || gemm_variant() == 0)) return SN_E_UNSUPPORTED;
   EpiArgs ep{bias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, nullptr, 0, 0, nullptr, elu_stats_part,
-             sn_linear_fwd_stats_blocks(rows), (int)J, nullptr, 0, nullptr, gemm_interleave(), tile_sums};
+             sn_linear_fwd_stats_blocks(rows), (int)J, nullptr, 0, nullptr, 1, tile_sums};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   const bool x3 = gemm_variant() != 0;
@@ -1263,25 +1124,12 @@ int sn_linear_fwd_tiles_f32(const float *x, int64_t ldx, const float *W, int64_t
     if (t_start) hipExtLaunchKernelGGL((gemm_fwd_w8_k<KK, RES, EL>), dim3(grid8), dim3(512), 0, s, t_start, t_stop, 0, x, ldx, W, ldw, y, ldy, rows, ep); \
     else hipLaunchKernelGGL((gemm_fwd_w8_k<KK, RES, EL>), dim3(grid8), dim3(512), 0, s, x, ldx, W, ldw, y, ldy, rows, ep); \
   } while (0)
-  // eight waves of 16 columns (gemm_fwd_w8_k), large operands.  SN_GEMM_W8: 0 off; 1 (default) the K = 256 launches that write
-  // only the activated copy (the one shape it wins: one output stream — a wave's rows are 64-byte segments, and with a
-  // residual and two outputs the three half-line streams cost more than the second wave per SIMD gains); 3 every K = 256
-  // launch; 2 every launch (A/B)
-  const int w8 = gemm_w8();
-  if (gemm_variant() == 2 && J == 128 && rows > kSmallRows && !tile_sums &&
-      (w8 == 2 || (w8 == 3 && K == 256) || (w8 == 1 && K == 256 && !residual && y_elu && !y))) {
+  // eight waves of 16 columns (gemm_fwd_w8_k), large operands: the K = 256 launches that write only the activated copy (the one
+  // shape it wins: one output stream — a wave's rows are 64-byte segments, and with a residual and two outputs the three
+  // half-line streams cost more than the second wave per SIMD gains; LABNOTES r4w8)
+  if (gemm_variant() == 2 && J == 128 && rows > kSmallRows && !tile_sums && K == 256 && !residual && y_elu && !y) {
     const unsigned grid8 = gemm_grid(rows, 1);
-    const int sel = (K == 256 ? 4 : 0) + (residual ? 2 : 0) + (y_elu ? 1 : 0);
-    switch (sel) {
-      case 0: SN_W8_FWD(128, false, false); break;
-      case 1: SN_W8_FWD(128, false, true); break;
-      case 2: SN_W8_FWD(128, true, false); break;
-      case 3: SN_W8_FWD(128, true, true); break;
-      case 4: SN_W8_FWD(256, false, false); break;
-      case 5: SN_W8_FWD(256, false, true); break;
-      case 6: SN_W8_FWD(256, true, false); break;
-      default: SN_W8_FWD(256, true, true); break;
-    }
+    SN_W8_FWD(256, false, true);
     return launch_status();
   }
   if (x3) {
@@ -1317,7 +1165,7 @@ int sn_linear_dgrad_f32(const float *dy, int64_t lddy, const float *W, int64_t l
   if (!aligned16(dy) || !aligned16(W) || !aligned16(dx) || (lddy % 4) || (ldw % 4) || (lddx % 4)) return SN_E_ALIGN;
   if (B && (!aligned16(x) || !aligned16(B) || !aligned16(Cc) || (center && !aligned16(center)) || (ldx % 4) || ldx < C))
     return SN_E_ALIGN;
-  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, nullptr, gemm_interleave(), nullptr};
+  EpiArgs ep{x, center, B, Cc, nullptr, ldx, 0, nullptr, 0, 0, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, nullptr, 1, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   const bool x3 = gemm_variant() != 0;
@@ -1367,7 +1215,7 @@ int sn_linear_dgrad_elu_absmax_f32(const float *dy, int64_t lddy, const float *W
       (lddy % 4) || (ldw % 4) || (lddx % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   const int half = C / 2;
-  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, gact_absmax, gemm_interleave(), nullptr};
+  EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, half, nullptr, 0, 0, nullptr, nullptr, 0, (int)J, nullptr, 0, gact_absmax, 1, nullptr};
   float *out = dx_hi - half;           // the kernel indexes absolute columns; only columns >= half are written through `out`
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
@@ -1402,7 +1250,7 @@ static int fwd_segbias_launch(const float *x, int64_t ldx, const float *W, int64
   if (elu_stats_part && !y_elu) return SN_E_UNSUPPORTED;
   if (tile_sums && (!elu_stats_part || J != 128)) return SN_E_UNSUPPORTED;
   EpiArgs ep{segbias, residual, nullptr, nullptr, y_elu, ldr, lde, nullptr, 0, 0, segbias, segoff ? 0 : rows_per_seg, J, nullptr,
-             elu_stats_part, sn_linear_fwd_stats_blocks(rows), (int)J, segoff, nseg, nullptr, gemm_interleave(), tile_sums};
+             elu_stats_part, sn_linear_fwd_stats_blocks(rows), (int)J, segoff, nseg, nullptr, 1, tile_sums};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(K, 1));
   hipEvent_t t_start = nullptr, t_stop = nullptr;
@@ -1478,7 +1326,7 @@ static int dgrad_eluseg_launch(const float *dy, int64_t lddy, const float *W, in
       (gadd && (!aligned16(gadd) || (ldgadd % 4) || ldgadd < C)) || (lddy % 4) || (ldw % 4) || (ldga % 4) || (ldx % 4))
     return SN_E_ALIGN;
   EpiArgs ep{x, center, B, Cc, gact, ldx, ldga, gadd, ldgadd, (int)C, segvec, (segvec && !segoff) ? rows_per_seg : 0, C, rowmask,
-             nullptr, 0, (int)J, segoff, nseg, gact_absmax, gemm_interleave(), nullptr};
+             nullptr, 0, (int)J, segoff, nseg, gact_absmax, 1, nullptr};
   hipStream_t s = static_cast<hipStream_t>(stream);
   const unsigned grid = gemm_grid(rows, gemm_wgs(128, C / 128));
   hipEvent_t t_start = nullptr, t_stop = nullptr;

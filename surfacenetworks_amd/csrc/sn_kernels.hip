@@ -4,12 +4,12 @@
 // HBM3E-bound arithmetic (≈2 flop/B), so everything here is about coalescing, bytes in flight
 // and L2 locality — there is no MFMA in this file on purpose.
 //
-// Kernel inventory
-//   spmm_csr_v4<N,XG,YG>   Y = A·X, CSR, N ∈ {16,32,64,128}: N/4 lanes own one row (float4 each),
-//                          a wave owns 256/N consecutive rows; no cross-lane reduction is needed
-//                          because a lane owns whole output columns.
-//   spmm_bsr4_v4<N,XG,YG>  same product for 4x4-block operators (Dirac): N/4 lanes own one block
-//                          row (4 output rows), each gathered X quad is used 16x from registers.
+// Kernel inventory (one kernel per storage form)
+//   spmm_csr_rows<N,XG,YG> Y = A·X, CSR, N ∈ {16,32,64,128}: N/4 lanes own one row (float4 each), a wave owns 256/N·iters
+//                          consecutive rows, its entries staged in LDS; no cross-lane reduction (a lane owns whole columns).
+//   spmm_bsr4_lds          the same product for 4x4-block operators: N/4 lanes own one block row (4 output rows).
+//   spmm_q3_lds            quaternion-packed Dirac operators (the default of the Dirac path).
+//   spmm_rb4 / spmm_ring_k row-blocked and sliding-window Laplacian kernels.
 //   spmm_csr_any           any N, one thread per output element (correctness fallback).
 //   coo_to_csr / transpose / bsr4 count+fill / blockdiag concat / scan / elu helpers.
 //
@@ -36,26 +36,14 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ f4 ld4(const float *p) { return *reinterpret_cast<const f4 *>(p); }
 __device__ __forceinline__ void st4(float *p, f4 v) { *reinterpret_cast<f4 *>(p) = v; }
-#ifndef SN_X_SPMM_ST_PLAIN
-#define SN_X_SPMM_ST_PLAIN 0
-#endif
-#ifndef SN_X_EW_ST_PLAIN
-#define SN_X_EW_ST_PLAIN 0
-#endif
-__device__ __forceinline__ void st4_stream(float *p, f4 v) {
-#if SN_X_SPMM_ST_PLAIN
-  *reinterpret_cast<f4 *>(p) = v;
-#else
-  __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
-#endif
-}
+__device__ __forceinline__ void st4_stream(float *p, f4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p)); }
 // streaming (non-temporal) forms for data that is touched once per kernel: measured +15-30 % on 1:1 copy-like passes
 constexpr int kStreamNT = 1;   // streamed-once operands use non-temporal loads/stores
 __device__ __forceinline__ f4 ld4_s(const float *p, int nt) {
   return nt ? __builtin_nontemporal_load(reinterpret_cast<const f4 *>(p)) : *reinterpret_cast<const f4 *>(p);
 }
 __device__ __forceinline__ void st4_s(float *p, f4 v, int nt) {
-  if (nt && !SN_X_EW_ST_PLAIN) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
+  if (nt) __builtin_nontemporal_store(v, reinterpret_cast<f4 *>(p));
   else *reinterpret_cast<f4 *>(p) = v;
 }
 __device__ __forceinline__ f4 fma4(float a, f4 x, f4 acc) {
@@ -81,50 +69,6 @@ __device__ __forceinline__ int my_chunk(int nchunks) {
   return (blockIdx.x % kXCD) * cpx + blockIdx.x / kXCD;      // may be >= nchunks for the padding workgroups: callers test rows
 }
 
-// ------------------------------------------------------------------------------------------------
-// CSR SpMM, N/4 lanes per row.
-// ------------------------------------------------------------------------------------------------
-template <int N, int XG, int YG>
-__global__ __launch_bounds__(kWG) void spmm_csr_v4(const int *__restrict__ rowptr,
-                                                   const int *__restrict__ colind,
-                                                   const float *__restrict__ vals, int M,
-                                                   const float *__restrict__ X, int64_t ldx,
-                                                   float *__restrict__ Y, int64_t ldy, int nchunks) {
-  constexpr int LPR = N / 4;       // lanes per row
-  constexpr int RPB = kWG / LPR;   // rows per workgroup
-  const int sub = threadIdx.x % LPR;
-  const int rloc = threadIdx.x / LPR;
-  const float *xb = X + sub * 4;
-  {
-    const int r = my_chunk(nchunks) * RPB + rloc;
-    if (r >= M) return;
-    int k = rowptr[r];
-    const int e = rowptr[r + 1];
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    // Batches of kBatch entries with ALL gathers of a batch in flight at once.  A short row (7 entries for the
-    // Laplacian, 9 for Di) is one or two batches — no serial tail loop of dependent colind -> gather round trips.
-    // Slots past the end re-read the row's last entry with a zero coefficient: fma(0, x, acc) == acc, and the
-    // re-read column already belongs to the row, so non-finite inputs propagate exactly as in the plain loop.
-    constexpr int kBatch = 8;
-    for (; k < e; k += kBatch) {
-      int c[kBatch];
-      float a[kBatch];
-      f4 x[kBatch];
-#pragma unroll
-      for (int i = 0; i < kBatch; ++i) {
-        const bool in = k + i < e;
-        const int kk = in ? k + i : e - 1;
-        c[i] = colind[kk];
-        a[i] = in ? vals[kk] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < kBatch; ++i) x[i] = ld4(xb + row_off<XG, N>(c[i], ldx));
-#pragma unroll
-      for (int i = 0; i < kBatch; ++i) acc = fma4(a[i], x[i], acc);
-    }
-    st4_stream(Y + row_off<YG, N>(r, ldy) + sub * 4, acc);
-  }
-}
 
 // Optional fused epilogue of the LDS SpMM kernels (the backward of an ELU-activated propagation stage):
 //     Y = (A·X) ∘ elu'(E) + G,    elu'(·) through the activation OUTPUT E: 1 where E > 0, E + 1 elsewhere,
@@ -160,99 +104,9 @@ __device__ __forceinline__ f4 elu_bwd4(const f4 &a, const f4 &o) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// CSR SpMM with the operator entries of each wave pass staged through LDS.
-//
-// In spmm_csr_v4 the N/4 lanes of a row all load the same colind / vals words: at N = 128 a wave issues 16 two-address
-// "broadcast" loads per pass next to 8 useful 1-KiB gathers, and vector-memory ISSUE, not HBM, bounds the kernel.
-// Here a wave copies the contiguous entry run [rowptr[r0], rowptr[r0 + P)) of its P = 256/N rows into its private LDS
-// slice with two coalesced 4-byte-per-lane DMA loads per 64 entries, and lane groups read their entries back with
-// broadcast ds_reads.  Same arithmetic order as spmm_csr_v4 (k-ascending FMA chain), so results are bit-identical.
-// ------------------------------------------------------------------------------------------------
-template <int N, int XG, int YG, bool EPI>
-__device__ __forceinline__ void spmm_csr_lds_body(const int *__restrict__ rowptr, const int *__restrict__ colind,
-                                                  const float *__restrict__ vals, int M,
-                                                  const float *__restrict__ X, int64_t ldx,
-                                                  float *__restrict__ Y, int64_t ldy, int nchunks, SpmmEpi epi) {
-  constexpr int LPR = N / 4;          // lanes per row
-  constexpr int P = 64 / LPR;         // rows per wave
-  constexpr int WAVES = kWG / 64;
-  constexpr int TILE = 256;           // entries staged per wave per tile
-  constexpr int KB = 8;               // gathers in flight per lane
-  __shared__ int s_col[WAVES][TILE];
-  __shared__ float s_val[WAVES][TILE];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int sub = lane % LPR, grp = lane / LPR;
-  const float *xb = X + sub * 4;
-  int *sc = s_col[wave];
-  float *sv = s_val[wave];
-  {
-    const int r0 = (my_chunk(nchunks) * WAVES + wave) * P;      // a chunk = WAVES * P rows
-    if (r0 >= M) return;              // wave-uniform
-    const int r = r0 + grp;
-    const int rc = r < M ? r : M;
-    const int kb = rowptr[rc];
-    const int ke = rowptr[rc + 1 <= M ? rc + 1 : M];
-    const int k0 = __builtin_amdgcn_readfirstlane(kb);
-    const int k1 = __builtin_amdgcn_readlane(ke, 63);
-    f4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int t0 = k0; t0 < k1; t0 += TILE) {
-      const int nt = (k1 - t0) < TILE ? (k1 - t0) : TILE;
-      for (int p0 = 0; p0 < nt; p0 += 64) {
-        int p = p0 + lane;
-        p = p < nt ? p : nt - 1;      // tail lanes re-read the last entry into spare slots
-        __builtin_amdgcn_global_load_lds(colind + t0 + p, sc + p0, 4, 0, 0);
-        __builtin_amdgcn_global_load_lds(vals + t0 + p, sv + p0, 4, 0, 0);
-      }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_wave_barrier();
-      int k = kb > t0 ? kb : t0;
-      const int kend = ke < t0 + nt ? ke : t0 + nt;
-      for (; k < kend; k += KB) {
-        int c[KB];
-        float a[KB];
-        f4 x[KB];
-#pragma unroll
-        for (int i = 0; i < KB; ++i) {
-          const bool in = k + i < kend;
-          const int o = (in ? k + i : kend - 1) - t0;
-          c[i] = sc[o];
-          a[i] = in ? sv[o] : 0.f;
-        }
-#pragma unroll
-        for (int i = 0; i < KB; ++i) x[i] = ld4(xb + row_off<XG, N>(c[i], ldx));
-#pragma unroll
-        for (int i = 0; i < KB; ++i) acc = fma4(a[i], x[i], acc);
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-    if constexpr (EPI) {
-      if (r < M) {
-        acc = elu_bwd4(acc, ld4_s(epi.e + row_off<YG, N>(r, epi.lde) + sub * 4, kStreamNT));
-        if (epi.g) acc += ld4_s(epi.g + row_off<YG, N>(r, epi.ldg) + sub * 4, kStreamNT);
-      }
-    }
-    if (r < M) st4_stream(Y + row_off<YG, N>(r, ldy) + sub * 4, acc);
-  }
-}
-template <int N, int XG, int YG>
-__global__ __launch_bounds__(kWG) void spmm_csr_lds(const int *__restrict__ rowptr, const int *__restrict__ colind,
-                                                    const float *__restrict__ vals, int M,
-                                                    const float *__restrict__ X, int64_t ldx,
-                                                    float *__restrict__ Y, int64_t ldy, int nchunks) {
-  spmm_csr_lds_body<N, XG, YG, false>(rowptr, colind, vals, M, X, ldx, Y, ldy, nchunks, SpmmEpi{nullptr, 0, nullptr, 0});
-}
-template <int N, int XG, int YG>
-__global__ __launch_bounds__(kWG) void spmm_csr_lds_epi(const int *__restrict__ rowptr, const int *__restrict__ colind,
-                                                        const float *__restrict__ vals, int M,
-                                                        const float *__restrict__ X, int64_t ldx,
-                                                        float *__restrict__ Y, int64_t ldy, int nchunks, SpmmEpi epi) {
-  spmm_csr_lds_body<N, XG, YG, true>(rowptr, colind, vals, M, X, ldx, Y, ldy, nchunks, epi);
-}
-
-// ------------------------------------------------------------------------------------------------
 // CSR SpMM, several row passes per wave ("rows" kernel) — the Laplacian kernel (N = 128: the products at utils_pt.py:167,176).
 //
-// spmm_csr_lds gives a wave ONE pass of P = 256/N rows.  Here a wave owns R = P*iters consecutive rows: ONE coalesced load
+// N/4 lanes per row, a float4 column slice per lane.  A wave owns R = P*iters consecutive rows (P = 256/N): ONE coalesced load
 // fetches its R+1 row pointers, the whole entry run of those rows goes to the wave's LDS slice with a few DMA instructions,
 // and the wave then walks its passes with LDS reads, gathers and stores only.  Measured on the Laplacian batches (N = 128):
 // +3 % at 2 passes, slower from 8 passes on (the row ranges the resident waves walk concurrently outgrow the XCD's L2) — the
@@ -422,57 +276,12 @@ __global__ __launch_bounds__(kWG) void spmm_csr_rows_stats(const int *__restrict
 }
 
 // ------------------------------------------------------------------------------------------------
-// BSR4 SpMM: N/4 lanes per block row; each lane keeps the 4 output rows of its column slice.
-// ------------------------------------------------------------------------------------------------
-template <int N, int XG, int YG>
-__global__ __launch_bounds__(kWG) void spmm_bsr4_v4(const int *__restrict__ b_rowptr,
-                                                    const int *__restrict__ b_colind,
-                                                    const float *__restrict__ b_vals, int Mb,
-                                                    const float *__restrict__ X, int64_t ldx,
-                                                    float *__restrict__ Y, int64_t ldy, int nchunks) {
-  constexpr int LPR = N / 4;
-  constexpr int RPB = kWG / LPR;   // block rows per workgroup pass
-  const int sub = threadIdx.x % LPR;
-  const int rloc = threadIdx.x / LPR;
-  // quad base offset and the stride between the 4 rows of a quad
-  const int64_t xq = (XG == 4) ? ldx : 4 * ldx;
-  const int64_t xs = (XG == 4) ? (int64_t)N : ldx;
-  const int64_t yq = (YG == 4) ? ldy : 4 * ldy;
-  const int64_t ys = (YG == 4) ? (int64_t)N : ldy;
-  const float *xb = X + sub * 4;
-  {
-    const int br = my_chunk(nchunks) * RPB + rloc;
-    if (br >= Mb) return;
-    int k = b_rowptr[br];
-    const int e = b_rowptr[br + 1];
-    f4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
-#pragma unroll 3
-    for (; k < e; ++k) {
-      const int bc = b_colind[k];
-      const f4 *bv = reinterpret_cast<const f4 *>(b_vals + 16 * (int64_t)k);
-      const f4 a0 = bv[0], a1 = bv[1], a2 = bv[2], a3 = bv[3];
-      const float *xp = xb + (int64_t)bc * xq;
-      const f4 x0 = ld4(xp), x1 = ld4(xp + xs), x2 = ld4(xp + 2 * xs), x3 = ld4(xp + 3 * xs);
-      acc0 = fma4(a0.x, x0, acc0); acc0 = fma4(a0.y, x1, acc0); acc0 = fma4(a0.z, x2, acc0); acc0 = fma4(a0.w, x3, acc0);
-      acc1 = fma4(a1.x, x0, acc1); acc1 = fma4(a1.y, x1, acc1); acc1 = fma4(a1.z, x2, acc1); acc1 = fma4(a1.w, x3, acc1);
-      acc2 = fma4(a2.x, x0, acc2); acc2 = fma4(a2.y, x1, acc2); acc2 = fma4(a2.z, x2, acc2); acc2 = fma4(a2.w, x3, acc2);
-      acc3 = fma4(a3.x, x0, acc3); acc3 = fma4(a3.y, x1, acc3); acc3 = fma4(a3.z, x2, acc3); acc3 = fma4(a3.w, x3, acc3);
-    }
-    float *yp = Y + (int64_t)br * yq + sub * 4;
-    st4_stream(yp, acc0);
-    st4_stream(yp + ys, acc1);
-    st4_stream(yp + 2 * ys, acc2);
-    st4_stream(yp + 3 * ys, acc3);
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
 // BSR4 SpMM with the operator tile staged through LDS.
 //
-// In spmm_bsr4_v4 every lane group re-reads its 64-byte blocks with 16-byte loads whose address is shared
-// by the N/4 lanes of the group: each such load occupies the texture-addresser like a full 1 KiB gather
-// but delivers 128 unique bytes (rocprof: SQ_WAIT_INST_ANY 39 % — the kernel is vector-memory-ISSUE bound,
-// not HBM bound).  Here each WAVE copies the contiguous run of blocks owned by its 256/N block rows
+// N/4 lanes per block row; each lane keeps the 4 output rows of its column slice.  Blocks re-read from global memory by
+// every lane group (the round-1 kernel) are 16-byte loads whose address is shared by the N/4 lanes of the group: each occupies
+// the texture-addresser like a full 1 KiB gather but delivers 128 unique bytes (rocprof: SQ_WAIT_INST_ANY 39 % — vector-memory-
+// ISSUE bound, not HBM bound; LABNOTES).  Here each WAVE copies the contiguous run of blocks owned by its 256/N block rows
 // (b_vals[16*k0 .. 16*k1), b_colind[k0..k1)) into its private LDS slice with fully coalesced 16-byte
 // loads, and the lane groups then read their blocks back with broadcast ds_read_b128.  Waves stay
 // independent (no workgroup barrier): DS operations of one wave complete in order.
@@ -1301,28 +1110,17 @@ __global__ __launch_bounds__(kWG) void spmm_rb4_stats(const int *__restrict__ b_
 //   * a column outside the window (|c - r| > H: wrap-around rows of closed meshes, unordered meshes) is gathered from
 //     global memory inside the same batch ("mixed" rounds); rows of more than 32 entries take an entry-by-entry path.
 // Same k-ascending FMA chain per row as every other CSR kernel: bit-identical results (slots past a row's end multiply the
-// row's own first column by 0, as in spmm_csr_v4).  Measured (MI355X, 128 channels): 0.65-0.67 of the HBM roofline on the
+// row's own first column by 0).  Measured (MI355X, 128 channels): 0.65-0.67 of the HBM roofline on the
 // config-5 Laplacian batch (RB4: 0.55-0.58), 0.83 on the config-3-sized batch (0.72-0.79), 0.81 on config 4's (0.57).
 // ------------------------------------------------------------------------------------------------
-// A/B switches of the ring kernel (measurement builds only; the defaults are the shipped kernel)
-#ifndef SN_X_RING_XAUX
-#define SN_X_RING_XAUX 2             // cache policy of the X DMA: 2 = non-temporal (every X line is requested once per slice: +2-3 %), 0 = default
-#endif
-#ifndef SN_X_RING_EAUX
-#define SN_X_RING_EAUX 0             // ... of the entry / row-pointer DMA
-#endif
-#ifndef SN_X_RING_ST_PLAIN
-#define SN_X_RING_ST_PLAIN 0         // 1: plain instead of non-temporal stores of Y
-#endif
-#ifndef SN_X_RING_NLW
-#define SN_X_RING_NLW 4
-#endif
+constexpr int kRingXAux = 2;         // cache policy of the X DMA: non-temporal (every X line is requested once per slice: +2-3 % over the default)
+constexpr int kRingEAux = 0;         // ... of the entry / row-pointer DMA: default
 constexpr int kRingCS = 64;          // dense columns per slice (one 256-byte piece of an X row)
 constexpr int kRingW = 512;          // ring rows (128 KiB)
 constexpr int kRingR = 64;           // rows per step
 constexpr int kRingH = 160;          // half window: columns within +-H of the row come from the ring
 constexpr int kRingD = 2;            // steps of DMA in flight
-constexpr int kRingNLW = SN_X_RING_NLW;   // loader waves
+constexpr int kRingNLW = 4;   // loader waves
 constexpr int kRingNCW = kRingR / 8; // compute waves
 constexpr int kRingThreads = (kRingNCW + kRingNLW) * 64;
 constexpr int kRingECap = kRingR * 8;                     // entry slots per step buffer
@@ -1396,7 +1194,7 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
     auto issue_rows = [&](int row0, int i) {                          // RPI rows from row0 + RPI*i -> ring
       int row = row0 + RPI * i + lane / LPX;
       row = row < 0 ? 0 : (row < K ? row : K - 1);
-      __builtin_amdgcn_global_load_lds(xg + (int64_t)row * ldx, xs + ((row0 + RPI * i) & (W - 1)) * CS, 16, 0, SN_X_RING_XAUX);
+      __builtin_amdgcn_global_load_lds(xg + (int64_t)row * ldx, xs + ((row0 + RPI * i) & (W - 1)) * CS, 16, 0, kRingXAux);
     };
     auto issue_step = [&](int t) {                                    // X piece, entries, row pointers of step t: NSTEP instr.
       const int buf = t % NB;
@@ -1419,8 +1217,8 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
         p = p < ne ? p : (ne > 0 ? ne - 1 : 0);
         int k = k0 + p;
         k = k < nnz ? k : nnz - 1;
-        __builtin_amdgcn_global_load_lds(colind + k, sc + buf * ECAP + p0, 4, 0, SN_X_RING_EAUX);
-        __builtin_amdgcn_global_load_lds(vals + k, sv + buf * ECAP + p0, 4, 0, SN_X_RING_EAUX);
+        __builtin_amdgcn_global_load_lds(colind + k, sc + buf * ECAP + p0, 4, 0, kRingEAux);
+        __builtin_amdgcn_global_load_lds(vals + k, sv + buf * ECAP + p0, 4, 0, kRingEAux);
       }
       const int r0 = t * R;
       int nr = M - r0;
@@ -1606,7 +1404,6 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
           o = ring_epilogue(o, ev[v], gv[v], epi.g != nullptr);
           if (epi.absmax) am = fmaxf(am, hmax_abs4(o));
         }
-        if (SN_X_RING_ST_PLAIN) st4(Y + (int64_t)r * ldy + c0 + v * 32 + sub * 4, o);
         else st4_stream(Y + (int64_t)r * ldy + c0 + v * 32 + sub * 4, o);
         if constexpr (STATS) {
           ssum[v] += o;
@@ -1969,10 +1766,6 @@ inline int launch_status() {
   return e == hipSuccess ? SN_OK : (int)e;
 }
 
-inline int env_int(const char *name, int dflt) {
-  const char *v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
 // Elementwise passes: one 16-byte item per thread and as many workgroups as that takes (measured faster than a capped
 // grid-stride loop: 6.5 vs 4.9 TB/s on a 1 GiB copy, tools/scratch/copybench.hip), non-temporal loads/stores (kStreamNT).
 inline unsigned grid_for(int64_t work_items, int per_block) {
@@ -1980,13 +1773,6 @@ inline unsigned grid_for(int64_t work_items, int per_block) {
   if (b < 1) b = 1;
   return (unsigned)(b < (int64_t)INT_MAX ? b : (int64_t)INT_MAX);
 }
-
-// A/B switches for measurements (read once from the environment; the defaults are the shipped kernels):
-//   SN_BSR4_VARIANT = 0 -> spmm_bsr4_v4 (operator blocks re-read from global by every lane group) instead of spmm_bsr4_lds
-//   SN_CSR_VARIANT  = 0 -> spmm_csr_v4 (entries loaded directly), 1 -> spmm_csr_lds (one row pass per wave) instead of
-//                          spmm_csr_rows (several passes per wave, the default); SN_CSR_ITERS forces its passes per wave
-inline int tune_bsr4_variant() { static const int v = env_int("SN_BSR4_VARIANT", 2); return v; }
-inline int tune_csr_variant() { static const int v = env_int("SN_CSR_VARIANT", 2); return v; }
 
 // grid of the chunked kernels: one workgroup per chunk, rounded up to a multiple of the 8 XCDs (see my_chunk)
 inline unsigned chunk_grid(int64_t nchunks) {
@@ -2113,11 +1899,9 @@ constexpr int kSpmmStatsBlocks = 128;        // partial rows after stage 1 of th
 // rows kernel: passes per wave.  As many as keep >= 8 workgroups per CU in the grid (small batches stay wide), at most 64 rows.
 static int csr_rows_iters(int64_t M, int N) {
   const int P = 64 / (N / 4);
-  static const int forced = env_int("SN_CSR_ITERS", 0);
-  int it = forced > 0 ? forced : 2;        // (measured best on the config-4 / config-5 Laplacian batches: 2..4 passes)
+  int it = 2;                              // (measured best on the config-4 / config-5 Laplacian batches: 2..4 passes)
   if (it * P > 64) it = 64 / P;
-  if (forced <= 0)
-    while (it > 1 && (M + (int64_t)4 * P * it - 1) / ((int64_t)4 * P * it) < 8 * kCUs) it >>= 1;
+  while (it > 1 && (M + (int64_t)4 * P * it - 1) / ((int64_t)4 * P * it) < 8 * kCUs) it >>= 1;
   return it < 1 ? 1 : it;
 }
 static int64_t csr_rows_chunks(int64_t M, int N, int iters) {
@@ -2162,7 +1946,7 @@ static int spmm_csr_launch(const int32_t *rowptr, const int32_t *colind, const f
     hipLaunchKernelGGL(spmm_stats_reduce_k, dim3(kSpmmStatsBlocks), dim3(kWG), 0, s, stats_part, (int64_t)grid, stats_out);
     return launch_status();
   }
-  if (vec && tune_csr_variant() >= 2) {
+  if (vec) {
     const int iters = csr_rows_iters(M, N);
     const int64_t nchunks = csr_rows_chunks(M, N, iters);
     const unsigned grid = chunk_grid(nchunks);
@@ -2170,16 +1954,6 @@ static int spmm_csr_launch(const int32_t *rowptr, const int32_t *colind, const f
       SN_DISPATCH_N(spmm_csr_rows_epi, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters, epi);
     else
       SN_DISPATCH_N(spmm_csr_rows, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, iters);
-  } else if (vec) {
-    const int rpb = kWG / (N / 4);
-    const int64_t nchunks = (M + rpb - 1) / rpb;
-    const unsigned grid = chunk_grid(nchunks);
-    if (epi.e)
-      SN_DISPATCH_N(spmm_csr_lds_epi, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks, epi);
-    else if (tune_csr_variant() == 0)
-      SN_DISPATCH_N(spmm_csr_v4, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks);
-    else
-      SN_DISPATCH_N(spmm_csr_lds, N, x_group, y_group, grid, s, rowptr, colind, vals, (int)M, X, ldx, Y, ldy, (int)nchunks);
   } else {
     SN_KLAUNCH(spmm_csr_any, grid_for(M * (int64_t)N, kWG), s, rowptr, colind, vals, M, (int)N, X, ldx, (int)x_group, Y,
                ldy, (int)y_group);
@@ -2225,12 +1999,9 @@ static int rb4_iters(int64_t Mb, int N) {
   const int P = 64 / (N / 4);
   // One pass per wave by default: with more, the row ranges the resident waves of an XCD walk concurrently no longer fit
   // its 4 MiB L2 together with their neighbours' X rows (measured: 0.59 -> 0.47 of the roofline from 1 to 8 passes).
-  static const int forced = env_int("SN_RB4_ITERS", 0);
-  int it = forced > 0 ? forced : 1;
-  if (it * P > 64) it = 64 / P;
-  if (forced <= 0)
-    while (it > 1 && (Mb + (int64_t)4 * P * it - 1) / ((int64_t)4 * P * it) < 8 * kCUs) it >>= 1;
-  return it < 1 ? 1 : it;
+  (void)Mb;
+  (void)P;
+  return 1;
 }
 static int64_t rb4_chunks(int64_t Mb, int N, int iters) {
   const int64_t per_wg = (int64_t)(kWG / 64) * (64 / (N / 4)) * iters;
@@ -2527,8 +2298,6 @@ static int spmm_bsr4_launch(const int32_t *b_rowptr, const int32_t *b_colind, co
   const unsigned grid = chunk_grid(nchunks);
   if (epi.e)
     SN_DISPATCH_N(spmm_bsr4_lds_epi, N, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks, epi);
-  else if (tune_bsr4_variant() == 0)
-    SN_DISPATCH_N(spmm_bsr4_v4, N, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks);
   else
     SN_DISPATCH_N(spmm_bsr4_lds, N, x_group, y_group, grid, s, b_rowptr, b_colind, b_vals, (int)Mb, X, ldx, Y, ldy, (int)nchunks);
   return launch_status();
@@ -2582,10 +2351,9 @@ static int spmm_q3_launch(const int32_t *b_rowptr, const float *q_blk, int64_t M
   const unsigned grid = chunk_grid(nchunks);
   const f4 *q = reinterpret_cast<const f4 *>(q_blk);
   // face-output products (3 blocks per block row) take the wide shape, vertex-output products (~6) the deep one
-  static const int force = env_int("SN_Q3_SHAPE", 0);                // A/B: 1 = always deep, 2 = always wide
   // (a grid of fewer than two rounds of the deep shape's 4 workgroups per CU — the Mesh-MNIST batches — also runs wide: at
   // 1 200 workgroups the deep shape leaves a 17 % tail, measured 0.67 -> 0.77 on the config-2 vertex-output products)
-  const bool wide = force == 2 || (force == 0 && (nblocks <= 4 * Mb || grid < 8u * kCUs));
+  const bool wide = nblocks <= 4 * Mb || grid < 8u * kCUs;
   if (stats_part) {
     if (epi.e || (N != 32 && N != 16) || y_group != 4) return SN_E_UNSUPPORTED;
     if (!stats_out) return SN_E_NULL;

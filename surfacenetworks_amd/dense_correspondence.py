@@ -161,7 +161,7 @@ _TOWER_STREAMS = weakref.WeakKeyDictionary()      # model -> (side stream, per-B
 # The two applications of the shared tower are independent until the score matrix; a 7000-row tower fills 219 of the chip's
 # 512 workgroup slots and its step is ~500 launches of a few microseconds, so running them on two streams (inside the one
 # captured hipGraph: two concurrent kernel chains) hides most of that latency.  SN_TWO_STREAM_TOWERS=0 switches it off.
-_TWO_STREAMS = __import__("os").environ.get("SN_TWO_STREAM_TOWERS", "1") != "0"
+_TWO_STREAMS = True          # (tests may set False: both towers on the caller's stream)
 
 
 class SiameseModel(nn.Module):
@@ -409,7 +409,7 @@ class _FusedCorrespondenceCE(torch.autograd.Function):
         return dFA, dFB, None, None, None
 
 
-_PREFETCH_TARGET = os.environ.get("SN_PREFETCH_TARGET", "1") != "0"      # A/B switch: "0" = the target on the caller's stream
+_PREFETCH_TARGET = True      # the argmin target of the NEXT pair on a side stream (False: on the caller's stream)
 _TARGET_STREAMS = {}
 
 

@@ -24,11 +24,12 @@ __all__ = ["spmm", "lap_propagate", "dirac_face_stage", "dirac_vert_stage", "avg
            "bnlin_backward", "bn_prepare", "avg_stage_forward_ragged", "avg_stage_backward_ragged", "set_dirac_format", "set_laplacian_format", "SpmmTimer", "thin_linear", "thin_linear_supported"]
 
 _DIRAC_FORMAT = "q3"
-_LAPLACIAN_FORMAT = os.environ.get("SN_LAP_FORMAT", "ring")     # (environment override for A/B measurements)
+_LAPLACIAN_FORMAT = "ring"       # set_laplacian_format
 
 
 def set_laplacian_format(fmt: str) -> None:
-    """Kernel / storage form of the group-1 (Laplacian-type) products at 64 / 128 dense columns:
+    """PROCESS DEFAULT of the kernel / storage form of the group-1 (Laplacian-type) products at 64 / 128 dense columns (one
+    operator can choose for itself: `op.format = "rb4"`):
     'ring' (default) the sliding-window kernel straight from the CSR arrays (X rows within +-160 of the current rows in an
                     LDS ring, everything requested once by LDS-DMA) for square operators of >= 131 072 rows whose entries all
                     lie in that window (SparseOperator.ring_ok: batches of meshes in a locality-preserving vertex order);
@@ -43,7 +44,8 @@ def set_laplacian_format(fmt: str) -> None:
 
 
 def set_dirac_format(fmt: str) -> None:
-    """Kernel / storage form of the group-4 (quaternionic Dirac) products:
+    """PROCESS DEFAULT of the kernel / storage form of the group-4 (quaternionic Dirac) products (one operator can choose for
+    itself: `op.format = "bsr4"`; batches a pool assembles in the packed form only multiply in that form):
     'q3'   (default) quaternion-packed blocks, 16 bytes each, when the operator's blocks are pure-quaternion matrices;
                      operators that are not fall back to 'bsr4';
     'bsr4' packed 4x4 blocks (68 bytes each) when the operator has them;
@@ -131,9 +133,6 @@ class SpmmTimer:
         return out
 
 
-# SN_LAP_ABSMAX=0: the fused transposed Laplacian products leave no maxima (the weight gradients behind them then take three
-# bf16 pieces) — A/B switch
-_LAP_ABSMAX = os.environ.get("SN_LAP_ABSMAX", "1") != "0"
 
 
 def _ctypes_i64_ref():
@@ -157,7 +156,12 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
     # the block-form kernels and every fused epilogue exist for N in {16, 32, 64, 128} dense columns (the widths the
     # reference models use: 64 / 128 channels); any other width takes the generic CSR kernel and an unfused epilogue
     vec = (y.shape[1] // group) in (16, 32, 64, 128)
-    if group == 4 and _DIRAC_FORMAT == "q3" and vec:
+    # storage form: the operator's own choice (SparseOperator.format: "q3" | "bsr4" | "ring" | "rb4" | "csr"), else the process
+    # defaults (set_dirac_format / set_laplacian_format)
+    own = getattr(op, "format", None)
+    dfmt = own if own in ("q3", "bsr4", "csr") else _DIRAC_FORMAT
+    lfmt = own if own in ("ring", "rb4", "csr") else _LAPLACIAN_FORMAT
+    if group == 4 and dfmt == "q3" and vec:
         q = op.q3()
         if q is not None:
             if stats and e is None and kernels.spmm_q3_stats_supported(y.shape[1] // group, group):
@@ -166,24 +170,24 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
             if am is not None:
                 kernels.note_absmax(y, am)           # a fused ELU-backward product writes a gradient: the dy of the layer below
             return None
-    b = op.bsr4() if (_DIRAC_FORMAT != "csr" and group == 4 and vec) else None
+    b = op.bsr4() if (dfmt != "csr" and group == 4 and vec) else None
     if b is not None:
         if elubwd is None:
             kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
         else:
             kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, x, e, g, y, group)
-    elif _LAPLACIAN_FORMAT == "ring" and group == 1 and op.ring_ok(y.shape[1]):
+    elif lfmt == "ring" and group == 1 and op.ring_ok(y.shape[1]):
         # banded square operator on a batch that fills the chip: sliding window over X in LDS, straight from the CSR arrays
         if stats and e is None and y.shape[1] == 128:
             return kernels.spmm_ring_stats(op.rowptr, op.colind, op.vals, M, K, x, y)
-        am = kernels.spmm_ring(op.rowptr, op.colind, op.vals, M, K, x, y, e, g, want_absmax=e is not None and _LAP_ABSMAX and kernels.absmax_wanted())
+        am = kernels.spmm_ring(op.rowptr, op.colind, op.vals, M, K, x, y, e, g, want_absmax=e is not None and kernels.absmax_wanted())
         if am is not None:
             kernels.note_absmax(y, am)               # (as the packed Dirac product above: y is the dy of the layer below)
-    elif _LAPLACIAN_FORMAT in ("ring", "rb4") and kernels.spmm_rb4_supported(y.shape[1] // group, group) and op.rb4() is not None:
+    elif lfmt in ("ring", "rb4") and kernels.spmm_rb4_supported(y.shape[1] // group, group) and op.rb4() is not None:
         r = op.rb4()                                   # Laplacian-type operator: one gather per listed column of a 4-row group
         if stats and e is None and y.shape[1] == 128:
             return kernels.spmm_rb4_stats(r[0], r[1], r[2], M, K, x, y)
-        am = kernels.spmm_rb4(r[0], r[1], r[2], M, K, x, y, e, g, want_absmax=e is not None and _LAP_ABSMAX and kernels.absmax_wanted())
+        am = kernels.spmm_rb4(r[0], r[1], r[2], M, K, x, y, e, g, want_absmax=e is not None and kernels.absmax_wanted())
         if am is not None:
             kernels.note_absmax(y, am)
     elif elubwd is None:
@@ -448,21 +452,6 @@ def _take_counter(running_mean):
     return d.pop("_sn_nbt", None) if d is not None else None
 
 
-def _fold_sources(x, part, part_hi, pre_stats):
-    """(lo, hi) producers of the column statistics of the (rows, C) operand x for kernels.bn_fold_parts: ready statistics as
-    a one-block partial; the partials left by the kernels that wrote the halves of a concat buffer; a statistics pass
-    (without its final reduction) over whatever has none."""
-    rows, C = x.shape
-    if pre_stats is not None:
-        return (pre_stats.reshape(1, 2, C), 1, C), (None, 0, 0)
-    if C == 256 and (part is not None or part_hi is not None):
-        h = C // 2
-        lo = (part, kernels.linear_fwd_stats_blocks(rows), h) if part is not None else (*kernels.colstats_partial(x[:, :h]), h)
-        hi = (part_hi, int(part_hi.shape[0]), h) if part_hi is not None else (*kernels.colstats_partial(x[:, h:]), h)
-        return lo, hi
-    return (*kernels.colstats_partial(x), C), (None, 0, 0)
-
-
 def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, momentum, eps, residual=None, elu_out=None,
                   want_y=True, elu_stats=None, pre_stats=None, tile_sums=None):
     """Forward of the folded BatchNorm1d("pre") + Linear on a (rows, C) operand (no autograd): statistics in one pass
@@ -473,13 +462,8 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     part, part_hi = getattr(x, "_sn_part", None), getattr(x, "_sn_part_hi", None)   # (hi: left by the SpMM that wrote P·e)
     x = _rows2d(x)
     rows = x.shape[0]
-    folded = None
     nbt = _take_counter(running_mean)
-    if training and _BN_SYNC is None and rows > 0 and kernels.fold_parts_supported(x.shape[1]):
-        # statistics reduction + fold in one launch, straight from the producers' partials
-        folded = kernels.bn_fold_parts(*_fold_sources(x, part, part_hi, pre_stats), rows, gamma, beta, W, b, eps, momentum,
-                                       running_mean, running_var, nbt)
-    if folded is not None or not training:
+    if not training:
         stats = None
     elif pre_stats is not None:                 # (2, C) float64 statistics of x supplied by its producer
         stats = pre_stats
@@ -489,13 +473,10 @@ def bnlin_forward(x, gamma, beta, W, b, running_mean, running_var, training, mom
     else:
         stats = kernels.colstats(x)
     rows_g = rows
-    if training and folded is None:
+    if training:
         stats, rows_g = _sync_stats(stats, rows)
-    if folded is not None:
-        mean, invstd, s, t, Wf, bf = folded
-    else:
-        mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
-                                                     running_var, nbt)
+    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
+                                                 running_var, nbt)
     if residual is not None:
         residual = _rows2d(residual)
     if kernels.linear_fwd_supported(x.shape[1], W.shape[0]):
@@ -559,14 +540,8 @@ def _centered_wgrad(dy, x, mean, bounds=None):
 
 def _wgrad_and_coeffs(dy, x, W, s, mean, invstd, beta, training, has_bias, rows_g):
     """(dW, db, dgamma, dbeta, Bc, Cc) of a folded BatchNorm+Linear: the centred weight gradient G = dyᵀ·(x - mean), colsum(dy) and
-    every BatchNorm reduction they give algebraically.  Training step with local statistics: the product and ONE finishing
-    launch (kernels.wgrad_bn); otherwise the product, [the all-reduce of synchronised statistics,] the coefficients."""
-    J, C = dy.shape[1], x.shape[1]
+    every BatchNorm reduction they give algebraically: the product, [the all-reduce of synchronised statistics,] the coefficients."""
     bounds = _dy_bounds(dy, invstd, rows_g, training)
-    if training and _BN_SYNC is None and x.shape[0] > 0 and kernels.wgrad_bn_supported(J, C):
-        r = kernels.wgrad_bn(dy, x, mean, W, s, invstd, beta, rows_g, has_bias, bounds)
-        if r is not None:
-            return r[:6]
     Gc, sdy = _centered_wgrad(dy, x, mean, bounds)
     scale = 1.0
     if training:
@@ -626,23 +601,16 @@ def bnlin_forward_zero_first(p, gamma, beta, W, b, running_mean, running_var, tr
     rows, C = p.shape
     stats = None
     rows_g = rows
-    folded = None
     nbt = _take_counter(running_mean)
-    if training and _BN_SYNC is None and rows > 0 and kernels.fold_parts_supported(2 * C):
-        hi = (part_hi, int(part_hi.shape[0]), C) if (part_hi is not None and C == 128) else (*kernels.colstats_partial(p), C)
-        folded = kernels.bn_fold_parts((None, 0, C), hi, rows, gamma, beta, W, b, eps, momentum, running_mean, running_var, nbt)
-    if folded is not None:
-        mean, invstd, s, t, Wf, bf = folded
-    else:
-        if training:
-            stats = torch.zeros((2, 2 * C), dtype=torch.float64, device=p.device)
-            if part_hi is not None and C == 128:
-                kernels.colstats_merge_into(part_hi, stats, C)
-            else:
-                kernels.colstats_into(p, stats, C)
-            stats, rows_g = _sync_stats(stats, rows)
-        mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
-                                                     running_var, nbt)
+    if training:
+        stats = torch.zeros((2, 2 * C), dtype=torch.float64, device=p.device)
+        if part_hi is not None and C == 128:
+            kernels.colstats_merge_into(part_hi, stats, C)
+        else:
+            kernels.colstats_into(p, stats, C)
+        stats, rows_g = _sync_stats(stats, rows)
+    mean, invstd, s, t, Wf, bf = kernels.bn_fold(stats, rows_g, gamma, beta, W, b, eps, momentum, training, running_mean,
+                                                 running_var, nbt)
     y = kernels.linear_fwd(p, Wf[:, C:], bf, None, elu_out, want_y, elu_stats)
     return y, (p, W, Wf, s, mean, invstd, beta, training, b is not None, rows_g)
 
@@ -725,22 +693,16 @@ def avg_stage_backward(state, mask_rows, inv_count, nseg, per, dy, gadd):
     dy = dy.contiguous()
     rows, C = e.shape
     bounds = _dy_bounds(dy, invstd[:C], rows_g, True)
-    r = None
-    if _BN_SYNC is None and rows > 0 and kernels.wgrad_bn_supported(dy.shape[1], C):
-        r = kernels.wgrad_bn(dy, e, mean[:C], W, s, invstd, beta, rows_g, has_bias, bounds, rows_per_seg=per, m=m, mu2=mean[C:])
-    if r is not None:
-        dW, db, dgamma, dbeta, Bc, Cc, Sg = r
-    else:
-        G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per, bounds=bounds)   # per-mesh column sums of dy from the same pass
-        if _BN_SYNC is None and kernels.avg_merged_supported(dy.shape[1], C, m.shape[0], 2):
-            dW, db, dgamma, dbeta, Bc, Cc, segvec = kernels.avg_bn_bwd(G1, sdy, Sg, m, mean[C:], W, s, invstd, beta, rows_g, has_bias,
-                                                                       Wf[:, C:], inv_count, rows_per_seg=per)
-            g = kernels.linear_dgrad_eluseg(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, per, mask_rows, gadd)
-            return g, dgamma, dbeta, dW, db
-        Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
-        Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
-        dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
-        dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per, bounds=bounds)   # per-mesh column sums of dy from the same pass
+    if _BN_SYNC is None and kernels.avg_merged_supported(dy.shape[1], C, m.shape[0], 2):
+        dW, db, dgamma, dbeta, Bc, Cc, segvec = kernels.avg_bn_bwd(G1, sdy, Sg, m, mean[C:], W, s, invstd, beta, rows_g, has_bias,
+                                                                   Wf[:, C:], inv_count, rows_per_seg=per)
+        g = kernels.linear_dgrad_eluseg(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, per, mask_rows, gadd)
+        return g, dgamma, dbeta, dW, db
+    Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
+    Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
+    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
     segvec = kernels.avg_bwd_segvec(Sg, Wf[:, C:], m, mean[C:], Bc[C:], Cc[C:], inv_count, per)
     g = kernels.linear_dgrad_eluseg(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, per, mask_rows, gadd)
     return g, dgamma, dbeta, dW, db
@@ -788,22 +750,16 @@ def avg_stage_backward_ragged(state, seg, dy, gadd):
     dy = dy.contiguous()
     rows, C = e.shape
     bounds = _dy_bounds(dy, invstd[:C], rows_g, True)
-    r = None
-    if _BN_SYNC is None and rows > 0 and kernels.wgrad_bn_supported(dy.shape[1], C):
-        r = kernels.wgrad_bn(dy, e, mean[:C], W, s, invstd, beta, rows_g, has_bias, bounds, seg=seg, m=m, mu2=mean[C:])
-    if r is not None:
-        dW, db, dgamma, dbeta, Bc, Cc, Sg = r
-    else:
-        G1, sdy, Sg = kernels.wgrad_slabs(dy, e, mean[:C], seg, bounds=bounds)
-        if _BN_SYNC is None and kernels.avg_merged_supported(dy.shape[1], C, m.shape[0], 2):
-            dW, db, dgamma, dbeta, Bc, Cc, segvec = kernels.avg_bn_bwd(G1, sdy, Sg, m.contiguous(), mean[C:], W, s, invstd, beta, rows_g,
-                                                                       has_bias, Wf[:, C:], seg.inv_count, segoff=seg.off_dev)
-            g = kernels.linear_dgrad_eluseg_ragged(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, seg, gadd)
-            return g, dgamma, dbeta, dW, db
-        Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
-        Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
-        dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
-        dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
+    G1, sdy, Sg = kernels.wgrad_slabs(dy, e, mean[:C], seg, bounds=bounds)
+    if _BN_SYNC is None and kernels.avg_merged_supported(dy.shape[1], C, m.shape[0], 2):
+        dW, db, dgamma, dbeta, Bc, Cc, segvec = kernels.avg_bn_bwd(G1, sdy, Sg, m.contiguous(), mean[C:], W, s, invstd, beta, rows_g,
+                                                                   has_bias, Wf[:, C:], seg.inv_count, segoff=seg.off_dev)
+        g = kernels.linear_dgrad_eluseg_ragged(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, seg, gadd)
+        return g, dgamma, dbeta, dW, db
+    Gc = kernels.avg_bwd_gc(G1, Sg, m, mean[C:])
+    Gc, sdy, scale = _sync_grad_stats(Gc, sdy)
+    dW, db, dgamma, dbeta, Bc, Cc = kernels.bn_bwd_coeffs(Gc, sdy, W, s, invstd, beta, rows_g, has_bias)
+    dW, db, dgamma, dbeta = _scale_param_grads(scale, dW, db, dgamma, dbeta)
     segvec = kernels.avg_bwd_segvec_ragged(Sg, Wf[:, C:], m, mean[C:], Bc[C:], Cc[C:], seg)
     g = kernels.linear_dgrad_eluseg_ragged(dy, Wf[:, :C], e, mean[:C], Bc[:C], Cc[:C], segvec, seg, gadd)
     return g, dgamma, dbeta, dW, db

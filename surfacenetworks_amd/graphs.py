@@ -94,10 +94,11 @@ def operator_tensors(op: Optional[SparseOperator]) -> List[torch.Tensor]:
         if o._csr is not None and not isinstance(o._bsr4, tuple) and not isinstance(o._q3, tuple):
             from . import functional as snF
 
-            if snF._LAPLACIAN_FORMAT in ("ring", "rb4") and o.is_cuda:
+            lfmt = o.format if o.format in ("ring", "rb4", "csr") else snF._LAPLACIAN_FORMAT
+            if lfmt in ("ring", "rb4") and o.is_cuda:
                 # (an operator that takes the sliding-window kernel is multiplied straight from its CSR arrays: nothing
                 #  derived to list; the decision — the band of the operator — is measured here, before the capture)
-                if snF._LAPLACIAN_FORMAT == "ring" and _ring_choice(o):
+                if lfmt == "ring" and _ring_choice(o):
                     continue
                 r = o.rb4()
                 if r is not None:

@@ -16,8 +16,8 @@ __all__ = [
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
-    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "pair_ce_fwd", "pair_ce_bwd", "pair_fused_fwd", "pair_fused_bwd", "bn_fold_parts", "colstats_partial", "linear_fwd_stats_blocks", "fold_parts_supported", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
-    "wgrad_bn_supported", "avg_merged_supported", "avg_stats_ragged", "avg_stats_from_tiles_ragged", "gather_segments_ragged",
+    "avg_stage_supported", "avg_fwd_prep", "avg_stats", "seg_affine", "avg_bwd_gc", "avg_bwd_segvec", "linear_fwd_segbias", "linear_dgrad_eluseg", "wgrad_seg", "wgrad_slabs", "avg_bwd_segvec_ragged", "linear_fwd_segbias_ragged", "linear_dgrad_eluseg_ragged", "avg_stage_ragged_supported", "wgrad_thin", "wgrad_thin_supported", "linear_thin_fwd", "masked_smooth_l1_fwd", "masked_smooth_l1_bwd", "gather_segments", "pair_argmin", "pair_ce_fwd", "pair_ce_bwd", "pair_fused_fwd", "pair_fused_bwd", "colstats_partial", "linear_fwd_stats_blocks", "elu_stats_supported", "new_elu_stats_part", "colstats_halves", "colstats_into", "colstats_from_part", "colstats_merge_into",
+    "avg_merged_supported", "avg_stats_ragged", "avg_stats_from_tiles_ragged", "gather_segments_ragged",
 ]
 
 
@@ -438,11 +438,15 @@ def wgrad_supported(J: int, C: int) -> bool:
 # in-place edit invalidates it); only the last few entries are kept (a gradient is consumed within a few launches).
 _ABSMAX_KEEP = 8
 _absmax_table = {}          # data_ptr -> (tensor, version, maxima)
-_absmax_enabled = __import__("os").environ.get("SN_WGRAD_H", "-2") != "-1" and __import__("os").environ.get("SN_GEMM_VARIANT", "2") != "0" \
-    and __import__("os").environ.get("SN_WGRAD_VARIANT", "2") == "2"
+_absmax_enabled = None
 
 
 def absmax_wanted() -> bool:
+    """Whether producers of gradient tensors should leave their maxima: asked of the library once (sn_wgrad_bounded_enabled —
+    the one place that decides whether the bounded two-piece weight gradient runs)."""
+    global _absmax_enabled
+    if _absmax_enabled is None:
+        _absmax_enabled = bool(_lib.load().sn_wgrad_bounded_enabled())
     return _absmax_enabled
 
 
@@ -539,43 +543,6 @@ def bn_fold(stats, rows: int, gamma, beta, W, b, eps: float, momentum: float, tr
     return vec[0], vec[1], vec[2], vec[3], Wf, bf
 
 
-_FOLD_COUNTERS = {}          # device index -> [int32 pool, {stream handle: [first slot, launches so far]}]
-_FOLD_STREAMS, _FOLD_SLOTS = 16, 4096
-
-
-def _fold_counter(device, n: int = 1):
-    """Address of n zeroed int32 for one ticketed launch (sn_bn_fold_parts_f32, sn_wgrad_bn_f32) on the current stream, or None
-    (then the caller takes the separate launches).  The kernel leaves its counters at 0, so slots are reused; launches of ONE
-    stream run in order, so a stream's slots (round-robin over 4096: consecutive nodes of a captured graph get different ones)
-    never serve two launches at once, and every stream has its own range.  The pool is created on the first eager call (never
-    during a capture: a fill recorded into a graph would not have run yet)."""
-    dev = torch.device(device)
-    key = dev.index if dev.index is not None else torch.cuda.current_device()
-    ent = _FOLD_COUNTERS.get(key)
-    if ent is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None
-        ent = _FOLD_COUNTERS[key] = [torch.zeros(_FOLD_STREAMS * _FOLD_SLOTS, dtype=torch.int32, device=dev), {}]
-    sid = torch.cuda.current_stream(dev).cuda_stream
-    slot = ent[1].get(sid)
-    if slot is None:
-        if len(ent[1]) >= _FOLD_STREAMS:
-            return None
-        slot = ent[1][sid] = [len(ent[1]) * _FOLD_SLOTS, 0]
-    if slot[1] % _FOLD_SLOTS + n > _FOLD_SLOTS:      # (a group of counters does not wrap around the stream's range)
-        slot[1] += _FOLD_SLOTS - slot[1] % _FOLD_SLOTS
-    idx = slot[0] + slot[1] % _FOLD_SLOTS
-    slot[1] += n
-    return ent[0].data_ptr() + 4 * idx
-
-
-def fold_parts_supported(C: int) -> bool:
-    import os
-
-    # off by default: measured no faster than the three launches it replaces (LABNOTES.md, "helper launches")
-    return C in (128, 256) and os.environ.get("SN_FOLD_PARTS", "0") == "1"
-
-
 def linear_fwd_stats_blocks(rows: int) -> int:
     """Partial rows the ELU-statistics epilogue of a forward GEMM over `rows` rows leaves (sn_linear_fwd_stats_blocks)."""
     return int(_lib.load().sn_linear_fwd_stats_blocks(rows))
@@ -583,40 +550,13 @@ def linear_fwd_stats_blocks(rows: int) -> int:
 
 def colstats_partial(x):
     """(partials (nblk, 2, C) float64, nblk): the statistics pass over the 2-D view x without its final reduction
-    (sn_colstats_partial_f32) — a producer for bn_fold_parts."""
+    (sn_colstats_partial_f32)."""
     _dev(x)
     rows, C = x.shape
     nblk = int(_lib.load().sn_colstats_blocks(rows))
     part = torch.empty((max(nblk, 1), 2, C), dtype=torch.float64, device=x.device)
     _lib.call("sn_colstats_partial_f32", _p(x), _ld(x), rows, C, _p(part), _stream())
     return part, nblk
-
-
-def bn_fold_parts(lo, hi, rows: int, gamma, beta, W, b, eps: float, momentum: float, running_mean, running_var,
-                  num_batches_tracked=None):
-    """Training-mode bn_fold with the statistics reduction inside (sn_bn_fold_parts_f32): lo / hi = (partials or None,
-    nblk, channels) of the two halves of the operand (hi may be (None, 0, 0)).  Returns (mean, invstd, s, t, Wf, bf), or None
-    when no launch counter is to be had (the caller then reduces the statistics and calls bn_fold)."""
-    J, C = W.shape
-    counter = _fold_counter(W.device)
-    if counter is None:
-        return None
-    _dev(lo[0], hi[0], gamma, beta, W, b, running_mean, running_var, num_batches_tracked)
-    if num_batches_tracked is not None and num_batches_tracked.dtype != torch.int64:
-        raise TypeError("num_batches_tracked must be int64")
-    for p_, nb, cx in (lo, hi):
-        if p_ is not None and (p_.dtype != torch.float64 or not p_.is_contiguous() or p_.shape[0] < nb or tuple(p_.shape[1:]) != (2, cx)):
-            raise ValueError("bn_fold_parts: partials must be contiguous (>= nblk, 2, channels) float64")
-    if lo[2] + hi[2] != C:
-        raise ValueError("bn_fold_parts: the halves do not add up to the Linear's input width")
-    dev = W.device
-    vec = torch.empty((4, C), dtype=torch.float32, device=dev)
-    Wf = torch.empty((J, C), dtype=torch.float32, device=dev)
-    bf = torch.empty(J, dtype=torch.float32, device=dev)
-    _lib.call("sn_bn_fold_parts_f32", _p(lo[0]), lo[1], lo[2], _p(hi[0]), hi[1], hi[2], rows, _p(gamma), _p(beta), _p(W.contiguous()), _p(b),
-              J, float(eps), float(momentum), _p(running_mean), _p(running_var), _p(num_batches_tracked), _p(vec[0]), _p(vec[1]),
-              _p(vec[2]), _p(vec[3]), _p(Wf), _p(bf), counter, _stream())
-    return vec[0], vec[1], vec[2], vec[3], Wf, bf
 
 
 def bn_bwd_coeffs(Gc, dystats, W, s, invstd, beta, rows: int, has_bias: bool):
@@ -630,51 +570,6 @@ def bn_bwd_coeffs(Gc, dystats, W, s, invstd, beta, rows: int, has_bias: bool):
     _lib.call("sn_bn_bwd_coeffs_f32", _p(Gc), _p(dystats), _p(W.contiguous()), _p(s), _p(invstd), _p(beta.contiguous()),
               rows, J, C, _p(dW), _p(db), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _stream())
     return dW, db, vec[0], vec[1], vec[2], vec[3]
-
-
-def wgrad_bn_supported(J: int, C: int) -> bool:
-    """Shapes (and the switch SN_WGRAD_BN=1; OFF by default) for which the weight gradient and the BatchNorm backward coefficients
-    come from two launches (wgrad_bn) instead of the product, its reduction, [the global-average half] and the coefficients.
-    Bit-identical, and measured no faster (LABNOTES.md, "helper launches, round 4"): a helper launch costs 3.4 us in the step,
-    the hand-over inside one kernel (write-through stores, ticket, loads past the L2) about the same — config-3 step 19.43 ->
-    19.58 ms, FAUST pair 3.45 -> 4.38 ms replayed."""
-    import os
-
-    return wgrad_supported(J, C) and os.environ.get("SN_WGRAD_BN", "0") == "1"
-
-
-def wgrad_bn(dy, x, center, W, s, invstd, beta, bn_rows: int, has_bias: bool, bounds=None, rows_per_seg: int = 0, seg=None, m=None,
-             mu2=None):
-    """(dW, db, dgamma, dbeta, Bc, Cc, per-mesh colsum(dy) | None) of the folded BatchNorm+Linear backward, or None when no
-    counters are to be had (the caller then takes wgrad + bn_bwd_coeffs): the split-K product of dy and x - center and ONE
-    finishing launch (sn_wgrad_bn_f32).  W is (J, Ct) with Ct = C, or 2 C for a global-average stage (then m (nseg, C), mu2 (C)
-    and meshes — rows_per_seg > 0 for equal ones, seg = operators.PackedSegments for ragged ones)."""
-    _dev(dy, x, center, W, s, invstd, beta, m, mu2)
-    rows, J = dy.shape
-    C = x.shape[1]
-    Ct = W.shape[1]
-    dev = dy.device
-    if x.shape[0] != rows or W.shape[0] != J or Ct not in (C, 2 * C):
-        raise ValueError("wgrad_bn: shape mismatch")
-    counters = _fold_counter(dev, Ct // 32)
-    if counters is None:
-        return None
-    nseg = seg.nseg if seg is not None else (rows // rows_per_seg if rows_per_seg > 0 else 0)
-    nslab_r = seg.nslab if seg is not None else 0
-    ws_bytes = int(_lib.load().sn_wgrad_bn_workspace_bytes(rows, rows_per_seg if seg is None else 0, nslab_r, J, C, Ct))
-    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
-    Gc = torch.empty((J, Ct), dtype=torch.float32, device=dev)
-    dW = torch.empty((J, Ct), dtype=torch.float32, device=dev)
-    db = torch.empty(J, dtype=torch.float32, device=dev) if has_bias else None
-    vec = torch.empty((4, Ct), dtype=torch.float32, device=dev)
-    Sg = torch.empty((nseg, J), dtype=torch.float32, device=dev) if nseg > 0 else None
-    b = _bounds_args(bounds, C) if bounds is not None else (None, 0, None, 0)
-    _lib.call("sn_wgrad_bn_f32", _p(dy), _ld(dy), _p(x), _ld(x), _p(center), rows, J, C, rows_per_seg if seg is None else 0,
-              _p(seg.slab_off) if seg is not None else None, nslab_r, _p(seg.seg_slab_ptr) if seg is not None else None,
-              seg.nseg if seg is not None else 0, *b, _p(W.contiguous()), _p(s), _p(invstd), _p(beta.contiguous()), bn_rows, Ct,
-              _p(m), _p(mu2), _p(Gc), _p(dW), _p(db), _p(vec[0]), _p(vec[1]), _p(vec[2]), _p(vec[3]), _p(Sg), None, _p(ws), ws_bytes,
-              counters, _stream())
-    return dW, db, vec[0], vec[1], vec[2], vec[3], Sg
 
 
 def segment_colsum(x, mask, rows_per_seg: int, nseg: int):
@@ -773,10 +668,16 @@ def laplacian_from_mesh(V, F):
     return rowptr, colind, vals
 
 
-def _split_gemm() -> bool:
-    import os
+_gemm_variant = None
 
-    return os.environ.get("SN_GEMM_VARIANT", "2") != "0"
+
+def _split_gemm() -> bool:
+    """True unless the process runs the fp32-MFMA A/B baseline of the Linear kernels (SN_GEMM_VARIANT=0) — asked of the library
+    (sn_gemm_variant), which reads the switch once: the fused epilogues exist in the 16-bit matrix-pipe kernels only."""
+    global _gemm_variant
+    if _gemm_variant is None:
+        _gemm_variant = int(_lib.load().sn_gemm_variant())
+    return _gemm_variant != 0
 
 
 def linear_fwd_supported(K: int, J: int) -> bool:
@@ -785,10 +686,8 @@ def linear_fwd_supported(K: int, J: int) -> bool:
 
 
 def elu_stats_supported() -> bool:
-    """Column statistics of the ELU output from the GEMM epilogue exist only in the split-bf16 kernels."""
-    import os
-
-    return os.environ.get("SN_GEMM_VARIANT", "1") != "0"
+    """Column statistics of the ELU output from the GEMM epilogue exist only in the 16-bit matrix-pipe kernels."""
+    return _split_gemm()
 
 
 def new_elu_stats_part(rows: int, device):
@@ -799,9 +698,7 @@ def new_elu_stats_part(rows: int, device):
 
 def tile_sums_supported() -> bool:
     """The forward kernels can leave per-tile column sums of their ELU output (sn_linear_fwd_tiles_f32): split kernels only."""
-    import os
-
-    return elu_stats_supported() and os.environ.get("SN_TILE_SUMS", "1") != "0"
+    return elu_stats_supported()
 
 
 def new_tile_sums(rows: int, device):
@@ -938,10 +835,8 @@ def linear_dgrad_supported(J: int, C: int) -> bool:
 
 
 def linear_dgrad_elu_supported(J: int, C: int) -> bool:
-    """The fused form exists only in the split-bf16 kernels (SN_GEMM_VARIANT != 0)."""
-    import os
-
-    return 0 < J <= 128 and J % 4 == 0 and C in (128, 256) and os.environ.get("SN_GEMM_VARIANT", "1") != "0"
+    """The fused form exists only in the 16-bit matrix-pipe kernels (SN_GEMM_VARIANT != 0)."""
+    return 0 < J <= 128 and J % 4 == 0 and C in (128, 256) and _split_gemm()
 
 
 def linear_dgrad_elu(dy, W, x, center, B, Cc, gadd=None):
@@ -962,7 +857,7 @@ def linear_dgrad_elu(dy, W, x, center, B, Cc, gadd=None):
 
 def _new_dgrad_absmax(device):
     """Buffer for the per-workgroup maxima an input-gradient launch leaves (None when the two-piece weight gradient is off)."""
-    if not _absmax_enabled:
+    if not absmax_wanted():
         return None
     return torch.empty(int(_lib.load().sn_linear_dgrad_absmax_blocks()), dtype=torch.float32, device=device)
 
@@ -980,9 +875,7 @@ def linear_dgrad(dy, W, x=None, center=None, B=None, Cc=None):
 
 # ---- half-width global-average stage (see include/sn_spmm.h) ----------------------------------------------------------
 def avg_stage_supported(C: int, J: int, rows_per_seg: int) -> bool:
-    import os
-
-    return C == 128 and J == 128 and rows_per_seg >= 32 and os.environ.get("SN_GEMM_VARIANT", "1") != "0"
+    return C == 128 and J == 128 and rows_per_seg >= 32 and _split_gemm()
 
 
 def avg_fwd_prep(segsum, inv_count, rows_per_seg: int, stats1):
@@ -1033,17 +926,15 @@ def avg_stats_ragged(m, seg, part, nblk: int):
 
 
 def avg_merged_supported(J: int, C: int, nseg: int, which: int = 1) -> bool:
-    """Shapes (and the switch SN_AVG_MERGED: bit 0 — forward, bit 1 — backward) for which a global-average stage folds its per-mesh
-    bias into the fold launch (bn_fold_seg, which = 1) / runs gc + coefficients + per-mesh vector of its backward as one launch
-    (avg_bn_bwd, which = 2)."""
-    import os
+    """Shapes for which a global-average stage folds its per-mesh bias into the fold launch (bn_fold_seg, which = 1) / runs gc +
+    coefficients + per-mesh vector of its backward as one launch (avg_bn_bwd, which = 2)."""
 
     # The merged launches run per-channel (backward) / per-output-row (forward) work that the separate kernels spread over many
     # more workgroups: they win while the per-mesh algebra is small.  Same box, config-3 step (64 meshes): forward merge 18.94 ->
     # 18.89 ms, backward merge 18.94 -> 19.63 (its 4 workgroups of the broadcast half walk 64 meshes x 128 rows each); FAUST pair
     # (one mesh per tower) with both 3.44 -> 3.35 ms.  Hence: forward up to 64 meshes, backward up to 8.
     lim = 64 if which == 1 else 8
-    return J <= 128 and C % 32 == 0 and 2 * C <= 256 and 0 < nseg <= lim and (int(os.environ.get("SN_AVG_MERGED", "3")) & which) != 0
+    return J <= 128 and C % 32 == 0 and 2 * C <= 256 and 0 < nseg <= lim
 
 
 def bn_fold_seg(stats, rows: int, gamma, beta, W, b, eps: float, momentum: float, running_mean, running_var, m, num_batches_tracked=None):
@@ -1184,10 +1075,7 @@ def linear_dgrad_eluseg_ragged(dy, W, x, center, B, Cc, segvec, seg, gadd=None):
 
 
 def avg_stage_ragged_supported(C: int, J: int, seg) -> bool:
-    import os
-
-    return C == 128 and J == 128 and seg.min_len >= 32 and os.environ.get("SN_GEMM_VARIANT", "2") != "0" and \
-        os.environ.get("SN_WGRAD_VARIANT", "2") == "2"
+    return C == 128 and J == 128 and seg.min_len >= 32 and _split_gemm()
 
 
 def wgrad_thin_supported(J: int, C: int) -> bool:

@@ -46,6 +46,7 @@ class SparseOperator:
 
     layout = "sn_csr"
     requires_grad = False
+    _format = None
 
     def __init__(self, rowptr, colind, vals, shape, *, batch: int = 1, transpose: "Optional[SparseOperator]" = None,
                  bsr4=None, q3=None):
@@ -75,6 +76,21 @@ class SparseOperator:
         self._q3 = q3                            # (b_rowptr, q_blk) quaternion-packed form | None (unknown) | False (not a Dirac-type operator)
         self._rb4 = None                         # (b_ptr, b_col, b_val) 4x1 row-blocked form | None (not built) | False (not worthwhile)
         self._band = None                        # (max |column - row|, longest row, rows outside the ring window) | None (not measured)
+
+    @property
+    def format(self):
+        """Storage form this operator's products take ("q3" | "bsr4" | "ring" | "rb4" | "csr"); None: the process default
+        (functional.set_dirac_format / set_laplacian_format).  Shared with the attached transpose."""
+        return self._format
+
+    @format.setter
+    def format(self, fmt):
+        if fmt not in (None, "q3", "bsr4", "ring", "rb4", "csr"):
+            raise ValueError(fmt)
+        self._format = fmt
+        t = self._t
+        if t is not None:
+            t._format = fmt
 
     @property
     def _t(self) -> "Optional[SparseOperator]":
@@ -208,6 +224,7 @@ class SparseOperator:
             M, K = self._shape
             tr, tc, tv = kernels.csr_transpose(self.rowptr, self.colind, self.vals, M, K)
             t = self._t = SparseOperator(tr, tc, tv, (K, M), batch=self.batch, transpose=self)
+            t._format = self._format
         return t
 
     T = property(t)
@@ -499,7 +516,7 @@ def h2d_async(arr, device) -> torch.Tensor:
     uploads of the samplers do not wait for the previous step's kernels — a pageable-source copy does."""
     t = torch.from_numpy(np.ascontiguousarray(arr))
     dev = torch.device(device)
-    if dev.type != "cuda" or os.environ.get("SN_PINNED_H2D", "1") == "0":
+    if dev.type != "cuda":
         return t.to(dev, non_blocking=True)
     stage = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
     stage.copy_(t)

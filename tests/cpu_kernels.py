@@ -197,10 +197,6 @@ def avg_merged_supported(J, C, nseg, which=1):
     return False          # the host twins keep the separate steps of a global-average stage
 
 
-def wgrad_bn_supported(J, C):
-    return False          # the host twins keep the separate steps (product, reduction, coefficients)
-
-
 def absmax_wanted():
     return False          # the host twins have one weight gradient (exact): no bounds are produced or consumed
 
@@ -378,24 +374,12 @@ def colstats_halves(x, part, part_hi=None):
     return out
 
 
-def fold_parts_supported(C):
-    return C in (128, 256)
-
-
 def linear_fwd_stats_blocks(rows):
     return 1
 
 
 def colstats_partial(x):
     return colstats(x).reshape(1, 2, x.shape[1]), 1
-
-
-def bn_fold_parts(lo, hi, rows, gamma, beta, W, b, eps, momentum, running_mean, running_var, num_batches_tracked=None):
-    halves = []
-    for p_, nb, cx in (lo, hi):
-        if cx:
-            halves.append(p_[:nb].sum(0) if (p_ is not None and nb) else torch.zeros((2, cx), dtype=torch.float64))
-    return bn_fold(torch.cat(halves, 1), rows, gamma, beta, W, b, eps, momentum, True, running_mean, running_var, num_batches_tracked)
 
 
 def spmm_q3_stats_supported(N, group):

@@ -451,25 +451,6 @@ def test_blocks_survive_degenerate_column_statistics(golden_dir, cname):
             assert ea <= max(4 * er, 2e-5), (whole, k, "product", ea, "reference fp32", er)
 
 
-@pytest.mark.parametrize("cname", ["LapResNet2", "DirResNet2", "AvgResNet2"])
-def test_blocks_with_the_two_launch_backward(golden_dir, cname, monkeypatch):
-    """The opt-in backward (SN_WGRAD_BN=1: weight gradient + BatchNorm coefficients from sn_wgrad_bn_f32) through the blocks'
-    own backward passes, against the reference's stored outputs and gradients."""
-    from surfacenetworks_amd import kernels
-
-    calls = []
-    real = kernels.wgrad_bn
-
-    def counted(*a, **k):
-        calls.append(1)
-        return real(*a, **k)
-
-    monkeypatch.setattr(kernels, "wgrad_bn_supported", kernels.wgrad_supported)
-    monkeypatch.setattr(kernels, "wgrad_bn", counted)
-    pc.check_block(golden_dir, cname, 128, "pool", DEV)
-    assert len(calls) == 2          # both Linear layers of the block took it
-
-
 def test_packed_model_with_and_without_tile_sums(monkeypatch):
     """The ARAP Dirac model on a PACKED batch with the tile-sum hand-off through the ragged global-average stages (forced: it is
     used from 32 768 rows on) and with the pass over every stage's operand: same loss, gradients equal up to what the fp32 tile

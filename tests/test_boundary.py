@@ -114,3 +114,23 @@ def test_debug_validation_mode_rejects_malformed_operators(cpu_kernels, monkeypa
     with pytest.raises(ValueError, match="column index out of range"):
         op.validate()
     operators.SparseOperator(rp, torch.tensor([0, 3, 1], dtype=torch.int32), va, (2, 4)).validate()
+
+
+def test_environment_switches_are_the_documented_ones():
+    """Every environment variable the library (getenv) and the package (os.environ) read is listed — completely — in
+    include/sn_spmm.h ("SWITCHES:" line), and nothing listed is dead.  Superseded kernels and their A/B toggles are deleted,
+    not hidden behind undocumented switches."""
+    header = open(os.path.join(ROOT, "include", "sn_spmm.h")).read()
+    documented = set(re.search(r"SWITCHES:((?:\s+SN_[A-Z0-9_]+)+)", header).group(1).split())
+    found = set()
+    for dirpath, _, files in os.walk(PKG):
+        for fn in files:
+            if not fn.endswith((".py", ".hip", ".h")):
+                continue
+            text = open(os.path.join(dirpath, fn)).read()
+            found.update(re.findall(r'getenv\(\s*"(SN_[A-Z0-9_]+)"', text))
+            found.update(re.findall(r'environ(?:\.get|\.setdefault)?\(\s*"(SN_[A-Z0-9_]+)"', text))
+            found.update(re.findall(r'environ\[\s*"(SN_[A-Z0-9_]+)"', text))
+            # compile-time ablation toggles of earlier rounds (SN_X_*) are gone too
+            assert not re.search(r"\bSN_X_[A-Z0-9_]+", text), f"{fn} still carries an SN_X_* ablation toggle"
+    assert found == documented, (sorted(found - documented), sorted(documented - found))

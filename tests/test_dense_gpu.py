@@ -611,21 +611,6 @@ def test_split_fp16_row_and_column_scaling_covers_the_fp32_range():
     assert (np.abs(gotd - refd) / np.maximum(scaled, 1e-300)).max() <= 4 * 2.0 ** -24 * np.sqrt(J)
 
 
-def test_three_piece_bf16_kernels_stay_covered():
-    """SN_GEMM_VARIANT=1 (three bf16 pieces, the previous default and A/B baseline of the fp16 form): the accuracy and
-    epilogue tests of this file in a subprocess, because the library reads the switch once per process."""
-    import os
-    import subprocess
-    import sys
-
-    here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, SN_GEMM_VARIANT="1")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(here, "test_dense_gpu.py"), "-q", "-x", "-m", "gpu", "-k",
-                          "linear_fwd_mfma or linear_dgrad or split_bf16 or per_mesh_bias or statistics_of_its_elu or bn_linear"],
-                         env=env, capture_output=True, text=True, timeout=1200, cwd=os.path.dirname(here))
-    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-1000:]
-
-
 # ---- the Linear kernels address their operands through raw buffer windows (sn_gemm.hip RowWindow, wgrad_u_k): every
 # operand below is a strided view inside an arena of NaNs, every output a view inside an arena of canaries ---------------
 def _arena(rows, width, pad_rows=3, pad_cols=8, seed=0, fill=float("nan")):
@@ -840,65 +825,6 @@ def test_pair_cross_entropy_matches_torch(N, NA, NB):
         assert gg[:, NB:].abs().max().item() == 0 if N > NB else True
 
 
-@pytest.mark.parametrize("C,J,rows", [(256, 128, 7000), (128, 64, 5000), (256, 120, 33), (128, 128, 1), (256, 128, 300000)])
-def test_fold_with_the_statistics_reduction_inside_matches_the_three_launch_path(C, J, rows):
-    """sn_bn_fold_parts_f32 (partials of the producers -> statistics -> fold, one launch) against sn_colstats_merge_f64 per
-    half + sn_bn_fold_f32 on the same partials: identical statistics, scalars, folded weights, running statistics and
-    batch counter (the bias dot product is summed in another fixed order: equal to the last bit or one off); a half that is
-    all zero needs no partials; the launch counter is left at zero (same result again, also from two streams at once)."""
-    from surfacenetworks_amd import kernels
-
-    g = torch.Generator().manual_seed(C + J + rows)
-    x = (torch.randn(rows, C, generator=g) * 2 + 0.7).to(DEV)
-    W = torch.randn(J, C, generator=g).to(DEV)
-    b = torch.randn(J, generator=g).to(DEV)
-    gamma, beta = (torch.rand(C, generator=g) + 0.5).to(DEV), torch.randn(C, generator=g).to(DEV)
-    h = C // 2
-
-    def run(fused, zero_lo, stream=None):
-        xx = x.clone()
-        if zero_lo:
-            xx[:, :h] = 0
-        rm, rv = torch.full((C,), 0.25, device=DEV), torch.full((C,), 2.0, device=DEV)
-        nbt = torch.tensor(3, dtype=torch.int64, device=DEV)
-        lo = (None, 0, h) if zero_lo else (*kernels.colstats_partial(xx[:, :h]), h)
-        hi = (*kernels.colstats_partial(xx[:, h:]), h)
-        if fused:
-            out = kernels.bn_fold_parts(lo, hi, rows, gamma, beta, W, b, 1e-5, 0.1, rm, rv, nbt)
-        else:
-            stats = torch.zeros((2, C), dtype=torch.float64, device=DEV)
-            if not zero_lo:
-                kernels.colstats_merge_into(lo[0][:lo[1]], stats, 0)
-            kernels.colstats_merge_into(hi[0][:hi[1]], stats, h)
-            out = kernels.bn_fold(stats, rows, gamma, beta, W, b, 1e-5, 0.1, True, rm, rv, nbt)
-        return [*out, rm, rv, nbt]
-
-    for zero_lo in (False, True):
-        want = run(False, zero_lo)
-        for rep in range(2):
-            got = run(True, zero_lo)
-            for k, (a, w_) in enumerate(zip(got, want)):
-                if k == 5:                                   # bf
-                    assert torch.allclose(a, w_, rtol=3e-7, atol=0), (k, zero_lo)
-                else:
-                    assert torch.equal(a, w_), (k, zero_lo, rep)
-        assert int(got[-1].item()) == 4
-    # two streams at once: each stream has its own counters
-    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
-    torch.cuda.synchronize()
-    outs = []
-    for _ in range(8):
-        for st in (s1, s2):
-            with torch.cuda.stream(st):
-                outs.append(run(True, False))
-    torch.cuda.synchronize()
-    want = run(False, False)
-    for got in outs:
-        assert torch.equal(got[4], want[4]) and torch.equal(got[0], want[0]) and torch.allclose(got[5], want[5], rtol=3e-7, atol=0)
-    pool = kernels._FOLD_COUNTERS[torch.cuda.current_device()][0]
-    assert int(pool.abs().sum().item()) == 0
-
-
 @pytest.mark.parametrize("rows,NA,NB,K", [(7, 7, 7, 120), (80, 63, 70, 120), (33, 33, 1, 5), (300, 257, 290, 128), (1024, 1000, 1021, 64),
                                           (7000, 6890, 6890, 120)])
 def test_fused_pair_cross_entropy_matches_the_score_matrix_path(rows, NA, NB, K):
@@ -1097,103 +1023,13 @@ def test_arap_model_with_and_without_tile_sums(monkeypatch):
     assert float((res[0][1] - res[1][1]).norm() / res[1][1].norm()) < 2e-5
 
 
-# ---- weight gradient + BatchNorm backward coefficients in two launches (sn_wgrad_bn_f32) -------------------------------------
+# ---- operands of the BatchNorm-backward helper tests ---------------------------------------------------------------------------
 def _bn_operands(rng, rows, J, C, Ct):
     dy = dev(rng.standard_normal((rows, J)).astype(np.float32))
     x = dev((rng.standard_normal((rows, C)) * 1.5 + rng.standard_normal(C)).astype(np.float32))
     W = dev((rng.standard_normal((J, Ct)) / 9).astype(np.float32))
     gamma, beta = [dev(rng.standard_normal(Ct).astype(np.float32)) for _ in range(2)]
     return dy, x, W, gamma, beta
-
-
-@pytest.mark.parametrize("bounded", [False, True])
-@pytest.mark.parametrize("rows,J,C", [(1, 128, 128), (37, 128, 256), (5000, 120, 128), (40001, 128, 256), (322624, 128, 128), (9000, 4, 256)])
-def test_weight_gradient_and_batchnorm_coefficients_in_two_launches(rows, J, C, bounded):
-    """kernels.wgrad_bn (product + ONE finishing launch with per-channel-group tickets) against the launches it replaces —
-    product, split-K reduction, coefficients — bit for bit, and against fp64."""
-    rng = np.random.default_rng(rows + J + C)
-    dy, x, W, gamma, beta = _bn_operands(rng, rows, J, C, C)
-    st = kernels.colstats(x)
-    mean64 = st[0] / rows
-    var64 = (st[1] / rows - mean64 * mean64).clamp_min(0)
-    invstd = (1.0 / torch.sqrt(var64 + 1e-5)).float()
-    mean = mean64.float()
-    s = (gamma.double() * invstd.double()).float()
-    bounds = (dy.abs().max().reshape(1), invstd, rows) if bounded else None
-    G, sdy = kernels.wgrad(dy, x, mean, want_colsum=True, bounds=bounds)
-    want = kernels.bn_bwd_coeffs(G, sdy, W, s, invstd, beta, rows, True)
-    for rep in range(3):                      # (the counters return to zero: repeated launches draw fresh tickets)
-        got = kernels.wgrad_bn(dy, x, mean, W, s, invstd, beta, rows, True, bounds)
-        assert got is not None and got[6] is None
-        for a, b, name in zip(got[:6], want, ("dW", "db", "dgamma", "dbeta", "Bc", "Cc")):
-            assert torch.equal(a, b), (name, rep, float((a - b).abs().max()))
-    G64 = dy.double().t() @ (x.double() - mean.double())
-    dW64 = G64 * s.double() + dy.double().sum(0)[:, None] * beta.double()
-    assert float((got[0].double() - dW64).abs().max()) <= 2e-5 * float(dW64.abs().max()) + 1e-6
-    assert kernels.wgrad_bn(dy, x, mean, W, s, invstd, beta, rows, False, bounds)[1] is None       # no bias: no db
-
-
-@pytest.mark.parametrize("bounded", [False, True])
-@pytest.mark.parametrize("nseg,per", [(3, 150), (7, 33), (2, 5041), (64, 300), (300, 40)])
-def test_global_average_stage_backward_in_two_launches(nseg, per, bounded):
-    """The same for a global-average stage (W over [e | per-mesh mean]): equal meshes and the ragged form of the same batch
-    against wgrad_seg / wgrad_slabs + avg_bwd_gc + bn_bwd_coeffs, bit for bit (the per-mesh column sums of dy included)."""
-    from surfacenetworks_amd.operators import PackedSegments
-
-    J = C = 128
-    rows = nseg * per
-    rng = np.random.default_rng(nseg * 1000 + per)
-    dy, e, W, gamma, beta = _bn_operands(rng, rows, J, C, 2 * C)
-    m = e.view(nseg, per, C).mean(1).contiguous()
-    mean = torch.cat([e.mean(0), m.mean(0)]).contiguous()
-    var = torch.cat([e.var(0, unbiased=False), m.var(0, unbiased=False)]) if rows > 1 else torch.ones(2 * C, device=DEV)
-    invstd = (1.0 / torch.sqrt(var + 1e-5)).contiguous()
-    s = (gamma * invstd).contiguous()
-    bounds = (dy.abs().max().reshape(1), invstd[:C].contiguous(), rows) if bounded else None
-    G1, sdy, Sg = kernels.wgrad_seg(dy, e, mean[:C], per, bounds=bounds)
-    want = kernels.bn_bwd_coeffs(kernels.avg_bwd_gc(G1, Sg, m, mean[C:]), sdy, W, s, invstd, beta, rows, True)
-    got = kernels.wgrad_bn(dy, e, mean[:C], W, s, invstd, beta, rows, True, bounds, rows_per_seg=per, m=m, mu2=mean[C:])
-    for a, b, name in zip(got[:6], want, ("dW", "db", "dgamma", "dbeta", "Bc", "Cc")):
-        assert torch.equal(a, b), (name, float((a - b).abs().max()))
-    assert torch.equal(got[6], Sg)
-    # ragged form of the same batch (slabs from the segment table)
-    seg = PackedSegments([per] * nseg, DEV)
-    G1r, sdyr, Sgr = kernels.wgrad_slabs(dy, e, mean[:C], seg, bounds=bounds)
-    wantr = kernels.bn_bwd_coeffs(kernels.avg_bwd_gc(G1r, Sgr, m, mean[C:]), sdyr, W, s, invstd, beta, rows, True)
-    gotr = kernels.wgrad_bn(dy, e, mean[:C], W, s, invstd, beta, rows, True, bounds, seg=seg, m=m, mu2=mean[C:])
-    for a, b, name in zip(gotr[:6], wantr, ("dW", "db", "dgamma", "dbeta", "Bc", "Cc")):
-        assert torch.equal(a, b), (name, float((a - b).abs().max()))
-    assert torch.equal(gotr[6], Sgr)
-
-
-def test_two_launch_backward_argument_checks():
-    from surfacenetworks_amd import _lib
-    from surfacenetworks_amd.kernels import _p, _ld, _stream
-
-    lib = _lib.load()
-    rows, J, C = 100, 128, 128
-    rng = np.random.default_rng(5)
-    dy, x, W, gamma, beta = _bn_operands(rng, rows, J, C, C)
-    v = torch.ones(C, device=DEV)
-    out = torch.empty(J, C, device=DEV)
-    o4 = torch.empty(4, C, device=DEV)
-    nbytes = int(lib.sn_wgrad_bn_workspace_bytes(rows, 0, 0, J, C, C))
-    ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
-    cnt = torch.zeros(8, dtype=torch.int32, device=DEV)
-
-    def call(rows_=rows, Ct=C, ws_bytes=nbytes, counters=cnt, m=None):
-        return lib.sn_wgrad_bn_f32(_p(dy), _ld(dy), _p(x), _ld(x), _p(v), rows_, J, C, 0, None, 0, None, 0, None, 0, None, 0, _p(W), _p(v),
-                                   _p(v), _p(v), rows, Ct, m, None, _p(out), _p(out), None, _p(o4[0]), _p(o4[1]), _p(o4[2]), _p(o4[3]),
-                                   None, None, _p(ws), ws_bytes, _p(counters) if counters is not None else None, _stream())
-
-    assert call() == 0
-    assert call(rows_=0) == -2                  # SN_E_SHAPE: nothing to finish
-    assert call(Ct=96) == -2                    # neither C nor 2 C
-    assert call(Ct=2 * C) == -1                 # SN_E_NULL: the global-average form needs meshes and their means
-    assert call(ws_bytes=nbytes - 16) == -6     # SN_E_WORKSPACE
-    assert call(counters=None) == -1
-    torch.cuda.synchronize()
-    assert int(cnt.abs().sum()) == 0
 
 
 @pytest.mark.parametrize("rows", [1, 2, 3, 31, 33, 1000])
