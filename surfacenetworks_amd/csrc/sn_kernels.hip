@@ -1404,7 +1404,7 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
           o = ring_epilogue(o, ev[v], gv[v], epi.g != nullptr);
           if (epi.absmax) am = fmaxf(am, hmax_abs4(o));
         }
-        else st4_stream(Y + (int64_t)r * ldy + c0 + v * 32 + sub * 4, o);
+        st4_stream(Y + (int64_t)r * ldy + c0 + v * 32 + sub * 4, o);
         if constexpr (STATS) {
           ssum[v] += o;
           ssq[v].x = __builtin_fmaf(o.x, o.x, ssq[v].x); ssq[v].y = __builtin_fmaf(o.y, o.y, ssq[v].y);

@@ -151,11 +151,11 @@ def load_faust_frame(path: str, device="cuda") -> Dict:
     return fr
 
 
-def faust_from_files(paths: Sequence[str], device="cuda", model="lap", pad_to=None):
-    """Resident FAUST dataset (dense_correspondence.FaustFrames) from reference .npz frames."""
+def faust_from_files(paths: Sequence[str], device="cuda", model="lap", pad_to=None, reorder="auto"):
+    """Resident FAUST dataset (dense_correspondence.FaustFrames) from reference .npz frames; `reorder` as FaustFrames."""
     from . import dense_correspondence as dc
 
-    return dc.FaustFrames([load_faust_frame(p, device) for p in paths], model=model, pad_to=pad_to, device=device)
+    return dc.FaustFrames([load_faust_frame(p, device) for p in paths], model=model, pad_to=pad_to, device=device, reorder=reorder)
 
 
 def write_faust_frame(path: str, V: np.ndarray, F: np.ndarray, label: np.ndarray, dist_mat: np.ndarray) -> None:

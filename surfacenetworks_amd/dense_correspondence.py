@@ -160,7 +160,7 @@ _TOWER_SLOTS = weakref.WeakKeyDictionary()
 _TOWER_STREAMS = weakref.WeakKeyDictionary()      # model -> (side stream, per-BatchNorm capture buffers)
 # The two applications of the shared tower are independent until the score matrix; a 7000-row tower fills 219 of the chip's
 # 512 workgroup slots and its step is ~500 launches of a few microseconds, so running them on two streams (inside the one
-# captured hipGraph: two concurrent kernel chains) hides most of that latency.  SN_TWO_STREAM_TOWERS=0 switches it off.
+# captured hipGraph: two concurrent kernel chains) hides most of that latency.  (_TWO_STREAMS = False: one stream.)
 _TWO_STREAMS = True          # (tests may set False: both towers on the caller's stream)
 
 
@@ -619,9 +619,15 @@ class FaustFrames:
     as a resident dataset with the TorusBodies interface: coordinates, label permutations and geodesic matrices as device
     tensors, the operators of the requested tower in OperatorPools; `sample(idx)` pads to `pad_to` vertices (main.py:193)."""
 
-    def __init__(self, frames, model="lap", pad_to=None, device="cuda"):
+    def __init__(self, frames, model="lap", pad_to=None, device="cuda", reorder="auto"):
+        """reorder ("auto" / True / False): scans arrive in whatever vertex order the scanner wrote (main.py:66-102 loads them as
+        stored); the frames are STORED in a locality numbering (mesh_ops.MeshOrder) — coordinates, operators, label permutations
+        and the geodesic matrix renumbered once.  The loss (rows of the score matrix against targets from G, label, label_inv)
+        is invariant to the numbering; `orders[i].vorder` maps stored positions back to the file's vertex ids."""
         self.device = torch.device(device)
         self.kind = "dir" if "dir" in model else ("amp" if "amp" in model else "lap")      # dispatch order of main.py:72-95
+        self.orders = [mesh_ops.MeshOrder.of_mesh(fr["F"].cpu().numpy(), int(fr["V"].shape[0]), reorder) for fr in frames]
+        frames = [fr if o.identity else _renumbered_frame(fr, o) for fr, o in zip(frames, self.orders)]
         self.frames = frames
         self.n = len(frames)
         nv = max(int(fr["V"].shape[0]) for fr in frames)
@@ -659,6 +665,23 @@ class FaustFrames:
                 ops = self.pool_L.assemble([idx], self.pad_to, self.pad_to)
             hit = self._samples[idx] = (inputs, [(fr["G"], fr["label"], fr["label_inv"])], mask, ops)
         return hit
+
+
+def _renumbered_frame(fr, order):
+    """A frame dict (datasets.load_faust_frame) in the stored numbering of `order`: vertex k is the file's vertex vorder[k]."""
+    dev = fr["V"].device
+    vo = torch.from_numpy(order.vorder).to(dev)
+    vr = torch.from_numpy(order.vrank).to(dev)
+    out = dict(fr)
+    out["V"] = fr["V"][vo]
+    out["F"] = vr[fr["F"].long()[torch.from_numpy(order.forder).to(dev)]]
+    out["label"] = fr["label"][vo]                          # label of the vertex now stored at position k
+    out["label_inv"] = vr[fr["label_inv"].long()]           # stored position of the vertex with label c
+    out["G"] = fr["G"][vo][:, vo].contiguous()
+    for key, rows, cols, group in (("L", "vorder", "vorder", 1), ("Di", "forder", "vorder", 4), ("DiA", "vorder", "forder", 4)):
+        if fr.get(key) is not None:
+            out[key] = mesh_ops.permute_operator(fr[key], getattr(order, rows), getattr(order, cols), group).astype(np.float32)
+    return out
 
 
 def forward_pair_loss(model, ds, ia: int, ib: int, streamed: bool = False, block: int = 1024):
