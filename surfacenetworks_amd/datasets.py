@@ -95,9 +95,16 @@ def load_mesh_mnist(path: str) -> List[Dict]:
         return list(np.load(fh, encoding="latin1", allow_pickle=True))
 
 
-def mnist_from_samples(samples: Sequence[Dict], device="cuda", model="dir"):
-    """Resident Mesh-MNIST dataset (MeshDigits interface) from reference sample dicts."""
+def mnist_from_samples(samples: Sequence[Dict], device="cuda", model="dir", reorder="auto"):
+    """Resident Mesh-MNIST dataset (MeshDigits interface) from reference sample dicts; `reorder`: stored in a locality numbering
+    (mesh_ops.MeshOrder — the file's operators become P_r A P_c^T; the model's output is per mesh, nothing maps back)."""
     from . import mesh_mnist as mm
+
+    orders = [mesh_ops.MeshOrder.of_mesh(np.asarray(s["F"]), s["V"].shape[0], reorder) for s in samples]
+
+    def op(i, key, rows, cols, group):
+        A, o = samples[i][key].astype(np.float32), orders[i]
+        return A if o.identity else mesh_ops.permute_operator(A, getattr(o, rows), getattr(o, cols), group)
 
     ds = mm.MeshDigits.__new__(mm.MeshDigits)
     ds.device, ds.kind, ds.n = torch.device(device), model, len(samples)
@@ -105,15 +112,16 @@ def mnist_from_samples(samples: Sequence[Dict], device="cuda", model="dir"):
     ds.nf = np.array([s["F"].shape[0] for s in samples])
     xyz = np.zeros((ds.n, int(ds.nv.max()), 3), np.float32)
     for i, s in enumerate(samples):
-        xyz[i, : ds.nv[i]] = np.asarray(s["V"], dtype=np.float32)
+        xyz[i, : ds.nv[i]] = orders[i].vertex_rows(np.asarray(s["V"], dtype=np.float32))
     ds.xyz = torch.from_numpy(xyz).to(ds.device)
     ds.vcount = torch.from_numpy(ds.nv).to(ds.device)
     ds.labels = torch.tensor([int(s["label"]) for s in samples], device=ds.device)
     if model == "dir":
-        ds.pool_Di = OperatorPool([s["Di"].astype(np.float32) for s in samples], ds.device, want_bsr4=True)
-        ds.pool_DiA = OperatorPool([s["DiA"].astype(np.float32) for s in samples], ds.device, want_bsr4=True)
+        ds.pool_Di = OperatorPool([op(i, "Di", "forder", "vorder", 4) for i in range(ds.n)], ds.device, want_bsr4=True)
+        ds.pool_DiA = OperatorPool([op(i, "DiA", "vorder", "forder", 4) for i in range(ds.n)], ds.device, want_bsr4=True)
     else:
-        ds.pool_L = OperatorPool([s["L"].astype(np.float32) for s in samples], ds.device)
+        ds.pool_L = OperatorPool([op(i, "L", "vorder", "vorder", 1) for i in range(ds.n)], ds.device)
+    ds.orders = orders
     ds.run_nv = ds.run_nf = 0
     return ds
 

@@ -120,7 +120,9 @@ class MeshDigits:
     """Synthetic stand-in for train_plus.np (mesh_mnist/add_laplacian.py:63-71): seeded Delaunay meshes of ~150
     vertices with the reference scaling, a label in 0..9, operators resident in HBM pools."""
 
-    def __init__(self, count, seed=2, device="cuda", vmin=140, vmax=230, fixed_vertices=None, model="dir"):
+    def __init__(self, count, seed=2, device="cuda", vmin=140, vmax=230, fixed_vertices=None, model="dir", reorder="auto"):
+        """reorder: the meshes are STORED in a locality numbering (mesh_ops.MeshOrder; Delaunay vertices come in random order).
+        The model's output is per mesh, so nothing maps back."""
         rng = np.random.default_rng(seed)
         self.device = torch.device(device)
         self.kind = model
@@ -129,6 +131,7 @@ class MeshDigits:
         for _ in range(count):
             n = fixed_vertices or int(rng.integers(vmin, vmax + 1))
             V, F_ = mesh_ops.delaunay_disc(n, rng)
+            V, F_ = mesh_ops.MeshOrder.of_mesh(F_, V.shape[0], reorder).mesh(V, F_)
             Vs.append(V.astype(np.float32))
             self.nv.append(V.shape[0])
             self.nf.append(F_.shape[0])

@@ -577,7 +577,12 @@ def check_dataset_files(golden_dir, dev):
         ds = datasets.mnist_from_samples(samples, device=dev, model=kind)
         b = ds.sample_batch(4, None, ids=np.array([2, 0, 3, 1]))
         assert b.targets.tolist() == [int(samples[i]["label"]) for i in (2, 0, 3, 1)]
+        # (stored in the locality numbering — Delaunay vertices arrive in random order: the file's operator, renumbered)
+        from surfacenetworks_amd import mesh_ops as _mo
+
+        o = ds.orders[2]
         want = samples[2]["L" if kind == "lap" else "Di"]
+        want = _mo.permute_operator(want, o.vorder, o.vorder) if kind == "lap" else _mo.permute_operator(want, o.forder, o.vorder, 4)
         got = (b.L if kind == "lap" else b.Di).to_scipy()
         assert abs(got[: want.shape[0], : want.shape[1]] - want).max() == 0
         model = cls().to(dev)

@@ -10,16 +10,22 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
-@pytest.mark.parametrize("fmt", ["q3", "bsr4", "csr"])
-@pytest.mark.parametrize("cname,C", pc.BLOCKS)
-@pytest.mark.parametrize("opkind", ["pool", "coo2d", "coo3d"])
+def _block_cases():
+    """(block, width, operator kind, Dirac format): the format switch only concerns Dirac blocks, the operator kind only blocks
+    with a sparse operator."""
+    out = []
+    for cname, C in pc.BLOCKS:
+        sparse = cname not in ("AvgResNet2", "MlpResNet2")
+        for opkind in (("pool", "coo2d", "coo3d") if sparse else ("pool",)):
+            for fmt in (("q3", "bsr4", "csr") if cname == "DirResNet2" else ("q3",)):
+                out.append((cname, C, opkind, fmt))
+    return out
+
+
+@pytest.mark.parametrize("cname,C,opkind,fmt", _block_cases())
 def test_blocks_match_reference(golden_dir, cname, C, opkind, fmt):
     from surfacenetworks_amd import functional as snF
 
-    if cname in ("AvgResNet2", "MlpResNet2") and (opkind != "pool" or fmt != "q3"):
-        pytest.skip("no sparse operator in this block")
-    if cname == "LapResNet2" and fmt != "q3":
-        pytest.skip("format switch only affects Dirac blocks")
     snF.set_dirac_format(fmt)
     try:
         pc.check_block(golden_dir, cname, C, opkind, DEV)

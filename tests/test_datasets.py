@@ -43,8 +43,15 @@ def test_mesh_mnist_roundtrip(tmp_path, cpu_kernels):
     ds = datasets.mnist_from_samples(samples, device="cpu", model="lap")
     b = ds.sample_batch(3, None, ids=np.array([2, 0, 1]))
     assert b.targets.tolist() == [4, 3, 1] and b.inputs.shape == (3, 41, 3)
-    want = samples[2]["L"]
+    # stored in the locality numbering (Delaunay vertices come in random order): the file's operator, renumbered
+    o = ds.orders[2]
+    assert not o.identity
+    want = mesh_ops.permute_operator(samples[2]["L"], o.vorder, o.vorder)
     assert abs(b.L.to_scipy()[: want.shape[0], : want.shape[1]] - want).max() == 0
+    assert np.array_equal(b.inputs[0, : o.vorder.size].numpy(), samples[2]["V"][o.vorder])
+    raw = datasets.mnist_from_samples(samples, device="cpu", model="lap", reorder=False)
+    b0 = raw.sample_batch(3, None, ids=np.array([2, 0, 1]))
+    assert abs(b0.L.to_scipy()[: want.shape[0], : want.shape[1]] - samples[2]["L"]).max() == 0
     loss, out = mesh_mnist.forward_loss(mesh_mnist.Model(), b)
     assert out.shape == (3, 10) and torch.isfinite(loss)
 

@@ -20,14 +20,11 @@ def dev(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
 
 
-@pytest.mark.parametrize("fmt", ["q3", "bsr4", "csr"])
-@pytest.mark.parametrize("which", ["Di", "DiA", "L"])
+@pytest.mark.parametrize("which,fmt", [("Di", "q3"), ("Di", "bsr4"), ("Di", "csr"), ("DiA", "q3"), ("DiA", "bsr4"), ("DiA", "csr"), ("L", "csr")])
 def test_spmm_through_the_reorder_is_bit_exact_against_the_oracle(fmt, which):
     from surfacenetworks_amd import functional as snF, mesh_ops as mo
     from surfacenetworks_amd.operators import SparseOperator
 
-    if which == "L" and fmt != "csr":
-        pytest.skip("block forms are Dirac-only")
     rng = np.random.default_rng(8)
     V, F = mo.grid_cloth(23, 19, rng, permute="both")
     o = mo.MeshOrder.of_mesh(F, V.shape[0], True)
@@ -155,3 +152,37 @@ def test_files_in_arbitrary_order_are_stored_renumbered(tmp_path):
         A0, A1 = getattr(b0, name).to_scipy(), getattr(b1, name).to_scipy()
         assert abs(mo.permute_operator(A0, rows, cols, 4) - A1).max() == 0
     assert mo.edge_span(np.asarray(o.vrank[F[o.forder]]))[1] <= 13
+
+
+def test_faust_pair_loss_is_invariant_to_the_stored_numbering():
+    """dense correspondence (src/dense_correspondence/main.py:229-240): frames whose file numbering is shuffled, stored as they
+    came vs renumbered (coordinates, Laplacian, label permutations and the geodesic matrix together): the same pair loss and the
+    same parameter gradients up to summation order."""
+    from helpers import deterministic_init
+    from surfacenetworks_amd import dense_correspondence as dc, mesh_ops as mo
+
+    rng = np.random.default_rng(9)
+    frames = []
+    for n, m in [(9, 11), (10, 10)]:
+        V, F = mo.torus_grid(n, m, rng, permute="both")
+        nv = V.shape[0]
+        label = rng.permutation(nv)
+        Vt = torch.from_numpy(V.astype(np.float32)).to(DEV)
+        frames.append({"V": Vt, "F": torch.from_numpy(F).to(DEV), "L": mo.laplacian(V, F).astype(np.float32), "Di": None, "DiA": None,
+                       "label": torch.from_numpy(label).to(DEV), "label_inv": torch.from_numpy(np.argsort(label)).to(DEV),
+                       "G": torch.cdist(Vt, Vt)})
+    ds_off = dc.FaustFrames(frames, model="lap", pad_to=112, device=DEV, reorder=False)
+    ds_on = dc.FaustFrames(frames, model="lap", pad_to=112, device=DEV, reorder=True)
+    assert not any(o.identity for o in ds_on.orders)
+    o = ds_on.orders[0]
+    fr = ds_on.frames[0]
+    assert torch.equal(fr["label_inv"][fr["label"].long()].cpu(), torch.arange(o.vorder.size))      # still inverse permutations
+    assert torch.equal(fr["G"].cpu(), frames[0]["G"].cpu()[o.vorder][:, o.vorder])
+    res = []
+    for ds in (ds_off, ds_on):
+        model = deterministic_init(dc.SiameseModel("lap", 3), 12).to(DEV).train()
+        loss = dc.forward_pair_loss(model, ds, 0, 1)
+        loss.backward()
+        res.append((loss.item(), torch.cat([p.grad.reshape(-1) for p in model.parameters()])))
+    assert abs(res[0][0] - res[1][0]) <= 1e-4 * abs(res[0][0]), (res[0][0], res[1][0])
+    assert float((res[0][1] - res[1][1]).norm() / res[0][1].norm()) < 2e-3

@@ -110,7 +110,7 @@ def test_arap_driver_functions_run_on_the_swapped_layer(golden_dir, reference_mo
         offsets.append(np.random.randint(0, len(sequences[ind]) - 2 - 40))
     np.random.seed(11)
     inputs, targets, mask, lap, Di, DiA, faces = sample_batch(sequences, True)
-    ds = datasets.arap_from_files(files, device="cpu", model=kind)
+    ds = datasets.arap_from_files(files, device="cpu", model=kind, reorder=False)          # (the reference sampler hands out the file numbering)
     b = ds.sample_batch(args.batch_size, None, seq_ids=np.array(seq_ids) % 2, offsets=np.array(offsets))
     assert torch.equal(b.inputs, inputs) and torch.equal(b.targets, targets) and torch.equal(b.mask, mask)
     if kind == "dir":
@@ -169,7 +169,9 @@ def test_mesh_mnist_driver_functions_run_on_the_swapped_layer(golden_dir, refere
     ids = [np.random.randint(0, len(train_data)) for _ in range(args.batch_size)]
     np.random.seed(3)
     inputs, targets, mask, lap, Di, DiA = sample_batch(train_data, is_training=True)
-    ds = datasets.mnist_from_samples(raw, device="cpu", model="lap" if kind == "lap" else "dir")
+    # (reorder=False: the file's own vertex numbering, which is what the reference's sampler hands out; the default stores the
+    #  meshes in a locality numbering — tests/test_order*.py)
+    ds = datasets.mnist_from_samples(raw, device="cpu", model="lap" if kind == "lap" else "dir", reorder=False)
     b = ds.sample_batch(args.batch_size, None, ids=np.array(ids))
     assert torch.equal(b.inputs, inputs) and torch.equal(b.targets, targets) and torch.equal(b.mask, mask)
     nv, nf = sample_batch.num_vertices, sample_batch.num_faces
@@ -232,7 +234,7 @@ def test_faust_driver_functions_run_on_the_swapped_layer(golden_dir, reference_m
     iteration = ref_train_iteration(rel, ns)
 
     # (1) the reference's reader and sampler against the product's
-    ds = datasets.faust_from_files([path, path], device="cpu", model="lap", pad_to=pad)
+    ds = datasets.faust_from_files([path, path], device="cpu", model="lap", pad_to=pad, reorder=False)
     inX, tX, mX, LX = ds.sample(0)
     rin, rt, rm, rop, _ = sample_batch(sequences, True, args)
     assert torch.equal(inX, rin) and torch.equal(mX, rm)
