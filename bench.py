@@ -319,6 +319,85 @@ def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10):
     return out
 
 
+def c5_pmc_child(plan_path: str, launches: int = 6):
+    """Child of c5_pmc_traffic (runs under rocprofv3 --pmc): the packed config-5 products of every order, `launches` launches
+    each, and the PLAN — (order, product, launches) in launch order — written to `plan_path`, so that the parent can attribute
+    the profiler's dispatch records (the k-th run of sparse-product dispatches belongs to the k-th plan entry)."""
+    from surfacenetworks_amd import functional as snF
+    from surfacenetworks_amd.operators import OperatorPool
+
+    device = torch.device("cuda:0")
+    g = torch.Generator(device=device).manual_seed(7)
+    sel = np.arange(C5_MESHES_PER_GPU)
+    plan = []
+    for order, (permute, reorder) in C5_ORDERS.items():
+        Dis, DiAs, Ls, _, _, _ = _c5_meshes(0, permute, reorder)
+        for name, mats, group, N in (("Di", Dis, 4, 32), ("DiA", DiAs, 4, 32), ("L", Ls, 1, 128)):
+            op = OperatorPool(mats, device, want_bsr4=(group == 4)).assemble(sel)
+            for prod, o in ((name, op), (name + "^T", op.t())):
+                M, K = o.shape
+                x = torch.randn(K // group, group * N, device=device, generator=g)
+                y = torch.empty(M // group, group * N, device=device)
+                if group == 1:
+                    o.ring_ok(N), o.rb4() if not o.ring_ok(N) else None        # (derived forms built before the counted launches)
+                torch.cuda.synchronize()
+                for _ in range(launches):
+                    snF._launch(o, x, y, group, "c5")
+                torch.cuda.synchronize()
+                plan.append({"order": order, "product": prod, "launches": launches})
+            del op
+        torch.cuda.empty_cache()
+    with open(plan_path, "w") as fh:
+        json.dump(plan, fh)
+
+
+def c5_pmc_traffic(launches: int = 6):
+    """HBM traffic per launch of the packed config-5 products, every order: this file re-executed (--c5-pmc-child) under
+    rocprofv3, one counter per pass (bytes = RDREQ*128 + WRREQ*64, MI355X_MICROARCH.md); returns {(order, product): bytes}
+    and a note, or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="sn_pmc5_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        per = {}
+        for ctr in (PMC_RD, PMC_WR):
+            out, plan_path = os.path.join(tmp, ctr), os.path.join(tmp, ctr + "_plan.json")
+            r = subprocess.run([exe, "--pmc", ctr, "-d", out, "-o", "pmc", "--output-format", "csv", "--", sys.executable,
+                                os.path.abspath(__file__), "--c5-pmc-child", f"{plan_path},{launches}"], cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=600)
+            hits = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not hits or not os.path.exists(plan_path):
+                return None, f"rocprofv3 --pmc {ctr} over the config-5 products failed (rc {r.returncode}): {r.stderr[-160:]!r}"
+            with open(plan_path) as fh:
+                plan = json.load(fh)
+            rows = sorted((int(x["Dispatch_Id"]), x["Kernel_Name"], float(x["Counter_Value"])) for x in csv.DictReader(open(hits[0]))
+                          if x["Counter_Name"] == ctr)
+            prods = [v for _, name, v in rows if "spmm_" in name and "stats_reduce" not in name]
+            if len(prods) != sum(e["launches"] for e in plan):
+                return None, f"{len(prods)} sparse-product dispatches recorded, {sum(e['launches'] for e in plan)} planned"
+            k = 0
+            for e in plan:
+                vals = prods[k:k + e["launches"]]
+                k += e["launches"]
+                per.setdefault((e["order"], e["product"]), {})[ctr] = float(np.mean(vals[1:] if len(vals) > 1 else vals))   # (first launch: cold)
+        traffic = {key: v[PMC_RD] * 128 + v[PMC_WR] * 64 for key, v in per.items()}
+        return traffic, (f"in-run: bench.py --c5-pmc-child under rocprofv3 --pmc {PMC_RD} / {PMC_WR} (one counter per pass), mean of "
+                         f"{launches - 1} launches per product; bytes = RDREQ*128 + WRREQ*64")
+    except (subprocess.TimeoutExpired, OSError, ValueError, KeyError) as exc:
+        return None, f"config-5 PMC pass failed: {exc!r}"[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def c3_order_secondary(device, meshes: int = MESHES_PER_GPU, steps: int = 10, warm: int = 4):
     """The headline step (config 3) on meshes that do NOT arrive in grid order: 64 grid-cloth meshes 71x71 with vertices and
     faces shuffled (seed 3), trained (a) as stored and (b) stored in the product's locality numbering (ClothSequences(reorder=
@@ -636,6 +715,7 @@ def main():
                          "(chosen automatically when there are fewer visible GPUs than ranks); none: no process group at N = 1")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config-5 SpMM roofline block")
     ap.add_argument("--cpu-leg", default=None, help=argparse.SUPPRESS)      # internal: one time-boxed leg of cpu_baseline()
+    ap.add_argument("--c5-pmc-child", default=None, help=argparse.SUPPRESS)  # internal: the config-5 products under the profiler
     args = ap.parse_args()
     world_hint = int(os.environ.get("WORLD_SIZE", str(args.gpus)))
     # N ranks on N devices: replay unless --eager (N eager-launching Python processes share one host).  Ranks that SHARE a
@@ -651,6 +731,10 @@ def main():
         n_, seed_, thr_, bud_, reps_ = args.cpu_leg.split(",")
         v, reps = _cpu_leg(int(n_), int(seed_), int(thr_), float(bud_), int(reps_))
         print(json.dumps({"value": v, "reps": reps, "threads": int(thr_), "meshes": int(n_)}), flush=True)
+        return
+    if args.c5_pmc_child:
+        plan_path, n_ = args.c5_pmc_child.rsplit(",", 1)
+        c5_pmc_child(plan_path, int(n_))
         return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, sys.argv[1:]))
@@ -848,7 +932,7 @@ def main():
     # figure is withheld (traffic: null) instead of quoted stale.
     traffic = traffic_src = None
     step_traffic = None
-    pmc_file = os.path.join("profiles", "r4_pmc_traffic_c3.json")
+    pmc_file = os.path.join("profiles", "r5_pmc_traffic_c3.json")
     table, in_run_note = (None, "not requested")
     if rank == 0 and world == 1 and not args.no_pmc:
         # release the device memory of the timed run first: the counter passes are child processes on the same GPU
@@ -991,6 +1075,15 @@ def main():
             sec["config4_dp"] = {"error": repr(exc)[:300]}
             if world > 1:
                 raise                               # (a rank that left the collectives would hang the others)
+        if rank == 0 and world == 1 and not args.no_pmc and "products" in sec:
+            torch.cuda.empty_cache()
+            tr5, note5 = c5_pmc_traffic()
+            sec["traffic_source"] = note5
+            if tr5:
+                for p_ in sec["products"] + sec["laplacian"]:
+                    t_ = tr5.get((p_["order"], p_["product"])) if p_["layout"] == "packed" else None
+                    p_["traffic"] = t_
+                    p_["frac_traffic"] = (t_ / (p_["ms_median"] * 1e-3) / HBM_PEAK) if t_ else None
         if rank == 0 and world == 1:
             # the small-batch configurations, driver-visible (rank 0 of a one-GPU run only: they are replicas, not a sharded job)
             for key, fn in (("config3_order", c3_order_secondary), ("config3_swap", c3_swap_secondary), ("config2", c2_secondary),

@@ -1174,3 +1174,42 @@ def test_gather_segments_into_a_packed_batch(length):
     want = padded[keep]
     got = kernels.gather_segments_ragged(src, base, seg, f3, length)
     assert got.shape == (seg.rows, length) and torch.equal(got, want)
+
+
+def test_operands_spanning_more_than_2_28_along_the_contraction():
+    """The documented edge of the two-piece fp16 split (sn_gemm.hip: "elements more than 2^28 below their row's maximum lose
+    low-order bits — an error below 2^-37 of the row's scale"): data rows AND weight columns whose elements span 2^60, forward and
+    input gradient; and the bounded two-piece weight gradient with columns of x spread over 2^40 about their mean and dy rows
+    from 1e-12 to 1e3.  Every output stays within a few fp32 roundings of fp64, relative to sum |a||b| of its own row / column —
+    what an fp32 dot product in any order guarantees."""
+    rng = np.random.default_rng(77)
+    rows, K, J = 257, 256, 128
+    x = (rng.standard_normal((rows, K)) * np.exp2(rng.integers(-30, 31, size=(rows, K)))).astype(np.float32)
+    W = (rng.standard_normal((J, K)) * np.exp2(rng.integers(-30, 31, size=(J, K)))).astype(np.float32)
+    ref = x.astype(np.float64) @ W.astype(np.float64).T
+    scale = np.abs(x).astype(np.float64) @ np.abs(W).astype(np.float64).T
+    got = kernels.linear_fwd(dev(x), dev(W), dev(np.zeros(J, np.float32))).cpu().numpy().astype(np.float64)
+    assert np.isfinite(got).all() and (np.abs(got - ref) / scale).max() <= 4 * 2.0 ** -24 * np.sqrt(K)
+    dy = (rng.standard_normal((rows, J)) * np.exp2(rng.integers(-30, 31, size=(rows, J)))).astype(np.float32)
+    refd = dy.astype(np.float64) @ W.astype(np.float64)
+    scaled = np.abs(dy).astype(np.float64) @ np.abs(W).astype(np.float64)
+    gotd = kernels.linear_dgrad(dev(dy), dev(W)).cpu().numpy().astype(np.float64)
+    assert np.isfinite(gotd).all() and (np.abs(gotd - refd) / scaled).max() <= 4 * 2.0 ** -24 * np.sqrt(J)
+    # weight gradient on two fp16 pieces: the bounds are max |dy| and BatchNorm's own statistics of x
+    rows = 4099
+    xs = (rng.standard_normal((rows, K)) * np.exp2(rng.integers(-20, 21, size=K))[None, :] + rng.standard_normal(K)[None, :] * 1e3)
+    xs = xs.astype(np.float32)
+    dys = (rng.standard_normal((rows, J)) * np.array([1e-12, 1e-6, 1.0, 1e3])[np.arange(rows) % 4][:, None]).astype(np.float32)
+    xd, dyd = dev(xs), dev(dys)
+    st = kernels.colstats(xd)
+    mean = (st[0] / rows).float()
+    var = (st[1] / rows - (st[0] / rows) ** 2).clamp_min(0)
+    invstd = (1.0 / torch.sqrt(var + 1e-5)).float()
+    bound = dyd.abs().max().reshape(1)
+    G = kernels.wgrad(dyd, xd, mean, bounds=(bound, invstd, rows)).cpu().numpy().astype(np.float64)
+    xc = xs.astype(np.float64) - mean.cpu().numpy().astype(np.float64)[None, :]
+    refg = dys.astype(np.float64).T @ xc
+    scaleg = np.abs(dys).astype(np.float64).T @ np.abs(xc)
+    assert np.isfinite(G).all() and (np.abs(G - refg) / scaleg).max() <= 8 * 2.0 ** -24 * np.sqrt(rows)
+    G3 = kernels.wgrad(dyd, xd, mean).cpu().numpy().astype(np.float64)          # (the unbounded three-piece form, same operands)
+    assert (np.abs(G3 - refg) / scaleg).max() <= 8 * 2.0 ** -24 * np.sqrt(rows)
