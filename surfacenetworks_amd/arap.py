@@ -420,6 +420,7 @@ def train_step(model, optimizer, batch: Batch, global_batch: Optional[int] = Non
     else:
         optimizer.zero_grad(set_to_none=False)
     loss.backward()
+    kernels.clear_absmax()
     if grad_sync is not None:
         grad_sync()
     optimizer.step()

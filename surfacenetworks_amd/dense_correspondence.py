@@ -710,6 +710,7 @@ def train_step(model, optimizer, ds, ia: int, ib: int, grad_sync=None, streamed:
     else:
         optimizer.zero_grad(set_to_none=False)
     loss.backward()
+    kernels.clear_absmax()
     if grad_sync is not None:
         grad_sync()
     optimizer.step()

@@ -21,6 +21,7 @@ from typing import Callable, List, Optional
 
 import torch
 
+from . import kernels
 from .operators import SparseOperator
 
 __all__ = ["operator_tensors", "batch_tensors", "batch_signature", "GraphedStep", "GraphedTrainStep"]
@@ -283,6 +284,7 @@ class GraphedTrainStep:
         def body(b):
             loss = loss_of(model, b)
             loss.backward()
+            kernels.clear_absmax()
             return loss
 
         # (the `zero_grads` slot of GraphedStep runs before the body, at warm-up and at capture time: host code, not recorded)

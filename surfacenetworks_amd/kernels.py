@@ -12,7 +12,7 @@ import torch
 from . import _lib
 
 __all__ = [
-    "note_absmax", "take_absmax", "absmax_wanted", "tile_sums_supported", "new_tile_sums", "avg_stats_from_tiles", "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "spmm_ring", "spmm_ring_stats", "spmm_ring_supported", "ring_half_window", "csr_band", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged", "validate_csr",
+    "note_absmax", "take_absmax", "absmax_wanted", "clear_absmax", "tile_sums_supported", "new_tile_sums", "avg_stats_from_tiles", "spmm_csr", "spmm_bsr4", "spmm_csr_elubwd", "spmm_bsr4_elubwd", "spmm_q3", "spmm_q3_stats", "spmm_q3_stats_supported", "spmm_csr_stats", "spmm_csr_stats_supported", "csr_to_rb4", "spmm_rb4", "spmm_rb4_stats", "spmm_rb4_supported", "spmm_ring", "spmm_ring_stats", "spmm_ring_supported", "ring_half_window", "csr_band", "bsr4_to_q3", "coo_to_csr", "csr_transpose", "csr_to_bsr4", "blockdiag_concat", "blockdiag_concat_ragged", "validate_csr",
     "elu_into", "elu_bwd", "colstats", "wgrad", "wgrad_supported", "affine_cols_acc", "affine_cols_elu_bwd",
     "bn_fold", "bn_bwd_coeffs", "segment_colsum", "bcast_rows", "segment_colsum_ragged", "bcast_rows_ragged", "elu_bwd_bcast", "dirac_from_mesh", "laplacian_from_mesh", "linear_fwd", "linear_fwd_supported", "linear_dgrad",
     "linear_dgrad_supported", "linear_dgrad_elu", "linear_dgrad_elu_supported",
@@ -459,6 +459,13 @@ def note_absmax(t, maxima) -> None:
             del _absmax_table[k]
     _absmax_table.pop(t.data_ptr(), None)
     _absmax_table[t.data_ptr()] = (t, t._version if not t.is_inference() else None, maxima)
+
+
+def clear_absmax() -> None:
+    """Drop every recorded bound (and with it the references to the gradient tensors they describe): called by the train steps
+    once a backward pass has run — bounds nobody took (a gradient consumed only as an added term, the gradient into the first
+    layer) would otherwise keep up to _ABSMAX_KEEP gradient tensors alive across steps."""
+    _absmax_table.clear()
 
 
 def take_absmax(t):

@@ -16,7 +16,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import mesh_ops
+from . import kernels, mesh_ops
 from . import utils_pt as utils
 from .arap import make_adam
 from .operators import OperatorPool
@@ -194,6 +194,7 @@ def train_step(model, optimizer, batch: Batch, grad_sync=None):
     loss, _ = forward_loss(model, batch)
     optimizer.zero_grad(set_to_none=False)
     loss.backward()
+    kernels.clear_absmax()
     if grad_sync is not None:
         grad_sync()
     optimizer.step()

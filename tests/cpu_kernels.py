@@ -197,6 +197,10 @@ def avg_merged_supported(J, C, nseg, which=1):
     return False          # the host twins keep the separate steps of a global-average stage
 
 
+def clear_absmax():
+    pass
+
+
 def absmax_wanted():
     return False          # the host twins have one weight gradient (exact): no bounds are produced or consumed
 

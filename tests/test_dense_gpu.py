@@ -1197,8 +1197,8 @@ def test_operands_spanning_more_than_2_28_along_the_contraction():
     assert np.isfinite(gotd).all() and (np.abs(gotd - refd) / scaled).max() <= 4 * 2.0 ** -24 * np.sqrt(J)
     # weight gradient on two fp16 pieces: the bounds are max |dy| and BatchNorm's own statistics of x
     rows = 4099
-    xs = (rng.standard_normal((rows, K)) * np.exp2(rng.integers(-20, 21, size=K))[None, :] + rng.standard_normal(K)[None, :] * 1e3)
-    xs = xs.astype(np.float32)
+    spread = np.exp2(rng.integers(-20, 21, size=K))[None, :]            # column c: standard deviation 2^e_c, mean a few of them
+    xs = ((rng.standard_normal((rows, K)) + 4 * rng.standard_normal(K)[None, :]) * spread).astype(np.float32)
     dys = (rng.standard_normal((rows, J)) * np.array([1e-12, 1e-6, 1.0, 1e3])[np.arange(rows) % 4][:, None]).astype(np.float32)
     xd, dyd = dev(xs), dev(dys)
     st = kernels.colstats(xd)
