@@ -273,7 +273,7 @@ C5_ORDERS = {
 }
 
 
-def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10):
+def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10, orders=None):
     """Config 5: 128 grid-cloth meshes per GPU, V_i uniform in [1000, 20000] (seed 5 + rank), Dirac
     operators, N = 32 (C = 128).  The four products Di, Di^T, DiA, DiA^T are launched back to back (>= 50 timed launches
     after >= 10 warm-ups, the kernel's own start/stop in HIP events on the launch stream) on
@@ -289,6 +289,8 @@ def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10):
     g = torch.Generator(device=device).manual_seed(7)
     out = None
     for order, (permute, reorder) in C5_ORDERS.items():
+        if orders is not None and order not in orders:
+            continue
         Dis, DiAs, Ls, sumV, sumF, span = _c5_meshes(rank, permute, reorder)
         if out is None:
             out = {"workload": f"BASELINE configs[4]: {C5_MESHES_PER_GPU} grid-cloth meshes per GPU, V in [{C5_VMIN}, {C5_VMAX}] "
@@ -310,12 +312,13 @@ def c5_secondary(device, rank: int, iters: int = 50, warm: int = 10):
         out["laplacian"] += _c5_laplacian_products(Ls, order, g, device, iters, warm)
         del Dis, DiAs, Ls
         torch.cuda.empty_cache()
-    packed = [p_ for p_ in out["products"] if p_["layout"] == "packed" and p_["order"] == "grid"]
+    done = [o for o in C5_ORDERS if orders is None or o in orders]
+    packed = [p_ for p_ in out["products"] if p_["layout"] == "packed" and p_["order"] == done[0]]      # (done[0] = "grid" by default)
     out["frac_min_packed"] = min(p_["frac"] for p_ in packed)
     out["GBps_mean_packed"] = float(np.mean([p_["GBps"] for p_ in packed]))
     out["frac_min_packed_by_order"] = {o: min(p_["frac"] for p_ in out["products"] if p_["layout"] == "packed" and p_["order"] == o)
-                                       for o in C5_ORDERS}
-    out["laplacian_frac_min_by_order"] = {o: min(p_["frac"] for p_ in out["laplacian"] if p_["order"] == o) for o in C5_ORDERS}
+                                       for o in done}
+    out["laplacian_frac_min_by_order"] = {o: min(p_["frac"] for p_ in out["laplacian"] if p_["order"] == o) for o in done}
     return out
 
 

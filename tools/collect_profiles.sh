@@ -25,8 +25,17 @@ bench)
 trace)
   kstats bench_c3 -- python $root/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-secondary --no-pmc
   grep '^{' $out/bench_c3_under_rocprof.log > $out/bench_c3_under_rocprof.json; rm -f $out/bench_c3_under_rocprof.log
-  kstats spmm_microbench_c5_orders -- python $root/tools/order_probe.py c5
-  grep -v amdgpu.ids $out/spmm_microbench_c5_orders_under_rocprof.log > $out/spmm_microbench_c5_orders.json; rm -f $out/spmm_microbench_c5_orders_under_rocprof.log ;;
+  for o in grid permuted permuted_both permuted_both+reorder; do
+    n=spmm_microbench_c5_$(echo $o | tr '+' '_')
+    kstats $n -- python $root/tools/order_probe.py c5 order=$o
+    grep -v amdgpu.ids $out/${n}_under_rocprof.log > $out/$n.json; rm -f $out/${n}_under_rocprof.log
+  done ;;
+orders)
+  for o in grid permuted permuted_both permuted_both+reorder; do
+    n=spmm_microbench_c5_$(echo $o | tr '+' '_')
+    kstats $n -- python $root/tools/order_probe.py c5 order=$o
+    grep -v amdgpu.ids $out/${n}_under_rocprof.log > $out/$n.json; rm -f $out/${n}_under_rocprof.log
+  done ;;
 pmc)
   for ctr in TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum; do
     rm -rf /tmp/pmc_$ctr
