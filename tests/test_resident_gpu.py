@@ -183,3 +183,39 @@ def test_in_place_replacement_of_a_dataset_matrix_is_noticed():
     L.data = L.data * 2                                                # new array object: noticed (an in-place `*=` would not be)
     b = U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(L)], L.shape[0], L.shape[1]).cuda()._sn_operator.to_scipy()
     assert np.array_equal(b.data, 2 * a.data)
+
+
+def test_resident_pools_grow_and_start_over_when_the_budget_is_spent():
+    """Operators arrive a few at a time (a driver sampling at random from a large dataset): the pools grow in place (arenas
+    that double; earlier members keep their offsets) and every batch — old members, new members, mixed — equals the
+    reference's tensor.  With a budget of a few hundred KB the cache starts over in between (generational reset) and the
+    batches are still right."""
+    import surfacenetworks_amd.utils_pt as U
+    from surfacenetworks_amd.resident import reference_diag_cat, reference_sp_to_coo, resident_cache
+
+    rng = np.random.default_rng(11)
+    ms = _meshes(rng, [(6 + i % 5, 5 + (3 * i) % 7) for i in range(14)])
+    cache = resident_cache()
+    cache.clear()
+    old_budget = cache.max_bytes
+    try:
+        for budget in (old_budget, 300_000):
+            cache.clear()
+            cache.max_bytes = budget
+            resets0 = cache.resets
+            for step in range(8):
+                sel = rng.integers(0, 2 + 2 * step if step < 6 else len(ms), size=5) % len(ms)     # the population grows step by step
+                for which, group in (("DiA", 4), ("L", 1)):
+                    mats = [ms[i][2][which] for i in sel]
+                    s0, s1 = max(a.shape[0] for a in mats), max(a.shape[1] for a in mats)
+                    got = U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(a) for a in mats], s0, s1).cuda()
+                    want = reference_diag_cat([reference_sp_to_coo(a) for a in mats], s0, s1)
+                    assert got._sn_operator is not None
+                    assert np.array_equal(np.asarray(got._sn_operator.to_scipy().todense()), want.to_dense().numpy()), (budget, step, which)
+                    t = got._sn_operator.t().to_scipy()
+                    assert np.array_equal(np.asarray(t.todense()), want.to_dense().numpy().T)
+            if budget < old_budget:
+                assert cache.resets > resets0                      # the small budget did force the cache to start over
+    finally:
+        cache.max_bytes = old_budget
+        cache.clear()
