@@ -29,7 +29,11 @@
 namespace {
 
 constexpr int kWG = 256;    // 4 wavefronts per workgroup
-constexpr int kXCD = 8;     // MI355X: 8 XCDs, workgroup b is dispatched to XCD b % 8
+// XCDs of the device the kernels run on (workgroup b is dispatched to XCD b % c_xcd): 8 on an MI355X in SPX mode — the value
+// this constant is built with; xcd_count() below reads hipDeviceAttributeNumberOfXccs once per device and rewrites it where the
+// partition mode says otherwise (4 / 2 / 1).  Only LOCALITY depends on it: every map below is a bijection for any value that
+// divides the grid.
+__constant__ int c_xcd = 8;
 constexpr int kCUs = 256;
 
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -65,8 +69,9 @@ __device__ __forceinline__ int64_t row_off(int r, int64_t ld) {
 // X rows shared by neighbouring mesh rows in ONE 4 MiB L2 instead of eight.  One workgroup per chunk: a capped persistent
 // grid measured 5 % slower (late workgroups lose L2 reuse with their spatial neighbours) — the grid is a multiple of 8.
 __device__ __forceinline__ int my_chunk(int nchunks) {
-  const int cpx = (nchunks + kXCD - 1) / kXCD;
-  return (blockIdx.x % kXCD) * cpx + blockIdx.x / kXCD;      // may be >= nchunks for the padding workgroups: callers test rows
+  const int X = c_xcd;
+  const int cpx = (nchunks + X - 1) / X;
+  return (blockIdx.x % X) * cpx + blockIdx.x / X;      // may be >= nchunks for the padding workgroups: callers test rows
 }
 
 
@@ -1167,8 +1172,9 @@ __global__ __launch_bounds__(kRingThreads) void spmm_ring_k(const int *__restric
 
   // workgroup b runs on XCD b % 8: an XCD owns a contiguous eighth of the strips, the slices of a strip sit next to each
   // other in dispatch order (they read the same entries: the second reader hits L2)
-  const int b = blockIdx.x, xcd = b & 7, li = b >> 3;
-  const int spx = nstrips >> 3;
+  const int nx = c_xcd;                                               // (nstrips is a multiple of it: ring_strips)
+  const int b = blockIdx.x, xcd = b % nx, li = b / nx;
+  const int spx = nstrips / nx;
   const int strip = xcd * spx + li / nsl, sl = li % nsl;
   const int nsteps = (M + R - 1) / R;
   const int t0 = strip * cps;
@@ -1774,10 +1780,29 @@ inline unsigned grid_for(int64_t work_items, int per_block) {
   return (unsigned)(b < (int64_t)INT_MAX ? b : (int64_t)INT_MAX);
 }
 
-// grid of the chunked kernels: one workgroup per chunk, rounded up to a multiple of the 8 XCDs (see my_chunk)
+// XCDs of the current device: hipDeviceAttributeNumberOfXccs, read once per device (a value that is not 1, 2, 4 or 8 — or a
+// failed query — keeps 8); the device-side copy c_xcd is rewritten the first time a device reports something else.
+inline int xcd_count() {
+  static std::mutex mu;
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 8;
+  std::lock_guard<std::mutex> lk(mu);
+  if (cached[dev] == 0) {
+    int x = 8;
+    if (hipDeviceGetAttribute(&x, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess || !(x == 1 || x == 2 || x == 4 || x == 8)) x = 8;
+    if (x != 8 && hipMemcpyToSymbol(HIP_SYMBOL(c_xcd), &x, sizeof(int)) != hipSuccess) x = 8;
+    (void)hipGetLastError();
+    cached[dev] = x;
+  }
+  return cached[dev];
+}
+
+// grid of the chunked kernels: one workgroup per chunk, rounded up to a multiple of the XCD count (see my_chunk)
 inline unsigned chunk_grid(int64_t nchunks) {
-  int64_t b = ((nchunks + kXCD - 1) / kXCD) * kXCD;
-  if (b < kXCD) b = kXCD;
+  const int X = xcd_count();
+  int64_t b = ((nchunks + X - 1) / X) * X;
+  if (b < X) b = X;
   return (unsigned)b;
 }
 
@@ -2138,7 +2163,7 @@ static int ring_strips(int64_t M, int N) {
   const int nsl = N / kRingCS;
   int nstrips = kCUs / nsl;
   const int64_t nsteps = (M + kRingR - 1) / kRingR;
-  while (nstrips > kXCD && nsteps < (int64_t)nstrips * 4) nstrips >>= 1;      // (a strip shorter than 4 steps is mostly prologue)
+  while (nstrips > xcd_count() && nsteps < (int64_t)nstrips * 4) nstrips >>= 1;      // (a strip shorter than 4 steps is mostly prologue)
   return nstrips;
 }
 
