@@ -22,12 +22,17 @@ The JSON line also carries
                (all of them, plus a 1-thread figure) on a bounded sample of the same workload (rank 0, N=1 only).
   secondary    BASELINE.json configs[4] (the config north_star's ">= 60 % of the HBM roofline on the Dirac SpMM at 128
                channels" is quoted on): 128 meshes per GPU with 1 000 .. 20 000 vertices, Di / Di^T / DiA / DiA^T at N = 32,
-               as a PACKED (unpadded, ragged) batch and — for comparison — padded to the batch maximum as the reference
+               as a PACKED (unpadded, ragged) batch and — grid order only — padded to the batch maximum as the reference
                batches; algorithmic bytes always from the real sum of V_i, F_i (`frac`), next to the bytes the packed
-               records really occupy (`actual_bytes`, `frac_actual`).  `laplacian`: the same meshes' cotangent Laplacians at
-               128 channels, packed (L, L^T).  `config2` / `config4_pair`: BASELINE.json configs[1] (Mesh-MNIST Dirac model,
-               batch 512) and the per-GPU work of configs[3] (one pair of 6890-vertex bodies, Laplacian towers): training
-               steps replayed from a hipGraph, ms per step and meshes/s.
+               records really occupy (`actual_bytes`, `frac_actual`) and the HBM traffic of an in-run counter pass (`traffic`,
+               `frac_traffic`).  Every entry names the vertex / face ORDER it was measured on (C5_ORDERS: the generator's grid
+               order, SURVEY 8d's random vertex permutation, vertices and faces both shuffled, the latter stored in the
+               product's locality numbering).  `laplacian`: the same meshes' cotangent Laplacians at 128 channels (L, L^T).
+               `config3_order`: the headline step on shuffled meshes, stored as they came / renumbered.  `config3_swap`: the
+               headline step behind the reference's own batching names and model calling sequence (an unmodified driver after
+               the import swap).  `config2` / `config4_pair` / `config4_dp`: BASELINE.json configs[1] (Mesh-MNIST Dirac model,
+               batch 512) and configs[3] (one pair of 6890-vertex bodies per rank, Laplacian towers): training steps replayed
+               from a hipGraph, ms per step and meshes/s.
   roofline.linear_kernels  the Linear-layer kernels of the same timed steps (forward / input gradient / weight gradient of
                the folded BatchNorm+Linear: two thirds of the step), each launch timed the same way: launches, average
                duration, algorithmic bytes (operands read + results written) and TB/s.

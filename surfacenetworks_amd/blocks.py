@@ -83,7 +83,10 @@ _TILE_SUMS_MIN_ROWS = 32768
 
 
 def _new_tiles(rows, C, device, part, wanted):
-    """Tile-sum buffer for a forward GEMM whose activated output feeds a global-average block (or None).  Only for operands
+    """Tile-sum buffer for a forward GEMM whose activated output feeds a global-average block (or None).  `wanted` comes from the
+    block's `avg_next` argument: True / None (not said: the unmodified reference models — every Dirac / Laplacian block but the
+    last is followed by an AvgResNet2, as_rigid_as_possible/models.py:115-121 — get the hand-off too; a buffer nobody picks up
+    costs 5 MB of stores per launch) or False.  Only for operands
     large enough that the statistics pass they save costs more than the per-tile path: a 7000-row FAUST tower runs FASTER with
     the pass (its per-mesh sums from tiles are four workgroups walking 218 tiles: replayed pair step 3.25 ms against 3.45, same
     box), the 322 624-row ARAP batch 0.28 ms per step slower."""
@@ -209,7 +212,7 @@ class _DiracBlock(torch.autograd.Function):
         return (g_v, g_f, None, None, None, None, None, None) + gp0 + gp1
 
 
-def dirac_block(mod, Di, DiA, v, f, need_f=True, num_faces=None, avg_next=False):
+def dirac_block(mod, Di, DiA, v, f, need_f=True, num_faces=None, avg_next=None):
     """DirResNet2.forward on (B, V, C) / (B, F, C) tensors; `mod` supplies bn_fc0 / bn_fc1.  need_f=False: the returned
     face features are only a carrier of the activated hand-off for the next Dirac block (see _DiracBlock.forward).
     f=None (with num_faces): all-zero face features, never materialised (zero_faces_ok says when).
@@ -224,7 +227,7 @@ def dirac_block(mod, Di, DiA, v, f, need_f=True, num_faces=None, avg_next=False)
     v_new, f_out, nxt_v, nxt_f = _DiracBlock.apply(v.reshape(rv, C), f.reshape(rf, C) if f is not None else None, opDi, opDiA,
                                                   take_activated(v, rv, C),
                                                   take_activated(f, rf, C) if f is not None else None, bool(need_f),
-                                                  bool(avg_next), *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+                                                  avg_next is not False, *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
     return attach_activated(v_new.view(B, V, C), nxt_v), attach_activated(f_out.view(B, F_, C), nxt_f)
 
 
@@ -447,13 +450,13 @@ def elu_conv_ok(conv, v) -> bool:
         conv.bn.affine and conv.bn.momentum is not None and conv.bn.track_running_stats
 
 
-def lap_block(mod, L, inputs, avg_next=False):
+def lap_block(mod, L, inputs, avg_next=None):
     B, V, C = inputs.shape
     rows = B * V
     op = as_operator(L)
     if op.shape != (rows, rows):
         raise ValueError(f"LapResNet2: operator {tuple(op.shape)} vs {rows} rows")
-    out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), op, None, None, 0, take_activated(inputs, rows, C), bool(avg_next),
+    out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), op, None, None, 0, take_activated(inputs, rows, C), avg_next is not False,
                                      *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
     return attach_activated(out.view(B, V, C), nxt)
 

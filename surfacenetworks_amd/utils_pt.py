@@ -195,8 +195,9 @@ class DenseLapResNet2(_TwoStage):
 class LapResNet2(_TwoStage):
     """x + Lin(BN([e1, L e1])), e1 = elu(Lin(BN([e0, L e0]))), e0 = elu(x)   (utils_pt.py:151-180)."""
 
-    def forward(self, L, mask, inputs, avg_next=False):
-        """avg_next=True (not in the reference's signature): the output feeds an AvgResNet2 next — the second GEMM then also
+    def forward(self, L, mask, inputs, avg_next=None):
+        """avg_next (not in the reference's signature; True / None = not said / False): the output feeds an AvgResNet2 next, as it
+        does in every model of the reference (the unmodified models.py say nothing and get the hand-off too) — the second GEMM then also
         leaves the per-tile column sums that block needs of its operand (no statistics pass over it)."""
         if isinstance(L, torch.Tensor) and L.layout == torch.strided:
             return DenseLapResNet2.forward(self, L, mask, inputs)
@@ -218,14 +219,14 @@ class DirResNet2(_TwoStage):
         super().__init__(num_outputs)
         self.res_f = res_f          # accepted and unused, as in the reference (utils_pt.py:189)
 
-    def forward(self, Di, DiA, v, f, f_out_needed=True, num_faces=None, avg_next=False):
+    def forward(self, Di, DiA, v, f, f_out_needed=True, num_faces=None, avg_next=None):
         """f_out_needed=False (not in the reference's signature): the caller promises to use the returned face features ONLY
         as the `f` argument of the next DirResNet2 — the block then skips writing them (the next block reads the activated
         copy handed over internally) and returns a NaN placeholder of the right shape in their place.
         f=None with num_faces=F (not in the reference's signature either): the face features are all zero — what every
         model of the reference feeds its first Dirac block (as_rigid_as_possible/models.py:138) — and are not materialised:
         the face stage runs over the propagated half only (same values).
-        avg_next=True (not in the reference's signature): the vertex output feeds an AvgResNet2 next (as in every model of the
+        avg_next (not in the reference's signature; True / None = not said / False): the vertex output feeds an AvgResNet2 next (as in every model of the
         reference): the vertex-stage GEMM also leaves the per-tile column sums that block needs of its operand."""
         batch_size, num_nodes, num_inputs = v.size()
         if f is None:
