@@ -186,3 +186,31 @@ def test_faust_pair_loss_is_invariant_to_the_stored_numbering():
         res.append((loss.item(), torch.cat([p.grad.reshape(-1) for p in model.parameters()])))
     assert abs(res[0][0] - res[1][0]) <= 1e-4 * abs(res[0][0]), (res[0][0], res[1][0])
     assert float((res[0][1] - res[1][1]).norm() / res[0][1].norm()) < 2e-3
+
+
+def test_device_built_operators_follow_the_stored_numbering():
+    """ClothSequences(operators="device") on shuffled meshes stored in the locality numbering: the Dirac operators built on the
+    GPU from the stored coordinates and faces are the pooled (host-built) operators of the same renumbered meshes — same
+    pattern, values equal to coordinate round-off — and banded; a packed batch of the renumbered pool trains."""
+    from surfacenetworks_amd import arap, mesh_ops as mo
+
+    kw = dict(frames=44, op_frames=2, seed=6, device=DEV, model="dir", permute="both", reorder=True)
+    ds_d = arap.ClothSequences([(11, 9)] * 3, operators="device", **kw)
+    ds_p = arap.ClothSequences([(11, 9)] * 3, operators="pool", **kw)
+    assert not any(o.identity for o in ds_d.orders)
+    ids, off = np.array([1, 2, 0]), np.zeros(3, dtype=np.int64)
+    bd = ds_d.sample_batch(3, None, seq_ids=ids, offsets=off)
+    bp = ds_p.sample_batch(3, None, seq_ids=ids, offsets=off)
+    assert torch.equal(bd.inputs, bp.inputs) and torch.equal(bd.targets, bp.targets)
+    for name in ("Di", "DiA"):
+        a, b = getattr(bd, name).to_scipy(), getattr(bp, name).to_scipy()
+        assert np.array_equal(a.indptr, b.indptr) and np.array_equal(a.indices, b.indices)
+        assert abs(a - b).max() <= 1e-4 * abs(b).max()
+    # banded: a face's three vertices lie within a dozen positions of each other (11 x 9 grid: row-major band 10)
+    blk = bp.Di.to_scipy()[: 4 * int(ds_p.num_faces[1]), : 4 * int(ds_p.num_vertices[1])].tocoo()
+    assert (np.abs(blk.col // 4 - np.round(blk.row // 4 / 2.0)) <= 3 * 11).all()
+    torch.manual_seed(0)
+    m = arap.DirModel().to(DEV)
+    opt = arap.make_optimizer(m)
+    assert torch.isfinite(arap.train_step(m, opt, bd))
+    assert torch.isfinite(arap.train_step(m, opt, ds_p.sample_batch(3, None, seq_ids=ids, offsets=off, packed=True)))
