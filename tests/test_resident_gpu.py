@@ -219,3 +219,68 @@ def test_resident_pools_grow_and_start_over_when_the_budget_is_spent():
     finally:
         cache.max_bytes = old_budget
         cache.clear()
+
+
+def test_driver_style_step_equals_the_products_own_step(tmp_path):
+    """The ARAP step as the reference's driver assembles it (src/as_rigid_as_possible/main.py:98-185,217-232, restated: frames
+    from the sequence files, inputs / targets / mask filled on the host, `sp_sparse_to_pt_sparse` per sample, `sparse_diag_cat`,
+    `.cuda()`, `outputs * mask`, `smooth_l1_loss(reduction='sum') / batch_size`) on the device, against the product's own
+    sampler and train step on the same files: the same loss and gradients — the batch operators are assembled from the same
+    matrices by the same launch on both sides, so bit for bit."""
+    import torch.nn.functional as F
+
+    import surfacenetworks_amd.utils_pt as utils
+    from helpers import deterministic_init
+    from surfacenetworks_amd import arap, datasets, mesh_ops as mo
+    from surfacenetworks_amd.resident import LazySparse
+
+    rng = np.random.default_rng(14)
+    T = arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 2
+    paths = []
+    for k, (n, m) in enumerate([(9, 8), (7, 6), (8, 8)]):
+        V, Fc = mo.grid_cloth(n, m, rng)
+        Vt = np.repeat(V[None], T, 0).copy()
+        Vt[:, :, 2] += 0.02 * np.sin(0.3 * np.arange(T))[:, None] * (1 + V[None, :, 0])
+        paths.append(str(tmp_path / f"seq{k}.npy"))
+        datasets.write_arap_sequence(paths[-1], Vt, Fc, op_frames=3)
+    sequences = [datasets.load_arap_sequence(p) for p in paths]              # what main.py:58-94 keeps: dicts of numpy / scipy objects
+    ds = datasets.arap_from_files(paths, DEV, "dir", reorder=False)          # the product's resident dataset of the same files
+    indices, offsets = [2, 0, 1, 0], [1, 0, 0, 1]
+    B = len(indices)
+    nv = max(sequences[i][0]["V"].shape[0] for i in indices)
+    nf = max(sequences[i][0]["F"].shape[0] for i in indices)
+    inputs, targets, mask = torch.zeros(B, nv, 6), torch.zeros(B, nv, 120), torch.zeros(B, nv, 1)
+    Di, DiA = [], []
+    for b, (ind, off) in enumerate(zip(indices, offsets)):
+        n_ = sequences[ind][0]["V"].shape[0]
+        for i in range(2):
+            inputs[b, :n_, 3 * i:3 * (i + 1)] = torch.from_numpy(sequences[ind][i + off]["V"])
+        for i in range(40):
+            targets[b, :n_, 3 * i:3 * (i + 1)] = torch.from_numpy(sequences[ind][i + off + 2]["V"])
+        mask[b, :n_] = 1
+        Di.append(utils.sp_sparse_to_pt_sparse(sequences[ind][off + 1]["Di"]))
+        DiA.append(utils.sp_sparse_to_pt_sparse(sequences[ind][off + 1]["DiA"]))
+    Di = utils.sparse_diag_cat(Di, 4 * nf, 4 * nv)
+    DiA = utils.sparse_diag_cat(DiA, 4 * nv, 4 * nf)
+    inputs, targets, mask, Di, DiA = inputs.cuda(), targets.cuda(), mask.cuda(), Di.cuda(), DiA.cuda()
+    assert isinstance(Di, LazySparse) and Di._sn_operator is not None and not Di._sn_payload.real       # nothing was materialised
+    own = ds.sample_batch(B, None, seq_ids=np.array(indices), offsets=np.array(offsets))
+    assert torch.equal(own.inputs, inputs) and torch.equal(own.targets, targets) and torch.equal(own.mask, mask)
+    for a, b_ in ((Di._sn_operator, own.Di), (DiA._sn_operator, own.DiA)):
+        assert abs(a.to_scipy() - b_.to_scipy()).max() == 0
+    res = []
+    for kind in ("driver", "product"):
+        model = deterministic_init(arap.DirModel(), 9).to(DEV).train()
+        if kind == "driver":
+            outputs = model(Di, DiA, mask, inputs)
+            outputs = outputs * mask.expand_as(outputs)
+            loss = F.smooth_l1_loss(outputs, targets, reduction="sum") / B
+        else:
+            loss, _ = arap.forward_loss(model, own)
+        loss.backward()
+        res.append((loss.detach().clone(), [p.grad.clone() for p in model.parameters()]))
+    assert abs(res[0][0].item() - res[1][0].item()) <= 1e-6 * abs(res[1][0].item())     # (torch's loss against the fused loss kernel)
+    gn = max(float(g.norm()) for g in res[1][1])
+    for g0, g1 in zip(res[0][1], res[1][1]):
+        assert float((g0 - g1).norm()) <= 1e-5 * float(g1.norm()) + 1e-6 * gn
+    assert not Di._sn_payload.real and not DiA._sn_payload.real                 # the whole step ran without the index arrays
