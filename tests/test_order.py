@@ -71,3 +71,21 @@ def test_faces_follow_their_vertices():
     assert (np.diff(lo) >= 0).all()                        # sorted by the smallest corner rank
     # face k sits near 2 x (its vertices' rank): the Dirac blocks stay near the diagonal of the (F x V) block pattern
     assert np.abs(np.arange(F2.shape[0]) / 2.0 - F2.mean(axis=1)).max() < 3 * 30
+
+
+def test_bench_config5_orders_are_what_they_say(monkeypatch):
+    """bench.C5_ORDERS: the same mesh sizes in every variant; mean edge span large for the shuffled variants, back to (below) the
+    grid's for the renumbered one; operators of every variant have the same entry counts."""
+    import bench
+
+    monkeypatch.setattr(bench, "C5_MESHES_PER_GPU", 6)
+    monkeypatch.setattr(bench, "C5_VMIN", 300)
+    monkeypatch.setattr(bench, "C5_VMAX", 900)
+    res = {o: bench._c5_meshes(0, *pr) for o, pr in bench.C5_ORDERS.items()}
+    sums = {o: (r[3], r[4]) for o, r in res.items()}
+    assert len(set(sums.values())) == 1                                   # same sum V, sum F everywhere
+    span = {o: r[5] for o, r in res.items()}
+    assert span["permuted"] > 5 * span["grid"] and span["permuted_both"] > 5 * span["grid"]
+    assert span["permuted_both+reorder"] <= span["grid"]
+    nnz = {o: [m.nnz for m in r[0]] for o, r in res.items()}
+    assert nnz["grid"] == nnz["permuted"] == nnz["permuted_both"] == nnz["permuted_both+reorder"]
