@@ -125,6 +125,21 @@ def _bn_args(conv):
 
 
 # ------------------------------------------------------------------------------------------------------------
+_NAN = {}
+
+
+def _nan_placeholder(device):
+    """One NaN element per device, made once: the stand-in for an output that is not written costs no launch per block (a
+    4-byte fill is a 4 us launch on the step's critical path, eight times per ARAP step).  Never cached from inside a graph
+    capture — the element would live in that graph's memory pool."""
+    t = _NAN.get(device)
+    if t is None:
+        t = torch.full((1, 1), float("nan"), dtype=torch.float32, device=device)
+        if device.type != "cuda" or not torch.cuda.is_current_stream_capturing():
+            _NAN[device] = t
+    return t
+
+
 class _DiracBlock(torch.autograd.Function):
     """DirResNet2 (utils_pt.py:191-220):
          cat0 = [elu(f), Di·elu(v)]  -> f_out = Lin(BN(cat0));   cat1 = [elu(v), DiA·elu(f_out)] -> v + Lin(BN(cat1))."""
@@ -154,7 +169,7 @@ class _DiracBlock(torch.autograd.Function):
             # The caller only chains f into the next Dirac block, which consumes the ACTIVATED hand-off: the pre-activation
             # face features are not written (321 MB per block at the ARAP batch).  What is returned in their place is a
             # zero-stride NaN view, so that any other use of it is loud instead of silently wrong.
-            f_out = torch.full((1, 1), float("nan"), dtype=torch.float32, device=v.device).expand(rf, C)
+            f_out = _nan_placeholder(v.device).expand(rf, C)
         _attach_hi(cat1, _launch(opDiA, nxt_f[:, :C], cat1[:, C:], 4, "fwd", stats=tr1))
         nxt_v = _new_cat(rv, C, v.device)
         pv = _new_part(rv, C, v.device, narrow=True)

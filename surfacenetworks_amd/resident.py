@@ -229,7 +229,13 @@ class ResidentCache:
     @staticmethod
     def _signature(A):
         arrays = [getattr(A, n, None) for n in ("data", "indices", "indptr", "row", "col")]
-        return (A.format, A.shape, int(A.nnz)) + tuple(a.ctypes.data for a in arrays if isinstance(a, np.ndarray))
+        sig = (A.format, A.shape, int(A.nnz)) + tuple(a.ctypes.data for a in arrays if isinstance(a, np.ndarray))
+        d = getattr(A, "data", None)
+        if isinstance(d, np.ndarray) and d.size:
+            # eight evenly spaced values: an in-place edit of the SAME arrays (A.data *= 2) is caught without reading them all
+            # (O(1) per call; an edit that misses all eight probes is not — resident_cache().clear() after such edits)
+            sig += (d.reshape(-1)[:: max(1, d.size // 8)][:8].tobytes(),)
+        return sig
 
     @staticmethod
     def _canonical(A):

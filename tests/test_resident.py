@@ -49,3 +49,20 @@ def test_batching_functions_without_a_gpu_are_the_references():
         assert torch.equal(got._indices(), want._indices()) and torch.equal(got._values(), want._values())
         mixed = fn([hs[0], real[1], hs[2]], 14, 10)
         assert torch.equal(mixed.to_dense(), want.to_dense())
+
+
+def test_cache_signature_notices_replaced_arrays_and_in_place_edits():
+    import scipy.sparse as sp
+
+    from surfacenetworks_amd.resident import ResidentCache
+
+    A = sp.random(40, 40, 0.2, "csr", np.float32, random_state=1)
+    s0 = ResidentCache._signature(A)
+    assert ResidentCache._signature(A) == s0                       # asked twice: the same
+    A.data *= 2                                                    # the same arrays, new values
+    s1 = ResidentCache._signature(A)
+    assert s1 != s0
+    A.data = A.data.copy()                                         # the same values, a new array
+    assert ResidentCache._signature(A) != s1
+    E = sp.csr_matrix((4, 4), dtype=np.float32)                    # no entries: nothing to probe
+    assert ResidentCache._signature(E) == ResidentCache._signature(E)

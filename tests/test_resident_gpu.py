@@ -180,9 +180,12 @@ def test_in_place_replacement_of_a_dataset_matrix_is_noticed():
     ms = _meshes(rng, [(6, 6)])
     L = ms[0][2]["L"].copy()
     a = U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(L)], L.shape[0], L.shape[1]).cuda()._sn_operator.to_scipy()
-    L.data = L.data * 2                                                # new array object: noticed (an in-place `*=` would not be)
+    L.data = L.data * 2                                                # new array object: noticed through its address
     b = U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(L)], L.shape[0], L.shape[1]).cuda()._sn_operator.to_scipy()
     assert np.array_equal(b.data, 2 * a.data)
+    L.data *= 3                                                        # the SAME array edited in place: noticed through the value probes
+    c = U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(L)], L.shape[0], L.shape[1]).cuda()._sn_operator.to_scipy()
+    assert np.array_equal(c.data, 6 * a.data)
 
 
 def test_resident_pools_grow_and_start_over_when_the_budget_is_spent():
