@@ -51,6 +51,7 @@ class SparseOperator:
     def __init__(self, rowptr, colind, vals, shape, *, batch: int = 1, transpose: "Optional[SparseOperator]" = None,
                  bsr4=None, q3=None):
         M, K = int(shape[0]), int(shape[1])
+        self._shape = (M, K)
         if rowptr is None:
             if not isinstance(bsr4, tuple) and not isinstance(q3, tuple):
                 raise ValueError("an operator needs CSR arrays, a BSR4 triple or a Q3 pair")
@@ -64,7 +65,6 @@ class SparseOperator:
             if _DEBUG_VALIDATE and rowptr.is_cuda:
                 self.validate()
         self._nnz_cache = None
-        self._shape = (M, K)
         self.batch = int(batch)                  # number of diagonal blocks (B of the reference's (B,R,K) operators)
         self.row_offsets = self.col_offsets = None   # packed (unpadded) batches: first row / column of every diagonal block
         # operator -> transpose is a strong reference, transpose -> operator a weak one: a strong pair would be a

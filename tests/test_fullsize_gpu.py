@@ -319,3 +319,32 @@ def test_debug_validator_flags_malformed_operators():
     nf = va.clone()
     nf[2] = float("inf")
     assert kernels.validate_csr(rp, ci, nf, 3, 5) & 32
+
+
+def test_debug_validation_switch_checks_operators_as_they_are_built(monkeypatch):
+    """SN_DEBUG_VALIDATE=1 (operators._DEBUG_VALIDATE): the constructor itself runs the validator on device CSR arrays — a
+    well-formed operator is built and multiplies as usual (transposes and batches included), a malformed one raises."""
+    from surfacenetworks_amd import operators
+    from surfacenetworks_amd.functional import spmm
+
+    monkeypatch.setattr(operators, "_DEBUG_VALIDATE", True)
+    rp = torch.tensor([0, 2, 2, 5], dtype=torch.int32, device=DEV)
+    ci = torch.tensor([0, 3, 1, 2, 4], dtype=torch.int32, device=DEV)
+    va = torch.arange(1, 6, dtype=torch.float32, device=DEV)
+    op = operators.SparseOperator(rp, ci, va, (3, 5))
+    x = torch.randn(5, 8, device=DEV)
+    dense = torch.zeros(3, 5, device=DEV)
+    dense[[0, 0, 2, 2, 2], [0, 3, 1, 2, 4]] = va
+    assert torch.allclose(spmm(op, x), dense @ x, atol=1e-6)
+    assert torch.allclose(spmm(op.t(), torch.ones(3, 8, device=DEV)), dense.t() @ torch.ones(3, 8, device=DEV), atol=1e-6)
+    L = sp.random(40, 40, 0.2, "csr", np.float32, random_state=2)
+    L.sort_indices()
+    pool = operators.OperatorPool([L, L], DEV)
+    batch = pool.assemble([0, 1])
+    assert tuple(batch.shape) == (80, 80) and batch.t().nnz == 2 * L.nnz
+    with pytest.raises(ValueError, match="column index out of range"):
+        operators.SparseOperator(rp, ci, va, (3, 4))
+    bad = ci.clone()
+    bad[1] = 0
+    with pytest.raises(ValueError, match="row not sorted"):
+        operators.SparseOperator(rp, bad, va, (3, 5))
