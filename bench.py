@@ -956,6 +956,11 @@ def main():
             table["_csrc_sha256"] = csrc_digest()
         if table.get("_csrc_sha256") != csrc_digest():
             traffic_src = f"{pmc_file} was measured on other kernel sources (sha256 mismatch): withheld; in-run pass: {in_run_note}"
+        elif file_note is not None and (args.meshes != MESHES_PER_GPU or args.format != "q3"):
+            # the committed file is the default configuration's (64 meshes per GPU, quaternion-packed operators): any other batch
+            # or storage form has other launches, so nothing is quoted rather than that file's bytes over this run's durations
+            traffic_src = (f"{pmc_file} holds the default configuration ({MESHES_PER_GPU} meshes per GPU, q3), this run is "
+                           f"{args.meshes} meshes / {args.format}: withheld; in-run pass: {in_run_note}")
         else:
             tot = table.get("_total_bytes_counted")
             n_counted = table.get("_steps_counted", 4)
