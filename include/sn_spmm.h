@@ -815,6 +815,42 @@ int sn_linear_dgrad_eluseg_ragged_absmax_f32(const float *dy, int64_t lddy, cons
                                              const float *gadd, int64_t ldgadd, int64_t rows, int32_t J, int32_t C,
                                              float *gact_absmax, void *stream);
 
+/* ---- launch plans: one host call enqueues a whole residual block ------------------------------------------------------------
+ * Replaces, per block, the Python dispatch the reference pays per op: LapResNet2 / DirResNet2 / AvgResNet2.forward
+ * (src/utils/utils_pt.py:159-180, 191-220, 230-243) and their autograd backward are sequences of torch ops launched one by one
+ * from the interpreter inside the training loops (src/as_rigid_as_possible/main.py:217-232, src/mesh_mnist/main.py:151-167,
+ * src/dense_correspondence/main.py:310-327), which cannot be graph-captured by an unmodified driver.
+ *
+ * A plan is a HOST object holding the launch list of one block direction: entries of this header (by index into the table
+ * sn_plan_lookup searches) with their scalar arguments, pointer arguments as (slot, byte offset).  The caller supplies the
+ * slots' base addresses per run — slot 0/1 by convention the block's two workspace arenas (ONE allocation each, sized once per
+ * shape by the caller), the rest the tensors the block reads or writes — and sn_plan_run calls the recorded entry points in
+ * order on `stream`: the same launchers, kernels and grids as calling them one by one, bit-identical results.  The library
+ * still never allocates device memory, synchronises or keeps per-shape state: plans are created, owned and destroyed by the
+ * caller, immutable while running, usable from several threads / streams at once.
+ *   kind[i]: 0 integer (ival), 1 floating point (dval), 2 pointer = slot_base[slot[i]] + ival[i], 3 NULL pointer, 4 the stream
+ *   (last argument of every entry point).  sn_plan_add_call checks every kind against the parameter type of the entry point
+ *   (SN_E_UNSUPPORTED on a mismatch, SN_E_SHAPE on a wrong argument count).
+ *   sn_plan_add_memset / sn_plan_add_copy: a byte fill / a device-to-device copy of a 2-D region (rows x width_bytes, pitches in
+ *   bytes; rows = 1: flat) — what torch.zeros / Tensor.copy_ do between the reference's ops.
+ *   sn_plan_run: 0, or the status of the first failing entry (its index in *failed_node, else -1); SN_E_NULL when a slot a
+ *   recorded pointer refers to is handed over as 0. */
+typedef struct sn_plan sn_plan;
+int sn_plan_create(sn_plan **out);
+int sn_plan_destroy(sn_plan *plan);
+int32_t sn_plan_lookup(const char *entry_point_name);
+int32_t sn_plan_entry_count(void);
+const char *sn_plan_entry_name(int32_t fn);
+const char *sn_plan_entry_signature(int32_t fn);        /* one char per parameter: p pointer, i integer, d floating point */
+int64_t sn_plan_length(const sn_plan *plan);
+int sn_plan_add_call(sn_plan *plan, int32_t fn, int32_t nargs, const int32_t *kind, const int32_t *slot, const int64_t *ival,
+                     const double *dval);
+int sn_plan_add_memset(sn_plan *plan, int32_t slot, int64_t offset, int32_t byte_value, int64_t pitch, int64_t width_bytes,
+                       int64_t rows);
+int sn_plan_add_copy(sn_plan *plan, int32_t dst_slot, int64_t dst_offset, int64_t dst_pitch, int32_t src_slot, int64_t src_offset,
+                     int64_t src_pitch, int64_t width_bytes, int64_t rows);
+int sn_plan_run(const sn_plan *plan, const uint64_t *slot_base, int32_t nslots, void *stream, int32_t *failed_node);
+
 #ifdef __cplusplus
 }
 #endif

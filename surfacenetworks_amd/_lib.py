@@ -153,6 +153,18 @@ SIGNATURES = {
                                                     _i64, _i64, _i32, _i32, _vp]),
     "sn_affine_cols_acc_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
     "sn_affine_cols_elu_bwd_f32": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i32, _vp]),
+    # launch plans (csrc/sn_plan.hip): host objects, no device work of their own
+    "sn_plan_create": (C.c_int, [C.POINTER(_vp)]),
+    "sn_plan_destroy": (C.c_int, [_vp]),
+    "sn_plan_lookup": (_i32, [C.c_char_p]),
+    "sn_plan_entry_count": (_i32, []),
+    "sn_plan_entry_name": (C.c_char_p, [_i32]),
+    "sn_plan_entry_signature": (C.c_char_p, [_i32]),
+    "sn_plan_length": (_i64, [_vp]),
+    "sn_plan_add_call": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "sn_plan_add_memset": (C.c_int, [_vp, _i32, _i64, _i32, _i64, _i64, _i64]),
+    "sn_plan_add_copy": (C.c_int, [_vp, _i32, _i64, _i64, _i32, _i64, _i64, _i64, _i64]),
+    "sn_plan_run": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
 }
 
 _lib = None
@@ -193,5 +205,13 @@ def check(status: int, what: str) -> None:
         raise SnError(f"{what} failed with status {status}: {msg}")
 
 
+# A launch-plan recorder (plans.py) while the launch list of a block is being taken down: every call() is then RECORDED, not
+# executed (a dry run of the block's host code); None otherwise.
+_recorder = None
+
+
 def call(name: str, *args) -> None:
+    if _recorder is not None:
+        _recorder.record_call(name, args)
+        return
     check(getattr(load(), name)(*args), name)

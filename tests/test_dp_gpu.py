@@ -235,8 +235,12 @@ def test_bench_runs_its_one_rank_through_rccl():
     assert len(lines) == 1 and lines[0].startswith("{"), lines       # the contract: ONE JSON line (RCCL's banner etc. go to stderr)
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 1 and rec["config"]["collective_backend"] == "nccl" and rec["config"]["rccl_ranks"] == 1
-    assert rec["config"]["collective_per_step"].startswith("pack + ncclAllReduce")
-    assert rec["roofline"]["linear_kernels"] and rec["roofline"]["linear_kernels"][0]["launches_per_step"] > 0
+    assert len(lines[0]) < 4096                                       # the compact line; the tables live in the detail file it names
+    with open(os.path.join(ROOT, rec["detail"])) as fh:
+        full = json.load(fh)
+    assert full["config"]["collective_per_step"].startswith("pack + ncclAllReduce")
+    assert full["roofline"]["linear_kernels"] and full["roofline"]["linear_kernels"][0]["launches_per_step"] > 0
+    assert rec["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-3)
 
 
 def _pair_worker(rank, world, port, q):
@@ -349,6 +353,7 @@ def test_bench_starts_eight_ranks_on_the_one_device(workload):
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
+    assert len(lines[0]) < 4096
     rec = json.loads(lines[0])
     cfg = rec["config"]
     assert rec["n_gpus"] == 8 and cfg["world_size"] == 8 and rec["value"] > 0 and np.isfinite(rec["ms_per_step"])
