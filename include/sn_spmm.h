@@ -24,7 +24,8 @@
  *                SN_RESIDENT          0 = utils_pt's batching functions take the reference's host path (no resident cache)
  *                SN_RESIDENT_MAX_GB   HBM budget of that cache (default 96)
  *                SN_DP_FORCE_CPU      1 = dp.init_distributed ignores the GPU (CPU gloo tests)
- *     SWITCHES: SN_GEMM_VARIANT SN_PAIR_FUSED SN_STRICT SN_DEBUG_VALIDATE SN_RESIDENT SN_RESIDENT_MAX_GB SN_DP_FORCE_CPU
+ *                SN_PLANS             0 = every block launches its kernels one by one from Python (no launch plans, plans.py)
+ *     SWITCHES: SN_GEMM_VARIANT SN_PAIR_FUSED SN_STRICT SN_DEBUG_VALIDATE SN_RESIDENT SN_RESIDENT_MAX_GB SN_DP_FORCE_CPU SN_PLANS
  *     (b) the opt-in per-launch timing facility sn_timing_* below (a mutex-guarded list, off by default).  Neither affects
  *     results.  The Python layer adds process-wide DEFAULTS with the same property: functional.set_dirac_format /
  *     set_laplacian_format (kernel form; one operator can choose for itself, SparseOperator.format) and set_bn_sync (opt-in

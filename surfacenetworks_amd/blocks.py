@@ -20,8 +20,8 @@ from __future__ import annotations
 
 import torch
 
-from . import kernels
-from .functional import (_launch, _rows2d, avg_stage_backward, avg_stage_backward_ragged, avg_stage_forward,
+from . import kernels, plans
+from .functional import (_launch, _rows2d, product_form, avg_stage_backward, avg_stage_backward_ragged, avg_stage_forward,
                          avg_stage_forward_ragged, bn_prepare, bnlin_backward,
                          bnlin_backward_elu_input, bnlin_backward_zero_first, bnlin_forward, bnlin_forward_zero_first, stash, unstash,
                          zero_first_supported)
@@ -124,6 +124,125 @@ def _bn_args(conv):
             training, momentum, eps)
 
 
+# ---- launch plans (plans.py): one host call per block direction ---------------------------------------------------------------
+# Every block below is written as two plain functions — `*_fwd(tensors..., operators..., constants...) -> (outputs, saved)` and
+# `*_bwd(saved, operators..., gradients..., constants...) -> gradients` — that launch through kernels.py.  The autograd nodes call
+# them directly (eager) or hand them to `_plan_forward` / `_plan_backward`, which record their launch list once per shape
+# signature and from then on enqueue it with one sn_plan_run.
+_MISSING = object()
+
+
+def _op_operands(ops, ncols):
+    """(arrays, key) of the forms in which the block multiplies its operators and their transposes (functional.product_form:
+    building a derived form launches and may synchronise — here, before anything is recorded)."""
+    arrays, key = [], []
+    for op, group in ops:
+        for o in (op, op.t()):
+            kind, arr, scal = product_form(o, group, ncols)
+            arrays.extend(arr)
+            key.append((kind, scal))
+    return arrays, tuple(key)
+
+
+def _plan_forward(ctx, site, impl, tensors, ops, consts, ncols, n_dyn, scan):
+    """Run `impl(*tensors, *operators, *consts)` through its launch plan.  Returns the block's outputs (views of the plan's
+    arenas) or None when the block is not plannable (the caller then runs `impl` eagerly).
+    tensors[:n_dyn] are the block's features (any shape / stride: part of the plan's key in full), the rest its parameters and
+    buffers (keyed by shape; a non-contiguous one makes the dry run refuse the plan); scan: positions whose `_sn_*` tensor
+    attributes are operands too (plans.expand_ext)."""
+    op_arrays, op_key = _op_operands(ops, ncols) if ops else ((), ())
+    ext, attr_key = plans.expand_ext(tensors, scan)
+    ext.extend(op_arrays)
+    dyn = tensors[:n_dyn]
+    ptrs = [t.data_ptr() if t is not None else 0 for t in dyn]
+    key = (tuple([None if t is None else (t.shape, t.stride(), t.dtype) for t in dyn]),
+           tuple([None if t is None else t.shape for t in tensors[n_dyn:]]), attr_key, op_key, consts,
+           tuple([ptrs.index(p_) for p_ in ptrs]),               # features that share memory must do so on every run of the plan
+           _TILE_SUMS_MIN_ROWS)
+    plan = site.plans.get(key, _MISSING)
+    if plan is None:
+        return None
+    if plan is _MISSING:
+        plan = plans.record(site, key, impl, (*tensors, *[o for o, _ in ops], *consts), ext, tensors[0].device)
+        if plan is None:
+            return None
+        need = set()
+
+        def slots(d):
+            if isinstance(d, plans._Desc):
+                if d.slot >= 2:
+                    need.add(d.slot - 2)
+            elif isinstance(d, tuple):
+                for v in d:
+                    slots(v)
+        slots(plan.result[1])
+        plan.saved_ext = sorted(need)                              # the operands the backward reaches through what was saved
+    big, small = plan.new_arenas()
+    plan.run(big, small, ext)
+    site.replayed += 1
+    build = plans._Builder(big, small, ext)
+    outs = build(plan.result[0])
+    if plan.effects:
+        plans.apply_effects(plan, build)
+    # What the backward needs: the arenas and the operands the saved descriptions point into.  Plain attributes, dropped by
+    # the backward itself: autograd's saved-tensor slots would tie the arena's version counter — shared by every view of
+    # it, i.e. by every output of the block — to the backward (an in-place edit of any output would then be an error).
+    ctx._sn_plan = (plan, big, small, [ext[j] for j in plan.saved_ext], ops, ncols)
+    return outs
+
+
+def _plan_backward(ctx, site, impl, grads, consts):
+    """The backward of a block whose forward ran through `_plan_forward`: `impl(saved, *operators, *grads, *consts)` through its
+    own plan, recorded against the forward plan's arena layout.  Returns the gradients (nested as `impl` returns them)."""
+    state = ctx._sn_plan
+    if state is None:
+        raise RuntimeError("a second backward through a block that ran from a launch plan (retain_graph): its workspace was "
+                           "released by the first one; run with SN_PLANS=0 for that")
+    fplan, big, small, kept, ops, ncols = state
+    ctx._sn_plan = None
+    op_arrays, op_key = _op_operands(ops, ncols) if ops else ((), ())
+    maxima = [kernels.take_absmax(g) if g is not None else None for g in grads]
+    ext = [big, small, *kept, *grads, *maxima, *op_arrays]
+    key = (tuple([None if g is None else (g.shape, g.stride(), g.dtype) for g in grads]), tuple([m is not None for m in maxima]),
+           op_key, consts)
+    plan = fplan.bwd.get(key, _MISSING)
+    if plan is _MISSING or plan is None:
+        fext = [None] * fplan.n_ext
+        for j, t in zip(fplan.saved_ext, kept):
+            fext[j] = t
+        saved = plans._Builder(big, small, fext)(fplan.result[1])
+        plans.renote(grads, maxima)
+        if plan is None:                                           # not plannable: the eager backward on the saved tensors
+            return impl(saved, *[o for o, _ in ops], *grads, *consts)
+        plan = plans.record(site, (id(fplan), key), impl, (saved, *[o for o, _ in ops], *grads, *consts), ext,
+                            grads_device(grads, big, small))
+        fplan.bwd[key] = plan
+        if plan is None:
+            return impl(saved, *[o for o, _ in ops], *grads, *consts)
+        for g in grads:                                            # (bounds the dry run did not take)
+            if g is not None:
+                kernels.take_absmax(g)
+    b2, s2 = plan.new_arenas()
+    plan.run(b2, s2, ext)
+    site.replayed += 1
+    build = plans._Builder(b2, s2, ext)
+    out = build(plan.result)
+    if plan.effects:
+        plans.apply_effects(plan, build)
+    return out
+
+
+def grads_device(grads, *others):
+    for t in (*grads, *others):
+        if t is not None:
+            return t.device
+    raise ValueError("no tensor to take the device from")
+
+
+_SITES = {name: plans.Site(name) for name in ("dirac_fwd", "dirac_bwd", "propagate_fwd", "propagate_bwd", "avg_fwd", "avg_bwd",
+                                              "avg_ragged_fwd", "avg_ragged_bwd", "elu_conv_fwd", "elu_conv_bwd")}
+
+
 # ------------------------------------------------------------------------------------------------------------
 _NAN = {}
 
@@ -140,91 +259,130 @@ def _nan_placeholder(device):
     return t
 
 
-class _DiracBlock(torch.autograd.Function):
+def _dirac_fwd(v, f, pre_v, pre_f, g0, b0, W0, c0, rm0, rv0, g1, b1, W1, c1, rm1, rv1, opDi, opDiA, need_f, avg_next, tr0, mo0,
+               ep0, tr1, mo1, ep1):
     """DirResNet2 (utils_pt.py:191-220):
-         cat0 = [elu(f), Di·elu(v)]  -> f_out = Lin(BN(cat0));   cat1 = [elu(v), DiA·elu(f_out)] -> v + Lin(BN(cat1))."""
+         cat0 = [elu(f), Di·elu(v)]  -> f_out = Lin(BN(cat0));   cat1 = [elu(v), DiA·elu(f_out)] -> v + Lin(BN(cat1)).
+    Returns ((v_new, f_out | None, nxt_v, nxt_f), saved)."""
+    rv, C = v.shape
+    rf = opDi.shape[0] // 4
+    cat1 = _activated(v, pre_v)
+    nxt_f = _new_cat(rf, C, v.device)                        # the next Dirac block's cat0; first half = elu(f_out)
+    pf = _new_part(rf, C, v.device, narrow=True)
+    if f is None:
+        # all-zero face features (the first Dirac block of a model): cat0 = [0 | Di·elu(v)] runs at half width
+        cat0 = torch.empty((rf, C), dtype=torch.float32, device=v.device)      # only the propagated half exists
+        _attach_hi(cat0, _launch(opDi, cat1[:, :C], cat0, 4, "fwd", stats=tr0))
+        f_out, st0 = bnlin_forward_zero_first(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, nxt_f[:, :C], need_f, pf)
+    else:
+        cat0 = pre_f if pre_f is not None else _activated(f, None)             # (f's values are not touched when handed off)
+        _attach_hi(cat0, _launch(opDi, cat1[:, :C], cat0[:, C:], 4, "fwd", stats=tr0))
+        f_out, st0 = bnlin_forward(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, nxt_f[:, :C], want_y=need_f,
+                                   elu_stats=pf)
+    _attach_part(nxt_f, pf)
+    _attach_hi(cat1, _launch(opDiA, nxt_f[:, :C], cat1[:, C:], 4, "fwd", stats=tr1))
+    nxt_v = _new_cat(rv, C, v.device)
+    pv = _new_part(rv, C, v.device, narrow=True)
+    tv = _new_tiles(rv, C, v.device, pv, avg_next)
+    v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C], elu_stats=pv, tile_sums=tv)
+    _attach_part(nxt_v, pv, tv)
+    return (v_new, f_out, nxt_v, nxt_f), ((cat0, cat1, nxt_f), st0, st1)
+
+
+def _dirac_bwd(saved, opDi, opDiA, g_vnew, g_fo, f_zero, need_gv, need_gf):
+    """Backward of _dirac_fwd: (g_v, g_f, dgamma0, dbeta0, dW0, db0, dgamma1, dbeta1, dW1, db1)."""
+    (cat0, cat1, nxt_f), st0, st1 = saved
+    C = cat1.shape[1] // 2
+    dev = cat1.device
+    # Every ELU backward of the block is fused: the dgrad GEMM's epilogue sends the first half of a stage's input
+    # gradient through the activation (h = dx[:, :C]·elu'(e) + the gradient of the other branch), and the transposed
+    # product's store does the same for the propagated half:  (opᵀ·dx[:, C:])·elu'(e) + h.
+    # ---- second stage (vertex rows) ----
+    gp1 = (None,) * 4
+    h1 = None                                                                   # dx1[:, :C]·elu'(e_v) + g_vnew
+    if g_vnew is not None:
+        (dx1_hi, h1), dg1, db1, dW1, dc1 = bnlin_backward(st1, g_vnew, through_elu=(g_vnew,))
+        gp1 = (dg1, db1, dW1, dc1)
+        g_sum = torch.empty((nxt_f.shape[0], C), dtype=torch.float32, device=dev)
+        # (DiA^T·dx1_hi)·elu'(e_f)  +  the gradient f_out receives from the next block
+        _launch(opDiA.t(), dx1_hi, g_sum, 4, "bwd", elubwd=(nxt_f[:, :C], g_fo))
+        g_fo = g_sum
+    # ---- first stage (face rows) ----
+    gp0 = (None,) * 4
+    g_v = g_f = None
+    dx0_hi = None
+    if g_fo is not None and f_zero:
+        dx0_hi, dg0, db0, dW0, dc0 = bnlin_backward_zero_first(st0, g_fo)          # no gradient for the zero half
+        gp0 = (dg0, db0, dW0, dc0)
+    elif g_fo is not None:
+        (dx0_hi, g_f), dg0, db0, dW0, dc0 = bnlin_backward(st0, g_fo, through_elu=(None,))   # g_f = dx0[:, :C]·elu'(e_f)
+        gp0 = (dg0, db0, dW0, dc0)
+    if need_gv:
+        if dx0_hi is not None:
+            g_v = torch.empty((cat1.shape[0], C), dtype=torch.float32, device=dev)
+            _launch(opDi.t(), dx0_hi, g_v, 4, "bwd", elubwd=(cat1[:, :C], h1))   # (Di^T·dx0_hi)·elu'(e_v) + h1
+        else:
+            g_v = h1
+    if f_zero or not need_gf:
+        g_f = None
+    return (g_v, g_f) + gp0 + gp1
+
+
+class _DiracBlock(torch.autograd.Function):
+    """DirResNet2 as one autograd node (_dirac_fwd / _dirac_bwd), through a launch plan when the block is plannable."""
 
     @staticmethod
     def forward(ctx, v, f, opDi, opDiA, pre_v, pre_f, need_f, avg_next, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1,
                 rm1, rv1, tr1, mo1, ep1):
         v = _rows2d(v)
-        rv, C = v.shape
-        rf = opDi.shape[0] // 4
-        cat1 = _activated(v, pre_v)
-        nxt_f = _new_cat(rf, C, v.device)                        # the next Dirac block's cat0; first half = elu(f_out)
-        pf = _new_part(rf, C, v.device, narrow=True)
+        if f is not None:
+            f = _rows2d(f)
         ctx.f_zero = f is None
-        if f is None:
-            # all-zero face features (the first Dirac block of a model): cat0 = [0 | Di·elu(v)] runs at half width
-            cat0 = torch.empty((rf, C), dtype=torch.float32, device=v.device)      # only the propagated half exists
-            _attach_hi(cat0, _launch(opDi, cat1[:, :C], cat0, 4, "fwd", stats=tr0))
-            f_out, st0 = bnlin_forward_zero_first(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, nxt_f[:, :C], need_f, pf)
-        else:
-            cat0 = pre_f if pre_f is not None else _activated(_rows2d(f), None)    # (f's values are not touched when handed off)
-            _attach_hi(cat0, _launch(opDi, cat1[:, :C], cat0[:, C:], 4, "fwd", stats=tr0))
-            f_out, st0 = bnlin_forward(cat0, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, nxt_f[:, :C], want_y=need_f,
-                                       elu_stats=pf)
-        _attach_part(nxt_f, pf)
+        ctx.ops = (opDi, opDiA)
+        tensors = (v, f, pre_v, pre_f, g0, b0, W0, c0, rm0, rv0, g1, b1, W1, c1, rm1, rv1)
+        consts = (need_f, avg_next, tr0, mo0, ep0, tr1, mo1, ep1)
+        outs = None
+        ctx._sn_plan = None
+        if plans.usable(v):
+            outs = _plan_forward(ctx, _SITES["dirac_fwd"], _dirac_fwd, tensors, ((opDi, 4), (opDiA, 4)), consts, v.shape[1], 4, (2, 3, 8, 14))
+            _drop_counters(rm0, rm1)
+        ctx._sn_planned = outs is not None
+        if outs is None:
+            outs, saved = _dirac_fwd(*tensors, opDi, opDiA, *consts)
+            stash(ctx, *saved)
+        v_new, f_out, nxt_v, nxt_f = outs
         if f_out is None:
             # The caller only chains f into the next Dirac block, which consumes the ACTIVATED hand-off: the pre-activation
             # face features are not written (321 MB per block at the ARAP batch).  What is returned in their place is a
             # zero-stride NaN view, so that any other use of it is loud instead of silently wrong.
-            f_out = _nan_placeholder(v.device).expand(rf, C)
-        _attach_hi(cat1, _launch(opDiA, nxt_f[:, :C], cat1[:, C:], 4, "fwd", stats=tr1))
-        nxt_v = _new_cat(rv, C, v.device)
-        pv = _new_part(rv, C, v.device, narrow=True)
-        tv = _new_tiles(rv, C, v.device, pv, avg_next)
-        v_new, st1 = bnlin_forward(cat1, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, v, nxt_v[:, :C], elu_stats=pv, tile_sums=tv)
-        _attach_part(nxt_v, pv, tv)
-        ctx.ops = (opDi, opDiA)
-        stash(ctx, (cat0, cat1, nxt_f), st0, st1)
+            f_out = _nan_placeholder(v.device).expand(nxt_f.shape[0], v.shape[1])
         ctx.mark_non_differentiable(nxt_v, nxt_f)
         ctx.set_materialize_grads(False)
         return v_new, f_out, nxt_v, nxt_f
 
     @staticmethod
     def backward(ctx, g_vnew, g_fout, _gv, _gf):
-        opDi, opDiA = ctx.ops
-        (cat0, cat1, nxt_f), st0, st1 = unstash(ctx)
-        C = cat1.shape[1] // 2
-        dev = cat1.device
-        none9 = (None,) * 9
         if g_vnew is None and g_fout is None:
             return (None,) * 26
-        # Every ELU backward of the block is fused: the dgrad GEMM's epilogue sends the first half of a stage's input
-        # gradient through the activation (h = dx[:, :C]·elu'(e) + the gradient of the other branch), and the transposed
-        # product's store does the same for the propagated half:  (opᵀ·dx[:, C:])·elu'(e) + h.
-        # ---- second stage (vertex rows) ----
-        g_fo = g_fout.contiguous() if g_fout is not None else None
-        gp1 = none9
-        h1 = None                                                                   # dx1[:, :C]·elu'(e_v) + g_vnew
-        if g_vnew is not None:
-            g_vnew = g_vnew.contiguous()
-            (dx1_hi, h1), dg1, db1, dW1, dc1 = bnlin_backward(st1, g_vnew, through_elu=(g_vnew,))
-            gp1 = (dg1, db1, dW1, dc1, None, None, None, None, None)
-            g_sum = torch.empty((nxt_f.shape[0], C), dtype=torch.float32, device=dev)
-            # (DiA^T·dx1_hi)·elu'(e_f)  +  the gradient f_out receives from the next block
-            _launch(opDiA.t(), dx1_hi, g_sum, 4, "bwd", elubwd=(nxt_f[:, :C], g_fo))
-            g_fo = g_sum
-        # ---- first stage (face rows) ----
-        gp0 = none9
-        g_v = g_f = None
-        dx0_hi = None
-        if g_fo is not None and ctx.f_zero:
-            dx0_hi, dg0, db0, dW0, dc0 = bnlin_backward_zero_first(st0, g_fo)          # no gradient for the zero half
-            gp0 = (dg0, db0, dW0, dc0, None, None, None, None, None)
-        elif g_fo is not None:
-            (dx0_hi, g_f), dg0, db0, dW0, dc0 = bnlin_backward(st0, g_fo, through_elu=(None,))   # g_f = dx0[:, :C]·elu'(e_f)
-            gp0 = (dg0, db0, dW0, dc0, None, None, None, None, None)
-        if ctx.needs_input_grad[0]:
-            if dx0_hi is not None:
-                g_v = torch.empty((cat1.shape[0], C), dtype=torch.float32, device=dev)
-                _launch(opDi.t(), dx0_hi, g_v, 4, "bwd", elubwd=(cat1[:, :C], h1))   # (Di^T·dx0_hi)·elu'(e_v) + h1
-            else:
-                g_v = h1
-        if ctx.f_zero or not ctx.needs_input_grad[1]:
-            g_f = None
-        return (g_v, g_f, None, None, None, None, None, None) + gp0 + gp1
+        opDi, opDiA = ctx.ops
+        g_vnew = g_vnew.contiguous() if g_vnew is not None else None
+        g_fout = g_fout.contiguous() if g_fout is not None else None
+        consts = (ctx.f_zero, bool(ctx.needs_input_grad[0]), bool(ctx.needs_input_grad[1]))
+        if ctx._sn_planned:
+            r = _plan_backward(ctx, _SITES["dirac_bwd"], _dirac_bwd, (g_vnew, g_fout), consts)
+        else:
+            r = _dirac_bwd(unstash(ctx), opDi, opDiA, g_vnew, g_fout, *consts)
+        none5 = (None,) * 5
+        return (r[0], r[1], None, None, None, None, None, None) + r[2:6] + none5 + r[6:10] + none5
+
+
+def _drop_counters(*running_means) -> None:
+    """bn_prepare hangs the batch counter on the running-mean buffer for the fold launch of THIS call; a planned call reaches it
+    as a plan operand — the one-shot attribute must not survive the call either way."""
+    for rm in running_means:
+        d = getattr(rm, "__dict__", None)
+        if d is not None:
+            d.pop("_sn_nbt", None)
 
 
 def dirac_block(mod, Di, DiA, v, f, need_f=True, num_faces=None, avg_next=None):
@@ -252,161 +410,264 @@ def zero_faces_ok(mod, C: int) -> bool:
 
 
 # ------------------------------------------------------------------------------------------------------------
-class _PropagateBlock(torch.autograd.Function):
+def _propagate_fwd(x, pre, mask_rows, inv_count, g0, b0, W0, c0, rm0, rv0, g1, b1, W1, c1, rm1, rv1, op, nseg, avg_next, tr0, mo0,
+                   ep0, tr1, mo1, ep1):
     """LapResNet2 (utils_pt.py:159-180) and AvgResNet2 (utils_pt.py:230-243): two stages  [e, P(e)] -> Lin(BN(.))  with the
     same propagation P — the sparse product with L, or the per-mesh masked mean broadcast back (global_average)."""
+    rows, C = x.shape
+    per = rows // nseg if nseg else 0
+
+    def propagate(cat, training):
+        if op is not None:
+            # (the Laplacian product leaves the BatchNorm statistics of the half it writes, like the Dirac products)
+            _attach_hi(cat, _launch(op, cat[:, :C], cat[:, C:], 1, "fwd", stats=training))
+        else:
+            mean = kernels.segment_colsum(cat[:, :C], mask_rows, per, nseg) * inv_count
+            kernels.bcast_rows(mean, cat[:, C:], per)
+
+    cat_a = _activated(x, pre)
+    propagate(cat_a, tr0)
+    cat_b = _new_cat(rows, C, x.device)
+    pb = _new_part(rows, C, x.device)
+    _, st0 = bnlin_forward(cat_a, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, cat_b[:, :C],
+                           want_y=False, elu_stats=pb)       # only elu(h) is consumed
+    _attach_part(cat_b, pb)
+    propagate(cat_b, tr1)
+    nxt = _new_cat(rows, C, x.device)
+    pn = _new_part(rows, C, x.device)
+    tn = _new_tiles(rows, C, x.device, pn, avg_next)
+    out, st1 = bnlin_forward(cat_b, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x, nxt[:, :C], elu_stats=pn, tile_sums=tn)
+    _attach_part(nxt, pn, tn)
+    return (out, nxt), ((cat_a, cat_b), st0, st1, (mask_rows, inv_count))
+
+
+def _propagate_bwd(saved, op, g_out, nseg, need_gx):
+    (cat_a, cat_b), st0, st1, (mask_rows, inv_count) = saved
+    C = cat_a.shape[1] // 2
+    per = cat_a.shape[0] // nseg if nseg else 0
+
+    def stage_backward(st, g_in, cat, gadd):
+        """gradient w.r.t. the stage input: ((dcat[:, :C] + P^T dcat[:, C:]) * elu'(e)) + gadd, and the parameter
+        gradients of the stage's BatchNorm+Linear."""
+        if op is not None:                       # sparse propagation: both ELU backward passes fused (see _dirac_bwd)
+            (d_hi, h), dg, db, dW, dc = bnlin_backward(st, g_in, through_elu=(gadd,))
+            g = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
+            _launch(op.t(), d_hi, g, 1, "bwd", elubwd=(cat[:, :C], h))
+        else:                                    # global average: per-mesh column sums of dcat[:, C:], broadcast back
+            dcat, dg, db, dW, dc = bnlin_backward(st, g_in)
+            g = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
+            gm = (kernels.segment_colsum(dcat[:, C:], None, per, nseg) * inv_count).contiguous()
+            kernels.elu_bwd_bcast(dcat[:, :C], cat[:, :C], gm, mask_rows, g, per, gadd)
+        return g, dg, db, dW, dc
+
+    g_h, dg1, db1, dW1, dc1 = stage_backward(st1, g_out, cat_b, None)
+    g_x, dg0, db0, dW0, dc0 = stage_backward(st0, g_h, cat_a, g_out)              # + residual-path gradient
+    return (g_x if need_gx else None, dg0, db0, dW0, dc0, dg1, db1, dW1, dc1)
+
+
+class _PropagateBlock(torch.autograd.Function):
+    """LapResNet2 / the full-width AvgResNet2 as one autograd node (_propagate_fwd / _propagate_bwd)."""
 
     @staticmethod
     def forward(ctx, x, op, mask_rows, inv_count, nseg, pre, avg_next, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1,
                 rm1, rv1, tr1, mo1, ep1):
         x = _rows2d(x)
-        rows, C = x.shape
-        per = rows // nseg if nseg else 0
-
-        def propagate(cat, training):
-            if op is not None:
-                # (the Laplacian product leaves the BatchNorm statistics of the half it writes, like the Dirac products)
-                _attach_hi(cat, _launch(op, cat[:, :C], cat[:, C:], 1, "fwd", stats=training))
-            else:
-                mean = kernels.segment_colsum(cat[:, :C], mask_rows, per, nseg) * inv_count
-                kernels.bcast_rows(mean, cat[:, C:], per)
-
-        cat_a = _activated(x, pre)
-        propagate(cat_a, tr0)
-        cat_b = _new_cat(rows, C, x.device)
-        pb = _new_part(rows, C, x.device)
-        _, st0 = bnlin_forward(cat_a, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, cat_b[:, :C],
-                               want_y=False, elu_stats=pb)       # only elu(h) is consumed
-        _attach_part(cat_b, pb)
-        propagate(cat_b, tr1)
-        nxt = _new_cat(rows, C, x.device)
-        pn = _new_part(rows, C, x.device)
-        tn = _new_tiles(rows, C, x.device, pn, avg_next)
-        out, st1 = bnlin_forward(cat_b, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x, nxt[:, :C], elu_stats=pn, tile_sums=tn)
-        _attach_part(nxt, pn, tn)
-        ctx.op, ctx.seg = op, (mask_rows, inv_count, nseg, per)
-        stash(ctx, (cat_a, cat_b), st0, st1)
+        tensors = (x, pre, mask_rows, inv_count, g0, b0, W0, c0, rm0, rv0, g1, b1, W1, c1, rm1, rv1)
+        consts = (nseg, avg_next, tr0, mo0, ep0, tr1, mo1, ep1)
+        ctx.op, ctx.nseg = op, nseg
+        ctx._sn_plan = None
+        outs = None
+        if op is not None and plans.usable(x):          # (the full-width average stage multiplies by 1/count with a torch op)
+            outs = _plan_forward(ctx, _SITES["propagate_fwd"], _propagate_fwd, tensors, ((op, 1),), consts, x.shape[1], 4, (1, 8, 14))
+            _drop_counters(rm0, rm1)
+        ctx._sn_planned = outs is not None
+        if outs is None:
+            outs, saved = _propagate_fwd(*tensors, op, *consts)
+            stash(ctx, *saved)
+        out, nxt = outs
         ctx.mark_non_differentiable(nxt)
         ctx.set_materialize_grads(False)          # else the engine fills a (rows, 2C) zero gradient for `nxt` every backward
         return out, nxt
 
     @staticmethod
     def backward(ctx, g_out, _gn):
-        op = ctx.op
-        mask_rows, inv_count, nseg, per = ctx.seg
-        (cat_a, cat_b), st0, st1 = unstash(ctx)
-        C = cat_a.shape[1] // 2
         if g_out is None:
             return (None,) * 25
         g_out = g_out.contiguous()
-
-        def stage_backward(st, g_in, cat, gadd):
-            """gradient w.r.t. the stage input: ((dcat[:, :C] + P^T dcat[:, C:]) * elu'(e)) + gadd, and the parameter
-            gradients of the stage's BatchNorm+Linear."""
-            if op is not None:                       # sparse propagation: both ELU backward passes fused (see _DiracBlock)
-                (d_hi, h), dg, db, dW, dc = bnlin_backward(st, g_in, through_elu=(gadd,))
-                g = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
-                _launch(op.t(), d_hi, g, 1, "bwd", elubwd=(cat[:, :C], h))
-            else:                                    # global average: per-mesh column sums of dcat[:, C:], broadcast back
-                dcat, dg, db, dW, dc = bnlin_backward(st, g_in)
-                g = torch.empty((cat.shape[0], C), dtype=torch.float32, device=cat.device)
-                gm = (kernels.segment_colsum(dcat[:, C:], None, per, nseg) * inv_count).contiguous()
-                kernels.elu_bwd_bcast(dcat[:, :C], cat[:, :C], gm, mask_rows, g, per, gadd)
-            return g, dg, db, dW, dc
-
-        g_h, dg1, db1, dW1, dc1 = stage_backward(st1, g_out, cat_b, None)
-        g_x, dg0, db0, dW0, dc0 = stage_backward(st0, g_h, cat_a, g_out)              # + residual-path gradient
-        if not ctx.needs_input_grad[0]:
-            g_x = None
-        return (g_x, None, None, None, None, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None,
-                None, None, None, None)
+        consts = (ctx.nseg, bool(ctx.needs_input_grad[0]))
+        if ctx._sn_planned:
+            r = _plan_backward(ctx, _SITES["propagate_bwd"], _propagate_bwd, (g_out,), consts)
+        else:
+            r = _propagate_bwd(unstash(ctx), ctx.op, g_out, *consts)
+        none5 = (None,) * 5
+        return (r[0], None, None, None, None, None, None) + r[1:5] + none5 + r[5:9] + none5
 
 
-class _AvgBlock(torch.autograd.Function):
+def _avg_fwd(x, pre, mask_rows, inv_count, g0, b0, W0, c0, rm0, rv0, g1, b1, W1, c1, rm1, rv1, nseg, tr0, mo0, ep0, tr1, mo1, ep1):
     """AvgResNet2 (utils_pt.py:230-243) at half width (functional.avg_stage_forward): the broadcast mean is never written,
     both Linear layers run over C instead of 2C columns, and the whole backward of a stage — BatchNorm tail, mean-path
     gradient, ELU derivative, residual-path gradient — leaves the dgrad GEMM's epilogue."""
+    rows, C = x.shape
+    per = rows // nseg
+    cat = _activated(x, pre)
+    e_a = cat[:, :C]
+    e_b = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    # per-mesh means and BatchNorm sums of a stage's operand: from what the GEMM that wrote it left (per-tile column sums +
+    # statistics partials) when there is such a producer — else one statistics pass over the operand
+    pb = _new_part(rows, C, x.device)
+    tb = _new_tiles(rows, C, x.device, pb, True)
+    _, st0 = avg_stage_forward(e_a, mask_rows, inv_count, nseg, per, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, e_b,
+                               want_y=False, elu_stats=pb if tb is not None else None, tile_sums=tb,
+                               e_tiles=_tiles_of(cat))             # only elu(h) is needed downstream
+    nxt = _new_cat(rows, C, x.device)
+    pn = _new_part(rows, C, x.device)
+    out, st1 = avg_stage_forward(e_b, mask_rows, inv_count, nseg, per, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x,
+                                 nxt[:, :C], elu_stats=pn, e_tiles=(tb, pb) if tb is not None else None)
+    _attach_part(nxt, pn)
+    return (out, nxt), (st0, st1, (mask_rows, inv_count))
+
+
+def _avg_bwd(saved, g_out, nseg, need_gx):
+    st0, st1, (mask_rows, inv_count) = saved
+    per = st0[0].shape[0] // nseg
+    g_h, dg1, db1, dW1, dc1 = avg_stage_backward(st1, mask_rows, inv_count, nseg, per, g_out, None)
+    g_x, dg0, db0, dW0, dc0 = avg_stage_backward(st0, mask_rows, inv_count, nseg, per, g_h, g_out)   # + residual path
+    return (g_x if need_gx else None, dg0, db0, dW0, dc0, dg1, db1, dW1, dc1)
+
+
+class _AvgBlock(torch.autograd.Function):
+    """AvgResNet2 at half width as one autograd node (_avg_fwd / _avg_bwd)."""
 
     @staticmethod
     def forward(ctx, x, mask_rows, inv_count, nseg, pre, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1, rm1, rv1,
                 tr1, mo1, ep1):
         x = _rows2d(x)
-        rows, C = x.shape
-        per = rows // nseg
-        cat = _activated(x, pre)
-        e_a = cat[:, :C]
-        e_b = torch.empty((rows, C), dtype=torch.float32, device=x.device)
-        # per-mesh means and BatchNorm sums of a stage's operand: from what the GEMM that wrote it left (per-tile column sums +
-        # statistics partials) when there is such a producer — else one statistics pass over the operand
-        pb = _new_part(rows, C, x.device)
-        tb = _new_tiles(rows, C, x.device, pb, True)
-        _, st0 = avg_stage_forward(e_a, mask_rows, inv_count, nseg, per, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, None, e_b,
-                                   want_y=False, elu_stats=pb if tb is not None else None, tile_sums=tb,
-                                   e_tiles=_tiles_of(cat))             # only elu(h) is needed downstream
-        nxt = _new_cat(rows, C, x.device)
-        pn = _new_part(rows, C, x.device)
-        out, st1 = avg_stage_forward(e_b, mask_rows, inv_count, nseg, per, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1, x,
-                                     nxt[:, :C], elu_stats=pn, e_tiles=(tb, pb) if tb is not None else None)
-        _attach_part(nxt, pn)
-        stash(ctx, st0, st1, (mask_rows, inv_count))
-        ctx.seg = (nseg, per)
+        tensors = (x, pre, mask_rows, inv_count, g0, b0, W0, c0, rm0, rv0, g1, b1, W1, c1, rm1, rv1)
+        consts = (nseg, tr0, mo0, ep0, tr1, mo1, ep1)
+        ctx.nseg = nseg
+        ctx._sn_plan = None
+        outs = None
+        if plans.usable(x):
+            outs = _plan_forward(ctx, _SITES["avg_fwd"], _avg_fwd, tensors, (), consts, x.shape[1], 4, (1, 8, 14))
+            _drop_counters(rm0, rm1)
+        ctx._sn_planned = outs is not None
+        if outs is None:
+            outs, saved = _avg_fwd(*tensors, *consts)
+            stash(ctx, *saved)
+        out, nxt = outs
         ctx.mark_non_differentiable(nxt)
         ctx.set_materialize_grads(False)          # else the engine fills a (rows, 2C) zero gradient for `nxt` every backward
         return out, nxt
 
     @staticmethod
     def backward(ctx, g_out, _gn):
-        st0, st1, (mask_rows, inv_count) = unstash(ctx)
-        nseg, per = ctx.seg
         if g_out is None:
             return (None,) * 23
         g_out = g_out.contiguous()
-        g_h, dg1, db1, dW1, dc1 = avg_stage_backward(st1, mask_rows, inv_count, nseg, per, g_out, None)
-        g_x, dg0, db0, dW0, dc0 = avg_stage_backward(st0, mask_rows, inv_count, nseg, per, g_h, g_out)   # + residual path
-        if not ctx.needs_input_grad[0]:
-            g_x = None
-        return (g_x, None, None, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None,
-                None, None, None, None)
+        consts = (ctx.nseg, bool(ctx.needs_input_grad[0]))
+        if ctx._sn_planned:
+            r = _plan_backward(ctx, _SITES["avg_bwd"], _avg_bwd, (g_out,), consts)
+        else:
+            r = _avg_bwd(unstash(ctx), g_out, *consts)
+        none5 = (None,) * 5
+        return (r[0], None, None, None, None) + r[1:5] + none5 + r[5:9] + none5
+
+
+def _seg_tensors(seg):
+    """The device tables of a PackedSegments (operands of a plan) and what identifies its layout."""
+    return (seg.tiles, seg.seg_tile_ptr, seg.inv_count, seg.off_dev, seg.slab_off, seg.seg_slab_ptr, seg.len_f64), \
+        (seg.nseg, seg.rows, seg.nslab, seg.min_len, int(seg.tiles.shape[0]))
+
+
+def _avg_ragged_fwd(x, pre, g0, b0, W0, c0, rm0, rv0, g1, b1, W1, c1, rm1, rv1, t0, t1, t2, t3, t4, t5, t6, seg, seg_key, mo0, ep0,
+                    mo1, ep1):
+    """_avg_fwd on a PACKED batch: `seg` (operators.PackedSegments) gives the meshes' row ranges; no mask, every row is real
+    (BatchNorm over real rows only — the reference's padded batch includes the padding rows, utils_pt.py:97-99).
+    (t0..t6: seg's device tables, listed so that a launch plan knows them as operands; seg_key: their layout.)"""
+    rows, C = x.shape
+    cat = _activated(x, pre)
+    e_a = cat[:, :C]
+    e_b = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    pb = _new_part(rows, C, x.device)
+    tb = _new_tiles(rows, C, x.device, pb, True)      # (as _avg_fwd: means and statistics from what the producing GEMM left)
+    _, st0 = avg_stage_forward_ragged(e_a, seg, g0, b0, W0, c0, rm0, rv0, mo0, ep0, None, e_b, want_y=False, elu_stats=pb,
+                                      part=getattr(cat, "_sn_part", None), tile_sums=tb, e_tiles=_tiles_of(cat))
+    nxt = _new_cat(rows, C, x.device)
+    pn = _new_part(rows, C, x.device)
+    out, st1 = avg_stage_forward_ragged(e_b, seg, g1, b1, W1, c1, rm1, rv1, mo1, ep1, x, nxt[:, :C], elu_stats=pn, part=pb,
+                                        e_tiles=(tb, pb) if tb is not None else None)
+    _attach_part(nxt, pn)
+    return (out, nxt), (st0, st1)
+
+
+def _avg_ragged_bwd(saved, g_out, t0, t1, t2, t3, t4, t5, t6, seg, seg_key, need_gx):
+    st0, st1 = saved
+    g_h, dg1, db1, dW1, dc1 = avg_stage_backward_ragged(st1, seg, g_out, None)
+    g_x, dg0, db0, dW0, dc0 = avg_stage_backward_ragged(st0, seg, g_h, g_out)      # + residual path
+    return (g_x if need_gx else None, dg0, db0, dW0, dc0, dg1, db1, dW1, dc1)
 
 
 class _AvgBlockRagged(torch.autograd.Function):
-    """_AvgBlock on a PACKED batch: `seg` (operators.PackedSegments) gives the meshes' row ranges; no mask, every row is real
-    (BatchNorm over real rows only — the reference's padded batch includes the padding rows, utils_pt.py:97-99)."""
+    """_AvgBlock on a PACKED batch (_avg_ragged_fwd / _avg_ragged_bwd)."""
 
     @staticmethod
     def forward(ctx, x, seg, pre, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1, rm1, rv1, tr1, mo1, ep1):
         x = _rows2d(x)
-        rows, C = x.shape
-        cat = _activated(x, pre)
-        e_a = cat[:, :C]
-        e_b = torch.empty((rows, C), dtype=torch.float32, device=x.device)
-        pb = _new_part(rows, C, x.device)
-        tb = _new_tiles(rows, C, x.device, pb, True)      # (as _AvgBlock: means and statistics from what the producing GEMM left)
-        _, st0 = avg_stage_forward_ragged(e_a, seg, g0, b0, W0, c0, rm0, rv0, mo0, ep0, None, e_b, want_y=False, elu_stats=pb,
-                                          part=getattr(cat, "_sn_part", None), tile_sums=tb, e_tiles=_tiles_of(cat))
-        nxt = _new_cat(rows, C, x.device)
-        pn = _new_part(rows, C, x.device)
-        out, st1 = avg_stage_forward_ragged(e_b, seg, g1, b1, W1, c1, rm1, rv1, mo1, ep1, x, nxt[:, :C], elu_stats=pn, part=pb,
-                                            e_tiles=(tb, pb) if tb is not None else None)
-        _attach_part(nxt, pn)
-        stash(ctx, st0, st1)
+        seg_t, seg_key = _seg_tensors(seg)
+        tensors = (x, pre, g0, b0, W0, c0, rm0, rv0, g1, b1, W1, c1, rm1, rv1, *seg_t)
+        consts = (_Opaque(seg), seg_key, mo0, ep0, mo1, ep1)
         ctx.seg = seg
+        ctx._sn_plan = None
+        outs = None
+        if plans.usable(x):
+            outs = _plan_forward(ctx, _SITES["avg_ragged_fwd"], _avg_ragged_fwd_u, tensors, (), consts, x.shape[1], 2, (1, 6, 12))
+            _drop_counters(rm0, rm1)
+        ctx._sn_planned = outs is not None
+        if outs is None:
+            outs, saved = _avg_ragged_fwd(*tensors, seg, seg_key, mo0, ep0, mo1, ep1)
+            stash(ctx, *saved)
+        out, nxt = outs
         ctx.mark_non_differentiable(nxt)
         ctx.set_materialize_grads(False)
         return out, nxt
 
     @staticmethod
     def backward(ctx, g_out, _gn):
-        st0, st1 = unstash(ctx)
         if g_out is None:
             return (None,) * 21
         g_out = g_out.contiguous()
-        g_h, dg1, db1, dW1, dc1 = avg_stage_backward_ragged(st1, ctx.seg, g_out, None)
-        g_x, dg0, db0, dW0, dc0 = avg_stage_backward_ragged(st0, ctx.seg, g_h, g_out)      # + residual path
-        if not ctx.needs_input_grad[0]:
-            g_x = None
-        return (g_x, None, None, dg0, db0, dW0, dc0, None, None, None, None, None, dg1, db1, dW1, dc1, None, None, None, None,
-                None)
+        seg = ctx.seg
+        seg_t, seg_key = _seg_tensors(seg)
+        need = bool(ctx.needs_input_grad[0])
+        if ctx._sn_planned:
+            r = _plan_backward(ctx, _SITES["avg_ragged_bwd"], _avg_ragged_bwd_u, (g_out, *seg_t), (_Opaque(seg), seg_key, need))
+        else:
+            r = _avg_ragged_bwd(unstash(ctx), g_out, *seg_t, seg, seg_key, need)
+        none5 = (None,) * 5
+        return (r[0], None, None) + r[1:5] + none5 + r[5:9] + none5
+
+
+class _Opaque:
+    """A host object a block needs (a PackedSegments) among a plan's constants: it takes no part in the plan's key — what
+    identifies it is listed next to it (`seg_key`) — and is handed to the block's function as it is."""
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = v
+
+    def __hash__(self):
+        return 0
+
+    def __eq__(self, other):
+        return isinstance(other, _Opaque)
+
+
+def _avg_ragged_fwd_u(*a):
+    return _avg_ragged_fwd(*a[:21], a[21].v, *a[22:])
+
+
+def _avg_ragged_bwd_u(saved, g_out, *a):
+    return _avg_ragged_bwd(saved, g_out, *a[:7], a[7].v, *a[8:])
 
 
 def avg_block_ragged_ok(mod, seg, inputs) -> bool:
@@ -426,6 +687,21 @@ def avg_block_ragged(mod, seg, inputs):
     return attach_activated(out.view(B, V, C), nxt)
 
 
+def _elu_conv_fwd(v, pre, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0):
+    C = v.shape[1]
+    cat = _activated(v, pre)
+    part = getattr(cat, "_sn_part", None)        # statistics of elu(v) left by the GEMM that wrote it
+    pre_stats = kernels.colstats_from_part(part, v.shape[0]) if (part is not None and tr0 and C == 128) else None
+    y, st = bnlin_forward(cat[:, :C], g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, pre_stats=pre_stats)
+    return (y,), (st,)
+
+
+def _elu_conv_bwd(saved, dy, need_gv):
+    (st,) = saved
+    g_v, dg, db, dW, dc = bnlin_backward_elu_input(st, dy)
+    return (g_v if need_gv else None, dg, db, dW, dc)
+
+
 class _EluConv(torch.autograd.Function):
     """GraphConv1x1("pre")(F.elu(v)) — the models' last layer (src/as_rigid_as_possible/models.py:148-150) — as one node:
     elu(v) is the activated hand-off of the preceding block when there is one (no ELU pass), and the backward runs the
@@ -434,21 +710,28 @@ class _EluConv(torch.autograd.Function):
     @staticmethod
     def forward(ctx, v, pre, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0):
         v = _rows2d(v)
-        C = v.shape[1]
-        cat = _activated(v, pre)
-        part = getattr(cat, "_sn_part", None)        # statistics of elu(v) left by the GEMM that wrote it
-        pre_stats = kernels.colstats_from_part(part, v.shape[0]) if (part is not None and tr0 and C == 128) else None
-        y, st = bnlin_forward(cat[:, :C], g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, pre_stats=pre_stats)
-        stash(ctx, st)
-        return y
+        tensors = (v, pre, g0, b0, W0, c0, rm0, rv0)
+        consts = (tr0, mo0, ep0)
+        ctx._sn_plan = None
+        outs = None
+        if plans.usable(v):
+            outs = _plan_forward(ctx, _SITES["elu_conv_fwd"], _elu_conv_fwd, tensors, (), consts, v.shape[1], 2, (1, 6))
+            _drop_counters(rm0)
+        ctx._sn_planned = outs is not None
+        if outs is None:
+            outs, saved = _elu_conv_fwd(*tensors, *consts)
+            stash(ctx, *saved)
+        return outs[0]
 
     @staticmethod
     def backward(ctx, dy):
-        (st,) = unstash(ctx)
-        g_v, dg, db, dW, dc = bnlin_backward_elu_input(st, dy)
-        if not ctx.needs_input_grad[0]:
-            g_v = None
-        return g_v, None, dg, db, dW, dc, None, None, None, None, None
+        dy = dy.contiguous()
+        need = bool(ctx.needs_input_grad[0])
+        if ctx._sn_planned:
+            r = _plan_backward(ctx, _SITES["elu_conv_bwd"], _elu_conv_bwd, (dy,), (need,))
+        else:
+            r = _elu_conv_bwd(unstash(ctx), dy, need)
+        return (r[0], None) + r[1:5] + (None,) * 5
 
 
 def elu_conv(conv, v):

@@ -142,9 +142,47 @@ def _ctypes_i64_ref():
     return ctypes.addressof(_ctypes_i64_ref.slot)
 
 
+def product_form(op: SparseOperator, group: int, ncols: int):
+    """(kind, arrays, (M, K, count)): the storage form in which `_launch` multiplies `op` with a dense operand of `ncols` columns in
+    groups of `group` — "q3" | "bsr4" | "ring" | "rb4" | "csr" — chosen by the operator's own `format`, else the process defaults
+    (set_dirac_format / set_laplacian_format).  A derived form is built on first use and cached on the operator; the choice
+    itself is cached per (group, width, defaults), so a launch plan (plans.py) can name the operator's arrays without launching."""
+    M, K = op.shape
+    own = getattr(op, "format", None)
+    dfmt = own if own in ("q3", "bsr4", "csr") else _DIRAC_FORMAT
+    lfmt = own if own in ("ring", "rb4", "csr") else _LAPLACIAN_FORMAT
+    ck = (group, ncols, dfmt, lfmt, kernels.RING_MIN_ROWS)
+    cache = op.__dict__.get("_form_cache")
+    if cache is not None and cache[0] == ck:
+        return cache[1]
+    # the block-form kernels and every fused epilogue exist for N in {16, 32, 64, 128} dense columns (the widths the
+    # reference models use: 64 / 128 channels); any other width takes the generic CSR kernel and an unfused epilogue
+    vec = (ncols // group) in (16, 32, 64, 128)
+    form = None
+    if group == 4 and dfmt == "q3" and vec:
+        q = op.q3()
+        if q is not None:
+            form = ("q3", q, (M, K, int(q[1].shape[0])))
+    if form is None:
+        b = op.bsr4() if (dfmt != "csr" and group == 4 and vec) else None
+        if b is not None:
+            form = ("bsr4", b, (M, K, int(b[1].numel())))
+        elif lfmt == "ring" and group == 1 and op.ring_ok(ncols):
+            # banded square operator on a batch that fills the chip: sliding window over X in LDS, straight from the CSR arrays
+            form = ("ring", (op.rowptr, op.colind, op.vals), (M, K, int(op.colind.numel())))
+        elif lfmt in ("ring", "rb4") and kernels.spmm_rb4_supported(ncols // group, group) and op.rb4() is not None:
+            r = op.rb4()                                   # Laplacian-type operator: one gather per listed column of a 4-row group
+            form = ("rb4", r, (M, K, int(r[1].numel())))
+        else:
+            form = ("csr", (op.rowptr, op.colind, op.vals), (M, K, int(op.colind.numel())))
+    if not (op.is_cuda and torch.cuda.is_current_stream_capturing()):     # (ring_ok answers False for an unmeasured band in a capture)
+        op.__dict__["_form_cache"] = (ck, form)
+    return form
+
+
 def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, tag: str = "", elubwd=None, stats: bool = False):
-    """y <- op·x with the best resident format of `op`.  elubwd = (e, g): y <- (op·x) * elu'(e) + g fused into the store
-    (the backward of an ELU-activated propagation stage; g may be None).  stats=True: where the kernel offers it (packed
+    """y <- op·x with the best resident format of `op` (product_form).  elubwd = (e, g): y <- (op·x) * elu'(e) + g fused into the
+    store (the backward of an ELU-activated propagation stage; g may be None).  stats=True: where the kernel offers it (packed
     Dirac operators and Laplacian-type CSR operators, 128 channels) the launch also leaves the column statistics of y and
     their partials are returned (kernels.spmm_q3_stats / spmm_csr_stats), else None."""
     M, K = op.shape
@@ -153,52 +191,40 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
         known = op._nnz_cache if op._nnz_cache is not None else (int(op._csr[1].numel()) if op._csr is not None else None)
         timer.tags.append((tag, op if known is None else known))
     e, g = elubwd if elubwd is not None else (None, None)
-    # the block-form kernels and every fused epilogue exist for N in {16, 32, 64, 128} dense columns (the widths the
-    # reference models use: 64 / 128 channels); any other width takes the generic CSR kernel and an unfused epilogue
     vec = (y.shape[1] // group) in (16, 32, 64, 128)
-    # storage form: the operator's own choice (SparseOperator.format: "q3" | "bsr4" | "ring" | "rb4" | "csr"), else the process
-    # defaults (set_dirac_format / set_laplacian_format)
-    own = getattr(op, "format", None)
-    dfmt = own if own in ("q3", "bsr4", "csr") else _DIRAC_FORMAT
-    lfmt = own if own in ("ring", "rb4", "csr") else _LAPLACIAN_FORMAT
-    if group == 4 and dfmt == "q3" and vec:
-        q = op.q3()
-        if q is not None:
-            if stats and e is None and kernels.spmm_q3_stats_supported(y.shape[1] // group, group):
-                return kernels.spmm_q3_stats(q[0], q[1], M // 4, K // 4, x, y, group)
-            am = kernels.spmm_q3(q[0], q[1], M // 4, K // 4, x, y, group, e, g, want_absmax=e is not None and kernels.absmax_wanted())
-            if am is not None:
-                kernels.note_absmax(y, am)           # a fused ELU-backward product writes a gradient: the dy of the layer below
-            return None
-    b = op.bsr4() if (dfmt != "csr" and group == 4 and vec) else None
-    if b is not None:
+    kind, arr, _ = product_form(op, group, y.shape[1])
+    if kind == "q3":
+        if stats and e is None and kernels.spmm_q3_stats_supported(y.shape[1] // group, group):
+            return kernels.spmm_q3_stats(arr[0], arr[1], M // 4, K // 4, x, y, group)
+        am = kernels.spmm_q3(arr[0], arr[1], M // 4, K // 4, x, y, group, e, g, want_absmax=e is not None and kernels.absmax_wanted())
+        if am is not None:
+            kernels.note_absmax(y, am)           # a fused ELU-backward product writes a gradient: the dy of the layer below
+    elif kind == "bsr4":
         if elubwd is None:
-            kernels.spmm_bsr4(b[0], b[1], b[2], M // 4, K // 4, x, y, group)
+            kernels.spmm_bsr4(arr[0], arr[1], arr[2], M // 4, K // 4, x, y, group)
         else:
-            kernels.spmm_bsr4_elubwd(b[0], b[1], b[2], M // 4, K // 4, x, e, g, y, group)
-    elif lfmt == "ring" and group == 1 and op.ring_ok(y.shape[1]):
-        # banded square operator on a batch that fills the chip: sliding window over X in LDS, straight from the CSR arrays
+            kernels.spmm_bsr4_elubwd(arr[0], arr[1], arr[2], M // 4, K // 4, x, e, g, y, group)
+    elif kind == "ring":
         if stats and e is None and y.shape[1] == 128:
-            return kernels.spmm_ring_stats(op.rowptr, op.colind, op.vals, M, K, x, y)
-        am = kernels.spmm_ring(op.rowptr, op.colind, op.vals, M, K, x, y, e, g, want_absmax=e is not None and kernels.absmax_wanted())
+            return kernels.spmm_ring_stats(arr[0], arr[1], arr[2], M, K, x, y)
+        am = kernels.spmm_ring(arr[0], arr[1], arr[2], M, K, x, y, e, g, want_absmax=e is not None and kernels.absmax_wanted())
         if am is not None:
             kernels.note_absmax(y, am)               # (as the packed Dirac product above: y is the dy of the layer below)
-    elif lfmt in ("ring", "rb4") and kernels.spmm_rb4_supported(y.shape[1] // group, group) and op.rb4() is not None:
-        r = op.rb4()                                   # Laplacian-type operator: one gather per listed column of a 4-row group
+    elif kind == "rb4":
         if stats and e is None and y.shape[1] == 128:
-            return kernels.spmm_rb4_stats(r[0], r[1], r[2], M, K, x, y)
-        am = kernels.spmm_rb4(r[0], r[1], r[2], M, K, x, y, e, g, want_absmax=e is not None and kernels.absmax_wanted())
+            return kernels.spmm_rb4_stats(arr[0], arr[1], arr[2], M, K, x, y)
+        am = kernels.spmm_rb4(arr[0], arr[1], arr[2], M, K, x, y, e, g, want_absmax=e is not None and kernels.absmax_wanted())
         if am is not None:
             kernels.note_absmax(y, am)
     elif elubwd is None:
         if stats and kernels.spmm_csr_stats_supported(y.shape[1] // group, group):
-            return kernels.spmm_csr_stats(op.rowptr, op.colind, op.vals, M, K, x, y)
-        kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x, y, group)
+            return kernels.spmm_csr_stats(arr[0], arr[1], arr[2], M, K, x, y)
+        kernels.spmm_csr(arr[0], arr[1], arr[2], M, K, x, y, group)
     elif vec:
-        kernels.spmm_csr_elubwd(op.rowptr, op.colind, op.vals, M, K, x, e, g, y, group)
+        kernels.spmm_csr_elubwd(arr[0], arr[1], arr[2], M, K, x, e, g, y, group)
     else:
         tmp = torch.empty(y.shape, dtype=torch.float32, device=y.device)
-        kernels.spmm_csr(op.rowptr, op.colind, op.vals, M, K, x, tmp, group)
+        kernels.spmm_csr(arr[0], arr[1], arr[2], M, K, x, tmp, group)
         kernels.elu_bwd(tmp, e, y, False, None, g)                      # y = tmp * elu'(e) + g
     return None
 
@@ -626,8 +652,12 @@ def bnlin_backward_zero_first(state, dy):
     G2, sdy = kernels.wgrad(dy, p, mean[C:], want_colsum=True, bounds=b2)
     # zero half: x - mean = -mean there, i.e. G[:, :C] = -colsum(dy) (x) mean[:C] — zero with batch statistics (mean = 0),
     # the running mean in eval mode
-    G1 = torch.zeros_like(G2) if training else -(sdy.to(torch.float32)[:, None] * mean[None, :C])
-    Gc = torch.cat([G1, G2], 1)
+    Gc = torch.empty((J, 2 * C), dtype=torch.float32, device=G2.device)
+    if training:
+        Gc[:, :C].zero_()
+    else:
+        Gc[:, :C].copy_(-(sdy.to(torch.float32)[:, None] * mean[None, :C]))
+    Gc[:, C:].copy_(G2)
     scale = 1.0
     if training:
         Gc, sdy, scale = _sync_grad_stats(Gc, sdy)

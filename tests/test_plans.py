@@ -1,0 +1,120 @@
+"""Launch plans, host side (no GPU): the entry table of csrc/sn_plan.hip is what tools/gen_plan_table.py writes from the ctypes
+signatures; the C plan object checks argument kinds against the entry points' parameter types; the dry run of the reference
+blocks on CPU tensors records launches only (no torch op that computes), resolves every pointer into an arena or an operand,
+and leaves the operands' attributes and the table of gradient bounds as it found them."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_committed_table_is_what_the_generator_writes():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_plan_table
+
+    with open(gen_plan_table.OUT) as fh:
+        assert fh.read() == gen_plan_table.text()
+
+
+def test_entry_signatures_match_the_ctypes_table():
+    from surfacenetworks_amd import _lib
+
+    lib = _lib.load()
+    n = int(lib.sn_plan_entry_count())
+    assert n >= 80
+    for i in range(n):
+        name = lib.sn_plan_entry_name(i).decode()
+        args = _lib.SIGNATURES[name][1]
+        want = "".join("p" if a is C.c_void_p else "d" if a in (C.c_double, C.c_float) else "i" for a in args)
+        assert lib.sn_plan_entry_signature(i).decode() == want, name
+    assert int(lib.sn_plan_lookup(b"sn_timing_drain")) == -1 and int(lib.sn_plan_lookup(b"no_such_entry")) == -1
+
+
+def test_add_call_rejects_wrong_kinds_and_counts():
+    from surfacenetworks_amd import _lib
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.sn_plan_create(C.byref(h)) == 0
+    fn = int(lib.sn_plan_lookup(b"sn_elu_into_f32"))          # (src, lds, dst, ldd, rows, C, stream)
+    n = 7
+    arr = lambda ty, v: (ty * n)(*v)
+    ok_kind = [2, 0, 2, 0, 0, 0, 4]
+    slot = arr(C.c_int32, [2, 0, 0, 0, 0, 0, 0])
+    ival = arr(C.c_int64, [0, 128, 256, 256, 10, 128, 0])
+    dval = arr(C.c_double, [0.0] * n)
+    assert lib.sn_plan_add_call(h, fn, n, arr(C.c_int32, ok_kind), slot, ival, dval) == 0
+    assert lib.sn_plan_length(h) == 1
+    bad = list(ok_kind)
+    bad[1] = 2                                                   # a pointer where the leading dimension belongs
+    assert lib.sn_plan_add_call(h, fn, n, arr(C.c_int32, bad), slot, ival, dval) == -7
+    bad = list(ok_kind)
+    bad[6] = 3                                                   # the stream must be the stream
+    assert lib.sn_plan_add_call(h, fn, n, arr(C.c_int32, bad), slot, ival, dval) == -7
+    assert lib.sn_plan_add_call(h, fn, n - 1, arr(C.c_int32, ok_kind), slot, ival, dval) == -2
+    # running with too few slots / an empty slot is an argument error, not a launch
+    failed = C.c_int32(-1)
+    bases = (C.c_uint64 * 3)(0, 0, 0)
+    assert lib.sn_plan_run(h, bases, 2, None, C.byref(failed)) == -2
+    assert lib.sn_plan_run(h, bases, 3, None, C.byref(failed)) == -1 and failed.value == 0
+    assert lib.sn_plan_destroy(h) == 0
+
+
+def test_dry_run_of_the_blocks_records_launches_only(monkeypatch):
+    from surfacenetworks_amd import blocks, functional as snF, kernels, mesh_ops, plans
+    from surfacenetworks_amd import utils_pt as U
+    from surfacenetworks_amd.operators import SparseOperator
+
+    monkeypatch.setattr(plans, "_ALLOW_CPU", True)
+    monkeypatch.setattr(plans.Plan, "run", lambda self, big, small, ext: None)        # (nothing can launch here)
+    monkeypatch.setenv("SN_STRICT", "1")                                               # a refused plan raises
+    plans.reset()
+    snF.set_dirac_format("csr")                                                        # (the packed forms are built by device kernels)
+    try:
+        rng = np.random.default_rng(0)
+        V, F = mesh_ops.grid_cloth(12, 9, rng)
+        ops = mesh_ops.mesh_operators(V, F)
+        nV, nF, Cc = V.shape[0], F.shape[0], 128
+
+        def op_of(A):
+            o = SparseOperator.from_scipy(A, "cpu")
+            At = A.T.tocsr()
+            At.sort_indices()
+            o._t = SparseOperator.from_scipy(At, "cpu")
+            return o
+
+        Di, DiA, L = op_of(ops["Di"]), op_of(ops["DiA"]), op_of(ops["L"])
+        for o in (L, L._t):
+            o.format = "csr"
+        b1, avg, b2, lap = U.DirResNet2(Cc), U.AvgResNet2(Cc), U.DirResNet2(Cc), U.LapResNet2(Cc)
+        conv = U.GraphConv1x1(Cc, 120, batch_norm="pre")
+        v = torch.randn(1, nV, Cc, requires_grad=True)
+        mask = torch.ones(1, nV, 1)
+        table_before = dict(kernels._absmax_table)
+        for _ in range(2):                                                             # the recording call, then a replay
+            v1, f1 = b1(Di, DiA, v, None, f_out_needed=False, num_faces=nF, avg_next=True)
+            v2 = avg(None, mask, v1)
+            v3, f3 = b2(Di, DiA, v2, f1, f_out_needed=True, num_faces=nF, avg_next=False)
+            v4 = lap(L, mask, v3)
+            y = U.elu_conv1x1(conv, v4)
+            (y.sum() + f3.sum()).backward()
+            kernels.clear_absmax()
+        st = plans.stats()
+        for site in ("dirac_fwd", "dirac_bwd", "avg_fwd", "avg_bwd", "propagate_fwd", "propagate_bwd", "elu_conv_fwd", "elu_conv_bwd"):
+            assert st[site]["refused"] == 0 and st[site]["recorded"] >= 1 and st[site]["replayed"] >= 2, (site, st[site])
+        assert st["dirac_fwd"]["recorded"] == 2                                          # zero-face block and the general one
+        for site in blocks._SITES.values():
+            for plan in site.plans.values():
+                assert plan is not None and plan.launches >= 3
+                assert plan.arena_bytes[0] % 256 == 0 and plan.arena_bytes[1] % 256 == 0
+        assert kernels._absmax_table == {} and table_before == {}
+        for bn in (b1.bn_fc0.bn, b1.bn_fc1.bn, avg.bn_fc0.bn, lap.bn_fc1.bn, conv.bn):
+            assert "_sn_nbt" not in bn.running_mean.__dict__                          # the one-shot counter attribute never survives
+    finally:
+        snF.set_dirac_format("q3")
+        plans.reset()

@@ -1,0 +1,156 @@
+"""Launch plans (surfacenetworks_amd/plans.py, csrc/sn_plan.hip): a block enqueued by one sn_plan_run is the block launched
+kernel by kernel from Python — same kernels, same order, same arguments — so every result must be BIT-identical: losses,
+parameter gradients, updated parameters and BatchNorm running statistics over several training steps of every model family,
+padded and packed batches, two steps per shape (the recording call and a pure replay), changing operators per step."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _fresh_plans():
+    from surfacenetworks_amd import plans
+
+    plans.reset()
+    plans.set_enabled(True)
+    yield
+    plans.set_enabled(True)
+
+
+def _steps(step_fn, model_e, model_p, n_steps, check_no_refusal=True):
+    """step_fn(model, k) -> loss runs one training step; eager on model_e (plans off), planned on model_p."""
+    from surfacenetworks_amd import plans
+
+    for k in range(n_steps):
+        plans.set_enabled(False)
+        torch.manual_seed(100 + k)                  # (dropout in the Mesh-MNIST head draws from the device generator)
+        le = step_fn(model_e, k)
+        plans.set_enabled(True)
+        torch.manual_seed(100 + k)
+        lp = step_fn(model_p, k)
+        assert torch.equal(le.detach(), lp.detach()), f"loss differs at step {k}: {le.item()} vs {lp.item()}"
+        for (name, pe), pp in zip(model_e.named_parameters(), model_p.parameters()):
+            assert (pe.grad is None) == (pp.grad is None), name
+            if pe.grad is not None:
+                assert torch.equal(pe.grad, pp.grad), f"grad of {name} differs at step {k}"
+            assert torch.equal(pe.detach(), pp.detach()), f"{name} differs after step {k}"
+        for (name, be), bp in zip(model_e.named_buffers(), model_p.buffers()):
+            assert torch.equal(be, bp), f"buffer {name} differs after step {k}"
+    st = plans.stats()
+    assert sum(s["replayed"] for s in st.values()) > 0, st
+    if check_no_refusal:
+        assert all(s["refused"] == 0 for s in st.values()), st
+    return st
+
+
+@pytest.mark.parametrize("model_kind", ["dir", "lap"])
+def test_arap_steps_planned_equal_eager(model_kind):
+    from surfacenetworks_amd import arap
+
+    torch.manual_seed(5)
+    ds = arap.ClothSequences([(9, 8)] * 3, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 3, op_frames=3, seed=11, device=DEV,
+                             model=model_kind)
+    model_e = (arap.DirModel() if model_kind == "dir" else arap.Model()).to(DEV).train()
+    model_p = copy.deepcopy(model_e)
+    opts = {id(model_e): arap.make_optimizer(model_e), id(model_p): arap.make_optimizer(model_p)}
+    rngs = {id(model_e): np.random.default_rng(1), id(model_p): np.random.default_rng(1)}
+
+    def step(model, k):
+        batch = ds.sample_batch(3, rngs[id(model)], seq_ids=np.arange(3))
+        return arap.train_step(model, opts[id(model)], batch, global_batch=3)
+
+    st = _steps(step, model_e, model_p, 4)
+    blk = "dirac" if model_kind == "dir" else "propagate"
+    assert st[f"{blk}_fwd"]["replayed"] >= 4 * 8 and st[f"{blk}_bwd"]["replayed"] >= 4 * 8
+    assert st["avg_fwd"]["replayed"] >= 4 * 7 and st["elu_conv_fwd"]["replayed"] >= 4
+    # one plan per distinct signature, recorded once: first Dirac block (zero faces), middle blocks, last block (no tile sums)
+    assert st[f"{blk}_fwd"]["recorded"] <= 3 and st["avg_fwd"]["recorded"] <= 2
+
+
+def test_packed_ragged_batch_planned_equals_eager():
+    from surfacenetworks_amd import arap
+
+    torch.manual_seed(6)
+    grids = [(9, 8), (7, 6), (8, 8)]
+    ds = arap.ClothSequences(grids, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 3, op_frames=3, seed=12, device=DEV, model="dir")
+    model_e = arap.DirModel().to(DEV).train()
+    model_p = copy.deepcopy(model_e)
+    opts = {id(model_e): arap.make_optimizer(model_e), id(model_p): arap.make_optimizer(model_p)}
+    orders = [[0, 1, 2], [2, 0, 1], [0, 1, 2], [1, 2, 0]]
+
+    def step(model, k):
+        batch = ds.sample_batch(3, None, seq_ids=np.array(orders[k]), offsets=np.zeros(3, dtype=np.int64), packed=True)
+        return arap.train_step(model, opts[id(model)], batch, global_batch=3)
+
+    st = _steps(step, model_e, model_p, 4)
+    assert st["avg_ragged_fwd"]["replayed"] >= 4 * 7, st
+
+
+def test_mesh_mnist_dirac_planned_equals_eager():
+    from surfacenetworks_amd import mesh_mnist as mm
+
+    torch.manual_seed(7)
+    ds = mm.MeshDigits(12, seed=2, device=DEV, fixed_vertices=150, model="dir")
+    model_e = mm.DirModel().to(DEV).train()
+    model_p = copy.deepcopy(model_e)
+    opts = {id(model_e): mm.make_optimizer(model_e), id(model_p): mm.make_optimizer(model_p)}
+    rngs = {id(model_e): np.random.default_rng(3), id(model_p): np.random.default_rng(3)}
+
+    def step(model, k):
+        return mm.train_step(model, opts[id(model)], ds.sample_batch(8, rngs[id(model)]))
+
+    _steps(step, model_e, model_p, 3)
+
+
+def test_faust_pair_planned_equals_eager():
+    from surfacenetworks_amd import dense_correspondence as dc
+
+    torch.manual_seed(8)
+    ds = dc.TorusBodies(3, n=13, m=17, pad_to=256, seed=5, device=DEV)
+    model_e = dc.SiameseModel("lap", 15).to(DEV).train()
+    model_p = copy.deepcopy(model_e)
+    opts = {id(model_e): dc.make_optimizer(model_e), id(model_p): dc.make_optimizer(model_p)}
+
+    def step(model, k):
+        return dc.train_step(model, opts[id(model)], ds, k % 3, (k + 1) % 3)
+
+    _steps(step, model_e, model_p, 3)
+
+
+def test_eval_mode_and_inference_fall_back_or_replay_identically():
+    """Evaluation (running statistics, no backward): whatever the planned path does — replay or refuse — the outputs are those of
+    the eager path."""
+    from surfacenetworks_amd import arap, plans
+
+    torch.manual_seed(9)
+    ds = arap.ClothSequences([(9, 8)] * 2, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 3, op_frames=3, seed=13, device=DEV, model="dir")
+    model = arap.DirModel().to(DEV).eval()
+    batch = ds.sample_batch(2, np.random.default_rng(0), seq_ids=np.arange(2))
+    with torch.no_grad():
+        plans.set_enabled(False)
+        want = model(batch.Di, batch.DiA, batch.mask, batch.inputs)
+        plans.set_enabled(True)
+        got1 = model(batch.Di, batch.DiA, batch.mask, batch.inputs)
+        got2 = model(batch.Di, batch.DiA, batch.mask, batch.inputs)
+    assert torch.equal(want, got1) and torch.equal(want, got2)
+
+
+def test_plan_entry_table_is_the_launchers_of_the_header():
+    import ctypes as C
+
+    from surfacenetworks_amd import _lib
+
+    lib = _lib.load()
+    n = int(lib.sn_plan_entry_count())
+    names = [lib.sn_plan_entry_name(i).decode() for i in range(n)]
+    for i, name in enumerate(names):
+        res, args = _lib.SIGNATURES[name]
+        sig = lib.sn_plan_entry_signature(i).decode()
+        want = "".join("p" if a is C.c_void_p else "d" if a in (C.c_double, C.c_float) else "i" for a in args)
+        assert sig == want, (name, sig, want)
+        assert int(lib.sn_plan_lookup(name.encode())) == i
