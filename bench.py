@@ -24,6 +24,9 @@ The full result carries
                HBM3E; frac_by_convention reports the alternative readings; traffic = in-step PMC of the same command.
   cpu_baseline the reference's own CPU torch.sparse path (oracle restatement = "port") timed on this box's host cores
                (all of them, plus a 1-thread figure) on a bounded sample of the same workload (rank 0, N=1 only).
+               config2_swap / config4_swap / config3_swap: configs[1] / [3] / [2] as the reference's own loops run them after the import
+               swap (its batching names per step, eager), on meshes as generated and (`shuffled_ms_per_step`) with vertices and
+               faces in random order.
   secondary    BASELINE.json configs[4] (the config north_star's ">= 60 % of the HBM roofline on the Dirac SpMM at 128
                channels" is quoted on): 128 meshes per GPU with 1 000 .. 20 000 vertices, Di / Di^T / DiA / DiA^T at N = 32,
                as a PACKED (unpadded, ragged) batch and — grid order only — padded to the batch maximum as the reference
@@ -107,7 +110,7 @@ def compact_line(full: dict, detail_path=None) -> dict:
     cfg = full.get("config") or {}
     keep = ("workload", "meshes_per_gpu", "global_batch", "global_pairs", "parallelism", "world_size", "rccl_ranks", "collective_backend",
             "devices_visible", "ranks_share_devices", "replicas_identical_after_the_run", "operator_format", "operators", "launch",
-            "graph_fallback", "grad_bucket_bytes", "host_enqueue_ms_per_step", "launches_per_step", "host_affinity")
+            "graph_fallback", "grad_bucket_bytes", "host_enqueue_ms_per_step", "host_enqueue_in_loop_ms_per_step", "host_affinity")
     out["config"] = {k: (_r(cfg[k]) if not isinstance(cfg[k], str) else cfg[k][:200]) for k in keep if cfg.get(k) is not None}
     roof = full.get("roofline")
     if roof:
@@ -529,14 +532,42 @@ def c3_order_secondary(device, meshes: int = MESHES_PER_GPU, steps: int = 10, wa
     return out
 
 
-def c3_swap_secondary(device, steps: int = 10):
-    """Config 3 behind the reference's OWN names (north_star: the training scripts "run unmodified apart from an import swap"):
-    tools/train_bench.py arap_swap — per step sp_sparse_to_pt_sparse per sample, sparse_diag_cat, .cuda(), the reference's model
-    calling sequence and loss — next to the headline, which uses the product's own sampler (ClothSequences / OperatorPool)."""
+def _swap_bench(name, device, **kw):
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import train_bench
 
-    return train_bench.arap_swap(str(device), steps, MESHES_PER_GPU)
+    from surfacenetworks_amd.resident import resident_cache
+
+    out = getattr(train_bench, name)(str(device), **kw)
+    torch.cuda.empty_cache()
+    c = resident_cache()
+    if c is not None:
+        c.clear()                                   # (the shuffled twin below brings its own matrices)
+    shuffled = getattr(train_bench, name)(str(device), permute=True, **kw)
+    out["shuffled_ms_per_step"] = shuffled["ms_per_step"]
+    if c is not None:
+        c.clear()
+    return out
+
+
+def c3_swap_secondary(device, steps: int = 10):
+    """Config 3 behind the reference's OWN names (north_star: the training scripts "run unmodified apart from an import swap"):
+    tools/train_bench.py arap_swap — per step sp_sparse_to_pt_sparse per sample, sparse_diag_cat, .cuda(), the reference's model
+    calling sequence and loss — next to the headline, which uses the product's own sampler (ClothSequences / OperatorPool).
+    `shuffled_ms_per_step`: the same loop on meshes whose vertices and faces arrive in random order, multiplied as stored (the
+    resident cache packs matrices as given: a scanned mesh in file order)."""
+    return _swap_bench("arap_swap", device, steps=steps, B=MESHES_PER_GPU)
+
+
+def c2_swap_secondary(device, steps: int = 30):
+    """Config 2 as the reference's Mesh-MNIST loop runs it after the import swap (tools/train_bench.py mnist_swap), eager."""
+    return _swap_bench("mnist_swap", device, steps=steps)
+
+
+def c4_swap_secondary(device, steps: int = 30):
+    """Config 4 (one pair) as the reference's dense-correspondence loop runs it after the import swap (tools/train_bench.py
+    faust_swap), eager."""
+    return _swap_bench("faust_swap", device, steps=steps)
 
 
 def _timed_steps(step, steps, warm):
@@ -856,7 +887,7 @@ def main():
 
     import torch.distributed as dist
 
-    from surfacenetworks_amd import arap, dp
+    from surfacenetworks_amd import arap, dp, plans
     from surfacenetworks_amd import functional as snF
 
     if not torch.cuda.is_available():
@@ -998,6 +1029,17 @@ def main():
             for _ in range(max(1, args.roofline_steps)):
                 eager_step()
         sync()
+    # host cost of issuing ONE step into an idle queue (after the timed region): inside the timed loop the host runs ahead of a
+    # GPU-bound step until the launch queue is full and then waits for the device — the in-loop figure measures the queue depth,
+    # not the host
+    host_alone = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        one_step()
+        host_alone.append(time.perf_counter() - th)
+    sync()
+    t_host_alone = float(np.median(host_alone))
     dt_t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
@@ -1121,8 +1163,15 @@ def main():
                                      "three-piece bf16 form, 0 the fp32-MFMA kernels; the weight gradient (wgrad_h_k) uses two fp16 pieces of each "
                                      "operand with the row / column bounds the step already holds, the first layer's (K = 6) wgrad_u_k"),
                    "allocator": alloc, "operator_format": args.format, "operators": args.operators,
-                   "host_enqueue_ms_per_step": t_enqueue / args.steps * 1e3, "host_affinity": affinity,
-                   "launch": "eager" if args.no_graph else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager",
+                   "host_enqueue_ms_per_step": t_host_alone * 1e3,
+                   "host_enqueue_definition": "host time to issue one step into an idle launch queue (median of 5, after the timed "
+                                              "region); in_loop: the same inside the timed loop, where a GPU-bound step makes the host "
+                                              "wait for queue space",
+                   "host_enqueue_in_loop_ms_per_step": t_enqueue / args.steps * 1e3, "host_affinity": affinity,
+                   "launch": ("eager: every block direction one launch plan (sn_plan_run), the rest launched from Python"
+                              if plans.enabled() else "eager: every kernel launched from Python (SN_PLANS=0)") if args.no_graph
+                   else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager",
+                   "launch_plans": {k: v["replayed"] for k, v in plans.stats().items() if v["replayed"] or v["refused"]},
                    "graph_fallback": graph_fallback, "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": dom_name + (" (the backward products Di^T, DiA^T, ELU backward fused into the store)" if "_epi" in dom_name
                                                           else " (the Dirac products launched without epilogue)"),
@@ -1200,7 +1249,7 @@ def main():
         if rank == 0 and world == 1:
             # the small-batch configurations, driver-visible (rank 0 of a one-GPU run only: they are replicas, not a sharded job)
             for key, fn in (("config3_order", c3_order_secondary), ("config3_swap", c3_swap_secondary), ("config2", c2_secondary),
-                            ("config4_pair", c4_pair_secondary)):
+                            ("config4_pair", c4_pair_secondary), ("config2_swap", c2_swap_secondary), ("config4_swap", c4_swap_secondary)):
                 torch.cuda.empty_cache()
                 try:
                     sec[key] = fn(device)

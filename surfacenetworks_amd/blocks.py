@@ -118,10 +118,14 @@ def _activated(x2d, pre):
 
 
 def _bn_args(conv):
-    """Flatten a GraphConv1x1("pre") into the tensors/flags bnlin_forward needs (and do BatchNorm's Python bookkeeping)."""
-    training, momentum, eps = bn_prepare(conv.bn)
-    return (conv.bn.weight, conv.bn.bias, conv.fc.weight, conv.fc.bias, conv.bn.running_mean, conv.bn.running_var,
-            training, momentum, eps)
+    """Flatten a GraphConv1x1("pre") into the tensors/flags bnlin_forward needs (and do BatchNorm's Python bookkeeping).
+    Parameters and buffers are read from the modules' own dictionaries: nn.Module.__getattr__ (a Python-level search through
+    three dictionaries per access) costs more than everything else here, twelve times per block."""
+    mods = conv.__dict__["_modules"]
+    bn, fc = mods["bn"], mods["fc"]
+    training, momentum, eps = bn_prepare(bn)
+    bp, bb, fp = bn.__dict__["_parameters"], bn.__dict__["_buffers"], fc.__dict__["_parameters"]
+    return (bp["weight"], bp["bias"], fp["weight"], fp["bias"], bb["running_mean"], bb["running_var"], training, momentum, eps)
 
 
 # ---- launch plans (plans.py): one host call per block direction ---------------------------------------------------------------

@@ -817,12 +817,17 @@ def bn_prepare(bn: torch.nn.BatchNorm1d):
     """Per-call bookkeeping nn.BatchNorm1d does in Python: returns (training, momentum, eps).  The num_batches_tracked
     counter is bumped by the fold kernel of this call (sn_bn_fold_f32) instead of a launch of its own: it rides on the
     running-mean buffer as a one-shot attribute that bnlin_forward / avg_stage_forward pick up."""
-    training = bn.training or not bn.track_running_stats
-    if bn.momentum is None or not bn.affine:
+    d = bn.__dict__
+    track = d["track_running_stats"]
+    training = d["training"] or not track
+    if d["momentum"] is None or not d["affine"]:
         raise NotImplementedError("the fused BatchNorm+Linear supports the default affine BatchNorm1d with a fixed momentum")
-    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None and bn.running_mean is not None:
-        bn.running_mean._sn_nbt = bn.num_batches_tracked
-    return training, bn.momentum, bn.eps
+    if d["training"] and track:
+        buf = d["_buffers"]
+        nbt, rm = buf.get("num_batches_tracked"), buf.get("running_mean")
+        if nbt is not None and rm is not None:
+            rm._sn_nbt = nbt
+    return training, d["momentum"], d["eps"]
 
 
 def bn_linear(x2d: torch.Tensor, bn: torch.nn.BatchNorm1d, fc: torch.nn.Linear, residual=None) -> torch.Tensor:

@@ -206,36 +206,80 @@ class LazySparse(torch.Tensor):
 
 
 # ---- resident copies of the source matrices ----------------------------------------------------------------------------------
+def _digest(A) -> int:
+    """Checksum of EVERY byte of a scipy matrix's arrays (xxh3 when the module is there, else zlib.adler32): ~0.3 ms for a
+    360 k-entry Dirac operator."""
+    arrays = [getattr(A, n, None) for n in ("data", "indices", "indptr", "row", "col")]
+    try:
+        import xxhash
+
+        h = xxhash.xxh3_64()
+        for a in arrays:
+            if isinstance(a, np.ndarray):
+                h.update(np.ascontiguousarray(a).view(np.uint8).data)
+        return h.intdigest()
+    except ImportError:
+        import zlib
+
+        v = 1
+        for a in arrays:
+            if isinstance(a, np.ndarray):
+                v = zlib.adler32(np.ascontiguousarray(a).view(np.uint8).data, v)
+        return v
+
+
 class ResidentCache:
     """Every source matrix the batching functions have been shown, packed in HBM once (module docstring).
 
     Entries are keyed on the scipy OBJECT (`id`, guarded by a weak reference and the addresses / sizes of its arrays): the
     reference drivers keep their datasets as lists of scipy matrices and pass the same objects every step.  A matrix whose
-    arrays are replaced is converted again; one whose values are overwritten IN PLACE is not noticed (the reference would pick
-    the new values up) — call `resident_cache().clear()` after editing a dataset in place.  Three growing pools per device:
-    quaternion-packed Dirac operators ("q3"), other operators with a 4x4 block structure ("bsr4"), plain CSR ("csr")."""
+    arrays are replaced is converted again.  One whose arrays are overwritten IN PLACE is caught in two ways: every call
+    compares eight probed values of each of `data` / `indices` / `indptr` (O(1)), and every call re-verifies the FULL checksum
+    of one resident member of the batch, round-robin — so any in-place edit is noticed within as many calls as the batch has
+    members (then the matrix is converted again), deterministically, at O(nnz of one mesh) per call.  `freeze = True`
+    (resident_cache().freeze = True, before the first batch) instead makes the admitted arrays read-only, so that an in-place
+    edit RAISES in the driver at the line that does it.
+    A source that dies takes its entry with it (weak-reference callback); the HBM of dead entries is reclaimed by starting the
+    pools over once it exceeds half of what is held (or the budget is reached): SN_RESIDENT_MAX_GB, at most half of the
+    device memory that was free when the cache was made.  Three growing pools per device: quaternion-packed Dirac operators
+    ("q3"), other operators with a 4x4 block structure ("bsr4"), plain CSR ("csr")."""
 
     def __init__(self, device):
         self.device = torch.device(device)
         self.pools = {}
         self.index = {}
         self.max_bytes = int(float(os.environ.get("SN_RESIDENT_MAX_GB", "96")) * 2**30)
-        self.hits = self.misses = self.resets = 0
+        try:
+            free, _total = torch.cuda.mem_get_info(self.device)
+            self.max_bytes = min(self.max_bytes, int(free) // 2)      # (a pool that grows holds old + new buffer for a moment)
+        except Exception:  # noqa: BLE001 — no device / no such query: the configured budget stands
+            pass
+        self.hits = self.misses = self.resets = self.stale = 0
+        self.dead_bytes = 0
+        self.freeze = False
+        self._rr = 0
 
     def clear(self):
         self.pools.clear()
         self.index.clear()
+        self.dead_bytes = 0
+
+    @staticmethod
+    def _probe(a):
+        return a.reshape(-1)[:: max(1, a.size // 8)][:8].tobytes() if isinstance(a, np.ndarray) and a.size else b""
 
     @staticmethod
     def _signature(A):
-        arrays = [getattr(A, n, None) for n in ("data", "indices", "indptr", "row", "col")]
-        sig = (A.format, A.shape, int(A.nnz)) + tuple(a.ctypes.data for a in arrays if isinstance(a, np.ndarray))
-        d = getattr(A, "data", None)
-        if isinstance(d, np.ndarray) and d.size:
-            # eight evenly spaced values: an in-place edit of the SAME arrays (A.data *= 2) is caught without reading them all
-            # (O(1) per call; an edit that misses all eight probes is not — resident_cache().clear() after such edits)
-            sig += (d.reshape(-1)[:: max(1, d.size // 8)][:8].tobytes(),)
-        return sig
+        """What is compared on EVERY call (a few hundred matrices per batch, twice per step: O(1) each and cheap): class, shape, the
+        identity of the arrays and eight evenly spaced values of the value array — the usual in-place edits (A.data *= 2) are
+        caught at once; whatever this misses, the round-robin checksum of assemble() finds."""
+        g = A.__dict__.get
+        d = g("data")
+        if d.__class__ is np.ndarray and d.size:
+            probe = d.reshape(-1)[:: max(1, d.size // 8)][:8].tobytes()
+        else:
+            probe = b""
+        return (A.__class__, g("_shape"), id(d), id(g("indices")), id(g("indptr")), id(g("row")), id(g("col")), probe)
 
     @staticmethod
     def _canonical(A):
@@ -260,8 +304,9 @@ class ResidentCache:
         """Convert the matrices in `mats` (not seen before) and add them to the pools."""
         from .operators import OperatorPool
 
-        if sum(p.device_bytes() for p in self.pools.values()) > self.max_bytes:
-            self.clear()                                    # generational: start over rather than track per-entry lifetimes
+        held = sum(p.device_bytes() for p in self.pools.values())
+        if held > self.max_bytes or (self.dead_bytes > (64 << 20) and 2 * self.dead_bytes > held):
+            self.clear()                                    # generational: start over rather than compact the pools
             self.resets += 1
         canon = [self._canonical(A) for A in mats]
         blocky = [i for i, C in enumerate(canon) if self._blocky(C)]
@@ -281,7 +326,20 @@ class ResidentCache:
                 slots = pool.absorb(chunk)
             for i, slot in zip(members, slots):
                 A = mats[i]
-                self.index[id(A)] = (weakref.ref(A), self._signature(A), kind, int(slot))
+                if self.freeze:
+                    for n in ("data", "indices", "indptr", "row", "col"):
+                        a = getattr(A, n, None)
+                        if isinstance(a, np.ndarray):
+                            a.flags.writeable = False
+                key, nbytes = id(A), int(24 * A.nnz)            # (A and A^T, packed: the order of magnitude is what matters)
+                self.index[key] = (weakref.ref(A, lambda _r, key=key, nbytes=nbytes: self._died(key, nbytes)), self._signature(A),
+                                   kind, int(slot), _digest(A))
+
+    def _died(self, key, nbytes) -> None:
+        ent = self.index.get(key)
+        if ent is not None and ent[0]() is None:
+            del self.index[key]
+            self.dead_bytes += nbytes
 
     def _entry(self, A):
         ent = self.index.get(id(A))
@@ -293,18 +351,29 @@ class ResidentCache:
         for A in sources:
             if A.dtype != np.float32 or A.ndim != 2 or A.shape[0] > size0 or A.shape[1] > size1:
                 return None
+        # one member's full checksum per call, round-robin over the batch: an in-place edit the probes miss is found within
+        # len(sources) calls
+        if len(sources):
+            A = sources[self._rr % len(sources)]
+            self._rr += 1
+            ent = self._entry(A)
+            if ent is not None and ent[4] != _digest(A):
+                del self.index[id(A)]
+                self.dead_bytes += int(24 * A.nnz)
+                self.stale += 1
+        ents = [self._entry(A) for A in sources]
         new = []
-        for A in sources:
-            if self._entry(A) is None and not any(A is b for b in new):
+        for A, e in zip(sources, ents):
+            if e is None and not any(A is b for b in new):
                 new.append(A)
         if new:
             self.misses += len(new)
             self._admit(new)
-        self.hits += len(sources) - len(new)
-        ents = [self._entry(A) for A in sources]
-        if any(e is None for e in ents):                     # (a reset dropped members admitted before this call)
-            self._admit([A for A, e in zip(sources, ents) if e is None])
             ents = [self._entry(A) for A in sources]
+            if any(e is None for e in ents):                 # (a reset dropped members admitted before this call)
+                self._admit([A for A, e in zip(sources, ents) if e is None])
+                ents = [self._entry(A) for A in sources]
+        self.hits += len(sources) - len(new)
         kinds = {e[2] for e in ents}
         if len(kinds) != 1:
             return None

@@ -66,3 +66,21 @@ def test_cache_signature_notices_replaced_arrays_and_in_place_edits():
     assert ResidentCache._signature(A) != s1
     E = sp.csr_matrix((4, 4), dtype=np.float32)                    # no entries: nothing to probe
     assert ResidentCache._signature(E) == ResidentCache._signature(E)
+
+
+def test_an_edit_that_misses_every_probe_changes_the_full_checksum():
+    """ResidentCache._signature probes eight values per array (O(1) per call); the round-robin full checksum (_digest) is what
+    makes the staleness check deterministic: an edit between the probes leaves the signature and changes the digest."""
+    import scipy.sparse as sp
+
+    from surfacenetworks_amd.resident import ResidentCache, _digest
+
+    A = sp.random(200, 200, 0.2, "csr", np.float32, random_state=2)
+    s0, d0 = ResidentCache._signature(A), _digest(A)
+    step = max(1, A.data.size // 8)
+    A.data[1] += 1.0                                               # index 1 is not one of 0, step, 2 step, ...
+    assert step > 1 and ResidentCache._signature(A) == s0 and _digest(A) != d0
+    d1 = _digest(A)
+    j = 3 if (3 % max(1, A.indices.size // 8)) else 4
+    A.indices[j], A.indices[j + 1] = A.indices[j + 1], A.indices[j]           # a structural edit that keeps nnz
+    assert _digest(A) != d1

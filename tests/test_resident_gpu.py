@@ -188,6 +188,59 @@ def test_in_place_replacement_of_a_dataset_matrix_is_noticed():
     assert np.array_equal(c.data, 6 * a.data)
 
 
+def test_an_in_place_edit_between_the_probes_is_found_by_the_round_robin_checksum():
+    """Eight probed values per array cannot see every edit; one member's FULL checksum is re-verified per call, round-robin, so
+    the edit is noticed within as many calls as the batch has members — deterministically."""
+    import surfacenetworks_amd.utils_pt as U
+    from surfacenetworks_amd.resident import ResidentCache, resident_cache
+
+    rng = np.random.default_rng(8)
+    ms = _meshes(rng, [(6, 6), (6, 6), (6, 6)])
+    Ls = [m[2]["L"].copy() for m in ms]
+    cache = resident_cache()
+    cache.clear()
+    batch = lambda: U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(L) for L in Ls], Ls[0].shape[0], Ls[0].shape[1]).cuda()._sn_operator.to_scipy()
+    a = batch()
+    sig = ResidentCache._signature(Ls[1])
+    Ls[1].data[1] *= 5.0                                               # between the probes (index 1 of a >= 16-entry array)
+    assert ResidentCache._signature(Ls[1]) == sig
+    stale0 = cache.stale
+    seen = [batch() for _ in range(len(Ls))]                           # every member's checksum has been re-verified once by now
+    assert cache.stale == stale0 + 1
+    want = a.copy()
+    n0 = Ls[0].nnz
+    want.data[n0 + 1] *= 5.0
+    assert np.array_equal(seen[-1].data, want.data) and np.array_equal(batch().data, want.data)
+
+
+def test_freeze_makes_in_place_edits_raise_and_dead_sources_leave_the_index():
+    import gc
+
+    import surfacenetworks_amd.utils_pt as U
+    from surfacenetworks_amd.resident import resident_cache
+
+    rng = np.random.default_rng(9)
+    ms = _meshes(rng, [(6, 6), (7, 5)])
+    cache = resident_cache()
+    cache.clear()
+    cache.freeze = True
+    try:
+        L = ms[0][2]["L"].copy()
+        U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(L)], L.shape[0], L.shape[1])
+        with pytest.raises(ValueError, match="read-only"):
+            L.data *= 2
+    finally:
+        cache.freeze = False
+    M = ms[1][2]["L"].copy()
+    U.sparse_diag_cat([U.sp_sparse_to_pt_sparse(M)], M.shape[0], M.shape[1])
+    n, dead = len(cache.index), cache.dead_bytes
+    key = id(M)
+    assert key in cache.index
+    del M
+    gc.collect()
+    assert key not in cache.index and len(cache.index) == n - 1 and cache.dead_bytes > dead
+
+
 def test_resident_pools_grow_and_start_over_when_the_budget_is_spent():
     """Operators arrive a few at a time (a driver sampling at random from a large dataset): the pools grow in place (arenas
     that double; earlier members keep their offsets) and every batch — old members, new members, mixed — equals the

@@ -66,6 +66,87 @@ def main():
     from surfacenetworks_amd import plans
 
     which = [a for a in sys.argv[1:] if not a.startswith("--")] or ["arap", "mnist", "faust"]
+    if "--sections" in sys.argv:
+        from surfacenetworks_amd import blocks, kernels
+
+        acc = {}
+
+        def wrap(obj, name, label):
+            fn = getattr(obj, name)
+
+            def inner(*a, **k):
+                t0 = time.perf_counter()
+                try:
+                    return fn(*a, **k)
+                finally:
+                    e = acc.setdefault(label, [0.0, 0])
+                    e[0] += time.perf_counter() - t0
+                    e[1] += 1
+            setattr(obj, name, inner)
+
+        wrap(plans.Plan, "_launch", "sn_plan_run")
+        wrap(plans.Plan, "new_arenas", "new_arenas")
+        wrap(plans.Plan, "run", "Plan.run (ptrs + launch)")
+        wrap(blocks, "_plan_forward", "_plan_forward")
+        wrap(blocks, "_plan_backward", "_plan_backward")
+        wrap(blocks, "_op_operands", "_op_operands")
+        wrap(plans, "expand_ext", "expand_ext")
+        wrap(plans._Builder, "__call__", "builder")
+        wrap(blocks, "_bn_args", "_bn_args")
+        for cls in ("_DiracBlock", "_PropagateBlock", "_AvgBlock", "_EluConv"):
+            c = getattr(blocks, cls)
+            for m in ("forward", "backward"):
+                f = getattr(c, m)
+
+                def mk(f, label):
+                    def inner(*a, **k):
+                        t0 = time.perf_counter()
+                        try:
+                            return f(*a, **k)
+                        finally:
+                            e = acc.setdefault(label, [0.0, 0])
+                            e[0] += time.perf_counter() - t0
+                            e[1] += 1
+                    return staticmethod(inner)
+                setattr(c, m, mk(f, f"{cls}.{m}"))
+        for fname in ("lap_block", "avg_block", "dirac_block", "elu_conv"):
+            wrap(blocks, fname, fname)
+        from surfacenetworks_amd import arap, dense_correspondence as dc, functional as snF, mesh_mnist as mm
+
+        wrap(dc, "forward_pair_loss", "dc.forward_pair_loss")
+        wrap(dc.SiameseModel, "towers", "Siamese.towers")
+        wrap(dc.Model, "forward", "dc.Model.forward")
+        wrap(dc, "loss_fun_delta_cross_entropy", "dc.loss_fun")
+        wrap(dc.TorusBodies, "sample", "TorusBodies.sample")
+        wrap(torch.Tensor, "backward", "Tensor.backward")
+        wrap(torch.optim.Adam, "step", "Adam.step")
+        wrap(torch.optim.Adam, "zero_grad", "Adam.zero_grad")
+        wrap(snF, "thin_linear", "thin_linear")
+        wrap(snF, "bn_linear", "bn_linear")
+        wrap(mm.MeshDigits, "sample_batch", "MeshDigits.sample_batch")
+        wrap(mm.DirModel, "forward", "mm.DirModel.forward")
+        wrap(mm._Head, "_classify", "mm._classify")
+        wrap(arap.ClothSequences, "sample_batch", "Cloth.sample_batch")
+        wrap(arap, "loss_fn", "arap.loss_fn")
+        wrap(arap.DirModel, "forward", "arap.DirModel.forward")
+        wrap(kernels, "clear_absmax", "clear_absmax")
+        for name in which:
+            plans.reset()
+            plans.set_enabled(True)
+            step = {"arap": arap_step, "arap4": lambda: arap_step(4), "mnist": mnist_step, "faust": faust_step}[name]()
+            for _ in range(5):
+                step()
+            torch.cuda.synchronize()
+            acc.clear()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                step()
+            tot = time.perf_counter() - t0
+            torch.cuda.synchronize()
+            print("=====", name, "ms/step", tot / 20 * 1e3)
+            for k, (t, n) in sorted(acc.items(), key=lambda kv: -kv[1][0]):
+                print(f"{k:32s} {t / 20 * 1e3:8.3f} ms/step  {n / 20:7.1f} calls/step  {t / n * 1e6:8.1f} us/call")
+        return
     if "--profile" in sys.argv:
         import cProfile
         import pstats

@@ -29,7 +29,7 @@ def timed(step, steps, warm=3):
     return (time.perf_counter() - t0) / steps
 
 
-def arap_swap(dev="cuda", steps=10, B=64):
+def arap_swap(dev="cuda", steps=10, B=64, permute=False):
     """BASELINE configs[2] through the reference's own batching names (module docstring: arap_swap)."""
     import torch.nn as nn
     import torch.nn.functional as F
@@ -67,7 +67,7 @@ def arap_swap(dev="cuda", steps=10, B=64):
     grid_rng = np.random.default_rng(3)
     samples = []
     for _ in range(B):                                          # the dataset as the reference keeps it: scipy operators per frame
-        V, F_ = mesh_ops.grid_cloth(71, 71, grid_rng)
+        V, F_ = mesh_ops.grid_cloth(71, 71, grid_rng, permute="both" if permute else False)
         Di, DiA = mesh_ops.dirac(V, F_)
         samples.append((V.astype(np.float32), Di.astype(np.float32), DiA.astype(np.float32), F_.shape[0]))
     nv, nf = samples[0][0].shape[0], samples[0][3]
@@ -98,12 +98,112 @@ def arap_swap(dev="cuda", steps=10, B=64):
     return {"workload": f"config 3 as an UNMODIFIED reference driver runs it after the import swap: per step {2 * B} x sp_sparse_to_pt_sparse, "
                         "2 x sparse_diag_cat, .cuda() of operators / inputs / targets / mask (host tensors, pageable), the reference's "
                         "DirModel calling sequence, mask multiply + smooth_l1_loss + Adam (src/as_rigid_as_possible/main.py:156-232)",
-            "meshes": B, "model": type(model).__name__, "resident": os.environ.get("SN_RESIDENT", "1") != "0",
+            "meshes": B, "model": type(model).__name__, "vertex_order": "shuffled (vertices and faces)" if permute else "grid", "resident": os.environ.get("SN_RESIDENT", "1") != "0",
             "steps": steps, "ms_per_step": dt * 1e3, "meshes_per_s": B / dt,
             "host_batching_calls_ms": float(np.mean(t_host[k:]) * 1e3), "driver_cuda_calls_host_ms": float(np.mean(t_h2d[k:]) * 1e3),
             "pageable_MB_per_step": (inputs.numel() + targets.numel() + mask.numel()) * 4 / 1e6,
             "resident_cache": None if c is None else {"hits": c.hits, "misses": c.misses,
                                                       "MB_in_HBM": sum(p_.device_bytes() for p_ in c.pools.values()) / 1e6}}
+
+
+def mnist_swap(dev="cuda", steps=20, B=512, permute=False):
+    """BASELINE configs[1] as the reference's Mesh-MNIST loop runs it after the import swap (src/mesh_mnist/main.py:79-117,151-167):
+    per step utils.sparse_cat of the batch's per-sample Di / DiA handles (3-D operators), .cuda() of inputs / targets / mask /
+    operators, DirModel(inputs, Di, DiA, mask), F.nll_loss, Adam — eager, nothing captured.
+    permute: the meshes' vertices and faces in random order, used as stored (the Delaunay generator's order otherwise)."""
+    import torch.nn.functional as F
+
+    import surfacenetworks_amd.utils_pt as utils
+    from surfacenetworks_amd import mesh_ops
+
+    rng = np.random.default_rng(2)
+    samples = []
+    for _ in range(B):
+        V, F_ = mesh_ops.delaunay_disc(150, rng)
+        if permute:
+            pv, pf = rng.permutation(V.shape[0]), rng.permutation(F_.shape[0])
+            inv = np.empty_like(pv)
+            inv[pv] = np.arange(pv.size)
+            V, F_ = V[pv], inv[F_][pf]
+        Di, DiA = mesh_ops.dirac(V, F_)
+        samples.append({"V": torch.from_numpy(V.astype(np.float32)), "F": F_, "label": int(rng.integers(0, 10)),
+                        "Di": utils.sp_sparse_to_pt_sparse(Di.astype(np.float32)), "DiA": utils.sp_sparse_to_pt_sparse(DiA.astype(np.float32))})
+    nv = max(s_["V"].shape[0] for s_ in samples)
+    nf = max(s_["F"].shape[0] for s_ in samples)
+    model = mm.DirModel().to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), 1e-3, weight_decay=1e-5)                    # main.py:139
+    inputs, targets, mask = torch.zeros(B, nv, 3), torch.zeros(B).long(), torch.zeros(B, nv, 1)
+    for b, s_ in enumerate(samples):
+        inputs[b, : s_["V"].shape[0]] = s_["V"]
+        targets[b] = s_["label"]
+        mask[b, : s_["V"].shape[0]] = 1
+
+    def step():
+        Di = utils.sparse_cat([s_["Di"] for s_ in samples], 4 * nf, 4 * nv)                                   # main.py:109-111
+        DiA = utils.sparse_cat([s_["DiA"] for s_ in samples], 4 * nv, 4 * nf)
+        x, y, m, Di, DiA = inputs.cuda(), targets.cuda(), mask.cuda(), Di.cuda(), DiA.cuda()                   # main.py:115
+        loss = F.nll_loss(model(x, Di, DiA, m), y)                                                             # main.py:157-160
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    dt = timed(step, steps, warm=3)
+    return {"workload": "config 2 as the reference's Mesh-MNIST loop runs it after the import swap: per step 2 x utils.sparse_cat of 512 "
+                        "per-sample handles, .cuda() of inputs / targets / mask / operators, DirModel, nll_loss, Adam (src/mesh_mnist/"
+                        "main.py:79-117,151-167); eager", "vertex_order": "shuffled" if permute else "as generated",
+            "steps": steps, "ms_per_step": dt * 1e3, "meshes_per_s": B / dt}
+
+
+def faust_swap(dev="cuda", steps=20, permute=False):
+    """BASELINE configs[3] (per-GPU work: one pair) as the reference's dense-correspondence loop runs it after the import swap
+    (src/dense_correspondence/main.py:106-191,310-327): per sample utils.sparse_diag_cat([L], 7000, 7000).coalesce().cuda(),
+    zero-padded inputs / mask .cuda(), SiameseModel(lap) -> (1, 7000, 7000) scores, loss_fun_delta_cross_entropy, Adam — eager.
+    The geodesic matrices and label vectors stay on the device (the reference moves them with .cuda() per step from wherever
+    its loader left them).  permute: vertices and faces of the bodies in random order, used as stored."""
+    import surfacenetworks_amd.utils_pt as utils
+    from surfacenetworks_amd import mesh_ops
+
+    rng = np.random.default_rng(4)
+    frames = []
+    for _ in range(4):
+        V, F_ = mesh_ops.torus_grid(65, 106, rng)
+        if permute:
+            pv, pf = rng.permutation(V.shape[0]), rng.permutation(F_.shape[0])
+            inv = np.empty_like(pv)
+            inv[pv] = np.arange(pv.size)
+            V, F_ = V[pv], inv[F_][pf]
+        nv = V.shape[0]
+        label = rng.permutation(nv)
+        Vd = torch.from_numpy(V.astype(np.float32)).to(dev)
+        frames.append({"V": torch.from_numpy(V.astype(np.float32)), "L": utils.sp_sparse_to_pt_sparse(mesh_ops.laplacian(V, F_).astype(np.float32)),
+                       "G": torch.cdist(Vd, Vd), "label": torch.from_numpy(label).to(dev), "label_inv": torch.from_numpy(np.argsort(label)).to(dev)})
+    model = dc.SiameseModel("lap", 15).to(dev).train()
+    opt = torch.optim.Adam(model.parameters(), 1e-3, weight_decay=1e-5)                    # main.py:285
+    k = [0]
+
+    def sample(i):
+        fr = frames[i]
+        nv = fr["V"].shape[0]
+        inputs, mask = torch.zeros(1, 7000, 3), torch.zeros(1, 7000, 1)
+        inputs[0, :nv] = fr["V"]
+        mask[0, :nv] = 1
+        L = utils.sparse_diag_cat([fr["L"]], 7000, 7000).coalesce()                                           # main.py:180
+        return inputs.cuda(), [(fr["G"].cuda(), fr["label"].cuda(), fr["label_inv"].cuda())], mask.cuda(), L.cuda()
+
+    def step():
+        k[0] += 1
+        inX, tX, mX, LX = sample(k[0] % 4)
+        inY, tY, mY, LY = sample((k[0] + 1) % 4)
+        out = model((LX, mX), (LY, mY), inX, inY)                                                              # main.py:317-321
+        loss = dc.loss_fun_delta_cross_entropy(out, tX, tY)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    dt = timed(step, steps, warm=3)
+    return {"workload": "config 4 (one pair) as the reference's dense-correspondence loop runs it after the import swap: per sample "
+                        "utils.sparse_diag_cat([L], 7000, 7000).coalesce().cuda(), padded inputs / mask .cuda(), SiameseModel(lap), "
+                        "loss_fun_delta_cross_entropy on the (1, 7000, 7000) scores, Adam (src/dense_correspondence/main.py:106-191,"
+                        "310-327); eager", "vertex_order": "shuffled" if permute else "as generated",
+            "steps": steps, "ms_per_step": dt * 1e3, "pairs_per_s": 1 / dt, "meshes_per_s": 2 / dt}
 
 
 def main():
