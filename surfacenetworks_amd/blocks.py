@@ -18,6 +18,8 @@ cannot be picked up either way.
 """
 from __future__ import annotations
 
+import weakref
+
 import torch
 
 from . import kernels, plans
@@ -83,16 +85,38 @@ _TILE_SUMS_MIN_ROWS = 32768
 
 
 def _new_tiles(rows, C, device, part, wanted):
-    """Tile-sum buffer for a forward GEMM whose activated output feeds a global-average block (or None).  `wanted` comes from the
-    block's `avg_next` argument: True / None (not said: the unmodified reference models — every Dirac / Laplacian block but the
-    last is followed by an AvgResNet2, as_rigid_as_possible/models.py:115-121 — get the hand-off too; a buffer nobody picks up
-    costs 5 MB of stores per launch) or False.  Only for operands
+    """Tile-sum buffer for a forward GEMM whose activated output feeds a global-average block (or None).  `wanted`: _wants_tiles
+    (the block's `avg_next` argument, or what the block has learnt when the caller cannot say).  Only for operands
     large enough that the statistics pass they save costs more than the per-tile path: a 7000-row FAUST tower runs FASTER with
     the pass (its per-mesh sums from tiles are four workgroups walking 218 tiles: replayed pair step 3.25 ms against 3.45, same
     box), the 322 624-row ARAP batch 0.28 ms per step slower."""
     if not wanted or part is None or C != 128 or rows < _TILE_SUMS_MIN_ROWS or not kernels.tile_sums_supported():
         return None
     return kernels.new_tile_sums(rows, device)
+
+
+def _wants_tiles(mod, avg_next) -> bool:
+    """Whether a Dirac / Laplacian block leaves the per-tile column sums a following global-average block reads instead of a
+    statistics pass (5 MB of stores per launch at the ARAP batch).  avg_next True / False: the caller says (the product's own
+    models do).  None — the reference's calling sequence, which cannot say: what the block has LEARNT: a global-average block
+    that receives this block's activated hand-off without tile sums (and is large enough to want them) marks the producer
+    (_learn_avg_next), so from the second step on exactly the blocks that feed one leave them and a model's last block never does."""
+    if avg_next is None:
+        return bool(mod.__dict__.get("_sn_avg_next", False))
+    return bool(avg_next)
+
+
+def _mark_producer(cat, mod, avg_next) -> None:
+    if avg_next is None and not mod.__dict__.get("_sn_avg_next", False):
+        cat._sn_producer = weakref.ref(mod)
+
+
+def _learn_avg_next(pre, rows) -> None:
+    if pre is not None and rows >= _TILE_SUMS_MIN_ROWS and _tiles_of(pre) is None:
+        ref = pre.__dict__.get("_sn_producer")
+        mod = ref() if ref is not None else None
+        if mod is not None:
+            mod._sn_avg_next = True
 
 
 def _tiles_of(cat):
@@ -404,7 +428,8 @@ def dirac_block(mod, Di, DiA, v, f, need_f=True, num_faces=None, avg_next=None):
     v_new, f_out, nxt_v, nxt_f = _DiracBlock.apply(v.reshape(rv, C), f.reshape(rf, C) if f is not None else None, opDi, opDiA,
                                                   take_activated(v, rv, C),
                                                   take_activated(f, rf, C) if f is not None else None, bool(need_f),
-                                                  avg_next is not False, *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+                                                  _wants_tiles(mod, avg_next), *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+    _mark_producer(nxt_v, mod, avg_next)
     return attach_activated(v_new.view(B, V, C), nxt_v), attach_activated(f_out.view(B, F_, C), nxt_f)
 
 
@@ -686,7 +711,9 @@ def avg_block_ragged(mod, seg, inputs):
     """AvgResNet2 on a packed (1, sum V_i, C) batch as one autograd node at half width."""
     B, V, C = inputs.shape
     rows = B * V
-    out, nxt = _AvgBlockRagged.apply(inputs.reshape(rows, C), seg, take_activated(inputs, rows, C), *_bn_args(mod.bn_fc0),
+    pre = take_activated(inputs, rows, C)
+    _learn_avg_next(pre, rows)
+    out, nxt = _AvgBlockRagged.apply(inputs.reshape(rows, C), seg, pre, *_bn_args(mod.bn_fc0),
                                      *_bn_args(mod.bn_fc1))
     return attach_activated(out.view(B, V, C), nxt)
 
@@ -758,8 +785,9 @@ def lap_block(mod, L, inputs, avg_next=None):
     op = as_operator(L)
     if op.shape != (rows, rows):
         raise ValueError(f"LapResNet2: operator {tuple(op.shape)} vs {rows} rows")
-    out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), op, None, None, 0, take_activated(inputs, rows, C), avg_next is not False,
-                                     *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+    out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), op, None, None, 0, take_activated(inputs, rows, C),
+                                     _wants_tiles(mod, avg_next), *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+    _mark_producer(nxt, mod, avg_next)
     return attach_activated(out.view(B, V, C), nxt)
 
 
@@ -790,7 +818,9 @@ def avg_block(mod, mask, inputs):
     a0, a1 = _bn_args(mod.bn_fc0), _bn_args(mod.bn_fc1)
     if a0[6] and a1[6] and kernels.avg_stage_supported(C, mod.bn_fc0.fc.weight.shape[0], V) and \
             mod.bn_fc0.fc.weight.shape[1] == 2 * C and mod.bn_fc1.fc.weight.shape[0] == C:
-        out, nxt = _AvgBlock.apply(inputs.reshape(rows, C), mask_rows, inv_count, B, take_activated(inputs, rows, C), *a0, *a1)
+        pre = take_activated(inputs, rows, C)
+        _learn_avg_next(pre, rows)
+        out, nxt = _AvgBlock.apply(inputs.reshape(rows, C), mask_rows, inv_count, B, pre, *a0, *a1)
     else:
         out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), None, mask_rows, inv_count, B, take_activated(inputs, rows, C),
                                          False, *a0, *a1)

@@ -17,12 +17,13 @@
 #include "sn_spmm.h"
 
 // per-launch timing shared with sn_kernels.hip (the facility behind sn_timing_*)
+int sn_internal_cu_count();
 bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e);
 
 namespace {
 
 constexpr int kWG = 256;
-constexpr int kCUs = 256;
+#define kCUs sn_internal_cu_count()      // compute units of the current device (256 on an MI355X in SPX mode)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 typedef float f16v __attribute__((ext_vector_type(16)));

@@ -26,6 +26,8 @@
 
 #include "sn_spmm.h"
 
+int sn_internal_cu_count();
+
 namespace {
 
 constexpr int kWG = 256;    // 4 wavefronts per workgroup
@@ -34,7 +36,7 @@ constexpr int kWG = 256;    // 4 wavefronts per workgroup
 // partition mode says otherwise (4 / 2 / 1).  Only LOCALITY depends on it: every map below is a bijection for any value that
 // divides the grid.
 __constant__ int c_xcd = 8;
-constexpr int kCUs = 256;
+#define kCUs sn_internal_cu_count()      // compute units of the current device (256 on an MI355X in SPX mode)
 
 typedef float f4 __attribute__((ext_vector_type(4)));
 
@@ -1887,6 +1889,27 @@ inline bool timing_slot(int kind, int64_t M, int64_t K, int64_t nnz, int N, hipE
 // The same timing slot for the Linear-layer launchers of the other translation units (sn_gemm.hip, sn_dense.hip): kind
 // 0x100 forward / 0x200 input gradient / 0x400 weight gradient (+ a variant number in the low byte), then rows, the contraction
 // or input width, the ALGORITHMIC bytes of the launch (operands read + results written, weights excluded) and the output width.
+// Compute units of the current device (hipDeviceAttributeMultiprocessorCount, read once per device): what every "one workgroup
+// per CU" / "whole rounds of the chip" grid of the three translation units is sized by — 256 on an MI355X in SPX mode, fewer in
+// the CPX / DPX / QPX partition modes.  256 when there is no device to ask (host-only callers of the *_blocks / *_bytes queries).
+int sn_internal_cu_count() {
+  static std::mutex mu;
+  static int cached[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+    (void)hipGetLastError();
+    return 256;
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  if (cached[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) n = 256;
+    (void)hipGetLastError();
+    cached[dev] = n;
+  }
+  return cached[dev];
+}
+
 bool g_timing_linear = true;      // sn_timing_enable(2): the sparse products only
 bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e) {
   {

@@ -646,6 +646,20 @@ class FaustFrames:
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)        # (as TorusBodies: the frames are read from other streams later)
 
+    def to_dataset_order(self, x: torch.Tensor, idx: int) -> torch.Tensor:
+        """Per-vertex rows (1, pad_to, C) of frame `idx` — tower features, per-vertex predictions — from the STORED numbering
+        (what sample() hands out and the towers return) back into the file's own vertex numbering; padding rows stay where they
+        are.  Evaluation / export only: the loss is invariant to the numbering."""
+        from .arap import reorder_rows
+
+        return reorder_rows(x, self.orders, [idx], "vrank")
+
+    def from_dataset_order(self, x: torch.Tensor, idx: int) -> torch.Tensor:
+        """The inverse: per-vertex rows given in the file's numbering, as the stored numbering wants them."""
+        from .arap import reorder_rows
+
+        return reorder_rows(x, self.orders, [idx], "vorder")
+
     def sample(self, idx):
         """As TorusBodies.sample: built once per frame, the dataset's own tensors from then on."""
         hit = self._samples.get(idx)

@@ -122,7 +122,8 @@ class MeshDigits:
 
     def __init__(self, count, seed=2, device="cuda", vmin=140, vmax=230, fixed_vertices=None, model="dir", reorder="auto"):
         """reorder: the meshes are STORED in a locality numbering (mesh_ops.MeshOrder; Delaunay vertices come in random order).
-        The model's output is per mesh, so nothing maps back."""
+        The model's output is per MESH (ten class scores), so nothing maps back; `orders[i].vorder` (stored position -> generated
+        vertex index) is kept for callers that look at per-vertex activations."""
         rng = np.random.default_rng(seed)
         self.device = torch.device(device)
         self.kind = model
@@ -131,7 +132,9 @@ class MeshDigits:
         for _ in range(count):
             n = fixed_vertices or int(rng.integers(vmin, vmax + 1))
             V, F_ = mesh_ops.delaunay_disc(n, rng)
-            V, F_ = mesh_ops.MeshOrder.of_mesh(F_, V.shape[0], reorder).mesh(V, F_)
+            order = mesh_ops.MeshOrder.of_mesh(F_, V.shape[0], reorder)
+            self.orders = getattr(self, "orders", []) + [order]
+            V, F_ = order.mesh(V, F_)
             Vs.append(V.astype(np.float32))
             self.nv.append(V.shape[0])
             self.nf.append(F_.shape[0])

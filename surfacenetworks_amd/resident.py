@@ -79,7 +79,7 @@ class _Payload:
         self.members = members              # list of LazySparse / torch COO tensors (kinds "diag", "cat")
         self.size0, self.size1 = size0, size1
         self.operator = operator            # the batch assembled on the device (SparseOperator) or None
-        self.real = {}                      # materialised torch tensors by (device type, coalesced)
+        self.real = {}                      # materialised torch tensors by (device, coalesced)
         self.coalesced = kind != "source"
 
     def build(self, coalesced: bool):
@@ -101,7 +101,16 @@ class LazySparse(torch.Tensor):
                                                 device=torch.device(device), requires_grad=False)
         t._sn_payload = payload
         t._sn_coalesced = bool(coalesced)
-        t._sn_operator = payload.operator if torch.device(device).type == "cuda" else None
+        # the assembled batch rides along only on the device it lives on: a handle moved to ANOTHER GPU (.cuda(1)) materialises
+        # there like any tensor the cache does not know (operators.as_operator -> from_torch_coo on that device)
+        dev, op = torch.device(device), payload.operator
+        if dev.type != "cuda" or op is None:
+            op = None
+        else:
+            idx = dev.index if dev.index is not None else torch.cuda.current_device()
+            if op.device.type != "cuda" or op.device.index != idx:
+                op = None
+        t._sn_operator = op
         return t
 
     def __init__(self, *args, **kwargs):
@@ -144,7 +153,12 @@ class LazySparse(torch.Tensor):
         if device is None:
             return self
         device = torch.device(device)
-        if device.type == self.device.type and (device.index is None or self.device.index is None or device.index == self.device.index):
+        if device.type == "cuda":
+            if not torch.cuda.is_available():
+                raise RuntimeError("LazySparse.cuda(): no GPU is available (torch.cuda.is_available() is False)")
+            if device.index is None:
+                device = torch.device("cuda", torch.cuda.current_device())
+        if device == self.device:
             return self
         return self._like(device=device)
 
@@ -161,7 +175,7 @@ class LazySparse(torch.Tensor):
     def materialize(self) -> torch.Tensor:
         """The real torch sparse COO tensor this handle stands for, built the way the reference builds it (and cached)."""
         p = self._sn_payload
-        key = (self.device.type, self._sn_coalesced or p.coalesced)
+        key = (str(self.device), self._sn_coalesced or p.coalesced)          # (the full device: cuda:0 and cuda:1 are two tensors)
         t = p.real.get(key)
         if t is None:
             base = p.real.get(("cpu", key[1]))

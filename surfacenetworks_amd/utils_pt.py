@@ -196,9 +196,10 @@ class LapResNet2(_TwoStage):
     """x + Lin(BN([e1, L e1])), e1 = elu(Lin(BN([e0, L e0]))), e0 = elu(x)   (utils_pt.py:151-180)."""
 
     def forward(self, L, mask, inputs, avg_next=None):
-        """avg_next (not in the reference's signature; True / None = not said / False): the output feeds an AvgResNet2 next, as it
-        does in every model of the reference (the unmodified models.py say nothing and get the hand-off too) — the second GEMM then also
-        leaves the per-tile column sums that block needs of its operand (no statistics pass over it)."""
+        """avg_next (not in the reference's signature; True / False / None = not said): the output feeds an AvgResNet2 next — the
+        second GEMM then also leaves the per-tile column sums that block needs of its operand (no statistics pass over it).  The
+        unmodified models.py say nothing: the block then LEARNS it (blocks._wants_tiles: the AvgResNet2 that receives its hand-off
+        without tile sums marks it), so from the second step on the hand-off exists exactly where it is read."""
         if isinstance(L, torch.Tensor) and L.layout == torch.strided:
             return DenseLapResNet2.forward(self, L, mask, inputs)
         batch, node, feat = inputs.size()
@@ -226,8 +227,8 @@ class DirResNet2(_TwoStage):
         f=None with num_faces=F (not in the reference's signature either): the face features are all zero — what every
         model of the reference feeds its first Dirac block (as_rigid_as_possible/models.py:138) — and are not materialised:
         the face stage runs over the propagated half only (same values).
-        avg_next (not in the reference's signature; True / None = not said / False): the vertex output feeds an AvgResNet2 next (as in every model of the
-        reference): the vertex-stage GEMM also leaves the per-tile column sums that block needs of its operand."""
+        avg_next (not in the reference's signature; True / False / None = not said): the vertex output feeds an AvgResNet2 next:
+        see LapResNet2.forward (None: learnt from the block that consumes the hand-off)."""
         batch_size, num_nodes, num_inputs = v.size()
         if f is None:
             if num_faces is None:

@@ -13,6 +13,18 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "pins_oracle: oracle-vs-golden checks (no GPU needed) that ALSO run under -m gpu, so that the "
+                                       "checker is pinned on the box where it checks")
+
+
+@pytest.hookimpl(tryfirst=True)
+def pytest_collection_modifyitems(config, items):
+    """`-m gpu` (the driver's round-end run on the MI355X) also selects the tests that pin the oracle against the reference's
+    golden vectors: they need no GPU, but they are what makes "HIP == oracle" mean "HIP == reference" on that box."""
+    if (config.getoption("-m") or "").strip() == "gpu":
+        for item in items:
+            if item.get_closest_marker("pins_oracle") is not None:
+                item.add_marker(pytest.mark.gpu)
 
 
 @pytest.fixture(scope="session")

@@ -11,6 +11,24 @@ from helpers import deterministic_init, grad_signature, rel_err, sigs_close
 from oracle import c_oracle, ref_blocks as OB
 from surfacenetworks_amd import mesh_ops
 
+# conftest.py: selected by -m "not gpu" AND by -m gpu — the checks whose arithmetic is order-deterministic (the C oracle, the
+# operator builders) or shallow (single blocks, 1e-5) also run on the GPU box, so that "HIP == oracle" there means "HIP ==
+# reference".  The 15-layer MODEL comparisons of the torch-CPU restatement stay in the container the fixtures were written in:
+# the same torch code on the GPU box's host (EPYC 9575F, AVX-512, 256 threads) differs from this container's by 2.5e-4 (Dirac) to
+# > 1e-3 (Laplacian) in the first layer's weight gradient — round-off amplified by depth (tools/scratch/oracle_host_check.py);
+# the product itself is compared with the same fixtures on the device (tests/product_checks.py).
+pins_oracle = pytest.mark.pins_oracle
+
+
+@pytest.fixture(autouse=True)
+def _fixture_thread_count():
+    """The torch-CPU restatement's fp32 reductions are partitioned by the thread count: run it with the count the fixtures were
+    written with (8), whatever the host has (the GPU box: 256 logical CPUs), so that the comparison is the same everywhere."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(8)
+    yield
+    torch.set_num_threads(n)
+
 
 def load(golden_dir, name):
     return np.load(os.path.join(golden_dir, name), allow_pickle=False)
@@ -20,6 +38,7 @@ def csr_of(z, k):
     return sp.csr_matrix((z[f"{k}_data"], z[f"{k}_indices"], z[f"{k}_indptr"]), shape=tuple(z[f"{k}_shape"]))
 
 
+@pins_oracle
 @pytest.mark.parametrize("mesh", ["cube", "delaunay150", "delaunay60"])
 def test_operator_construction_matches_reference(golden_dir, mesh):
     """mesh_ops (sparse-direct) == utils.mesh / utils.graph (dense builders) on the fixture meshes, fp32-identical."""
@@ -35,6 +54,7 @@ def test_operator_construction_matches_reference(golden_dir, mesh):
         assert (mine["L"].nnz, mine["Di"].nnz, mine["DiA"].nnz) == (44, 192, 192)
 
 
+@pins_oracle
 def test_operator_identities(golden_dir):
     """rows of L sum to ~0; DiA has the pattern of Di^T; 9 nnz per Di row on a generic mesh."""
     z = load(golden_dir, "ops_delaunay150.npz")
@@ -46,6 +66,7 @@ def test_operator_identities(golden_dir):
     assert np.array_equal(P.indptr, Q.indptr) and np.array_equal(P.indices, Q.indices)
 
 
+@pins_oracle
 def test_c_oracle_spmm_matches_reference_torch_mm(golden_dir):
     """oracle_spmm_csr_f32 (forward) and transpose+spmm (backward) vs torch.mm(sparse, dense) + autograd of the
     reference path, <= 1e-6 relative (tolerance of SURVEY.md §8c); and vs fp64."""
@@ -66,6 +87,7 @@ def test_c_oracle_spmm_matches_reference_torch_mm(golden_dir):
                 assert rel_err(yo, y64) <= 1e-6 and rel_err(Y, y64) <= 1e-6
 
 
+@pins_oracle
 def test_literal_cuda_kernel_restatements(golden_dir):
     """oracle_batch_csr + oracle_sparse_bmm (line-by-line batch_csr.cu / sparse_bmm.cu) reproduce the reference's
     own torch.mm results on the 3-D batched operator of the ragged batch, where batch_csr is valid (no interior
@@ -148,6 +170,7 @@ def _batch_ops(golden_dir):
 BLOCKS = [("LapResNet2", 64), ("LapResNet2", 128), ("DirResNet2", 64), ("DirResNet2", 128), ("AvgResNet2", 128), ("MlpResNet2", 128)]
 
 
+@pins_oracle
 @pytest.mark.parametrize("cname,C", BLOCKS)
 def test_oracle_blocks_match_reference(golden_dir, cname, C):
     from helpers import det_tensor
@@ -166,14 +189,20 @@ def test_oracle_blocks_match_reference(golden_dir, cname, C):
         outs, gin = (mod(ops["L"], mask, v),), [v]
     loss = sum((o * torch.from_numpy(det_tensor(tuple(o.shape), s))).sum() for o, s in zip(outs, [21, 22]))
     loss.backward()
+    # ref_blocks.py is a torch-CPU restatement: torch's fp32 reductions change their order with the thread count (and the host's
+    # vector width), so this comparison against the reference's stored results holds to a few 1e-6, not bit for bit — the fixture
+    # was written with 8 threads; one thread here, or the GPU box's 256, deviate by up to 4e-6.  north_star's bound is 1e-5.
+    # (The C oracle of the SpMM itself is order-deterministic: test_c_oracle_spmm_matches_reference_torch_mm stays at 1e-6.)
     for i, o in enumerate(outs):
-        assert rel_err(o.detach().numpy(), g[f"{tag}_out{i}"]) <= 1e-6
+        assert rel_err(o.detach().numpy(), g[f"{tag}_out{i}"]) <= 1e-5
     for i, t in enumerate(gin):
-        assert rel_err(t.grad.numpy(), g[f"{tag}_gin{i}"]) <= 1e-6
+        assert rel_err(t.grad.numpy(), g[f"{tag}_gin{i}"]) <= 1e-5
     assert not sigs_close(grad_signature(mod), lambda k: g[f"{tag}_psig_{k}"])
     for k, t in mod.state_dict().items():
         if "running" in k:
-            assert np.allclose(t.numpy(), g[f"{tag}_{k}"], rtol=1e-6, atol=1e-7)
+            # (running statistics of L·x are means of values of order 1e2 with cancellation: torch's CPU reduction order
+            #  depends on the host's core count — 3.4e-6 between this container and the GPU box's EPYC for the same code)
+            assert np.allclose(t.numpy(), g[f"{tag}_{k}"], rtol=1e-5, atol=1e-6)
 
 
 def _bn_train_only(m):

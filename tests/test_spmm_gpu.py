@@ -621,3 +621,45 @@ def test_entry_points_from_two_host_threads_on_two_streams():
         for got in results[k][::7] + results[k][-3:]:
             for a, r in zip(got, ref[0]):
                 assert (a is None and r is None) or torch.equal(a, r)
+
+
+# ---- the parity chain closed on the device: HIP product vs the REFERENCE's stored results ------------------------------------------
+@pytest.mark.parametrize("mesh", ["cube", "delaunay150"])
+@pytest.mark.parametrize("fmt", ["csr", "bsr4", "q3", "rb4", "ring"])
+def test_hip_products_match_the_references_stored_results(golden_dir, mesh, fmt, monkeypatch):
+    """tests/golden/spmm_reference.npz holds X, G and the reference's own Y = torch.mm(A_coo, X), GX = its autograd backward
+    (written by tests/golden/make_golden.py from the imported reference).  The HIP products in every storage form, through
+    functional.spmm, against those numbers directly (<= 1e-6 relative) — not only through the oracle."""
+    import os
+
+    import scipy.sparse as sp
+
+    from helpers import rel_err
+    from surfacenetworks_amd import functional as snF, kernels
+    from surfacenetworks_amd.operators import SparseOperator
+
+    g = np.load(os.path.join(golden_dir, "spmm_reference.npz"))
+    z = np.load(os.path.join(golden_dir, f"ops_{mesh}.npz"))
+    monkeypatch.setattr(kernels, "RING_MIN_ROWS", 8)                 # (the sliding-window kernel is chosen from 131 072 rows on)
+    dirac = fmt in ("bsr4", "q3")
+    ran = hits = 0
+    for k, Ns, group in (("L", (64, 128), 1), ("Di", (16, 32), 4), ("DiA", (16, 32), 4)):
+        if (group == 4) != dirac and fmt != "csr":
+            continue
+        A = sp.csr_matrix((z[f"{k}_data"], z[f"{k}_indices"], z[f"{k}_indptr"]), shape=tuple(z[f"{k}_shape"]))
+        M, K = A.shape
+        for N in Ns:
+            t = f"{mesh}_{k}_N{N}"
+            X, Y, G, GX = g[f"{t}_X"], g[f"{t}_Y"], g[f"{t}_G"], g[f"{t}_GX"]
+            op = SparseOperator.from_scipy(A, "cuda")
+            op.format = fmt
+            kind = snF.product_form(op, group, group * N)[0]
+            hits += kind == fmt                                      # (e.g. the 8-row cube has no row-blocked form: falls back)
+            assert kind in (fmt, "csr", "rb4", "bsr4"), (fmt, kind)
+            x = torch.from_numpy(X.reshape(K // group, group * N)).cuda().requires_grad_(True)
+            y = snF.spmm(op, x, group=group)
+            y.backward(torch.from_numpy(G.reshape(M // group, group * N)).cuda())
+            assert rel_err(y.detach().cpu().numpy().reshape(M, N), Y) <= 1e-6, (t, fmt, kind)
+            assert rel_err(x.grad.cpu().numpy().reshape(K, N), GX) <= 1e-6, (t, fmt, kind)
+            ran += 1
+    assert ran >= 2 and (hits > 0 or mesh == "cube"), (ran, hits)      # the 150-vertex mesh takes every requested form
