@@ -1,5 +1,5 @@
 """Step-time measurements of the other BASELINE configs (parity-test cases, not bench lines):
-   python tools/train_bench.py mnist_dir|mnist_lap|faust_lap|arap_lap|arap_ragged|arap_swap [steps]
+   python tools/train_bench.py mnist_dir|mnist_lap|faust_lap|arap_lap|arap_ragged|arap_swap|mnist_swap|faust_swap [steps]
 mnist_dir = config 2 (Mesh-MNIST Dirac, batch 512); mnist_lap = config 1 shape on the GPU; faust_lap = config 4 per-GPU
 work (one pair of 6890-vertex bodies padded to 7000); arap_lap = the Laplacian variant of config 3; arap_swap = config 3
 as an UNMODIFIED reference driver runs it after the import swap: per step and per sample sp_sparse_to_pt_sparse,
@@ -290,6 +290,12 @@ def main():
               f"{r['ms_per_step']:.1f} ms/step, {r['meshes_per_s']:.1f} meshes/s (host batching calls {r['host_batching_calls_ms']:.2f} ms, the driver's "
               f".cuda() calls incl. {r['pageable_MB_per_step']:.0f} MB of pageable inputs/targets {r['driver_cuda_calls_host_ms']:.2f} ms host time; "
               f"resident cache {r['resident_cache']})")
+    elif what in ("mnist_swap", "faust_swap"):
+        fn = mnist_swap if what == "mnist_swap" else faust_swap
+        r = fn(dev, steps)
+        r2 = fn(dev, steps, permute=True)
+        print(f"{what}: {r['ms_per_step']:.2f} ms/step ({r['meshes_per_s']:.0f} meshes/s) behind the reference's names, eager; vertices and "
+              f"faces shuffled, as stored: {r2['ms_per_step']:.2f} ms/step")
     else:
         raise SystemExit(__doc__)
 
