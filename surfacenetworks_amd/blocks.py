@@ -187,10 +187,10 @@ def _plan_forward(ctx, site, impl, tensors, ops, consts, ncols, n_dyn, scan):
            tuple([None if t is None else t.shape for t in tensors[n_dyn:]]), attr_key, op_key, consts,
            tuple([ptrs.index(p_) for p_ in ptrs]),               # features that share memory must do so on every run of the plan
            _TILE_SUMS_MIN_ROWS)
-    plan = site.plans.get(key, _MISSING)
+    plan, may_record = site.lookup(key)
     if plan is None:
-        return None
-    if plan is _MISSING:
+        if not may_record:
+            return None
         plan = plans.record(site, key, impl, (*tensors, *[o for o, _ in ops], *consts), ext, tensors[0].device)
         if plan is None:
             return None

@@ -23,6 +23,7 @@ SN_PLANS=0 disables the mechanism (every block launches its kernels from Python,
 from __future__ import annotations
 
 import bisect
+import collections
 import ctypes as C
 import os
 from typing import Any, List, Optional, Sequence
@@ -214,8 +215,7 @@ class Plan:
         self.arena_bytes = lay.arena_bytes
         self.n_ext = len(rec.ext)
         self.used_ext = sorted(lay.used_ext)
-        self._bases = (C.c_uint64 * (2 + self.n_ext))()
-        self._failed = C.c_int32(-1)
+        self._BasesT = C.c_uint64 * (2 + self.n_ext)
         self.bwd = {}                       # backward plans recorded against this forward's layout, by their own key
 
     def _describe(self, t, lay, rec):
@@ -313,18 +313,20 @@ class Plan:
         return big, small
 
     def run(self, big, small, ext):
-        b = self._bases
+        """Enqueue the plan on torch's current stream.  (The slot table is made per call: a plan may be run from several threads —
+        the autograd engine's device thread runs backward plans while the caller's thread runs forward ones.)"""
+        b = self._BasesT()
         b[0] = big.data_ptr() if big is not None else 0
         b[1] = small.data_ptr() if small is not None else 0
         for j in self.used_ext:
             b[2 + j] = ext[j].data_ptr()
-        self._launch()
+        self._launch(b)
 
-    def _launch(self):
-        b = self._bases
-        st = self._lib.sn_plan_run(self.handle, b, 2 + self.n_ext, kernels._stream(), C.byref(self._failed))
+    def _launch(self, b):
+        failed = C.c_int32(-1)
+        st = self._lib.sn_plan_run(self.handle, b, 2 + self.n_ext, kernels._stream(), C.byref(failed))
         if st != 0:
-            _lib.check(st, f"sn_plan_run (entry {self._failed.value})")
+            _lib.check(st, f"sn_plan_run (entry {failed.value})")
 
 
 class _Builder:
@@ -373,18 +375,57 @@ class _Builder:
 _SITES = []
 
 
+MAX_PLANS_PER_SITE = 64       # distinct shape signatures kept per call site (least recently used beyond that)
+THRASH_WINDOW = 16            # a site whose last THRASH_WINDOW lookups were (nearly) all new signatures ...
+THRASH_MISSES = 12
+COOLDOWN_CALLS = 256          # ... stops recording for this many calls (known signatures still replay; the rest run eagerly)
+
+
 class Site:
-    """One block call site (e.g. the forward of the Dirac block): its plans by shape signature."""
+    """One block call site (e.g. the forward of the Dirac block): its plans by shape signature.
+
+    Recording a plan costs a dry run of the block's host code (~1 ms) and every plan keeps a launch list in host memory: a
+    caller whose shapes change every step — random ragged batches — must not pay that per step nor grow the table without
+    bound.  Hence: at most MAX_PLANS_PER_SITE signatures per site (least recently used dropped), and a site that keeps
+    missing (THRASH_MISSES of the last THRASH_WINDOW lookups) leaves new signatures to the eager path for COOLDOWN_CALLS calls."""
 
     def __init__(self, name: str):
         self.name = name
-        self.plans = {}
-        self.recorded = self.replayed = self.refused = 0
+        self.plans = collections.OrderedDict()
+        self.recorded = self.replayed = self.refused = self.skipped = 0
         self.reasons = {}
+        self.recent = collections.deque(maxlen=THRASH_WINDOW)
+        self.cooldown = 0
         _SITES.append(self)
 
+    def lookup(self, key):
+        """(plan | None, may_record): the plan of `key` if there is one (None also for a signature that was refused before);
+        may_record says whether a missing one should be recorded now."""
+        plan = self.plans.get(key, self)
+        if plan is not self:
+            self.recent.append(0)
+            if plan is not None:
+                self.plans.move_to_end(key)
+            return plan, False
+        self.recent.append(1)
+        if self.cooldown > 0:
+            self.cooldown -= 1
+            self.skipped += 1
+            return None, False
+        if len(self.recent) == THRASH_WINDOW and sum(self.recent) >= THRASH_MISSES:
+            self.cooldown = COOLDOWN_CALLS
+            self.recent.clear()
+            self.skipped += 1
+            return None, False
+        return None, True
+
+    def store(self, key, plan) -> None:
+        self.plans[key] = plan
+        while len(self.plans) > MAX_PLANS_PER_SITE:
+            self.plans.popitem(last=False)
+
     def refuse(self, key, why: str):
-        self.plans[key] = None
+        self.store(key, None)
         self.refused += 1
         self.reasons[why] = self.reasons.get(why, 0) + 1
         if os.environ.get("SN_STRICT", "0") == "1":
@@ -394,14 +435,16 @@ class Site:
 def stats():
     """{site: {"plans", "recorded", "replayed", "refused", "reasons"}} — bench.py / tests read it."""
     return {s.name: {"plans": sum(1 for p in s.plans.values() if p is not None), "recorded": s.recorded, "replayed": s.replayed,
-                     "refused": s.refused, "reasons": dict(s.reasons)} for s in _SITES}
+                     "refused": s.refused, "skipped": s.skipped, "reasons": dict(s.reasons)} for s in _SITES}
 
 
 def reset() -> None:
     for s in _SITES:
         s.plans.clear()
-        s.recorded = s.replayed = s.refused = 0
+        s.recorded = s.replayed = s.refused = s.skipped = 0
         s.reasons.clear()
+        s.recent.clear()
+        s.cooldown = 0
 
 
 def usable(*tensors) -> bool:
@@ -468,7 +511,7 @@ def record(site: Site, key, impl, args, ext, device) -> Optional[Plan]:
     except PlanError as exc:
         site.refuse(key, str(exc)[:200])
         return None
-    site.plans[key] = plan
+    site.store(key, plan)
     site.recorded += 1
     return plan
 

@@ -118,3 +118,49 @@ def test_dry_run_of_the_blocks_records_launches_only(monkeypatch):
     finally:
         snF.set_dirac_format("q3")
         plans.reset()
+
+
+def test_sites_stop_recording_when_every_call_has_a_new_shape_and_keep_a_bounded_table(monkeypatch):
+    """Random ragged batches: a new signature per call.  The site records a few, notices that nothing comes back, leaves the
+    following calls to the eager path (plans.Site.lookup) — and a table never holds more than MAX_PLANS_PER_SITE plans."""
+    from surfacenetworks_amd import blocks, plans
+    from surfacenetworks_amd import utils_pt as U
+
+    monkeypatch.setattr(plans, "_ALLOW_CPU", True)
+    monkeypatch.setattr(plans.Plan, "run", lambda self, big, small, ext: None)
+    monkeypatch.setattr(plans, "MAX_PLANS_PER_SITE", 6)
+    plans.reset()
+    site = blocks._SITES["avg_fwd"]
+    fell_back = []
+    real = blocks._avg_fwd
+
+    def counting(*a):
+        if plans._lib._recorder is None:
+            fell_back.append(a[0].shape)
+            raise _Eager()
+        return real(*a)
+
+    class _Eager(Exception):
+        pass
+
+    monkeypatch.setattr(blocks, "_avg_fwd", counting)
+    avg = U.AvgResNet2(128)
+    try:
+        for i in range(40):
+            nv = 40 + i                                           # a new shape every call
+            x = torch.randn(1, nv, 128)
+            try:
+                avg(None, torch.ones(1, nv, 1), x)
+            except _Eager:
+                pass
+        st = plans.stats()["avg_fwd"]
+        assert st["recorded"] <= plans.THRASH_WINDOW and st["skipped"] >= 40 - plans.THRASH_WINDOW - 1, st
+        assert len(fell_back) == st["skipped"]
+        assert len(site.plans) <= 6
+        # a shape that was recorded and is still in the table replays even during the cool-down
+        nv = 40 + st["recorded"] - 1
+        before = st["replayed"]
+        avg(None, torch.ones(1, nv, 1), torch.randn(1, nv, 128))
+        assert plans.stats()["avg_fwd"]["replayed"] == before + 1
+    finally:
+        plans.reset()

@@ -154,3 +154,48 @@ def test_plan_entry_table_is_the_launchers_of_the_header():
         want = "".join("p" if a is C.c_void_p else "d" if a in (C.c_double, C.c_float) else "i" for a in args)
         assert sig == want, (name, sig, want)
         assert int(lib.sn_plan_lookup(name.encode())) == i
+
+
+def _one_block(C=128):
+    from surfacenetworks_amd import mesh_ops
+    from surfacenetworks_amd import utils_pt as U
+    from surfacenetworks_amd.operators import SparseOperator
+
+    rng = np.random.default_rng(3)
+    V, F = mesh_ops.grid_cloth(12, 9, rng)
+    ops = mesh_ops.mesh_operators(V, F)
+    L = SparseOperator.from_scipy(ops["L"], DEV)
+    torch.manual_seed(4)
+    blk = U.LapResNet2(C).to(DEV).train()
+    x = torch.randn(1, V.shape[0], C, device=DEV)
+    return blk, L, x
+
+
+def test_second_backward_through_a_planned_block_says_what_to_do():
+    from surfacenetworks_amd import plans
+
+    blk, L, x = _one_block()
+    plans.set_enabled(True)
+    xi = x.clone().requires_grad_(True)
+    loss = blk(L, None, xi).sum()
+    loss.backward(retain_graph=True)
+    with pytest.raises(RuntimeError, match="SN_PLANS=0"):
+        loss.backward()
+
+
+def test_planned_forward_without_a_backward_releases_its_workspace():
+    from surfacenetworks_amd import plans
+
+    blk, L, x = _one_block()
+    plans.set_enabled(True)
+    with torch.no_grad():
+        blk(L, None, x)                                            # records
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
+    for _ in range(5):
+        with torch.no_grad():
+            y = blk(L, None, x)
+        del y
+    torch.cuda.synchronize()
+    assert torch.cuda.memory_allocated() <= base + (1 << 20)       # nothing accumulates over calls
