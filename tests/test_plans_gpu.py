@@ -199,3 +199,48 @@ def test_planned_forward_without_a_backward_releases_its_workspace():
         del y
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() <= base + (1 << 20)       # nothing accumulates over calls
+
+
+def test_a_hand_built_plan_through_the_c_abi_equals_the_two_calls_it_records():
+    """The binding INTEGRATION.md §2 shows: an ELU pass and a CSR product recorded into a plan through ctypes alone, run on new
+    tensors — against the same two entry points called one by one."""
+    import ctypes
+
+    from helpers import mesh_fixture
+    from surfacenetworks_amd import _lib
+
+    lib = _lib.load()
+    _, _, ops = mesh_fixture("cloth")
+    A = ops["L"].tocsr()
+    A.sort_indices()
+    rows, C, nnz = A.shape[0], 64, A.nnz
+    rowptr = torch.from_numpy(A.indptr.astype(np.int32)).to(DEV)
+    colind = torch.from_numpy(A.indices.astype(np.int32)).to(DEV)
+    vals = torch.from_numpy(A.data.astype(np.float32)).to(DEV)
+    plan = ctypes.c_void_p()
+    assert lib.sn_plan_create(ctypes.byref(plan)) == 0
+
+    def add(name, kinds, slots, ivals):
+        n = len(kinds)
+        I32, I64, F64 = ctypes.c_int32 * n, ctypes.c_int64 * n, ctypes.c_double * n
+        st = lib.sn_plan_add_call(plan, lib.sn_plan_lookup(name), n, I32(*kinds), I32(*slots), I64(*ivals), F64())
+        assert st == 0, lib.sn_status_string(st)
+
+    add(b"sn_elu_into_f32", [2, 0, 2, 0, 0, 0, 4], [0, 0, 1, 0, 0, 0, 0], [0, C, 0, 2 * C, rows, C, 0])
+    add(b"sn_spmm_csr_f32", [2, 2, 2, 0, 0, 0, 2, 0, 0, 0, 2, 0, 0, 4], [2, 3, 4, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0],
+        [0, 0, 0, rows, rows, nnz, 0, 2 * C, 1, C, 4 * C, 2 * C, 1, 0])
+    assert lib.sn_plan_length(plan) == 2
+    stream = torch.cuda.current_stream().cuda_stream
+    for seed in (0, 1):                                            # the same plan on new tensors
+        g = torch.Generator(device=DEV).manual_seed(seed)
+        x = torch.randn(rows, C, device=DEV, generator=g)
+        y = torch.full((rows, 2 * C), float("nan"), device=DEV)
+        bases = (ctypes.c_uint64 * 5)(x.data_ptr(), y.data_ptr(), rowptr.data_ptr(), colind.data_ptr(), vals.data_ptr())
+        assert lib.sn_plan_run(plan, bases, 5, stream, None) == 0
+        want = torch.full((rows, 2 * C), float("nan"), device=DEV)
+        _lib.call("sn_elu_into_f32", x.data_ptr(), C, want.data_ptr(), 2 * C, rows, C, stream)
+        _lib.call("sn_spmm_csr_f32", rowptr.data_ptr(), colind.data_ptr(), vals.data_ptr(), rows, rows, nnz, want.data_ptr(), 2 * C, 1, C,
+                  want.data_ptr() + 4 * C, 2 * C, 1, stream)
+        torch.cuda.synchronize()
+        assert torch.equal(y, want) and not torch.isnan(y).any()
+    assert lib.sn_plan_destroy(plan) == 0

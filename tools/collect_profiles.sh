@@ -18,7 +18,7 @@ for w in $what; do case $w in
 tests)
   (cd $root && timeout 2400 python -m pytest tests -q -m gpu 2>&1 | tail -6) > $out/gpu_tests.txt ;;
 bench)
-  (cd $root && timeout 1500 python bench.py > $out/bench_c3_final.json 2> $out/bench_c3_final.err)
+  (cd $root && timeout 1500 python bench.py > $out/bench_c3_final.json 2> $out/bench_c3_final.err; cp bench_detail.json $out/bench_c3_final_detail.json)
   (cd $root && timeout 600 python bench.py --graph --no-cpu-baseline --no-secondary --no-pmc > $out/bench_c3_graph.json 2>/dev/null)
   (cd $root && timeout 600 python bench.py --workload faust > $out/bench_faust_n1.json 2>/dev/null)
   (cd $root && timeout 900 python bench.py --gpus 2 --steps 10 --warmup 3 --no-secondary --no-cpu-baseline > $out/bench_gpus2_gloo_one_device.json 2>/dev/null) ;;
