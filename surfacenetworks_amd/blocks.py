@@ -23,7 +23,7 @@ import weakref
 import torch
 
 from . import kernels, plans
-from .functional import (_launch, _rows2d, product_form, avg_stage_backward, avg_stage_backward_ragged, avg_stage_forward,
+from .functional import (SpmmTimer, _launch, _rows2d, product_form, avg_stage_backward, avg_stage_backward_ragged, avg_stage_forward,
                          avg_stage_forward_ragged, bn_prepare, bnlin_backward,
                          bnlin_backward_elu_input, bnlin_backward_zero_first, bnlin_forward, bnlin_forward_zero_first, stash, unstash,
                          zero_first_supported)
@@ -205,7 +205,12 @@ def _plan_forward(ctx, site, impl, tensors, ops, consts, ncols, n_dyn, scan):
                     slots(v)
         slots(plan.result[1])
         plan.saved_ext = sorted(need)                              # the operands the backward reaches through what was saved
-    big, small = plan.new_arenas()
+    timer = SpmmTimer.active
+    if timer is not None:
+        if plan.tags is None:
+            return None                                            # (a product without a host-side entry count: eager under a timer)
+        timer.tags.extend(plan.tags)
+    big, small = plan.new_arenas(tensors[0].device)
     plan.run(big, small, ext)
     site.replayed += 1
     build = plans._Builder(big, small, ext)
@@ -250,7 +255,16 @@ def _plan_backward(ctx, site, impl, grads, consts):
         for g in grads:                                            # (bounds the dry run did not take)
             if g is not None:
                 kernels.take_absmax(g)
-    b2, s2 = plan.new_arenas()
+    timer = SpmmTimer.active
+    if timer is not None:
+        if plan.tags is None:
+            fext = [None] * fplan.n_ext
+            for j, t in zip(fplan.saved_ext, kept):
+                fext[j] = t
+            plans.renote(grads, maxima)
+            return impl(plans._Builder(big, small, fext)(fplan.result[1]), *[o for o, _ in ops], *grads, *consts)
+        timer.tags.extend(plan.tags)
+    b2, s2 = plan.new_arenas(grads_device(grads, big, small))
     plan.run(b2, s2, ext)
     site.replayed += 1
     build = plans._Builder(b2, s2, ext)

@@ -17,6 +17,7 @@ import os
 
 import torch
 
+from . import _lib as _lib_mod
 from . import kernels
 from .operators import SparseOperator, as_operator
 
@@ -187,9 +188,13 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
     their partials are returned (kernels.spmm_q3_stats / spmm_csr_stats), else None."""
     M, K = op.shape
     timer = SpmmTimer.active
-    if timer is not None:
+    rec = _lib_mod._recorder
+    if timer is not None or rec is not None:
         known = op._nnz_cache if op._nnz_cache is not None else (int(op._csr[1].numel()) if op._csr is not None else None)
-        timer.tags.append((tag, op if known is None else known))
+        if rec is not None:
+            rec.tags.append((tag, known))                # (a launch plan replays its products' tags into an active timer)
+        else:
+            timer.tags.append((tag, op if known is None else known))
     e, g = elubwd if elubwd is not None else (None, None)
     vec = (y.shape[1] // group) in (16, 32, 64, 128)
     kind, arr, _ = product_form(op, group, y.shape[1])

@@ -89,6 +89,7 @@ class _Recorder(TorchDispatchMode):
         self.stray: List[str] = []
         self.notes: List[tuple] = []          # (tensor, maxima) recorded by kernels.note_absmax and not taken again
         self.allow_cpu = _ALLOW_CPU
+        self.tags: List[tuple] = []           # (tag, entry count | None) of every sparse product, in launch order (SpmmTimer)
 
     # -- launches --------------------------------------------------------------------------------------------------------------
     def record_call(self, name, args):
@@ -212,6 +213,9 @@ class Plan:
                 self._add_copy(node[1], node[2], lay)
         self.result = _map_structure(result, lambda t: self._describe(t, lay, rec))
         self.effects = [(lay.describe(t, rec), lay.describe(m, rec)) for t, m in rec.notes]
+        # what a per-launch timer (functional.SpmmTimer) wants to know of this plan's sparse products; None: one of them has no
+        # entry count on the host (the plan then steps aside while a timer runs)
+        self.tags = list(rec.tags) if all(k is not None for _, k in rec.tags) else None
         self.arena_bytes = lay.arena_bytes
         self.n_ext = len(rec.ext)
         self.used_ext = sorted(lay.used_ext)
@@ -306,8 +310,8 @@ class Plan:
             pass
 
     # -- per call ---------------------------------------------------------------------------------------------------------------
-    def new_arenas(self):
-        dev = self.device
+    def new_arenas(self, dev=None):
+        dev = self.device if dev is None else dev
         big = torch.empty(self.arena_bytes[0] // 4, dtype=torch.float32, device=dev) if self.arena_bytes[0] else None
         small = torch.empty(self.arena_bytes[1] // 4, dtype=torch.float32, device=dev) if self.arena_bytes[1] else None
         return big, small
@@ -448,12 +452,12 @@ def reset() -> None:
 
 
 def usable(*tensors) -> bool:
-    """Plans apply: switched on, no per-launch timer running (its tags are appended by the Python launchers), operands on the GPU."""
+    """Plans apply: switched on, no synchronised BatchNorm (its collectives sit between the launches), operands on the GPU."""
     if not _ENABLED:
         return False
-    from .functional import SpmmTimer, _BN_SYNC
+    from .functional import _BN_SYNC
 
-    if SpmmTimer.active is not None or _BN_SYNC is not None:
+    if _BN_SYNC is not None:
         return False
     for t in tensors:
         if t is not None:

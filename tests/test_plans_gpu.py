@@ -244,3 +244,27 @@ def test_a_hand_built_plan_through_the_c_abi_equals_the_two_calls_it_records():
         torch.cuda.synchronize()
         assert torch.equal(y, want) and not torch.isnan(y).any()
     assert lib.sn_plan_destroy(plan) == 0
+
+
+def test_per_launch_timer_sees_the_same_products_through_plans():
+    """functional.SpmmTimer (bench.py's roofline measurement) under launch plans: the plan replays the tags of its sparse
+    products into the active timer, the C-side records come from the same launchers — same list as the eager step's."""
+    from surfacenetworks_amd import arap, functional as snF, plans
+
+    torch.manual_seed(5)
+    ds = arap.ClothSequences([(9, 8)] * 3, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 3, op_frames=3, seed=11, device=DEV, model="dir")
+    model = arap.DirModel().to(DEV).train()
+    opt = arap.make_optimizer(model)
+    got = {}
+    for on in (False, True):
+        plans.set_enabled(on)
+        for _ in range(2):                                         # (with plans: the recording step, then a pure replay)
+            arap.train_step(model, opt, ds.sample_batch(3, np.random.default_rng(1), seq_ids=np.arange(3)), global_batch=3)
+        timer = snF.SpmmTimer()
+        with timer:
+            arap.train_step(model, opt, ds.sample_batch(3, np.random.default_rng(1), seq_ids=np.arange(3)), global_batch=3)
+        recs = timer.results()
+        got[on] = ([r[:5] for r in recs], sorted((k, r, w, o) for k, r, w, o, _b, _ms in timer.linear))
+        assert all(r[5] > 0 for r in recs)
+    assert got[True] == got[False] and len(got[True][0]) == 32     # 8 Dirac blocks x (2 forward + 2 backward products)
+    assert plans.stats()["dirac_fwd"]["replayed"] >= 16
