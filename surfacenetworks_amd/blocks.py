@@ -442,7 +442,7 @@ def dirac_block(mod, Di, DiA, v, f, need_f=True, num_faces=None, avg_next=None):
     v_new, f_out, nxt_v, nxt_f = _DiracBlock.apply(v.reshape(rv, C), f.reshape(rf, C) if f is not None else None, opDi, opDiA,
                                                   take_activated(v, rv, C),
                                                   take_activated(f, rf, C) if f is not None else None, bool(need_f),
-                                                  _wants_tiles(mod, avg_next), *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+                                                  _wants_tiles(mod, avg_next), *_bn_args(mod._modules["bn_fc0"]), *_bn_args(mod._modules["bn_fc1"]))
     _mark_producer(nxt_v, mod, avg_next)
     return attach_activated(v_new.view(B, V, C), nxt_v), attach_activated(f_out.view(B, F_, C), nxt_f)
 
@@ -715,7 +715,7 @@ def _avg_ragged_bwd_u(saved, g_out, *a):
 
 def avg_block_ragged_ok(mod, seg, inputs) -> bool:
     C = inputs.shape[-1]
-    a0, a1 = _bn_args(mod.bn_fc0), _bn_args(mod.bn_fc1)
+    a0, a1 = _bn_args(mod._modules["bn_fc0"]), _bn_args(mod._modules["bn_fc1"])
     return bool(a0[6] and a1[6]) and inputs.dtype == torch.float32 and mod.bn_fc0.fc.weight.shape == (C, 2 * C) and \
         mod.bn_fc1.fc.weight.shape == (C, 2 * C) and kernels.avg_stage_ragged_supported(C, C, seg) and \
         seg.rows == inputs.shape[0] * inputs.shape[1]
@@ -800,7 +800,7 @@ def lap_block(mod, L, inputs, avg_next=None):
     if op.shape != (rows, rows):
         raise ValueError(f"LapResNet2: operator {tuple(op.shape)} vs {rows} rows")
     out, nxt = _PropagateBlock.apply(inputs.reshape(rows, C), op, None, None, 0, take_activated(inputs, rows, C),
-                                     _wants_tiles(mod, avg_next), *_bn_args(mod.bn_fc0), *_bn_args(mod.bn_fc1))
+                                     _wants_tiles(mod, avg_next), *_bn_args(mod._modules["bn_fc0"]), *_bn_args(mod._modules["bn_fc1"]))
     _mark_producer(nxt, mod, avg_next)
     return attach_activated(out.view(B, V, C), nxt)
 
@@ -829,9 +829,8 @@ def avg_block(mod, mask, inputs):
             except AttributeError:
                 pass
     _, mask_rows, inv_count = cached
-    a0, a1 = _bn_args(mod.bn_fc0), _bn_args(mod.bn_fc1)
-    if a0[6] and a1[6] and kernels.avg_stage_supported(C, mod.bn_fc0.fc.weight.shape[0], V) and \
-            mod.bn_fc0.fc.weight.shape[1] == 2 * C and mod.bn_fc1.fc.weight.shape[0] == C:
+    a0, a1 = _bn_args(mod._modules["bn_fc0"]), _bn_args(mod._modules["bn_fc1"])
+    if a0[6] and a1[6] and kernels.avg_stage_supported(C, a0[2].shape[0], V) and a0[2].shape[1] == 2 * C and a1[2].shape[0] == C:
         pre = take_activated(inputs, rows, C)
         _learn_avg_next(pre, rows)
         out, nxt = _AvgBlock.apply(inputs.reshape(rows, C), mask_rows, inv_count, B, pre, *a0, *a1)

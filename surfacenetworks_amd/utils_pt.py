@@ -159,12 +159,17 @@ class GraphBatchNorm(nn.Module):
 
 def _blocks_ok(mod, x) -> bool:
     """Whole-block path (blocks.py): fp32, default affine BatchNorm with a fixed momentum, channel count the vector kernels
-    take.  Everything else goes through the per-stage functions."""
+    take.  Everything else goes through the per-stage functions.  (Sub-modules and flags are read from the instances' own
+    dictionaries: nn.Module.__getattr__ is a Python-level search, a dozen of them cost more than the rest of this check.)"""
     c = x.shape[-1]
     if not USE_WHOLE_BLOCKS or x.dtype != torch.float32 or c % 4 or 256 % (c // 4):
         return False
-    return all(conv.bn.affine and conv.bn.momentum is not None and conv.bn.track_running_stats
-               for conv in (mod.bn_fc0, mod.bn_fc1))
+    mods = mod.__dict__["_modules"]
+    for name in ("bn_fc0", "bn_fc1"):
+        bn = mods[name].__dict__["_modules"]["bn"].__dict__
+        if not (bn["affine"] and bn["momentum"] is not None and bn["track_running_stats"]):
+            return False
+    return True
 
 
 USE_WHOLE_BLOCKS = True     # set False to run the per-stage autograd functions (functional.py) instead — for A/B tests
