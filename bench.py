@@ -1081,7 +1081,7 @@ def main():
     # figure is withheld (traffic: null) instead of quoted stale.
     traffic = traffic_src = None
     step_traffic = None
-    pmc_file = os.path.join("profiles", "r5_pmc_traffic_c3.json")
+    pmc_file = os.path.join("profiles", "r6_pmc_traffic_c3.json")
     table, in_run_note = (None, "not requested")
     if rank == 0 and world == 1 and not args.no_pmc:
         # release the device memory of the timed run first: the counter passes are child processes on the same GPU
