@@ -1160,34 +1160,83 @@ __global__ __launch_bounds__(kWG) void avg_bwd_segvec_k(const float *__restrict_
 // A global-average stage's  avg_bwd_gc_k -> bn_bwd_coeffs_k -> avg_bwd_segvec_k  in ONE launch (sn_avg_bn_bwd_f32): each of the
 // three is per channel — the broadcast half of G, the BatchNorm sums over j, the per-mesh vector of the mean path —, so the
 // workgroup that owns 32 channels runs all three for them; nothing passes between workgroups (no ticket, no fence).  Same
-// operands, same order of every sum as the three kernels: bit-identical (tests/test_dense_gpu.py).  grid 2 C / 32; the first
-// C / 32 workgroups are bn_bwd_coeffs_k over G1, the others also form their columns of the broadcast half (64 meshes at a time
-// through LDS) before and the per-mesh vector after.
+// operands, same order of every sum as the three kernels: bit-identical (tests/test_dense_gpu.py).  Grid: the first C / 32
+// workgroups are bn_bwd_coeffs_k over G1; then (C / 32) x nchunk workgroups for the broadcast half: workgroup (channel block, mesh
+// chunk q) forms its 32 columns of the broadcast half of G (all meshes, 64 at a time through LDS) and the coefficients —
+// every chunk redundantly (a few thousand FMAs), chunk 0 writes them — and then the per-mesh vector of ITS meshes
+// [q mpc, (q + 1) mpc): the 128-term dot products per (mesh, channel) are what the launch costs, eight meshes in flight per
+// workgroup; with one workgroup per channel block (round 4) 64 meshes were eight serial rounds and the merged launch lost to
+// the three it replaces beyond 8 meshes.
 __global__ __launch_bounds__(kWG) void avg_bn_bwd_k(const float *__restrict__ G1, const double *__restrict__ sdy,
                                                     const float *__restrict__ Sg, const float *__restrict__ m,
                                                     const float *__restrict__ mu2v, const float *__restrict__ W,
                                                     const float *__restrict__ s, const float *__restrict__ invstd,
                                                     const float *__restrict__ beta, int64_t rows, int J, int C, int nseg,
                                                     const float *__restrict__ Wf2, int64_t ldw, const float *__restrict__ inv_count,
-                                                    double per, const int64_t *__restrict__ segoff, float *__restrict__ dW,
+                                                    double per, const int64_t *__restrict__ segoff, int mpc /* meshes per chunk */, float *__restrict__ dW,
                                                     float *__restrict__ db, float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                     float *__restrict__ Bc, float *__restrict__ Cc, float *__restrict__ segvec) {
   __shared__ double sa[8][32], sp[8][32];
-  __shared__ float s_sg[64][129];                // per-mesh column sums of dy, 64 meshes at a time
+  // per-mesh column sums of dy, 64 meshes at a time, columns PERMUTED: column j sits at (j % 8) * 16 + j / 8, so that the 16
+  // rows j = gq, gq + 8, ... a lane group owns are 16 consecutive floats (four 16-byte LDS reads per mesh instead of sixteen)
+  __shared__ __attribute__((aligned(16))) float s_sg[64][132];
   __shared__ float s_m[64][33];                  // per-mesh means of my 32 channels, the same meshes
   __shared__ float s_wf[128][33];                // my 32 columns of Wf2
   __shared__ float s_b[32], s_c[32];
   const int tid = threadIdx.x, cl = tid & 31, gq = tid >> 5;
   const int Ct = 2 * C;
-  const int c = blockIdx.x * 32 + cl;            // < Ct (C % 32 == 0)
-  const bool first = (int)blockIdx.x * 32 < C;   // (workgroup-uniform)
-  const int c2 = c - C;
+  // ng meshes' column sums of dy (ng x J floats from Sg row g0 on) into s_sg: eight loads in flight per thread, then the stores —
+  // issued one by one (a load, its index arithmetic, its LDS store per iteration) the 8 192 values of 64 meshes were 32
+  // dependent round trips to memory: 30 of the launch's 57 us at 64 meshes
+  auto stage_sg = [&](int g0, int ng) {
+    const int n = ng * J;
+    const float *src = Sg + (int64_t)g0 * J;
+    for (int base = 0; base < n; base += 8 * kWG) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * kWG + tid;
+        v[u] = i < n ? src[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = base + u * kWG + tid;
+        if (i < n) {
+          const int j = i % J;
+          s_sg[i / J][(j & 7) * 16 + (j >> 3)] = v[u];
+        }
+      }
+    }
+  };
+  const int nfirst = C / 32;                     // (C % 32 == 0)
+  const bool first = (int)blockIdx.x < nfirst;   // (workgroup-uniform)
+  const int cb = first ? (int)blockIdx.x : ((int)blockIdx.x - nfirst) % nfirst;     // 32-channel block inside my half
+  const int q = first ? 0 : ((int)blockIdx.x - nfirst) / nfirst;                    // my mesh chunk
+  const int c2 = cb * 32 + cl;                   // channel inside the half
+  const int c = (first ? 0 : C) + c2;            // < Ct
+  const bool writer = first || q == 0;           // (the chunks of one channel block all hold the same coefficients)
   if (blockIdx.x == 0 && db)
     for (int j = tid; j < J; j += kWG) db[j] = (float)sdy[j];
+  // Everything that depends on nothing is requested FIRST — the coefficient operands of my 16 rows (W, colsum(dy)) and, for the
+  // broadcast half, my 32 columns of Wf2 —: the launch is a chain of load -> LDS -> barrier round trips (2-3 us each), and
+  // these used to start only after the meshes had been walked.
+  float wv[16];
+  double sd[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {                 // (row index clamped, not branched on: a branch per row serialises the loads)
+    const int j = gq + 8 * i, jj = j < J ? j : J - 1;
+    wv[i] = W[(int64_t)jj * Ct + c];
+    sd[i] = sdy[jj];
+  }
+  if (!first)
+    for (int i = tid; i < J * 32; i += kWG) s_wf[i >> 5][i & 31] = Wf2[(int64_t)(i >> 5) * ldw + cb * 32 + (i & 31)];
   float gv[16];                                  // G of my channel in rows gq, gq + 8, ... (J <= 128)
   if (first) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) gv[i] = gq + 8 * i < J ? G1[(int64_t)(gq + 8 * i) * C + c] : 0.f;
+    for (int i = 0; i < 16; ++i) {               // (row index clamped, not branched on: sixteen loads in flight)
+      const int j = gq + 8 * i;
+      gv[i] = G1[(int64_t)(j < J ? j : J - 1) * C + c];
+    }
   } else {
     double acc[16];
 #pragma unroll
@@ -1196,14 +1245,18 @@ __global__ __launch_bounds__(kWG) void avg_bn_bwd_k(const float *__restrict__ G1
     for (int g0 = 0; g0 < nseg; g0 += 64) {
       const int ng = nseg - g0 < 64 ? nseg - g0 : 64;
       __syncthreads();
-      for (int i = tid; i < ng * J; i += kWG) s_sg[i / J][i % J] = Sg[(int64_t)g0 * J + i];
-      for (int i = tid; i < ng * 32; i += kWG) s_m[i >> 5][i & 31] = m[(int64_t)(g0 + (i >> 5)) * C + (int)blockIdx.x * 32 - C + (i & 31)];
+      stage_sg(g0, ng);
+      for (int i = tid; i < ng * 32; i += kWG) s_m[i >> 5][i & 31] = m[(int64_t)(g0 + (i >> 5)) * C + cb * 32 + (i & 31)];
       __syncthreads();
       for (int k = 0; k < ng; ++k) {             // meshes in ascending order: avg_bwd_gc_k's sum
         const double d = (double)s_m[k][cl] - mu;
+        // all 16 rows unconditionally (rows >= J read staging space nobody wrote and feed accumulators nobody reads): a
+        // condition per row made every LDS read wait for the previous one's branch — 43 of the launch's 57 us at 64 meshes
+        const f4 *r = reinterpret_cast<const f4 *>(&s_sg[k][gq * 16]);
+        const f4 v0 = r[0], v1 = r[1], v2 = r[2], v3 = r[3];
+        const float sv[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
 #pragma unroll
-        for (int i = 0; i < 16; ++i)
-          if (gq + 8 * i < J) acc[i] += (double)s_sg[k][gq + 8 * i] * d;
+        for (int i = 0; i < 16; ++i) acc[i] += (double)sv[i] * d;
       }
     }
 #pragma unroll
@@ -1213,14 +1266,15 @@ __global__ __launch_bounds__(kWG) void avg_bn_bwd_k(const float *__restrict__ G1
   double a = 0, p = 0;
   {
     const double sc = s[c], bc = beta[c];
+    // (operands loaded above; the sums in bn_bwd_coeffs_k's order)
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const int j = gq + 8 * i;
       if (j < J) {
-        const double w = W[(int64_t)j * Ct + c], gg = gv[i];
-        a += sdy[j] * w;
+        const double w = wv[i], gg = gv[i];
+        a += sd[i] * w;
         p += w * gg;
-        dW[(int64_t)j * Ct + c] = (float)(gg * sc + sdy[j] * bc);
+        if (writer) dW[(int64_t)j * Ct + c] = (float)(gg * sc + sd[i] * bc);
       }
     }
   }
@@ -1236,29 +1290,35 @@ __global__ __launch_bounds__(kWG) void avg_bn_bwd_k(const float *__restrict__ G1
     }
     const double sc = s[c], is = invstd[c];
     const double dg = is * pt;
-    dgamma[c] = (float)dg;
-    dbeta[c] = (float)at;
     const float bq = (float)(-(sc * is * dg) / (double)rows), cq = (float)(-(sc * at) / (double)rows);
-    Bc[c] = bq;
-    Cc[c] = cq;
+    if (writer) {
+      dgamma[c] = (float)dg;
+      dbeta[c] = (float)at;
+      Bc[c] = bq;
+      Cc[c] = cq;
+    }
     s_b[cl] = bq;
     s_c[cl] = cq;
   }
   if (first) return;
   // ---- avg_bwd_segvec_k for my 32 channels: segvec[g][c2] = inv_count[g] (sum_j Sg[g][j] Wf2[j][c2] + per ((m - mu2) B2 + C2)) ----
-  for (int i = tid; i < J * 32; i += kWG) s_wf[i >> 5][i & 31] = Wf2[(int64_t)(i >> 5) * ldw + (int)blockIdx.x * 32 - C + (i & 31)];
   const double mu = (double)mu2v[c2];
-  for (int g0 = 0; g0 < nseg; g0 += 64) {
-    const int ng = nseg - g0 < 64 ? nseg - g0 : 64;
+  const int g_lo = q * mpc, g_hi = g_lo + mpc < nseg ? g_lo + mpc : nseg;        // my meshes
+  const bool resident = nseg <= 64;              // the one staging round above holds every mesh: rows g_lo .. of s_sg / s_m are mine
+  for (int g0 = g_lo; g0 < g_hi; g0 += 64) {
+    const int ng = g_hi - g0 < 64 ? g_hi - g0 : 64;
     __syncthreads();                             // (s_b, s_c, s_wf written; the tiles of the previous round read)
-    for (int i = tid; i < ng * J; i += kWG) s_sg[i / J][i % J] = Sg[(int64_t)g0 * J + i];
-    for (int i = tid; i < ng * 32; i += kWG) s_m[i >> 5][i & 31] = m[(int64_t)(g0 + (i >> 5)) * C + (int)blockIdx.x * 32 - C + (i & 31)];
-    __syncthreads();
-    for (int k = gq; k < ng; k += 8) {
-      const int g = g0 + k;
+    if (!resident) {
+      stage_sg(g0, ng);
+      for (int i = tid; i < ng * 32; i += kWG) s_m[i >> 5][i & 31] = m[(int64_t)(g0 + (i >> 5)) * C + cb * 32 + (i & 31)];
+      __syncthreads();
+    }
+    const int r0 = resident ? g0 : 0;            // staging row of mesh g0
+    for (int kk = gq; kk < ng; kk += 8) {
+      const int g = g0 + kk, k = r0 + kk;
       double acc = 0;
 #pragma unroll 16
-      for (int j = 0; j < J; ++j) acc += (double)s_sg[k][j] * (double)s_wf[j][cl];
+      for (int j = 0; j < J; ++j) acc += (double)s_sg[k][(j & 7) * 16 + (j >> 3)] * (double)s_wf[j][cl];
       const double pr = segoff ? (double)(segoff[g + 1] - segoff[g]) : per;
       acc += pr * (((double)s_m[k][cl] - mu) * (double)s_b[cl] + (double)s_c[cl]);
       segvec[(int64_t)g * C + c2] = (float)(acc * (double)inv_count[g]);
@@ -2865,9 +2925,14 @@ int sn_avg_bn_bwd_f32(const float *G1, const double *dystats, const float *seg_d
   if (!G1 || !dystats || !seg_dy || !seg_mean || !mu2 || !W || !s || !invstd || !beta || !Wf2 || !inv_count || !dW || !dgamma ||
       !dbeta || !Bc || !Cc || !segvec)
     return SN_E_NULL;
-  hipLaunchKernelGGL(avg_bn_bwd_k, dim3((unsigned)(2 * C / 32)), dim3(kWG), 0, static_cast<hipStream_t>(stream), G1, dystats, seg_dy,
-                     seg_mean, mu2, W, s, invstd, beta, rows, (int)J, (int)C, (int)nseg, Wf2, ldw, inv_count, (double)rows_per_seg,
-                     segoff, dW, db, dgamma, dbeta, Bc, Cc, segvec);
+  // mesh chunks of the broadcast half: eight meshes per workgroup (one per 32-lane group) up to 64 chunks, more per chunk beyond
+  int64_t nch = (nseg + 7) / 8;
+  if (nch > 64) nch = 64;
+  const int mpc = (int)(((nseg + nch - 1) / nch + 7) / 8 * 8);
+  nch = (nseg + mpc - 1) / mpc;
+  hipLaunchKernelGGL(avg_bn_bwd_k, dim3((unsigned)((C / 32) * (1 + nch))), dim3(kWG), 0, static_cast<hipStream_t>(stream), G1, dystats,
+                     seg_dy, seg_mean, mu2, W, s, invstd, beta, rows, (int)J, (int)C, (int)nseg, Wf2, ldw, inv_count,
+                     (double)rows_per_seg, segoff, mpc, dW, db, dgamma, dbeta, Bc, Cc, segvec);
   return launch_status();
 }
 

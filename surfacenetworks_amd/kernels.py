@@ -940,15 +940,23 @@ def avg_stats_ragged(m, seg, part, nblk: int):
     return stats
 
 
+AVG_BWD_MERGE_MAX = 64        # meshes up to which a global-average stage's backward trio runs as one launch (A/B below)
+
+
 def avg_merged_supported(J: int, C: int, nseg: int, which: int = 1) -> bool:
     """Shapes for which a global-average stage folds its per-mesh bias into the fold launch (bn_fold_seg, which = 1) / runs gc +
-    coefficients + per-mesh vector of its backward as one launch (avg_bn_bwd, which = 2)."""
+    coefficients + per-mesh vector of its backward as one launch (avg_bn_bwd, which = 2).
 
-    # The merged launches run per-channel (backward) / per-output-row (forward) work that the separate kernels spread over many
-    # more workgroups: they win while the per-mesh algebra is small.  Same box, config-3 step (64 meshes): forward merge 18.94 ->
-    # 18.89 ms, backward merge 18.94 -> 19.63 (its 4 workgroups of the broadcast half walk 64 meshes x 128 rows each); FAUST pair
-    # (one mesh per tower) with both 3.44 -> 3.35 ms.  Hence: forward up to 64 meshes, backward up to 8.
-    lim = 64 if which == 1 else 8
+    The merged launches run per-channel (backward) / per-output-row (forward) work that the separate kernels spread over many
+    more workgroups: they win while the per-mesh algebra is small.  Forward: up to 64 meshes (round 4: config-3 step 18.94 ->
+    18.89 ms).  Backward: round 4's kernel lost beyond 8 meshes (57 us at 64 against 19.7 us for the three launches); round 6
+    found why — a branch per row serialised its LDS reads and its operand loads, one workgroup per channel block walked every
+    mesh's dot product — and the kernel now costs 10 us at one mesh (15), 21 us at 64: same-box config-3 steps 6.84 -> 6.79 ms at
+    16 meshes, 10.97 -> 10.94 at 32, 19.26 -> 19.25 at 64 (28 launches fewer per step), FAUST pair replayed 3.39 -> 3.28 ms.
+    One staging round of the kernel holds 64 meshes: the limit."""
+    from . import kernels as _self      # (the limit is read through the module so that tests / tools can move it)
+
+    lim = 64 if which == 1 else _self.AVG_BWD_MERGE_MAX
     return J <= 128 and C % 32 == 0 and 2 * C <= 256 and 0 < nseg <= lim
 
 
