@@ -251,6 +251,7 @@ def _plan_backward(ctx, site, impl, grads, consts):
                             grads_device(grads, big, small))
         fplan.bwd[key] = plan
         if plan is None:
+            plans.renote(grads, maxima)                            # (the dry run took them)
             return impl(saved, *[o for o, _ in ops], *grads, *consts)
         for g in grads:                                            # (bounds the dry run did not take)
             if g is not None:

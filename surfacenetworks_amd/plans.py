@@ -26,7 +26,7 @@ import bisect
 import collections
 import ctypes as C
 import os
-from typing import Any, List, Optional, Sequence
+from typing import List, Optional, Sequence
 
 import torch
 from torch.utils._python_dispatch import TorchDispatchMode
@@ -465,10 +465,6 @@ def usable(*tensors) -> bool:
     return False
 
 
-def sig(t: Optional[torch.Tensor]):
-    return None if t is None else (t.shape, t.stride(), t.dtype)
-
-
 def expand_ext(tensors: Sequence[Optional[torch.Tensor]], scan: Sequence[int]):
     """(ext list, key part): the tensors themselves followed by the `_sn_*` tensor attributes riding on those at the positions
     `scan` (the block's features — statistics partials / tile sums of an activated hand-off — and the running-mean buffers —
@@ -518,11 +514,6 @@ def record(site: Site, key, impl, args, ext, device) -> Optional[Plan]:
     site.store(key, plan)
     site.recorded += 1
     return plan
-
-
-def absmax_operands(grads: Sequence[Optional[torch.Tensor]]):
-    """The maxima riding on incoming gradient tensors (kernels.note_absmax), TAKEN from the table: [(maxima | None)]."""
-    return [kernels.take_absmax(g) if g is not None else None for g in grads]
 
 
 def renote(grads, maxima) -> None:

@@ -30,7 +30,7 @@ from __future__ import annotations
 
 import os
 import weakref
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import torch
