@@ -388,7 +388,8 @@ class _DiracBlock(torch.autograd.Function):
         ctx._sn_plan = None
         if plans.usable(v):
             outs = _plan_forward(ctx, _SITES["dirac_fwd"], _dirac_fwd, tensors, ((opDi, 4), (opDiA, 4)), consts, v.shape[1], 4, (2, 3, 8, 14))
-            _drop_counters(rm0, rm1)
+            if outs is not None:
+                _drop_counters(rm0, rm1)
         ctx._sn_planned = outs is not None
         if outs is None:
             outs, saved = _dirac_fwd(*tensors, opDi, opDiA, *consts)
@@ -523,7 +524,8 @@ class _PropagateBlock(torch.autograd.Function):
         outs = None
         if op is not None and plans.usable(x):          # (the full-width average stage multiplies by 1/count with a torch op)
             outs = _plan_forward(ctx, _SITES["propagate_fwd"], _propagate_fwd, tensors, ((op, 1),), consts, x.shape[1], 4, (1, 8, 14))
-            _drop_counters(rm0, rm1)
+            if outs is not None:
+                _drop_counters(rm0, rm1)
         ctx._sn_planned = outs is not None
         if outs is None:
             outs, saved = _propagate_fwd(*tensors, op, *consts)
@@ -593,7 +595,8 @@ class _AvgBlock(torch.autograd.Function):
         outs = None
         if plans.usable(x):
             outs = _plan_forward(ctx, _SITES["avg_fwd"], _avg_fwd, tensors, (), consts, x.shape[1], 4, (1, 8, 14))
-            _drop_counters(rm0, rm1)
+            if outs is not None:
+                _drop_counters(rm0, rm1)
         ctx._sn_planned = outs is not None
         if outs is None:
             outs, saved = _avg_fwd(*tensors, *consts)
@@ -665,7 +668,8 @@ class _AvgBlockRagged(torch.autograd.Function):
         outs = None
         if plans.usable(x):
             outs = _plan_forward(ctx, _SITES["avg_ragged_fwd"], _avg_ragged_fwd_u, tensors, (), consts, x.shape[1], 2, (1, 6, 12))
-            _drop_counters(rm0, rm1)
+            if outs is not None:
+                _drop_counters(rm0, rm1)
         ctx._sn_planned = outs is not None
         if outs is None:
             outs, saved = _avg_ragged_fwd(*tensors, seg, seg_key, mo0, ep0, mo1, ep1)
@@ -762,7 +766,8 @@ class _EluConv(torch.autograd.Function):
         outs = None
         if plans.usable(v):
             outs = _plan_forward(ctx, _SITES["elu_conv_fwd"], _elu_conv_fwd, tensors, (), consts, v.shape[1], 2, (1, 6))
-            _drop_counters(rm0)
+            if outs is not None:
+                _drop_counters(rm0)
         ctx._sn_planned = outs is not None
         if outs is None:
             outs, saved = _elu_conv_fwd(*tensors, *consts)
