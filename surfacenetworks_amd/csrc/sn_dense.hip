@@ -1359,6 +1359,10 @@ __global__ __launch_bounds__(kWG) void segsum_tiles_k(const float *__restrict__ 
     for (int64_t i = 0; i < (nt + 31) / 32 * 32; i += 32) {      // (uniform trip count: the vote below needs the whole wave)
       const int64_t t = t0 + i + tl;
       bool clean = true;
+      // the tile's stored sums are requested BEFORE its mask values are known (used only for a clean tile): asked for after
+      // the vote, every round of 32 tiles was two dependent memory round trips
+      f4 tv = {0.f, 0.f, 0.f, 0.f};
+      if (t < t1) tv = *reinterpret_cast<const f4 *>(tile_sums + t * 128 + c);
       if (mask) {
         // the tile's 32 mask values: one 16-byte piece per chunk lane, combined by a vote among the 8 lanes of the tile
         bool mine = true;
@@ -1371,8 +1375,7 @@ __global__ __launch_bounds__(kWG) void segsum_tiles_k(const float *__restrict__ 
       }
       if (t >= t1) continue;
       if (clean) {
-        const f4 v = *reinterpret_cast<const f4 *>(tile_sums + t * 128 + c);
-        s[0] += (double)v.x; s[1] += (double)v.y; s[2] += (double)v.z; s[3] += (double)v.w;
+        s[0] += (double)tv.x; s[1] += (double)tv.y; s[2] += (double)tv.z; s[3] += (double)tv.w;
       } else {
         rows_from_e(32 * t, 32 * t + 32);                        // (a tile with masked-out rows: one per mesh with prefix masks)
       }
