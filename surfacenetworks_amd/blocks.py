@@ -378,9 +378,9 @@ class _DiracBlock(torch.autograd.Function):
     def forward(ctx, v, f, opDi, opDiA, pre_v, pre_f, need_f, avg_next, g0, b0, W0, c0, rm0, rv0, tr0, mo0, ep0, g1, b1, W1, c1,
                 rm1, rv1, tr1, mo1, ep1):
         v = _rows2d(v)
-        if f is not None:
-            f = _rows2d(f)
-        ctx.f_zero = f is None
+        if f is not None and pre_f is None:
+            f = _rows2d(f)                     # (with a hand-off f is only a carrier — possibly the zero-stride NaN placeholder of
+        ctx.f_zero = f is None                 #  need_f=False: making THAT contiguous wrote 321 MB per block at the ARAP batch)
         ctx.ops = (opDi, opDiA)
         tensors = (v, f, pre_v, pre_f, g0, b0, W0, c0, rm0, rv0, g1, b1, W1, c1, rm1, rv1)
         consts = (need_f, avg_next, tr0, mo0, ep0, tr1, mo1, ep1)

@@ -135,7 +135,7 @@ class _Layout:
         for n in self.sizes:
             a = 0 if n >= _BIG_BYTES else 1
             self.where.append((a, tot[a]))
-            tot[a] += (n + _ALIGN - 1) // _ALIGN * _ALIGN
+            tot[a] += (n + _ALIGN - 1) // _ALIGN * _ALIGN        # (2 MiB alignment of the large ones measured: no effect on the step)
         self.arena_bytes = tuple(tot)
         self.ext = []
         for j, t in enumerate(rec.ext):

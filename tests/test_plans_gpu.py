@@ -286,3 +286,34 @@ def test_a_block_whose_plan_is_refused_runs_exactly_the_eager_path(monkeypatch):
     st = plans.stats()
     assert st["propagate_fwd"]["refused"] == 1 and st["propagate_fwd"]["replayed"] == 0
     assert int(blk.bn_fc0.bn.num_batches_tracked) == 3 and int(blk.bn_fc1.bn.num_batches_tracked) == 3
+
+
+def test_the_placeholder_face_features_are_never_materialised():
+    """need_f=False hands the next Dirac block a zero-stride NaN placeholder as `f` (the activated hand-off carries the values):
+    nothing may make it contiguous — a (faces, C) copy per block, 321 MB at the ARAP batch (a round-6 regression, found by a
+    same-box A/B against the round-5 tree: +0.33 ms per step)."""
+    from surfacenetworks_amd import arap, plans
+
+    torch.manual_seed(5)
+    ds = arap.ClothSequences([(9, 8)] * 2, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 3, op_frames=3, seed=11, device=DEV, model="dir")
+    model = arap.DirModel().to(DEV).train()
+    opt = arap.make_optimizer(model)
+    batch = ds.sample_batch(2, np.random.default_rng(1), seq_ids=np.arange(2))
+    arap.train_step(model, opt, batch, global_batch=2)
+    orig = torch.Tensor.contiguous
+    copies = []
+
+    def spy(self, *a, **k):
+        if not self.is_contiguous() and self.dim() == 2 and self.stride() == (0, 0):
+            copies.append(tuple(self.shape))
+        return orig(self, *a, **k)
+
+    torch.Tensor.contiguous = spy
+    try:
+        for on in (True, False):
+            plans.set_enabled(on)
+            arap.train_step(model, opt, ds.sample_batch(2, np.random.default_rng(1), seq_ids=np.arange(2)), global_batch=2)
+    finally:
+        torch.Tensor.contiguous = orig
+        plans.set_enabled(True)
+    assert copies == []
