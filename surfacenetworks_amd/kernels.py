@@ -940,7 +940,7 @@ def avg_stats_ragged(m, seg, part, nblk: int):
     return stats
 
 
-AVG_BWD_MERGE_MAX = 64        # meshes up to which a global-average stage's backward trio runs as one launch (A/B below)
+AVG_BWD_MERGE_MAX = 32        # meshes up to which a global-average stage's backward trio runs as one launch (A/B below)
 
 
 def avg_merged_supported(J: int, C: int, nseg: int, which: int = 1) -> bool:
@@ -952,8 +952,9 @@ def avg_merged_supported(J: int, C: int, nseg: int, which: int = 1) -> bool:
     18.89 ms).  Backward: round 4's kernel lost beyond 8 meshes (57 us at 64 against 19.7 us for the three launches); round 6
     found why — a branch per row serialised its LDS reads and its operand loads, one workgroup per channel block walked every
     mesh's dot product — and the kernel now costs 10 us at one mesh (15), 21 us at 64: same-box config-3 steps 6.84 -> 6.79 ms at
-    16 meshes, 10.97 -> 10.94 at 32, 19.26 -> 19.25 at 64 (28 launches fewer per step), FAUST pair replayed 3.39 -> 3.28 ms.
-    One staging round of the kernel holds 64 meshes: the limit."""
+    16 meshes, 10.97 -> 10.94 at 32, FAUST pair replayed 3.39 -> 3.28 ms.  At 64 meshes the one launch (21.0 us) and the three
+    (19.6 us) are level within the noise of a step (19.26 / 19.25 ms) and the trace puts the three 1.3 us ahead per stage: the
+    limit stays at 32."""
     from . import kernels as _self      # (the limit is read through the module so that tests / tools can move it)
 
     lim = 64 if which == 1 else _self.AVG_BWD_MERGE_MAX
