@@ -18,6 +18,8 @@
 
 // per-launch timing shared with sn_kernels.hip (the facility behind sn_timing_*)
 int sn_internal_cu_count();
+hipError_t sn_internal_fill(void *dst, int value, size_t bytes, hipStream_t s);
+hipError_t sn_internal_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch, int64_t width, int64_t rows, hipStream_t s);
 bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e);
 
 namespace {
@@ -2537,8 +2539,8 @@ static int colstats_launch(const float *x, int64_t ld, int64_t rows, int32_t C, 
   if (!out) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (rows == 0) {
-    hipError_t e = hipMemsetAsync(out + out_off, 0, (size_t)C * sizeof(double), s);
-    if (e == hipSuccess) e = hipMemsetAsync(out + out_ld + out_off, 0, (size_t)C * sizeof(double), s);
+    hipError_t e = sn_internal_fill(out + out_off, 0, (size_t)C * sizeof(double), s);
+    if (e == hipSuccess) e = sn_internal_fill(out + out_ld + out_off, 0, (size_t)C * sizeof(double), s);
     return e == hipSuccess ? SN_OK : (int)e;
   }
   if (!x || !workspace) return SN_E_NULL;
@@ -2621,8 +2623,8 @@ static int wgrad_launch(const float *dy, int64_t lddy, const float *x, int64_t l
   if (segmented && (!x3 || !dysum || !seg_dysum || rows % rows_per_seg)) return x3 ? SN_E_SHAPE : SN_E_UNSUPPORTED;
   if (ragged && (nslab_tab < 1 || nseg_tab < 1 || !seg_slab_ptr || !dysum || !seg_dysum)) return SN_E_SHAPE;
   if (rows == 0) {
-    hipError_t e = hipMemsetAsync(G, 0, (size_t)J * C * sizeof(float), s);
-    if (e == hipSuccess && dysum) e = hipMemsetAsync(dysum, 0, (size_t)J * sizeof(double), s);
+    hipError_t e = sn_internal_fill(G, 0, (size_t)J * C * sizeof(float), s);
+    if (e == hipSuccess && dysum) e = sn_internal_fill(dysum, 0, (size_t)J * sizeof(double), s);
     return e == hipSuccess ? SN_OK : (int)e;
   }
   if (!dy || !x || !workspace) return SN_E_NULL;
@@ -2779,8 +2781,8 @@ int sn_wgrad_thin_f32(const float *dy, int64_t lddy, const float *x, int64_t ldx
   if (!G) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (rows == 0) {
-    hipError_t e = hipMemsetAsync(G, 0, (size_t)J * C * sizeof(float), s);
-    if (e == hipSuccess && db) e = hipMemsetAsync(db, 0, (size_t)J * sizeof(float), s);
+    hipError_t e = sn_internal_fill(G, 0, (size_t)J * C * sizeof(float), s);
+    if (e == hipSuccess && db) e = sn_internal_fill(db, 0, (size_t)J * sizeof(float), s);
     return e == hipSuccess ? SN_OK : (int)e;
   }
   if (!dy || !x || !workspace) return SN_E_NULL;
@@ -3131,7 +3133,7 @@ int sn_masked_smooth_l1_fwd_f32(const float *out, int64_t ldo, const float *targ
   if (!loss) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (rows == 0) {
-    const hipError_t e = hipMemsetAsync(loss, 0, sizeof(float), s);
+    const hipError_t e = sn_internal_fill(loss, 0, sizeof(float), s);
     return e == hipSuccess ? SN_OK : (int)e;
   }
   if (!out || !target || !workspace) return SN_E_NULL;
@@ -3254,7 +3256,7 @@ int sn_pair_fused_fwd_f32(const float *FA, int64_t lda, const float *FB, int64_t
   if (workspace_bytes < sn_pair_fused_workspace_bytes(rowsA, rowsB)) return SN_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const PairWs w = pair_ws(workspace, rowsA, rowsB);
-  hipError_t e = hipMemsetAsync(w.header, 0, kPairHeader, s);
+  hipError_t e = sn_internal_fill(w.header, 0, kPairHeader, s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(pair_maxabs_k, dim3((unsigned)std::min<int64_t>(1024, (std::max(rowsA, rowsB) * K + 4 * kWG - 1) / (4 * kWG)), 2), dim3(kWG), 0, s, FA, lda, (int)rowsA, FB, ldb, (int)rowsB, (int)K, w.header);
   const int64_t quads = (int64_t)std::max(w.pa, w.pb) * 32;

@@ -22,6 +22,8 @@
 
 // per-launch timing shared with sn_kernels.hip (the facility behind sn_timing_*)
 int sn_internal_cu_count();
+hipError_t sn_internal_fill(void *dst, int value, size_t bytes, hipStream_t s);
+hipError_t sn_internal_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch, int64_t width, int64_t rows, hipStream_t s);
 bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e);
 
 namespace {
@@ -1206,7 +1208,7 @@ int sn_linear_dgrad_elu_absmax_f32(const float *dy, int64_t lddy, const float *W
   if (J > 128 || (J % 4) || (C != 128 && C != 256) || gemm_variant() == 0 || !ld32(lddy, ldx, lddx, ldga, ldgadd))
     return SN_E_UNSUPPORTED;
   if (rows == 0) {                     // nothing to launch; the bound of an empty operand is 0
-    if (gact_absmax && hipMemsetAsync(gact_absmax, 0, kAbsmaxBlocks * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
+    if (gact_absmax && sn_internal_fill(gact_absmax, 0, kAbsmaxBlocks * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
       return (int)hipGetLastError();
     return SN_OK;
   }
@@ -1317,7 +1319,7 @@ static int dgrad_eluseg_launch(const float *dy, int64_t lddy, const float *W, in
       (segvec && !segoff && (rows_per_seg < 32 || rows_per_seg > 0x7fffffffLL)))
     return SN_E_UNSUPPORTED;
   if (rows == 0) {                     // nothing to launch; the bound of an empty operand is 0
-    if (gact_absmax && hipMemsetAsync(gact_absmax, 0, kAbsmaxBlocks * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
+    if (gact_absmax && sn_internal_fill(gact_absmax, 0, kAbsmaxBlocks * sizeof(float), static_cast<hipStream_t>(stream)) != hipSuccess)
       return (int)hipGetLastError();
     return SN_OK;
   }

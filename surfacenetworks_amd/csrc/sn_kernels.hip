@@ -27,6 +27,8 @@
 #include "sn_spmm.h"
 
 int sn_internal_cu_count();
+hipError_t sn_internal_fill(void *dst, int value, size_t bytes, hipStream_t s);
+hipError_t sn_internal_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch, int64_t width, int64_t rows, hipStream_t s);
 
 namespace {
 
@@ -1910,6 +1912,60 @@ int sn_internal_cu_count() {
   return cached[dev];
 }
 
+namespace {
+
+// Fills and device-to-device copies are kernels of this library, not hipMemsetAsync / hipMemcpy2DAsync: a hipMemsetAsync of more
+// than 4 bytes captured into a hipGraph replays wrongly on this runtime (ROCm 7.2; tools/scratch/plan_memset_graph.py: from the second
+// replay on 3 bytes of every 16 are not the fill value), and every entry point has to write the same bytes launched directly, under
+// stream capture and on replay.
+template <class U>
+__global__ void __launch_bounds__(256) fill2d_k(char *__restrict__ dst, int64_t pitch, int64_t wunits, int64_t total, U v) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / wunits, c = i - r * wunits;
+    *(U *)(dst + r * pitch + c * (int64_t)sizeof(U)) = v;
+  }
+}
+template <class U>
+__global__ void __launch_bounds__(256) copy2d_k(char *__restrict__ dst, int64_t dpitch, const char *__restrict__ src, int64_t spitch,
+                                                     int64_t wunits, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / wunits, c = i - r * wunits;
+    *(U *)(dst + r * dpitch + c * (int64_t)sizeof(U)) = *(const U *)(src + r * spitch + c * (int64_t)sizeof(U));
+  }
+}
+inline unsigned fill_grid(int64_t total) {
+  const int64_t want = (total + 255) / 256, cap = (int64_t)sn_internal_cu_count() * 16;
+  return (unsigned)(want < cap ? (want < 1 ? 1 : want) : cap);
+}
+inline int fill_unit(uint64_t bits) { return (bits & 15) == 0 ? 16 : (bits & 3) == 0 ? 4 : 1; }
+
+}  // namespace
+
+hipError_t sn_internal_fill2d(void *dst, int64_t pitch, int value, int64_t width, int64_t rows, hipStream_t s) {
+  if (rows == 1) pitch = 0;
+  const int u = fill_unit((uint64_t)(uintptr_t)dst | (uint64_t)pitch | (uint64_t)width);
+  const int64_t wunits = width / u, total = wunits * rows;
+  const uint32_t b = (uint32_t)(value & 0xff) * 0x01010101u;
+  if (u == 16) fill2d_k<uint4><<<fill_grid(total), 256, 0, s>>>((char *)dst, pitch, wunits, total, make_uint4(b, b, b, b));
+  else if (u == 4) fill2d_k<uint32_t><<<fill_grid(total), 256, 0, s>>>((char *)dst, pitch, wunits, total, b);
+  else fill2d_k<uint8_t><<<fill_grid(total), 256, 0, s>>>((char *)dst, pitch, wunits, total, (uint8_t)b);
+  return hipGetLastError();
+}
+hipError_t sn_internal_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch, int64_t width, int64_t rows, hipStream_t s) {
+  if (rows == 1) dpitch = spitch = 0;
+  const int u = fill_unit((uint64_t)(uintptr_t)dst | (uint64_t)(uintptr_t)src | (uint64_t)dpitch | (uint64_t)spitch | (uint64_t)width);
+  const int64_t wunits = width / u, total = wunits * rows;
+  if (u == 16) copy2d_k<uint4><<<fill_grid(total), 256, 0, s>>>((char *)dst, dpitch, (const char *)src, spitch, wunits, total);
+  else if (u == 4) copy2d_k<uint32_t><<<fill_grid(total), 256, 0, s>>>((char *)dst, dpitch, (const char *)src, spitch, wunits, total);
+  else copy2d_k<uint8_t><<<fill_grid(total), 256, 0, s>>>((char *)dst, dpitch, (const char *)src, spitch, wunits, total);
+  return hipGetLastError();
+}
+
+hipError_t sn_internal_fill(void *dst, int value, size_t bytes, hipStream_t s) {
+  return bytes ? sn_internal_fill2d(dst, 0, value, (int64_t)bytes, 1, s) : hipSuccess;
+}
+
+
 bool g_timing_linear = true;      // sn_timing_enable(2): the sparse products only
 bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e) {
   {
@@ -2065,7 +2121,7 @@ int sn_rb4_count(const int32_t *rowptr, const int32_t *colind, int64_t M, int64_
   const int64_t Mb = (M + 3) / 4;
   if (workspace_bytes < sn_scan_workspace_bytes(Mb + 1) || !workspace) return SN_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(b_ptr + Mb, 0, sizeof(int), s);
+  hipError_t e = sn_internal_fill(b_ptr + Mb, 0, sizeof(int), s);
   if (e != hipSuccess) return (int)e;
   if (Mb > 0)
     hipLaunchKernelGGL((rb4_merge<false>), dim3(grid_for(Mb, kWG)), dim3(kWG), 0, s, rowptr, colind, (const float *)nullptr, M, Mb,
@@ -2306,7 +2362,7 @@ int sn_csr_band_i32(const int32_t *rowptr, const int32_t *colind, int64_t M, int
   if (!fits_i32(M + 1) || !fits_i32(K)) return SN_E_RANGE;
   if (!band_longest_outside || (M > 0 && !rowptr)) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(band_longest_outside, 0, 3 * sizeof(int32_t), s);
+  hipError_t e = sn_internal_fill(band_longest_outside, 0, 3 * sizeof(int32_t), s);
   if (e != hipSuccess) return (int)e;
   if (M == 0) return SN_OK;
   if (!colind) return SN_E_NULL;
@@ -2487,7 +2543,7 @@ int sn_bsr4_to_q3_f32(const int32_t *b_colind, const float *b_vals, int64_t nblo
   if (nblocks < 0) return SN_E_SHAPE;
   if (!not_quaternion) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(not_quaternion, 0, sizeof(int32_t), s);
+  hipError_t e = sn_internal_fill(not_quaternion, 0, sizeof(int32_t), s);
   if (e != hipSuccess) return (int)e;
   if (nblocks == 0) return SN_OK;
   if (!b_colind || !b_vals || !q_blk) return SN_E_NULL;
@@ -2536,7 +2592,7 @@ int sn_csr_transpose_f32(const int32_t *rowptr, const int32_t *colind, const flo
   if (workspace_bytes < sn_csr_transpose_workspace_bytes(M, K, nnz) || (!workspace && K > 0))
     return SN_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(t_rowptr, 0, (size_t)(K + 1) * sizeof(int), s);
+  hipError_t e = sn_internal_fill(t_rowptr, 0, (size_t)(K + 1) * sizeof(int), s);
   if (e != hipSuccess) return (int)e;
   if (nnz == 0 || K == 0) return SN_OK;
   int *cursor = static_cast<int *>(workspace);
@@ -2545,7 +2601,7 @@ int sn_csr_transpose_f32(const int32_t *rowptr, const int32_t *colind, const flo
   hipLaunchKernelGGL(histogram_cols, dim3(grid_for(nnz, kWG)), dim3(kWG), 0, s, colind, nnz, t_rowptr);
   int st = exclusive_scan_i32(t_rowptr, K + 1, t_rowptr, scan_ws, workspace_bytes - cursor_bytes, s);
   if (st) return st;
-  e = hipMemcpyAsync(cursor, t_rowptr, (size_t)K * sizeof(int), hipMemcpyDeviceToDevice, s);
+  e = sn_internal_copy2d(cursor, 0, t_rowptr, 0, (int64_t)((size_t)K * sizeof(int)), 1, s);
   if (e != hipSuccess) return (int)e;
   hipLaunchKernelGGL(transpose_scatter, dim3(grid_for(M, kWG)), dim3(kWG), 0, s, rowptr, colind, vals, M,
                      cursor, t_colind, t_vals);
@@ -2564,7 +2620,7 @@ int sn_bsr4_count(const int32_t *rowptr, const int32_t *colind, int64_t M, int64
   const int64_t Mb = M / 4;
   if (workspace_bytes < sn_scan_workspace_bytes(Mb + 1) || !workspace) return SN_E_WORKSPACE;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(b_rowptr + Mb, 0, sizeof(int), s);
+  hipError_t e = sn_internal_fill(b_rowptr + Mb, 0, sizeof(int), s);
   if (e != hipSuccess) return (int)e;
   if (Mb > 0)
     hipLaunchKernelGGL((bsr4_merge<false>), dim3(grid_for(Mb, kWG)), dim3(kWG), 0, s, rowptr, colind,
@@ -2632,7 +2688,7 @@ int sn_blockdiag_concat_ragged_i32(const int32_t *pool_rowptr, const int32_t *po
   if (vals_per_entry != 1 && total > 0 && (!aligned16(pool_vals) || !aligned16(out_vals))) return SN_E_ALIGN;
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (B == 0) {
-    hipError_t e = hipMemsetAsync(out_rowptr, 0, sizeof(int32_t), s);
+    hipError_t e = sn_internal_fill(out_rowptr, 0, sizeof(int32_t), s);
     return e == hipSuccess ? SN_OK : (int)e;
   }
   hipLaunchKernelGGL(blockdiag_rowptr_ragged, dim3(grid_for(total_rows + 1, kWG)), dim3(kWG), 0, s, pool_rowptr, desc, B,
@@ -2656,7 +2712,7 @@ int sn_validate_csr_i32(const int32_t *rowptr, const int32_t *colind, const floa
   if (!fits_i32(M + 1) || !fits_i32(K) || !fits_i32(nnz)) return SN_E_RANGE;
   if (!flags) return SN_E_NULL;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(flags, 0, sizeof(int32_t), s);
+  hipError_t e = sn_internal_fill(flags, 0, sizeof(int32_t), s);
   if (e != hipSuccess) return (int)e;
   if (M == 0) return SN_OK;
   if (!rowptr || (nnz > 0 && !colind)) return SN_E_NULL;

@@ -9,6 +9,10 @@
 
 #include "sn_spmm.h"
 
+// fills / device copies as kernels of this library (sn_kernels.hip says why not hipMemsetAsync)
+hipError_t sn_internal_fill(void *dst, int value, size_t bytes, hipStream_t s);
+hipError_t sn_internal_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch, int64_t width, int64_t rows, hipStream_t s);
+
 namespace {
 
 constexpr int kWG = 256;
@@ -353,7 +357,7 @@ int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_
   int *cursor = reinterpret_cast<int *>(w); w += align16((size_t)(nV + 1) * sizeof(int));
   int *inc = reinterpret_cast<int *>(w); w += align16((size_t)3 * nF * sizeof(int));
   int *sums = reinterpret_cast<int *>(w);
-  hipError_t e = hipMemsetAsync(vptr, 0, (size_t)(nV + 1) * sizeof(int), s);
+  hipError_t e = sn_internal_fill(vptr, 0, (size_t)(nV + 1) * sizeof(int), s);
   if (e != hipSuccess) return (int)e;
   if (nF > 0) hipLaunchKernelGGL(face_area_k, dim3(grid_for(nF)), dim3(kWG), 0, s, V, F, nF, Af, vptr);
   const int64_t n = nV + 1;
@@ -361,7 +365,7 @@ int sn_dirac_bsr4_from_mesh(const float *V, const int32_t *F, int64_t nV, int64_
   hipLaunchKernelGGL(scan_sums_k, dim3(nblk), dim3(kWG), 0, s, vptr, n, sums);
   hipLaunchKernelGGL(scan_top_k, dim3(1), dim3(kWG), 0, s, sums, nblk);
   hipLaunchKernelGGL(scan_apply_k, dim3(nblk), dim3(kWG), 0, s, vptr, n, sums, vptr);
-  e = hipMemcpyAsync(cursor, vptr, (size_t)(nV + 1) * sizeof(int), hipMemcpyDeviceToDevice, s);
+  e = sn_internal_copy2d(cursor, 0, vptr, 0, (int64_t)((size_t)(nV + 1) * sizeof(int)), 1, s);
   if (e != hipSuccess) return (int)e;
   if (nF > 0) hipLaunchKernelGGL(incidence_scatter_k, dim3(grid_for(nF)), dim3(kWG), 0, s, F, nF, cursor, inc);
   if (nV > 0) hipLaunchKernelGGL(vertex_lists_k, dim3(grid_for(nV)), dim3(kWG), 0, s, vptr, nV, inc, Af, Av, dia_colind);
@@ -393,21 +397,21 @@ int sn_laplacian_csr_from_mesh(const float *V, const int32_t *F, int64_t nV, int
   const int64_t n = nV + 1;
   const int nblk = (int)((n + kScanTile - 1) / kScanTile);
   if (phase == 0) {
-    hipError_t e = hipMemsetAsync(vptr, 0, (size_t)(nV + 1) * sizeof(int), s);
+    hipError_t e = sn_internal_fill(vptr, 0, (size_t)(nV + 1) * sizeof(int), s);
     if (e != hipSuccess) return (int)e;
     if (status_flag) {
-      e = hipMemsetAsync(status_flag, 0, sizeof(int), s);
+      e = sn_internal_fill(status_flag, 0, sizeof(int), s);
       if (e != hipSuccess) return (int)e;
     }
     if (nF > 0) hipLaunchKernelGGL(face_area_k, dim3(grid_for(nF)), dim3(kWG), 0, s, V, F, nF, Af, vptr);
     hipLaunchKernelGGL(scan_sums_k, dim3(nblk), dim3(kWG), 0, s, vptr, n, sums);
     hipLaunchKernelGGL(scan_top_k, dim3(1), dim3(kWG), 0, s, sums, nblk);
     hipLaunchKernelGGL(scan_apply_k, dim3(nblk), dim3(kWG), 0, s, vptr, n, sums, vptr);
-    e = hipMemcpyAsync(cursor, vptr, (size_t)(nV + 1) * sizeof(int), hipMemcpyDeviceToDevice, s);
+    e = sn_internal_copy2d(cursor, 0, vptr, 0, (int64_t)((size_t)(nV + 1) * sizeof(int)), 1, s);
     if (e != hipSuccess) return (int)e;
     if (nF > 0) hipLaunchKernelGGL(incidence_scatter_k, dim3(grid_for(nF)), dim3(kWG), 0, s, F, nF, cursor, inc);
     if (nV > 0) hipLaunchKernelGGL(vertex_sort_k, dim3(grid_for(nV)), dim3(kWG), 0, s, vptr, nV, inc);
-    e = hipMemsetAsync(rowptr + nV, 0, sizeof(int), s);
+    e = sn_internal_fill(rowptr + nV, 0, sizeof(int), s);
     if (e != hipSuccess) return (int)e;
     if (nV > 0)
       hipLaunchKernelGGL((laplacian_rows_k<false>), dim3(grid_for(nV)), dim3(kWG), 0, s, V, F, nV, vptr, inc, Af, rowptr,

@@ -19,6 +19,10 @@
 
 #include "sn_spmm.h"
 
+// fills and copies as kernels of this library (sn_kernels.hip says why they are not hipMemsetAsync / hipMemcpy2DAsync)
+hipError_t sn_internal_fill2d(void *dst, int64_t pitch, int value, int64_t width, int64_t rows, hipStream_t s);
+hipError_t sn_internal_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch, int64_t width, int64_t rows, hipStream_t s);
+
 namespace {
 
 union PlanArg {
@@ -222,9 +226,7 @@ int sn_plan_run(const sn_plan *p, const uint64_t *slot_base, int32_t nslots, voi
       if (!base) st = SN_E_NULL;
       else if (n.val[3].i > 0 && n.val[4].i > 0) {
         void *dst = (void *)(uintptr_t)(base + (uint64_t)n.val[0].i);
-        hipError_t e = n.val[4].i == 1 ? hipMemsetAsync(dst, (int)n.val[1].i, (size_t)n.val[3].i, s)
-                                       : hipMemset2DAsync(dst, (size_t)n.val[2].i, (int)n.val[1].i, (size_t)n.val[3].i, (size_t)n.val[4].i, s);
-        st = (int)e;
+        st = (int)sn_internal_fill2d(dst, n.val[2].i, (int)n.val[1].i, n.val[3].i, n.val[4].i, s);
       }
     } else {
       const uint64_t db = slot_base[n.slot[0]], sb = slot_base[n.slot[2]];
@@ -232,10 +234,7 @@ int sn_plan_run(const sn_plan *p, const uint64_t *slot_base, int32_t nslots, voi
       else if (n.val[4].i > 0 && n.val[5].i > 0) {
         void *dst = (void *)(uintptr_t)(db + (uint64_t)n.val[0].i);
         const void *src = (const void *)(uintptr_t)(sb + (uint64_t)n.val[2].i);
-        hipError_t e = n.val[5].i == 1 ? hipMemcpyAsync(dst, src, (size_t)n.val[4].i, hipMemcpyDeviceToDevice, s)
-                                       : hipMemcpy2DAsync(dst, (size_t)n.val[1].i, src, (size_t)n.val[3].i, (size_t)n.val[4].i,
-                                                          (size_t)n.val[5].i, hipMemcpyDeviceToDevice, s);
-        st = (int)e;
+        st = (int)sn_internal_copy2d(dst, n.val[1].i, src, n.val[3].i, n.val[4].i, n.val[5].i, s);
       }
     }
     if (st != SN_OK) {

@@ -317,3 +317,75 @@ def test_the_placeholder_face_features_are_never_materialised():
         torch.Tensor.contiguous = orig
         plans.set_enabled(True)
     assert copies == []
+
+
+@pytest.mark.parametrize("off,pitch,width,rows", [(0, 1024, 512, 37), (4, 1028, 516, 9), (3, 611, 333, 5), (16, 0, 1 << 20, 1), (1, 0, 7, 1),
+                                                    (0, 64, 64, 1000), (0, 0, 0, 1)])
+def test_plan_fill_and_copy_nodes_write_exactly_their_region(off, pitch, width, rows):
+    """The fill / copy nodes are kernels of the library (16-, 4- or 1-byte units by alignment): the region and nothing around it."""
+    import ctypes
+
+    from surfacenetworks_amd import _lib
+
+    lib = _lib.load()
+    span = off + (pitch * (rows - 1) if rows > 1 else 0) + width + 64
+    g = torch.Generator(device=DEV).manual_seed(5)
+    src = torch.randint(1, 255, (span,), dtype=torch.uint8, device=DEV, generator=g)
+    dst_f = torch.full((span,), 0xAA, dtype=torch.uint8, device=DEV)
+    dst_c = dst_f.clone()
+    plan = ctypes.c_void_p()
+    assert lib.sn_plan_create(ctypes.byref(plan)) == 0
+    assert lib.sn_plan_add_memset(plan, 0, off, 0x5C, pitch, width, rows) == 0
+    assert lib.sn_plan_add_copy(plan, 1, off, pitch, 2, off, pitch, width, rows) == 0
+    bases = (ctypes.c_uint64 * 3)(dst_f.data_ptr(), dst_c.data_ptr(), src.data_ptr())
+    assert lib.sn_plan_run(plan, bases, 3, torch.cuda.current_stream().cuda_stream, None) == 0
+    torch.cuda.synchronize()
+    want_f = torch.full((span,), 0xAA, dtype=torch.uint8)
+    want_c = want_f.clone()
+    s = src.cpu()
+    for r in range(rows):
+        a = off + r * pitch
+        want_f[a:a + width] = 0x5C
+        want_c[a:a + width] = s[a:a + width]
+    assert torch.equal(dst_f.cpu(), want_f)
+    assert torch.equal(dst_c.cpu(), want_c)
+    lib.sn_plan_destroy(plan)
+
+
+def test_plan_fill_nodes_replay_correctly_from_a_captured_graph():
+    """A flat hipMemsetAsync captured into a graph replays with wrong bytes from the second replay on (ROCm 7.2): the plan's fills
+    are kernels, and a plan captured by a caller's graph gives the eager bytes on every replay."""
+    import ctypes
+
+    from surfacenetworks_amd import _lib
+
+    lib = _lib.load()
+    rows, C = 128, 256
+    for twod in (False, True):
+        plan = ctypes.c_void_p()
+        assert lib.sn_plan_create(ctypes.byref(plan)) == 0
+        if twod:
+            assert lib.sn_plan_add_memset(plan, 0, 0, 0, C * 4, C // 2 * 4, rows) == 0
+        else:
+            assert lib.sn_plan_add_memset(plan, 0, 0, 0, rows * C * 4, rows * C * 4, 1) == 0
+        n = 7
+        I32, I64, F64 = ctypes.c_int32 * n, ctypes.c_int64 * n, ctypes.c_double * n
+        assert lib.sn_plan_add_call(plan, lib.sn_plan_lookup(b"sn_elu_into_f32"), n, I32(2, 0, 2, 0, 0, 0, 4), I32(0, 0, 1, 0, 0, 0, 0),
+                                    I64(0, C, 0, C, rows, C, 0), F64()) == 0
+        x = torch.full((rows, C), 3.0, device=DEV)
+        y = torch.empty((rows, C), device=DEV)
+        bases = (ctypes.c_uint64 * 2)(x.data_ptr(), y.data_ptr())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            assert lib.sn_plan_run(plan, bases, 2, torch.cuda.current_stream().cuda_stream, None) == 0
+        for rep in range(4):
+            x.fill_(5.0 + rep)
+            y.fill_(-1.0)
+            graph.replay()
+            torch.cuda.synchronize()
+            zero_cols = C // 2 if twod else C
+            assert float(y[:, :zero_cols].abs().max()) == 0.0, (twod, rep)
+            if twod:
+                assert torch.equal(y[:, zero_cols:], torch.full((rows, C - zero_cols), 5.0 + rep, device=DEV))
+        del graph
+        lib.sn_plan_destroy(plan)
