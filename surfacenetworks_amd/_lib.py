@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsn_hip.so")
@@ -208,10 +209,20 @@ def check(status: int, what: str) -> None:
 # A launch-plan recorder (plans.py) while the launch list of a block is being taken down: every call() is then RECORDED, not
 # executed (a dry run of the block's host code); None otherwise.
 _recorder = None
+_recorder_tid = 0                 # the thread whose calls are being recorded: every other thread (autograd's device threads, a
+_record_lock = threading.RLock()  # loader thread) keeps LAUNCHING while a dry run is in progress; dry runs themselves are serialised
+
+
+def recorder():
+    """The recorder of a dry run in progress ON THIS THREAD, else None."""
+    r = _recorder
+    return r if r is not None and _recorder_tid == threading.get_ident() else None
 
 
 def call(name: str, *args) -> None:
     if _recorder is not None:
-        _recorder.record_call(name, args)
-        return
+        r = recorder()
+        if r is not None:
+            r.record_call(name, args)
+            return
     check(getattr(load(), name)(*args), name)

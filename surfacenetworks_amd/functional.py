@@ -188,7 +188,7 @@ def _launch(op: SparseOperator, x: torch.Tensor, y: torch.Tensor, group: int, ta
     their partials are returned (kernels.spmm_q3_stats / spmm_csr_stats), else None."""
     M, K = op.shape
     timer = SpmmTimer.active
-    rec = _lib_mod._recorder
+    rec = _lib_mod.recorder() if _lib_mod._recorder is not None else None
     if timer is not None or rec is not None:
         known = op._nnz_cache if op._nnz_cache is not None else (int(op._csr[1].numel()) if op._csr is not None else None)
         if rec is not None:

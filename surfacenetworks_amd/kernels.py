@@ -22,7 +22,7 @@ __all__ = [
 
 
 def _dev(*tensors) -> None:
-    if _lib._recorder is not None and _lib._recorder.allow_cpu:
+    if _lib._recorder is not None and _lib.recorder() is not None and _lib._recorder.allow_cpu:
         return                                # (tests record — never run — launch plans on CPU tensors)
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -43,8 +43,8 @@ def _stream():
     """hipStream_t of torch's current stream on the current device.  Through the two C entry points behind
     torch.cuda.current_stream() when this torch has them: the Stream-object route costs ~8 us per call on the host, as
     much as everything else around a launch."""
-    if _lib._recorder is not None:          # a launch plan is being recorded: the stream is an argument of sn_plan_run
-        return 0
+    if _lib._recorder is not None and _lib.recorder() is not None:      # a launch plan is being recorded: the stream is an
+        return 0                                                         # argument of sn_plan_run
     if _raw_stream is not None and _cur_device is not None:
         return _raw_stream(_cur_device())
     return torch.cuda.current_stream().cuda_stream
@@ -463,8 +463,9 @@ def note_absmax(t, maxima) -> None:
             del _absmax_table[k]
     _absmax_table.pop(t.data_ptr(), None)
     _absmax_table[t.data_ptr()] = (t, t._version if not t.is_inference() else None, maxima)
-    if _lib._recorder is not None:          # (a launch plan re-attaches what is still noted when its dry run ends)
-        _lib._recorder.notes.append((t, maxima))
+    rec = _lib.recorder() if _lib._recorder is not None else None
+    if rec is not None:                     # (a launch plan re-attaches what is still noted when its dry run ends)
+        rec.notes.append((t, maxima))
 
 
 def clear_absmax() -> None:
@@ -480,8 +481,9 @@ def take_absmax(t):
     if ent is None:
         return None
     src, version, maxima = ent
-    if _lib._recorder is not None:
-        _lib._recorder.notes[:] = [n for n in _lib._recorder.notes if n[1] is not maxima]
+    rec = _lib.recorder() if _lib._recorder is not None else None
+    if rec is not None:
+        rec.notes[:] = [n for n in rec.notes if n[1] is not maxima]
     if src.numel() != t.numel() or not t.is_contiguous() or src.dtype != t.dtype or \
             (version is not None and src._version != version):
         return None

@@ -26,6 +26,7 @@ import bisect
 import collections
 import ctypes as C
 import os
+import threading
 from typing import List, Optional, Sequence
 
 import torch
@@ -486,13 +487,16 @@ def expand_ext(tensors: Sequence[Optional[torch.Tensor]], scan: Sequence[int]):
 def _dry_run(impl, args, ext):
     rec = _Recorder(ext)
     keep = [(t, dict(t.__dict__)) for t in ext if t is not None and hasattr(t, "__dict__")]
-    prev = _lib._recorder
+    _lib._record_lock.acquire()                    # one dry run at a time; calls of OTHER threads keep launching (_lib.recorder)
+    prev, prev_tid = _lib._recorder, _lib._recorder_tid
+    _lib._recorder_tid = threading.get_ident()
     _lib._recorder = rec
     try:
         with torch.no_grad(), rec:
             result = impl(*args)
     finally:
-        _lib._recorder = prev
+        _lib._recorder, _lib._recorder_tid = prev, prev_tid
+        _lib._record_lock.release()
         for t, m in rec.notes:                      # bounds noted on the dry run's scratch tensors: the replay notes the real ones
             ent = kernels._absmax_table.get(t.data_ptr())
             if ent is not None and ent[2] is m:

@@ -164,3 +164,48 @@ def test_sites_stop_recording_when_every_call_has_a_new_shape_and_keep_a_bounded
         assert plans.stats()["avg_fwd"]["replayed"] == before + 1
     finally:
         plans.reset()
+
+
+def test_a_dry_run_records_only_the_calls_of_its_own_thread(monkeypatch):
+    """The recorder belongs to the thread that runs the dry run: a call of another thread during it (autograd's device threads, a
+    loader thread) is a launch, not an entry of somebody else's plan — and a second dry run waits for the first."""
+    import threading
+
+    from surfacenetworks_amd import _lib, plans
+
+    launched, order = [], []
+
+    class _FakeLib:
+        def __getattr__(self, name):
+            return lambda *a: launched.append((name, threading.get_ident())) or 0
+
+    monkeypatch.setattr(_lib, "load", lambda: _FakeLib())
+    inside, release = threading.Event(), threading.Event()
+
+    def impl():
+        _lib.call("sn_mine", 1)                                  # recorded: this thread owns the recorder
+        inside.set()
+        assert release.wait(10)
+        return None
+
+    def other():
+        assert inside.wait(10)
+        assert _lib._recorder is not None and _lib.recorder() is None
+        _lib.call("sn_theirs", 2)                                # launched
+        second = threading.Thread(target=lambda: (plans._dry_run(lambda: order.append("second"), (), []), None))
+        second.start()
+        second.join(0.2)
+        assert second.is_alive() and order == []                 # a second dry run waits for the first
+        order.append("first ends")
+        release.set()
+        second.join(10)
+
+    t = threading.Thread(target=other)
+    t.start()
+    rec, _ = plans._dry_run(impl, (), [])
+    t.join(10)
+    assert not t.is_alive()
+    assert [n.name if hasattr(n, "name") else n[0] for n in rec.nodes] == ["sn_mine"] or len(rec.nodes) == 1
+    assert [name for name, _ in launched] == ["sn_theirs"]
+    assert order == ["first ends", "second"]
+    assert _lib._recorder is None
