@@ -191,7 +191,7 @@ def _plan_forward(ctx, site, impl, tensors, ops, consts, ncols, n_dyn, scan):
     if plan is None:
         if not may_record:
             return None
-        plan = plans.record(site, key, impl, (*tensors, *[o for o, _ in ops], *consts), ext, tensors[0].device)
+        plan = plans.record(site, key, impl, (*tensors, *[o for o, _ in ops], *consts), ext, tensors[0].device, range(n_dyn))
         if plan is None:
             return None
         need = set()
@@ -236,8 +236,9 @@ def _plan_backward(ctx, site, impl, grads, consts):
     op_arrays, op_key = _op_operands(ops, ncols) if ops else ((), ())
     maxima = [kernels.take_absmax(g) if g is not None else None for g in grads]
     ext = [big, small, *kept, *grads, *maxima, *op_arrays]
+    gptrs = [g.data_ptr() if g is not None else 0 for g in grads]
     key = (tuple([None if g is None else (g.shape, g.stride(), g.dtype) for g in grads]), tuple([m is not None for m in maxima]),
-           op_key, consts)
+           op_key, consts, tuple([gptrs.index(p_) for p_ in gptrs]))      # (one gradient tensor handed in for two outputs)
     plan = fplan.bwd.get(key, _MISSING)
     if plan is _MISSING or plan is None:
         fext = [None] * fplan.n_ext
@@ -247,8 +248,9 @@ def _plan_backward(ctx, site, impl, grads, consts):
         plans.renote(grads, maxima)
         if plan is None:                                           # not plannable: the eager backward on the saved tensors
             return impl(saved, *[o for o, _ in ops], *grads, *consts)
+        g0 = 2 + len(kept)
         plan = plans.record(site, (id(fplan), key), impl, (saved, *[o for o, _ in ops], *grads, *consts), ext,
-                            grads_device(grads, big, small))
+                            grads_device(grads, big, small), range(g0, g0 + len(grads)))
         fplan.bwd[key] = plan
         if plan is None:
             plans.renote(grads, maxima)                            # (the dry run took them)

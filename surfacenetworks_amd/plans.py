@@ -122,7 +122,7 @@ class _Recorder(TorchDispatchMode):
 class _Layout:
     """Arena offsets of the dry run's allocations and the (slot, offset) of any pointer into them or into an ext tensor."""
 
-    def __init__(self, rec: _Recorder):
+    def __init__(self, rec: _Recorder, alias_ok=()):
         regions = {}
         for t in rec.allocs:
             st = t.untyped_storage()
@@ -142,6 +142,15 @@ class _Layout:
         for j, t in enumerate(rec.ext):
             if t is not None and t.numel():
                 self.ext.append((t.data_ptr(), _span_bytes(t), j))
+        # A pointer is attributed to the FIRST operand whose range holds it: two operands that overlap in memory during the dry
+        # run and do not on a later call (or the other way round in a way the key does not see) would make the plan read the
+        # wrong one.  Same first byte among the positions the caller keys the sharing pattern of (`alias_ok`): fine; any other
+        # overlap: no plan for this signature.
+        by_addr = sorted(self.ext)
+        ok = set(alias_ok)
+        for (p0, n0, j0), (p1, n1, j1) in zip(by_addr, by_addr[1:]):
+            if p1 < p0 + n0 and not (p1 == p0 and j0 in ok and j1 in ok):
+                raise PlanError("two operands of the block overlap in memory")
         self.used_ext = set()
 
     def resolve(self, p: int):
@@ -193,10 +202,10 @@ class Plan:
 
     _n_alive = 0
 
-    def __init__(self, rec: _Recorder, result, device):
+    def __init__(self, rec: _Recorder, result, device, alias_ok=()):
         if rec.stray:
             raise PlanError("torch ops that compute inside the block: " + ", ".join(sorted(set(rec.stray))))
-        lay = _Layout(rec)
+        lay = _Layout(rec, alias_ok)
         lib = _lib.load()
         handle = C.c_void_p()
         _lib.check(lib.sn_plan_create(C.byref(handle)), "sn_plan_create")
@@ -507,11 +516,12 @@ def _dry_run(impl, args, ext):
     return rec, result
 
 
-def record(site: Site, key, impl, args, ext, device) -> Optional[Plan]:
-    """Dry-run `impl(*args)` and turn what it would have launched into a plan (None, and the reason noted, when it cannot be)."""
+def record(site: Site, key, impl, args, ext, device, alias_ok=()) -> Optional[Plan]:
+    """Dry-run `impl(*args)` and turn what it would have launched into a plan (None, and the reason noted, when it cannot be).
+    alias_ok: positions of `ext` that may start at the same address because the caller's key holds their sharing pattern."""
     try:
         rec, result = _dry_run(impl, args, ext)
-        plan = Plan(rec, result, device)
+        plan = Plan(rec, result, device, alias_ok)
     except PlanError as exc:
         site.refuse(key, str(exc)[:200])
         return None

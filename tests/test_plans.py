@@ -209,3 +209,23 @@ def test_a_dry_run_records_only_the_calls_of_its_own_thread(monkeypatch):
     assert [name for name, _ in launched] == ["sn_theirs"]
     assert order == ["first ends", "second"]
     assert _lib._recorder is None
+
+
+def test_operands_that_overlap_in_memory_get_no_plan():
+    """A recorded pointer is attributed to the first operand whose range holds it; operands that overlap during the dry run
+    would be told apart wrongly on a call where they do not.  Same first byte among the positions whose sharing pattern the
+    caller's key holds is the one exception."""
+    from surfacenetworks_amd import plans
+
+    buf = torch.zeros(4, 129)
+    x, m = buf[:, :128], buf[:, 128:]                              # interleaved rows: disjoint elements, overlapping ranges
+    other = torch.zeros(16)
+    with pytest.raises(plans.PlanError, match="overlap"):
+        plans._Layout(plans._Recorder([x, other, m]))
+    with pytest.raises(plans.PlanError, match="overlap"):
+        plans._Layout(plans._Recorder([other, other[4:]]))
+    with pytest.raises(plans.PlanError, match="overlap"):
+        plans._Layout(plans._Recorder([other, other]))             # the same memory twice, not keyed by the caller
+    lay = plans._Layout(plans._Recorder([other, x, other]), alias_ok=(0, 2))
+    assert lay.resolve(other.data_ptr() + 8) == (2 + 0, 8)
+    assert plans._Layout(plans._Recorder([other[:8], other[8:], None, torch.zeros(0)])).resolve(other.data_ptr() + 32) == (3, 0)
