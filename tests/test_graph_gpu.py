@@ -22,10 +22,19 @@ def _setup(model_kind, meshes=3, grid=(9, 8)):
 @pytest.mark.parametrize("model_kind", ["dir", "lap"])
 def test_graph_replay_is_bit_identical_to_eager(model_kind):
     arap, ds, model_e = _setup(model_kind)
+    _replay_equals_eager(arap, ds, model_e, np.arange(ds.n))
+
+
+def test_graph_replay_of_the_headline_batch_is_bit_identical_to_eager():
+    """BASELINE config 3 at its full size: 64 meshes of 71 x 71 per step, launch plans inside the captured step."""
+    arap, ds, model_e = _setup("dir", 4, (71, 71))
+    _replay_equals_eager(arap, ds, model_e, np.arange(64) % 4)
+
+
+def _replay_equals_eager(arap, ds, model_e, ids):
     model_g = copy.deepcopy(model_e)
     opt_e, opt_g = arap.make_optimizer(model_e), arap.make_optimizer(model_g)
-    n = ds.n
-    ids = np.arange(n)
+    n = len(ids)
     example = ds.sample_batch(n, np.random.default_rng(0), seq_ids=ids)
     state0 = [b.clone() for b in model_g.buffers()]
     graphed = arap.GraphedTrainStep(model_g, opt_g, example, global_batch=n)

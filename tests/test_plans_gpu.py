@@ -74,6 +74,26 @@ def test_arap_steps_planned_equal_eager(model_kind):
     assert st[f"{blk}_fwd"]["recorded"] <= 3 and st["avg_fwd"]["recorded"] <= 2
 
 
+def test_the_headline_batch_planned_equals_eager():
+    """BASELINE config 3 at its full size (64 meshes of 71 x 71, the arenas in the hundreds of MB, the global-average stages past
+    the merged launch's mesh limit): two steps, planned against eager, every gradient, parameter and buffer bit for bit."""
+    from surfacenetworks_amd import arap
+
+    torch.manual_seed(7)
+    ds = arap.ClothSequences([(71, 71)] * 4, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 2, op_frames=2, seed=3, device=DEV, model="dir")
+    model_e = arap.DirModel().to(DEV).train()
+    model_p = copy.deepcopy(model_e)
+    opts = {id(model_e): arap.make_optimizer(model_e), id(model_p): arap.make_optimizer(model_p)}
+    rngs = {id(model_e): np.random.default_rng(2), id(model_p): np.random.default_rng(2)}
+
+    def step(model, k):
+        batch = ds.sample_batch(64, rngs[id(model)], seq_ids=np.arange(64) % 4)
+        return arap.train_step(model, opts[id(model)], batch, global_batch=64)
+
+    st = _steps(step, model_e, model_p, 2)
+    assert st["dirac_fwd"]["replayed"] >= 2 * 8 and st["avg_bwd"]["replayed"] >= 2 * 7, st
+
+
 def test_packed_ragged_batch_planned_equals_eager():
     from surfacenetworks_amd import arap
 
