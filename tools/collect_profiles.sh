@@ -2,6 +2,7 @@
 # Evidence of one round, collected on the GPU box into gpurun_out/$1/ (copy what is to be judged into profiles/):
 #   tools/collect_profiles.sh r5_final [tests|bench|trace|pmc|configs ...]      (default: everything)
 # rocprofv3 runs from /tmp with TMPDIR=/tmp; counter passes (--pmc) are separate runs without any trace domain.
+[ -e /dev/kfd ] || { echo "no GPU here: run this through gpurun (gpurun -- bash tools/collect_profiles.sh ...)" >&2; exit 2; }
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 tag=${1:-r5_final}; shift
 what=${*:-tests bench trace pmc q3pmc plans configs}

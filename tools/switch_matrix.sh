@@ -1,6 +1,7 @@
 #!/bin/bash
 # The GPU suite under every switch of include/sn_spmm.h's SWITCHES line, one line per leg into gpurun_out/$1/switch_matrix.txt
 # (run on the GPU box: gpurun -- 'bash tools/switch_matrix.sh r6').  Failing test ids of every leg are listed under its line.
+[ -e /dev/kfd ] || { echo "no GPU here: run this through gpurun (gpurun -- bash tools/switch_matrix.sh ...)" >&2; exit 2; }
 tag=${1:-scratch}; root=$(cd "$(dirname "$0")/.." && pwd); out=$root/gpurun_out/$tag; mkdir -p $out
 cd $root
 : > $out/switch_matrix.txt
