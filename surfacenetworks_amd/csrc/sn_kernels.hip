@@ -1888,9 +1888,6 @@ inline bool timing_slot(int kind, int64_t M, int64_t K, int64_t nnz, int N, hipE
 
 }  // namespace
 
-// The same timing slot for the Linear-layer launchers of the other translation units (sn_gemm.hip, sn_dense.hip): kind
-// 0x100 forward / 0x200 input gradient / 0x400 weight gradient (+ a variant number in the low byte), then rows, the contraction
-// or input width, the ALGORITHMIC bytes of the launch (operands read + results written, weights excluded) and the output width.
 // Compute units of the current device (hipDeviceAttributeMultiprocessorCount, read once per device): what every "one workgroup
 // per CU" / "whole rounds of the chip" grid of the three translation units is sized by — 256 on an MI355X in SPX mode, fewer in
 // the CPX / DPX / QPX partition modes.  256 when there is no device to ask (host-only callers of the *_blocks / *_bytes queries).
@@ -1942,6 +1939,7 @@ inline int fill_unit(uint64_t bits) { return (bits & 15) == 0 ? 16 : (bits & 3) 
 }  // namespace
 
 hipError_t sn_internal_fill2d(void *dst, int64_t pitch, int value, int64_t width, int64_t rows, hipStream_t s) {
+  (void)hipGetLastError();      // a stale error left by an earlier runtime call of this thread is not ours to report
   if (rows == 1) pitch = 0;
   const int u = fill_unit((uint64_t)(uintptr_t)dst | (uint64_t)pitch | (uint64_t)width);
   const int64_t wunits = width / u, total = wunits * rows;
@@ -1952,6 +1950,7 @@ hipError_t sn_internal_fill2d(void *dst, int64_t pitch, int value, int64_t width
   return hipGetLastError();
 }
 hipError_t sn_internal_copy2d(void *dst, int64_t dpitch, const void *src, int64_t spitch, int64_t width, int64_t rows, hipStream_t s) {
+  (void)hipGetLastError();
   if (rows == 1) dpitch = spitch = 0;
   const int u = fill_unit((uint64_t)(uintptr_t)dst | (uint64_t)(uintptr_t)src | (uint64_t)dpitch | (uint64_t)spitch | (uint64_t)width);
   const int64_t wunits = width / u, total = wunits * rows;
@@ -1965,7 +1964,9 @@ hipError_t sn_internal_fill(void *dst, int value, size_t bytes, hipStream_t s) {
   return bytes ? sn_internal_fill2d(dst, 0, value, (int64_t)bytes, 1, s) : hipSuccess;
 }
 
-
+// The same timing slot for the Linear-layer launchers of the other translation units (sn_gemm.hip, sn_dense.hip): kind
+// 0x100 forward / 0x200 input gradient / 0x400 weight gradient (+ a variant number in the low byte), then rows, the contraction
+// or input width, the ALGORITHMIC bytes of the launch (operands read + results written, weights excluded) and the output width.
 bool g_timing_linear = true;      // sn_timing_enable(2): the sparse products only
 bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e) {
   {
