@@ -1172,6 +1172,7 @@ def main():
                               if plans.enabled() else "eager: every kernel launched from Python (SN_PLANS=0)") if args.no_graph
                    else "hipGraph replay of fwd+loss+bwd; sampling, all-reduce, Adam eager",
                    "launch_plans": {k: v["replayed"] for k, v in plans.stats().items() if v["replayed"] or v["refused"]},
+                   "plan_graph_launches": plans.graph_stats()["launched"],
                    "graph_fallback": graph_fallback, "grad_bucket_bytes": bucket.nbytes},
         "roofline": {"bound": "hbm", "kernel": dom_name + (" (the backward products Di^T, DiA^T, ELU backward fused into the store)" if "_epi" in dom_name
                                                           else " (the Dirac products launched without epilogue)"),

@@ -25,7 +25,8 @@
  *                SN_RESIDENT_MAX_GB   HBM budget of that cache (default 96)
  *                SN_DP_FORCE_CPU      1 = dp.init_distributed ignores the GPU (CPU gloo tests)
  *                SN_PLANS             0 = every block launches its kernels one by one from Python (no launch plans, plans.py)
- *     SWITCHES: SN_GEMM_VARIANT SN_PAIR_FUSED SN_STRICT SN_DEBUG_VALIDATE SN_RESIDENT SN_RESIDENT_MAX_GB SN_DP_FORCE_CPU SN_PLANS
+ *                SN_PLAN_GRAPHS       0 = a plan run always walks its launch list (no graph launch at repeating addresses)
+ *     SWITCHES: SN_GEMM_VARIANT SN_PAIR_FUSED SN_STRICT SN_DEBUG_VALIDATE SN_RESIDENT SN_RESIDENT_MAX_GB SN_DP_FORCE_CPU SN_PLANS SN_PLAN_GRAPHS
  *     (b) the opt-in per-launch timing facility sn_timing_* below (a mutex-guarded list, off by default).  Neither affects
  *     results.  The Python layer adds process-wide DEFAULTS with the same property: functional.set_dirac_format /
  *     set_laplacian_format (kernel form; one operator can choose for itself, SparseOperator.format) and set_bn_sync (opt-in
@@ -851,6 +852,19 @@ int sn_plan_add_memset(sn_plan *plan, int32_t slot, int64_t offset, int32_t byte
 int sn_plan_add_copy(sn_plan *plan, int32_t dst_slot, int64_t dst_offset, int64_t dst_pitch, int32_t src_slot, int64_t src_offset,
                      int64_t src_pitch, int64_t width_bytes, int64_t rows);
 int sn_plan_run(const sn_plan *plan, const uint64_t *slot_base, int32_t nslots, void *stream, int32_t *failed_node);
+
+/* A plan at FIXED slot addresses as one graph launch.  In a training loop the addresses of a plan run repeat from step to step (the
+ * framework's caching allocator hands the same blocks to the same sequence of requests); sn_plan_instantiate captures the launch
+ * list at those addresses into an executable hipGraph (kernel nodes only; on a private stream, thread-local capture mode, nothing
+ * runs), sn_plan_exec_launch enqueues it on `stream` with ONE hipGraphLaunch — or walks the list like sn_plan_run when `stream` is
+ * itself being captured by the caller or the per-launch timer is on (plan and addresses are passed for that).  Same kernels, same
+ * arguments, same order: bit-identical to sn_plan_run.  The object is the caller's (keyed by the addresses it was made for, valid
+ * while the memory behind them is), holds no device memory; SN_E_UNSUPPORTED while the timer is on. */
+typedef struct sn_plan_exec sn_plan_exec;
+int sn_plan_instantiate(const sn_plan *plan, const uint64_t *slot_base, int32_t nslots, sn_plan_exec **out, int32_t *failed_node);
+int sn_plan_exec_launch(const sn_plan_exec *exec, const sn_plan *plan, const uint64_t *slot_base, int32_t nslots, void *stream,
+                        int32_t *failed_node);
+int sn_plan_exec_destroy(sn_plan_exec *exec);
 
 #ifdef __cplusplus
 }

@@ -166,6 +166,9 @@ SIGNATURES = {
     "sn_plan_add_memset": (C.c_int, [_vp, _i32, _i64, _i32, _i64, _i64, _i64]),
     "sn_plan_add_copy": (C.c_int, [_vp, _i32, _i64, _i64, _i32, _i64, _i64, _i64, _i64]),
     "sn_plan_run": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "sn_plan_instantiate": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
+    "sn_plan_exec_launch": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp]),
+    "sn_plan_exec_destroy": (C.c_int, [_vp]),
 }
 
 _lib = None

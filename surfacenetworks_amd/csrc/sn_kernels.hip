@@ -1968,6 +1968,10 @@ hipError_t sn_internal_fill(void *dst, int value, size_t bytes, hipStream_t s) {
 // 0x100 forward / 0x200 input gradient / 0x400 weight gradient (+ a variant number in the low byte), then rows, the contraction
 // or input width, the ALGORITHMIC bytes of the launch (operands read + results written, weights excluded) and the output width.
 bool g_timing_linear = true;      // sn_timing_enable(2): the sparse products only
+bool sn_internal_timing_on() {
+  std::lock_guard<std::mutex> lk(g_timing_mu);
+  return g_timing_on;
+}
 bool sn_internal_timing_slot(int kind, int64_t rows, int64_t width, int64_t bytes, int outw, hipEvent_t *s, hipEvent_t *e) {
   {
     std::lock_guard<std::mutex> lk(g_timing_mu);

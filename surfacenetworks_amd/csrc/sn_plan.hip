@@ -92,6 +92,58 @@ struct sn_plan {
   int32_t max_slot = -1;
 };
 
+struct sn_plan_exec {
+  hipGraphExec_t exec = nullptr;
+};
+
+bool sn_internal_timing_on();
+
+static int walk(const sn_plan *p, const uint64_t *slot_base, void *stream, int32_t *failed_node) {
+  hipStream_t s = (hipStream_t)stream;
+  const int nn = (int)p->nodes.size();
+  for (int k = 0; k < nn; ++k) {
+    const Node &n = p->nodes[k];
+    int st = SN_OK;
+    if (n.kind == kCall) {
+      PlanArg a[kMaxArgs];
+      for (int i = 0; i < n.nargs; ++i) {
+        switch (n.akind[i]) {
+          case kPtr: {
+            const uint64_t base = slot_base[n.slot[i]];
+            if (!base) st = SN_E_NULL;                   // a slot the plan dereferences was handed over empty
+            a[i].p = (void *)(uintptr_t)(base + (uint64_t)n.val[i].i);
+            break;
+          }
+          case kNull: a[i].p = nullptr; break;
+          case kStream: a[i].p = stream; break;
+          default: a[i] = n.val[i]; break;
+        }
+      }
+      if (st == SN_OK) st = kTable[n.fn].tramp(a);
+    } else if (n.kind == kMemset2D) {
+      const uint64_t base = slot_base[n.slot[0]];
+      if (!base) st = SN_E_NULL;
+      else if (n.val[3].i > 0 && n.val[4].i > 0) {
+        void *dst = (void *)(uintptr_t)(base + (uint64_t)n.val[0].i);
+        st = (int)sn_internal_fill2d(dst, n.val[2].i, (int)n.val[1].i, n.val[3].i, n.val[4].i, s);
+      }
+    } else {
+      const uint64_t db = slot_base[n.slot[0]], sb = slot_base[n.slot[2]];
+      if (!db || !sb) st = SN_E_NULL;
+      else if (n.val[4].i > 0 && n.val[5].i > 0) {
+        void *dst = (void *)(uintptr_t)(db + (uint64_t)n.val[0].i);
+        const void *src = (const void *)(uintptr_t)(sb + (uint64_t)n.val[2].i);
+        st = (int)sn_internal_copy2d(dst, n.val[1].i, src, n.val[3].i, n.val[4].i, n.val[5].i, s);
+      }
+    }
+    if (st != SN_OK) {
+      if (failed_node) *failed_node = k;
+      return st;
+    }
+  }
+  return SN_OK;
+}
+
 extern "C" {
 
 int sn_plan_create(sn_plan **out) {
@@ -200,47 +252,76 @@ int sn_plan_run(const sn_plan *p, const uint64_t *slot_base, int32_t nslots, voi
   if (failed_node) *failed_node = -1;
   if (!p || (!slot_base && p->max_slot >= 0)) return SN_E_NULL;
   if (nslots <= p->max_slot) return SN_E_SHAPE;
+  return walk(p, slot_base, stream, failed_node);
+}
+
+// ---- a plan at FIXED addresses as one graph launch ------------------------------------------------------------------------------
+// The torch caching allocator hands the same blocks to the same sequence of requests: in a training loop the slot addresses of a
+// plan run repeat from step to step (tools/scratch/plan_addr_probe.py: every run after the first step, on all three drivers).  For
+// such a run the launch list can be captured ONCE into a hipGraph — kernel nodes only: fills and copies are kernels of this library —
+// and enqueued by one hipGraphLaunch: 9-25 us of host time instead of 42-57 for the 6-9 launches of a block direction
+// (tools/scratch/plan_graph_probe.py).  Same kernels, same arguments, same order: bit-identical.  The executable graph is the CALLER's
+// object like the plan (create / launch / destroy), holds no device memory, and is only valid for the addresses it was made for:
+// the caller keys it by them.
+int sn_plan_instantiate(const sn_plan *p, const uint64_t *slot_base, int32_t nslots, sn_plan_exec **out, int32_t *failed_node) {
+  if (failed_node) *failed_node = -1;
+  if (!p || !out || (!slot_base && p->max_slot >= 0)) return SN_E_NULL;
+  *out = nullptr;
+  if (nslots <= p->max_slot) return SN_E_SHAPE;
+  if (p->nodes.empty()) return SN_E_SHAPE;
+  if (sn_internal_timing_on()) return SN_E_UNSUPPORTED;        // (event records of the per-launch timer do not belong in a graph)
+  (void)hipGetLastError();
+  hipStream_t cs = nullptr;
+  hipError_t e = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+  if (e != hipSuccess) return (int)e;
+  e = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+  if (e != hipSuccess) {
+    (void)hipStreamDestroy(cs);
+    return (int)e;
+  }
+  const int st = walk(p, slot_base, (void *)cs, failed_node);
+  hipGraph_t graph = nullptr;
+  e = hipStreamEndCapture(cs, &graph);
+  (void)hipStreamDestroy(cs);
+  if (st != SN_OK || e != hipSuccess || !graph) {
+    if (graph) (void)hipGraphDestroy(graph);
+    (void)hipGetLastError();
+    return st != SN_OK ? st : (e != hipSuccess ? (int)e : SN_E_UNSUPPORTED);
+  }
+  hipGraphExec_t exec = nullptr;
+  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(graph);
+  if (e != hipSuccess || !exec) return e != hipSuccess ? (int)e : SN_E_UNSUPPORTED;
+  sn_plan_exec *x = new (std::nothrow) sn_plan_exec();
+  if (!x) {
+    (void)hipGraphExecDestroy(exec);
+    return SN_E_WORKSPACE;
+  }
+  x->exec = exec;
+  *out = x;
+  return SN_OK;
+}
+
+// Enqueue: the graph when `stream` is an ordinary stream; the recorded launches one by one (sn_plan_run on the same addresses)
+// when the stream is itself being captured by the caller or the per-launch timer is on.
+int sn_plan_exec_launch(const sn_plan_exec *x, const sn_plan *p, const uint64_t *slot_base, int32_t nslots, void *stream,
+                        int32_t *failed_node) {
+  if (failed_node) *failed_node = -1;
+  if (!x || !x->exec) return SN_E_NULL;
   hipStream_t s = (hipStream_t)stream;
-  const int nn = (int)p->nodes.size();
-  for (int k = 0; k < nn; ++k) {
-    const Node &n = p->nodes[k];
-    int st = SN_OK;
-    if (n.kind == kCall) {
-      PlanArg a[kMaxArgs];
-      for (int i = 0; i < n.nargs; ++i) {
-        switch (n.akind[i]) {
-          case kPtr: {
-            const uint64_t base = slot_base[n.slot[i]];
-            if (!base) st = SN_E_NULL;                   // a slot the plan dereferences was handed over empty
-            a[i].p = (void *)(uintptr_t)(base + (uint64_t)n.val[i].i);
-            break;
-          }
-          case kNull: a[i].p = nullptr; break;
-          case kStream: a[i].p = stream; break;
-          default: a[i] = n.val[i]; break;
-        }
-      }
-      if (st == SN_OK) st = kTable[n.fn].tramp(a);
-    } else if (n.kind == kMemset2D) {
-      const uint64_t base = slot_base[n.slot[0]];
-      if (!base) st = SN_E_NULL;
-      else if (n.val[3].i > 0 && n.val[4].i > 0) {
-        void *dst = (void *)(uintptr_t)(base + (uint64_t)n.val[0].i);
-        st = (int)sn_internal_fill2d(dst, n.val[2].i, (int)n.val[1].i, n.val[3].i, n.val[4].i, s);
-      }
-    } else {
-      const uint64_t db = slot_base[n.slot[0]], sb = slot_base[n.slot[2]];
-      if (!db || !sb) st = SN_E_NULL;
-      else if (n.val[4].i > 0 && n.val[5].i > 0) {
-        void *dst = (void *)(uintptr_t)(db + (uint64_t)n.val[0].i);
-        const void *src = (const void *)(uintptr_t)(sb + (uint64_t)n.val[2].i);
-        st = (int)sn_internal_copy2d(dst, n.val[1].i, src, n.val[3].i, n.val[4].i, n.val[5].i, s);
-      }
-    }
-    if (st != SN_OK) {
-      if (failed_node) *failed_node = k;
-      return st;
-    }
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
+    (void)hipGetLastError();
+    cap = hipStreamCaptureStatusActive;
+  }
+  if (cap != hipStreamCaptureStatusNone || sn_internal_timing_on()) return sn_plan_run(p, slot_base, nslots, stream, failed_node);
+  return (int)hipGraphLaunch(x->exec, s);
+}
+
+int sn_plan_exec_destroy(sn_plan_exec *x) {
+  if (x) {
+    if (x->exec) (void)hipGraphExecDestroy(x->exec);
+    delete x;
   }
   return SN_OK;
 }

@@ -37,6 +37,40 @@ from . import _lib, kernels
 __all__ = ["enabled", "set_enabled", "Site", "stats", "reset", "PlanError"]
 
 _ENABLED = os.environ.get("SN_PLANS", "1") != "0"
+# A plan run whose slot addresses were seen before is enqueued as ONE graph launch (sn_plan_instantiate: csrc/sn_plan.hip says why the
+# addresses repeat and what it saves).  SN_PLAN_GRAPHS=0: every run walks its launch list.
+_GRAPHS = os.environ.get("SN_PLAN_GRAPHS", "1") != "0"
+MAX_EXECS_PER_PLAN = 64       # address sets kept per plan (a plan shared by the middle blocks of a model runs on one set per block)
+# A graph launch costs the DEVICE ~7 us more than the same launches issued one by one (measured: +0.23 ms on the 32 plan runs of the
+# 64-mesh step, which the device bounds) and saves the HOST ~30 us.  It pays where the host is the bound, i.e. where a block direction
+# is short on the device: plans whose workspace is below this size (a Dirac block direction with 256 MiB of workspace runs ~0.25 ms).
+GRAPH_MAX_ARENA_BYTES = 256 << 20
+_graveyard = collections.deque()  # (event, handle, lib) of graphs dropped while a launch of theirs may still be in flight
+
+
+def _bury(lib, handle) -> None:
+    try:
+        ev = torch.cuda.Event()
+        ev.record()
+    except Exception:  # noqa: BLE001 — no device any more (interpreter shutdown)
+        ev = None
+    _graveyard.append((ev, handle, lib))
+    while len(_graveyard) > 32:
+        ev0, h0, lib0 = _graveyard.popleft()
+        if ev0 is not None:
+            ev0.synchronize()
+        lib0.sn_plan_exec_destroy(h0)
+_SEEN, _NEVER = object(), object()
+_graph_counts = {"instantiated": 0, "launched": 0, "refused": 0, "evicted": 0}
+
+
+def graph_stats():
+    return dict(_graph_counts)
+
+
+def set_graphs(on: bool) -> None:
+    global _GRAPHS
+    _GRAPHS = bool(on)
 _BIG_BYTES = 1 << 20          # allocations from this size on live in the first arena
 _ALIGN = 256
 _ALLOW_CPU = False            # tests: record (never run) plans on CPU tensors
@@ -231,6 +265,8 @@ class Plan:
         self.used_ext = sorted(lay.used_ext)
         self._BasesT = C.c_uint64 * (2 + self.n_ext)
         self.bwd = {}                       # backward plans recorded against this forward's layout, by their own key
+        self.execs = collections.OrderedDict()   # slot addresses (the bytes of the slot table) -> _SEEN | graph handle | _NEVER
+        self.graphable = 0 < sum(lay.arena_bytes) <= GRAPH_MAX_ARENA_BYTES and self.launches >= 2
 
     def _describe(self, t, lay, rec):
         d = lay.describe(t, rec)
@@ -312,6 +348,10 @@ class Plan:
 
     def __del__(self):
         try:
+            for x in self.execs.values():
+                if x is not _SEEN and x is not _NEVER:
+                    _bury(self._lib, x)
+            self.execs.clear()
             if self.handle:
                 self._lib.sn_plan_destroy(self.handle)
                 self.handle = None
@@ -338,9 +378,44 @@ class Plan:
 
     def _launch(self, b):
         failed = C.c_int32(-1)
+        if _GRAPHS and self.graphable:
+            k = bytes(b)
+            execs = self.execs
+            x = execs.get(k)
+            if x is None:
+                execs[k] = _SEEN                                 # first sighting: remember the addresses, walk the list
+                if len(execs) > MAX_EXECS_PER_PLAN:
+                    old = execs.popitem(last=False)[1]
+                    if old is not _SEEN and old is not _NEVER:
+                        _bury(self._lib, old)
+                        _graph_counts["evicted"] += 1
+            elif x is not _NEVER:
+                execs.move_to_end(k)
+                if x is _SEEN:
+                    x = execs[k] = self._instantiate(b)          # second sighting: these addresses come back
+                if x is not _NEVER and x is not _SEEN:
+                    st = self._lib.sn_plan_exec_launch(x, self.handle, b, 2 + self.n_ext, kernels._stream(), C.byref(failed))
+                    if st != 0:
+                        _lib.check(st, f"sn_plan_exec_launch (entry {failed.value})")
+                    _graph_counts["launched"] += 1
+                    return
         st = self._lib.sn_plan_run(self.handle, b, 2 + self.n_ext, kernels._stream(), C.byref(failed))
         if st != 0:
             _lib.check(st, f"sn_plan_run (entry {failed.value})")
+
+    def _instantiate(self, b):
+        """The graph of this plan at the addresses `b`, or _NEVER (the caller's stream is being captured, the per-launch timer is on,
+        the runtime refuses): the run then walks its list, now and on every later call with these addresses."""
+        if torch.cuda.is_current_stream_capturing():
+            return _SEEN                                         # (not now: a capture of the caller's is in progress on this thread)
+        x = C.c_void_p()
+        failed = C.c_int32(-1)
+        st = self._lib.sn_plan_instantiate(self.handle, b, 2 + self.n_ext, C.byref(x), C.byref(failed))
+        if st != 0 or not x:
+            _graph_counts["refused"] += 1
+            return _NEVER
+        _graph_counts["instantiated"] += 1
+        return x
 
 
 class _Builder:
@@ -453,6 +528,8 @@ def stats():
 
 
 def reset() -> None:
+    for k in _graph_counts:
+        _graph_counts[k] = 0
     for s in _SITES:
         s.plans.clear()
         s.recorded = s.replayed = s.refused = s.skipped = 0

@@ -18,8 +18,10 @@ def _fresh_plans():
 
     plans.reset()
     plans.set_enabled(True)
+    plans.set_graphs(True)
     yield
     plans.set_enabled(True)
+    plans.set_graphs(True)
 
 
 def _steps(step_fn, model_e, model_p, n_steps, check_no_refusal=True):
@@ -409,3 +411,99 @@ def test_plan_fill_nodes_replay_correctly_from_a_captured_graph():
                 assert torch.equal(y[:, zero_cols:], torch.full((rows, C - zero_cols), 5.0 + rep, device=DEV))
         del graph
         lib.sn_plan_destroy(plan)
+
+
+def test_plan_runs_at_repeating_addresses_are_graph_launches_with_the_same_results(monkeypatch):
+    """In a training loop the slot addresses of a plan run repeat (the caching allocator); from the second sighting such a run is ONE
+    graph launch (sn_plan_instantiate / sn_plan_exec_launch).  Same kernels, same arguments: the model trained with graph launches
+    equals, bit for bit, the one whose plan runs walk their lists — and plans past the workspace limit never use a graph."""
+    from surfacenetworks_amd import arap, plans
+
+    torch.manual_seed(5)
+    ds = arap.ClothSequences([(9, 8)] * 3, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 3, op_frames=3, seed=11, device=DEV, model="dir")
+    model_w = arap.DirModel().to(DEV).train()
+    model_g = copy.deepcopy(model_w)
+    for model, graphs in ((model_w, False), (model_g, True)):
+        plans.reset()
+        plans.set_graphs(graphs)
+        opt = arap.make_optimizer(model)
+        rng = np.random.default_rng(1)
+        for _ in range(8):
+            arap.train_step(model, opt, ds.sample_batch(3, rng, seq_ids=np.arange(3)), global_batch=3)
+        torch.cuda.synchronize()
+        g = plans.graph_stats()
+        if graphs:
+            assert g["instantiated"] >= 16 and g["launched"] >= 5 * g["instantiated"] and g["refused"] == 0, g
+        else:
+            assert g["launched"] == g["instantiated"] == 0, g
+    for (name, pw), pg in zip(model_w.named_parameters(), model_g.parameters()):
+        assert torch.equal(pw.detach(), pg.detach()), name
+    for (name, bw), bg in zip(model_w.named_buffers(), model_g.buffers()):
+        assert torch.equal(bw, bg), name
+    monkeypatch.setattr(plans, "GRAPH_MAX_ARENA_BYTES", 1024)
+    plans.reset()
+    opt = arap.make_optimizer(model_g)
+    for _ in range(4):
+        arap.train_step(model_g, opt, ds.sample_batch(3, np.random.default_rng(2), seq_ids=np.arange(3)), global_batch=3)
+    assert plans.graph_stats()["instantiated"] == 0 and sum(s["replayed"] for s in plans.stats().values()) > 0
+
+
+def test_a_plan_as_a_graph_through_the_c_abi():
+    """sn_plan_instantiate at fixed addresses, then sn_plan_exec_launch: the same bytes as sn_plan_run on new CONTENTS of the same
+    buffers; inside a capture of the caller's it walks the list (and the caller's graph replays right); refused while the
+    per-launch timer is on."""
+    import ctypes
+
+    from surfacenetworks_amd import _lib
+
+    lib = _lib.load()
+    rows, C = 257, 128
+    plan = ctypes.c_void_p()
+    assert lib.sn_plan_create(ctypes.byref(plan)) == 0
+    assert lib.sn_plan_add_memset(plan, 1, 0, 0, C * 4, C // 2 * 4, rows) == 0                      # zero the left half of y
+    n = 7
+    I32, I64, F64 = ctypes.c_int32 * n, ctypes.c_int64 * n, ctypes.c_double * n
+    assert lib.sn_plan_add_call(plan, lib.sn_plan_lookup(b"sn_elu_into_f32"), n, I32(2, 0, 2, 0, 0, 0, 4), I32(0, 0, 1, 0, 0, 0, 0),
+                                I64(0, C, C // 2 * 4, C, rows, C // 2, 0), F64()) == 0             # elu(x[:, :C/2]) into the right half
+    x = torch.randn(rows, C, device=DEV)
+    y = torch.empty(rows, C, device=DEV)
+    bases = (ctypes.c_uint64 * 2)(x.data_ptr(), y.data_ptr())
+    ex = ctypes.c_void_p()
+    assert lib.sn_plan_instantiate(plan, bases, 2, ctypes.byref(ex), None) == 0 and ex
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def want():
+        return torch.cat([torch.zeros(rows, C // 2, device=DEV), torch.nn.functional.elu(x[:, :C // 2])], dim=1)
+
+    for seed in range(3):
+        x.copy_(torch.randn(rows, C, device=DEV))
+        y.fill_(float("nan"))
+        assert lib.sn_plan_exec_launch(ex, plan, bases, 2, stream, None) == 0
+        got = y.clone()
+        y.fill_(float("nan"))
+        assert lib.sn_plan_run(plan, bases, 2, stream, None) == 0
+        assert torch.equal(got, y) and torch.equal(got, want())
+    g = torch.cuda.CUDAGraph()                                     # the caller captures: the launch walks the list into ITS graph
+    with torch.cuda.graph(g):
+        assert lib.sn_plan_exec_launch(ex, plan, bases, 2, torch.cuda.current_stream().cuda_stream, None) == 0
+    for seed in range(3):
+        x.copy_(torch.randn(rows, C, device=DEV))
+        y.fill_(float("nan"))
+        g.replay()
+        assert torch.equal(y, want())
+    del g
+    assert lib.sn_timing_enable(1) == 0
+    try:
+        ex2 = ctypes.c_void_p()
+        assert lib.sn_plan_instantiate(plan, bases, 2, ctypes.byref(ex2), None) == -7 and not ex2      # SN_E_UNSUPPORTED
+        y.fill_(float("nan"))
+        assert lib.sn_plan_exec_launch(ex, plan, bases, 2, stream, None) == 0                           # (walks the list)
+        assert torch.equal(y, want())
+    finally:
+        lib.sn_timing_enable(0)
+        meta = (ctypes.c_int64 * 64)()
+        ms = (ctypes.c_double * 8)()
+        wr = ctypes.c_int64()
+        lib.sn_timing_drain(ms, meta, 8, ctypes.byref(wr))
+    torch.cuda.synchronize()
+    assert lib.sn_plan_exec_destroy(ex) == 0 and lib.sn_plan_destroy(plan) == 0

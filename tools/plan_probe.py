@@ -170,18 +170,23 @@ def main():
     out = {}
     for name in which:
         mk = {"arap": arap_step, "arap4": lambda: arap_step(4), "mnist": mnist_step, "faust": faust_step}[name]
-        for on in (False, True):
+        for on, graphs in ((False, False), (True, False), (True, True)):
             torch.manual_seed(1)
             plans.reset()
             plans.set_enabled(on)
+            plans.set_graphs(graphs)
+            g0 = plans.graph_stats()
             step = mk()
-            enq, tot = timed(step, 20, 5)
+            enq, tot = timed(step, int(os.environ.get("PROBE_STEPS", "20")), int(os.environ.get("PROBE_WARM", "5")))
             st = plans.stats()
-            out[f"{name}/{'plans' if on else 'eager'}"] = {
+            label = "eager" if not on else ("plans+graphs" if graphs else "plans")
+            g1 = plans.graph_stats()
+            out[f"{name}/{label}"] = {
+                "graph": {k: g1[k] - g0[k] for k in g1},
                 "host_enqueue_ms": round(enq, 3), "ms_per_step": round(tot, 3),
                 "replayed": sum(s["replayed"] for s in st.values()), "recorded": sum(s["recorded"] for s in st.values()),
                 "refused": {k: s["reasons"] for k, s in st.items() if s["refused"]}}
-            print(name, "plans" if on else "eager", json.dumps(out[f"{name}/{'plans' if on else 'eager'}"]), flush=True)
+            print(name, label, json.dumps(out[f"{name}/{label}"]), flush=True)
             del step
             torch.cuda.empty_cache()
     print(json.dumps(out))
