@@ -5,7 +5,7 @@
 tag=${1:-scratch}; root=$(cd "$(dirname "$0")/.." && pwd); out=$root/gpurun_out/$tag; mkdir -p $out
 cd $root
 : > $out/switch_matrix.txt
-for leg in "SN_PLANS=0" "SN_DEBUG_VALIDATE=1" "SN_STRICT=1" "SN_RESIDENT=0" "SN_RESIDENT_MAX_GB=0.05" "SN_PAIR_FUSED=0" "SN_GEMM_VARIANT=0" "SN_GEMM_VARIANT=1"; do
+for leg in "SN_PLANS=0" "SN_PLAN_GRAPHS=0" "SN_DEBUG_VALIDATE=1" "SN_STRICT=1" "SN_RESIDENT=0" "SN_RESIDENT_MAX_GB=0.05" "SN_PAIR_FUSED=0" "SN_GEMM_VARIANT=0" "SN_GEMM_VARIANT=1"; do
   log=/tmp/leg_$(echo $leg | tr '=.' '__').log
   env $leg timeout 900 python -m pytest tests -m gpu -q -p no:cacheprovider > $log 2>&1
   echo "$leg: $(tail -1 $log)" >> $out/switch_matrix.txt
