@@ -60,7 +60,11 @@ def _bury(lib, handle) -> None:
         if ev0 is not None:
             ev0.synchronize()
         lib0.sn_plan_exec_destroy(h0)
-_SEEN, _NEVER = object(), object()
+_NEVER = object()
+# Instantiating a graph costs ~270 us, a graph launch saves ~30: an address set pays for its graph after ~9 more runs.  The classic
+# rent-or-buy answer: walk the list until the set has come back this many times, then buy (a loop that cycles few sets gets its
+# graphs within a few steps; address sets that do not come back never cost an instantiation).
+GRAPH_AFTER_SIGHTINGS = 6
 _graph_counts = {"instantiated": 0, "launched": 0, "refused": 0, "evicted": 0}
 
 
@@ -265,7 +269,7 @@ class Plan:
         self.used_ext = sorted(lay.used_ext)
         self._BasesT = C.c_uint64 * (2 + self.n_ext)
         self.bwd = {}                       # backward plans recorded against this forward's layout, by their own key
-        self.execs = collections.OrderedDict()   # slot addresses (the bytes of the slot table) -> _SEEN | graph handle | _NEVER
+        self.execs = collections.OrderedDict()   # slot addresses (the bytes of the slot table) -> sightings (int) | graph handle | _NEVER
         self.graphable = 0 < sum(lay.arena_bytes) <= GRAPH_MAX_ARENA_BYTES and self.launches >= 2
 
     def _describe(self, t, lay, rec):
@@ -349,7 +353,7 @@ class Plan:
     def __del__(self):
         try:
             for x in self.execs.values():
-                if x is not _SEEN and x is not _NEVER:
+                if x.__class__ is not int and x is not _NEVER:
                     _bury(self._lib, x)
             self.execs.clear()
             if self.handle:
@@ -383,31 +387,38 @@ class Plan:
             execs = self.execs
             x = execs.get(k)
             if x is None:
-                execs[k] = _SEEN                                 # first sighting: remember the addresses, walk the list
+                execs[k] = 1                                     # first sighting: remember the addresses, walk the list
                 if len(execs) > MAX_EXECS_PER_PLAN:
                     old = execs.popitem(last=False)[1]
-                    if old is not _SEEN and old is not _NEVER:
+                    if old.__class__ is not int and old is not _NEVER:
                         _bury(self._lib, old)
                         _graph_counts["evicted"] += 1
             elif x is not _NEVER:
                 execs.move_to_end(k)
-                if x is _SEEN:
-                    x = execs[k] = self._instantiate(b)          # second sighting: these addresses come back
-                if x is not _NEVER and x is not _SEEN:
+                if x.__class__ is int:
+                    if x + 1 < GRAPH_AFTER_SIGHTINGS:
+                        execs[k] = x + 1
+                    else:
+                        x = execs[k] = self._instantiate(b, x)   # these addresses keep coming back
+                if x.__class__ is not int and x is not _NEVER:
                     st = self._lib.sn_plan_exec_launch(x, self.handle, b, 2 + self.n_ext, kernels._stream(), C.byref(failed))
-                    if st != 0:
+                    if st == 0:
+                        _graph_counts["launched"] += 1
+                        return
+                    if failed.value >= 0:                        # (it walked the list — a capture of the caller's — and an entry failed)
                         _lib.check(st, f"sn_plan_exec_launch (entry {failed.value})")
-                    _graph_counts["launched"] += 1
-                    return
+                    execs[k] = _NEVER                            # the runtime would not launch the graph: these addresses walk the list
+                    _bury(self._lib, x)
+                    _graph_counts["refused"] += 1
         st = self._lib.sn_plan_run(self.handle, b, 2 + self.n_ext, kernels._stream(), C.byref(failed))
         if st != 0:
             _lib.check(st, f"sn_plan_run (entry {failed.value})")
 
-    def _instantiate(self, b):
-        """The graph of this plan at the addresses `b`, or _NEVER (the caller's stream is being captured, the per-launch timer is on,
-        the runtime refuses): the run then walks its list, now and on every later call with these addresses."""
+    def _instantiate(self, b, sightings):
+        """The graph of this plan at the addresses `b`; `sightings` back when a capture of the caller's is in progress on this thread
+        (not now); _NEVER when the per-launch timer is on or the runtime refuses (these addresses then always walk the list)."""
         if torch.cuda.is_current_stream_capturing():
-            return _SEEN                                         # (not now: a capture of the caller's is in progress on this thread)
+            return sightings
         x = C.c_void_p()
         failed = C.c_int32(-1)
         st = self._lib.sn_plan_instantiate(self.handle, b, 2 + self.n_ext, C.byref(x), C.byref(failed))
