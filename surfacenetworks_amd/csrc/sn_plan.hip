@@ -8,8 +8,9 @@
 // expressed as (slot, byte offset).  Slots are base addresses the caller supplies per run: the block's workspace arenas (one
 // allocation each, sized once per shape) and the tensors it reads or writes (features, weights, operator arrays).
 // sn_plan_run walks the list and calls the SAME launchers a caller would call one by one, in the same order, on the caller's
-// stream: same kernels, same grids, bit-identical results.  Nothing is captured, cached per shape or kept on the device: a plan is
-// host memory owned by the caller (sn_plan_create / sn_plan_destroy), immutable while it runs, re-entrant across streams.
+// stream: same kernels, same grids, bit-identical results.  A plan holds no addresses and nothing on the device (its graph form
+// at fixed addresses is a separate object, below): it is host memory owned by the caller (sn_plan_create / sn_plan_destroy),
+// immutable while it runs, re-entrant across streams.
 #include <hip/hip_runtime.h>
 
 #include <cstring>
