@@ -17,9 +17,13 @@ What happens here, per block call site and per distinct shape signature:
     ~40), hand the slots' base addresses to sn_plan_run — which calls the same launchers in the same order — and rebuild only
     the block's OUTPUTS as views of the arenas.  What the backward needs stays a description (offsets into the forward arenas,
     which autograd keeps alive) until the backward's own plan runs.
+  * a plan run whose slot addresses have come back several times (a training loop's caching allocator repeats them from step to
+    step) is captured once at those addresses and from then on enqueued as ONE graph launch of the same kernels
+    (sn_plan_instantiate / sn_plan_exec_launch; small plans only: GRAPH_MAX_ARENA_BYTES).
 Same kernels, same order, same arguments: results are bit-identical to the eager path (tests/test_plans_gpu.py).
 
-SN_PLANS=0 disables the mechanism (every block launches its kernels from Python, as before)."""
+SN_PLANS=0 disables the mechanism (every block launches its kernels from Python, as before); SN_PLAN_GRAPHS=0 only the graph
+launches (every plan run walks its list)."""
 from __future__ import annotations
 
 import bisect
@@ -34,7 +38,7 @@ from torch.utils._python_dispatch import TorchDispatchMode
 
 from . import _lib, kernels
 
-__all__ = ["enabled", "set_enabled", "Site", "stats", "reset", "PlanError"]
+__all__ = ["enabled", "set_enabled", "set_graphs", "graph_stats", "Site", "stats", "reset", "PlanError"]
 
 _ENABLED = os.environ.get("SN_PLANS", "1") != "0"
 # A plan run whose slot addresses were seen before is enqueued as ONE graph launch (sn_plan_instantiate: csrc/sn_plan.hip says why the
