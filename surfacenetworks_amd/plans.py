@@ -44,7 +44,8 @@ _ENABLED = os.environ.get("SN_PLANS", "1") != "0"
 # A plan run whose slot addresses were seen before is enqueued as ONE graph launch (sn_plan_instantiate: csrc/sn_plan.hip says why the
 # addresses repeat and what it saves).  SN_PLAN_GRAPHS=0: every run walks its launch list.
 _GRAPHS = os.environ.get("SN_PLAN_GRAPHS", "1") != "0"
-MAX_EXECS_PER_PLAN = 64       # address sets kept per plan (a plan shared by the middle blocks of a model runs on one set per block)
+MAX_EXECS_PER_PLAN = 256      # address sets kept per plan: a plan shared by the middle blocks of a model runs on one set per block, tower and
+                              # batch of a cycling loader (the FAUST loop behind the reference's names: 56-80 per plan)
 # A graph launch costs the DEVICE ~7 us more than the same launches issued one by one (measured: +0.23 ms on the 32 plan runs of the
 # 64-mesh step, which the device bounds) and saves the HOST ~30 us.  It pays where the host is the bound, i.e. where a block direction
 # is short on the device: plans whose workspace is below this size (a Dirac block direction with 256 MiB of workspace runs ~0.25 ms).
