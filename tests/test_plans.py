@@ -229,3 +229,82 @@ def test_operands_that_overlap_in_memory_get_no_plan():
     lay = plans._Layout(plans._Recorder([other, x, other]), alias_ok=(0, 2))
     assert lay.resolve(other.data_ptr() + 8) == (2 + 0, 8)
     assert plans._Layout(plans._Recorder([other[:8], other[8:], None, torch.zeros(0)])).resolve(other.data_ptr() + 32) == (3, 0)
+
+
+def test_rent_or_buy_policy_of_plan_graphs(monkeypatch):
+    """Plan._launch without a device: an address set walks the list until it has come back GRAPH_AFTER_SIGHTINGS times, then buys its
+    graph and launches it; a capture of the caller's postpones the purchase; a refused instantiation or a failed graph launch sends
+    the set back to the list for good; the table is bounded and evicted graphs are destroyed."""
+    import collections
+    import ctypes
+
+    from surfacenetworks_amd import kernels, plans
+
+    events = []
+
+    class _Lib:
+        fail_launch = False
+        refuse = False
+
+        def sn_plan_run(self, h, b, n, s, failed):
+            events.append(("walk", bytes(b)))
+            return 0
+
+        def sn_plan_instantiate(self, h, b, n, out, failed):
+            if self.refuse:
+                return -7
+            ctypes.cast(out, ctypes.POINTER(ctypes.c_void_p))[0] = 0x1000 + len(events)
+            events.append(("buy", bytes(b)))
+            return 0
+
+        def sn_plan_exec_launch(self, x, h, b, n, s, failed):
+            if self.fail_launch:
+                return 1
+            events.append(("graph", bytes(b)))
+            return 0
+
+        def sn_plan_exec_destroy(self, x):
+            events.append(("destroy", x.value if hasattr(x, "value") else x))
+            return 0
+
+    capturing = [False]
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing[0])
+    monkeypatch.setattr(kernels, "_stream", lambda: 0)
+    monkeypatch.setattr(plans, "_GRAPHS", True)
+    monkeypatch.setattr(plans, "GRAPH_AFTER_SIGHTINGS", 3)
+    monkeypatch.setattr(plans, "MAX_EXECS_PER_PLAN", 2)
+    plans._graveyard.clear()
+    lib = _Lib()
+    plan = object.__new__(plans.Plan)
+    plan._lib, plan.handle, plan.n_ext, plan.graphable = lib, ctypes.c_void_p(1), 1, True
+    plan.execs = collections.OrderedDict()
+    T = ctypes.c_uint64 * 3
+    a, b, c = T(1, 2, 3), T(4, 5, 6), T(7, 8, 9)
+    kinds = lambda: [e[0] for e in events]
+    for _ in range(2):
+        plan._launch(a)
+    assert kinds() == ["walk", "walk"]
+    capturing[0] = True
+    plan._launch(a)                                                # third sighting, but the caller is capturing: not now
+    assert kinds() == ["walk"] * 3
+    capturing[0] = False
+    plan._launch(a)
+    plan._launch(a)
+    assert kinds() == ["walk"] * 3 + ["buy", "graph", "graph"]
+    lib.refuse = True
+    for _ in range(5):
+        plan._launch(b)
+    assert kinds()[6:] == ["walk"] * 5 and plan.execs[bytes(b)] is plans._NEVER
+    lib.refuse, lib.fail_launch = False, True
+    plan._launch(a)                                                # the runtime will not launch the graph: the list, for good
+    assert kinds()[11:] == ["walk"] and plan.execs[bytes(a)] is plans._NEVER and len(plans._graveyard) == 1
+    lib.fail_launch = False
+    plan._launch(a)
+    assert kinds()[12:] == ["walk"]
+    plan._launch(c)                                                # a third set: the least recently used one leaves the table
+    assert len(plan.execs) == 2 and bytes(b) not in plan.execs
+    plan.graphable = False
+    plan._launch(c)
+    assert plan.execs[bytes(c)] == 1                               # (large plans never count sightings)
+    plan.handle = None
+    plans._graveyard.clear()
