@@ -593,7 +593,7 @@ def c2_secondary(device, steps: int = 60, warm: int = 10):
     model = mm.DirModel().to(device).train()
     opt = mm.make_optimizer(model)
     ids = np.arange(B)
-    eager = _timed_steps(lambda: mm.train_step(model, opt, ds.sample_batch(B, rng, ids=ids)), 10, 10)   # (steady state: plan graphs made)
+    eager = _timed_steps(lambda: mm.train_step(model, opt, ds.sample_batch(B, rng, ids=ids)), 10, 14)   # (steady state: plan graphs made)
     from surfacenetworks_amd.graphs import BatchAhead
 
     g = mm.graphed_train_step(model, opt, ds.sample_batch(B, rng, ids=ids))
@@ -621,7 +621,7 @@ def c4_pair_secondary(device, steps: int = 60, warm: int = 10):
     def estep():
         k[0] += 1
         dc.train_step(model, opt, ds, k[0] % 4, (k[0] + 1) % 4)
-    eager = _timed_steps(estep, 12, 28)              # (steady state: every address set of the four-pair cycle has its plan graphs)
+    eager = _timed_steps(estep, 12, 52)              # (steady state: every address set of the four-pair cycle has its plan graphs)
     g = dc.graphed_train_step(model, opt, dc.PairBatch(ds, 0, 1))
 
     def gstep():

@@ -48,8 +48,9 @@ MAX_EXECS_PER_PLAN = 256      # address sets kept per plan: a plan shared by the
                               # batch of a cycling loader (the FAUST loop behind the reference's names: 56-80 per plan)
 # A graph launch costs the DEVICE ~7 us more than the same launches issued one by one (measured: +0.23 ms on the 32 plan runs of the
 # 64-mesh step, which the device bounds) and saves the HOST ~30 us.  It pays where the host is the bound, i.e. where a block direction
-# is short on the device: plans whose workspace is below this size (a Dirac block direction with 256 MiB of workspace runs ~0.25 ms).
-GRAPH_MAX_ARENA_BYTES = 256 << 20
+# is shorter on the device than its ~100 us of host time: plans whose workspace is below this size (a Dirac block direction runs ~1 us
+# per MiB of workspace; ARAP at 4 meshes, 110 MiB, is the crossover: 5.3 -> 4.7 ms per step on a slow host, 3.64 -> 3.82 on a fast one).
+GRAPH_MAX_ARENA_BYTES = 64 << 20
 _graveyard = collections.deque()  # (event, handle, lib) of graphs dropped while a launch of theirs may still be in flight
 
 
@@ -66,10 +67,10 @@ def _bury(lib, handle) -> None:
             ev0.synchronize()
         lib0.sn_plan_exec_destroy(h0)
 _NEVER = object()
-# Instantiating a graph costs ~270 us, a graph launch saves ~30: an address set pays for its graph after ~9 more runs.  The classic
-# rent-or-buy answer: walk the list until the set has come back this many times, then buy (a loop that cycles few sets gets its
-# graphs within a few steps; address sets that do not come back never cost an instantiation).
-GRAPH_AFTER_SIGHTINGS = 6
+# Instantiating a graph costs 270-540 us (6-9 kernel nodes), a graph launch saves ~30: an address set pays for its graph after 9-18
+# more runs.  The classic rent-or-buy answer: walk the list until the set has come back about that often, then buy (a loop that cycles
+# few sets gets its graphs within a dozen steps; address sets that do not keep coming back never cost an instantiation).
+GRAPH_AFTER_SIGHTINGS = 12
 _graph_counts = {"instantiated": 0, "launched": 0, "refused": 0, "evicted": 0}
 
 

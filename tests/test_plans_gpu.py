@@ -423,7 +423,7 @@ def test_plan_runs_at_repeating_addresses_are_graph_launches_with_the_same_resul
     ds = arap.ClothSequences([(9, 8)] * 3, frames=arap.INPUT_FRAMES + arap.OUTPUT_FRAMES + 3, op_frames=3, seed=11, device=DEV, model="dir")
     model_w = arap.DirModel().to(DEV).train()
     model_g = copy.deepcopy(model_w)
-    monkeypatch.setattr(plans, "GRAPH_AFTER_SIGHTINGS", 2)        # (the default buys a graph at the sixth sighting of an address set)
+    monkeypatch.setattr(plans, "GRAPH_AFTER_SIGHTINGS", 2)        # (the default buys a graph at the twelfth sighting of an address set)
     for model, graphs in ((model_w, False), (model_g, True)):
         plans.reset()
         plans.set_graphs(graphs)

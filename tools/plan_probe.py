@@ -177,7 +177,7 @@ def main():
             plans.set_graphs(graphs)
             g0 = plans.graph_stats()
             step = mk()
-            enq, tot = timed(step, int(os.environ.get("PROBE_STEPS", "20")), int(os.environ.get("PROBE_WARM", "30")))
+            enq, tot = timed(step, int(os.environ.get("PROBE_STEPS", "20")), int(os.environ.get("PROBE_WARM", "56")))
             st = plans.stats()
             label = "eager" if not on else ("plans+graphs" if graphs else "plans")
             g1 = plans.graph_stats()

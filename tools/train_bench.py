@@ -146,7 +146,7 @@ def mnist_swap(dev="cuda", steps=20, B=512, permute=False):
         opt.zero_grad()
         loss.backward()
         opt.step()
-    dt = timed(step, steps, warm=10)
+    dt = timed(step, steps, warm=14)
     return {"workload": "config 2 as the reference's Mesh-MNIST loop runs it after the import swap: per step 2 x utils.sparse_cat of 512 "
                         "per-sample handles, .cuda() of inputs / targets / mask / operators, DirModel, nll_loss, Adam (src/mesh_mnist/"
                         "main.py:79-117,151-167); eager", "vertex_order": "shuffled" if permute else "as generated",
@@ -198,7 +198,7 @@ def faust_swap(dev="cuda", steps=20, permute=False):
         opt.zero_grad()
         loss.backward()
         opt.step()
-    dt = timed(step, steps, warm=28)
+    dt = timed(step, steps, warm=52)
     return {"workload": "config 4 (one pair) as the reference's dense-correspondence loop runs it after the import swap: per sample "
                         "utils.sparse_diag_cat([L], 7000, 7000).coalesce().cuda(), padded inputs / mask .cuda(), SiameseModel(lap), "
                         "loss_fun_delta_cross_entropy on the (1, 7000, 7000) scores, Adam (src/dense_correspondence/main.py:106-191,"
@@ -219,7 +219,7 @@ def main():
         model = (mm.DirModel() if what == "mnist_dir" else mm.Model()).to(dev).train()
         opt = mm.make_optimizer(model)
         ids = np.arange(B)
-        dt = timed(lambda: mm.train_step(model, opt, ds.sample_batch(B, rng, ids=ids)), steps, warm=10)
+        dt = timed(lambda: mm.train_step(model, opt, ds.sample_batch(B, rng, ids=ids)), steps, warm=14)
         ex = ds.sample_batch(B, rng, ids=ids)
         try:
             g = mm.graphed_train_step(model, opt, ex)
@@ -246,7 +246,7 @@ def main():
         def step():
             k[0] += 1
             dc.train_step(model, opt, ds, k[0] % 4, (k[0] + 1) % 4)
-        dt = timed(step, steps, warm=28)
+        dt = timed(step, steps, warm=52)
         print(f"{what}: 1 pair of 6890-vertex bodies (padded 7000), {dt * 1e3:.2f} ms/step, {2 / dt:.1f} meshes/s")
         try:
             g = dc.graphed_train_step(model, opt, dc.PairBatch(ds, 0, 1))
